@@ -1,0 +1,378 @@
+"""ctypes binding of the C-ABI declared in include/gpx.h.
+
+`GpxLib(path, prefix)` binds one shared library that exports the ABI under a symbol
+prefix.  The product library is ``gigapaxos_amd/csrc/libgpx_hip.so`` (prefix ``gpx_``,
+hand-written HIP for gfx950); there is NO CPU fallback: if that library is missing
+or fails to load, `load_hip()` raises.  (tests/ bind the CPU oracle through the same
+class with prefix ``orc_`` — as the checker only.)
+
+`Engine` is the thin host-side handle: numpy arrays in, numpy arrays out, one method
+per reference handler it replaces (PaxosInstanceStateMachine.handlePaxosMessage's
+switch, PaxosInstanceStateMachine.java:423-583).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+KMAX_LIMIT = 16
+
+# status / kind constants (include/gpx.h)
+S_OK, S_NOGROUP, S_STOPPED, S_WINDOW, S_FORWARD, S_REFUSED, S_EXISTS, S_BUSY = range(8)
+D_DECISION, D_PREEMPTED = 1, 2
+R_TOLOG, R_STORED = 1, 2
+A_STOP = 1
+C_HASVALUE, C_STOP = 1, 2
+F_ACCEPTS_FROM_DISK = 1
+RETIRE_PAUSE, RETIRE_KILL = 0, 1
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+HIP_LIB_PATH = os.path.join(_HERE, "csrc", "libgpx_hip.so")
+
+
+class GpxConfig(C.Structure):
+    _fields_ = [
+        ("my_id", C.c_int32),
+        ("max_groups", C.c_int32),
+        ("kmax", C.c_int32),
+        ("window", C.c_int32),
+        ("max_batch", C.c_int32),
+        ("device", C.c_int32),
+        ("flags", C.c_uint32),
+        ("reserved", C.c_uint32),
+    ]
+
+
+class GpxKernelStat(C.Structure):
+    _fields_ = [("name", C.c_char * 48), ("launches", C.c_uint64), ("total_ms", C.c_double)]
+
+
+# numpy mirror of struct gpx_hri (HotRestoreInfo.java:35-84 minus the name)
+HRI_DTYPE = np.dtype(
+    [
+        ("version", "<i4"),
+        ("acc_slot", "<i4"),
+        ("acc_bnum", "<i4"),
+        ("acc_bcoord", "<i4"),
+        ("acc_gc_slot", "<i4"),
+        ("has_coord", "<i4"),
+        ("coord_bnum", "<i4"),
+        ("coord_bcoord", "<i4"),
+        ("next_proposal_slot", "<i4"),
+        ("node_slots", "<i4", (KMAX_LIMIT,)),
+    ]
+)
+assert HRI_DTYPE.itemsize == 4 * (9 + KMAX_LIMIT)
+
+_I32P = C.POINTER(C.c_int32)
+_U8P = C.POINTER(C.c_uint8)
+_VP = C.c_void_p
+
+# name -> argtypes (after the engine handle); every function returns int
+_SIGS = {
+    "engine_destroy": [],
+    "engine_sync": [],
+    "engine_counters": [C.POINTER(C.c_uint64)],
+    "group_create": [C.c_int32, _VP, _VP, _VP, _VP, _VP],
+    "group_retire": [C.c_int32, _VP, C.c_int32, _VP, _VP],
+    "group_snapshot": [C.c_int32, _VP, _VP, _VP],
+    "group_dump": [C.c_int32, _VP, C.c_int32],
+    "propose_batch": [C.c_int32] + [_VP] * 7,
+    "accept_batch": [C.c_int32] + [_VP] * 15,
+    "accept_reply_batch": [C.c_int32] + [_VP] * 14,
+    "commit_batch": [C.c_int32] + [_VP] * 11,
+}
+_DEV_SIGS = {
+    "engine_set_stream": [_VP],
+    "propose_batch_dev": [C.c_int32] + [_VP] * 7,
+    "accept_batch_dev": [C.c_int32] + [_VP] * 15,
+    "accept_reply_batch_dev": [C.c_int32] + [_VP] * 14,
+    "commit_batch_dev": [C.c_int32] + [_VP] * 11,
+    "profile_enable": [C.c_int32],
+    "profile_read": [C.POINTER(GpxKernelStat), C.c_int32],
+}
+
+EXPORTED_SYMBOLS = (
+    ["abi_version", "last_error", "engine_create"] + list(_SIGS) + list(_DEV_SIGS)
+)
+
+
+class GpxError(RuntimeError):
+    pass
+
+
+class GpxLib:
+    """One loaded shared library exporting the gpx ABI under `prefix`."""
+
+    def __init__(self, path: str, prefix: str = "gpx_", device_api: bool = True):
+        if not os.path.exists(path):
+            raise GpxError(
+                f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'`"
+            )
+        self.path = path
+        self.prefix = prefix
+        self.lib = C.CDLL(path)
+        self.fn = {}
+        f = getattr(self.lib, prefix + "abi_version")
+        f.restype = C.c_int
+        self.abi_version = f()
+        f = getattr(self.lib, prefix + "last_error")
+        f.restype = C.c_char_p
+        self.fn["last_error"] = f
+        f = getattr(self.lib, prefix + "engine_create")
+        f.argtypes = [C.POINTER(GpxConfig), C.POINTER(_VP)]
+        f.restype = C.c_int
+        self.fn["engine_create"] = f
+        sigs = dict(_SIGS)
+        if device_api:
+            sigs.update(_DEV_SIGS)
+        for name, args in sigs.items():
+            f = getattr(self.lib, prefix + name)
+            f.argtypes = [_VP] + args
+            f.restype = C.c_int
+            self.fn[name] = f
+        self.device_api = device_api
+
+    def check(self, rc: int, what: str) -> int:
+        if rc < 0:
+            msg = self.fn["last_error"]()
+            raise GpxError(f"{self.prefix}{what} failed rc={rc} {msg.decode() if msg else ''}")
+        return rc
+
+
+_hip_lib = None
+
+
+def load_hip() -> GpxLib:
+    """The product library.  Fails loudly when the HIP extension is missing."""
+    global _hip_lib
+    if _hip_lib is None:
+        _hip_lib = GpxLib(HIP_LIB_PATH, "gpx_", device_api=True)
+    return _hip_lib
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(_VP)
+
+
+def _i32(a, n=None):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    if n is not None and a.shape[0] != n:
+        raise ValueError("column length mismatch")
+    return a
+
+
+def _u8(a, n=None):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=np.uint8)
+    if n is not None and a.shape[0] != n:
+        raise ValueError("column length mismatch")
+    return a
+
+
+@dataclass
+class Decisions:
+    gidx: np.ndarray
+    slot: np.ndarray
+    bnum: np.ndarray
+    bcoord: np.ndarray
+    median_cp: np.ndarray
+    kind: np.ndarray
+    status: np.ndarray  # per input vote
+
+    def as_tuple_array(self):
+        return np.stack(
+            [self.gidx, self.slot, self.bnum, self.bcoord, self.median_cp, self.kind.astype(np.int32)],
+            axis=1,
+        )
+
+
+@dataclass
+class ExecRuns:
+    gidx: np.ndarray
+    first: np.ndarray
+    count: np.ndarray
+
+    def as_tuple_array(self):
+        return np.stack([self.gidx, self.first, self.count], axis=1)
+
+
+def make_hri(n: int) -> np.ndarray:
+    return np.zeros(n, dtype=HRI_DTYPE)
+
+
+def hri_create(n: int, k: int, coordinator) -> np.ndarray:
+    """Rows as HotRestoreInfo.createHRI gives them (HotRestoreInfo.java:145-157):
+    accSlot=1, accBallot=coordBallot=(0,coordinator), accGCSlot=-1, nextProposalSlot=1,
+    nodeSlots = zeros."""
+    rows = make_hri(n)
+    rows["acc_slot"] = 1
+    rows["acc_bcoord"] = coordinator
+    rows["acc_gc_slot"] = -1
+    rows["has_coord"] = 1
+    rows["coord_bcoord"] = coordinator
+    rows["next_proposal_slot"] = 1
+    return rows
+
+
+def hri_initial(n: int, k: int, coordinator) -> np.ndarray:
+    """Rows equivalent to regular creation with an initial-state checkpoint
+    (PaxosInstanceStateMachine.java:612-618, 656-668, 692-699): acceptor slot 1,
+    gcSlot 0, ballot (0,coordinator); coordinator nextProposalSlot 1 and
+    nodeSlotNumbers = -1 (PaxosCoordinatorState.java:173-175)."""
+    rows = hri_create(n, k, coordinator)
+    rows["acc_gc_slot"] = 0
+    rows["node_slots"][:, :k] = -1
+    return rows
+
+
+class Engine:
+    """Host handle over one engine (`gpx_engine*`): the device-resident replacement of
+    PaxosManager's name->PaxosInstanceStateMachine table for one node id."""
+
+    def __init__(self, lib: GpxLib, my_id: int, max_groups: int, kmax: int = 3, window: int = 8,
+                 max_batch: int = 1 << 20, device: int = -1, flags: int = F_ACCEPTS_FROM_DISK):
+        self.lib = lib
+        self.cfg = GpxConfig(my_id, max_groups, kmax, window, max_batch, device, flags, 0)
+        h = _VP()
+        lib.check(lib.fn["engine_create"](C.byref(self.cfg), C.byref(h)), "engine_create")
+        self.h = h
+        self.kmax = kmax
+        self.my_id = my_id
+
+    def close(self):
+        if self.h:
+            self.lib.fn["engine_destroy"](self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- lifecycle (PaxosManager.createPaxosInstance / kill / pause) ---------------
+    def create_groups(self, gidx, members, k, rows) -> np.ndarray:
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        members = np.ascontiguousarray(members, dtype=np.int32).reshape(n, self.kmax)
+        k = _u8(np.broadcast_to(np.asarray(k, dtype=np.uint8), (n,)), n)
+        rows = np.ascontiguousarray(rows, dtype=HRI_DTYPE)
+        assert rows.shape[0] == n
+        status = np.zeros(n, np.uint8)
+        self.lib.check(
+            self.lib.fn["group_create"](self.h, n, _p(gidx), _p(members), _p(k), _p(rows), _p(status)),
+            "group_create",
+        )
+        return status
+
+    def retire_groups(self, gidx, mode=RETIRE_PAUSE):
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        rows = make_hri(n)
+        status = np.zeros(n, np.uint8)
+        self.lib.check(
+            self.lib.fn["group_retire"](self.h, n, _p(gidx), mode, _p(rows), _p(status)), "group_retire"
+        )
+        return rows, status
+
+    def snapshot(self, gidx):
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        rows = make_hri(n)
+        status = np.zeros(n, np.uint8)
+        self.lib.check(
+            self.lib.fn["group_snapshot"](self.h, n, _p(gidx), _p(rows), _p(status)), "group_snapshot"
+        )
+        return rows, status
+
+    def dump(self, g: int) -> np.ndarray:
+        cap = 16 + 3 * KMAX_LIMIT + 16 * 64 * 6
+        buf = np.zeros(cap, np.int32)
+        nw = self.lib.check(self.lib.fn["group_dump"](self.h, int(g), _p(buf), cap), "group_dump")
+        return buf[:nw].copy()
+
+    def counters(self):
+        out = (C.c_uint64 * 3)()
+        self.lib.check(self.lib.fn["engine_counters"](self.h, out), "engine_counters")
+        return tuple(int(x) for x in out)
+
+    def sync(self):
+        self.lib.check(self.lib.fn["engine_sync"](self.h), "engine_sync")
+
+    # -- data path ---------------------------------------------------------------
+    def propose(self, gidx, is_stop=None):
+        """PISM.handleRequest/handleProposal for a batch of (already batched) requests."""
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        is_stop = _u8(is_stop, n)
+        slot, bnum, bcoord, median = (np.zeros(n, np.int32) for _ in range(4))
+        status = np.zeros(n, np.uint8)
+        self.lib.check(
+            self.lib.fn["propose_batch"](self.h, n, _p(gidx), _p(is_stop), _p(slot), _p(bnum),
+                                         _p(bcoord), _p(median), _p(status)),
+            "propose_batch",
+        )
+        return slot, bnum, bcoord, median, status
+
+    def accept(self, gidx, bnum, bcoord, slot, median_cp, a_flags=None):
+        """PISM.handleAccept for a batch of ACCEPTs."""
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        bnum, bcoord, slot, median_cp = (_i32(x, n) for x in (bnum, bcoord, slot, median_cp))
+        a_flags = _u8(a_flags, n)
+        r_bnum, r_bcoord, r_maxcp = (np.zeros(n, np.int32) for _ in range(3))
+        r_flags = np.zeros(n, np.uint8)
+        status = np.zeros(n, np.uint8)
+        xg, xf, xc = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+        nr = np.zeros(1, np.int32)
+        self.lib.check(
+            self.lib.fn["accept_batch"](self.h, n, _p(gidx), _p(bnum), _p(bcoord), _p(slot),
+                                        _p(median_cp), _p(a_flags), _p(r_bnum), _p(r_bcoord),
+                                        _p(r_maxcp), _p(r_flags), _p(status), _p(xg), _p(xf), _p(xc),
+                                        _p(nr)),
+            "accept_batch",
+        )
+        m = int(nr[0])
+        return (r_bnum, r_bcoord, r_maxcp, r_flags, status), ExecRuns(xg[:m], xf[:m], xc[:m])
+
+    def accept_reply(self, gidx, bnum, bcoord, slot, acceptor, max_cp) -> Decisions:
+        """PISM.handleBatchedAcceptReply/handleAcceptReply for a batch of votes."""
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        bnum, bcoord, slot, acceptor, max_cp = (_i32(x, n) for x in (bnum, bcoord, slot, acceptor, max_cp))
+        cap = max(n, 1)
+        dg, ds, db, dc, dm = (np.zeros(cap, np.int32) for _ in range(5))
+        dk = np.zeros(cap, np.uint8)
+        status = np.zeros(n, np.uint8)
+        no = np.zeros(1, np.int32)
+        self.lib.check(
+            self.lib.fn["accept_reply_batch"](self.h, n, _p(gidx), _p(bnum), _p(bcoord), _p(slot),
+                                              _p(acceptor), _p(max_cp), _p(dg), _p(ds), _p(db), _p(dc),
+                                              _p(dm), _p(dk), _p(no), _p(status)),
+            "accept_reply_batch",
+        )
+        m = int(no[0])
+        return Decisions(dg[:m], ds[:m], db[:m], dc[:m], dm[:m], dk[:m], status)
+
+    def commit(self, gidx, bnum, bcoord, slot, median_cp, c_kind=None):
+        """PISM.handleBatchedCommit/handleCommittedRequest for a batch of committed slots."""
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        bnum, bcoord, slot, median_cp = (_i32(x, n) for x in (bnum, bcoord, slot, median_cp))
+        c_kind = _u8(c_kind, n)
+        status = np.zeros(n, np.uint8)
+        xg, xf, xc = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+        nr = np.zeros(1, np.int32)
+        self.lib.check(
+            self.lib.fn["commit_batch"](self.h, n, _p(gidx), _p(bnum), _p(bcoord), _p(slot),
+                                        _p(median_cp), _p(c_kind), _p(status), _p(xg), _p(xf), _p(xc),
+                                        _p(nr)),
+            "commit_batch",
+        )
+        m = int(nr[0])
+        return status, ExecRuns(xg[:m], xf[:m], xc[:m])

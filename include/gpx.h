@@ -1,0 +1,268 @@
+/*
+ * gpx.h — C-ABI of the MI355X batched-consensus engine.
+ *
+ * This is the drop-in boundary for ONE hot path of MobilityFirst/gigapaxos: the
+ * per-group PaxosInstanceStateMachine propose / accept / accept-reply / commit
+ * pipeline.  The reference (100 % Java) has no FFI for this path; the seam is the
+ * Java call PaxosManager.handlePaxosPacket -> PaxosInstanceStateMachine
+ * .handlePaxosMessage (PaxosManager.java:1126-1204, PaxosInstanceStateMachine
+ * .java:411-583).  Every entry point below replaces one branch of that switch
+ * for a whole batch of (group, packet) records at once, and is what a JNI stub
+ * in RequestBatcher.process / PaxosPacketBatcher.dequeueImpl / PaxosManager
+ * .handlePaxosPacket would bind.
+ *
+ * Conventions
+ *   - plain pointers + sizes; no C++ / torch types; no exception crosses the ABI.
+ *   - every function returns 0 or a negative GPX_E* code (whole call rejected,
+ *     no state changed).  Per-record soft errors go to a `status` column
+ *     (GPX_S_*): such a record is DROPPED exactly like a lost / version-
+ *     mismatched packet in the reference (PaxosInstanceStateMachine.java:441-460)
+ *     and no state of its group changes.
+ *   - all buffers are caller-owned and only valid for the duration of the call.
+ *   - "gidx" is a dense group index in [0, max_groups): the Java host keeps the
+ *     (paxosID, version) -> gidx map (it replaces MultiArrayMap,
+ *     PaxosManager.java:1816-1832).  Values (request payloads) never cross the
+ *     boundary; the host keeps (gidx, slot) -> RequestPacket.
+ *   - ORDER: within one call, records of the same group are applied in array
+ *     order, exactly as if handlePaxosMessage had been called once per record in
+ *     that order.  Records of different groups are independent
+ *     (PaxosManager.java:3170-3171).  Compacted outputs (decisions, exec runs)
+ *     are emitted in the array order of the record that produced them.
+ *   - one submitting thread per engine at a time (the ConsumerTask single-
+ *     consumer discipline, ConsumerTask.java:163-174); different engines are
+ *     fully concurrent.
+ *   - the plain entry points take HOST pointers (what a JNI direct ByteBuffer
+ *     gives); the *_dev twins take DEVICE pointers, run asynchronously on the
+ *     engine's stream and leave counts in device memory (used when the batch is
+ *     already resident in HBM).
+ */
+#ifndef GPX_H
+#define GPX_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPX_ABI_VERSION 1
+#define GPX_KMAX_LIMIT 16 /* PC.MAX_GROUP_SIZE = 16, PaxosConfig.java:532 */
+
+/* whole-call errors */
+#define GPX_OK 0
+#define GPX_EINVAL (-1)    /* bad argument / null handle */
+#define GPX_ECAPACITY (-2) /* n > max_batch, gidx space exhausted */
+#define GPX_EDEVICE (-3)   /* HIP runtime error (gpx_last_error has text) */
+#define GPX_ENOMEM (-4)
+
+/* per-record status column (uint8) */
+#define GPX_S_OK 0
+#define GPX_S_NOGROUP 1 /* gidx out of range / no such instance: PaxosManager.java:1162-1194 */
+#define GPX_S_STOPPED 2 /* acceptor stopped: PaxosInstanceStateMachine.java:456-460 */
+#define GPX_S_WINDOW 3  /* slot outside the engine's fixed window; record not applied */
+#define GPX_S_FORWARD 4 /* propose only: no coordinator here, forward to `bcoord`
+                           (PaxosInstanceStateMachine.java:854-860) */
+#define GPX_S_REFUSED 5 /* propose only: proposal after a stop, nothing sent
+                           (PaxosCoordinatorState.java:235-239) */
+#define GPX_S_EXISTS 6  /* group_create on a live gidx */
+#define GPX_S_BUSY 7    /* group_retire(GPX_RETIRE_PAUSE) on a group that is not
+                           caught up (PaxosInstanceStateMachine.java:2004-2035) */
+
+/* decision kinds (d_kind) */
+#define GPX_D_DECISION 1  /* PValuePacket.makeDecision, PaxosCoordinatorState.java:630-635 */
+#define GPX_D_PREEMPTED 2 /* PaxosCoordinatorState.java:661-675 */
+
+/* accept-reply flag bits (r_flags) */
+#define GPX_R_TOLOG 1  /* PaxosInstanceStateMachine.java:1146-1149 */
+#define GPX_R_STORED 2 /* accept was put into acceptedProposals, PaxosAcceptor.java:315-316 */
+
+/* accept flag bits (a_flags) / propose is_stop / commit kind bits */
+#define GPX_A_STOP 1       /* request is a stop request */
+#define GPX_C_HASVALUE 1   /* commit record is a full DECISION (value at host) rather
+                              than a BATCHED_COMMIT slot */
+#define GPX_C_STOP 2       /* (only with GPX_C_HASVALUE) the decision is a stop */
+
+/* engine flags */
+#define GPX_F_ACCEPTS_FROM_DISK 1u /* PaxosAcceptor.GET_ACCEPTED_PVALUES_FROM_DISK
+                                      (PaxosAcceptor.java:75-76): default true */
+
+/* group_retire modes */
+#define GPX_RETIRE_PAUSE 0 /* only if caught up (tryPause) */
+#define GPX_RETIRE_KILL 1  /* unconditional (PaxosManager.kill, PaxosManager.java:2162) */
+
+typedef struct gpx_engine gpx_engine;
+
+typedef struct gpx_config {
+  int32_t my_id;      /* this node's integer id (PaxosInstanceStateMachine.getMyID) */
+  int32_t max_groups; /* capacity of the gidx space (PC.PINSTANCES_CAPACITY) */
+  int32_t kmax;       /* largest replica-group size that will be created (1..16) */
+  int32_t window;     /* W: slots tracked per group per map; power of two, 4..64 */
+  int32_t max_batch;  /* largest n of any batch call */
+  int32_t device;     /* HIP device ordinal, -1 = current device */
+  uint32_t flags;     /* GPX_F_* */
+  uint32_t reserved;
+} gpx_config;
+
+/*
+ * One group's pausable state == HotRestoreInfo (HotRestoreInfo.java:35-84) minus
+ * the name.  gpx_group_create applies it verbatim (regular creation
+ * and createHRI give different rows; the host decides which).
+ */
+typedef struct gpx_hri {
+  int32_t version;
+  int32_t acc_slot;   /* accSlot */
+  int32_t acc_bnum;   /* accBallot.ballotNumber */
+  int32_t acc_bcoord; /* accBallot.coordinatorID */
+  int32_t acc_gc_slot;
+  int32_t has_coord;  /* coordBallot != null */
+  int32_t coord_bnum;
+  int32_t coord_bcoord;
+  int32_t next_proposal_slot;
+  int32_t node_slots[GPX_KMAX_LIMIT]; /* first k entries used */
+} gpx_hri;
+
+/* ---- lifecycle ------------------------------------------------------------ */
+
+/* replaces: new PaxosManager(...)'s instance table (PaxosManager.java:380-400) */
+int gpx_engine_create(const gpx_config* cfg, gpx_engine** out);
+int gpx_engine_destroy(gpx_engine* h);
+/* text of the last GPX_EDEVICE on this thread ("" if none) */
+const char* gpx_last_error(void);
+/* run subsequent *_dev calls on this hipStream_t (NULL = the engine's own stream) */
+int gpx_engine_set_stream(gpx_engine* h, void* hip_stream);
+/* block until everything submitted on the engine's stream has finished */
+int gpx_engine_sync(gpx_engine* h);
+
+/*
+ * replaces: PaxosManager.createPaxosInstance(Map nameStates, gms) batch create
+ * (PaxosManager.java:664-691) -> new PaxosInstanceStateMachine(..., hri, ...)
+ * -> hotRestore (PaxosInstanceStateMachine.java:677-690).
+ * members: n x kmax int32, each row ascending (PaxosInstanceStateMachine.java:205),
+ * unused tail ignored; k[i] = group size.
+ * A coordinator is created only when rows[i].has_coord and coord_bcoord == my_id
+ * (PaxosInstanceStateMachine.java:682-684).
+ */
+int gpx_group_create(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* members,
+                     const uint8_t* k, const gpx_hri* rows, uint8_t* status);
+
+/*
+ * replaces: PaxosInstanceStateMachine.tryPause (PISM:2004-2035) / PaxosManager.kill.
+ * rows (nullable) receives the HotRestoreInfo of each retired group.
+ */
+int gpx_group_retire(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mode, gpx_hri* rows,
+                     uint8_t* status);
+
+/* read-only snapshot of the HotRestoreInfo rows (no state change) */
+int gpx_group_snapshot(gpx_engine* h, int32_t n, const int32_t* gidx, gpx_hri* rows,
+                       uint8_t* status);
+
+/*
+ * Canonical dump of ONE group's full protocol state for parity checks
+ * (int32 words; layout in DESIGN.md §state-dump).  Returns the number of words
+ * written (<= cap) or a negative error.
+ */
+int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap);
+
+/* ---- data path (host pointers) ---------------------------------------------- */
+
+/*
+ * replaces: RequestBatcher.process -> PaxosManager.proposeBatched -> PISM.handleRequest
+ * -> handleProposal -> PaxosCoordinatorState.propose + initCommander
+ * (RequestBatcher.java:79-81, PaxosInstanceStateMachine.java:767-888,
+ *  PaxosCoordinatorState.java:233-263, 841-851).
+ * One record = one (already batched) RequestPacket for group gidx[i].
+ * is_stop (nullable): 1 if the request is a stop request.
+ * status[i]==GPX_S_OK: an ACCEPT(bnum,bcoord,slot,median_cp) must be multicast.
+ */
+int gpx_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                      int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
+                      uint8_t* status);
+
+/*
+ * replaces: PISM.handleAccept (PaxosInstanceStateMachine.java:1080-1166) ->
+ * PaxosAcceptor.acceptAndUpdateBallot (PaxosAcceptor.java:302-322), then
+ * reconstructDecision -> handleCommittedRequest -> extractExecuteAndCheckpoint.
+ * Dense outputs (one per record): the ACCEPT_REPLY (r_bnum, r_bcoord, slot echoed by
+ * caller, r_maxcp = acceptor slot - 1), r_flags = GPX_R_*, status.
+ * Compacted outputs: in-order execution runs (x_gidx, x_first, x_count), *n_runs of them.
+ */
+int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                     const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                     const uint8_t* a_flags, int32_t* r_bnum, int32_t* r_bcoord,
+                     int32_t* r_maxcp, uint8_t* r_flags, uint8_t* status, int32_t* x_gidx,
+                     int32_t* x_first, int32_t* x_count, int32_t* n_runs);
+
+/*
+ * replaces: PISM.handleBatchedAcceptReply / handleAcceptReply
+ * (PaxosInstanceStateMachine.java:1248-1419) -> PaxosCoordinator.handleAcceptReply
+ * (PaxosCoordinator.java:210-250) -> PaxosCoordinatorState.handleAcceptReplyMyBallot /
+ * handleAcceptReplyHigherBallot (PaxosCoordinatorState.java:597-683).
+ * One record = one vote (one slot of a BATCHED_ACCEPT_REPLY).  Compacted outputs: one
+ * entry per DECISION / PREEMPTED, in vote order; *n_out of them (<= n).
+ * status (nullable): per-vote GPX_S_*.
+ */
+int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                           const int32_t* bcoord, const int32_t* slot, const int32_t* acceptor,
+                           const int32_t* max_cp, int32_t* d_gidx, int32_t* d_slot,
+                           int32_t* d_bnum, int32_t* d_bcoord, int32_t* d_median_cp,
+                           uint8_t* d_kind, int32_t* n_out, uint8_t* status);
+
+/*
+ * replaces: PISM.handleBatchedCommit / handleCommittedRequest
+ * (PaxosInstanceStateMachine.java:1432-1528) -> extractExecuteAndCheckpoint
+ * (:1619-1701) -> PaxosAcceptor.putAndRemoveNextExecutable (PaxosAcceptor.java:325-366).
+ * One record = one committed slot.  c_kind (nullable) = GPX_C_* bits.
+ * Compacted outputs: execution runs as in gpx_accept_batch.
+ */
+int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                     const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                     const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx, int32_t* x_first,
+                     int32_t* x_count, int32_t* n_runs);
+
+/* ---- data path (device pointers, asynchronous on the engine stream) ---------- */
+/* Same semantics; every pointer is device memory; n_out / n_runs are device int32. */
+
+int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                          int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
+                          uint8_t* status);
+int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                         const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                         const uint8_t* a_flags, int32_t* r_bnum, int32_t* r_bcoord,
+                         int32_t* r_maxcp, uint8_t* r_flags, uint8_t* status, int32_t* x_gidx,
+                         int32_t* x_first, int32_t* x_count, int32_t* n_runs);
+int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
+                               const int32_t* bnum, const int32_t* bcoord, const int32_t* slot,
+                               const int32_t* acceptor, const int32_t* max_cp, int32_t* d_gidx,
+                               int32_t* d_slot, int32_t* d_bnum, int32_t* d_bcoord,
+                               int32_t* d_median_cp, uint8_t* d_kind, int32_t* n_out,
+                               uint8_t* status);
+int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                         const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                         const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx,
+                         int32_t* x_first, int32_t* x_count, int32_t* n_runs);
+
+/* ---- telemetry --------------------------------------------------------------- */
+
+/* cumulative counters since engine creation: votes, decisions, dropped records */
+int gpx_engine_counters(gpx_engine* h, uint64_t out[3]);
+
+/*
+ * Per-kernel timing with hipEvents on the launch stream.  enable=1 brackets every
+ * kernel launch with events (adds host overhead: never enable inside a timed
+ * throughput region).  gpx_profile_read copies up to cap entries
+ * (name, launches, total_ms) and returns the number of distinct kernels.
+ */
+typedef struct gpx_kernel_stat {
+  char name[48];
+  uint64_t launches;
+  double total_ms;
+} gpx_kernel_stat;
+int gpx_profile_enable(gpx_engine* h, int32_t enable);
+int gpx_profile_read(gpx_engine* h, gpx_kernel_stat* out, int32_t cap);
+
+int gpx_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPX_H */

@@ -1,0 +1,751 @@
+/*
+ * gpx_oracle.cpp — CPU ORACLE.  TEST INFRASTRUCTURE ONLY.
+ *
+ * A deliberately plain, one-object-per-group, std::map-based restatement of the
+ * gigapaxos accept / accept-reply / commit hot path, used ONLY as the checker by
+ * tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg.  Nothing in the
+ * product path (gigapaxos_amd/, libgpx_hip.so) may link, import or call it.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * /root/reference/src/edu/umass/cs/gigapaxos/).  Java semantics reproduced on
+ * purpose: 32-bit two's-complement wraparound in `a - b < 0` comparisons, plain
+ * `<` where the reference uses it (PaxosCoordinatorState.java:815), TreeMap
+ * signed-ascending iteration order, integer-division majority.
+ *
+ * PARITY STATUS: "parity unpinned by reference fixtures" for the decided
+ * (group, slot, ballot, medianCheckpointedSlot) stream — the reference ships no
+ * golden vectors for this path and no JVM exists in the build container, so the
+ * Java cannot be run to produce any.  What IS pinned: the
+ * known-answer assertions the reference's own self-tests make
+ * (WaitforUtility.main, PaxosCoordinatorState.main's accept-reply section,
+ * PaxosAcceptor.testAcceptor's monotone-ballot property, HotRestoreInfoTest),
+ * re-expressed in tests/test_oracle_kat.py against this file.
+ *
+ * Modelling assumptions (same as the engine, stated in DESIGN.md):
+ *   - steady state: no wall-clock event fires (no checkRunForCoordinator election,
+ *     no accept retransmit; PaxosInstanceStateMachine.java:480-492 preamble is a
+ *     no-op), i.e. BOOTSTRAP_COORD_DETERMINISTIC-like behaviour;
+ *   - coordinators are always active (ballot-0 / hot-restored coordinators are
+ *     created active: PaxosCoordinator.java:91-104, 122-131);
+ *   - DIGEST_REQUESTS=false, BATCHED_COMMITS=true, GC_MAJORITY_EXECUTED=true,
+ *     FORWARD_PREEMPTED_REQUESTS=false, EXECUTE_UPON_ACCEPT=false (defaults,
+ *     PaxosConfig.java:435-453, 466, 788, 882, 927).
+ */
+#include <algorithm>
+#include <cstdint>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <vector>
+
+#include "../include/gpx.h"
+
+namespace {
+
+/* Java `a - b` on ints: wraps. */
+static inline int32_t jsub(int32_t a, int32_t b) {
+  return (int32_t)((uint32_t)a - (uint32_t)b);
+}
+
+/* paxosutil/Ballot.java:60-73 */
+struct Ballot {
+  int32_t num = 0, coord = 0;
+  int compareTo(const Ballot& b) const {
+    if (num != b.num) return jsub(num, b.num); /* "will handle wraparounds correctly" */
+    return jsub(coord, b.coord);
+  }
+  bool equals(const Ballot& b) const { return compareTo(b) == 0; } /* :76-78 */
+};
+
+/* paxosutil/WaitforUtility.java:36-115 */
+struct WaitforUtility {
+  const std::vector<int32_t>* members;
+  std::vector<bool> responded;
+  int heardCount = 0;
+  explicit WaitforUtility(const std::vector<int32_t>* m) : members(m), responded(m->size(), false) {}
+  int getIndex(int32_t node) const { /* :108-115 — LAST matching index */
+    int index = -1;
+    for (size_t i = 0; i < members->size(); i++)
+      if ((*members)[i] == node) index = (int)i;
+    return index;
+  }
+  bool updateHeardFrom(int32_t node) { /* :51-62 */
+    bool changed = false;
+    int index = getIndex(node);
+    if (index >= 0 && index < (int)members->size()) {
+      if (!responded[index]) {
+        changed = true;
+        heardCount++;
+      }
+      responded[index] = true;
+    }
+    return changed;
+  }
+  bool heardFromMajority() const { return heardCount > (int)members->size() / 2; } /* :64-68 */
+  bool contains(int32_t node) const { return getIndex(node) >= 0; }
+};
+
+/* An accepted pvalue as the acceptor remembers it (paxospackets/AcceptPacket.java:36-66,
+ * PValuePacket.java:38-74).  The value itself stays with the host. */
+struct Accepted {
+  Ballot ballot;
+  int32_t slot;
+  bool stop;
+};
+
+/* A committed decision (PValuePacket after makeDecision, PValuePacket.java:135-143). */
+struct Decision {
+  Ballot ballot;
+  int32_t slot;
+  int32_t median;
+  bool hasValue; /* RequestPacket.hasRequestValue(): false for BATCHED_COMMIT placeholders */
+  bool stop;
+};
+
+/* PaxosAcceptor.java:94-110 */
+struct PaxosAcceptor {
+  int32_t _slot = 0;
+  int32_t ballotNum = -1, ballotCoord = -1;
+  int32_t acceptedGCSlot = -1;
+  bool stopped = false;
+  std::map<int32_t, Accepted> acceptedProposals; /* NullIfEmptyMap == TreeMap */
+  std::map<int32_t, Decision> committedRequests;
+  bool fromDisk = true; /* GET_ACCEPTED_PVALUES_FROM_DISK, PaxosAcceptor.java:75-76 */
+
+  Ballot getBallot() const { return Ballot{ballotNum, ballotCoord}; }
+
+  /* PaxosAcceptor.java:476-494 */
+  void garbageCollectAccepted(int32_t gcSlot) {
+    if (jsub(_slot, gcSlot) <= 0) gcSlot = jsub(_slot, 1);
+    if (jsub(gcSlot, acceptedGCSlot) > 0) {
+      acceptedGCSlot = gcSlot;
+      for (auto it = acceptedProposals.begin(); it != acceptedProposals.end();) {
+        if (jsub(it->first, gcSlot) <= 0)
+          it = acceptedProposals.erase(it);
+        else
+          ++it;
+      }
+    }
+    garbageCollectDecisions(gcSlot);
+  }
+  /* PaxosAcceptor.java:496-506 */
+  void garbageCollectDecisions(int32_t slot) {
+    if (jsub(slot, _slot) >= 0) return;
+    for (auto it = committedRequests.begin(); it != committedRequests.end();) {
+      if (jsub(slot, it->first) > 0)
+        it = committedRequests.erase(it);
+      else
+        ++it;
+    }
+  }
+  /* PaxosAcceptor.java:302-322.  Returns false iff stopped (Java returns null). */
+  bool acceptAndUpdateBallot(const Accepted& accept, int32_t medianCP, Ballot* out, bool* stored) {
+    if (stopped) return false;
+    *stored = false;
+    if (accept.ballot.compareTo(getBallot()) >= 0) {
+      ballotNum = accept.ballot.num;
+      ballotCoord = accept.ballot.coord;
+      if (jsub(accept.slot, acceptedGCSlot) > 0) {
+        acceptedProposals[accept.slot] = accept;
+        *stored = true;
+      }
+    }
+    garbageCollectAccepted(medianCP);
+    *out = getBallot();
+    return true;
+  }
+  /* PaxosAcceptor.java:369-385 */
+  bool reconstructDecision(int32_t slot, Decision* out) const {
+    auto c = committedRequests.find(slot);
+    if (c != committedRequests.end()) {
+      if (c->second.hasValue) {
+        *out = c->second;
+        return true;
+      }
+      auto a = acceptedProposals.find(slot);
+      if (a != acceptedProposals.end() && a->second.ballot.equals(c->second.ballot)) {
+        *out = Decision{a->second.ballot, slot, c->second.median, true, a->second.stop};
+        return true;
+      }
+    }
+    return false;
+  }
+  /* PaxosAcceptor.java:462-474 */
+  void executed(int32_t s, bool stop) {
+    /* s == _slot by construction; the Java asserts/suicides otherwise */
+    _slot = (int32_t)((uint32_t)_slot + 1u);
+    if (stop) stopped = true;
+    if (stopped) committedRequests.clear();
+    (void)s;
+  }
+  /* PaxosAcceptor.java:325-366.  `decision` may be null (poke). Returns true and
+   * fills *next when an in-order executable decision was extracted. */
+  bool putAndRemoveNextExecutable(const Decision* decision, Decision* next) {
+    if (stopped) return false;
+    Decision tmp;
+    if (decision == nullptr) {
+      auto c = committedRequests.find(_slot);
+      if (c == committedRequests.end()) return false;
+      tmp = c->second;
+      decision = &tmp;
+    }
+    garbageCollectAccepted(decision->median);
+    if (jsub(decision->slot, _slot) >= 0) {
+      auto c = committedRequests.find(decision->slot);
+      if (c == committedRequests.end() || !c->second.hasValue)
+        committedRequests[decision->slot] = *decision;
+    }
+    bool haveNext = false;
+    if (committedRequests.count(_slot)) {
+      haveNext = reconstructDecision(_slot, next);
+      if (haveNext && next->hasValue) {
+        committedRequests.erase(_slot);
+        executed(next->slot, next->stop);
+      }
+    }
+    if (haveNext && fromDisk) acceptedProposals.erase(next->slot);
+    return haveNext;
+  }
+};
+
+/* PaxosCoordinatorState.java:69-181 (only what the accept phase touches) */
+struct ProposalState {
+  bool stop;
+  WaitforUtility waitfor;
+};
+struct PaxosCoordinatorState {
+  Ballot myBallot;
+  int32_t nextProposalSlotNumber = 0;
+  bool active = false;
+  std::vector<int32_t> nodeSlotNumbers;
+  std::map<int32_t, ProposalState> myProposals;
+
+  /* PaxosCoordinatorState.java:867-875 (Arrays.sort = signed ascending) */
+  int32_t getMedianMinus() const {
+    std::vector<int32_t> copy(nodeSlotNumbers);
+    std::sort(copy.begin(), copy.end());
+    size_t medianMinus = copy.size() % 2 == 0 ? copy.size() / 2 - 1 : copy.size() / 2;
+    return copy[medianMinus];
+  }
+  int32_t getMajorityCommittedSlot() const { return getMedianMinus(); } /* :859-861 */
+
+  /* PaxosCoordinatorState.java:809-825 — note the PLAIN `<` */
+  void recordSlotNumber(const std::vector<int32_t>& members, int32_t acceptor, int32_t maxCP) {
+    for (size_t i = 0; i < members.size(); i++)
+      if (members[i] == acceptor)
+        if (nodeSlotNumbers[i] < maxCP) nodeSlotNumbers[i] = maxCP;
+  }
+  /* PaxosCoordinatorState.java:233-263 + initCommander :841-851.
+   * returns 0 = ACCEPT issued, 1 = refused (after stop) */
+  int propose(const std::vector<int32_t>& members, bool stop, int32_t* slot, int32_t* median) {
+    auto prev = myProposals.find(jsub(nextProposalSlotNumber, 1));
+    if (prev != myProposals.end() && prev->second.stop) return 1;
+    int32_t s = nextProposalSlotNumber;
+    nextProposalSlotNumber = (int32_t)((uint32_t)nextProposalSlotNumber + 1u);
+    myProposals.emplace(s, ProposalState{stop, WaitforUtility(&members)});
+    *slot = s;
+    *median = getMajorityCommittedSlot();
+    return 0; /* active is always true here (see header) */
+  }
+  /* PaxosCoordinatorState.java:597-640; returns true on first majority */
+  bool handleAcceptReplyMyBallot(const std::vector<int32_t>& members, int32_t slot,
+                                 int32_t acceptor, int32_t maxCP, int32_t* median) {
+    recordSlotNumber(members, acceptor, maxCP);
+    auto p = myProposals.find(slot);
+    if (p == myProposals.end()) return false;
+    p->second.waitfor.updateHeardFrom(acceptor);
+    if (p->second.waitfor.heardFromMajority()) {
+      *median = getMajorityCommittedSlot();
+      myProposals.erase(p);
+      return true;
+    }
+    return false;
+  }
+  /* PaxosCoordinatorState.java:661-675; true if a proposal was preempted */
+  bool handleAcceptReplyHigherBallot(int32_t slot) { return myProposals.erase(slot) > 0; }
+  bool preemptedFully() const { return myProposals.empty(); } /* :677-683 */
+};
+
+/* PaxosInstanceStateMachine.java:193-238 (the fields the accept phase touches) */
+struct Group {
+  int32_t version = 0;
+  std::vector<int32_t> members;
+  PaxosAcceptor paxosState;
+  std::unique_ptr<PaxosCoordinatorState> coordinator;
+};
+
+struct ExecRun {
+  int32_t first, count;
+};
+
+struct Engine {
+  gpx_config cfg;
+  std::vector<std::unique_ptr<Group>> groups;
+  uint64_t counters[3] = {0, 0, 0};
+
+  Group* get(int32_t g) {
+    if (g < 0 || g >= cfg.max_groups) return nullptr;
+    return groups[g].get();
+  }
+
+  /* PaxosInstanceStateMachine.java:1619-1701 (protocol part: no app upcall here,
+   * the executed slots are reported to the caller who performs Replicable.execute) */
+  ExecRun extractExecuteAndCheckpoint(Group& g, const Decision* logged) {
+    ExecRun run{g.paxosState._slot, 0};
+    if (g.paxosState.stopped) return run;
+    Decision inorder;
+    while (g.paxosState.putAndRemoveNextExecutable(logged, &inorder)) {
+      run.count++;
+      if (inorder.stop) break; /* :1678-1685 (copyEpochFinalCheckpointState assumed ok) */
+    }
+    return run;
+  }
+  /* PaxosInstanceStateMachine.java:1432-1478 */
+  ExecRun handleCommittedRequest(Group& g, const Decision& committed) {
+    return extractExecuteAndCheckpoint(g, &committed);
+  }
+};
+
+static thread_local char g_err[8] = "";
+
+static void fill_hri(const Group& g, gpx_hri* r) {
+  /* PaxosInstanceStateMachine.java:2011-2020 */
+  std::memset(r, 0, sizeof(*r));
+  r->version = g.version;
+  r->acc_slot = g.paxosState._slot;
+  r->acc_bnum = g.paxosState.ballotNum;
+  r->acc_bcoord = g.paxosState.ballotCoord;
+  r->acc_gc_slot = g.paxosState.acceptedGCSlot;
+  if (g.coordinator && g.coordinator->active) {
+    r->has_coord = 1;
+    r->coord_bnum = g.coordinator->myBallot.num;
+    r->coord_bcoord = g.coordinator->myBallot.coord;
+    r->next_proposal_slot = g.coordinator->nextProposalSlotNumber;
+    for (size_t i = 0; i < g.members.size(); i++) r->node_slots[i] = g.coordinator->nodeSlotNumbers[i];
+  } else {
+    r->has_coord = 0;
+    r->next_proposal_slot = -1; /* getNextProposalSlotIfActive, PaxosCoordinator.java:375-377 */
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int orc_abi_version(void) { return GPX_ABI_VERSION; }
+const char* orc_last_error(void) { return g_err; }
+
+int orc_engine_create(const gpx_config* cfg, gpx_engine** out) {
+  if (!cfg || !out || cfg->max_groups <= 0 || cfg->kmax < 1 || cfg->kmax > GPX_KMAX_LIMIT)
+    return GPX_EINVAL;
+  Engine* e = new Engine();
+  e->cfg = *cfg;
+  e->groups.resize((size_t)cfg->max_groups);
+  *out = reinterpret_cast<gpx_engine*>(e);
+  return GPX_OK;
+}
+int orc_engine_destroy(gpx_engine* h) {
+  delete reinterpret_cast<Engine*>(h);
+  return GPX_OK;
+}
+int orc_engine_sync(gpx_engine*) { return GPX_OK; }
+int orc_engine_counters(gpx_engine* h, uint64_t out[3]) {
+  if (!h) return GPX_EINVAL;
+  Engine* e = reinterpret_cast<Engine*>(h);
+  for (int i = 0; i < 3; i++) out[i] = e->counters[i];
+  return GPX_OK;
+}
+
+/* PaxosInstanceStateMachine.java:677-690 hotRestore; PaxosAcceptor.java:121-134;
+ * PaxosCoordinator.java:122-131 */
+int orc_group_create(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* members,
+                     const uint8_t* k, const gpx_hri* rows, uint8_t* status) {
+  if (!h || n < 0) return GPX_EINVAL;
+  Engine* e = reinterpret_cast<Engine*>(h);
+  for (int32_t i = 0; i < n; i++) {
+    int32_t g = gidx[i];
+    if (g < 0 || g >= e->cfg.max_groups || k[i] < 1 || k[i] > e->cfg.kmax) {
+      if (status) status[i] = GPX_S_NOGROUP;
+      continue;
+    }
+    if (e->groups[g]) {
+      if (status) status[i] = GPX_S_EXISTS;
+      continue;
+    }
+    auto grp = std::make_unique<Group>();
+    grp->version = rows[i].version;
+    grp->members.assign(members + (size_t)i * e->cfg.kmax, members + (size_t)i * e->cfg.kmax + k[i]);
+    grp->paxosState.ballotNum = rows[i].acc_bnum;
+    grp->paxosState.ballotCoord = rows[i].acc_bcoord;
+    grp->paxosState._slot = rows[i].acc_slot;
+    grp->paxosState.acceptedGCSlot = rows[i].acc_gc_slot;
+    grp->paxosState.fromDisk = (e->cfg.flags & GPX_F_ACCEPTS_FROM_DISK) != 0;
+    if (rows[i].has_coord && rows[i].coord_bcoord == e->cfg.my_id) {
+      auto c = std::make_unique<PaxosCoordinatorState>();
+      c->myBallot = Ballot{rows[i].coord_bnum, rows[i].coord_bcoord};
+      c->nextProposalSlotNumber = rows[i].next_proposal_slot;
+      c->active = true;
+      c->nodeSlotNumbers.assign(rows[i].node_slots, rows[i].node_slots + k[i]);
+      grp->coordinator = std::move(c);
+    }
+    e->groups[g] = std::move(grp);
+    if (status) status[i] = GPX_S_OK;
+  }
+  return GPX_OK;
+}
+
+/* PaxosInstanceStateMachine.java:2004-2035 tryPause / PaxosManager.java:2162 kill */
+int orc_group_retire(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mode, gpx_hri* rows,
+                     uint8_t* status) {
+  if (!h || n < 0) return GPX_EINVAL;
+  Engine* e = reinterpret_cast<Engine*>(h);
+  for (int32_t i = 0; i < n; i++) {
+    Group* g = e->get(gidx[i]);
+    if (rows) std::memset(&rows[i], 0, sizeof(gpx_hri));
+    if (!g) {
+      if (status) status[i] = GPX_S_NOGROUP;
+      continue;
+    }
+    if (mode == GPX_RETIRE_PAUSE) {
+      /* PaxosAcceptor.caughtUp :451-459, PaxosCoordinatorState.caughtUp :758-761 */
+      bool caughtUp = g->paxosState.committedRequests.empty() &&
+                      (g->paxosState.acceptedProposals.empty() || g->paxosState.fromDisk) &&
+                      (!g->coordinator || g->coordinator->myProposals.empty());
+      if (!caughtUp) {
+        if (status) status[i] = GPX_S_BUSY;
+        continue;
+      }
+    }
+    if (rows) fill_hri(*g, &rows[i]);
+    e->groups[gidx[i]].reset();
+    if (status) status[i] = GPX_S_OK;
+  }
+  return GPX_OK;
+}
+
+int orc_group_snapshot(gpx_engine* h, int32_t n, const int32_t* gidx, gpx_hri* rows,
+                       uint8_t* status) {
+  if (!h || n < 0 || !rows) return GPX_EINVAL;
+  Engine* e = reinterpret_cast<Engine*>(h);
+  for (int32_t i = 0; i < n; i++) {
+    Group* g = e->get(gidx[i]);
+    std::memset(&rows[i], 0, sizeof(gpx_hri));
+    if (!g) {
+      if (status) status[i] = GPX_S_NOGROUP;
+      continue;
+    }
+    fill_hri(*g, &rows[i]);
+    if (status) status[i] = GPX_S_OK;
+  }
+  return GPX_OK;
+}
+
+/* canonical state dump: see DESIGN.md §state-dump */
+int orc_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
+  if (!h || !buf) return GPX_EINVAL;
+  Engine* e = reinterpret_cast<Engine*>(h);
+  std::vector<int32_t> w;
+  Group* g = e->get(gidx);
+  w.push_back(g ? 1 : 0);
+  if (g) {
+    w.push_back(g->version);
+    w.push_back((int32_t)g->members.size());
+    for (int32_t m : g->members) w.push_back(m);
+    const PaxosAcceptor& a = g->paxosState;
+    w.push_back(a._slot);
+    w.push_back(a.ballotNum);
+    w.push_back(a.ballotCoord);
+    w.push_back(a.acceptedGCSlot);
+    w.push_back(a.stopped ? 1 : 0);
+    w.push_back((int32_t)a.acceptedProposals.size());
+    for (auto& kv : a.acceptedProposals) {
+      w.push_back(kv.first);
+      w.push_back(kv.second.ballot.num);
+      w.push_back(kv.second.ballot.coord);
+      w.push_back(kv.second.stop ? 1 : 0);
+    }
+    w.push_back((int32_t)a.committedRequests.size());
+    for (auto& kv : a.committedRequests) {
+      w.push_back(kv.first);
+      w.push_back(kv.second.ballot.num);
+      w.push_back(kv.second.ballot.coord);
+      w.push_back(kv.second.median);
+      w.push_back(kv.second.hasValue ? 1 : 0);
+      w.push_back(kv.second.stop ? 1 : 0);
+    }
+    w.push_back(g->coordinator ? 1 : 0);
+    if (g->coordinator) {
+      const PaxosCoordinatorState& c = *g->coordinator;
+      w.push_back(c.myBallot.num);
+      w.push_back(c.myBallot.coord);
+      w.push_back(c.nextProposalSlotNumber);
+      for (int32_t s : c.nodeSlotNumbers) w.push_back(s);
+      w.push_back((int32_t)c.myProposals.size());
+      for (auto& kv : c.myProposals) {
+        w.push_back(kv.first);
+        w.push_back(kv.second.stop ? 1 : 0);
+        int32_t mask = 0;
+        for (size_t i = 0; i < kv.second.waitfor.responded.size(); i++)
+          if (kv.second.waitfor.responded[i]) mask |= (1 << i);
+        w.push_back(mask);
+      }
+    }
+  }
+  if ((int32_t)w.size() > cap) return GPX_ECAPACITY;
+  std::memcpy(buf, w.data(), w.size() * sizeof(int32_t));
+  return (int32_t)w.size();
+}
+
+/* PaxosInstanceStateMachine.java:767-888 handleRequest -> handleProposal */
+int orc_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                      int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
+                      uint8_t* status) {
+  if (!h || n < 0) return GPX_EINVAL;
+  Engine* e = reinterpret_cast<Engine*>(h);
+  for (int32_t i = 0; i < n; i++) {
+    slot[i] = bnum[i] = bcoord[i] = median_cp[i] = 0;
+    Group* g = e->get(gidx[i]);
+    if (!g) {
+      status[i] = GPX_S_NOGROUP;
+      e->counters[2]++;
+      continue;
+    }
+    if (g->paxosState.stopped) { /* :456-460 */
+      status[i] = GPX_S_STOPPED;
+      e->counters[2]++;
+      continue;
+    }
+    /* PaxosCoordinator.exists(c, paxosState.getBallot()) :213-219, PISM:825-826 */
+    if (g->coordinator && g->coordinator->myBallot.compareTo(g->paxosState.getBallot()) >= 0) {
+      int32_t s = 0, m = 0;
+      int rc = g->coordinator->propose(g->members, is_stop && (is_stop[i] & 1), &s, &m);
+      if (rc != 0) {
+        status[i] = GPX_S_REFUSED;
+        continue;
+      }
+      slot[i] = s;
+      bnum[i] = g->coordinator->myBallot.num;
+      bcoord[i] = g->coordinator->myBallot.coord;
+      median_cp[i] = m;
+      status[i] = GPX_S_OK;
+    } else {
+      /* :854-860 unicast to paxosState.getBallotCoord() */
+      bnum[i] = g->paxosState.ballotNum;
+      bcoord[i] = g->paxosState.ballotCoord;
+      status[i] = GPX_S_FORWARD;
+    }
+  }
+  return GPX_OK;
+}
+
+/* PaxosInstanceStateMachine.java:1080-1166 handleAccept */
+int orc_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                     const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                     const uint8_t* a_flags, int32_t* r_bnum, int32_t* r_bcoord,
+                     int32_t* r_maxcp, uint8_t* r_flags, uint8_t* status, int32_t* x_gidx,
+                     int32_t* x_first, int32_t* x_count, int32_t* n_runs) {
+  if (!h || n < 0) return GPX_EINVAL;
+  Engine* e = reinterpret_cast<Engine*>(h);
+  int32_t runs = 0;
+  for (int32_t i = 0; i < n; i++) {
+    r_bnum[i] = r_bcoord[i] = r_maxcp[i] = 0;
+    r_flags[i] = 0;
+    Group* g = e->get(gidx[i]);
+    if (!g) {
+      status[i] = GPX_S_NOGROUP;
+      e->counters[2]++;
+      continue;
+    }
+    if (g->paxosState.stopped) {
+      status[i] = GPX_S_STOPPED;
+      e->counters[2]++;
+      continue;
+    }
+    Accepted accept{Ballot{bnum[i], bcoord[i]}, slot[i], a_flags && (a_flags[i] & GPX_A_STOP)};
+    /* :1122 PValuePacket prev = paxosState.getAccept(accept.slot) — BEFORE accepting */
+    bool havePrev = false;
+    Ballot prevBallot;
+    auto pit = g->paxosState.acceptedProposals.find(accept.slot);
+    if (pit != g->paxosState.acceptedProposals.end()) {
+      havePrev = true;
+      prevBallot = pit->second.ballot;
+    }
+    Ballot ballot;
+    bool stored = false;
+    g->paxosState.acceptAndUpdateBallot(accept, median_cp[i], &ballot, &stored);
+    /* :1139-1143 reply(myID, ballot, slot, getSlot()-1) — GC_MAJORITY_EXECUTED */
+    r_bnum[i] = ballot.num;
+    r_bcoord[i] = ballot.coord;
+    r_maxcp[i] = jsub(g->paxosState._slot, 1);
+    /* :1146-1149 */
+    bool toLog = accept.ballot.compareTo(ballot) >= 0 &&
+                 jsub(accept.slot, g->paxosState.acceptedGCSlot) > 0 &&
+                 (!havePrev || prevBallot.compareTo(accept.ballot) < 0);
+    r_flags[i] = (uint8_t)((toLog ? GPX_R_TOLOG : 0) | (stored ? GPX_R_STORED : 0));
+    status[i] = GPX_S_OK;
+    /* :1158-1161 might release some meta-commits */
+    Decision recon;
+    if (g->paxosState.reconstructDecision(accept.slot, &recon)) {
+      ExecRun run = e->handleCommittedRequest(*g, recon);
+      if (run.count > 0) {
+        x_gidx[runs] = gidx[i];
+        x_first[runs] = run.first;
+        x_count[runs] = run.count;
+        runs++;
+      }
+    }
+  }
+  *n_runs = runs;
+  return GPX_OK;
+}
+
+/* PaxosInstanceStateMachine.java:1248-1419 handleAcceptReply (per vote) */
+int orc_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                           const int32_t* bcoord, const int32_t* slot, const int32_t* acceptor,
+                           const int32_t* max_cp, int32_t* d_gidx, int32_t* d_slot,
+                           int32_t* d_bnum, int32_t* d_bcoord, int32_t* d_median_cp,
+                           uint8_t* d_kind, int32_t* n_out, uint8_t* status) {
+  if (!h || n < 0) return GPX_EINVAL;
+  Engine* e = reinterpret_cast<Engine*>(h);
+  int32_t out = 0;
+  for (int32_t i = 0; i < n; i++) {
+    e->counters[0]++;
+    Group* g = e->get(gidx[i]);
+    if (!g) {
+      if (status) status[i] = GPX_S_NOGROUP;
+      e->counters[2]++;
+      continue;
+    }
+    if (g->paxosState.stopped) {
+      if (status) status[i] = GPX_S_STOPPED;
+      e->counters[2]++;
+      continue;
+    }
+    if (status) status[i] = GPX_S_OK;
+    /* PaxosCoordinator.handleAcceptReply, PaxosCoordinator.java:210-250 */
+    PaxosCoordinatorState* c = g->coordinator.get();
+    if (c && c->active) {
+      Ballot rb{bnum[i], bcoord[i]};
+      int cmp = rb.compareTo(c->myBallot);
+      if (cmp > 0) {
+        if (c->handleAcceptReplyHigherBallot(slot[i])) {
+          d_gidx[out] = gidx[i];
+          d_slot[out] = slot[i];
+          d_bnum[out] = c->myBallot.num; /* preempted pvalue keeps MY ballot */
+          d_bcoord[out] = c->myBallot.coord;
+          d_median_cp[out] = -1; /* PValuePacket.medianCheckpointedSlot default, :80 */
+          d_kind[out] = GPX_D_PREEMPTED;
+          out++;
+        }
+      } else if (cmp == 0) {
+        int32_t median = 0;
+        if (c->handleAcceptReplyMyBallot(g->members, slot[i], acceptor[i], max_cp[i], &median)) {
+          d_gidx[out] = gidx[i];
+          d_slot[out] = slot[i];
+          d_bnum[out] = c->myBallot.num;
+          d_bcoord[out] = c->myBallot.coord;
+          d_median_cp[out] = median;
+          d_kind[out] = GPX_D_DECISION;
+          out++;
+          e->counters[1]++;
+        }
+      }
+      /* PISM:1361-1364 + PaxosCoordinator.java:110-115 nullifyCoordinatorIfPreemptedFully */
+      if (cmp > 0 && c->preemptedFully()) g->coordinator.reset();
+    }
+  }
+  *n_out = out;
+  return GPX_OK;
+}
+
+/* PaxosInstanceStateMachine.java:1480-1528 handleBatchedCommit (per slot) and
+ * :1432-1478 handleCommittedRequest (GPX_C_HASVALUE records) */
+int orc_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                     const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                     const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx, int32_t* x_first,
+                     int32_t* x_count, int32_t* n_runs) {
+  if (!h || n < 0) return GPX_EINVAL;
+  Engine* e = reinterpret_cast<Engine*>(h);
+  int32_t runs = 0;
+  for (int32_t i = 0; i < n; i++) {
+    Group* g = e->get(gidx[i]);
+    if (!g) {
+      status[i] = GPX_S_NOGROUP;
+      e->counters[2]++;
+      continue;
+    }
+    if (g->paxosState.stopped) {
+      status[i] = GPX_S_STOPPED;
+      e->counters[2]++;
+      continue;
+    }
+    status[i] = GPX_S_OK;
+    Ballot b{bnum[i], bcoord[i]};
+    uint8_t kind = c_kind ? c_kind[i] : 0;
+    Decision d;
+    if (kind & GPX_C_HASVALUE) {
+      d = Decision{b, slot[i], median_cp[i], true, (kind & GPX_C_STOP) != 0};
+    } else {
+      /* :1488-1524 */
+      auto a = g->paxosState.acceptedProposals.find(slot[i]);
+      if (a != g->paxosState.acceptedProposals.end() && a->second.ballot.equals(b))
+        d = Decision{a->second.ballot, slot[i], median_cp[i], true, a->second.stop};
+      else
+        d = Decision{b, slot[i], median_cp[i], false, false}; /* placeholder */
+    }
+    ExecRun run = e->handleCommittedRequest(*g, d);
+    if (run.count > 0) {
+      x_gidx[runs] = gidx[i];
+      x_first[runs] = run.first;
+      x_count[runs] = run.count;
+      runs++;
+    }
+  }
+  *n_runs = runs;
+  return GPX_OK;
+}
+
+/* ---- small pure functions exported for the known-answer tests ---------------- */
+
+/* Ballot.compareTo sign: -1/0/1 */
+int orc_ballot_compare(int32_t n1, int32_t c1, int32_t n2, int32_t c2) {
+  int r = Ballot{n1, c1}.compareTo(Ballot{n2, c2});
+  return r < 0 ? -1 : (r > 0 ? 1 : 0);
+}
+
+/* WaitforUtility driven as in WaitforUtility.main: feed nodes in order; out[i] =
+ * (changed << 1) | majority after node i. */
+int orc_waitfor_trace(const int32_t* members, int32_t k, const int32_t* nodes, int32_t n,
+                      uint8_t* out) {
+  std::vector<int32_t> m(members, members + k);
+  WaitforUtility w(&m);
+  for (int32_t i = 0; i < n; i++) {
+    bool ch = w.updateHeardFrom(nodes[i]);
+    out[i] = (uint8_t)((ch ? 2 : 0) | (w.heardFromMajority() ? 1 : 0));
+  }
+  return w.heardCount;
+}
+
+/* PaxosCoordinatorState.getMedianMinus */
+int32_t orc_median_minus(const int32_t* a, int32_t k) {
+  PaxosCoordinatorState c;
+  c.nodeSlotNumbers.assign(a, a + k);
+  return c.getMedianMinus();
+}
+
+/* PISM.roundRobinCoordinator (PaxosInstanceStateMachine.java:2251-2256) with Java
+ * String.hashCode (s[0]*31^(n-1)+...) over ISO-8859-1/ASCII bytes and Java
+ * Math.abs / % semantics.  Returns the member, or INT32_MIN if Java would throw
+ * (negative index when ballotnum + hash == Integer.MIN_VALUE). */
+int32_t orc_round_robin_coordinator(const char* paxos_id, const int32_t* members, int32_t k,
+                                    int32_t ballotnum) {
+  uint32_t hsh = 0;
+  for (const unsigned char* p = (const unsigned char*)paxos_id; *p; ++p) hsh = 31u * hsh + *p;
+  int32_t x = (int32_t)((uint32_t)ballotnum + hsh);
+  int32_t ax = x < 0 ? (int32_t)(0u - (uint32_t)x) : x; /* Math.abs(MIN_VALUE) == MIN_VALUE */
+  int32_t idx = ax % k; /* sign follows dividend, like Java */
+  if (idx < 0) return INT32_MIN;
+  return members[idx];
+}
+
+} /* extern "C" */

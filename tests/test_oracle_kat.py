@@ -1,0 +1,381 @@
+"""Pins the CPU oracle against every known-answer / property assertion the reference's own
+self-tests hold for this path.  The reference has no golden-vector files and
+cannot be run here (no JVM), so these restated assertions are the pinning there is.
+
+Each test names the reference self-test it restates.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from gigapaxos_amd import (Engine, hri_create, hri_initial, make_hri, S_OK, S_FORWARD, S_REFUSED,
+                           S_STOPPED, S_NOGROUP, S_EXISTS, S_BUSY, D_DECISION, D_PREEMPTED, R_TOLOG,
+                           R_STORED, A_STOP, C_HASVALUE, RETIRE_PAUSE, RETIRE_KILL)
+from gigapaxos_amd.loopback import LoopbackCluster
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_waitfor_main_known_answer(oracle_lib):
+    """WaitforUtility.main (paxosutil/WaitforUtility.java:145-161): members {0,9,4,23};
+    9 -> changed, no majority; 23 -> changed, no majority; 0 -> changed, majority."""
+    members = np.array([0, 9, 4, 23], np.int32)
+    nodes = np.array([9, 23, 0], np.int32)
+    out = np.zeros(3, np.uint8)
+    heard = oracle_lib.lib.orc_waitfor_trace(_p(members), 4, _p(nodes), 3, _p(out))
+    assert out.tolist() == [2, 2, 3]
+    assert heard == 3
+    # !contains(32): a non-member is silently ignored; duplicates are idempotent
+    nodes = np.array([32, 9, 9, 4], np.int32)
+    out = np.zeros(4, np.uint8)
+    heard = oracle_lib.lib.orc_waitfor_trace(_p(members), 4, _p(nodes), 4, _p(out))
+    assert out.tolist() == [0, 2, 0, 2] and heard == 2
+
+
+def test_ballot_compare_wraparound(oracle_lib):
+    """Ballot.compareTo (paxosutil/Ballot.java:60-73) incl. the int-subtraction wraparound."""
+    f = oracle_lib.lib.orc_ballot_compare
+    assert f(1, 5, 1, 5) == 0
+    assert f(2, 0, 1, 9) == 1
+    assert f(1, 4, 1, 9) == -1
+    # wraparound: MIN_VALUE is "after" MAX_VALUE
+    assert f(-2147483648, 0, 2147483647, 0) == 1
+    assert f(2147483647, 0, -2147483648, 0) == -1
+    # PaxosPacketBatcher.main (PaxosPacketBatcher.java:556-567): Ballot(23,456) equals itself
+    assert f(23, 456, 23, 456) == 0
+
+
+def test_median_minus(oracle_lib):
+    """PaxosCoordinatorState.getMedianMinus (PaxosCoordinatorState.java:867-875)."""
+    f = oracle_lib.lib.orc_median_minus
+
+    def med(xs):
+        a = np.array(xs, np.int32)
+        return f(_p(a), len(xs))
+
+    assert med([5]) == 5
+    assert med([3, 1, 2]) == 2  # odd: index k/2
+    assert med([4, 1, 3, 2]) == 2  # even: index k/2-1
+    assert med([0, 0, 0]) == 0
+    assert med([-1, 7, 7, -1, 3]) == 3
+    rng = np.random.default_rng(1)
+    for k in range(1, 17):
+        xs = rng.integers(-50, 50, k).astype(np.int32)
+        idx = k // 2 - 1 if k % 2 == 0 else k // 2
+        assert med(xs.tolist()) == np.sort(xs)[idx]
+
+
+def _java_string_hash(s: str) -> int:
+    h = 0
+    for ch in s.encode("latin-1"):
+        h = (31 * h + ch) & 0xFFFFFFFF
+    return h - (1 << 32) if h >= (1 << 31) else h
+
+
+def test_round_robin_coordinator(oracle_lib):
+    """PISM.roundRobinCoordinator (PaxosInstanceStateMachine.java:2251-2256) with Java
+    String.hashCode: "hello".hashCode() == 99162322 is the well-known Java value."""
+    assert _java_string_hash("hello") == 99162322
+    f = oracle_lib.lib.orc_round_robin_coordinator
+    members = np.array([100, 101, 102], np.int32)
+    assert f(b"hello", _p(members), 3, 0) == members[99162322 % 3]
+    for name in ["paxos0", "TESTPaxosApp17", "a", "zzzzzzzzzzzzzzzz", "service_name_42"]:
+        for b in (0, 1, 7):
+            x = (_java_string_hash(name) + b + (1 << 31)) % (1 << 32) - (1 << 31)
+            ax = -x if x < 0 else x
+            if ax >= (1 << 31):  # Math.abs(MIN_VALUE)
+                continue
+            assert f(name.encode(), _p(members), 3, b) == members[ax % 3]
+
+
+def _mk(oracle_lib, my_id, members, n_groups=1, window=64, rows=None):
+    k = len(members)
+    e = Engine(oracle_lib, my_id, n_groups, kmax=k, window=window)
+    mem = np.tile(np.array(members, np.int32), (n_groups, 1))
+    if rows is None:
+        rows = hri_create(n_groups, k, my_id)
+    st = e.create_groups(np.arange(n_groups), mem, k, rows)
+    assert (st == S_OK).all()
+    return e
+
+
+def test_pcs_main_accept_reply_section(oracle_lib):
+    """PaxosCoordinatorState.main, "Testing accept replies" (PaxosCoordinatorState.java:
+    1166-1212): the reference uses 43 members; the ABI caps groups at PC.MAX_GROUP_SIZE = 16
+    (PaxosConfig.java:532), so 15 here.  For each outstanding proposal feed a reply from every
+    member, a few % of them with a higher ballot.  Assertions restated: a returned pvalue is a DECISION (my ballot)
+    or PREEMPTED (higher ballot); the slot is gone from myProposals afterwards; DECISION only
+    after a majority; myProposals ends empty (or the coordinator resigned)."""
+    rng = np.random.default_rng(7)
+    members = [21]
+    for _ in range(14):
+        members.append(members[-1] + 1 + int(rng.integers(0, 10)))
+    rows = make_hri(1)
+    rows["acc_bnum"] = 2
+    rows["acc_bcoord"] = 21
+    rows["has_coord"] = 1
+    rows["coord_bnum"] = 2
+    rows["coord_bcoord"] = 21
+    rows["node_slots"][:] = -1
+    e = _mk(oracle_lib, 21, members, rows=rows)
+    nprop = 9
+    slot, bnum, bcoord, median, st = e.propose(np.zeros(nprop, np.int32))
+    assert (st == S_OK).all() and slot.tolist() == list(range(nprop))
+    assert (bnum == 2).all() and (bcoord == 21).all() and (median == -1).all()
+    resigned = False
+    for s in range(nprop):
+        heard = 0
+        done = False
+        for m in members:
+            higher = rng.random() > 0.96
+            d = e.accept_reply([0], [3 if higher else 2], [21], [s], [m], [-1])
+            if resigned:
+                assert d.gidx.shape[0] == 0
+                continue
+            if higher:
+                if not done:
+                    assert d.kind.tolist() == [D_PREEMPTED]
+                    done = True
+                else:
+                    assert d.gidx.shape[0] == 0
+            else:
+                heard += 1
+                if not done and heard > len(members) // 2:
+                    assert d.kind.tolist() == [D_DECISION] and d.slot.tolist() == [s]
+                    assert d.bnum.tolist() == [2] and d.bcoord.tolist() == [21]
+                    done = True
+                else:
+                    assert d.gidx.shape[0] == 0
+            dump = e.dump(0)
+            has_coord = _parse_dump(dump)["coord"] is not None
+            if not has_coord:
+                resigned = True
+    st = _parse_dump(e.dump(0))
+    assert st["coord"] is None or st["coord"]["proposals"] == []
+
+
+def _parse_dump(w):
+    w = list(map(int, w))
+    i = 0
+    out = {}
+    exists = w[i]; i += 1
+    if not exists:
+        return None
+    out["version"] = w[i]; i += 1
+    k = w[i]; i += 1
+    out["members"] = w[i:i + k]; i += k
+    out["acc"] = dict(slot=w[i], bnum=w[i + 1], bcoord=w[i + 2], gc=w[i + 3], stopped=w[i + 4]); i += 5
+    na = w[i]; i += 1
+    out["accepted"] = [tuple(w[i + 4 * j:i + 4 * j + 4]) for j in range(na)]; i += 4 * na
+    nc = w[i]; i += 1
+    out["committed"] = [tuple(w[i + 6 * j:i + 6 * j + 6]) for j in range(nc)]; i += 6 * nc
+    hc = w[i]; i += 1
+    out["coord"] = None
+    if hc:
+        c = dict(bnum=w[i], bcoord=w[i + 1], next=w[i + 2]); i += 3
+        c["node_slots"] = w[i:i + k]; i += k
+        npn = w[i]; i += 1
+        c["proposals"] = [tuple(w[i + 3 * j:i + 3 * j + 3]) for j in range(npn)]; i += 3 * npn
+        out["coord"] = c
+    assert i == len(w)
+    return out
+
+
+def test_acceptor_monotone_ballot_property(oracle_lib):
+    """PaxosAcceptor.testAcceptor (PaxosAcceptor.java:749-776): acceptor(22:1, slot 7);
+    100k random accepts: response ballot >= request ballot and >= previous ballot."""
+    rows = make_hri(1)
+    rows["acc_slot"] = 7
+    rows["acc_bnum"] = 22
+    rows["acc_bcoord"] = 1
+    rows["acc_gc_slot"] = -1
+    e = _mk(oracle_lib, 9, [9, 10, 11], rows=rows)
+    rng = np.random.default_rng(3)
+    n = 100000
+    bnum = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+    bcoord = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+    slot = rng.integers(0, 2**31 - 1, n).astype(np.int32)
+    (rb, rc, rmax, rfl, st), runs = e.accept(np.zeros(n, np.int32), bnum, bcoord, slot,
+                                             np.full(n, -1, np.int32))
+    assert (st == S_OK).all()
+    f = oracle_lib.lib.orc_ballot_compare
+    prev = (22, 1)
+    for i in range(0, n, 97):  # sample (python loop)
+        assert f(int(rb[i]), int(rc[i]), int(bnum[i]), int(bcoord[i])) >= 0
+    # monotone over the whole stream
+    r64 = rb.astype(np.int64) * (1 << 32) + rc.astype(np.int64)
+    assert (np.diff(r64) >= 0).all()
+    assert r64[0] >= 22 * (1 << 32) + 1
+    assert runs.gidx.shape[0] == 0
+
+
+def test_hri_roundtrip(oracle_lib):
+    """HotRestoreInfoTest.testToStringAndBack (HotRestoreInfo.java:159-175) restated on the
+    binary row: create from a row, pause, get the identical row back.
+    members {1,4,67}, accSlot 5, accBallot 3:4, gc 3, coordBallot 45:67, next 34, nodeSlots {1,3,5}."""
+    rows = make_hri(1)
+    rows["version"] = 2
+    rows["acc_slot"] = 5
+    rows["acc_bnum"] = 3
+    rows["acc_bcoord"] = 4
+    rows["acc_gc_slot"] = 3
+    rows["has_coord"] = 1
+    rows["coord_bnum"] = 45
+    rows["coord_bcoord"] = 67
+    rows["next_proposal_slot"] = 34
+    rows["node_slots"][0, :3] = [1, 3, 5]
+    e = _mk(oracle_lib, 67, [1, 4, 67], rows=rows)
+    snap, st = e.snapshot([0])
+    assert st.tolist() == [S_OK]
+    assert snap.tobytes() == rows.tobytes()
+    back, st = e.retire_groups([0], RETIRE_PAUSE)
+    assert st.tolist() == [S_OK]
+    assert back.tobytes() == rows.tobytes()
+    # gone now
+    _, st = e.snapshot([0])
+    assert st.tolist() == [S_NOGROUP]
+    # a node that is not the coordinator restores no coordinator (PISM:682-684)
+    e2 = _mk(oracle_lib, 4, [1, 4, 67], rows=rows)
+    snap, _ = e2.snapshot([0])
+    assert snap["has_coord"][0] == 0 and snap["next_proposal_slot"][0] == -1
+
+
+def test_accept_tolog_and_gc_rules(oracle_lib):
+    """handleAccept's toLog rule (PaxosInstanceStateMachine.java:1146-1149) and
+    acceptAndUpdateBallot / garbageCollectAccepted (PaxosAcceptor.java:302-322, 476-494)."""
+    e = _mk(oracle_lib, 101, [100, 101, 102], rows=hri_create(1, 3, 100))
+    z = np.zeros(1, np.int32)
+    # fresh accept at current ballot: stored + logged; reply maxcp = slot-1 = 0
+    (rb, rc, rmax, rfl, st), _ = e.accept(z, [0], [100], [1], [0])
+    assert (rb[0], rc[0], rmax[0], rfl[0]) == (0, 100, 0, R_TOLOG | R_STORED)
+    # same accept again: stored (put) but NOT logged (prev.ballot == ballot)
+    (_, _, _, rfl, _), _ = e.accept(z, [0], [100], [1], [0])
+    assert rfl[0] == R_STORED
+    # lower ballot: NACK with current ballot, nothing stored/logged
+    (rb, rc, _, rfl, _), _ = e.accept(z, [0], [99], [2], [0])
+    assert (rb[0], rc[0], rfl[0]) == (0, 100, 0)
+    # higher ballot: adopted
+    (rb, rc, _, rfl, _), _ = e.accept(z, [1], [102], [1], [0])
+    assert (rb[0], rc[0], rfl[0]) == (1, 102, R_TOLOG | R_STORED)
+    d = _parse_dump(e.dump(0))
+    assert d["acc"] == dict(slot=1, bnum=1, bcoord=102, gc=0, stopped=0)
+    assert d["accepted"] == [(1, 1, 102, 0)]
+    # slot <= gcSlot: not stored, not logged
+    (_, _, _, rfl, _), _ = e.accept(z, [1], [102], [0], [0])
+    assert rfl[0] == 0
+
+
+def test_batched_commit_placeholder_then_accept(oracle_lib):
+    """a BATCHED_COMMIT slot without a matching stored ACCEPT queues a value-less
+    placeholder; execution stalls until the ACCEPT arrives (PISM:1492, 1158-1161;
+    PaxosAcceptor.java:369-385)."""
+    e = _mk(oracle_lib, 101, [100, 101, 102], rows=hri_create(1, 3, 100))
+    z = np.zeros(1, np.int32)
+    st, runs = e.commit(z, [0], [100], [1], [0])
+    assert st.tolist() == [S_OK] and runs.gidx.shape[0] == 0
+    d = _parse_dump(e.dump(0))
+    assert d["committed"] == [(1, 0, 100, 0, 0, 0)]
+    # commit for slot 2 with a stored accept: still stalls behind slot 1
+    e.accept(z, [0], [100], [2], [0])
+    st, runs = e.commit(z, [0], [100], [2], [0])
+    assert runs.gidx.shape[0] == 0
+    # the accept for slot 1 arrives: releases 1 and 2 in one run
+    (_, _, rmax, _, _), runs = e.accept(z, [0], [100], [1], [0])
+    assert rmax.tolist() == [0]  # reply is built BEFORE the release
+    assert runs.as_tuple_array().tolist() == [[0, 1, 2]]
+    d = _parse_dump(e.dump(0))
+    assert d["acc"]["slot"] == 3 and d["committed"] == [] and d["accepted"] == []
+    # mismatching ballot: placeholder, not executed
+    e.accept(z, [0], [100], [3], [0])
+    st, runs = e.commit(z, [1], [102], [3], [0])
+    assert runs.gidx.shape[0] == 0
+    assert _parse_dump(e.dump(0))["committed"] == [(3, 1, 102, 0, 0, 0)]
+    # a full DECISION (value at host) for the same slot overrides the placeholder
+    st, runs = e.commit(z, [1], [102], [3], [0], [C_HASVALUE])
+    assert runs.as_tuple_array().tolist() == [[0, 3, 1]]
+
+
+def test_stop_request_semantics(oracle_lib):
+    """Stop: no proposal after a stop (PaxosCoordinatorState.java:235-239); executing a stop
+    stops the acceptor and clears committedRequests (PaxosAcceptor.java:462-474); later packets
+    are dropped (PaxosInstanceStateMachine.java:456-460)."""
+    c = LoopbackCluster(oracle_lib, [100, 101, 102], 2, window=16)
+    c.round([0, 1])
+    c.round([0, 1], is_stop=[1, 0])
+    slot, _, _, _, st = c.engines[100].propose([0, 1])
+    assert st.tolist() == [S_STOPPED, S_OK]
+    for nid in (100, 101, 102):
+        d = _parse_dump(c.engines[nid].dump(0))
+        assert d["acc"]["stopped"] == 1 and d["acc"]["slot"] == 3
+        st, _ = c.engines[nid].commit([0], [0], [100], [5], [0])
+        assert st.tolist() == [S_STOPPED]
+    # refused: stop proposed but not yet decided
+    e = _mk(oracle_lib, 100, [100, 101, 102])
+    e.propose([0], [1])
+    _, _, _, _, st = e.propose([0])
+    assert st.tolist() == [S_REFUSED]
+
+
+def test_preemption_and_resignation(oracle_lib):
+    """higher-ballot reply removes just that slot; the coordinator object is dropped
+    only when myProposals is then empty; lower-ballot replies are ignored; late votes still
+    update nodeSlotNumbers (§9.6)."""
+    e = _mk(oracle_lib, 100, [100, 101, 102])
+    e.propose([0, 0])  # slots 1, 2
+    d = e.accept_reply([0], [1], [101], [1], [101], [0])
+    assert d.as_tuple_array().tolist() == [[0, 1, 0, 100, -1, D_PREEMPTED]]
+    assert _parse_dump(e.dump(0))["coord"] is not None
+    # lower ballot ignored with no side effect
+    before = e.dump(0).tolist()
+    d = e.accept_reply([0], [0], [99], [2], [101], [5])
+    assert d.gidx.shape[0] == 0 and e.dump(0).tolist() == before
+    # two votes decide slot 2; third (late) vote only bumps nodeSlots
+    d = e.accept_reply([0, 0, 0], [0] * 3, [100] * 3, [2] * 3, [100, 101, 102], [1, 1, 7])
+    assert d.as_tuple_array().tolist() == [[0, 2, 0, 100, 1, D_DECISION]]
+    st = _parse_dump(e.dump(0))
+    assert st["coord"]["node_slots"] == [1, 1, 7] and st["coord"]["proposals"] == []
+    # higher ballot with nothing outstanding: coordinator resigns even though nothing preempted
+    d = e.accept_reply([0], [1], [101], [9], [101], [0])
+    assert d.gidx.shape[0] == 0
+    assert _parse_dump(e.dump(0))["coord"] is None
+    # afterwards proposals are forwarded to the acceptor's ballot coordinator
+    _, bnum, bcoord, _, st = e.propose([0])
+    assert st.tolist() == [S_FORWARD] and bcoord.tolist() == [100]
+
+
+def test_config1_loopback_one_group(oracle_lib):
+    """BASELINE config #1 semantics (tests/loopback_1_group: nodes 100..102, 1 group,
+    NUM_REQUESTS=10000): every replica executes slots 1..10000 in order, identical streams —
+    the TESTPaxosApp invariant `state.seqnum == requestPacket.slot` (TESTPaxosApp.java:190)."""
+    c = LoopbackCluster(oracle_lib, [100, 101, 102], 1, window=8)
+    n = 10000
+    for r in range(n):
+        dec = c.round([0])
+        assert dec.tolist() == [[0, r + 1, 0, 100, max(r - 0, 0) if r == 0 else dec[0, 4], D_DECISION]]
+    ref = None
+    for nid in (100, 101, 102):
+        ex = c.executed(nid)
+        slots = np.concatenate([np.arange(f, f + cnt) for _, f, cnt in ex])
+        assert slots.tolist() == list(range(1, n + 1))
+        ref = slots if ref is None else ref
+        assert (slots == ref).all()
+    # medians are monotone and trail the slot
+    med = np.concatenate(c.decision_log)[:, 4]
+    assert (np.diff(med) >= 0).all() and med[-1] == n - 1
+
+
+def test_lifecycle_statuses(oracle_lib):
+    e = Engine(oracle_lib, 100, 4, kmax=3, window=8)
+    mem = np.tile(np.array([100, 101, 102], np.int32), (2, 1))
+    assert e.create_groups([0, 7], mem, 3, hri_create(2, 3, 100)).tolist() == [S_OK, S_NOGROUP]
+    assert e.create_groups([0], mem[:1], 3, hri_create(1, 3, 100)).tolist() == [S_EXISTS]
+    e.propose([0])
+    _, st = e.retire_groups([0, 1], RETIRE_PAUSE)
+    assert st.tolist() == [S_BUSY, S_NOGROUP]
+    _, st = e.retire_groups([0], RETIRE_KILL)
+    assert st.tolist() == [S_OK]
+    d = e.accept_reply([0, -1, 9], [0] * 3, [100] * 3, [1] * 3, [100] * 3, [0] * 3)
+    assert d.status.tolist() == [S_NOGROUP] * 3
