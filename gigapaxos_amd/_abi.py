@@ -304,6 +304,26 @@ class Engine:
     def sync(self):
         self.lib.check(self.lib.fn["engine_sync"](self.h), "engine_sync")
 
+    # -- device-pointer path (batches already resident in HBM) ----------------------
+    def set_stream(self, hip_stream_handle: int):
+        """Run the *_dev calls on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
+        self.lib.check(self.lib.fn["engine_set_stream"](self.h, _VP(hip_stream_handle or None)),
+                       "engine_set_stream")
+
+    def call_dev(self, name: str, n: int, *ptrs):
+        """Raw asynchronous call of gpx_<name>_dev with integer device addresses (0 = NULL)."""
+        args = [_VP(int(p)) if p else None for p in ptrs]
+        self.lib.check(self.lib.fn[name + "_dev"](self.h, int(n), *args), name + "_dev")
+
+    def profile(self, enable: int):
+        """0 = off, 1 = on, 2 = on + reset accumulated stats."""
+        self.lib.check(self.lib.fn["profile_enable"](self.h, int(enable)), "profile_enable")
+
+    def profile_read(self):
+        buf = (GpxKernelStat * 32)()
+        nk = self.lib.check(self.lib.fn["profile_read"](self.h, buf, 32), "profile_read")
+        return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(nk, 32))}
+
     # -- data path ---------------------------------------------------------------
     def propose(self, gidx, is_stop=None):
         """PISM.handleRequest/handleProposal for a batch of (already batched) requests."""

@@ -1,0 +1,751 @@
+/*
+ * gpx_engine.hip — host side of libgpx_hip.so: device-resident group state, batch
+ * sequencing on a HIP stream and the extern "C" entry points of include/gpx.h.
+ *
+ * Build (gfx950 only, no other target, no compatibility paths):
+ *   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o libgpx_hip.so gpx_engine.hip
+ */
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+#include <algorithm>
+
+#include "gpx_kernels.hip.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+
+#define HIPCHK(expr)                                                                      \
+  do {                                                                                    \
+    hipError_t _e = (expr);                                                               \
+    if (_e != hipSuccess) {                                                               \
+      snprintf(g_err, sizeof(g_err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,         \
+               hipGetErrorString(_e));                                                    \
+      return GPX_EDEVICE;                                                                 \
+    }                                                                                     \
+  } while (0)
+
+struct PendingEvent {
+  const char* name;
+  hipEvent_t start, stop;
+};
+
+}  // namespace
+
+struct gpx_engine {
+  gpx_config cfg;
+  int device = 0;
+  DevState S{};
+  DevScratch X{};
+  hipStream_t own_stream = nullptr;
+  hipStream_t stream = nullptr;
+  std::vector<void*> allocs;
+  /* device staging for the host-pointer entry points */
+  int32_t* st_i32[12] = {};
+  uint8_t* st_u8[4] = {};
+  int32_t* st_count = nullptr;
+  /* profiling */
+  bool profiling = false;
+  std::vector<PendingEvent> pending;
+  std::map<std::string, std::pair<uint64_t, double>> prof;
+  int32_t biglist_cap = 0;
+  int32_t nb_max = 0;
+};
+
+namespace {
+
+template <typename T>
+int dev_alloc(gpx_engine* e, T** p, size_t count, bool zero) {
+  void* q = nullptr;
+  size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  hipError_t err = hipMalloc(&q, bytes);
+  if (err != hipSuccess) {
+    snprintf(g_err, sizeof(g_err), "hipMalloc(%zu) -> %s", bytes, hipGetErrorString(err));
+    return GPX_ENOMEM;
+  }
+  e->allocs.push_back(q);
+  if (zero) {
+    err = hipMemset(q, 0, bytes);
+    if (err != hipSuccess) {
+      snprintf(g_err, sizeof(g_err), "hipMemset -> %s", hipGetErrorString(err));
+      return GPX_EDEVICE;
+    }
+  }
+  *p = (T*)q;
+  return GPX_OK;
+}
+
+inline int grid_for(int64_t n) { return (int)((n + GPX_BLOCK - 1) / GPX_BLOCK); }
+inline int tiles_for(int64_t n) { return (int)((n + GPX_SCAN_TILE - 1) / GPX_SCAN_TILE); }
+
+/* brackets a launch with events when profiling is on */
+struct LaunchScope {
+  gpx_engine* e;
+  PendingEvent pe{};
+  bool on;
+  LaunchScope(gpx_engine* e_, const char* name) : e(e_), on(e_->profiling) {
+    if (on) {
+      pe.name = name;
+      hipEventCreate(&pe.start);
+      hipEventCreate(&pe.stop);
+      hipEventRecord(pe.start, e->stream);
+    }
+  }
+  ~LaunchScope() {
+    if (on) {
+      hipEventRecord(pe.stop, e->stream);
+      e->pending.push_back(pe);
+    }
+  }
+};
+
+int flush_profile(gpx_engine* e) {
+  if (e->pending.empty()) return GPX_OK;
+  HIPCHK(hipStreamSynchronize(e->stream));
+  for (auto& pe : e->pending) {
+    float ms = 0.f;
+    hipEventElapsedTime(&ms, pe.start, pe.stop);
+    auto& slot = e->prof[pe.name];
+    slot.first += 1;
+    slot.second += ms;
+    hipEventDestroy(pe.start);
+    hipEventDestroy(pe.stop);
+  }
+  e->pending.clear();
+  return GPX_OK;
+}
+
+#define LAUNCH(e, name, kernel, grid, ...)                                        \
+  do {                                                                            \
+    LaunchScope _ls(e, name);                                                     \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(GPX_BLOCK), 0, (e)->stream, __VA_ARGS__); \
+  } while (0)
+
+/* exclusive scan of cnt[0..G) -> offs; long segments -> biglist */
+void scan_groups(gpx_engine* e) {
+  const int nb = tiles_for(e->cfg.max_groups);
+  LAUNCH(e, "k_scan_reduce_cnt", (k_scan_reduce<0>), nb, (const void*)e->X.cnt, e->cfg.max_groups,
+         e->X.blocksum);
+  LAUNCH(e, "k_scan_top", k_scan_top, 1, e->X.blocksum, nb, (int32_t*)nullptr,
+         (unsigned long long*)nullptr);
+  LAUNCH(e, "k_scan_down_offs", k_scan_down_offs, nb, (const int32_t*)e->X.cnt, e->cfg.max_groups,
+         (const int32_t*)e->X.blocksum, e->X.offs, e->X.biglist, e->biglist_cap);
+}
+
+void sort_big(gpx_engine* e) {
+  LAUNCH(e, "k_sort_big", k_sort_big, 64, (const int32_t*)e->X.biglist, (const int32_t*)e->X.cnt,
+         (const int32_t*)e->X.offs, (const int4*)e->X.seg_a, e->X.ord);
+}
+
+/* scan of the per-record output flags; total -> n_out (device) */
+void scan_outputs(gpx_engine* e, int32_t n, int32_t* n_out_dev, unsigned long long* acc = nullptr) {
+  const int nb = tiles_for(n);
+  LAUNCH(e, "k_scan_reduce_out", (k_scan_reduce<1>), nb, (const void*)e->X.o_kind, n,
+         e->X.blocksum);
+  LAUNCH(e, "k_scan_top", k_scan_top, 1, e->X.blocksum, nb, n_out_dev, acc);
+}
+
+int check_batch(gpx_engine* h, int32_t n) {
+  if (!h || n < 0) return GPX_EINVAL;
+  if (n > h->cfg.max_batch) return GPX_ECAPACITY;
+  return GPX_OK;
+}
+
+template <int KMAX>
+void launch_apply_ar(gpx_engine* e, uint8_t* status) {
+  LAUNCH(e, "k_apply_ar", (k_apply_ar<KMAX>), grid_for(e->cfg.max_groups), e->S, e->X, status);
+}
+template <int KMAX>
+void launch_apply_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t* bcoord,
+                          int32_t* median, uint8_t* status) {
+  LAUNCH(e, "k_apply_propose", (k_apply_propose<KMAX>), grid_for(e->cfg.max_groups), e->S, e->X,
+         slot, bnum, bcoord, median, status);
+}
+
+}  // namespace
+
+extern "C" {
+
+int gpx_abi_version(void) { return GPX_ABI_VERSION; }
+const char* gpx_last_error(void) { return g_err; }
+
+int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
+  g_err[0] = 0;
+  if (!cfg || !out) return GPX_EINVAL;
+  if (cfg->max_groups <= 0 || cfg->kmax < 1 || cfg->kmax > GPX_KMAX_LIMIT || cfg->max_batch <= 0)
+    return GPX_EINVAL;
+  if (cfg->window < 4 || cfg->window > 64 || (cfg->window & (cfg->window - 1))) return GPX_EINVAL;
+  int ndev = 0;
+  HIPCHK(hipGetDeviceCount(&ndev));
+  if (ndev <= 0) {
+    snprintf(g_err, sizeof(g_err), "no HIP device visible");
+    return GPX_EDEVICE;
+  }
+  gpx_engine* e = new gpx_engine();
+  e->cfg = *cfg;
+  if (cfg->device >= 0) {
+    HIPCHK(hipSetDevice(cfg->device));
+    e->device = cfg->device;
+  } else {
+    HIPCHK(hipGetDevice(&e->device));
+  }
+  HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
+  e->stream = e->own_stream;
+  const size_t G = (size_t)cfg->max_groups, W = (size_t)cfg->window, K = (size_t)cfg->kmax;
+  const size_t N = (size_t)cfg->max_batch;
+  DevState& S = e->S;
+  S.G = cfg->max_groups;
+  S.kmax = cfg->kmax;
+  S.W = cfg->window;
+  S.my_id = cfg->my_id;
+  S.flags = cfg->flags;
+  int rc = GPX_OK;
+#define A(ptr, count, zero)                                   \
+  if ((rc = dev_alloc(e, &(ptr), (count), (zero))) != GPX_OK) { \
+    gpx_engine_destroy(e);                                    \
+    return rc;                                                \
+  }
+  A(S.g_flags, G, true);
+  A(S.g_version, G, true);
+  A(S.a_slot, G, true);
+  A(S.a_bnum, G, true);
+  A(S.a_bcoord, G, true);
+  A(S.a_gc, G, true);
+  A(S.c_bnum, G, true);
+  A(S.c_bcoord, G, true);
+  A(S.c_next, G, true);
+  A(S.c_pcount, G, true);
+  A(S.members, K * G, true);
+  A(S.node_slots, K * G, true);
+  A(S.p_ring, W * G, true);
+  A(S.acc_ring, W * G, true);
+  A(S.acc_flags, W * G, true);
+  A(S.com_ring, W * G, true);
+  A(S.com_flags, W * G, true);
+  DevScratch& X = e->X;
+  A(X.cnt, G, true);
+  A(X.offs, G, true);
+  A(X.rank, N, false);
+  A(X.seg_a, N, false);
+  A(X.seg_b, N, false);
+  A(X.o_kind, N, true);
+  A(X.o_rec, N, false);
+  e->nb_max = std::max(tiles_for((int64_t)G), tiles_for((int64_t)N)) + 1;
+  A(X.blocksum, (size_t)e->nb_max, true);
+  e->biglist_cap = (int32_t)(N / (GPX_SMALL_SEG + 1) + 1);
+  A(X.biglist, (size_t)e->biglist_cap + 1, true);
+  A(X.ord, N, false);
+  A(X.counters, 3, true);
+  for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
+  for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
+  A(e->st_count, 4, true);
+#undef A
+  HIPCHK(hipDeviceSynchronize());
+  *out = e;
+  return GPX_OK;
+}
+
+int gpx_engine_destroy(gpx_engine* h) {
+  if (!h) return GPX_EINVAL;
+  if (h->stream) hipStreamSynchronize(h->stream);
+  for (auto& pe : h->pending) {
+    hipEventDestroy(pe.start);
+    hipEventDestroy(pe.stop);
+  }
+  for (void* p : h->allocs) hipFree(p);
+  if (h->own_stream) hipStreamDestroy(h->own_stream);
+  delete h;
+  return GPX_OK;
+}
+
+int gpx_engine_set_stream(gpx_engine* h, void* hip_stream) {
+  if (!h) return GPX_EINVAL;
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return GPX_OK;
+}
+
+int gpx_engine_sync(gpx_engine* h) {
+  if (!h) return GPX_EINVAL;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return GPX_OK;
+}
+
+int gpx_engine_counters(gpx_engine* h, uint64_t out[3]) {
+  if (!h || !out) return GPX_EINVAL;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  unsigned long long tmp[3];
+  HIPCHK(hipMemcpy(tmp, h->X.counters, sizeof(tmp), hipMemcpyDeviceToHost));
+  for (int i = 0; i < 3; i++) out[i] = tmp[i];
+  return GPX_OK;
+}
+
+int gpx_profile_enable(gpx_engine* h, int32_t enable) {
+  if (!h) return GPX_EINVAL;
+  int rc = flush_profile(h);
+  if (rc != GPX_OK) return rc;
+  h->profiling = enable != 0;
+  if (enable == 2) h->prof.clear(); /* 2 = enable and reset */
+  return GPX_OK;
+}
+
+int gpx_profile_read(gpx_engine* h, gpx_kernel_stat* out, int32_t cap) {
+  if (!h) return GPX_EINVAL;
+  int rc = flush_profile(h);
+  if (rc != GPX_OK) return rc;
+  int32_t i = 0;
+  for (auto& kv : h->prof) {
+    if (i < cap && out) {
+      memset(&out[i], 0, sizeof(out[i]));
+      strncpy(out[i].name, kv.first.c_str(), sizeof(out[i].name) - 1);
+      out[i].launches = kv.second.first;
+      out[i].total_ms = kv.second.second;
+    }
+    i++;
+  }
+  return i;
+}
+
+/* ---- device-pointer data path ------------------------------------------------- */
+
+int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
+                               const int32_t* bnum, const int32_t* bcoord, const int32_t* slot,
+                               const int32_t* acceptor, const int32_t* max_cp, int32_t* d_gidx,
+                               int32_t* d_slot, int32_t* d_bnum, int32_t* d_bcoord,
+                               int32_t* d_median_cp, uint8_t* d_kind, int32_t* n_out,
+                               uint8_t* status) {
+  int rc = check_batch(h, n);
+  if (rc != GPX_OK) return rc;
+  if (n == 0) {
+    HIPCHK(hipMemsetAsync(n_out, 0, sizeof(int32_t), h->stream));
+    return GPX_OK;
+  }
+  gpx_engine* e = h;
+  LAUNCH(e, "k_count", k_count, grid_for(n), n, gidx, e->S.G, e->X.cnt, e->X.rank, e->X.o_kind,
+         status, e->X.counters, e->X.biglist, 1);
+  scan_groups(e);
+  LAUNCH(e, "k_fill_ar", k_fill_ar, grid_for(n), n, gidx, bnum, bcoord, slot, acceptor, max_cp,
+         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b);
+  sort_big(e);
+  if (e->cfg.kmax <= 4)
+    launch_apply_ar<4>(e, status);
+  else if (e->cfg.kmax <= 8)
+    launch_apply_ar<8>(e, status);
+  else
+    launch_apply_ar<16>(e, status);
+  scan_outputs(e, n, n_out, &e->X.counters[1]);
+  LAUNCH(e, "k_compact_dec", k_compact_dec, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
+         (const int4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, slot, d_gidx, d_slot, d_bnum,
+         d_bcoord, d_median_cp, d_kind);
+  HIPCHK(hipGetLastError());
+  return GPX_OK;
+}
+
+int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                         const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                         const uint8_t* a_flags, int32_t* r_bnum, int32_t* r_bcoord,
+                         int32_t* r_maxcp, uint8_t* r_flags, uint8_t* status, int32_t* x_gidx,
+                         int32_t* x_first, int32_t* x_count, int32_t* n_runs) {
+  int rc = check_batch(h, n);
+  if (rc != GPX_OK) return rc;
+  if (n == 0) {
+    HIPCHK(hipMemsetAsync(n_runs, 0, sizeof(int32_t), h->stream));
+    return GPX_OK;
+  }
+  gpx_engine* e = h;
+  LAUNCH(e, "k_count", k_count, grid_for(n), n, gidx, e->S.G, e->X.cnt, e->X.rank, e->X.o_kind,
+         status, e->X.counters, e->X.biglist, 0);
+  scan_groups(e);
+  LAUNCH(e, "k_fill_ac", k_fill_ac, grid_for(n), n, gidx, bnum, bcoord, slot, median_cp, a_flags,
+         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b);
+  sort_big(e);
+  LAUNCH(e, "k_apply_accept", k_apply_accept, grid_for(e->cfg.max_groups), e->S, e->X, r_bnum,
+         r_bcoord, r_maxcp, r_flags, status);
+  scan_outputs(e, n, n_runs);
+  LAUNCH(e, "k_compact_runs", k_compact_runs, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
+         (const int4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
+  HIPCHK(hipGetLastError());
+  return GPX_OK;
+}
+
+int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                         const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                         const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx,
+                         int32_t* x_first, int32_t* x_count, int32_t* n_runs) {
+  int rc = check_batch(h, n);
+  if (rc != GPX_OK) return rc;
+  if (n == 0) {
+    HIPCHK(hipMemsetAsync(n_runs, 0, sizeof(int32_t), h->stream));
+    return GPX_OK;
+  }
+  gpx_engine* e = h;
+  LAUNCH(e, "k_count", k_count, grid_for(n), n, gidx, e->S.G, e->X.cnt, e->X.rank, e->X.o_kind,
+         status, e->X.counters, e->X.biglist, 0);
+  scan_groups(e);
+  LAUNCH(e, "k_fill_ac", k_fill_ac, grid_for(n), n, gidx, bnum, bcoord, slot, median_cp, c_kind,
+         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b);
+  sort_big(e);
+  LAUNCH(e, "k_apply_commit", k_apply_commit, grid_for(e->cfg.max_groups), e->S, e->X, status);
+  scan_outputs(e, n, n_runs);
+  LAUNCH(e, "k_compact_runs", k_compact_runs, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
+         (const int4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
+  HIPCHK(hipGetLastError());
+  return GPX_OK;
+}
+
+int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                          int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
+                          uint8_t* status) {
+  int rc = check_batch(h, n);
+  if (rc != GPX_OK) return rc;
+  if (n == 0) return GPX_OK;
+  gpx_engine* e = h;
+  LAUNCH(e, "k_count", k_count, grid_for(n), n, gidx, e->S.G, e->X.cnt, e->X.rank, e->X.o_kind,
+         status, e->X.counters, e->X.biglist, 0);
+  scan_groups(e);
+  LAUNCH(e, "k_fill_pr", k_fill_pr, grid_for(n), n, gidx, is_stop, (const int32_t*)e->X.rank,
+         (const int32_t*)e->X.offs, e->X.seg_a);
+  sort_big(e);
+  if (e->cfg.kmax <= 4)
+    launch_apply_propose<4>(e, slot, bnum, bcoord, median_cp, status);
+  else if (e->cfg.kmax <= 8)
+    launch_apply_propose<8>(e, slot, bnum, bcoord, median_cp, status);
+  else
+    launch_apply_propose<16>(e, slot, bnum, bcoord, median_cp, status);
+  HIPCHK(hipGetLastError());
+  return GPX_OK;
+}
+
+/* ---- host-pointer data path ---------------------------------------------------- */
+/* H2D into the engine's staging columns, the _dev twin, D2H of the results.        */
+
+#define H2D(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->stream))
+#define D2H(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->stream))
+
+int gpx_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                      int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
+                      uint8_t* status) {
+  int rc = check_batch(h, n);
+  if (rc != GPX_OK) return rc;
+  if (n == 0) return GPX_OK;
+  if (!gidx || !slot || !bnum || !bcoord || !median_cp || !status) return GPX_EINVAL;
+  const size_t b4 = (size_t)n * 4;
+  H2D(h->st_i32[0], gidx, b4);
+  if (is_stop) H2D(h->st_u8[0], is_stop, (size_t)n);
+  rc = gpx_propose_batch_dev(h, n, h->st_i32[0], is_stop ? h->st_u8[0] : nullptr, h->st_i32[1],
+                             h->st_i32[2], h->st_i32[3], h->st_i32[4], h->st_u8[1]);
+  if (rc != GPX_OK) return rc;
+  D2H(slot, h->st_i32[1], b4);
+  D2H(bnum, h->st_i32[2], b4);
+  D2H(bcoord, h->st_i32[3], b4);
+  D2H(median_cp, h->st_i32[4], b4);
+  D2H(status, h->st_u8[1], (size_t)n);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  return GPX_OK;
+}
+
+int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                     const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                     const uint8_t* a_flags, int32_t* r_bnum, int32_t* r_bcoord,
+                     int32_t* r_maxcp, uint8_t* r_flags, uint8_t* status, int32_t* x_gidx,
+                     int32_t* x_first, int32_t* x_count, int32_t* n_runs) {
+  int rc = check_batch(h, n);
+  if (rc != GPX_OK) return rc;
+  if (!n_runs) return GPX_EINVAL;
+  *n_runs = 0;
+  if (n == 0) return GPX_OK;
+  const size_t b4 = (size_t)n * 4;
+  H2D(h->st_i32[0], gidx, b4);
+  H2D(h->st_i32[1], bnum, b4);
+  H2D(h->st_i32[2], bcoord, b4);
+  H2D(h->st_i32[3], slot, b4);
+  H2D(h->st_i32[4], median_cp, b4);
+  if (a_flags) H2D(h->st_u8[0], a_flags, (size_t)n);
+  rc = gpx_accept_batch_dev(h, n, h->st_i32[0], h->st_i32[1], h->st_i32[2], h->st_i32[3],
+                            h->st_i32[4], a_flags ? h->st_u8[0] : nullptr, h->st_i32[5],
+                            h->st_i32[6], h->st_i32[7], h->st_u8[1], h->st_u8[2], h->st_i32[8],
+                            h->st_i32[9], h->st_i32[10], h->st_count);
+  if (rc != GPX_OK) return rc;
+  D2H(n_runs, h->st_count, 4);
+  D2H(r_bnum, h->st_i32[5], b4);
+  D2H(r_bcoord, h->st_i32[6], b4);
+  D2H(r_maxcp, h->st_i32[7], b4);
+  D2H(r_flags, h->st_u8[1], (size_t)n);
+  D2H(status, h->st_u8[2], (size_t)n);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t m4 = (size_t)(*n_runs) * 4;
+  if (m4) {
+    D2H(x_gidx, h->st_i32[8], m4);
+    D2H(x_first, h->st_i32[9], m4);
+    D2H(x_count, h->st_i32[10], m4);
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return GPX_OK;
+}
+
+int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                           const int32_t* bcoord, const int32_t* slot, const int32_t* acceptor,
+                           const int32_t* max_cp, int32_t* d_gidx, int32_t* d_slot,
+                           int32_t* d_bnum, int32_t* d_bcoord, int32_t* d_median_cp,
+                           uint8_t* d_kind, int32_t* n_out, uint8_t* status) {
+  int rc = check_batch(h, n);
+  if (rc != GPX_OK) return rc;
+  if (!n_out) return GPX_EINVAL;
+  *n_out = 0;
+  if (n == 0) return GPX_OK;
+  const size_t b4 = (size_t)n * 4;
+  H2D(h->st_i32[0], gidx, b4);
+  H2D(h->st_i32[1], bnum, b4);
+  H2D(h->st_i32[2], bcoord, b4);
+  H2D(h->st_i32[3], slot, b4);
+  H2D(h->st_i32[4], acceptor, b4);
+  H2D(h->st_i32[5], max_cp, b4);
+  rc = gpx_accept_reply_batch_dev(h, n, h->st_i32[0], h->st_i32[1], h->st_i32[2], h->st_i32[3],
+                                  h->st_i32[4], h->st_i32[5], h->st_i32[6], h->st_i32[7],
+                                  h->st_i32[8], h->st_i32[9], h->st_i32[10], h->st_u8[0],
+                                  h->st_count, h->st_u8[1]);
+  if (rc != GPX_OK) return rc;
+  D2H(n_out, h->st_count, 4);
+  if (status) D2H(status, h->st_u8[1], (size_t)n);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t m = (size_t)(*n_out);
+  if (m) {
+    D2H(d_gidx, h->st_i32[6], m * 4);
+    D2H(d_slot, h->st_i32[7], m * 4);
+    D2H(d_bnum, h->st_i32[8], m * 4);
+    D2H(d_bcoord, h->st_i32[9], m * 4);
+    D2H(d_median_cp, h->st_i32[10], m * 4);
+    D2H(d_kind, h->st_u8[0], m);
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return GPX_OK;
+}
+
+int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                     const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                     const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx, int32_t* x_first,
+                     int32_t* x_count, int32_t* n_runs) {
+  int rc = check_batch(h, n);
+  if (rc != GPX_OK) return rc;
+  if (!n_runs) return GPX_EINVAL;
+  *n_runs = 0;
+  if (n == 0) return GPX_OK;
+  const size_t b4 = (size_t)n * 4;
+  H2D(h->st_i32[0], gidx, b4);
+  H2D(h->st_i32[1], bnum, b4);
+  H2D(h->st_i32[2], bcoord, b4);
+  H2D(h->st_i32[3], slot, b4);
+  H2D(h->st_i32[4], median_cp, b4);
+  if (c_kind) H2D(h->st_u8[0], c_kind, (size_t)n);
+  rc = gpx_commit_batch_dev(h, n, h->st_i32[0], h->st_i32[1], h->st_i32[2], h->st_i32[3],
+                            h->st_i32[4], c_kind ? h->st_u8[0] : nullptr, h->st_u8[1],
+                            h->st_i32[5], h->st_i32[6], h->st_i32[7], h->st_count);
+  if (rc != GPX_OK) return rc;
+  D2H(n_runs, h->st_count, 4);
+  D2H(status, h->st_u8[1], (size_t)n);
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const size_t m4 = (size_t)(*n_runs) * 4;
+  if (m4) {
+    D2H(x_gidx, h->st_i32[5], m4);
+    D2H(x_first, h->st_i32[6], m4);
+    D2H(x_count, h->st_i32[7], m4);
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  return GPX_OK;
+}
+
+/* ---- lifecycle ------------------------------------------------------------------ */
+
+int gpx_group_create(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* members,
+                     const uint8_t* k, const gpx_hri* rows, uint8_t* status) {
+  if (!h || n < 0) return GPX_EINVAL;
+  if (n == 0) return GPX_OK;
+  if (!gidx || !members || !k || !rows) return GPX_EINVAL;
+  /* chunked through temporary device buffers: creation is not on the data path */
+  const int32_t chunk = 1 << 18;
+  int32_t *d_g = nullptr, *d_m = nullptr;
+  uint8_t *d_k = nullptr, *d_s = nullptr;
+  gpx_hri* d_r = nullptr;
+  const int32_t c0 = std::min(n, chunk);
+  HIPCHK(hipMalloc((void**)&d_g, (size_t)c0 * 4));
+  HIPCHK(hipMalloc((void**)&d_m, (size_t)c0 * 4 * h->cfg.kmax));
+  HIPCHK(hipMalloc((void**)&d_k, (size_t)c0));
+  HIPCHK(hipMalloc((void**)&d_s, (size_t)c0));
+  HIPCHK(hipMalloc((void**)&d_r, (size_t)c0 * sizeof(gpx_hri)));
+  int rc = GPX_OK;
+  for (int32_t o = 0; o < n && rc == GPX_OK; o += chunk) {
+    const int32_t c = std::min(chunk, n - o);
+    H2D(d_g, gidx + o, (size_t)c * 4);
+    H2D(d_m, members + (size_t)o * h->cfg.kmax, (size_t)c * 4 * h->cfg.kmax);
+    H2D(d_k, k + o, (size_t)c);
+    H2D(d_r, rows + o, (size_t)c * sizeof(gpx_hri));
+    LAUNCH(h, "k_group_create", k_group_create, grid_for(c), h->S, c, (const int32_t*)d_g,
+           (const int32_t*)d_m, (const uint8_t*)d_k, (const gpx_hri*)d_r, d_s);
+    if (status) D2H(status + o, d_s, (size_t)c);
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  hipFree(d_g);
+  hipFree(d_m);
+  hipFree(d_k);
+  hipFree(d_s);
+  hipFree(d_r);
+  return rc;
+}
+
+static int retire_impl(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mode, gpx_hri* rows,
+                       uint8_t* status) {
+  if (!h || n < 0) return GPX_EINVAL;
+  if (n == 0) return GPX_OK;
+  if (!gidx) return GPX_EINVAL;
+  const int32_t chunk = 1 << 18;
+  int32_t* d_g = nullptr;
+  uint8_t* d_s = nullptr;
+  gpx_hri* d_r = nullptr;
+  const int32_t c0 = std::min(n, chunk);
+  HIPCHK(hipMalloc((void**)&d_g, (size_t)c0 * 4));
+  HIPCHK(hipMalloc((void**)&d_s, (size_t)c0));
+  HIPCHK(hipMalloc((void**)&d_r, (size_t)c0 * sizeof(gpx_hri)));
+  for (int32_t o = 0; o < n; o += chunk) {
+    const int32_t c = std::min(chunk, n - o);
+    H2D(d_g, gidx + o, (size_t)c * 4);
+    LAUNCH(h, "k_group_retire", k_group_retire, grid_for(c), h->S, c, (const int32_t*)d_g, mode, d_r,
+           d_s);
+    if (rows) D2H(rows + o, d_r, (size_t)c * sizeof(gpx_hri));
+    if (status) D2H(status + o, d_s, (size_t)c);
+    HIPCHK(hipStreamSynchronize(h->stream));
+  }
+  hipFree(d_g);
+  hipFree(d_s);
+  hipFree(d_r);
+  return GPX_OK;
+}
+
+int gpx_group_retire(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mode, gpx_hri* rows,
+                     uint8_t* status) {
+  if (mode != GPX_RETIRE_PAUSE && mode != GPX_RETIRE_KILL) return GPX_EINVAL;
+  return retire_impl(h, n, gidx, mode, rows, status);
+}
+
+int gpx_group_snapshot(gpx_engine* h, int32_t n, const int32_t* gidx, gpx_hri* rows,
+                       uint8_t* status) {
+  if (!rows) return GPX_EINVAL;
+  return retire_impl(h, n, gidx, 2, rows, status);
+}
+
+/* canonical dump (same word layout as the oracle's orc_group_dump) */
+int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
+  if (!h || !buf) return GPX_EINVAL;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  std::vector<int32_t> w;
+  const DevState& S = h->S;
+  auto rd32 = [&](const void* base, int64_t idx, int32_t* out) -> hipError_t {
+    return hipMemcpy(out, (const char*)base + idx * 4, 4, hipMemcpyDeviceToHost);
+  };
+  auto rd8 = [&](const void* base, int64_t idx, uint8_t* out) -> hipError_t {
+    return hipMemcpy(out, (const char*)base + idx, 1, hipMemcpyDeviceToHost);
+  };
+  if (gidx < 0 || gidx >= S.G) {
+    if (cap < 1) return GPX_ECAPACITY;
+    buf[0] = 0;
+    return 1;
+  }
+  int32_t gf_i = 0;
+  HIPCHK(rd32(S.g_flags, gidx, &gf_i));
+  const uint32_t gf = (uint32_t)gf_i;
+  w.push_back((gf & GF_EXISTS) ? 1 : 0);
+  if (gf & GF_EXISTS) {
+    const int32_t k = (int32_t)GF_K(gf);
+    int32_t v = 0;
+    HIPCHK(rd32(S.g_version, gidx, &v));
+    w.push_back(v);
+    w.push_back(k);
+    for (int j = 0; j < k; j++) {
+      HIPCHK(rd32(S.members, (int64_t)j * S.G + gidx, &v));
+      w.push_back(v);
+    }
+    const void* accf[4] = {S.a_slot, S.a_bnum, S.a_bcoord, S.a_gc};
+    for (auto p : accf) {
+      HIPCHK(rd32(p, gidx, &v));
+      w.push_back(v);
+    }
+    w.push_back((gf & GF_STOPPED) ? 1 : 0);
+    struct Ent {
+      int32_t slot, a, b, c;
+      uint8_t f;
+    };
+    auto read_ring = [&](const int4* ring, const uint8_t* flags, std::vector<Ent>& out) -> int {
+      for (int32_t x = 0; x < S.W; x++) {
+        uint8_t f = 0;
+        HIPCHK(rd8(flags, (int64_t)x * S.G + gidx, &f));
+        if (!(f & RF_PRESENT)) continue;
+        int4 r;
+        HIPCHK(hipMemcpy(&r, ring + ((int64_t)x * S.G + gidx), sizeof(int4), hipMemcpyDeviceToHost));
+        out.push_back(Ent{r.x, r.y, r.z, r.w, f});
+      }
+      std::sort(out.begin(), out.end(), [](const Ent& p, const Ent& q) { return p.slot < q.slot; });
+      return GPX_OK;
+    };
+    std::vector<Ent> acc, com;
+    int rc = read_ring(S.acc_ring, S.acc_flags, acc);
+    if (rc != GPX_OK) return rc;
+    rc = read_ring(S.com_ring, S.com_flags, com);
+    if (rc != GPX_OK) return rc;
+    w.push_back((int32_t)acc.size());
+    for (auto& en : acc) {
+      w.push_back(en.slot);
+      w.push_back(en.a);
+      w.push_back(en.b);
+      w.push_back((en.f & RF_STOP) ? 1 : 0);
+    }
+    w.push_back((int32_t)com.size());
+    for (auto& en : com) {
+      w.push_back(en.slot);
+      w.push_back(en.a);
+      w.push_back(en.b);
+      w.push_back(en.c);
+      w.push_back((en.f & RF_HASVALUE) ? 1 : 0);
+      w.push_back((en.f & RF_STOP) ? 1 : 0);
+    }
+    w.push_back((gf & GF_HASCOORD) ? 1 : 0);
+    if (gf & GF_HASCOORD) {
+      int32_t next = 0;
+      HIPCHK(rd32(S.c_bnum, gidx, &v));
+      w.push_back(v);
+      HIPCHK(rd32(S.c_bcoord, gidx, &v));
+      w.push_back(v);
+      HIPCHK(rd32(S.c_next, gidx, &next));
+      w.push_back(next);
+      for (int j = 0; j < k; j++) {
+        HIPCHK(rd32(S.node_slots, (int64_t)j * S.G + gidx, &v));
+        w.push_back(v);
+      }
+      /* myProposals: slots next-W .. next-1 that are present, ascending signed order */
+      std::vector<std::pair<int32_t, uint32_t>> props;
+      for (int32_t d = S.W; d >= 1; d--) {
+        const int32_t s = (int32_t)((uint32_t)next - (uint32_t)d);
+        int32_t ev = 0;
+        HIPCHK(rd32(S.p_ring, (int64_t)(s & (S.W - 1)) * S.G + gidx, &ev));
+        if ((uint32_t)ev & PR_PRESENT) props.push_back({s, (uint32_t)ev});
+      }
+      std::sort(props.begin(), props.end(),
+                [](const std::pair<int32_t, uint32_t>& p, const std::pair<int32_t, uint32_t>& q) {
+                  return p.first < q.first;
+                });
+      w.push_back((int32_t)props.size());
+      for (auto& pr : props) {
+        w.push_back(pr.first);
+        w.push_back((pr.second & PR_STOP) ? 1 : 0);
+        w.push_back((int32_t)(pr.second & 0xffffu));
+      }
+    }
+  }
+  if ((int32_t)w.size() > cap) return GPX_ECAPACITY;
+  memcpy(buf, w.data(), w.size() * sizeof(int32_t));
+  return (int32_t)w.size();
+}
+
+} /* extern "C" */

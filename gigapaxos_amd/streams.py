@@ -1,0 +1,75 @@
+"""Deterministic synthetic accept-reply streams (BASELINE configs 3-5).
+
+For round r every group g has slot s = r + 1 outstanding at the coordinator (engine id
+`coordinator`) and receives K votes (gidx, bnum=0, bcoord=coordinator, slot=s,
+acceptor=members[pi(j)], max_cp=s-1), pi a per-(g, r) permutation; the round's K*G records are
+shuffled globally (variant "shuffled") or kept sorted by gidx (variant "sorted").
+
+Adversarial mix (variant mix=True): 1 % duplicated votes, 0.5 % stale-ballot votes
+(bcoord - 1), 0.1 % higher-ballot votes (bnum = 1), appended and shuffled in.
+
+Seeding: numpy PCG64 seeded with SEED ^ (config_id << 32) ^ round.  (SURVEY.md §8d suggests
+xorshift64* + Fisher-Yates; a scalar generator cannot fill 3 M-record rounds fast enough in
+Python, and parity only needs the oracle and the engine to consume IDENTICAL arrays, which
+this guarantees.)
+"""
+from __future__ import annotations
+
+import numpy as np
+
+SEED = 0x9E3779B97F4A7C15
+
+
+def _rng(config_id: int, rnd: int) -> np.random.Generator:
+    return np.random.Generator(np.random.PCG64((SEED ^ (config_id << 32) ^ rnd) & ((1 << 64) - 1)))
+
+
+def vote_round(num_groups: int, members, rnd: int, coordinator: int, config_id: int = 3,
+               shuffled: bool = True, mix: bool = False, groups=None):
+    """One round of votes as six int32 columns (gidx, bnum, bcoord, slot, acceptor, max_cp)."""
+    members = np.asarray(members, np.int32)
+    k = members.shape[0]
+    rng = _rng(config_id, rnd)
+    g = np.arange(num_groups, dtype=np.int32) if groups is None else np.asarray(groups, np.int32)
+    G = g.shape[0]
+    s = rnd + 1
+    # per-(g, r) acceptor permutation: argsort of random keys
+    perm = np.argsort(rng.random((G, k)), axis=1).astype(np.int32)
+    gidx = np.repeat(g, k)
+    acceptor = members[perm].reshape(-1)
+    n = G * k
+    bnum = np.zeros(n, np.int32)
+    bcoord = np.full(n, coordinator, np.int32)
+    slot = np.full(n, s, np.int32)
+    max_cp = np.full(n, s - 1, np.int32)
+    cols = [gidx, bnum, bcoord, slot, acceptor, max_cp]
+    if mix:
+        nd, ns_, nh = max(1, n // 100), max(1, n // 200), max(1, n // 1000)
+        pick = rng.integers(0, n, nd + ns_ + nh)
+        extra = [c[pick].copy() for c in cols]
+        extra[2][nd:nd + ns_] -= 1  # stale: bcoord - 1
+        extra[1][nd + ns_:] = 1  # higher ballot: bnum = 1
+        cols = [np.concatenate([c, e]) for c, e in zip(cols, extra)]
+        n = cols[0].shape[0]
+    if shuffled:
+        order = rng.permutation(n)
+        cols = [np.ascontiguousarray(c[order]) for c in cols]
+    elif mix:
+        order = np.argsort(cols[0], kind="stable")
+        cols = [np.ascontiguousarray(c[order]) for c in cols]
+    return tuple(cols)
+
+
+def fmix32(h):
+    """murmur3 finaliser — the group -> GPU shard hash."""
+    h = np.asarray(h, np.uint32).copy()
+    h ^= h >> np.uint32(16)
+    h *= np.uint32(0x85EBCA6B)
+    h ^= h >> np.uint32(13)
+    h *= np.uint32(0xC2B2AE35)
+    h ^= h >> np.uint32(16)
+    return h
+
+
+def shard_of(gidx, n_shards: int):
+    return (fmix32(gidx) % np.uint32(n_shards)).astype(np.int32)

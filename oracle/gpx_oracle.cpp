@@ -636,6 +636,7 @@ int orc_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
           d_median_cp[out] = -1; /* PValuePacket.medianCheckpointedSlot default, :80 */
           d_kind[out] = GPX_D_PREEMPTED;
           out++;
+          e->counters[1]++;
         }
       } else if (cmp == 0) {
         int32_t median = 0;

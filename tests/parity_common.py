@@ -1,0 +1,127 @@
+"""Differential driver: applies one seeded op sequence to two engines behind the same C-ABI
+(the HIP engine and the CPU oracle) and compares every output column and the full per-group
+state dump bit for bit."""
+import numpy as np
+
+from gigapaxos_amd import Engine, hri_create, hri_initial, make_hri, S_OK, S_WINDOW
+
+
+def wrap32(x):
+    """Java int wraparound of an int64 value (array or scalar)."""
+    return (np.asarray(x, np.int64) & 0xFFFFFFFF).astype(np.uint32).view(np.int32)
+
+
+def make_pair(lib_a, lib_b, my_id, G, kmax, window, max_batch=1 << 16, flags=1):
+    return (Engine(lib_a, my_id, G, kmax=kmax, window=window, max_batch=max_batch, flags=flags),
+            Engine(lib_b, my_id, G, kmax=kmax, window=window, max_batch=max_batch, flags=flags))
+
+
+def assert_same_state(ea, eb, groups):
+    for g in groups:
+        da, db = ea.dump(int(g)), eb.dump(int(g))
+        assert da.tolist() == db.tolist(), f"group {g} state differs:\n{da.tolist()}\n{db.tolist()}"
+
+
+def create_mixed_groups(ea, eb, G, kmax, node_ids, rng, slot_base=1, my_id=None):
+    """Groups of varying size k <= kmax, members drawn (sorted) from node_ids; half created with
+    createHRI rows, half with regular-creation rows; coordinator = my_id for ~2/3 of them."""
+    my_id = ea.my_id if my_id is None else my_id
+    gidx = np.arange(G, dtype=np.int32)
+    members = np.zeros((G, kmax), np.int32)
+    ks = np.zeros(G, np.uint8)
+    rows = make_hri(G)
+    for g in range(G):
+        k = int(rng.integers(1, kmax + 1))
+        others = [n for n in node_ids if n != my_id]
+        mem = sorted([my_id] + list(rng.choice(others, size=k - 1, replace=False))) if k > 1 else [my_id]
+        ks[g] = k
+        members[g, :k] = mem
+        coord = my_id if rng.random() < 0.67 else int(rng.choice(mem))
+        r = (hri_create if g % 2 == 0 else hri_initial)(1, k, coord)
+        r["acc_slot"] = wrap32(int(r["acc_slot"][0]) - 1 + slot_base)
+        r["acc_gc_slot"] = wrap32(int(r["acc_gc_slot"][0]) - 1 + slot_base)
+        r["next_proposal_slot"] = wrap32(int(r["next_proposal_slot"][0]) - 1 + slot_base)
+        if g % 2 == 0:
+            r["node_slots"][0, :k] = wrap32(np.full(k, slot_base - 1))
+        rows[g] = r[0]
+    sa = ea.create_groups(gidx, members, ks, rows)
+    sb = eb.create_groups(gidx, members, ks, rows)
+    assert sa.tolist() == sb.tolist() and (sa == S_OK).all()
+    return members, ks
+
+
+def fuzz(ea, eb, G, node_ids, rng, steps, batch, slot_base=1, span=40, my_id=None, p_stop=0.01):
+    """Random interleaving of propose / accept / accept_reply / commit batches with colliding
+    slots, duplicate votes, stale and higher ballots, non-member acceptors, unknown groups."""
+    my_id = ea.my_id if my_id is None else my_id
+    nodes = np.array(list(node_ids) + [my_id - 7], np.int32)  # last = never a member
+
+    def gids(n):
+        g = rng.integers(0, G, n).astype(np.int32)
+        bad = rng.random(n) < 0.01
+        g[bad] = rng.choice([-1, G, G + 5], size=int(bad.sum()))
+        return g
+
+    def slots(n):
+        return wrap32(slot_base + rng.integers(-2, span, n))
+
+    def ballots(n):
+        bnum = rng.choice([0, 0, 0, 0, 1, 2], size=n).astype(np.int32)
+        bcoord = rng.choice(nodes[:-1], size=n).astype(np.int32)
+        pref = rng.random(n) < 0.7
+        bcoord[pref] = my_id
+        bnum[pref & (rng.random(n) < 0.9)] = 0
+        return bnum, bcoord
+
+    for step in range(steps):
+        op = rng.integers(0, 4)
+        n = int(rng.integers(1, batch + 1))
+        g = gids(n)
+        if op == 0:
+            # keep every group's proposal frontier inside the slot span the votes can reach, so
+            # the engine's fixed window never fills (the oracle's maps are unbounded): at most one
+            # proposal per group per batch, only for groups whose next slot is still in range
+            rows, _ = ea.snapshot(np.arange(G))
+            room = (rows["next_proposal_slot"].astype(np.int64) - slot_base) < span - 2
+            ok = (g < 0) | (g >= G)
+            inr = ~ok
+            ok[inr] = room[g[inr]] | (rows["has_coord"][g[inr]] == 0)
+            _, first = np.unique(g, return_index=True)
+            uniq = np.zeros(n, bool)
+            uniq[first] = True
+            g = g[ok & uniq]
+            n = g.shape[0]
+            if n == 0:
+                continue
+            stop = (rng.random(n) < p_stop).astype(np.uint8) if rng.random() < 0.5 else None
+            ra, rb = ea.propose(g, stop), eb.propose(g, stop)
+            for x, y, nm in zip(ra, rb, ("slot", "bnum", "bcoord", "median", "status")):
+                assert x.tolist() == y.tolist(), f"step {step} propose {nm}"
+        elif op == 1:
+            bnum, bcoord = ballots(n)
+            sl = slots(n)
+            med = wrap32(slot_base + rng.integers(-3, span, n))
+            fl = (rng.random(n) < p_stop).astype(np.uint8)
+            (ra, xa), (rb, xb) = ea.accept(g, bnum, bcoord, sl, med, fl), eb.accept(g, bnum, bcoord, sl, med, fl)
+            for x, y, nm in zip(ra, rb, ("r_bnum", "r_bcoord", "r_maxcp", "r_flags", "status")):
+                assert x.tolist() == y.tolist(), f"step {step} accept {nm}"
+            assert xa.as_tuple_array().tolist() == xb.as_tuple_array().tolist(), f"step {step} accept runs"
+        elif op == 2:
+            bnum, bcoord = ballots(n)
+            sl = slots(n)
+            acc = rng.choice(nodes, size=n).astype(np.int32)
+            mcp = wrap32(slot_base + rng.integers(-3, span, n))
+            da, db = ea.accept_reply(g, bnum, bcoord, sl, acc, mcp), eb.accept_reply(g, bnum, bcoord, sl, acc, mcp)
+            assert da.as_tuple_array().tolist() == db.as_tuple_array().tolist(), f"step {step} decisions"
+            assert da.status.tolist() == db.status.tolist(), f"step {step} ar status"
+        else:
+            bnum, bcoord = ballots(n)
+            sl = slots(n)
+            med = wrap32(slot_base + rng.integers(-3, span, n))
+            kind = rng.choice([0, 0, 0, 1, 3], size=n).astype(np.uint8)
+            (sa, xa), (sb, xb) = ea.commit(g, bnum, bcoord, sl, med, kind), eb.commit(g, bnum, bcoord, sl, med, kind)
+            assert sa.tolist() == sb.tolist(), f"step {step} commit status"
+            assert xa.as_tuple_array().tolist() == xb.as_tuple_array().tolist(), f"step {step} commit runs"
+    assert_same_state(ea, eb, range(G))
+    ca, cb = ea.counters(), eb.counters()
+    assert ca == cb, (ca, cb)

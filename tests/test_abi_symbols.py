@@ -1,0 +1,57 @@
+"""The C-ABI shared library builds for gfx950, loads without a GPU and exports every entry point
+include/gpx.h declares (no compute calls here)."""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    src = open(os.path.join(ROOT, "include", "gpx.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpx_[a-z_]+)\s*\(", src)))
+
+
+def test_header_declares_expected_entry_points():
+    names = _declared()
+    for must in ("gpx_engine_create", "gpx_group_create", "gpx_group_retire", "gpx_propose_batch",
+                 "gpx_accept_batch", "gpx_accept_reply_batch", "gpx_commit_batch",
+                 "gpx_accept_reply_batch_dev"):
+        assert must in names
+
+
+def test_hip_library_exports_every_declared_symbol():
+    import ctypes
+
+    import __graft_entry__ as ge
+
+    ge.build()
+    lib = ctypes.CDLL(ge.HIP_SO)
+    for name in _declared():
+        assert hasattr(lib, name), f"{name} declared in include/gpx.h but not exported"
+    lib.gpx_abi_version.restype = ctypes.c_int
+    assert lib.gpx_abi_version() == 1
+
+
+def test_oracle_exports_matching_symbols(oracle_lib):
+    for name in _declared():
+        if name.endswith("_dev") or name in ("gpx_engine_set_stream", "gpx_profile_enable",
+                                              "gpx_profile_read"):
+            continue
+        assert hasattr(oracle_lib.lib, "orc_" + name[4:]), name
+
+
+def test_engine_create_rejects_bad_config_without_gpu():
+    """Argument validation happens before any device call."""
+    import ctypes
+
+    import __graft_entry__ as ge
+    from gigapaxos_amd._abi import GpxConfig
+
+    ge.build()
+    lib = ctypes.CDLL(ge.HIP_SO)
+    h = ctypes.c_void_p()
+    for bad in (GpxConfig(100, 0, 3, 8, 16, -1, 1, 0), GpxConfig(100, 8, 17, 8, 16, -1, 1, 0),
+                GpxConfig(100, 8, 3, 6, 16, -1, 1, 0), GpxConfig(100, 8, 3, 128, 16, -1, 1, 0)):
+        assert lib.gpx_engine_create(ctypes.byref(bad), ctypes.byref(h)) == -1
+    assert lib.gpx_engine_create(None, ctypes.byref(h)) == -1

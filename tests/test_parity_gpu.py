@@ -1,0 +1,198 @@
+"""Parity tests proper: the hand-written HIP engine (libgpx_hip.so, through the C-ABI) against the
+CPU oracle on identical seeded inputs.  Bit-exact: every output column, the decided
+(group, slot, ballot, medianCheckpointedSlot) stream in order, and the full per-group state."""
+import numpy as np
+import pytest
+
+from gigapaxos_amd import (Engine, hri_create, hri_initial, make_hri, streams, S_OK, S_WINDOW,
+                           D_DECISION, D_PREEMPTED)
+from gigapaxos_amd.loopback import LoopbackCluster
+from tests.parity_common import make_pair, create_mixed_groups, fuzz, assert_same_state, wrap32
+
+pytestmark = pytest.mark.gpu
+
+NODES = [100, 101, 102, 103, 104, 105, 106, 107]
+
+
+@pytest.mark.parametrize("kmax,seed", [(3, 1), (5, 2), (8, 3), (16, 4)])
+def test_fuzz_mixed_ops(hip_lib, oracle_lib, kmax, seed):
+    rng = np.random.default_rng(seed)
+    nodes = NODES if kmax <= 8 else list(range(100, 120))
+    G = 64
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, kmax, 64)
+    create_mixed_groups(eh, eo, G, kmax, nodes, rng)
+    fuzz(eh, eo, G, nodes, rng, steps=250, batch=300)
+
+
+def test_fuzz_wraparound(hip_lib, oracle_lib):
+    """slots straddle Integer.MAX_VALUE -> MIN_VALUE."""
+    rng = np.random.default_rng(5)
+    base = (1 << 31) - 15
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, 32, 3, 64)
+    create_mixed_groups(eh, eo, 32, 3, NODES[:4], rng, slot_base=base)
+    fuzz(eh, eo, 32, NODES[:4], rng, steps=200, batch=150, slot_base=base)
+
+
+def test_fuzz_accepts_in_memory(hip_lib, oracle_lib):
+    """GET_ACCEPTED_PVALUES_FROM_DISK = false (logging disabled): accepts stay after execution."""
+    rng = np.random.default_rng(6)
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, 32, 3, 64, flags=0)
+    create_mixed_groups(eh, eo, 32, 3, NODES[:4], rng)
+    fuzz(eh, eo, 32, NODES[:4], rng, steps=200, batch=150)
+
+
+def _same_decisions(da, db):
+    assert da.as_tuple_array().tolist() == db.as_tuple_array().tolist()
+    assert da.status.tolist() == db.status.tolist()
+
+
+@pytest.mark.parametrize("nvotes", [17, 600, 4096, 20000])
+def test_hot_group_long_segments(hip_lib, oracle_lib, nvotes):
+    """All votes of a batch hit ONE group (a BATCHED_ACCEPT_REPLY with many slots):
+    exercises the long-segment arrival-order sort (LDS and global-memory variants)."""
+    rng = np.random.default_rng(nvotes)
+    W = 64
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, 4, 3, W, max_batch=1 << 15)
+    mem = np.tile(np.array([100, 101, 102], np.int32), (4, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(4), mem, 3, hri_create(4, 3, 100)) == S_OK).all()
+    nprop = 40
+    g = np.full(nprop, 2, np.int32)
+    for x, y in zip(eh.propose(g), eo.propose(g)):
+        assert x.tolist() == y.tolist()
+    slot = rng.integers(1, nprop + 1, nvotes).astype(np.int32)
+    acc = rng.choice([100, 101, 102, 55], size=nvotes).astype(np.int32)
+    mcp = rng.integers(-1, 30, nvotes).astype(np.int32)
+    bnum = (rng.random(nvotes) < 0.002).astype(np.int32)
+    gv = np.full(nvotes, 2, np.int32)
+    gv[rng.random(nvotes) < 0.05] = 1
+    args = (gv, bnum, np.full(nvotes, 100, np.int32), slot, acc, mcp)
+    _same_decisions(eh.accept_reply(*args), eo.accept_reply(*args))
+    assert_same_state(eh, eo, range(4))
+
+
+def test_window_overflow_statuses(hip_lib, oracle_lib):
+    """The engine tracks W slots per group per map; beyond that a record is DROPPED with
+    GPX_S_WINDOW and no state changes.  Feeding the oracle only the accepted records must give
+    the same state."""
+    W = 4
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, 2, 3, W)
+    mem = np.tile(np.array([100, 101, 102], np.int32), (2, 1))
+    for e in (eh, eo):
+        e.create_groups(np.arange(2), mem, 3, hri_create(2, 3, 100))
+    g = np.zeros(7, np.int32)
+    sl, bn, bc, md, st = eh.propose(g)
+    assert st.tolist() == [S_OK] * 4 + [S_WINDOW] * 3 and sl[:4].tolist() == [1, 2, 3, 4]
+    eo.propose(g[:4])
+    assert_same_state(eh, eo, range(2))
+    # decide slot 1 -> one more proposal fits
+    v = (np.zeros(2, np.int32), np.zeros(2, np.int32), np.full(2, 100, np.int32),
+         np.ones(2, np.int32), np.array([100, 101], np.int32), np.zeros(2, np.int32))
+    _same_decisions(eh.accept_reply(*v), eo.accept_reply(*v))
+    sl, _, _, _, st = eh.propose(g[:2])
+    assert st.tolist() == [S_OK, S_WINDOW] and sl[0] == 5
+    eo.propose(g[:1])
+    assert_same_state(eh, eo, range(2))
+    # acceptor side: commits further ahead than W, accepts colliding in the ring
+    slots = np.array([1, 2, 7, 5, 9], np.int32)  # 5 and 9 collide with live slot 1 in a W=4 ring
+    z = np.zeros(5, np.int32)
+    (rb, rc, rm, rf, st), _ = eh.accept(np.ones(5, np.int32), z, np.full(5, 100, np.int32), slots, z)
+    assert st.tolist() == [S_OK, S_OK, S_OK, S_WINDOW, S_WINDOW]
+    eo.accept(np.ones(3, np.int32), z[:3], np.full(3, 100, np.int32), slots[:3], z[:3])
+    st, _ = eh.commit(np.ones(3, np.int32), z[:3], np.full(3, 100, np.int32),
+                      np.array([5, 4, 2], np.int32), z[:3])
+    assert st.tolist() == [S_WINDOW, S_OK, S_OK]
+    eo.commit(np.ones(2, np.int32), z[:2], np.full(2, 100, np.int32), np.array([4, 2], np.int32), z[:2])
+    assert_same_state(eh, eo, range(2))
+
+
+def test_config1_loopback_one_group(hip_lib):
+    """BASELINE config #1 on the engine: 3 replicas, 1 group, in-order execution everywhere."""
+    c = LoopbackCluster(hip_lib, [100, 101, 102], 1, window=8, max_batch=1024)
+    n = 300
+    for r in range(n):
+        dec = c.round([0])
+        assert dec[0, :4].tolist() == [0, r + 1, 0, 100] and dec[0, 5] == D_DECISION
+    for nid in (100, 101, 102):
+        ex = c.executed(nid)
+        slots = np.concatenate([np.arange(f, f + cnt) for _, f, cnt in ex])
+        assert slots.tolist() == list(range(1, n + 1))
+
+
+def test_config2_10k_groups_full_pipeline(hip_lib, oracle_lib):
+    """BASELINE config #2: 10k groups, 3 replicas, propose -> accept x3 -> reply x3 -> decide ->
+    commit x3 -> exec, one batch per round; coordinators spread over the replicas as
+    roundRobinCoordinator(name_g) would.  Engine cluster vs oracle cluster, identical streams."""
+    G, R = 10000, 12
+    rng = np.random.default_rng(2)
+    coord = rng.choice([100, 101, 102], size=G).astype(np.int32)
+    ch = LoopbackCluster(hip_lib, [100, 101, 102], G, window=8, max_batch=1 << 16, coordinator=coord)
+    co = LoopbackCluster(oracle_lib, [100, 101, 102], G, window=8, coordinator=coord)
+    for r in range(R):
+        groups = rng.permutation(G).astype(np.int32)
+        dh, do = ch.round(groups), co.round(groups)
+        assert dh.tolist() == do.tolist()
+        assert dh.shape[0] == G
+    for nid in (100, 101, 102):
+        assert ch.executed(nid).tolist() == co.executed(nid).tolist()
+        eh, eo = ch.engines[nid], co.engines[nid]
+        sh, so = eh.snapshot(np.arange(G))[0], eo.snapshot(np.arange(G))[0]
+        assert sh.tobytes() == so.tobytes()
+        assert (sh["acc_slot"] == R + 1).all()
+        assert_same_state(eh, eo, rng.integers(0, G, 40))
+
+
+@pytest.mark.parametrize("k,mix,shuffled", [(3, False, True), (3, True, True), (3, True, False), (5, True, True)])
+def test_config3_vote_stream(hip_lib, oracle_lib, k, mix, shuffled):
+    """BASELINE config #3/#4 stream (synthetic accept-reply stream, engine = coordinator of every
+    group) at a size the oracle finishes in seconds: decided stream identical, in order."""
+    G, R = 1 << 16, 6
+    members = list(range(100, 100 + k))
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=1 << 19)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 100)) == S_OK).all()
+    for r in range(R):
+        g = np.arange(G, dtype=np.int32)
+        for x, y in zip(eh.propose(g), eo.propose(g)):
+            assert (x == y).all()
+        cols = streams.vote_round(G, members, r, 100, config_id=3 if k == 3 else 4, shuffled=shuffled, mix=mix)
+        dh, do = eh.accept_reply(*cols), eo.accept_reply(*cols)
+        assert (dh.as_tuple_array() == do.as_tuple_array()).all()
+        assert dh.as_tuple_array().shape == do.as_tuple_array().shape
+        assert (dh.status == do.status).all()
+        if not mix:
+            assert dh.gidx.shape[0] == G and (dh.kind == D_DECISION).all()
+    sh, so = eh.snapshot(np.arange(G))[0], eo.snapshot(np.arange(G))[0]
+    assert sh.tobytes() == so.tobytes()
+    assert_same_state(eh, eo, np.random.default_rng(0).integers(0, G, 64))
+    assert eh.counters() == eo.counters()
+
+
+def test_full_size_properties_1m_groups(hip_lib):
+    """BASELINE config #3 at FULL size (1 M groups, 3 M votes per round): size-independent
+    properties instead of the oracle — exactly one DECISION per group per clean round, each at the
+    round's slot with median = round (createHRI rows), output in vote-arrival order, and the
+    state rows advance uniformly."""
+    G, R = 1_000_000, 3
+    e = Engine(hip_lib, 100, G, kmax=3, window=8, max_batch=3 * G + 65536)
+    mem = np.tile(np.array([100, 101, 102], np.int32), (G, 1))
+    assert (e.create_groups(np.arange(G), mem, 3, hri_create(G, 3, 100)) == S_OK).all()
+    for r in range(R):
+        sl, bn, bc, md, st = e.propose(np.arange(G, dtype=np.int32))
+        assert (st == S_OK).all() and (sl == r + 1).all() and (md == max(r - 1, 0)).all()
+        cols = streams.vote_round(G, [100, 101, 102], r, 100)
+        d = e.accept_reply(*cols)
+        assert d.gidx.shape[0] == G and (d.kind == D_DECISION).all()
+        assert (d.slot == r + 1).all() and (d.median_cp == r).all()
+        assert (np.bincount(d.gidx, minlength=G) == 1).all()
+        # arrival order: the decision of group g is produced by its SECOND vote (majority of 3)
+        gcol = cols[0]
+        order = np.argsort(gcol, kind="stable")
+        second = order.reshape(G, 3)[:, 1]  # index of the 2nd vote of each group (stable sort)
+        expect = gcol[np.sort(second)]
+        assert (d.gidx == expect).all()
+    rows, st = e.snapshot(np.arange(G))
+    assert (rows["next_proposal_slot"] == R + 1).all()
+    assert (rows["node_slots"][:, :3] == R - 1).all()
+    assert e.counters()[:2] == (3 * G * R, G * R)
