@@ -139,7 +139,7 @@ void scan_groups(gpx_engine* e) {
 
 void sort_big(gpx_engine* e) {
   LAUNCH(e, "k_sort_big", k_sort_big, 64, (const int32_t*)e->X.biglist, (const int32_t*)e->X.cnt,
-         (const int32_t*)e->X.offs, (const int4*)e->X.seg_a, e->X.ord);
+         (const int32_t*)e->X.offs, (const I4*)e->X.seg_a, e->X.ord);
 }
 
 /* scan of the per-record output flags; total -> n_out (device) */
@@ -339,7 +339,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     launch_apply_ar<16>(e, status);
   scan_outputs(e, n, n_out, &e->X.counters[1]);
   LAUNCH(e, "k_compact_dec", k_compact_dec, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
-         (const int4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, slot, d_gidx, d_slot, d_bnum,
+         (const I4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, slot, d_gidx, d_slot, d_bnum,
          d_bcoord, d_median_cp, d_kind);
   HIPCHK(hipGetLastError());
   return GPX_OK;
@@ -361,13 +361,14 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
          status, e->X.counters, e->X.biglist, 0);
   scan_groups(e);
   LAUNCH(e, "k_fill_ac", k_fill_ac, grid_for(n), n, gidx, bnum, bcoord, slot, median_cp, a_flags,
-         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b);
+         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b, r_bnum,
+         r_bcoord, r_maxcp, r_flags);
   sort_big(e);
   LAUNCH(e, "k_apply_accept", k_apply_accept, grid_for(e->cfg.max_groups), e->S, e->X, r_bnum,
          r_bcoord, r_maxcp, r_flags, status);
   scan_outputs(e, n, n_runs);
   LAUNCH(e, "k_compact_runs", k_compact_runs, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
-         (const int4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
+         (const I4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -387,12 +388,13 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
          status, e->X.counters, e->X.biglist, 0);
   scan_groups(e);
   LAUNCH(e, "k_fill_ac", k_fill_ac, grid_for(n), n, gidx, bnum, bcoord, slot, median_cp, c_kind,
-         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b);
+         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b,
+         (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
   sort_big(e);
   LAUNCH(e, "k_apply_commit", k_apply_commit, grid_for(e->cfg.max_groups), e->S, e->X, status);
   scan_outputs(e, n, n_runs);
   LAUNCH(e, "k_compact_runs", k_compact_runs, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
-         (const int4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
+         (const I4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -408,7 +410,7 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
          status, e->X.counters, e->X.biglist, 0);
   scan_groups(e);
   LAUNCH(e, "k_fill_pr", k_fill_pr, grid_for(n), n, gidx, is_stop, (const int32_t*)e->X.rank,
-         (const int32_t*)e->X.offs, e->X.seg_a);
+         (const int32_t*)e->X.offs, e->X.seg_a, slot, bnum, bcoord, median_cp);
   sort_big(e);
   if (e->cfg.kmax <= 4)
     launch_apply_propose<4>(e, slot, bnum, bcoord, median_cp, status);
@@ -677,13 +679,13 @@ int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
       int32_t slot, a, b, c;
       uint8_t f;
     };
-    auto read_ring = [&](const int4* ring, const uint8_t* flags, std::vector<Ent>& out) -> int {
+    auto read_ring = [&](const I4* ring, const uint8_t* flags, std::vector<Ent>& out) -> int {
       for (int32_t x = 0; x < S.W; x++) {
         uint8_t f = 0;
         HIPCHK(rd8(flags, (int64_t)x * S.G + gidx, &f));
         if (!(f & RF_PRESENT)) continue;
-        int4 r;
-        HIPCHK(hipMemcpy(&r, ring + ((int64_t)x * S.G + gidx), sizeof(int4), hipMemcpyDeviceToHost));
+        I4 r;
+        HIPCHK(hipMemcpy(&r, ring + ((int64_t)x * S.G + gidx), sizeof(I4), hipMemcpyDeviceToHost));
         out.push_back(Ent{r.x, r.y, r.z, r.w, f});
       }
       std::sort(out.begin(), out.end(), [](const Ent& p, const Ent& q) { return p.slot < q.slot; });

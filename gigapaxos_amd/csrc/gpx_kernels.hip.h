@@ -27,6 +27,30 @@
 
 #include "../../include/gpx.h"
 
+/* Plain 16-/8-byte aggregates for packed records and ring entries.  (Deliberately NOT HIP's
+ * I4/I2 = HIP_vector_type: with ROCm 7.2 -O3 a `.w` read through its accessor proxy came out
+ * undefined on one path of acc_reconstruct; plain structs give the same dwordx4 accesses.) */
+struct __attribute__((aligned(16))) I4 {
+  int32_t x, y, z, w;
+};
+struct __attribute__((aligned(8))) I2 {
+  int32_t x, y;
+};
+__host__ __device__ __forceinline__ I4 mk4(int32_t x, int32_t y, int32_t z, int32_t w) {
+  I4 r;
+  r.x = x;
+  r.y = y;
+  r.z = z;
+  r.w = w;
+  return r;
+}
+__host__ __device__ __forceinline__ I2 mk2(int32_t x, int32_t y) {
+  I2 r;
+  r.x = x;
+  r.y = y;
+  return r;
+}
+
 #define GPX_BLOCK 256
 #define GPX_SCAN_ITEMS 8 /* items per thread in the scan kernels */
 #define GPX_SCAN_TILE (GPX_BLOCK * GPX_SCAN_ITEMS)
@@ -57,9 +81,9 @@ struct DevState {
   int32_t* members;                                 /* [kmax][G] */
   int32_t* node_slots;                              /* [kmax][G] nodeSlotNumbers */
   uint32_t* p_ring;                                 /* [W][G] myProposals */
-  int4* acc_ring;                                   /* [W][G] acceptedProposals {slot,bnum,bcoord,-} */
+  I4* acc_ring;                                   /* [W][G] acceptedProposals {slot,bnum,bcoord,-} */
   uint8_t* acc_flags;                               /* [W][G] */
-  int4* com_ring;                                   /* [W][G] committedRequests {slot,bnum,bcoord,median} */
+  I4* com_ring;                                   /* [W][G] committedRequests {slot,bnum,bcoord,median} */
   uint8_t* com_flags;                               /* [W][G] */
 };
 
@@ -67,10 +91,10 @@ struct DevScratch {
   int32_t* cnt;      /* [G] per-group record count of the current batch (zero between calls) */
   int32_t* offs;     /* [G] exclusive scan of cnt */
   int32_t* rank;     /* [n] */
-  int4* seg_a;       /* [n] packed record, .w = arrival index */
-  int2* seg_b;       /* [n] */
+  I4* seg_a;       /* [n] packed record, .w = arrival index */
+  I2* seg_b;       /* [n] */
   uint8_t* o_kind;   /* [n] per-record output flag (0 = none) */
-  int4* o_rec;       /* [n] per-record output payload */
+  I4* o_rec;       /* [n] per-record output payload */
   int32_t* blocksum; /* scan partials */
   int32_t* biglist;  /* [1 + cap] count + gidx of long segments */
   unsigned long long* ord; /* [n] (arrival idx << 32 | pos) for long segments, sorted */
@@ -215,15 +239,15 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_fill_ar(
     int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
     const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
     const int32_t* __restrict__ acceptor, const int32_t* __restrict__ max_cp,
-    const int32_t* __restrict__ rank, const int32_t* __restrict__ offs, int4* __restrict__ seg_a,
-    int2* __restrict__ seg_b) {
+    const int32_t* __restrict__ rank, const int32_t* __restrict__ offs, I4* __restrict__ seg_a,
+    I2* __restrict__ seg_b) {
   int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (i >= n) return;
   int32_t r = rank[i];
   if (r < 0) return;
   int32_t pos = offs[gidx[i]] + r;
-  seg_a[pos] = make_int4(slot[i], acceptor[i], max_cp[i], i);
-  seg_b[pos] = make_int2(bnum[i], bcoord[i]);
+  seg_a[pos] = mk4(slot[i], acceptor[i], max_cp[i], i);
+  seg_b[pos] = mk2(bnum[i], bcoord[i]);
 }
 
 /* fill: accepts / commits.  seg_a = {slot, median_cp, flags, idx}, seg_b = {bnum, bcoord} */
@@ -231,15 +255,24 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_fill_ac(
     int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
     const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
     const int32_t* __restrict__ median_cp, const uint8_t* __restrict__ flags,
-    const int32_t* __restrict__ rank, const int32_t* __restrict__ offs, int4* __restrict__ seg_a,
-    int2* __restrict__ seg_b) {
+    const int32_t* __restrict__ rank, const int32_t* __restrict__ offs, I4* __restrict__ seg_a,
+    I2* __restrict__ seg_b, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
+    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags) {
   int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (i >= n) return;
   int32_t r = rank[i];
-  if (r < 0) return;
+  if (r < 0) {
+    if (r_bnum) { /* accept: the dense reply columns of a dropped record read as zero */
+      r_bnum[i] = 0;
+      r_bcoord[i] = 0;
+      r_maxcp[i] = 0;
+      r_flags[i] = 0;
+    }
+    return;
+  }
   int32_t pos = offs[gidx[i]] + r;
-  seg_a[pos] = make_int4(slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0, i);
-  seg_b[pos] = make_int2(bnum[i], bcoord[i]);
+  seg_a[pos] = mk4(slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0, i);
+  seg_b[pos] = mk2(bnum[i], bcoord[i]);
 }
 
 /* fill: proposals.  seg_a = {is_stop, 0, 0, idx} */
@@ -247,13 +280,23 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_fill_pr(int32_t n, const int32_t*
                                                       const uint8_t* __restrict__ is_stop,
                                                       const int32_t* __restrict__ rank,
                                                       const int32_t* __restrict__ offs,
-                                                      int4* __restrict__ seg_a) {
+                                                      I4* __restrict__ seg_a,
+                                                      int32_t* __restrict__ o_slot,
+                                                      int32_t* __restrict__ o_bnum,
+                                                      int32_t* __restrict__ o_bcoord,
+                                                      int32_t* __restrict__ o_median) {
   int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (i >= n) return;
   int32_t r = rank[i];
-  if (r < 0) return;
+  if (r < 0) {
+    o_slot[i] = 0;
+    o_bnum[i] = 0;
+    o_bcoord[i] = 0;
+    o_median[i] = 0;
+    return;
+  }
   int32_t pos = offs[gidx[i]] + r;
-  seg_a[pos] = make_int4(is_stop ? (int32_t)(is_stop[i] & 1) : 0, 0, 0, i);
+  seg_a[pos] = mk4(is_stop ? (int32_t)(is_stop[i] & 1) : 0, 0, 0, i);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -273,7 +316,7 @@ __device__ __forceinline__ void cmpxchg_asc(unsigned long long* a, uint32_t lo, 
 __global__ __launch_bounds__(GPX_BLOCK) void k_sort_big(const int32_t* __restrict__ biglist,
                                                        const int32_t* __restrict__ cnt,
                                                        const int32_t* __restrict__ offs,
-                                                       const int4* __restrict__ seg_a,
+                                                       const I4* __restrict__ seg_a,
                                                        unsigned long long* ord) {
   __shared__ unsigned long long lds[GPX_SORT_LDS_MAX];
   const int32_t nbig = biglist[0];
@@ -311,11 +354,11 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_sort_big(const int32_t* __restric
 /* Iterates one group's records in arrival order.  Short segments: repeated min-scan over
  * the arrival indices (c <= GPX_SMALL_SEG, typically 1..5).  Long: the sorted `ord`. */
 struct SegIter {
-  const int4* seg_a;
+  const I4* seg_a;
   const unsigned long long* ord;
   int32_t base, c, done;
   int32_t last; /* last arrival idx consumed */
-  __device__ __forceinline__ void init(const int4* a, const unsigned long long* o, int32_t b,
+  __device__ __forceinline__ void init(const I4* a, const unsigned long long* o, int32_t b,
                                        int32_t n) {
     seg_a = a;
     ord = o;
@@ -410,8 +453,8 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_ar(DevState S, DevScratch X
   }
   bool ns_dirty = false;
   for (int32_t pos = it.next(); pos >= 0; pos = it.next()) {
-    const int4 ra = X.seg_a[pos];
-    const int2 rb = X.seg_b[pos];
+    const I4 ra = X.seg_a[pos];
+    const I2 rb = X.seg_b[pos];
     const int32_t slot = ra.x, acc = ra.y, maxcp = ra.z, ix = ra.w;
     if (status) status[ix] = GPX_S_OK;
     if (!has_coord) continue; /* PaxosCoordinator.java:196-198: c == null -> null */
@@ -426,7 +469,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_ar(DevState S, DevScratch X
         if (e & PR_PRESENT) {
           *pe = 0;
           pcount--;
-          X.o_rec[ix] = make_int4(my_bnum, my_bcoord, -1, 0); /* preempt(): median stays -1 */
+          X.o_rec[ix] = mk4(my_bnum, my_bcoord, -1, 0); /* preempt(): median stays -1 */
           X.o_kind[ix] = GPX_D_PREEMPTED;
         }
       }
@@ -453,7 +496,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_ar(DevState S, DevScratch X
           if (__popc(e & 0xffffu) > k / 2) { /* heardFromMajority :64-68 */
             *pe = 0;
             pcount--;
-            X.o_rec[ix] = make_int4(my_bnum, my_bcoord, median_minus<KMAX>(ns, k), 0);
+            X.o_rec[ix] = mk4(my_bnum, my_bcoord, median_minus<KMAX>(ns, k), 0);
             X.o_kind[ix] = GPX_D_DECISION;
           } else {
             *pe = e;
@@ -511,27 +554,33 @@ struct Dec {
   bool has_value, stop;
 };
 
-/* PaxosAcceptor.reconstructDecision (PaxosAcceptor.java:369-385) */
+/* PaxosAcceptor.reconstructDecision (PaxosAcceptor.java:369-385).
+ * Written branch-free on purpose.  The natural nested-if form (return early per failed test,
+ * assign *out inside the two succeeding branches) was MISCOMPILED by hipcc (ROCm 7.2, -O3,
+ * gfx950) once inlined into k_apply_accept: after CFG structurization the median of the
+ * "placeholder + matching accept" path was replaced by the failing paths' value (an undefined
+ * register, or 0 when *out was pre-zeroed) — the isolated function's LLVM IR was correct, the
+ * kernel's ISA was not.  Found by the parity fuzz; the select form below has no merge to get
+ * wrong.  All four loads are always in bounds (same ring index for both rings). */
 __device__ __forceinline__ bool acc_reconstruct(const DevState& S, int32_t g, int32_t slot,
                                                 Dec* out) {
   const int64_t o = (int64_t)(slot & (S.W - 1)) * S.G + g;
-  const uint8_t cf = S.com_flags[o];
-  if (!(cf & RF_PRESENT)) return false;
-  const int4 cr = S.com_ring[o];
-  if (cr.x != slot) return false;
-  if (cf & RF_HASVALUE) {
-    *out = Dec{cr.y, cr.z, slot, cr.w, true, (cf & RF_STOP) != 0};
-    return true;
-  }
-  const uint8_t af = S.acc_flags[o];
-  if (af & RF_PRESENT) {
-    const int4 ar = S.acc_ring[o];
-    if (ar.x == slot && ballot_cmp(ar.y, ar.z, cr.y, cr.z) == 0) {
-      *out = Dec{ar.y, ar.z, slot, cr.w, true, (af & RF_STOP) != 0};
-      return true;
-    }
-  }
-  return false;
+  const uint32_t cf = S.com_flags[o];
+  const uint32_t af = S.acc_flags[o];
+  const I4 cr = S.com_ring[o];
+  const I4 ar = S.acc_ring[o];
+  const bool committed = (cf & RF_PRESENT) && cr.x == slot;
+  const bool hasv = (cf & RF_HASVALUE) != 0;
+  const bool acc_ok = (af & RF_PRESENT) && ar.x == slot && ballot_cmp(ar.y, ar.z, cr.y, cr.z) == 0;
+  Dec d;
+  d.bnum = hasv ? cr.y : ar.y;
+  d.bcoord = hasv ? cr.z : ar.z;
+  d.slot = slot;
+  d.median = cr.w; /* the decision keeps the COMMIT's medianCheckpointedSlot (:379-382) */
+  d.has_value = true;
+  d.stop = ((hasv ? cf : af) & RF_STOP) != 0;
+  *out = d;
+  return committed && (hasv || acc_ok);
 }
 
 /* PaxosInstanceStateMachine.extractExecuteAndCheckpoint (PISM:1619-1701) around
@@ -550,12 +599,12 @@ __device__ __forceinline__ int32_t acc_eec(const DevState& S, int32_t g, AccStat
       const uint8_t cf = S.com_flags[o];
       const bool same = (cf & RF_PRESENT) && S.com_ring[o].x == d.slot;
       if (!same || !(cf & RF_HASVALUE)) {
-        S.com_ring[o] = make_int4(d.slot, d.bnum, d.bcoord, d.median);
+        S.com_ring[o] = mk4(d.slot, d.bnum, d.bcoord, d.median);
         S.com_flags[o] =
             (uint8_t)(RF_PRESENT | (d.has_value ? RF_HASVALUE : 0) | (d.stop ? RF_STOP : 0));
       }
     }
-    Dec nx;
+    Dec nx = Dec{0, 0, 0, 0, false, false};
     if (!acc_reconstruct(S, g, a.slot, &nx)) break;
     /* committedRequests.remove(_slot); executed(slot, isStop) */
     const int64_t o0 = (int64_t)(a.slot & Wm) * S.G + g;
@@ -610,8 +659,8 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_accept(
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
   for (int32_t pos = it.next(); pos >= 0; pos = it.next()) {
-    const int4 ra = X.seg_a[pos];
-    const int2 rb = X.seg_b[pos];
+    const I4 ra = X.seg_a[pos];
+    const I2 rb = X.seg_b[pos];
     const int32_t slot = ra.x, median = ra.y, ix = ra.w;
     const bool stop = (ra.z & GPX_A_STOP) != 0;
     r_bnum[ix] = 0;
@@ -626,7 +675,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_accept(
     const int64_t o = (int64_t)(slot & Wm) * S.G + g;
     /* PValuePacket prev = paxosState.getAccept(accept.slot)  (:1122, before accepting) */
     const uint8_t af = S.acc_flags[o];
-    const int4 ar = S.acc_ring[o];
+    const I4 ar = S.acc_ring[o];
     const bool live = (af & RF_PRESENT) != 0;
     const bool have_prev = live && ar.x == slot;
     /* PaxosAcceptor.acceptAndUpdateBallot (PaxosAcceptor.java:302-322) */
@@ -641,7 +690,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_accept(
       a.bnum = rb.x;
       a.bcoord = rb.y;
       if (will_store) {
-        S.acc_ring[o] = make_int4(slot, rb.x, rb.y, 0);
+        S.acc_ring[o] = mk4(slot, rb.x, rb.y, 0);
         S.acc_flags[o] = (uint8_t)(RF_PRESENT | (stop ? RF_STOP : 0));
       }
     }
@@ -656,12 +705,12 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_accept(
     r_flags[ix] = (uint8_t)((to_log ? GPX_R_TOLOG : 0) | (will_store ? GPX_R_STORED : 0));
     status[ix] = GPX_S_OK;
     /* might release some meta-commits (:1158-1161) */
-    Dec rd;
+    Dec rd = Dec{0, 0, 0, 0, false, false};
     if (acc_reconstruct(S, g, slot, &rd)) {
       const int32_t first = a.slot;
       const int32_t cnt_exec = acc_eec(S, g, a, rd);
       if (cnt_exec > 0) {
-        X.o_rec[ix] = make_int4(first, cnt_exec, 0, 0);
+        X.o_rec[ix] = mk4(first, cnt_exec, 0, 0);
         X.o_kind[ix] = 1;
       }
     }
@@ -690,8 +739,8 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_commit(DevState S, DevScrat
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
   for (int32_t pos = it.next(); pos >= 0; pos = it.next()) {
-    const int4 ra = X.seg_a[pos];
-    const int2 rb = X.seg_b[pos];
+    const I4 ra = X.seg_a[pos];
+    const I2 rb = X.seg_b[pos];
     const int32_t slot = ra.x, median = ra.y, kind = ra.z, ix = ra.w;
     if (!exists || a.stopped) {
       status[ix] = exists ? GPX_S_STOPPED : GPX_S_NOGROUP;
@@ -704,14 +753,14 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_commit(DevState S, DevScrat
       continue;
     }
     status[ix] = GPX_S_OK;
-    Dec d;
+    Dec d = Dec{0, 0, 0, 0, false, false};
     if (kind & GPX_C_HASVALUE) {
       d = Dec{rb.x, rb.y, slot, median, true, (kind & GPX_C_STOP) != 0};
     } else {
       /* accept != null && accept.ballot.equals(batchedCommit.ballot) (:1492) */
       const int64_t o = (int64_t)(slot & Wm) * S.G + g;
       const uint8_t af = S.acc_flags[o];
-      const int4 ar = S.acc_ring[o];
+      const I4 ar = S.acc_ring[o];
       if ((af & RF_PRESENT) && ar.x == slot && ballot_cmp(ar.y, ar.z, rb.x, rb.y) == 0)
         d = Dec{ar.y, ar.z, slot, median, true, (af & RF_STOP) != 0};
       else
@@ -720,7 +769,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_commit(DevState S, DevScrat
     const int32_t first = a.slot;
     const int32_t cnt_exec = acc_eec(S, g, a, d);
     if (cnt_exec > 0) {
-      X.o_rec[ix] = make_int4(first, cnt_exec, 0, 0);
+      X.o_rec[ix] = mk4(first, cnt_exec, 0, 0);
       X.o_kind[ix] = 1;
     }
   }
@@ -760,7 +809,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_propose(
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
   for (int32_t pos = it.next(); pos >= 0; pos = it.next()) {
-    const int4 ra = X.seg_a[pos];
+    const I4 ra = X.seg_a[pos];
     const int32_t ix = ra.w;
     const bool stop = ra.x != 0;
     o_slot[ix] = 0;
@@ -812,7 +861,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_propose(
 
 /* decisions: d_* columns; gidx/slot are re-read from the input columns */
 __global__ __launch_bounds__(GPX_BLOCK) void k_compact_dec(
-    int32_t n, const uint8_t* __restrict__ o_kind, const int4* __restrict__ o_rec,
+    int32_t n, const uint8_t* __restrict__ o_kind, const I4* __restrict__ o_rec,
     const int32_t* __restrict__ blocksum, const int32_t* __restrict__ gidx,
     const int32_t* __restrict__ slot, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
     int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
@@ -833,7 +882,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_compact_dec(
   for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
     if (kd[j]) {
       const int64_t i = base + j;
-      const int4 r = o_rec[i];
+      const I4 r = o_rec[i];
       d_gidx[ex] = gidx[i];
       d_slot[ex] = slot[i];
       d_bnum[ex] = r.x;
@@ -847,7 +896,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_compact_dec(
 
 /* exec runs: (gidx, first, count) */
 __global__ __launch_bounds__(GPX_BLOCK) void k_compact_runs(
-    int32_t n, const uint8_t* __restrict__ o_kind, const int4* __restrict__ o_rec,
+    int32_t n, const uint8_t* __restrict__ o_kind, const I4* __restrict__ o_rec,
     const int32_t* __restrict__ blocksum, const int32_t* __restrict__ gidx,
     int32_t* __restrict__ x_gidx, int32_t* __restrict__ x_first, int32_t* __restrict__ x_count) {
   const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE + (int64_t)threadIdx.x * GPX_SCAN_ITEMS;
@@ -866,7 +915,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_compact_runs(
   for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
     if (kd[j]) {
       const int64_t i = base + j;
-      const int4 r = o_rec[i];
+      const I4 r = o_rec[i];
       x_gidx[ex] = gidx[i];
       x_first[ex] = r.x;
       x_count[ex] = r.y;
