@@ -67,7 +67,12 @@ def main():
     rounds = warmup + steps + psteps
     nv_round = G * K + (G * K // 100 + G * K // 200 + G * K // 1000 if args.mix else 0)
     eng = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
-    eng.set_stream(torch.cuda.current_stream().cuda_stream)
+    # a dedicated (non-default) torch stream carries every engine launch, so torch.cuda.Event
+    # and the engine's own hipEvents observe the same stream
+    tstream = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(tstream)
+    assert tstream.cuda_stream != 0
+    eng.set_stream(tstream.cuda_stream)
     mem = np.tile(np.array(members, np.int32), (G, 1))
     assert (eng.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
 
@@ -158,9 +163,23 @@ def main():
         achieved = alg / (avg_ms * 1e-3) / 1e9
         pipe_ms = sum(v[1] for v in kstats.values()) / psteps
         pipe_achieved = alg_bytes_per_vote(K) * nv / (pipe_ms * 1e-3) / 1e9
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
+        # they come from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this
+        # same command, summarised by scripts/rocprof_summary.py into profiles/pmc_traffic.json
+        # (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md §HBM).
+        traffic = traffic_raw = None
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            cands = [(int(k.split("@")[1]), v) for k, v in pmc.items() if k.split("@")[0].split("<")[0] == dom_name]
+            if cands and G == 1_000_000 and K == 3 and not args.mix and not args.sorted:
+                _, v = max(cands, key=lambda kv: kv[0])
+                traffic, traffic_raw = int(v["hbm_bytes_corrected"]), int(v["hbm_bytes_raw"])
+        except (OSError, ValueError, KeyError):
+            pass
         roofline = {
             "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "traffic_raw_counters": traffic_raw,
             "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg),
             "pipeline_ms_per_step": round(pipe_ms, 4),
             "pipeline_achieved": round(pipe_achieved, 1),
