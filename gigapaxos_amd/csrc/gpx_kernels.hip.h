@@ -231,6 +231,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_count(int32_t n, const int32_t* _
     atomicAdd(&counters[2], 1ull);
     return;
   }
+  /* the common per-record status is written here, coalesced; k_apply_* only overwrites the
+   * rare non-OK ones (a per-vote status byte scattered by arrival index from k_apply_ar cost a
+   * 32 B sector write per vote: 96 MB per 3 M-vote batch in the round-1 profile) */
+  if (status && is_votes) status[i] = GPX_S_OK;
   rank[i] = atomicAdd(&cnt[g], 1);
 }
 
@@ -456,7 +460,6 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_ar(DevState S, DevScratch X
     const I4 ra = X.seg_a[pos];
     const I2 rb = X.seg_b[pos];
     const int32_t slot = ra.x, acc = ra.y, maxcp = ra.z, ix = ra.w;
-    if (status) status[ix] = GPX_S_OK;
     if (!has_coord) continue; /* PaxosCoordinator.java:196-198: c == null -> null */
     const int32_t cmp = ballot_cmp(rb.x, rb.y, my_bnum, my_bcoord);
     const int32_t d = jsub(next, slot); /* slot in myProposals' window iff 1 <= d <= W */
@@ -859,13 +862,13 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_propose(
 /* ------------------------------------------------------------------------- */
 /* ordered compaction of the per-record outputs (phase 3 of the flag scan)      */
 
-/* decisions: d_* columns; gidx/slot are re-read from the input columns */
-__global__ __launch_bounds__(GPX_BLOCK) void k_compact_dec(
-    int32_t n, const uint8_t* __restrict__ o_kind, const I4* __restrict__ o_rec,
-    const int32_t* __restrict__ blocksum, const int32_t* __restrict__ gidx,
-    const int32_t* __restrict__ slot, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
-    int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
-    uint8_t* __restrict__ d_kind) {
+/* Both compaction kernels first build the tile's list of flagged record indices in LDS (in
+ * arrival order, via the same blocked scan as phase 1), then thread t gathers the t-th flagged
+ * record and writes output row base+t: every output column is written as a dense coalesced run
+ * (the direct form, each thread storing its own ex++ rows, cost 5x sector write amplification in
+ * the round-1 profile). */
+__device__ __forceinline__ int32_t compact_tile_list(int32_t n, const uint8_t* __restrict__ o_kind,
+                                                     int32_t* lds_idx, uint8_t* lds_kind) {
   const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE + (int64_t)threadIdx.x * GPX_SCAN_ITEMS;
   uint8_t kd[GPX_SCAN_ITEMS];
   int32_t s = 0;
@@ -876,21 +879,39 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_compact_dec(
     s += kd[j] != 0;
   }
   int32_t tot;
-  int32_t ex = block_exscan(s, &tot) + blocksum[blockIdx.x];
-  if (s == 0) return;
+  int32_t ex = block_exscan(s, &tot);
 #pragma unroll
   for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
     if (kd[j]) {
-      const int64_t i = base + j;
-      const I4 r = o_rec[i];
-      d_gidx[ex] = gidx[i];
-      d_slot[ex] = slot[i];
-      d_bnum[ex] = r.x;
-      d_bcoord[ex] = r.y;
-      d_median[ex] = r.z;
-      d_kind[ex] = kd[j];
+      lds_idx[ex] = (int32_t)(base + j);
+      lds_kind[ex] = kd[j];
       ex++;
     }
+  }
+  __syncthreads();
+  return tot;
+}
+
+/* decisions: d_* columns; gidx/slot are re-read from the input columns */
+__global__ __launch_bounds__(GPX_BLOCK) void k_compact_dec(
+    int32_t n, const uint8_t* __restrict__ o_kind, const I4* __restrict__ o_rec,
+    const int32_t* __restrict__ blocksum, const int32_t* __restrict__ gidx,
+    const int32_t* __restrict__ slot, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
+    int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
+    uint8_t* __restrict__ d_kind) {
+  __shared__ int32_t lds_idx[GPX_SCAN_TILE];
+  __shared__ uint8_t lds_kind[GPX_SCAN_TILE];
+  const int32_t tot = compact_tile_list(n, o_kind, lds_idx, lds_kind);
+  const int32_t out0 = blocksum[blockIdx.x];
+  for (int32_t t = threadIdx.x; t < tot; t += GPX_BLOCK) {
+    const int32_t i = lds_idx[t];
+    const I4 r = o_rec[i];
+    d_gidx[out0 + t] = gidx[i];
+    d_slot[out0 + t] = slot[i];
+    d_bnum[out0 + t] = r.x;
+    d_bcoord[out0 + t] = r.y;
+    d_median[out0 + t] = r.z;
+    d_kind[out0 + t] = lds_kind[t];
   }
 }
 
@@ -899,28 +920,16 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_compact_runs(
     int32_t n, const uint8_t* __restrict__ o_kind, const I4* __restrict__ o_rec,
     const int32_t* __restrict__ blocksum, const int32_t* __restrict__ gidx,
     int32_t* __restrict__ x_gidx, int32_t* __restrict__ x_first, int32_t* __restrict__ x_count) {
-  const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE + (int64_t)threadIdx.x * GPX_SCAN_ITEMS;
-  uint8_t kd[GPX_SCAN_ITEMS];
-  int32_t s = 0;
-#pragma unroll
-  for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
-    int64_t i = base + j;
-    kd[j] = (i < n) ? o_kind[i] : 0;
-    s += kd[j] != 0;
-  }
-  int32_t tot;
-  int32_t ex = block_exscan(s, &tot) + blocksum[blockIdx.x];
-  if (s == 0) return;
-#pragma unroll
-  for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
-    if (kd[j]) {
-      const int64_t i = base + j;
-      const I4 r = o_rec[i];
-      x_gidx[ex] = gidx[i];
-      x_first[ex] = r.x;
-      x_count[ex] = r.y;
-      ex++;
-    }
+  __shared__ int32_t lds_idx[GPX_SCAN_TILE];
+  __shared__ uint8_t lds_kind[GPX_SCAN_TILE];
+  const int32_t tot = compact_tile_list(n, o_kind, lds_idx, lds_kind);
+  const int32_t out0 = blocksum[blockIdx.x];
+  for (int32_t t = threadIdx.x; t < tot; t += GPX_BLOCK) {
+    const int32_t i = lds_idx[t];
+    const I4 r = o_rec[i];
+    x_gidx[out0 + t] = gidx[i];
+    x_first[out0 + t] = r.x;
+    x_count[out0 + t] = r.y;
   }
 }
 
