@@ -53,7 +53,7 @@ struct gpx_engine {
   bool profiling = false;
   std::vector<PendingEvent> pending;
   std::map<std::string, std::pair<uint64_t, double>> prof;
-  int32_t biglist_cap = 0;
+  size_t bucket_lds = 0;
   int32_t nb_max = 0;
 };
 
@@ -120,33 +120,34 @@ int flush_profile(gpx_engine* e) {
   return GPX_OK;
 }
 
-#define LAUNCH(e, name, kernel, grid, ...)                                        \
-  do {                                                                            \
-    LaunchScope _ls(e, name);                                                     \
-    hipLaunchKernelGGL(kernel, dim3(grid), dim3(GPX_BLOCK), 0, (e)->stream, __VA_ARGS__); \
+#define LAUNCH_L(e, name, kernel, grid, lds_bytes, ...)                                          \
+  do {                                                                                           \
+    LaunchScope _ls(e, name);                                                                    \
+    hipLaunchKernelGGL(kernel, grid, dim3(GPX_BLOCK), (size_t)(lds_bytes), (e)->stream, __VA_ARGS__); \
   } while (0)
+#define LAUNCH(e, name, kernel, grid, ...) LAUNCH_L(e, name, kernel, dim3(grid), 0, __VA_ARGS__)
 
-/* exclusive scan of cnt[0..G) -> offs; long segments -> biglist */
-void scan_groups(gpx_engine* e) {
-  const int nb = tiles_for(e->cfg.max_groups);
-  LAUNCH(e, "k_scan_reduce_cnt", (k_scan_reduce<0>), nb, (const void*)e->X.cnt, e->cfg.max_groups,
-         e->X.blocksum);
-  LAUNCH(e, "k_scan_top", k_scan_top, 1, e->X.blocksum, nb, (int32_t*)nullptr,
-         (unsigned long long*)nullptr);
-  LAUNCH(e, "k_scan_down_offs", k_scan_down_offs, nb, (const int32_t*)e->X.cnt, e->cfg.max_groups,
-         (const int32_t*)e->X.blocksum, e->X.offs, e->X.biglist, e->biglist_cap);
-}
+/* tiles per column-scan chunk: keeps both scan loops short for any batch size */
+inline int chunk_tiles(int ntiles) { return ntiles <= 1024 ? 16 : 64; }
 
-void sort_big(gpx_engine* e) {
-  LAUNCH(e, "k_sort_big", k_sort_big, 64, (const int32_t*)e->X.biglist, (const int32_t*)e->X.cnt,
-         (const int32_t*)e->X.offs, (const I4*)e->X.seg_a, e->X.ord);
+/* bucket partition front end: histogram per tile, offsets; returns the chunk size used */
+int front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, int is_votes) {
+  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
+  const int tc = chunk_tiles(ntiles);
+  const int nchunks = (ntiles + tc - 1) / tc;
+  const size_t lds = (size_t)e->X.nbk * sizeof(int32_t);
+  LAUNCH_L(e, "k_hist", k_hist, dim3(ntiles), lds, n, gidx, e->S.G, e->X, status, is_votes);
+  LAUNCH_L(e, "k_colscan", k_colscan, dim3((e->X.nbk + GPX_BLOCK - 1) / GPX_BLOCK, nchunks), 0, e->X,
+           ntiles, tc);
+  LAUNCH(e, "k_chunkscan", k_chunkscan, (e->X.nbk + GPX_BLOCK - 1) / GPX_BLOCK, e->X, nchunks);
+  LAUNCH(e, "k_bucketscan", k_bucketscan, 1, e->X);
+  return tc;
 }
 
 /* scan of the per-record output flags; total -> n_out (device) */
 void scan_outputs(gpx_engine* e, int32_t n, int32_t* n_out_dev, unsigned long long* acc = nullptr) {
   const int nb = tiles_for(n);
-  LAUNCH(e, "k_scan_reduce_out", (k_scan_reduce<1>), nb, (const void*)e->X.o_kind, n,
-         e->X.blocksum);
+  LAUNCH(e, "k_flag_reduce", k_flag_reduce, nb, (const uint8_t*)e->X.o_kind, n, e->X.blocksum);
   LAUNCH(e, "k_scan_top", k_scan_top, 1, e->X.blocksum, nb, n_out_dev, acc);
 }
 
@@ -157,14 +158,14 @@ int check_batch(gpx_engine* h, int32_t n) {
 }
 
 template <int KMAX>
-void launch_apply_ar(gpx_engine* e, uint8_t* status) {
-  LAUNCH(e, "k_apply_ar", (k_apply_ar<KMAX>), grid_for(e->cfg.max_groups), e->S, e->X, status);
+void launch_bucket_ar(gpx_engine* e, uint8_t* status) {
+  LAUNCH_L(e, "k_bucket_ar", (k_bucket_ar<KMAX>), dim3(e->X.nbk), e->bucket_lds, e->S, e->X, status);
 }
 template <int KMAX>
-void launch_apply_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t* bcoord,
-                          int32_t* median, uint8_t* status) {
-  LAUNCH(e, "k_apply_propose", (k_apply_propose<KMAX>), grid_for(e->cfg.max_groups), e->S, e->X,
-         slot, bnum, bcoord, median, status);
+void launch_bucket_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t* bcoord,
+                           int32_t* median, uint8_t* status) {
+  LAUNCH_L(e, "k_bucket_propose", (k_bucket_propose<KMAX>), dim3(e->X.nbk), e->bucket_lds, e->S,
+           e->X, slot, bnum, bcoord, median, status);
 }
 
 }  // namespace
@@ -228,18 +229,24 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(S.com_ring, W * G, true);
   A(S.com_flags, W * G, true);
   DevScratch& X = e->X;
-  A(X.cnt, G, true);
-  A(X.offs, G, true);
-  A(X.rank, N, false);
-  A(X.seg_a, N, false);
-  A(X.seg_b, N, false);
+  X.shift = GPX_MIN_SHIFT;
+  while ((int64_t)((G + ((size_t)1 << X.shift) - 1) >> X.shift) > GPX_MAX_BUCKETS) X.shift++;
+  X.gb = 1 << X.shift;
+  X.nbk = (int32_t)((G + (size_t)X.gb - 1) >> X.shift);
+  e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb);
+  const size_t ntiles_max = (N + GPX_TILE - 1) / GPX_TILE;
+  const size_t nchunks_max = (ntiles_max + 15) / 16;
+  A(X.tile_hist, ntiles_max * (size_t)X.nbk, false);
+  A(X.chunk_part, nchunks_max * (size_t)X.nbk, false);
+  A(X.bucket_off, (size_t)X.nbk + 1, true);
+  A(X.rec, N, false);
+  A(X.rank2, N, false);
+  A(X.perm, N, false);
+  A(X.ord, N, false);
   A(X.o_kind, N, true);
   A(X.o_rec, N, false);
-  e->nb_max = std::max(tiles_for((int64_t)G), tiles_for((int64_t)N)) + 1;
+  e->nb_max = tiles_for((int64_t)N) + 1;
   A(X.blocksum, (size_t)e->nb_max, true);
-  e->biglist_cap = (int32_t)(N / (GPX_SMALL_SEG + 1) + 1);
-  A(X.biglist, (size_t)e->biglist_cap + 1, true);
-  A(X.ord, N, false);
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
@@ -325,18 +332,16 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     return GPX_OK;
   }
   gpx_engine* e = h;
-  LAUNCH(e, "k_count", k_count, grid_for(n), n, gidx, e->S.G, e->X.cnt, e->X.rank, e->X.o_kind,
-         status, e->X.counters, e->X.biglist, 1);
-  scan_groups(e);
-  LAUNCH(e, "k_fill_ar", k_fill_ar, grid_for(n), n, gidx, bnum, bcoord, slot, acceptor, max_cp,
-         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b);
-  sort_big(e);
+  const int tc = front_hist(e, n, gidx, status, 1);
+  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
+  LAUNCH_L(e, "k_scatter_ar", k_scatter_ar, dim3(ntiles), (size_t)e->X.nbk * 4, n, e->S.G, tc, e->X,
+           gidx, bnum, bcoord, slot, acceptor, max_cp);
   if (e->cfg.kmax <= 4)
-    launch_apply_ar<4>(e, status);
+    launch_bucket_ar<4>(e, status);
   else if (e->cfg.kmax <= 8)
-    launch_apply_ar<8>(e, status);
+    launch_bucket_ar<8>(e, status);
   else
-    launch_apply_ar<16>(e, status);
+    launch_bucket_ar<16>(e, status);
   scan_outputs(e, n, n_out, &e->X.counters[1]);
   LAUNCH(e, "k_compact_dec", k_compact_dec, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
          (const I4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, slot, d_gidx, d_slot, d_bnum,
@@ -357,15 +362,12 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     return GPX_OK;
   }
   gpx_engine* e = h;
-  LAUNCH(e, "k_count", k_count, grid_for(n), n, gidx, e->S.G, e->X.cnt, e->X.rank, e->X.o_kind,
-         status, e->X.counters, e->X.biglist, 0);
-  scan_groups(e);
-  LAUNCH(e, "k_fill_ac", k_fill_ac, grid_for(n), n, gidx, bnum, bcoord, slot, median_cp, a_flags,
-         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b, r_bnum,
-         r_bcoord, r_maxcp, r_flags);
-  sort_big(e);
-  LAUNCH(e, "k_apply_accept", k_apply_accept, grid_for(e->cfg.max_groups), e->S, e->X, r_bnum,
-         r_bcoord, r_maxcp, r_flags, status);
+  const int tc = front_hist(e, n, gidx, status, 0);
+  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
+  LAUNCH_L(e, "k_scatter_ac", k_scatter_ac, dim3(ntiles), (size_t)e->X.nbk * 4, n, e->S.G, tc, e->X,
+           gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+  LAUNCH_L(e, "k_bucket_accept", k_bucket_accept, dim3(e->X.nbk), e->bucket_lds, e->S, e->X, r_bnum,
+           r_bcoord, r_maxcp, r_flags, status);
   scan_outputs(e, n, n_runs);
   LAUNCH(e, "k_compact_runs", k_compact_runs, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
          (const I4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
@@ -384,14 +386,12 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     return GPX_OK;
   }
   gpx_engine* e = h;
-  LAUNCH(e, "k_count", k_count, grid_for(n), n, gidx, e->S.G, e->X.cnt, e->X.rank, e->X.o_kind,
-         status, e->X.counters, e->X.biglist, 0);
-  scan_groups(e);
-  LAUNCH(e, "k_fill_ac", k_fill_ac, grid_for(n), n, gidx, bnum, bcoord, slot, median_cp, c_kind,
-         (const int32_t*)e->X.rank, (const int32_t*)e->X.offs, e->X.seg_a, e->X.seg_b,
-         (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr);
-  sort_big(e);
-  LAUNCH(e, "k_apply_commit", k_apply_commit, grid_for(e->cfg.max_groups), e->S, e->X, status);
+  const int tc = front_hist(e, n, gidx, status, 0);
+  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
+  LAUNCH_L(e, "k_scatter_ac", k_scatter_ac, dim3(ntiles), (size_t)e->X.nbk * 4, n, e->S.G, tc, e->X,
+           gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
+           (int32_t*)nullptr, (uint8_t*)nullptr);
+  LAUNCH_L(e, "k_bucket_commit", k_bucket_commit, dim3(e->X.nbk), e->bucket_lds, e->S, e->X, status);
   scan_outputs(e, n, n_runs);
   LAUNCH(e, "k_compact_runs", k_compact_runs, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
          (const I4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
@@ -406,18 +406,16 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
   if (rc != GPX_OK) return rc;
   if (n == 0) return GPX_OK;
   gpx_engine* e = h;
-  LAUNCH(e, "k_count", k_count, grid_for(n), n, gidx, e->S.G, e->X.cnt, e->X.rank, e->X.o_kind,
-         status, e->X.counters, e->X.biglist, 0);
-  scan_groups(e);
-  LAUNCH(e, "k_fill_pr", k_fill_pr, grid_for(n), n, gidx, is_stop, (const int32_t*)e->X.rank,
-         (const int32_t*)e->X.offs, e->X.seg_a, slot, bnum, bcoord, median_cp);
-  sort_big(e);
+  const int tc = front_hist(e, n, gidx, status, 0);
+  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
+  LAUNCH_L(e, "k_scatter_pr", k_scatter_pr, dim3(ntiles), (size_t)e->X.nbk * 4, n, e->S.G, tc, e->X,
+           gidx, is_stop, slot, bnum, bcoord, median_cp);
   if (e->cfg.kmax <= 4)
-    launch_apply_propose<4>(e, slot, bnum, bcoord, median_cp, status);
+    launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status);
   else if (e->cfg.kmax <= 8)
-    launch_apply_propose<8>(e, slot, bnum, bcoord, median_cp, status);
+    launch_bucket_propose<8>(e, slot, bnum, bcoord, median_cp, status);
   else
-    launch_apply_propose<16>(e, slot, bnum, bcoord, median_cp, status);
+    launch_bucket_propose<16>(e, slot, bnum, bcoord, median_cp, status);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }

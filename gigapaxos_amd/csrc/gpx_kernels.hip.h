@@ -3,20 +3,24 @@
  *
  * Integer / indexing work only: HBM-bound, no MFMA.  Wave = 64 lanes everywhere.
  *
- * Pipeline of every batch call:
- *   k_count   : one lane per record; rank[i] = atomicAdd(&cnt[gidx[i]], 1)
- *   scan      : exclusive scan of cnt[0..G) -> offs (3 small kernels)
- *   k_fill_*  : record i is packed and written to its group's segment
- *               seg[offs[g] + rank[i]]   (group-contiguous, order inside a segment
- *               is the atomic order, fixed up below)
- *   k_biglist / k_sort_big : segments longer than SMALL_SEG get an arrival-order
- *               permutation from a workgroup-wide bitonic sort
- *   k_apply_* : ONE LANE PER GROUP sweeps groups in gidx order (coalesced SoA state),
- *               replays that group's records in ARRIVAL ORDER exactly as the Java
- *               state machine would (PaxosInstanceStateMachine.handlePaxosMessage once
- *               per record), and writes per-record dense outputs
- *   compact   : scan of the per-record output flags + ordered gather, so decisions /
- *               exec runs leave in the arrival order of the record that produced them
+ * Pipeline of every batch call.  Groups are binned into BUCKETS of
+ * GB = 2^shift consecutive group indices; a batch is partitioned by bucket with LDS histograms
+ * (no global atomics anywhere on the data path), then ONE WORKGROUP PER BUCKET regroups its
+ * records by group in LDS-counted order and ONE LANE PER GROUP replays them in arrival order:
+ *
+ *   k_hist          one workgroup per 4096-record tile: LDS histogram over buckets -> tile_hist
+ *   k_colscan       per bucket: exclusive scan of tile_hist down the tiles (in chunks)
+ *   k_bucket_offs   per bucket: scan of the chunk sums; exclusive scan over buckets -> bucket_off
+ *   k_scatter_*     per tile: record i is packed into a 32-byte Rec and written to its bucket's
+ *                   region (LDS cursor per bucket) — bucket-contiguous, any order inside
+ *   k_bucket_*      per bucket: LDS count per local group -> scan -> perm (records of one group
+ *                   contiguous); long segments (> 16) get a cooperative arrival-order sort;
+ *                   then one lane per group loads its SoA state (coalesced: consecutive lanes own
+ *                   consecutive groups), replays the group's records in ARRIVAL ORDER exactly as
+ *                   PaxosInstanceStateMachine.handlePaxosMessage would, once per record, and
+ *                   writes per-record dense outputs at the record's arrival index
+ *   compact         scan of the per-record output flags + LDS-staged ordered gather, so
+ *                   decisions / exec runs leave in the arrival order of the record that made them
  *
  * Each device function cites the reference method it implements (paths relative to
  * /root/reference/src/edu/umass/cs/gigapaxos/).
@@ -27,14 +31,10 @@
 
 #include "../../include/gpx.h"
 
-/* Plain 16-/8-byte aggregates for packed records and ring entries.  (Deliberately NOT HIP's
- * I4/I2 = HIP_vector_type: with ROCm 7.2 -O3 a `.w` read through its accessor proxy came out
- * undefined on one path of acc_reconstruct; plain structs give the same dwordx4 accesses.) */
+/* Plain aggregates for packed records and ring entries (not HIP's int4: plain structs give the
+ * same dwordx4 accesses and keep the code independent of the vector-type accessor proxies). */
 struct __attribute__((aligned(16))) I4 {
   int32_t x, y, z, w;
-};
-struct __attribute__((aligned(8))) I2 {
-  int32_t x, y;
 };
 __host__ __device__ __forceinline__ I4 mk4(int32_t x, int32_t y, int32_t z, int32_t w) {
   I4 r;
@@ -44,18 +44,22 @@ __host__ __device__ __forceinline__ I4 mk4(int32_t x, int32_t y, int32_t z, int3
   r.w = w;
   return r;
 }
-__host__ __device__ __forceinline__ I2 mk2(int32_t x, int32_t y) {
-  I2 r;
-  r.x = x;
-  r.y = y;
-  return r;
-}
+/* one batch record after partitioning: exactly one 32-byte sector.
+ *   accept-reply: a=slot b=acceptor c=max_cp        accept/commit: a=slot b=median_cp c=flags
+ *   propose:      a=is_stop                          idx = arrival index, lg = gidx & (GB-1) */
+struct __attribute__((aligned(32))) Rec {
+  int32_t a, b, c, idx, bnum, bcoord, lg, pad;
+};
 
 #define GPX_BLOCK 256
-#define GPX_SCAN_ITEMS 8 /* items per thread in the scan kernels */
+#define GPX_TILE 4096 /* records per k_hist / k_scatter workgroup */
+#define GPX_TILE_ITEMS (GPX_TILE / GPX_BLOCK)
+#define GPX_SCAN_ITEMS 8 /* items per thread in the output-flag scan kernels */
 #define GPX_SCAN_TILE (GPX_BLOCK * GPX_SCAN_ITEMS)
-#define GPX_SMALL_SEG 16 /* segments up to this long are ordered by per-lane min-scan */
-#define GPX_SORT_LDS_MAX 4096 /* bitonic in LDS up to this many records */
+#define GPX_SMALL_SEG 16  /* segments up to this long are ordered by per-lane min-scan */
+#define GPX_MIN_SHIFT 8   /* >= 256 groups per bucket */
+#define GPX_LDS_RECS 1024 /* a bucket with at most this many records is regrouped entirely in LDS */
+#define GPX_MAX_BUCKETS 4096
 
 /* group flag word */
 #define GF_EXISTS 1u
@@ -63,7 +67,7 @@ __host__ __device__ __forceinline__ I2 mk2(int32_t x, int32_t y) {
 #define GF_HASCOORD 4u /* PaxosInstanceStateMachine.coordinator != null */
 #define GF_K(f) (((f) >> 8) & 0xffu)
 
-/* proposal ring entry: bits 0..15 = responded mask (WaitforUtility.responded), */
+/* proposal ring entry: bits 0..15 = responded mask (WaitforUtility.responded) */
 #define PR_PRESENT 0x10000u
 #define PR_STOP 0x20000u
 /* accepted / committed ring flags */
@@ -76,29 +80,30 @@ struct DevState {
   uint32_t flags;
   uint32_t* g_flags;
   int32_t* g_version;
-  int32_t *a_slot, *a_bnum, *a_bcoord, *a_gc;       /* PaxosAcceptor.java:94-99 */
-  int32_t *c_bnum, *c_bcoord, *c_next, *c_pcount;   /* PaxosCoordinatorState.java:69-105 */
-  int32_t* members;                                 /* [kmax][G] */
-  int32_t* node_slots;                              /* [kmax][G] nodeSlotNumbers */
-  uint32_t* p_ring;                                 /* [W][G] myProposals */
+  int32_t *a_slot, *a_bnum, *a_bcoord, *a_gc;     /* PaxosAcceptor.java:94-99 */
+  int32_t *c_bnum, *c_bcoord, *c_next, *c_pcount; /* PaxosCoordinatorState.java:69-105 */
+  int32_t* members;                               /* [kmax][G] */
+  int32_t* node_slots;                            /* [kmax][G] nodeSlotNumbers */
+  uint32_t* p_ring;                               /* [W][G] myProposals */
   I4* acc_ring;                                   /* [W][G] acceptedProposals {slot,bnum,bcoord,-} */
-  uint8_t* acc_flags;                               /* [W][G] */
+  uint8_t* acc_flags;                             /* [W][G] */
   I4* com_ring;                                   /* [W][G] committedRequests {slot,bnum,bcoord,median} */
-  uint8_t* com_flags;                               /* [W][G] */
+  uint8_t* com_flags;                             /* [W][G] */
 };
 
 struct DevScratch {
-  int32_t* cnt;      /* [G] per-group record count of the current batch (zero between calls) */
-  int32_t* offs;     /* [G] exclusive scan of cnt */
-  int32_t* rank;     /* [n] */
-  I4* seg_a;       /* [n] packed record, .w = arrival index */
-  I2* seg_b;       /* [n] */
-  uint8_t* o_kind;   /* [n] per-record output flag (0 = none) */
-  I4* o_rec;       /* [n] per-record output payload */
-  int32_t* blocksum; /* scan partials */
-  int32_t* biglist;  /* [1 + cap] count + gidx of long segments */
-  unsigned long long* ord; /* [n] (arrival idx << 32 | pos) for long segments, sorted */
-  unsigned long long* counters; /* [3] votes, decisions, dropped */
+  int32_t shift, nbk, gb; /* bucket = gidx >> shift; nbk buckets of gb = 1 << shift groups */
+  int32_t* tile_hist;     /* [ntiles][nbk] per-tile bucket histogram -> in-chunk exclusive prefix */
+  int32_t* chunk_part;    /* [nchunks][nbk] chunk sums -> exclusive prefix over chunks */
+  int32_t* bucket_off;    /* [nbk + 1] */
+  Rec* rec;               /* [n] bucket-partitioned records */
+  int32_t* rank2;         /* [n] rank of a record among its group's records (LDS atomic order) */
+  int32_t* perm;          /* [n] per bucket: record positions grouped by local group */
+  unsigned long long* ord; /* [n] sort keys of long segments */
+  uint8_t* o_kind;        /* [n] per-record output flag (0 = none) */
+  I4* o_rec;              /* [n] per-record output payload */
+  int32_t* blocksum;      /* output-flag scan partials */
+  unsigned long long* counters; /* [3] votes, outputs (decisions + preempts), dropped */
 };
 
 /* Java int subtraction (wraps) */
@@ -135,181 +140,221 @@ __device__ __forceinline__ int32_t block_exscan(int32_t v, int32_t* total) {
   return base + x - v;
 }
 
-/* scan phase 1: per-tile sums.  MODE 0: int32 input; MODE 1: uint8 flags (!=0 -> 1) */
-template <int MODE>
-__global__ __launch_bounds__(GPX_BLOCK) void k_scan_reduce(const void* in, int32_t n,
-                                                          int32_t* blocksum) {
-  const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE;
-  int32_t s = 0;
-#pragma unroll
-  for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
-    int64_t i = base + j * GPX_BLOCK + threadIdx.x;
-    if (i < n) s += (MODE == 0) ? ((const int32_t*)in)[i] : (((const uint8_t*)in)[i] != 0);
-  }
-  int32_t tot;
-  block_exscan(s, &tot);
-  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
-}
+/* ------------------------------------------------------------------------- */
+/* front end                                                                    */
 
-/* scan phase 2: one block turns the tile sums into exclusive prefixes; total -> *total_out */
-__global__ __launch_bounds__(GPX_BLOCK) void k_scan_top(int32_t* blocksum, int32_t nb,
-                                                       int32_t* total_out,
-                                                       unsigned long long* acc) {
-  __shared__ int32_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
+/* per-tile bucket histogram in LDS; also resets the per-record output flag and writes the
+ * common per-record status (coalesced) so the apply kernels only touch the rare non-OK ones */
+__global__ __launch_bounds__(GPX_BLOCK) void k_hist(int32_t n, const int32_t* __restrict__ gidx,
+                                                   int32_t G, DevScratch X,
+                                                   uint8_t* __restrict__ status,
+                                                   int32_t is_votes) {
+  extern __shared__ int32_t lds[];
+  for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_BLOCK) lds[b] = 0;
   __syncthreads();
-  for (int32_t start = 0; start < nb; start += GPX_BLOCK) {
-    int32_t i = start + threadIdx.x;
-    int32_t v = (i < nb) ? blocksum[i] : 0;
-    int32_t tot;
-    int32_t ex = block_exscan(v, &tot);
-    int32_t carry = carry_s;
-    if (i < nb) blocksum[i] = carry + ex;
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s = carry + tot;
-    __syncthreads();
+  const int64_t base = (int64_t)blockIdx.x * GPX_TILE;
+  int32_t bad = 0;
+#pragma unroll
+  for (int j = 0; j < GPX_TILE_ITEMS; j++) {
+    const int64_t i = base + j * GPX_BLOCK + threadIdx.x;
+    if (i < n) {
+      const int32_t g = gidx[i];
+      X.o_kind[i] = 0;
+      if ((uint32_t)g < (uint32_t)G) {
+        atomicAdd(&lds[g >> X.shift], 1);
+        if (status) status[i] = GPX_S_OK;
+      } else {
+        if (status) status[i] = GPX_S_NOGROUP; /* PaxosManager.java:1162-1194: no such instance */
+        bad++;
+      }
+    }
   }
-  if (threadIdx.x == 0) {
-    if (total_out) *total_out = carry_s;
-    if (acc) atomicAdd(acc, (unsigned long long)carry_s);
-  }
+  if (bad) atomicAdd(&X.counters[2], (unsigned long long)bad);
+  if (blockIdx.x == 0 && threadIdx.x == 0 && is_votes) atomicAdd(&X.counters[0], (unsigned long long)n);
+  __syncthreads();
+  int32_t* out = X.tile_hist + (int64_t)blockIdx.x * X.nbk;
+  for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_BLOCK) out[b] = lds[b];
 }
 
-/* scan phase 3 for the group counts: offs[g] = exclusive prefix.  Thread t owns
- * GPX_SCAN_ITEMS CONSECUTIVE items so a running sum gives the in-tile prefix. */
-__global__ __launch_bounds__(GPX_BLOCK) void k_scan_down_offs(const int32_t* cnt, int32_t n,
-                                                             const int32_t* blocksum,
-                                                             int32_t* offs, int32_t* biglist,
-                                                             int32_t cap) {
-  const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE + (int64_t)threadIdx.x * GPX_SCAN_ITEMS;
-  int32_t v[GPX_SCAN_ITEMS];
+/* exclusive scan of tile_hist down the tiles of one chunk, per bucket; chunk sum -> chunk_part */
+__global__ __launch_bounds__(GPX_BLOCK) void k_colscan(DevScratch X, int32_t ntiles, int32_t tc) {
+  const int32_t b = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (b >= X.nbk) return;
+  const int32_t t0 = blockIdx.y * tc;
+  const int32_t t1 = min(t0 + tc, ntiles);
+  int32_t run = 0;
+  for (int32_t t = t0; t < t1; t++) {
+    int32_t* p = X.tile_hist + (int64_t)t * X.nbk + b;
+    const int32_t v = *p;
+    *p = run;
+    run += v;
+  }
+  X.chunk_part[(int64_t)blockIdx.y * X.nbk + b] = run;
+}
+
+/* per bucket: exclusive scan of the chunk sums (parallel over buckets; loads issued in batches of
+ * 8 so the loop is not one memory latency per chunk); bucket total -> bucket_off[b] (unscanned) */
+__global__ __launch_bounds__(GPX_BLOCK) void k_chunkscan(DevScratch X, int32_t nchunks) {
+  const int32_t b = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (b >= X.nbk) return;
+  int32_t run = 0;
+  for (int32_t c0 = 0; c0 < nchunks; c0 += 8) {
+    int32_t v[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++)
+      v[q] = (c0 + q < nchunks) ? X.chunk_part[(int64_t)(c0 + q) * X.nbk + b] : 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (c0 + q < nchunks) X.chunk_part[(int64_t)(c0 + q) * X.nbk + b] = run;
+      run += v[q];
+    }
+  }
+  X.bucket_off[b] = run;
+}
+
+/* one workgroup: exclusive scan of the bucket totals in place; thread t owns a run of
+ * consecutive buckets, so a single block scan covers all of them (nbk <= 256 * 64) */
+__global__ __launch_bounds__(GPX_BLOCK) void k_bucketscan(DevScratch X) {
+  const int32_t per = (X.nbk + GPX_BLOCK - 1) / GPX_BLOCK;
+  const int32_t b0 = threadIdx.x * per;
+  int32_t v[64];
   int32_t s = 0;
 #pragma unroll
-  for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
-    int64_t i = base + j;
-    v[j] = (i < n) ? cnt[i] : 0;
-    s += v[j];
+  for (int q = 0; q < 64; q++) {
+    if (q < per) {
+      v[q] = (b0 + q < X.nbk) ? X.bucket_off[b0 + q] : 0;
+      s += v[q];
+    }
   }
   int32_t tot;
-  int32_t ex = block_exscan(s, &tot) + blocksum[blockIdx.x];
+  int32_t ex = block_exscan(s, &tot);
 #pragma unroll
-  for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
-    int64_t i = base + j;
-    if (i < n) offs[i] = ex;
-    ex += v[j];
-    if (v[j] > GPX_SMALL_SEG) { /* long segment: needs k_sort_big */
-      int32_t q = atomicAdd(&biglist[0], 1);
-      if (q < cap) biglist[1 + q] = (int32_t)i;
+  for (int q = 0; q < 64; q++) {
+    if (q < per) {
+      if (b0 + q < X.nbk) X.bucket_off[b0 + q] = ex;
+      ex += v[q];
+    }
+  }
+  if (threadIdx.x == 0) X.bucket_off[X.nbk] = tot;
+}
+
+/* LDS cursor per bucket for this tile = bucket_off + chunk prefix + in-chunk tile prefix */
+__device__ __forceinline__ void scatter_init(const DevScratch& X, int32_t* lds, int32_t tc) {
+  const int32_t* th = X.tile_hist + (int64_t)blockIdx.x * X.nbk;
+  const int32_t* cp = X.chunk_part + (int64_t)(blockIdx.x / tc) * X.nbk;
+  for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_BLOCK) lds[b] = X.bucket_off[b] + cp[b] + th[b];
+  __syncthreads();
+}
+
+/* accept-reply votes */
+__global__ __launch_bounds__(GPX_BLOCK) void k_scatter_ar(
+    int32_t n, int32_t G, int32_t tc, DevScratch X, const int32_t* __restrict__ gidx,
+    const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord,
+    const int32_t* __restrict__ slot, const int32_t* __restrict__ acceptor,
+    const int32_t* __restrict__ max_cp) {
+  extern __shared__ int32_t lds[];
+  scatter_init(X, lds, tc);
+  const int64_t base = (int64_t)blockIdx.x * GPX_TILE;
+  const int32_t mask = X.gb - 1;
+#pragma unroll 4
+  for (int j = 0; j < GPX_TILE_ITEMS; j++) {
+    const int64_t i = base + j * GPX_BLOCK + threadIdx.x;
+    if (i < n) {
+      const int32_t g = gidx[i];
+      if ((uint32_t)g < (uint32_t)G) {
+        const int32_t pos = atomicAdd(&lds[g >> X.shift], 1);
+        Rec r;
+        r.a = slot[i];
+        r.b = acceptor[i];
+        r.c = max_cp[i];
+        r.idx = (int32_t)i;
+        r.bnum = bnum[i];
+        r.bcoord = bcoord[i];
+        r.lg = g & mask;
+        r.pad = 0;
+        X.rec[pos] = r;
+      }
     }
   }
 }
 
-/* NOTE: k_scan_reduce sums a tile in strided order, k_scan_down_* in blocked order: both
- * cover the same GPX_SCAN_TILE items of tile blockIdx.x, so the tile sums agree. */
-
-/* ------------------------------------------------------------------------- */
-/* front end: count + rank.  Also clears the per-record output flag and writes  */
-/* the NOGROUP status for out-of-range gidx.                                    */
-__global__ __launch_bounds__(GPX_BLOCK) void k_count(int32_t n, const int32_t* __restrict__ gidx,
-                                                    int32_t G, int32_t* cnt,
-                                                    int32_t* __restrict__ rank,
-                                                    uint8_t* __restrict__ o_kind,
-                                                    uint8_t* __restrict__ status,
-                                                    unsigned long long* counters,
-                                                    int32_t* biglist, int32_t is_votes) {
-  int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  if (i == 0) {
-    biglist[0] = 0; /* consumed by the previous batch's k_sort_big / k_apply (stream order) */
-    if (is_votes) atomicAdd(&counters[0], (unsigned long long)n);
-  }
-  int32_t g = gidx[i];
-  o_kind[i] = 0;
-  if ((uint32_t)g >= (uint32_t)G) {
-    rank[i] = -1;
-    if (status) status[i] = GPX_S_NOGROUP;
-    atomicAdd(&counters[2], 1ull);
-    return;
-  }
-  /* the common per-record status is written here, coalesced; k_apply_* only overwrites the
-   * rare non-OK ones (a per-vote status byte scattered by arrival index from k_apply_ar cost a
-   * 32 B sector write per vote: 96 MB per 3 M-vote batch in the round-1 profile) */
-  if (status && is_votes) status[i] = GPX_S_OK;
-  rank[i] = atomicAdd(&cnt[g], 1);
-}
-
-/* fill: accept-reply votes.  seg_a = {slot, acceptor, max_cp, idx}, seg_b = {bnum, bcoord} */
-__global__ __launch_bounds__(GPX_BLOCK) void k_fill_ar(
-    int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
-    const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
-    const int32_t* __restrict__ acceptor, const int32_t* __restrict__ max_cp,
-    const int32_t* __restrict__ rank, const int32_t* __restrict__ offs, I4* __restrict__ seg_a,
-    I2* __restrict__ seg_b) {
-  int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  int32_t r = rank[i];
-  if (r < 0) return;
-  int32_t pos = offs[gidx[i]] + r;
-  seg_a[pos] = mk4(slot[i], acceptor[i], max_cp[i], i);
-  seg_b[pos] = mk2(bnum[i], bcoord[i]);
-}
-
-/* fill: accepts / commits.  seg_a = {slot, median_cp, flags, idx}, seg_b = {bnum, bcoord} */
-__global__ __launch_bounds__(GPX_BLOCK) void k_fill_ac(
-    int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
-    const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
-    const int32_t* __restrict__ median_cp, const uint8_t* __restrict__ flags,
-    const int32_t* __restrict__ rank, const int32_t* __restrict__ offs, I4* __restrict__ seg_a,
-    I2* __restrict__ seg_b, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
+/* accepts / commits; for accepts also zeroes the dense reply columns of dropped records */
+__global__ __launch_bounds__(GPX_BLOCK) void k_scatter_ac(
+    int32_t n, int32_t G, int32_t tc, DevScratch X, const int32_t* __restrict__ gidx,
+    const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord,
+    const int32_t* __restrict__ slot, const int32_t* __restrict__ median_cp,
+    const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags) {
-  int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  int32_t r = rank[i];
-  if (r < 0) {
-    if (r_bnum) { /* accept: the dense reply columns of a dropped record read as zero */
-      r_bnum[i] = 0;
-      r_bcoord[i] = 0;
-      r_maxcp[i] = 0;
-      r_flags[i] = 0;
+  extern __shared__ int32_t lds[];
+  scatter_init(X, lds, tc);
+  const int64_t base = (int64_t)blockIdx.x * GPX_TILE;
+  const int32_t mask = X.gb - 1;
+#pragma unroll 4
+  for (int j = 0; j < GPX_TILE_ITEMS; j++) {
+    const int64_t i = base + j * GPX_BLOCK + threadIdx.x;
+    if (i < n) {
+      const int32_t g = gidx[i];
+      if ((uint32_t)g < (uint32_t)G) {
+        const int32_t pos = atomicAdd(&lds[g >> X.shift], 1);
+        Rec r;
+        r.a = slot[i];
+        r.b = median_cp[i];
+        r.c = flags ? (int32_t)flags[i] : 0;
+        r.idx = (int32_t)i;
+        r.bnum = bnum[i];
+        r.bcoord = bcoord[i];
+        r.lg = g & mask;
+        r.pad = 0;
+        X.rec[pos] = r;
+      } else if (r_bnum) {
+        r_bnum[i] = 0;
+        r_bcoord[i] = 0;
+        r_maxcp[i] = 0;
+        r_flags[i] = 0;
+      }
     }
-    return;
   }
-  int32_t pos = offs[gidx[i]] + r;
-  seg_a[pos] = mk4(slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0, i);
-  seg_b[pos] = mk2(bnum[i], bcoord[i]);
 }
 
-/* fill: proposals.  seg_a = {is_stop, 0, 0, idx} */
-__global__ __launch_bounds__(GPX_BLOCK) void k_fill_pr(int32_t n, const int32_t* __restrict__ gidx,
-                                                      const uint8_t* __restrict__ is_stop,
-                                                      const int32_t* __restrict__ rank,
-                                                      const int32_t* __restrict__ offs,
-                                                      I4* __restrict__ seg_a,
-                                                      int32_t* __restrict__ o_slot,
-                                                      int32_t* __restrict__ o_bnum,
-                                                      int32_t* __restrict__ o_bcoord,
-                                                      int32_t* __restrict__ o_median) {
-  int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (i >= n) return;
-  int32_t r = rank[i];
-  if (r < 0) {
-    o_slot[i] = 0;
-    o_bnum[i] = 0;
-    o_bcoord[i] = 0;
-    o_median[i] = 0;
-    return;
+/* proposals */
+__global__ __launch_bounds__(GPX_BLOCK) void k_scatter_pr(
+    int32_t n, int32_t G, int32_t tc, DevScratch X, const int32_t* __restrict__ gidx,
+    const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
+    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median) {
+  extern __shared__ int32_t lds[];
+  scatter_init(X, lds, tc);
+  const int64_t base = (int64_t)blockIdx.x * GPX_TILE;
+  const int32_t mask = X.gb - 1;
+#pragma unroll 4
+  for (int j = 0; j < GPX_TILE_ITEMS; j++) {
+    const int64_t i = base + j * GPX_BLOCK + threadIdx.x;
+    if (i < n) {
+      const int32_t g = gidx[i];
+      if ((uint32_t)g < (uint32_t)G) {
+        const int32_t pos = atomicAdd(&lds[g >> X.shift], 1);
+        Rec r;
+        r.a = is_stop ? (int32_t)(is_stop[i] & 1) : 0;
+        r.b = 0;
+        r.c = 0;
+        r.idx = (int32_t)i;
+        r.bnum = 0;
+        r.bcoord = 0;
+        r.lg = g & mask;
+        r.pad = 0;
+        X.rec[pos] = r;
+      } else {
+        o_slot[i] = 0;
+        o_bnum[i] = 0;
+        o_bcoord[i] = 0;
+        o_median[i] = 0;
+      }
+    }
   }
-  int32_t pos = offs[gidx[i]] + r;
-  seg_a[pos] = mk4(is_stop ? (int32_t)(is_stop[i] & 1) : 0, 0, 0, i);
 }
 
 /* ------------------------------------------------------------------------- */
-/* long segments: list them, then sort (arrival idx, pos) per segment           */
-/* one workgroup per long segment: ord[base + j] = key of the j-th record in arrival order,
- * key = (idx << 32) | pos.  Bitonic network in its all-ascending form (first stage of every
- * merge compares t with its mirror t ^ (k-1), the rest with t ^ j): positions >= c behave as
- * +inf simply by being skipped.  In LDS when the segment fits, else in global memory (correct
- * but slow: one hot group is serial under the per-group ordering contract anyway). */
+/* per-bucket regrouping (phases A-D of every k_bucket_* kernel)                */
+
 __device__ __forceinline__ void cmpxchg_asc(unsigned long long* a, uint32_t lo, uint32_t hi) {
   unsigned long long x = a[lo], y = a[hi];
   if (x > y) {
@@ -317,82 +362,197 @@ __device__ __forceinline__ void cmpxchg_asc(unsigned long long* a, uint32_t lo, 
     a[hi] = x;
   }
 }
-__global__ __launch_bounds__(GPX_BLOCK) void k_sort_big(const int32_t* __restrict__ biglist,
-                                                       const int32_t* __restrict__ cnt,
-                                                       const int32_t* __restrict__ offs,
-                                                       const I4* __restrict__ seg_a,
-                                                       unsigned long long* ord) {
-  __shared__ unsigned long long lds[GPX_SORT_LDS_MAX];
-  const int32_t nbig = biglist[0];
-  for (int32_t b = blockIdx.x; b < nbig; b += gridDim.x) {
-    const int32_t g = biglist[1 + b];
-    const uint32_t c = (uint32_t)cnt[g];
-    const int32_t base = offs[g];
-    uint32_t p2 = 1;
-    while (p2 < c) p2 <<= 1;
-    const bool in_lds = c <= GPX_SORT_LDS_MAX;
-    unsigned long long* a = in_lds ? lds : (ord + base);
-    for (uint32_t j = threadIdx.x; j < c; j += GPX_BLOCK)
-      a[j] = ((unsigned long long)(uint32_t)seg_a[base + j].w << 32) | (uint32_t)(base + j);
+
+/* Sorts perm[0 .. c) of ONE long segment by arrival index, cooperatively by the whole workgroup,
+ * through 64-bit keys (idx << 32 | j) in global scratch `a`.  All-ascending bitonic network
+ * (first stage of every merge compares t with its mirror t ^ (k-1), the rest with t ^ j), so
+ * positions >= c behave as +inf simply by being skipped.  A single hot group is inherently serial
+ * under the per-group ordering contract (like the Java monitor); this only has to be correct.
+ * rec / perm may point to LDS or to global memory. */
+__device__ void sort_long_segment(const Rec* rec, int32_t* perm, unsigned long long* a, uint32_t c) {
+  for (uint32_t t = threadIdx.x; t < c; t += GPX_BLOCK) {
+    const int32_t j = perm[t];
+    a[t] = ((unsigned long long)(uint32_t)rec[j].idx << 32) | (uint32_t)j;
+  }
+  __syncthreads();
+  uint32_t p2 = 1;
+  while (p2 < c) p2 <<= 1;
+  for (uint32_t k = 2; k <= p2; k <<= 1) {
+    for (uint32_t t = threadIdx.x; t < c; t += GPX_BLOCK) {
+      const uint32_t q = t ^ (k - 1);
+      if (q > t && q < c) cmpxchg_asc(a, t, q);
+    }
     __syncthreads();
-    for (uint32_t k = 2; k <= p2; k <<= 1) {
+    for (uint32_t j = k >> 2; j > 0; j >>= 1) {
       for (uint32_t t = threadIdx.x; t < c; t += GPX_BLOCK) {
-        const uint32_t q = t ^ (k - 1);
+        const uint32_t q = t ^ j;
         if (q > t && q < c) cmpxchg_asc(a, t, q);
       }
       __syncthreads();
-      for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-        for (uint32_t t = threadIdx.x; t < c; t += GPX_BLOCK) {
-          const uint32_t q = t ^ j;
-          if (q > t && q < c) cmpxchg_asc(a, t, q);
-        }
-        __syncthreads();
-      }
     }
-    if (in_lds)
-      for (uint32_t j = threadIdx.x; j < c; j += GPX_BLOCK) ord[base + j] = lds[j];
-    __syncthreads();
   }
+  for (uint32_t t = threadIdx.x; t < c; t += GPX_BLOCK) perm[t] = (int32_t)(uint32_t)(a[t] & 0xffffffffull);
+  __syncthreads();
 }
 
-/* Iterates one group's records in arrival order.  Short segments: repeated min-scan over
- * the arrival indices (c <= GPX_SMALL_SEG, typically 1..5).  Long: the sorted `ord`. */
-struct SegIter {
-  const I4* seg_a;
-  const unsigned long long* ord;
-  int32_t base, c, done;
-  int32_t last; /* last arrival idx consumed */
-  __device__ __forceinline__ void init(const I4* a, const unsigned long long* o, int32_t b,
-                                       int32_t n) {
-    seg_a = a;
-    ord = o;
-    base = b;
+/* What one workgroup sees of its bucket after regrouping: records (bucket-relative index j) and
+ * perm (records of local group lg at perm[loff[lg] .. loff[lg] + lcnt[lg])).  Both live in LDS
+ * when the bucket has at most GPX_LDS_RECS records (the normal case: ~K records per group), else
+ * in global scratch. */
+struct BucketView {
+  const Rec* rec;
+  int32_t* perm;
+  int32_t* lcnt;
+  int32_t* loff;
+};
+
+/* dynamic LDS of every k_bucket_* kernel: lcnt[gb] | loff[gb] | Rec[GPX_LDS_RECS] | perm[GPX_LDS_RECS] */
+#define GPX_BUCKET_LDS_BYTES(gb) ((size_t)(gb) * 8 + (size_t)GPX_LDS_RECS * (sizeof(Rec) + 4))
+
+/* Returns false (whole workgroup) when the bucket received no record. */
+__device__ __forceinline__ bool bucket_prepare(const DevScratch& X, int32_t* lds, BucketView* bv) {
+  const int32_t b = blockIdx.x;
+  const int32_t boff = X.bucket_off[b];
+  const int32_t nb = X.bucket_off[b + 1] - boff;
+  if (nb == 0) return false;
+  const int32_t gb = X.gb;
+  int32_t* lcnt = lds;
+  int32_t* loff = lds + gb;
+  Rec* recL = (Rec*)(lds + 2 * gb);
+  int32_t* permL = (int32_t*)(recL + GPX_LDS_RECS);
+  const bool in_lds = nb <= GPX_LDS_RECS;
+  const Rec* recG = X.rec + boff;
+  bv->lcnt = lcnt;
+  bv->loff = loff;
+  bv->rec = in_lds ? (const Rec*)recL : recG;
+  bv->perm = in_lds ? permL : (X.perm + boff);
+  for (int32_t l = threadIdx.x; l < gb; l += GPX_BLOCK) lcnt[l] = 0;
+  __syncthreads();
+  /* A: count per local group (LDS atomics); remember each record's rank */
+  int32_t rk[GPX_LDS_RECS / GPX_BLOCK];
+  if (in_lds) {
+#pragma unroll
+    for (int m = 0; m < GPX_LDS_RECS / GPX_BLOCK; m++) {
+      const int32_t j = m * GPX_BLOCK + threadIdx.x;
+      rk[m] = 0;
+      if (j < nb) {
+        const Rec r = recG[j]; /* coalesced 32 B per lane */
+        recL[j] = r;
+        rk[m] = atomicAdd(&lcnt[r.lg], 1);
+      }
+    }
+  } else {
+    for (int32_t j = threadIdx.x; j < nb; j += GPX_BLOCK)
+      X.rank2[boff + j] = atomicAdd(&lcnt[recG[j].lg], 1);
+  }
+  __syncthreads();
+  /* B: exclusive scan lcnt -> loff; thread t owns gb/256 consecutive groups */
+  const int32_t per = gb / GPX_BLOCK;
+  int32_t s = 0;
+  for (int32_t q = 0; q < per; q++) s += lcnt[threadIdx.x * per + q];
+  int32_t tot;
+  int32_t ex = block_exscan(s, &tot);
+  int32_t any_long = 0;
+  for (int32_t q = 0; q < per; q++) {
+    const int32_t l = threadIdx.x * per + q;
+    loff[l] = ex;
+    ex += lcnt[l];
+    any_long |= lcnt[l] > GPX_SMALL_SEG;
+  }
+  any_long = __syncthreads_or(any_long);
+  /* C: perm */
+  if (in_lds) {
+#pragma unroll
+    for (int m = 0; m < GPX_LDS_RECS / GPX_BLOCK; m++) {
+      const int32_t j = m * GPX_BLOCK + threadIdx.x;
+      if (j < nb) permL[loff[recL[j].lg] + rk[m]] = j;
+    }
+  } else {
+    for (int32_t j = threadIdx.x; j < nb; j += GPX_BLOCK)
+      X.perm[boff + loff[recG[j].lg] + X.rank2[boff + j]] = j;
+  }
+  __syncthreads();
+  /* D: arrival-order sort of long segments (rare) */
+  if (any_long) {
+    for (int32_t l = 0; l < gb; l++) {
+      const int32_t c = lcnt[l]; /* uniform across the workgroup */
+      if (c > GPX_SMALL_SEG)
+        sort_long_segment(bv->rec, bv->perm + loff[l], X.ord + boff + loff[l], (uint32_t)c);
+    }
+  }
+  return true;
+}
+
+/* Iterates one group's records in arrival order.  c <= 4: (idx, j) pairs sorted in registers;
+ * c <= GPX_SMALL_SEG: repeated min-scan; longer: perm is already in arrival order. */
+struct GroupIter {
+  const Rec* rec;      /* bucket base */
+  const int32_t* perm; /* segment base */
+  int32_t c, done, last;
+  int32_t j0, j1, j2, j3;
+  __device__ __forceinline__ void init(const Rec* r, const int32_t* p, int32_t n) {
+    rec = r;
+    perm = p;
     c = n;
     done = 0;
     last = -1;
+    j0 = j1 = j2 = j3 = 0;
+    if (n <= 4) {
+      int32_t i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
+      j0 = perm[0];
+      i0 = rec[j0].idx;
+      if (n > 1) {
+        j1 = perm[1];
+        i1 = rec[j1].idx;
+      }
+      if (n > 2) {
+        j2 = perm[2];
+        i2 = rec[j2].idx;
+      }
+      if (n > 3) {
+        j3 = perm[3];
+        i3 = rec[j3].idx;
+      }
+#define GPX_CSWAP(ia, ja, ib, jb) \
+  if (ia > ib) {                  \
+    int32_t t_ = ia;              \
+    ia = ib;                      \
+    ib = t_;                      \
+    t_ = ja;                      \
+    ja = jb;                      \
+    jb = t_;                      \
   }
-  /* returns position in seg arrays of the next record, or -1 */
+      GPX_CSWAP(i0, j0, i1, j1)
+      GPX_CSWAP(i2, j2, i3, j3)
+      GPX_CSWAP(i0, j0, i2, j2)
+      GPX_CSWAP(i1, j1, i3, j3)
+      GPX_CSWAP(i1, j1, i2, j2)
+#undef GPX_CSWAP
+    }
+  }
+  /* bucket-relative record position of the next record, or -1 */
   __device__ __forceinline__ int32_t next() {
     if (done >= c) return -1;
-    int32_t pos;
-    if (c == 1) {
-      pos = base;
+    int32_t j;
+    if (c <= 4) {
+      j = done == 0 ? j0 : (done == 1 ? j1 : (done == 2 ? j2 : j3));
     } else if (c <= GPX_SMALL_SEG) {
-      int32_t best = 0x7fffffff, bp = -1;
-      for (int32_t j = 0; j < c; j++) {
-        int32_t ix = seg_a[base + j].w;
+      int32_t best = 0x7fffffff, bj = -1;
+      for (int32_t t = 0; t < c; t++) {
+        const int32_t jj = perm[t];
+        const int32_t ix = rec[jj].idx;
         if (ix > last && ix < best) {
           best = ix;
-          bp = base + j;
+          bj = jj;
         }
       }
       last = best;
-      pos = bp;
+      j = bj;
     } else {
-      pos = (int32_t)(uint32_t)(ord[base + done] & 0xffffffffull);
+      j = perm[done];
     }
     done++;
-    return pos;
+    return j;
   }
 };
 
@@ -416,31 +576,21 @@ __device__ __forceinline__ int32_t median_minus(const int32_t (&ns)[KMAX], int32
 }
 
 /* ------------------------------------------------------------------------- */
-/* k_apply_ar: the coordinator side — one lane per group.                       */
+/* coordinator side                                                             */
 /* PaxosInstanceStateMachine.handleAcceptReply (PISM:1248-1364) ->              */
 /* PaxosCoordinator.handleAcceptReply (PaxosCoordinator.java:210-250) ->        */
 /* PaxosCoordinatorState.handleAcceptReplyMyBallot / HigherBallot (:597-683)    */
 template <int KMAX>
-__global__ __launch_bounds__(GPX_BLOCK) void k_apply_ar(DevState S, DevScratch X,
-                                                       uint8_t* __restrict__ status) {
-  const int32_t g = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (g >= S.G) return;
-  const int32_t c = X.cnt[g];
-  if (c == 0) return;
-  X.cnt[g] = 0;
-  const int32_t base = X.offs[g];
+__device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScratch& X, int32_t g,
+                                               GroupIter& it, uint8_t* __restrict__ status) {
   const int32_t G = S.G;
-  uint32_t gf = S.g_flags[g];
-  SegIter it;
-  it.init(X.seg_a, X.ord, base, c);
+  const uint32_t gf = S.g_flags[g];
   if (!(gf & GF_EXISTS) || (gf & GF_STOPPED)) {
     /* PaxosManager.java:1162-1194 / PaxosInstanceStateMachine.java:456-460: dropped */
     const uint8_t st = (gf & GF_EXISTS) ? GPX_S_STOPPED : GPX_S_NOGROUP;
-    for (int32_t j = 0; j < c; j++) {
-      int32_t ix = X.seg_a[base + j].w;
-      if (status) status[ix] = st;
-    }
-    atomicAdd(&X.counters[2], (unsigned long long)c); /* rare path */
+    for (int32_t j = it.next(); j >= 0; j = it.next())
+      if (status) status[it.rec[j].idx] = st;
+    atomicAdd(&X.counters[2], (unsigned long long)it.c); /* rare path */
     return;
   }
   const int32_t k = (int32_t)GF_K(gf);
@@ -448,6 +598,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_ar(DevState S, DevScratch X
   const int32_t my_bnum = S.c_bnum[g], my_bcoord = S.c_bcoord[g];
   const int32_t next = S.c_next[g];
   int32_t pcount = S.c_pcount[g];
+  const int32_t pcount0 = pcount;
   const int32_t Wm = S.W - 1;
   int32_t mem[KMAX], ns[KMAX];
 #pragma unroll
@@ -456,12 +607,11 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_ar(DevState S, DevScratch X
     ns[j] = (j < k) ? S.node_slots[(int64_t)j * G + g] : 0;
   }
   bool ns_dirty = false;
-  for (int32_t pos = it.next(); pos >= 0; pos = it.next()) {
-    const I4 ra = X.seg_a[pos];
-    const I2 rb = X.seg_b[pos];
-    const int32_t slot = ra.x, acc = ra.y, maxcp = ra.z, ix = ra.w;
+  for (int32_t j = it.next(); j >= 0; j = it.next()) {
+    const Rec r = it.rec[j];
+    const int32_t slot = r.a, acc = r.b, maxcp = r.c, ix = r.idx;
     if (!has_coord) continue; /* PaxosCoordinator.java:196-198: c == null -> null */
-    const int32_t cmp = ballot_cmp(rb.x, rb.y, my_bnum, my_bcoord);
+    const int32_t cmp = ballot_cmp(r.bnum, r.bcoord, my_bnum, my_bcoord);
     const int32_t d = jsub(next, slot); /* slot in myProposals' window iff 1 <= d <= W */
     const bool inwin = (d >= 1) && (d <= S.W);
     if (cmp > 0) {
@@ -482,11 +632,11 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_ar(DevState S, DevScratch X
       /* handleAcceptReplyMyBallot :597-640; recordSlotNumber :809-825 (plain <) */
       int32_t midx = -1;
 #pragma unroll
-      for (int j = 0; j < KMAX; j++) {
-        if (j < k && mem[j] == acc) {
-          midx = j; /* WaitforUtility.getIndex: last match */
-          if (ns[j] < maxcp) {
-            ns[j] = maxcp;
+      for (int q = 0; q < KMAX; q++) {
+        if (q < k && mem[q] == acc) {
+          midx = q; /* WaitforUtility.getIndex: last match */
+          if (ns[q] < maxcp) {
+            ns[q] = maxcp;
             ns_dirty = true;
           }
         }
@@ -511,11 +661,27 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_ar(DevState S, DevScratch X
   }
   if (ns_dirty) {
 #pragma unroll
-    for (int j = 0; j < KMAX; j++)
-      if (j < k) S.node_slots[(int64_t)j * G + g] = ns[j];
+    for (int q = 0; q < KMAX; q++)
+      if (q < k) S.node_slots[(int64_t)q * G + g] = ns[q];
   }
-  S.c_pcount[g] = pcount;
+  if (pcount != pcount0) S.c_pcount[g] = pcount;
   if (!has_coord && (gf & GF_HASCOORD)) S.g_flags[g] = gf & ~GF_HASCOORD;
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(GPX_BLOCK) void k_bucket_ar(DevState S, DevScratch X,
+                                                        uint8_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(32))) int32_t lds[];
+  BucketView bv;
+  if (!bucket_prepare(X, lds, &bv)) return;
+  const int32_t g0 = blockIdx.x << X.shift;
+  for (int32_t l = threadIdx.x; l < X.gb; l += GPX_BLOCK) {
+    const int32_t c = bv.lcnt[l];
+    if (c == 0 || g0 + l >= S.G) continue;
+    GroupIter it;
+    it.init(bv.rec, bv.perm + bv.loff[l], c);
+    apply_ar_group<KMAX>(S, X, g0 + l, it, status);
+  }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -560,7 +726,7 @@ struct Dec {
 /* PaxosAcceptor.reconstructDecision (PaxosAcceptor.java:369-385).
  * Written branch-free on purpose.  The natural nested-if form (return early per failed test,
  * assign *out inside the two succeeding branches) was MISCOMPILED by hipcc (ROCm 7.2, -O3,
- * gfx950) once inlined into k_apply_accept: after CFG structurization the median of the
+ * gfx950) once inlined into the accept kernel: after CFG structurization the median of the
  * "placeholder + matching accept" path was replaced by the failing paths' value (an undefined
  * register, or 0 when *out was pre-zeroed) — the isolated function's LLVM IR was correct, the
  * kernel's ISA was not.  Found by the parity fuzz; the select form below has no merge to get
@@ -642,30 +808,23 @@ __device__ __forceinline__ void acc_store(const DevState& S, int32_t g, uint32_t
   if (a.stopped && !(gf & GF_STOPPED)) S.g_flags[g] = gf | GF_STOPPED;
 }
 
-/* k_apply_accept: PaxosInstanceStateMachine.handleAccept (PISM:1080-1166) */
-__global__ __launch_bounds__(GPX_BLOCK) void k_apply_accept(
-    DevState S, DevScratch X, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
-    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status) {
-  const int32_t g = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (g >= S.G) return;
-  const int32_t c = X.cnt[g];
-  if (c == 0) return;
-  X.cnt[g] = 0;
-  const int32_t base = X.offs[g];
+/* PaxosInstanceStateMachine.handleAccept (PISM:1080-1166) */
+__device__ __forceinline__ void apply_accept_group(
+    const DevState& S, const DevScratch& X, int32_t g, GroupIter& it, int32_t* __restrict__ r_bnum,
+    int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
+    uint8_t* __restrict__ status) {
   const uint32_t gf = S.g_flags[g];
-  SegIter it;
-  it.init(X.seg_a, X.ord, base, c);
   AccState a;
+  a.slot = a.bnum = a.bcoord = a.gc = 0;
   a.stopped = false;
   const bool exists = (gf & GF_EXISTS) != 0;
   if (exists) acc_load(S, g, gf, a);
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
-  for (int32_t pos = it.next(); pos >= 0; pos = it.next()) {
-    const I4 ra = X.seg_a[pos];
-    const I2 rb = X.seg_b[pos];
-    const int32_t slot = ra.x, median = ra.y, ix = ra.w;
-    const bool stop = (ra.z & GPX_A_STOP) != 0;
+  for (int32_t j = it.next(); j >= 0; j = it.next()) {
+    const Rec r = it.rec[j];
+    const int32_t slot = r.a, median = r.b, ix = r.idx;
+    const bool stop = (r.c & GPX_A_STOP) != 0;
     r_bnum[ix] = 0;
     r_bcoord[ix] = 0;
     r_maxcp[ix] = 0;
@@ -682,7 +841,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_accept(
     const bool live = (af & RF_PRESENT) != 0;
     const bool have_prev = live && ar.x == slot;
     /* PaxosAcceptor.acceptAndUpdateBallot (PaxosAcceptor.java:302-322) */
-    const bool ballot_ok = ballot_cmp(rb.x, rb.y, a.bnum, a.bcoord) >= 0;
+    const bool ballot_ok = ballot_cmp(r.bnum, r.bcoord, a.bnum, a.bcoord) >= 0;
     const bool will_store = ballot_ok && jsub(slot, a.gc) > 0;
     if (will_store && live && ar.x != slot) {
       status[ix] = GPX_S_WINDOW; /* ring slot held by another live accepted slot */
@@ -690,10 +849,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_accept(
       continue;
     }
     if (ballot_ok) {
-      a.bnum = rb.x;
-      a.bcoord = rb.y;
+      a.bnum = r.bnum;
+      a.bcoord = r.bcoord;
       if (will_store) {
-        S.acc_ring[o] = mk4(slot, rb.x, rb.y, 0);
+        S.acc_ring[o] = mk4(slot, r.bnum, r.bcoord, 0);
         S.acc_flags[o] = (uint8_t)(RF_PRESENT | (stop ? RF_STOP : 0));
       }
     }
@@ -703,10 +862,11 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_accept(
     r_bcoord[ix] = a.bcoord;
     r_maxcp[ix] = jsub(a.slot, 1);
     /* toLog (:1146-1149) */
-    const bool to_log = ballot_cmp(rb.x, rb.y, a.bnum, a.bcoord) >= 0 && jsub(slot, a.gc) > 0 &&
-                        (!have_prev || ballot_cmp(ar.y, ar.z, rb.x, rb.y) < 0);
+    const bool to_log = ballot_cmp(r.bnum, r.bcoord, a.bnum, a.bcoord) >= 0 &&
+                        jsub(slot, a.gc) > 0 &&
+                        (!have_prev || ballot_cmp(ar.y, ar.z, r.bnum, r.bcoord) < 0);
     r_flags[ix] = (uint8_t)((to_log ? GPX_R_TOLOG : 0) | (will_store ? GPX_R_STORED : 0));
-    status[ix] = GPX_S_OK;
+    /* status[ix] stays GPX_S_OK (prefilled by k_hist) */
     /* might release some meta-commits (:1158-1161) */
     Dec rd = Dec{0, 0, 0, 0, false, false};
     if (acc_reconstruct(S, g, slot, &rd)) {
@@ -722,29 +882,38 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_accept(
   if (n_drop) atomicAdd(&X.counters[2], n_drop);
 }
 
-/* k_apply_commit: PaxosInstanceStateMachine.handleBatchedCommit (PISM:1480-1528) per slot and
+__global__ __launch_bounds__(GPX_BLOCK) void k_bucket_accept(
+    DevState S, DevScratch X, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
+    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(32))) int32_t lds[];
+  BucketView bv;
+  if (!bucket_prepare(X, lds, &bv)) return;
+  const int32_t g0 = blockIdx.x << X.shift;
+  for (int32_t l = threadIdx.x; l < X.gb; l += GPX_BLOCK) {
+    const int32_t c = bv.lcnt[l];
+    if (c == 0 || g0 + l >= S.G) continue;
+    GroupIter it;
+    it.init(bv.rec, bv.perm + bv.loff[l], c);
+    apply_accept_group(S, X, g0 + l, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+  }
+}
+
+/* PaxosInstanceStateMachine.handleBatchedCommit (PISM:1480-1528) per slot and
  * handleCommittedRequest (:1432-1478) for full decisions */
-__global__ __launch_bounds__(GPX_BLOCK) void k_apply_commit(DevState S, DevScratch X,
-                                                           uint8_t* __restrict__ status) {
-  const int32_t g = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (g >= S.G) return;
-  const int32_t c = X.cnt[g];
-  if (c == 0) return;
-  X.cnt[g] = 0;
-  const int32_t base = X.offs[g];
+__device__ __forceinline__ void apply_commit_group(const DevState& S, const DevScratch& X,
+                                                   int32_t g, GroupIter& it,
+                                                   uint8_t* __restrict__ status) {
   const uint32_t gf = S.g_flags[g];
-  SegIter it;
-  it.init(X.seg_a, X.ord, base, c);
   AccState a;
+  a.slot = a.bnum = a.bcoord = a.gc = 0;
   a.stopped = false;
   const bool exists = (gf & GF_EXISTS) != 0;
   if (exists) acc_load(S, g, gf, a);
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
-  for (int32_t pos = it.next(); pos >= 0; pos = it.next()) {
-    const I4 ra = X.seg_a[pos];
-    const I2 rb = X.seg_b[pos];
-    const int32_t slot = ra.x, median = ra.y, kind = ra.z, ix = ra.w;
+  for (int32_t j = it.next(); j >= 0; j = it.next()) {
+    const Rec r = it.rec[j];
+    const int32_t slot = r.a, median = r.b, kind = r.c, ix = r.idx;
     if (!exists || a.stopped) {
       status[ix] = exists ? GPX_S_STOPPED : GPX_S_NOGROUP;
       n_drop++;
@@ -755,19 +924,18 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_commit(DevState S, DevScrat
       n_drop++;
       continue;
     }
-    status[ix] = GPX_S_OK;
     Dec d = Dec{0, 0, 0, 0, false, false};
     if (kind & GPX_C_HASVALUE) {
-      d = Dec{rb.x, rb.y, slot, median, true, (kind & GPX_C_STOP) != 0};
+      d = Dec{r.bnum, r.bcoord, slot, median, true, (kind & GPX_C_STOP) != 0};
     } else {
       /* accept != null && accept.ballot.equals(batchedCommit.ballot) (:1492) */
       const int64_t o = (int64_t)(slot & Wm) * S.G + g;
       const uint8_t af = S.acc_flags[o];
       const I4 ar = S.acc_ring[o];
-      if ((af & RF_PRESENT) && ar.x == slot && ballot_cmp(ar.y, ar.z, rb.x, rb.y) == 0)
+      if ((af & RF_PRESENT) && ar.x == slot && ballot_cmp(ar.y, ar.z, r.bnum, r.bcoord) == 0)
         d = Dec{ar.y, ar.z, slot, median, true, (af & RF_STOP) != 0};
       else
-        d = Dec{rb.x, rb.y, slot, median, false, false}; /* placeholder (:1510-1520) */
+        d = Dec{r.bnum, r.bcoord, slot, median, false, false}; /* placeholder (:1510-1520) */
     }
     const int32_t first = a.slot;
     const int32_t cnt_exec = acc_eec(S, g, a, d);
@@ -780,22 +948,30 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_commit(DevState S, DevScrat
   if (n_drop) atomicAdd(&X.counters[2], n_drop);
 }
 
-/* k_apply_propose: PaxosInstanceStateMachine.handleProposal (PISM:818-888) ->
+__global__ __launch_bounds__(GPX_BLOCK) void k_bucket_commit(DevState S, DevScratch X,
+                                                            uint8_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(32))) int32_t lds[];
+  BucketView bv;
+  if (!bucket_prepare(X, lds, &bv)) return;
+  const int32_t g0 = blockIdx.x << X.shift;
+  for (int32_t l = threadIdx.x; l < X.gb; l += GPX_BLOCK) {
+    const int32_t c = bv.lcnt[l];
+    if (c == 0 || g0 + l >= S.G) continue;
+    GroupIter it;
+    it.init(bv.rec, bv.perm + bv.loff[l], c);
+    apply_commit_group(S, X, g0 + l, it, status);
+  }
+}
+
+/* PaxosInstanceStateMachine.handleProposal (PISM:818-888) ->
  * PaxosCoordinatorState.propose (:233-263) + initCommander (:841-851) */
 template <int KMAX>
-__global__ __launch_bounds__(GPX_BLOCK) void k_apply_propose(
-    DevState S, DevScratch X, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
-    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status) {
-  const int32_t g = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (g >= S.G) return;
-  const int32_t c = X.cnt[g];
-  if (c == 0) return;
-  X.cnt[g] = 0;
-  const int32_t base = X.offs[g];
+__device__ __forceinline__ void apply_propose_group(
+    const DevState& S, const DevScratch& X, int32_t g, GroupIter& it, int32_t* __restrict__ o_slot,
+    int32_t* __restrict__ o_bnum, int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median,
+    uint8_t* __restrict__ status) {
   const int32_t G = S.G;
   const uint32_t gf = S.g_flags[g];
-  SegIter it;
-  it.init(X.seg_a, X.ord, base, c);
   const bool exists = (gf & GF_EXISTS) != 0, stopped = (gf & GF_STOPPED) != 0;
   const int32_t k = (int32_t)GF_K(gf);
   const int32_t a_bnum = exists ? S.a_bnum[g] : 0, a_bcoord = exists ? S.a_bcoord[g] : 0;
@@ -807,14 +983,14 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_propose(
   int32_t pcount = coord_ok ? S.c_pcount[g] : 0;
   int32_t ns[KMAX];
 #pragma unroll
-  for (int j = 0; j < KMAX; j++) ns[j] = (coord_ok && j < k) ? S.node_slots[(int64_t)j * G + g] : 0;
+  for (int q = 0; q < KMAX; q++) ns[q] = (coord_ok && q < k) ? S.node_slots[(int64_t)q * G + g] : 0;
   const int32_t median = coord_ok ? median_minus<KMAX>(ns, k) : 0;
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
-  for (int32_t pos = it.next(); pos >= 0; pos = it.next()) {
-    const I4 ra = X.seg_a[pos];
-    const int32_t ix = ra.w;
-    const bool stop = ra.x != 0;
+  for (int32_t j = it.next(); j >= 0; j = it.next()) {
+    const Rec r = it.rec[j];
+    const int32_t ix = r.idx;
+    const bool stop = r.a != 0;
     o_slot[ix] = 0;
     o_bnum[ix] = 0;
     o_bcoord[ix] = 0;
@@ -849,7 +1025,6 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_propose(
     o_bnum[ix] = my_bnum;
     o_bcoord[ix] = my_bcoord;
     o_median[ix] = median; /* getMajorityCommittedSlot: nodeSlots unchanged by propose */
-    status[ix] = GPX_S_OK;
     next = (int32_t)((uint32_t)next + 1u);
   }
   if (coord_ok) {
@@ -859,14 +1034,68 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_apply_propose(
   if (n_drop) atomicAdd(&X.counters[2], n_drop);
 }
 
-/* ------------------------------------------------------------------------- */
-/* ordered compaction of the per-record outputs (phase 3 of the flag scan)      */
+template <int KMAX>
+__global__ __launch_bounds__(GPX_BLOCK) void k_bucket_propose(
+    DevState S, DevScratch X, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
+    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(32))) int32_t lds[];
+  BucketView bv;
+  if (!bucket_prepare(X, lds, &bv)) return;
+  const int32_t g0 = blockIdx.x << X.shift;
+  for (int32_t l = threadIdx.x; l < X.gb; l += GPX_BLOCK) {
+    const int32_t c = bv.lcnt[l];
+    if (c == 0 || g0 + l >= S.G) continue;
+    GroupIter it;
+    it.init(bv.rec, bv.perm + bv.loff[l], c);
+    apply_propose_group<KMAX>(S, X, g0 + l, it, o_slot, o_bnum, o_bcoord, o_median, status);
+  }
+}
 
-/* Both compaction kernels first build the tile's list of flagged record indices in LDS (in
- * arrival order, via the same blocked scan as phase 1), then thread t gathers the t-th flagged
- * record and writes output row base+t: every output column is written as a dense coalesced run
- * (the direct form, each thread storing its own ex++ rows, cost 5x sector write amplification in
- * the round-1 profile). */
+/* ------------------------------------------------------------------------- */
+/* ordered compaction of the per-record outputs                                 */
+
+/* phase 1: per-tile count of flagged records */
+__global__ __launch_bounds__(GPX_BLOCK) void k_flag_reduce(const uint8_t* __restrict__ o_kind,
+                                                          int32_t n, int32_t* blocksum) {
+  const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE;
+  int32_t s = 0;
+#pragma unroll
+  for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
+    int64_t i = base + j * GPX_BLOCK + threadIdx.x;
+    if (i < n) s += o_kind[i] != 0;
+  }
+  int32_t tot;
+  block_exscan(s, &tot);
+  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
+}
+
+/* phase 2: one block turns the tile sums into exclusive prefixes; total -> *total_out */
+__global__ __launch_bounds__(GPX_BLOCK) void k_scan_top(int32_t* blocksum, int32_t nb,
+                                                       int32_t* total_out,
+                                                       unsigned long long* acc) {
+  __shared__ int32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (int32_t start = 0; start < nb; start += GPX_BLOCK) {
+    int32_t i = start + threadIdx.x;
+    int32_t v = (i < nb) ? blocksum[i] : 0;
+    int32_t tot;
+    int32_t ex = block_exscan(v, &tot);
+    int32_t carry = carry_s;
+    if (i < nb) blocksum[i] = carry + ex;
+    __syncthreads();
+    if (threadIdx.x == 0) carry_s = carry + tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    if (total_out) *total_out = carry_s;
+    if (acc) atomicAdd(acc, (unsigned long long)carry_s);
+  }
+}
+
+/* phase 3: the tile's flagged record indices go to LDS in arrival order (blocked scan: thread t
+ * owns GPX_SCAN_ITEMS consecutive records), then thread t gathers the t-th flagged record and
+ * writes output row base+t, so every output column is written as a dense coalesced run. */
 __device__ __forceinline__ int32_t compact_tile_list(int32_t n, const uint8_t* __restrict__ o_kind,
                                                      int32_t* lds_idx, uint8_t* lds_kind) {
   const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE + (int64_t)threadIdx.x * GPX_SCAN_ITEMS;
