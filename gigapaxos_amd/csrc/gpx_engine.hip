@@ -8,11 +8,13 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
 #include <vector>
 #include <algorithm>
+#include <initializer_list>
 
 #include "gpx_kernels.hip.h"
 
@@ -54,6 +56,7 @@ struct gpx_engine {
   std::vector<PendingEvent> pending;
   std::map<std::string, std::pair<uint64_t, double>> prof;
   size_t bucket_lds = 0;
+  int bucket_threads = 256;
   int32_t nb_max = 0;
 };
 
@@ -126,29 +129,46 @@ int flush_profile(gpx_engine* e) {
     hipLaunchKernelGGL(kernel, grid, dim3(GPX_BLOCK), (size_t)(lds_bytes), (e)->stream, __VA_ARGS__); \
   } while (0)
 #define LAUNCH(e, name, kernel, grid, ...) LAUNCH_L(e, name, kernel, dim3(grid), 0, __VA_ARGS__)
+/* per-bucket kernels: one workgroup per bucket, one lane per group (up to 1024) */
+#define LAUNCH_B(e, name, kernel, ...)                                                            \
+  do {                                                                                            \
+    LaunchScope _ls(e, name);                                                                     \
+    hipLaunchKernelGGL(kernel, dim3((e)->X.nbk), dim3((e)->bucket_threads), (e)->bucket_lds,      \
+                       (e)->stream, __VA_ARGS__);                                                 \
+  } while (0)
+/* streaming kernels: GPX_FBLOCK threads */
+#define LAUNCH_F(e, name, kernel, grid, lds_bytes, ...)                                           \
+  do {                                                                                            \
+    LaunchScope _ls(e, name);                                                                     \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(GPX_FBLOCK), (size_t)(lds_bytes), (e)->stream,    \
+                       __VA_ARGS__);                                                              \
+  } while (0)
 
-/* tiles per column-scan chunk: keeps both scan loops short for any batch size */
-inline int chunk_tiles(int ntiles) { return ntiles <= 1024 ? 16 : 64; }
-
-/* bucket partition front end: histogram per tile, offsets; returns the chunk size used */
-int front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, int is_votes) {
-  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
-  const int tc = chunk_tiles(ntiles);
-  const int nchunks = (ntiles + tc - 1) / tc;
-  const size_t lds = (size_t)e->X.nbk * sizeof(int32_t);
-  LAUNCH_L(e, "k_hist", k_hist, dim3(ntiles), lds, n, gidx, e->S.G, e->X, status, is_votes);
-  LAUNCH_L(e, "k_colscan", k_colscan, dim3((e->X.nbk + GPX_BLOCK - 1) / GPX_BLOCK, nchunks), 0, e->X,
-           ntiles, tc);
-  LAUNCH(e, "k_chunkscan", k_chunkscan, (e->X.nbk + GPX_BLOCK - 1) / GPX_BLOCK, e->X, nchunks);
-  LAUNCH(e, "k_bucketscan", k_bucketscan, 1, e->X);
-  return tc;
+inline int ntiles_for(int64_t n) { return (int)((n + GPX_TILE - 1) / GPX_TILE); }
+/* k_hist / k_scatter grids: 8 XCD slices of ceil(ntiles / 8) tiles (tile_of_block) */
+inline int tile_grid(int ntiles) { return 8 * ((ntiles + 7) / 8); }
+inline bool aligned16(std::initializer_list<const void*> ps) {
+  for (const void* p : ps)
+    if ((uintptr_t)p & 15) return false;
+  return true;
 }
 
-/* scan of the per-record output flags; total -> n_out (device) */
-void scan_outputs(gpx_engine* e, int32_t n, int32_t* n_out_dev, unsigned long long* acc = nullptr) {
-  const int nb = tiles_for(n);
-  LAUNCH(e, "k_flag_reduce", k_flag_reduce, nb, (const uint8_t*)e->X.o_kind, n, e->X.blocksum);
-  LAUNCH(e, "k_scan_top", k_scan_top, 1, e->X.blocksum, nb, n_out_dev, acc);
+/* bucket partition front end, part 1: per-bucket record counts of the batch */
+void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, int is_votes) {
+  const int ntiles = ntiles_for(n);
+  const size_t lds = (size_t)e->X.nbk * sizeof(int32_t);
+  if (aligned16({gidx}))
+    LAUNCH_F(e, "k_hist", k_hist<true>, tile_grid(ntiles), lds, n, ntiles, gidx, e->S.G, e->X, status,
+             is_votes);
+  else
+    LAUNCH_F(e, "k_hist", k_hist<false>, tile_grid(ntiles), lds, n, ntiles, gidx, e->S.G, e->X, status,
+             is_votes);
+}
+
+/* per-tile counts of the per-record output flags */
+void scan_outputs(gpx_engine* e, int32_t n) {
+  LAUNCH_F(e, "k_flag_reduce", k_flag_reduce, tiles_for(n), 0, (const uint8_t*)e->X.o_kind, n,
+           e->X.blocksum);
 }
 
 int check_batch(gpx_engine* h, int32_t n) {
@@ -159,13 +179,13 @@ int check_batch(gpx_engine* h, int32_t n) {
 
 template <int KMAX>
 void launch_bucket_ar(gpx_engine* e, uint8_t* status) {
-  LAUNCH_L(e, "k_bucket_ar", (k_bucket_ar<KMAX>), dim3(e->X.nbk), e->bucket_lds, e->S, e->X, status);
+  LAUNCH_B(e, "k_bucket_ar", (k_bucket_ar<KMAX>), e->S, e->X, status);
 }
 template <int KMAX>
 void launch_bucket_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t* bcoord,
                            int32_t* median, uint8_t* status) {
-  LAUNCH_L(e, "k_bucket_propose", (k_bucket_propose<KMAX>), dim3(e->X.nbk), e->bucket_lds, e->S,
-           e->X, slot, bnum, bcoord, median, status);
+  LAUNCH_B(e, "k_bucket_propose", (k_bucket_propose<KMAX>), e->S, e->X, slot, bnum, bcoord, median,
+           status);
 }
 
 }  // namespace
@@ -229,20 +249,44 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(S.com_ring, W * G, true);
   A(S.com_flags, W * G, true);
   DevScratch& X = e->X;
+  /* buckets of 256 groups (one lane per group, whole bucket staged in LDS, 4 workgroups per
+   * CU); beyond 1M groups the buckets grow so that there are at most GPX_MAX_BUCKETS */
+  auto nbk_for = [&](int sh) { return (int64_t)((G + ((size_t)1 << sh) - 1) >> sh); };
   X.shift = GPX_MIN_SHIFT;
-  while ((int64_t)((G + ((size_t)1 << X.shift) - 1) >> X.shift) > GPX_MAX_BUCKETS) X.shift++;
+  while (nbk_for(X.shift) > GPX_MAX_BUCKETS) X.shift++;
+  if (const char* sh = getenv("GPX_BUCKET_SHIFT")) { /* tuning knob */
+    const int v = atoi(sh);
+    if (v >= GPX_MIN_SHIFT && v <= 20 && nbk_for(v) <= GPX_MAX_BUCKETS) X.shift = v;
+  }
   X.gb = 1 << X.shift;
-  X.nbk = (int32_t)((G + (size_t)X.gb - 1) >> X.shift);
-  e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb);
-  const size_t ntiles_max = (N + GPX_TILE - 1) / GPX_TILE;
-  const size_t nchunks_max = (ntiles_max + 15) / 16;
-  A(X.tile_hist, ntiles_max * (size_t)X.nbk, false);
-  A(X.chunk_part, nchunks_max * (size_t)X.nbk, false);
+  X.nbk = (int32_t)nbk_for(X.shift);
+  e->bucket_threads = std::min(1024, X.gb);
+  /* LDS staging capacity: the expected kmax * gb records of a full round + ~7 sigma, within
+   * 8 records per thread and the CU's 160 KiB; 960 (K <= 3, gb 256) keeps 4 workgroups per CU */
+  {
+    int64_t want = (int64_t)cfg->kmax * X.gb;
+    want += want / 4 + 64;
+    if (cfg->kmax <= 3 && X.gb == 256) want = 960;
+    const int64_t lds_cap = ((int64_t)160 * 1024 - 1024 - (int64_t)X.gb * 8) / (8 + (int64_t)sizeof(Rec));
+    want = std::min<int64_t>(want, std::min<int64_t>(lds_cap, (int64_t)GPX_BUCKET_ITEMS * e->bucket_threads));
+    if (const char* lr = getenv("GPX_LDS_RECS")) want = std::min<int64_t>(want, std::max(64, atoi(lr)));
+    X.lds_recs = (int32_t)want;
+  }
+  e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs);
+  if (e->bucket_lds > 64 * 1024) { /* more dynamic LDS than the default limit: opt in per kernel */
+    const void* fns[] = {(const void*)k_bucket_ar<4>,      (const void*)k_bucket_ar<8>,
+                         (const void*)k_bucket_ar<16>,     (const void*)k_bucket_propose<4>,
+                         (const void*)k_bucket_propose<8>, (const void*)k_bucket_propose<16>,
+                         (const void*)k_bucket_accept,     (const void*)k_bucket_commit};
+    for (const void* f : fns)
+      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bucket_lds));
+  }
+  A(X.bucket_tot, (size_t)X.nbk, true);
+  A(X.tile_rel, ((N + GPX_TILE - 1) / GPX_TILE) * (size_t)X.nbk, false);
   A(X.bucket_off, (size_t)X.nbk + 1, true);
   A(X.rec, N, false);
   A(X.rank2, N, false);
   A(X.perm, N, false);
-  A(X.ord, N, false);
   A(X.o_kind, N, true);
   A(X.o_rec, N, false);
   e->nb_max = tiles_for((int64_t)N) + 1;
@@ -332,20 +376,24 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     return GPX_OK;
   }
   gpx_engine* e = h;
-  const int tc = front_hist(e, n, gidx, status, 1);
-  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
-  LAUNCH_L(e, "k_scatter_ar", k_scatter_ar, dim3(ntiles), (size_t)e->X.nbk * 4, n, e->S.G, tc, e->X,
-           gidx, bnum, bcoord, slot, acceptor, max_cp);
+  front_hist(e, n, gidx, status, 1);
+  const int ntiles = ntiles_for(n);
+  if (aligned16({gidx, bnum, bcoord, slot, acceptor, max_cp}))
+    LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+             ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+  else
+    LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+             ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
   if (e->cfg.kmax <= 4)
     launch_bucket_ar<4>(e, status);
   else if (e->cfg.kmax <= 8)
     launch_bucket_ar<8>(e, status);
   else
     launch_bucket_ar<16>(e, status);
-  scan_outputs(e, n, n_out, &e->X.counters[1]);
-  LAUNCH(e, "k_compact_dec", k_compact_dec, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
-         (const I4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, slot, d_gidx, d_slot, d_bnum,
-         d_bcoord, d_median_cp, d_kind);
+  scan_outputs(e, n);
+  LAUNCH_F(e, "k_compact_dec", k_compact_dec, tiles_for(n), 0, n, (const uint8_t*)e->X.o_kind,
+           (const Out*)e->X.o_rec, (const int32_t*)e->X.blocksum, d_gidx, d_slot, d_bnum, d_bcoord,
+           d_median_cp, d_kind, n_out, &e->X.counters[1]);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -362,15 +410,16 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     return GPX_OK;
   }
   gpx_engine* e = h;
-  const int tc = front_hist(e, n, gidx, status, 0);
-  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
-  LAUNCH_L(e, "k_scatter_ac", k_scatter_ac, dim3(ntiles), (size_t)e->X.nbk * 4, n, e->S.G, tc, e->X,
+  front_hist(e, n, gidx, status, 0);
+  const int ntiles = ntiles_for(n);
+  LAUNCH_F(e, "k_scatter_ac", k_scatter_ac, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
+           e->S.G, e->X,
            gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
-  LAUNCH_L(e, "k_bucket_accept", k_bucket_accept, dim3(e->X.nbk), e->bucket_lds, e->S, e->X, r_bnum,
-           r_bcoord, r_maxcp, r_flags, status);
-  scan_outputs(e, n, n_runs);
-  LAUNCH(e, "k_compact_runs", k_compact_runs, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
-         (const I4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
+  LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags,
+           status);
+  scan_outputs(e, n);
+  LAUNCH_F(e, "k_compact_runs", k_compact_runs, tiles_for(n), 0, n, (const uint8_t*)e->X.o_kind,
+           (const Out*)e->X.o_rec, (const int32_t*)e->X.blocksum, x_gidx, x_first, x_count, n_runs);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -386,15 +435,16 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     return GPX_OK;
   }
   gpx_engine* e = h;
-  const int tc = front_hist(e, n, gidx, status, 0);
-  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
-  LAUNCH_L(e, "k_scatter_ac", k_scatter_ac, dim3(ntiles), (size_t)e->X.nbk * 4, n, e->S.G, tc, e->X,
+  front_hist(e, n, gidx, status, 0);
+  const int ntiles = ntiles_for(n);
+  LAUNCH_F(e, "k_scatter_ac", k_scatter_ac, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
+           e->S.G, e->X,
            gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
            (int32_t*)nullptr, (uint8_t*)nullptr);
-  LAUNCH_L(e, "k_bucket_commit", k_bucket_commit, dim3(e->X.nbk), e->bucket_lds, e->S, e->X, status);
-  scan_outputs(e, n, n_runs);
-  LAUNCH(e, "k_compact_runs", k_compact_runs, tiles_for(n), n, (const uint8_t*)e->X.o_kind,
-         (const I4*)e->X.o_rec, (const int32_t*)e->X.blocksum, gidx, x_gidx, x_first, x_count);
+  LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
+  scan_outputs(e, n);
+  LAUNCH_F(e, "k_compact_runs", k_compact_runs, tiles_for(n), 0, n, (const uint8_t*)e->X.o_kind,
+           (const Out*)e->X.o_rec, (const int32_t*)e->X.blocksum, x_gidx, x_first, x_count, n_runs);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -406,9 +456,10 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
   if (rc != GPX_OK) return rc;
   if (n == 0) return GPX_OK;
   gpx_engine* e = h;
-  const int tc = front_hist(e, n, gidx, status, 0);
-  const int ntiles = (int)(((int64_t)n + GPX_TILE - 1) / GPX_TILE);
-  LAUNCH_L(e, "k_scatter_pr", k_scatter_pr, dim3(ntiles), (size_t)e->X.nbk * 4, n, e->S.G, tc, e->X,
+  front_hist(e, n, gidx, status, 0);
+  const int ntiles = ntiles_for(n);
+  LAUNCH_F(e, "k_scatter_pr", k_scatter_pr, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
+           e->S.G, e->X,
            gidx, is_stop, slot, bnum, bcoord, median_cp);
   if (e->cfg.kmax <= 4)
     launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status);

@@ -48,17 +48,37 @@ __host__ __device__ __forceinline__ I4 mk4(int32_t x, int32_t y, int32_t z, int3
  *   accept-reply: a=slot b=acceptor c=max_cp        accept/commit: a=slot b=median_cp c=flags
  *   propose:      a=is_stop                          idx = arrival index, lg = gidx & (GB-1) */
 struct __attribute__((aligned(32))) Rec {
-  int32_t a, b, c, idx, bnum, bcoord, lg, pad;
+  int32_t idx, lg, a, b, c, bnum, bcoord, pad;
 };
+/* one per-record output (decision / preempt / exec run), written as one full 32-byte sector at
+ * the record's arrival index and gathered by the ordered compaction:
+ *   accept-reply: x=bnum y=bcoord z=median_cp, slot=slot    exec runs: x=first y=count */
+struct __attribute__((aligned(32))) Out {
+  int32_t gidx, slot, x, y, z, kind, pad0, pad1;
+};
+__device__ __forceinline__ Out mk_out(int32_t gidx, int32_t slot, int32_t x, int32_t y, int32_t z,
+                                      int32_t kind) {
+  Out o;
+  o.gidx = gidx;
+  o.slot = slot;
+  o.x = x;
+  o.y = y;
+  o.z = z;
+  o.kind = kind;
+  o.pad0 = 0;
+  o.pad1 = 0;
+  return o;
+}
 
-#define GPX_BLOCK 256
-#define GPX_TILE 4096 /* records per k_hist / k_scatter workgroup */
-#define GPX_TILE_ITEMS (GPX_TILE / GPX_BLOCK)
-#define GPX_SCAN_ITEMS 8 /* items per thread in the output-flag scan kernels */
-#define GPX_SCAN_TILE (GPX_BLOCK * GPX_SCAN_ITEMS)
+#define GPX_BLOCK 256   /* threads of a per-bucket / lifecycle workgroup */
+#define GPX_FBLOCK 1024 /* threads of a streaming (histogram / scatter / compaction) workgroup */
+#define GPX_TILE 8192   /* records per streaming workgroup */
+#define GPX_TILE_ITEMS (GPX_TILE / GPX_FBLOCK)
+#define GPX_TILE_VECS (GPX_TILE_ITEMS / 4)
+#define GPX_SCAN_ITEMS 8 /* records per thread in the output-flag kernels (one 8-byte load) */
+#define GPX_SCAN_TILE (GPX_FBLOCK * GPX_SCAN_ITEMS)
 #define GPX_SMALL_SEG 16  /* segments up to this long are ordered by per-lane min-scan */
 #define GPX_MIN_SHIFT 8   /* >= 256 groups per bucket */
-#define GPX_LDS_RECS 1024 /* a bucket with at most this many records is regrouped entirely in LDS */
 #define GPX_MAX_BUCKETS 4096
 
 /* group flag word */
@@ -93,15 +113,15 @@ struct DevState {
 
 struct DevScratch {
   int32_t shift, nbk, gb; /* bucket = gidx >> shift; nbk buckets of gb = 1 << shift groups */
-  int32_t* tile_hist;     /* [ntiles][nbk] per-tile bucket histogram -> in-chunk exclusive prefix */
-  int32_t* chunk_part;    /* [nchunks][nbk] chunk sums -> exclusive prefix over chunks */
-  int32_t* bucket_off;    /* [nbk + 1] */
+  int32_t lds_recs;       /* a bucket with at most this many records is regrouped entirely in LDS */
+  int32_t* bucket_tot;    /* [nbk] records per bucket of the current batch (k_hist; re-zeroed by k_bucket_*) */
+  int32_t* tile_rel;      /* [ntiles][nbk] start of each tile's slice inside each bucket region (k_hist) */
+  int32_t* bucket_off;    /* [nbk + 1] exclusive prefix of bucket_tot (written by tile 0 of k_scatter_*) */
   Rec* rec;               /* [n] bucket-partitioned records */
   int32_t* rank2;         /* [n] rank of a record among its group's records (LDS atomic order) */
-  int32_t* perm;          /* [n] per bucket: record positions grouped by local group */
-  unsigned long long* ord; /* [n] sort keys of long segments */
+  unsigned long long* perm; /* [n] sort keys (arrival idx << 32 | position) of buckets too big for LDS */
   uint8_t* o_kind;        /* [n] per-record output flag (0 = none) */
-  I4* o_rec;              /* [n] per-record output payload */
+  Out* o_rec;             /* [n] per-record output payload */
   int32_t* blocksum;      /* output-flag scan partials */
   unsigned long long* counters; /* [3] votes, outputs (decisions + preempts), dropped */
 };
@@ -117,20 +137,26 @@ __device__ __forceinline__ int32_t ballot_cmp(int32_t n1, int32_t c1, int32_t n2
 
 /* ------------------------------------------------------------------------- */
 /* block-wide exclusive scan of one int per thread (256 threads = 4 waves)     */
-__device__ __forceinline__ int32_t block_exscan(int32_t v, int32_t* total) {
-  __shared__ int32_t wsum[GPX_BLOCK / 64];
-  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+__device__ __forceinline__ int32_t wave_incscan(int32_t v) {
+  const int lane = threadIdx.x & 63;
   int32_t x = v;
 #pragma unroll
   for (int d = 1; d < 64; d <<= 1) {
     int32_t y = __shfl_up(x, d, 64);
     if (lane >= d) x += y;
   }
+  return x;
+}
+template <int NT>
+__device__ __forceinline__ int32_t block_exscan_n(int32_t v, int32_t* total) {
+  __shared__ int32_t wsum[NT / 64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int32_t x = wave_incscan(v);
   if (lane == 63) wsum[wid] = x;
   __syncthreads();
   int32_t base = 0, tot = 0;
 #pragma unroll
-  for (int w = 0; w < GPX_BLOCK / 64; w++) {
+  for (int w = 0; w < NT / 64; w++) {
     int32_t s = wsum[w];
     if (w < wid) base += s;
     tot += s;
@@ -139,174 +165,238 @@ __device__ __forceinline__ int32_t block_exscan(int32_t v, int32_t* total) {
   *total = tot;
   return base + x - v;
 }
+__device__ __forceinline__ int32_t block_exscan(int32_t v, int32_t* total) {
+  return block_exscan_n<GPX_BLOCK>(v, total);
+}
 
 /* ------------------------------------------------------------------------- */
-/* front end                                                                    */
+/* front end: bucket partition without a per-tile histogram matrix               */
+/*   k_hist      per tile: LDS histogram -> one global atomicAdd per touched bucket into bucket_tot
+ *   k_scatter_* per tile: LDS histogram again, every workgroup scans bucket_tot itself (nbk <= 4096
+ *               ints from L2), reserves its slice of each bucket region with ONE returning global
+ *               atomic per touched bucket (cursor), then writes its records there.  The order
+ *               inside a bucket region is whatever the atomics gave: every record carries its
+ *               arrival index and the per-bucket kernels restore arrival order per group.
+ * Streaming workgroups are 1024 threads x 8 records: the chip holds only a few hundred tiles, so
+ * the loads of a tile must all be in flight at once (16 waves per tile, 2 x 16-byte loads per
+ * column per lane). */
 
-/* per-tile bucket histogram in LDS; also resets the per-record output flag and writes the
- * common per-record status (coalesced) so the apply kernels only touch the rare non-OK ones */
-__global__ __launch_bounds__(GPX_BLOCK) void k_hist(int32_t n, const int32_t* __restrict__ gidx,
-                                                   int32_t G, DevScratch X,
-                                                   uint8_t* __restrict__ status,
-                                                   int32_t is_votes) {
-  extern __shared__ int32_t lds[];
-  for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_BLOCK) lds[b] = 0;
-  __syncthreads();
-  const int64_t base = (int64_t)blockIdx.x * GPX_TILE;
+/* Workgroup -> tile.  Block b runs on XCD b % 8 (observed dispatch order; only speed depends on
+ * it): each XCD gets a contiguous run of tiles. */
+__device__ __forceinline__ int32_t tile_of_block(int32_t ntiles) {
+  const int32_t per = (ntiles + 7) >> 3;
+  return (int32_t)(blockIdx.x & 7) * per + (int32_t)(blockIdx.x >> 3);
+}
+
+/* LDS histogram of one tile over buckets; returns the number of out-of-range gidx seen by this
+ * lane.  VEC: gidx is 16-byte aligned -> 4 consecutive records per lane per load. */
+template <bool VEC>
+__device__ __forceinline__ int32_t tile_histogram(int32_t n, int64_t base,
+                                                  const int32_t* __restrict__ gidx, int32_t G,
+                                                  int32_t shift, int32_t* lds) {
   int32_t bad = 0;
+  if (VEC) {
 #pragma unroll
-  for (int j = 0; j < GPX_TILE_ITEMS; j++) {
-    const int64_t i = base + j * GPX_BLOCK + threadIdx.x;
-    if (i < n) {
-      const int32_t g = gidx[i];
-      X.o_kind[i] = 0;
-      if ((uint32_t)g < (uint32_t)G) {
-        atomicAdd(&lds[g >> X.shift], 1);
-        if (status) status[i] = GPX_S_OK;
+    for (int j = 0; j < GPX_TILE_VECS; j++) {
+      const int64_t i0 = base + (int64_t)(j * GPX_FBLOCK + threadIdx.x) * 4;
+      if (i0 + 3 < n) {
+        const I4 g4 = *(const I4*)(gidx + i0);
+        const int32_t gg[4] = {g4.x, g4.y, g4.z, g4.w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if ((uint32_t)gg[q] < (uint32_t)G)
+            atomicAdd(&lds[gg[q] >> shift], 1);
+          else
+            bad++;
+        }
       } else {
-        if (status) status[i] = GPX_S_NOGROUP; /* PaxosManager.java:1162-1194: no such instance */
-        bad++;
+        for (int q = 0; q < 4; q++) {
+          if (i0 + q < n) {
+            const int32_t g = gidx[i0 + q];
+            if ((uint32_t)g < (uint32_t)G)
+              atomicAdd(&lds[g >> shift], 1);
+            else
+              bad++;
+          }
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < GPX_TILE_ITEMS; j++) {
+      const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
+      if (i < n) {
+        const int32_t g = gidx[i];
+        if ((uint32_t)g < (uint32_t)G)
+          atomicAdd(&lds[g >> shift], 1);
+        else
+          bad++;
+      }
+    }
+  }
+  return bad;
+}
+
+/* per-tile bucket histogram -> bucket_tot; also resets the per-record output flag and writes the
+ * common per-record status (coalesced) so the apply kernels only touch the rare non-OK ones */
+template <bool VEC>
+__global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
+                                                    const int32_t* __restrict__ gidx, int32_t G,
+                                                    DevScratch X, uint8_t* __restrict__ status,
+                                                    int32_t is_votes) {
+  extern __shared__ int32_t lds[];
+  const int32_t tile = tile_of_block(ntiles);
+  if (tile >= ntiles) return;
+  for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_FBLOCK) lds[b] = 0;
+  __syncthreads();
+  const int64_t base = (int64_t)tile * GPX_TILE;
+  const int32_t bad = tile_histogram<VEC>(n, base, gidx, G, X.shift, lds);
+  /* flags + status: 8 consecutive records per lane (o_kind is ours: 8-byte aligned) */
+  {
+    const int64_t i0 = base + (int64_t)threadIdx.x * 8;
+    if (i0 + 7 < n && !((uintptr_t)status & 7)) {
+      *(unsigned long long*)(X.o_kind + i0) = 0ull;
+      if (status) {
+        unsigned long long st = 0;
+        for (int q = 0; q < 8; q++)
+          if ((uint32_t)gidx[i0 + q] >= (uint32_t)G) st |= (unsigned long long)GPX_S_NOGROUP << (8 * q);
+        *(unsigned long long*)(status + i0) = st; /* GPX_S_OK == 0; PaxosManager.java:1162-1194 */
+      }
+    } else {
+      for (int q = 0; q < 8; q++) {
+        const int64_t i = i0 + q;
+        if (i < n) {
+          X.o_kind[i] = 0;
+          if (status) status[i] = ((uint32_t)gidx[i] < (uint32_t)G) ? GPX_S_OK : GPX_S_NOGROUP;
+        }
       }
     }
   }
   if (bad) atomicAdd(&X.counters[2], (unsigned long long)bad);
-  if (blockIdx.x == 0 && threadIdx.x == 0 && is_votes) atomicAdd(&X.counters[0], (unsigned long long)n);
+  if (tile == 0 && threadIdx.x == 0 && is_votes) atomicAdd(&X.counters[0], (unsigned long long)n);
   __syncthreads();
-  int32_t* out = X.tile_hist + (int64_t)blockIdx.x * X.nbk;
-  for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_BLOCK) out[b] = lds[b];
-}
-
-/* exclusive scan of tile_hist down the tiles of one chunk, per bucket; chunk sum -> chunk_part */
-__global__ __launch_bounds__(GPX_BLOCK) void k_colscan(DevScratch X, int32_t ntiles, int32_t tc) {
-  const int32_t b = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (b >= X.nbk) return;
-  const int32_t t0 = blockIdx.y * tc;
-  const int32_t t1 = min(t0 + tc, ntiles);
-  int32_t run = 0;
-  for (int32_t t = t0; t < t1; t++) {
-    int32_t* p = X.tile_hist + (int64_t)t * X.nbk + b;
-    const int32_t v = *p;
-    *p = run;
-    run += v;
+  /* reserve this tile's slice of every bucket region: one returning atomic per touched bucket.
+   * The order of the slices inside a region is whatever the atomics give (records carry their
+   * arrival index; the per-bucket kernels restore arrival order per group). */
+  int32_t* rel = X.tile_rel + (int64_t)tile * X.nbk;
+  for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_FBLOCK) {
+    const int32_t c = lds[b];
+    rel[b] = c ? atomicAdd(&X.bucket_tot[b], c) : 0;
   }
-  X.chunk_part[(int64_t)blockIdx.y * X.nbk + b] = run;
 }
 
-/* per bucket: exclusive scan of the chunk sums (parallel over buckets; loads issued in batches of
- * 8 so the loop is not one memory latency per chunk); bucket total -> bucket_off[b] (unscanned) */
-__global__ __launch_bounds__(GPX_BLOCK) void k_chunkscan(DevScratch X, int32_t nchunks) {
-  const int32_t b = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (b >= X.nbk) return;
-  int32_t run = 0;
-  for (int32_t c0 = 0; c0 < nchunks; c0 += 8) {
-    int32_t v[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++)
-      v[q] = (c0 + q < nchunks) ? X.chunk_part[(int64_t)(c0 + q) * X.nbk + b] : 0;
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      if (c0 + q < nchunks) X.chunk_part[(int64_t)(c0 + q) * X.nbk + b] = run;
-      run += v[q];
-    }
-  }
-  X.bucket_off[b] = run;
-}
-
-/* one workgroup: exclusive scan of the bucket totals in place; thread t owns a run of
- * consecutive buckets, so a single block scan covers all of them (nbk <= 256 * 64) */
-__global__ __launch_bounds__(GPX_BLOCK) void k_bucketscan(DevScratch X) {
-  const int32_t per = (X.nbk + GPX_BLOCK - 1) / GPX_BLOCK;
+/* Leaves in lds[b] the position where this tile's next record of bucket b goes: every workgroup
+ * scans the bucket totals itself (nbk <= 4096 ints from L2: thread t owns `per` <= 4 consecutive
+ * buckets) and adds the slice start k_hist reserved for it. */
+__device__ __forceinline__ void scatter_init(const DevScratch& X, int32_t tile, int32_t* lds) {
+  const int32_t per = (X.nbk + GPX_FBLOCK - 1) / GPX_FBLOCK;
   const int32_t b0 = threadIdx.x * per;
-  int32_t v[64];
+  const int32_t* rel = X.tile_rel + (int64_t)tile * X.nbk;
+  int32_t v[GPX_MAX_BUCKETS / GPX_FBLOCK], rl[GPX_MAX_BUCKETS / GPX_FBLOCK];
   int32_t s = 0;
 #pragma unroll
-  for (int q = 0; q < 64; q++) {
-    if (q < per) {
-      v[q] = (b0 + q < X.nbk) ? X.bucket_off[b0 + q] : 0;
-      s += v[q];
-    }
+  for (int q = 0; q < GPX_MAX_BUCKETS / GPX_FBLOCK; q++) {
+    const bool on = q < per && b0 + q < X.nbk;
+    v[q] = on ? X.bucket_tot[b0 + q] : 0;
+    rl[q] = on ? rel[b0 + q] : 0;
+    s += v[q];
   }
   int32_t tot;
-  int32_t ex = block_exscan(s, &tot);
+  int32_t ex = block_exscan_n<GPX_FBLOCK>(s, &tot);
 #pragma unroll
-  for (int q = 0; q < 64; q++) {
-    if (q < per) {
-      if (b0 + q < X.nbk) X.bucket_off[b0 + q] = ex;
+  for (int q = 0; q < GPX_MAX_BUCKETS / GPX_FBLOCK; q++) {
+    const int32_t b = b0 + q;
+    if (q < per && b < X.nbk) {
+      lds[b] = ex + rl[q];
+      if (tile == 0) X.bucket_off[b] = ex;
       ex += v[q];
     }
   }
-  if (threadIdx.x == 0) X.bucket_off[X.nbk] = tot;
-}
-
-/* LDS cursor per bucket for this tile = bucket_off + chunk prefix + in-chunk tile prefix */
-__device__ __forceinline__ void scatter_init(const DevScratch& X, int32_t* lds, int32_t tc) {
-  const int32_t* th = X.tile_hist + (int64_t)blockIdx.x * X.nbk;
-  const int32_t* cp = X.chunk_part + (int64_t)(blockIdx.x / tc) * X.nbk;
-  for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_BLOCK) lds[b] = X.bucket_off[b] + cp[b] + th[b];
+  if (tile == 0 && threadIdx.x == 0) X.bucket_off[X.nbk] = tot;
   __syncthreads();
 }
 
+__device__ __forceinline__ void put_rec(const DevScratch& X, int32_t* lds, int32_t G, int32_t mask,
+                                        int64_t i, int32_t g, int32_t a, int32_t b, int32_t c,
+                                        int32_t bnum, int32_t bcoord) {
+  if ((uint32_t)g < (uint32_t)G) {
+    const int32_t pos = atomicAdd(&lds[g >> X.shift], 1);
+    Rec r;
+    r.idx = (int32_t)i;
+    r.lg = g & mask;
+    r.a = a;
+    r.b = b;
+    r.c = c;
+    r.bnum = bnum;
+    r.bcoord = bcoord;
+    r.pad = 0;
+    X.rec[pos] = r;
+  }
+}
+
 /* accept-reply votes */
-__global__ __launch_bounds__(GPX_BLOCK) void k_scatter_ar(
-    int32_t n, int32_t G, int32_t tc, DevScratch X, const int32_t* __restrict__ gidx,
+template <bool VEC>
+__global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ar(
+    int32_t n, int32_t ntiles, int32_t G, DevScratch X, const int32_t* __restrict__ gidx,
     const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord,
     const int32_t* __restrict__ slot, const int32_t* __restrict__ acceptor,
     const int32_t* __restrict__ max_cp) {
   extern __shared__ int32_t lds[];
-  scatter_init(X, lds, tc);
-  const int64_t base = (int64_t)blockIdx.x * GPX_TILE;
+  const int32_t tile = tile_of_block(ntiles);
+  if (tile >= ntiles) return;
+  scatter_init(X, tile, lds);
+  const int64_t base = (int64_t)tile * GPX_TILE;
   const int32_t mask = X.gb - 1;
-#pragma unroll 4
-  for (int j = 0; j < GPX_TILE_ITEMS; j++) {
-    const int64_t i = base + j * GPX_BLOCK + threadIdx.x;
-    if (i < n) {
-      const int32_t g = gidx[i];
-      if ((uint32_t)g < (uint32_t)G) {
-        const int32_t pos = atomicAdd(&lds[g >> X.shift], 1);
-        Rec r;
-        r.a = slot[i];
-        r.b = acceptor[i];
-        r.c = max_cp[i];
-        r.idx = (int32_t)i;
-        r.bnum = bnum[i];
-        r.bcoord = bcoord[i];
-        r.lg = g & mask;
-        r.pad = 0;
-        X.rec[pos] = r;
+  if (VEC) {
+#pragma unroll
+    for (int j = 0; j < GPX_TILE_VECS; j++) {
+      const int64_t i0 = base + (int64_t)(j * GPX_FBLOCK + threadIdx.x) * 4;
+      if (i0 + 3 < n) {
+        const I4 g4 = *(const I4*)(gidx + i0), s4 = *(const I4*)(slot + i0);
+        const I4 a4 = *(const I4*)(acceptor + i0), m4 = *(const I4*)(max_cp + i0);
+        const I4 n4 = *(const I4*)(bnum + i0), c4 = *(const I4*)(bcoord + i0);
+        put_rec(X, lds, G, mask, i0 + 0, g4.x, s4.x, a4.x, m4.x, n4.x, c4.x);
+        put_rec(X, lds, G, mask, i0 + 1, g4.y, s4.y, a4.y, m4.y, n4.y, c4.y);
+        put_rec(X, lds, G, mask, i0 + 2, g4.z, s4.z, a4.z, m4.z, n4.z, c4.z);
+        put_rec(X, lds, G, mask, i0 + 3, g4.w, s4.w, a4.w, m4.w, n4.w, c4.w);
+      } else {
+        for (int q = 0; q < 4; q++) {
+          const int64_t i = i0 + q;
+          if (i < n)
+            put_rec(X, lds, G, mask, i, gidx[i], slot[i], acceptor[i], max_cp[i], bnum[i], bcoord[i]);
+        }
       }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < GPX_TILE_ITEMS; j++) {
+      const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
+      if (i < n) put_rec(X, lds, G, mask, i, gidx[i], slot[i], acceptor[i], max_cp[i], bnum[i], bcoord[i]);
     }
   }
 }
 
 /* accepts / commits; for accepts also zeroes the dense reply columns of dropped records */
-__global__ __launch_bounds__(GPX_BLOCK) void k_scatter_ac(
-    int32_t n, int32_t G, int32_t tc, DevScratch X, const int32_t* __restrict__ gidx,
+__global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ac(
+    int32_t n, int32_t ntiles, int32_t G, DevScratch X, const int32_t* __restrict__ gidx,
     const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord,
     const int32_t* __restrict__ slot, const int32_t* __restrict__ median_cp,
     const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags) {
   extern __shared__ int32_t lds[];
-  scatter_init(X, lds, tc);
-  const int64_t base = (int64_t)blockIdx.x * GPX_TILE;
+  const int32_t tile = tile_of_block(ntiles);
+  if (tile >= ntiles) return;
+  scatter_init(X, tile, lds);
+  const int64_t base = (int64_t)tile * GPX_TILE;
   const int32_t mask = X.gb - 1;
-#pragma unroll 4
+#pragma unroll
   for (int j = 0; j < GPX_TILE_ITEMS; j++) {
-    const int64_t i = base + j * GPX_BLOCK + threadIdx.x;
+    const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
     if (i < n) {
       const int32_t g = gidx[i];
-      if ((uint32_t)g < (uint32_t)G) {
-        const int32_t pos = atomicAdd(&lds[g >> X.shift], 1);
-        Rec r;
-        r.a = slot[i];
-        r.b = median_cp[i];
-        r.c = flags ? (int32_t)flags[i] : 0;
-        r.idx = (int32_t)i;
-        r.bnum = bnum[i];
-        r.bcoord = bcoord[i];
-        r.lg = g & mask;
-        r.pad = 0;
-        X.rec[pos] = r;
-      } else if (r_bnum) {
+      put_rec(X, lds, G, mask, i, g, slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0, bnum[i],
+              bcoord[i]);
+      if ((uint32_t)g >= (uint32_t)G && r_bnum) {
         r_bnum[i] = 0;
         r_bcoord[i] = 0;
         r_maxcp[i] = 0;
@@ -317,32 +407,23 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_scatter_ac(
 }
 
 /* proposals */
-__global__ __launch_bounds__(GPX_BLOCK) void k_scatter_pr(
-    int32_t n, int32_t G, int32_t tc, DevScratch X, const int32_t* __restrict__ gidx,
+__global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_pr(
+    int32_t n, int32_t ntiles, int32_t G, DevScratch X, const int32_t* __restrict__ gidx,
     const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median) {
   extern __shared__ int32_t lds[];
-  scatter_init(X, lds, tc);
-  const int64_t base = (int64_t)blockIdx.x * GPX_TILE;
+  const int32_t tile = tile_of_block(ntiles);
+  if (tile >= ntiles) return;
+  scatter_init(X, tile, lds);
+  const int64_t base = (int64_t)tile * GPX_TILE;
   const int32_t mask = X.gb - 1;
-#pragma unroll 4
+#pragma unroll
   for (int j = 0; j < GPX_TILE_ITEMS; j++) {
-    const int64_t i = base + j * GPX_BLOCK + threadIdx.x;
+    const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
     if (i < n) {
       const int32_t g = gidx[i];
-      if ((uint32_t)g < (uint32_t)G) {
-        const int32_t pos = atomicAdd(&lds[g >> X.shift], 1);
-        Rec r;
-        r.a = is_stop ? (int32_t)(is_stop[i] & 1) : 0;
-        r.b = 0;
-        r.c = 0;
-        r.idx = (int32_t)i;
-        r.bnum = 0;
-        r.bcoord = 0;
-        r.lg = g & mask;
-        r.pad = 0;
-        X.rec[pos] = r;
-      } else {
+      put_rec(X, lds, G, mask, i, g, is_stop ? (int32_t)(is_stop[i] & 1) : 0, 0, 0, 0, 0);
+      if ((uint32_t)g >= (uint32_t)G) {
         o_slot[i] = 0;
         o_bnum[i] = 0;
         o_bcoord[i] = 0;
@@ -354,6 +435,11 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_scatter_pr(
 
 /* ------------------------------------------------------------------------- */
 /* per-bucket regrouping (phases A-D of every k_bucket_* kernel)                */
+/* A bucket with at most X.lds_recs records (the normal case: ~K records per group) is staged in
+ * LDS whole: 32-byte records + one 8-byte sort key each (arrival idx << 32 | bucket-relative
+ * record position j).  Bigger buckets (a hot group) keep records and keys in global memory.
+ * (Measured on MI355X: re-reading single records from L2 in the apply phase instead of staging
+ * them doubles the kernel's time.) */
 
 __device__ __forceinline__ void cmpxchg_asc(unsigned long long* a, uint32_t lo, uint32_t hi) {
   unsigned long long x = a[lo], y = a[hi];
@@ -363,95 +449,110 @@ __device__ __forceinline__ void cmpxchg_asc(unsigned long long* a, uint32_t lo, 
   }
 }
 
-/* Sorts perm[0 .. c) of ONE long segment by arrival index, cooperatively by the whole workgroup,
- * through 64-bit keys (idx << 32 | j) in global scratch `a`.  All-ascending bitonic network
- * (first stage of every merge compares t with its mirror t ^ (k-1), the rest with t ^ j), so
- * positions >= c behave as +inf simply by being skipped.  A single hot group is inherently serial
- * under the per-group ordering contract (like the Java monitor); this only has to be correct.
- * rec / perm may point to LDS or to global memory. */
-__device__ void sort_long_segment(const Rec* rec, int32_t* perm, unsigned long long* a, uint32_t c) {
-  for (uint32_t t = threadIdx.x; t < c; t += GPX_BLOCK) {
-    const int32_t j = perm[t];
-    a[t] = ((unsigned long long)(uint32_t)rec[j].idx << 32) | (uint32_t)j;
-  }
-  __syncthreads();
+/* Sorts the keys a[0 .. c) of ONE long segment ascending (= by arrival index), cooperatively by
+ * the whole workgroup.  All-ascending bitonic network (first stage of every merge compares t with
+ * its mirror t ^ (k-1), the rest with t ^ j), so positions >= c behave as +inf simply by being
+ * skipped.  A single hot group is inherently serial under the per-group ordering contract (like
+ * the Java monitor); this only has to be correct.  `a` may point to LDS or to global memory. */
+__device__ void sort_long_segment(unsigned long long* a, uint32_t c) {
   uint32_t p2 = 1;
   while (p2 < c) p2 <<= 1;
   for (uint32_t k = 2; k <= p2; k <<= 1) {
-    for (uint32_t t = threadIdx.x; t < c; t += GPX_BLOCK) {
+    for (uint32_t t = threadIdx.x; t < c; t += blockDim.x) {
       const uint32_t q = t ^ (k - 1);
       if (q > t && q < c) cmpxchg_asc(a, t, q);
     }
     __syncthreads();
     for (uint32_t j = k >> 2; j > 0; j >>= 1) {
-      for (uint32_t t = threadIdx.x; t < c; t += GPX_BLOCK) {
+      for (uint32_t t = threadIdx.x; t < c; t += blockDim.x) {
         const uint32_t q = t ^ j;
         if (q > t && q < c) cmpxchg_asc(a, t, q);
       }
       __syncthreads();
     }
   }
-  for (uint32_t t = threadIdx.x; t < c; t += GPX_BLOCK) perm[t] = (int32_t)(uint32_t)(a[t] & 0xffffffffull);
-  __syncthreads();
 }
 
-/* What one workgroup sees of its bucket after regrouping: records (bucket-relative index j) and
- * perm (records of local group lg at perm[loff[lg] .. loff[lg] + lcnt[lg])).  Both live in LDS
- * when the bucket has at most GPX_LDS_RECS records (the normal case: ~K records per group), else
- * in global scratch. */
+/* block-wide exclusive scan for a runtime block size (<= 1024 threads) */
+__device__ __forceinline__ int32_t block_exscan_rt(int32_t v, int32_t* total) {
+  __shared__ int32_t wsum[16];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = (int)(blockDim.x >> 6);
+  const int32_t x = wave_incscan(v);
+  if (lane == 63) wsum[wid] = x;
+  __syncthreads();
+  int32_t base = 0, tot = 0;
+  for (int w = 0; w < nw; w++) {
+    int32_t s = wsum[w];
+    if (w < wid) base += s;
+    tot += s;
+  }
+  __syncthreads();
+  *total = tot;
+  return base + x - v;
+}
+
+/* What one workgroup sees of its bucket after regrouping: the bucket's records (bucket-relative
+ * index j) and keys: the records of local group lg are keys[loff[lg] .. loff[lg] + lcnt[lg]),
+ * low word = j.  Both in LDS or both in global memory (see above). */
 struct BucketView {
   const Rec* rec;
-  int32_t* perm;
+  unsigned long long* keys;
   int32_t* lcnt;
   int32_t* loff;
 };
 
-/* dynamic LDS of every k_bucket_* kernel: lcnt[gb] | loff[gb] | Rec[GPX_LDS_RECS] | perm[GPX_LDS_RECS] */
-#define GPX_BUCKET_LDS_BYTES(gb) ((size_t)(gb) * 8 + (size_t)GPX_LDS_RECS * (sizeof(Rec) + 4))
+#define GPX_BUCKET_ITEMS 8 /* max LDS-staged records per thread (X.lds_recs <= 8 * threads) */
+/* dynamic LDS of every k_bucket_* kernel: lcnt[gb] | loff[gb] | keys[lds_recs] | Rec[lds_recs] */
+#define GPX_BUCKET_LDS_BYTES(gb, lds_recs) ((size_t)(gb) * 8 + (size_t)(lds_recs) * (8 + sizeof(Rec)))
 
 /* Returns false (whole workgroup) when the bucket received no record. */
 __device__ __forceinline__ bool bucket_prepare(const DevScratch& X, int32_t* lds, BucketView* bv) {
   const int32_t b = blockIdx.x;
   const int32_t boff = X.bucket_off[b];
   const int32_t nb = X.bucket_off[b + 1] - boff;
+  if (threadIdx.x == 0) X.bucket_tot[b] = 0; /* ready for the next batch's k_hist */
   if (nb == 0) return false;
   const int32_t gb = X.gb;
+  const int32_t nt = (int32_t)blockDim.x;
   int32_t* lcnt = lds;
   int32_t* loff = lds + gb;
-  Rec* recL = (Rec*)(lds + 2 * gb);
-  int32_t* permL = (int32_t*)(recL + GPX_LDS_RECS);
-  const bool in_lds = nb <= GPX_LDS_RECS;
+  unsigned long long* keysL = (unsigned long long*)(lds + 2 * gb);
+  Rec* recL = (Rec*)(keysL + X.lds_recs);
+  const bool in_lds = nb <= X.lds_recs;
   const Rec* recG = X.rec + boff;
   bv->lcnt = lcnt;
   bv->loff = loff;
   bv->rec = in_lds ? (const Rec*)recL : recG;
-  bv->perm = in_lds ? permL : (X.perm + boff);
-  for (int32_t l = threadIdx.x; l < gb; l += GPX_BLOCK) lcnt[l] = 0;
+  bv->keys = in_lds ? keysL : (X.perm + boff);
+  for (int32_t l = threadIdx.x; l < gb; l += nt) lcnt[l] = 0;
   __syncthreads();
-  /* A: count per local group (LDS atomics); remember each record's rank */
-  int32_t rk[GPX_LDS_RECS / GPX_BLOCK];
+  /* A: stage + count per local group (LDS atomics); remember each record's rank */
+  int32_t ix[GPX_BUCKET_ITEMS], lr[GPX_BUCKET_ITEMS]; /* lr = lg << 16 | rank */
   if (in_lds) {
 #pragma unroll
-    for (int m = 0; m < GPX_LDS_RECS / GPX_BLOCK; m++) {
-      const int32_t j = m * GPX_BLOCK + threadIdx.x;
-      rk[m] = 0;
+    for (int m = 0; m < GPX_BUCKET_ITEMS; m++) {
+      const int32_t j = m * nt + threadIdx.x;
+      ix[m] = 0;
+      lr[m] = 0;
       if (j < nb) {
         const Rec r = recG[j]; /* coalesced 32 B per lane */
         recL[j] = r;
-        rk[m] = atomicAdd(&lcnt[r.lg], 1);
+        ix[m] = r.idx;
+        lr[m] = (r.lg << 16) | atomicAdd(&lcnt[r.lg], 1);
       }
     }
   } else {
-    for (int32_t j = threadIdx.x; j < nb; j += GPX_BLOCK)
+    for (int32_t j = threadIdx.x; j < nb; j += nt)
       X.rank2[boff + j] = atomicAdd(&lcnt[recG[j].lg], 1);
   }
   __syncthreads();
-  /* B: exclusive scan lcnt -> loff; thread t owns gb/256 consecutive groups */
-  const int32_t per = gb / GPX_BLOCK;
+  /* B: exclusive scan lcnt -> loff; thread t owns gb / threads consecutive groups */
+  const int32_t per = gb / nt;
   int32_t s = 0;
   for (int32_t q = 0; q < per; q++) s += lcnt[threadIdx.x * per + q];
   int32_t tot;
-  int32_t ex = block_exscan(s, &tot);
+  int32_t ex = block_exscan_rt(s, &tot);
   int32_t any_long = 0;
   for (int32_t q = 0; q < per; q++) {
     const int32_t l = threadIdx.x * per + q;
@@ -460,99 +561,92 @@ __device__ __forceinline__ bool bucket_prepare(const DevScratch& X, int32_t* lds
     any_long |= lcnt[l] > GPX_SMALL_SEG;
   }
   any_long = __syncthreads_or(any_long);
-  /* C: perm */
+  /* C: keys, grouped by local group */
   if (in_lds) {
 #pragma unroll
-    for (int m = 0; m < GPX_LDS_RECS / GPX_BLOCK; m++) {
-      const int32_t j = m * GPX_BLOCK + threadIdx.x;
-      if (j < nb) permL[loff[recL[j].lg] + rk[m]] = j;
+    for (int m = 0; m < GPX_BUCKET_ITEMS; m++) {
+      const int32_t j = m * nt + threadIdx.x;
+      if (j < nb)
+        keysL[loff[lr[m] >> 16] + (lr[m] & 0xffff)] =
+            ((unsigned long long)(uint32_t)ix[m] << 32) | (uint32_t)j;
     }
   } else {
-    for (int32_t j = threadIdx.x; j < nb; j += GPX_BLOCK)
-      X.perm[boff + loff[recG[j].lg] + X.rank2[boff + j]] = j;
+    for (int32_t j = threadIdx.x; j < nb; j += nt) {
+      const int2 h = *(const int2*)&recG[j]; /* {idx, lg} */
+      X.perm[boff + loff[h.y] + X.rank2[boff + j]] = ((unsigned long long)(uint32_t)h.x << 32) | (uint32_t)j;
+    }
   }
   __syncthreads();
   /* D: arrival-order sort of long segments (rare) */
   if (any_long) {
     for (int32_t l = 0; l < gb; l++) {
       const int32_t c = lcnt[l]; /* uniform across the workgroup */
-      if (c > GPX_SMALL_SEG)
-        sort_long_segment(bv->rec, bv->perm + loff[l], X.ord + boff + loff[l], (uint32_t)c);
+      if (c > GPX_SMALL_SEG) sort_long_segment(bv->keys + loff[l], (uint32_t)c);
     }
   }
   return true;
 }
 
-/* Iterates one group's records in arrival order.  c <= 4: (idx, j) pairs sorted in registers;
- * c <= GPX_SMALL_SEG: repeated min-scan; longer: perm is already in arrival order. */
+/* Iterates one group's records in arrival order.  c <= 4 (the normal case): keys sorted in
+ * registers; c <= GPX_SMALL_SEG: repeated min-scan; longer: the keys are already in arrival
+ * order. */
 struct GroupIter {
-  const Rec* rec;      /* bucket base */
-  const int32_t* perm; /* segment base */
-  int32_t c, done, last;
-  int32_t j0, j1, j2, j3;
-  __device__ __forceinline__ void init(const Rec* r, const int32_t* p, int32_t n) {
+  const Rec* rec;                 /* bucket base */
+  const unsigned long long* keys; /* segment base */
+  int32_t c, done;
+  unsigned long long last;
+  uint32_t j0, j1, j2, j3;
+  __device__ __forceinline__ void init(const Rec* r, const unsigned long long* k, int32_t n) {
     rec = r;
-    perm = p;
+    keys = k;
     c = n;
     done = 0;
-    last = -1;
+    last = 0;
     j0 = j1 = j2 = j3 = 0;
     if (n <= 4) {
-      int32_t i0 = 0x7fffffff, i1 = 0x7fffffff, i2 = 0x7fffffff, i3 = 0x7fffffff;
-      j0 = perm[0];
-      i0 = rec[j0].idx;
-      if (n > 1) {
-        j1 = perm[1];
-        i1 = rec[j1].idx;
-      }
-      if (n > 2) {
-        j2 = perm[2];
-        i2 = rec[j2].idx;
-      }
-      if (n > 3) {
-        j3 = perm[3];
-        i3 = rec[j3].idx;
-      }
-#define GPX_CSWAP(ia, ja, ib, jb) \
-  if (ia > ib) {                  \
-    int32_t t_ = ia;              \
-    ia = ib;                      \
-    ib = t_;                      \
-    t_ = ja;                      \
-    ja = jb;                      \
-    jb = t_;                      \
+      const unsigned long long inf = ~0ull;
+      unsigned long long k0 = keys[0];
+      unsigned long long k1 = (n > 1) ? keys[1] : inf;
+      unsigned long long k2 = (n > 2) ? keys[2] : inf;
+      unsigned long long k3 = (n > 3) ? keys[3] : inf;
+#define GPX_CSWAP(x, y)              \
+  if (x > y) {                       \
+    const unsigned long long t_ = x; \
+    x = y;                           \
+    y = t_;                          \
   }
-      GPX_CSWAP(i0, j0, i1, j1)
-      GPX_CSWAP(i2, j2, i3, j3)
-      GPX_CSWAP(i0, j0, i2, j2)
-      GPX_CSWAP(i1, j1, i3, j3)
-      GPX_CSWAP(i1, j1, i2, j2)
+      GPX_CSWAP(k0, k1)
+      GPX_CSWAP(k2, k3)
+      GPX_CSWAP(k0, k2)
+      GPX_CSWAP(k1, k3)
+      GPX_CSWAP(k1, k2)
 #undef GPX_CSWAP
+      j0 = (uint32_t)k0;
+      j1 = (uint32_t)k1;
+      j2 = (uint32_t)k2;
+      j3 = (uint32_t)k3;
     }
   }
-  /* bucket-relative record position of the next record, or -1 */
-  __device__ __forceinline__ int32_t next() {
-    if (done >= c) return -1;
-    int32_t j;
+  /* next record in arrival order; false when exhausted */
+  __device__ __forceinline__ bool next(Rec& out) {
+    if (done >= c) return false;
+    uint32_t j;
     if (c <= 4) {
       j = done == 0 ? j0 : (done == 1 ? j1 : (done == 2 ? j2 : j3));
     } else if (c <= GPX_SMALL_SEG) {
-      int32_t best = 0x7fffffff, bj = -1;
+      unsigned long long best = ~0ull;
       for (int32_t t = 0; t < c; t++) {
-        const int32_t jj = perm[t];
-        const int32_t ix = rec[jj].idx;
-        if (ix > last && ix < best) {
-          best = ix;
-          bj = jj;
-        }
+        const unsigned long long k = keys[t];
+        if ((done == 0 || k > last) && k < best) best = k;
       }
       last = best;
-      j = bj;
+      j = (uint32_t)best;
     } else {
-      j = perm[done];
+      j = (uint32_t)keys[done];
     }
+    out = rec[j];
     done++;
-    return j;
+    return true;
   }
 };
 
@@ -588,8 +682,9 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
   if (!(gf & GF_EXISTS) || (gf & GF_STOPPED)) {
     /* PaxosManager.java:1162-1194 / PaxosInstanceStateMachine.java:456-460: dropped */
     const uint8_t st = (gf & GF_EXISTS) ? GPX_S_STOPPED : GPX_S_NOGROUP;
-    for (int32_t j = it.next(); j >= 0; j = it.next())
-      if (status) status[it.rec[j].idx] = st;
+    Rec r;
+    while (it.next(r))
+      if (status) status[r.idx] = st;
     atomicAdd(&X.counters[2], (unsigned long long)it.c); /* rare path */
     return;
   }
@@ -607,8 +702,26 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
     ns[j] = (j < k) ? S.node_slots[(int64_t)j * G + g] : 0;
   }
   bool ns_dirty = false;
-  for (int32_t j = it.next(); j >= 0; j = it.next()) {
-    const Rec r = it.rec[j];
+  /* one-entry write-back register cache over this group's myProposals ring: the K votes of one
+   * slot (the normal case) cost one load and one store instead of K dependent round trips */
+  int64_t pc_off = -1;
+  uint32_t pc_val = 0;
+  bool pc_dirty = false;
+  auto pr_load = [&](int64_t off) -> uint32_t {
+    if (off != pc_off) {
+      if (pc_dirty) S.p_ring[pc_off] = pc_val;
+      pc_val = S.p_ring[off];
+      pc_off = off;
+      pc_dirty = false;
+    }
+    return pc_val;
+  };
+  auto pr_store = [&](uint32_t v) {
+    pc_val = v;
+    pc_dirty = true;
+  };
+  Rec r;
+  while (it.next(r)) {
     const int32_t slot = r.a, acc = r.b, maxcp = r.c, ix = r.idx;
     if (!has_coord) continue; /* PaxosCoordinator.java:196-198: c == null -> null */
     const int32_t cmp = ballot_cmp(r.bnum, r.bcoord, my_bnum, my_bcoord);
@@ -617,12 +730,11 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
     if (cmp > 0) {
       /* handleAcceptReplyHigherBallot :661-675 */
       if (inwin) {
-        uint32_t* pe = &S.p_ring[(int64_t)(slot & Wm) * G + g];
-        const uint32_t e = *pe;
+        const uint32_t e = pr_load((int64_t)(slot & Wm) * G + g);
         if (e & PR_PRESENT) {
-          *pe = 0;
+          pr_store(0);
           pcount--;
-          X.o_rec[ix] = mk4(my_bnum, my_bcoord, -1, 0); /* preempt(): median stays -1 */
+          X.o_rec[ix] = mk_out(g, slot, my_bnum, my_bcoord, -1, GPX_D_PREEMPTED); /* preempt(): median stays -1 */
           X.o_kind[ix] = GPX_D_PREEMPTED;
         }
       }
@@ -642,23 +754,23 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
         }
       }
       if (inwin) {
-        uint32_t* pe = &S.p_ring[(int64_t)(slot & Wm) * G + g];
-        uint32_t e = *pe;
+        uint32_t e = pr_load((int64_t)(slot & Wm) * G + g);
         if (e & PR_PRESENT) {
           if (midx >= 0) e |= (1u << midx); /* updateHeardFrom :51-62 */
           if (__popc(e & 0xffffu) > k / 2) { /* heardFromMajority :64-68 */
-            *pe = 0;
+            pr_store(0);
             pcount--;
-            X.o_rec[ix] = mk4(my_bnum, my_bcoord, median_minus<KMAX>(ns, k), 0);
+            X.o_rec[ix] = mk_out(g, slot, my_bnum, my_bcoord, median_minus<KMAX>(ns, k), GPX_D_DECISION);
             X.o_kind[ix] = GPX_D_DECISION;
           } else {
-            *pe = e;
+            pr_store(e);
           }
         }
       }
     }
     /* cmp < 0: reply to a lower ballot, ignored (PaxosCoordinator.java:241-247) */
   }
+  if (pc_dirty) S.p_ring[pc_off] = pc_val;
   if (ns_dirty) {
 #pragma unroll
     for (int q = 0; q < KMAX; q++)
@@ -669,17 +781,17 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(GPX_BLOCK) void k_bucket_ar(DevState S, DevScratch X,
+__global__ __launch_bounds__(1024) void k_bucket_ar(DevState S, DevScratch X,
                                                         uint8_t* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(32))) int32_t lds[];
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
   if (!bucket_prepare(X, lds, &bv)) return;
   const int32_t g0 = blockIdx.x << X.shift;
-  for (int32_t l = threadIdx.x; l < X.gb; l += GPX_BLOCK) {
+  for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
     if (c == 0 || g0 + l >= S.G) continue;
     GroupIter it;
-    it.init(bv.rec, bv.perm + bv.loff[l], c);
+    it.init(bv.rec, bv.keys + bv.loff[l], c);
     apply_ar_group<KMAX>(S, X, g0 + l, it, status);
   }
 }
@@ -821,8 +933,8 @@ __device__ __forceinline__ void apply_accept_group(
   if (exists) acc_load(S, g, gf, a);
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
-  for (int32_t j = it.next(); j >= 0; j = it.next()) {
-    const Rec r = it.rec[j];
+  Rec r;
+  while (it.next(r)) {
     const int32_t slot = r.a, median = r.b, ix = r.idx;
     const bool stop = (r.c & GPX_A_STOP) != 0;
     r_bnum[ix] = 0;
@@ -873,7 +985,7 @@ __device__ __forceinline__ void apply_accept_group(
       const int32_t first = a.slot;
       const int32_t cnt_exec = acc_eec(S, g, a, rd);
       if (cnt_exec > 0) {
-        X.o_rec[ix] = mk4(first, cnt_exec, 0, 0);
+        X.o_rec[ix] = mk_out(g, 0, first, cnt_exec, 0, 1);
         X.o_kind[ix] = 1;
       }
     }
@@ -882,18 +994,18 @@ __device__ __forceinline__ void apply_accept_group(
   if (n_drop) atomicAdd(&X.counters[2], n_drop);
 }
 
-__global__ __launch_bounds__(GPX_BLOCK) void k_bucket_accept(
+__global__ __launch_bounds__(1024) void k_bucket_accept(
     DevState S, DevScratch X, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(32))) int32_t lds[];
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
   if (!bucket_prepare(X, lds, &bv)) return;
   const int32_t g0 = blockIdx.x << X.shift;
-  for (int32_t l = threadIdx.x; l < X.gb; l += GPX_BLOCK) {
+  for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
     if (c == 0 || g0 + l >= S.G) continue;
     GroupIter it;
-    it.init(bv.rec, bv.perm + bv.loff[l], c);
+    it.init(bv.rec, bv.keys + bv.loff[l], c);
     apply_accept_group(S, X, g0 + l, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
   }
 }
@@ -911,8 +1023,8 @@ __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevS
   if (exists) acc_load(S, g, gf, a);
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
-  for (int32_t j = it.next(); j >= 0; j = it.next()) {
-    const Rec r = it.rec[j];
+  Rec r;
+  while (it.next(r)) {
     const int32_t slot = r.a, median = r.b, kind = r.c, ix = r.idx;
     if (!exists || a.stopped) {
       status[ix] = exists ? GPX_S_STOPPED : GPX_S_NOGROUP;
@@ -940,7 +1052,7 @@ __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevS
     const int32_t first = a.slot;
     const int32_t cnt_exec = acc_eec(S, g, a, d);
     if (cnt_exec > 0) {
-      X.o_rec[ix] = mk4(first, cnt_exec, 0, 0);
+      X.o_rec[ix] = mk_out(g, 0, first, cnt_exec, 0, 1);
       X.o_kind[ix] = 1;
     }
   }
@@ -948,17 +1060,17 @@ __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevS
   if (n_drop) atomicAdd(&X.counters[2], n_drop);
 }
 
-__global__ __launch_bounds__(GPX_BLOCK) void k_bucket_commit(DevState S, DevScratch X,
+__global__ __launch_bounds__(1024) void k_bucket_commit(DevState S, DevScratch X,
                                                             uint8_t* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(32))) int32_t lds[];
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
   if (!bucket_prepare(X, lds, &bv)) return;
   const int32_t g0 = blockIdx.x << X.shift;
-  for (int32_t l = threadIdx.x; l < X.gb; l += GPX_BLOCK) {
+  for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
     if (c == 0 || g0 + l >= S.G) continue;
     GroupIter it;
-    it.init(bv.rec, bv.perm + bv.loff[l], c);
+    it.init(bv.rec, bv.keys + bv.loff[l], c);
     apply_commit_group(S, X, g0 + l, it, status);
   }
 }
@@ -987,8 +1099,8 @@ __device__ __forceinline__ void apply_propose_group(
   const int32_t median = coord_ok ? median_minus<KMAX>(ns, k) : 0;
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
-  for (int32_t j = it.next(); j >= 0; j = it.next()) {
-    const Rec r = it.rec[j];
+  Rec r;
+  while (it.next(r)) {
     const int32_t ix = r.idx;
     const bool stop = r.a != 0;
     o_slot[ix] = 0;
@@ -1035,18 +1147,18 @@ __device__ __forceinline__ void apply_propose_group(
 }
 
 template <int KMAX>
-__global__ __launch_bounds__(GPX_BLOCK) void k_bucket_propose(
+__global__ __launch_bounds__(1024) void k_bucket_propose(
     DevState S, DevScratch X, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(32))) int32_t lds[];
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
   if (!bucket_prepare(X, lds, &bv)) return;
   const int32_t g0 = blockIdx.x << X.shift;
-  for (int32_t l = threadIdx.x; l < X.gb; l += GPX_BLOCK) {
+  for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
     if (c == 0 || g0 + l >= S.G) continue;
     GroupIter it;
-    it.init(bv.rec, bv.perm + bv.loff[l], c);
+    it.init(bv.rec, bv.keys + bv.loff[l], c);
     apply_propose_group<KMAX>(S, X, g0 + l, it, o_slot, o_bnum, o_bcoord, o_median, status);
   }
 }
@@ -1054,109 +1166,99 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_bucket_propose(
 /* ------------------------------------------------------------------------- */
 /* ordered compaction of the per-record outputs                                 */
 
-/* phase 1: per-tile count of flagged records */
-__global__ __launch_bounds__(GPX_BLOCK) void k_flag_reduce(const uint8_t* __restrict__ o_kind,
-                                                          int32_t n, int32_t* blocksum) {
-  const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE;
+/* the 8 flags of lane-owned consecutive records as one word */
+__device__ __forceinline__ unsigned long long load_flags8(const uint8_t* __restrict__ o_kind,
+                                                          int64_t base, int32_t n) {
+  unsigned long long w = 0;
+  if (base + GPX_SCAN_ITEMS <= n) {
+    w = *(const unsigned long long*)(o_kind + base);
+  } else {
+    for (int j = 0; j < GPX_SCAN_ITEMS; j++)
+      if (base + j < n) w |= (unsigned long long)o_kind[base + j] << (8 * j);
+  }
+  return w;
+}
+__device__ __forceinline__ int32_t count_flags8(unsigned long long w) {
   int32_t s = 0;
 #pragma unroll
-  for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
-    int64_t i = base + j * GPX_BLOCK + threadIdx.x;
-    if (i < n) s += o_kind[i] != 0;
-  }
+  for (int j = 0; j < GPX_SCAN_ITEMS; j++) s += ((w >> (8 * j)) & 0xffull) != 0;
+  return s;
+}
+
+/* phase 1: per-tile count of flagged records */
+__global__ __launch_bounds__(GPX_FBLOCK) void k_flag_reduce(const uint8_t* __restrict__ o_kind,
+                                                           int32_t n, int32_t* blocksum) {
+  const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE + (int64_t)threadIdx.x * GPX_SCAN_ITEMS;
+  const int32_t s = count_flags8(load_flags8(o_kind, base, n));
   int32_t tot;
-  block_exscan(s, &tot);
+  block_exscan_n<GPX_FBLOCK>(s, &tot);
   if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
 }
 
-/* phase 2: one block turns the tile sums into exclusive prefixes; total -> *total_out */
-__global__ __launch_bounds__(GPX_BLOCK) void k_scan_top(int32_t* blocksum, int32_t nb,
-                                                       int32_t* total_out,
-                                                       unsigned long long* acc) {
-  __shared__ int32_t carry_s;
-  if (threadIdx.x == 0) carry_s = 0;
-  __syncthreads();
-  for (int32_t start = 0; start < nb; start += GPX_BLOCK) {
-    int32_t i = start + threadIdx.x;
-    int32_t v = (i < nb) ? blocksum[i] : 0;
-    int32_t tot;
-    int32_t ex = block_exscan(v, &tot);
-    int32_t carry = carry_s;
-    if (i < nb) blocksum[i] = carry + ex;
-    __syncthreads();
-    if (threadIdx.x == 0) carry_s = carry + tot;
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    if (total_out) *total_out = carry_s;
-    if (acc) atomicAdd(acc, (unsigned long long)carry_s);
-  }
-}
-
-/* phase 3: the tile's flagged record indices go to LDS in arrival order (blocked scan: thread t
- * owns GPX_SCAN_ITEMS consecutive records), then thread t gathers the t-th flagged record and
- * writes output row base+t, so every output column is written as a dense coalesced run. */
+/* phase 2: every tile sums the counts of the tiles before it (a few hundred ints), lists its
+ * flagged record indices in LDS in arrival order (blocked scan: thread t owns GPX_SCAN_ITEMS
+ * consecutive records), then thread t gathers the t-th flagged record (one 32-byte sector) and
+ * writes output row out0+t, so every output column is written as a dense coalesced run.  The
+ * last tile publishes the total. */
 __device__ __forceinline__ int32_t compact_tile_list(int32_t n, const uint8_t* __restrict__ o_kind,
-                                                     int32_t* lds_idx, uint8_t* lds_kind) {
+                                                     const int32_t* __restrict__ blocksum,
+                                                     int32_t* lds_idx, int32_t* out0,
+                                                     int32_t* total_out, unsigned long long* acc) {
+  int32_t before = 0;
+  for (int32_t t = threadIdx.x; t < (int32_t)blockIdx.x; t += GPX_FBLOCK) before += blocksum[t];
   const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE + (int64_t)threadIdx.x * GPX_SCAN_ITEMS;
-  uint8_t kd[GPX_SCAN_ITEMS];
-  int32_t s = 0;
-#pragma unroll
-  for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
-    int64_t i = base + j;
-    kd[j] = (i < n) ? o_kind[i] : 0;
-    s += kd[j] != 0;
-  }
+  const unsigned long long w = load_flags8(o_kind, base, n);
+  int32_t pre;
+  block_exscan_n<GPX_FBLOCK>(before, &pre);
   int32_t tot;
-  int32_t ex = block_exscan(s, &tot);
+  int32_t ex = block_exscan_n<GPX_FBLOCK>(count_flags8(w), &tot);
 #pragma unroll
   for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
-    if (kd[j]) {
+    if ((w >> (8 * j)) & 0xffull) {
       lds_idx[ex] = (int32_t)(base + j);
-      lds_kind[ex] = kd[j];
       ex++;
     }
   }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+    if (total_out) *total_out = pre + tot;
+    if (acc) atomicAdd(acc, (unsigned long long)(pre + tot));
+  }
   __syncthreads();
+  *out0 = pre;
   return tot;
 }
 
-/* decisions: d_* columns; gidx/slot are re-read from the input columns */
-__global__ __launch_bounds__(GPX_BLOCK) void k_compact_dec(
-    int32_t n, const uint8_t* __restrict__ o_kind, const I4* __restrict__ o_rec,
-    const int32_t* __restrict__ blocksum, const int32_t* __restrict__ gidx,
-    const int32_t* __restrict__ slot, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
+/* decisions: d_* columns */
+__global__ __launch_bounds__(GPX_FBLOCK) void k_compact_dec(
+    int32_t n, const uint8_t* __restrict__ o_kind, const Out* __restrict__ o_rec,
+    const int32_t* __restrict__ blocksum, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
     int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
-    uint8_t* __restrict__ d_kind) {
+    uint8_t* __restrict__ d_kind, int32_t* total_out, unsigned long long* acc) {
   __shared__ int32_t lds_idx[GPX_SCAN_TILE];
-  __shared__ uint8_t lds_kind[GPX_SCAN_TILE];
-  const int32_t tot = compact_tile_list(n, o_kind, lds_idx, lds_kind);
-  const int32_t out0 = blocksum[blockIdx.x];
-  for (int32_t t = threadIdx.x; t < tot; t += GPX_BLOCK) {
-    const int32_t i = lds_idx[t];
-    const I4 r = o_rec[i];
-    d_gidx[out0 + t] = gidx[i];
-    d_slot[out0 + t] = slot[i];
+  int32_t out0;
+  const int32_t tot = compact_tile_list(n, o_kind, blocksum, lds_idx, &out0, total_out, acc);
+  for (int32_t t = threadIdx.x; t < tot; t += GPX_FBLOCK) {
+    const Out r = o_rec[lds_idx[t]];
+    d_gidx[out0 + t] = r.gidx;
+    d_slot[out0 + t] = r.slot;
     d_bnum[out0 + t] = r.x;
     d_bcoord[out0 + t] = r.y;
     d_median[out0 + t] = r.z;
-    d_kind[out0 + t] = lds_kind[t];
+    d_kind[out0 + t] = (uint8_t)r.kind;
   }
 }
 
 /* exec runs: (gidx, first, count) */
-__global__ __launch_bounds__(GPX_BLOCK) void k_compact_runs(
-    int32_t n, const uint8_t* __restrict__ o_kind, const I4* __restrict__ o_rec,
-    const int32_t* __restrict__ blocksum, const int32_t* __restrict__ gidx,
-    int32_t* __restrict__ x_gidx, int32_t* __restrict__ x_first, int32_t* __restrict__ x_count) {
+__global__ __launch_bounds__(GPX_FBLOCK) void k_compact_runs(
+    int32_t n, const uint8_t* __restrict__ o_kind, const Out* __restrict__ o_rec,
+    const int32_t* __restrict__ blocksum, int32_t* __restrict__ x_gidx,
+    int32_t* __restrict__ x_first, int32_t* __restrict__ x_count, int32_t* total_out) {
   __shared__ int32_t lds_idx[GPX_SCAN_TILE];
-  __shared__ uint8_t lds_kind[GPX_SCAN_TILE];
-  const int32_t tot = compact_tile_list(n, o_kind, lds_idx, lds_kind);
-  const int32_t out0 = blocksum[blockIdx.x];
-  for (int32_t t = threadIdx.x; t < tot; t += GPX_BLOCK) {
-    const int32_t i = lds_idx[t];
-    const I4 r = o_rec[i];
-    x_gidx[out0 + t] = gidx[i];
+  int32_t out0;
+  const int32_t tot = compact_tile_list(n, o_kind, blocksum, lds_idx, &out0, total_out, nullptr);
+  for (int32_t t = threadIdx.x; t < tot; t += GPX_FBLOCK) {
+    const Out r = o_rec[lds_idx[t]];
+    x_gidx[out0 + t] = r.gidx;
     x_first[out0 + t] = r.x;
     x_count[out0 + t] = r.y;
   }

@@ -32,9 +32,12 @@ def kernel_stats(db):
 
 def counter_avgs(db, counter):
     c = sqlite3.connect(db)
-    rows = c.execute(
-        "select kernel_name, grid_size, count(*), avg(value), avg(duration) from counters_collection "
-        "where counter_name=? group by kernel_name, grid_size", (counter,)).fetchall()
+    try:
+        rows = c.execute(
+            "select kernel_name, grid_size, count(*), avg(value), avg(duration) from counters_collection "
+            "where counter_name=? group by kernel_name, grid_size", (counter,)).fetchall()
+    except sqlite3.Error:
+        return []  # a trace without this PMC pass
     return [(short(n), int(grid), int(cnt), float(val), float(dur)) for n, grid, cnt, val, dur in rows]
 
 
