@@ -150,7 +150,8 @@ def load_hip() -> GpxLib:
     """The product library.  Fails loudly when the HIP extension is missing."""
     global _hip_lib
     if _hip_lib is None:
-        _hip_lib = GpxLib(HIP_LIB_PATH, "gpx_", device_api=True)
+        # GPX_HIP_LIB: tuning aid, points at an alternative build of the same HIP library
+        _hip_lib = GpxLib(os.environ.get("GPX_HIP_LIB", HIP_LIB_PATH), "gpx_", device_api=True)
     return _hip_lib
 
 

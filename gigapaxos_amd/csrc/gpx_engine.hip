@@ -57,7 +57,6 @@ struct gpx_engine {
   std::map<std::string, std::pair<uint64_t, double>> prof;
   size_t bucket_lds = 0;
   int bucket_threads = 256;
-  int32_t nb_max = 0;
 };
 
 namespace {
@@ -84,7 +83,6 @@ int dev_alloc(gpx_engine* e, T** p, size_t count, bool zero) {
 }
 
 inline int grid_for(int64_t n) { return (int)((n + GPX_BLOCK - 1) / GPX_BLOCK); }
-inline int tiles_for(int64_t n) { return (int)((n + GPX_SCAN_TILE - 1) / GPX_SCAN_TILE); }
 
 /* brackets a launch with events when profiling is on */
 struct LaunchScope {
@@ -163,12 +161,6 @@ void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, 
   else
     LAUNCH_F(e, "k_hist", k_hist<false>, tile_grid(ntiles), lds, n, ntiles, gidx, e->S.G, e->X, status,
              is_votes);
-}
-
-/* per-tile counts of the per-record output flags */
-void scan_outputs(gpx_engine* e, int32_t n) {
-  LAUNCH_F(e, "k_flag_reduce", k_flag_reduce, tiles_for(n), 0, (const uint8_t*)e->X.o_kind, n,
-           e->X.blocksum);
 }
 
 int check_batch(gpx_engine* h, int32_t n) {
@@ -287,10 +279,8 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.rec, N, false);
   A(X.rank2, N, false);
   A(X.perm, N, false);
-  A(X.o_kind, N, true);
   A(X.o_rec, N, false);
-  e->nb_max = tiles_for((int64_t)N) + 1;
-  A(X.blocksum, (size_t)e->nb_max, true);
+  A(X.bucket_nout, (size_t)X.nbk, true);
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
@@ -390,10 +380,8 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     launch_bucket_ar<8>(e, status);
   else
     launch_bucket_ar<16>(e, status);
-  scan_outputs(e, n);
-  LAUNCH_F(e, "k_compact_dec", k_compact_dec, tiles_for(n), 0, n, (const uint8_t*)e->X.o_kind,
-           (const Out*)e->X.o_rec, (const int32_t*)e->X.blocksum, d_gidx, d_slot, d_bnum, d_bcoord,
-           d_median_cp, d_kind, n_out, &e->X.counters[1]);
+  LAUNCH(e, "k_emit_dec", k_emit_dec, e->X.nbk, e->X, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp,
+         d_kind, n_out, &e->X.counters[1]);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -417,9 +405,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
            gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
   LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags,
            status);
-  scan_outputs(e, n);
-  LAUNCH_F(e, "k_compact_runs", k_compact_runs, tiles_for(n), 0, n, (const uint8_t*)e->X.o_kind,
-           (const Out*)e->X.o_rec, (const int32_t*)e->X.blocksum, x_gidx, x_first, x_count, n_runs);
+  LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -442,9 +428,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
            gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
            (int32_t*)nullptr, (uint8_t*)nullptr);
   LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
-  scan_outputs(e, n);
-  LAUNCH_F(e, "k_compact_runs", k_compact_runs, tiles_for(n), 0, n, (const uint8_t*)e->X.o_kind,
-           (const Out*)e->X.o_rec, (const int32_t*)e->X.blocksum, x_gidx, x_first, x_count, n_runs);
+  LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }

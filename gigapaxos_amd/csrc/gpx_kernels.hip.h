@@ -71,8 +71,12 @@ __device__ __forceinline__ Out mk_out(int32_t gidx, int32_t slot, int32_t x, int
 }
 
 #define GPX_BLOCK 256   /* threads of a per-bucket / lifecycle workgroup */
+#ifndef GPX_FBLOCK
 #define GPX_FBLOCK 1024 /* threads of a streaming (histogram / scatter / compaction) workgroup */
-#define GPX_TILE 8192   /* records per streaming workgroup */
+#endif
+#ifndef GPX_TILE
+#define GPX_TILE 8192 /* records per streaming workgroup */
+#endif
 #define GPX_TILE_ITEMS (GPX_TILE / GPX_FBLOCK)
 #define GPX_TILE_VECS (GPX_TILE_ITEMS / 4)
 #define GPX_SCAN_ITEMS 8 /* records per thread in the output-flag kernels (one 8-byte load) */
@@ -120,9 +124,8 @@ struct DevScratch {
   Rec* rec;               /* [n] bucket-partitioned records */
   int32_t* rank2;         /* [n] rank of a record among its group's records (LDS atomic order) */
   unsigned long long* perm; /* [n] sort keys (arrival idx << 32 | position) of buckets too big for LDS */
-  uint8_t* o_kind;        /* [n] per-record output flag (0 = none) */
-  Out* o_rec;             /* [n] per-record output payload */
-  int32_t* blocksum;      /* output-flag scan partials */
+  Out* o_rec;             /* [n] compacted outputs of bucket b as a dense run at o_rec[bucket_off[b] ..] */
+  int32_t* bucket_nout;   /* [nbk] number of compacted outputs of each bucket */
   unsigned long long* counters; /* [3] votes, outputs (decisions + preempts), dropped */
 };
 
@@ -237,8 +240,8 @@ __device__ __forceinline__ int32_t tile_histogram(int32_t n, int64_t base,
   return bad;
 }
 
-/* per-tile bucket histogram -> bucket_tot; also resets the per-record output flag and writes the
- * common per-record status (coalesced) so the apply kernels only touch the rare non-OK ones */
+/* per-tile bucket histogram -> bucket_tot; also writes the common per-record status (coalesced)
+ * so the apply kernels only touch the rare non-OK ones */
 template <bool VEC>
 __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
                                                     const int32_t* __restrict__ gidx, int32_t G,
@@ -251,12 +254,11 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
   __syncthreads();
   const int64_t base = (int64_t)tile * GPX_TILE;
   const int32_t bad = tile_histogram<VEC>(n, base, gidx, G, X.shift, lds);
-  /* flags + status: 8 consecutive records per lane (o_kind is ours: 8-byte aligned) */
-  {
-    const int64_t i0 = base + (int64_t)threadIdx.x * 8;
+  /* status: 8 consecutive records per lane */
+  if (status)
+  for (int64_t i0 = base + (int64_t)threadIdx.x * 8; i0 < base + GPX_TILE; i0 += GPX_FBLOCK * 8) {
     if (i0 + 7 < n && !((uintptr_t)status & 7)) {
-      *(unsigned long long*)(X.o_kind + i0) = 0ull;
-      if (status) {
+      {
         unsigned long long st = 0;
         for (int q = 0; q < 8; q++)
           if ((uint32_t)gidx[i0 + q] >= (uint32_t)G) st |= (unsigned long long)GPX_S_NOGROUP << (8 * q);
@@ -265,10 +267,7 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
     } else {
       for (int q = 0; q < 8; q++) {
         const int64_t i = i0 + q;
-        if (i < n) {
-          X.o_kind[i] = 0;
-          if (status) status[i] = ((uint32_t)gidx[i] < (uint32_t)G) ? GPX_S_OK : GPX_S_NOGROUP;
-        }
+        if (i < n) status[i] = ((uint32_t)gidx[i] < (uint32_t)G) ? GPX_S_OK : GPX_S_NOGROUP;
       }
     }
   }
@@ -496,7 +495,7 @@ __device__ __forceinline__ int32_t block_exscan_rt(int32_t v, int32_t* total) {
  * index j) and keys: the records of local group lg are keys[loff[lg] .. loff[lg] + lcnt[lg]),
  * low word = j.  Both in LDS or both in global memory (see above). */
 struct BucketView {
-  const Rec* rec;
+  Rec* rec;
   unsigned long long* keys;
   int32_t* lcnt;
   int32_t* loff;
@@ -511,7 +510,10 @@ __device__ __forceinline__ bool bucket_prepare(const DevScratch& X, int32_t* lds
   const int32_t b = blockIdx.x;
   const int32_t boff = X.bucket_off[b];
   const int32_t nb = X.bucket_off[b + 1] - boff;
-  if (threadIdx.x == 0) X.bucket_tot[b] = 0; /* ready for the next batch's k_hist */
+  if (threadIdx.x == 0) {
+    X.bucket_tot[b] = 0; /* ready for the next batch's k_hist */
+    if (nb == 0) X.bucket_nout[b] = 0;
+  }
   if (nb == 0) return false;
   const int32_t gb = X.gb;
   const int32_t nt = (int32_t)blockDim.x;
@@ -520,10 +522,10 @@ __device__ __forceinline__ bool bucket_prepare(const DevScratch& X, int32_t* lds
   unsigned long long* keysL = (unsigned long long*)(lds + 2 * gb);
   Rec* recL = (Rec*)(keysL + X.lds_recs);
   const bool in_lds = nb <= X.lds_recs;
-  const Rec* recG = X.rec + boff;
+  Rec* recG = X.rec + boff;
   bv->lcnt = lcnt;
   bv->loff = loff;
-  bv->rec = in_lds ? (const Rec*)recL : recG;
+  bv->rec = in_lds ? recL : recG;
   bv->keys = in_lds ? keysL : (X.perm + boff);
   for (int32_t l = threadIdx.x; l < gb; l += nt) lcnt[l] = 0;
   __syncthreads();
@@ -588,20 +590,23 @@ __device__ __forceinline__ bool bucket_prepare(const DevScratch& X, int32_t* lds
 }
 
 /* Iterates one group's records in arrival order.  c <= 4 (the normal case): keys sorted in
- * registers; c <= GPX_SMALL_SEG: repeated min-scan; longer: the keys are already in arrival
- * order. */
+ * registers; longer segments are sorted in place first (4 < c <= GPX_SMALL_SEG by this lane,
+ * beyond that cooperatively in bucket_prepare), then read sequentially.
+ * emit() parks an output of the CURRENT record in that record's slot and lists the slot in
+ * keys[nout]: entry nout <= done - 1 has always been consumed already. */
 struct GroupIter {
-  const Rec* rec;                 /* bucket base */
-  const unsigned long long* keys; /* segment base */
-  int32_t c, done;
-  unsigned long long last;
+  Rec* rec;                 /* bucket base */
+  unsigned long long* keys; /* segment base */
+  int32_t c, done, nout;
+  uint32_t cur;
   uint32_t j0, j1, j2, j3;
-  __device__ __forceinline__ void init(const Rec* r, const unsigned long long* k, int32_t n) {
+  __device__ __forceinline__ void init(Rec* r, unsigned long long* k, int32_t n) {
     rec = r;
     keys = k;
     c = n;
     done = 0;
-    last = 0;
+    nout = 0;
+    cur = 0;
     j0 = j1 = j2 = j3 = 0;
     if (n <= 4) {
       const unsigned long long inf = ~0ull;
@@ -625,28 +630,32 @@ struct GroupIter {
       j1 = (uint32_t)k1;
       j2 = (uint32_t)k2;
       j3 = (uint32_t)k3;
+    } else if (n <= GPX_SMALL_SEG) {
+      for (int32_t i = 1; i < n; i++) { /* insertion sort, this lane only */
+        const unsigned long long x = keys[i];
+        int32_t p = i - 1;
+        while (p >= 0 && keys[p] > x) {
+          keys[p + 1] = keys[p];
+          p--;
+        }
+        keys[p + 1] = x;
+      }
     }
   }
   /* next record in arrival order; false when exhausted */
   __device__ __forceinline__ bool next(Rec& out) {
     if (done >= c) return false;
-    uint32_t j;
-    if (c <= 4) {
-      j = done == 0 ? j0 : (done == 1 ? j1 : (done == 2 ? j2 : j3));
-    } else if (c <= GPX_SMALL_SEG) {
-      unsigned long long best = ~0ull;
-      for (int32_t t = 0; t < c; t++) {
-        const unsigned long long k = keys[t];
-        if ((done == 0 || k > last) && k < best) best = k;
-      }
-      last = best;
-      j = (uint32_t)best;
-    } else {
-      j = (uint32_t)keys[done];
-    }
-    out = rec[j];
+    if (c <= 4)
+      cur = done == 0 ? j0 : (done == 1 ? j1 : (done == 2 ? j2 : j3));
+    else
+      cur = (uint32_t)keys[done];
+    out = rec[cur];
     done++;
     return true;
+  }
+  __device__ __forceinline__ void emit(const Out& o) {
+    *(Out*)&rec[cur] = o;
+    keys[nout++] = cur;
   }
 };
 
@@ -667,6 +676,96 @@ __device__ __forceinline__ int32_t median_minus(const int32_t (&ns)[KMAX], int32
     }
   }
   return res;
+}
+
+/* ------------------------------------------------------------------------- */
+/* compacted outputs (decisions / preempts / exec runs)                         */
+/* Output order contract (include/gpx.h): grouped by gidx ascending; the entries of one group in
+ * the array order of the records that produced them.  That is the order the per-bucket kernels
+ * produce for free (one lane per group, groups of a bucket consecutive, buckets consecutive), and
+ * the shape the reference's next stage wants anyway: PaxosPacketBatcher keys outgoing decisions
+ * by paxosID (PaxosPacketBatcher.java:121-156).
+ *
+ * During the replay a lane parks each output in the LDS (or scratch) slot of the record that
+ * produced it and lists the slot in its group's key segment (GroupIter::emit).  bucket_emit then
+ * writes the bucket's outputs, group-major, as one dense run of 32-byte rows at o_rec[boff ..]
+ * (outputs <= records, so the bucket's own record range always has room) and their count to
+ * bucket_nout[b]; k_emit_* turns the per-bucket runs into the caller's dense SoA columns. */
+
+/* all lanes of the workgroup; nout = number of outputs this thread's groups produced, already
+ * stored per group in bv.lcnt[l] (overwriting the record count, which is no longer needed) */
+__device__ __forceinline__ void bucket_emit(const DevScratch& X, const BucketView& bv) {
+  __syncthreads();
+  const int32_t b = blockIdx.x;
+  const int32_t boff = X.bucket_off[b];
+  const int32_t nt = (int32_t)blockDim.x;
+  const int32_t per = X.gb / nt;
+  int32_t s = 0;
+  for (int32_t q = 0; q < per; q++) s += bv.lcnt[threadIdx.x * per + q];
+  int32_t tot;
+  int32_t ex = block_exscan_rt(s, &tot);
+  Out* dst = X.o_rec + boff;
+  const Out* src = (const Out*)bv.rec;
+  for (int32_t q = 0; q < per; q++) {
+    const int32_t l = threadIdx.x * per + q;
+    const int32_t d = bv.lcnt[l];
+    const unsigned long long* kk = bv.keys + bv.loff[l];
+    for (int32_t t = 0; t < d; t++) dst[ex + t] = src[(uint32_t)kk[t]];
+    ex += d;
+  }
+  if (threadIdx.x == 0) X.bucket_nout[b] = tot;
+}
+
+/* Number of outputs of the buckets before this one (every workgroup sums the counts itself: at
+ * most GPX_MAX_BUCKETS ints from L2); the last bucket publishes the total. */
+__device__ __forceinline__ int32_t emit_base(const DevScratch& X, int32_t* total_out,
+                                             unsigned long long* acc) {
+  const int32_t b = blockIdx.x;
+  int32_t before = 0;
+  for (int32_t t = threadIdx.x; t < b; t += GPX_BLOCK) before += X.bucket_nout[t];
+  int32_t pre;
+  block_exscan(before, &pre);
+  if (b == (int32_t)gridDim.x - 1 && threadIdx.x == 0) {
+    const int32_t tot = pre + X.bucket_nout[b];
+    if (total_out) *total_out = tot;
+    if (acc) atomicAdd(acc, (unsigned long long)tot);
+  }
+  return pre;
+}
+
+/* decisions: d_* columns */
+__global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec(
+    DevScratch X, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
+    int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
+    uint8_t* __restrict__ d_kind, int32_t* total_out, unsigned long long* acc) {
+  const int32_t out0 = emit_base(X, total_out, acc);
+  const int32_t nd = X.bucket_nout[blockIdx.x];
+  const Out* src = X.o_rec + X.bucket_off[blockIdx.x];
+  for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {
+    const Out r = src[t];
+    d_gidx[out0 + t] = r.gidx;
+    d_slot[out0 + t] = r.slot;
+    d_bnum[out0 + t] = r.x;
+    d_bcoord[out0 + t] = r.y;
+    d_median[out0 + t] = r.z;
+    d_kind[out0 + t] = (uint8_t)r.kind;
+  }
+}
+
+/* exec runs: (gidx, first, count) */
+__global__ __launch_bounds__(GPX_BLOCK) void k_emit_runs(DevScratch X, int32_t* __restrict__ x_gidx,
+                                                        int32_t* __restrict__ x_first,
+                                                        int32_t* __restrict__ x_count,
+                                                        int32_t* total_out) {
+  const int32_t out0 = emit_base(X, total_out, nullptr);
+  const int32_t nd = X.bucket_nout[blockIdx.x];
+  const Out* src = X.o_rec + X.bucket_off[blockIdx.x];
+  for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {
+    const Out r = src[t];
+    x_gidx[out0 + t] = r.gidx;
+    x_first[out0 + t] = r.x;
+    x_count[out0 + t] = r.y;
+  }
 }
 
 /* ------------------------------------------------------------------------- */
@@ -734,8 +833,7 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
         if (e & PR_PRESENT) {
           pr_store(0);
           pcount--;
-          X.o_rec[ix] = mk_out(g, slot, my_bnum, my_bcoord, -1, GPX_D_PREEMPTED); /* preempt(): median stays -1 */
-          X.o_kind[ix] = GPX_D_PREEMPTED;
+          it.emit(mk_out(g, slot, my_bnum, my_bcoord, -1, GPX_D_PREEMPTED)); /* preempt(): median stays -1 */
         }
       }
       /* nullifyCoordinatorIfPreemptedFully, PISM:1361-1364 */
@@ -760,8 +858,7 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
           if (__popc(e & 0xffffu) > k / 2) { /* heardFromMajority :64-68 */
             pr_store(0);
             pcount--;
-            X.o_rec[ix] = mk_out(g, slot, my_bnum, my_bcoord, median_minus<KMAX>(ns, k), GPX_D_DECISION);
-            X.o_kind[ix] = GPX_D_DECISION;
+            it.emit(mk_out(g, slot, my_bnum, my_bcoord, median_minus<KMAX>(ns, k), GPX_D_DECISION));
           } else {
             pr_store(e);
           }
@@ -789,11 +886,16 @@ __global__ __launch_bounds__(1024) void k_bucket_ar(DevState S, DevScratch X,
   const int32_t g0 = blockIdx.x << X.shift;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
-    if (c == 0 || g0 + l >= S.G) continue;
-    GroupIter it;
-    it.init(bv.rec, bv.keys + bv.loff[l], c);
-    apply_ar_group<KMAX>(S, X, g0 + l, it, status);
+    int32_t nout = 0;
+    if (c != 0 && g0 + l < S.G) {
+      GroupIter it;
+      it.init(bv.rec, bv.keys + bv.loff[l], c);
+      apply_ar_group<KMAX>(S, X, g0 + l, it, status);
+      nout = it.nout;
+    }
+    bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
   }
+  bucket_emit(X, bv);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -985,8 +1087,7 @@ __device__ __forceinline__ void apply_accept_group(
       const int32_t first = a.slot;
       const int32_t cnt_exec = acc_eec(S, g, a, rd);
       if (cnt_exec > 0) {
-        X.o_rec[ix] = mk_out(g, 0, first, cnt_exec, 0, 1);
-        X.o_kind[ix] = 1;
+        it.emit(mk_out(g, 0, first, cnt_exec, 0, 1));
       }
     }
   }
@@ -1003,11 +1104,16 @@ __global__ __launch_bounds__(1024) void k_bucket_accept(
   const int32_t g0 = blockIdx.x << X.shift;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
-    if (c == 0 || g0 + l >= S.G) continue;
-    GroupIter it;
-    it.init(bv.rec, bv.keys + bv.loff[l], c);
-    apply_accept_group(S, X, g0 + l, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+    int32_t nout = 0;
+    if (c != 0 && g0 + l < S.G) {
+      GroupIter it;
+      it.init(bv.rec, bv.keys + bv.loff[l], c);
+      apply_accept_group(S, X, g0 + l, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+      nout = it.nout;
+    }
+    bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
   }
+  bucket_emit(X, bv);
 }
 
 /* PaxosInstanceStateMachine.handleBatchedCommit (PISM:1480-1528) per slot and
@@ -1052,8 +1158,7 @@ __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevS
     const int32_t first = a.slot;
     const int32_t cnt_exec = acc_eec(S, g, a, d);
     if (cnt_exec > 0) {
-      X.o_rec[ix] = mk_out(g, 0, first, cnt_exec, 0, 1);
-      X.o_kind[ix] = 1;
+      it.emit(mk_out(g, 0, first, cnt_exec, 0, 1));
     }
   }
   if (exists) acc_store(S, g, gf, a);
@@ -1068,11 +1173,16 @@ __global__ __launch_bounds__(1024) void k_bucket_commit(DevState S, DevScratch X
   const int32_t g0 = blockIdx.x << X.shift;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
-    if (c == 0 || g0 + l >= S.G) continue;
-    GroupIter it;
-    it.init(bv.rec, bv.keys + bv.loff[l], c);
-    apply_commit_group(S, X, g0 + l, it, status);
+    int32_t nout = 0;
+    if (c != 0 && g0 + l < S.G) {
+      GroupIter it;
+      it.init(bv.rec, bv.keys + bv.loff[l], c);
+      apply_commit_group(S, X, g0 + l, it, status);
+      nout = it.nout;
+    }
+    bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
   }
+  bucket_emit(X, bv);
 }
 
 /* PaxosInstanceStateMachine.handleProposal (PISM:818-888) ->
@@ -1163,106 +1273,6 @@ __global__ __launch_bounds__(1024) void k_bucket_propose(
   }
 }
 
-/* ------------------------------------------------------------------------- */
-/* ordered compaction of the per-record outputs                                 */
-
-/* the 8 flags of lane-owned consecutive records as one word */
-__device__ __forceinline__ unsigned long long load_flags8(const uint8_t* __restrict__ o_kind,
-                                                          int64_t base, int32_t n) {
-  unsigned long long w = 0;
-  if (base + GPX_SCAN_ITEMS <= n) {
-    w = *(const unsigned long long*)(o_kind + base);
-  } else {
-    for (int j = 0; j < GPX_SCAN_ITEMS; j++)
-      if (base + j < n) w |= (unsigned long long)o_kind[base + j] << (8 * j);
-  }
-  return w;
-}
-__device__ __forceinline__ int32_t count_flags8(unsigned long long w) {
-  int32_t s = 0;
-#pragma unroll
-  for (int j = 0; j < GPX_SCAN_ITEMS; j++) s += ((w >> (8 * j)) & 0xffull) != 0;
-  return s;
-}
-
-/* phase 1: per-tile count of flagged records */
-__global__ __launch_bounds__(GPX_FBLOCK) void k_flag_reduce(const uint8_t* __restrict__ o_kind,
-                                                           int32_t n, int32_t* blocksum) {
-  const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE + (int64_t)threadIdx.x * GPX_SCAN_ITEMS;
-  const int32_t s = count_flags8(load_flags8(o_kind, base, n));
-  int32_t tot;
-  block_exscan_n<GPX_FBLOCK>(s, &tot);
-  if (threadIdx.x == 0) blocksum[blockIdx.x] = tot;
-}
-
-/* phase 2: every tile sums the counts of the tiles before it (a few hundred ints), lists its
- * flagged record indices in LDS in arrival order (blocked scan: thread t owns GPX_SCAN_ITEMS
- * consecutive records), then thread t gathers the t-th flagged record (one 32-byte sector) and
- * writes output row out0+t, so every output column is written as a dense coalesced run.  The
- * last tile publishes the total. */
-__device__ __forceinline__ int32_t compact_tile_list(int32_t n, const uint8_t* __restrict__ o_kind,
-                                                     const int32_t* __restrict__ blocksum,
-                                                     int32_t* lds_idx, int32_t* out0,
-                                                     int32_t* total_out, unsigned long long* acc) {
-  int32_t before = 0;
-  for (int32_t t = threadIdx.x; t < (int32_t)blockIdx.x; t += GPX_FBLOCK) before += blocksum[t];
-  const int64_t base = (int64_t)blockIdx.x * GPX_SCAN_TILE + (int64_t)threadIdx.x * GPX_SCAN_ITEMS;
-  const unsigned long long w = load_flags8(o_kind, base, n);
-  int32_t pre;
-  block_exscan_n<GPX_FBLOCK>(before, &pre);
-  int32_t tot;
-  int32_t ex = block_exscan_n<GPX_FBLOCK>(count_flags8(w), &tot);
-#pragma unroll
-  for (int j = 0; j < GPX_SCAN_ITEMS; j++) {
-    if ((w >> (8 * j)) & 0xffull) {
-      lds_idx[ex] = (int32_t)(base + j);
-      ex++;
-    }
-  }
-  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-    if (total_out) *total_out = pre + tot;
-    if (acc) atomicAdd(acc, (unsigned long long)(pre + tot));
-  }
-  __syncthreads();
-  *out0 = pre;
-  return tot;
-}
-
-/* decisions: d_* columns */
-__global__ __launch_bounds__(GPX_FBLOCK) void k_compact_dec(
-    int32_t n, const uint8_t* __restrict__ o_kind, const Out* __restrict__ o_rec,
-    const int32_t* __restrict__ blocksum, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
-    int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
-    uint8_t* __restrict__ d_kind, int32_t* total_out, unsigned long long* acc) {
-  __shared__ int32_t lds_idx[GPX_SCAN_TILE];
-  int32_t out0;
-  const int32_t tot = compact_tile_list(n, o_kind, blocksum, lds_idx, &out0, total_out, acc);
-  for (int32_t t = threadIdx.x; t < tot; t += GPX_FBLOCK) {
-    const Out r = o_rec[lds_idx[t]];
-    d_gidx[out0 + t] = r.gidx;
-    d_slot[out0 + t] = r.slot;
-    d_bnum[out0 + t] = r.x;
-    d_bcoord[out0 + t] = r.y;
-    d_median[out0 + t] = r.z;
-    d_kind[out0 + t] = (uint8_t)r.kind;
-  }
-}
-
-/* exec runs: (gidx, first, count) */
-__global__ __launch_bounds__(GPX_FBLOCK) void k_compact_runs(
-    int32_t n, const uint8_t* __restrict__ o_kind, const Out* __restrict__ o_rec,
-    const int32_t* __restrict__ blocksum, int32_t* __restrict__ x_gidx,
-    int32_t* __restrict__ x_first, int32_t* __restrict__ x_count, int32_t* total_out) {
-  __shared__ int32_t lds_idx[GPX_SCAN_TILE];
-  int32_t out0;
-  const int32_t tot = compact_tile_list(n, o_kind, blocksum, lds_idx, &out0, total_out, nullptr);
-  for (int32_t t = threadIdx.x; t < tot; t += GPX_FBLOCK) {
-    const Out r = o_rec[lds_idx[t]];
-    x_gidx[out0 + t] = r.gidx;
-    x_first[out0 + t] = r.x;
-    x_count[out0 + t] = r.y;
-  }
-}
 
 /* ------------------------------------------------------------------------- */
 /* lifecycle                                                                    */

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <initializer_list>
 #include <map>
 #include <memory>
 #include <vector>
@@ -538,6 +539,31 @@ int orc_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8
   return GPX_OK;
 }
 
+/* Output order contract of include/gpx.h: compacted outputs leave grouped by gidx ascending, the
+ * entries of one group in the array order of the records that produced them.  The per-record
+ * loops below collect outputs in arrival order (what sequential handlePaxosMessage calls give);
+ * this is the regrouping by group that the reference's own next stage performs when it files
+ * outgoing decisions under their paxosID (PaxosPacketBatcher.java:121-156) — a STABLE sort by
+ * gidx, so nothing inside a group moves. */
+static void regroup_by_gidx(int32_t m, int32_t* gidx, std::initializer_list<int32_t*> cols,
+                            uint8_t* kind) {
+  std::vector<int32_t> order(m);
+  for (int32_t i = 0; i < m; i++) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return gidx[a] < gidx[b]; });
+  std::vector<int32_t> tmp(m);
+  auto permute = [&](int32_t* col) {
+    for (int32_t i = 0; i < m; i++) tmp[i] = col[order[i]];
+    std::memcpy(col, tmp.data(), (size_t)m * sizeof(int32_t));
+  };
+  for (int32_t* c : cols) permute(c);
+  if (kind) {
+    std::vector<uint8_t> tk(m);
+    for (int32_t i = 0; i < m; i++) tk[i] = kind[order[i]];
+    std::memcpy(kind, tk.data(), (size_t)m);
+  }
+  permute(gidx);
+}
+
 /* PaxosInstanceStateMachine.java:1080-1166 handleAccept */
 int orc_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
                      const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
@@ -595,6 +621,7 @@ int orc_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
       }
     }
   }
+  regroup_by_gidx(runs, x_gidx, {x_first, x_count}, nullptr);
   *n_runs = runs;
   return GPX_OK;
 }
@@ -655,6 +682,7 @@ int orc_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
       if (cmp > 0 && c->preemptedFully()) g->coordinator.reset();
     }
   }
+  regroup_by_gidx(out, d_gidx, {d_slot, d_bnum, d_bcoord, d_median_cp}, d_kind);
   *n_out = out;
   return GPX_OK;
 }
@@ -702,6 +730,7 @@ int orc_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
       runs++;
     }
   }
+  regroup_by_gidx(runs, x_gidx, {x_first, x_count}, nullptr);
   *n_runs = runs;
   return GPX_OK;
 }
