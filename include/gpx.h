@@ -27,7 +27,11 @@
  *     order, exactly as if handlePaxosMessage had been called once per record in
  *     that order.  Records of different groups are independent
  *     (PaxosManager.java:3170-3171).  Compacted outputs (decisions, exec runs)
- *     are emitted in the array order of the record that produced them.
+ *     leave GROUPED BY GIDX ASCENDING; the entries of one group keep the array
+ *     order of the records that produced them.  (The reference's next stage
+ *     files outgoing decisions under their paxosID anyway:
+ *     PaxosPacketBatcher.java:121-156; per group the decided stream is exactly
+ *     the sequential one, across groups the reference defines no order.)
  *   - one submitting thread per engine at a time (the ConsumerTask single-
  *     consumer discipline, ConsumerTask.java:163-174); different engines are
  *     fully concurrent.
@@ -198,7 +202,7 @@ int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
  * (PaxosCoordinator.java:210-250) -> PaxosCoordinatorState.handleAcceptReplyMyBallot /
  * handleAcceptReplyHigherBallot (PaxosCoordinatorState.java:597-683).
  * One record = one vote (one slot of a BATCHED_ACCEPT_REPLY).  Compacted outputs: one
- * entry per DECISION / PREEMPTED, in vote order; *n_out of them (<= n).
+ * entry per DECISION / PREEMPTED, grouped by gidx (ORDER above); *n_out of them (<= n).
  * status (nullable): per-vote GPX_S_*.
  */
 int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
