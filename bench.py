@@ -43,6 +43,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--cpu-rounds", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true",
+                    help="no cross-call pipelining: every kernel of every call in order on one stream")
     args = ap.parse_args()
 
     import torch
@@ -73,6 +75,9 @@ def main():
     torch.cuda.set_stream(tstream)
     assert tstream.cuda_stream != 0
     eng.set_stream(tstream.cuda_stream)
+    # pipelined mode (include/gpx.h): the partition front end of call N+1 overlaps the per-bucket
+    # back end of call N on two engine streams; group state is still updated in call order
+    eng.set_pipeline(not args.serial)
     mem = np.tile(np.array(members, np.int32), (G, 1))
     assert (eng.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
 
@@ -105,6 +110,7 @@ def main():
 
     for r in range(warmup):
         step(r)
+    eng.sync()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -113,7 +119,9 @@ def main():
     ev0.record()
     for r in range(warmup, warmup + steps):
         step(r)
+    eng.fence()  # order the caller's stream (and ev1) behind everything submitted
     ev1.record()
+    eng.sync()
     torch.cuda.synchronize()
     barrier()
     torch.cuda.synchronize()
@@ -146,6 +154,9 @@ def main():
     roofline = None
     kstats = {}
     if psteps > 0:
+        # per-kernel durations are taken WITHOUT cross-call overlap (each kernel alone on the GPU)
+        eng.sync()
+        eng.set_pipeline(False)
         eng.profile(2)
         for r in range(warmup + steps, rounds):
             step(r)
@@ -238,6 +249,7 @@ def main():
             "votes_per_sec": round(votes_total / elapsed, 1),
             "votes_per_sec_per_gpu": round(votes_total / elapsed / world, 1),
             "gpu_ms_per_step_rank0": round(gpu_ms / steps, 4),
+            "pipelined": not args.serial,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
         }

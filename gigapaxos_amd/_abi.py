@@ -87,6 +87,8 @@ _SIGS = {
 }
 _DEV_SIGS = {
     "engine_set_stream": [_VP],
+    "engine_set_pipeline": [C.c_int32],
+    "engine_fence": [],
     "propose_batch_dev": [C.c_int32] + [_VP] * 7,
     "accept_batch_dev": [C.c_int32] + [_VP] * 15,
     "accept_reply_batch_dev": [C.c_int32] + [_VP] * 14,
@@ -310,6 +312,14 @@ class Engine:
         """Run the *_dev calls on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
         self.lib.check(self.lib.fn["engine_set_stream"](self.h, _VP(hip_stream_handle or None)),
                        "engine_set_stream")
+
+    def set_pipeline(self, on: bool):
+        """Overlap the streaming front end of call N+1 with the back end of call N (*_dev calls)."""
+        self.lib.check(self.lib.fn["engine_set_pipeline"](self.h, int(bool(on))), "engine_set_pipeline")
+
+    def fence(self):
+        """Pipelined mode: order later work on the caller's stream behind everything submitted."""
+        self.lib.check(self.lib.fn["engine_fence"](self.h), "engine_fence")
 
     def call_dev(self, name: str, n: int, *ptrs):
         """Raw asynchronous call of gpx_<name>_dev with integer device addresses (0 = NULL)."""

@@ -44,8 +44,28 @@ struct gpx_engine {
   int device = 0;
   DevState S{};
   DevScratch X{};
-  hipStream_t own_stream = nullptr;
-  hipStream_t stream = nullptr;
+  hipStream_t own_stream = nullptr;   /* back-end stream when the caller gave none */
+  hipStream_t front_stream = nullptr; /* pipelined mode: streaming front end (k_hist, k_scatter_*) */
+  hipStream_t back_stream = nullptr;  /* pipelined mode: per-bucket back end (k_bucket_*, k_emit_*) */
+  hipStream_t user_stream = nullptr;  /* gpx_engine_set_stream */
+  hipStream_t sF = nullptr, sB = nullptr; /* the streams in force (equal unless pipelined) */
+  hipStream_t stream = nullptr;           /* where the next launch goes: sF inside a front section, else sB */
+  bool pipeline = false;
+  /* front-end scratch is double-buffered so that call N+1's front end can run beside call N's
+   * back end; evF[s] = front end of the call using set s done, evB[s] = its back end done */
+  struct FrontSet {
+    int32_t *bucket_tot = nullptr, *tile_rel = nullptr, *bucket_off = nullptr;
+    Rec* rec = nullptr;
+    hipEvent_t evF = nullptr, evB = nullptr;
+    bool used = false;
+  } fs[2];
+  hipEvent_t ev_in = nullptr;
+  uint64_t call_seq = 0;
+  struct Range {
+    const void* p;
+    size_t n;
+  };
+  std::vector<Range> last_outputs; /* buffers the previous call's back end writes */
   std::vector<void*> allocs;
   /* device staging for the host-pointer entry points */
   int32_t* st_i32[12] = {};
@@ -107,7 +127,8 @@ struct LaunchScope {
 
 int flush_profile(gpx_engine* e) {
   if (e->pending.empty()) return GPX_OK;
-  HIPCHK(hipStreamSynchronize(e->stream));
+  HIPCHK(hipStreamSynchronize(e->sF));
+  HIPCHK(hipStreamSynchronize(e->sB));
   for (auto& pe : e->pending) {
     float ms = 0.f;
     hipEventElapsedTime(&ms, pe.start, pe.stop);
@@ -149,6 +170,71 @@ inline bool aligned16(std::initializer_list<const void*> ps) {
   for (const void* p : ps)
     if ((uintptr_t)p & 15) return false;
   return true;
+}
+
+using Range = gpx_engine::Range;
+inline bool ranges_overlap(std::initializer_list<Range> a, const std::vector<Range>& b) {
+  for (const Range& x : a) {
+    if (!x.p || !x.n) continue;
+    for (const Range& y : b) {
+      if (!y.p || !y.n) continue;
+      const char *x0 = (const char*)x.p, *y0 = (const char*)y.p;
+      if (x0 < y0 + y.n && y0 < x0 + x.n) return true;
+    }
+  }
+  return false;
+}
+
+void apply_streams(gpx_engine* e) {
+  if (e->pipeline) {
+    e->sF = e->front_stream;
+    e->sB = e->back_stream;
+  } else {
+    e->sF = e->sB = e->user_stream ? e->user_stream : e->own_stream;
+  }
+  e->stream = e->sB;
+}
+
+/* Opens the front section of a batch call: picks the scratch set, points e->X at it, orders the
+ * front stream behind (a) whatever the caller enqueued on its own stream so far (input producers),
+ * (b) the back end of the call that used this scratch set before (two calls ago), (c) the previous
+ * call's back end when this call reads, or writes early, a buffer that back end writes.
+ * `touched` = this call's inputs and the outputs its front end already writes (status prefill,
+ * zeroed rows of dropped records). */
+int begin_front(gpx_engine* e, std::initializer_list<Range> touched) {
+  const int s = (int)(e->call_seq & 1);
+  gpx_engine::FrontSet& f = e->fs[s];
+  e->X.bucket_tot = f.bucket_tot;
+  e->X.tile_rel = f.tile_rel;
+  e->X.bucket_off = f.bucket_off;
+  e->X.rec = f.rec;
+  e->stream = e->sF;
+  if (e->pipeline) {
+    if (e->user_stream) {
+      hipEventRecord(e->ev_in, e->user_stream);
+      hipStreamWaitEvent(e->sF, e->ev_in, 0);
+    }
+    if (f.used) hipStreamWaitEvent(e->sF, f.evB, 0);
+    gpx_engine::FrontSet& prev = e->fs[s ^ 1];
+    if (prev.used && ranges_overlap(touched, e->last_outputs)) hipStreamWaitEvent(e->sF, prev.evB, 0);
+  }
+  return s;
+}
+/* front section done: the back end (on sB) may start once the records are partitioned */
+void begin_back(gpx_engine* e, int s) {
+  if (e->pipeline) {
+    hipEventRecord(e->fs[s].evF, e->sF);
+    hipStreamWaitEvent(e->sB, e->fs[s].evF, 0);
+  }
+  e->stream = e->sB;
+}
+void end_call(gpx_engine* e, int s, std::initializer_list<Range> outputs) {
+  if (e->pipeline) {
+    hipEventRecord(e->fs[s].evB, e->sB);
+    e->fs[s].used = true;
+    e->last_outputs.assign(outputs.begin(), outputs.end());
+  }
+  e->call_seq++;
 }
 
 /* bucket partition front end, part 1: per-bucket record counts of the batch */
@@ -208,7 +294,14 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     HIPCHK(hipGetDevice(&e->device));
   }
   HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
-  e->stream = e->own_stream;
+  HIPCHK(hipStreamCreateWithFlags(&e->front_stream, hipStreamNonBlocking));
+  HIPCHK(hipStreamCreateWithFlags(&e->back_stream, hipStreamNonBlocking));
+  HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
+  for (auto& f : e->fs) {
+    HIPCHK(hipEventCreateWithFlags(&f.evF, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&f.evB, hipEventDisableTiming));
+  }
+  apply_streams(e);
   const size_t G = (size_t)cfg->max_groups, W = (size_t)cfg->window, K = (size_t)cfg->kmax;
   const size_t N = (size_t)cfg->max_batch;
   DevState& S = e->S;
@@ -273,10 +366,16 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bucket_lds));
   }
-  A(X.bucket_tot, (size_t)X.nbk, true);
-  A(X.tile_rel, ((N + GPX_TILE - 1) / GPX_TILE) * (size_t)X.nbk, false);
-  A(X.bucket_off, (size_t)X.nbk + 1, true);
-  A(X.rec, N, false);
+  for (auto& f : e->fs) { /* double-buffered front-end scratch */
+    A(f.bucket_tot, (size_t)X.nbk, true);
+    A(f.tile_rel, ((N + GPX_TILE - 1) / GPX_TILE) * (size_t)X.nbk, false);
+    A(f.bucket_off, (size_t)X.nbk + 1, true);
+    A(f.rec, N, false);
+  }
+  X.bucket_tot = e->fs[0].bucket_tot;
+  X.tile_rel = e->fs[0].tile_rel;
+  X.bucket_off = e->fs[0].bucket_off;
+  X.rec = e->fs[0].rec;
   A(X.rank2, N, false);
   A(X.perm, N, false);
   A(X.o_rec, N, false);
@@ -293,32 +392,66 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
 
 int gpx_engine_destroy(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
-  if (h->stream) hipStreamSynchronize(h->stream);
+  if (h->sF) hipStreamSynchronize(h->sF);
+  if (h->sB) hipStreamSynchronize(h->sB);
   for (auto& pe : h->pending) {
     hipEventDestroy(pe.start);
     hipEventDestroy(pe.stop);
   }
   for (void* p : h->allocs) hipFree(p);
   if (h->own_stream) hipStreamDestroy(h->own_stream);
+  if (h->front_stream) hipStreamDestroy(h->front_stream);
+  if (h->back_stream) hipStreamDestroy(h->back_stream);
+  if (h->ev_in) hipEventDestroy(h->ev_in);
+  for (auto& f : h->fs) {
+    if (f.evF) hipEventDestroy(f.evF);
+    if (f.evB) hipEventDestroy(f.evB);
+  }
   delete h;
   return GPX_OK;
 }
 
 int gpx_engine_set_stream(gpx_engine* h, void* hip_stream) {
   if (!h) return GPX_EINVAL;
-  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  HIPCHK(hipStreamSynchronize(h->sF));
+  HIPCHK(hipStreamSynchronize(h->sB));
+  h->user_stream = (hipStream_t)hip_stream;
+  apply_streams(h);
+  return GPX_OK;
+}
+
+int gpx_engine_set_pipeline(gpx_engine* h, int32_t on) {
+  if (!h) return GPX_EINVAL;
+  HIPCHK(hipStreamSynchronize(h->sF));
+  HIPCHK(hipStreamSynchronize(h->sB));
+  h->pipeline = on != 0;
+  for (auto& f : h->fs) f.used = false;
+  h->last_outputs.clear();
+  apply_streams(h);
+  return GPX_OK;
+}
+
+int gpx_engine_fence(gpx_engine* h) {
+  if (!h) return GPX_EINVAL;
+  if (h->pipeline && h->user_stream) {
+    /* everything submitted so far completes before later work on the caller's stream */
+    HIPCHK(hipEventRecord(h->ev_in, h->sB));
+    HIPCHK(hipStreamWaitEvent(h->user_stream, h->ev_in, 0));
+  }
   return GPX_OK;
 }
 
 int gpx_engine_sync(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->sF));
+  HIPCHK(hipStreamSynchronize(h->sB));
   return GPX_OK;
 }
 
 int gpx_engine_counters(gpx_engine* h, uint64_t out[3]) {
   if (!h || !out) return GPX_EINVAL;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->sF));
+  HIPCHK(hipStreamSynchronize(h->sB));
   unsigned long long tmp[3];
   HIPCHK(hipMemcpy(tmp, h->X.counters, sizeof(tmp), hipMemcpyDeviceToHost));
   for (int i = 0; i < 3; i++) out[i] = tmp[i];
@@ -362,10 +495,13 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
   int rc = check_batch(h, n);
   if (rc != GPX_OK) return rc;
   if (n == 0) {
-    HIPCHK(hipMemsetAsync(n_out, 0, sizeof(int32_t), h->stream));
+    HIPCHK(hipMemsetAsync(n_out, 0, sizeof(int32_t), h->sB));
     return GPX_OK;
   }
   gpx_engine* e = h;
+  const size_t b4 = (size_t)n * 4;
+  const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {acceptor, b4},
+                                 {max_cp, b4}, {status, (size_t)n}});
   front_hist(e, n, gidx, status, 1);
   const int ntiles = ntiles_for(n);
   if (aligned16({gidx, bnum, bcoord, slot, acceptor, max_cp}))
@@ -374,6 +510,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
   else
     LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
              ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+  begin_back(e, fs);
   if (e->cfg.kmax <= 4)
     launch_bucket_ar<4>(e, status);
   else if (e->cfg.kmax <= 8)
@@ -382,6 +519,8 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     launch_bucket_ar<16>(e, status);
   LAUNCH(e, "k_emit_dec", k_emit_dec, e->X.nbk, e->X, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp,
          d_kind, n_out, &e->X.counters[1]);
+  end_call(e, fs, {{d_gidx, b4}, {d_slot, b4}, {d_bnum, b4}, {d_bcoord, b4}, {d_median_cp, b4},
+                   {d_kind, (size_t)n}, {n_out, 4}, {status, (size_t)n}});
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -394,18 +533,25 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   int rc = check_batch(h, n);
   if (rc != GPX_OK) return rc;
   if (n == 0) {
-    HIPCHK(hipMemsetAsync(n_runs, 0, sizeof(int32_t), h->stream));
+    HIPCHK(hipMemsetAsync(n_runs, 0, sizeof(int32_t), h->sB));
     return GPX_OK;
   }
   gpx_engine* e = h;
+  const size_t b4 = (size_t)n * 4;
+  const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {median_cp, b4},
+                                 {a_flags, (size_t)n}, {r_bnum, b4}, {r_bcoord, b4}, {r_maxcp, b4},
+                                 {r_flags, (size_t)n}, {status, (size_t)n}});
   front_hist(e, n, gidx, status, 0);
   const int ntiles = ntiles_for(n);
   LAUNCH_F(e, "k_scatter_ac", k_scatter_ac, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
            e->S.G, e->X,
            gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+  begin_back(e, fs);
   LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags,
            status);
   LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+  end_call(e, fs, {{r_bnum, b4}, {r_bcoord, b4}, {r_maxcp, b4}, {r_flags, (size_t)n},
+                   {status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -417,18 +563,23 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   int rc = check_batch(h, n);
   if (rc != GPX_OK) return rc;
   if (n == 0) {
-    HIPCHK(hipMemsetAsync(n_runs, 0, sizeof(int32_t), h->stream));
+    HIPCHK(hipMemsetAsync(n_runs, 0, sizeof(int32_t), h->sB));
     return GPX_OK;
   }
   gpx_engine* e = h;
+  const size_t b4 = (size_t)n * 4;
+  const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {median_cp, b4},
+                                 {c_kind, (size_t)n}, {status, (size_t)n}});
   front_hist(e, n, gidx, status, 0);
   const int ntiles = ntiles_for(n);
   LAUNCH_F(e, "k_scatter_ac", k_scatter_ac, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
            e->S.G, e->X,
            gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
            (int32_t*)nullptr, (uint8_t*)nullptr);
+  begin_back(e, fs);
   LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
   LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+  end_call(e, fs, {{status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -440,17 +591,22 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
   if (rc != GPX_OK) return rc;
   if (n == 0) return GPX_OK;
   gpx_engine* e = h;
+  const size_t b4 = (size_t)n * 4;
+  const int fs = begin_front(e, {{gidx, b4}, {is_stop, (size_t)n}, {slot, b4}, {bnum, b4}, {bcoord, b4},
+                                 {median_cp, b4}, {status, (size_t)n}});
   front_hist(e, n, gidx, status, 0);
   const int ntiles = ntiles_for(n);
   LAUNCH_F(e, "k_scatter_pr", k_scatter_pr, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
            e->S.G, e->X,
            gidx, is_stop, slot, bnum, bcoord, median_cp);
+  begin_back(e, fs);
   if (e->cfg.kmax <= 4)
     launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status);
   else if (e->cfg.kmax <= 8)
     launch_bucket_propose<8>(e, slot, bnum, bcoord, median_cp, status);
   else
     launch_bucket_propose<16>(e, slot, bnum, bcoord, median_cp, status);
+  end_call(e, fs, {{slot, b4}, {bnum, b4}, {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -458,8 +614,10 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
 /* ---- host-pointer data path ---------------------------------------------------- */
 /* H2D into the engine's staging columns, the _dev twin, D2H of the results.        */
 
-#define H2D(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->stream))
-#define D2H(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->stream))
+#define H2D(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->sF))
+/* lifecycle calls change group state: everything on the back-end stream, in call order */
+#define H2D_B(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->sB))
+#define D2H(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->sB))
 
 int gpx_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
                       int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
@@ -479,7 +637,7 @@ int gpx_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8
   D2H(bcoord, h->st_i32[3], b4);
   D2H(median_cp, h->st_i32[4], b4);
   D2H(status, h->st_u8[1], (size_t)n);
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->sB));
   return GPX_OK;
 }
 
@@ -511,13 +669,13 @@ int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   D2H(r_maxcp, h->st_i32[7], b4);
   D2H(r_flags, h->st_u8[1], (size_t)n);
   D2H(status, h->st_u8[2], (size_t)n);
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->sB));
   const size_t m4 = (size_t)(*n_runs) * 4;
   if (m4) {
     D2H(x_gidx, h->st_i32[8], m4);
     D2H(x_first, h->st_i32[9], m4);
     D2H(x_count, h->st_i32[10], m4);
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->sB));
   }
   return GPX_OK;
 }
@@ -546,7 +704,7 @@ int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
   if (rc != GPX_OK) return rc;
   D2H(n_out, h->st_count, 4);
   if (status) D2H(status, h->st_u8[1], (size_t)n);
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->sB));
   const size_t m = (size_t)(*n_out);
   if (m) {
     D2H(d_gidx, h->st_i32[6], m * 4);
@@ -555,7 +713,7 @@ int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
     D2H(d_bcoord, h->st_i32[9], m * 4);
     D2H(d_median_cp, h->st_i32[10], m * 4);
     D2H(d_kind, h->st_u8[0], m);
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->sB));
   }
   return GPX_OK;
 }
@@ -582,13 +740,13 @@ int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   if (rc != GPX_OK) return rc;
   D2H(n_runs, h->st_count, 4);
   D2H(status, h->st_u8[1], (size_t)n);
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->sB));
   const size_t m4 = (size_t)(*n_runs) * 4;
   if (m4) {
     D2H(x_gidx, h->st_i32[5], m4);
     D2H(x_first, h->st_i32[6], m4);
     D2H(x_count, h->st_i32[7], m4);
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->sB));
   }
   return GPX_OK;
 }
@@ -614,14 +772,14 @@ int gpx_group_create(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   int rc = GPX_OK;
   for (int32_t o = 0; o < n && rc == GPX_OK; o += chunk) {
     const int32_t c = std::min(chunk, n - o);
-    H2D(d_g, gidx + o, (size_t)c * 4);
-    H2D(d_m, members + (size_t)o * h->cfg.kmax, (size_t)c * 4 * h->cfg.kmax);
-    H2D(d_k, k + o, (size_t)c);
-    H2D(d_r, rows + o, (size_t)c * sizeof(gpx_hri));
+    H2D_B(d_g, gidx + o, (size_t)c * 4);
+    H2D_B(d_m, members + (size_t)o * h->cfg.kmax, (size_t)c * 4 * h->cfg.kmax);
+    H2D_B(d_k, k + o, (size_t)c);
+    H2D_B(d_r, rows + o, (size_t)c * sizeof(gpx_hri));
     LAUNCH(h, "k_group_create", k_group_create, grid_for(c), h->S, c, (const int32_t*)d_g,
            (const int32_t*)d_m, (const uint8_t*)d_k, (const gpx_hri*)d_r, d_s);
     if (status) D2H(status + o, d_s, (size_t)c);
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->sB));
   }
   hipFree(d_g);
   hipFree(d_m);
@@ -646,12 +804,12 @@ static int retire_impl(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mo
   HIPCHK(hipMalloc((void**)&d_r, (size_t)c0 * sizeof(gpx_hri)));
   for (int32_t o = 0; o < n; o += chunk) {
     const int32_t c = std::min(chunk, n - o);
-    H2D(d_g, gidx + o, (size_t)c * 4);
+    H2D_B(d_g, gidx + o, (size_t)c * 4);
     LAUNCH(h, "k_group_retire", k_group_retire, grid_for(c), h->S, c, (const int32_t*)d_g, mode, d_r,
            d_s);
     if (rows) D2H(rows + o, d_r, (size_t)c * sizeof(gpx_hri));
     if (status) D2H(status + o, d_s, (size_t)c);
-    HIPCHK(hipStreamSynchronize(h->stream));
+    HIPCHK(hipStreamSynchronize(h->sB));
   }
   hipFree(d_g);
   hipFree(d_s);
@@ -674,7 +832,7 @@ int gpx_group_snapshot(gpx_engine* h, int32_t n, const int32_t* gidx, gpx_hri* r
 /* canonical dump (same word layout as the oracle's orc_group_dump) */
 int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
   if (!h || !buf) return GPX_EINVAL;
-  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipStreamSynchronize(h->sB));
   std::vector<int32_t> w;
   const DevState& S = h->S;
   auto rd32 = [&](const void* base, int64_t idx, int32_t* out) -> hipError_t {

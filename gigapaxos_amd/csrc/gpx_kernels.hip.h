@@ -191,6 +191,34 @@ __device__ __forceinline__ int32_t tile_of_block(int32_t ntiles) {
   return (int32_t)(blockIdx.x & 7) * per + (int32_t)(blockIdx.x >> 3);
 }
 
+/* LDS bucket counters under sorted input: when every active lane of the wave addresses the SAME
+ * bucket (a batch the host already grouped by group, or a proposal batch in gidx order), one lane
+ * adds the whole wave's count instead of 64 serialised LDS atomics on one address.  The check is
+ * wave-uniform; shuffled input takes the per-lane path. */
+__device__ __forceinline__ void bucket_count(int32_t* lds, int32_t b) {
+  const unsigned long long act = __ballot(1);
+  const int32_t b0 = __builtin_amdgcn_readfirstlane(b);
+  if (__ballot(b == b0) == act) {
+    if ((int)__lane_id() == __ffsll((long long)act) - 1) atomicAdd(&lds[b0], (int32_t)__popcll(act));
+  } else {
+    atomicAdd(&lds[b], 1);
+  }
+}
+/* same for the cursors: returns this lane's position */
+__device__ __forceinline__ int32_t bucket_take(int32_t* lds, int32_t b) {
+  const unsigned long long act = __ballot(1);
+  const int32_t b0 = __builtin_amdgcn_readfirstlane(b);
+  if (__ballot(b == b0) == act) {
+    const int lane = (int)__lane_id();
+    const int leader = __ffsll((long long)act) - 1;
+    const int32_t rank = (int32_t)__popcll(act & ((1ull << lane) - 1ull));
+    int32_t base = 0;
+    if (lane == leader) base = atomicAdd(&lds[b0], (int32_t)__popcll(act));
+    return __shfl(base, leader, 64) + rank;
+  }
+  return atomicAdd(&lds[b], 1);
+}
+
 /* LDS histogram of one tile over buckets; returns the number of out-of-range gidx seen by this
  * lane.  VEC: gidx is 16-byte aligned -> 4 consecutive records per lane per load. */
 template <bool VEC>
@@ -208,7 +236,7 @@ __device__ __forceinline__ int32_t tile_histogram(int32_t n, int64_t base,
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           if ((uint32_t)gg[q] < (uint32_t)G)
-            atomicAdd(&lds[gg[q] >> shift], 1);
+            bucket_count(lds, gg[q] >> shift);
           else
             bad++;
         }
@@ -217,7 +245,7 @@ __device__ __forceinline__ int32_t tile_histogram(int32_t n, int64_t base,
           if (i0 + q < n) {
             const int32_t g = gidx[i0 + q];
             if ((uint32_t)g < (uint32_t)G)
-              atomicAdd(&lds[g >> shift], 1);
+              bucket_count(lds, g >> shift);
             else
               bad++;
           }
@@ -231,7 +259,7 @@ __device__ __forceinline__ int32_t tile_histogram(int32_t n, int64_t base,
       if (i < n) {
         const int32_t g = gidx[i];
         if ((uint32_t)g < (uint32_t)G)
-          atomicAdd(&lds[g >> shift], 1);
+          bucket_count(lds, g >> shift);
         else
           bad++;
       }
@@ -319,7 +347,7 @@ __device__ __forceinline__ void put_rec(const DevScratch& X, int32_t* lds, int32
                                         int64_t i, int32_t g, int32_t a, int32_t b, int32_t c,
                                         int32_t bnum, int32_t bcoord) {
   if ((uint32_t)g < (uint32_t)G) {
-    const int32_t pos = atomicAdd(&lds[g >> X.shift], 1);
+    const int32_t pos = bucket_take(lds, g >> X.shift);
     Rec r;
     r.idx = (int32_t)i;
     r.lg = g & mask;

@@ -134,8 +134,25 @@ int gpx_engine_destroy(gpx_engine* h);
 const char* gpx_last_error(void);
 /* run subsequent *_dev calls on this hipStream_t (NULL = the engine's own stream) */
 int gpx_engine_set_stream(gpx_engine* h, void* hip_stream);
-/* block until everything submitted on the engine's stream has finished */
+/* block until everything submitted to the engine has finished */
 int gpx_engine_sync(gpx_engine* h);
+/*
+ * Pipelined mode (off by default).  A batch call has a streaming front end (partition of the
+ * batch by group bucket: reads only the input columns) and a per-bucket back end (the state
+ * machine proper).  With pipelining on, the *_dev calls run the front end of call N+1 beside the
+ * back end of call N on two engine-owned streams (front-end scratch is double-buffered); group
+ * state is still updated strictly in call order.  Stream contract in this mode:
+ *   - inputs may be produced by work already enqueued on the caller's stream
+ *     (gpx_engine_set_stream): the front end waits for it;
+ *   - a call whose inputs (or early-written outputs) overlap the previous call's outputs is
+ *     detected and not overlapped;
+ *   - outputs are complete after gpx_engine_sync, or, for later work on the caller's stream,
+ *     after gpx_engine_fence.
+ * With pipelining off every *_dev call is simply enqueued on the caller's (or the engine's
+ * own) stream and gpx_engine_fence is a no-op.
+ */
+int gpx_engine_set_pipeline(gpx_engine* h, int32_t on);
+int gpx_engine_fence(gpx_engine* h);
 
 /*
  * replaces: PaxosManager.createPaxosInstance(Map nameStates, gms) batch create

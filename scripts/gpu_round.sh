@@ -26,10 +26,15 @@ timeout 600 python bench.py >"$OUT/bench.json" 2>"$OUT/bench.err"
 echo "bench exit $?"
 cat "$OUT/bench.json"
 tail -3 "$OUT/bench.err"
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --profile-steps 0 --no-cpu-baseline"
+# per-kernel traces are taken with --serial (no cross-call overlap: each kernel alone on the GPU, the
+# regime bench.py's own hipEvent pass measures); the pipelined default is traced once as well
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --profile-steps 0 --no-cpu-baseline --serial"
+BENCH_PIPE="python $REPO/bench.py --steps 10 --warmup 2 --profile-steps 0 --no-cpu-baseline"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_kt" -o kt -- $BENCH >"$OUT/prof_kt.log" 2>&1
 echo "kt exit $?"
+timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_kt_pipe" -o ktp -- $BENCH_PIPE >"$OUT/prof_kt_pipe.log" 2>&1
+echo "kt pipelined exit $?"
 if [ $NOPMC = 0 ]; then
   timeout 600 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d "$OUT/prof_fetch" -o fetch -- $BENCH >"$OUT/prof_fetch.log" 2>&1
   echo "fetch exit $?"
@@ -45,6 +50,8 @@ if [ -n "$KT" ] && [ -n "$FE" ] && [ -n "$WR" ]; then
 elif [ -n "$KT" ]; then
   python scripts/rocprof_summary.py "$KT" "$KT" "$KT" "$OUT/rocprof_summary.txt" "$OUT/pmc_traffic.json" | head -30
 fi
+KTP=$(find "$OUT/prof_kt_pipe" -name '*_results.db' | head -1)
+[ -n "$KTP" ] && python scripts/rocprof_summary.py "$KTP" "$KTP" "$KTP" "$OUT/rocprof_summary_pipelined.txt" /dev/null | head -12
 # keep the merge-back small: drop the raw databases, keep csv/txt/json
 find "$OUT" -name '*.db' -size +8M -delete
 du -sh "$OUT"
