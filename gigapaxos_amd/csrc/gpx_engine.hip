@@ -75,7 +75,8 @@ struct gpx_engine {
   bool profiling = false;
   std::vector<PendingEvent> pending;
   std::map<std::string, std::pair<uint64_t, double>> prof;
-  size_t bucket_lds = 0;
+  size_t bucket_lds = 0;      /* dynamic LDS of the current per-bucket launch */
+  int32_t lds_recs_max = 0;   /* staging capacity the engine was sized for (kmax records per group) */
   int bucket_threads = 256;
 };
 
@@ -221,7 +222,16 @@ int begin_front(gpx_engine* e, std::initializer_list<Range> touched) {
   return s;
 }
 /* front section done: the back end (on sB) may start once the records are partitioned */
-void begin_back(gpx_engine* e, int s) {
+void begin_back(gpx_engine* e, int s, int32_t n) {
+  /* LDS staging area of the per-bucket kernel, sized for THIS batch: mean records per bucket
+   * + 25 % + 128, so that a thin batch (e.g. one proposal per group on an engine sized for 5-vote
+   * rounds) still gets many workgroups per CU.  Buckets above it take the global-memory path. */
+  {
+    int64_t want = (int64_t)n / std::max(1, e->X.nbk);
+    want = (want + want / 4 + 128 + 63) / 64 * 64;
+    e->X.lds_recs = (int32_t)std::max<int64_t>(256, std::min<int64_t>(want, e->lds_recs_max));
+    e->bucket_lds = GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs);
+  }
   if (e->pipeline) {
     hipEventRecord(e->fs[s].evF, e->sF);
     hipStreamWaitEvent(e->sB, e->fs[s].evF, 0);
@@ -356,6 +366,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     want = std::min<int64_t>(want, std::min<int64_t>(lds_cap, (int64_t)GPX_BUCKET_ITEMS * e->bucket_threads));
     if (const char* lr = getenv("GPX_LDS_RECS")) want = std::min<int64_t>(want, std::max(64, atoi(lr)));
     X.lds_recs = (int32_t)want;
+    e->lds_recs_max = X.lds_recs;
   }
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs);
   if (e->bucket_lds > 64 * 1024) { /* more dynamic LDS than the default limit: opt in per kernel */
@@ -510,7 +521,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
   else
     LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
              ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-  begin_back(e, fs);
+  begin_back(e, fs, n);
   if (e->cfg.kmax <= 4)
     launch_bucket_ar<4>(e, status);
   else if (e->cfg.kmax <= 8)
@@ -546,7 +557,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   LAUNCH_F(e, "k_scatter_ac", k_scatter_ac, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
            e->S.G, e->X,
            gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
-  begin_back(e, fs);
+  begin_back(e, fs, n);
   LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags,
            status);
   LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
@@ -576,7 +587,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
            e->S.G, e->X,
            gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
            (int32_t*)nullptr, (uint8_t*)nullptr);
-  begin_back(e, fs);
+  begin_back(e, fs, n);
   LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
   LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   end_call(e, fs, {{status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
@@ -599,7 +610,7 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
   LAUNCH_F(e, "k_scatter_pr", k_scatter_pr, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
            e->S.G, e->X,
            gidx, is_stop, slot, bnum, bcoord, median_cp);
-  begin_back(e, fs);
+  begin_back(e, fs, n);
   if (e->cfg.kmax <= 4)
     launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status);
   else if (e->cfg.kmax <= 8)
