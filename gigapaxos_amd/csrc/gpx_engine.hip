@@ -78,6 +78,7 @@ struct gpx_engine {
   size_t bucket_lds = 0;      /* dynamic LDS of the current per-bucket launch */
   int32_t lds_recs_max = 0;   /* staging capacity the engine was sized for (kmax records per group) */
   int bucket_threads = 256;
+  size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
 };
 
 namespace {
@@ -230,7 +231,7 @@ void begin_back(gpx_engine* e, int s, int32_t n) {
     int64_t want = (int64_t)n / std::max(1, e->X.nbk);
     want = (want + want / 4 + 128 + 63) / 64 * 64;
     e->X.lds_recs = (int32_t)std::max<int64_t>(256, std::min<int64_t>(want, e->lds_recs_max));
-    e->bucket_lds = GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs);
+    e->bucket_lds = GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs) + e->lds_pad;
   }
   if (e->pipeline) {
     hipEventRecord(e->fs[s].evF, e->sF);
@@ -362,13 +363,14 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     int64_t want = (int64_t)cfg->kmax * X.gb;
     want += want / 4 + 64;
     if (cfg->kmax <= 3 && X.gb == 256) want = 960;
-    const int64_t lds_cap = ((int64_t)160 * 1024 - 1024 - (int64_t)X.gb * 8) / (8 + (int64_t)sizeof(Rec));
+    const int64_t lds_cap = ((int64_t)160 * 1024 - 1024 - (int64_t)X.gb * 8) / (8 + 4 * GPX_PAY_WORDS);
     want = std::min<int64_t>(want, std::min<int64_t>(lds_cap, (int64_t)GPX_BUCKET_ITEMS * e->bucket_threads));
     if (const char* lr = getenv("GPX_LDS_RECS")) want = std::min<int64_t>(want, std::max(64, atoi(lr)));
     X.lds_recs = (int32_t)want;
     e->lds_recs_max = X.lds_recs;
   }
-  e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs);
+  if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
+  e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
   if (e->bucket_lds > 64 * 1024) { /* more dynamic LDS than the default limit: opt in per kernel */
     const void* fns[] = {(const void*)k_bucket_ar<4>,      (const void*)k_bucket_ar<8>,
                          (const void*)k_bucket_ar<16>,     (const void*)k_bucket_propose<4>,
