@@ -238,6 +238,12 @@ void begin_back(gpx_engine* e, int s, int32_t n) {
     hipStreamWaitEvent(e->sB, e->fs[s].evF, 0);
   }
   e->stream = e->sB;
+  /* look-back epoch of this call's per-bucket kernel: 30 bits, never 0 (0 = the cleared array) */
+  e->X.epoch = (e->X.epoch + 1u) & 0x3fffffffu;
+  if (e->X.epoch == 0) {
+    hipMemsetAsync(e->X.lb, 0, (size_t)e->X.nbk * sizeof(unsigned long long), e->sB);
+    e->X.epoch = 1;
+  }
 }
 void end_call(gpx_engine* e, int s, std::initializer_list<Range> outputs) {
   if (e->pipeline) {
@@ -267,8 +273,8 @@ int check_batch(gpx_engine* h, int32_t n) {
 }
 
 template <int KMAX>
-void launch_bucket_ar(gpx_engine* e, uint8_t* status) {
-  LAUNCH_B(e, "k_bucket_ar", (k_bucket_ar<KMAX>), e->S, e->X, status);
+void launch_bucket_ar(gpx_engine* e, uint8_t* status, const DecCols& D, const OutTotals& T) {
+  LAUNCH_B(e, "k_bucket_ar", (k_bucket_ar<KMAX>), e->S, e->X, status, D, T);
 }
 template <int KMAX>
 void launch_bucket_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t* bcoord,
@@ -394,6 +400,10 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.o_rec, N, false);
   A(X.bucket_nout, (size_t)X.nbk, true);
   A(X.counters, 3, true);
+  A(X.lb, (size_t)X.nbk, true);
+  A(X.err, 1, true);
+  X.epoch = 0;
+  X.lookback = getenv("GPX_NO_LOOKBACK") ? 0 : 1; /* 0: per-bucket rows + k_emit_* (two kernels) */
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
   A(e->st_count, 4, true);
@@ -458,6 +468,12 @@ int gpx_engine_sync(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
   HIPCHK(hipStreamSynchronize(h->sF));
   HIPCHK(hipStreamSynchronize(h->sB));
+  int32_t err = 0;
+  HIPCHK(hipMemcpy(&err, h->X.err, sizeof(err), hipMemcpyDeviceToHost));
+  if (err) {
+    snprintf(g_err, sizeof(g_err), "device error word %d (look-back over buckets timed out)", err);
+    return GPX_EDEVICE;
+  }
   return GPX_OK;
 }
 
@@ -524,14 +540,17 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
              ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
   begin_back(e, fs, n);
+  const DecCols D{d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind};
+  const OutTotals T{n_out, &e->X.counters[1]};
   if (e->cfg.kmax <= 4)
-    launch_bucket_ar<4>(e, status);
+    launch_bucket_ar<4>(e, status, D, T);
   else if (e->cfg.kmax <= 8)
-    launch_bucket_ar<8>(e, status);
+    launch_bucket_ar<8>(e, status, D, T);
   else
-    launch_bucket_ar<16>(e, status);
-  LAUNCH(e, "k_emit_dec", k_emit_dec, e->X.nbk, e->X, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp,
-         d_kind, n_out, &e->X.counters[1]);
+    launch_bucket_ar<16>(e, status, D, T);
+  if (!e->X.lookback)
+    LAUNCH(e, "k_emit_dec", k_emit_dec, e->X.nbk, e->X, d_gidx, d_slot, d_bnum, d_bcoord,
+           d_median_cp, d_kind, n_out, &e->X.counters[1]);
   end_call(e, fs, {{d_gidx, b4}, {d_slot, b4}, {d_bnum, b4}, {d_bcoord, b4}, {d_median_cp, b4},
                    {d_kind, (size_t)n}, {n_out, 4}, {status, (size_t)n}});
   HIPCHK(hipGetLastError());
@@ -561,8 +580,9 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
            gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
   begin_back(e, fs, n);
   LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags,
-           status);
-  LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+           status, RunCols{x_gidx, x_first, x_count}, OutTotals{n_runs, nullptr});
+  if (!e->X.lookback)
+    LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   end_call(e, fs, {{r_bnum, b4}, {r_bcoord, b4}, {r_maxcp, b4}, {r_flags, (size_t)n},
                    {status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
   HIPCHK(hipGetLastError());
@@ -590,8 +610,10 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
            gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
            (int32_t*)nullptr, (uint8_t*)nullptr);
   begin_back(e, fs, n);
-  LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
-  LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+  LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status,
+           RunCols{x_gidx, x_first, x_count}, OutTotals{n_runs, nullptr});
+  if (!e->X.lookback)
+    LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   end_call(e, fs, {{status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
   HIPCHK(hipGetLastError());
   return GPX_OK;

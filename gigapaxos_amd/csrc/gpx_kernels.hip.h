@@ -127,6 +127,10 @@ struct DevScratch {
   Out* o_rec;             /* [n] compacted outputs of bucket b as a dense run at o_rec[bucket_off[b] ..] */
   int32_t* bucket_nout;   /* [nbk] number of compacted outputs of each bucket */
   unsigned long long* counters; /* [3] votes, outputs (decisions + preempts), dropped */
+  unsigned long long* lb;       /* [nbk] decoupled look-back words: epoch << 34 | flag << 32 | count */
+  uint32_t epoch;               /* back-end launch number (30 bits, never 0): stale words are ignored */
+  int32_t lookback;             /* 1: k_bucket_* write the caller's columns themselves (no k_emit_*) */
+  int32_t* err;                 /* [1] sticky device-side error word (look-back timeout) */
 };
 
 /* Java int subtraction (wraps) */
@@ -542,8 +546,12 @@ struct BucketView {
 #define GPX_BUCKET_LDS_BYTES(gb, lds_recs) \
   ((size_t)(gb) * 8 + (size_t)(lds_recs) * (8 + 4 * GPX_PAY_WORDS))
 
-/* Returns false (whole workgroup) when the bucket received no record. */
-__device__ __forceinline__ bool bucket_prepare(const DevScratch& X, int32_t* lds, BucketView* bv) {
+/* Returns false (whole workgroup) when the bucket received no record.  after_a() runs once the
+ * loads of phase A have been issued and consumed: the place for loads that depend on state fetched
+ * at kernel entry (they overlap phases B-D). */
+template <class F>
+__device__ __forceinline__ bool bucket_prepare(const DevScratch& X, int32_t* lds, BucketView* bv,
+                                               F after_a) {
   const int32_t b = blockIdx.x;
   const int32_t boff = X.bucket_off[b];
   const int32_t nb = X.bucket_off[b + 1] - boff;
@@ -593,6 +601,7 @@ __device__ __forceinline__ bool bucket_prepare(const DevScratch& X, int32_t* lds
       X.rank2[boff + j] = atomicAdd(&lcnt[recG[j].lg], 1);
   }
   __syncthreads();
+  after_a();
   /* B: exclusive scan lcnt -> loff; thread t owns gb / threads consecutive groups */
   const int32_t per = gb / nt;
   int32_t s = 0;
@@ -751,9 +760,92 @@ __device__ __forceinline__ int32_t median_minus(const int32_t (&ns)[KMAX], int32
  * (outputs <= records, so the bucket's own record range always has room) and their count to
  * bucket_nout[b]; k_emit_* turns the per-bucket runs into the caller's dense SoA columns. */
 
-/* all lanes of the workgroup; nout = number of outputs this thread's groups produced, already
- * stored per group in bv.lcnt[l] (overwriting the record count, which is no longer needed) */
-__device__ __forceinline__ void bucket_emit(const DevScratch& X, const BucketView& bv) {
+/* ---- decoupled look-back over buckets -------------------------------------------------------
+ * Each bucket workgroup publishes its output count in lb[b] as soon as its replay is done, then
+ * sums the counts of the buckets before it by walking back over their words (64 per step) until
+ * it meets one that already carries an inclusive prefix, and publishes its own inclusive prefix.
+ * The count travels INSIDE the 64-bit word (epoch << 34 | flag << 32 | value), so no release /
+ * acquire fence is needed (an agent-scope release writes back the XCD's whole L2 on this chip:
+ * measured +20..50 us per kernel); words are read and written with agent-scope RMW atomics only,
+ * which are coherent across XCDs.  Words of earlier launches carry an older epoch and read as
+ * "not ready" - lb[] is never cleared.  Workgroups are dispatched in blockIdx order per XCD, so
+ * the lowest unfinished bucket is always resident and never waits on anybody; the spin is bounded
+ * anyway (a timeout sets *X.err and lets the kernel finish with a wrong offset instead of hanging
+ * the GPU). */
+#define LB_AGG 1ull
+#define LB_PREFIX 2ull
+#define LB_SPIN_LIMIT (1u << 21)
+__device__ __forceinline__ unsigned long long lb_pack(uint32_t epoch, unsigned long long flag,
+                                                      int32_t v) {
+  return ((unsigned long long)epoch << 34) | (flag << 32) | (unsigned long long)(uint32_t)v;
+}
+/* Wave 0 of the workgroup only (all 64 lanes).  Returns the number of outputs of the buckets
+ * before b. */
+__device__ __forceinline__ int32_t lb_resolve(const DevScratch& X, int32_t b, int32_t tot) {
+  const int lane = (int)(threadIdx.x & 63);
+  unsigned long long* lb = X.lb;
+  if (lane == 0)
+    __hip_atomic_exchange(&lb[b], lb_pack(X.epoch, LB_AGG, tot), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+  int32_t sum = 0;
+  int32_t base = b - 1;
+  bool done = base < 0;
+  while (!done) { /* wave-uniform */
+    const int32_t i = base - lane;
+    unsigned long long v = lb_pack(X.epoch, LB_PREFIX, 0); /* virtual word before bucket 0 */
+    if (i >= 0) {
+      uint32_t spins = 0;
+      for (;;) {
+        v = __hip_atomic_fetch_or(&lb[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 34) == X.epoch) break;
+        if (++spins > LB_SPIN_LIMIT) {
+          atomicOr(X.err, 1);
+          v = lb_pack(X.epoch, LB_PREFIX, 0);
+          break;
+        }
+        __builtin_amdgcn_s_sleep(4);
+      }
+    }
+    const unsigned long long pm = __ballot(((v >> 32) & 3ull) == LB_PREFIX);
+    const int first = pm ? (__ffsll((long long)pm) - 1) : 64; /* nearest bucket holding a prefix */
+    int32_t c = (lane <= first) ? (int32_t)(uint32_t)v : 0;
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
+    sum += c;
+    done = pm != 0;
+    base -= 64;
+  }
+  if (lane == 0)
+    __hip_atomic_exchange(&lb[b], lb_pack(X.epoch, LB_PREFIX, sum + tot), __ATOMIC_RELAXED,
+                          __HIP_MEMORY_SCOPE_AGENT);
+  return sum;
+}
+
+/* where the compacted outputs of a call go: the caller's n_out word and the engine counter */
+struct OutTotals {
+  int32_t* total_out;
+  unsigned long long* acc;
+};
+
+/* a bucket without records still takes part in the look-back (whole workgroup calls this) */
+__device__ __forceinline__ void bucket_empty(const DevScratch& X, const OutTotals& T) {
+  if (!X.lookback) return;
+  if (threadIdx.x < 64) {
+    const int32_t pre = lb_resolve(X, (int32_t)blockIdx.x, 0);
+    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
+      if (T.total_out) *T.total_out = pre;
+      if (T.acc) atomicAdd(T.acc, (unsigned long long)pre);
+    }
+  }
+}
+
+/* all lanes of the workgroup; the number of outputs of each group is already stored in bv.lcnt[l]
+ * (overwriting the record count, which is no longer needed).  wr(o, gidx, p0, p1, p2, p3, p4)
+ * stores output o of the call into the caller's columns. */
+template <class WR>
+__device__ __forceinline__ void bucket_emit(const DevScratch& X, const BucketView& bv,
+                                            const OutTotals& T, WR wr) {
+  __shared__ int32_t s_pre;
   __syncthreads();
   const int32_t b = blockIdx.x;
   const int32_t boff = X.bucket_off[b];
@@ -763,8 +855,34 @@ __device__ __forceinline__ void bucket_emit(const DevScratch& X, const BucketVie
   for (int32_t q = 0; q < per; q++) s += bv.lcnt[threadIdx.x * per + q];
   int32_t tot;
   int32_t ex = block_exscan_rt(s, &tot);
-  Out* dst = X.o_rec + boff;
   const int32_t g0 = b << X.shift;
+  if (X.lookback) {
+    if (threadIdx.x < 64) {
+      const int32_t pre = lb_resolve(X, b, tot);
+      if (threadIdx.x == 0) {
+        s_pre = pre;
+        if (b == (int32_t)gridDim.x - 1) {
+          if (T.total_out) *T.total_out = pre + tot;
+          if (T.acc) atomicAdd(T.acc, (unsigned long long)(pre + tot));
+        }
+      }
+    }
+    __syncthreads();
+    ex += s_pre;
+    for (int32_t q = 0; q < per; q++) {
+      const int32_t l = threadIdx.x * per + q;
+      const int32_t d = bv.lcnt[l];
+      const unsigned long long* kk = bv.keys + bv.loff[l];
+      for (int32_t t = 0; t < d; t++) {
+        const int32_t* p = bv.pay + (int64_t)(uint32_t)kk[t] * bv.rs;
+        wr(ex + t, g0 + l, p[0], p[bv.fs], p[2 * bv.fs], p[3 * bv.fs], p[4 * bv.fs]);
+      }
+      ex += d;
+    }
+    return;
+  }
+  /* two-kernel form: dense run of rows at o_rec[boff ..], k_emit_* transposes */
+  Out* dst = X.o_rec + boff;
   for (int32_t q = 0; q < per; q++) {
     const int32_t l = threadIdx.x * per + q;
     const int32_t d = bv.lcnt[l];
@@ -832,14 +950,49 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_runs(DevScratch X, int32_t* 
 
 /* ------------------------------------------------------------------------- */
 /* coordinator side                                                             */
+/* Coordinator-side state of one group, fetched by the lane that owns it.  In a dense batch the
+ * loads are issued at kernel entry, before the bucket's records are staged, so that their latency
+ * hides behind phases A-D of bucket_prepare (these kernels are latency-bound: each dependent
+ * round trip to HBM costs a few microseconds per workgroup). */
+template <int KMAX>
+struct CoordPre {
+  uint32_t gf;
+  int32_t my_bnum, my_bcoord, next, pcount;
+  int32_t mem[KMAX], ns[KMAX];
+  uint32_t pe; /* speculative: myProposals entry of slot next - 1 (the usual outstanding slot) */
+  bool have_pe;
+};
+template <int KMAX>
+__device__ __forceinline__ void coord_preload(const DevState& S, int32_t g, CoordPre<KMAX>& P) {
+  const int32_t G = S.G;
+  P.gf = S.g_flags[g];
+  P.my_bnum = S.c_bnum[g];
+  P.my_bcoord = S.c_bcoord[g];
+  P.next = S.c_next[g];
+  P.pcount = S.c_pcount[g];
+#pragma unroll
+  for (int j = 0; j < KMAX; j++) { /* rows >= k of a group hold 0 (k_group_create) */
+    P.mem[j] = (j < S.kmax) ? S.members[(int64_t)j * G + g] : 0;
+    P.ns[j] = (j < S.kmax) ? S.node_slots[(int64_t)j * G + g] : 0;
+  }
+  P.pe = 0;
+  P.have_pe = false;
+}
+template <int KMAX>
+__device__ __forceinline__ void coord_preload_ring(const DevState& S, int32_t g, CoordPre<KMAX>& P) {
+  P.pe = S.p_ring[(int64_t)(jsub(P.next, 1) & (S.W - 1)) * S.G + g];
+  P.have_pe = true;
+}
+
 /* PaxosInstanceStateMachine.handleAcceptReply (PISM:1248-1364) ->              */
 /* PaxosCoordinator.handleAcceptReply (PaxosCoordinator.java:210-250) ->        */
 /* PaxosCoordinatorState.handleAcceptReplyMyBallot / HigherBallot (:597-683)    */
 template <int KMAX>
 __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScratch& X, int32_t g,
-                                               GroupIter& it, uint8_t* __restrict__ status) {
+                                               GroupIter& it, uint8_t* __restrict__ status,
+                                               const CoordPre<KMAX>& P) {
   const int32_t G = S.G;
-  const uint32_t gf = S.g_flags[g];
+  const uint32_t gf = P.gf;
   if (!(gf & GF_EXISTS) || (gf & GF_STOPPED)) {
     /* PaxosManager.java:1162-1194 / PaxosInstanceStateMachine.java:456-460: dropped */
     const uint8_t st = (gf & GF_EXISTS) ? GPX_S_STOPPED : GPX_S_NOGROUP;
@@ -851,22 +1004,22 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
   }
   const int32_t k = (int32_t)GF_K(gf);
   bool has_coord = (gf & GF_HASCOORD) != 0;
-  const int32_t my_bnum = S.c_bnum[g], my_bcoord = S.c_bcoord[g];
-  const int32_t next = S.c_next[g];
-  int32_t pcount = S.c_pcount[g];
+  const int32_t my_bnum = P.my_bnum, my_bcoord = P.my_bcoord;
+  const int32_t next = P.next;
+  int32_t pcount = P.pcount;
   const int32_t pcount0 = pcount;
   const int32_t Wm = S.W - 1;
   int32_t mem[KMAX], ns[KMAX];
 #pragma unroll
   for (int j = 0; j < KMAX; j++) {
-    mem[j] = (j < k) ? S.members[(int64_t)j * G + g] : 0;
-    ns[j] = (j < k) ? S.node_slots[(int64_t)j * G + g] : 0;
+    mem[j] = (j < k) ? P.mem[j] : 0;
+    ns[j] = (j < k) ? P.ns[j] : 0;
   }
   bool ns_dirty = false;
   /* one-entry write-back register cache over this group's myProposals ring: the K votes of one
    * slot (the normal case) cost one load and one store instead of K dependent round trips */
-  int64_t pc_off = -1;
-  uint32_t pc_val = 0;
+  int64_t pc_off = P.have_pe ? ((int64_t)(jsub(next, 1) & Wm) * G + g) : -1;
+  uint32_t pc_val = P.pe;
   bool pc_dirty = false;
   auto pr_load = [&](int64_t off) -> uint32_t {
     if (off != pc_off) {
@@ -883,7 +1036,7 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
   };
   Rec r;
   while (it.next(r)) {
-    const int32_t slot = r.a, acc = r.b, maxcp = r.c, ix = r.idx;
+    const int32_t slot = r.a, acc = r.b, maxcp = r.c;
     if (!has_coord) continue; /* PaxosCoordinator.java:196-198: c == null -> null */
     const int32_t cmp = ballot_cmp(r.bnum, r.bcoord, my_bnum, my_bcoord);
     const int32_t d = jsub(next, slot); /* slot in myProposals' window iff 1 <= d <= W */
@@ -939,25 +1092,54 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
   if (!has_coord && (gf & GF_HASCOORD)) S.g_flags[g] = gf & ~GF_HASCOORD;
 }
 
+/* decisions / preempts -> the caller's d_* columns */
+struct DecCols {
+  int32_t *gidx, *slot, *bnum, *bcoord, *median;
+  uint8_t* kind;
+};
+
 template <int KMAX>
 __global__ __launch_bounds__(1024) void k_bucket_ar(DevState S, DevScratch X,
-                                                        uint8_t* __restrict__ status) {
+                                                    uint8_t* __restrict__ status, DecCols D,
+                                                    OutTotals T) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
-  if (!bucket_prepare(X, lds, &bv)) return;
   const int32_t g0 = blockIdx.x << X.shift;
+  /* dense batch (at least one record per two groups of this bucket) and one lane per group:
+   * fetch every group's coordinator state now */
+  const int32_t nb_ = X.bucket_off[blockIdx.x + 1] - X.bucket_off[blockIdx.x];
+  const bool pre = (int32_t)blockDim.x == X.gb && 2 * nb_ >= X.gb;
+  const int32_t gme = g0 + (int32_t)threadIdx.x;
+  CoordPre<KMAX> P;
+  P.have_pe = false;
+  if (pre && gme < S.G) coord_preload<KMAX>(S, gme, P);
+  if (!bucket_prepare(X, lds, &bv, [&]() {
+        if (pre && gme < S.G) coord_preload_ring<KMAX>(S, gme, P);
+      })) {
+    bucket_empty(X, T);
+    return;
+  }
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
     int32_t nout = 0;
     if (c != 0 && g0 + l < S.G) {
       GroupIter it;
       it.init(bv, l, c);
-      apply_ar_group<KMAX>(S, X, g0 + l, it, status);
+      if (!pre) coord_preload<KMAX>(S, g0 + l, P);
+      apply_ar_group<KMAX>(S, X, g0 + l, it, status, P);
       nout = it.nout;
     }
     bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
   }
-  bucket_emit(X, bv);
+  bucket_emit(X, bv, T,
+              [&](int32_t o, int32_t g, int32_t slot, int32_t x, int32_t y, int32_t z, int32_t kind) {
+                D.gidx[o] = g;
+                D.slot[o] = slot;
+                D.bnum[o] = x;
+                D.bcoord[o] = y;
+                D.median[o] = z;
+                D.kind[o] = (uint8_t)kind;
+              });
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1157,12 +1339,27 @@ __device__ __forceinline__ void apply_accept_group(
   if (n_drop) atomicAdd(&X.counters[2], n_drop);
 }
 
+/* exec runs -> the caller's x_* columns */
+struct RunCols {
+  int32_t *gidx, *first, *count;
+};
+#define GPX_RUN_WRITER(R)                                                                       \
+  [&](int32_t o, int32_t g, int32_t, int32_t first, int32_t cnt, int32_t, int32_t) {            \
+    (R).gidx[o] = g;                                                                            \
+    (R).first[o] = first;                                                                       \
+    (R).count[o] = cnt;                                                                         \
+  }
+
 __global__ __launch_bounds__(1024) void k_bucket_accept(
     DevState S, DevScratch X, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
-    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status) {
+    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status,
+    RunCols R, OutTotals T) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
-  if (!bucket_prepare(X, lds, &bv)) return;
+  if (!bucket_prepare(X, lds, &bv, []() {})) {
+    bucket_empty(X, T);
+    return;
+  }
   const int32_t g0 = blockIdx.x << X.shift;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
@@ -1175,7 +1372,7 @@ __global__ __launch_bounds__(1024) void k_bucket_accept(
     }
     bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
   }
-  bucket_emit(X, bv);
+  bucket_emit(X, bv, T, GPX_RUN_WRITER(R));
 }
 
 /* PaxosInstanceStateMachine.handleBatchedCommit (PISM:1480-1528) per slot and
@@ -1228,10 +1425,14 @@ __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevS
 }
 
 __global__ __launch_bounds__(1024) void k_bucket_commit(DevState S, DevScratch X,
-                                                            uint8_t* __restrict__ status) {
+                                                        uint8_t* __restrict__ status, RunCols R,
+                                                        OutTotals T) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
-  if (!bucket_prepare(X, lds, &bv)) return;
+  if (!bucket_prepare(X, lds, &bv, []() {})) {
+    bucket_empty(X, T);
+    return;
+  }
   const int32_t g0 = blockIdx.x << X.shift;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
@@ -1244,32 +1445,65 @@ __global__ __launch_bounds__(1024) void k_bucket_commit(DevState S, DevScratch X
     }
     bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
   }
-  bucket_emit(X, bv);
+  bucket_emit(X, bv, T, GPX_RUN_WRITER(R));
 }
 
 /* PaxosInstanceStateMachine.handleProposal (PISM:818-888) ->
  * PaxosCoordinatorState.propose (:233-263) + initCommander (:841-851) */
 template <int KMAX>
+struct ProposePre {
+  uint32_t gf;
+  int32_t a_bnum, a_bcoord, my_bnum, my_bcoord, next, pcount;
+  int32_t ns[KMAX];
+  uint32_t pe_prev, pe_cur; /* myProposals entries of slots next - 1 and next */
+};
+template <int KMAX>
+__device__ __forceinline__ void propose_preload(const DevState& S, int32_t g, ProposePre<KMAX>& P) {
+  const int32_t G = S.G;
+  P.gf = S.g_flags[g];
+  P.a_bnum = S.a_bnum[g];
+  P.a_bcoord = S.a_bcoord[g];
+  P.my_bnum = S.c_bnum[g];
+  P.my_bcoord = S.c_bcoord[g];
+  P.next = S.c_next[g];
+  P.pcount = S.c_pcount[g];
+#pragma unroll
+  for (int q = 0; q < KMAX; q++) P.ns[q] = (q < S.kmax) ? S.node_slots[(int64_t)q * G + g] : 0;
+}
+template <int KMAX>
+__device__ __forceinline__ void propose_preload_ring(const DevState& S, int32_t g,
+                                                     ProposePre<KMAX>& P) {
+  const int32_t Wm = S.W - 1;
+  P.pe_prev = S.p_ring[(int64_t)(jsub(P.next, 1) & Wm) * S.G + g];
+  P.pe_cur = S.p_ring[(int64_t)(P.next & Wm) * S.G + g];
+}
+
+template <int KMAX>
 __device__ __forceinline__ void apply_propose_group(
     const DevState& S, const DevScratch& X, int32_t g, GroupIter& it, int32_t* __restrict__ o_slot,
     int32_t* __restrict__ o_bnum, int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median,
-    uint8_t* __restrict__ status) {
+    uint8_t* __restrict__ status, const ProposePre<KMAX>& P) {
   const int32_t G = S.G;
-  const uint32_t gf = S.g_flags[g];
+  const uint32_t gf = P.gf;
   const bool exists = (gf & GF_EXISTS) != 0, stopped = (gf & GF_STOPPED) != 0;
   const int32_t k = (int32_t)GF_K(gf);
-  const int32_t a_bnum = exists ? S.a_bnum[g] : 0, a_bcoord = exists ? S.a_bcoord[g] : 0;
-  const int32_t my_bnum = exists ? S.c_bnum[g] : 0, my_bcoord = exists ? S.c_bcoord[g] : 0;
+  const int32_t a_bnum = exists ? P.a_bnum : 0, a_bcoord = exists ? P.a_bcoord : 0;
+  const int32_t my_bnum = exists ? P.my_bnum : 0, my_bcoord = exists ? P.my_bcoord : 0;
   /* PaxosCoordinator.exists(coordinator, paxosState.getBallot()) (PISM:825-826) */
   const bool coord_ok = exists && (gf & GF_HASCOORD) &&
                         ballot_cmp(my_bnum, my_bcoord, a_bnum, a_bcoord) >= 0;
-  int32_t next = coord_ok ? S.c_next[g] : 0;
-  int32_t pcount = coord_ok ? S.c_pcount[g] : 0;
+  int32_t next = coord_ok ? P.next : 0;
+  const int32_t next0 = next;
+  int32_t pcount = coord_ok ? P.pcount : 0;
   int32_t ns[KMAX];
 #pragma unroll
-  for (int q = 0; q < KMAX; q++) ns[q] = (coord_ok && q < k) ? S.node_slots[(int64_t)q * G + g] : 0;
+  for (int q = 0; q < KMAX; q++) ns[q] = (coord_ok && q < k) ? P.ns[q] : 0;
   const int32_t median = coord_ok ? median_minus<KMAX>(ns, k) : 0;
   const int32_t Wm = S.W - 1;
+  /* entry of the slot before `next` and of `next` itself: after a successful proposal the entry
+   * just written IS the previous one of the following record, so only the new current entry is
+   * loaded */
+  uint32_t pe_prev = P.pe_prev, pe_cur = P.pe_cur;
   unsigned long long n_drop = 0;
   Rec r;
   while (it.next(r)) {
@@ -1292,26 +1526,27 @@ __device__ __forceinline__ void apply_propose_group(
       continue;
     }
     /* no point enqueuing anything after stop (PaxosCoordinatorState.java:235-239) */
-    const uint32_t pe_prev = S.p_ring[(int64_t)(jsub(next, 1) & Wm) * G + g];
     if ((pe_prev & PR_PRESENT) && (pe_prev & PR_STOP)) {
       status[ix] = GPX_S_REFUSED;
       continue;
     }
-    uint32_t* pe = &S.p_ring[(int64_t)(next & Wm) * G + g];
-    if (*pe & PR_PRESENT) {
+    if (pe_cur & PR_PRESENT) {
       status[ix] = GPX_S_WINDOW; /* slot next-W still outstanding */
       n_drop++;
       continue;
     }
-    *pe = PR_PRESENT | (stop ? PR_STOP : 0u);
+    const uint32_t e = PR_PRESENT | (stop ? PR_STOP : 0u);
+    S.p_ring[(int64_t)(next & Wm) * G + g] = e;
     pcount++;
     o_slot[ix] = next;
     o_bnum[ix] = my_bnum;
     o_bcoord[ix] = my_bcoord;
     o_median[ix] = median; /* getMajorityCommittedSlot: nodeSlots unchanged by propose */
     next = (int32_t)((uint32_t)next + 1u);
+    pe_prev = e;
+    if (it.done < it.c) pe_cur = S.p_ring[(int64_t)(next & Wm) * G + g];
   }
-  if (coord_ok) {
+  if (coord_ok && next != next0) {
     S.c_next[g] = next;
     S.c_pcount[g] = pcount;
   }
@@ -1324,14 +1559,26 @@ __global__ __launch_bounds__(1024) void k_bucket_propose(
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
-  if (!bucket_prepare(X, lds, &bv)) return;
   const int32_t g0 = blockIdx.x << X.shift;
+  const int32_t nb_ = X.bucket_off[blockIdx.x + 1] - X.bucket_off[blockIdx.x];
+  const bool pre = (int32_t)blockDim.x == X.gb && 2 * nb_ >= X.gb;
+  const int32_t gme = g0 + (int32_t)threadIdx.x;
+  ProposePre<KMAX> P;
+  if (pre && gme < S.G) propose_preload<KMAX>(S, gme, P);
+  if (!bucket_prepare(X, lds, &bv, [&]() {
+        if (pre && gme < S.G) propose_preload_ring<KMAX>(S, gme, P);
+      }))
+    return;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
     if (c == 0 || g0 + l >= S.G) continue;
     GroupIter it;
     it.init(bv, l, c);
-    apply_propose_group<KMAX>(S, X, g0 + l, it, o_slot, o_bnum, o_bcoord, o_median, status);
+    if (!pre) {
+      propose_preload<KMAX>(S, g0 + l, P);
+      propose_preload_ring<KMAX>(S, g0 + l, P);
+    }
+    apply_propose_group<KMAX>(S, X, g0 + l, it, o_slot, o_bnum, o_bcoord, o_median, status, P);
   }
 }
 

@@ -3,7 +3,7 @@
 state dump bit for bit."""
 import numpy as np
 
-from gigapaxos_amd import Engine, hri_create, hri_initial, make_hri, S_OK, S_WINDOW
+from gigapaxos_amd import Engine, hri_create, hri_initial, make_hri, streams, S_OK, S_WINDOW
 
 
 def wrap32(x):
@@ -125,3 +125,52 @@ def fuzz(ea, eb, G, node_ids, rng, steps, batch, slot_base=1, span=40, my_id=Non
     assert_same_state(ea, eb, range(G))
     ca, cb = ea.counters(), eb.counters()
     assert ca == cb, (ca, cb)
+
+
+def churn_run(engines, G_live, cap, R, k, seed, churn_frac=0.01):
+    """BASELINE config #5 driver (reconfiguration churn): every round proposes + votes for all live
+    groups, then retires churn_frac of them (PaxosManager.kill) and creates the same number on
+    fresh gidx rows (free list); the next round's stream still carries votes for the groups just
+    retired, which must be dropped with GPX_S_NOGROUP (PaxosManager.java:1162-1194).  Applies the
+    identical op sequence to every engine in `engines` and returns, per engine, the list of
+    (decisions, vote status, propose status, retire rows, create status) per round."""
+    from gigapaxos_amd import RETIRE_KILL
+    members = list(range(100, 100 + k))
+    rng = np.random.default_rng(seed)
+    from collections import deque
+    live = np.arange(G_live, dtype=np.int32)
+    free = deque(range(G_live, cap))  # FIFO: a retired row is reused a few rounds later
+    outs = [[] for _ in engines]
+    for e in engines:
+        mem = np.tile(np.array(members, np.int32), (G_live, 1))
+        assert (e.create_groups(live, mem, k, hri_create(G_live, k, 100)) == S_OK).all()
+    ghost = np.zeros(0, np.int32)  # retired last round: still addressed by late votes
+    slot_of = np.ones(cap, np.int64)  # next slot each gidx row will propose (fresh rows restart at 1)
+    for r in range(R):
+        rng_r = np.random.default_rng(seed * 1000 + r)
+        pg = rng_r.permutation(np.concatenate([live, ghost])).astype(np.int32)
+        cols = streams.vote_round(0, members, 0, 100, config_id=5, groups=np.concatenate([live, ghost]))
+        cols = list(cols)
+        cols[3] = slot_of[cols[0]].astype(np.int32)          # slot = the row's outstanding slot
+        cols[5] = (slot_of[cols[0]] - 1).astype(np.int32)    # max_cp = slot - 1
+        order = rng_r.permutation(cols[0].shape[0])
+        cols = [np.ascontiguousarray(c[order]) for c in cols]
+        n_ret = max(1, int(live.shape[0] * churn_frac))
+        victims = rng_r.choice(live, size=n_ret, replace=False).astype(np.int32)
+        fresh = np.array([free.popleft() for _ in range(n_ret)], np.int32)
+        for e, out in zip(engines, outs):
+            pr = e.propose(pg)
+            d = e.accept_reply(*cols)
+            rows, st_ret = e.retire_groups(victims, RETIRE_KILL)
+            mem = np.tile(np.array(members, np.int32), (n_ret, 1))
+            st_new = e.create_groups(fresh, mem, k, hri_create(n_ret, k, 100))
+            out.append((d.as_tuple_array(), d.status, np.stack(pr[:4], 1), pr[4], rows.tobytes(),
+                        st_ret, st_new))
+        slot_of[live] += 1
+        keep = np.ones(cap, bool)
+        keep[victims] = False
+        live = np.concatenate([live[keep[live]], fresh])
+        slot_of[fresh] = 1
+        free.extend(int(v) for v in victims)
+        ghost = victims
+    return outs, live

@@ -62,3 +62,21 @@ def test_shard_hash():
     cnt = np.bincount(s, minlength=8)
     assert cnt.min() > 7500 and cnt.max() < 8900
     assert int(streams.fmix32(np.array([1], np.uint32))[0]) == 0x514E28B7  # murmur3 fmix32(1)
+
+
+def test_config5_churn_properties_on_oracle(oracle_lib):
+    """BASELINE config #5 driver on the oracle alone (the GPU test compares the engine with it):
+    every live group decides every round, late votes / proposals for retired groups are dropped
+    with NOGROUP, retired rows come back as HotRestoreInfo and are reusable."""
+    from tests.parity_common import churn_run
+    from gigapaxos_amd import Engine, S_NOGROUP, HRI_DTYPE
+    G_live, cap, R, k = 2000, 2000 + 3 * 20, 6, 5
+    e = Engine(oracle_lib, 100, cap, kmax=k, window=8)
+    (out,), live = churn_run([e], G_live, cap, R, k, seed=7)
+    for r, (dec, vst, pout, pst, rows, st_ret, st_new) in enumerate(out):
+        assert dec.shape[0] == G_live and (st_ret == 0).all() and (st_new == 0).all()
+        assert (vst == S_NOGROUP).sum() == (k * 20 if r else 0)
+        assert (pst == S_NOGROUP).sum() == (20 if r else 0)
+        hri = np.frombuffer(rows, dtype=HRI_DTYPE)
+        assert (hri["has_coord"] == 1).all() and (hri["acc_slot"] >= 1).all()
+    assert len(set(live.tolist())) == G_live

@@ -5,9 +5,10 @@ import numpy as np
 import pytest
 
 from gigapaxos_amd import (Engine, hri_create, hri_initial, make_hri, streams, S_OK, S_WINDOW,
-                           D_DECISION, D_PREEMPTED)
+                           S_NOGROUP, D_DECISION, D_PREEMPTED)
 from gigapaxos_amd.loopback import LoopbackCluster
-from tests.parity_common import make_pair, create_mixed_groups, fuzz, assert_same_state, wrap32
+from tests.parity_common import (make_pair, create_mixed_groups, fuzz, assert_same_state, wrap32,
+                                 churn_run)
 
 pytestmark = pytest.mark.gpu
 
@@ -192,3 +193,28 @@ def test_full_size_properties_1m_groups(hip_lib):
     assert (rows["next_proposal_slot"] == R + 1).all()
     assert (rows["node_slots"][:, :3] == R - 1).all()
     assert e.counters()[:2] == (3 * G * R, G * R)
+
+
+def test_config5_churn_create_retire_mid_run(hip_lib, oracle_lib):
+    """BASELINE config #5 at a size the oracle finishes in seconds: group create / delete mid-run,
+    gidx rows reused, late votes for retired groups dropped — decided stream, per-record statuses,
+    HotRestoreInfo rows of the retired groups and the final state identical to the oracle."""
+    G_live, cap, R, k = 20000, 20000 + 3 * 200, 8, 5
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, cap, k, 8, max_batch=1 << 18)
+    (oh, oo), live = churn_run([eh, eo], G_live, cap, R, k, seed=5)
+    for r, (a, b) in enumerate(zip(oh, oo)):
+        for x, y, nm in zip(a, b, ("decisions", "vote status", "propose out", "propose status",
+                                    "retired rows", "retire status", "create status")):
+            if isinstance(x, bytes):
+                assert x == y, f"round {r} {nm}"
+            else:
+                assert x.shape == y.shape and (x == y).all(), f"round {r} {nm}"
+        dec, vst = a[0], a[1]
+        assert (a[5] == S_OK).all() and (a[6] == S_OK).all()
+        assert dec.shape[0] == G_live          # every live group decides every round
+        if r > 0:
+            assert (vst == S_NOGROUP).sum() == k * max(1, int(G_live * 0.01))
+    sh, so = eh.snapshot(np.arange(cap))[0], eo.snapshot(np.arange(cap))[0]
+    assert sh.tobytes() == so.tobytes()
+    assert_same_state(eh, eo, np.random.default_rng(1).integers(0, cap, 64))
+    assert eh.counters() == eo.counters()
