@@ -56,6 +56,7 @@ struct gpx_engine {
   struct FrontSet {
     int32_t *bucket_tot = nullptr, *tile_rel = nullptr, *bucket_off = nullptr;
     Rec* rec = nullptr;
+    uint32_t* unsorted = nullptr;
     hipEvent_t evF = nullptr, evB = nullptr;
     bool used = false;
   } fs[2];
@@ -210,6 +211,15 @@ int begin_front(gpx_engine* e, std::initializer_list<Range> touched) {
   e->X.tile_rel = f.tile_rel;
   e->X.bucket_off = f.bucket_off;
   e->X.rec = f.rec;
+  e->X.unsorted = f.unsorted;
+  /* per-scratch-set epoch (the word is only ever raised to the epoch of a call using this set) */
+  e->X.epoch = (uint32_t)(e->call_seq + 1);
+  if (e->X.epoch == 0) { /* 2^32 calls: restart the epochs from cleared words */
+    hipStreamSynchronize(e->sF);
+    hipStreamSynchronize(e->sB);
+    for (auto& fx : e->fs) hipMemset(fx.unsorted, 0, sizeof(uint32_t));
+    e->X.epoch = 1;
+  }
   e->stream = e->sF;
   if (e->pipeline) {
     if (e->user_stream) {
@@ -238,12 +248,6 @@ void begin_back(gpx_engine* e, int s, int32_t n) {
     hipStreamWaitEvent(e->sB, e->fs[s].evF, 0);
   }
   e->stream = e->sB;
-  /* look-back epoch of this call's per-bucket kernel: 30 bits, never 0 (0 = the cleared array) */
-  e->X.epoch = (e->X.epoch + 1u) & 0x3fffffffu;
-  if (e->X.epoch == 0) {
-    hipMemsetAsync(e->X.lb, 0, (size_t)e->X.nbk * sizeof(unsigned long long), e->sB);
-    e->X.epoch = 1;
-  }
 }
 void end_call(gpx_engine* e, int s, std::initializer_list<Range> outputs) {
   if (e->pipeline) {
@@ -255,15 +259,16 @@ void end_call(gpx_engine* e, int s, std::initializer_list<Range> outputs) {
 }
 
 /* bucket partition front end, part 1: per-bucket record counts of the batch */
-void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, int is_votes) {
+void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, int is_votes,
+                int check_order = 0) {
   const int ntiles = ntiles_for(n);
   const size_t lds = (size_t)e->X.nbk * sizeof(int32_t);
   if (aligned16({gidx}))
     LAUNCH_F(e, "k_hist", k_hist<true>, tile_grid(ntiles), lds, n, ntiles, gidx, e->S.G, e->X, status,
-             is_votes);
+             is_votes, check_order);
   else
     LAUNCH_F(e, "k_hist", k_hist<false>, tile_grid(ntiles), lds, n, ntiles, gidx, e->S.G, e->X, status,
-             is_votes);
+             is_votes, check_order);
 }
 
 int check_batch(gpx_engine* h, int32_t n) {
@@ -273,8 +278,8 @@ int check_batch(gpx_engine* h, int32_t n) {
 }
 
 template <int KMAX>
-void launch_bucket_ar(gpx_engine* e, uint8_t* status, const DecCols& D, const OutTotals& T) {
-  LAUNCH_B(e, "k_bucket_ar", (k_bucket_ar<KMAX>), e->S, e->X, status, D, T);
+void launch_bucket_ar(gpx_engine* e, uint8_t* status) {
+  LAUNCH_B(e, "k_bucket_ar", (k_bucket_ar<KMAX>), e->S, e->X, status);
 }
 template <int KMAX>
 void launch_bucket_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t* bcoord,
@@ -390,20 +395,19 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     A(f.tile_rel, ((N + GPX_TILE - 1) / GPX_TILE) * (size_t)X.nbk, false);
     A(f.bucket_off, (size_t)X.nbk + 1, true);
     A(f.rec, N, false);
+    A(f.unsorted, 1, true);
   }
   X.bucket_tot = e->fs[0].bucket_tot;
   X.tile_rel = e->fs[0].tile_rel;
   X.bucket_off = e->fs[0].bucket_off;
   X.rec = e->fs[0].rec;
+  X.unsorted = e->fs[0].unsorted;
+  X.epoch = 1;
   A(X.rank2, N, false);
   A(X.perm, N, false);
   A(X.o_rec, N, false);
   A(X.bucket_nout, (size_t)X.nbk, true);
   A(X.counters, 3, true);
-  A(X.lb, (size_t)X.nbk, true);
-  A(X.err, 1, true);
-  X.epoch = 0;
-  X.lookback = getenv("GPX_NO_LOOKBACK") ? 0 : 1; /* 0: per-bucket rows + k_emit_* (two kernels) */
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
   A(e->st_count, 4, true);
@@ -468,12 +472,6 @@ int gpx_engine_sync(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
   HIPCHK(hipStreamSynchronize(h->sF));
   HIPCHK(hipStreamSynchronize(h->sB));
-  int32_t err = 0;
-  HIPCHK(hipMemcpy(&err, h->X.err, sizeof(err), hipMemcpyDeviceToHost));
-  if (err) {
-    snprintf(g_err, sizeof(g_err), "device error word %d (look-back over buckets timed out)", err);
-    return GPX_EDEVICE;
-  }
   return GPX_OK;
 }
 
@@ -540,16 +538,13 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
              ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
   begin_back(e, fs, n);
-  const DecCols D{d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind};
-  const OutTotals T{n_out, &e->X.counters[1]};
   if (e->cfg.kmax <= 4)
-    launch_bucket_ar<4>(e, status, D, T);
+    launch_bucket_ar<4>(e, status);
   else if (e->cfg.kmax <= 8)
-    launch_bucket_ar<8>(e, status, D, T);
+    launch_bucket_ar<8>(e, status);
   else
-    launch_bucket_ar<16>(e, status, D, T);
-  if (!e->X.lookback)
-    LAUNCH(e, "k_emit_dec", k_emit_dec, e->X.nbk, e->X, d_gidx, d_slot, d_bnum, d_bcoord,
+    launch_bucket_ar<16>(e, status);
+  LAUNCH(e, "k_emit_dec", k_emit_dec, e->X.nbk, e->X, d_gidx, d_slot, d_bnum, d_bcoord,
            d_median_cp, d_kind, n_out, &e->X.counters[1]);
   end_call(e, fs, {{d_gidx, b4}, {d_slot, b4}, {d_bnum, b4}, {d_bcoord, b4}, {d_median_cp, b4},
                    {d_kind, (size_t)n}, {n_out, 4}, {status, (size_t)n}});
@@ -580,9 +575,8 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
            gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
   begin_back(e, fs, n);
   LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags,
-           status, RunCols{x_gidx, x_first, x_count}, OutTotals{n_runs, nullptr});
-  if (!e->X.lookback)
-    LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+           status);
+  LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   end_call(e, fs, {{r_bnum, b4}, {r_bcoord, b4}, {r_maxcp, b4}, {r_flags, (size_t)n},
                    {status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
   HIPCHK(hipGetLastError());
@@ -610,10 +604,8 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
            gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
            (int32_t*)nullptr, (uint8_t*)nullptr);
   begin_back(e, fs, n);
-  LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status,
-           RunCols{x_gidx, x_first, x_count}, OutTotals{n_runs, nullptr});
-  if (!e->X.lookback)
-    LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+  LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
+  LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   end_call(e, fs, {{status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
   HIPCHK(hipGetLastError());
   return GPX_OK;
@@ -629,18 +621,27 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
   const size_t b4 = (size_t)n * 4;
   const int fs = begin_front(e, {{gidx, b4}, {is_stop, (size_t)n}, {slot, b4}, {bnum, b4}, {bcoord, b4},
                                  {median_cp, b4}, {status, (size_t)n}});
-  front_hist(e, n, gidx, status, 0);
+  front_hist(e, n, gidx, status, 0, 1);
   const int ntiles = ntiles_for(n);
   LAUNCH_F(e, "k_scatter_pr", k_scatter_pr, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
            e->S.G, e->X,
            gidx, is_stop, slot, bnum, bcoord, median_cp);
   begin_back(e, fs, n);
-  if (e->cfg.kmax <= 4)
+  /* exactly one of the two back ends does the work (device-side choice on *X.unsorted, set by
+   * k_hist): strictly ascending batch -> k_propose_direct, anything else -> k_bucket_propose */
+  if (e->cfg.kmax <= 4) {
+    LAUNCH(e, "k_propose_direct", k_propose_direct<4>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
+           bnum, bcoord, median_cp, status);
     launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status);
-  else if (e->cfg.kmax <= 8)
+  } else if (e->cfg.kmax <= 8) {
+    LAUNCH(e, "k_propose_direct", k_propose_direct<8>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
+           bnum, bcoord, median_cp, status);
     launch_bucket_propose<8>(e, slot, bnum, bcoord, median_cp, status);
-  else
+  } else {
+    LAUNCH(e, "k_propose_direct", k_propose_direct<16>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
+           bnum, bcoord, median_cp, status);
     launch_bucket_propose<16>(e, slot, bnum, bcoord, median_cp, status);
+  }
   end_call(e, fs, {{slot, b4}, {bnum, b4}, {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
   HIPCHK(hipGetLastError());
   return GPX_OK;

@@ -127,10 +127,9 @@ struct DevScratch {
   Out* o_rec;             /* [n] compacted outputs of bucket b as a dense run at o_rec[bucket_off[b] ..] */
   int32_t* bucket_nout;   /* [nbk] number of compacted outputs of each bucket */
   unsigned long long* counters; /* [3] votes, outputs (decisions + preempts), dropped */
-  unsigned long long* lb;       /* [nbk] decoupled look-back words: epoch << 34 | flag << 32 | count */
-  uint32_t epoch;               /* back-end launch number (30 bits, never 0): stale words are ignored */
-  int32_t lookback;             /* 1: k_bucket_* write the caller's columns themselves (no k_emit_*) */
-  int32_t* err;                 /* [1] sticky device-side error word (look-back timeout) */
+  uint32_t* unsorted;           /* [1] = `epoch` iff the current batch's gidx column is NOT strictly
+                                 * ascending and in range (k_hist); stale values mean "sorted" */
+  uint32_t epoch;               /* call number, > 0 */
 };
 
 /* Java int subtraction (wraps) */
@@ -278,7 +277,7 @@ template <bool VEC>
 __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
                                                     const int32_t* __restrict__ gidx, int32_t G,
                                                     DevScratch X, uint8_t* __restrict__ status,
-                                                    int32_t is_votes) {
+                                                    int32_t is_votes, int32_t check_order) {
   extern __shared__ int32_t lds[];
   const int32_t tile = tile_of_block(ntiles);
   if (tile >= ntiles) return;
@@ -286,6 +285,14 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
   __syncthreads();
   const int64_t base = (int64_t)tile * GPX_TILE;
   const int32_t bad = tile_histogram<VEC>(n, base, gidx, G, X.shift, lds);
+  if (check_order) {
+    /* strictly ascending, in-range gidx = every group at most once: such a batch needs no
+     * regrouping (k_propose_direct); anything else marks the call's epoch in *X.unsorted */
+    bool out_of_order = bad != 0;
+    for (int64_t i = base + threadIdx.x; i < base + GPX_TILE && i + 1 < n; i += GPX_FBLOCK)
+      out_of_order |= gidx[i] >= gidx[i + 1];
+    if (__syncthreads_or(out_of_order) && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
+  }
   /* status: 8 consecutive records per lane */
   if (status)
   for (int64_t i0 = base + (int64_t)threadIdx.x * 8; i0 < base + GPX_TILE; i0 += GPX_FBLOCK * 8) {
@@ -445,6 +452,7 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_pr(
   extern __shared__ int32_t lds[];
   const int32_t tile = tile_of_block(ntiles);
   if (tile >= ntiles) return;
+  if (*X.unsorted != X.epoch) return; /* strictly ascending batch: k_propose_direct handles it */
   scatter_init(X, tile, lds);
   const int64_t base = (int64_t)tile * GPX_TILE;
   const int32_t mask = X.gb - 1;
@@ -760,92 +768,13 @@ __device__ __forceinline__ int32_t median_minus(const int32_t (&ns)[KMAX], int32
  * (outputs <= records, so the bucket's own record range always has room) and their count to
  * bucket_nout[b]; k_emit_* turns the per-bucket runs into the caller's dense SoA columns. */
 
-/* ---- decoupled look-back over buckets -------------------------------------------------------
- * Each bucket workgroup publishes its output count in lb[b] as soon as its replay is done, then
- * sums the counts of the buckets before it by walking back over their words (64 per step) until
- * it meets one that already carries an inclusive prefix, and publishes its own inclusive prefix.
- * The count travels INSIDE the 64-bit word (epoch << 34 | flag << 32 | value), so no release /
- * acquire fence is needed (an agent-scope release writes back the XCD's whole L2 on this chip:
- * measured +20..50 us per kernel); words are read and written with agent-scope RMW atomics only,
- * which are coherent across XCDs.  Words of earlier launches carry an older epoch and read as
- * "not ready" - lb[] is never cleared.  Workgroups are dispatched in blockIdx order per XCD, so
- * the lowest unfinished bucket is always resident and never waits on anybody; the spin is bounded
- * anyway (a timeout sets *X.err and lets the kernel finish with a wrong offset instead of hanging
- * the GPU). */
-#define LB_AGG 1ull
-#define LB_PREFIX 2ull
-#define LB_SPIN_LIMIT (1u << 21)
-__device__ __forceinline__ unsigned long long lb_pack(uint32_t epoch, unsigned long long flag,
-                                                      int32_t v) {
-  return ((unsigned long long)epoch << 34) | (flag << 32) | (unsigned long long)(uint32_t)v;
-}
-/* Wave 0 of the workgroup only (all 64 lanes).  Returns the number of outputs of the buckets
- * before b. */
-__device__ __forceinline__ int32_t lb_resolve(const DevScratch& X, int32_t b, int32_t tot) {
-  const int lane = (int)(threadIdx.x & 63);
-  unsigned long long* lb = X.lb;
-  if (lane == 0)
-    __hip_atomic_exchange(&lb[b], lb_pack(X.epoch, LB_AGG, tot), __ATOMIC_RELAXED,
-                          __HIP_MEMORY_SCOPE_AGENT);
-  int32_t sum = 0;
-  int32_t base = b - 1;
-  bool done = base < 0;
-  while (!done) { /* wave-uniform */
-    const int32_t i = base - lane;
-    unsigned long long v = lb_pack(X.epoch, LB_PREFIX, 0); /* virtual word before bucket 0 */
-    if (i >= 0) {
-      uint32_t spins = 0;
-      for (;;) {
-        v = __hip_atomic_fetch_or(&lb[i], 0ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(v >> 34) == X.epoch) break;
-        if (++spins > LB_SPIN_LIMIT) {
-          atomicOr(X.err, 1);
-          v = lb_pack(X.epoch, LB_PREFIX, 0);
-          break;
-        }
-        __builtin_amdgcn_s_sleep(4);
-      }
-    }
-    const unsigned long long pm = __ballot(((v >> 32) & 3ull) == LB_PREFIX);
-    const int first = pm ? (__ffsll((long long)pm) - 1) : 64; /* nearest bucket holding a prefix */
-    int32_t c = (lane <= first) ? (int32_t)(uint32_t)v : 0;
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) c += __shfl_xor(c, d, 64);
-    sum += c;
-    done = pm != 0;
-    base -= 64;
-  }
-  if (lane == 0)
-    __hip_atomic_exchange(&lb[b], lb_pack(X.epoch, LB_PREFIX, sum + tot), __ATOMIC_RELAXED,
-                          __HIP_MEMORY_SCOPE_AGENT);
-  return sum;
-}
-
-/* where the compacted outputs of a call go: the caller's n_out word and the engine counter */
-struct OutTotals {
-  int32_t* total_out;
-  unsigned long long* acc;
-};
-
-/* a bucket without records still takes part in the look-back (whole workgroup calls this) */
-__device__ __forceinline__ void bucket_empty(const DevScratch& X, const OutTotals& T) {
-  if (!X.lookback) return;
-  if (threadIdx.x < 64) {
-    const int32_t pre = lb_resolve(X, (int32_t)blockIdx.x, 0);
-    if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) {
-      if (T.total_out) *T.total_out = pre;
-      if (T.acc) atomicAdd(T.acc, (unsigned long long)pre);
-    }
-  }
-}
-
 /* all lanes of the workgroup; the number of outputs of each group is already stored in bv.lcnt[l]
- * (overwriting the record count, which is no longer needed).  wr(o, gidx, p0, p1, p2, p3, p4)
- * stores output o of the call into the caller's columns. */
-template <class WR>
-__device__ __forceinline__ void bucket_emit(const DevScratch& X, const BucketView& bv,
-                                            const OutTotals& T, WR wr) {
-  __shared__ int32_t s_pre;
+ * (overwriting the record count, which is no longer needed).
+ * (Measured and rejected: letting this kernel place its outputs in the caller's columns itself -
+ * offset from a decoupled look-back over the buckets' counts, or from one returning atomic per
+ * workgroup - costs the per-bucket kernel exactly the 13-14 us k_emit_* takes: the kernel is
+ * latency-bound and every extra dependent global round trip per workgroup shows up in full.) */
+__device__ __forceinline__ void bucket_emit(const DevScratch& X, const BucketView& bv) {
   __syncthreads();
   const int32_t b = blockIdx.x;
   const int32_t boff = X.bucket_off[b];
@@ -855,34 +784,8 @@ __device__ __forceinline__ void bucket_emit(const DevScratch& X, const BucketVie
   for (int32_t q = 0; q < per; q++) s += bv.lcnt[threadIdx.x * per + q];
   int32_t tot;
   int32_t ex = block_exscan_rt(s, &tot);
-  const int32_t g0 = b << X.shift;
-  if (X.lookback) {
-    if (threadIdx.x < 64) {
-      const int32_t pre = lb_resolve(X, b, tot);
-      if (threadIdx.x == 0) {
-        s_pre = pre;
-        if (b == (int32_t)gridDim.x - 1) {
-          if (T.total_out) *T.total_out = pre + tot;
-          if (T.acc) atomicAdd(T.acc, (unsigned long long)(pre + tot));
-        }
-      }
-    }
-    __syncthreads();
-    ex += s_pre;
-    for (int32_t q = 0; q < per; q++) {
-      const int32_t l = threadIdx.x * per + q;
-      const int32_t d = bv.lcnt[l];
-      const unsigned long long* kk = bv.keys + bv.loff[l];
-      for (int32_t t = 0; t < d; t++) {
-        const int32_t* p = bv.pay + (int64_t)(uint32_t)kk[t] * bv.rs;
-        wr(ex + t, g0 + l, p[0], p[bv.fs], p[2 * bv.fs], p[3 * bv.fs], p[4 * bv.fs]);
-      }
-      ex += d;
-    }
-    return;
-  }
-  /* two-kernel form: dense run of rows at o_rec[boff ..], k_emit_* transposes */
   Out* dst = X.o_rec + boff;
+  const int32_t g0 = b << X.shift;
   for (int32_t q = 0; q < per; q++) {
     const int32_t l = threadIdx.x * per + q;
     const int32_t d = bv.lcnt[l];
@@ -1092,16 +995,9 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
   if (!has_coord && (gf & GF_HASCOORD)) S.g_flags[g] = gf & ~GF_HASCOORD;
 }
 
-/* decisions / preempts -> the caller's d_* columns */
-struct DecCols {
-  int32_t *gidx, *slot, *bnum, *bcoord, *median;
-  uint8_t* kind;
-};
-
 template <int KMAX>
 __global__ __launch_bounds__(1024) void k_bucket_ar(DevState S, DevScratch X,
-                                                    uint8_t* __restrict__ status, DecCols D,
-                                                    OutTotals T) {
+                                                    uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
   const int32_t g0 = blockIdx.x << X.shift;
@@ -1115,10 +1011,8 @@ __global__ __launch_bounds__(1024) void k_bucket_ar(DevState S, DevScratch X,
   if (pre && gme < S.G) coord_preload<KMAX>(S, gme, P);
   if (!bucket_prepare(X, lds, &bv, [&]() {
         if (pre && gme < S.G) coord_preload_ring<KMAX>(S, gme, P);
-      })) {
-    bucket_empty(X, T);
+      }))
     return;
-  }
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
     int32_t nout = 0;
@@ -1131,15 +1025,7 @@ __global__ __launch_bounds__(1024) void k_bucket_ar(DevState S, DevScratch X,
     }
     bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
   }
-  bucket_emit(X, bv, T,
-              [&](int32_t o, int32_t g, int32_t slot, int32_t x, int32_t y, int32_t z, int32_t kind) {
-                D.gidx[o] = g;
-                D.slot[o] = slot;
-                D.bnum[o] = x;
-                D.bcoord[o] = y;
-                D.median[o] = z;
-                D.kind[o] = (uint8_t)kind;
-              });
+  bucket_emit(X, bv);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1339,27 +1225,12 @@ __device__ __forceinline__ void apply_accept_group(
   if (n_drop) atomicAdd(&X.counters[2], n_drop);
 }
 
-/* exec runs -> the caller's x_* columns */
-struct RunCols {
-  int32_t *gidx, *first, *count;
-};
-#define GPX_RUN_WRITER(R)                                                                       \
-  [&](int32_t o, int32_t g, int32_t, int32_t first, int32_t cnt, int32_t, int32_t) {            \
-    (R).gidx[o] = g;                                                                            \
-    (R).first[o] = first;                                                                       \
-    (R).count[o] = cnt;                                                                         \
-  }
-
 __global__ __launch_bounds__(1024) void k_bucket_accept(
     DevState S, DevScratch X, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
-    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status,
-    RunCols R, OutTotals T) {
+    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
-  if (!bucket_prepare(X, lds, &bv, []() {})) {
-    bucket_empty(X, T);
-    return;
-  }
+  if (!bucket_prepare(X, lds, &bv, []() {})) return;
   const int32_t g0 = blockIdx.x << X.shift;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
@@ -1372,7 +1243,7 @@ __global__ __launch_bounds__(1024) void k_bucket_accept(
     }
     bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
   }
-  bucket_emit(X, bv, T, GPX_RUN_WRITER(R));
+  bucket_emit(X, bv);
 }
 
 /* PaxosInstanceStateMachine.handleBatchedCommit (PISM:1480-1528) per slot and
@@ -1425,14 +1296,10 @@ __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevS
 }
 
 __global__ __launch_bounds__(1024) void k_bucket_commit(DevState S, DevScratch X,
-                                                        uint8_t* __restrict__ status, RunCols R,
-                                                        OutTotals T) {
+                                                        uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
-  if (!bucket_prepare(X, lds, &bv, []() {})) {
-    bucket_empty(X, T);
-    return;
-  }
+  if (!bucket_prepare(X, lds, &bv, []() {})) return;
   const int32_t g0 = blockIdx.x << X.shift;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
     const int32_t c = bv.lcnt[l];
@@ -1445,7 +1312,7 @@ __global__ __launch_bounds__(1024) void k_bucket_commit(DevState S, DevScratch X
     }
     bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
   }
-  bucket_emit(X, bv, T, GPX_RUN_WRITER(R));
+  bucket_emit(X, bv);
 }
 
 /* PaxosInstanceStateMachine.handleProposal (PISM:818-888) ->
@@ -1478,9 +1345,21 @@ __device__ __forceinline__ void propose_preload_ring(const DevState& S, int32_t 
   P.pe_cur = S.p_ring[(int64_t)(P.next & Wm) * S.G + g];
 }
 
-template <int KMAX>
+/* the one record of a group in a strictly ascending batch, with GroupIter's reading interface */
+struct OneRec {
+  int32_t idx, a, c, done;
+  __device__ __forceinline__ bool next(Rec& out) {
+    if (done) return false;
+    out.idx = idx;
+    out.a = a;
+    done = 1;
+    return true;
+  }
+};
+
+template <int KMAX, class IT>
 __device__ __forceinline__ void apply_propose_group(
-    const DevState& S, const DevScratch& X, int32_t g, GroupIter& it, int32_t* __restrict__ o_slot,
+    const DevState& S, const DevScratch& X, int32_t g, IT& it, int32_t* __restrict__ o_slot,
     int32_t* __restrict__ o_bnum, int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median,
     uint8_t* __restrict__ status, const ProposePre<KMAX>& P) {
   const int32_t G = S.G;
@@ -1559,6 +1438,10 @@ __global__ __launch_bounds__(1024) void k_bucket_propose(
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
+  if (*X.unsorted != X.epoch) { /* handled by k_propose_direct; leave the counts ready for the next call */
+    if (threadIdx.x == 0) X.bucket_tot[blockIdx.x] = 0;
+    return;
+  }
   const int32_t g0 = blockIdx.x << X.shift;
   const int32_t nb_ = X.bucket_off[blockIdx.x + 1] - X.bucket_off[blockIdx.x];
   const bool pre = (int32_t)blockDim.x == X.gb && 2 * nb_ >= X.gb;
@@ -1578,10 +1461,34 @@ __global__ __launch_bounds__(1024) void k_bucket_propose(
       propose_preload<KMAX>(S, g0 + l, P);
       propose_preload_ring<KMAX>(S, g0 + l, P);
     }
-    apply_propose_group<KMAX>(S, X, g0 + l, it, o_slot, o_bnum, o_bcoord, o_median, status, P);
+    apply_propose_group<KMAX, GroupIter>(S, X, g0 + l, it, o_slot, o_bnum, o_bcoord, o_median, status, P);
   }
 }
 
+
+/* Proposal batch whose gidx column is strictly ascending (every group at most once - what
+ * RequestBatcher produces: one batched request per group per dequeue, RequestBatcher.java:79-81):
+ * no regrouping needed, one lane per record applies it straight to its group.  Consecutive
+ * records address ascending groups, so the state accesses are coalesced when the batch is dense. */
+template <int KMAX>
+__global__ __launch_bounds__(GPX_BLOCK) void k_propose_direct(
+    DevState S, DevScratch X, int32_t n, const int32_t* __restrict__ gidx,
+    const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
+    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status) {
+  if (*X.unsorted == X.epoch) return;
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t g = gidx[i]; /* in range: k_hist marks out-of-range batches unsorted */
+  ProposePre<KMAX> P;
+  propose_preload<KMAX>(S, g, P);
+  propose_preload_ring<KMAX>(S, g, P);
+  OneRec it;
+  it.idx = i;
+  it.a = is_stop ? (int32_t)(is_stop[i] & 1) : 0;
+  it.c = 1;
+  it.done = 0;
+  apply_propose_group<KMAX, OneRec>(S, X, g, it, o_slot, o_bnum, o_bcoord, o_median, status, P);
+}
 
 /* ------------------------------------------------------------------------- */
 /* lifecycle                                                                    */

@@ -1,9 +1,14 @@
 #!/bin/bash
 # bench every library build under scratch/variants/ (tuning aid; see scripts/gpu_round.sh for the judged run)
+#   sweep_variants.sh [bench.py flags]      env: SWEEP_ENV="A=1 B=2" extra environment per run
 for f in scratch/variants/*.so; do
-  echo "== $f $*"
-  GPX_HIP_LIB=$PWD/$f python bench.py --no-cpu-baseline --steps 10 "$@" 2>&1 | python -c "
+  echo "== $f $* $SWEEP_ENV"
+  env $SWEEP_ENV GPX_HIP_LIB=$PWD/$f python bench.py --no-cpu-baseline --steps 10 "$@" 2>&1 | python -c "
 import sys,json
-d=json.loads(sys.stdin.read().strip().splitlines()[-1])
-print(d['ms_per_step'], {k:round(v*1000,1) for k,v in d['roofline']['kernels_ms_per_step'].items()})"
+txt=sys.stdin.read().strip().splitlines()
+try:
+    d=json.loads(txt[-1])
+    print(d['ms_per_step'], {k:round(v*1000,1) for k,v in d['roofline']['kernels_ms_per_step'].items()})
+except Exception as e:
+    print('FAILED', txt[-3:])"
 done

@@ -218,3 +218,33 @@ def test_config5_churn_create_retire_mid_run(hip_lib, oracle_lib):
     assert sh.tobytes() == so.tobytes()
     assert_same_state(eh, eo, np.random.default_rng(1).integers(0, cap, 64))
     assert eh.counters() == eo.counters()
+
+
+@pytest.mark.parametrize("order", ["ascending", "ascending_sparse", "duplicates", "descending", "out_of_range"])
+def test_propose_batch_orders(hip_lib, oracle_lib, order):
+    """The proposal path picks its back end on the device: a strictly ascending in-range gidx column
+    (one record per group) is applied directly, anything else is regrouped first.  Both must give
+    the oracle's answer, including stop requests, non-existent / stopped groups and forwards."""
+    G, k = 5000, 3
+    rng = np.random.default_rng(11)
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 32, max_batch=1 << 15)  # window 32: never fills here
+    create_mixed_groups(eh, eo, G - 500, k, NODES[:5], rng)  # rows G-500.. stay non-existent
+    for rnd in range(4):
+        if order == "ascending":
+            g = np.arange(G, dtype=np.int32)
+        elif order == "ascending_sparse":
+            g = np.sort(rng.choice(G, size=G // 7, replace=False)).astype(np.int32)
+        elif order == "duplicates":
+            g = np.sort(rng.integers(0, G, G // 2)).astype(np.int32)
+        elif order == "descending":
+            g = np.arange(G, dtype=np.int32)[::-1].copy()
+        else:
+            g = np.arange(-1, G + 1, dtype=np.int32)
+        stop = (rng.random(g.shape[0]) < (0.02 if rnd == 2 else 0.0)).astype(np.uint8)
+        ra, rb = eh.propose(g, stop), eo.propose(g, stop)
+        for x, y, nm in zip(ra, rb, ("slot", "bnum", "bcoord", "median", "status")):
+            assert x.tolist() == y.tolist(), f"round {rnd} {nm}"
+    sh, so = eh.snapshot(np.arange(G))[0], eo.snapshot(np.arange(G))[0]
+    assert sh.tobytes() == so.tobytes()
+    assert_same_state(eh, eo, rng.integers(0, G, 48))
+    assert eh.counters() == eo.counters()
