@@ -17,6 +17,7 @@
 #include <initializer_list>
 
 #include "gpx_kernels.hip.h"
+#include "gpx_wire.hip.h"
 
 namespace {
 
@@ -80,6 +81,14 @@ struct gpx_engine {
   int32_t lds_recs_max = 0;   /* staging capacity the engine was sized for (kmax records per group) */
   int bucket_threads = 256;
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
+  /* wire codec (gpx_wire_host.inc): paxosID table, row free list, scratch - allocated on first use */
+  DevNames N{};
+  int64_t nm_tomb = 0;
+  std::vector<int32_t> free_rows;
+  bool free_init = false;
+  int32_t *w_cnt = nullptr, *w_tile = nullptr, *w_err = nullptr;
+  int8_t* w_cls = nullptr;
+  long long* w_tile_b = nullptr;
 };
 
 namespace {
@@ -978,3 +987,5 @@ int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
 }
 
 } /* extern "C" */
+
+#include "gpx_wire_host.inc"

@@ -1,0 +1,763 @@
+/*
+ * gpx_wire.hip.h — CDNA4 (gfx950) kernels of the wire codec (include/gpx_wire.h): device-resident
+ * paxosID table, frames -> SoA decode, decisions -> BATCHED_COMMIT frames.
+ *
+ * Byte / integer work, HBM-bound; one lane per frame (a frame is ~50-100 bytes: neighbouring
+ * lanes read neighbouring cache lines).  Every function cites the reference code it replaces
+ * (paths relative to /root/reference/src/edu/umass/cs/gigapaxos/).
+ */
+#pragma once
+#include "gpx_kernels.hip.h"
+#include "../../include/gpx_wire.h"
+
+#define NM_STRIDE 128 /* bytes per name row: paxosIDLength <= 127 */
+#define GPX_W_MAX_DEPTH 6   /* nesting of batched RequestPackets the walker follows */
+#define GPX_W_MAX_SEG 256   /* rows of one group a BATCHED_COMMIT frame may span (>= 2 * window) */
+
+/* device mirror of PaxosManager.pinstances' key side: open addressing over the paxosID bytes */
+struct DevNames {
+  int32_t cap;     /* table slots, power of two, >= 2 * G */
+  int32_t* tab;    /* 0 empty, -1 tombstone, else row + 1 */
+  uint8_t* bytes;  /* [G][NM_STRIDE] */
+  uint8_t* len;    /* [G], 0 = row has no name */
+  int32_t* hash;   /* [G] java.lang.String.hashCode of the name */
+};
+
+__device__ __forceinline__ uint32_t w_fmix32(uint32_t h) {
+  h ^= h >> 16;
+  h *= 0x85ebca6bu;
+  h ^= h >> 13;
+  h *= 0xc2b2ae35u;
+  h ^= h >> 16;
+  return h;
+}
+/* String.hashCode of an ISO-8859-1 string: s[0]*31^(n-1) + ... + s[n-1] (int arithmetic) */
+__device__ __forceinline__ int32_t w_java_hash(const uint8_t* p, int32_t n) {
+  uint32_t h = 0;
+  for (int32_t i = 0; i < n; i++) h = 31u * h + (uint32_t)p[i];
+  return (int32_t)h;
+}
+__device__ __forceinline__ bool w_bytes_eq(const uint8_t* a, const uint8_t* b, int32_t n) {
+  for (int32_t i = 0; i < n; i++)
+    if (a[i] != b[i]) return false;
+  return true;
+}
+/* MultiArrayMap.get(paxosID) (PaxosManager.getInstance, PaxosManager.java:1816-1832): row or -1 */
+__device__ __forceinline__ int32_t names_find(const DevNames& N, const uint8_t* p, int32_t len,
+                                              int32_t hash) {
+  if (!N.tab) return -1;
+  const uint32_t mask = (uint32_t)N.cap - 1u;
+  uint32_t s = w_fmix32((uint32_t)hash) & mask;
+  for (int32_t probe = 0; probe < N.cap; probe++) {
+    const int32_t v = N.tab[s];
+    if (v == 0) return -1;
+    if (v > 0) {
+      const int32_t g = v - 1;
+      if (N.hash[g] == hash && (int32_t)N.len[g] == len &&
+          w_bytes_eq(N.bytes + (int64_t)g * NM_STRIDE, p, len))
+        return g;
+    }
+    s = (s + 1) & mask;
+  }
+  return -1;
+}
+
+__global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevNames N, int32_t G, int32_t n,
+                                                         const uint8_t* __restrict__ names,
+                                                         const int32_t* __restrict__ name_off,
+                                                         const int32_t* __restrict__ gidx,
+                                                         uint8_t* __restrict__ status) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t g = gidx[i];
+  const int32_t len = name_off[i + 1] - name_off[i];
+  if ((uint32_t)g >= (uint32_t)G || len < 1 || len > GPX_W_MAX_NAME) {
+    status[i] = GPX_S_NOGROUP;
+    return;
+  }
+  if (N.len[g] != 0) { /* the row already carries a name */
+    status[i] = GPX_S_EXISTS;
+    return;
+  }
+  const uint8_t* p = names + name_off[i];
+  const int32_t h = w_java_hash(p, len);
+  uint8_t* row = N.bytes + (int64_t)g * NM_STRIDE;
+  for (int32_t b = 0; b < len; b++) row[b] = p[b];
+  N.hash[g] = h;
+  N.len[g] = (uint8_t)len;
+  __threadfence(); /* the row is complete before the table can point at it */
+  const uint32_t mask = (uint32_t)N.cap - 1u;
+  uint32_t s = w_fmix32((uint32_t)h) & mask;
+  for (int32_t probe = 0; probe < N.cap; probe++) {
+    int32_t v = N.tab[s];
+    if (v == 0) {
+      v = atomicCAS(&N.tab[s], 0, g + 1);
+      if (v == 0) {
+        status[i] = GPX_S_OK;
+        return;
+      }
+      __threadfence();
+    }
+    if (v > 0 && v - 1 != g) {
+      const int32_t o = v - 1;
+      if (N.hash[o] == h && (int32_t)N.len[o] == len &&
+          w_bytes_eq(N.bytes + (int64_t)o * NM_STRIDE, p, len)) {
+        N.len[g] = 0; /* name already bound to another row */
+        status[i] = GPX_S_EXISTS;
+        return;
+      }
+    }
+    s = (s + 1) & mask;
+  }
+  N.len[g] = 0;
+  status[i] = GPX_S_NOGROUP; /* table full: cannot happen with cap >= 2 G */
+}
+
+__global__ __launch_bounds__(GPX_BLOCK) void k_names_unbind(DevNames N, int32_t G, int32_t n,
+                                                           const int32_t* __restrict__ gidx,
+                                                           uint8_t* __restrict__ status) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t g = gidx[i];
+  if ((uint32_t)g >= (uint32_t)G || N.len[g] == 0) {
+    if (status) status[i] = GPX_S_NOGROUP;
+    return;
+  }
+  const uint32_t mask = (uint32_t)N.cap - 1u;
+  uint32_t s = w_fmix32((uint32_t)N.hash[g]) & mask;
+  for (int32_t probe = 0; probe < N.cap; probe++) {
+    const int32_t v = N.tab[s];
+    if (v == g + 1) {
+      N.tab[s] = -1; /* tombstone: later probes walk over it */
+      break;
+    }
+    if (v == 0) break;
+    s = (s + 1) & mask;
+  }
+  N.len[g] = 0;
+  if (status) status[i] = GPX_S_OK;
+}
+
+/* rebuild after many unbinds: table cleared by the host, every named row re-inserted */
+__global__ __launch_bounds__(GPX_BLOCK) void k_names_reinsert(DevNames N, int32_t G) {
+  const int32_t g = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (g >= G || N.len[g] == 0) return;
+  const uint32_t mask = (uint32_t)N.cap - 1u;
+  uint32_t s = w_fmix32((uint32_t)N.hash[g]) & mask;
+  for (int32_t probe = 0; probe < N.cap; probe++) {
+    if (N.tab[s] == 0 && atomicCAS(&N.tab[s], 0, g + 1) == 0) return;
+    s = (s + 1) & mask;
+  }
+}
+
+__global__ __launch_bounds__(GPX_BLOCK) void k_names_lookup(DevNames N, int32_t n,
+                                                           const uint8_t* __restrict__ names,
+                                                           const int32_t* __restrict__ name_off,
+                                                           int32_t* __restrict__ out) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t len = name_off[i + 1] - name_off[i];
+  const uint8_t* p = names + name_off[i];
+  out[i] = (len >= 1 && len <= GPX_W_MAX_NAME) ? names_find(N, p, len, w_java_hash(p, len)) : -1;
+}
+
+/* ------------------------------------------------------------------------- */
+/* decode                                                                       */
+
+/* java.nio.ByteBuffer.getInt at an arbitrary byte position (big-endian) */
+__device__ __forceinline__ int32_t w_be32(const uint8_t* p) {
+  return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) |
+                   (uint32_t)p[3]);
+}
+__device__ __forceinline__ int64_t w_be64(const uint8_t* p) {
+  return (int64_t)(((uint64_t)(uint32_t)w_be32(p) << 32) | (uint64_t)(uint32_t)w_be32(p + 4));
+}
+
+/* PaxosPacket.PaxosPacketType.getPaxosPacketType(int) != null (PaxosPacket.java:202-300) */
+__device__ __forceinline__ bool w_known_type(int32_t t) {
+  return (t >= 1 && t <= 9) || t == 13 || t == 21 || t == 23 || (t >= 32 && t <= 37) || t == 90 ||
+         t == 9999;
+}
+
+/* One RequestPacket body starting at its PaxosPacket header, inside the buffer [.., end):
+ * RequestPacket(ByteBuffer) up to and including numBatched (RequestPacket.java:956-1005).
+ * Returns false where the constructor would throw. */
+__device__ __forceinline__ bool w_request_fixed(const uint8_t* p, int64_t& pos, int64_t end,
+                                                int32_t& num_batched, bool& stop, int64_t& req_id) {
+  if (pos + 13 > end) return false;
+  const int32_t idl = (int32_t)(int8_t)p[pos + 12];
+  if (idl < 0 || pos + 13 + idl > end) return false;
+  pos += 13 + idl;
+  /* requestID 8, stop 1, addresses 12, entryReplica 4, entryTime 8, shouldReturn 1,
+   * forwardCount 4, broadcasted 1 = 39, then int digestLength */
+  if (pos + 39 + 4 > end) return false;
+  req_id = w_be64(p + pos);
+  stop = p[pos + 8] == 1;
+  pos += 39;
+  const int32_t dl = w_be32(p + pos);
+  pos += 4;
+  if (dl > 0) {
+    if (pos + dl > end) return false;
+    pos += dl;
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++) { /* requestValue, responseValue: new byte[len] */
+    if (pos + 4 > end) return false;
+    const int32_t vl = w_be32(p + pos);
+    pos += 4;
+    if (vl < 0 || pos + vl > end) return false;
+    pos += vl;
+  }
+  if (pos + 4 > end) return false;
+  num_batched = w_be32(p + pos);
+  pos += 4;
+  return num_batched >= 0; /* new RequestPacket[numBatched] */
+}
+
+/* Whole RequestPacket incl. its batched sub-requests, each a complete RequestPacket byte array
+ * parsed by its own constructor (RequestPacket.java:1006-1019).  On success pos = first byte after
+ * the request (where an ACCEPT's slot / ballot tail starts); stop_any = isStopRequest()
+ * (RequestPacket.java:1069-1080). */
+__device__ bool w_walk_request(const uint8_t* p, int64_t& pos, int64_t end, bool& stop_any,
+                               int64_t& req_id) {
+  int64_t bend[GPX_W_MAX_DEPTH + 1];
+  int32_t rem[GPX_W_MAX_DEPTH + 1];
+  int32_t nb = 0;
+  bool st = false;
+  if (!w_request_fixed(p, pos, end, nb, st, req_id)) return false;
+  stop_any = st;
+  bend[0] = end;
+  int d = 0;
+  if (nb > 0) {
+    d = 1;
+    rem[1] = nb;
+  }
+  while (d >= 1) {
+    /* next element of the list at level d; it lives in the buffer of level d - 1 */
+    rem[d]--;
+    if (pos + 4 > bend[d - 1]) return false;
+    const int32_t len = w_be32(p + pos);
+    pos += 4;
+    if (len < 0 || pos + len > bend[d - 1]) return false;
+    bend[d] = pos + len;
+    int64_t rid;
+    if (!w_request_fixed(p, pos, bend[d], nb, st, rid)) return false;
+    stop_any = stop_any || st;
+    if (nb > 0) {
+      if (d + 1 > GPX_W_MAX_DEPTH) return false; /* engine limit on nesting */
+      d++;
+      rem[d] = nb;
+      continue;
+    }
+    pos = bend[d]; /* element done (trailing bytes of an element are ignored) */
+    while (d >= 1 && rem[d] == 0) { /* a finished list completes the element that holds it */
+      d--;
+      if (d >= 1) pos = bend[d];
+    }
+  }
+  return true;
+}
+
+struct WFrame {
+  int32_t st, type, gidx, cnt, cls; /* cls: 0 votes 1 commits 2 accepts 3 requests, -1 none */
+  int32_t hdr;                      /* bytes of the PaxosPacket header incl. the paxosID */
+  int32_t raw_n;                    /* entries of the slot list on the wire */
+  bool ascending;
+  bool stop;
+  int64_t req_id, tail;             /* ACCEPT: byte position of the slot / ballot tail */
+};
+
+/* strictly ascending signed order = what TreeMap / TreeSet iteration put on the wire */
+__device__ __forceinline__ bool w_list_ascending(const uint8_t* e, int32_t n, int32_t stride) {
+  int32_t prev = 0;
+  for (int32_t j = 0; j < n; j++) {
+    const int32_t s = w_be32(e + (int64_t)j * stride);
+    if (j > 0 && !(prev < s)) return false;
+    prev = s;
+  }
+  return true;
+}
+/* TreeSet size of a non-ascending list (n <= GPX_W_MAX_UNSORTED) */
+__device__ __forceinline__ int32_t w_list_distinct(const uint8_t* e, int32_t n, int32_t stride) {
+  int32_t c = 0;
+  for (int32_t j = 0; j < n; j++) {
+    const int32_t s = w_be32(e + (int64_t)j * stride);
+    bool seen = false;
+    for (int32_t q = 0; q < j && !seen; q++) seen = w_be32(e + (int64_t)q * stride) == s;
+    c += !seen;
+  }
+  return c;
+}
+
+/* PaxosPacketDemultiplexerFast.toPaxosPacket (paxosutil/PaxosPacketDemultiplexerFast.java:66-103)
+ * + the four ByteBuffer constructors + PaxosManager.handlePaxosPacket's getInstance / version test
+ * (PaxosManager.java:1153-1162), for one frame. */
+__device__ void w_parse(const DevState& S, const DevNames& N, const uint8_t* p, int64_t L,
+                        WFrame& f) {
+  f.st = GPX_W_MALFORMED;
+  f.type = -1;
+  f.gidx = -1;
+  f.cnt = 0;
+  f.cls = -1;
+  f.hdr = 0;
+  f.raw_n = 0;
+  f.ascending = true;
+  f.stop = false;
+  f.req_id = 0;
+  f.tail = 0;
+  if (L < 8) return; /* BufferUnderflowException */
+  if (w_be32(p) != GPX_WT_PAXOS_PACKET) return; /* type == null -> fatal(bytes) */
+  const int32_t t = w_be32(p + 4);
+  if (!w_known_type(t)) return;
+  if (t != GPX_WT_REQUEST && t != GPX_WT_ACCEPT && t != GPX_WT_BATCHED_COMMIT &&
+      t != GPX_WT_BATCHED_ACCEPT_REPLY) {
+    f.st = GPX_W_UNSUPPORTED; /* assert(false): paxosPacket stays null */
+    f.type = t;
+    return;
+  }
+  /* PaxosPacket(ByteBuffer) (PaxosPacket.java:443-458) */
+  if (L < 13) return;
+  const int32_t version = w_be32(p + 8);
+  const int32_t idl = (int32_t)(int8_t)p[12];
+  if (idl < 0 || 13 + (int64_t)idl > L) return; /* NegativeArraySize / underflow */
+  const int64_t hdr = 13 + idl;
+  f.hdr = (int32_t)hdr;
+  if (t == GPX_WT_BATCHED_ACCEPT_REPLY) {
+    if (idl == 0) return;          /* getPaxosID().getBytes on null (AcceptReplyPacket.java:153) */
+    if (hdr + 29 + 4 > L) return;  /* AcceptReplyPacket fields + numSlots */
+    const int32_t n = w_be32(p + hdr + 29);
+    if (n > 0) {
+      if (hdr + 33 + 12 * (int64_t)n > L) return;
+      f.raw_n = n;
+      f.ascending = w_list_ascending(p + hdr + 33, n, 12);
+      if (!f.ascending && n > GPX_W_MAX_UNSORTED) return;
+      f.cnt = f.ascending ? n : w_list_distinct(p + hdr + 33, n, 12);
+    }
+    f.cls = 0;
+  } else if (t == GPX_WT_BATCHED_COMMIT) {
+    if (hdr + 16 > L) return; /* ballot, medianCheckpointedSlot, numSlots */
+    const int32_t n = w_be32(p + hdr + 12);
+    int64_t gpos = hdr + 16;
+    if (n > 0) {
+      if (hdr + 16 + 4 * (int64_t)n > L) return;
+      f.raw_n = n;
+      f.ascending = w_list_ascending(p + hdr + 16, n, 4);
+      if (!f.ascending && n > GPX_W_MAX_UNSORTED) return;
+      f.cnt = f.ascending ? n : w_list_distinct(p + hdr + 16, n, 4);
+      gpos += 4 * (int64_t)n;
+    }
+    if (gpos + 4 > L) return; /* groupSize */
+    const int32_t gs = w_be32(p + gpos);
+    if (gs > 0 && gpos + 4 + 4 * (int64_t)gs > L) return;
+    f.cls = 1;
+  } else {
+    int64_t pos = 0;
+    bool stop_any = false;
+    int64_t rid = 0;
+    if (!w_walk_request(p, pos, L, stop_any, rid)) return;
+    f.stop = stop_any;
+    f.req_id = rid;
+    if (t == GPX_WT_ACCEPT) {
+      if (pos + 22 > L) return; /* slot 4, ballot 8, recovery 1, median 4, noCoalesce 1, sender 4 */
+      f.tail = pos;
+      f.cls = 2;
+    } else {
+      f.cls = 3;
+    }
+    f.cnt = 1;
+  }
+  f.type = t;
+  /* getInstance(paxosID) and the version check */
+  int32_t g = -1;
+  if (idl > 0) g = names_find(N, p + 13, idl, w_java_hash(p + 13, idl));
+  if (g < 0 || !(S.g_flags[g] & GF_EXISTS)) {
+    f.st = GPX_W_NOGROUP;
+    f.cnt = 0;
+    return;
+  }
+  f.gidx = g;
+  if (S.g_version[g] != version) {
+    f.st = GPX_W_VERSION;
+    f.cnt = 0;
+    return;
+  }
+  f.st = GPX_W_OK;
+}
+
+/* the caller's column structs, by value (device pointers; cap = 0 when the struct was NULL) */
+struct WireOut {
+  gpx_wire_votes V;
+  gpx_wire_commits C;
+  gpx_wire_accepts A;
+  gpx_wire_requests R;
+};
+
+struct WireScratch {
+  int32_t* cnt;   /* [frames] records of each frame */
+  int8_t* cls;    /* [frames] */
+  int32_t* tile;  /* [4][ntiles] records per class per 256-frame tile, then exclusive bases */
+  int32_t ntiles;
+};
+
+/* pass 1: parse every frame, count its records; per-tile totals per class */
+__global__ __launch_bounds__(GPX_BLOCK) void k_wire_scan(DevState S, DevNames N, WireScratch W,
+                                                        int32_t nf,
+                                                        const uint8_t* __restrict__ frames,
+                                                        const int64_t* __restrict__ frame_off,
+                                                        uint8_t* __restrict__ f_status,
+                                                        int32_t* __restrict__ f_gidx,
+                                                        int32_t* __restrict__ f_type,
+                                                        gpx_wire_counts* counts) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  WFrame f;
+  f.st = GPX_W_OK;
+  f.cnt = 0;
+  f.cls = -1;
+  if (i < nf) {
+    const int64_t o = frame_off[i];
+    w_parse(S, N, frames + o, frame_off[i + 1] - o, f);
+    f_status[i] = (uint8_t)f.st;
+    if (f_gidx) f_gidx[i] = f.gidx;
+    if (f_type) f_type[i] = f.type;
+    W.cnt[i] = f.cnt;
+    W.cls[i] = (int8_t)f.cls;
+  }
+  int32_t tot;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    block_exscan((i < nf && f.cls == c && f.st == GPX_W_OK) ? f.cnt : 0, &tot);
+    if (threadIdx.x == 0) W.tile[(int64_t)c * W.ntiles + blockIdx.x] = tot;
+  }
+  block_exscan((i < nf && f.st != GPX_W_OK) ? 1 : 0, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(&counts->n_bad_frames, tot);
+}
+
+/* pass 2 (one workgroup): exclusive scan of the tile totals per class; the class totals */
+__global__ __launch_bounds__(GPX_FBLOCK) void k_wire_offsets(WireScratch W, gpx_wire_counts* counts) {
+  for (int c = 0; c < 4; c++) {
+    int32_t run = 0;
+    for (int32_t t0 = 0; t0 < W.ntiles; t0 += GPX_FBLOCK) {
+      const int32_t t = t0 + (int32_t)threadIdx.x;
+      int32_t* q = &W.tile[(int64_t)c * W.ntiles + t];
+      const int32_t v = t < W.ntiles ? *q : 0;
+      int32_t tot;
+      const int32_t ex = block_exscan_n<GPX_FBLOCK>(v, &tot);
+      if (t < W.ntiles) *q = run + ex;
+      run += tot;
+    }
+    if (threadIdx.x == 0) (&counts->n_votes)[c] = run;
+  }
+}
+
+/* the r-th smallest distinct slot of a non-ascending list: smallest value greater than `last` */
+__device__ __forceinline__ int32_t w_next_slot(const uint8_t* e, int32_t n, int32_t stride,
+                                               int64_t last) {
+  int64_t best = (int64_t)1 << 40;
+  for (int32_t j = 0; j < n; j++) {
+    const int64_t s = w_be32(e + (int64_t)j * stride);
+    if (s > last && s < best) best = s;
+  }
+  return (int32_t)best;
+}
+
+/* pass 3: every frame writes its records at its class offset (frame order; slots ascending) */
+__global__ __launch_bounds__(GPX_BLOCK) void k_wire_unpack(DevState S, DevNames N, WireScratch W,
+                                                          WireOut O, int32_t nf,
+                                                          const uint8_t* __restrict__ frames,
+                                                          const int64_t* __restrict__ frame_off,
+                                                          uint8_t* __restrict__ f_status,
+                                                          gpx_wire_counts* counts) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  const bool live = i < nf && f_status[i] == GPX_W_OK;
+  const int32_t cls = live ? (int32_t)W.cls[i] : -1;
+  const int32_t cnt = live ? W.cnt[i] : 0;
+  int32_t off = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    int32_t tot;
+    const int32_t ex = block_exscan(cls == c ? cnt : 0, &tot);
+    if (cls == c) off = W.tile[(int64_t)c * W.ntiles + blockIdx.x] + ex;
+  }
+  bool over = false;
+  if (live) {
+    const int32_t cap = cls == 0 ? O.V.cap : cls == 1 ? O.C.cap : cls == 2 ? O.A.cap : O.R.cap;
+    over = (int64_t)off + cnt > cap;
+    if (over) f_status[i] = GPX_W_CAPACITY;
+  }
+  int32_t tot;
+  block_exscan(over ? 1 : 0, &tot);
+  if (threadIdx.x == 0 && tot) atomicAdd(&counts->n_bad_frames, tot);
+  if (!live || over) return;
+  const uint8_t* p = frames + frame_off[i];
+  WFrame f;
+  w_parse(S, N, p, frame_off[i + 1] - frame_off[i], f); /* same answer as pass 1 */
+  const int32_t g = f.gidx;
+  const int64_t hdr = f.hdr;
+  if (cls == 0) {
+    /* BatchedAcceptReply: acceptor, ballot, (slotNumber), maxCheckpointedSlot once; slots
+     * (PISM.handleBatchedAcceptReply iterates getAcceptedSlots(): TreeMap key order) */
+    const int32_t acceptor = w_be32(p + hdr), bnum = w_be32(p + hdr + 4);
+    const int32_t bcoord = w_be32(p + hdr + 8), maxcp = w_be32(p + hdr + 16);
+    const uint8_t* e = p + hdr + 33;
+    int64_t last = -((int64_t)1 << 40);
+    for (int32_t r = 0; r < cnt; r++) {
+      const int32_t s = f.ascending ? w_be32(e + (int64_t)r * 12) : w_next_slot(e, f.raw_n, 12, last);
+      last = s;
+      const int32_t o = off + r;
+      O.V.gidx[o] = g;
+      O.V.bnum[o] = bnum;
+      O.V.bcoord[o] = bcoord;
+      O.V.slot[o] = s;
+      O.V.acceptor[o] = acceptor;
+      O.V.max_cp[o] = maxcp;
+      if (O.V.frame) O.V.frame[o] = i;
+    }
+  } else if (cls == 1) {
+    const int32_t bnum = w_be32(p + hdr), bcoord = w_be32(p + hdr + 4);
+    const int32_t median = w_be32(p + hdr + 8);
+    const uint8_t* e = p + hdr + 16;
+    int64_t last = -((int64_t)1 << 40);
+    for (int32_t r = 0; r < cnt; r++) {
+      const int32_t s = f.ascending ? w_be32(e + (int64_t)r * 4) : w_next_slot(e, f.raw_n, 4, last);
+      last = s;
+      const int32_t o = off + r;
+      O.C.gidx[o] = g;
+      O.C.bnum[o] = bnum;
+      O.C.bcoord[o] = bcoord;
+      O.C.slot[o] = s;
+      O.C.median_cp[o] = median;
+      O.C.kind[o] = 0; /* meta-commit: PISM.handleBatchedCommit finds the value in the stored ACCEPT */
+      if (O.C.frame) O.C.frame[o] = i;
+    }
+  } else if (cls == 2) {
+    const uint8_t* t = p + f.tail;
+    O.A.gidx[off] = g;
+    O.A.slot[off] = w_be32(t);
+    O.A.bnum[off] = w_be32(t + 4);
+    O.A.bcoord[off] = w_be32(t + 8);
+    O.A.median_cp[off] = w_be32(t + 13);
+    O.A.sender[off] = w_be32(t + 18);
+    O.A.flags[off] = f.stop ? GPX_A_STOP : 0;
+    O.A.req_id[off] = f.req_id;
+    if (O.A.frame) O.A.frame[off] = i;
+  } else {
+    O.R.gidx[off] = g;
+    O.R.is_stop[off] = f.stop ? 1 : 0;
+    O.R.req_id[off] = f.req_id;
+    if (O.R.frame) O.R.frame[off] = i;
+  }
+}
+
+/* ------------------------------------------------------------------------- */
+/* encode: decisions -> BATCHED_COMMIT frames                                    */
+
+struct PackIn {
+  int32_t n;
+  const int32_t* n_dev; /* nullable: the row count still lives in device memory */
+  const int32_t *gidx, *slot, *bnum, *bcoord, *median;
+  const uint8_t* kind;
+};
+struct PackScratch {
+  int32_t* err;      /* [1] set when one group's block of rows exceeds GPX_W_MAX_SEG */
+  int32_t* size;     /* [rows] padded frame size of a head row, else 0 */
+  long long* tile_b; /* [ntiles] bytes per tile, then exclusive bases */
+  int32_t* tile_f;   /* [ntiles] frames per tile, then exclusive bases */
+  int32_t ntiles;
+};
+
+__device__ __forceinline__ int32_t pack_rows(const PackIn& P) {
+  int32_t n = P.n;
+  if (P.n_dev) {
+    const int32_t m = *P.n_dev;
+    n = m < n ? (m < 0 ? 0 : m) : n;
+  }
+  return n;
+}
+__device__ __forceinline__ bool pack_same(const PackIn& P, int32_t i, int32_t j) {
+  return P.kind[j] == GPX_D_DECISION && P.bnum[j] == P.bnum[i] && P.bcoord[j] == P.bcoord[i];
+}
+/* Row i opens a frame iff it is the first DECISION of its (group, ballot) inside the group's block
+ * of rows (PaxosPacketBatcher.enqueueImpl(BatchedCommit): one entry per paxosID and ballot,
+ * PaxosPacketBatcher.java:139-156). */
+__device__ __forceinline__ bool pack_is_head(const PackIn& P, const PackScratch& X, int32_t n,
+                                             int32_t i) {
+  const int32_t g = P.gidx[i];
+  bool head = P.kind[i] == GPX_D_DECISION; /* allCoalescableDecisions (:451-457) */
+  int32_t j = i - 1;
+  for (; j >= 0 && i - j < GPX_W_MAX_SEG && P.gidx[j] == g; j--)
+    if (pack_same(P, i, j)) head = false;
+  /* contract: the engine emits at most `window` rows per group and call; a longer block is
+   * refused (bounded work per lane whatever the caller passes) */
+  if (j >= 0 && i - j >= GPX_W_MAX_SEG && P.gidx[j] == g) *X.err = 1;
+  return head;
+}
+
+/* big-endian byte stream into 4-byte aligned memory through a one-word accumulator */
+struct BEWriter {
+  uint32_t* w;
+  uint32_t acc;
+  int32_t k;
+  __device__ __forceinline__ void init(uint8_t* p) {
+    w = (uint32_t*)p;
+    acc = 0;
+    k = 0;
+  }
+  __device__ __forceinline__ void put8(uint32_t b) {
+    acc |= (b & 0xffu) << (8 * k);
+    if (++k == 4) {
+      *w++ = acc;
+      acc = 0;
+      k = 0;
+    }
+  }
+  __device__ __forceinline__ void put32(int32_t v) { /* ByteBuffer.putInt */
+    const uint32_t u = (uint32_t)v;
+    put8(u >> 24);
+    put8(u >> 16);
+    put8(u >> 8);
+    put8(u);
+  }
+  __device__ __forceinline__ void flush() {
+    if (k) *w = acc;
+  }
+};
+
+/* pass 1: frame sizes of the head rows */
+__global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N, PackIn P,
+                                                        PackScratch X) {
+  const int32_t n = pack_rows(P);
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  int32_t size = 0;
+  if (i < n && pack_is_head(P, X, n, i)) {
+    const int32_t g = P.gidx[i];
+    if ((uint32_t)g < (uint32_t)S.G && (S.g_flags[g] & GF_EXISTS) && N.tab && N.len[g] != 0) {
+      /* TreeSet of the slots of this (group, ballot) */
+      int32_t m = 0;
+      for (int32_t j = i; j < n && j - i < GPX_W_MAX_SEG && P.gidx[j] == g; j++) {
+        if (!pack_same(P, i, j)) continue;
+        bool seen = false;
+        for (int32_t q = i; q < j && !seen; q++) seen = pack_same(P, i, q) && P.slot[q] == P.slot[j];
+        m += !seen;
+      }
+      const uint32_t gf = S.g_flags[g];
+      const int32_t k = (int32_t)GF_K(gf);
+      int32_t gs = 0;
+      for (int32_t q = 0; q < k; q++) gs += S.members[(int64_t)q * S.G + g] != S.my_id;
+      /* SIZEOF_PAXOSPACKET_FIXED + idLen + SIZEOF_BATCHEDCOMMIT_FIXED + 4 (n + 1 + g + 1)
+       * (BatchedCommit.java:197-203), rounded up so that every frame starts 4-byte aligned */
+      size = (13 + (int32_t)N.len[g] + 12 + 4 * (m + 1 + gs + 1) + 3) & ~3;
+    }
+  }
+  if (i < n) X.size[i] = size;
+  int32_t tb, tf;
+  block_exscan(size, &tb);
+  block_exscan(size ? 1 : 0, &tf);
+  if (threadIdx.x == 0) {
+    X.tile_b[blockIdx.x] = tb;
+    X.tile_f[blockIdx.x] = tf;
+  }
+}
+
+/* pass 2 (one workgroup): exclusive scan of the tile totals; totals to the caller */
+__global__ __launch_bounds__(GPX_FBLOCK) void k_pack_offsets(PackIn P, PackScratch X,
+                                                            int32_t* n_frames, long long* n_bytes) {
+  const int32_t n = pack_rows(P);
+  const int32_t nt = (n + GPX_BLOCK - 1) / GPX_BLOCK;
+  __shared__ long long run_b;
+  __shared__ int32_t run_f;
+  if (threadIdx.x == 0) {
+    run_b = 0;
+    run_f = 0;
+  }
+  __syncthreads();
+  for (int32_t t0 = 0; t0 < nt; t0 += GPX_FBLOCK) {
+    const int32_t t = t0 + (int32_t)threadIdx.x;
+    const int32_t vb = t < nt ? (int32_t)X.tile_b[t] : 0; /* one tile: < 256 * 1 KiB */
+    const int32_t vf = t < nt ? X.tile_f[t] : 0;
+    int32_t tb, tf;
+    const int32_t eb = block_exscan_n<GPX_FBLOCK>(vb, &tb);
+    const int32_t ef = block_exscan_n<GPX_FBLOCK>(vf, &tf);
+    if (t < nt) {
+      X.tile_b[t] = run_b + eb;
+      X.tile_f[t] = run_f + ef;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      run_b += tb;
+      run_f += tf;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    *n_frames = *X.err ? -1 : run_f;
+    *n_bytes = run_b;
+  }
+}
+
+/* pass 3: BatchedCommit.toBytes (BatchedCommit.java:184-215) of every head row */
+__global__ __launch_bounds__(GPX_BLOCK) void k_pack_write(DevState S, DevNames N, PackIn P,
+                                                         PackScratch X, uint8_t* __restrict__ out,
+                                                         long long cap_bytes,
+                                                         long long* __restrict__ frame_off,
+                                                         int32_t* __restrict__ frame_len,
+                                                         int32_t* __restrict__ f_gidx) {
+  const int32_t n = pack_rows(P);
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  const int32_t size = i < n ? X.size[i] : 0;
+  int32_t tb, tf;
+  const int32_t eb = block_exscan(size, &tb);
+  const int32_t ef = block_exscan(size ? 1 : 0, &tf);
+  if (!size) return;
+  const long long off = X.tile_b[blockIdx.x] + eb;
+  const int32_t fi = X.tile_f[blockIdx.x] + ef;
+  if (off + size > cap_bytes) return; /* the host sees n_bytes > cap_bytes */
+  const int32_t g = P.gidx[i];
+  const int32_t idl = (int32_t)N.len[g];
+  BEWriter w;
+  w.init(out + off);
+  w.put32(GPX_WT_PAXOS_PACKET);       /* PaxosPacket.toBytes (PaxosPacket.java:461-476) */
+  w.put32(GPX_WT_BATCHED_COMMIT);
+  w.put32(S.g_version[g]);
+  w.put8((uint32_t)idl);
+  const uint8_t* nm = N.bytes + (int64_t)g * NM_STRIDE;
+  for (int32_t b = 0; b < idl; b++) w.put8(nm[b]);
+  w.put32(P.bnum[i]);
+  w.put32(P.bcoord[i]);
+  /* medianCheckpointedSlot: addCommit keeps the later one when `b - cur > 0` (:104-112) */
+  int32_t med = P.median[i];
+  int32_t m = 0;
+  int32_t jend = i;
+  for (int32_t j = i; j < n && j - i < GPX_W_MAX_SEG && P.gidx[j] == g; j++) {
+    jend = j + 1;
+    if (!pack_same(P, i, j)) continue;
+    if (j > i && jsub(P.median[j], med) > 0) med = P.median[j];
+    bool seen = false;
+    for (int32_t q = i; q < j && !seen; q++) seen = pack_same(P, i, q) && P.slot[q] == P.slot[j];
+    m += !seen;
+  }
+  w.put32(med);
+  w.put32(m);
+  long long last = -(1ll << 40);
+  for (int32_t r = 0; r < m; r++) { /* TreeSet iteration: ascending */
+    long long best = 1ll << 40;
+    for (int32_t j = i; j < jend; j++)
+      if (pack_same(P, i, j) && (long long)P.slot[j] > last && (long long)P.slot[j] < best)
+        best = P.slot[j];
+    w.put32((int32_t)best);
+    last = best;
+  }
+  /* group = Util.arrayToIntSet(Util.filter(recipients, myID)) (PaxosPacketBatcher.java:391-395):
+   * members are kept ascending, so this is TreeSet order */
+  const int32_t k = (int32_t)GF_K(S.g_flags[g]);
+  int32_t gs = 0;
+  for (int32_t q = 0; q < k; q++) gs += S.members[(int64_t)q * S.G + g] != S.my_id;
+  w.put32(gs);
+  for (int32_t q = 0; q < k; q++) {
+    const int32_t mem = S.members[(int64_t)q * S.G + g];
+    if (mem != S.my_id) w.put32(mem);
+  }
+  w.flush();
+  frame_off[fi] = off;
+  frame_len[fi] = 13 + idl + 12 + 4 * (m + 1 + gs + 1);
+  f_gidx[fi] = g;
+}

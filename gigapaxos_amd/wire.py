@@ -1,0 +1,283 @@
+"""Host side of the wire codec (include/gpx_wire.h): ctypes binding of the names / decode /
+pack entry points and byte-level builders of the four byteified packet types.
+
+The builders restate the reference's ``toBytes()`` methods (big-endian java.nio.ByteBuffer
+layouts) so that tests, the loopback cluster and bench.py can produce the frames a gigapaxos
+node would put on the wire:
+
+* PaxosPacket header            paxospackets/PaxosPacket.java:461-476
+* RequestPacket.toBytes         paxospackets/RequestPacket.java:819-948
+* AcceptPacket.toBytes          paxospackets/AcceptPacket.java:95-135
+* BatchedAcceptReply.toBytes    paxospackets/BatchedAcceptReply.java:119-173
+* BatchedCommit.toBytes         paxospackets/BatchedCommit.java:184-215
+
+The compute path (frames -> SoA, SoA -> frames) is the HIP library; nothing here parses a frame.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+from ._abi import Engine, GpxLib, _p, _i32
+
+WT_PAXOS_PACKET, WT_REQUEST, WT_ACCEPT, WT_BATCHED_ACCEPT_REPLY, WT_BATCHED_COMMIT = 90, 1, 3, 34, 35
+W_OK, W_NOGROUP, W_VERSION, W_MALFORMED, W_UNSUPPORTED, W_CAPACITY = range(6)
+W_MAX_UNSORTED = 1024
+
+_VP = C.c_void_p
+
+
+class WireVotes(C.Structure):
+    _fields_ = [("cap", C.c_int32)] + [(n, _VP) for n in
+                                       ("gidx", "bnum", "bcoord", "slot", "acceptor", "max_cp", "frame")]
+
+
+class WireCommits(C.Structure):
+    _fields_ = [("cap", C.c_int32)] + [(n, _VP) for n in
+                                       ("gidx", "bnum", "bcoord", "slot", "median_cp", "kind", "frame")]
+
+
+class WireAccepts(C.Structure):
+    _fields_ = [("cap", C.c_int32)] + [(n, _VP) for n in
+                                       ("gidx", "bnum", "bcoord", "slot", "median_cp", "flags", "sender",
+                                        "req_id", "frame")]
+
+
+class WireRequests(C.Structure):
+    _fields_ = [("cap", C.c_int32)] + [(n, _VP) for n in ("gidx", "is_stop", "req_id", "frame")]
+
+
+class WireCounts(C.Structure):
+    _fields_ = [("n_votes", C.c_int32), ("n_commits", C.c_int32), ("n_accepts", C.c_int32),
+                ("n_requests", C.c_int32), ("n_bad_frames", C.c_int32), ("reserved", C.c_int32 * 3)]
+
+
+_WIRE_SIGS = {
+    "names_bind": [C.c_int32, _VP, _VP, _VP, _VP],
+    "names_unbind": [C.c_int32, _VP, _VP],
+    "names_lookup": [C.c_int32, _VP, _VP, _VP],
+    "rows_alloc": [C.c_int32, _VP],
+    "rows_free": [C.c_int32, _VP],
+    "wire_decode": [C.c_int32, _VP, _VP, _VP, _VP, _VP, C.POINTER(WireVotes), C.POINTER(WireCommits),
+                    C.POINTER(WireAccepts), C.POINTER(WireRequests), _VP],
+    "wire_pack_commits": [C.c_int32] + [_VP] * 7 + [C.c_int64] + [_VP] * 5,
+}
+_WIRE_DEV_SIGS = {
+    "wire_decode_dev": _WIRE_SIGS["wire_decode"],
+    "wire_pack_commits_dev": [C.c_int32, _VP] + [_VP] * 7 + [C.c_int64] + [_VP] * 5,
+}
+WIRE_EXPORTED_SYMBOLS = list(_WIRE_SIGS) + list(_WIRE_DEV_SIGS)
+
+
+def bind_wire(lib: GpxLib):
+    """Adds the gpx_wire.h entry points to a loaded library (idempotent)."""
+    if "wire_decode" in lib.fn:
+        return lib
+    sigs = dict(_WIRE_SIGS)
+    if lib.device_api:
+        sigs.update(_WIRE_DEV_SIGS)
+    for name, args in sigs.items():
+        f = getattr(lib.lib, lib.prefix + name)
+        f.argtypes = [_VP] + args
+        f.restype = C.c_int
+        lib.fn[name] = f
+    return lib
+
+
+# ---- frame builders (what a reference node sends) ----------------------------------------
+
+
+def _hdr(ptype: int, version: int, paxos_id: bytes) -> bytes:
+    assert len(paxos_id) <= 127
+    return struct.pack(">iiib", WT_PAXOS_PACKET, ptype, version, len(paxos_id)) + paxos_id
+
+
+def batched_accept_reply(paxos_id: bytes, version: int, acceptor: int, bnum: int, bcoord: int,
+                         max_cp: int, slots, req_ids=None, first_slot=None) -> bytes:
+    """BatchedAcceptReply.toBytes: header + AcceptReplyPacket fields (29 B) + n + n x (slot, reqID)."""
+    slots = list(slots)
+    req_ids = [0] * len(slots) if req_ids is None else list(req_ids)
+    first = slots[0] if (first_slot is None and slots) else (first_slot or 0)
+    out = _hdr(WT_BATCHED_ACCEPT_REPLY, version, paxos_id)
+    out += struct.pack(">iiiiiqb", acceptor, bnum, bcoord, first, max_cp, req_ids[0] if req_ids else 0, 0)
+    out += struct.pack(">i", len(slots))
+    for s, q in zip(slots, req_ids):
+        out += struct.pack(">iq", s, q)
+    return out
+
+
+def batched_commit(paxos_id: bytes, version: int, bnum: int, bcoord: int, median_cp: int, slots,
+                   group) -> bytes:
+    """BatchedCommit.toBytes: header + ballot + medianCheckpointedSlot + n + slots + g + members."""
+    slots, group = list(slots), list(group)
+    out = _hdr(WT_BATCHED_COMMIT, version, paxos_id)
+    out += struct.pack(">iiii", bnum, bcoord, median_cp, len(slots))
+    out += b"".join(struct.pack(">i", s) for s in slots)
+    out += struct.pack(">i", len(group)) + b"".join(struct.pack(">i", m) for m in group)
+    return out
+
+
+def request(paxos_id: bytes, version: int, req_id: int, value: bytes = b"", stop: bool = False,
+            batched=(), ptype: int = WT_REQUEST, entry_replica: int = -1, digest: bytes = b"",
+            response: bytes = b"") -> bytes:
+    """RequestPacket.toBytes(): header, requestID, stop, addresses, entry info, digest, value,
+    response, batched sub-requests (each a complete RequestPacket byte array)."""
+    out = _hdr(ptype, version, paxos_id)
+    out += struct.pack(">qb", req_id, 1 if stop else 0)
+    out += b"\x00" * 4 + struct.pack(">h", 0) + b"\x00" * 4 + struct.pack(">h", 0)
+    out += struct.pack(">iqbi", entry_replica, 0, 0, 0)
+    out += struct.pack(">b", 0)  # broadcasted
+    out += struct.pack(">i", len(digest)) + digest
+    out += struct.pack(">i", len(value)) + value
+    out += struct.pack(">i", len(response)) + response
+    out += struct.pack(">i", len(batched))
+    for el in batched:
+        out += struct.pack(">i", len(el)) + el
+    return out
+
+
+def accept(paxos_id: bytes, version: int, req_id: int, slot: int, bnum: int, bcoord: int,
+           median_cp: int, sender: int, value: bytes = b"", stop: bool = False, batched=(),
+           recovery: bool = False) -> bytes:
+    """AcceptPacket.toBytes: the request part (packet type ACCEPT) + slot + ballot + recovery +
+    medianCheckpointedSlot + noCoalesce + sender."""
+    out = request(paxos_id, version, req_id, value, stop, batched, ptype=WT_ACCEPT)
+    out += struct.pack(">iiibibi", slot, bnum, bcoord, 1 if recovery else 0, median_cp, 0, sender)
+    return out
+
+
+def concat_frames(frames):
+    """One byte buffer + int64 offsets (n + 1), the form gpx_wire_decode takes."""
+    off = np.zeros(len(frames) + 1, np.int64)
+    np.cumsum([len(f) for f in frames], out=off[1:])
+    buf = np.frombuffer(b"".join(frames), dtype=np.uint8).copy() if frames else np.zeros(0, np.uint8)
+    return buf, off
+
+
+def concat_names(names):
+    off = np.zeros(len(names) + 1, np.int32)
+    np.cumsum([len(x) for x in names], out=off[1:])
+    buf = np.frombuffer(b"".join(names), dtype=np.uint8).copy() if names else np.zeros(0, np.uint8)
+    return buf, off
+
+
+def java_string_hash(b: bytes) -> int:
+    """java.lang.String.hashCode of the ISO-8859-1 string with these bytes."""
+    h = 0
+    for c in b:
+        h = (31 * h + c) & 0xFFFFFFFF
+    return h - (1 << 32) if h >= (1 << 31) else h
+
+
+# ---- engine-level API ---------------------------------------------------------------------
+
+
+@dataclass
+class Decoded:
+    f_status: np.ndarray
+    f_gidx: np.ndarray
+    f_type: np.ndarray
+    votes: dict
+    commits: dict
+    accepts: dict
+    requests: dict
+    counts: dict
+
+
+class WireEngine:
+    """The wire entry points over one Engine handle."""
+
+    def __init__(self, engine: Engine):
+        self.e = engine
+        self.lib = bind_wire(engine.lib)
+
+    # names --------------------------------------------------------------------------------
+    def bind(self, names, gidx) -> np.ndarray:
+        buf, off = concat_names(names)
+        gidx = _i32(gidx, len(names))
+        status = np.zeros(len(names), np.uint8)
+        self.lib.check(self.lib.fn["names_bind"](self.e.h, len(names), _p(buf), _p(off), _p(gidx),
+                                                 _p(status)), "names_bind")
+        return status
+
+    def unbind(self, gidx) -> np.ndarray:
+        gidx = _i32(gidx)
+        status = np.zeros(gidx.shape[0], np.uint8)
+        self.lib.check(self.lib.fn["names_unbind"](self.e.h, gidx.shape[0], _p(gidx), _p(status)),
+                       "names_unbind")
+        return status
+
+    def lookup(self, names) -> np.ndarray:
+        buf, off = concat_names(names)
+        out = np.zeros(len(names), np.int32)
+        self.lib.check(self.lib.fn["names_lookup"](self.e.h, len(names), _p(buf), _p(off), _p(out)),
+                       "names_lookup")
+        return out
+
+    def rows_alloc(self, n: int) -> np.ndarray:
+        out = np.zeros(n, np.int32)
+        self.lib.check(self.lib.fn["rows_alloc"](self.e.h, n, _p(out)), "rows_alloc")
+        return out
+
+    def rows_free(self, gidx):
+        gidx = _i32(gidx)
+        self.lib.check(self.lib.fn["rows_free"](self.e.h, gidx.shape[0], _p(gidx)), "rows_free")
+
+    # decode -------------------------------------------------------------------------------
+    def decode(self, frames, cap_votes=None, cap_commits=None, cap_accepts=None, cap_requests=None,
+               buf_off=None) -> Decoded:
+        """frames: list of bytes (or pass buf_off=(uint8 buffer, int64 offsets))."""
+        buf, off = concat_frames(frames) if buf_off is None else buf_off
+        nf = off.shape[0] - 1
+        total = int(off[-1])
+        # a frame of L bytes holds at most L / 4 slot entries: safe default capacities
+        dv = total // 12 + 1 if cap_votes is None else cap_votes
+        dc = total // 4 + 1 if cap_commits is None else cap_commits
+        da = nf if cap_accepts is None else cap_accepts
+        dr = nf if cap_requests is None else cap_requests
+        i32 = lambda n: np.zeros(max(n, 1), np.int32)  # noqa: E731
+        u8 = lambda n: np.zeros(max(n, 1), np.uint8)  # noqa: E731
+        i64 = lambda n: np.zeros(max(n, 1), np.int64)  # noqa: E731
+        vcols = {k: i32(dv) for k in ("gidx", "bnum", "bcoord", "slot", "acceptor", "max_cp", "frame")}
+        ccols = {k: i32(dc) for k in ("gidx", "bnum", "bcoord", "slot", "median_cp", "frame")}
+        ccols["kind"] = u8(dc)
+        acols = {k: i32(da) for k in ("gidx", "bnum", "bcoord", "slot", "median_cp", "sender", "frame")}
+        acols["flags"], acols["req_id"] = u8(da), i64(da)
+        rcols = {"gidx": i32(dr), "is_stop": u8(dr), "req_id": i64(dr), "frame": i32(dr)}
+        V = WireVotes(dv, *[_p(vcols[k]) for k in ("gidx", "bnum", "bcoord", "slot", "acceptor", "max_cp", "frame")])
+        Cc = WireCommits(dc, *[_p(ccols[k]) for k in ("gidx", "bnum", "bcoord", "slot", "median_cp", "kind", "frame")])
+        A = WireAccepts(da, *[_p(acols[k]) for k in ("gidx", "bnum", "bcoord", "slot", "median_cp", "flags",
+                                                     "sender", "req_id", "frame")])
+        R = WireRequests(dr, *[_p(rcols[k]) for k in ("gidx", "is_stop", "req_id", "frame")])
+        f_status, f_gidx, f_type = u8(nf), i32(nf), i32(nf)
+        cn = WireCounts()
+        self.lib.check(self.lib.fn["wire_decode"](self.e.h, nf, _p(buf), _p(off), _p(f_status), _p(f_gidx),
+                                                  _p(f_type), C.byref(V), C.byref(Cc), C.byref(A),
+                                                  C.byref(R), C.addressof(cn)), "wire_decode")
+        counts = {k: int(getattr(cn, k)) for k in ("n_votes", "n_commits", "n_accepts", "n_requests",
+                                                   "n_bad_frames")}
+        cut = lambda cols, n, cap: {k: v[:min(n, cap)].copy() for k, v in cols.items()}  # noqa: E731
+        return Decoded(f_status[:nf], f_gidx[:nf], f_type[:nf],
+                       cut(vcols, counts["n_votes"], dv), cut(ccols, counts["n_commits"], dc),
+                       cut(acols, counts["n_accepts"], da), cut(rcols, counts["n_requests"], dr), counts)
+
+    # encode -------------------------------------------------------------------------------
+    def pack_commits(self, decisions, cap_bytes=None):
+        """decisions: a gigapaxos_amd.Decisions (group-major, as accept_reply returns them).
+        Returns (list of frame bytes, f_gidx array)."""
+        n = int(decisions.gidx.shape[0])
+        cap = (256 + 8 * 4) * max(n, 1) if cap_bytes is None else cap_bytes
+        out = np.zeros(cap, np.uint8)
+        foff, flen, fg = np.zeros(max(n, 1), np.int64), np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+        nf, nb = np.zeros(1, np.int32), np.zeros(1, np.int64)
+        cols = [_i32(getattr(decisions, k), n) for k in ("gidx", "slot", "bnum", "bcoord", "median_cp")]
+        kind = np.ascontiguousarray(decisions.kind, dtype=np.uint8)
+        self.lib.check(self.lib.fn["wire_pack_commits"](self.e.h, n, *[_p(c) for c in cols], _p(kind), _p(out),
+                                                        cap, _p(foff), _p(flen), _p(fg), _p(nf), _p(nb)),
+                       "wire_pack_commits")
+        m = int(nf[0])
+        frames = [out[int(foff[i]):int(foff[i]) + int(flen[i])].tobytes() for i in range(m)]
+        return frames, fg[:m].copy(), int(nb[0])

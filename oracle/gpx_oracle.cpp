@@ -37,9 +37,12 @@
 #include <initializer_list>
 #include <map>
 #include <memory>
+#include <set>
+#include <string>
 #include <vector>
 
 #include "../include/gpx.h"
+#include "../include/gpx_wire.h"
 
 namespace {
 
@@ -283,6 +286,11 @@ struct Engine {
   gpx_config cfg;
   std::vector<std::unique_ptr<Group>> groups;
   uint64_t counters[3] = {0, 0, 0};
+  /* PaxosManager.pinstances (paxosID -> instance), PaxosManager.java:1816-1832; wire oracle only */
+  std::map<std::string, int32_t> name2row;
+  std::vector<std::string> row2name;
+  std::vector<int32_t> free_rows;
+  bool free_init = false;
 
   Group* get(int32_t g) {
     if (g < 0 || g >= cfg.max_groups) return nullptr;
@@ -779,3 +787,6 @@ int32_t orc_round_robin_coordinator(const char* paxos_id, const int32_t* members
 }
 
 } /* extern "C" */
+
+/* wire codec oracle (same translation unit: it reads the Engine's groups) */
+#include "gpx_wire_oracle.inc"

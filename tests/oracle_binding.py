@@ -14,10 +14,10 @@ _lib = None
 
 
 def build_oracle():
-    src = os.path.join(ORACLE_DIR, "gpx_oracle.cpp")
-    hdr = os.path.join(ROOT, "include", "gpx.h")
+    deps = [os.path.join(ORACLE_DIR, "gpx_oracle.cpp"), os.path.join(ORACLE_DIR, "gpx_wire_oracle.inc"),
+            os.path.join(ROOT, "include", "gpx.h"), os.path.join(ROOT, "include", "gpx_wire.h")]
     if (not os.path.exists(ORACLE_SO)
-            or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(src), os.path.getmtime(hdr))):
+            or os.path.getmtime(ORACLE_SO) < max(os.path.getmtime(d) for d in deps)):
         subprocess.check_call(["make", "-C", ORACLE_DIR, "-s"])
     return ORACLE_SO
 

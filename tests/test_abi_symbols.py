@@ -7,16 +7,20 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def _declared():
-    src = open(os.path.join(ROOT, "include", "gpx.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    return sorted(set(re.findall(r"\b(gpx_[a-z_]+)\s*\(", src)))
+    names = set()
+    for hdr in ("gpx.h", "gpx_wire.h"):
+        src = open(os.path.join(ROOT, "include", hdr)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(gpx_[a-z_]+)\s*\(", src))
+    return sorted(names)
 
 
 def test_header_declares_expected_entry_points():
     names = _declared()
     for must in ("gpx_engine_create", "gpx_group_create", "gpx_group_retire", "gpx_propose_batch",
                  "gpx_accept_batch", "gpx_accept_reply_batch", "gpx_commit_batch",
-                 "gpx_accept_reply_batch_dev"):
+                 "gpx_accept_reply_batch_dev", "gpx_names_bind", "gpx_wire_decode",
+                 "gpx_wire_decode_dev", "gpx_wire_pack_commits", "gpx_wire_pack_commits_dev"):
         assert must in names
 
 
@@ -28,7 +32,7 @@ def test_hip_library_exports_every_declared_symbol():
     ge.build()
     lib = ctypes.CDLL(ge.HIP_SO)
     for name in _declared():
-        assert hasattr(lib, name), f"{name} declared in include/gpx.h but not exported"
+        assert hasattr(lib, name), f"{name} declared in include/*.h but not exported"
     lib.gpx_abi_version.restype = ctypes.c_int
     assert lib.gpx_abi_version() == 1
 
