@@ -89,6 +89,8 @@ struct gpx_engine {
   int32_t *w_cnt = nullptr, *w_tile = nullptr, *w_err = nullptr;
   int8_t* w_cls = nullptr;
   long long* w_tile_b = nullptr;
+  uint8_t* w_stage = nullptr;      /* staging of BATCHED_ACCEPT_REPLY frames, 188 B per reply */
+  long long* w_bucket_bytes = nullptr;
 };
 
 namespace {
@@ -104,7 +106,10 @@ int dev_alloc(gpx_engine* e, T** p, size_t count, bool zero) {
   }
   e->allocs.push_back(q);
   if (zero) {
+    /* null-stream memset + wait: the engine's streams are non-blocking, so nothing else orders the
+     * fill before the first kernel that uses the buffer (lazily allocated tables) */
     err = hipMemset(q, 0, bytes);
+    if (err == hipSuccess) err = hipStreamSynchronize(nullptr);
     if (err != hipSuccess) {
       snprintf(g_err, sizeof(g_err), "hipMemset -> %s", hipGetErrorString(err));
       return GPX_EDEVICE;
@@ -395,7 +400,8 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     const void* fns[] = {(const void*)k_bucket_ar<4>,      (const void*)k_bucket_ar<8>,
                          (const void*)k_bucket_ar<16>,     (const void*)k_bucket_propose<4>,
                          (const void*)k_bucket_propose<8>, (const void*)k_bucket_propose<16>,
-                         (const void*)k_bucket_accept,     (const void*)k_bucket_commit};
+                         (const void*)k_bucket_accept,     (const void*)k_bucket_commit,
+                         (const void*)k_bucket_pack_ar};
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bucket_lds));
   }

@@ -310,8 +310,9 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
       }
     }
   }
-  if (bad) atomicAdd(&X.counters[2], (unsigned long long)bad);
-  if (tile == 0 && threadIdx.x == 0 && is_votes) atomicAdd(&X.counters[0], (unsigned long long)n);
+  /* is_votes < 0: a regrouping pass over records an earlier call already counted */
+  if (bad && is_votes >= 0) atomicAdd(&X.counters[2], (unsigned long long)bad);
+  if (tile == 0 && threadIdx.x == 0 && is_votes > 0) atomicAdd(&X.counters[0], (unsigned long long)n);
   __syncthreads();
   /* reserve this tile's slice of every bucket region: one returning atomic per touched bucket.
    * The order of the slices inside a region is whatever the atomics give (records carry their

@@ -761,3 +761,229 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_write(DevState S, DevNames N
   frame_len[fi] = 13 + idl + 12 + 4 * (m + 1 + gs + 1);
   f_gidx[fi] = g;
 }
+
+/* ------------------------------------------------------------------------- */
+/* encode: accept replies -> BATCHED_ACCEPT_REPLY frames                         */
+/* replaces PaxosPacketBatcher.enqueueImpl(AcceptReplyPacket) / dequeueImplAR
+ * (PaxosPacketBatcher.java:121-137, 211-224) + BatchedAcceptReply.toBytes
+ * (BatchedAcceptReply.java:119-173) for the replies of one gpx_accept_batch call.
+ *
+ * The replies are regrouped by group with the engine's own front end (k_hist + k_scatter_ac carry
+ * {slot, maxCP, reply ballot} per record); one workgroup per bucket then stages the bucket in LDS
+ * (bucket_prepare) and ONE LANE PER GROUP walks its replies in arrival order exactly like the
+ * batcher's HashMap<paxosID, HashMap<Ballot, BatchedAcceptReply>> would see them.  Frames are
+ * first written to a per-bucket staging area (a bucket's bytes are bounded by 188 per reply), then
+ * k_emit_frames compacts them, buckets in order, into the caller's buffer. */
+#define GPX_W_BAR_MAX_RECS 256  /* replies of one group coalesced per call; the rest leave unbatched */
+#define GPX_W_BAR_MAX_BALLOTS 4 /* distinct reply ballots of one group coalesced per call */
+#define GPX_W_BAR_REC_BYTES 188 /* >= 13 + 127 + 29 + 4 + 12, 4-byte aligned: staging per reply */
+
+struct PackArIn {
+  const int32_t* sender;  /* nullable: ACCEPT's sender; a reply whose ballot coordinator differs is
+                             not coalescable (allPositiveAcceptReplies, PaxosPacketBatcher.java:438-446) */
+  const long long* req_id; /* nullable */
+  const uint8_t* status;   /* the accept call's status column: GPX_S_OK = a reply exists */
+  uint8_t* unbatched;      /* nullable out: 1 = reply exists but was not packed */
+  uint8_t* stage;          /* [max_batch * GPX_W_BAR_REC_BYTES] */
+  long long* bucket_bytes; /* [nbk] */
+};
+
+__global__ __launch_bounds__(1024) void k_bucket_pack_ar(DevState S, DevScratch X, DevNames N,
+                                                         PackArIn P) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  BucketView bv;
+  const int32_t b = blockIdx.x;
+  if (!bucket_prepare(X, lds, &bv, []() {})) {
+    if (threadIdx.x == 0) P.bucket_bytes[b] = 0;
+    return;
+  }
+  const int32_t boff = X.bucket_off[b];
+  const int32_t g0 = b << X.shift;
+  const int32_t nt = (int32_t)blockDim.x;
+  /* pass 1: per group, the distinct reply ballots (first-appearance order), their slot counts,
+   * the group's bytes and frames.  Thread t owns groups t, t + nt, ... */
+  int32_t my_bytes = 0, my_frames = 0;
+  const int32_t per = X.gb / nt;
+  for (int32_t qq = 0; qq < per; qq++) {
+    const int32_t l = (int32_t)threadIdx.x * per + qq;
+    const int32_t c = bv.lcnt[l];
+    const int32_t g = g0 + l;
+    if (c == 0 || g >= S.G) continue;
+    unsigned long long* keys = bv.keys + bv.loff[l];
+    if (c <= GPX_SMALL_SEG) { /* arrival order in place (longer segments were sorted cooperatively) */
+      for (int32_t i = 1; i < c; i++) {
+        const unsigned long long x = keys[i];
+        int32_t p = i - 1;
+        while (p >= 0 && keys[p] > x) {
+          keys[p + 1] = keys[p];
+          p--;
+        }
+        keys[p + 1] = x;
+      }
+    }
+    const bool named = (S.g_flags[g] & GF_EXISTS) && N.tab && N.len[g] != 0;
+    const int32_t cc = c < GPX_W_BAR_MAX_RECS ? c : GPX_W_BAR_MAX_RECS;
+    int32_t nbal = 0, bn[GPX_W_BAR_MAX_BALLOTS], bc[GPX_W_BAR_MAX_BALLOTS];
+    for (int32_t t = 0; t < c; t++) {
+      const unsigned long long k = keys[t];
+      const int32_t ix = (int32_t)(k >> 32);
+      const int32_t* pay = bv.pay + (int64_t)(uint32_t)k * bv.rs;
+      const bool has_reply = P.status[ix] == GPX_S_OK;
+      const int32_t rbn = pay[3 * bv.fs], rbc = pay[4 * bv.fs];
+      bool ok = has_reply && named && t < cc && (!P.sender || P.sender[ix] == rbc);
+      int32_t q = -1;
+      if (ok) {
+        for (int32_t z = 0; z < nbal; z++)
+          if (bn[z] == rbn && bc[z] == rbc) q = z;
+        if (q < 0 && nbal < GPX_W_BAR_MAX_BALLOTS) {
+          q = nbal++;
+          bn[q] = rbn;
+          bc[q] = rbc;
+        }
+        ok = q >= 0;
+      }
+      /* remember the verdict in the record's third payload word (unused so far): ballot index
+       * or -1 */
+      const_cast<int32_t*>(pay)[2 * bv.fs] = ok ? q : -1;
+      if (P.unbatched) P.unbatched[ix] = (has_reply && !ok) ? 1 : 0;
+    }
+    for (int32_t q = 0; q < nbal; q++) {
+      int32_t m = 0; /* TreeMap size: distinct slots of this ballot */
+      for (int32_t t = 0; t < cc; t++) {
+        const int32_t* pt = bv.pay + (int64_t)(uint32_t)keys[t] * bv.rs;
+        if (pt[2 * bv.fs] != q) continue;
+        bool seen = false;
+        for (int32_t u = 0; u < t && !seen; u++) {
+          const int32_t* pu = bv.pay + (int64_t)(uint32_t)keys[u] * bv.rs;
+          seen = pu[2 * bv.fs] == q && pu[0] == pt[0];
+        }
+        m += !seen;
+      }
+      my_bytes += (13 + (int32_t)N.len[g] + 29 + 4 + 12 * m + 3) & ~3;
+      my_frames++;
+    }
+  }
+  __syncthreads();
+  int32_t tot_b, tot_f;
+  int32_t ex_b = block_exscan_rt(my_bytes, &tot_b);
+  int32_t ex_f = block_exscan_rt(my_frames, &tot_f);
+  if (threadIdx.x == 0) {
+    P.bucket_bytes[b] = tot_b;
+    X.bucket_nout[b] = tot_f;
+  }
+  /* pass 2: the frames, into the bucket's staging area; one table row per frame in o_rec */
+  uint8_t* stage = P.stage + (int64_t)boff * GPX_W_BAR_REC_BYTES;
+  Out* ftab = X.o_rec + boff;
+  for (int32_t qq = 0; qq < per; qq++) {
+    const int32_t l = (int32_t)threadIdx.x * per + qq;
+    const int32_t c = bv.lcnt[l];
+    const int32_t g = g0 + l;
+    if (c == 0 || g >= S.G) continue;
+    const unsigned long long* keys = bv.keys + bv.loff[l];
+    const int32_t cc = c < GPX_W_BAR_MAX_RECS ? c : GPX_W_BAR_MAX_RECS;
+    const int32_t idl = N.tab ? (int32_t)N.len[g] : 0;
+    for (int32_t q = 0; q < GPX_W_BAR_MAX_BALLOTS; q++) {
+      int32_t head = -1;
+      for (int32_t t = 0; t < cc && head < 0; t++)
+        if ((bv.pay + (int64_t)(uint32_t)keys[t] * bv.rs)[2 * bv.fs] == q) head = t;
+      if (head < 0) break; /* ballot indices are dense */
+      const unsigned long long kh = keys[head];
+      const int32_t* ph = bv.pay + (int64_t)(uint32_t)kh * bv.rs;
+      const int32_t ixh = (int32_t)(kh >> 32);
+      BEWriter w;
+      w.init(stage + ex_b);
+      w.put32(GPX_WT_PAXOS_PACKET);
+      w.put32(GPX_WT_BATCHED_ACCEPT_REPLY);
+      w.put32(S.g_version[g]);
+      w.put8((uint32_t)idl);
+      const uint8_t* nm = N.bytes + (int64_t)g * NM_STRIDE;
+      for (int32_t z = 0; z < idl; z++) w.put8(nm[z]);
+      /* new BatchedAcceptReply(first reply): acceptor, ballot, its slot, its maxCheckpointedSlot,
+       * its requestID, undigestRequest = false (BatchedAcceptReply.java:49-54,
+       * AcceptReplyPacket.toBytes :170-180) */
+      w.put32(S.my_id);
+      w.put32(ph[3 * bv.fs]);
+      w.put32(ph[4 * bv.fs]);
+      w.put32(ph[0]);
+      w.put32(ph[bv.fs]);
+      const long long rq0 = P.req_id ? P.req_id[ixh] : 0;
+      w.put32((int32_t)(rq0 >> 32));
+      w.put32((int32_t)rq0);
+      w.put8(0);
+      int32_t m = 0;
+      for (int32_t t = 0; t < cc; t++) {
+        const int32_t* pt = bv.pay + (int64_t)(uint32_t)keys[t] * bv.rs;
+        if (pt[2 * bv.fs] != q) continue;
+        bool seen = false;
+        for (int32_t u = 0; u < t && !seen; u++) {
+          const int32_t* pu = bv.pay + (int64_t)(uint32_t)keys[u] * bv.rs;
+          seen = pu[2 * bv.fs] == q && pu[0] == pt[0];
+        }
+        m += !seen;
+      }
+      w.put32(m);
+      long long last = -(1ll << 40);
+      for (int32_t r = 0; r < m; r++) { /* TreeMap iteration; put() keeps the LAST request id */
+        long long best = 1ll << 40;
+        int32_t who = -1;
+        for (int32_t t = 0; t < cc; t++) {
+          const int32_t* pt = bv.pay + (int64_t)(uint32_t)keys[t] * bv.rs;
+          if (pt[2 * bv.fs] != q) continue;
+          const long long s = pt[0];
+          if (s > last && s <= best) {
+            best = s;
+            who = t;
+          }
+        }
+        w.put32((int32_t)best);
+        const long long rq = P.req_id ? P.req_id[(int32_t)(keys[who] >> 32)] : 0;
+        w.put32((int32_t)(rq >> 32));
+        w.put32((int32_t)rq);
+        last = best;
+      }
+      w.flush();
+      const int32_t len = 13 + idl + 29 + 4 + 12 * m;
+      ftab[ex_f] = mk_out(g, len, ex_b, ph[4 * bv.fs], 0, 0); /* gidx, len, rel. offset, dest */
+      ex_b += (len + 3) & ~3;
+      ex_f++;
+    }
+  }
+}
+
+/* per bucket: copy its staged frames behind those of the buckets before it; frame table */
+__global__ __launch_bounds__(GPX_BLOCK) void k_emit_frames(DevScratch X, PackArIn P,
+                                                          uint8_t* __restrict__ out,
+                                                          long long cap_bytes,
+                                                          long long* __restrict__ frame_off,
+                                                          int32_t* __restrict__ frame_len,
+                                                          int32_t* __restrict__ f_gidx,
+                                                          int32_t* __restrict__ f_dest,
+                                                          int32_t* n_frames, long long* n_bytes) {
+  __shared__ long long red[GPX_BLOCK / 64];
+  const int32_t b = blockIdx.x;
+  const int32_t fbase = emit_base(X, n_frames, nullptr);
+  long long before = 0;
+  for (int32_t t = threadIdx.x; t < b; t += GPX_BLOCK) before += P.bucket_bytes[t];
+#pragma unroll
+  for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = before;
+  __syncthreads();
+  long long bbase = 0;
+  for (int w = 0; w < GPX_BLOCK / 64; w++) bbase += red[w];
+  const long long mine = P.bucket_bytes[b];
+  if (b == (int32_t)gridDim.x - 1 && threadIdx.x == 0) *n_bytes = bbase + mine;
+  if (bbase + mine > cap_bytes) return; /* the caller sees n_bytes > cap_bytes */
+  const int32_t boff = X.bucket_off[b];
+  const uint32_t* src = (const uint32_t*)(P.stage + (int64_t)boff * GPX_W_BAR_REC_BYTES);
+  uint32_t* dst = (uint32_t*)(out + bbase);
+  for (int32_t i = threadIdx.x; i < (int32_t)(mine >> 2); i += GPX_BLOCK) dst[i] = src[i];
+  const int32_t nfr = X.bucket_nout[b];
+  const Out* ftab = X.o_rec + boff;
+  for (int32_t f = threadIdx.x; f < nfr; f += GPX_BLOCK) {
+    const Out r = ftab[f];
+    frame_off[fbase + f] = bbase + r.x;
+    frame_len[fbase + f] = r.slot;
+    f_gidx[fbase + f] = r.gidx;
+    f_dest[fbase + f] = r.y;
+  }
+}

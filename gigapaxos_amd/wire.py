@@ -64,10 +64,12 @@ _WIRE_SIGS = {
     "wire_decode": [C.c_int32, _VP, _VP, _VP, _VP, _VP, C.POINTER(WireVotes), C.POINTER(WireCommits),
                     C.POINTER(WireAccepts), C.POINTER(WireRequests), _VP],
     "wire_pack_commits": [C.c_int32] + [_VP] * 7 + [C.c_int64] + [_VP] * 5,
+    "wire_pack_accept_replies": [C.c_int32] + [_VP] * 10 + [C.c_int64] + [_VP] * 6,
 }
 _WIRE_DEV_SIGS = {
     "wire_decode_dev": _WIRE_SIGS["wire_decode"],
     "wire_pack_commits_dev": [C.c_int32, _VP] + [_VP] * 7 + [C.c_int64] + [_VP] * 5,
+    "wire_pack_accept_replies_dev": [C.c_int32] + [_VP] * 10 + [C.c_int64] + [_VP] * 6,
 }
 WIRE_EXPORTED_SYMBOLS = list(_WIRE_SIGS) + list(_WIRE_DEV_SIGS)
 
@@ -281,3 +283,27 @@ class WireEngine:
         m = int(nf[0])
         frames = [out[int(foff[i]):int(foff[i]) + int(flen[i])].tobytes() for i in range(m)]
         return frames, fg[:m].copy(), int(nb[0])
+
+    def pack_accept_replies(self, gidx, slot, r_bnum, r_bcoord, r_maxcp, status, sender=None, req_id=None,
+                            cap_bytes=None):
+        """The replies of one Engine.accept call -> BATCHED_ACCEPT_REPLY frames.
+        Returns (frames, f_gidx, f_dest, unbatched flags, bytes used)."""
+        gidx = _i32(gidx)
+        n = int(gidx.shape[0])
+        cols = [_i32(x, n) for x in (slot, r_bnum, r_bcoord, r_maxcp)]
+        status = np.ascontiguousarray(status, dtype=np.uint8)
+        sender = None if sender is None else _i32(sender, n)
+        req_id = None if req_id is None else np.ascontiguousarray(req_id, dtype=np.int64)
+        cap = 188 * max(n, 1) if cap_bytes is None else cap_bytes
+        out = np.zeros(cap, np.uint8)
+        m = max(n, 1)
+        foff, flen, fg, fd = np.zeros(m, np.int64), np.zeros(m, np.int32), np.zeros(m, np.int32), np.zeros(m, np.int32)
+        ub = np.zeros(m, np.uint8)
+        nf, nb = np.zeros(1, np.int32), np.zeros(1, np.int64)
+        self.lib.check(self.lib.fn["wire_pack_accept_replies"](
+            self.e.h, n, _p(gidx), _p(cols[0]), _p(sender), _p(req_id), _p(cols[1]), _p(cols[2]), _p(cols[3]),
+            _p(status), _p(ub), _p(out), cap, _p(foff), _p(flen), _p(fg), _p(fd), _p(nf), _p(nb)),
+            "wire_pack_accept_replies")
+        k = int(nf[0])
+        frames = [out[int(foff[i]):int(foff[i]) + int(flen[i])].tobytes() for i in range(k)]
+        return frames, fg[:k].copy(), fd[:k].copy(), ub[:n].copy(), int(nb[0])

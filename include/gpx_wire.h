@@ -168,6 +168,42 @@ int gpx_wire_pack_commits_dev(gpx_engine* h, int32_t n, const int32_t* n_dev,
                               int64_t* frame_off, int32_t* frame_len, int32_t* f_gidx,
                               int32_t* n_frames /* device */, int64_t* n_bytes /* device */);
 
+/* ---- encode: accept replies -> BATCHED_ACCEPT_REPLY frames ----------------------- */
+
+/*
+ * replaces: PaxosPacketBatcher.coalesce -> enqueueImpl(AcceptReplyPacket) -> dequeueImplAR ->
+ * BatchedAcceptReply.toBytes (PaxosPacketBatcher.java:121-137, 211-224, 353-388;
+ * BatchedAcceptReply.java:119-173) for the replies of one gpx_accept_batch call.  Record i is the
+ * reply to ACCEPT i: (gidx, slot) from the accept, (r_bnum, r_bcoord, r_maxcp, status) as
+ * gpx_accept_batch returned them, sender / req_id (nullable) as gpx_wire_decode gave them.  A reply
+ * exists iff status[i] == GPX_S_OK; it is coalescable iff its ballot's coordinator is the
+ * ACCEPT's sender (allPositiveAcceptReplies, PaxosPacketBatcher.java:438-446).  All coalescable
+ * replies of one (group, reply ballot) become ONE frame: acceptor = this node, the ballot, the
+ * slot / maxCheckpointedSlot / requestID of the FIRST such reply in array order
+ * (BatchedAcceptReply.java:49-54), then the TreeMap slot -> requestID (ascending, a repeated slot
+ * keeps the last request id).  Frames leave grouped by gidx ascending, the ballots of one group in
+ * first-appearance order; f_dest[f] = the ballot's coordinator, the node the frame goes to.
+ * Engine limits: per call at most 256 replies and 4 distinct reply ballots of one group are
+ * coalesced.  unbatched[i] (nullable) = 1 for every existing reply that was NOT packed (not
+ * coalescable, over a limit, unnamed group): the host sends it as a plain ACCEPT_REPLY, which is
+ * what the reference does with BATCHED_ACCEPT_REPLIES off.  frame_off is 4-byte aligned.
+ */
+int gpx_wire_pack_accept_replies(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* slot,
+                                 const int32_t* sender, const int64_t* req_id,
+                                 const int32_t* r_bnum, const int32_t* r_bcoord,
+                                 const int32_t* r_maxcp, const uint8_t* status, uint8_t* unbatched,
+                                 uint8_t* out, int64_t cap_bytes, int64_t* frame_off,
+                                 int32_t* frame_len, int32_t* f_gidx, int32_t* f_dest,
+                                 int32_t* n_frames, int64_t* n_bytes);
+int gpx_wire_pack_accept_replies_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
+                                     const int32_t* slot, const int32_t* sender,
+                                     const int64_t* req_id, const int32_t* r_bnum,
+                                     const int32_t* r_bcoord, const int32_t* r_maxcp,
+                                     const uint8_t* status, uint8_t* unbatched, uint8_t* out,
+                                     int64_t cap_bytes, int64_t* frame_off, int32_t* frame_len,
+                                     int32_t* f_gidx, int32_t* f_dest, int32_t* n_frames /* device */,
+                                     int64_t* n_bytes /* device */);
+
 #ifdef __cplusplus
 }
 #endif

@@ -92,3 +92,57 @@ def test_pack_commits_matches_oracle_and_roundtrips(hip_lib, oracle_lib):
         want = sorted(zip(dh.gidx[dh.kind == D_DECISION].tolist(), dh.slot[dh.kind == D_DECISION].tolist()))
         got = sorted(zip(dec.commits["gidx"].tolist(), dec.commits["slot"].tolist()))
         assert got == want
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_pack_accept_replies_fuzz(hip_lib, oracle_lib, seed):
+    """Random accept batches (several slots and ballots per group, NACKs, dropped accepts, a hot
+    group beyond the per-call limits, unnamed rows): BATCHED_ACCEPT_REPLY bytes, destinations and
+    the unbatched flags identical to the oracle's."""
+    rng = np.random.default_rng(seed)
+    ((eh, wh), (eo, wo)), names = make_wire_pair(hip_lib, oracle_lib, 1500, 5, rng)
+    G = 1500
+    for it in range(4):
+        n = 6000
+        g = rng.integers(-1, G + 1, n).astype(np.int32)
+        g[rng.random(n) < 0.25] = 77        # hot group: > 256 replies in one call
+        g[rng.random(n) < 0.05] = 78        # > 16 records: cooperative sort path
+        slot = rng.integers(1, 40, n).astype(np.int32)
+        bnum = rng.choice([0, 0, 0, 1, 2, 3, 4, 5], size=n).astype(np.int32)
+        bcoord = rng.integers(100, 105, n).astype(np.int32)
+        sender = np.where(rng.random(n) < 0.9, bcoord, 100).astype(np.int32)
+        maxcp = rng.integers(-1, 30, n).astype(np.int32)
+        status = rng.choice([0, 0, 0, 0, 2, 3], size=n).astype(np.uint8)
+        status[(g < 0) | (g >= G)] = 1
+        req = rng.integers(-2**62, 2**62, n)
+        use_opt = it % 2 == 0
+        a = wh.pack_accept_replies(g, slot, bnum, bcoord, maxcp, status, sender if use_opt else None,
+                                   req if use_opt else None)
+        b = wo.pack_accept_replies(g, slot, bnum, bcoord, maxcp, status, sender if use_opt else None,
+                                   req if use_opt else None)
+        assert a[1].tolist() == b[1].tolist() and a[2].tolist() == b[2].tolist(), f"iter {it} frame table"
+        assert a[3].tolist() == b[3].tolist(), f"iter {it} unbatched"
+        assert a[4] == b[4] and a[0] == b[0], f"iter {it} bytes"
+        assert eh.counters() == eo.counters()
+
+
+def test_frame_level_cluster_matches_oracle(hip_lib, oracle_lib):
+    """Three replicas exchanging nothing but wire frames (tests/wire_cluster.py), engine cluster vs
+    oracle cluster: every frame on the wire and every execution log identical."""
+    from tests.wire_cluster import WireCluster
+    G, R = 3000, 6
+    names = [b"service/%d" % g for g in range(G)]
+    rng = np.random.default_rng(8)
+    coord = rng.choice([100, 101, 102], size=G).astype(np.int32)
+    ch = WireCluster(hip_lib, [100, 101, 102], names, coord)
+    co = WireCluster(oracle_lib, [100, 101, 102], names, coord)
+    for r in range(R):
+        groups = rng.permutation(G)[: G - 100 * r]
+        dh, do = ch.round(groups, r), co.round(groups, r)
+        for c in dh:
+            assert (dh[c].as_tuple_array() == do[c].as_tuple_array()).all()
+    assert ch.trace == co.trace
+    for nid in (100, 101, 102):
+        assert ch.executed(nid).tolist() == co.executed(nid).tolist()
+        sh, so = ch.eng[nid].snapshot(np.arange(G))[0], co.eng[nid].snapshot(np.arange(G))[0]
+        assert sh.tobytes() == so.tobytes()

@@ -211,3 +211,58 @@ def test_rows_allocator(oracle_lib):
     with pytest.raises(Exception):
         we.rows_alloc(2)
     assert we.rows_alloc(1).tolist() == [7]
+
+
+def test_pack_accept_replies_batcher_semantics(oracle_lib):
+    """PaxosPacketBatcher.enqueueImpl(AcceptReplyPacket): one BatchedAcceptReply per (paxosID,
+    ballot) keeps the FIRST reply's slot / maxCheckpointedSlot / requestID in its fixed part and
+    TreeMap-merges the slots (a repeated slot keeps the last request id); replies whose ballot
+    coordinator is not the ACCEPT's sender are not coalescable; dropped accepts have no reply."""
+    e, we, names = make_engine(oracle_lib, k=3, my_id=101)
+    #        gidx slot bnum bcoord maxcp status sender reqid
+    rows = [(3, 7, 0, 100, 5, 0, 100, 70),
+            (5, 1, 0, 102, 0, 0, 102, 10),
+            (3, 6, 0, 100, 9, 0, 100, 60),
+            (3, 7, 0, 100, 9, 0, 100, 71),   # same slot again: request id 71 wins, maxCP stays 5
+            (3, 8, 1, 102, 9, 0, 100, 80),   # acceptor already promised (1,102): NACK, not coalescable
+            (3, 9, 1, 102, 9, 0, 102, 90),   # a second ballot of group 3
+            (5, 2, 0, 102, 0, 2, 102, 20),   # status STOPPED: no reply at all
+            (40, 1, 0, 100, 0, 0, 100, 1),   # row without a name
+            (-1, 1, 0, 100, 0, 1, 100, 1)]   # unknown group: dropped by the accept call
+    a = np.array(rows, np.int64)
+    frames, fg, fd, ub, nbytes = we.pack_accept_replies(a[:, 0], a[:, 1], a[:, 2], a[:, 3], a[:, 4],
+                                                        a[:, 5].astype(np.uint8), sender=a[:, 6], req_id=a[:, 7])
+    assert fg.tolist() == [3, 3, 5] and fd.tolist() == [100, 102, 102]
+    assert frames[0] == W.batched_accept_reply(b"pid3", 0, 101, 0, 100, 5, [6, 7], [60, 71]) \
+        .replace(struct.pack(">iiq", 6, 5, 60), struct.pack(">iiq", 7, 5, 70), 1)
+    assert frames[1] == W.batched_accept_reply(b"pid3", 0, 101, 1, 102, 9, [9], [90])
+    assert frames[2] == W.batched_accept_reply(b"pid5", 0, 101, 0, 102, 0, [1], [10])
+    assert ub.tolist() == [0, 0, 0, 0, 1, 0, 0, 1, 0]
+    assert nbytes == sum((len(f) + 3) // 4 * 4 for f in frames)
+    # the coordinator's decoder turns them back into votes
+    e2, we2, _ = make_engine(oracle_lib, k=3, my_id=100)
+    d = we2.decode(frames[:1])
+    assert d.votes["slot"].tolist() == [6, 7] and d.votes["max_cp"].tolist() == [5, 5]
+    assert d.votes["acceptor"].tolist() == [101, 101]
+
+
+def test_frame_level_cluster_executes_in_order(oracle_lib):
+    """BASELINE config #1/#2 shape with every hop crossing the wire formats (tests/wire_cluster.py):
+    3 replicas, coordinators spread over them, every replica executes every group's slots 1..R in
+    order."""
+    from tests.wire_cluster import WireCluster
+    G, R = 60, 5
+    names = [b"svc-%d" % g for g in range(G)]
+    coord = np.array([100 + g % 3 for g in range(G)], np.int32)
+    c = WireCluster(oracle_lib, [100, 101, 102], names, coord)
+    rng = np.random.default_rng(3)
+    for r in range(R):
+        dec = c.round(rng.permutation(G), r)
+        assert sum(d.gidx.shape[0] for d in dec.values()) == G
+    for nid in (100, 101, 102):
+        ex = c.executed(nid)
+        for g in range(G):
+            runs = ex[ex[:, 0] == g]
+            slots = np.concatenate([np.arange(f, f + n) for _, f, n in runs])
+            assert slots.tolist() == list(range(1, R + 1))
+    c.close()
