@@ -86,7 +86,7 @@ struct gpx_engine {
   int64_t nm_tomb = 0;
   std::vector<int32_t> free_rows;
   bool free_init = false;
-  int32_t *w_cnt = nullptr, *w_tile = nullptr, *w_err = nullptr;
+  int32_t *w_cnt = nullptr, *w_tile = nullptr, *w_err = nullptr, *w_gidx = nullptr, *w_aux = nullptr;
   int8_t* w_cls = nullptr;
   long long* w_tile_b = nullptr;
   uint8_t* w_stage = nullptr;      /* staging of BATCHED_ACCEPT_REPLY frames, 188 B per reply */

@@ -10,18 +10,30 @@
 #include "gpx_kernels.hip.h"
 #include "../../include/gpx_wire.h"
 
-#define NM_STRIDE 128 /* bytes per name row: paxosIDLength <= 127 */
+/* One row per group: int32 String.hashCode | uint8 length (0 = no name) | 3 pad | name bytes.
+ * Header and the first 24 name bytes share one 32-byte sector: a lookup of a short paxosID costs
+ * the table probe plus ONE row access. */
+#define NM_STRIDE 144
+#define NM_NAME 8 /* offset of the name bytes inside a row */
 #define GPX_W_MAX_DEPTH 6   /* nesting of batched RequestPackets the walker follows */
 #define GPX_W_MAX_SEG 256   /* rows of one group a BATCHED_COMMIT frame may span (>= 2 * window) */
 
 /* device mirror of PaxosManager.pinstances' key side: open addressing over the paxosID bytes */
 struct DevNames {
-  int32_t cap;     /* table slots, power of two, >= 2 * G */
-  int32_t* tab;    /* 0 empty, -1 tombstone, else row + 1 */
-  uint8_t* bytes;  /* [G][NM_STRIDE] */
-  uint8_t* len;    /* [G], 0 = row has no name */
-  int32_t* hash;   /* [G] java.lang.String.hashCode of the name */
+  int32_t cap;    /* table slots, power of two, >= 2 * G */
+  int32_t* tab;   /* 0 empty, -1 tombstone, else row + 1 */
+  uint8_t* rows;  /* [G][NM_STRIDE] */
+  __device__ __forceinline__ uint8_t* row(int32_t g) const { return rows + (int64_t)g * NM_STRIDE; }
+  __device__ __forceinline__ int32_t hash(int32_t g) const { return *(const int32_t*)row(g); }
+  __device__ __forceinline__ int32_t len(int32_t g) const { return (int32_t)row(g)[4]; }
+  __device__ __forceinline__ const uint8_t* name(int32_t g) const { return row(g) + NM_NAME; }
 };
+
+/* Frame bytes are parsed either in place (generic pointer) or from the LDS staging area.  The
+ * parsers are templates over the pointer type so that the staged case compiles to ds_read_u8
+ * (a generic pointer into LDS becomes a flat load: every byte then waits on both memory counters) */
+typedef const uint8_t* GenBytes;
+typedef const __attribute__((address_space(3))) uint8_t* LdsBytes;
 
 __device__ __forceinline__ uint32_t w_fmix32(uint32_t h) {
   h ^= h >> 16;
@@ -32,20 +44,29 @@ __device__ __forceinline__ uint32_t w_fmix32(uint32_t h) {
   return h;
 }
 /* String.hashCode of an ISO-8859-1 string: s[0]*31^(n-1) + ... + s[n-1] (int arithmetic) */
-__device__ __forceinline__ int32_t w_java_hash(const uint8_t* p, int32_t n) {
+template <class BP>
+__device__ __forceinline__ int32_t w_java_hash(BP p, int32_t n) {
   uint32_t h = 0;
   for (int32_t i = 0; i < n; i++) h = 31u * h + (uint32_t)p[i];
   return (int32_t)h;
 }
-__device__ __forceinline__ bool w_bytes_eq(const uint8_t* a, const uint8_t* b, int32_t n) {
+template <class BP>
+__device__ __forceinline__ bool w_bytes_eq(const uint8_t* a, BP b, int32_t n) {
   for (int32_t i = 0; i < n; i++)
     if (a[i] != b[i]) return false;
   return true;
 }
-/* MultiArrayMap.get(paxosID) (PaxosManager.getInstance, PaxosManager.java:1816-1832): row or -1 */
-__device__ __forceinline__ int32_t names_find(const DevNames& N, const uint8_t* p, int32_t len,
-                                              int32_t hash) {
+/* MultiArrayMap.get(paxosID) (PaxosManager.getInstance, PaxosManager.java:1816-1832): row or -1.
+ * The first 24 name bytes of the probe are packed into six dwords once; a candidate row's header
+ * and its first 24 name bytes (zero padded by k_names_bind) arrive with two 16-byte loads of one
+ * 32-byte sector, so a probe step costs one table read plus one row read. */
+template <class BP>
+__device__ __forceinline__ int32_t names_find(const DevNames& N, BP p, int32_t len, int32_t hash) {
   if (!N.tab) return -1;
+  uint32_t q[6] = {0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int32_t i = 0; i < 24; i++)
+    if (i < len) q[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
   const uint32_t mask = (uint32_t)N.cap - 1u;
   uint32_t s = w_fmix32((uint32_t)hash) & mask;
   for (int32_t probe = 0; probe < N.cap; probe++) {
@@ -53,9 +74,14 @@ __device__ __forceinline__ int32_t names_find(const DevNames& N, const uint8_t* 
     if (v == 0) return -1;
     if (v > 0) {
       const int32_t g = v - 1;
-      if (N.hash[g] == hash && (int32_t)N.len[g] == len &&
-          w_bytes_eq(N.bytes + (int64_t)g * NM_STRIDE, p, len))
-        return g;
+      const uint4* r = (const uint4*)N.row(g);
+      const uint4 r0 = r[0], r1 = r[1];
+      if ((int32_t)r0.x == hash && (int32_t)(r0.y & 0xffu) == len && r0.z == q[0] && r0.w == q[1] &&
+          r1.x == q[2] && r1.y == q[3] && r1.z == q[4] && r1.w == q[5]) {
+        bool same = true;
+        for (int32_t i = 24; i < len && same; i++) same = N.name(g)[i] == p[i];
+        if (same) return g;
+      }
     }
     s = (s + 1) & mask;
   }
@@ -75,16 +101,17 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevNames N, int32_t G,
     status[i] = GPX_S_NOGROUP;
     return;
   }
-  if (N.len[g] != 0) { /* the row already carries a name */
+  if (N.len(g) != 0) { /* the row already carries a name */
     status[i] = GPX_S_EXISTS;
     return;
   }
   const uint8_t* p = names + name_off[i];
   const int32_t h = w_java_hash(p, len);
-  uint8_t* row = N.bytes + (int64_t)g * NM_STRIDE;
-  for (int32_t b = 0; b < len; b++) row[b] = p[b];
-  N.hash[g] = h;
-  N.len[g] = (uint8_t)len;
+  uint8_t* row = N.row(g);
+  for (int32_t b = 0; b < len; b++) row[NM_NAME + b] = p[b];
+  for (int32_t b = len; b < 24; b++) row[NM_NAME + b] = 0; /* names_find compares 24 padded bytes */
+  *(int32_t*)row = h;
+  row[4] = (uint8_t)len;
   __threadfence(); /* the row is complete before the table can point at it */
   const uint32_t mask = (uint32_t)N.cap - 1u;
   uint32_t s = w_fmix32((uint32_t)h) & mask;
@@ -100,16 +127,15 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevNames N, int32_t G,
     }
     if (v > 0 && v - 1 != g) {
       const int32_t o = v - 1;
-      if (N.hash[o] == h && (int32_t)N.len[o] == len &&
-          w_bytes_eq(N.bytes + (int64_t)o * NM_STRIDE, p, len)) {
-        N.len[g] = 0; /* name already bound to another row */
+      if (N.hash(o) == h && N.len(o) == len && w_bytes_eq(N.name(o), p, len)) {
+        N.row(g)[4] = 0; /* name already bound to another row */
         status[i] = GPX_S_EXISTS;
         return;
       }
     }
     s = (s + 1) & mask;
   }
-  N.len[g] = 0;
+  N.row(g)[4] = 0;
   status[i] = GPX_S_NOGROUP; /* table full: cannot happen with cap >= 2 G */
 }
 
@@ -119,12 +145,12 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_unbind(DevNames N, int32_t 
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (i >= n) return;
   const int32_t g = gidx[i];
-  if ((uint32_t)g >= (uint32_t)G || N.len[g] == 0) {
+  if ((uint32_t)g >= (uint32_t)G || N.len(g) == 0) {
     if (status) status[i] = GPX_S_NOGROUP;
     return;
   }
   const uint32_t mask = (uint32_t)N.cap - 1u;
-  uint32_t s = w_fmix32((uint32_t)N.hash[g]) & mask;
+  uint32_t s = w_fmix32((uint32_t)N.hash(g)) & mask;
   for (int32_t probe = 0; probe < N.cap; probe++) {
     const int32_t v = N.tab[s];
     if (v == g + 1) {
@@ -134,16 +160,16 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_unbind(DevNames N, int32_t 
     if (v == 0) break;
     s = (s + 1) & mask;
   }
-  N.len[g] = 0;
+  N.row(g)[4] = 0;
   if (status) status[i] = GPX_S_OK;
 }
 
 /* rebuild after many unbinds: table cleared by the host, every named row re-inserted */
 __global__ __launch_bounds__(GPX_BLOCK) void k_names_reinsert(DevNames N, int32_t G) {
   const int32_t g = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  if (g >= G || N.len[g] == 0) return;
+  if (g >= G || N.len(g) == 0) return;
   const uint32_t mask = (uint32_t)N.cap - 1u;
-  uint32_t s = w_fmix32((uint32_t)N.hash[g]) & mask;
+  uint32_t s = w_fmix32((uint32_t)N.hash(g)) & mask;
   for (int32_t probe = 0; probe < N.cap; probe++) {
     if (N.tab[s] == 0 && atomicCAS(&N.tab[s], 0, g + 1) == 0) return;
     s = (s + 1) & mask;
@@ -165,11 +191,13 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_lookup(DevNames N, int32_t 
 /* decode                                                                       */
 
 /* java.nio.ByteBuffer.getInt at an arbitrary byte position (big-endian) */
-__device__ __forceinline__ int32_t w_be32(const uint8_t* p) {
+template <class BP>
+__device__ __forceinline__ int32_t w_be32(BP p) {
   return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) |
                    (uint32_t)p[3]);
 }
-__device__ __forceinline__ int64_t w_be64(const uint8_t* p) {
+template <class BP>
+__device__ __forceinline__ int64_t w_be64(BP p) {
   return (int64_t)(((uint64_t)(uint32_t)w_be32(p) << 32) | (uint64_t)(uint32_t)w_be32(p + 4));
 }
 
@@ -182,7 +210,8 @@ __device__ __forceinline__ bool w_known_type(int32_t t) {
 /* One RequestPacket body starting at its PaxosPacket header, inside the buffer [.., end):
  * RequestPacket(ByteBuffer) up to and including numBatched (RequestPacket.java:956-1005).
  * Returns false where the constructor would throw. */
-__device__ __forceinline__ bool w_request_fixed(const uint8_t* p, int64_t& pos, int64_t end,
+template <class BP>
+__device__ __forceinline__ bool w_request_fixed(BP p, int64_t& pos, int64_t end,
                                                 int32_t& num_batched, bool& stop, int64_t& req_id) {
   if (pos + 13 > end) return false;
   const int32_t idl = (int32_t)(int8_t)p[pos + 12];
@@ -218,8 +247,8 @@ __device__ __forceinline__ bool w_request_fixed(const uint8_t* p, int64_t& pos, 
  * parsed by its own constructor (RequestPacket.java:1006-1019).  On success pos = first byte after
  * the request (where an ACCEPT's slot / ballot tail starts); stop_any = isStopRequest()
  * (RequestPacket.java:1069-1080). */
-__device__ bool w_walk_request(const uint8_t* p, int64_t& pos, int64_t end, bool& stop_any,
-                               int64_t& req_id) {
+template <class BP>
+__device__ bool w_walk_request(BP p, int64_t& pos, int64_t end, bool& stop_any, int64_t& req_id) {
   int64_t bend[GPX_W_MAX_DEPTH + 1];
   int32_t rem[GPX_W_MAX_DEPTH + 1];
   int32_t nb = 0;
@@ -268,7 +297,8 @@ struct WFrame {
 };
 
 /* strictly ascending signed order = what TreeMap / TreeSet iteration put on the wire */
-__device__ __forceinline__ bool w_list_ascending(const uint8_t* e, int32_t n, int32_t stride) {
+template <class BP>
+__device__ __forceinline__ bool w_list_ascending(BP e, int32_t n, int32_t stride) {
   int32_t prev = 0;
   for (int32_t j = 0; j < n; j++) {
     const int32_t s = w_be32(e + (int64_t)j * stride);
@@ -278,7 +308,8 @@ __device__ __forceinline__ bool w_list_ascending(const uint8_t* e, int32_t n, in
   return true;
 }
 /* TreeSet size of a non-ascending list (n <= GPX_W_MAX_UNSORTED) */
-__device__ __forceinline__ int32_t w_list_distinct(const uint8_t* e, int32_t n, int32_t stride) {
+template <class BP>
+__device__ __forceinline__ int32_t w_list_distinct(BP e, int32_t n, int32_t stride) {
   int32_t c = 0;
   for (int32_t j = 0; j < n; j++) {
     const int32_t s = w_be32(e + (int64_t)j * stride);
@@ -292,8 +323,8 @@ __device__ __forceinline__ int32_t w_list_distinct(const uint8_t* e, int32_t n, 
 /* PaxosPacketDemultiplexerFast.toPaxosPacket (paxosutil/PaxosPacketDemultiplexerFast.java:66-103)
  * + the four ByteBuffer constructors + PaxosManager.handlePaxosPacket's getInstance / version test
  * (PaxosManager.java:1153-1162), for one frame. */
-__device__ void w_parse(const DevState& S, const DevNames& N, const uint8_t* p, int64_t L,
-                        WFrame& f) {
+template <class BP>
+__device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, WFrame& f) {
   f.st = GPX_W_MALFORMED;
   f.type = -1;
   f.gidx = -1;
@@ -394,10 +425,41 @@ struct WireOut {
 
 struct WireScratch {
   int32_t* cnt;   /* [frames] records of each frame */
-  int8_t* cls;    /* [frames] */
+  int8_t* cls;    /* [frames] class (bits 0-2, 7 = none) | slot list ascending << 3 | stop << 4 */
+  int32_t* gidx;  /* [frames] group row of each frame */
+  int32_t* aux;   /* [frames] ACCEPT: byte position of the slot / ballot tail */
   int32_t* tile;  /* [4][ntiles] records per class per 256-frame tile, then exclusive bases */
   int32_t ntiles;
 };
+
+/* The 256 frames of a workgroup's tile are contiguous in the burst: copy their bytes to LDS with
+ * coalesced dword loads and let every lane parse its frame from there (a lane walking ~70 bytes
+ * of its own frame in global memory touches a different cache line than its neighbours on every
+ * load: measured 8x slower).  Tiles longer than the staging area (big request values) are parsed
+ * in place.  Returns true (workgroup-uniform) when the tile is staged; *pos = this lane's frame as a
+ * byte offset into the staging area (staged) or into `frames` (not staged). */
+#define GPX_W_STAGE_BYTES (32 * 1024)
+__device__ __forceinline__ bool wire_stage_tile(const uint8_t* __restrict__ frames,
+                                                const int64_t* __restrict__ frame_off, int32_t nf,
+                                                uint32_t* lds, int32_t i, int64_t* pos) {
+  const int32_t t0 = (int32_t)blockIdx.x * GPX_BLOCK;
+  const int32_t t1 = t0 + GPX_BLOCK < nf ? t0 + GPX_BLOCK : nf;
+  const int64_t b0 = frame_off[t0], b1 = frame_off[t1];
+  const uintptr_t a0 = (uintptr_t)(frames + b0) & ~(uintptr_t)3; /* dword-aligned start */
+  const int64_t span = (int64_t)((uintptr_t)(frames + b1) - a0);
+  const bool staged = span >= 0 && span <= GPX_W_STAGE_BYTES;
+  if (staged) {
+    const uint32_t* src = (const uint32_t*)a0;
+    const int32_t nw = (int32_t)(span >> 2);
+    for (int32_t w = threadIdx.x; w < nw; w += GPX_BLOCK) lds[w] = src[w];
+    if ((int32_t)threadIdx.x < (int32_t)(span & 3)) /* tail bytes one by one: never read past b1 */
+      ((uint8_t*)lds)[(nw << 2) + threadIdx.x] = ((const uint8_t*)a0)[(nw << 2) + threadIdx.x];
+  }
+  __syncthreads();
+  const int64_t o = i < nf ? frame_off[i] : b0;
+  *pos = staged ? (int64_t)((uintptr_t)(frames + o) - a0) : o;
+  return staged;
+}
 
 /* pass 1: parse every frame, count its records; per-tile totals per class */
 __global__ __launch_bounds__(GPX_BLOCK) void k_wire_scan(DevState S, DevNames N, WireScratch W,
@@ -408,19 +470,27 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_scan(DevState S, DevNames N,
                                                         int32_t* __restrict__ f_gidx,
                                                         int32_t* __restrict__ f_type,
                                                         gpx_wire_counts* counts) {
+  __shared__ uint32_t stage[GPX_W_STAGE_BYTES / 4 + 1];
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  int64_t pos;
+  const bool staged = wire_stage_tile(frames, frame_off, nf, stage, i, &pos);
   WFrame f;
   f.st = GPX_W_OK;
   f.cnt = 0;
   f.cls = -1;
   if (i < nf) {
-    const int64_t o = frame_off[i];
-    w_parse(S, N, frames + o, frame_off[i + 1] - o, f);
+    const int64_t L = frame_off[i + 1] - frame_off[i];
+    if (staged)
+      w_parse<LdsBytes>(S, N, (LdsBytes)stage + pos, L, f);
+    else
+      w_parse<GenBytes>(S, N, frames + pos, L, f);
     f_status[i] = (uint8_t)f.st;
     if (f_gidx) f_gidx[i] = f.gidx;
     if (f_type) f_type[i] = f.type;
     W.cnt[i] = f.cnt;
-    W.cls[i] = (int8_t)f.cls;
+    W.cls[i] = (int8_t)((f.cls & 7) | (f.ascending ? 8 : 0) | (f.stop ? 16 : 0));
+    W.gidx[i] = f.gidx;
+    W.aux[i] = (int32_t)f.tail;
   }
   int32_t tot;
 #pragma unroll
@@ -432,9 +502,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_scan(DevState S, DevNames N,
   if (threadIdx.x == 0 && tot) atomicAdd(&counts->n_bad_frames, tot);
 }
 
-/* pass 2 (one workgroup): exclusive scan of the tile totals per class; the class totals */
+/* pass 2 (one workgroup per class): exclusive scan of the tile totals; the class totals */
 __global__ __launch_bounds__(GPX_FBLOCK) void k_wire_offsets(WireScratch W, gpx_wire_counts* counts) {
-  for (int c = 0; c < 4; c++) {
+  {
+    const int c = (int)blockIdx.x;
     int32_t run = 0;
     for (int32_t t0 = 0; t0 < W.ntiles; t0 += GPX_FBLOCK) {
       const int32_t t = t0 + (int32_t)threadIdx.x;
@@ -450,8 +521,8 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_wire_offsets(WireScratch W, gpx_
 }
 
 /* the r-th smallest distinct slot of a non-ascending list: smallest value greater than `last` */
-__device__ __forceinline__ int32_t w_next_slot(const uint8_t* e, int32_t n, int32_t stride,
-                                               int64_t last) {
+template <class BP>
+__device__ __forceinline__ int32_t w_next_slot(BP e, int32_t n, int32_t stride, int64_t last) {
   int64_t best = (int64_t)1 << 40;
   for (int32_t j = 0; j < n; j++) {
     const int64_t s = w_be32(e + (int64_t)j * stride);
@@ -460,16 +531,84 @@ __device__ __forceinline__ int32_t w_next_slot(const uint8_t* e, int32_t n, int3
   return (int32_t)best;
 }
 
-/* pass 3: every frame writes its records at its class offset (frame order; slots ascending) */
-__global__ __launch_bounds__(GPX_BLOCK) void k_wire_unpack(DevState S, DevNames N, WireScratch W,
-                                                          WireOut O, int32_t nf,
+/* pass 3: every frame writes its records at its class offset (frame order; slots ascending).
+ * Nothing is validated again: pass 1 left the frame's class, group row, list order and tail. */
+/* the records of one frame, written at its class offset */
+template <class BP>
+__device__ __forceinline__ void wire_emit(const WireScratch& W, const WireOut& O, int32_t i, BP p,
+                                          int32_t flags, int32_t cls, int32_t cnt, int32_t off) {
+  const int32_t g = W.gidx[i];
+  const int64_t hdr = 13 + (int64_t)p[12];
+  const bool ascending = (flags & 8) != 0;
+  if (cls == 0) {
+    /* BatchedAcceptReply: acceptor, ballot, (slotNumber), maxCheckpointedSlot once; slots
+     * (PISM.handleBatchedAcceptReply iterates getAcceptedSlots(): TreeMap key order) */
+    const int32_t acceptor = w_be32(p + hdr), bnum = w_be32(p + hdr + 4);
+    const int32_t bcoord = w_be32(p + hdr + 8), maxcp = w_be32(p + hdr + 16);
+    const int32_t raw_n = w_be32(p + hdr + 29);
+    const BP e = p + hdr + 33;
+    int64_t last = -((int64_t)1 << 40);
+    for (int32_t r = 0; r < cnt; r++) {
+      const int32_t s = ascending ? w_be32(e + (int64_t)r * 12) : w_next_slot(e, raw_n, 12, last);
+      last = s;
+      const int32_t o = off + r;
+      O.V.gidx[o] = g;
+      O.V.bnum[o] = bnum;
+      O.V.bcoord[o] = bcoord;
+      O.V.slot[o] = s;
+      O.V.acceptor[o] = acceptor;
+      O.V.max_cp[o] = maxcp;
+      if (O.V.frame) O.V.frame[o] = i;
+    }
+  } else if (cls == 1) {
+    const int32_t bnum = w_be32(p + hdr), bcoord = w_be32(p + hdr + 4);
+    const int32_t median = w_be32(p + hdr + 8);
+    const int32_t raw_n = w_be32(p + hdr + 12);
+    const BP e = p + hdr + 16;
+    int64_t last = -((int64_t)1 << 40);
+    for (int32_t r = 0; r < cnt; r++) {
+      const int32_t s = ascending ? w_be32(e + (int64_t)r * 4) : w_next_slot(e, raw_n, 4, last);
+      last = s;
+      const int32_t o = off + r;
+      O.C.gidx[o] = g;
+      O.C.bnum[o] = bnum;
+      O.C.bcoord[o] = bcoord;
+      O.C.slot[o] = s;
+      O.C.median_cp[o] = median;
+      O.C.kind[o] = 0; /* meta-commit: PISM.handleBatchedCommit finds the value in the stored ACCEPT */
+      if (O.C.frame) O.C.frame[o] = i;
+    }
+  } else if (cls == 2) {
+    const BP t = p + W.aux[i];
+    O.A.gidx[off] = g;
+    O.A.slot[off] = w_be32(t);
+    O.A.bnum[off] = w_be32(t + 4);
+    O.A.bcoord[off] = w_be32(t + 8);
+    O.A.median_cp[off] = w_be32(t + 13);
+    O.A.sender[off] = w_be32(t + 18);
+    O.A.flags[off] = (flags & 16) ? GPX_A_STOP : 0;
+    O.A.req_id[off] = w_be64(p + hdr);
+    if (O.A.frame) O.A.frame[off] = i;
+  } else {
+    O.R.gidx[off] = g;
+    O.R.is_stop[off] = (flags & 16) ? 1 : 0;
+    O.R.req_id[off] = w_be64(p + hdr);
+    if (O.R.frame) O.R.frame[off] = i;
+  }
+}
+
+__global__ __launch_bounds__(GPX_BLOCK) void k_wire_unpack(WireScratch W, WireOut O, int32_t nf,
                                                           const uint8_t* __restrict__ frames,
                                                           const int64_t* __restrict__ frame_off,
                                                           uint8_t* __restrict__ f_status,
                                                           gpx_wire_counts* counts) {
+  __shared__ uint32_t stage[GPX_W_STAGE_BYTES / 4 + 1];
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  int64_t pos;
+  const bool staged = wire_stage_tile(frames, frame_off, nf, stage, i, &pos);
   const bool live = i < nf && f_status[i] == GPX_W_OK;
-  const int32_t cls = live ? (int32_t)W.cls[i] : -1;
+  const int32_t flags = live ? (int32_t)W.cls[i] : 7;
+  const int32_t cls = (flags & 7) == 7 ? -1 : (flags & 7);
   const int32_t cnt = live ? W.cnt[i] : 0;
   int32_t off = 0;
 #pragma unroll
@@ -488,64 +627,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_unpack(DevState S, DevNames 
   block_exscan(over ? 1 : 0, &tot);
   if (threadIdx.x == 0 && tot) atomicAdd(&counts->n_bad_frames, tot);
   if (!live || over) return;
-  const uint8_t* p = frames + frame_off[i];
-  WFrame f;
-  w_parse(S, N, p, frame_off[i + 1] - frame_off[i], f); /* same answer as pass 1 */
-  const int32_t g = f.gidx;
-  const int64_t hdr = f.hdr;
-  if (cls == 0) {
-    /* BatchedAcceptReply: acceptor, ballot, (slotNumber), maxCheckpointedSlot once; slots
-     * (PISM.handleBatchedAcceptReply iterates getAcceptedSlots(): TreeMap key order) */
-    const int32_t acceptor = w_be32(p + hdr), bnum = w_be32(p + hdr + 4);
-    const int32_t bcoord = w_be32(p + hdr + 8), maxcp = w_be32(p + hdr + 16);
-    const uint8_t* e = p + hdr + 33;
-    int64_t last = -((int64_t)1 << 40);
-    for (int32_t r = 0; r < cnt; r++) {
-      const int32_t s = f.ascending ? w_be32(e + (int64_t)r * 12) : w_next_slot(e, f.raw_n, 12, last);
-      last = s;
-      const int32_t o = off + r;
-      O.V.gidx[o] = g;
-      O.V.bnum[o] = bnum;
-      O.V.bcoord[o] = bcoord;
-      O.V.slot[o] = s;
-      O.V.acceptor[o] = acceptor;
-      O.V.max_cp[o] = maxcp;
-      if (O.V.frame) O.V.frame[o] = i;
-    }
-  } else if (cls == 1) {
-    const int32_t bnum = w_be32(p + hdr), bcoord = w_be32(p + hdr + 4);
-    const int32_t median = w_be32(p + hdr + 8);
-    const uint8_t* e = p + hdr + 16;
-    int64_t last = -((int64_t)1 << 40);
-    for (int32_t r = 0; r < cnt; r++) {
-      const int32_t s = f.ascending ? w_be32(e + (int64_t)r * 4) : w_next_slot(e, f.raw_n, 4, last);
-      last = s;
-      const int32_t o = off + r;
-      O.C.gidx[o] = g;
-      O.C.bnum[o] = bnum;
-      O.C.bcoord[o] = bcoord;
-      O.C.slot[o] = s;
-      O.C.median_cp[o] = median;
-      O.C.kind[o] = 0; /* meta-commit: PISM.handleBatchedCommit finds the value in the stored ACCEPT */
-      if (O.C.frame) O.C.frame[o] = i;
-    }
-  } else if (cls == 2) {
-    const uint8_t* t = p + f.tail;
-    O.A.gidx[off] = g;
-    O.A.slot[off] = w_be32(t);
-    O.A.bnum[off] = w_be32(t + 4);
-    O.A.bcoord[off] = w_be32(t + 8);
-    O.A.median_cp[off] = w_be32(t + 13);
-    O.A.sender[off] = w_be32(t + 18);
-    O.A.flags[off] = f.stop ? GPX_A_STOP : 0;
-    O.A.req_id[off] = f.req_id;
-    if (O.A.frame) O.A.frame[off] = i;
-  } else {
-    O.R.gidx[off] = g;
-    O.R.is_stop[off] = f.stop ? 1 : 0;
-    O.R.req_id[off] = f.req_id;
-    if (O.R.frame) O.R.frame[off] = i;
-  }
+  if (staged)
+    wire_emit<LdsBytes>(W, O, i, (LdsBytes)stage + pos, flags, cls, cnt, off);
+  else
+    wire_emit<GenBytes>(W, O, i, frames + pos, flags, cls, cnt, off);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -630,7 +715,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N,
   int32_t size = 0;
   if (i < n && pack_is_head(P, X, n, i)) {
     const int32_t g = P.gidx[i];
-    if ((uint32_t)g < (uint32_t)S.G && (S.g_flags[g] & GF_EXISTS) && N.tab && N.len[g] != 0) {
+    if ((uint32_t)g < (uint32_t)S.G && (S.g_flags[g] & GF_EXISTS) && N.tab && N.len(g) != 0) {
       /* TreeSet of the slots of this (group, ballot) */
       int32_t m = 0;
       for (int32_t j = i; j < n && j - i < GPX_W_MAX_SEG && P.gidx[j] == g; j++) {
@@ -645,7 +730,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N,
       for (int32_t q = 0; q < k; q++) gs += S.members[(int64_t)q * S.G + g] != S.my_id;
       /* SIZEOF_PAXOSPACKET_FIXED + idLen + SIZEOF_BATCHEDCOMMIT_FIXED + 4 (n + 1 + g + 1)
        * (BatchedCommit.java:197-203), rounded up so that every frame starts 4-byte aligned */
-      size = (13 + (int32_t)N.len[g] + 12 + 4 * (m + 1 + gs + 1) + 3) & ~3;
+      size = (13 + N.len(g) + 12 + 4 * (m + 1 + gs + 1) + 3) & ~3;
     }
   }
   if (i < n) X.size[i] = size;
@@ -712,14 +797,14 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_write(DevState S, DevNames N
   const int32_t fi = X.tile_f[blockIdx.x] + ef;
   if (off + size > cap_bytes) return; /* the host sees n_bytes > cap_bytes */
   const int32_t g = P.gidx[i];
-  const int32_t idl = (int32_t)N.len[g];
+  const int32_t idl = N.len(g);
   BEWriter w;
   w.init(out + off);
   w.put32(GPX_WT_PAXOS_PACKET);       /* PaxosPacket.toBytes (PaxosPacket.java:461-476) */
   w.put32(GPX_WT_BATCHED_COMMIT);
   w.put32(S.g_version[g]);
   w.put8((uint32_t)idl);
-  const uint8_t* nm = N.bytes + (int64_t)g * NM_STRIDE;
+  const uint8_t* nm = N.name(g);
   for (int32_t b = 0; b < idl; b++) w.put8(nm[b]);
   w.put32(P.bnum[i]);
   w.put32(P.bcoord[i]);
@@ -821,7 +906,7 @@ __global__ __launch_bounds__(1024) void k_bucket_pack_ar(DevState S, DevScratch 
         keys[p + 1] = x;
       }
     }
-    const bool named = (S.g_flags[g] & GF_EXISTS) && N.tab && N.len[g] != 0;
+    const bool named = (S.g_flags[g] & GF_EXISTS) && N.tab && N.len(g) != 0;
     const int32_t cc = c < GPX_W_BAR_MAX_RECS ? c : GPX_W_BAR_MAX_RECS;
     int32_t nbal = 0, bn[GPX_W_BAR_MAX_BALLOTS], bc[GPX_W_BAR_MAX_BALLOTS];
     for (int32_t t = 0; t < c; t++) {
@@ -859,7 +944,7 @@ __global__ __launch_bounds__(1024) void k_bucket_pack_ar(DevState S, DevScratch 
         }
         m += !seen;
       }
-      my_bytes += (13 + (int32_t)N.len[g] + 29 + 4 + 12 * m + 3) & ~3;
+      my_bytes += (13 + N.len(g) + 29 + 4 + 12 * m + 3) & ~3;
       my_frames++;
     }
   }
@@ -881,7 +966,7 @@ __global__ __launch_bounds__(1024) void k_bucket_pack_ar(DevState S, DevScratch 
     if (c == 0 || g >= S.G) continue;
     const unsigned long long* keys = bv.keys + bv.loff[l];
     const int32_t cc = c < GPX_W_BAR_MAX_RECS ? c : GPX_W_BAR_MAX_RECS;
-    const int32_t idl = N.tab ? (int32_t)N.len[g] : 0;
+    const int32_t idl = N.tab ? N.len(g) : 0;
     for (int32_t q = 0; q < GPX_W_BAR_MAX_BALLOTS; q++) {
       int32_t head = -1;
       for (int32_t t = 0; t < cc && head < 0; t++)
@@ -896,7 +981,7 @@ __global__ __launch_bounds__(1024) void k_bucket_pack_ar(DevState S, DevScratch 
       w.put32(GPX_WT_BATCHED_ACCEPT_REPLY);
       w.put32(S.g_version[g]);
       w.put8((uint32_t)idl);
-      const uint8_t* nm = N.bytes + (int64_t)g * NM_STRIDE;
+      const uint8_t* nm = N.name(g);
       for (int32_t z = 0; z < idl; z++) w.put8(nm[z]);
       /* new BatchedAcceptReply(first reply): acceptor, ballot, its slot, its maxCheckpointedSlot,
        * its requestID, undigestRequest = false (BatchedAcceptReply.java:49-54,

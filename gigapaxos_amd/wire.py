@@ -307,3 +307,73 @@ class WireEngine:
         k = int(nf[0])
         frames = [out[int(foff[i]):int(foff[i]) + int(flen[i])].tobytes() for i in range(k)]
         return frames, fg[:k].copy(), fd[:k].copy(), ub[:n].copy(), int(nb[0])
+
+
+# ---- vectorised builders for large synthetic bursts (bench / scale tests) -----------------
+
+
+def fixed_names(gidx, width=9):
+    """paxosIDs of equal length for many groups: b"g" + zero-padded decimal, as an [n, width] uint8 array."""
+    gidx = np.asarray(gidx, np.int64)
+    out = np.empty((gidx.shape[0], width), np.uint8)
+    out[:, 0] = ord("g")
+    v = gidx.copy()
+    for c in range(width - 1, 0, -1):
+        out[:, c] = ord("0") + v % 10
+        v //= 10
+    return out
+
+
+def _be32_cols(x):
+    return np.ascontiguousarray(np.asarray(x, np.int64).astype(">i4")).view(np.uint8).reshape(-1, 4)
+
+
+def bar_frames_single_slot(name_rows, version, acceptor, bnum, bcoord, max_cp, slot):
+    """n BATCHED_ACCEPT_REPLY frames of ONE slot each (the common case at 1 M groups: every remote
+    acceptor answers one ACCEPT per group and round), all the same length: returns the byte buffer
+    and the int64 offsets gpx_wire_decode takes.  Same layout as batched_accept_reply()."""
+    name_rows = np.asarray(name_rows, np.uint8)
+    n, L = name_rows.shape
+    flen = 13 + L + 29 + 4 + 12
+    f = np.zeros((n, flen), np.uint8)
+    bc = lambda v: _be32_cols(np.broadcast_to(np.asarray(v, np.int64), (n,)))  # noqa: E731
+    f[:, 0:4], f[:, 4:8], f[:, 8:12] = bc(WT_PAXOS_PACKET), bc(WT_BATCHED_ACCEPT_REPLY), bc(version)
+    f[:, 12] = L
+    f[:, 13:13 + L] = name_rows
+    o = 13 + L
+    f[:, o:o + 4], f[:, o + 4:o + 8], f[:, o + 8:o + 12] = bc(acceptor), bc(bnum), bc(bcoord)
+    f[:, o + 12:o + 16], f[:, o + 16:o + 20] = bc(slot), bc(max_cp)
+    # requestID (8) = 0, undigestRequest (1) = 0
+    f[:, o + 29:o + 33] = bc(1)
+    f[:, o + 33:o + 37] = bc(slot)
+    off = np.arange(n + 1, dtype=np.int64) * flen
+    return f.reshape(-1), off
+
+
+def _dev_struct(cls, cap, ptrs):
+    return cls(cap, *[_VP(int(p)) if p else None for p in ptrs])
+
+
+def decode_dev(we: "WireEngine", n_frames, frames_ptr, off_ptr, f_status_ptr, f_gidx_ptr, f_type_ptr,
+               votes=None, commits=None, accepts=None, requests=None, counts_ptr=0):
+    """gpx_wire_decode_dev with integer device addresses.  votes / commits / accepts / requests:
+    (cap, [column addresses in struct order]) or None."""
+    mk = lambda cls, spec: None if spec is None else _dev_struct(cls, spec[0], spec[1])  # noqa: E731
+    V, Cc, A, R = mk(WireVotes, votes), mk(WireCommits, commits), mk(WireAccepts, accepts), mk(WireRequests, requests)
+    ref = lambda s: None if s is None else C.byref(s)  # noqa: E731
+    we.lib.check(we.lib.fn["wire_decode_dev"](we.e.h, int(n_frames), _VP(int(frames_ptr)), _VP(int(off_ptr)),
+                                              _VP(int(f_status_ptr)), _VP(int(f_gidx_ptr) or None),
+                                              _VP(int(f_type_ptr) or None), ref(V), ref(Cc), ref(A), ref(R),
+                                              _VP(int(counts_ptr))), "wire_decode_dev")
+
+
+def pack_commits_dev(we: "WireEngine", n, n_dev_ptr, dec_ptrs, out_ptr, cap_bytes, frame_off_ptr, frame_len_ptr,
+                     f_gidx_ptr, n_frames_ptr, n_bytes_ptr):
+    """gpx_wire_pack_commits_dev with integer device addresses; dec_ptrs = (gidx, slot, bnum, bcoord,
+    median_cp, kind)."""
+    a = [_VP(int(p)) for p in dec_ptrs]
+    we.lib.check(we.lib.fn["wire_pack_commits_dev"](we.e.h, int(n), _VP(int(n_dev_ptr) or None), *a,
+                                                    _VP(int(out_ptr)), int(cap_bytes), _VP(int(frame_off_ptr)),
+                                                    _VP(int(frame_len_ptr)), _VP(int(f_gidx_ptr)),
+                                                    _VP(int(n_frames_ptr)), _VP(int(n_bytes_ptr))),
+                 "wire_pack_commits_dev")
