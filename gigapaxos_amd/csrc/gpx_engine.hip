@@ -91,6 +91,7 @@ struct gpx_engine {
   long long* w_tile_b = nullptr;
   uint8_t* w_stage = nullptr;      /* staging of BATCHED_ACCEPT_REPLY frames, 188 B per reply */
   long long* w_bucket_bytes = nullptr;
+  int32_t* w_ones = nullptr;       /* a column of ones (gpx_request_batch without weights) */
 };
 
 namespace {
@@ -401,7 +402,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
                          (const void*)k_bucket_ar<16>,     (const void*)k_bucket_propose<4>,
                          (const void*)k_bucket_propose<8>, (const void*)k_bucket_propose<16>,
                          (const void*)k_bucket_accept,     (const void*)k_bucket_commit,
-                         (const void*)k_bucket_pack_ar};
+                         (const void*)k_bucket_pack_ar,    (const void*)k_bucket_reqbatch};
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bucket_lds));
   }

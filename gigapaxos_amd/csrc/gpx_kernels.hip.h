@@ -734,6 +734,17 @@ struct GroupIter {
     p[4 * fs] = kind;
     keys[nout++] = cur;
   }
+  /* same, parked in the slot of an EARLIER record of this group (its payload is consumed too) */
+  __device__ __forceinline__ void emit_at(uint32_t where, int32_t slot, int32_t x, int32_t y, int32_t z,
+                                          int32_t kind) {
+    int32_t* p = pay + (int64_t)where * rs;
+    p[0] = slot;
+    p[fs] = x;
+    p[2 * fs] = y;
+    p[3 * fs] = z;
+    p[4 * fs] = kind;
+    keys[nout++] = where;
+  }
 };
 
 /* PaxosCoordinatorState.getMedianMinus (PaxosCoordinatorState.java:867-875): element of rank
@@ -1489,6 +1500,134 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_direct(
   it.c = 1;
   it.done = 0;
   apply_propose_group<KMAX, OneRec>(S, X, g, it, o_slot, o_bnum, o_bcoord, o_median, status, P);
+}
+
+/* ------------------------------------------------------------------------- */
+/* RequestBatcher (RequestBatcher.java:111-239)                                  */
+/* The batcher keeps one FIFO per paxosID; every dequeue takes the head of a queue and latches the
+ * following requests of that group onto it while the byte and batch-size limits hold
+ * (dequeueImpl :163-239).  For a whole burst that is a regrouping by group plus, per group, a greedy
+ * split of the FIFO into consecutive batches - one lane per group again.  Record payload (via
+ * k_scatter_ac): a = lengthEstimate, b = batchSize() + 1, c = stop flag.  Dense output
+ * leader[i] = the request whose batch request i was latched onto (itself for a batch head);
+ * compacted rows, group-major: one per batch = one proposal. */
+__global__ __launch_bounds__(1024) void k_bucket_reqbatch(DevState S, DevScratch X, int32_t max_bytes,
+                                                          int32_t max_size,
+                                                          int32_t* __restrict__ leader) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  BucketView bv;
+  if (!bucket_prepare(X, lds, &bv, []() {})) return;
+  const int32_t g0 = blockIdx.x << X.shift;
+  for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
+    const int32_t c = bv.lcnt[l];
+    int32_t nout = 0;
+    if (c != 0 && g0 + l < S.G) {
+      GroupIter it;
+      it.init(bv, l, c);
+      int32_t head = -1, count = 0, stop = 0;
+      uint32_t head_cur = 0;
+      long long bytes = 0, size = 0;
+      Rec r;
+      while (it.next(r)) {
+        const long long est = r.a, w = r.b;
+        bool fresh = head < 0;
+        if (!fresh) {
+          /* ((totalByteLength += next.lengthEstimate()) > limit) ||
+           * ((totalBatchSize += next.batchSize() + 1) > MAX_BATCH_SIZE) -> break   (:205-211) */
+          if (bytes + est > max_bytes || size + w > max_size) {
+            it.emit_at(head_cur, head, count, (int32_t)bytes, (int32_t)size, stop);
+            fresh = true;
+          }
+        }
+        if (fresh) { /* RequestPacket first = reqPktIter.next()  (:175-177) */
+          head = r.idx;
+          head_cur = it.cur;
+          count = 1;
+          bytes = est;
+          size = w;
+          stop = r.c & 1;
+        } else { /* batch.add(next) -> first.latchToBatch(...)  (:213-219) */
+          count++;
+          bytes += est;
+          size += w;
+          stop |= r.c & 1;
+        }
+        leader[r.idx] = head;
+      }
+      if (head >= 0) it.emit_at(head_cur, head, count, (int32_t)bytes, (int32_t)size, stop);
+      nout = it.nout;
+    }
+    bv.lcnt[l] = nout;
+  }
+  bucket_emit(X, bv);
+}
+
+/* dense prefill of the leader column for records the partition drops (gidx out of range) */
+__global__ __launch_bounds__(GPX_BLOCK) void k_fill_i32(int32_t n, int32_t v, int32_t* __restrict__ a) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i < n) a[i] = v;
+}
+
+/* ------------------------------------------------------------------------- */
+/* gap detection (PaxosAcceptor.getMissingCommittedSlots / getMaxCommittedSlot,  */
+/* PaxosAcceptor.java:405-438; PISM.shouldSync, PISM:2341-2364)                  */
+/* One lane per listed group.  The committed window holds slots in [_slot, _slot + W), so the
+ * missing set fits a 64-bit mask relative to _slot. */
+__global__ __launch_bounds__(GPX_BLOCK) void k_gap_scan(DevState S, int32_t n,
+                                                       const int32_t* __restrict__ gidx,
+                                                       int32_t threshold, int32_t sync_mode,
+                                                       int32_t size_limit,
+                                                       int32_t* __restrict__ first_slot,
+                                                       int32_t* __restrict__ max_committed,
+                                                       unsigned long long* __restrict__ missing,
+                                                       uint8_t* __restrict__ should_sync,
+                                                       uint8_t* __restrict__ status) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t g = gidx[i];
+  first_slot[i] = 0;
+  max_committed[i] = 0;
+  missing[i] = 0;
+  should_sync[i] = 0;
+  if ((uint32_t)g >= (uint32_t)S.G || !(S.g_flags[g] & GF_EXISTS)) {
+    status[i] = GPX_S_NOGROUP;
+    return;
+  }
+  const uint32_t gf = S.g_flags[g];
+  const int32_t slot = S.a_slot[g];
+  first_slot[i] = slot;
+  const bool stopped = (gf & GF_STOPPED) != 0;
+  /* getMaxCommittedSlot: stopped or empty -> getSlot() - 1; else the wraparound-aware maximum */
+  int32_t maxc = jsub(slot, 1);
+  if (!stopped)
+    for (int32_t w = 0; w < S.W; w++) {
+      const int64_t o = (int64_t)w * S.G + g;
+      if ((S.com_flags[o] & RF_PRESENT) && jsub(S.com_ring[o].x, maxc) > 0) maxc = S.com_ring[o].x;
+    }
+  max_committed[i] = maxc;
+  /* shouldSync (PISM:2341-2364), DISABLE_SYNC_DECISIONS = false */
+  const int32_t gap = jsub(maxc, slot);
+  const bool nontrivial = gap >= threshold / 100;       /* NONTRIVIAL_GAP_FACTOR */
+  const bool small_thr = threshold <= 1;                /* INITIAL_SYNC_THRESHOLD */
+  const bool sync = (gap >= threshold) || ((slot == 0 || slot == 1) && (nontrivial || small_thr)) ||
+                    (nontrivial && sync_mode == GPX_SYNC_TO_PAUSE) || sync_mode == GPX_SYNC_FORCE;
+  should_sync[i] = sync ? 1 : 0;
+  status[i] = stopped ? GPX_S_STOPPED : GPX_S_OK;
+  if (stopped) return; /* getMissingCommittedSlots returns null */
+  /* missing: no commit, or a meta-commit without its accept (:414-420) */
+  unsigned long long m = 0;
+  const int32_t limit = (int32_t)((uint32_t)slot + (uint32_t)size_limit);
+  const int32_t Wm = S.W - 1;
+  int32_t j = 0;
+  for (int32_t s = slot; jsub(s, maxc) < 0 && jsub(s, limit) < 0 && j < 64;
+       s = (int32_t)((uint32_t)s + 1u), j++) {
+    const int64_t o = (int64_t)(s & Wm) * S.G + g;
+    const uint8_t cf = S.com_flags[o];
+    const bool have = (cf & RF_PRESENT) && S.com_ring[o].x == s;
+    const bool acc = (S.acc_flags[o] & RF_PRESENT) && S.acc_ring[o].x == s;
+    if (!have || (!(cf & RF_HASVALUE) && !acc)) m |= 1ull << j;
+  }
+  missing[i] = m;
 }
 
 /* ------------------------------------------------------------------------- */

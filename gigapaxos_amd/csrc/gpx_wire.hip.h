@@ -187,6 +187,25 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_lookup(DevNames N, int32_t 
   out[i] = (len >= 1 && len <= GPX_W_MAX_NAME) ? names_find(N, p, len, w_java_hash(p, len)) : -1;
 }
 
+/* PISM.roundRobinCoordinator (PaxosInstanceStateMachine.java:2251-2256) */
+__global__ __launch_bounds__(GPX_BLOCK) void k_names_coordinator(DevState S, DevNames N, int32_t n,
+                                                                const int32_t* __restrict__ gidx,
+                                                                int32_t ballotnum,
+                                                                int32_t* __restrict__ out) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t g = gidx[i];
+  int32_t r = INT32_MIN;
+  if ((uint32_t)g < (uint32_t)S.G && (S.g_flags[g] & GF_EXISTS) && N.tab && N.len(g) != 0) {
+    const int32_t k = (int32_t)GF_K(S.g_flags[g]);
+    const int32_t x = (int32_t)((uint32_t)ballotnum + (uint32_t)N.hash(g));
+    const int32_t ax = x < 0 ? (int32_t)(0u - (uint32_t)x) : x; /* Math.abs */
+    const int32_t idx = ax % k;                                   /* sign follows the dividend */
+    if (idx >= 0) r = S.members[(int64_t)idx * S.G + g];
+  }
+  out[i] = r;
+}
+
 /* ------------------------------------------------------------------------- */
 /* decode                                                                       */
 

@@ -377,3 +377,57 @@ def pack_commits_dev(we: "WireEngine", n, n_dev_ptr, dec_ptrs, out_ptr, cap_byte
                                                     _VP(int(frame_len_ptr)), _VP(int(f_gidx_ptr)),
                                                     _VP(int(n_frames_ptr)), _VP(int(n_bytes_ptr))),
                  "wire_pack_commits_dev")
+
+
+_EXTRA_SIGS = {
+    "names_coordinator": [C.c_int32, _VP, C.c_int32, _VP],
+    "request_batch": [C.c_int32, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32] + [_VP] * 9,
+    "gap_scan": [C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int32] + [_VP] * 5,
+}
+_EXTRA_DEV_SIGS = {"request_batch_dev": _EXTRA_SIGS["request_batch"]}
+WIRE_EXPORTED_SYMBOLS += list(_EXTRA_SIGS) + list(_EXTRA_DEV_SIGS)
+_WIRE_SIGS.update(_EXTRA_SIGS)
+_WIRE_DEV_SIGS.update(_EXTRA_DEV_SIGS)
+
+SYNC_DEFAULT, SYNC_TO_PAUSE, SYNC_FORCE = 0, 1, 2
+
+
+def names_coordinator(we: WireEngine, gidx, ballotnum=0) -> np.ndarray:
+    """PISM.roundRobinCoordinator for bound rows (INT32_MIN where the Java would throw / no name)."""
+    gidx = _i32(gidx)
+    out = np.zeros(gidx.shape[0], np.int32)
+    we.lib.check(we.lib.fn["names_coordinator"](we.e.h, gidx.shape[0], _p(gidx), int(ballotnum), _p(out)),
+                 "names_coordinator")
+    return out
+
+
+def request_batch(we: WireEngine, gidx, est_bytes, weight=None, is_stop=None, max_bytes=1 << 20, max_size=2000):
+    """RequestBatcher for a burst: returns (leader, status, batches dict of arrays)."""
+    gidx = _i32(gidx)
+    n = gidx.shape[0]
+    est = _i32(est_bytes, n)
+    weight = None if weight is None else _i32(weight, n)
+    is_stop = None if is_stop is None else np.ascontiguousarray(is_stop, dtype=np.uint8)
+    m = max(n, 1)
+    leader, status = np.zeros(m, np.int32), np.zeros(m, np.uint8)
+    cols = [np.zeros(m, np.int32) for _ in range(5)]
+    bstop, nb = np.zeros(m, np.uint8), np.zeros(1, np.int32)
+    we.lib.check(we.lib.fn["request_batch"](we.e.h, n, _p(gidx), _p(est), _p(weight), _p(is_stop), int(max_bytes),
+                                            int(max_size), _p(leader), _p(status), *[_p(c) for c in cols],
+                                            _p(bstop), _p(nb)), "request_batch")
+    k = int(nb[0])
+    names = ("gidx", "leader", "count", "bytes", "size")
+    b = {nm: c[:k].copy() for nm, c in zip(names, cols)}
+    b["stop"] = bstop[:k].copy()
+    return leader[:n].copy(), status[:n].copy(), b
+
+
+def gap_scan(we: WireEngine, gidx, threshold, sync_mode=SYNC_DEFAULT, size_limit=64):
+    """PaxosAcceptor.getMissingCommittedSlots / getMaxCommittedSlot + PISM.shouldSync per group."""
+    gidx = _i32(gidx)
+    n = gidx.shape[0]
+    first, maxc = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    missing, sync, st = np.zeros(n, np.uint64), np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+    we.lib.check(we.lib.fn["gap_scan"](we.e.h, n, _p(gidx), int(threshold), int(sync_mode), int(size_limit),
+                                       _p(first), _p(maxc), _p(missing), _p(sync), _p(st)), "gap_scan")
+    return first, maxc, missing, sync, st

@@ -262,6 +262,53 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
                          const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx,
                          int32_t* x_first, int32_t* x_count, int32_t* n_runs);
 
+/* ---- batching of client requests (RequestBatcher) ----------------------------- */
+
+/*
+ * replaces: RequestBatcher.enqueueImpl / dequeueImpl (RequestBatcher.java:111-129, 163-239) for a
+ * whole burst of client requests.  Record i = one RequestPacket for group gidx[i] with
+ * est_bytes[i] = lengthEstimate() and weight[i] = batchSize() + 1 (NULL = 1), is_stop nullable.
+ * Per group, in array order (the per-paxosID FIFO), requests are split greedily into consecutive
+ * batches: a request opens a new batch when adding it would push the byte total over max_bytes
+ * (min(NIOTransport.MAX_PAYLOAD_SIZE, SQLPaxosLogger.MAX_LOG_MESSAGE_SIZE)) or the size total over
+ * max_size (PC.MAX_BATCH_SIZE = 2000); a batch head is taken whatever its own size.
+ * Dense output: leader[i] = index of the request record i is latched onto (i itself for a head;
+ * -1 if gidx[i] is out of range, status[i] = GPX_S_NOGROUP).  Compacted output, grouped by gidx
+ * ascending, the batches of one group in FIFO order: b_gidx, b_leader, b_count,
+ * b_bytes, b_size (the totals), b_stop (any member is a stop request), *n_batches of them.
+ * One batch = one record of gpx_propose_batch.
+ */
+int gpx_request_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* est_bytes,
+                      const int32_t* weight, const uint8_t* is_stop, int32_t max_bytes,
+                      int32_t max_size, int32_t* leader, uint8_t* status, int32_t* b_gidx,
+                      int32_t* b_leader, int32_t* b_count, int32_t* b_bytes, int32_t* b_size,
+                      uint8_t* b_stop, int32_t* n_batches);
+int gpx_request_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* est_bytes,
+                          const int32_t* weight, const uint8_t* is_stop, int32_t max_bytes,
+                          int32_t max_size, int32_t* leader, uint8_t* status, int32_t* b_gidx,
+                          int32_t* b_leader, int32_t* b_count, int32_t* b_bytes, int32_t* b_size,
+                          uint8_t* b_stop, int32_t* n_batches);
+
+/* ---- gap detection ------------------------------------------------------------ */
+
+#define GPX_SYNC_DEFAULT 0  /* SyncMode.DEFAULT_SYNC */
+#define GPX_SYNC_TO_PAUSE 1 /* SyncMode.SYNC_TO_PAUSE */
+#define GPX_SYNC_FORCE 2    /* SyncMode.FORCE_SYNC */
+/*
+ * replaces: PaxosAcceptor.getMaxCommittedSlot / getMissingCommittedSlots
+ * (PaxosAcceptor.java:405-438) and PISM.shouldSync (PaxosInstanceStateMachine.java:2341-2364,
+ * the decision behind syncLongDecisionGaps :1550-1570) for n groups at once.  Outputs per listed
+ * group: first_slot = getSlot(), max_committed = getMaxCommittedSlot(), should_sync (with
+ * `threshold` = PaxosManager.getOutOfOrderLimit() / getMaxSyncDecisionsGap()), and missing = a
+ * bit mask over first_slot + j, j < min(size_limit, 64): bit set = slot neither committed with its
+ * value nor meta-committed with a stored accept.  status: GPX_S_OK, GPX_S_STOPPED (missing = 0, as
+ * the Java returns null), GPX_S_NOGROUP.  The time test (canSync) and the SYNC_DECISIONS request
+ * packet stay in the host.  Host pointers.
+ */
+int gpx_gap_scan(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t threshold,
+                 int32_t sync_mode, int32_t size_limit, int32_t* first_slot,
+                 int32_t* max_committed, uint64_t* missing, uint8_t* should_sync, uint8_t* status);
+
 /* ---- telemetry --------------------------------------------------------------- */
 
 /* cumulative counters since engine creation: votes, decisions, dropped records */

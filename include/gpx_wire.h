@@ -71,6 +71,16 @@ int gpx_names_lookup(gpx_engine* h, int32_t n, const uint8_t* names, const int32
                      int32_t* gidx_out);
 
 /*
+ * replaces: PISM.roundRobinCoordinator(paxosID, members, ballotnum)
+ * (PaxosInstanceStateMachine.java:2251-2256): members[Math.abs(ballotnum + paxosID.hashCode()) %
+ * members.length] from the bound name's String.hashCode, for n group rows.  out[i] = the node id,
+ * or INT32_MIN where the Java would throw (Math.abs(Integer.MIN_VALUE) stays negative) or the row
+ * has no name / no group.  Host pointers.
+ */
+int gpx_names_coordinator(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t ballotnum,
+                          int32_t* out);
+
+/*
  * Dense row allocator for the caller's (paxosID, version) -> gidx map: LIFO free list over
  * [0, max_groups) (host side, control plane).  Returns GPX_ECAPACITY when fewer than n rows are
  * free (nothing allocated).
