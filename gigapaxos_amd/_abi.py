@@ -84,6 +84,7 @@ _SIGS = {
     "accept_batch": [C.c_int32] + [_VP] * 15,
     "accept_reply_batch": [C.c_int32] + [_VP] * 14,
     "commit_batch": [C.c_int32] + [_VP] * 11,
+    "prepare_batch": [C.c_int32] + [_VP] * 13,
 }
 _DEV_SIGS = {
     "engine_set_stream": [_VP],
@@ -93,6 +94,7 @@ _DEV_SIGS = {
     "accept_batch_dev": [C.c_int32] + [_VP] * 15,
     "accept_reply_batch_dev": [C.c_int32] + [_VP] * 14,
     "commit_batch_dev": [C.c_int32] + [_VP] * 11,
+    "prepare_batch_dev": [C.c_int32] + [_VP] * 13,
     "profile_enable": [C.c_int32],
     "profile_read": [C.POINTER(GpxKernelStat), C.c_int32],
 }
@@ -389,6 +391,32 @@ class Engine:
         )
         m = int(no[0])
         return Decisions(dg[:m], ds[:m], db[:m], dc[:m], dm[:m], dk[:m], status)
+
+    def prepare(self, gidx, bnum, bcoord, first_slot):
+        """PISM.handlePrepare for a batch of PREPAREs (acceptor side of a view change).
+        Returns (r_bnum, r_bcoord, r_gc, r_flags, status) and the accepted pvalues as a list of
+        (record index, slot, bnum, bcoord) rows sorted by (record, slot plane)."""
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        bnum, bcoord, first_slot = (_i32(x, n) for x in (bnum, bcoord, first_slot))
+        W = int(self.cfg.window)
+        m = max(n, 1)
+        rb, rc, rg = (np.zeros(m, np.int32) for _ in range(3))
+        rf, st = np.zeros(m, np.uint8), np.zeros(m, np.uint8)
+        mask = np.zeros(m, np.uint64)
+        ps, pb, pc = (np.zeros(m * W, np.int32) for _ in range(3))
+        self.lib.check(
+            self.lib.fn["prepare_batch"](self.h, n, _p(gidx), _p(bnum), _p(bcoord), _p(first_slot), _p(rb),
+                                         _p(rc), _p(rg), _p(rf), _p(mask), _p(ps), _p(pb), _p(pc), _p(st)),
+            "prepare_batch",
+        )
+        rows = []
+        for w in range(W):
+            sel = np.nonzero((mask[:n] >> np.uint64(w)) & np.uint64(1))[0]
+            for i in sel:
+                rows.append((int(i), int(ps[w * n + i]), int(pb[w * n + i]), int(pc[w * n + i])))
+        rows.sort()
+        return (rb[:n], rc[:n], rg[:n], rf[:n], st[:n]), rows
 
     def commit(self, gidx, bnum, bcoord, slot, median_cp, c_kind=None):
         """PISM.handleBatchedCommit/handleCommittedRequest for a batch of committed slots."""

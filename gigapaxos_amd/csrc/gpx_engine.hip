@@ -402,7 +402,8 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
                          (const void*)k_bucket_ar<16>,     (const void*)k_bucket_propose<4>,
                          (const void*)k_bucket_propose<8>, (const void*)k_bucket_propose<16>,
                          (const void*)k_bucket_accept,     (const void*)k_bucket_commit,
-                         (const void*)k_bucket_pack_ar,    (const void*)k_bucket_reqbatch};
+                         (const void*)k_bucket_pack_ar,    (const void*)k_bucket_reqbatch,
+                         (const void*)k_bucket_prepare};
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bucket_lds));
   }

@@ -1503,6 +1503,86 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_direct(
 }
 
 /* ------------------------------------------------------------------------- */
+/* view change, acceptor side                                                   */
+/* PISM.handlePrepare (PISM:900-1006) -> PaxosAcceptor.handlePrepare (PaxosAcceptor.java:239-273).
+ * Record payload (k_scatter_ac): a = firstUndecidedSlot, bnum / bcoord = the prepare's ballot. */
+struct PrepOut {
+  int32_t n;
+  int32_t *r_bnum, *r_bcoord, *r_gc;
+  uint8_t* r_flags;
+  unsigned long long* p_mask;
+  int32_t *p_slot, *p_bnum, *p_bcoord; /* [W][n] */
+  uint8_t* status;
+};
+__global__ __launch_bounds__(1024) void k_bucket_prepare(DevState S, DevScratch X, PrepOut O) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  BucketView bv;
+  if (!bucket_prepare(X, lds, &bv, []() {})) return;
+  const int32_t g0 = blockIdx.x << X.shift;
+  for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
+    const int32_t c = bv.lcnt[l];
+    const int32_t g = g0 + l;
+    if (c == 0 || g >= S.G) continue;
+    GroupIter it;
+    it.init(bv, l, c);
+    const uint32_t gf = S.g_flags[g];
+    const bool exists = (gf & GF_EXISTS) != 0, stopped = (gf & GF_STOPPED) != 0;
+    int32_t bn = exists ? S.a_bnum[g] : 0, bc = exists ? S.a_bcoord[g] : 0;
+    const int32_t bn0 = bn, bc0 = bc;
+    const int32_t gc = exists ? S.a_gc[g] : 0;
+    unsigned long long n_drop = 0;
+    Rec r;
+    while (it.next(r)) {
+      const int32_t ix = r.idx, first = r.a;
+      O.r_bnum[ix] = 0;
+      O.r_bcoord[ix] = 0;
+      O.r_gc[ix] = 0;
+      O.r_flags[ix] = 0;
+      O.p_mask[ix] = 0;
+      if (!exists || stopped) { /* isStopped() -> null (PaxosAcceptor.java:241-242) */
+        O.status[ix] = exists ? GPX_S_STOPPED : GPX_S_NOGROUP;
+        n_drop++;
+        continue;
+      }
+      const int32_t pn = bn, pc = bc; /* prevBallot (PISM:903) */
+      if (ballot_cmp(r.bnum, r.bcoord, bn, bc) > 0) { /* strictly greater: adopt (:246-252) */
+        bn = r.bnum;
+        bc = r.bcoord;
+      }
+      const bool nack = ballot_cmp(bn, bc, r.bnum, r.bcoord) > 0;
+      unsigned long long mask = 0;
+      if (!nack) {
+        /* pruneAcceptedProposals: keep slot - firstUndecidedSlot >= 0 (:283-293) */
+        for (int32_t w = 0; w < S.W; w++) {
+          const int64_t o = (int64_t)w * S.G + g;
+          if (!(S.acc_flags[o] & RF_PRESENT)) continue;
+          const I4 a = S.acc_ring[o];
+          if (jsub(a.x, first) < 0) continue;
+          mask |= 1ull << w;
+          const int64_t q = (int64_t)w * O.n + ix;
+          O.p_slot[q] = a.x;
+          O.p_bnum[q] = a.y;
+          O.p_bcoord[q] = a.z;
+        }
+      }
+      O.r_bnum[ix] = bn;
+      O.r_bcoord[ix] = bc;
+      /* getMaxGCSlotFirstUndecidedSlot (:275-280) */
+      const int32_t fm1 = jsub(first, 1);
+      O.r_gc[ix] = jsub(gc, fm1) < 0 ? fm1 : gc;
+      O.r_flags[ix] = (uint8_t)((nack ? GPX_P_NACK : 0) | (ballot_cmp(pn, pc, bn, bc) < 0 ? GPX_P_TOLOG : 0));
+      O.p_mask[ix] = mask;
+      /* status stays GPX_S_OK (k_hist) */
+    }
+    if (exists && (bn != bn0 || bc != bc0)) {
+      S.a_bnum[g] = bn;
+      S.a_bcoord[g] = bc;
+    }
+    if (n_drop) atomicAdd(&X.counters[2], n_drop);
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* RequestBatcher (RequestBatcher.java:111-239)                                  */
 /* The batcher keeps one FIFO per paxosID; every dequeue takes the head of a queue and latches the
  * following requests of that group onto it while the byte and batch-size limits hold

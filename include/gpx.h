@@ -262,6 +262,35 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
                          const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx,
                          int32_t* x_first, int32_t* x_count, int32_t* n_runs);
 
+/* ---- view change, acceptor side ------------------------------------------------ */
+
+#define GPX_P_NACK 1  /* the acceptor's ballot is higher than the prepare's: no pvalues returned */
+#define GPX_P_TOLOG 2 /* the acceptor's ballot went up: the PREPARE must be logged before the reply
+                         leaves (LogMessagingTask, PaxosInstanceStateMachine.java:985-993) */
+/*
+ * replaces: PISM.handlePrepare (PaxosInstanceStateMachine.java:900-1006) ->
+ * PaxosAcceptor.handlePrepare (PaxosAcceptor.java:239-273) + pruneAcceptedProposals (:283-293) +
+ * getMaxGCSlotFirstUndecidedSlot (:275-280) for n PREPAREs at once (a coordinator node dies and
+ * every group it led runs an election: each surviving acceptor receives one PREPARE per group).
+ * Record i = PreparePacket(ballot (bnum, bcoord), first_slot = firstUndecidedSlot) for gidx[i].
+ * Dense outputs: the PREPARE_REPLY's ballot (r_bnum, r_bcoord), r_gc = max(acceptedGCSlot,
+ * firstUndecidedSlot - 1) (wraparound-aware), r_flags = GPX_P_*, and the in-memory accepted
+ * pvalues with slot - firstUndecidedSlot >= 0 of an acknowledged prepare as `window` planes of n
+ * entries each: p_mask[i] bit w set => (p_slot[w * n + i], p_bnum[w * n + i], p_bcoord[w * n + i])
+ * is one (the host adds the disk-logged accepts, GET_ACCEPTED_PVALUES_FROM_DISK, and the values).
+ * status: GPX_S_OK, GPX_S_STOPPED (no reply), GPX_S_NOGROUP.  Only the acceptor's ballot changes.
+ * Not modelled: the re-send of this node's own pending higher prepare (coordinators are always
+ * active here, PaxosCoordinator.getPendingBallot == null).
+ */
+int gpx_prepare_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                      const int32_t* bcoord, const int32_t* first_slot, int32_t* r_bnum,
+                      int32_t* r_bcoord, int32_t* r_gc, uint8_t* r_flags, uint64_t* p_mask,
+                      int32_t* p_slot, int32_t* p_bnum, int32_t* p_bcoord, uint8_t* status);
+int gpx_prepare_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                          const int32_t* bcoord, const int32_t* first_slot, int32_t* r_bnum,
+                          int32_t* r_bcoord, int32_t* r_gc, uint8_t* r_flags, uint64_t* p_mask,
+                          int32_t* p_slot, int32_t* p_bnum, int32_t* p_bcoord, uint8_t* status);
+
 /* ---- batching of client requests (RequestBatcher) ----------------------------- */
 
 /*

@@ -74,7 +74,7 @@ def fuzz(ea, eb, G, node_ids, rng, steps, batch, slot_base=1, span=40, my_id=Non
         return bnum, bcoord
 
     for step in range(steps):
-        op = rng.integers(0, 4)
+        op = rng.integers(0, 5)
         n = int(rng.integers(1, batch + 1))
         g = gids(n)
         if op == 0:
@@ -114,6 +114,15 @@ def fuzz(ea, eb, G, node_ids, rng, steps, batch, slot_base=1, span=40, my_id=Non
             da, db = ea.accept_reply(g, bnum, bcoord, sl, acc, mcp), eb.accept_reply(g, bnum, bcoord, sl, acc, mcp)
             assert da.as_tuple_array().tolist() == db.as_tuple_array().tolist(), f"step {step} decisions"
             assert da.status.tolist() == db.status.tolist(), f"step {step} ar status"
+        elif op == 4:
+            # PREPAREs (view change, acceptor side): ballots around the current ones, so that acks,
+            # NACKs and ballot upgrades all occur; firstUndecidedSlot around the live slots
+            bnum, bcoord = ballots(n)
+            first = slots(n)
+            (ra, pa), (rb, pb) = ea.prepare(g, bnum, bcoord, first), eb.prepare(g, bnum, bcoord, first)
+            for x, y, nm in zip(ra, rb, ("r_bnum", "r_bcoord", "r_gc", "r_flags", "status")):
+                assert x.tolist() == y.tolist(), f"step {step} prepare {nm}"
+            assert pa == pb, f"step {step} prepare pvalues"
         else:
             bnum, bcoord = ballots(n)
             sl = slots(n)

@@ -379,3 +379,30 @@ def test_lifecycle_statuses(oracle_lib):
     assert st.tolist() == [S_OK]
     d = e.accept_reply([0, -1, 9], [0] * 3, [100] * 3, [1] * 3, [100] * 3, [0] * 3)
     assert d.status.tolist() == [S_NOGROUP] * 3
+
+
+def test_prepare_acceptor_side(oracle_lib):
+    """PaxosAcceptor.handlePrepare (PaxosAcceptor.java:239-273): adopt a strictly higher ballot, NACK
+    (no pvalues) a lower one, return accepted pvalues with slot >= firstUndecidedSlot, gcSlot =
+    max(acceptedGCSlot, firstUndecidedSlot - 1); log the prepare iff the ballot went up
+    (PISM:985-993); a stopped acceptor does not answer."""
+    from gigapaxos_amd import Engine, hri_create, S_OK, S_STOPPED, S_NOGROUP, A_STOP, C_HASVALUE, C_STOP
+    e = Engine(oracle_lib, 101, 4, kmax=3, window=8)
+    mem = np.tile(np.array([100, 101, 102], np.int32), (3, 1))
+    assert (e.create_groups(np.arange(3), mem, 3, hri_create(3, 3, 100)) == S_OK).all()
+    z = lambda n: np.zeros(n, np.int32)  # noqa: E731
+    c = lambda n: np.full(n, 100, np.int32)  # noqa: E731
+    e.accept([0, 0, 0], z(3), c(3), [1, 2, 3], z(3))            # group 0 accepted slots 1..3 at (0,100)
+    (rb, rc, rg, rf, st), rows = e.prepare([0, 0, 0, 1, 3], [0, 1, 0, 5, 0], [100, 102, 100, 101, 100],
+                                           [2, 2, 1, 1, 1])
+    assert st.tolist() == [S_OK, S_OK, S_OK, S_OK, S_NOGROUP]
+    assert list(zip(rb.tolist(), rc.tolist()))[:4] == [(0, 100), (1, 102), (1, 102), (5, 101)]
+    assert rf.tolist() == [0, 2, 1, 2, 0]                        # ack; upgrade -> TOLOG; NACK; upgrade
+    assert rg.tolist()[:4] == [1, 1, 0, 0]                       # max(gc = -1, first - 1)
+    assert rows == [(0, 2, 0, 100), (0, 3, 0, 100), (1, 2, 0, 100), (1, 3, 0, 100)]  # none for the NACK
+    # a stopped acceptor (executed a stop decision) answers nothing
+    e.commit([2], z(1), c(1), [1], z(1), np.array([C_HASVALUE | C_STOP], np.uint8))
+    (rb, rc, rg, rf, st), rows = e.prepare([2], [9], [102], [1])
+    assert st.tolist() == [S_STOPPED] and rows == [] and rb.tolist() == [0]
+    assert e.dump(2).tolist()[:20] == e.dump(2).tolist()[:20]
+    e.close()
