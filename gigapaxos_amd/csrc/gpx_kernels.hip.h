@@ -369,6 +369,8 @@ __device__ __forceinline__ void put_rec(const DevScratch& X, int32_t* lds, int32
     r.bnum = bnum;
     r.bcoord = bcoord;
     r.pad = 0;
+    /* (non-temporal stores measured: 2.6x slower - the L2 merges the halves of a record and
+     * neighbouring records of a slice before they reach HBM) */
     X.rec[pos] = r;
   }
 }
