@@ -277,13 +277,17 @@ void end_call(gpx_engine* e, int s, std::initializer_list<Range> outputs) {
 void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, int is_votes,
                 int check_order = 0) {
   const int ntiles = ntiles_for(n);
-  const size_t lds = (size_t)e->X.nbk * sizeof(int32_t);
+  /* one histogram workgroup per `hsub` scatter tiles: about one workgroup per CU */
+  int hsub = std::max(1, std::min(GPX_HSUB_MAX, (ntiles + 127) / 245));
+  if (const char* hs = getenv("GPX_HSUB")) hsub = std::max(1, std::min(GPX_HSUB_MAX, atoi(hs))); /* tuning */
+  const int nsuper = (ntiles + hsub - 1) / hsub;
+  const size_t lds = (size_t)hsub * e->X.nbk * sizeof(int32_t);
   if (aligned16({gidx}))
-    LAUNCH_F(e, "k_hist", k_hist<true>, tile_grid(ntiles), lds, n, ntiles, gidx, e->S.G, e->X, status,
-             is_votes, check_order);
+    LAUNCH_F(e, "k_hist", k_hist<true>, tile_grid(nsuper), lds, n, ntiles, gidx, e->S.G, e->X, status,
+             is_votes, check_order, hsub);
   else
-    LAUNCH_F(e, "k_hist", k_hist<false>, tile_grid(ntiles), lds, n, ntiles, gidx, e->S.G, e->X, status,
-             is_votes, check_order);
+    LAUNCH_F(e, "k_hist", k_hist<false>, tile_grid(nsuper), lds, n, ntiles, gidx, e->S.G, e->X, status,
+             is_votes, check_order, hsub);
 }
 
 int check_batch(gpx_engine* h, int32_t n) {
@@ -406,6 +410,13 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
                          (const void*)k_bucket_prepare};
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bucket_lds));
+  }
+  { /* k_hist may take up to GPX_HSUB_MAX histograms of dynamic LDS */
+    const int hl = GPX_HSUB_MAX * X.nbk * (int)sizeof(int32_t);
+    if (hl > 64 * 1024) {
+      HIPCHK(hipFuncSetAttribute((const void*)k_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, hl));
+      HIPCHK(hipFuncSetAttribute((const void*)k_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, hl));
+    }
   }
   for (auto& f : e->fs) { /* double-buffered front-end scratch */
     A(f.bucket_tot, (size_t)X.nbk, true);

@@ -75,8 +75,18 @@ __device__ __forceinline__ Out mk_out(int32_t gidx, int32_t slot, int32_t x, int
 #define GPX_FBLOCK 1024 /* threads of a streaming (histogram / scatter / compaction) workgroup */
 #endif
 #ifndef GPX_TILE
-#define GPX_TILE 8192 /* records per streaming workgroup */
+#define GPX_TILE 4096 /* records per scatter workgroup */
 #endif
+#define GPX_HSUB_MAX 8 /* most scatter tiles one histogram workgroup covers (LDS: 16 KiB each) */
+/* Two tile sizes on purpose.  k_scatter_* is bound by what ONE CU can push out, so its tiles must
+ * spread evenly over the 256 CUs x 2 resident workgroups: 3 M records in 8192-record tiles are 366
+ * workgroups - 110 CUs carry two, 146 carry one, and the kernel lasts as long as the loaded ones
+ * (88 us); in 4096-record tiles it is 66 us.  k_hist pays one returning atomic per (workgroup,
+ * touched bucket) on only nbk addresses, so IT wants few, big tiles: one histogram workgroup covers
+ * `hsub` consecutive scatter tiles - chosen per call so that there are about 245 histogram
+ * workgroups, one per CU: 3 tiles = 12,288 records for 3 M votes - keeps one LDS histogram per
+ * sub-tile, reserves the bucket slices of all of them with one atomic and hands
+ * each sub-tile its share. */
 #define GPX_TILE_ITEMS (GPX_TILE / GPX_FBLOCK)
 #define GPX_TILE_VECS (GPX_TILE_ITEMS / 4)
 #define GPX_SCAN_ITEMS 8 /* records per thread in the output-flag kernels (one 8-byte load) */
@@ -277,31 +287,36 @@ template <bool VEC>
 __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
                                                     const int32_t* __restrict__ gidx, int32_t G,
                                                     DevScratch X, uint8_t* __restrict__ status,
-                                                    int32_t is_votes, int32_t check_order) {
-  extern __shared__ int32_t lds[];
-  const int32_t tile = tile_of_block(ntiles);
-  if (tile >= ntiles) return;
-  for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_FBLOCK) lds[b] = 0;
+                                                    int32_t is_votes, int32_t check_order,
+                                                    int32_t hsub) {
+  extern __shared__ int32_t lds[]; /* [hsub][nbk] */
+  const int32_t nsuper = (ntiles + hsub - 1) / hsub;
+  const int32_t st = tile_of_block(nsuper);
+  if (st >= nsuper) return;
+  for (int32_t b = threadIdx.x; b < hsub * X.nbk; b += GPX_FBLOCK) lds[b] = 0;
   __syncthreads();
-  const int64_t base = (int64_t)tile * GPX_TILE;
-  const int32_t bad = tile_histogram<VEC>(n, base, gidx, G, X.shift, lds);
+  const int64_t base = (int64_t)st * hsub * GPX_TILE;
+  const int64_t end = base + (int64_t)hsub * GPX_TILE;
+  int32_t bad = 0;
+  for (int sub = 0; sub < hsub; sub++)
+    bad += tile_histogram<VEC>(n, base + (int64_t)sub * GPX_TILE, gidx, G, X.shift, lds + sub * X.nbk);
   if (check_order) {
     /* strictly ascending, in-range gidx = every group at most once: such a batch needs no
      * regrouping (k_propose_direct); anything else marks the call's epoch in *X.unsorted */
     bool out_of_order = bad != 0;
-    for (int64_t i = base + threadIdx.x; i < base + GPX_TILE && i + 1 < n; i += GPX_FBLOCK)
+    for (int64_t i = base + threadIdx.x; i < end && i + 1 < n; i += GPX_FBLOCK)
       out_of_order |= gidx[i] >= gidx[i + 1];
     if (__syncthreads_or(out_of_order) && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
   }
   /* status: 8 consecutive records per lane */
   if (status)
-  for (int64_t i0 = base + (int64_t)threadIdx.x * 8; i0 < base + GPX_TILE; i0 += GPX_FBLOCK * 8) {
+  for (int64_t i0 = base + (int64_t)threadIdx.x * 8; i0 < end; i0 += GPX_FBLOCK * 8) {
     if (i0 + 7 < n && !((uintptr_t)status & 7)) {
       {
-        unsigned long long st = 0;
+        unsigned long long stw = 0;
         for (int q = 0; q < 8; q++)
-          if ((uint32_t)gidx[i0 + q] >= (uint32_t)G) st |= (unsigned long long)GPX_S_NOGROUP << (8 * q);
-        *(unsigned long long*)(status + i0) = st; /* GPX_S_OK == 0; PaxosManager.java:1162-1194 */
+          if ((uint32_t)gidx[i0 + q] >= (uint32_t)G) stw |= (unsigned long long)GPX_S_NOGROUP << (8 * q);
+        *(unsigned long long*)(status + i0) = stw; /* GPX_S_OK == 0; PaxosManager.java:1162-1194 */
       }
     } else {
       for (int q = 0; q < 8; q++) {
@@ -312,15 +327,21 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
   }
   /* is_votes < 0: a regrouping pass over records an earlier call already counted */
   if (bad && is_votes >= 0) atomicAdd(&X.counters[2], (unsigned long long)bad);
-  if (tile == 0 && threadIdx.x == 0 && is_votes > 0) atomicAdd(&X.counters[0], (unsigned long long)n);
+  if (st == 0 && threadIdx.x == 0 && is_votes > 0) atomicAdd(&X.counters[0], (unsigned long long)n);
   __syncthreads();
-  /* reserve this tile's slice of every bucket region: one returning atomic per touched bucket.
+  /* reserve the slices of this workgroup's sub-tiles in every bucket region: one returning atomic
+   * per touched bucket for all of them; sub-tile `sub` starts behind its predecessors' records.
    * The order of the slices inside a region is whatever the atomics give (records carry their
    * arrival index; the per-bucket kernels restore arrival order per group). */
-  int32_t* rel = X.tile_rel + (int64_t)tile * X.nbk;
   for (int32_t b = threadIdx.x; b < X.nbk; b += GPX_FBLOCK) {
-    const int32_t c = lds[b];
-    rel[b] = c ? atomicAdd(&X.bucket_tot[b], c) : 0;
+    int32_t tot = 0;
+    for (int sub = 0; sub < hsub; sub++) tot += lds[sub * X.nbk + b];
+    int32_t rel = tot ? atomicAdd(&X.bucket_tot[b], tot) : 0;
+    for (int sub = 0; sub < hsub; sub++) {
+      const int32_t tile = st * hsub + sub;
+      if (tile < ntiles) X.tile_rel[(int64_t)tile * X.nbk + b] = rel;
+      rel += lds[sub * X.nbk + b];
+    }
   }
 }
 
