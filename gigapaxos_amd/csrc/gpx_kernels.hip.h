@@ -376,24 +376,53 @@ __device__ __forceinline__ void scatter_init(const DevScratch& X, int32_t tile, 
   __syncthreads();
 }
 
+/* value of the neighbouring lane (lane ^ 1): DPP quad_perm [1,0,3,2], no LDS traffic */
+__device__ __forceinline__ int32_t lane_xor1(int32_t v) {
+  return __builtin_amdgcn_mov_dpp(v, 0xB1, 0xF, 0xF, true);
+}
+
+/* Writes this lane's 32-byte record r to base[pos] (pos < 0: nothing to write) together with its
+ * neighbour lane: a lane can store 16 bytes per instruction, so a record written by ONE lane is two
+ * requests of 16 bytes each whatever its address - k_scatter_ar issued 6 M of them for 3 M votes
+ * and was bound by that, not by HBM (storing the records coalesced at their arrival index took
+ * just as long).  Here the even lane writes the low halves and the odd lane the high halves of
+ * both lanes' records: each store instruction then has lane pairs on 32 contiguous bytes, which
+ * leave the CU as one request. */
+__device__ __forceinline__ void store_rec_pair(void* __restrict__ base32, int32_t pos, const I4 lo,
+                                               const I4 hi) {
+  I4* base = (I4*)base32; /* element pos = the two I4 at base[2 * pos], base[2 * pos + 1] */
+  const int lane = (int)__lane_id();
+  const unsigned long long act = __ballot(1);
+  if (!((act >> (lane ^ 1)) & 1ull)) { /* neighbour not here (tail of the batch): write it alone */
+    if (pos >= 0) {
+      base[2 * (int64_t)pos] = lo;
+      base[2 * (int64_t)pos + 1] = hi;
+    }
+    return;
+  }
+  const bool odd = (lane & 1) != 0;
+  /* the half the neighbour writes for me goes over; its half for me comes back */
+  const int32_t sx = odd ? lo.x : hi.x, sy = odd ? lo.y : hi.y, sz = odd ? lo.z : hi.z,
+                sw = odd ? lo.w : hi.w;
+  const int32_t rx = lane_xor1(sx), ry = lane_xor1(sy), rz = lane_xor1(sz), rw = lane_xor1(sw);
+  const int32_t pos_n = lane_xor1(pos);
+  const int32_t pos_even = odd ? pos_n : pos, pos_odd = odd ? pos : pos_n;
+  const int32_t half = odd ? 1 : 0;
+  if (pos_even >= 0) /* the even lane's record: even lane writes its lo, odd lane the hi it received */
+    base[2 * (int64_t)pos_even + half] = odd ? mk4(rx, ry, rz, rw) : lo;
+  if (pos_odd >= 0) /* the odd lane's record: even lane writes the lo it received, odd lane its hi */
+    base[2 * (int64_t)pos_odd + half] = odd ? hi : mk4(rx, ry, rz, rw);
+}
+
 __device__ __forceinline__ void put_rec(const DevScratch& X, int32_t* lds, int32_t G, int32_t mask,
                                         int64_t i, int32_t g, int32_t a, int32_t b, int32_t c,
                                         int32_t bnum, int32_t bcoord) {
-  if ((uint32_t)g < (uint32_t)G) {
-    const int32_t pos = bucket_take(lds, g >> X.shift);
-    Rec r;
-    r.idx = (int32_t)i;
-    r.lg = g & mask;
-    r.a = a;
-    r.b = b;
-    r.c = c;
-    r.bnum = bnum;
-    r.bcoord = bcoord;
-    r.pad = 0;
-    /* (non-temporal stores measured: 2.6x slower - the L2 merges the halves of a record and
-     * neighbouring records of a slice before they reach HBM) */
-    X.rec[pos] = r;
-  }
+  int32_t pos = -1;
+  if ((uint32_t)g < (uint32_t)G) pos = bucket_take(lds, g >> X.shift);
+  /* Rec = {idx, lg, a, b | c, bnum, bcoord, pad}
+   * (non-temporal stores measured: 2.6x slower - the L2 merges neighbouring records of a slice
+   * before they reach HBM) */
+  store_rec_pair(X.rec, pos, mk4((int32_t)i, g & mask, a, b), mk4(c, bnum, bcoord, 0));
 }
 
 /* accept-reply votes */
@@ -825,9 +854,17 @@ __device__ __forceinline__ void bucket_emit(const DevScratch& X, const BucketVie
     const int32_t l = threadIdx.x * per + q;
     const int32_t d = bv.lcnt[l];
     const unsigned long long* kk = bv.keys + bv.loff[l];
-    for (int32_t t = 0; t < d; t++) {
-      const int32_t* p = bv.pay + (int64_t)(uint32_t)kk[t] * bv.rs;
-      dst[ex + t] = mk_out(g0 + l, p[0], p[bv.fs], p[2 * bv.fs], p[3 * bv.fs], p[4 * bv.fs]);
+    /* rows are 32 bytes: written by lane pairs (store_rec_pair), all lanes of the wave in step */
+    for (int32_t t = 0; __any(t < d); t++) {
+      int32_t pos = -1;
+      I4 lo = mk4(0, 0, 0, 0), hi = mk4(0, 0, 0, 0);
+      if (t < d) {
+        const int32_t* p = bv.pay + (int64_t)(uint32_t)kk[t] * bv.rs;
+        pos = ex + t;
+        lo = mk4(g0 + l, p[0], p[bv.fs], p[2 * bv.fs]);   /* Out = {gidx, slot, x, y | z, kind, 0, 0} */
+        hi = mk4(p[3 * bv.fs], p[4 * bv.fs], 0, 0);
+      }
+      store_rec_pair(dst, pos, lo, hi);
     }
     ex += d;
   }
