@@ -3,24 +3,26 @@
  *
  * Integer / indexing work only: HBM-bound, no MFMA.  Wave = 64 lanes everywhere.
  *
- * Pipeline of every batch call.  Groups are binned into BUCKETS of
- * GB = 2^shift consecutive group indices; a batch is partitioned by bucket with LDS histograms
- * (no global atomics anywhere on the data path), then ONE WORKGROUP PER BUCKET regroups its
- * records by group in LDS-counted order and ONE LANE PER GROUP replays them in arrival order:
+ * Pipeline of every batch call.  Groups are binned into BUCKETS of GB = 2^shift
+ * consecutive group indices; a batch is partitioned by bucket in one pass, then ONE WORKGROUP PER
+ * BUCKET regroups its records by group in LDS and ONE LANE PER GROUP replays them in arrival order:
  *
- *   k_hist          one workgroup per 4096-record tile: LDS histogram over buckets -> tile_hist
- *   k_colscan       per bucket: exclusive scan of tile_hist down the tiles (in chunks)
- *   k_bucket_offs   per bucket: scan of the chunk sums; exclusive scan over buckets -> bucket_off
- *   k_scatter_*     per tile: record i is packed into a 32-byte Rec and written to its bucket's
- *                   region (LDS cursor per bucket) — bucket-contiguous, any order inside
- *   k_bucket_*      per bucket: LDS count per local group -> scan -> perm (records of one group
- *                   contiguous); long segments (> 16) get a cooperative arrival-order sort;
- *                   then one lane per group loads its SoA state (coalesced: consecutive lanes own
- *                   consecutive groups), replays the group's records in ARRIVAL ORDER exactly as
- *                   PaxosInstanceStateMachine.handlePaxosMessage would, once per record, and
- *                   writes per-record dense outputs at the record's arrival index
- *   compact         scan of the per-record output flags + LDS-staged ordered gather, so
- *                   decisions / exec runs leave in the arrival order of the record that made them
+ *   k_hist          one workgroup per `hsub` tiles of 4096 records: LDS histograms over buckets; one
+ *                   returning atomic per touched bucket reserves the tiles' slices of the bucket
+ *                   regions (tile_rel); also the common per-record status and, for proposals, whether
+ *                   the gidx column is strictly ascending
+ *   k_scatter_*     per tile: every workgroup scans the bucket totals itself, then packs record i into
+ *                   a 32-byte Rec and writes it to its bucket's region (LDS cursor per bucket; lane
+ *                   pairs write one record per request) — bucket-contiguous, any order inside
+ *   k_bucket_*      per bucket: LDS count per local group -> scan -> keys grouped by group; long
+ *                   segments (> 16) get a cooperative arrival-order sort; then one lane per group loads
+ *                   its SoA state (coalesced: consecutive lanes own consecutive groups; prefetched at
+ *                   kernel entry for dense batches), replays the group's records in ARRIVAL ORDER
+ *                   exactly as PaxosInstanceStateMachine.handlePaxosMessage would, once per record;
+ *                   dense per-record outputs go to the record's arrival index, compacted outputs
+ *                   (decisions / exec runs / batches) leave as one run of 32-byte rows per bucket
+ *   k_emit_*        per bucket: rows -> the caller's dense SoA columns, buckets in order
+ *   k_propose_direct  proposals whose gidx column is strictly ascending need no regrouping
  *
  * Each device function cites the reference method it implements (paths relative to
  * /root/reference/src/edu/umass/cs/gigapaxos/).
