@@ -1,0 +1,109 @@
+#!/usr/bin/env python
+"""Whole-protocol round on one MI355X (not the judged bench line; numbers go to DESIGN.md §5).
+
+Three engines = the three replicas of every group (BASELINE config #2's shape at config #3's size),
+all on one GPU, columns resident in HBM.  One round =
+  coordinator: propose(G)                       -> ACCEPT (slot, ballot) per group
+  3 acceptors: accept(G) each                   -> replies
+  coordinator: accept_reply(3 G shuffled votes) -> G decisions
+  3 replicas:  commit(G) each                   -> in-order execution runs
+Per-phase GPU time with torch events; per-kernel split from the engines' hipEvent profile."""
+import argparse
+import json
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gigapaxos_amd import Engine, hri_create, load_hip, S_OK, C_HASVALUE  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--groups", type=int, default=1_000_000)
+    ap.add_argument("--rounds", type=int, default=8)
+    args = ap.parse_args()
+    G, K = args.groups, 3
+    ids = [100, 101, 102]
+    dev = torch.device("cuda:0")
+    ts = torch.cuda.Stream(device=dev)
+    torch.cuda.set_stream(ts)
+    mem = np.tile(np.array(ids, np.int32), (G, 1))
+    eng = {}
+    for nid in ids:
+        e = Engine(load_hip(), nid, G, kmax=K, window=8, max_batch=3 * G + 1024)
+        assert (e.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
+        e.set_stream(ts.cuda_stream)
+        eng[nid] = e
+    i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)  # noqa: E731
+    P = lambda t: t.data_ptr()  # noqa: E731
+    g_all = torch.arange(G, dtype=torch.int32, device=dev)
+    p_slot, p_bnum, p_bcoord, p_med, p_st = i32(G), i32(G), i32(G), i32(G), u8(G)
+    rep = {nid: [i32(G), i32(G), i32(G), u8(G), u8(G)] for nid in ids}       # r_bnum r_bcoord r_maxcp r_flags status
+    runs = {nid: [i32(G), i32(G), i32(G), torch.zeros(1, dtype=torch.int32, device=dev)] for nid in ids}
+    v = [i32(3 * G) for _ in range(6)]
+    d = [i32(3 * G) for _ in range(5)] + [u8(3 * G)]
+    n_out, v_st = torch.zeros(1, dtype=torch.int32, device=dev), u8(3 * G)
+    ckind = torch.full((G,), C_HASVALUE, dtype=torch.uint8, device=dev)
+    c_st = u8(G)
+    rng = np.random.default_rng(0)
+    perms = [torch.from_numpy(rng.permutation(3 * G)).to(dev) for _ in range(2)]
+    acc_col = torch.cat([torch.full((G,), nid, dtype=torch.int32, device=dev) for nid in ids])
+    t = {"propose": 0.0, "accept_x3": 0.0, "accept_reply": 0.0, "commit_x3": 0.0}
+    for r in range(args.rounds):
+        if r == 1:
+            for e in eng.values():
+                e.profile(2)
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        eng[100].call_dev("propose_batch", G, P(g_all), 0, P(p_slot), P(p_bnum), P(p_bcoord), P(p_med), P(p_st))
+        ev[1].record()
+        for nid in ids:
+            rb, rc, rm, rf, st = rep[nid]
+            xg, xf, xc, nr = runs[nid]
+            eng[nid].call_dev("accept_batch", G, P(g_all), P(p_bnum), P(p_bcoord), P(p_slot), P(p_med), 0,
+                              P(rb), P(rc), P(rm), P(rf), P(st), P(xg), P(xf), P(xc), P(nr))
+        ev[2].record()
+        # the replies of the three acceptors, shuffled, as the coordinator's vote columns
+        pm = perms[r & 1]
+        cat = lambda k: torch.cat([rep[nid][k] for nid in ids])  # noqa: E731
+        v[0].copy_(g_all.repeat(3)[pm]); v[1].copy_(cat(0)[pm]); v[2].copy_(cat(1)[pm])
+        v[3].copy_(p_slot.repeat(3)[pm]); v[4].copy_(acc_col[pm]); v[5].copy_(cat(2)[pm])
+        ev2b = torch.cuda.Event(enable_timing=True)
+        ev2b.record()
+        eng[100].call_dev("accept_reply_batch", 3 * G, *[P(x) for x in v], *[P(x) for x in d], P(n_out), P(v_st))
+        ev[3].record()
+        for nid in ids:
+            xg, xf, xc, nr = runs[nid]
+            eng[nid].call_dev("commit_batch", G, P(d[0]), P(d[2]), P(d[3]), P(d[1]), P(d[4]), P(ckind), P(c_st),
+                              P(xg), P(xf), P(xc), P(nr))
+        ev[4].record()
+        for e in eng.values():
+            e.sync()
+        torch.cuda.synchronize()
+        assert int(n_out) == G, int(n_out)
+        for nid in ids:
+            assert int(runs[nid][3]) == G and bool((runs[nid][2][:G] == 1).all())
+        if r > 0:
+            t["propose"] += ev[0].elapsed_time(ev[1])
+            t["accept_x3"] += ev[1].elapsed_time(ev[2])
+            t["accept_reply"] += ev2b.elapsed_time(ev[3])
+            t["commit_x3"] += ev[3].elapsed_time(ev[4])
+    k = args.rounds - 1
+    kern = {}
+    for nid, e in eng.items():
+        for name, (cnt, ms) in e.profile_read().items():
+            kern[name] = kern.get(name, 0.0) + ms * 1e3 / k
+    tot = sum(t.values()) / k
+    print(json.dumps({"groups": G, "replicas": K, "ms_per_round": round(tot, 4),
+                      "phases_ms": {a: round(b / k, 4) for a, b in t.items()},
+                      "decided_and_executed_per_s": round(G / tot * 1e3, 1),
+                      "kernels_us_per_round": {a: round(b, 1) for a, b in sorted(kern.items())}}))
+
+
+if __name__ == "__main__":
+    main()
