@@ -1711,6 +1711,64 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_fill_i32(int32_t n, int32_t v, in
 }
 
 /* ------------------------------------------------------------------------- */
+/* PISM.checkRunForCoordinator's decision (PISM:2090-2176), one lane per group    */
+#define GPX_MAX_NODE_LIST 16
+struct NodeLists {
+  int32_t n_down, n_long;
+  int32_t down[GPX_MAX_NODE_LIST], longdead[GPX_MAX_NODE_LIST];
+};
+__global__ __launch_bounds__(GPX_BLOCK) void k_election_scan(DevState S, int32_t n,
+                                                            const int32_t* __restrict__ gidx,
+                                                            NodeLists L, int32_t force,
+                                                            uint8_t* __restrict__ run,
+                                                            int32_t* __restrict__ p_bnum,
+                                                            int32_t* __restrict__ p_first,
+                                                            uint8_t* __restrict__ status) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t g = gidx ? gidx[i] : i;
+  run[i] = GPX_RUN_NO;
+  p_bnum[i] = 0;
+  p_first[i] = 0;
+  if ((uint32_t)g >= (uint32_t)S.G || !(S.g_flags[g] & GF_EXISTS)) {
+    status[i] = GPX_S_NOGROUP;
+    return;
+  }
+  status[i] = GPX_S_OK;
+  const uint32_t gf = S.g_flags[g];
+  const int32_t k = (int32_t)GF_K(gf);
+  const int32_t bn = S.a_bnum[g], bc = S.a_bcoord[g]; /* curBallot = paxosState.getBallot() */
+  /* PaxosCoordinator.exists(coordinator, curBallot): coordinator != null && its ballot >= curBallot */
+  const bool have = (gf & GF_HASCOORD) && ballot_cmp(S.c_bnum[g], S.c_bcoord[g], bn, bc) >= 0;
+  bool down = false, longdead = false;
+  for (int32_t q = 0; q < L.n_down; q++) down |= L.down[q] == bc;
+  for (int32_t q = 0; q < L.n_long; q++) longdead |= L.longdead[q] == bc;
+  /* getNextCoordinator: the member after the coordinator, members ascending, wrapping (:2231-2240) */
+  int32_t next = INT32_MIN;
+  bool member = false;
+  for (int32_t q = 0; q < k; q++)
+    if (S.members[(int64_t)q * S.G + g] == bc) {
+      next = S.members[(int64_t)((q + 1) % k) * S.G + g];
+      member = true;
+    }
+  int32_t why = GPX_RUN_NO;
+  if (!have) {
+    if (bc == S.my_id)
+      why = GPX_RUN_MINE;
+    else if (down && member && next == S.my_id)
+      why = GPX_RUN_NEXT;
+    else if (down && longdead)
+      why = GPX_RUN_LONGDEAD;
+  }
+  if (why == GPX_RUN_NO && force) why = GPX_RUN_FORCED;
+  if (why != GPX_RUN_NO) {
+    run[i] = (uint8_t)why;
+    p_bnum[i] = (int32_t)((uint32_t)bn + 1u); /* new Ballot(curBallot.ballotNumber + 1, myID) */
+    p_first[i] = S.a_slot[g];                 /* new PreparePacket(newBallot, paxosState.getSlot()) */
+  }
+}
+
+/* ------------------------------------------------------------------------- */
 /* gap detection (PaxosAcceptor.getMissingCommittedSlots / getMaxCommittedSlot,  */
 /* PaxosAcceptor.java:405-438; PISM.shouldSync, PISM:2341-2364)                  */
 /* One lane per listed group.  The committed window holds slots in [_slot, _slot + W), so the

@@ -383,6 +383,7 @@ _EXTRA_SIGS = {
     "names_coordinator": [C.c_int32, _VP, C.c_int32, _VP],
     "request_batch": [C.c_int32, _VP, _VP, _VP, _VP, C.c_int32, C.c_int32] + [_VP] * 9,
     "gap_scan": [C.c_int32, _VP, C.c_int32, C.c_int32, C.c_int32] + [_VP] * 5,
+    "election_scan": [C.c_int32, _VP, _VP, C.c_int32, _VP, C.c_int32, C.c_int32] + [_VP] * 4,
 }
 _EXTRA_DEV_SIGS = {"request_batch_dev": _EXTRA_SIGS["request_batch"]}
 WIRE_EXPORTED_SYMBOLS += list(_EXTRA_SIGS) + list(_EXTRA_DEV_SIGS)
@@ -431,3 +432,21 @@ def gap_scan(we: WireEngine, gidx, threshold, sync_mode=SYNC_DEFAULT, size_limit
     we.lib.check(we.lib.fn["gap_scan"](we.e.h, n, _p(gidx), int(threshold), int(sync_mode), int(size_limit),
                                        _p(first), _p(maxc), _p(missing), _p(sync), _p(st)), "gap_scan")
     return first, maxc, missing, sync, st
+
+
+def election_scan(we: WireEngine, gidx, down_nodes=(), long_dead_nodes=(), force=False):
+    """PISM.checkRunForCoordinator's decision per group: (run reason, PREPARE ballot number,
+    firstUndecidedSlot, status).  gidx None = all groups 0 .. max_groups-1."""
+    if gidx is None:
+        n, g = int(we.e.cfg.max_groups), None
+    else:
+        g = _i32(gidx)
+        n = g.shape[0]
+    dn = np.ascontiguousarray(list(down_nodes), dtype=np.int32)
+    ld = np.ascontiguousarray(list(long_dead_nodes), dtype=np.int32)
+    run, st = np.zeros(max(n, 1), np.uint8), np.zeros(max(n, 1), np.uint8)
+    pb, pf = np.zeros(max(n, 1), np.int32), np.zeros(max(n, 1), np.int32)
+    we.lib.check(we.lib.fn["election_scan"](we.e.h, n, _p(g), _p(dn) if dn.size else None, int(dn.size),
+                                            _p(ld) if ld.size else None, int(ld.size), int(bool(force)),
+                                            _p(run), _p(pb), _p(pf), _p(st)), "election_scan")
+    return run[:n], pb[:n], pf[:n], st[:n]

@@ -291,6 +291,32 @@ int gpx_prepare_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const i
                           int32_t* r_bcoord, int32_t* r_gc, uint8_t* r_flags, uint64_t* p_mask,
                           int32_t* p_slot, int32_t* p_bnum, int32_t* p_bcoord, uint8_t* status);
 
+/* ---- view change: who runs for coordinator ------------------------------------ */
+
+#define GPX_RUN_NO 0
+#define GPX_RUN_MINE 1      /* I am my acceptor's ballot coordinator but hold no such coordinator */
+#define GPX_RUN_NEXT 2      /* the ballot coordinator is down and I am next in line */
+#define GPX_RUN_LONGDEAD 3  /* it has been down for long (lastCoordinatorLongDead) */
+#define GPX_RUN_FORCED 4    /* forceRun */
+/*
+ * replaces: the decision of PISM.checkRunForCoordinator (PaxosInstanceStateMachine.java:2090-2176)
+ * for n groups at once - the scan a node runs when the failure detector declares another node dead
+ * (PaxosManager.isNodeUp / lastCoordinatorLongDead: passed in as the lists of node ids that are
+ * down / long dead).  For group gidx[i] (gidx == NULL: groups 0 .. n-1) with acceptor ballot
+ * (b, c):   run iff  !(coordinator != null && its ballot >= (b, c))  &&  ( c == me  ||
+ * ( c is down && ( me == next member after c (members ascending, wrapping)  ||  c is long dead ) ) )
+ * or force.  run[i] = GPX_RUN_*; for a running group the PREPARE to multicast is ballot
+ * (p_bnum[i] = b + 1, my_id) with firstUndecidedSlot p_first[i] = the acceptor's slot
+ * (PISM:2153-2160).  status: GPX_S_OK / GPX_S_NOGROUP.  Not modelled (time based, host side):
+ * ranRecently, waitingTooLong (PREPARE retransmission), notRunYet; when the ballot coordinator is not
+ * a member the Java picks a random member as "next" - here nobody is next.  No state changes: the
+ * host hands a running group to its own coordinator code.  Host pointers.
+ */
+int gpx_election_scan(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* down_nodes,
+                      int32_t n_down, const int32_t* long_dead_nodes, int32_t n_long_dead,
+                      int32_t force, uint8_t* run, int32_t* p_bnum, int32_t* p_first,
+                      uint8_t* status);
+
 /* ---- batching of client requests (RequestBatcher) ----------------------------- */
 
 /*

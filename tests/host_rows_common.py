@@ -101,3 +101,35 @@ def gap_run(lib, seed=0):
         out.append([x.tolist() for x in W.gap_scan(we, q, thr, mode, lim)])
     e.close()
     return out
+
+
+def election_run(lib, seed=0):
+    """Groups of mixed size whose acceptor ballots point at various coordinators (moved there by
+    PREPAREs); some groups have a local coordinator at or above that ballot.  The fail-over scan for
+    several (down, long dead) combinations."""
+    rng = np.random.default_rng(seed)
+    G, k = 2000, 5
+    e = Engine(lib, 102, G, kmax=k, window=8, max_batch=1 << 14)
+    we = W.WireEngine(e)
+    ks = rng.integers(1, k + 1, G).astype(np.uint8)
+    members = np.zeros((G, k), np.int32)
+    for g in range(G):
+        others = rng.choice([100, 101, 103, 104, 105, 106], size=ks[g] - 1, replace=False)
+        members[g, :ks[g]] = np.sort(np.concatenate([[102], others]))
+    coord0 = np.array([members[g, rng.integers(0, ks[g])] for g in range(G)], np.int32)
+    created = np.arange(G - 50, dtype=np.int32)
+    assert (e.create_groups(created, members[created], ks[created], hri_create(G - 50, k, coord0[created])) == S_OK).all()
+    # move some acceptor ballots: higher ballots of member and non-member coordinators
+    n = 1200
+    g = rng.integers(0, G, n).astype(np.int32)
+    bn = rng.integers(1, 4, n).astype(np.int32)
+    bc = rng.choice([100, 101, 102, 103, 104, 105, 106, 999], size=n).astype(np.int32)
+    e.prepare(g, bn, bc, np.ones(n, np.int32))
+    out = []
+    q = np.arange(-1, G + 1, dtype=np.int32)
+    for down, longdead, force in (((), (), False), ((100,), (), False), ((100, 104), (104,), False),
+                                  ((100, 101, 103, 104, 105, 106, 999), (999, 105), False), ((), (), True)):
+        out.append([x.tolist() for x in W.election_scan(we, q, down, longdead, force)])
+    out.append([x.tolist() for x in W.election_scan(we, None, (101,), (), False)])
+    e.close()
+    return out

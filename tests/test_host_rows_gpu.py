@@ -27,3 +27,13 @@ def test_round_robin_coordinator_matches_oracle(hip_lib, oracle_lib):
 @pytest.mark.parametrize("seed", [0, 1])
 def test_gap_detection_matches_oracle(hip_lib, oracle_lib, seed):
     assert H.gap_run(hip_lib, seed) == H.gap_run(oracle_lib, seed)
+
+
+def test_election_scan_known_answer(hip_lib):
+    from tests.test_host_rows_oracle import test_election_scan_known_answer as kat
+    kat(hip_lib)
+
+
+@pytest.mark.parametrize("seed", [0, 1])
+def test_election_scan_matches_oracle(hip_lib, oracle_lib, seed):
+    assert H.election_run(hip_lib, seed) == H.election_run(oracle_lib, seed)

@@ -57,3 +57,33 @@ def test_gap_detection_known_answer(oracle_lib):
     assert missing.tolist() == [0b001, 0, 0] and sync.tolist() == [1, 0, 0]  # expectedSlot 1 and gap >= 100/100
     assert W.gap_scan(we, [1], 100, W.SYNC_FORCE)[3].tolist() == [1]
     e.close()
+
+
+def test_election_scan_known_answer(oracle_lib):
+    """PISM.checkRunForCoordinator (PISM:2090-2176): run iff I hold no coordinator at or above my
+    acceptor's ballot AND (its coordinator is me, or it is down and I am the next member after it, or
+    it is long dead); the PREPARE carries ballot (b + 1, me) and firstUndecidedSlot = my slot."""
+    from gigapaxos_amd import Engine, hri_create
+    e = Engine(oracle_lib, 101, 8, kmax=3, window=8)
+    we = W.WireEngine(e)
+    mem = np.array([[100, 101, 102]] * 4 + [[100, 102, 103]] + [[101, 0, 0]], np.int32)
+    ks = np.array([3, 3, 3, 3, 3, 1], np.uint8)
+    #                        group: 0    1    2    3    4    5
+    rows = hri_create(6, 3, np.array([100, 101, 102, 100, 100, 101], np.int32))
+    e.create_groups(np.arange(6), mem, ks, rows)
+    # group 3: the acceptor has promised (2, 102); group 1: I coordinate it already
+    e.prepare([3], [2], [102], [1])
+    run, pb, pf, st = W.election_scan(we, [0, 1, 2, 3, 4, 5, 6], down_nodes=[100])
+    #  0: coordinator 100 down, next after 100 is 101 = me -> NEXT, PREPARE (1, 101) from slot 1
+    #  1: I am the coordinator and hold it -> no        2: coordinator 102 is up -> no
+    #  3: ballot (2,102), 102 up -> no                  4: 100 down but next after 100 is 102 -> no
+    #  5: single member group, mine, held -> no         6: no such group
+    assert run.tolist() == [2, 0, 0, 0, 0, 0, 0] and st.tolist() == [0, 0, 0, 0, 0, 0, 1]
+    assert pb.tolist()[:1] == [1] and pf.tolist()[:1] == [1]
+    run, pb, pf, st = W.election_scan(we, [0, 2, 3, 4], down_nodes=[100, 102], long_dead_nodes=[100])
+    assert run.tolist() == [2, 0, 0, 3]            # 2 / 3: next after 102 is 100, not me; 4: long dead
+    assert pb.tolist() == [1, 0, 0, 1]
+    assert W.election_scan(we, [3], down_nodes=[102], long_dead_nodes=[102])[0].tolist() == [3]
+    assert W.election_scan(we, [3], down_nodes=[102], long_dead_nodes=[102])[1].tolist() == [3]   # (2 + 1, me)
+    assert W.election_scan(we, [1, 2], force=True)[0].tolist() == [4, 4]
+    e.close()
