@@ -1218,11 +1218,12 @@ __device__ __forceinline__ void acc_load(const DevState& S, int32_t g, uint32_t 
   a.stopped = (gf & GF_STOPPED) != 0;
 }
 __device__ __forceinline__ void acc_store(const DevState& S, int32_t g, uint32_t gf,
-                                          const AccState& a) {
-  S.a_slot[g] = a.slot;
-  S.a_bnum[g] = a.bnum;
-  S.a_bcoord[g] = a.bcoord;
-  S.a_gc[g] = a.gc;
+                                          const AccState& a, const AccState& a0) {
+  /* only what changed: every store instruction is a request the CU has to get out */
+  if (a.slot != a0.slot) S.a_slot[g] = a.slot;
+  if (a.bnum != a0.bnum) S.a_bnum[g] = a.bnum;
+  if (a.bcoord != a0.bcoord) S.a_bcoord[g] = a.bcoord;
+  if (a.gc != a0.gc) S.a_gc[g] = a.gc;
   if (a.stopped && !(gf & GF_STOPPED)) S.g_flags[g] = gf | GF_STOPPED;
 }
 
@@ -1237,17 +1238,18 @@ __device__ __forceinline__ void apply_accept_group(
   a.stopped = false;
   const bool exists = (gf & GF_EXISTS) != 0;
   if (exists) acc_load(S, g, gf, a);
+  const AccState a0 = a;
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
   Rec r;
   while (it.next(r)) {
     const int32_t slot = r.a, median = r.b, ix = r.idx;
     const bool stop = (r.c & GPX_A_STOP) != 0;
-    r_bnum[ix] = 0;
-    r_bcoord[ix] = 0;
-    r_maxcp[ix] = 0;
-    r_flags[ix] = 0;
     if (!exists || a.stopped) {
+      r_bnum[ix] = 0;
+      r_bcoord[ix] = 0;
+      r_maxcp[ix] = 0;
+      r_flags[ix] = 0;
       status[ix] = exists ? GPX_S_STOPPED : GPX_S_NOGROUP;
       n_drop++;
       continue;
@@ -1262,6 +1264,10 @@ __device__ __forceinline__ void apply_accept_group(
     const bool ballot_ok = ballot_cmp(r.bnum, r.bcoord, a.bnum, a.bcoord) >= 0;
     const bool will_store = ballot_ok && jsub(slot, a.gc) > 0;
     if (will_store && live && ar.x != slot) {
+      r_bnum[ix] = 0;
+      r_bcoord[ix] = 0;
+      r_maxcp[ix] = 0;
+      r_flags[ix] = 0;
       status[ix] = GPX_S_WINDOW; /* ring slot held by another live accepted slot */
       n_drop++;
       continue;
@@ -1295,7 +1301,7 @@ __device__ __forceinline__ void apply_accept_group(
       }
     }
   }
-  if (exists) acc_store(S, g, gf, a);
+  if (exists) acc_store(S, g, gf, a, a0);
   if (n_drop) atomicAdd(&X.counters[2], n_drop);
 }
 
@@ -1331,6 +1337,7 @@ __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevS
   a.stopped = false;
   const bool exists = (gf & GF_EXISTS) != 0;
   if (exists) acc_load(S, g, gf, a);
+  const AccState a0 = a;
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
   Rec r;
@@ -1365,7 +1372,7 @@ __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevS
       it.emit(0, first, cnt_exec, 0, 1);
     }
   }
-  if (exists) acc_store(S, g, gf, a);
+  if (exists) acc_store(S, g, gf, a, a0);
   if (n_drop) atomicAdd(&X.counters[2], n_drop);
 }
 
@@ -1462,30 +1469,30 @@ __device__ __forceinline__ void apply_propose_group(
   while (it.next(r)) {
     const int32_t ix = r.idx;
     const bool stop = r.a != 0;
-    o_slot[ix] = 0;
-    o_bnum[ix] = 0;
-    o_bcoord[ix] = 0;
-    o_median[ix] = 0;
+    /* every record writes its four output words exactly once (a store instruction is a request
+     * the CU has to get out: pre-zeroing them cost k_propose_direct four extra stores per record) */
+    int32_t st = GPX_S_OK, ob = 0, oc = 0;
     if (!exists || stopped) {
-      status[ix] = exists ? GPX_S_STOPPED : GPX_S_NOGROUP;
+      st = exists ? GPX_S_STOPPED : GPX_S_NOGROUP;
       n_drop++;
-      continue;
-    }
-    if (!coord_ok) {
+    } else if (!coord_ok) {
       /* unicast to paxosState.getBallotCoord() (PISM:854-860) */
-      o_bnum[ix] = a_bnum;
-      o_bcoord[ix] = a_bcoord;
-      status[ix] = GPX_S_FORWARD;
-      continue;
-    }
-    /* no point enqueuing anything after stop (PaxosCoordinatorState.java:235-239) */
-    if ((pe_prev & PR_PRESENT) && (pe_prev & PR_STOP)) {
-      status[ix] = GPX_S_REFUSED;
-      continue;
-    }
-    if (pe_cur & PR_PRESENT) {
-      status[ix] = GPX_S_WINDOW; /* slot next-W still outstanding */
+      ob = a_bnum;
+      oc = a_bcoord;
+      st = GPX_S_FORWARD;
+    } else if ((pe_prev & PR_PRESENT) && (pe_prev & PR_STOP)) {
+      /* no point enqueuing anything after stop (PaxosCoordinatorState.java:235-239) */
+      st = GPX_S_REFUSED;
+    } else if (pe_cur & PR_PRESENT) {
+      st = GPX_S_WINDOW; /* slot next-W still outstanding */
       n_drop++;
+    }
+    if (st != GPX_S_OK) {
+      o_slot[ix] = 0;
+      o_bnum[ix] = ob;
+      o_bcoord[ix] = oc;
+      o_median[ix] = 0;
+      status[ix] = (uint8_t)st;
       continue;
     }
     const uint32_t e = PR_PRESENT | (stop ? PR_STOP : 0u);
