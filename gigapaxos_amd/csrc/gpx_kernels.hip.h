@@ -1192,6 +1192,9 @@ __device__ __forceinline__ int32_t acc_eec(const DevState& S, int32_t g, AccStat
       }
     }
     Dec nx = Dec{0, 0, 0, 0, false, false};
+    /* nothing committed in the next slot's ring entry (the usual end of the loop): the one flag
+     * byte says so without the three other loads of acc_reconstruct */
+    if (!(S.com_flags[(int64_t)(a.slot & Wm) * S.G + g] & RF_PRESENT)) break;
     if (!acc_reconstruct(S, g, a.slot, &nx)) break;
     /* committedRequests.remove(_slot); executed(slot, isStop) */
     const int64_t o0 = (int64_t)(a.slot & Wm) * S.G + g;
@@ -1293,7 +1296,7 @@ __device__ __forceinline__ void apply_accept_group(
     /* status[ix] stays GPX_S_OK (prefilled by k_hist) */
     /* might release some meta-commits (:1158-1161) */
     Dec rd = Dec{0, 0, 0, 0, false, false};
-    if (acc_reconstruct(S, g, slot, &rd)) {
+    if ((S.com_flags[o] & RF_PRESENT) && acc_reconstruct(S, g, slot, &rd)) {
       const int32_t first = a.slot;
       const int32_t cnt_exec = acc_eec(S, g, a, rd);
       if (cnt_exec > 0) {
