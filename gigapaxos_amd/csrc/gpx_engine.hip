@@ -290,6 +290,21 @@ void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, 
              is_votes, check_order, hsub);
 }
 
+/* k_scatter_ac with 16-byte column loads when the caller's columns allow it */
+void launch_scatter_ac(gpx_engine* e, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                       const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                       const uint8_t* flags, int32_t* r_bnum, int32_t* r_bcoord, int32_t* r_maxcp,
+                       uint8_t* r_flags) {
+  const int ntiles = ntiles_for(n);
+  const bool vec = aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)flags & 3);
+  if (vec)
+    LAUNCH_F(e, "k_scatter_ac", k_scatter_ac<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
+             e->S.G, e->X, gidx, bnum, bcoord, slot, median_cp, flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+  else
+    LAUNCH_F(e, "k_scatter_ac", k_scatter_ac<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
+             e->S.G, e->X, gidx, bnum, bcoord, slot, median_cp, flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+}
+
 int check_batch(gpx_engine* h, int32_t n) {
   if (!h || n < 0) return GPX_EINVAL;
   if (n > h->cfg.max_batch) return GPX_ECAPACITY;
@@ -597,10 +612,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
                                  {a_flags, (size_t)n}, {r_bnum, b4}, {r_bcoord, b4}, {r_maxcp, b4},
                                  {r_flags, (size_t)n}, {status, (size_t)n}});
   front_hist(e, n, gidx, status, 0);
-  const int ntiles = ntiles_for(n);
-  LAUNCH_F(e, "k_scatter_ac", k_scatter_ac, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
-           e->S.G, e->X,
-           gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+  launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
   begin_back(e, fs, n);
   LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags,
            status);
@@ -626,11 +638,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {median_cp, b4},
                                  {c_kind, (size_t)n}, {status, (size_t)n}});
   front_hist(e, n, gidx, status, 0);
-  const int ntiles = ntiles_for(n);
-  LAUNCH_F(e, "k_scatter_ac", k_scatter_ac, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
-           e->S.G, e->X,
-           gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
-           (int32_t*)nullptr, (uint8_t*)nullptr);
+  launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, c_kind, nullptr, nullptr, nullptr, nullptr);
   begin_back(e, fs, n);
   LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
   LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);

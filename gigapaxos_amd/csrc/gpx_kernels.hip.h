@@ -469,7 +469,10 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ar(
   }
 }
 
-/* accepts / commits; for accepts also zeroes the dense reply columns of dropped records */
+/* accepts / commits (and every other call whose record is {a, b, c, ballot}); for accepts also
+ * zeroes the dense reply columns of dropped records.  VEC: the int columns are 16-byte aligned and
+ * `flags` 4-byte aligned -> 4 consecutive records per lane per load. */
+template <bool VEC>
 __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ac(
     int32_t n, int32_t ntiles, int32_t G, DevScratch X, const int32_t* __restrict__ gidx,
     const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord,
@@ -482,19 +485,40 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ac(
   scatter_init(X, tile, lds);
   const int64_t base = (int64_t)tile * GPX_TILE;
   const int32_t mask = X.gb - 1;
+  auto one = [&](int64_t i, int32_t g, int32_t a, int32_t b, int32_t c, int32_t bn, int32_t bc) {
+    put_rec(X, lds, G, mask, i, g, a, b, c, bn, bc);
+    if ((uint32_t)g >= (uint32_t)G && r_bnum) {
+      r_bnum[i] = 0;
+      r_bcoord[i] = 0;
+      r_maxcp[i] = 0;
+      r_flags[i] = 0;
+    }
+  };
+  if (VEC) {
 #pragma unroll
-  for (int j = 0; j < GPX_TILE_ITEMS; j++) {
-    const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
-    if (i < n) {
-      const int32_t g = gidx[i];
-      put_rec(X, lds, G, mask, i, g, slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0, bnum[i],
-              bcoord[i]);
-      if ((uint32_t)g >= (uint32_t)G && r_bnum) {
-        r_bnum[i] = 0;
-        r_bcoord[i] = 0;
-        r_maxcp[i] = 0;
-        r_flags[i] = 0;
+    for (int j = 0; j < GPX_TILE_VECS; j++) {
+      const int64_t i0 = base + (int64_t)(j * GPX_FBLOCK + threadIdx.x) * 4;
+      if (i0 + 3 < n) {
+        const I4 g4 = *(const I4*)(gidx + i0), s4 = *(const I4*)(slot + i0);
+        const I4 m4 = *(const I4*)(median_cp + i0);
+        const I4 n4 = *(const I4*)(bnum + i0), c4 = *(const I4*)(bcoord + i0);
+        const uint32_t f4 = flags ? *(const uint32_t*)(flags + i0) : 0u;
+        one(i0 + 0, g4.x, s4.x, m4.x, (int32_t)(f4 & 0xffu), n4.x, c4.x);
+        one(i0 + 1, g4.y, s4.y, m4.y, (int32_t)((f4 >> 8) & 0xffu), n4.y, c4.y);
+        one(i0 + 2, g4.z, s4.z, m4.z, (int32_t)((f4 >> 16) & 0xffu), n4.z, c4.z);
+        one(i0 + 3, g4.w, s4.w, m4.w, (int32_t)(f4 >> 24), n4.w, c4.w);
+      } else {
+        for (int q = 0; q < 4; q++) {
+          const int64_t i = i0 + q;
+          if (i < n) one(i, gidx[i], slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0, bnum[i], bcoord[i]);
+        }
       }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < GPX_TILE_ITEMS; j++) {
+      const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
+      if (i < n) one(i, gidx[i], slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0, bnum[i], bcoord[i]);
     }
   }
 }
