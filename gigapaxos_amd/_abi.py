@@ -85,6 +85,9 @@ _SIGS = {
     "accept_reply_batch": [C.c_int32] + [_VP] * 14,
     "commit_batch": [C.c_int32] + [_VP] * 11,
     "prepare_batch": [C.c_int32] + [_VP] * 13,
+    "election_begin": [C.c_int32] + [_VP] * 3,
+    "prepare_reply_batch": [C.c_int32] + [_VP] * 19,
+    "propose_batch_h": [C.c_int32] + [_VP] * 8,
 }
 _DEV_SIGS = {
     "engine_set_stream": [_VP],
@@ -338,19 +341,71 @@ class Engine:
         return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(nk, 32))}
 
     # -- data path ---------------------------------------------------------------
-    def propose(self, gidx, is_stop=None):
-        """PISM.handleRequest/handleProposal for a batch of (already batched) requests."""
+    def propose(self, gidx, is_stop=None, handle=None):
+        """PISM.handleRequest/handleProposal for a batch of (already batched) requests.
+        With `handle` (int64 per request) the call goes through gpx_propose_batch_h."""
         gidx = _i32(gidx)
         n = gidx.shape[0]
         is_stop = _u8(is_stop, n)
         slot, bnum, bcoord, median = (np.zeros(n, np.int32) for _ in range(4))
         status = np.zeros(n, np.uint8)
-        self.lib.check(
-            self.lib.fn["propose_batch"](self.h, n, _p(gidx), _p(is_stop), _p(slot), _p(bnum),
-                                         _p(bcoord), _p(median), _p(status)),
-            "propose_batch",
-        )
+        if handle is None:
+            self.lib.check(
+                self.lib.fn["propose_batch"](self.h, n, _p(gidx), _p(is_stop), _p(slot), _p(bnum),
+                                             _p(bcoord), _p(median), _p(status)),
+                "propose_batch",
+            )
+        else:
+            handle = np.ascontiguousarray(handle, np.int64)
+            assert handle.shape[0] == n
+            self.lib.check(
+                self.lib.fn["propose_batch_h"](self.h, n, _p(gidx), _p(is_stop), _p(handle), _p(slot),
+                                               _p(bnum), _p(bcoord), _p(median), _p(status)),
+                "propose_batch_h",
+            )
         return slot, bnum, bcoord, median, status
+
+    def election_begin(self, gidx, bnum):
+        """PISM.tryMakeCoordinator -> PaxosCoordinator.makeCoordinator for a batch of groups."""
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        bnum = _i32(bnum, n)
+        st = np.zeros(max(n, 1), np.uint8)
+        self.lib.check(self.lib.fn["election_begin"](self.h, n, _p(gidx), _p(bnum), _p(st)), "election_begin")
+        return st[:n]
+
+    def prepare_reply(self, gidx, acceptor, r_bnum, r_bcoord, first_slot, pvalues=None):
+        """PISM.handlePrepareReply for a batch of PREPARE_REPLYs.  `pvalues[i]` = the reply's
+        accepted pvalues as (slot, bnum, bcoord, handle, flags) tuples.  Returns (v_kind, e_median,
+        status) and per record the list of (slot, kind, handle, flags) entries."""
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        acceptor, r_bnum, r_bcoord, first_slot = (_i32(x, n) for x in (acceptor, r_bnum, r_bcoord, first_slot))
+        pvalues = pvalues if pvalues is not None else [[] for _ in range(n)]
+        off = np.zeros(n + 1, np.int32)
+        off[1:] = np.cumsum([len(p) for p in pvalues])
+        flat = [t for p in pvalues for t in p]
+        m = max(len(flat), 1)
+        ps, pb, pc = (np.zeros(m, np.int32) for _ in range(3))
+        ph, pf = np.zeros(m, np.int64), np.zeros(m, np.uint8)
+        for j, t in enumerate(flat):
+            ps[j], pb[j], pc[j], ph[j], pf[j] = t
+        W = int(self.cfg.window)
+        q = max(n, 1)
+        vk, st = np.zeros(q, np.uint8), np.zeros(q, np.uint8)
+        ec, em = np.zeros(q, np.int32), np.zeros(q, np.int32)
+        es = np.zeros(q * W, np.int32)
+        ek, ef = np.zeros(q * W, np.uint8), np.zeros(q * W, np.uint8)
+        eh = np.zeros(q * W, np.int64)
+        self.lib.check(
+            self.lib.fn["prepare_reply_batch"](self.h, n, _p(gidx), _p(acceptor), _p(r_bnum), _p(r_bcoord),
+                                               _p(first_slot), _p(off), _p(ps), _p(pb), _p(pc), _p(ph), _p(pf),
+                                               _p(vk), _p(ec), _p(em), _p(es), _p(ek), _p(eh), _p(ef), _p(st)),
+            "prepare_reply_batch",
+        )
+        lists = [[(int(es[j * n + i]), int(ek[j * n + i]), int(eh[j * n + i]), int(ef[j * n + i]))
+                  for j in range(int(ec[i]))] for i in range(n)]
+        return (vk[:n], em[:n], st[:n]), lists
 
     def accept(self, gidx, bnum, bcoord, slot, median_cp, a_flags=None):
         """PISM.handleAccept for a batch of ACCEPTs."""

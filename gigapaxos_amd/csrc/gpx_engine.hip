@@ -18,6 +18,7 @@
 
 #include "gpx_kernels.hip.h"
 #include "gpx_wire.hip.h"
+#include "gpx_elect.hip.h"
 
 namespace {
 
@@ -73,6 +74,7 @@ struct gpx_engine {
   int32_t* st_i32[12] = {};
   uint8_t* st_u8[4] = {};
   int32_t* st_count = nullptr;
+  int64_t* st_handle = nullptr; /* gpx_propose_batch_h, allocated on first use */
   /* profiling */
   bool profiling = false;
   std::vector<PendingEvent> pending;
@@ -317,9 +319,9 @@ void launch_bucket_ar(gpx_engine* e, uint8_t* status) {
 }
 template <int KMAX>
 void launch_bucket_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t* bcoord,
-                           int32_t* median, uint8_t* status) {
+                           int32_t* median, uint8_t* status, const int64_t* handle) {
   LAUNCH_B(e, "k_bucket_propose", (k_bucket_propose<KMAX>), e->S, e->X, slot, bnum, bcoord, median,
-           status);
+           status, handle);
 }
 
 }  // namespace
@@ -422,7 +424,10 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
                          (const void*)k_bucket_propose<8>, (const void*)k_bucket_propose<16>,
                          (const void*)k_bucket_accept,     (const void*)k_bucket_commit,
                          (const void*)k_bucket_pack_ar,    (const void*)k_bucket_reqbatch,
-                         (const void*)k_bucket_prepare};
+                         (const void*)k_bucket_prepare,
+                         (const void*)k_bucket_prepare_reply<4>,
+                         (const void*)k_bucket_prepare_reply<8>,
+                         (const void*)k_bucket_prepare_reply<16>};
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bucket_lds));
   }
@@ -647,16 +652,17 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   return GPX_OK;
 }
 
-int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
-                          int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
-                          uint8_t* status) {
+/* handle: device pointer or null (gpx_propose_batch_h) */
+static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                            const int64_t* handle, int32_t* slot, int32_t* bnum, int32_t* bcoord,
+                            int32_t* median_cp, uint8_t* status) {
   int rc = check_batch(h, n);
   if (rc != GPX_OK) return rc;
   if (n == 0) return GPX_OK;
   gpx_engine* e = h;
   const size_t b4 = (size_t)n * 4;
-  const int fs = begin_front(e, {{gidx, b4}, {is_stop, (size_t)n}, {slot, b4}, {bnum, b4}, {bcoord, b4},
-                                 {median_cp, b4}, {status, (size_t)n}});
+  const int fs = begin_front(e, {{gidx, b4}, {is_stop, (size_t)n}, {handle, b4 * 2}, {slot, b4}, {bnum, b4},
+                                 {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
   front_hist(e, n, gidx, status, 0, 1);
   const int ntiles = ntiles_for(n);
   LAUNCH_F(e, "k_scatter_pr", k_scatter_pr, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
@@ -667,20 +673,26 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
    * k_hist): strictly ascending batch -> k_propose_direct, anything else -> k_bucket_propose */
   if (e->cfg.kmax <= 4) {
     LAUNCH(e, "k_propose_direct", k_propose_direct<4>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
-           bnum, bcoord, median_cp, status);
-    launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status);
+           bnum, bcoord, median_cp, status, handle);
+    launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status, handle);
   } else if (e->cfg.kmax <= 8) {
     LAUNCH(e, "k_propose_direct", k_propose_direct<8>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
-           bnum, bcoord, median_cp, status);
-    launch_bucket_propose<8>(e, slot, bnum, bcoord, median_cp, status);
+           bnum, bcoord, median_cp, status, handle);
+    launch_bucket_propose<8>(e, slot, bnum, bcoord, median_cp, status, handle);
   } else {
     LAUNCH(e, "k_propose_direct", k_propose_direct<16>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
-           bnum, bcoord, median_cp, status);
-    launch_bucket_propose<16>(e, slot, bnum, bcoord, median_cp, status);
+           bnum, bcoord, median_cp, status, handle);
+    launch_bucket_propose<16>(e, slot, bnum, bcoord, median_cp, status, handle);
   }
   end_call(e, fs, {{slot, b4}, {bnum, b4}, {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
   HIPCHK(hipGetLastError());
   return GPX_OK;
+}
+
+int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                          int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
+                          uint8_t* status) {
+  return propose_dev_impl(h, n, gidx, is_stop, nullptr, slot, bnum, bcoord, median_cp, status);
 }
 
 /* ---- host-pointer data path ---------------------------------------------------- */
@@ -694,6 +706,12 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
 int gpx_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
                       int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
                       uint8_t* status) {
+  return gpx_propose_batch_h(h, n, gidx, is_stop, nullptr, slot, bnum, bcoord, median_cp, status);
+}
+
+int gpx_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                        const int64_t* handle, int32_t* slot, int32_t* bnum, int32_t* bcoord,
+                        int32_t* median_cp, uint8_t* status) {
   int rc = check_batch(h, n);
   if (rc != GPX_OK) return rc;
   if (n == 0) return GPX_OK;
@@ -701,8 +719,18 @@ int gpx_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8
   const size_t b4 = (size_t)n * 4;
   H2D(h->st_i32[0], gidx, b4);
   if (is_stop) H2D(h->st_u8[0], is_stop, (size_t)n);
-  rc = gpx_propose_batch_dev(h, n, h->st_i32[0], is_stop ? h->st_u8[0] : nullptr, h->st_i32[1],
-                             h->st_i32[2], h->st_i32[3], h->st_i32[4], h->st_u8[1]);
+  /* staging column of the 64-bit handles: allocated on first use */
+  int64_t* d_handle = nullptr;
+  if (handle) {
+    if (!h->st_handle) {
+      rc = dev_alloc(h, &h->st_handle, (size_t)h->cfg.max_batch, false);
+      if (rc != GPX_OK) return rc;
+    }
+    d_handle = h->st_handle;
+    H2D(d_handle, handle, b4 * 2);
+  }
+  rc = propose_dev_impl(h, n, h->st_i32[0], is_stop ? h->st_u8[0] : nullptr, d_handle, h->st_i32[1],
+                        h->st_i32[2], h->st_i32[3], h->st_i32[4], h->st_u8[1]);
   if (rc != GPX_OK) return rc;
   D2H(slot, h->st_i32[1], b4);
   D2H(bnum, h->st_i32[2], b4);
@@ -1006,6 +1034,46 @@ int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
         w.push_back((pr.second & PR_STOP) ? 1 : 0);
         w.push_back((int32_t)(pr.second & 0xffffu));
       }
+      /* view change: active flag; while running for coordinator the heard-from mask, the
+       * pre-active proposals' handles and the carried-over pvalues */
+      const bool preparing = (gf & GF_PREPARING) != 0;
+      w.push_back(preparing ? 0 : 1);
+      if (preparing) {
+        auto rd64 = [&](const int64_t* base, int64_t idx, int64_t* out) -> hipError_t {
+          return hipMemcpy(out, base + idx, 8, hipMemcpyDeviceToHost);
+        };
+        w.push_back(1); /* waitforMyBallot armed */
+        HIPCHK(rd32(S.c_wait, gidx, &v));
+        w.push_back(v);
+        for (auto& pr : props) {
+          int64_t hv = 0;
+          HIPCHK(rd64(S.p_handle, (int64_t)(pr.first & (S.W - 1)) * S.G + gidx, &hv));
+          w.push_back((int32_t)(uint32_t)hv);
+          w.push_back((int32_t)((uint64_t)hv >> 32));
+        }
+        struct Co {
+          I4 v;
+          int64_t hv;
+        };
+        std::vector<Co> cos;
+        for (int32_t x = 0; x < S.W; x++) {
+          Co c;
+          HIPCHK(hipMemcpy(&c.v, S.co_ring + ((int64_t)x * S.G + gidx), sizeof(I4), hipMemcpyDeviceToHost));
+          if (!(c.v.w & CO_PRESENT)) continue;
+          HIPCHK(rd64(S.co_handle, (int64_t)x * S.G + gidx, &c.hv));
+          cos.push_back(c);
+        }
+        std::sort(cos.begin(), cos.end(), [](const Co& p, const Co& q) { return p.v.x < q.v.x; });
+        w.push_back((int32_t)cos.size());
+        for (auto& c : cos) {
+          w.push_back(c.v.x);
+          w.push_back(c.v.y);
+          w.push_back(c.v.z);
+          w.push_back(c.v.w & (GPX_PV_STOP | GPX_PV_NOOP));
+          w.push_back((int32_t)(uint32_t)c.hv);
+          w.push_back((int32_t)((uint64_t)c.hv >> 32));
+        }
+      }
     }
   }
   if ((int32_t)w.size() > cap) return GPX_ECAPACITY;
@@ -1016,3 +1084,4 @@ int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
 } /* extern "C" */
 
 #include "gpx_wire_host.inc"
+#include "gpx_elect_host.inc"

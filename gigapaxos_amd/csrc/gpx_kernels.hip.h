@@ -101,6 +101,7 @@ __device__ __forceinline__ Out mk_out(int32_t gidx, int32_t slot, int32_t x, int
 #define GF_EXISTS 1u
 #define GF_STOPPED 2u  /* PaxosAcceptor.STATES.STOPPED */
 #define GF_HASCOORD 4u /* PaxosInstanceStateMachine.coordinator != null */
+#define GF_PREPARING 8u /* ... and !coordinator.isActive(): running for coordinator (view change) */
 #define GF_K(f) (((f) >> 8) & 0xffu)
 
 /* proposal ring entry: bits 0..15 = responded mask (WaitforUtility.responded) */
@@ -125,7 +126,14 @@ struct DevState {
   uint8_t* acc_flags;                             /* [W][G] */
   I4* com_ring;                                   /* [W][G] committedRequests {slot,bnum,bcoord,median} */
   uint8_t* com_flags;                             /* [W][G] */
+  /* view change, coordinator side; allocated by the first gpx_election_begin (null before: no
+   * group can be GF_PREPARING then) */
+  uint32_t* c_wait;   /* [G] waitforMyBallot: members heard from */
+  I4* co_ring;        /* [W][G] carryoverProposals {slot, bnum, bcoord, CO_PRESENT | GPX_PV_*} */
+  int64_t* co_handle; /* [W][G] the caller's key of a carried-over request value */
+  int64_t* p_handle;  /* [W][G] ... and of a pre-active proposal (myProposals while not active) */
 };
+#define CO_PRESENT 0x100
 
 struct DevScratch {
   int32_t shift, nbk, gb; /* bucket = gidx >> shift; nbk buckets of gb = 1 << shift groups */
@@ -1005,6 +1013,7 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
   }
   const int32_t k = (int32_t)GF_K(gf);
   bool has_coord = (gf & GF_HASCOORD) != 0;
+  const bool preparing = (gf & GF_PREPARING) != 0;
   const int32_t my_bnum = P.my_bnum, my_bcoord = P.my_bcoord;
   const int32_t next = P.next;
   int32_t pcount = P.pcount;
@@ -1041,7 +1050,7 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
     if (!has_coord) continue; /* PaxosCoordinator.java:196-198: c == null -> null */
     const int32_t cmp = ballot_cmp(r.bnum, r.bcoord, my_bnum, my_bcoord);
     const int32_t d = jsub(next, slot); /* slot in myProposals' window iff 1 <= d <= W */
-    const bool inwin = (d >= 1) && (d <= S.W);
+    const bool inwin = (d >= 1) && (d <= S.W) && !preparing; /* !isActive() -> null (:212-213) */
     if (cmp > 0) {
       /* handleAcceptReplyHigherBallot :661-675 */
       if (inwin) {
@@ -1052,9 +1061,9 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
           it.emit(slot, my_bnum, my_bcoord, -1, GPX_D_PREEMPTED); /* preempt(): median stays -1 */
         }
       }
-      /* nullifyCoordinatorIfPreemptedFully, PISM:1361-1364 */
+      /* nullifyCoordinatorIfPreemptedFully, PISM:1361-1364: active or not */
       if (pcount == 0) has_coord = false;
-    } else if (cmp == 0) {
+    } else if (cmp == 0 && !preparing) {
       /* handleAcceptReplyMyBallot :597-640; recordSlotNumber :809-825 (plain <) */
       int32_t midx = -1;
 #pragma unroll
@@ -1090,7 +1099,7 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
       if (q < k) S.node_slots[(int64_t)q * G + g] = ns[q];
   }
   if (pcount != pcount0) S.c_pcount[g] = pcount;
-  if (!has_coord && (gf & GF_HASCOORD)) S.g_flags[g] = gf & ~GF_HASCOORD;
+  if (!has_coord && (gf & GF_HASCOORD)) S.g_flags[g] = gf & ~(GF_HASCOORD | GF_PREPARING);
 }
 
 template <int KMAX>
@@ -1469,9 +1478,11 @@ template <int KMAX, class IT>
 __device__ __forceinline__ void apply_propose_group(
     const DevState& S, const DevScratch& X, int32_t g, IT& it, int32_t* __restrict__ o_slot,
     int32_t* __restrict__ o_bnum, int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median,
-    uint8_t* __restrict__ status, const ProposePre<KMAX>& P) {
+    uint8_t* __restrict__ status, const ProposePre<KMAX>& P, const int64_t* __restrict__ handle) {
   const int32_t G = S.G;
   const uint32_t gf = P.gf;
+  /* not active: the proposal is kept (pre-active) but no ACCEPT goes out (PCS:254-261) */
+  const bool preparing = (gf & GF_PREPARING) != 0;
   const bool exists = (gf & GF_EXISTS) != 0, stopped = (gf & GF_STOPPED) != 0;
   const int32_t k = (int32_t)GF_K(gf);
   const int32_t a_bnum = exists ? P.a_bnum : 0, a_bcoord = exists ? P.a_bcoord : 0;
@@ -1528,7 +1539,11 @@ __device__ __forceinline__ void apply_propose_group(
     o_slot[ix] = next;
     o_bnum[ix] = my_bnum;
     o_bcoord[ix] = my_bcoord;
-    o_median[ix] = median; /* getMajorityCommittedSlot: nodeSlots unchanged by propose */
+    o_median[ix] = preparing ? 0 : median; /* getMajorityCommittedSlot: nodeSlots unchanged by propose */
+    if (preparing) {
+      S.p_handle[(int64_t)(next & Wm) * G + g] = handle ? handle[ix] : 0;
+      status[ix] = GPX_S_PREACTIVE; /* over k_hist's GPX_S_OK */
+    }
     next = (int32_t)((uint32_t)next + 1u);
     pe_prev = e;
     if (it.done < it.c) pe_cur = S.p_ring[(int64_t)(next & Wm) * G + g];
@@ -1543,7 +1558,8 @@ __device__ __forceinline__ void apply_propose_group(
 template <int KMAX>
 __global__ __launch_bounds__(1024) void k_bucket_propose(
     DevState S, DevScratch X, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
-    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status) {
+    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
+    const int64_t* __restrict__ handle) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
   if (*X.unsorted != X.epoch) { /* handled by k_propose_direct; leave the counts ready for the next call */
@@ -1569,7 +1585,7 @@ __global__ __launch_bounds__(1024) void k_bucket_propose(
       propose_preload<KMAX>(S, g0 + l, P);
       propose_preload_ring<KMAX>(S, g0 + l, P);
     }
-    apply_propose_group<KMAX, GroupIter>(S, X, g0 + l, it, o_slot, o_bnum, o_bcoord, o_median, status, P);
+    apply_propose_group<KMAX, GroupIter>(S, X, g0 + l, it, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
   }
 }
 
@@ -1582,7 +1598,8 @@ template <int KMAX>
 __global__ __launch_bounds__(GPX_BLOCK) void k_propose_direct(
     DevState S, DevScratch X, int32_t n, const int32_t* __restrict__ gidx,
     const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
-    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status) {
+    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
+    const int64_t* __restrict__ handle) {
   if (*X.unsorted == X.epoch) return;
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (i >= n) return;
@@ -1595,7 +1612,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_direct(
   it.a = is_stop ? (int32_t)(is_stop[i] & 1) : 0;
   it.c = 1;
   it.done = 0;
-  apply_propose_group<KMAX, OneRec>(S, X, g, it, o_slot, o_bnum, o_bcoord, o_median, status, P);
+  apply_propose_group<KMAX, OneRec>(S, X, g, it, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
 }
 
 /* ------------------------------------------------------------------------- */
@@ -1921,7 +1938,9 @@ __device__ __forceinline__ void fill_hri_dev(const DevState& S, int32_t g, uint3
   r.acc_bnum = S.a_bnum[g];
   r.acc_bcoord = S.a_bcoord[g];
   r.acc_gc_slot = S.a_gc[g];
-  const bool coord = (gf & GF_HASCOORD) != 0;
+  /* getNextProposalSlotIfActive / getNodeSlots / getBallot: only of an ACTIVE coordinator
+   * (PaxosCoordinator.java:375-402) */
+  const bool coord = (gf & GF_HASCOORD) != 0 && !(gf & GF_PREPARING);
   const int32_t k = (int32_t)GF_K(gf);
   r.has_coord = coord ? 1 : 0;
   r.coord_bnum = coord ? S.c_bnum[g] : 0;

@@ -71,6 +71,9 @@ extern "C" {
 #define GPX_S_EXISTS 6  /* group_create on a live gidx */
 #define GPX_S_BUSY 7    /* group_retire(GPX_RETIRE_PAUSE) on a group that is not
                            caught up (PaxosInstanceStateMachine.java:2004-2035) */
+#define GPX_S_PREACTIVE 8 /* propose only: the coordinator here is still being elected; the
+                            proposal got slot `slot` but no ACCEPT goes out yet
+                            (PaxosCoordinatorState.java:254-261) */
 
 /* decision kinds (d_kind) */
 #define GPX_D_DECISION 1  /* PValuePacket.makeDecision, PaxosCoordinatorState.java:630-635 */
@@ -290,6 +293,76 @@ int gpx_prepare_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const i
                           const int32_t* bcoord, const int32_t* first_slot, int32_t* r_bnum,
                           int32_t* r_bcoord, int32_t* r_gc, uint8_t* r_flags, uint64_t* p_mask,
                           int32_t* p_slot, int32_t* p_bnum, int32_t* p_bcoord, uint8_t* status);
+
+/* ---- view change, coordinator side ---------------------------------------------- */
+
+/* gpx_election_begin status */
+#define GPX_EB_PREPARING 0 /* new coordinator state created, waiting for PREPARE replies */
+#define GPX_EB_ACTIVE 1    /* ballot number 0: active at once (PaxosCoordinator.java:74-76) */
+#define GPX_EB_RESEND 2    /* same ballot, still not active: send the PREPARE again */
+#define GPX_EB_UNCHANGED 3 /* a coordinator with a ballot at least as high exists */
+/*
+ * replaces: PISM.tryMakeCoordinator -> PaxosCoordinator.makeCoordinator(c, bnum, myID, members,
+ * paxosState.getSlot(), false) (PaxosInstanceStateMachine.java:2178-2183,
+ * PaxosCoordinator.java:66-89) for the groups gpx_election_scan selected: a coordinator with a
+ * lower ballot (or none) is replaced by a fresh PaxosCoordinatorState(bnum, myID, acceptor slot,
+ * members, null) - nextProposalSlot = the acceptor's slot, nodeSlotNumbers = -1, no proposals -
+ * whose prepare() arms waitforMyBallot.  gidx must be pairwise distinct.  e_status: GPX_EB_* (255 for
+ * a missing group).  Host pointers.
+ */
+int gpx_election_begin(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                       uint8_t* e_status);
+
+/* gpx_prepare_reply_batch: what a reply did (v_kind) and what an entry of the lists is (e_kind) */
+#define GPX_V_IGNORED 0   /* no coordinator, not waiting, lower ballot, non-member or repeated acceptor
+                             (PaxosCoordinatorState.canIgnorePrepareReply, PCS:285-316) */
+#define GPX_V_RECORDED 1  /* counted; no majority yet */
+#define GPX_V_ELECTED 2   /* majority: the coordinator is active now; e_* = the ACCEPTs to multicast */
+#define GPX_V_PREEMPTED 3 /* higher ballot: the coordinator is gone; e_* = its pre-active proposals,
+                             to be forwarded to the reply ballot's coordinator (PISM:1042-1048) */
+#define GPX_E_CARRY 1     /* a pvalue carried over from the replies: value = the one with e_handle */
+#define GPX_E_NOOP 2      /* no-op for a slot neither carried over nor proposed (PCS:407-411) */
+#define GPX_E_PREACTIVE 3 /* a proposal made while not active: e_handle = its handle */
+#define GPX_E_NEWSTOP 4   /* the stop request processStop appends (PCS:512-516) */
+#define GPX_PV_STOP 1     /* pv_flags / e_flags: the request is a stop request */
+#define GPX_PV_NOOP 2     /* pv_flags: the carried request value is the NO_OP value */
+/*
+ * replaces: PISM.handlePrepareReply (PaxosInstanceStateMachine.java:1008-1068) ->
+ * PaxosCoordinator.getPreActivesIfPreempted / handlePrepareReply (PaxosCoordinator.java:264-310)
+ * -> PaxosCoordinatorState.isPreemptable, isPrepareAcceptedByMajority (carry-over of the highest
+ * ballot pvalue per slot), combinePValuesOntoProposals, reproposePreemptedProposals, processStop,
+ * spawnCommandersForProposals, setCoordinatorActive (PaxosCoordinatorState.java:271-587).
+ * Record i = PrepareReplyPacket(acceptor, ballot (r_bnum, r_bcoord), accepted pvalues, minSlot =
+ * the reply's gcSlot) for gidx[i]; its accepted pvalues are entries pv_off[i] .. pv_off[i+1] of the
+ * pv_* columns ({slot, ballot, flags} + pv_handle, the caller's 64-bit key of the value: two
+ * requests are RequestPacket.equals iff their handles are equal).
+ * Outputs per record: v_kind; for ELECTED / PREEMPTED e_count[i] list entries in `window` planes
+ * of n entries (entry j of record i at [j * n + i], ascending slot): e_slot, e_kind, e_handle,
+ * e_flags; for ELECTED e_median[i] = the medianCheckpointedSlot of the ACCEPTs
+ * (getMajorityCommittedSlot at initCommander, PCS:841-851).  status: GPX_S_OK, GPX_S_NOGROUP,
+ * GPX_S_STOPPED is not applied (PISM handles prepare replies of a stopped instance alike),
+ * GPX_S_WINDOW = the carried-over range and the re-proposed pre-actives do not fit `window` slots:
+ * the record is dropped whole (nothing recorded) and the host must run this election itself.
+ * Java assertions are taken as disabled (production): processStop's stop / request conversions
+ * are unreachable then, because ProposalStateAtCoordinator re-stamps every pvalue with the
+ * coordinator's own ballot (PCS:153-157), so only its final "append a stop" step acts.
+ */
+int gpx_prepare_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* acceptor,
+                            const int32_t* r_bnum, const int32_t* r_bcoord, const int32_t* first_slot,
+                            const int32_t* pv_off, const int32_t* pv_slot, const int32_t* pv_bnum,
+                            const int32_t* pv_bcoord, const int64_t* pv_handle,
+                            const uint8_t* pv_flags, uint8_t* v_kind, int32_t* e_count,
+                            int32_t* e_median, int32_t* e_slot, uint8_t* e_kind, int64_t* e_handle,
+                            uint8_t* e_flags, uint8_t* status);
+
+/*
+ * gpx_propose_batch with the caller's 64-bit handle of each request (nullable).  Only needed for
+ * groups whose coordinator is being elected: their proposals are kept as pre-active proposals
+ * (status GPX_S_PREACTIVE) and come back, by handle, from gpx_prepare_reply_batch.
+ */
+int gpx_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                        const int64_t* handle, int32_t* slot, int32_t* bnum, int32_t* bcoord,
+                        int32_t* median_cp, uint8_t* status);
 
 /* ---- view change: who runs for coordinator ------------------------------------ */
 

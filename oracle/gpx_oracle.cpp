@@ -216,6 +216,14 @@ struct PaxosAcceptor {
 struct ProposalState {
   bool stop;
   WaitforUtility waitfor;
+  int64_t handle = 0; /* the caller's key of the request value (RequestPacket.equals <=> same handle) */
+  int kind = 0;       /* 0 proposed here, else GPX_E_CARRY / GPX_E_NOOP / GPX_E_NEWSTOP (view change) */
+};
+/* a pvalue reported in a PREPARE_REPLY (PCS.carryoverProposals, PaxosCoordinatorState.java:88-94) */
+struct Carryover {
+  Ballot ballot;
+  int64_t handle;
+  bool stop, noop;
 };
 struct PaxosCoordinatorState {
   Ballot myBallot;
@@ -223,6 +231,8 @@ struct PaxosCoordinatorState {
   bool active = false;
   std::vector<int32_t> nodeSlotNumbers;
   std::map<int32_t, ProposalState> myProposals;
+  std::unique_ptr<WaitforUtility> waitforMyBallot;   /* != null while running for coordinator */
+  std::map<int32_t, Carryover> carryoverProposals;
 
   /* PaxosCoordinatorState.java:867-875 (Arrays.sort = signed ascending) */
   int32_t getMedianMinus() const {
@@ -240,16 +250,106 @@ struct PaxosCoordinatorState {
         if (nodeSlotNumbers[i] < maxCP) nodeSlotNumbers[i] = maxCP;
   }
   /* PaxosCoordinatorState.java:233-263 + initCommander :841-851.
-   * returns 0 = ACCEPT issued, 1 = refused (after stop) */
-  int propose(const std::vector<int32_t>& members, bool stop, int32_t* slot, int32_t* median) {
+   * returns 0 = ACCEPT issued, 1 = refused (after stop), 2 = inserted but not active (pre-active) */
+  int propose(const std::vector<int32_t>& members, bool stop, int32_t* slot, int32_t* median,
+              int64_t handle = 0, int kind = 0) {
     auto prev = myProposals.find(jsub(nextProposalSlotNumber, 1));
     if (prev != myProposals.end() && prev->second.stop) return 1;
     int32_t s = nextProposalSlotNumber;
     nextProposalSlotNumber = (int32_t)((uint32_t)nextProposalSlotNumber + 1u);
-    myProposals.emplace(s, ProposalState{stop, WaitforUtility(&members)});
+    ProposalState ps{stop, WaitforUtility(&members)};
+    ps.handle = handle;
+    ps.kind = kind;
+    myProposals.emplace(s, ps);
     *slot = s;
     *median = getMajorityCommittedSlot();
-    return 0; /* active is always true here (see header) */
+    return active ? 0 : 2;
+  }
+
+  /* ---- phase 1b (PaxosCoordinatorState.java:265-587) ---- */
+  bool isPreemptable(const Ballot& b) const { return b.compareTo(myBallot) > 0; } /* :271-279 */
+  bool canIgnorePrepareReply(const Ballot& b, int32_t acceptor,
+                             const std::vector<int32_t>& members) const { /* :285-316 */
+    if (!waitforMyBallot) return true;
+    if (b.compareTo(myBallot) < 0) return true;
+    bool member = false;
+    for (int32_t m : members) member = member || m == acceptor;
+    int idx = waitforMyBallot->getIndex(acceptor);
+    if (!member || (idx >= 0 && waitforMyBallot->responded[idx])) return true;
+    return false;
+  }
+  /* recordSlotNumber(members, PrepareReplyPacket) :786-803 - wraparound-aware */
+  void recordMinSlot(const std::vector<int32_t>& members, int32_t acceptor, int32_t minSlot) {
+    for (size_t i = 0; i < members.size(); i++)
+      if (members[i] == acceptor && jsub(nodeSlotNumbers[i], minSlot) < 0) nodeSlotNumbers[i] = minSlot;
+  }
+  /* isPrepareAcceptedByMajority :329-381 after canIgnorePrepareReply said no */
+  bool recordPrepareReply(const std::vector<int32_t>& members, int32_t acceptor, int32_t minSlot,
+                          int32_t npv, const int32_t* pslot, const int32_t* pbnum,
+                          const int32_t* pbcoord, const int64_t* phandle, const uint8_t* pflags) {
+    recordMinSlot(members, acceptor, minSlot);
+    for (int32_t j = 0; j < npv; j++) {
+      const Ballot b{pbnum[j], pbcoord[j]};
+      auto ex = carryoverProposals.find(pslot[j]);
+      if (ex == carryoverProposals.end() || b.compareTo(ex->second.ballot) > 0)
+        carryoverProposals[pslot[j]] = Carryover{b, phandle ? phandle[j] : 0,
+                                                 pflags && (pflags[j] & GPX_PV_STOP),
+                                                 pflags && (pflags[j] & GPX_PV_NOOP)};
+    }
+    waitforMyBallot->updateHeardFrom(acceptor);
+    return waitforMyBallot->heardFromMajority();
+  }
+  /* combinePValuesOntoProposals :393-444 + reproposePreemptedProposals :460-468 + processStop
+   * :478-517 (assertions off: its conversions are unreachable, every ProposalStateAtCoordinator
+   * carries the coordinator's own ballot, :153-157) */
+  void combinePValuesOntoProposals(const std::vector<int32_t>& members) {
+    if (carryoverProposals.empty()) return;
+    int32_t maxCarry = carryoverProposals.begin()->first; /* getMaxPValueSlot :899-910 */
+    for (auto& kv : carryoverProposals)
+      if (jsub(kv.first, maxCarry) > 0) maxCarry = kv.first;
+    int32_t maxMin = nodeSlotNumbers[0]; /* getMaxMinCarryoverSlot :917-927 */
+    for (int32_t v : nodeSlotNumbers)
+      if (jsub(v, maxMin) > 0) maxMin = v;
+    std::map<int32_t, ProposalState> preActives;
+    preActives.swap(myProposals);
+    for (int32_t cur = maxMin; jsub(cur, maxCarry) <= 0; cur = (int32_t)((uint32_t)cur + 1u)) {
+      auto co = carryoverProposals.find(cur);
+      auto pa = preActives.find(cur);
+      if (co != carryoverProposals.end()) {
+        ProposalState ps{co->second.stop, WaitforUtility(&members)};
+        ps.handle = co->second.handle;
+        ps.kind = GPX_E_CARRY;
+        myProposals.emplace(cur, ps);
+      } else if (pa == preActives.end()) {
+        ProposalState ps{false, WaitforUtility(&members)};
+        ps.kind = GPX_E_NOOP;
+        myProposals.emplace(cur, ps);
+      } else {
+        bool dup = false; /* isDuplicate :446-452: RequestPacket.equals over the carry-overs */
+        for (auto& kv : carryoverProposals) dup = dup || kv.second.handle == pa->second.handle;
+        if (!dup) myProposals.emplace(cur, pa->second);
+        preActives.erase(pa);
+      }
+    }
+    nextProposalSlotNumber = (int32_t)((uint32_t)maxCarry + 1u);
+    for (auto& kv : preActives) { /* reproposePreemptedProposals: TreeMap order */
+      int32_t sl, md;
+      propose(members, kv.second.stop, &sl, &md, kv.second.handle, kv.second.kind);
+    }
+    bool stopExists = false; /* processStop */
+    for (auto& kv : myProposals) stopExists = stopExists || kv.second.stop;
+    if (stopExists) {
+      auto last = myProposals.find(jsub(nextProposalSlotNumber, 1));
+      if (last != myProposals.end() && !last->second.stop) {
+        int32_t sl, md;
+        propose(members, true, &sl, &md, 0, GPX_E_NEWSTOP); /* new RequestPacket(0, STOP, true) */
+      }
+    }
+  }
+  void setCoordinatorActive() { /* :568-578 */
+    active = true;
+    waitforMyBallot.reset();
+    carryoverProposals.clear();
   }
   /* PaxosCoordinatorState.java:597-640; returns true on first majority */
   bool handleAcceptReplyMyBallot(const std::vector<int32_t>& members, int32_t slot,
@@ -498,6 +598,30 @@ int orc_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
           if (kv.second.waitfor.responded[i]) mask |= (1 << i);
         w.push_back(mask);
       }
+      /* view change: active flag; while running for coordinator the heard-from mask, the
+       * pre-active proposals' handles and the carried-over pvalues */
+      w.push_back(c.active ? 1 : 0);
+      if (!c.active) {
+        int32_t mask = 0;
+        if (c.waitforMyBallot)
+          for (size_t i = 0; i < c.waitforMyBallot->responded.size(); i++)
+            if (c.waitforMyBallot->responded[i]) mask |= (1 << i);
+        w.push_back(c.waitforMyBallot ? 1 : 0);
+        w.push_back(mask);
+        for (auto& kv : c.myProposals) {
+          w.push_back((int32_t)(uint32_t)kv.second.handle);
+          w.push_back((int32_t)((uint64_t)kv.second.handle >> 32));
+        }
+        w.push_back((int32_t)c.carryoverProposals.size());
+        for (auto& kv : c.carryoverProposals) {
+          w.push_back(kv.first);
+          w.push_back(kv.second.ballot.num);
+          w.push_back(kv.second.ballot.coord);
+          w.push_back((kv.second.stop ? GPX_PV_STOP : 0) | (kv.second.noop ? GPX_PV_NOOP : 0));
+          w.push_back((int32_t)(uint32_t)kv.second.handle);
+          w.push_back((int32_t)((uint64_t)kv.second.handle >> 32));
+        }
+      }
     }
   }
   if ((int32_t)w.size() > cap) return GPX_ECAPACITY;
@@ -506,9 +630,17 @@ int orc_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
 }
 
 /* PaxosInstanceStateMachine.java:767-888 handleRequest -> handleProposal */
+int orc_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                        const int64_t* handle, int32_t* slot, int32_t* bnum, int32_t* bcoord,
+                        int32_t* median_cp, uint8_t* status);
 int orc_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
                       int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
                       uint8_t* status) {
+  return orc_propose_batch_h(h, n, gidx, is_stop, nullptr, slot, bnum, bcoord, median_cp, status);
+}
+int orc_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                        const int64_t* handle, int32_t* slot, int32_t* bnum, int32_t* bcoord,
+                        int32_t* median_cp, uint8_t* status) {
   if (!h || n < 0) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);
   for (int32_t i = 0; i < n; i++) {
@@ -527,16 +659,29 @@ int orc_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8
     /* PaxosCoordinator.exists(c, paxosState.getBallot()) :213-219, PISM:825-826 */
     if (g->coordinator && g->coordinator->myBallot.compareTo(g->paxosState.getBallot()) >= 0) {
       int32_t s = 0, m = 0;
-      int rc = g->coordinator->propose(g->members, is_stop && (is_stop[i] & 1), &s, &m);
-      if (rc != 0) {
+      {
+        /* engine limit, not in the reference (whose map is unbounded): myProposals is a ring of
+         * `window` slots - a proposal whose slot - window is still outstanding is refused */
+        const PaxosCoordinatorState& c = *g->coordinator;
+        auto prev = c.myProposals.find(jsub(c.nextProposalSlotNumber, 1));
+        const bool after_stop = prev != c.myProposals.end() && prev->second.stop;
+        if (!after_stop && c.myProposals.count(jsub(c.nextProposalSlotNumber, e->cfg.window))) {
+          status[i] = GPX_S_WINDOW;
+          e->counters[2]++;
+          continue;
+        }
+      }
+      int rc = g->coordinator->propose(g->members, is_stop && (is_stop[i] & 1), &s, &m,
+                                       handle ? handle[i] : 0);
+      if (rc == 1) {
         status[i] = GPX_S_REFUSED;
         continue;
       }
       slot[i] = s;
       bnum[i] = g->coordinator->myBallot.num;
       bcoord[i] = g->coordinator->myBallot.coord;
-      median_cp[i] = m;
-      status[i] = GPX_S_OK;
+      median_cp[i] = rc == 0 ? m : 0;
+      status[i] = rc == 0 ? GPX_S_OK : GPX_S_PREACTIVE; /* not active: no ACCEPT yet (:254-261) */
     } else {
       /* :854-860 unicast to paxosState.getBallotCoord() */
       bnum[i] = g->paxosState.ballotNum;
@@ -686,9 +831,11 @@ int orc_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
           e->counters[1]++;
         }
       }
-      /* PISM:1361-1364 + PaxosCoordinator.java:110-115 nullifyCoordinatorIfPreemptedFully */
-      if (cmp > 0 && c->preemptedFully()) g->coordinator.reset();
     }
+    /* PISM:1273, 1361-1364 + PaxosCoordinator.isPreemptedFully (PaxosCoordinator.java:110-115):
+     * for ANY coordinator, active or still being elected */
+    if (c && Ballot{bnum[i], bcoord[i]}.compareTo(c->myBallot) > 0 && c->preemptedFully())
+      g->coordinator.reset();
   }
   regroup_by_gidx(out, d_gidx, {d_slot, d_bnum, d_bcoord, d_median_cp}, d_kind);
   *n_out = out;

@@ -1,0 +1,182 @@
+"""Coordinator side of the view change (gpx_election_begin / gpx_propose_batch_h /
+gpx_prepare_reply_batch): scenarios that run unchanged over the HIP library and over the oracle.
+Every function returns a trace (plain python / numpy values) the tests compare."""
+import numpy as np
+
+from gigapaxos_amd import Engine, make_hri, S_OK
+
+# include/gpx.h
+S_PREACTIVE, S_WINDOW = 8, 3
+EB_PREPARING, EB_ACTIVE, EB_RESEND, EB_UNCHANGED = 0, 1, 2, 3
+V_IGNORED, V_RECORDED, V_ELECTED, V_PREEMPTED = 0, 1, 2, 3
+E_CARRY, E_NOOP, E_PREACTIVE, E_NEWSTOP = 1, 2, 3, 4
+PV_STOP, PV_NOOP = 1, 2
+
+
+def plain_rows(n, acc_slot, acc_bnum, acc_bcoord, gc=-1):
+    """Acceptor-only rows (no coordinator object), as a replica that never was coordinator holds."""
+    rows = make_hri(n)
+    rows["acc_slot"] = acc_slot
+    rows["acc_bnum"] = acc_bnum
+    rows["acc_bcoord"] = acc_bcoord
+    rows["acc_gc_slot"] = gc
+    rows["has_coord"] = 0
+    rows["next_proposal_slot"] = -1
+    return rows
+
+
+def pcs_main_scenario(lib):
+    """PaxosCoordinatorState.main (PaxosCoordinatorState.java:1008-1180), its prepare phase, with 9
+    members instead of 43 (the engine's kmax limit is 16).  Returns the list of step results."""
+    my_id, bnum = 21, 2
+    members = np.array([[21, 23, 30, 31, 40, 41, 50, 51, 60]], np.int32)
+    e = Engine(lib, my_id, 4, kmax=9, window=16, max_batch=64)
+    assert (e.create_groups(np.array([0]), members, 9, plain_rows(1, 0, 0, 23)) == S_OK).all()
+    out = []
+    g = np.array([0], np.int32)
+    out.append(("begin", e.election_begin(g, [bnum]).tolist()))
+    # three pre-active proposals: reqs[0], the stop, reqs[9] (refused: nothing goes after a stop)
+    for stop, h in ((0, 100), (1, 900), (0, 109)):
+        slot, bn, bc, med, st = e.propose(g, [stop], handle=[h])
+        out.append(("propose", int(slot[0]), int(bn[0]), int(bc[0]), int(med[0]), int(st[0])))
+
+    def reply(acceptor, b, pv):
+        (vk, em, st), lists = e.prepare_reply(g, [acceptor], [b[0]], [b[1]], [0], [pv])
+        out.append(("reply", acceptor, int(vk[0]), int(em[0]), int(st[0]), lists[0]))
+
+    mb = (bnum, my_id)
+    reply(10, (bnum - 1, my_id), [])          # lower ballot number: ignored
+    reply(10, (bnum, my_id - 1), [])          # lower coordinator id: ignored
+    reply(10, mb, [])                         # 10 is not a member: ignored
+    m = members[0]
+    acc = [(2, bnum - 1, my_id - 1, 100, 0)]  # pvalues[0] = reqs[0] at slot 2 in ballot (1, 20)
+    reply(int(m[2]), mb, acc)
+    reply(int(m[2]), mb, acc)                 # no duplicates
+    acc = [(2, bnum - 1, my_id, 101, 0), (6, bnum - 1, my_id, 102, 0)]
+    reply(int(m[0]), mb, acc)                 # slot 2 now in the higher ballot (1, 21)
+    reply(int(m[0]), mb, acc)
+    acc = [(7, bnum - 1, my_id, 103, 0), (8, bnum - 1, my_id + 1, 104, 0), (9, bnum - 1, my_id - 1, 105, 0)]
+    reply(int(m[4]), mb, acc)
+    reply(int(m[4]), mb, acc)
+    for i in range(0, 9, 2):
+        reply(int(m[i]), mb, [])
+    out.append(("dump", e.dump(0).tolist()))
+    # active now: a further proposal gets an ACCEPT (refused here: the last proposal is a stop)
+    slot, bn, bc, med, st = e.propose(g, [0], handle=[110])
+    out.append(("propose", int(slot[0]), int(bn[0]), int(bc[0]), int(med[0]), int(st[0])))
+    e.close()
+    return out
+
+
+def small_scenarios(lib):
+    """Hand-made cases around makeCoordinator / handlePrepareReply / nullifyCoordinatorIfPreemptedFully."""
+    my_id = 1
+    G, k, W = 8, 3, 8
+    members = np.tile(np.array([0, 1, 2], np.int32), (G, 1))
+    e = Engine(lib, my_id, G, kmax=k, window=W, max_batch=64)
+    assert (e.create_groups(np.arange(G), members, k, plain_rows(G, 5, 0, 0, gc=3)) == S_OK).all()
+    out = []
+    allg = np.arange(G, dtype=np.int32)
+    # ballot number 0 is active at once; the others wait for PREPARE replies
+    out.append(("begin", e.election_begin(allg, [0, 1, 1, 1, 1, 1, 1, 1]).tolist()))
+    out.append(("begin-again", e.election_begin(allg, [0, 1, 0, 2, 1, 1, 1, 1]).tolist()))
+    # group 1: preempted by a higher ballot while holding two pre-active proposals
+    r = e.propose(np.array([1, 1], np.int32), [0, 1], handle=[11, 12])
+    out.append(("propose", [x.tolist() for x in r]))
+    (vk, em, st), lists = e.prepare_reply([1], [2], [1], [2], [4], [[]])
+    out.append(("preempted", vk.tolist(), em.tolist(), st.tolist(), lists))
+    out.append(("dump1", e.dump(1).tolist()))
+    # group 2: elected with nothing to carry over and no proposals ("no ACCEPTs to send")
+    a = e.prepare_reply([2, 2], [0, 1], [1, 1], [1, 1], [4, 4], [[], []])
+    out.append(("elected-empty", a[0][0].tolist(), a[0][1].tolist(), a[0][2].tolist(), a[1]))
+    # group 3 (ballot 2): duplicate of a carried-over request is dropped, a pre-active below the
+    # carried range is re-proposed after it, no-ops fill the holes
+    r = e.propose(np.array([3, 3, 3], np.int32), [0, 0, 0], handle=[31, 32, 33])  # slots 5, 6, 7
+    out.append(("propose3", [x.tolist() for x in r]))
+    a = e.prepare_reply([3, 3], [2, 0], [2, 2], [1, 1], [6, 7],
+                        [[(9, 1, 0, 32, 0), (7, 1, 2, 77, 0)], [(8, 0, 0, 88, PV_NOOP)]])
+    out.append(("elected3", a[0][0].tolist(), a[0][1].tolist(), a[0][2].tolist(), a[1]))
+    out.append(("dump3", e.dump(3).tolist()))
+    # group 4: accept replies while not active decide nothing; a higher-ballot one with no proposals
+    # outstanding removes the coordinator (PISM:1361-1364)
+    d = e.accept_reply([4, 4], [1, 3], [1, 2], [5, 5], [0, 2], [4, 4])
+    out.append(("ar4", d.as_tuple_array().tolist() if hasattr(d, "as_tuple_array") else None))
+    out.append(("dump4", e.dump(4).tolist()))
+    # group 5: a carried-over stop that is not the last proposal gets a new stop appended
+    a = e.prepare_reply([5, 5], [0, 2], [1, 1], [1, 1], [5, 5],
+                        [[(5, 0, 0, 51, PV_STOP)], [(6, 0, 2, 52, 0)]])
+    out.append(("elected5", a[0][0].tolist(), a[0][1].tolist(), a[0][2].tolist(), a[1]))
+    # group 6: carried slots that collide in the ring of `window` entries: reply refused whole
+    a = e.prepare_reply([6, 6, 6], [0, 0, 2], [1, 1, 1], [1, 1, 1], [5, 5, 5],
+                        [[(5, 0, 0, 61, 0), (13, 0, 0, 62, 0)], [(5, 0, 0, 61, 0)], [(14, 0, 2, 63, 0)]])
+    out.append(("window6", a[0][0].tolist(), a[0][1].tolist(), a[0][2].tolist(), a[1]))
+    out.append(("dump6", e.dump(6).tolist()))
+    out.append(("counters", [int(x) for x in e.counters()]))
+    e.close()
+    return out
+
+
+def fuzz_run(lib, seed, G=96, k=3, W=8, steps=60, my_id=1):
+    """Random interleaving of elections, pre-active proposals, prepare replies, accept replies and
+    ordinary rounds over G groups; returns every output and the final dump of every group."""
+    rng = np.random.default_rng(seed)
+    ids = np.arange(k, dtype=np.int32)
+    members = np.tile(ids, (G, 1))
+    e = Engine(lib, my_id, G, kmax=k, window=W, max_batch=max(4096, 4 * G))
+    base_slot = rng.integers(0, 50, G).astype(np.int32)
+    rows = plain_rows(G, base_slot, 0, 0, gc=base_slot - 1)
+    rows["acc_bcoord"] = rng.integers(0, k, G)
+    assert (e.create_groups(np.arange(G), members, k, rows) == S_OK).all()
+    cur_b = np.zeros(G, np.int32)       # the ballot number this node last ran with
+    trace = []
+    hctr = 1000
+    for step in range(steps):
+        op = rng.integers(0, 6)
+        if op == 0:  # run for coordinator in a random subset
+            sel = np.nonzero(rng.random(G) < 0.3)[0].astype(np.int32)
+            if sel.size == 0:
+                continue
+            bn = cur_b[sel] + rng.integers(0, 3, sel.size).astype(np.int32)
+            cur_b[sel] = np.maximum(cur_b[sel], bn)
+            trace.append(("begin", e.election_begin(sel, bn).tolist()))
+        elif op == 1:  # proposals (pre-active where an election is running)
+            n = int(rng.integers(1, 2 * G))
+            gi = rng.integers(0, G, n).astype(np.int32)
+            stop = (rng.random(n) < 0.03).astype(np.uint8)
+            h = np.arange(hctr, hctr + n, dtype=np.int64)
+            hctr += n
+            trace.append(("propose", [x.tolist() for x in e.propose(gi, stop, handle=h)]))
+        elif op in (2, 3):  # prepare replies
+            n = int(rng.integers(1, 3 * G))
+            gi = rng.integers(0, G, n).astype(np.int32)
+            acc = rng.integers(0, k + 1, n).astype(np.int32)  # k = not a member
+            rb = cur_b[gi] + (rng.random(n) < 0.08).astype(np.int32) - (rng.random(n) < 0.08).astype(np.int32)
+            rc = np.where(rng.random(n) < 0.9, my_id, rng.integers(0, k, n)).astype(np.int32)
+            first = base_slot[gi] + rng.integers(-1, 3, n).astype(np.int32)
+            pvs = []
+            for i in range(n):
+                m = int(rng.integers(0, 4)) if rng.random() < 0.6 else 0
+                slots = rng.choice(np.arange(first[i] - 1, first[i] + (W if rng.random() < 0.9 else 2 * W)), m,
+                                   replace=False)
+                pv = []
+                for s in slots:
+                    hh = int(rng.integers(1000, max(hctr, 1001))) if rng.random() < 0.3 else int(10 ** 6 + s)
+                    pv.append((int(s), int(rng.integers(0, max(int(rb[i]), 1))), int(rng.integers(0, k)), hh,
+                               int(rng.choice([0, 0, 0, PV_STOP, PV_NOOP]))))
+                pvs.append(pv)
+            (vk, em, st), lists = e.prepare_reply(gi, acc, rb, rc, first, pvs)
+            trace.append(("reply", vk.tolist(), em.tolist(), st.tolist(), lists))
+        elif op == 4:  # accept replies, some with a higher ballot
+            n = int(rng.integers(1, 2 * G))
+            gi = rng.integers(0, G, n).astype(np.int32)
+            hb = rng.random(n) < 0.15
+            d = e.accept_reply(gi, cur_b[gi] + hb, np.where(hb, rng.integers(0, k, n), my_id),
+                               base_slot[gi] + rng.integers(0, W, n), rng.integers(0, k, n),
+                               base_slot[gi] - 1 + rng.integers(0, 2, n))
+            trace.append(("ar", d.as_tuple_array().tolist()))
+        else:
+            trace.append(("dump", [e.dump(int(g)).tolist() for g in rng.integers(0, G, 8)]))
+    trace.append(("final", [e.dump(g).tolist() for g in range(G)]))
+    trace.append(("counters", [int(x) for x in e.counters()]))
+    e.close()
+    return trace

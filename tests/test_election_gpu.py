@@ -1,0 +1,32 @@
+"""Coordinator side of the view change on the GPU: the HIP library against the oracle, bit for bit -
+the PaxosCoordinatorState.main restatement, the hand-made cases, and random interleavings of
+elections, pre-active proposals, prepare replies and accept replies."""
+import pytest
+
+from tests.election_common import pcs_main_scenario, small_scenarios, fuzz_run, V_ELECTED, V_PREEMPTED
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for x, y in zip(a, b):
+        assert x == y, (x[0], x, y)
+
+
+def test_pcs_main_parity(hip_lib, oracle_lib):
+    _same(pcs_main_scenario(hip_lib), pcs_main_scenario(oracle_lib))
+
+
+def test_small_scenarios_parity(hip_lib, oracle_lib):
+    _same(small_scenarios(hip_lib), small_scenarios(oracle_lib))
+
+
+@pytest.mark.parametrize("seed,G,k,W,steps", [(1, 96, 3, 8, 60), (2, 300, 5, 16, 60), (3, 700, 3, 8, 80),
+                                              (4, 64, 9, 32, 50), (5, 2000, 3, 8, 40)])
+def test_election_fuzz_parity(hip_lib, oracle_lib, seed, G, k, W, steps):
+    a = fuzz_run(hip_lib, seed, G=G, k=k, W=W, steps=steps)
+    b = fuzz_run(oracle_lib, seed, G=G, k=k, W=W, steps=steps)
+    _same(a, b)
+    kinds = [v for x in b if x[0] == "reply" for v in x[1]]
+    assert V_ELECTED in kinds and V_PREEMPTED in kinds

@@ -179,6 +179,12 @@ def _parse_dump(w):
         c["node_slots"] = w[i:i + k]; i += k
         npn = w[i]; i += 1
         c["proposals"] = [tuple(w[i + 3 * j:i + 3 * j + 3]) for j in range(npn)]; i += 3 * npn
+        c["active"] = w[i]; i += 1
+        if not c["active"]:  # running for coordinator: waitfor, pre-active handles, carry-overs
+            c["waitfor"] = (w[i], w[i + 1]); i += 2
+            i += 2 * npn
+            nco = w[i]; i += 1
+            c["carryover"] = [tuple(w[i + 6 * j:i + 6 * j + 6]) for j in range(nco)]; i += 6 * nco
         out["coord"] = c
     assert i == len(w)
     return out
