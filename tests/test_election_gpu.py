@@ -30,3 +30,17 @@ def test_election_fuzz_parity(hip_lib, oracle_lib, seed, G, k, W, steps):
     _same(a, b)
     kinds = [v for x in b if x[0] == "reply" for v in x[1]]
     assert V_ELECTED in kinds and V_PREEMPTED in kinds
+
+
+@pytest.mark.parametrize("G,seed,window", [(200, 0, 8), (3000, 1, 8), (500, 2, 16)])
+def test_failover_end_to_end_parity(hip_lib, oracle_lib, G, seed, window):
+    """Three engines: node 0 dies with ACCEPTs in flight, node 1 scans, runs, is elected and carries the
+    accepted values over; every step's outputs, the execution logs and the state dumps equal the
+    oracle's (the safety invariants are asserted inside failover_run for both)."""
+    from tests.failover_common import failover_run
+
+    a = failover_run(hip_lib, G=G, seed=seed, window=window)
+    b = failover_run(oracle_lib, G=G, seed=seed, window=window)
+    assert a.keys() == b.keys()
+    for key in a:
+        assert a[key] == b[key], key
