@@ -88,6 +88,7 @@ _SIGS = {
     "election_begin": [C.c_int32] + [_VP] * 3,
     "prepare_reply_batch": [C.c_int32] + [_VP] * 19,
     "propose_batch_h": [C.c_int32] + [_VP] * 8,
+    "poke_scan": [C.c_int32] + [_VP] * 9,
 }
 _DEV_SIGS = {
     "engine_set_stream": [_VP],
@@ -373,6 +374,23 @@ class Engine:
         st = np.zeros(max(n, 1), np.uint8)
         self.lib.check(self.lib.fn["election_begin"](self.h, n, _p(gidx), _p(bnum), _p(st)), "election_begin")
         return st[:n]
+
+    def poke_scan(self, gidx=None):
+        """What is waiting for replies (pokeLocalCoordinator / PREPARE resend minus the clocks):
+        (poke kind, slot, bnum, bcoord, median_cp, flags, heard mask, status) per group; gidx None =
+        all groups."""
+        if gidx is None:
+            n, g = int(self.cfg.max_groups), None
+        else:
+            g = _i32(gidx)
+            n = g.shape[0]
+        m = max(n, 1)
+        pk, fl, st = (np.zeros(m, np.uint8) for _ in range(3))
+        sl, bn, bc, md = (np.zeros(m, np.int32) for _ in range(4))
+        hd = np.zeros(m, np.uint32)
+        self.lib.check(self.lib.fn["poke_scan"](self.h, n, _p(g) if g is not None else None, _p(pk), _p(sl), _p(bn),
+                                                _p(bc), _p(md), _p(fl), _p(hd), _p(st)), "poke_scan")
+        return pk[:n], sl[:n], bn[:n], bc[:n], md[:n], fl[:n], hd[:n], st[:n]
 
     def prepare_reply(self, gidx, acceptor, r_bnum, r_bcoord, first_slot, pvalues=None):
         """PISM.handlePrepareReply for a batch of PREPARE_REPLYs.  `pvalues[i]` = the reply's

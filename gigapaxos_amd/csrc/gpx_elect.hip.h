@@ -83,6 +83,64 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_election_begin(DevState S, int32_
   }
 }
 
+/* pokeLocalCoordinator / PREPARE resend, minus the clocks (include/gpx.h gpx_poke_scan) */
+template <int KMAX>
+__global__ __launch_bounds__(GPX_BLOCK) void k_poke_scan(DevState S, int32_t n,
+                                                        const int32_t* __restrict__ gidx,
+                                                        uint8_t* __restrict__ poke,
+                                                        int32_t* __restrict__ slot,
+                                                        int32_t* __restrict__ bnum,
+                                                        int32_t* __restrict__ bcoord,
+                                                        int32_t* __restrict__ median_cp,
+                                                        uint8_t* __restrict__ p_flags,
+                                                        uint32_t* __restrict__ heard,
+                                                        uint8_t* __restrict__ status) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const int32_t g = gidx ? gidx[i] : i;
+  uint8_t pk = GPX_POKE_NONE, fl = 0, st = GPX_S_OK;
+  int32_t sl = 0, bn = 0, bc = 0, med = 0;
+  uint32_t hd = 0;
+  if ((uint32_t)g >= (uint32_t)S.G || !(S.g_flags[g] & GF_EXISTS)) {
+    st = GPX_S_NOGROUP;
+  } else {
+    const uint32_t gf = S.g_flags[g];
+    if (gf & GF_HASCOORD) {
+      const int32_t s = S.a_slot[g];
+      if (gf & GF_PREPARING) {
+        pk = GPX_POKE_PREPARE;
+        hd = S.c_wait[g];
+      } else {
+        const int32_t d = jsub(S.c_next[g], s); /* in myProposals' window iff 1 <= d <= W */
+        const uint32_t e = (d >= 1 && d <= S.W) ? S.p_ring[(int64_t)(s & (S.W - 1)) * S.G + g] : 0u;
+        if (e & PR_PRESENT) {
+          const int32_t k = (int32_t)GF_K(gf);
+          int32_t ns[KMAX];
+#pragma unroll
+          for (int q = 0; q < KMAX; q++) ns[q] = (q < k) ? S.node_slots[(int64_t)q * S.G + g] : 0;
+          pk = GPX_POKE_ACCEPT;
+          med = median_minus<KMAX>(ns, k);
+          fl = (e & PR_STOP) ? GPX_PV_STOP : 0;
+          hd = e & 0xffffu;
+        }
+      }
+      if (pk != GPX_POKE_NONE) {
+        sl = s;
+        bn = S.c_bnum[g];
+        bc = S.c_bcoord[g];
+      }
+    }
+  }
+  poke[i] = pk;
+  slot[i] = sl;
+  bnum[i] = bn;
+  bcoord[i] = bc;
+  median_cp[i] = med;
+  p_flags[i] = fl;
+  heard[i] = hd;
+  status[i] = st;
+}
+
 /* fe[] entry of the proposal list being built */
 #define FE_PRESENT 0x1000u
 #define FE_STOP 0x1u

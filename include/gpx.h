@@ -364,6 +364,30 @@ int gpx_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uin
                         const int64_t* handle, int32_t* slot, int32_t* bnum, int32_t* bcoord,
                         int32_t* median_cp, uint8_t* status);
 
+/* ---- retransmission: what is waiting for replies ------------------------------- */
+
+#define GPX_POKE_NONE 0
+#define GPX_POKE_ACCEPT 1  /* the active coordinator is commandering the acceptor's next slot */
+#define GPX_POKE_PREPARE 2 /* the coordinator is not active: its PREPARE is outstanding */
+/*
+ * replaces: the state half of the per-message preamble (PaxosInstanceStateMachine.java:480-492):
+ * pokeLocalCoordinator (PISM:2268-2279) -> PaxosCoordinator.reissueAcceptIfWaitingTooLong(c,
+ * paxosState.getSlot()) (PaxosCoordinator.java:334-350) -> isCommandering(slot) + reInitCommander
+ * (PaxosCoordinatorState.java:741-750, 841-851), and the PREPARE resend branch of
+ * checkRunForCoordinator (PISM:2169-2181) -> remakeCoordinator -> prepare() (PCS:214-220).
+ * For group gidx[i] (gidx == NULL: groups 0 .. n-1): poke[i] = GPX_POKE_ACCEPT with the ACCEPT to
+ * multicast again {slot = the acceptor's slot, ballot, median_cp = getMajorityCommittedSlot() NOW,
+ * p_flags = GPX_PV_STOP bit, heard = members that already replied (bit per member index)} iff the
+ * coordinator is active and still holds a proposal for that slot - only the head-of-line slot is ever
+ * re-sent; GPX_POKE_PREPARE with {ballot, slot = the acceptor's slot = PreparePacket.firstUndecidedSlot,
+ * heard = waitforMyBallot's mask} iff a coordinator exists and is not active.  The clocks stay with
+ * the host (testAndSetWaitingTooLong's ACCEPT_TIMEOUT / PREPARE_TIMEOUT with exponential backoff, PCS:
+ * 715-739): it calls this for the groups whose batch timer expired.  No state changes.  Host pointers.
+ */
+int gpx_poke_scan(gpx_engine* h, int32_t n, const int32_t* gidx, uint8_t* poke, int32_t* slot,
+                  int32_t* bnum, int32_t* bcoord, int32_t* median_cp, uint8_t* p_flags,
+                  uint32_t* heard, uint8_t* status);
+
 /* ---- view change: who runs for coordinator ------------------------------------ */
 
 #define GPX_RUN_NO 0

@@ -45,6 +45,7 @@ def pcs_main_scenario(lib):
         out.append(("reply", acceptor, int(vk[0]), int(em[0]), int(st[0]), lists[0]))
 
     mb = (bnum, my_id)
+    out.append(("poke", [x.tolist() for x in e.poke_scan(g)]))
     reply(10, (bnum - 1, my_id), [])          # lower ballot number: ignored
     reply(10, (bnum, my_id - 1), [])          # lower coordinator id: ignored
     reply(10, mb, [])                         # 10 is not a member: ignored
@@ -61,6 +62,7 @@ def pcs_main_scenario(lib):
     for i in range(0, 9, 2):
         reply(int(m[i]), mb, [])
     out.append(("dump", e.dump(0).tolist()))
+    out.append(("poke", [x.tolist() for x in e.poke_scan(g)]))
     # active now: a further proposal gets an ACCEPT (refused here: the last proposal is a stop)
     slot, bn, bc, med, st = e.propose(g, [0], handle=[110])
     out.append(("propose", int(slot[0]), int(bn[0]), int(bc[0]), int(med[0]), int(st[0])))
@@ -176,6 +178,8 @@ def fuzz_run(lib, seed, G=96, k=3, W=8, steps=60, my_id=1):
             trace.append(("ar", d.as_tuple_array().tolist()))
         else:
             trace.append(("dump", [e.dump(int(g)).tolist() for g in rng.integers(0, G, 8)]))
+            trace.append(("poke", [x.tolist() for x in e.poke_scan()]))
+            trace.append(("poke-some", [x.tolist() for x in e.poke_scan(rng.integers(-2, G + 2, 50))]))
     trace.append(("final", [e.dump(g).tolist() for g in range(G)]))
     trace.append(("counters", [int(x) for x in e.counters()]))
     e.close()

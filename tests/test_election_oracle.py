@@ -21,6 +21,8 @@ def test_pcs_main_prepare_phase(oracle_lib):
     assert next(it) == ("propose", 1, 2, 21, 0, S_PREACTIVE)
     assert next(it)[-1] == S_REFUSED  # after the stop
     # canIgnorePrepareReply: lower ballot number, lower coordinator id, non-member
+    # running for coordinator: the PREPARE (2, 21) from slot 0 is what a timer would resend
+    assert next(it) == ("poke", [[2], [0], [2], [21], [0], [0], [0], [0]])
     for _ in range(3):
         r = next(it)
         assert r[2] == V_IGNORED and r[5] == []
@@ -44,6 +46,9 @@ def test_pcs_main_prepare_phase(oracle_lib):
         (10, E_NEWSTOP, 0, PV_STOP),    # processStop: a stop exists and the last proposal is none
     ]
     next(it)  # dump
+    # active: the head-of-line proposal (the acceptor's slot 0) is the one ACCEPT a poke re-sends,
+    # with the median of the node slots as they are now and nobody heard from yet
+    assert next(it) == ("poke", [[1], [0], [2], [21], [0], [0], [0], [0]])
     assert next(it)[-1] == S_REFUSED
 
 
