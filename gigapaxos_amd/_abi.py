@@ -99,6 +99,9 @@ _DEV_SIGS = {
     "accept_reply_batch_dev": [C.c_int32] + [_VP] * 14,
     "commit_batch_dev": [C.c_int32] + [_VP] * 11,
     "prepare_batch_dev": [C.c_int32] + [_VP] * 13,
+    "election_begin_dev": [C.c_int32] + [_VP] * 3,
+    "propose_batch_h_dev": [C.c_int32] + [_VP] * 8,
+    "prepare_reply_batch_dev": [C.c_int32] + [_VP] * 6 + [C.c_int32] + [_VP] * 13,
     "profile_enable": [C.c_int32],
     "profile_read": [C.POINTER(GpxKernelStat), C.c_int32],
 }

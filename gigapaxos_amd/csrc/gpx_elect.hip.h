@@ -25,7 +25,9 @@
 #pragma once
 
 struct PReplyIn {
-  const int32_t *pv_off, *pv_slot, *pv_bnum, *pv_bcoord;
+  const int32_t* pv_off;
+  int32_t pv_total;
+  const int32_t *pv_slot, *pv_bnum, *pv_bcoord;
   const int64_t* pv_handle;
   const uint8_t* pv_flags;
 };
@@ -241,9 +243,10 @@ __device__ __noinline__ void elect_group(const DevState& S, const DevScratch& X,
             co_loaded = true;
           }
           const int32_t o = I.pv_off[ix], m = I.pv_off[ix + 1] - o;
-          /* engine limit: carried slots must not collide in the ring (reply dropped whole) */
-          bool clash = false;
-          {
+          /* engine limit: carried slots must not collide in the ring (reply dropped whole); a slice
+           * outside the pvalue columns (device-pointer callers: nothing validated it) likewise */
+          bool clash = o < 0 || m < 0 || (int64_t)o + m > (int64_t)I.pv_total;
+          if (!clash) {
             int32_t claimed[64];
             unsigned long long nm = 0;
             for (int32_t j = 0; j < m; j++) {

@@ -364,6 +364,26 @@ int gpx_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uin
                         const int64_t* handle, int32_t* slot, int32_t* bnum, int32_t* bcoord,
                         int32_t* median_cp, uint8_t* status);
 
+/*
+ * Device-pointer twins of the three calls above (conventions of the other *_dev calls: asynchronous
+ * on the engine's streams, columns resident in HBM).  gpx_prepare_reply_batch_dev takes the number
+ * of pvalue entries as pv_total (= pv_off[n]); the offsets are not validated on the host - a record
+ * whose slice falls outside [0, pv_total] is refused with GPX_S_WINDOW.
+ */
+int gpx_election_begin_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                           uint8_t* e_status);
+int gpx_propose_batch_h_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
+                            const int64_t* handle, int32_t* slot, int32_t* bnum, int32_t* bcoord,
+                            int32_t* median_cp, uint8_t* status);
+int gpx_prepare_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* acceptor,
+                                const int32_t* r_bnum, const int32_t* r_bcoord,
+                                const int32_t* first_slot, const int32_t* pv_off, int32_t pv_total,
+                                const int32_t* pv_slot, const int32_t* pv_bnum,
+                                const int32_t* pv_bcoord, const int64_t* pv_handle,
+                                const uint8_t* pv_flags, uint8_t* v_kind, int32_t* e_count,
+                                int32_t* e_median, int32_t* e_slot, uint8_t* e_kind,
+                                int64_t* e_handle, uint8_t* e_flags, uint8_t* status);
+
 /* ---- retransmission: what is waiting for replies ------------------------------- */
 
 #define GPX_POKE_NONE 0
