@@ -161,8 +161,12 @@ __device__ __forceinline__ void for_signed_order(int32_t lo, int32_t cnt, F f) {
   for (int32_t j = 0; j < split; j++) f(j);
 }
 
-template <int KMAX>
-__device__ __noinline__ void elect_group(const DevState& S, const DevScratch& X, int32_t g,
+/* WMAX >= window: size of the per-lane arrays (scratch-backed; the host instantiates 64 only).
+ * __forceinline__ like every other per-group function here: as a __noinline__ call (an earlier
+ * build) the kernel faulted intermittently on the GPU box (SIGSEGV inside elect_group under rocgdb,
+ * a silent abort outside it) with the same source that runs clean inlined. */
+template <int KMAX, int WMAX>
+__device__ __forceinline__ void elect_group(const DevState& S, const DevScratch& X, int32_t g,
                                          GroupIter& it, const PReplyIn& I, const PReplyOut& O) {
   const int32_t G = S.G, W = S.W, Wm = W - 1, n = O.n;
   uint32_t gf = S.g_flags[g];
@@ -181,8 +185,8 @@ __device__ __noinline__ void elect_group(const DevState& S, const DevScratch& X,
   }
   bool ns_dirty = false, wait_dirty = false, prop_dirty = false;
   /* this group's carried-over pvalues, by ring index */
-  int32_t cs[64], cb[64], cc[64], cf[64];
-  int64_t ch[64];
+  int32_t cs[WMAX], cb[WMAX], cc[WMAX], cf[WMAX];
+  int64_t ch[WMAX];
   bool co_loaded = false;
   unsigned long long cmask = 0, co_dirty = 0;
   unsigned long long n_drop = 0;
@@ -247,7 +251,7 @@ __device__ __noinline__ void elect_group(const DevState& S, const DevScratch& X,
            * outside the pvalue columns (device-pointer callers: nothing validated it) likewise */
           bool clash = o < 0 || m < 0 || (int64_t)o + m > (int64_t)I.pv_total;
           if (!clash) {
-            int32_t claimed[64];
+            int32_t claimed[WMAX];
             unsigned long long nm = 0;
             for (int32_t j = 0; j < m; j++) {
               const int32_t s = I.pv_slot[o + j], x = s & Wm;
@@ -297,8 +301,8 @@ __device__ __noinline__ void elect_group(const DevState& S, const DevScratch& X,
             if (__popc(wait & 0xffffu) > k / 2) {
               /* heardFromMajority: combinePValuesOntoProposals into fe[] / fh[], position j =
                * slot lo + j; committed to p_ring only if it fits `window` slots */
-              uint32_t fe[64];
-              int64_t fh[64];
+              uint32_t fe[WMAX];
+              int64_t fh[WMAX];
               bool fits = true;
               int32_t lo = jsub(next, pcount), pos = pcount;
               if (cmask == 0) {
@@ -439,7 +443,7 @@ __device__ __noinline__ void elect_group(const DevState& S, const DevScratch& X,
 
 /* Record payload (k_scatter_ac): a = acceptor, b = firstSlot, bnum / bcoord = the reply's ballot;
  * the accepted pvalues are read through pv_off[idx]. */
-template <int KMAX>
+template <int KMAX, int WMAX>
 __global__ __launch_bounds__(1024) void k_bucket_prepare_reply(DevState S, DevScratch X, PReplyIn I,
                                                                PReplyOut O) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
@@ -452,6 +456,6 @@ __global__ __launch_bounds__(1024) void k_bucket_prepare_reply(DevState S, DevSc
     if (c == 0 || g >= S.G) continue;
     GroupIter it;
     it.init(bv, l, c);
-    elect_group<KMAX>(S, X, g, it, I, O);
+    elect_group<KMAX, WMAX>(S, X, g, it, I, O);
   }
 }

@@ -33,6 +33,10 @@ thread_local char g_err[256] = "";
       return GPX_EDEVICE;                                                                 \
     }                                                                                     \
   } while (0)
+/* unchecked on purpose: ordering / teardown calls inside helpers that cannot return an error; a
+ * failure stays pending in the runtime and surfaces in the closing HIPCHK(hipGetLastError()) of the
+ * entry point that called the helper */
+#define HIPQ(call) ((void)(call))
 
 struct PendingEvent {
   const char* name;
@@ -132,14 +136,14 @@ struct LaunchScope {
   LaunchScope(gpx_engine* e_, const char* name) : e(e_), on(e_->profiling) {
     if (on) {
       pe.name = name;
-      hipEventCreate(&pe.start);
-      hipEventCreate(&pe.stop);
-      hipEventRecord(pe.start, e->stream);
+      HIPQ(hipEventCreate(&pe.start));
+      HIPQ(hipEventCreate(&pe.stop));
+      HIPQ(hipEventRecord(pe.start, e->stream));
     }
   }
   ~LaunchScope() {
     if (on) {
-      hipEventRecord(pe.stop, e->stream);
+      HIPQ(hipEventRecord(pe.stop, e->stream));
       e->pending.push_back(pe);
     }
   }
@@ -151,12 +155,12 @@ int flush_profile(gpx_engine* e) {
   HIPCHK(hipStreamSynchronize(e->sB));
   for (auto& pe : e->pending) {
     float ms = 0.f;
-    hipEventElapsedTime(&ms, pe.start, pe.stop);
+    HIPQ(hipEventElapsedTime(&ms, pe.start, pe.stop));
     auto& slot = e->prof[pe.name];
     slot.first += 1;
     slot.second += ms;
-    hipEventDestroy(pe.start);
-    hipEventDestroy(pe.stop);
+    HIPQ(hipEventDestroy(pe.start));
+    HIPQ(hipEventDestroy(pe.stop));
   }
   e->pending.clear();
   return GPX_OK;
@@ -232,20 +236,20 @@ int begin_front(gpx_engine* e, std::initializer_list<Range> touched) {
   /* per-scratch-set epoch (the word is only ever raised to the epoch of a call using this set) */
   e->X.epoch = (uint32_t)(e->call_seq + 1);
   if (e->X.epoch == 0) { /* 2^32 calls: restart the epochs from cleared words */
-    hipStreamSynchronize(e->sF);
-    hipStreamSynchronize(e->sB);
-    for (auto& fx : e->fs) hipMemset(fx.unsorted, 0, sizeof(uint32_t));
+    HIPQ(hipStreamSynchronize(e->sF));
+    HIPQ(hipStreamSynchronize(e->sB));
+    for (auto& fx : e->fs) HIPQ(hipMemset(fx.unsorted, 0, sizeof(uint32_t)));
     e->X.epoch = 1;
   }
   e->stream = e->sF;
   if (e->pipeline) {
     if (e->user_stream) {
-      hipEventRecord(e->ev_in, e->user_stream);
-      hipStreamWaitEvent(e->sF, e->ev_in, 0);
+      HIPQ(hipEventRecord(e->ev_in, e->user_stream));
+      HIPQ(hipStreamWaitEvent(e->sF, e->ev_in, 0));
     }
-    if (f.used) hipStreamWaitEvent(e->sF, f.evB, 0);
+    if (f.used) HIPQ(hipStreamWaitEvent(e->sF, f.evB, 0));
     gpx_engine::FrontSet& prev = e->fs[s ^ 1];
-    if (prev.used && ranges_overlap(touched, e->last_outputs)) hipStreamWaitEvent(e->sF, prev.evB, 0);
+    if (prev.used && ranges_overlap(touched, e->last_outputs)) HIPQ(hipStreamWaitEvent(e->sF, prev.evB, 0));
   }
   return s;
 }
@@ -261,14 +265,14 @@ void begin_back(gpx_engine* e, int s, int32_t n) {
     e->bucket_lds = GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs) + e->lds_pad;
   }
   if (e->pipeline) {
-    hipEventRecord(e->fs[s].evF, e->sF);
-    hipStreamWaitEvent(e->sB, e->fs[s].evF, 0);
+    HIPQ(hipEventRecord(e->fs[s].evF, e->sF));
+    HIPQ(hipStreamWaitEvent(e->sB, e->fs[s].evF, 0));
   }
   e->stream = e->sB;
 }
 void end_call(gpx_engine* e, int s, std::initializer_list<Range> outputs) {
   if (e->pipeline) {
-    hipEventRecord(e->fs[s].evB, e->sB);
+    HIPQ(hipEventRecord(e->fs[s].evB, e->sB));
     e->fs[s].used = true;
     e->last_outputs.assign(outputs.begin(), outputs.end());
   }
@@ -425,9 +429,9 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
                          (const void*)k_bucket_accept,     (const void*)k_bucket_commit,
                          (const void*)k_bucket_pack_ar,    (const void*)k_bucket_reqbatch,
                          (const void*)k_bucket_prepare,
-                         (const void*)k_bucket_prepare_reply<4>,
-                         (const void*)k_bucket_prepare_reply<8>,
-                         (const void*)k_bucket_prepare_reply<16>};
+                         (const void*)k_bucket_prepare_reply<4, 64>,
+                         (const void*)k_bucket_prepare_reply<8, 64>,
+                         (const void*)k_bucket_prepare_reply<16, 64>};
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bucket_lds));
   }
@@ -467,20 +471,20 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
 
 int gpx_engine_destroy(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
-  if (h->sF) hipStreamSynchronize(h->sF);
-  if (h->sB) hipStreamSynchronize(h->sB);
+  if (h->sF) HIPQ(hipStreamSynchronize(h->sF));
+  if (h->sB) HIPQ(hipStreamSynchronize(h->sB));
   for (auto& pe : h->pending) {
-    hipEventDestroy(pe.start);
-    hipEventDestroy(pe.stop);
+    HIPQ(hipEventDestroy(pe.start));
+    HIPQ(hipEventDestroy(pe.stop));
   }
-  for (void* p : h->allocs) hipFree(p);
-  if (h->own_stream) hipStreamDestroy(h->own_stream);
-  if (h->front_stream) hipStreamDestroy(h->front_stream);
-  if (h->back_stream) hipStreamDestroy(h->back_stream);
-  if (h->ev_in) hipEventDestroy(h->ev_in);
+  for (void* p : h->allocs) HIPQ(hipFree(p));
+  if (h->own_stream) HIPQ(hipStreamDestroy(h->own_stream));
+  if (h->front_stream) HIPQ(hipStreamDestroy(h->front_stream));
+  if (h->back_stream) HIPQ(hipStreamDestroy(h->back_stream));
+  if (h->ev_in) HIPQ(hipEventDestroy(h->ev_in));
   for (auto& f : h->fs) {
-    if (f.evF) hipEventDestroy(f.evF);
-    if (f.evB) hipEventDestroy(f.evB);
+    if (f.evF) HIPQ(hipEventDestroy(f.evF));
+    if (f.evB) HIPQ(hipEventDestroy(f.evB));
   }
   delete h;
   return GPX_OK;
@@ -881,11 +885,11 @@ int gpx_group_create(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
     if (status) D2H(status + o, d_s, (size_t)c);
     HIPCHK(hipStreamSynchronize(h->sB));
   }
-  hipFree(d_g);
-  hipFree(d_m);
-  hipFree(d_k);
-  hipFree(d_s);
-  hipFree(d_r);
+  (void)hipFree(d_g);
+  (void)hipFree(d_m);
+  (void)hipFree(d_k);
+  (void)hipFree(d_s);
+  (void)hipFree(d_r);
   return rc;
 }
 
@@ -911,9 +915,9 @@ static int retire_impl(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mo
     if (status) D2H(status + o, d_s, (size_t)c);
     HIPCHK(hipStreamSynchronize(h->sB));
   }
-  hipFree(d_g);
-  hipFree(d_s);
-  hipFree(d_r);
+  (void)hipFree(d_g);
+  (void)hipFree(d_s);
+  (void)hipFree(d_r);
   return GPX_OK;
 }
 
