@@ -85,6 +85,7 @@ struct gpx_engine {
   std::map<std::string, std::pair<uint64_t, double>> prof;
   size_t bucket_lds = 0;      /* dynamic LDS of the current per-bucket launch */
   int32_t lds_recs_max = 0;   /* staging capacity the engine was sized for (kmax records per group) */
+  int32_t lds_recs_hw = 0;    /* ... and the most a workgroup can stage (oversized calls) */
   int bucket_threads = 256;
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
   /* wire codec (gpx_wire_host.inc): paxosID table, row free list, scratch - allocated on first use */
@@ -261,7 +262,16 @@ void begin_back(gpx_engine* e, int s, int32_t n) {
   {
     int64_t want = (int64_t)n / std::max(1, e->X.nbk);
     want = (want + want / 4 + 128 + 63) / 64 * 64;
-    e->X.lds_recs = (int32_t)std::max<int64_t>(256, std::min<int64_t>(want, e->lds_recs_max));
+    /* a call that carries more than the round the engine was sized for (several slots per group in
+     * one batch) may take the LDS the hardware allows rather than fall back to the global-memory
+     * path for every bucket */
+    const int64_t mean = (int64_t)n / std::max(1, e->X.nbk);
+    const bool oversized = mean + mean / 8 > e->lds_recs_max;
+    const int64_t cap = oversized ? e->lds_recs_hw : e->lds_recs_max;
+    e->X.lds_recs = (int32_t)std::max<int64_t>(256, std::min<int64_t>(want, cap));
+    /* beyond that too: nearly every bucket is regrouped in global memory - do not hold LDS it
+     * will not use */
+    if (oversized && mean > e->lds_recs_hw + e->lds_recs_hw / 4) e->X.lds_recs = 256;
     e->bucket_lds = GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs) + e->lds_pad;
   }
   if (e->pipeline) {
@@ -419,10 +429,12 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     if (const char* lr = getenv("GPX_LDS_RECS")) want = std::min<int64_t>(want, std::max(64, atoi(lr)));
     X.lds_recs = (int32_t)want;
     e->lds_recs_max = X.lds_recs;
+    e->lds_recs_hw = (int32_t)std::max<int64_t>(want, std::min<int64_t>(lds_cap, (int64_t)GPX_BUCKET_ITEMS * e->bucket_threads));
   }
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
-  if (e->bucket_lds > 64 * 1024) { /* more dynamic LDS than the default limit: opt in per kernel */
+  const size_t bucket_lds_hw = GPX_BUCKET_LDS_BYTES(X.gb, e->lds_recs_hw) + e->lds_pad;
+  if (bucket_lds_hw > 64 * 1024) { /* more dynamic LDS than the default limit: opt in per kernel */
     const void* fns[] = {(const void*)k_bucket_ar<4>,      (const void*)k_bucket_ar<8>,
                          (const void*)k_bucket_ar<16>,     (const void*)k_bucket_propose<4>,
                          (const void*)k_bucket_propose<8>, (const void*)k_bucket_propose<16>,
@@ -433,7 +445,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
                          (const void*)k_bucket_prepare_reply<8, 64>,
                          (const void*)k_bucket_prepare_reply<16, 64>};
     for (const void* f : fns)
-      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->bucket_lds));
+      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_hw));
   }
   { /* k_hist may take up to GPX_HSUB_MAX histograms of dynamic LDS */
     const int hl = GPX_HSUB_MAX * X.nbk * (int)sizeof(int32_t);
