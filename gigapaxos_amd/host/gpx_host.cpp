@@ -1,0 +1,523 @@
+// gpx::PaxosManager - see gpx_host.hpp.  Everything protocol goes through the C-ABI (include/gpx.h,
+// include/gpx_wire.h); this file moves frames, keeps request values and performs the upcalls.
+#include "gpx_host.hpp"
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+
+namespace gpx {
+
+namespace {
+
+/* big-endian java.nio.ByteBuffer writes */
+void put8(Frame& f, int v) { f.push_back((uint8_t)v); }
+void put16(Frame& f, int v) {
+  f.push_back((uint8_t)(v >> 8));
+  f.push_back((uint8_t)v);
+}
+void put32(Frame& f, int32_t v) {
+  for (int s = 24; s >= 0; s -= 8) f.push_back((uint8_t)((uint32_t)v >> s));
+}
+void put64(Frame& f, int64_t v) {
+  for (int s = 56; s >= 0; s -= 8) f.push_back((uint8_t)((uint64_t)v >> s));
+}
+int32_t get32(const uint8_t* p) {
+  return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]);
+}
+int64_t get64(const uint8_t* p) {
+  uint64_t v = 0;
+  for (int i = 0; i < 8; i++) v = (v << 8) | p[i];
+  return (int64_t)v;
+}
+/* PaxosPacket header (PaxosPacket.java:461-476) */
+void putHeader(Frame& f, int32_t type, int32_t version, const std::string& paxosID) {
+  put32(f, GPX_WT_PAXOS_PACKET);
+  put32(f, type);
+  put32(f, version);
+  put8(f, (int)paxosID.size());
+  f.insert(f.end(), paxosID.begin(), paxosID.end());
+}
+/* fixed part of RequestPacket.toBytes between the header and the digest length:
+ * requestID 8 | stop 1 | client address 4 + 2 | listen address 4 + 2 | entryReplica 4 | entryTime 8 |
+ * shouldReturnRequestValue 1 | forwardCount 4 | broadcasted 1 */
+constexpr size_t kReqFixed = 8 + 1 + 6 + 6 + 4 + 8 + 1 + 4 + 1;
+constexpr size_t kAcceptTail = 4 + 4 + 4 + 1 + 4 + 1 + 4; /* AcceptPacket.java:95-135 */
+
+/* BatchedAcceptReply.toBytes of ONE reply (BatchedAcceptReply.java:119-173): what goes out for a
+ * reply gpx_wire_pack_accept_replies left unbatched */
+Frame makeSingleAcceptReply(const std::string& paxosID, int32_t version, int32_t acceptor, int32_t bnum,
+                            int32_t bcoord, int32_t slot, int32_t maxCheckpointedSlot, int64_t requestID) {
+  Frame f;
+  putHeader(f, GPX_WT_BATCHED_ACCEPT_REPLY, version, paxosID);
+  put32(f, acceptor);
+  put32(f, bnum);
+  put32(f, bcoord);
+  put32(f, slot);
+  put32(f, maxCheckpointedSlot);
+  put64(f, requestID);
+  put8(f, 0);
+  put32(f, 1);
+  put32(f, slot);
+  put64(f, requestID);
+  return f;
+}
+
+}  // namespace
+
+int32_t javaStringHash(const std::string& s) {
+  uint32_t h = 0;
+  for (unsigned char c : s) h = 31u * h + c;
+  return (int32_t)h;
+}
+
+int32_t roundRobinCoordinator(const std::string& paxosID, const std::vector<int32_t>& members, int32_t ballotnum) {
+  /* members[Math.abs(ballotnum + paxosID.hashCode()) % members.length] (PISM:2251-2256) */
+  const int32_t x = (int32_t)((uint32_t)ballotnum + (uint32_t)javaStringHash(paxosID));
+  const int64_t a = x == INT32_MIN ? (int64_t)INT32_MIN : (x < 0 ? -(int64_t)x : (int64_t)x);
+  int64_t idx = a % (int64_t)members.size(); /* sign follows the dividend, as in Java */
+  if (idx < 0) return INT32_MIN;             /* the Java would throw ArrayIndexOutOfBounds */
+  return members[(size_t)idx];
+}
+
+Frame makeRequestFrame(const std::string& paxosID, int32_t version, int64_t requestID, const std::string& value,
+                       bool stop, int32_t entryReplica) {
+  Frame f;
+  f.reserve(13 + paxosID.size() + kReqFixed + 16 + value.size());
+  putHeader(f, GPX_WT_REQUEST, version, paxosID);
+  put64(f, requestID);
+  put8(f, stop ? 1 : 0);
+  put32(f, 0), put16(f, 0); /* client address */
+  put32(f, 0), put16(f, 0); /* listen address */
+  put32(f, entryReplica);
+  put64(f, 0); /* entryTime */
+  put8(f, 0);  /* shouldReturnRequestValue */
+  put32(f, 0); /* forwardCount */
+  put8(f, 0);  /* broadcasted */
+  put32(f, 0); /* digest */
+  put32(f, (int32_t)value.size());
+  f.insert(f.end(), value.begin(), value.end());
+  put32(f, 0); /* response */
+  put32(f, 0); /* batched */
+  return f;
+}
+
+Frame makeAcceptFrame(const Frame& req, int32_t slot, int32_t bnum, int32_t bcoord, int32_t median, int32_t sender) {
+  Frame f;
+  f.reserve(req.size() + kAcceptTail);
+  f = req;
+  const int32_t t = GPX_WT_ACCEPT; /* the packet type int of the header */
+  for (int i = 0; i < 4; i++) f[4 + i] = (uint8_t)((uint32_t)t >> (24 - 8 * i));
+  put32(f, slot);
+  put32(f, bnum);
+  put32(f, bcoord);
+  put8(f, 0); /* recovery */
+  put32(f, median);
+  put8(f, 0); /* noCoalesce */
+  put32(f, sender);
+  return f;
+}
+
+bool parseRequest(const Frame& f, Request* out) {
+  if (f.size() < 13) return false;
+  const size_t idLen = f[12];
+  size_t p = 13 + idLen;
+  if (f.size() < p + kReqFixed + 8) return false;
+  out->paxosID.assign((const char*)&f[13], idLen);
+  out->requestID = get64(&f[p]);
+  out->stop = f[p + 8] != 0;
+  p += kReqFixed;
+  const int32_t dl = get32(&f[p]);
+  p += 4;
+  if (dl < 0 || f.size() < p + (size_t)dl + 4) return false;
+  p += (size_t)dl;
+  const int32_t vl = get32(&f[p]);
+  p += 4;
+  if (vl < 0 || f.size() < p + (size_t)vl) return false;
+  out->requestValue.assign((const char*)&f[p], (size_t)vl);
+  return true;
+}
+
+/* ------------------------------------------------------------------------------------------ */
+
+PaxosManager::PaxosManager(int32_t myID, Replicable* app, Messenger* messenger, const Options& opt)
+    : myID_(myID), app_(app), messenger_(messenger), opt_(opt), nextRequestID_(((int64_t)myID << 40) + 1) {
+  gpx_config cfg;
+  std::memset(&cfg, 0, sizeof(cfg));
+  cfg.my_id = myID;
+  cfg.max_groups = opt.maxGroups;
+  cfg.kmax = opt.kmax;
+  cfg.window = opt.window;
+  cfg.max_batch = opt.maxBatch;
+  cfg.device = opt.device;
+  cfg.flags = GPX_F_ACCEPTS_FROM_DISK;
+  if (!check(gpx_engine_create(&cfg, &engine_), "gpx_engine_create")) engine_ = nullptr;
+  rowName_.resize((size_t)opt.maxGroups);
+}
+
+PaxosManager::~PaxosManager() {
+  if (engine_) gpx_engine_destroy(engine_);
+}
+
+bool PaxosManager::check(int rc, const char* what) {
+  if (rc >= 0) return true;
+  char buf[256];
+  std::snprintf(buf, sizeof(buf), "%s failed rc=%d %s", what, rc, gpx_last_error());
+  err_ = buf;
+  std::fprintf(stderr, "gpx::PaxosManager(%d): %s\n", myID_, buf);
+  return false;
+}
+
+bool PaxosManager::createPaxosInstance(const std::string& paxosID, const std::vector<int32_t>& members,
+                                       const std::string& initialState) {
+  if (!initialState.empty()) app_->restore(paxosID, initialState);
+  return createPaxosInstances({paxosID}, members) == 1;
+}
+
+int PaxosManager::createPaxosInstances(const std::vector<std::string>& ids, const std::vector<int32_t>& gms) {
+  if (!engine_ || ids.empty()) return 0;
+  std::vector<int32_t> members(gms);
+  std::sort(members.begin(), members.end()); /* PISM:205 */
+  const int32_t k = (int32_t)members.size();
+  if (k < 1 || k > opt_.kmax) return 0;
+  std::vector<std::string> fresh;
+  for (auto& id : ids)
+    if (!id.empty() && id.size() <= GPX_W_MAX_NAME && !pinstances_.count(id)) fresh.push_back(id);
+  const int32_t n = (int32_t)fresh.size();
+  if (n == 0) return 0;
+  std::vector<int32_t> gidx((size_t)n);
+  if (!check(gpx_rows_alloc(engine_, n, gidx.data()), "gpx_rows_alloc")) return 0;
+  std::vector<int32_t> mem((size_t)n * opt_.kmax, 0);
+  std::vector<uint8_t> ks((size_t)n, (uint8_t)k), st((size_t)n, 0);
+  std::vector<gpx_hri> rows((size_t)n);
+  for (int32_t i = 0; i < n; i++) {
+    for (int32_t j = 0; j < k; j++) mem[(size_t)i * opt_.kmax + j] = members[(size_t)j];
+    /* regular creation with an initial-state checkpoint (PISM:612-618, 656-668, 692-699): acceptor
+     * slot 1, gcSlot 0, ballot (0, coordinator); the coordinator object only on the coordinator */
+    const int32_t coord = roundRobinCoordinator(fresh[(size_t)i], members, 0);
+    gpx_hri& r = rows[(size_t)i];
+    std::memset(&r, 0, sizeof(r));
+    r.acc_slot = 1;
+    r.acc_bcoord = coord;
+    r.acc_gc_slot = 0;
+    r.has_coord = coord == myID_ ? 1 : 0;
+    r.coord_bcoord = coord;
+    r.next_proposal_slot = r.has_coord ? 1 : -1;
+    for (int32_t j = 0; j < k; j++) r.node_slots[j] = r.has_coord ? -1 : 0;
+  }
+  if (!check(gpx_group_create(engine_, n, gidx.data(), mem.data(), ks.data(), rows.data(), st.data()),
+             "gpx_group_create"))
+    return 0;
+  std::vector<uint8_t> names;
+  std::vector<int32_t> off((size_t)n + 1, 0);
+  for (int32_t i = 0; i < n; i++) {
+    names.insert(names.end(), fresh[(size_t)i].begin(), fresh[(size_t)i].end());
+    off[(size_t)i + 1] = (int32_t)names.size();
+  }
+  std::vector<uint8_t> bst((size_t)n, 0);
+  if (!check(gpx_names_bind(engine_, n, names.data(), off.data(), gidx.data(), bst.data()), "gpx_names_bind"))
+    return 0;
+  int made = 0;
+  for (int32_t i = 0; i < n; i++) {
+    if (st[(size_t)i] != GPX_S_OK || bst[(size_t)i] != GPX_S_OK) continue;
+    pinstances_[fresh[(size_t)i]] = Instance{gidx[(size_t)i], 0, members};
+    rowName_[(size_t)gidx[(size_t)i]] = fresh[(size_t)i];
+    made++;
+  }
+  return made;
+}
+
+bool PaxosManager::kill(const std::string& paxosID) {
+  auto it = pinstances_.find(paxosID);
+  if (it == pinstances_.end() || !engine_) return false;
+  const int32_t g = it->second.gidx;
+  uint8_t st = 0;
+  check(gpx_group_retire(engine_, 1, &g, GPX_RETIRE_KILL, nullptr, &st), "gpx_group_retire");
+  check(gpx_names_unbind(engine_, 1, &g, &st), "gpx_names_unbind");
+  check(gpx_rows_free(engine_, 1, &g), "gpx_rows_free");
+  for (auto a = accepted_.begin(); a != accepted_.end();)
+    a = (int32_t)(a->first >> 32) == g ? accepted_.erase(a) : std::next(a);
+  rowName_[(size_t)g].clear();
+  pinstances_.erase(it);
+  return true;
+}
+
+int64_t PaxosManager::propose(const std::string& paxosID, const std::string& value, bool stop) {
+  auto it = pinstances_.find(paxosID);
+  if (it == pinstances_.end()) return 0;
+  const int64_t id = nextRequestID_++;
+  requests_.push_back(makeRequestFrame(paxosID, it->second.version, id, value, stop, myID_));
+  return id;
+}
+
+void PaxosManager::handleIncomingPacket(const uint8_t* frame, size_t len) { inbox_.emplace_back(frame, frame + len); }
+void PaxosManager::handleIncomingPacket(Frame&& frame) { inbox_.push_back(std::move(frame)); }
+
+void PaxosManager::sendToMembers(const Instance& in, const Frame& frame, bool includeSelf) {
+  /* loopback first, then the others ascending (SHORT_CIRCUIT_LOCAL, PaxosManager.java:2116-2128) */
+  if (includeSelf) inbox_.push_back(frame);
+  for (int32_t m : in.members)
+    if (m != myID_) messenger_->send(m, Frame(frame));
+}
+
+void PaxosManager::executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* xf, const int32_t* xc) {
+  /* extractExecuteAndCheckpoint's upcalls (PISM:1619-1701, 1755-1842): per run, slot order */
+  for (int32_t r = 0; r < nRuns; r++) {
+    for (int32_t j = 0; j < xc[r]; j++) {
+      const int32_t slot = (int32_t)((uint32_t)xf[r] + (uint32_t)j);
+      auto a = accepted_.find(key(xg[r], slot));
+      if (a == accepted_.end()) {
+        err_ = "decided slot without a stored ACCEPT";
+        std::fprintf(stderr, "gpx::PaxosManager(%d): %s (gidx %d slot %d)\n", myID_, err_.c_str(), xg[r], slot);
+        continue;
+      }
+      Request req;
+      if (parseRequest(a->second.frame, &req)) {
+        req.slot = slot;
+        for (int tries = 0; tries < 3 && !app_->execute(req, false); tries++) {
+        }
+        stats_.executed++;
+      }
+      accepted_.erase(a); /* acceptedProposals.remove(slot) on execution (PaxosAcceptor.java:357-359) */
+    }
+  }
+}
+
+size_t PaxosManager::process() {
+  if (!engine_) return 0;
+  /* everything queued so far, bounded by the engine's batch capacity */
+  std::vector<Frame> frames;
+  const size_t maxFrames = (size_t)std::max(1, opt_.maxBatch / 4);
+  while (!inbox_.empty() && frames.size() < maxFrames) {
+    frames.push_back(std::move(inbox_.front()));
+    inbox_.pop_front();
+  }
+  while (!requests_.empty() && frames.size() < maxFrames) {
+    frames.push_back(std::move(requests_.front()));
+    requests_.pop_front();
+  }
+  if (frames.empty()) return 0;
+  const int32_t nF = (int32_t)frames.size();
+  std::vector<int64_t> off((size_t)nF + 1, 0);
+  for (int32_t i = 0; i < nF; i++) off[(size_t)i + 1] = off[(size_t)i] + (int64_t)frames[(size_t)i].size();
+  std::vector<uint8_t> buf((size_t)off[(size_t)nF]);
+  for (int32_t i = 0; i < nF; i++)
+    std::memcpy(buf.data() + off[(size_t)i], frames[(size_t)i].data(), frames[(size_t)i].size());
+
+  /* ---- bytes -> columns (PaxosPacketDemultiplexerFast + the ByteBuffer constructors + getInstance) */
+  const int32_t capV = (int32_t)std::min<int64_t>(opt_.maxBatch, off[(size_t)nF] / 12 + nF);
+  const int32_t capC = (int32_t)std::min<int64_t>(opt_.maxBatch, off[(size_t)nF] / 4 + nF);
+  struct Cols {
+    std::vector<int32_t> gidx, bnum, bcoord, slot, x, y, frame;
+    std::vector<uint8_t> f;
+    std::vector<int64_t> id;
+    explicit Cols(int32_t cap)
+        : gidx((size_t)cap), bnum((size_t)cap), bcoord((size_t)cap), slot((size_t)cap), x((size_t)cap),
+          y((size_t)cap), frame((size_t)cap), f((size_t)cap), id((size_t)cap) {}
+  };
+  Cols v(capV), c(capC), a(nF), q(nF);
+  gpx_wire_votes V{capV, v.gidx.data(), v.bnum.data(), v.bcoord.data(), v.slot.data(), v.x.data(), v.y.data(),
+                   v.frame.data()};
+  gpx_wire_commits C{capC, c.gidx.data(), c.bnum.data(), c.bcoord.data(), c.slot.data(), c.x.data(), c.f.data(),
+                     c.frame.data()};
+  gpx_wire_accepts A{nF, a.gidx.data(), a.bnum.data(), a.bcoord.data(), a.slot.data(), a.x.data(), a.f.data(),
+                     a.y.data(), a.id.data(), a.frame.data()};
+  gpx_wire_requests Q{nF, q.gidx.data(), q.f.data(), q.id.data(), q.frame.data()};
+  std::vector<uint8_t> fst((size_t)nF);
+  std::vector<int32_t> fg((size_t)nF), ft((size_t)nF);
+  gpx_wire_counts cnt;
+  std::memset(&cnt, 0, sizeof(cnt));
+  if (!check(gpx_wire_decode(engine_, nF, buf.data(), off.data(), fst.data(), fg.data(), ft.data(), &V, &C, &A, &Q,
+                             &cnt),
+             "gpx_wire_decode"))
+    return 0;
+  stats_.engine_calls++;
+  for (int32_t i = nF - 1; i >= 0; i--) { /* back to front: push_front keeps their order */
+    if (fst[(size_t)i] == GPX_W_CAPACITY) {
+      inbox_.push_front(std::move(frames[(size_t)i])); /* did not fit the columns: next pass */
+      frames[(size_t)i].clear();
+    } else if (fst[(size_t)i] != GPX_W_OK) {
+      stats_.dropped_frames++; /* the reference drops such a packet */
+    }
+  }
+  const int32_t nV = std::min(cnt.n_votes, capV), nC = std::min(cnt.n_commits, capC);
+  const int32_t nA = std::min(cnt.n_accepts, nF), nQ = std::min(cnt.n_requests, nF);
+  std::vector<int32_t> xg, xf, xc;
+  int32_t nRuns = 0;
+  auto runsFor = [&](int32_t n) {
+    xg.assign((size_t)std::max(n, 1), 0);
+    xf.assign((size_t)std::max(n, 1), 0);
+    xc.assign((size_t)std::max(n, 1), 0);
+    nRuns = 0;
+  };
+
+  /* ---- REQUEST -> handleProposal (PISM:818-888): ACCEPT multicast or forward to the coordinator */
+  std::vector<Frame> localAccepts; /* my own ACCEPTs: short-circuited, never byteified twice */
+  std::vector<int32_t> la[6];      /* gidx bnum bcoord slot median flags of those */
+  std::vector<int64_t> laId;
+  if (nQ > 0) {
+    std::vector<int32_t> slot((size_t)nQ), bn((size_t)nQ), bc((size_t)nQ), med((size_t)nQ);
+    std::vector<uint8_t> st((size_t)nQ);
+    if (!check(gpx_propose_batch(engine_, nQ, q.gidx.data(), q.f.data(), slot.data(), bn.data(), bc.data(),
+                                 med.data(), st.data()),
+               "gpx_propose_batch"))
+      return 0;
+    stats_.engine_calls++;
+    for (int32_t i = 0; i < nQ; i++) {
+      const Frame& rf = frames[(size_t)q.frame[(size_t)i]];
+      if (st[(size_t)i] == GPX_S_OK) {
+        const Instance& in = pinstances_.at(rowName_[(size_t)q.gidx[(size_t)i]]);
+        Frame acc = makeAcceptFrame(rf, slot[(size_t)i], bn[(size_t)i], bc[(size_t)i], med[(size_t)i], myID_);
+        for (int32_t m : in.members)
+          if (m != myID_) messenger_->send(m, Frame(acc));
+        la[0].push_back(q.gidx[(size_t)i]), la[1].push_back(bn[(size_t)i]), la[2].push_back(bc[(size_t)i]);
+        la[3].push_back(slot[(size_t)i]), la[4].push_back(med[(size_t)i]);
+        la[5].push_back(q.f[(size_t)i] ? GPX_A_STOP : 0);
+        laId.push_back(q.id[(size_t)i]);
+        localAccepts.push_back(std::move(acc));
+        stats_.proposed++;
+      } else if (st[(size_t)i] == GPX_S_FORWARD && bc[(size_t)i] != myID_) {
+        messenger_->send(bc[(size_t)i], Frame(rf)); /* unicast to paxosState.getBallotCoord() */
+        stats_.forwarded++;
+      } else {
+        stats_.refused++;
+      }
+    }
+  }
+
+  /* ---- ACCEPT -> handleAccept (PISM:1080-1166): store, reply (coalesced per ballot), maybe execute */
+  const int32_t nLA = (int32_t)localAccepts.size();
+  const int32_t nAll = nLA + nA;
+  if (nAll > 0) {
+    std::vector<int32_t> g((size_t)nAll), bn((size_t)nAll), bc((size_t)nAll), sl((size_t)nAll), md((size_t)nAll),
+        snd((size_t)nAll);
+    std::vector<uint8_t> fl((size_t)nAll);
+    std::vector<int64_t> id((size_t)nAll);
+    std::vector<const Frame*> src((size_t)nAll);
+    for (int32_t i = 0; i < nLA; i++) { /* loopback first */
+      g[(size_t)i] = la[0][(size_t)i], bn[(size_t)i] = la[1][(size_t)i], bc[(size_t)i] = la[2][(size_t)i];
+      sl[(size_t)i] = la[3][(size_t)i], md[(size_t)i] = la[4][(size_t)i], fl[(size_t)i] = (uint8_t)la[5][(size_t)i];
+      snd[(size_t)i] = myID_, id[(size_t)i] = laId[(size_t)i], src[(size_t)i] = &localAccepts[(size_t)i];
+    }
+    for (int32_t i = 0; i < nA; i++) {
+      const size_t o = (size_t)(nLA + i), s = (size_t)i;
+      g[o] = a.gidx[s], bn[o] = a.bnum[s], bc[o] = a.bcoord[s], sl[o] = a.slot[s], md[o] = a.x[s], fl[o] = a.f[s];
+      snd[o] = a.y[s], id[o] = a.id[s], src[o] = &frames[(size_t)a.frame[s]];
+    }
+    std::vector<int32_t> rb((size_t)nAll), rc((size_t)nAll), rm((size_t)nAll);
+    std::vector<uint8_t> rf((size_t)nAll), st((size_t)nAll), unb((size_t)nAll);
+    runsFor(nAll);
+    if (!check(gpx_accept_batch(engine_, nAll, g.data(), bn.data(), bc.data(), sl.data(), md.data(), fl.data(),
+                                rb.data(), rc.data(), rm.data(), rf.data(), st.data(), xg.data(), xf.data(),
+                                xc.data(), &nRuns),
+               "gpx_accept_batch"))
+      return 0;
+    stats_.engine_calls++;
+    stats_.accepts += (uint64_t)nAll;
+    for (int32_t i = 0; i < nAll; i++)
+      if (st[(size_t)i] == GPX_S_OK && (rf[(size_t)i] & GPX_R_STORED))
+        accepted_[key(g[(size_t)i], sl[(size_t)i])] = StoredAccept{bn[(size_t)i], bc[(size_t)i], *src[(size_t)i]};
+    executeRuns(nRuns, xg.data(), xf.data(), xc.data()); /* meta-commits an ACCEPT released (:1158-1161) */
+    const int64_t capB = (int64_t)nAll * 192 + 1024;
+    std::vector<uint8_t> out((size_t)capB);
+    std::vector<int64_t> fo((size_t)nAll);
+    std::vector<int32_t> flen((size_t)nAll), fgi((size_t)nAll), fd((size_t)nAll);
+    int32_t nf = 0;
+    int64_t nb = 0;
+    if (!check(gpx_wire_pack_accept_replies(engine_, nAll, g.data(), sl.data(), snd.data(), id.data(), rb.data(),
+                                            rc.data(), rm.data(), st.data(), unb.data(), out.data(), capB,
+                                            fo.data(), flen.data(), fgi.data(), fd.data(), &nf, &nb),
+               "gpx_wire_pack_accept_replies"))
+      return 0;
+    stats_.engine_calls++;
+    for (int32_t f = 0; f < nf; f++) {
+      Frame fr(out.begin() + fo[(size_t)f], out.begin() + fo[(size_t)f] + flen[(size_t)f]);
+      if (fd[(size_t)f] == myID_)
+        inbox_.push_back(std::move(fr));
+      else
+        messenger_->send(fd[(size_t)f], std::move(fr));
+    }
+    for (int32_t i = 0; i < nAll; i++)
+      if (unb[(size_t)i]) { /* e.g. a reply in a higher ballot than the sender's: back to the sender */
+        Frame fr = makeSingleAcceptReply(rowName_[(size_t)g[(size_t)i]], 0, myID_, rb[(size_t)i], rc[(size_t)i],
+                                         sl[(size_t)i], rm[(size_t)i], id[(size_t)i]);
+        if (snd[(size_t)i] == myID_)
+          inbox_.push_back(std::move(fr));
+        else
+          messenger_->send(snd[(size_t)i], std::move(fr));
+      }
+  }
+
+  /* ---- BATCHED_ACCEPT_REPLY -> handleBatchedAcceptReply (PISM:1370-1419): decisions */
+  if (nV > 0) {
+    std::vector<int32_t> dg((size_t)nV), ds((size_t)nV), db((size_t)nV), dc((size_t)nV), dm((size_t)nV);
+    std::vector<uint8_t> dk((size_t)nV), st((size_t)nV);
+    int32_t nOut = 0;
+    if (!check(gpx_accept_reply_batch(engine_, nV, v.gidx.data(), v.bnum.data(), v.bcoord.data(), v.slot.data(),
+                                      v.x.data(), v.y.data(), dg.data(), ds.data(), db.data(), dc.data(), dm.data(),
+                                      dk.data(), &nOut, st.data()),
+               "gpx_accept_reply_batch"))
+      return 0;
+    stats_.engine_calls++;
+    stats_.votes += (uint64_t)nV;
+    if (nOut > 0) {
+      /* BATCHED_COMMIT to the other members, coalesced per (group, ballot) */
+      const int64_t capB = (int64_t)nOut * 128 + 1024;
+      std::vector<uint8_t> out((size_t)capB);
+      std::vector<int64_t> fo((size_t)nOut);
+      std::vector<int32_t> flen((size_t)nOut), fgi((size_t)nOut);
+      int32_t nf = 0;
+      int64_t nb = 0;
+      if (!check(gpx_wire_pack_commits(engine_, nOut, dg.data(), ds.data(), db.data(), dc.data(), dm.data(),
+                                       dk.data(), out.data(), capB, fo.data(), flen.data(), fgi.data(), &nf, &nb),
+                 "gpx_wire_pack_commits"))
+        return 0;
+      stats_.engine_calls++;
+      for (int32_t f = 0; f < nf; f++) {
+        const Instance& in = pinstances_.at(rowName_[(size_t)fgi[(size_t)f]]);
+        Frame fr(out.begin() + fo[(size_t)f], out.begin() + fo[(size_t)f] + flen[(size_t)f]);
+        sendToMembers(in, fr, false);
+      }
+      /* my own copy of a decision is handled as a full DECISION (local short circuit) */
+      std::vector<int32_t> lg, lb, lc, ls, lm;
+      std::vector<uint8_t> lk;
+      for (int32_t i = 0; i < nOut; i++) {
+        if (dk[(size_t)i] != GPX_D_DECISION) continue; /* PREEMPTED: dropped (FORWARD_PREEMPTED_REQUESTS off) */
+        uint8_t kind = GPX_C_HASVALUE;
+        auto sa = accepted_.find(key(dg[(size_t)i], ds[(size_t)i]));
+        Request rq;
+        if (sa != accepted_.end() && parseRequest(sa->second.frame, &rq) && rq.stop) kind |= GPX_C_STOP;
+        lg.push_back(dg[(size_t)i]), lb.push_back(db[(size_t)i]), lc.push_back(dc[(size_t)i]);
+        ls.push_back(ds[(size_t)i]), lm.push_back(dm[(size_t)i]), lk.push_back(kind);
+        stats_.decisions++;
+      }
+      const int32_t nL = (int32_t)lg.size();
+      if (nL > 0) {
+        std::vector<uint8_t> cst((size_t)nL);
+        runsFor(nL);
+        if (!check(gpx_commit_batch(engine_, nL, lg.data(), lb.data(), lc.data(), ls.data(), lm.data(), lk.data(),
+                                    cst.data(), xg.data(), xf.data(), xc.data(), &nRuns),
+                   "gpx_commit_batch"))
+          return 0;
+        stats_.engine_calls++;
+        executeRuns(nRuns, xg.data(), xf.data(), xc.data());
+      }
+    }
+  }
+
+  /* ---- BATCHED_COMMIT -> handleBatchedCommit (PISM:1480-1528) -> in-order execution */
+  if (nC > 0) {
+    std::vector<uint8_t> cst((size_t)nC);
+    runsFor(nC);
+    if (!check(gpx_commit_batch(engine_, nC, c.gidx.data(), c.bnum.data(), c.bcoord.data(), c.slot.data(),
+                                c.x.data(), c.f.data(), cst.data(), xg.data(), xf.data(), xc.data(), &nRuns),
+               "gpx_commit_batch"))
+      return 0;
+    stats_.engine_calls++;
+    stats_.commits += (uint64_t)nC;
+    executeRuns(nRuns, xg.data(), xf.data(), xc.data());
+  }
+  return (size_t)nF;
+}
+
+}  // namespace gpx

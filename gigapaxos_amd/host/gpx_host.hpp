@@ -1,0 +1,149 @@
+// Host side above the C-ABI, in C++: the mirror of the reference's PaxosManager surface for the
+// accept / decide path (the reference is Java and no JDK exists in the build image or on the GPU box,
+// so this is where the host code lives; INTEGRATION.md shows the JNI binding a Java host would use
+// instead).  Names and meaning follow the reference:
+//
+//   gpx::Replicable      edu.umass.cs.gigapaxos.interfaces.Replicable (execute / checkpoint / restore)
+//   gpx::Messenger       what PaxosManager.send hands MessagingTasks to (PaxosManager.java:2098-2128)
+//   gpx::PaxosManager    PaxosManager: createPaxosInstance (PM:611-810), propose (PM:1206-1260),
+//                        handleIncomingPacket -> handlePaxosPacket (PM:1126-1204), kill (PM:2162)
+//
+// One PaxosManager = one node id = one engine handle.  Everything the per-group Java objects did
+// (PaxosInstanceStateMachine, PaxosAcceptor, PaxosCoordinatorState, PaxosPacketBatcher's coalescing,
+// the byte decoding of the four byteified packet types) happens behind include/gpx.h and
+// include/gpx_wire.h; this layer only moves frames, keeps the request VALUES (the engine never sees
+// them) and performs the application upcalls in slot order.
+#pragma once
+
+#include <cstdint>
+#include <deque>
+#include <map>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "gpx.h"
+#include "gpx_wire.h"
+
+namespace gpx {
+
+using Frame = std::vector<uint8_t>;
+
+/* RequestPacket as the application sees it (paxospackets/RequestPacket.java:60-160) */
+struct Request {
+  std::string paxosID;
+  int64_t requestID = 0;
+  std::string requestValue;
+  bool stop = false;
+  int32_t slot = 0; /* the slot it was decided in */
+};
+
+/* interfaces/Replicable.java: the replicated application */
+class Replicable {
+ public:
+  virtual ~Replicable() = default;
+  /* execute(Request, doNotReplyToClient): must be deterministic; false = retry (PISM:1755-1842) */
+  virtual bool execute(const Request& request, bool doNotReplyToClient) = 0;
+  virtual std::string checkpoint(const std::string& name) = 0;
+  virtual bool restore(const std::string& name, const std::string& state) = 0;
+};
+
+/* the transport under PaxosManager.send: unicast of one byteified packet to a node id */
+class Messenger {
+ public:
+  virtual ~Messenger() = default;
+  virtual void send(int32_t nodeID, Frame&& frame) = 0;
+};
+
+struct Options {
+  int32_t maxGroups = 1 << 16; /* PC.PINSTANCES_CAPACITY */
+  int32_t kmax = 3;            /* largest replica group */
+  int32_t window = 8;
+  int32_t maxBatch = 1 << 18;
+  int32_t device = -1;
+};
+
+struct Stats {
+  uint64_t proposed = 0, forwarded = 0, accepts = 0, votes = 0, decisions = 0, commits = 0, executed = 0;
+  uint64_t dropped_frames = 0, refused = 0, engine_calls = 0;
+};
+
+class PaxosManager {
+ public:
+  PaxosManager(int32_t myID, Replicable* app, Messenger* messenger, const Options& opt);
+  ~PaxosManager();
+  PaxosManager(const PaxosManager&) = delete;
+  PaxosManager& operator=(const PaxosManager&) = delete;
+
+  /* PaxosManager.createPaxosInstance(paxosID, version, gms, app, initialState) (PM:611-810):
+   * members sorted ascending; the ballot-0 coordinator is roundRobinCoordinator(paxosID, members, 0)
+   * (PISM:2251-2256), created active; false if the name exists or the table is full */
+  bool createPaxosInstance(const std::string& paxosID, const std::vector<int32_t>& members,
+                           const std::string& initialState = std::string());
+  /* many at once (PM:664-691) */
+  int createPaxosInstances(const std::vector<std::string>& paxosIDs, const std::vector<int32_t>& members);
+  /* PaxosManager.propose(paxosID, requestValue, callback) (PM:1206-1260): this node is the entry
+   * replica; returns the request id, 0 if there is no such instance here */
+  int64_t propose(const std::string& paxosID, const std::string& requestValue, bool stop = false);
+  /* a byteified packet from the network (PaxosManager.handleIncomingPacket -> handlePaxosPacket) */
+  void handleIncomingPacket(const uint8_t* frame, size_t len);
+  void handleIncomingPacket(Frame&& frame);
+  /* PaxosManager.kill(paxosID) (PM:2162-2192) */
+  bool kill(const std::string& paxosID);
+
+  /* one pass of the node's pipeline over everything queued so far (the reference spreads this over
+   * its demultiplexer pool, RequestBatcher, PaxosPacketBatcher and the per-instance monitors):
+   * decode -> propose -> accept -> accept-reply -> commit -> in-order execution -> outgoing frames.
+   * Returns the number of frames and requests it consumed (0 = idle). */
+  size_t process();
+
+  int32_t myID() const { return myID_; }
+  const Stats& stats() const { return stats_; }
+  const char* lastError() const { return err_.c_str(); }
+
+ private:
+  struct Instance {
+    int32_t gidx;
+    int32_t version;
+    std::vector<int32_t> members;
+  };
+  struct StoredAccept { /* acceptedProposals' value side: the ACCEPT frame itself */
+    int32_t bnum, bcoord;
+    Frame frame;
+  };
+  static uint64_t key(int32_t gidx, int32_t slot) { return ((uint64_t)(uint32_t)gidx << 32) | (uint32_t)slot; }
+
+  bool check(int rc, const char* what);
+  void executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* xf, const int32_t* xc);
+  void sendToMembers(const Instance& in, const Frame& frame, bool includeSelf);
+
+  int32_t myID_;
+  Replicable* app_;
+  Messenger* messenger_;
+  Options opt_;
+  gpx_engine* engine_ = nullptr;
+  std::unordered_map<std::string, Instance> pinstances_; /* PaxosManager.pinstances */
+  std::vector<std::string> rowName_;                      /* gidx -> paxosID */
+  std::unordered_map<uint64_t, StoredAccept> accepted_;   /* (gidx, slot) -> the stored ACCEPT */
+  std::deque<Frame> inbox_;                               /* frames from the network and from myself */
+  std::deque<Frame> requests_;                            /* REQUEST frames of local clients */
+  int64_t nextRequestID_;
+  Stats stats_;
+  std::string err_;
+};
+
+/* ---- byte-level helpers shared with the example cluster (what a reference node puts on the wire) */
+
+/* RequestPacket.toBytes (RequestPacket.java:819-948) of a plain client request */
+Frame makeRequestFrame(const std::string& paxosID, int32_t version, int64_t requestID,
+                       const std::string& value, bool stop, int32_t entryReplica);
+/* AcceptPacket.toBytes (AcceptPacket.java:95-135): the request bytes re-typed ACCEPT + the 22-byte tail */
+Frame makeAcceptFrame(const Frame& requestFrame, int32_t slot, int32_t bnum, int32_t bcoord,
+                      int32_t medianCheckpointedSlot, int32_t sender);
+/* the request inside a REQUEST / ACCEPT frame; false if the bytes do not parse */
+bool parseRequest(const Frame& frame, Request* out);
+/* java.lang.String.hashCode of an ISO-8859-1 string; PISM.roundRobinCoordinator (PISM:2251-2256) */
+int32_t javaStringHash(const std::string& s);
+int32_t roundRobinCoordinator(const std::string& paxosID, const std::vector<int32_t>& members, int32_t ballotnum);
+
+}  // namespace gpx

@@ -1,0 +1,168 @@
+// In-process replica cluster over gpx::PaxosManager: N nodes, one engine each, frames carried by an
+// in-memory messenger (what tests/loopback_1_group and TESTPaxosMain do over 127.0.0.1 in the
+// reference).  Clients send requests to random entry replicas; a request that lands on a
+// non-coordinator is forwarded (PISM:854-860).  The app mirrors TESTPaxosApp's invariant
+// (testing/TESTPaxosApp.java:190): the request's slot is the group's sequence number, and every
+// replica ends with the same (count, hash chain) per group.
+//
+//   gpx_loopback_cluster [--nodes 3] [--groups 1000] [--rounds 20] [--seed 1] [--value-bytes 64]
+//                        [--stop-last] [--entry any|coordinator]
+// Prints one JSON line; exit code 1 if the replicas disagree or a request was lost.
+#include <cinttypes>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "gpx_host.hpp"
+
+namespace {
+
+struct GroupState {
+  int64_t seqnum = 0;
+  uint64_t hash = 1469598103934665603ull;
+  bool stopped = false;
+};
+
+class HashChainApp : public gpx::Replicable {
+ public:
+  std::map<std::string, GroupState> state;
+  uint64_t outOfOrder = 0;
+  bool execute(const gpx::Request& r, bool) override {
+    GroupState& g = state[r.paxosID];
+    g.seqnum++;
+    if (g.seqnum != r.slot) outOfOrder++; /* assert state.seqnum == requestPacket.slot */
+    uint64_t h = g.hash;
+    auto mix = [&](const void* p, size_t n) {
+      const unsigned char* c = (const unsigned char*)p;
+      for (size_t i = 0; i < n; i++) h = (h ^ c[i]) * 1099511628211ull;
+    };
+    mix(&r.requestID, sizeof(r.requestID));
+    mix(r.requestValue.data(), r.requestValue.size());
+    g.hash = h;
+    if (r.stop) g.stopped = true;
+    return true;
+  }
+  std::string checkpoint(const std::string& name) override { return std::to_string(state[name].seqnum); }
+  bool restore(const std::string&, const std::string&) override { return true; }
+};
+
+class LoopbackMessenger : public gpx::Messenger {
+ public:
+  std::map<int32_t, gpx::PaxosManager*> nodes;
+  uint64_t frames = 0, bytes = 0;
+  void send(int32_t nodeID, gpx::Frame&& f) override {
+    auto it = nodes.find(nodeID);
+    if (it == nodes.end()) return; /* a dead node: the frame is lost */
+    frames++;
+    bytes += f.size();
+    it->second->handleIncomingPacket(std::move(f));
+  }
+};
+
+uint64_t xorshift(uint64_t& s) {
+  s ^= s >> 12;
+  s ^= s << 25;
+  s ^= s >> 27;
+  return s * 2685821657736338717ull;
+}
+
+}  // namespace
+
+int main(int argc, char** argv) {
+  int nNodes = 3, G = 1000, R = 20, valueBytes = 64;
+  uint64_t seed = 1;
+  bool stopLast = false, entryAny = true;
+  for (int i = 1; i < argc; i++) {
+    auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
+    if (is("--nodes") && i + 1 < argc) nNodes = std::atoi(argv[++i]);
+    else if (is("--groups") && i + 1 < argc) G = std::atoi(argv[++i]);
+    else if (is("--rounds") && i + 1 < argc) R = std::atoi(argv[++i]);
+    else if (is("--seed") && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
+    else if (is("--value-bytes") && i + 1 < argc) valueBytes = std::atoi(argv[++i]);
+    else if (is("--stop-last")) stopLast = true;
+    else if (is("--entry") && i + 1 < argc) entryAny = std::strcmp(argv[++i], "any") == 0;
+    else {
+      std::fprintf(stderr, "unknown argument %s\n", argv[i]);
+      return 2;
+    }
+  }
+  std::vector<int32_t> ids;
+  for (int i = 0; i < nNodes; i++) ids.push_back(100 + i);
+  LoopbackMessenger net;
+  std::vector<std::unique_ptr<HashChainApp>> apps;
+  std::vector<std::unique_ptr<gpx::PaxosManager>> pms;
+  gpx::Options opt;
+  opt.maxGroups = G + 16;
+  opt.kmax = nNodes < 3 ? 3 : nNodes;
+  opt.maxBatch = std::max(1 << 16, 8 * G);
+  for (int i = 0; i < nNodes; i++) {
+    apps.emplace_back(new HashChainApp());
+    pms.emplace_back(new gpx::PaxosManager(ids[(size_t)i], apps.back().get(), &net, opt));
+    net.nodes[ids[(size_t)i]] = pms.back().get();
+  }
+  std::vector<std::string> names;
+  for (int g = 0; g < G; g++) names.push_back("TESTPaxosApp" + std::to_string(g));
+  for (auto& pm : pms)
+    if (pm->createPaxosInstances(names, ids) != G) {
+      std::fprintf(stderr, "createPaxosInstances failed on node %d: %s\n", pm->myID(), pm->lastError());
+      return 2;
+    }
+  auto drain = [&]() { /* until no node has anything left to do */
+    for (;;) {
+      size_t work = 0;
+      for (auto& pm : pms) work += pm->process();
+      if (work == 0) break;
+    }
+  };
+  uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 1;
+  uint64_t sent = 0;
+  std::string value((size_t)valueBytes, 'x');
+  for (int r = 0; r < R; r++) {
+    for (int g = 0; g < G; g++) {
+      const uint64_t x = xorshift(rng);
+      for (size_t b = 0; b < value.size() && b < 8; b++) value[b] = (char)('a' + ((x >> (8 * b)) & 15));
+      size_t entry = entryAny ? (size_t)(x % (uint64_t)nNodes) : 0;
+      if (!entryAny) { /* the coordinator itself */
+        const int32_t c = gpx::roundRobinCoordinator(names[(size_t)g], ids, 0);
+        for (size_t i = 0; i < ids.size(); i++)
+          if (ids[i] == c) entry = i;
+      }
+      const bool stop = stopLast && r == R - 1;
+      if (pms[entry]->propose(names[(size_t)g], value, stop)) sent++;
+    }
+    drain();
+  }
+  /* verdict */
+  bool ok = true;
+  uint64_t digest[8] = {0};
+  uint64_t executed0 = 0;
+  for (int i = 0; i < nNodes; i++) {
+    uint64_t d = 0, ex = 0;
+    for (auto& kv : apps[(size_t)i]->state) {
+      d = (d ^ kv.second.hash) * 1099511628211ull + (uint64_t)kv.second.seqnum;
+      ex += (uint64_t)kv.second.seqnum;
+      if (kv.second.seqnum != R) ok = false;
+      if (stopLast && !kv.second.stopped) ok = false;
+    }
+    if (i < 8) digest[i] = d;
+    if (i == 0) executed0 = ex;
+    if ((int)apps[(size_t)i]->state.size() != G || apps[(size_t)i]->outOfOrder || d != digest[0] || ex != sent) ok = false;
+  }
+  std::printf("{\"nodes\": %d, \"groups\": %d, \"rounds\": %d, \"requests\": %" PRIu64 ", \"executed_per_node\": %" PRIu64
+              ", \"state_digest\": \"%016" PRIx64 "\", \"frames\": %" PRIu64 ", \"bytes\": %" PRIu64 ", \"ok\": %s, \"per_node\": [",
+              nNodes, G, R, sent, executed0, digest[0], net.frames, net.bytes, ok ? "true" : "false");
+  for (int i = 0; i < nNodes; i++) {
+    const gpx::Stats& s = pms[(size_t)i]->stats();
+    std::printf("%s{\"id\": %d, \"proposed\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
+                ", \"votes\": %" PRIu64 ", \"decisions\": %" PRIu64 ", \"commits\": %" PRIu64 ", \"executed\": %" PRIu64
+                ", \"refused\": %" PRIu64 ", \"dropped_frames\": %" PRIu64 ", \"engine_calls\": %" PRIu64 "}",
+                i ? ", " : "", pms[(size_t)i]->myID(), s.proposed, s.forwarded, s.accepts, s.votes, s.decisions,
+                s.commits, s.executed, s.refused, s.dropped_frames, s.engine_calls);
+  }
+  std::printf("]}\n");
+  return ok ? 0 : 1;
+}

@@ -1,0 +1,45 @@
+"""Builds and runs the C++ host layer's in-process cluster (gigapaxos_amd/host) - against
+libgpx_hip.so (the product build, made by __graft_entry__.build) or, for the CPU checks of the host
+logic, against the oracle (symbols renamed by tests/host_oracle_prefix.h).  Test infrastructure."""
+import json
+import os
+import subprocess
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HOST = os.path.join(ROOT, "gigapaxos_amd", "host")
+HIP_BIN = os.path.join(HOST, "gpx_loopback_cluster")
+ORC_BIN = os.path.join(ROOT, "oracle", "_host_cluster_oracle")
+
+CASES = [
+    # config #1's shape: 3 replicas, 1 group, 10,000 requests, any entry replica
+    ["--groups", "1", "--rounds", "10000"],
+    # config #2's shape: 10 k groups, full pipeline over frames
+    ["--groups", "10000", "--rounds", "4", "--seed", "7"],
+    ["--groups", "500", "--rounds", "12", "--nodes", "5", "--seed", "3"],
+    ["--groups", "300", "--rounds", "6", "--stop-last", "--entry", "coordinator"],
+    ["--groups", "64", "--rounds", "9", "--value-bytes", "1500", "--seed", "11"],
+]
+
+
+# on the GPU every engine call of the host-pointer API is a synchronous round trip: fewer rounds
+CASES_GPU = [["--groups", "1", "--rounds", "1000"]] + CASES[1:]
+
+
+def build_oracle_cluster():
+    from tests.oracle_binding import build_oracle
+
+    build_oracle()
+    srcs = [os.path.join(HOST, f) for f in ("gpx_host.cpp", "loopback_cluster.cpp")]
+    deps = srcs + [os.path.join(HOST, "gpx_host.hpp"), os.path.join(ROOT, "tests", "host_oracle_prefix.h"),
+                   os.path.join(ROOT, "oracle", "libgpx_oracle.so")]
+    if not os.path.exists(ORC_BIN) or os.path.getmtime(ORC_BIN) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                               "-include", os.path.join(ROOT, "tests", "host_oracle_prefix.h"), "-o", ORC_BIN]
+                              + srcs + ["-L", os.path.join(ROOT, "oracle"), "-lgpx_oracle", "-Wl,-rpath,$ORIGIN"])
+    return ORC_BIN
+
+
+def run_cluster(binary, args, timeout=300):
+    p = subprocess.run([binary] + list(args), capture_output=True, text=True, timeout=timeout)
+    assert p.returncode == 0, (p.returncode, p.stdout[-400:], p.stderr[-400:])
+    return json.loads(p.stdout.strip().splitlines()[-1])
