@@ -126,6 +126,7 @@ bool parseRequest(const Frame& f, Request* out) {
   out->paxosID.assign((const char*)&f[13], idLen);
   out->requestID = get64(&f[p]);
   out->stop = f[p + 8] != 0;
+  out->entryReplica = get32(&f[p + 8 + 1 + 12]);
   p += kReqFixed;
   const int32_t dl = get32(&f[p]);
   p += 4;
@@ -274,7 +275,9 @@ void PaxosManager::executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* 
       Request req;
       if (parseRequest(a->second.frame, &req)) {
         req.slot = slot;
-        for (int tries = 0; tries < 3 && !app_->execute(req, false); tries++) {
+        /* doNotReplyToClient unless this node is the entry replica (PISM:1800-1806); no-ops are fed
+         * to the application as they are to TESTPaxosApp */
+        for (int tries = 0; tries < 3 && !app_->execute(req, req.entryReplica != myID_); tries++) {
         }
         stats_.executed++;
       }
@@ -283,21 +286,238 @@ void PaxosManager::executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* 
   }
 }
 
+void PaxosManager::issueAccept(std::vector<OutAccept>& out, int32_t gidx, const Frame& requestFrame,
+                               int64_t requestID, bool stop, int32_t slot, int32_t bnum, int32_t bcoord,
+                               int32_t median) {
+  const Instance& in = pinstances_.at(rowName_[(size_t)gidx]);
+  Frame acc = makeAcceptFrame(requestFrame, slot, bnum, bcoord, median, myID_);
+  for (int32_t m : in.members)
+    if (m != myID_) messenger_->send(m, Frame(acc));
+  out.push_back(OutAccept{gidx, bnum, bcoord, slot, median, (uint8_t)(stop ? GPX_A_STOP : 0), requestID,
+                          std::move(acc)});
+}
+
+size_t PaxosManager::nodeDown(int32_t nodeID) {
+  if (!engine_) return 0;
+  if (std::find(downNodes_.begin(), downNodes_.end(), nodeID) == downNodes_.end()) downNodes_.push_back(nodeID);
+  /* checkRunForCoordinator's decision for every instance at once */
+  const int32_t n = opt_.maxGroups;
+  std::vector<uint8_t> run((size_t)n), st((size_t)n);
+  std::vector<int32_t> pb((size_t)n), pf((size_t)n);
+  if (!check(gpx_election_scan(engine_, n, nullptr, downNodes_.data(), (int32_t)downNodes_.size(), nullptr, 0, 0,
+                               run.data(), pb.data(), pf.data(), st.data()),
+             "gpx_election_scan"))
+    return 0;
+  stats_.engine_calls++;
+  std::vector<int32_t> g, b;
+  for (int32_t i = 0; i < n; i++)
+    if (st[(size_t)i] == GPX_S_OK && run[(size_t)i] != GPX_RUN_NO) g.push_back(i), b.push_back(pb[(size_t)i]);
+  if (g.empty()) return 0;
+  std::vector<uint8_t> es(g.size());
+  if (!check(gpx_election_begin(engine_, (int32_t)g.size(), g.data(), b.data(), es.data()), "gpx_election_begin"))
+    return 0;
+  stats_.engine_calls++;
+  size_t started = 0;
+  for (size_t i = 0; i < g.size(); i++) {
+    if (es[i] != GPX_EB_PREPARING && es[i] != GPX_EB_RESEND) continue;
+    /* PreparePacket(newBallot, paxosState.getSlot()) to all members, myself included (PISM:2153-2160) */
+    const std::string& name = rowName_[(size_t)g[i]];
+    Frame f;
+    putHeader(f, kTypePrepare, 0, name);
+    put32(f, b[i]);
+    put32(f, myID_);
+    put32(f, pf[(size_t)g[i]]);
+    sendToMembers(pinstances_.at(name), f, true);
+    started++;
+  }
+  stats_.elections_started += started;
+  return started;
+}
+
+/* PISM.handlePrepare (PISM:900-1006): adopt a higher ballot, answer with the accepted pvalues */
+bool PaxosManager::handlePrepares(std::vector<Frame>& prepares) {
+  const int32_t n = (int32_t)prepares.size();
+  std::vector<int32_t> g, bn, bc, fs;
+  for (auto& f : prepares) {
+    const size_t idLen = f.size() > 12 ? f[12] : 0, p = 13 + idLen;
+    auto it = f.size() >= p + 12 ? pinstances_.find(std::string((const char*)&f[13], idLen)) : pinstances_.end();
+    if (it == pinstances_.end()) {
+      stats_.dropped_frames++;
+      continue;
+    }
+    g.push_back(it->second.gidx), bn.push_back(get32(&f[p])), bc.push_back(get32(&f[p + 4]));
+    fs.push_back(get32(&f[p + 8]));
+  }
+  const int32_t m = (int32_t)g.size();
+  if (m == 0) return n > 0;
+  const size_t W = (size_t)opt_.window;
+  std::vector<int32_t> rb((size_t)m), rc((size_t)m), rg((size_t)m), ps((size_t)m * W), pb((size_t)m * W),
+      pc((size_t)m * W);
+  std::vector<uint8_t> rf((size_t)m), st((size_t)m);
+  std::vector<uint64_t> mask((size_t)m);
+  if (!check(gpx_prepare_batch(engine_, m, g.data(), bn.data(), bc.data(), fs.data(), rb.data(), rc.data(),
+                               rg.data(), rf.data(), mask.data(), ps.data(), pb.data(), pc.data(), st.data()),
+             "gpx_prepare_batch"))
+    return false;
+  stats_.engine_calls++;
+  stats_.prepares += (uint64_t)m;
+  for (int32_t i = 0; i < m; i++) {
+    if (st[(size_t)i] != GPX_S_OK) continue;
+    /* PrepareReplyPacket(myID, the acceptor's ballot now, accepted pvalues, gcSlot): a NACK carries
+     * the higher ballot and nothing else, which makes the candidate resign */
+    Frame f, body;
+    int32_t cnt = 0;
+    for (size_t w = 0; w < W; w++) {
+      if (!((mask[(size_t)i] >> w) & 1ull)) continue;
+      const size_t q = w * (size_t)m + (size_t)i;
+      auto a = accepted_.find(key(g[(size_t)i], ps[q]));
+      if (a == accepted_.end()) continue; /* value not at hand: the logger's job in the reference */
+      put32(body, ps[q]), put32(body, pb[q]), put32(body, pc[q]);
+      put32(body, (int32_t)a->second.frame.size());
+      body.insert(body.end(), a->second.frame.begin(), a->second.frame.end());
+      cnt++;
+    }
+    putHeader(f, kTypePrepareReply, 0, rowName_[(size_t)g[(size_t)i]]);
+    put32(f, myID_), put32(f, rb[(size_t)i]), put32(f, rc[(size_t)i]);
+    put32(f, (int32_t)((uint32_t)rg[(size_t)i] + 1u)); /* firstSlot = gcSlot + 1 */
+    put32(f, cnt);
+    f.insert(f.end(), body.begin(), body.end());
+    if (bc[(size_t)i] == myID_)
+      inbox_.push_back(std::move(f));
+    else
+      messenger_->send(bc[(size_t)i], std::move(f)); /* to the PREPARE's sender */
+  }
+  return true;
+}
+
+/* PISM.handlePrepareReply (PISM:1008-1068): record, and on a majority re-issue what was carried over */
+bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector<OutAccept>& out) {
+  std::vector<int32_t> g, acc, rb, rc, fs, off(1, 0), ps, pb, pc;
+  std::vector<int64_t> ph;
+  std::vector<uint8_t> pfl;
+  for (auto& f : replies) {
+    const size_t idLen = f.size() > 12 ? f[12] : 0;
+    size_t p = 13 + idLen;
+    auto it = f.size() >= p + 20 ? pinstances_.find(std::string((const char*)&f[13], idLen)) : pinstances_.end();
+    if (it == pinstances_.end()) {
+      stats_.dropped_frames++;
+      continue;
+    }
+    const int32_t gi = it->second.gidx;
+    g.push_back(gi), acc.push_back(get32(&f[p])), rb.push_back(get32(&f[p + 4])), rc.push_back(get32(&f[p + 8]));
+    fs.push_back(get32(&f[p + 12]));
+    const int32_t cnt = get32(&f[p + 16]);
+    p += 20;
+    for (int32_t j = 0; j < cnt && p + 16 <= f.size(); j++) {
+      const int32_t len = get32(&f[p + 12]);
+      if (len < 0 || p + 16 + (size_t)len > f.size()) break;
+      Frame pv(f.begin() + (long)(p + 16), f.begin() + (long)(p + 16 + (size_t)len));
+      Request rq;
+      if (parseRequest(pv, &rq)) {
+        ps.push_back(get32(&f[p])), pb.push_back(get32(&f[p + 4])), pc.push_back(get32(&f[p + 8]));
+        ph.push_back(rq.requestID);
+        pfl.push_back((uint8_t)((rq.stop ? GPX_PV_STOP : 0) | (rq.isNoop() ? GPX_PV_NOOP : 0)));
+        carried_[{gi, rq.requestID}] = std::move(pv);
+      }
+      p += 16 + (size_t)len;
+    }
+    off.push_back((int32_t)ps.size());
+  }
+  const int32_t n = (int32_t)g.size();
+  if (n == 0) return true;
+  const size_t W = (size_t)opt_.window;
+  std::vector<uint8_t> vk((size_t)n), st((size_t)n), ek((size_t)n * W), ef((size_t)n * W);
+  std::vector<int32_t> ec((size_t)n), em((size_t)n), es((size_t)n * W);
+  std::vector<int64_t> eh((size_t)n * W);
+  ps.push_back(0), pb.push_back(0), pc.push_back(0), ph.push_back(0), pfl.push_back(0); /* never null */
+  if (!check(gpx_prepare_reply_batch(engine_, n, g.data(), acc.data(), rb.data(), rc.data(), fs.data(), off.data(),
+                                     ps.data(), pb.data(), pc.data(), ph.data(), pfl.data(), vk.data(), ec.data(),
+                                     em.data(), es.data(), ek.data(), eh.data(), ef.data(), st.data()),
+             "gpx_prepare_reply_batch"))
+    return false;
+  stats_.engine_calls++;
+  for (int32_t i = 0; i < n; i++) {
+    const int32_t gi = g[(size_t)i];
+    const std::string& name = rowName_[(size_t)gi];
+    if (vk[(size_t)i] == GPX_V_PREEMPTED) {
+      /* hand the pre-active requests to the coordinator I deferred to (PISM:1042-1048) */
+      for (int32_t j = 0; j < ec[(size_t)i]; j++) {
+        auto pa = preactive_.find({gi, eh[(size_t)j * (size_t)n + (size_t)i]});
+        if (pa == preactive_.end()) continue;
+        if (rc[(size_t)i] != myID_) messenger_->send(rc[(size_t)i], std::move(pa->second));
+        preactive_.erase(pa);
+      }
+      stats_.elections_lost++;
+    } else if (vk[(size_t)i] == GPX_V_ELECTED) {
+      /* spawnCommandersForProposals: one ACCEPT per entry, all in my new ballot (rb, me) */
+      for (int32_t j = 0; j < ec[(size_t)i]; j++) {
+        const size_t q = (size_t)j * (size_t)n + (size_t)i;
+        const bool stop = (ef[q] & GPX_PV_STOP) != 0;
+        Frame req;
+        int64_t id = eh[q];
+        if (ek[q] == GPX_E_CARRY) {
+          auto cf = carried_.find({gi, id});
+          if (cf == carried_.end()) continue;
+          req.assign(cf->second.begin(), cf->second.end() - (long)kAcceptTail); /* the request part */
+          stats_.carried_over++;
+        } else if (ek[q] == GPX_E_PREACTIVE) {
+          auto pa = preactive_.find({gi, id});
+          if (pa == preactive_.end()) continue;
+          req = std::move(pa->second);
+          preactive_.erase(pa);
+        } else if (ek[q] == GPX_E_NOOP) {
+          req = makeRequestFrame(name, 0, 0, "NO_OP", false, myID_); /* makeNoopPValue (PCS:878-893) */
+          id = 0;
+          stats_.noops++;
+        } else { /* GPX_E_NEWSTOP: new RequestPacket(0, STOP, true) (PCS:512-516) */
+          req = makeRequestFrame(name, 0, 0, "STOP", true, myID_);
+          id = 0;
+        }
+        issueAccept(out, gi, req, id, stop, es[q], rb[(size_t)i], myID_, em[(size_t)i]);
+      }
+      for (auto c = carried_.lower_bound({gi, INT64_MIN}); c != carried_.end() && c->first.first == gi;)
+        c = carried_.erase(c);
+      stats_.elections_won++;
+    }
+  }
+  return true;
+}
+
 size_t PaxosManager::process() {
   if (!engine_) return 0;
-  /* everything queued so far, bounded by the engine's batch capacity */
+  /* The longest run of queued frames of one kind - PREPAREs, PREPARE replies, or the four byteified
+   * types - bounded by the engine's batch capacity: a whole run goes through the engine as one
+   * batch, and runs are taken in arrival order (a PREPARE that arrived after an ACCEPT is handled
+   * after it, as the reference's per-packet handling would). */
+  auto kindOf = [](const Frame& f) {
+    const int32_t t = f.size() >= 8 ? get32(&f[4]) : -1;
+    return t == kTypePrepare ? 1 : t == kTypePrepareReply ? 2 : 0;
+  };
   std::vector<Frame> frames;
   const size_t maxFrames = (size_t)std::max(1, opt_.maxBatch / 4);
-  while (!inbox_.empty() && frames.size() < maxFrames) {
+  const int kind = inbox_.empty() ? 0 : kindOf(inbox_.front());
+  while (!inbox_.empty() && frames.size() < maxFrames && kindOf(inbox_.front()) == kind) {
     frames.push_back(std::move(inbox_.front()));
     inbox_.pop_front();
   }
-  while (!requests_.empty() && frames.size() < maxFrames) {
-    frames.push_back(std::move(requests_.front()));
-    requests_.pop_front();
-  }
+  if (kind == 0 && inbox_.empty())
+    while (!requests_.empty() && frames.size() < maxFrames) {
+      frames.push_back(std::move(requests_.front()));
+      requests_.pop_front();
+    }
   if (frames.empty()) return 0;
+  const size_t consumed = frames.size();
+  std::vector<OutAccept> outAccepts; /* my own ACCEPTs of this pass: short-circuited, never decoded */
+  if (kind == 1) { /* not among the byteified types: handled from the host layer's own layout */
+    handlePrepares(frames);
+    return consumed;
+  }
+  if (kind == 2) {
+    if (!handlePrepareReplies(frames, outAccepts)) return consumed;
+    frames.clear();
+  }
   const int32_t nF = (int32_t)frames.size();
+  if (nF == 0 && outAccepts.empty()) return consumed;
   std::vector<int64_t> off((size_t)nF + 1, 0);
   for (int32_t i = 0; i < nF; i++) off[(size_t)i + 1] = off[(size_t)i] + (int64_t)frames[(size_t)i].size();
   std::vector<uint8_t> buf((size_t)off[(size_t)nF]);
@@ -315,7 +535,7 @@ size_t PaxosManager::process() {
         : gidx((size_t)cap), bnum((size_t)cap), bcoord((size_t)cap), slot((size_t)cap), x((size_t)cap),
           y((size_t)cap), frame((size_t)cap), f((size_t)cap), id((size_t)cap) {}
   };
-  Cols v(capV), c(capC), a(nF), q(nF);
+  Cols v(std::max(capV, 1)), c(std::max(capC, 1)), a(std::max(nF, 1)), q(std::max(nF, 1));
   gpx_wire_votes V{capV, v.gidx.data(), v.bnum.data(), v.bcoord.data(), v.slot.data(), v.x.data(), v.y.data(),
                    v.frame.data()};
   gpx_wire_commits C{capC, c.gidx.data(), c.bnum.data(), c.bcoord.data(), c.slot.data(), c.x.data(), c.f.data(),
@@ -327,11 +547,13 @@ size_t PaxosManager::process() {
   std::vector<int32_t> fg((size_t)nF), ft((size_t)nF);
   gpx_wire_counts cnt;
   std::memset(&cnt, 0, sizeof(cnt));
-  if (!check(gpx_wire_decode(engine_, nF, buf.data(), off.data(), fst.data(), fg.data(), ft.data(), &V, &C, &A, &Q,
-                             &cnt),
-             "gpx_wire_decode"))
-    return 0;
-  stats_.engine_calls++;
+  if (nF > 0) {
+    if (!check(gpx_wire_decode(engine_, nF, buf.data(), off.data(), fst.data(), fg.data(), ft.data(), &V, &C, &A,
+                               &Q, &cnt),
+               "gpx_wire_decode"))
+      return 0;
+    stats_.engine_calls++;
+  }
   for (int32_t i = nF - 1; i >= 0; i--) { /* back to front: push_front keeps their order */
     if (fst[(size_t)i] == GPX_W_CAPACITY) {
       inbox_.push_front(std::move(frames[(size_t)i])); /* did not fit the columns: next pass */
@@ -351,31 +573,25 @@ size_t PaxosManager::process() {
     nRuns = 0;
   };
 
-  /* ---- REQUEST -> handleProposal (PISM:818-888): ACCEPT multicast or forward to the coordinator */
-  std::vector<Frame> localAccepts; /* my own ACCEPTs: short-circuited, never byteified twice */
-  std::vector<int32_t> la[6];      /* gidx bnum bcoord slot median flags of those */
-  std::vector<int64_t> laId;
+  /* ---- REQUEST -> handleProposal (PISM:818-888): ACCEPT multicast, forward to the coordinator, or -
+   * while my election is running - a pre-active proposal */
   if (nQ > 0) {
     std::vector<int32_t> slot((size_t)nQ), bn((size_t)nQ), bc((size_t)nQ), med((size_t)nQ);
     std::vector<uint8_t> st((size_t)nQ);
-    if (!check(gpx_propose_batch(engine_, nQ, q.gidx.data(), q.f.data(), slot.data(), bn.data(), bc.data(),
-                                 med.data(), st.data()),
-               "gpx_propose_batch"))
+    if (!check(gpx_propose_batch_h(engine_, nQ, q.gidx.data(), q.f.data(), q.id.data(), slot.data(), bn.data(),
+                                   bc.data(), med.data(), st.data()),
+               "gpx_propose_batch_h"))
       return 0;
     stats_.engine_calls++;
     for (int32_t i = 0; i < nQ; i++) {
-      const Frame& rf = frames[(size_t)q.frame[(size_t)i]];
+      Frame& rf = frames[(size_t)q.frame[(size_t)i]];
       if (st[(size_t)i] == GPX_S_OK) {
-        const Instance& in = pinstances_.at(rowName_[(size_t)q.gidx[(size_t)i]]);
-        Frame acc = makeAcceptFrame(rf, slot[(size_t)i], bn[(size_t)i], bc[(size_t)i], med[(size_t)i], myID_);
-        for (int32_t m : in.members)
-          if (m != myID_) messenger_->send(m, Frame(acc));
-        la[0].push_back(q.gidx[(size_t)i]), la[1].push_back(bn[(size_t)i]), la[2].push_back(bc[(size_t)i]);
-        la[3].push_back(slot[(size_t)i]), la[4].push_back(med[(size_t)i]);
-        la[5].push_back(q.f[(size_t)i] ? GPX_A_STOP : 0);
-        laId.push_back(q.id[(size_t)i]);
-        localAccepts.push_back(std::move(acc));
+        issueAccept(outAccepts, q.gidx[(size_t)i], rf, q.id[(size_t)i], q.f[(size_t)i] != 0, slot[(size_t)i],
+                    bn[(size_t)i], bc[(size_t)i], med[(size_t)i]);
         stats_.proposed++;
+      } else if (st[(size_t)i] == GPX_S_PREACTIVE) {
+        preactive_[{q.gidx[(size_t)i], q.id[(size_t)i]}] = std::move(rf); /* comes back by handle */
+        stats_.preactive++;
       } else if (st[(size_t)i] == GPX_S_FORWARD && bc[(size_t)i] != myID_) {
         messenger_->send(bc[(size_t)i], Frame(rf)); /* unicast to paxosState.getBallotCoord() */
         stats_.forwarded++;
@@ -386,7 +602,7 @@ size_t PaxosManager::process() {
   }
 
   /* ---- ACCEPT -> handleAccept (PISM:1080-1166): store, reply (coalesced per ballot), maybe execute */
-  const int32_t nLA = (int32_t)localAccepts.size();
+  const int32_t nLA = (int32_t)outAccepts.size();
   const int32_t nAll = nLA + nA;
   if (nAll > 0) {
     std::vector<int32_t> g((size_t)nAll), bn((size_t)nAll), bc((size_t)nAll), sl((size_t)nAll), md((size_t)nAll),
@@ -395,9 +611,10 @@ size_t PaxosManager::process() {
     std::vector<int64_t> id((size_t)nAll);
     std::vector<const Frame*> src((size_t)nAll);
     for (int32_t i = 0; i < nLA; i++) { /* loopback first */
-      g[(size_t)i] = la[0][(size_t)i], bn[(size_t)i] = la[1][(size_t)i], bc[(size_t)i] = la[2][(size_t)i];
-      sl[(size_t)i] = la[3][(size_t)i], md[(size_t)i] = la[4][(size_t)i], fl[(size_t)i] = (uint8_t)la[5][(size_t)i];
-      snd[(size_t)i] = myID_, id[(size_t)i] = laId[(size_t)i], src[(size_t)i] = &localAccepts[(size_t)i];
+      const OutAccept& oa = outAccepts[(size_t)i];
+      g[(size_t)i] = oa.gidx, bn[(size_t)i] = oa.bnum, bc[(size_t)i] = oa.bcoord, sl[(size_t)i] = oa.slot;
+      md[(size_t)i] = oa.median, fl[(size_t)i] = oa.flags, snd[(size_t)i] = myID_, id[(size_t)i] = oa.requestID;
+      src[(size_t)i] = &oa.frame;
     }
     for (int32_t i = 0; i < nA; i++) {
       const size_t o = (size_t)(nLA + i), s = (size_t)i;
@@ -517,7 +734,7 @@ size_t PaxosManager::process() {
     stats_.commits += (uint64_t)nC;
     executeRuns(nRuns, xg.data(), xf.data(), xc.data());
   }
-  return (size_t)nF;
+  return consumed;
 }
 
 }  // namespace gpx

@@ -35,7 +35,9 @@ struct Request {
   int64_t requestID = 0;
   std::string requestValue;
   bool stop = false;
+  int32_t entryReplica = -1;
   int32_t slot = 0; /* the slot it was decided in */
+  bool isNoop() const { return requestValue == "NO_OP"; } /* interfaces/Request.NO_OP */
 };
 
 /* interfaces/Replicable.java: the replicated application */
@@ -66,6 +68,8 @@ struct Options {
 struct Stats {
   uint64_t proposed = 0, forwarded = 0, accepts = 0, votes = 0, decisions = 0, commits = 0, executed = 0;
   uint64_t dropped_frames = 0, refused = 0, engine_calls = 0;
+  uint64_t elections_started = 0, elections_won = 0, elections_lost = 0, prepares = 0, carried_over = 0,
+           noops = 0, preactive = 0;
 };
 
 class PaxosManager {
@@ -90,6 +94,10 @@ class PaxosManager {
   void handleIncomingPacket(Frame&& frame);
   /* PaxosManager.kill(paxosID) (PM:2162-2192) */
   bool kill(const std::string& paxosID);
+  /* the failure detector's verdict (FailureDetection -> PaxosManager.isNodeUp == false): runs
+   * checkRunForCoordinator over every instance (PISM:2090-2176) and multicasts the PREPAREs of the
+   * groups this node must run for; returns their number */
+  size_t nodeDown(int32_t nodeID);
 
   /* one pass of the node's pipeline over everything queued so far (the reference spreads this over
    * its demultiplexer pool, RequestBatcher, PaxosPacketBatcher and the per-instance monitors):
@@ -113,9 +121,21 @@ class PaxosManager {
   };
   static uint64_t key(int32_t gidx, int32_t slot) { return ((uint64_t)(uint32_t)gidx << 32) | (uint32_t)slot; }
 
+  /* an ACCEPT this node issues (after propose or after winning an election): multicast at once, my
+   * own copy short-circuited into the accept phase of the same pass */
+  struct OutAccept {
+    int32_t gidx, bnum, bcoord, slot, median;
+    uint8_t flags;
+    int64_t requestID;
+    Frame frame;
+  };
   bool check(int rc, const char* what);
   void executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* xf, const int32_t* xc);
   void sendToMembers(const Instance& in, const Frame& frame, bool includeSelf);
+  void issueAccept(std::vector<OutAccept>& out, int32_t gidx, const Frame& requestFrame, int64_t requestID,
+                   bool stop, int32_t slot, int32_t bnum, int32_t bcoord, int32_t median);
+  bool handlePrepares(std::vector<Frame>& prepares);
+  bool handlePrepareReplies(std::vector<Frame>& replies, std::vector<OutAccept>& out);
 
   int32_t myID_;
   Replicable* app_;
@@ -127,6 +147,10 @@ class PaxosManager {
   std::unordered_map<uint64_t, StoredAccept> accepted_;   /* (gidx, slot) -> the stored ACCEPT */
   std::deque<Frame> inbox_;                               /* frames from the network and from myself */
   std::deque<Frame> requests_;                            /* REQUEST frames of local clients */
+  /* view change: request bytes by (gidx, requestID) - proposals made while not active, and the
+   * pvalues the PREPARE replies carried */
+  std::map<std::pair<int32_t, int64_t>, Frame> preactive_, carried_;
+  std::vector<int32_t> downNodes_;
   int64_t nextRequestID_;
   Stats stats_;
   std::string err_;
@@ -140,6 +164,10 @@ Frame makeRequestFrame(const std::string& paxosID, int32_t version, int64_t requ
 /* AcceptPacket.toBytes (AcceptPacket.java:95-135): the request bytes re-typed ACCEPT + the 22-byte tail */
 Frame makeAcceptFrame(const Frame& requestFrame, int32_t slot, int32_t bnum, int32_t bcoord,
                       int32_t medianCheckpointedSlot, int32_t sender);
+/* PREPARE / PREPARE_REPLY: the reference ships these two as JSON only (no toBytes); the byte layout
+ * here is this host layer's own - PaxosPacket header, then {bnum, bcoord, firstUndecidedSlot} and
+ * {acceptor, bnum, bcoord, firstSlot, n, n x {slot, bnum, bcoord, len, the ACCEPT frame}} */
+constexpr int32_t kTypePrepare = 2, kTypePrepareReply = 7; /* PaxosPacketType ints (PaxosPacket.java:202-230) */
 /* the request inside a REQUEST / ACCEPT frame; false if the bytes do not parse */
 bool parseRequest(const Frame& frame, Request* out);
 /* java.lang.String.hashCode of an ISO-8859-1 string; PISM.roundRobinCoordinator (PISM:2251-2256) */

@@ -6,7 +6,11 @@
 // replica ends with the same (count, hash chain) per group.
 //
 //   gpx_loopback_cluster [--nodes 3] [--groups 1000] [--rounds 20] [--seed 1] [--value-bytes 64]
-//                        [--stop-last] [--entry any|coordinator]
+//                        [--stop-last] [--entry any|coordinator] [--kill-round r [--kill-node i]]
+// --kill-round r: in round r node i (default 0) dies after ONE pipeline pass - ACCEPTs are in flight,
+// no reply has been processed; the survivors' failure detectors fire (PaxosManager::nodeDown), the
+// next member in line runs for coordinator in every group the dead node coordinated, takes a few
+// client requests while not yet elected, carries the accepted values over and the cluster goes on.
 // Prints one JSON line; exit code 1 if the replicas disagree or a request was lost.
 #include <cinttypes>
 #include <cstdio>
@@ -76,6 +80,7 @@ int main(int argc, char** argv) {
   int nNodes = 3, G = 1000, R = 20, valueBytes = 64;
   uint64_t seed = 1;
   bool stopLast = false, entryAny = true;
+  int killRound = -1, killNode = 0;
   for (int i = 1; i < argc; i++) {
     auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
     if (is("--nodes") && i + 1 < argc) nNodes = std::atoi(argv[++i]);
@@ -84,6 +89,8 @@ int main(int argc, char** argv) {
     else if (is("--seed") && i + 1 < argc) seed = std::strtoull(argv[++i], nullptr, 10);
     else if (is("--value-bytes") && i + 1 < argc) valueBytes = std::atoi(argv[++i]);
     else if (is("--stop-last")) stopLast = true;
+    else if (is("--kill-round") && i + 1 < argc) killRound = std::atoi(argv[++i]);
+    else if (is("--kill-node") && i + 1 < argc) killNode = std::atoi(argv[++i]);
     else if (is("--entry") && i + 1 < argc) entryAny = std::strcmp(argv[++i], "any") == 0;
     else {
       std::fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -111,13 +118,16 @@ int main(int argc, char** argv) {
       std::fprintf(stderr, "createPaxosInstances failed on node %d: %s\n", pm->myID(), pm->lastError());
       return 2;
     }
+  std::vector<bool> alive((size_t)nNodes, true);
   auto drain = [&]() { /* until no node has anything left to do */
     for (;;) {
       size_t work = 0;
-      for (auto& pm : pms) work += pm->process();
+      for (int i = 0; i < nNodes; i++)
+        if (alive[(size_t)i]) work += pms[(size_t)i]->process();
       if (work == 0) break;
     }
   };
+  uint64_t sentKillRound = 0;
   uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 1;
   uint64_t sent = 0;
   std::string value((size_t)valueBytes, 'x');
@@ -126,42 +136,68 @@ int main(int argc, char** argv) {
       const uint64_t x = xorshift(rng);
       for (size_t b = 0; b < value.size() && b < 8; b++) value[b] = (char)('a' + ((x >> (8 * b)) & 15));
       size_t entry = entryAny ? (size_t)(x % (uint64_t)nNodes) : 0;
+      while (!alive[entry]) entry = (entry + 1) % (size_t)nNodes;
       if (!entryAny) { /* the coordinator itself */
         const int32_t c = gpx::roundRobinCoordinator(names[(size_t)g], ids, 0);
         for (size_t i = 0; i < ids.size(); i++)
-          if (ids[i] == c) entry = i;
+          if (ids[i] == c && alive[i]) entry = i;
       }
       const bool stop = stopLast && r == R - 1;
-      if (pms[entry]->propose(names[(size_t)g], value, stop)) sent++;
+      if (pms[entry]->propose(names[(size_t)g], value, stop)) {
+        sent++;
+        if (r == killRound) sentKillRound++;
+      }
+    }
+    if (r == killRound && killNode >= 0 && killNode < nNodes && alive[(size_t)killNode]) {
+      for (int i = 0; i < nNodes; i++) pms[(size_t)i]->process(); /* ONE pass each: ACCEPTs in flight */
+      alive[(size_t)killNode] = false;
+      net.nodes.erase(ids[(size_t)killNode]); /* frames to it are lost from now on */
+      for (int i = 0; i < nNodes; i++)
+        if (alive[(size_t)i]) pms[(size_t)i]->nodeDown(ids[(size_t)killNode]);
+      /* clients keep sending while the elections run: every third group, at the node next in line */
+      const size_t cand = (size_t)((killNode + 1) % nNodes);
+      for (int g = 0; g < G; g += 3) { /* as REQUEST packets off the network: queued behind the PREPAREs */
+        pms[cand]->handleIncomingPacket(gpx::makeRequestFrame(names[(size_t)g], 0, ((int64_t)1 << 50) + g, value,
+                                                              false, ids[cand]));
+        sent++, sentKillRound++;
+      }
     }
     drain();
   }
-  /* verdict */
+  /* verdict: the survivors must agree; without a failure every request is executed everywhere, with
+   * one only the requests of the failure round may be lost (they died with the node or were sent
+   * to it) */
   bool ok = true;
-  uint64_t digest[8] = {0};
-  uint64_t executed0 = 0;
+  uint64_t digest0 = 0, executed0 = 0;
+  bool first = true;
   for (int i = 0; i < nNodes; i++) {
+    if (!alive[(size_t)i]) continue;
     uint64_t d = 0, ex = 0;
     for (auto& kv : apps[(size_t)i]->state) {
       d = (d ^ kv.second.hash) * 1099511628211ull + (uint64_t)kv.second.seqnum;
       ex += (uint64_t)kv.second.seqnum;
-      if (kv.second.seqnum != R) ok = false;
+      if (killRound < 0 && kv.second.seqnum != R) ok = false;
       if (stopLast && !kv.second.stopped) ok = false;
     }
-    if (i < 8) digest[i] = d;
-    if (i == 0) executed0 = ex;
-    if ((int)apps[(size_t)i]->state.size() != G || apps[(size_t)i]->outOfOrder || d != digest[0] || ex != sent) ok = false;
+    if (first) digest0 = d, executed0 = ex, first = false;
+    if ((int)apps[(size_t)i]->state.size() != G || apps[(size_t)i]->outOfOrder || d != digest0) ok = false;
+    if (killRound < 0 ? ex != sent : ex + sentKillRound < sent) ok = false;
   }
+  uint64_t digest[1] = {digest0};
   std::printf("{\"nodes\": %d, \"groups\": %d, \"rounds\": %d, \"requests\": %" PRIu64 ", \"executed_per_node\": %" PRIu64
               ", \"state_digest\": \"%016" PRIx64 "\", \"frames\": %" PRIu64 ", \"bytes\": %" PRIu64 ", \"ok\": %s, \"per_node\": [",
               nNodes, G, R, sent, executed0, digest[0], net.frames, net.bytes, ok ? "true" : "false");
   for (int i = 0; i < nNodes; i++) {
     const gpx::Stats& s = pms[(size_t)i]->stats();
-    std::printf("%s{\"id\": %d, \"proposed\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
+    std::printf("%s{\"id\": %d, \"alive\": %s, \"proposed\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
                 ", \"votes\": %" PRIu64 ", \"decisions\": %" PRIu64 ", \"commits\": %" PRIu64 ", \"executed\": %" PRIu64
-                ", \"refused\": %" PRIu64 ", \"dropped_frames\": %" PRIu64 ", \"engine_calls\": %" PRIu64 "}",
-                i ? ", " : "", pms[(size_t)i]->myID(), s.proposed, s.forwarded, s.accepts, s.votes, s.decisions,
-                s.commits, s.executed, s.refused, s.dropped_frames, s.engine_calls);
+                ", \"refused\": %" PRIu64 ", \"dropped_frames\": %" PRIu64 ", \"engine_calls\": %" PRIu64
+                ", \"elections_started\": %" PRIu64 ", \"elections_won\": %" PRIu64 ", \"elections_lost\": %" PRIu64
+                ", \"prepares\": %" PRIu64 ", \"carried_over\": %" PRIu64 ", \"noops\": %" PRIu64 ", \"preactive\": %" PRIu64 "}",
+                i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.proposed, s.forwarded,
+                s.accepts, s.votes, s.decisions, s.commits, s.executed, s.refused, s.dropped_frames, s.engine_calls,
+                s.elections_started, s.elections_won, s.elections_lost, s.prepares, s.carried_over, s.noops,
+                s.preactive);
   }
   std::printf("]}\n");
   return ok ? 0 : 1;

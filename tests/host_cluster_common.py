@@ -18,6 +18,10 @@ CASES = [
     ["--groups", "500", "--rounds", "12", "--nodes", "5", "--seed", "3"],
     ["--groups", "300", "--rounds", "6", "--stop-last", "--entry", "coordinator"],
     ["--groups", "64", "--rounds", "9", "--value-bytes", "1500", "--seed", "11"],
+    # coordinator failover: a node dies with ACCEPTs in flight, the next in line is elected everywhere
+    ["--groups", "300", "--rounds", "8", "--kill-round", "3"],
+    ["--groups", "2000", "--rounds", "6", "--kill-round", "2", "--kill-node", "1", "--seed", "5"],
+    ["--groups", "400", "--rounds", "7", "--nodes", "5", "--kill-round", "4", "--kill-node", "4", "--seed", "9"],
 ]
 
 

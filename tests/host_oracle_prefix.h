@@ -17,3 +17,8 @@
 #define gpx_commit_batch orc_commit_batch
 #define gpx_wire_pack_accept_replies orc_wire_pack_accept_replies
 #define gpx_wire_pack_commits orc_wire_pack_commits
+#define gpx_propose_batch_h orc_propose_batch_h
+#define gpx_election_scan orc_election_scan
+#define gpx_election_begin orc_election_begin
+#define gpx_prepare_batch orc_prepare_batch
+#define gpx_prepare_reply_batch orc_prepare_reply_batch
