@@ -118,25 +118,109 @@ Frame makeAcceptFrame(const Frame& req, int32_t slot, int32_t bnum, int32_t bcoo
   return f;
 }
 
-bool parseRequest(const Frame& f, Request* out) {
-  if (f.size() < 13) return false;
-  const size_t idLen = f[12];
-  size_t p = 13 + idLen;
-  if (f.size() < p + kReqFixed + 8) return false;
-  out->paxosID.assign((const char*)&f[13], idLen);
+/* one RequestPacket at f[at ..); *end = the offset of its batched-count field */
+static bool parseRequestAt(const uint8_t* f, size_t size, size_t at, Request* out, size_t* end) {
+  if (size < at + 13) return false;
+  const size_t idLen = f[at + 12];
+  size_t p = at + 13 + idLen;
+  if (size < p + kReqFixed + 8) return false;
+  out->paxosID.assign((const char*)&f[at + 13], idLen);
   out->requestID = get64(&f[p]);
   out->stop = f[p + 8] != 0;
   out->entryReplica = get32(&f[p + 8 + 1 + 12]);
   p += kReqFixed;
   const int32_t dl = get32(&f[p]);
   p += 4;
-  if (dl < 0 || f.size() < p + (size_t)dl + 4) return false;
+  if (dl < 0 || size < p + (size_t)dl + 4) return false;
   p += (size_t)dl;
   const int32_t vl = get32(&f[p]);
   p += 4;
-  if (vl < 0 || f.size() < p + (size_t)vl) return false;
+  if (vl < 0 || size < p + (size_t)vl + 4) return false;
   out->requestValue.assign((const char*)&f[p], (size_t)vl);
+  p += (size_t)vl;
+  const int32_t rl = get32(&f[p]); /* response */
+  p += 4;
+  if (rl < 0 || size < p + (size_t)rl + 4) return false;
+  *end = p + (size_t)rl;
   return true;
+}
+
+/* RequestPacket.isStopRequest(): its own flag or any batched request's (RequestPacket.java:371-378) */
+static bool frameIsStop(const Frame& f, bool* noop = nullptr) {
+  std::vector<Request> rs;
+  if (!parseRequests(f, &rs)) return false;
+  bool stop = false;
+  for (auto& r : rs) stop = stop || r.stop;
+  if (noop) *noop = rs.size() == 1 && rs[0].isNoop();
+  return stop;
+}
+
+bool parseRequest(const Frame& f, Request* out) {
+  size_t end = 0;
+  return parseRequestAt(f.data(), f.size(), 0, out, &end);
+}
+
+bool parseRequests(const Frame& f, std::vector<Request>* out) {
+  Request head;
+  size_t p = 0;
+  if (!parseRequestAt(f.data(), f.size(), 0, &head, &p)) return false;
+  out->push_back(head);
+  const int32_t nb = get32(&f[p]);
+  p += 4;
+  for (int32_t j = 0; j < nb; j++) {
+    if (f.size() < p + 4) return false;
+    const int32_t len = get32(&f[p]);
+    p += 4;
+    Request r;
+    size_t e = 0;
+    if (len < 0 || f.size() < p + (size_t)len || !parseRequestAt(f.data(), p + (size_t)len, p, &r, &e)) return false;
+    out->push_back(r);
+    p += (size_t)len;
+  }
+  return true;
+}
+
+/* the unbatched requests a frame holds, each as a stand-alone byte array (RequestPacket.toArray,
+ * :1117-1127): its head with an empty batched array, then its batched elements as they are */
+static bool flattenRequests(const Frame& f, std::vector<Frame>* out) {
+  Request head;
+  size_t p = 0;
+  if (!parseRequestAt(f.data(), f.size(), 0, &head, &p) || f.size() < p + 4) return false;
+  Frame h(f.begin(), f.begin() + (long)p);
+  put32(h, 0);
+  out->push_back(std::move(h));
+  const int32_t nb = get32(&f[p]);
+  p += 4;
+  for (int32_t j = 0; j < nb; j++) {
+    if (f.size() < p + 4) return false;
+    const int32_t len = get32(&f[p]);
+    p += 4;
+    if (len < 0 || f.size() < p + (size_t)len) return false;
+    out->emplace_back(f.begin() + (long)p, f.begin() + (long)(p + (size_t)len));
+    p += (size_t)len;
+  }
+  return true;
+}
+
+int32_t batchSizeOf(const Frame& f) {
+  Request head;
+  size_t p = 0;
+  if (!parseRequestAt(f.data(), f.size(), 0, &head, &p) || f.size() < p + 4) return 0;
+  return get32(&f[p]);
+}
+
+Frame latchToBatch(const Frame& first, const std::vector<const Frame*>& rest) {
+  /* first flatten out the argument; batched = concatenate(this.batched, allThreaded) */
+  std::vector<Frame> all;
+  if (!flattenRequests(first, &all)) return first;
+  for (const Frame* r : rest) flattenRequests(*r, &all);
+  Frame f(all[0].begin(), all[0].end() - 4); /* the head up to its batched-count field */
+  put32(f, (int32_t)all.size() - 1);
+  for (size_t i = 1; i < all.size(); i++) {
+    put32(f, (int32_t)all[i].size());
+    f.insert(f.end(), all[i].begin(), all[i].end());
+  }
+  return f;
 }
 
 /* ------------------------------------------------------------------------------------------ */
@@ -272,15 +356,16 @@ void PaxosManager::executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* 
         std::fprintf(stderr, "gpx::PaxosManager(%d): %s (gidx %d slot %d)\n", myID_, err_.c_str(), xg[r], slot);
         continue;
       }
-      Request req;
-      if (parseRequest(a->second.frame, &req)) {
-        req.slot = slot;
-        /* doNotReplyToClient unless this node is the entry replica (PISM:1800-1806); no-ops are fed
-         * to the application as they are to TESTPaxosApp */
-        for (int tries = 0; tries < 3 && !app_->execute(req, req.entryReplica != myID_); tries++) {
+      std::vector<Request> reqs; /* the request and the requests batched into it, in that order */
+      if (parseRequests(a->second.frame, &reqs))
+        for (Request& req : reqs) {
+          req.slot = slot;
+          /* doNotReplyToClient unless this node is the entry replica (PISM:1800-1806); no-ops are fed
+           * to the application as they are to TESTPaxosApp */
+          for (int tries = 0; tries < 3 && !app_->execute(req, req.entryReplica != myID_); tries++) {
+          }
+          stats_.executed++;
         }
-        stats_.executed++;
-      }
       accepted_.erase(a); /* acceptedProposals.remove(slot) on execution (PaxosAcceptor.java:357-359) */
     }
   }
@@ -416,7 +501,9 @@ bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector
       if (parseRequest(pv, &rq)) {
         ps.push_back(get32(&f[p])), pb.push_back(get32(&f[p + 4])), pc.push_back(get32(&f[p + 8]));
         ph.push_back(rq.requestID);
-        pfl.push_back((uint8_t)((rq.stop ? GPX_PV_STOP : 0) | (rq.isNoop() ? GPX_PV_NOOP : 0)));
+        bool noop = false;
+        const bool stop = frameIsStop(pv, &noop);
+        pfl.push_back((uint8_t)((stop ? GPX_PV_STOP : 0) | (noop ? GPX_PV_NOOP : 0)));
         carried_[{gi, rq.requestID}] = std::move(pv);
       }
       p += 16 + (size_t)len;
@@ -576,21 +663,68 @@ size_t PaxosManager::process() {
   /* ---- REQUEST -> handleProposal (PISM:818-888): ACCEPT multicast, forward to the coordinator, or -
    * while my election is running - a pre-active proposal */
   if (nQ > 0) {
-    std::vector<int32_t> slot((size_t)nQ), bn((size_t)nQ), bc((size_t)nQ), med((size_t)nQ);
-    std::vector<uint8_t> st((size_t)nQ);
-    if (!check(gpx_propose_batch_h(engine_, nQ, q.gidx.data(), q.f.data(), q.id.data(), slot.data(), bn.data(),
-                                   bc.data(), med.data(), st.data()),
-               "gpx_propose_batch_h"))
+    /* RequestBatcher: the requests of one group queued together ride in ONE proposal */
+    std::vector<int32_t> pg(q.gidx.begin(), q.gidx.begin() + nQ);
+    std::vector<uint8_t> pstop(q.f.begin(), q.f.begin() + nQ);
+    std::vector<int64_t> pid(q.id.begin(), q.id.begin() + nQ);
+    std::vector<Frame> latched; /* owns the batched frames */
+    std::vector<Frame*> pframe((size_t)nQ);
+    for (int32_t i = 0; i < nQ; i++) pframe[(size_t)i] = &frames[(size_t)q.frame[(size_t)i]];
+    int32_t nP = nQ;
+    if (opt_.batchRequests && nQ > 1) {
+      std::vector<int32_t> est((size_t)nQ), leader((size_t)nQ), bg((size_t)nQ), bl((size_t)nQ), bcnt((size_t)nQ),
+          bbytes((size_t)nQ), bsize((size_t)nQ);
+      std::vector<uint8_t> st((size_t)nQ), bstop((size_t)nQ);
+      std::vector<int32_t> weight((size_t)nQ);
+      for (int32_t i = 0; i < nQ; i++) {
+        est[(size_t)i] = (int32_t)pframe[(size_t)i]->size();
+        weight[(size_t)i] = batchSizeOf(*pframe[(size_t)i]) + 1; /* a forwarded request may be a batch already */
+      }
+      int32_t nB = 0;
+      if (!check(gpx_request_batch(engine_, nQ, q.gidx.data(), est.data(), weight.data(), q.f.data(), opt_.maxBatchBytes,
+                                   opt_.maxBatchSize, leader.data(), st.data(), bg.data(), bl.data(), bcnt.data(),
+                                   bbytes.data(), bsize.data(), bstop.data(), &nB),
+                 "gpx_request_batch"))
+        return 0;
+      stats_.engine_calls++;
+      std::vector<std::vector<const Frame*>> rest((size_t)nQ);
+      for (int32_t i = 0; i < nQ; i++)
+        if (leader[(size_t)i] >= 0 && leader[(size_t)i] != i) rest[(size_t)leader[(size_t)i]].push_back(pframe[(size_t)i]);
+      latched.reserve((size_t)nB);
+      std::vector<int32_t> ng;
+      std::vector<uint8_t> ns;
+      std::vector<int64_t> ni;
+      std::vector<Frame*> nf;
+      for (int32_t b = 0; b < nB; b++) {
+        const int32_t l = bl[(size_t)b];
+        Frame* fr = pframe[(size_t)l];
+        if (bcnt[(size_t)b] > 1) {
+          latched.push_back(latchToBatch(*fr, rest[(size_t)l])); /* first.latchToBatch(...) */
+          fr = &latched.back();
+          stats_.batched_requests += (uint64_t)(bsize[(size_t)b] - weight[(size_t)l]);
+        }
+        ng.push_back(bg[(size_t)b]), ns.push_back(bstop[(size_t)b]), ni.push_back(q.id[(size_t)l]), nf.push_back(fr);
+      }
+      for (int32_t i = 0; i < nQ; i++) /* requests for groups this node does not have: dropped */
+        if (leader[(size_t)i] < 0) stats_.refused++;
+      pg.swap(ng), pstop.swap(ns), pid.swap(ni), pframe.swap(nf);
+      nP = nB;
+    }
+    std::vector<int32_t> slot((size_t)nP), bn((size_t)nP), bc((size_t)nP), med((size_t)nP);
+    std::vector<uint8_t> st((size_t)nP);
+    if (nP > 0 && !check(gpx_propose_batch_h(engine_, nP, pg.data(), pstop.data(), pid.data(), slot.data(),
+                                             bn.data(), bc.data(), med.data(), st.data()),
+                         "gpx_propose_batch_h"))
       return 0;
     stats_.engine_calls++;
-    for (int32_t i = 0; i < nQ; i++) {
-      Frame& rf = frames[(size_t)q.frame[(size_t)i]];
+    for (int32_t i = 0; i < nP; i++) {
+      Frame& rf = *pframe[(size_t)i];
       if (st[(size_t)i] == GPX_S_OK) {
-        issueAccept(outAccepts, q.gidx[(size_t)i], rf, q.id[(size_t)i], q.f[(size_t)i] != 0, slot[(size_t)i],
+        issueAccept(outAccepts, pg[(size_t)i], rf, pid[(size_t)i], pstop[(size_t)i] != 0, slot[(size_t)i],
                     bn[(size_t)i], bc[(size_t)i], med[(size_t)i]);
         stats_.proposed++;
       } else if (st[(size_t)i] == GPX_S_PREACTIVE) {
-        preactive_[{q.gidx[(size_t)i], q.id[(size_t)i]}] = std::move(rf); /* comes back by handle */
+        preactive_[{pg[(size_t)i], pid[(size_t)i]}] = std::move(rf); /* comes back by handle */
         stats_.preactive++;
       } else if (st[(size_t)i] == GPX_S_FORWARD && bc[(size_t)i] != myID_) {
         messenger_->send(bc[(size_t)i], Frame(rf)); /* unicast to paxosState.getBallotCoord() */
@@ -702,8 +836,7 @@ size_t PaxosManager::process() {
         if (dk[(size_t)i] != GPX_D_DECISION) continue; /* PREEMPTED: dropped (FORWARD_PREEMPTED_REQUESTS off) */
         uint8_t kind = GPX_C_HASVALUE;
         auto sa = accepted_.find(key(dg[(size_t)i], ds[(size_t)i]));
-        Request rq;
-        if (sa != accepted_.end() && parseRequest(sa->second.frame, &rq) && rq.stop) kind |= GPX_C_STOP;
+        if (sa != accepted_.end() && frameIsStop(sa->second.frame)) kind |= GPX_C_STOP;
         lg.push_back(dg[(size_t)i]), lb.push_back(db[(size_t)i]), lc.push_back(dc[(size_t)i]);
         ls.push_back(ds[(size_t)i]), lm.push_back(dm[(size_t)i]), lk.push_back(kind);
         stats_.decisions++;

@@ -63,11 +63,17 @@ struct Options {
   int32_t window = 8;
   int32_t maxBatch = 1 << 18;
   int32_t device = -1;
+  /* RequestBatcher (RequestBatcher.java:40-239): requests of one group that are queued together
+   * become ONE proposal, up to these limits (PC.MAX_BATCH_SIZE; min(NIO payload, log message size)) */
+  bool batchRequests = true;
+  int32_t maxBatchSize = 2000;
+  int32_t maxBatchBytes = 1 << 20;
 };
 
 struct Stats {
   uint64_t proposed = 0, forwarded = 0, accepts = 0, votes = 0, decisions = 0, commits = 0, executed = 0;
   uint64_t dropped_frames = 0, refused = 0, engine_calls = 0;
+  uint64_t batched_requests = 0; /* requests that rode in another request's proposal */
   uint64_t elections_started = 0, elections_won = 0, elections_lost = 0, prepares = 0, carried_over = 0,
            noops = 0, preactive = 0;
 };
@@ -170,6 +176,12 @@ Frame makeAcceptFrame(const Frame& requestFrame, int32_t slot, int32_t bnum, int
 constexpr int32_t kTypePrepare = 2, kTypePrepareReply = 7; /* PaxosPacketType ints (PaxosPacket.java:202-230) */
 /* the request inside a REQUEST / ACCEPT frame; false if the bytes do not parse */
 bool parseRequest(const Frame& frame, Request* out);
+/* ... and with the requests batched into it (RequestPacket.getRequestPackets, :1239-1245): itself
+ * first, then batched[] in order */
+bool parseRequests(const Frame& frame, std::vector<Request>* out);
+/* first.latchToBatch(rest) on the bytes (RequestPacket.java:1090-1100, toBytes :930-948) */
+Frame latchToBatch(const Frame& first, const std::vector<const Frame*>& rest);
+int32_t batchSizeOf(const Frame& requestFrame); /* RequestPacket.batchSize() */
 /* java.lang.String.hashCode of an ISO-8859-1 string; PISM.roundRobinCoordinator (PISM:2251-2256) */
 int32_t javaStringHash(const std::string& s);
 int32_t roundRobinCoordinator(const std::string& paxosID, const std::vector<int32_t>& members, int32_t ballotnum);

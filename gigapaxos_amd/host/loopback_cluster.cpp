@@ -7,6 +7,9 @@
 //
 //   gpx_loopback_cluster [--nodes 3] [--groups 1000] [--rounds 20] [--seed 1] [--value-bytes 64]
 //                        [--stop-last] [--entry any|coordinator] [--kill-round r [--kill-node i]]
+//                        [--burst b] [--no-batching]
+// --burst b: b requests per group per round, queued together: RequestBatcher latches the requests
+// of one group that meet at a replica into one proposal (turned off by --no-batching).
 // --kill-round r: in round r node i (default 0) dies after ONE pipeline pass - ACCEPTs are in flight,
 // no reply has been processed; the survivors' failure detectors fire (PaxosManager::nodeDown), the
 // next member in line runs for coordinator in every group the dead node coordinated, takes a few
@@ -26,7 +29,8 @@
 namespace {
 
 struct GroupState {
-  int64_t seqnum = 0;
+  int64_t seqnum = 0;  /* requests executed */
+  int32_t lastSlot = 0; /* slots start at 1 (initial-state checkpoint) */
   uint64_t hash = 1469598103934665603ull;
   bool stopped = false;
 };
@@ -38,7 +42,10 @@ class HashChainApp : public gpx::Replicable {
   bool execute(const gpx::Request& r, bool) override {
     GroupState& g = state[r.paxosID];
     g.seqnum++;
-    if (g.seqnum != r.slot) outOfOrder++; /* assert state.seqnum == requestPacket.slot */
+    /* TESTPaxosApp's `assert state.seqnum == requestPacket.slot`, for batches too: requests arrive in
+     * slot order, every slot is seen, the requests of one batch share theirs */
+    if (r.slot != g.lastSlot && r.slot != g.lastSlot + 1) outOfOrder++;
+    g.lastSlot = r.slot;
     uint64_t h = g.hash;
     auto mix = [&](const void* p, size_t n) {
       const unsigned char* c = (const unsigned char*)p;
@@ -80,7 +87,8 @@ int main(int argc, char** argv) {
   int nNodes = 3, G = 1000, R = 20, valueBytes = 64;
   uint64_t seed = 1;
   bool stopLast = false, entryAny = true;
-  int killRound = -1, killNode = 0;
+  int killRound = -1, killNode = 0, burst = 1;
+  bool batching = true;
   for (int i = 1; i < argc; i++) {
     auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
     if (is("--nodes") && i + 1 < argc) nNodes = std::atoi(argv[++i]);
@@ -91,6 +99,8 @@ int main(int argc, char** argv) {
     else if (is("--stop-last")) stopLast = true;
     else if (is("--kill-round") && i + 1 < argc) killRound = std::atoi(argv[++i]);
     else if (is("--kill-node") && i + 1 < argc) killNode = std::atoi(argv[++i]);
+    else if (is("--burst") && i + 1 < argc) burst = std::atoi(argv[++i]);
+    else if (is("--no-batching")) batching = false;
     else if (is("--entry") && i + 1 < argc) entryAny = std::strcmp(argv[++i], "any") == 0;
     else {
       std::fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -105,7 +115,8 @@ int main(int argc, char** argv) {
   gpx::Options opt;
   opt.maxGroups = G + 16;
   opt.kmax = nNodes < 3 ? 3 : nNodes;
-  opt.maxBatch = std::max(1 << 16, 8 * G);
+  opt.maxBatch = std::max(1 << 16, 8 * G * burst);
+  opt.batchRequests = batching;
   for (int i = 0; i < nNodes; i++) {
     apps.emplace_back(new HashChainApp());
     pms.emplace_back(new gpx::PaxosManager(ids[(size_t)i], apps.back().get(), &net, opt));
@@ -132,7 +143,8 @@ int main(int argc, char** argv) {
   uint64_t sent = 0;
   std::string value((size_t)valueBytes, 'x');
   for (int r = 0; r < R; r++) {
-    for (int g = 0; g < G; g++) {
+    for (int gb = 0; gb < G * burst; gb++) {
+      const int g = gb % G;
       const uint64_t x = xorshift(rng);
       for (size_t b = 0; b < value.size() && b < 8; b++) value[b] = (char)('a' + ((x >> (8 * b)) & 15));
       size_t entry = entryAny ? (size_t)(x % (uint64_t)nNodes) : 0;
@@ -176,7 +188,7 @@ int main(int argc, char** argv) {
     for (auto& kv : apps[(size_t)i]->state) {
       d = (d ^ kv.second.hash) * 1099511628211ull + (uint64_t)kv.second.seqnum;
       ex += (uint64_t)kv.second.seqnum;
-      if (killRound < 0 && kv.second.seqnum != R) ok = false;
+      if (killRound < 0 && kv.second.seqnum != (int64_t)R * burst) ok = false;
       if (stopLast && !kv.second.stopped) ok = false;
     }
     if (first) digest0 = d, executed0 = ex, first = false;
@@ -189,12 +201,12 @@ int main(int argc, char** argv) {
               nNodes, G, R, sent, executed0, digest[0], net.frames, net.bytes, ok ? "true" : "false");
   for (int i = 0; i < nNodes; i++) {
     const gpx::Stats& s = pms[(size_t)i]->stats();
-    std::printf("%s{\"id\": %d, \"alive\": %s, \"proposed\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
+    std::printf("%s{\"id\": %d, \"alive\": %s, \"proposed\": %" PRIu64 ", \"batched_requests\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
                 ", \"votes\": %" PRIu64 ", \"decisions\": %" PRIu64 ", \"commits\": %" PRIu64 ", \"executed\": %" PRIu64
                 ", \"refused\": %" PRIu64 ", \"dropped_frames\": %" PRIu64 ", \"engine_calls\": %" PRIu64
                 ", \"elections_started\": %" PRIu64 ", \"elections_won\": %" PRIu64 ", \"elections_lost\": %" PRIu64
                 ", \"prepares\": %" PRIu64 ", \"carried_over\": %" PRIu64 ", \"noops\": %" PRIu64 ", \"preactive\": %" PRIu64 "}",
-                i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.proposed, s.forwarded,
+                i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.proposed, s.batched_requests, s.forwarded,
                 s.accepts, s.votes, s.decisions, s.commits, s.executed, s.refused, s.dropped_frames, s.engine_calls,
                 s.elections_started, s.elections_won, s.elections_lost, s.prepares, s.carried_over, s.noops,
                 s.preactive);

@@ -22,6 +22,11 @@ CASES = [
     ["--groups", "300", "--rounds", "8", "--kill-round", "3"],
     ["--groups", "2000", "--rounds", "6", "--kill-round", "2", "--kill-node", "1", "--seed", "5"],
     ["--groups", "400", "--rounds", "7", "--nodes", "5", "--kill-round", "4", "--kill-node", "4", "--seed", "9"],
+    # RequestBatcher: bursts of requests per group, latched into one proposal where they meet
+    ["--groups", "100", "--rounds", "4", "--burst", "6"],
+    ["--groups", "50", "--rounds", "3", "--burst", "40", "--nodes", "5", "--seed", "4"],
+    ["--groups", "200", "--rounds", "6", "--burst", "3", "--kill-round", "2"],
+    ["--groups", "100", "--rounds", "3", "--burst", "4", "--no-batching"],
 ]
 
 

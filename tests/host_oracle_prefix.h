@@ -22,3 +22,4 @@
 #define gpx_election_begin orc_election_begin
 #define gpx_prepare_batch orc_prepare_batch
 #define gpx_prepare_reply_batch orc_prepare_reply_batch
+#define gpx_request_batch orc_request_batch

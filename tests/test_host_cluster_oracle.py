@@ -22,10 +22,17 @@ def test_cluster_invariants(case):
         assert sum(n["carried_over"] for n in alive) > 0 and sum(n["preactive"] for n in alive) > 0
         assert out["executed_per_node"] >= out["groups"] * (out["rounds"] - 1)
         return
-    assert out["executed_per_node"] == out["requests"] == out["groups"] * out["rounds"]
+    args = CASES[case]
+    burst = int(args[args.index("--burst") + 1]) if "--burst" in args else 1
+    assert out["executed_per_node"] == out["requests"] == out["groups"] * out["rounds"] * burst
     for n in out["per_node"]:
         assert n["executed"] == out["requests"] and n["dropped_frames"] == 0 and n["refused"] == 0
-    assert sum(n["proposed"] for n in out["per_node"]) == out["requests"]
-    assert sum(n["decisions"] for n in out["per_node"]) == out["requests"]
+    proposed = sum(n["proposed"] for n in out["per_node"])
+    assert sum(n["decisions"] for n in out["per_node"]) == proposed
+    if burst > 1 and "--no-batching" not in args:
+        # several requests per proposal: fewer proposals than requests, none lost
+        assert proposed < out["requests"] and sum(n["batched_requests"] for n in out["per_node"]) > 0
+    else:
+        assert proposed == out["requests"]
     if "--entry" not in CASES[case]:
         assert sum(n["forwarded"] for n in out["per_node"]) > 0 or out["groups"] == 1
