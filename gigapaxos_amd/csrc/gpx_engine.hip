@@ -79,6 +79,10 @@ struct gpx_engine {
   uint8_t* st_u8[4] = {};
   int32_t* st_count = nullptr;
   int64_t* st_handle = nullptr; /* gpx_propose_batch_h, allocated on first use */
+  /* arena of the host-pointer calls' temporary device buffers (TmpDev, gpx_wire_host.inc) */
+  char* arena = nullptr;
+  size_t arena_cap = 0, arena_used = 0, arena_demand = 0, arena_want = 0;
+  bool arena_busy = false;
   /* profiling */
   bool profiling = false;
   std::vector<PendingEvent> pending;
@@ -490,6 +494,7 @@ int gpx_engine_destroy(gpx_engine* h) {
     HIPQ(hipEventDestroy(pe.stop));
   }
   for (void* p : h->allocs) HIPQ(hipFree(p));
+  if (h->arena) HIPQ(hipFree(h->arena));
   if (h->own_stream) HIPQ(hipStreamDestroy(h->own_stream));
   if (h->front_stream) HIPQ(hipStreamDestroy(h->front_stream));
   if (h->back_stream) HIPQ(hipStreamDestroy(h->back_stream));
