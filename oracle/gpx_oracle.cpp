@@ -700,6 +700,7 @@ int orc_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uin
  * gidx, so nothing inside a group moves. */
 static void regroup_by_gidx(int32_t m, int32_t* gidx, std::initializer_list<int32_t*> cols,
                             uint8_t* kind) {
+  if (m <= 0) return; /* memcpy from an empty vector's null data() is undefined */
   std::vector<int32_t> order(m);
   for (int32_t i = 0; i < m; i++) order[i] = i;
   std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return gidx[a] < gidx[b]; });

@@ -36,3 +36,24 @@ def test_cluster_invariants(case):
         assert proposed == out["requests"]
     if "--entry" not in CASES[case]:
         assert sum(n["forwarded"] for n in out["per_node"]) > 0 or out["groups"] == 1
+
+
+def test_cluster_under_sanitizers(tmp_path):
+    """The host layer and the oracle compiled together with AddressSanitizer + UBSan: a failover run
+    and a batching run must finish clean (no report on stderr)."""
+    import os
+    import subprocess
+
+    from tests.host_cluster_common import HOST, ROOT
+
+    exe = str(tmp_path / "cluster_san")
+    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17",
+                           "-I", os.path.join(ROOT, "include"), "-include",
+                           os.path.join(ROOT, "tests", "host_oracle_prefix.h"), "-o", exe,
+                           os.path.join(HOST, "gpx_host.cpp"), os.path.join(HOST, "loopback_cluster.cpp"),
+                           os.path.join(ROOT, "oracle", "gpx_oracle.cpp")])
+    for args in (["--groups", "300", "--rounds", "8", "--kill-round", "3"],
+                 ["--groups", "50", "--rounds", "3", "--burst", "20", "--nodes", "5", "--stop-last"]):
+        p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
+        assert p.returncode == 0, p.stderr[-600:]
+        assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-600:]
