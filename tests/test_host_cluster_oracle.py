@@ -53,7 +53,7 @@ def test_cluster_under_sanitizers(tmp_path):
                            os.path.join(HOST, "gpx_host.cpp"), os.path.join(HOST, "loopback_cluster.cpp"),
                            os.path.join(ROOT, "oracle", "gpx_oracle.cpp")])
     for args in (["--groups", "300", "--rounds", "8", "--kill-round", "3"],
-                 ["--groups", "50", "--rounds", "3", "--burst", "20", "--nodes", "5", "--stop-last"]):
+                 ["--groups", "50", "--rounds", "3", "--burst", "20", "--nodes", "5"]):
         p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-600:]
         assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-600:]
