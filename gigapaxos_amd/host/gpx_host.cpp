@@ -238,6 +238,8 @@ PaxosManager::PaxosManager(int32_t myID, Replicable* app, Messenger* messenger, 
   cfg.flags = GPX_F_ACCEPTS_FROM_DISK;
   if (!check(gpx_engine_create(&cfg, &engine_), "gpx_engine_create")) engine_ = nullptr;
   rowName_.resize((size_t)opt.maxGroups);
+  lastActive_.assign((size_t)opt.maxGroups, 0);
+  liveAccepts_.assign((size_t)opt.maxGroups, 0);
 }
 
 PaxosManager::~PaxosManager() {
@@ -271,6 +273,8 @@ int PaxosManager::createPaxosInstances(const std::vector<std::string>& ids, cons
   const int32_t n = (int32_t)fresh.size();
   if (n == 0) return 0;
   std::vector<int32_t> gidx((size_t)n);
+  pass_++; /* groups made by earlier calls count as idle for this one */
+  if (!makeRoom(n)) return 0;
   if (!check(gpx_rows_alloc(engine_, n, gidx.data()), "gpx_rows_alloc")) return 0;
   std::vector<int32_t> mem((size_t)n * opt_.kmax, 0);
   std::vector<uint8_t> ks((size_t)n, (uint8_t)k), st((size_t)n, 0);
@@ -307,6 +311,9 @@ int PaxosManager::createPaxosInstances(const std::vector<std::string>& ids, cons
     if (st[(size_t)i] != GPX_S_OK || bst[(size_t)i] != GPX_S_OK) continue;
     pinstances_[fresh[(size_t)i]] = Instance{gidx[(size_t)i], 0, members};
     rowName_[(size_t)gidx[(size_t)i]] = fresh[(size_t)i];
+    lastActive_[(size_t)gidx[(size_t)i]] = pass_;
+    liveAccepts_[(size_t)gidx[(size_t)i]] = 0;
+    liveRows_++;
     made++;
   }
   return made;
@@ -323,15 +330,88 @@ bool PaxosManager::kill(const std::string& paxosID) {
   for (auto a = accepted_.begin(); a != accepted_.end();)
     a = (int32_t)(a->first >> 32) == g ? accepted_.erase(a) : std::next(a);
   rowName_[(size_t)g].clear();
+  liveAccepts_[(size_t)g] = 0;
+  liveRows_--;
   pinstances_.erase(it);
+  return true;
+}
+
+bool PaxosManager::pause(const std::string& paxosID) {
+  auto it = pinstances_.find(paxosID);
+  if (it == pinstances_.end() || !engine_) return false;
+  const int32_t g = it->second.gidx;
+  if (liveAccepts_[(size_t)g] != 0) return false; /* accepted values live only here: keep the group */
+  Paused p;
+  uint8_t st = 0;
+  if (!check(gpx_group_retire(engine_, 1, &g, GPX_RETIRE_PAUSE, &p.hri, &st), "gpx_group_retire")) return false;
+  stats_.engine_calls++;
+  if (st != GPX_S_OK) return false; /* GPX_S_BUSY: not caught up (tryPause refuses) */
+  check(gpx_names_unbind(engine_, 1, &g, &st), "gpx_names_unbind");
+  check(gpx_rows_free(engine_, 1, &g), "gpx_rows_free");
+  p.members = it->second.members;
+  p.version = it->second.version;
+  paused_[paxosID] = std::move(p);
+  rowName_[(size_t)g].clear();
+  liveRows_--;
+  pinstances_.erase(it);
+  stats_.pauses++;
+  return true;
+}
+
+/* frees `rows` rows of the device table by pausing the groups idle the longest */
+bool PaxosManager::makeRoom(int32_t rows) {
+  if (liveRows_ + rows <= opt_.maxGroups) return true;
+  std::vector<std::pair<uint64_t, int32_t>> idle;
+  for (auto& kv : pinstances_)
+    if (lastActive_[(size_t)kv.second.gidx] < pass_ && liveAccepts_[(size_t)kv.second.gidx] == 0)
+      idle.push_back({lastActive_[(size_t)kv.second.gidx], kv.second.gidx});
+  std::sort(idle.begin(), idle.end());
+  for (auto& c : idle) {
+    if (liveRows_ + rows <= opt_.maxGroups) break;
+    pause(std::string(rowName_[(size_t)c.second]));
+  }
+  return liveRows_ + rows <= opt_.maxGroups;
+}
+
+bool PaxosManager::unpause(const std::string& paxosID) {
+  auto it = paused_.find(paxosID);
+  if (it == paused_.end() || !engine_) return false;
+  if (!makeRoom(1)) return false;
+  int32_t g = -1;
+  if (!check(gpx_rows_alloc(engine_, 1, &g), "gpx_rows_alloc")) return false;
+  const Paused& p = it->second;
+  std::vector<int32_t> mem((size_t)opt_.kmax, 0);
+  for (size_t j = 0; j < p.members.size(); j++) mem[j] = p.members[j];
+  const uint8_t k = (uint8_t)p.members.size();
+  uint8_t st = 0;
+  /* hotRestore(hri) (PISM:677-690) */
+  if (!check(gpx_group_create(engine_, 1, &g, mem.data(), &k, &p.hri, &st), "gpx_group_create") || st != GPX_S_OK)
+    return false;
+  const int32_t off[2] = {0, (int32_t)paxosID.size()};
+  if (!check(gpx_names_bind(engine_, 1, (const uint8_t*)paxosID.data(), off, &g, &st), "gpx_names_bind")) return false;
+  stats_.engine_calls += 2;
+  pinstances_[paxosID] = Instance{g, p.version, p.members};
+  rowName_[(size_t)g] = paxosID;
+  lastActive_[(size_t)g] = pass_;
+  liveAccepts_[(size_t)g] = 0;
+  liveRows_++;
+  paused_.erase(it);
+  stats_.unpauses++;
   return true;
 }
 
 int64_t PaxosManager::propose(const std::string& paxosID, const std::string& value, bool stop) {
   auto it = pinstances_.find(paxosID);
-  if (it == pinstances_.end()) return 0;
+  int32_t version = 0;
+  if (it != pinstances_.end()) {
+    version = it->second.version;
+  } else {
+    auto pz = paused_.find(paxosID); /* comes back when the request is processed */
+    if (pz == paused_.end()) return 0;
+    version = pz->second.version;
+  }
   const int64_t id = nextRequestID_++;
-  requests_.push_back(makeRequestFrame(paxosID, it->second.version, id, value, stop, myID_));
+  requests_.push_back(makeRequestFrame(paxosID, version, id, value, stop, myID_));
   return id;
 }
 
@@ -367,6 +447,7 @@ void PaxosManager::executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* 
           stats_.executed++;
         }
       accepted_.erase(a); /* acceptedProposals.remove(slot) on execution (PaxosAcceptor.java:357-359) */
+      liveAccepts_[(size_t)xg[r]]--;
     }
   }
 }
@@ -427,7 +508,10 @@ bool PaxosManager::handlePrepares(std::vector<Frame>& prepares) {
     const size_t idLen = f.size() > 12 ? f[12] : 0, p = 13 + idLen;
     auto it = f.size() >= p + 12 ? pinstances_.find(std::string((const char*)&f[13], idLen)) : pinstances_.end();
     if (it == pinstances_.end()) {
-      stats_.dropped_frames++;
+      if (f.size() >= p + 12 && paused_.count(std::string((const char*)&f[13], idLen)))
+        retry_.push_back(std::move(f));
+      else
+        stats_.dropped_frames++;
       continue;
     }
     g.push_back(it->second.gidx), bn.push_back(get32(&f[p])), bc.push_back(get32(&f[p + 4]));
@@ -485,7 +569,10 @@ bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector
     size_t p = 13 + idLen;
     auto it = f.size() >= p + 20 ? pinstances_.find(std::string((const char*)&f[13], idLen)) : pinstances_.end();
     if (it == pinstances_.end()) {
-      stats_.dropped_frames++;
+      if (f.size() >= p + 20 && paused_.count(std::string((const char*)&f[13], idLen)))
+        retry_.push_back(std::move(f));
+      else
+        stats_.dropped_frames++;
       continue;
     }
     const int32_t gi = it->second.gidx;
@@ -570,7 +657,7 @@ bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector
   return true;
 }
 
-size_t PaxosManager::process() {
+size_t PaxosManager::processRun() {
   if (!engine_) return 0;
   /* The longest run of queued frames of one kind - PREPAREs, PREPARE replies, or the four byteified
    * types - bounded by the engine's batch capacity: a whole run goes through the engine as one
@@ -593,6 +680,7 @@ size_t PaxosManager::process() {
       requests_.pop_front();
     }
   if (frames.empty()) return 0;
+  pass_++;
   const size_t consumed = frames.size();
   std::vector<OutAccept> outAccepts; /* my own ACCEPTs of this pass: short-circuited, never decoded */
   if (kind == 1) { /* not among the byteified types: handled from the host layer's own layout */
@@ -645,8 +733,15 @@ size_t PaxosManager::process() {
     if (fst[(size_t)i] == GPX_W_CAPACITY) {
       inbox_.push_front(std::move(frames[(size_t)i])); /* did not fit the columns: next pass */
       frames[(size_t)i].clear();
+    } else if (fst[(size_t)i] == GPX_W_NOGROUP && frames[(size_t)i].size() > 13 &&
+               paused_.count(std::string((const char*)&frames[(size_t)i][13],
+                                         std::min<size_t>(frames[(size_t)i][12], frames[(size_t)i].size() - 13)))) {
+      retry_.push_front(std::move(frames[(size_t)i])); /* its group is paused: unpause, then again */
+      frames[(size_t)i].clear();
     } else if (fst[(size_t)i] != GPX_W_OK) {
       stats_.dropped_frames++; /* the reference drops such a packet */
+    } else {
+      lastActive_[(size_t)fg[(size_t)i]] = pass_;
     }
   }
   const int32_t nV = std::min(cnt.n_votes, capV), nC = std::min(cnt.n_commits, capC);
@@ -766,8 +861,11 @@ size_t PaxosManager::process() {
     stats_.engine_calls++;
     stats_.accepts += (uint64_t)nAll;
     for (int32_t i = 0; i < nAll; i++)
-      if (st[(size_t)i] == GPX_S_OK && (rf[(size_t)i] & GPX_R_STORED))
-        accepted_[key(g[(size_t)i], sl[(size_t)i])] = StoredAccept{bn[(size_t)i], bc[(size_t)i], *src[(size_t)i]};
+      if (st[(size_t)i] == GPX_S_OK && (rf[(size_t)i] & GPX_R_STORED)) {
+        auto ins = accepted_.insert_or_assign(key(g[(size_t)i], sl[(size_t)i]),
+                                              StoredAccept{bn[(size_t)i], bc[(size_t)i], *src[(size_t)i]});
+        if (ins.second) liveAccepts_[(size_t)g[(size_t)i]]++;
+      }
     executeRuns(nRuns, xg.data(), xf.data(), xc.data()); /* meta-commits an ACCEPT released (:1158-1161) */
     const int64_t capB = (int64_t)nAll * 192 + 1024;
     std::vector<uint8_t> out((size_t)capB);
@@ -866,6 +964,31 @@ size_t PaxosManager::process() {
     stats_.engine_calls++;
     stats_.commits += (uint64_t)nC;
     executeRuns(nRuns, xg.data(), xf.data(), xc.data());
+  }
+  return consumed;
+}
+
+size_t PaxosManager::process() {
+  size_t consumed = processRun();
+  /* frames that found their group paused: bring the groups back (getInstance -> unpause), pausing
+   * idle ones if the table is full, and queue the frames again.  A frame whose group cannot come
+   * back yet (every row holds a group with work in flight) waits for a later pass. */
+  if (!retry_.empty()) {
+    if (consumed == 0) pass_++; /* nothing else to do: every group without work in flight is idle */
+    std::deque<Frame> again, wait;
+    again.swap(retry_);
+    while (!again.empty()) {
+      Frame f = std::move(again.back());
+      again.pop_back();
+      const std::string name((const char*)&f[13], std::min<size_t>(f[12], f.size() - 13));
+      if (paused_.count(name) && !unpause(name)) {
+        wait.push_front(std::move(f));
+        continue;
+      }
+      inbox_.push_front(std::move(f));
+      consumed++;
+    }
+    retry_.swap(wait);
   }
   return consumed;
 }

@@ -73,6 +73,7 @@ struct Options {
 struct Stats {
   uint64_t proposed = 0, forwarded = 0, accepts = 0, votes = 0, decisions = 0, commits = 0, executed = 0;
   uint64_t dropped_frames = 0, refused = 0, engine_calls = 0;
+  uint64_t pauses = 0, unpauses = 0;
   uint64_t batched_requests = 0; /* requests that rode in another request's proposal */
   uint64_t elections_started = 0, elections_won = 0, elections_lost = 0, prepares = 0, carried_over = 0,
            noops = 0, preactive = 0;
@@ -100,6 +101,13 @@ class PaxosManager {
   void handleIncomingPacket(Frame&& frame);
   /* PaxosManager.kill(paxosID) (PM:2162-2192) */
   bool kill(const std::string& paxosID);
+  /* PaxosManager.pause (Deactivator -> PISM.tryPause, PM:2284-2412, PISM:2004-2035): the group's
+   * HotRestoreInfo leaves the device table and its row is free for another group; only a caught-up
+   * group with no accepted value outstanding is paused.  A packet or a request for a paused name
+   * brings it back (PaxosManager.getInstance -> unpause, PM:1816-1832), pausing idle groups first if
+   * the table is full. */
+  bool pause(const std::string& paxosID);
+  size_t pausedCount() const { return paused_.size(); }
   /* the failure detector's verdict (FailureDetection -> PaxosManager.isNodeUp == false): runs
    * checkRunForCoordinator over every instance (PISM:2090-2176) and multicasts the PREPAREs of the
    * groups this node must run for; returns their number */
@@ -140,6 +148,14 @@ class PaxosManager {
   void sendToMembers(const Instance& in, const Frame& frame, bool includeSelf);
   void issueAccept(std::vector<OutAccept>& out, int32_t gidx, const Frame& requestFrame, int64_t requestID,
                    bool stop, int32_t slot, int32_t bnum, int32_t bcoord, int32_t median);
+  struct Paused { /* what Deactivator keeps of a paused instance: its HotRestoreInfo */
+    gpx_hri hri;
+    std::vector<int32_t> members;
+    int32_t version;
+  };
+  bool unpause(const std::string& paxosID);
+  bool makeRoom(int32_t rows);
+  size_t processRun();
   bool handlePrepares(std::vector<Frame>& prepares);
   bool handlePrepareReplies(std::vector<Frame>& replies, std::vector<OutAccept>& out);
 
@@ -157,6 +173,12 @@ class PaxosManager {
    * pvalues the PREPARE replies carried */
   std::map<std::pair<int32_t, int64_t>, Frame> preactive_, carried_;
   std::vector<int32_t> downNodes_;
+  std::unordered_map<std::string, Paused> paused_;
+  std::vector<uint64_t> lastActive_; /* per row: the pass that last touched the group */
+  std::vector<int32_t> liveAccepts_; /* per row: accepted values the host still holds */
+  std::deque<Frame> retry_;          /* frames that found their group paused */
+  uint64_t pass_ = 0;
+  int32_t liveRows_ = 0;
   int64_t nextRequestID_;
   Stats stats_;
   std::string err_;

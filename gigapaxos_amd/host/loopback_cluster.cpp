@@ -7,7 +7,11 @@
 //
 //   gpx_loopback_cluster [--nodes 3] [--groups 1000] [--rounds 20] [--seed 1] [--value-bytes 64]
 //                        [--stop-last] [--entry any|coordinator] [--kill-round r [--kill-node i]]
-//                        [--burst b] [--no-batching]
+//                        [--burst b] [--no-batching] [--capacity c]
+// --capacity c: the engines' group tables hold only c < groups rows: idle groups are paused (their
+// HotRestoreInfo kept by the manager) and come back when a packet or request names them.  The
+// table must hold the groups that are busy at the same time: use --active a (a < c) so that a
+// round touches only a (rotating) window of a groups.
 // --burst b: b requests per group per round, queued together: RequestBatcher latches the requests
 // of one group that meet at a replica into one proposal (turned off by --no-batching).
 // --kill-round r: in round r node i (default 0) dies after ONE pipeline pass - ACCEPTs are in flight,
@@ -87,7 +91,7 @@ int main(int argc, char** argv) {
   int nNodes = 3, G = 1000, R = 20, valueBytes = 64;
   uint64_t seed = 1;
   bool stopLast = false, entryAny = true;
-  int killRound = -1, killNode = 0, burst = 1;
+  int killRound = -1, killNode = 0, burst = 1, capacity = 0, active = 0;
   bool batching = true;
   for (int i = 1; i < argc; i++) {
     auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
@@ -101,6 +105,8 @@ int main(int argc, char** argv) {
     else if (is("--kill-node") && i + 1 < argc) killNode = std::atoi(argv[++i]);
     else if (is("--burst") && i + 1 < argc) burst = std::atoi(argv[++i]);
     else if (is("--no-batching")) batching = false;
+    else if (is("--capacity") && i + 1 < argc) capacity = std::atoi(argv[++i]);
+    else if (is("--active") && i + 1 < argc) active = std::atoi(argv[++i]);
     else if (is("--entry") && i + 1 < argc) entryAny = std::strcmp(argv[++i], "any") == 0;
     else {
       std::fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -113,7 +119,7 @@ int main(int argc, char** argv) {
   std::vector<std::unique_ptr<HashChainApp>> apps;
   std::vector<std::unique_ptr<gpx::PaxosManager>> pms;
   gpx::Options opt;
-  opt.maxGroups = G + 16;
+  opt.maxGroups = capacity > 0 ? capacity : G + 16;
   opt.kmax = nNodes < 3 ? 3 : nNodes;
   opt.maxBatch = std::max(1 << 16, 8 * G * burst);
   opt.batchRequests = batching;
@@ -124,11 +130,19 @@ int main(int argc, char** argv) {
   }
   std::vector<std::string> names;
   for (int g = 0; g < G; g++) names.push_back("TESTPaxosApp" + std::to_string(g));
-  for (auto& pm : pms)
-    if (pm->createPaxosInstances(names, ids) != G) {
+  for (auto& pm : pms) {
+    int made = 0;
+    const size_t chunk = capacity > 0 ? (size_t)std::max(1, capacity / 4) : names.size();
+    for (size_t o = 0; o < names.size(); o += chunk) {
+      std::vector<std::string> part(names.begin() + (long)o, names.begin() + (long)std::min(names.size(), o + chunk));
+      made += pm->createPaxosInstances(part, ids);
+      pm->process(); /* a pass goes by: the groups just made count as idle for the next chunk */
+    }
+    if (made != G) {
       std::fprintf(stderr, "createPaxosInstances failed on node %d: %s\n", pm->myID(), pm->lastError());
       return 2;
     }
+  }
   std::vector<bool> alive((size_t)nNodes, true);
   auto drain = [&]() { /* until no node has anything left to do */
     for (;;) {
@@ -143,8 +157,9 @@ int main(int argc, char** argv) {
   uint64_t sent = 0;
   std::string value((size_t)valueBytes, 'x');
   for (int r = 0; r < R; r++) {
-    for (int gb = 0; gb < G * burst; gb++) {
-      const int g = gb % G;
+    const int nAct = active > 0 && active < G ? active : G;
+    for (int gb = 0; gb < nAct * burst; gb++) {
+      const int g = (int)(((long)r * nAct + gb % nAct) % G); /* a window of groups that moves every round */
       const uint64_t x = xorshift(rng);
       for (size_t b = 0; b < value.size() && b < 8; b++) value[b] = (char)('a' + ((x >> (8 * b)) & 15));
       size_t entry = entryAny ? (size_t)(x % (uint64_t)nNodes) : 0;
@@ -188,11 +203,11 @@ int main(int argc, char** argv) {
     for (auto& kv : apps[(size_t)i]->state) {
       d = (d ^ kv.second.hash) * 1099511628211ull + (uint64_t)kv.second.seqnum;
       ex += (uint64_t)kv.second.seqnum;
-      if (killRound < 0 && kv.second.seqnum != (int64_t)R * burst) ok = false;
+      if (killRound < 0 && active <= 0 && kv.second.seqnum != (int64_t)R * burst) ok = false;
       if (stopLast && !kv.second.stopped) ok = false;
     }
     if (first) digest0 = d, executed0 = ex, first = false;
-    if ((int)apps[(size_t)i]->state.size() != G || apps[(size_t)i]->outOfOrder || d != digest0) ok = false;
+    if ((active <= 0 && (int)apps[(size_t)i]->state.size() != G) || apps[(size_t)i]->outOfOrder || d != digest0) ok = false;
     if (killRound < 0 ? ex != sent : ex + sentKillRound < sent) ok = false;
   }
   uint64_t digest[1] = {digest0};
@@ -201,12 +216,13 @@ int main(int argc, char** argv) {
               nNodes, G, R, sent, executed0, digest[0], net.frames, net.bytes, ok ? "true" : "false");
   for (int i = 0; i < nNodes; i++) {
     const gpx::Stats& s = pms[(size_t)i]->stats();
-    std::printf("%s{\"id\": %d, \"alive\": %s, \"proposed\": %" PRIu64 ", \"batched_requests\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
+    std::printf("%s{\"id\": %d, \"alive\": %s, \"pauses\": %" PRIu64 ", \"unpauses\": %" PRIu64 ", \"paused_now\": %zu, \"proposed\": %" PRIu64 ", \"batched_requests\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
                 ", \"votes\": %" PRIu64 ", \"decisions\": %" PRIu64 ", \"commits\": %" PRIu64 ", \"executed\": %" PRIu64
                 ", \"refused\": %" PRIu64 ", \"dropped_frames\": %" PRIu64 ", \"engine_calls\": %" PRIu64
                 ", \"elections_started\": %" PRIu64 ", \"elections_won\": %" PRIu64 ", \"elections_lost\": %" PRIu64
                 ", \"prepares\": %" PRIu64 ", \"carried_over\": %" PRIu64 ", \"noops\": %" PRIu64 ", \"preactive\": %" PRIu64 "}",
-                i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.proposed, s.batched_requests, s.forwarded,
+                i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.pauses, s.unpauses,
+                pms[(size_t)i]->pausedCount(), s.proposed, s.batched_requests, s.forwarded,
                 s.accepts, s.votes, s.decisions, s.commits, s.executed, s.refused, s.dropped_frames, s.engine_calls,
                 s.elections_started, s.elections_won, s.elections_lost, s.prepares, s.carried_over, s.noops,
                 s.preactive);

@@ -27,6 +27,10 @@ CASES = [
     ["--groups", "50", "--rounds", "3", "--burst", "40", "--nodes", "5", "--seed", "4"],
     ["--groups", "200", "--rounds", "6", "--burst", "3", "--kill-round", "2"],
     ["--groups", "100", "--rounds", "3", "--burst", "4", "--no-batching"],
+    # device tables smaller than the number of groups: pause / unpause by HotRestoreInfo on demand
+    ["--groups", "600", "--rounds", "30", "--capacity", "128", "--active", "40"],
+    ["--groups", "500", "--rounds", "25", "--capacity", "96", "--active", "24", "--nodes", "5", "--burst", "2",
+     "--seed", "6"],
 ]
 
 

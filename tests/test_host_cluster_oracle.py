@@ -23,8 +23,14 @@ def test_cluster_invariants(case):
         assert out["executed_per_node"] >= out["groups"] * (out["rounds"] - 1)
         return
     args = CASES[case]
+    if "--capacity" in args:
+        cap = int(args[args.index("--capacity") + 1])
+        for n in out["per_node"]:
+            assert n["pauses"] >= out["groups"] - cap and n["unpauses"] > 0
+            assert n["paused_now"] >= out["groups"] - cap
     burst = int(args[args.index("--burst") + 1]) if "--burst" in args else 1
-    assert out["executed_per_node"] == out["requests"] == out["groups"] * out["rounds"] * burst
+    per_round = int(args[args.index("--active") + 1]) if "--active" in args else out["groups"]
+    assert out["executed_per_node"] == out["requests"] == per_round * out["rounds"] * burst
     for n in out["per_node"]:
         assert n["executed"] == out["requests"] and n["dropped_frames"] == 0 and n["refused"] == 0
     proposed = sum(n["proposed"] for n in out["per_node"])
