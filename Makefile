@@ -1,0 +1,30 @@
+# Builds what __graft_entry__.build() builds, for maintainers who do not go through Python:
+#   make            the gfx950 library, the C++ host layer's cluster example, the CPU oracle (checker)
+#   make test-cpu   the CPU test suite (oracle KATs, ABI, host logic, gloo multi-rank)
+# hipcc cross-compiles for gfx950 without a GPU.
+HIPCC ?= hipcc
+CXX ?= g++
+CSRC := gigapaxos_amd/csrc
+HOST := gigapaxos_amd/host
+LIB := $(CSRC)/libgpx_hip.so
+CLUSTER := $(HOST)/gpx_loopback_cluster
+
+all: $(LIB) $(CLUSTER) oracle
+
+$(LIB): $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.inc) include/gpx.h include/gpx_wire.h
+	cd $(CSRC) && $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result -o libgpx_hip.so gpx_engine.hip
+
+$(CLUSTER): $(HOST)/gpx_host.cpp $(HOST)/loopback_cluster.cpp $(HOST)/gpx_host.hpp $(LIB)
+	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude -o $@ $(HOST)/gpx_host.cpp $(HOST)/loopback_cluster.cpp \
+	    -L$(CSRC) -lgpx_hip '-Wl,-rpath,$$ORIGIN/../csrc' -Wl,-rpath-link,/opt/rocm/lib
+
+oracle:
+	$(MAKE) -C oracle -s
+
+test-cpu: all
+	python -m pytest tests -q -m "not gpu"
+
+clean:
+	rm -f $(LIB) $(CLUSTER) oracle/libgpx_oracle.so oracle/_host_cluster_oracle
+
+.PHONY: all oracle test-cpu clean
