@@ -118,15 +118,21 @@ def small_scenarios(lib):
     return out
 
 
-def fuzz_run(lib, seed, G=96, k=3, W=8, steps=60, my_id=1):
+def w32(x):
+    """Java int arithmetic: wrap to 32 bits."""
+    return ((np.asarray(x, np.int64) + (1 << 31)) % (1 << 32) - (1 << 31)).astype(np.int32)
+
+
+def fuzz_run(lib, seed, G=96, k=3, W=8, steps=60, my_id=1, slot0=0):
     """Random interleaving of elections, pre-active proposals, prepare replies, accept replies and
     ordinary rounds over G groups; returns every output and the final dump of every group."""
     rng = np.random.default_rng(seed)
     ids = np.arange(k, dtype=np.int32)
     members = np.tile(ids, (G, 1))
     e = Engine(lib, my_id, G, kmax=k, window=W, max_batch=max(4096, 4 * G))
-    base_slot = rng.integers(0, 50, G).astype(np.int32)
-    rows = plain_rows(G, base_slot, 0, 0, gc=base_slot - 1)
+    # slot0 near Integer.MAX_VALUE makes every slot sequence straddle the wraparound
+    base_slot = w32(slot0 + rng.integers(0, 50, G))
+    rows = plain_rows(G, base_slot, 0, 0, gc=w32(base_slot.astype(np.int64) - 1))
     rows["acc_bcoord"] = rng.integers(0, k, G)
     assert (e.create_groups(np.arange(G), members, k, rows) == S_OK).all()
     cur_b = np.zeros(G, np.int32)       # the ballot number this node last ran with
@@ -154,15 +160,16 @@ def fuzz_run(lib, seed, G=96, k=3, W=8, steps=60, my_id=1):
             acc = rng.integers(0, k + 1, n).astype(np.int32)  # k = not a member
             rb = cur_b[gi] + (rng.random(n) < 0.08).astype(np.int32) - (rng.random(n) < 0.08).astype(np.int32)
             rc = np.where(rng.random(n) < 0.9, my_id, rng.integers(0, k, n)).astype(np.int32)
-            first = base_slot[gi] + rng.integers(-1, 3, n).astype(np.int32)
+            first = w32(base_slot[gi].astype(np.int64) + rng.integers(-1, 3, n))
             pvs = []
             for i in range(n):
                 m = int(rng.integers(0, 4)) if rng.random() < 0.6 else 0
-                slots = rng.choice(np.arange(first[i] - 1, first[i] + (W if rng.random() < 0.9 else 2 * W)), m,
-                                   replace=False)
+                slots = w32(rng.choice(np.arange(int(first[i]) - 1,
+                                                 int(first[i]) + (W if rng.random() < 0.9 else 2 * W)), m,
+                                       replace=False))
                 pv = []
                 for s in slots:
-                    hh = int(rng.integers(1000, max(hctr, 1001))) if rng.random() < 0.3 else int(10 ** 6 + s)
+                    hh = int(rng.integers(1000, max(hctr, 1001))) if rng.random() < 0.3 else int(10 ** 10 + int(s))
                     pv.append((int(s), int(rng.integers(0, max(int(rb[i]), 1))), int(rng.integers(0, k)), hh,
                                int(rng.choice([0, 0, 0, PV_STOP, PV_NOOP]))))
                 pvs.append(pv)
@@ -173,8 +180,8 @@ def fuzz_run(lib, seed, G=96, k=3, W=8, steps=60, my_id=1):
             gi = rng.integers(0, G, n).astype(np.int32)
             hb = rng.random(n) < 0.15
             d = e.accept_reply(gi, cur_b[gi] + hb, np.where(hb, rng.integers(0, k, n), my_id),
-                               base_slot[gi] + rng.integers(0, W, n), rng.integers(0, k, n),
-                               base_slot[gi] - 1 + rng.integers(0, 2, n))
+                               w32(base_slot[gi].astype(np.int64) + rng.integers(0, W, n)), rng.integers(0, k, n),
+                               w32(base_slot[gi].astype(np.int64) - 1 + rng.integers(0, 2, n)))
             trace.append(("ar", d.as_tuple_array().tolist()))
         else:
             trace.append(("dump", [e.dump(int(g)).tolist() for g in rng.integers(0, G, 8)]))

@@ -22,11 +22,13 @@ def test_small_scenarios_parity(hip_lib, oracle_lib):
     _same(small_scenarios(hip_lib), small_scenarios(oracle_lib))
 
 
-@pytest.mark.parametrize("seed,G,k,W,steps", [(1, 96, 3, 8, 60), (2, 300, 5, 16, 60), (3, 700, 3, 8, 80),
-                                              (4, 64, 9, 32, 50), (5, 2000, 3, 8, 40)])
-def test_election_fuzz_parity(hip_lib, oracle_lib, seed, G, k, W, steps):
-    a = fuzz_run(hip_lib, seed, G=G, k=k, W=W, steps=steps)
-    b = fuzz_run(oracle_lib, seed, G=G, k=k, W=W, steps=steps)
+@pytest.mark.parametrize("seed,G,k,W,steps,slot0", [(1, 96, 3, 8, 60, 0), (2, 300, 5, 16, 60, 0), (3, 700, 3, 8, 80, 0),
+                                                    (4, 64, 9, 32, 50, 0), (5, 2000, 3, 8, 40, 0),
+                                                    # slots straddling Integer.MAX_VALUE -> MIN_VALUE
+                                                    (6, 400, 3, 8, 70, 2 ** 31 - 30), (7, 200, 5, 16, 60, 2 ** 31 - 55)])
+def test_election_fuzz_parity(hip_lib, oracle_lib, seed, G, k, W, steps, slot0):
+    a = fuzz_run(hip_lib, seed, G=G, k=k, W=W, steps=steps, slot0=slot0)
+    b = fuzz_run(oracle_lib, seed, G=G, k=k, W=W, steps=steps, slot0=slot0)
     _same(a, b)
     kinds = [v for x in b if x[0] == "reply" for v in x[1]]
     assert V_ELECTED in kinds and V_PREEMPTED in kinds
