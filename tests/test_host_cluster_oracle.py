@@ -53,7 +53,7 @@ def test_cluster_under_sanitizers(tmp_path):
     from tests.host_cluster_common import HOST, ROOT
 
     exe = str(tmp_path / "cluster_san")
-    subprocess.check_call(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17",
+    subprocess.check_call(["g++", "-O0", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17",
                            "-I", os.path.join(ROOT, "include"), "-include",
                            os.path.join(ROOT, "tests", "host_oracle_prefix.h"), "-o", exe,
                            os.path.join(HOST, "gpx_host.cpp"), os.path.join(HOST, "loopback_cluster.cpp"),
