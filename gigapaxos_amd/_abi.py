@@ -76,6 +76,8 @@ _SIGS = {
     "engine_destroy": [],
     "engine_sync": [],
     "engine_counters": [C.POINTER(C.c_uint64)],
+    "host_register": [_VP, C.c_size_t],
+    "host_unregister": [_VP],
     "group_create": [C.c_int32, _VP, _VP, _VP, _VP, _VP],
     "group_retire": [C.c_int32, _VP, C.c_int32, _VP, _VP],
     "group_snapshot": [C.c_int32, _VP, _VP, _VP],
@@ -312,6 +314,16 @@ class Engine:
         out = (C.c_uint64 * 3)()
         self.lib.check(self.lib.fn["engine_counters"](self.h, out), "engine_counters")
         return tuple(int(x) for x in out)
+
+    def host_register(self, *arrays):
+        """Pins numpy arrays for DMA (gpx_host_register); returns them.  Unpin with host_unregister."""
+        for a in arrays:
+            self.lib.check(self.lib.fn["host_register"](self.h, _p(a), a.nbytes), "host_register")
+        return arrays
+
+    def host_unregister(self, *arrays):
+        for a in arrays:
+            self.lib.check(self.lib.fn["host_unregister"](self.h, _p(a)), "host_unregister")
 
     def sync(self):
         self.lib.check(self.lib.fn["engine_sync"](self.h), "engine_sync")

@@ -537,6 +537,17 @@ int gpx_engine_fence(gpx_engine* h) {
   return GPX_OK;
 }
 
+int gpx_host_register(gpx_engine* h, void* ptr, size_t bytes) {
+  if (!h || !ptr || !bytes) return GPX_EINVAL;
+  HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  return GPX_OK;
+}
+int gpx_host_unregister(gpx_engine* h, void* ptr) {
+  if (!h || !ptr) return GPX_EINVAL;
+  HIPCHK(hipHostUnregister(ptr));
+  return GPX_OK;
+}
+
 int gpx_engine_sync(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
   HIPCHK(hipStreamSynchronize(h->sF));

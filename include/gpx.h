@@ -137,6 +137,14 @@ int gpx_engine_destroy(gpx_engine* h);
 const char* gpx_last_error(void);
 /* run subsequent *_dev calls on this hipStream_t (NULL = the engine's own stream) */
 int gpx_engine_set_stream(gpx_engine* h, void* hip_stream);
+/*
+ * Pins a caller-owned host buffer for DMA (hipHostRegister): the host-pointer entry points copy
+ * their columns with asynchronous DMA from / to registered memory instead of the runtime's staged
+ * copies of pageable memory.  A JNI host registers the memory of its direct ByteBuffers once, after
+ * allocating them.  Purely an optimisation: unregistered pointers keep working.
+ */
+int gpx_host_register(gpx_engine* h, void* ptr, size_t bytes);
+int gpx_host_unregister(gpx_engine* h, void* ptr);
 /* block until everything submitted to the engine has finished */
 int gpx_engine_sync(gpx_engine* h);
 /*

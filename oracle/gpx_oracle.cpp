@@ -458,6 +458,8 @@ int orc_engine_destroy(gpx_engine* h) {
   return GPX_OK;
 }
 int orc_engine_sync(gpx_engine*) { return GPX_OK; }
+int orc_host_register(gpx_engine* h, void* p, size_t n) { return h && p && n ? GPX_OK : GPX_EINVAL; }
+int orc_host_unregister(gpx_engine* h, void* p) { return h && p ? GPX_OK : GPX_EINVAL; }
 int orc_engine_counters(gpx_engine* h, uint64_t out[3]) {
   if (!h) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);
