@@ -446,6 +446,10 @@ void PaxosManager::executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* 
           }
           stats_.executed++;
         }
+      /* the decision stays available to replicas that missed its commit (the logger's job in the
+       * reference), a bounded number of slots back */
+      decided_[key(xg[r], slot)] = std::move(a->second);
+      decided_.erase(key(xg[r], (int32_t)((uint32_t)slot - (uint32_t)opt_.decisionLogSlots)));
       accepted_.erase(a); /* acceptedProposals.remove(slot) on execution (PaxosAcceptor.java:357-359) */
       liveAccepts_[(size_t)xg[r]]--;
     }
@@ -657,6 +661,112 @@ bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector
   return true;
 }
 
+/* PISM.syncLongDecisionGaps -> requestMissingDecisions (PISM:1550-1570, 2284-2330): which of these
+ * groups have a long gap, and which slots are missing */
+bool PaxosManager::syncGaps(const std::vector<int32_t>& gidx, const std::vector<int32_t>& bcoord) {
+  const int32_t n = (int32_t)gidx.size();
+  if (n == 0) return true;
+  std::vector<int32_t> first((size_t)n), maxc((size_t)n);
+  std::vector<uint64_t> missing((size_t)n);
+  std::vector<uint8_t> sync((size_t)n), st((size_t)n);
+  if (!check(gpx_gap_scan(engine_, n, gidx.data(), opt_.syncGapThreshold, GPX_SYNC_DEFAULT, 64, first.data(),
+                          maxc.data(), missing.data(), sync.data(), st.data()),
+             "gpx_gap_scan"))
+    return false;
+  stats_.engine_calls++;
+  for (int32_t i = 0; i < n; i++) {
+    if (st[(size_t)i] != GPX_S_OK || !sync[(size_t)i] || !missing[(size_t)i] || bcoord[(size_t)i] == myID_) continue;
+    std::vector<int32_t> slots;
+    for (int j = 0; j < 64; j++)
+      if ((missing[(size_t)i] >> j) & 1ull) {
+        const int32_t s = (int32_t)((uint32_t)first[(size_t)i] + (uint32_t)j);
+        uint64_t& asked = syncAsked_[key(gidx[(size_t)i], s)]; /* canSync: not again right away */
+        if (asked == 0 || pass_ - asked > 8) slots.push_back(s), asked = pass_;
+      }
+    if (slots.empty()) continue;
+    Frame f;
+    putHeader(f, kTypeSyncDecisions, 0, rowName_[(size_t)gidx[(size_t)i]]);
+    put32(f, myID_);
+    put32(f, (int32_t)slots.size());
+    for (int32_t s : slots) put32(f, s);
+    messenger_->send(bcoord[(size_t)i], std::move(f));
+    stats_.sync_requests++;
+  }
+  return true;
+}
+
+/* PISM.handleSyncDecisionsPacket (PISM:2372-2440): answer with the decisions I still hold */
+bool PaxosManager::handleSyncRequests(std::vector<Frame>& reqs) {
+  for (auto& f : reqs) {
+    const size_t idLen = f.size() > 12 ? f[12] : 0, p = 13 + idLen;
+    if (f.size() < p + 8) continue;
+    auto it = pinstances_.find(std::string((const char*)&f[13], idLen));
+    if (it == pinstances_.end()) continue; /* (a paused group has nothing newer than the requester) */
+    const int32_t sender = get32(&f[p]), cnt = get32(&f[p + 4]);
+    for (int32_t j = 0; j < cnt && p + 8 + 4 * (size_t)j + 4 <= f.size(); j++) {
+      const int32_t slot = get32(&f[p + 8 + 4 * (size_t)j]);
+      auto d = decided_.find(key(it->second.gidx, slot));
+      if (d == decided_.end()) continue;
+      Frame out;
+      putHeader(out, kTypeDecision, 0, it->first);
+      put32(out, slot), put32(out, d->second.bnum), put32(out, d->second.bcoord);
+      put32(out, (int32_t)((uint32_t)slot - 1u)); /* a median that is safe for anyone who lacks this slot */
+      put32(out, (int32_t)d->second.frame.size());
+      out.insert(out.end(), d->second.frame.begin(), d->second.frame.end());
+      messenger_->send(sender, std::move(out));
+      stats_.sync_decisions_sent++;
+    }
+  }
+  return true;
+}
+
+/* a full DECISION (value included): handleCommittedRequest (PISM:1432-1478) */
+bool PaxosManager::handleDecisions(std::vector<Frame>& decisions) {
+  std::vector<int32_t> g, bn, bc, sl, md;
+  std::vector<uint8_t> kind;
+  for (auto& f : decisions) {
+    const size_t idLen = f.size() > 12 ? f[12] : 0, p = 13 + idLen;
+    if (f.size() < p + 20) continue;
+    auto it = pinstances_.find(std::string((const char*)&f[13], idLen));
+    if (it == pinstances_.end()) {
+      if (paused_.count(std::string((const char*)&f[13], idLen))) retry_.push_back(std::move(f));
+      continue;
+    }
+    const int32_t len = get32(&f[p + 16]);
+    if (len < 0 || f.size() < p + 20 + (size_t)len) continue;
+    const int32_t gi = it->second.gidx, slot = get32(&f[p]);
+    Frame val(f.begin() + (long)(p + 20), f.begin() + (long)(p + 20 + (size_t)len));
+    const bool stop = frameIsStop(val);
+    auto ins = accepted_.insert_or_assign(key(gi, slot), StoredAccept{get32(&f[p + 4]), get32(&f[p + 8]), std::move(val)});
+    if (ins.second) liveAccepts_[(size_t)gi]++;
+    g.push_back(gi), sl.push_back(slot), bn.push_back(get32(&f[p + 4])), bc.push_back(get32(&f[p + 8]));
+    md.push_back(get32(&f[p + 12]));
+    kind.push_back((uint8_t)(GPX_C_HASVALUE | (stop ? GPX_C_STOP : 0)));
+    lastActive_[(size_t)gi] = pass_;
+  }
+  const int32_t n = (int32_t)g.size();
+  if (n == 0) return true;
+  std::vector<uint8_t> st((size_t)n);
+  std::vector<int32_t> xg((size_t)n), xf((size_t)n), xc((size_t)n);
+  int32_t nRuns = 0;
+  if (!check(gpx_commit_batch(engine_, n, g.data(), bn.data(), bc.data(), sl.data(), md.data(), kind.data(), st.data(),
+                              xg.data(), xf.data(), xc.data(), &nRuns),
+             "gpx_commit_batch"))
+    return false;
+  stats_.engine_calls++;
+  stats_.sync_decisions_applied += (uint64_t)n;
+  executeRuns(nRuns, xg.data(), xf.data(), xc.data());
+  /* a decision for a slot already executed here left its value behind: drop it again */
+  for (int32_t i = 0; i < n; i++) {
+    auto a = accepted_.find(key(g[(size_t)i], sl[(size_t)i]));
+    if (a != accepted_.end() && decided_.count(key(g[(size_t)i], sl[(size_t)i]))) {
+      accepted_.erase(a);
+      liveAccepts_[(size_t)g[(size_t)i]]--;
+    }
+  }
+  return true;
+}
+
 size_t PaxosManager::processRun() {
   if (!engine_) return 0;
   /* The longest run of queued frames of one kind - PREPAREs, PREPARE replies, or the four byteified
@@ -665,7 +775,7 @@ size_t PaxosManager::processRun() {
    * after it, as the reference's per-packet handling would). */
   auto kindOf = [](const Frame& f) {
     const int32_t t = f.size() >= 8 ? get32(&f[4]) : -1;
-    return t == kTypePrepare ? 1 : t == kTypePrepareReply ? 2 : 0;
+    return t == kTypePrepare ? 1 : t == kTypePrepareReply ? 2 : t == kTypeSyncDecisions ? 3 : t == kTypeDecision ? 4 : 0;
   };
   std::vector<Frame> frames;
   const size_t maxFrames = (size_t)std::max(1, opt_.maxBatch / 4);
@@ -690,6 +800,14 @@ size_t PaxosManager::processRun() {
   if (kind == 2) {
     if (!handlePrepareReplies(frames, outAccepts)) return consumed;
     frames.clear();
+  }
+  if (kind == 3) {
+    handleSyncRequests(frames);
+    return consumed;
+  }
+  if (kind == 4) {
+    handleDecisions(frames);
+    return consumed;
   }
   const int32_t nF = (int32_t)frames.size();
   if (nF == 0 && outAccepts.empty()) return consumed;
@@ -964,6 +1082,11 @@ size_t PaxosManager::processRun() {
     stats_.engine_calls++;
     stats_.commits += (uint64_t)nC;
     executeRuns(nRuns, xg.data(), xf.data(), xc.data());
+    /* did a commit of mine get lost on the way?  the groups these commits name, once each */
+    std::vector<int32_t> sg, sb;
+    for (int32_t i = 0; i < nC; i++)
+      if (i == 0 || c.gidx[(size_t)i] != c.gidx[(size_t)i - 1]) sg.push_back(c.gidx[(size_t)i]), sb.push_back(c.bcoord[(size_t)i]);
+    syncGaps(sg, sb);
   }
   return consumed;
 }

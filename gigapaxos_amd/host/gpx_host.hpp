@@ -65,6 +65,10 @@ struct Options {
   int32_t device = -1;
   /* RequestBatcher (RequestBatcher.java:40-239): requests of one group that are queued together
    * become ONE proposal, up to these limits (PC.MAX_BATCH_SIZE; min(NIO payload, log message size)) */
+  /* PISM.syncLongDecisionGaps (PISM:1550-1570): a group whose newest commit is this many slots ahead
+   * of its next undecided slot asks the commit's coordinator for the missing decisions */
+  int32_t syncGapThreshold = 2;
+  int32_t decisionLogSlots = 64; /* executed decisions kept per group to answer such requests */
   bool batchRequests = true;
   int32_t maxBatchSize = 2000;
   int32_t maxBatchBytes = 1 << 20;
@@ -74,6 +78,7 @@ struct Stats {
   uint64_t proposed = 0, forwarded = 0, accepts = 0, votes = 0, decisions = 0, commits = 0, executed = 0;
   uint64_t dropped_frames = 0, refused = 0, engine_calls = 0;
   uint64_t pauses = 0, unpauses = 0;
+  uint64_t sync_requests = 0, sync_decisions_sent = 0, sync_decisions_applied = 0;
   uint64_t batched_requests = 0; /* requests that rode in another request's proposal */
   uint64_t elections_started = 0, elections_won = 0, elections_lost = 0, prepares = 0, carried_over = 0,
            noops = 0, preactive = 0;
@@ -156,6 +161,9 @@ class PaxosManager {
   bool unpause(const std::string& paxosID);
   bool makeRoom(int32_t rows);
   size_t processRun();
+  bool handleSyncRequests(std::vector<Frame>& reqs);
+  bool handleDecisions(std::vector<Frame>& decisions);
+  bool syncGaps(const std::vector<int32_t>& gidx, const std::vector<int32_t>& bcoord);
   bool handlePrepares(std::vector<Frame>& prepares);
   bool handlePrepareReplies(std::vector<Frame>& replies, std::vector<OutAccept>& out);
 
@@ -173,6 +181,9 @@ class PaxosManager {
    * pvalues the PREPARE replies carried */
   std::map<std::pair<int32_t, int64_t>, Frame> preactive_, carried_;
   std::vector<int32_t> downNodes_;
+  /* what the logger's getLoggedDecisions would return: the last decisions executed here */
+  std::unordered_map<uint64_t, StoredAccept> decided_;
+  std::unordered_map<uint64_t, uint64_t> syncAsked_; /* (gidx, slot) -> the pass a sync was last requested in */
   std::unordered_map<std::string, Paused> paused_;
   std::vector<uint64_t> lastActive_; /* per row: the pass that last touched the group */
   std::vector<int32_t> liveAccepts_; /* per row: accepted values the host still holds */
@@ -196,6 +207,9 @@ Frame makeAcceptFrame(const Frame& requestFrame, int32_t slot, int32_t bnum, int
  * here is this host layer's own - PaxosPacket header, then {bnum, bcoord, firstUndecidedSlot} and
  * {acceptor, bnum, bcoord, firstSlot, n, n x {slot, bnum, bcoord, len, the ACCEPT frame}} */
 constexpr int32_t kTypePrepare = 2, kTypePrepareReply = 7; /* PaxosPacketType ints (PaxosPacket.java:202-230) */
+/* SYNC_DECISIONS_REQUEST and DECISION, JSON-only as well: {sender, n, n x slot} and
+ * {slot, bnum, bcoord, medianCheckpointedSlot, len, the ACCEPT frame} */
+constexpr int32_t kTypeSyncDecisions = 32, kTypeDecision = 6;
 /* the request inside a REQUEST / ACCEPT frame; false if the bytes do not parse */
 bool parseRequest(const Frame& frame, Request* out);
 /* ... and with the requests batched into it (RequestPacket.getRequestPackets, :1239-1245): itself

@@ -7,7 +7,10 @@
 //
 //   gpx_loopback_cluster [--nodes 3] [--groups 1000] [--rounds 20] [--seed 1] [--value-bytes 64]
 //                        [--stop-last] [--entry any|coordinator] [--kill-round r [--kill-node i]]
-//                        [--burst b] [--no-batching] [--capacity c]
+//                        [--burst b] [--no-batching] [--capacity c] [--drop-commits permille]
+// --drop-commits p: the network loses p of 1000 BATCHED_COMMIT frames; a replica that sees newer
+// commits while an older slot is undecided (gpx_gap_scan) asks the coordinator for the decisions it
+// missed (two extra loss-free rounds at the end let the tail catch up).
 // --capacity c: the engines' group tables hold only c < groups rows: idle groups are paused (their
 // HotRestoreInfo kept by the manager) and come back when a packet or request names them.  The
 // table must hold the groups that are busy at the same time: use --active a (a < c) so that a
@@ -68,10 +71,18 @@ class HashChainApp : public gpx::Replicable {
 class LoopbackMessenger : public gpx::Messenger {
  public:
   std::map<int32_t, gpx::PaxosManager*> nodes;
-  uint64_t frames = 0, bytes = 0;
+  uint64_t frames = 0, bytes = 0, lost = 0, rng = 88172645463325252ull;
+  int dropCommitsPermille = 0;
   void send(int32_t nodeID, gpx::Frame&& f) override {
     auto it = nodes.find(nodeID);
     if (it == nodes.end()) return; /* a dead node: the frame is lost */
+    if (dropCommitsPermille > 0 && f.size() >= 8 && f[7] == GPX_WT_BATCHED_COMMIT && f[6] == 0) {
+      rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17;
+      if ((int)(rng % 1000) < dropCommitsPermille) {
+        lost++;
+        return;
+      }
+    }
     frames++;
     bytes += f.size();
     it->second->handleIncomingPacket(std::move(f));
@@ -91,7 +102,7 @@ int main(int argc, char** argv) {
   int nNodes = 3, G = 1000, R = 20, valueBytes = 64;
   uint64_t seed = 1;
   bool stopLast = false, entryAny = true;
-  int killRound = -1, killNode = 0, burst = 1, capacity = 0, active = 0;
+  int killRound = -1, killNode = 0, burst = 1, capacity = 0, active = 0, dropCommits = 0;
   bool batching = true;
   for (int i = 1; i < argc; i++) {
     auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
@@ -107,6 +118,7 @@ int main(int argc, char** argv) {
     else if (is("--no-batching")) batching = false;
     else if (is("--capacity") && i + 1 < argc) capacity = std::atoi(argv[++i]);
     else if (is("--active") && i + 1 < argc) active = std::atoi(argv[++i]);
+    else if (is("--drop-commits") && i + 1 < argc) dropCommits = std::atoi(argv[++i]);
     else if (is("--entry") && i + 1 < argc) entryAny = std::strcmp(argv[++i], "any") == 0;
     else {
       std::fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -156,7 +168,9 @@ int main(int argc, char** argv) {
   uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 1;
   uint64_t sent = 0;
   std::string value((size_t)valueBytes, 'x');
+  net.dropCommitsPermille = dropCommits;
   for (int r = 0; r < R; r++) {
+    if (dropCommits > 0 && r >= R - 2) net.dropCommitsPermille = 0; /* the tail catches up */
     const int nAct = active > 0 && active < G ? active : G;
     for (int gb = 0; gb < nAct * burst; gb++) {
       const int g = (int)(((long)r * nAct + gb % nAct) % G); /* a window of groups that moves every round */
@@ -212,20 +226,21 @@ int main(int argc, char** argv) {
   }
   uint64_t digest[1] = {digest0};
   std::printf("{\"nodes\": %d, \"groups\": %d, \"rounds\": %d, \"requests\": %" PRIu64 ", \"executed_per_node\": %" PRIu64
-              ", \"state_digest\": \"%016" PRIx64 "\", \"frames\": %" PRIu64 ", \"bytes\": %" PRIu64 ", \"ok\": %s, \"per_node\": [",
-              nNodes, G, R, sent, executed0, digest[0], net.frames, net.bytes, ok ? "true" : "false");
+              ", \"state_digest\": \"%016" PRIx64 "\", \"frames\": %" PRIu64 ", \"bytes\": %" PRIu64 ", \"frames_lost\": %" PRIu64 ", \"ok\": %s, \"per_node\": [",
+              nNodes, G, R, sent, executed0, digest[0], net.frames, net.bytes, net.lost, ok ? "true" : "false");
   for (int i = 0; i < nNodes; i++) {
     const gpx::Stats& s = pms[(size_t)i]->stats();
     std::printf("%s{\"id\": %d, \"alive\": %s, \"pauses\": %" PRIu64 ", \"unpauses\": %" PRIu64 ", \"paused_now\": %zu, \"proposed\": %" PRIu64 ", \"batched_requests\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
                 ", \"votes\": %" PRIu64 ", \"decisions\": %" PRIu64 ", \"commits\": %" PRIu64 ", \"executed\": %" PRIu64
                 ", \"refused\": %" PRIu64 ", \"dropped_frames\": %" PRIu64 ", \"engine_calls\": %" PRIu64
                 ", \"elections_started\": %" PRIu64 ", \"elections_won\": %" PRIu64 ", \"elections_lost\": %" PRIu64
-                ", \"prepares\": %" PRIu64 ", \"carried_over\": %" PRIu64 ", \"noops\": %" PRIu64 ", \"preactive\": %" PRIu64 "}",
+                ", \"prepares\": %" PRIu64 ", \"carried_over\": %" PRIu64 ", \"noops\": %" PRIu64 ", \"preactive\": %" PRIu64
+                ", \"sync_requests\": %" PRIu64 ", \"sync_decisions_sent\": %" PRIu64 ", \"sync_decisions_applied\": %" PRIu64 "}",
                 i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.pauses, s.unpauses,
                 pms[(size_t)i]->pausedCount(), s.proposed, s.batched_requests, s.forwarded,
                 s.accepts, s.votes, s.decisions, s.commits, s.executed, s.refused, s.dropped_frames, s.engine_calls,
                 s.elections_started, s.elections_won, s.elections_lost, s.prepares, s.carried_over, s.noops,
-                s.preactive);
+                s.preactive, s.sync_requests, s.sync_decisions_sent, s.sync_decisions_applied);
   }
   std::printf("]}\n");
   return ok ? 0 : 1;

@@ -31,6 +31,9 @@ CASES = [
     ["--groups", "600", "--rounds", "30", "--capacity", "128", "--active", "40"],
     ["--groups", "500", "--rounds", "25", "--capacity", "96", "--active", "24", "--nodes", "5", "--burst", "2",
      "--seed", "6"],
+    # a lossy network for BATCHED_COMMITs: gap detection (gpx_gap_scan) and decision sync
+    ["--groups", "200", "--rounds", "12", "--drop-commits", "100"],
+    ["--groups", "1000", "--rounds", "10", "--drop-commits", "250", "--nodes", "5", "--seed", "8"],
 ]
 
 

@@ -23,3 +23,4 @@
 #define gpx_prepare_batch orc_prepare_batch
 #define gpx_prepare_reply_batch orc_prepare_reply_batch
 #define gpx_request_batch orc_request_batch
+#define gpx_gap_scan orc_gap_scan

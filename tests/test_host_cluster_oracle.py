@@ -28,6 +28,10 @@ def test_cluster_invariants(case):
         for n in out["per_node"]:
             assert n["pauses"] >= out["groups"] - cap and n["unpauses"] > 0
             assert n["paused_now"] >= out["groups"] - cap
+    if "--drop-commits" in args:
+        assert out["frames_lost"] > 0
+        assert sum(n["sync_requests"] for n in out["per_node"]) > 0
+        assert sum(n["sync_decisions_applied"] for n in out["per_node"]) > 0
     burst = int(args[args.index("--burst") + 1]) if "--burst" in args else 1
     per_round = int(args[args.index("--active") + 1]) if "--active" in args else out["groups"]
     assert out["executed_per_node"] == out["requests"] == per_round * out["rounds"] * burst
