@@ -22,6 +22,7 @@ void put32(Frame& f, int32_t v) {
 void put64(Frame& f, int64_t v) {
   for (int s = 56; s >= 0; s -= 8) f.push_back((uint8_t)((uint64_t)v >> s));
 }
+int32_t jsub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); } /* Java int a - b */
 int32_t get32(const uint8_t* p) {
   return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]);
 }
@@ -502,6 +503,77 @@ size_t PaxosManager::nodeDown(int32_t nodeID) {
   }
   stats_.elections_started += started;
   return started;
+}
+
+size_t PaxosManager::poke() {
+  if (!engine_) return 0;
+  const int32_t n = opt_.maxGroups;
+  std::vector<uint8_t> pk((size_t)n), fl((size_t)n), st((size_t)n);
+  std::vector<int32_t> sl((size_t)n), bn((size_t)n), bc((size_t)n), md((size_t)n);
+  std::vector<uint32_t> heard((size_t)n);
+  if (!check(gpx_poke_scan(engine_, n, nullptr, pk.data(), sl.data(), bn.data(), bc.data(), md.data(), fl.data(),
+                           heard.data(), st.data()),
+             "gpx_poke_scan"))
+    return 0;
+  stats_.engine_calls++;
+  size_t resent = 0;
+  for (int32_t g = 0; g < n; g++) {
+    if (st[(size_t)g] != GPX_S_OK || pk[(size_t)g] == GPX_POKE_NONE) continue;
+    const Instance& in = pinstances_.at(rowName_[(size_t)g]);
+    if (pk[(size_t)g] == GPX_POKE_ACCEPT) {
+      /* reInitCommander: the same pvalue, the median as it is now; to the members not heard from */
+      auto a = accepted_.find(key(g, sl[(size_t)g]));
+      if (a == accepted_.end()) continue;
+      Frame req(a->second.frame.begin(), a->second.frame.end() - (long)kAcceptTail);
+      Frame acc = makeAcceptFrame(req, sl[(size_t)g], bn[(size_t)g], bc[(size_t)g], md[(size_t)g], myID_);
+      for (size_t j = 0; j < in.members.size(); j++)
+        if (in.members[j] != myID_ && !((heard[(size_t)g] >> j) & 1u)) messenger_->send(in.members[j], Frame(acc)), resent++;
+      stats_.accepts_resent++;
+    } else { /* GPX_POKE_PREPARE */
+      Frame f;
+      putHeader(f, kTypePrepare, 0, rowName_[(size_t)g]);
+      put32(f, bn[(size_t)g]), put32(f, bc[(size_t)g]), put32(f, sl[(size_t)g]);
+      for (size_t j = 0; j < in.members.size(); j++)
+        if (in.members[j] != myID_ && !((heard[(size_t)g] >> j) & 1u)) messenger_->send(in.members[j], Frame(f)), resent++;
+      stats_.prepares_resent++;
+    }
+  }
+  /* ... and the periodic decision sync (SyncMode.FORCE_SYNC on a poke, PISM:2341-2364): slots that
+   * are committed here without their value, or missing below a commit, are asked for again - from
+   * every other member, whoever still holds the decision answers */
+  std::vector<int32_t> live;
+  for (auto& kv : pinstances_) live.push_back(kv.second.gidx);
+  std::sort(live.begin(), live.end());
+  const int32_t m = (int32_t)live.size();
+  if (m > 0) {
+    std::vector<int32_t> first((size_t)m), maxc((size_t)m);
+    std::vector<uint64_t> missing((size_t)m);
+    std::vector<uint8_t> sync((size_t)m), gst((size_t)m);
+    if (check(gpx_gap_scan(engine_, m, live.data(), opt_.syncGapThreshold, GPX_SYNC_FORCE, 64, first.data(),
+                           maxc.data(), missing.data(), sync.data(), gst.data()),
+              "gpx_gap_scan")) {
+      stats_.engine_calls++;
+      for (int32_t i = 0; i < m; i++) {
+        /* something is committed at or beyond my next slot and I have not executed it: the missing
+         * slots below the newest commit, or - none missing - my next slot itself, whose commit may
+         * be a placeholder without a value (requestMissingDecisions, PISM:2292-2300) */
+        if (gst[(size_t)i] != GPX_S_OK || jsub32(maxc[(size_t)i], first[(size_t)i]) < 0) continue;
+        uint64_t mask = missing[(size_t)i];
+        if (!mask) mask = 1;
+        Frame f;
+        putHeader(f, kTypeSyncDecisions, 0, rowName_[(size_t)live[(size_t)i]]);
+        put32(f, myID_);
+        put32(f, __builtin_popcountll(mask));
+        for (int j = 0; j < 64; j++)
+          if ((mask >> j) & 1ull) put32(f, (int32_t)((uint32_t)first[(size_t)i] + (uint32_t)j));
+        const Instance& in = pinstances_.at(rowName_[(size_t)live[(size_t)i]]);
+        for (int32_t mem : in.members)
+          if (mem != myID_) messenger_->send(mem, Frame(f)), resent++;
+        stats_.sync_requests++;
+      }
+    }
+  }
+  return resent;
 }
 
 /* PISM.handlePrepare (PISM:900-1006): adopt a higher ballot, answer with the accepted pvalues */

@@ -78,6 +78,7 @@ struct Stats {
   uint64_t proposed = 0, forwarded = 0, accepts = 0, votes = 0, decisions = 0, commits = 0, executed = 0;
   uint64_t dropped_frames = 0, refused = 0, engine_calls = 0;
   uint64_t pauses = 0, unpauses = 0;
+  uint64_t accepts_resent = 0, prepares_resent = 0;
   uint64_t sync_requests = 0, sync_decisions_sent = 0, sync_decisions_applied = 0;
   uint64_t batched_requests = 0; /* requests that rode in another request's proposal */
   uint64_t elections_started = 0, elections_won = 0, elections_lost = 0, prepares = 0, carried_over = 0,
@@ -112,6 +113,11 @@ class PaxosManager {
    * brings it back (PaxosManager.getInstance -> unpause, PM:1816-1832), pausing idle groups first if
    * the table is full. */
   bool pause(const std::string& paxosID);
+  /* the retransmission timer firing (ACCEPT_TIMEOUT / PREPARE_TIMEOUT, PCS:715-739): re-multicasts
+   * the ACCEPT of every group's head-of-line proposal that is still waiting for a majority
+   * (pokeLocalCoordinator, PISM:2268-2279) and the PREPAREs of elections still running; returns the
+   * number of packets re-sent */
+  size_t poke();
   size_t pausedCount() const { return paused_.size(); }
   /* the failure detector's verdict (FailureDetection -> PaxosManager.isNodeUp == false): runs
    * checkRunForCoordinator over every instance (PISM:2090-2176) and multicasts the PREPAREs of the

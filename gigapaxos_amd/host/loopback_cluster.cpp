@@ -11,6 +11,8 @@
 // --drop-commits p: the network loses p of 1000 BATCHED_COMMIT frames; a replica that sees newer
 // commits while an older slot is undecided (gpx_gap_scan) asks the coordinator for the decisions it
 // missed (two extra loss-free rounds at the end let the tail catch up).
+// --drop-accepts p: p of 1000 ACCEPT and BATCHED_ACCEPT_REPLY frames are lost; whenever the cluster
+// goes quiet with proposals outstanding the retransmission timers fire (PaxosManager::poke).
 // --capacity c: the engines' group tables hold only c < groups rows: idle groups are paused (their
 // HotRestoreInfo kept by the manager) and come back when a packet or request names them.  The
 // table must hold the groups that are busy at the same time: use --active a (a < c) so that a
@@ -25,6 +27,8 @@
 #include <cinttypes>
 #include <cstdio>
 #include <cstdlib>
+#include <algorithm>
+#include <climits>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -72,11 +76,19 @@ class LoopbackMessenger : public gpx::Messenger {
  public:
   std::map<int32_t, gpx::PaxosManager*> nodes;
   uint64_t frames = 0, bytes = 0, lost = 0, rng = 88172645463325252ull;
-  int dropCommitsPermille = 0;
+  int dropCommitsPermille = 0, dropAcceptsPermille = 0;
   void send(int32_t nodeID, gpx::Frame&& f) override {
     auto it = nodes.find(nodeID);
     if (it == nodes.end()) return; /* a dead node: the frame is lost */
-    if (dropCommitsPermille > 0 && f.size() >= 8 && f[7] == GPX_WT_BATCHED_COMMIT && f[6] == 0) {
+    const int type = f.size() >= 8 && f[4] == 0 && f[5] == 0 && f[6] == 0 ? f[7] : -1;
+    if (dropAcceptsPermille > 0 && (type == GPX_WT_ACCEPT || type == GPX_WT_BATCHED_ACCEPT_REPLY)) {
+      rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17;
+      if ((int)(rng % 1000) < dropAcceptsPermille) {
+        lost++;
+        return;
+      }
+    }
+    if (dropCommitsPermille > 0 && type == GPX_WT_BATCHED_COMMIT) {
       rng ^= rng << 13, rng ^= rng >> 7, rng ^= rng << 17;
       if ((int)(rng % 1000) < dropCommitsPermille) {
         lost++;
@@ -102,7 +114,7 @@ int main(int argc, char** argv) {
   int nNodes = 3, G = 1000, R = 20, valueBytes = 64;
   uint64_t seed = 1;
   bool stopLast = false, entryAny = true;
-  int killRound = -1, killNode = 0, burst = 1, capacity = 0, active = 0, dropCommits = 0;
+  int killRound = -1, killNode = 0, burst = 1, capacity = 0, active = 0, dropCommits = 0, dropAccepts = 0;
   bool batching = true;
   for (int i = 1; i < argc; i++) {
     auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
@@ -119,6 +131,7 @@ int main(int argc, char** argv) {
     else if (is("--capacity") && i + 1 < argc) capacity = std::atoi(argv[++i]);
     else if (is("--active") && i + 1 < argc) active = std::atoi(argv[++i]);
     else if (is("--drop-commits") && i + 1 < argc) dropCommits = std::atoi(argv[++i]);
+    else if (is("--drop-accepts") && i + 1 < argc) dropAccepts = std::atoi(argv[++i]);
     else if (is("--entry") && i + 1 < argc) entryAny = std::strcmp(argv[++i], "any") == 0;
     else {
       std::fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -157,10 +170,15 @@ int main(int argc, char** argv) {
   }
   std::vector<bool> alive((size_t)nNodes, true);
   auto drain = [&]() { /* until no node has anything left to do */
-    for (;;) {
+    for (int fired = 0;;) {
       size_t work = 0;
       for (int i = 0; i < nNodes; i++)
         if (alive[(size_t)i]) work += pms[(size_t)i]->process();
+      if (work) continue;
+      /* quiet: the retransmission timers fire (only a lossy network leaves anything to re-send) */
+      if (dropAccepts > 0 && fired++ < 400)
+        for (int i = 0; i < nNodes; i++)
+          if (alive[(size_t)i]) work += pms[(size_t)i]->poke();
       if (work == 0) break;
     }
   };
@@ -169,6 +187,7 @@ int main(int argc, char** argv) {
   uint64_t sent = 0;
   std::string value((size_t)valueBytes, 'x');
   net.dropCommitsPermille = dropCommits;
+  net.dropAcceptsPermille = dropAccepts;
   for (int r = 0; r < R; r++) {
     if (dropCommits > 0 && r >= R - 2) net.dropCommitsPermille = 0; /* the tail catches up */
     const int nAct = active > 0 && active < G ? active : G;
@@ -225,6 +244,24 @@ int main(int argc, char** argv) {
     if (killRound < 0 ? ex != sent : ex + sentKillRound < sent) ok = false;
   }
   uint64_t digest[1] = {digest0};
+  if (!ok && std::getenv("GPX_CLUSTER_DEBUG")) { /* which groups disagree, and where each replica stands */
+    int shown = 0;
+    for (auto& name : names) {
+      int64_t lo = INT64_MAX, hi = -1;
+      for (int i = 0; i < nNodes; i++)
+        if (alive[(size_t)i]) {
+          const int64_t q = apps[(size_t)i]->state[name].seqnum;
+          lo = std::min(lo, q), hi = std::max(hi, q);
+        }
+      if (lo == hi || shown++ > 12) continue;
+      std::fprintf(stderr, "%s:", name.c_str());
+      for (int i = 0; i < nNodes; i++)
+        if (alive[(size_t)i])
+          std::fprintf(stderr, " node %d seq %lld slot %d |", ids[(size_t)i], (long long)apps[(size_t)i]->state[name].seqnum,
+                       apps[(size_t)i]->state[name].lastSlot);
+      std::fprintf(stderr, "\n");
+    }
+  }
   std::printf("{\"nodes\": %d, \"groups\": %d, \"rounds\": %d, \"requests\": %" PRIu64 ", \"executed_per_node\": %" PRIu64
               ", \"state_digest\": \"%016" PRIx64 "\", \"frames\": %" PRIu64 ", \"bytes\": %" PRIu64 ", \"frames_lost\": %" PRIu64 ", \"ok\": %s, \"per_node\": [",
               nNodes, G, R, sent, executed0, digest[0], net.frames, net.bytes, net.lost, ok ? "true" : "false");
@@ -235,12 +272,12 @@ int main(int argc, char** argv) {
                 ", \"refused\": %" PRIu64 ", \"dropped_frames\": %" PRIu64 ", \"engine_calls\": %" PRIu64
                 ", \"elections_started\": %" PRIu64 ", \"elections_won\": %" PRIu64 ", \"elections_lost\": %" PRIu64
                 ", \"prepares\": %" PRIu64 ", \"carried_over\": %" PRIu64 ", \"noops\": %" PRIu64 ", \"preactive\": %" PRIu64
-                ", \"sync_requests\": %" PRIu64 ", \"sync_decisions_sent\": %" PRIu64 ", \"sync_decisions_applied\": %" PRIu64 "}",
+                ", \"accepts_resent\": %" PRIu64 ", \"sync_requests\": %" PRIu64 ", \"sync_decisions_sent\": %" PRIu64 ", \"sync_decisions_applied\": %" PRIu64 "}",
                 i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.pauses, s.unpauses,
                 pms[(size_t)i]->pausedCount(), s.proposed, s.batched_requests, s.forwarded,
                 s.accepts, s.votes, s.decisions, s.commits, s.executed, s.refused, s.dropped_frames, s.engine_calls,
                 s.elections_started, s.elections_won, s.elections_lost, s.prepares, s.carried_over, s.noops,
-                s.preactive, s.sync_requests, s.sync_decisions_sent, s.sync_decisions_applied);
+                s.preactive, s.accepts_resent, s.sync_requests, s.sync_decisions_sent, s.sync_decisions_applied);
   }
   std::printf("]}\n");
   return ok ? 0 : 1;

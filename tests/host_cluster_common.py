@@ -34,6 +34,9 @@ CASES = [
     # a lossy network for BATCHED_COMMITs: gap detection (gpx_gap_scan) and decision sync
     ["--groups", "200", "--rounds", "12", "--drop-commits", "100"],
     ["--groups", "1000", "--rounds", "10", "--drop-commits", "250", "--nodes", "5", "--seed", "8"],
+    # lost ACCEPTs / accept replies: the retransmission timers (gpx_poke_scan) and the forced sync
+    ["--groups", "200", "--rounds", "10", "--drop-accepts", "150"],
+    ["--groups", "300", "--rounds", "8", "--drop-accepts", "100", "--drop-commits", "100", "--nodes", "5", "--seed", "2"],
 ]
 
 

@@ -24,3 +24,4 @@
 #define gpx_prepare_reply_batch orc_prepare_reply_batch
 #define gpx_request_batch orc_request_batch
 #define gpx_gap_scan orc_gap_scan
+#define gpx_poke_scan orc_poke_scan

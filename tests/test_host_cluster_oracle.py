@@ -28,6 +28,8 @@ def test_cluster_invariants(case):
         for n in out["per_node"]:
             assert n["pauses"] >= out["groups"] - cap and n["unpauses"] > 0
             assert n["paused_now"] >= out["groups"] - cap
+    if "--drop-accepts" in args:
+        assert out["frames_lost"] > 0 and sum(n["accepts_resent"] for n in out["per_node"]) > 0
     if "--drop-commits" in args:
         assert out["frames_lost"] > 0
         assert sum(n["sync_requests"] for n in out["per_node"]) > 0
