@@ -1,0 +1,77 @@
+#!/usr/bin/env python
+"""Soak: the differential fuzzes of the test suite with fresh seeds (HIP library vs oracle, bit for
+bit).  One-off robustness run on the GPU box; not part of the test suite.
+    python scripts/soak.py [--seeds 40] [--first 1000]
+Slot ranges stay inside the engine's window (the oracle's maps are unbounded: outside it the
+statuses differ by design, GPX_S_WINDOW).  Every seed runs under a 60 s alarm.
+Round-1 note: a first run (16 seeds, slot span wider than the window) finished with the expected
+status mismatches only; the second run (span inside the window) ended with the GPU box lost
+("transient" per gpurun) before any output came back - not reproduced since, the GPU budget of the
+round was spent; run it under `timeout` and look at the last "seed" line if it happens again."""
+import argparse
+import os
+import signal
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from gigapaxos_amd import load_hip  # noqa: E402
+from tests.oracle_binding import load_oracle  # noqa: E402
+from tests.parity_common import make_pair, create_mixed_groups, fuzz  # noqa: E402
+from tests.election_common import fuzz_run  # noqa: E402
+from tests.failover_common import failover_run  # noqa: E402
+
+NODES = [100, 101, 102, 103, 104, 105, 106, 107]
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seeds", type=int, default=40)
+    ap.add_argument("--first", type=int, default=1000)
+    args = ap.parse_args()
+    hip, orc = load_hip(), load_oracle()
+    t0 = time.time()
+    done = {"mixed": 0, "election": 0, "failover": 0}
+    for seed in range(args.first, args.first + args.seeds):
+        signal.alarm(60)
+        rng = np.random.default_rng(seed)
+        kmax = int(rng.choice([3, 5, 8, 16]))
+        W = int(rng.choice([8, 16, 64]))
+        G = int(rng.choice([17, 64, 300, 1500]))
+        nodes = NODES if kmax <= 8 else list(range(100, 120))
+        base = int(rng.choice([1, (1 << 31) - 20]))
+        batch = int(rng.choice([50, 400, 3000]))
+        print("seed", seed, "kmax", kmax, "W", W, "G", G, "base", base, "batch", batch, flush=True)
+        eh, eo = make_pair(hip, orc, 100, G, kmax, W)
+        create_mixed_groups(eh, eo, G, kmax, nodes, rng, slot_base=base)
+        try:
+            fuzz(eh, eo, G, nodes, rng, steps=120, batch=batch, slot_base=base, span=W - 3)  # inside the window: the oracle has none
+        except AssertionError as ex:
+            print("  MISMATCH", ex, flush=True)
+            done.setdefault("mismatch", 0)
+            done["mismatch"] += 1
+        eh.close(), eo.close()
+        done["mixed"] += 1
+        k = int(rng.choice([3, 5, 9]))
+        We = int(rng.choice([8, 16, 32]))
+        Ge = int(rng.choice([50, 300, 1200]))
+        s0 = int(rng.choice([0, 2 ** 31 - 40]))
+        a = fuzz_run(hip, seed, G=Ge, k=k, W=We, steps=50, slot0=s0)
+        b = fuzz_run(orc, seed, G=Ge, k=k, W=We, steps=50, slot0=s0)
+        assert a == b, ("election fuzz", seed)
+        done["election"] += 1
+        if seed % 4 == 0:
+            Gf = int(rng.choice([150, 900]))
+            fa = failover_run(hip, G=Gf, seed=seed, window=We)
+            fb = failover_run(orc, G=Gf, seed=seed, window=We)
+            assert fa == fb, ("failover", seed)
+            done["failover"] += 1
+    signal.alarm(0)
+    print("soak ok", done, "in %.1f s" % (time.time() - t0))
+
+
+if __name__ == "__main__":
+    main()
