@@ -320,7 +320,9 @@ __device__ __forceinline__ void elect_group(const DevState& S, const DevScratch&
                 for (int q = 0; q < KMAX; q++)
                   if (q < k && jsub(ns[q], maxMin) > 0) maxMin = ns[q];
                 const int32_t R = jsub(maxCarry, maxMin);
-                if (R >= W) {
+                /* R == INT32_MIN: exactly 2^31 apart (an unheard node's -1 against slot
+                 * Integer.MAX_VALUE): the reference's loop would run 2^31 times; refused */
+                if (R >= W || R == INT32_MIN) {
                   fits = false;
                 } else {
                   const int32_t pre_lo = jsub(next, pcount);

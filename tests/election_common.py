@@ -118,6 +118,25 @@ def small_scenarios(lib):
     return out
 
 
+def boundary_scenario(lib):
+    """Slot Integer.MAX_VALUE carried over while member 0 has not answered (its nodeSlotNumbers entry
+    is still -1): max(nodeSlotNumbers) under the wraparound compare is -1, exactly 2^31 below the
+    carried slot - the reference's `curSlot - maxCarryoverSlot <= 0` loop would run 2^31 times.  The
+    engine (and the oracle) refuse the view change with GPX_S_WINDOW instead."""
+    IMAX = 2 ** 31 - 1
+    members = np.tile(np.array([0, 1, 2], np.int32), (2, 1))
+    e = Engine(lib, 1, 2, kmax=3, window=8, max_batch=64)
+    assert (e.create_groups(np.arange(2), members, 3, plain_rows(2, IMAX, 0, 0, gc=IMAX - 1)) == S_OK).all()
+    out = [("begin", e.election_begin([0, 1], [1, 1]).tolist())]
+    # group 0: acceptors 1 and 2 answer (member 0 stays at -1); group 1: acceptors 0 and 1 (fine)
+    a = e.prepare_reply([0, 0, 1, 1], [1, 2, 0, 1], [1] * 4, [1] * 4, [IMAX] * 4,
+                        [[(IMAX, 0, 0, 7, 0)], [], [(IMAX, 0, 0, 8, 0)], []])
+    out.append(("replies", a[0][0].tolist(), a[0][1].tolist(), a[0][2].tolist(), a[1]))
+    out.append(("dumps", e.dump(0).tolist(), e.dump(1).tolist()))
+    e.close()
+    return out
+
+
 def w32(x):
     """Java int arithmetic: wrap to 32 bits."""
     return ((np.asarray(x, np.int64) + (1 << 31)) % (1 << 32) - (1 << 31)).astype(np.int32)

@@ -3,7 +3,8 @@ the PaxosCoordinatorState.main restatement, the hand-made cases, and random inte
 elections, pre-active proposals, prepare replies and accept replies."""
 import pytest
 
-from tests.election_common import pcs_main_scenario, small_scenarios, fuzz_run, V_ELECTED, V_PREEMPTED
+from tests.election_common import (pcs_main_scenario, small_scenarios, boundary_scenario, fuzz_run, V_ELECTED,
+                                   V_PREEMPTED)
 
 pytestmark = pytest.mark.gpu
 
@@ -20,6 +21,10 @@ def test_pcs_main_parity(hip_lib, oracle_lib):
 
 def test_small_scenarios_parity(hip_lib, oracle_lib):
     _same(small_scenarios(hip_lib), small_scenarios(oracle_lib))
+
+
+def test_half_range_boundary_parity(hip_lib, oracle_lib):
+    _same(boundary_scenario(hip_lib), boundary_scenario(oracle_lib))
 
 
 @pytest.mark.parametrize("seed,G,k,W,steps,slot0", [(1, 96, 3, 8, 60, 0), (2, 300, 5, 16, 60, 0), (3, 700, 3, 8, 80, 0),

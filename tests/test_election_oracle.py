@@ -6,7 +6,7 @@ The reference's only executable statement of this phase is PaxosCoordinatorState
 not hold for its own inputs - with assertions enabled processStop's `assert (false)` fires for the
 pre-active stop at slot 1 followed by carried requests in the same (re-stamped) ballot - so the
 expected proposal list below is what the code computes with assertions disabled (production)."""
-from tests.election_common import (pcs_main_scenario, small_scenarios, fuzz_run, S_PREACTIVE, S_WINDOW,
+from tests.election_common import (pcs_main_scenario, small_scenarios, boundary_scenario, fuzz_run, S_PREACTIVE, S_WINDOW,
                                    EB_PREPARING, EB_ACTIVE, EB_RESEND, EB_UNCHANGED, V_IGNORED, V_RECORDED,
                                    V_ELECTED, V_PREEMPTED, E_CARRY, E_NOOP, E_PREACTIVE, E_NEWSTOP, PV_STOP)
 from gigapaxos_amd import S_OK, S_REFUSED
@@ -95,3 +95,12 @@ def test_failover_end_to_end(oracle_lib):
     assert len(t["inflight"]) > 0
     kinds = {e[1] for lists in t["reply2"][2] for e in lists}
     assert {1, 2, 3} <= kinds  # carried over, no-op filled and pre-active entries all occur
+
+
+def test_half_range_boundary_is_refused(oracle_lib):
+    t = dict((x[0], x[1:]) for x in boundary_scenario(oracle_lib))
+    vk, em, st, lists = t["replies"]
+    # group 0: recorded twice, the majority reply cannot complete the view change (GPX_S_WINDOW);
+    # group 1 (member 0 answered): elected, slot Integer.MAX_VALUE carried over
+    assert vk == [V_RECORDED, V_RECORDED, V_RECORDED, V_ELECTED] and st == [S_OK, S_WINDOW, S_OK, S_OK]
+    assert lists[3] == [(2 ** 31 - 1, E_CARRY, 8, 0)]
