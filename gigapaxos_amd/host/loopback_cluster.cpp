@@ -115,7 +115,7 @@ int main(int argc, char** argv) {
   uint64_t seed = 1;
   bool stopLast = false, entryAny = true;
   int killRound = -1, killNode = 0, burst = 1, capacity = 0, active = 0, dropCommits = 0, dropAccepts = 0;
-  bool batching = true;
+  bool batching = true, dumpFrames = false;
   for (int i = 1; i < argc; i++) {
     auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
     if (is("--nodes") && i + 1 < argc) nNodes = std::atoi(argv[++i]);
@@ -128,6 +128,7 @@ int main(int argc, char** argv) {
     else if (is("--kill-node") && i + 1 < argc) killNode = std::atoi(argv[++i]);
     else if (is("--burst") && i + 1 < argc) burst = std::atoi(argv[++i]);
     else if (is("--no-batching")) batching = false;
+    else if (is("--dump-frames")) dumpFrames = true;
     else if (is("--capacity") && i + 1 < argc) capacity = std::atoi(argv[++i]);
     else if (is("--active") && i + 1 < argc) active = std::atoi(argv[++i]);
     else if (is("--drop-commits") && i + 1 < argc) dropCommits = std::atoi(argv[++i]);
@@ -137,6 +138,25 @@ int main(int argc, char** argv) {
       std::fprintf(stderr, "unknown argument %s\n", argv[i]);
       return 2;
     }
+  }
+  if (dumpFrames) { /* the byte builders, for comparison with an independent restatement of toBytes() */
+    auto hex = [](const gpx::Frame& f) {
+      std::string s;
+      char b[3];
+      for (uint8_t c : f) std::snprintf(b, sizeof(b), "%02x", c), s += b;
+      return s;
+    };
+    const gpx::Frame rq = gpx::makeRequestFrame("TESTPaxosApp7", 0, 0x1122334455667788ll, "hello-value", false, 101);
+    const gpx::Frame st = gpx::makeRequestFrame("g", 3, -5, "", true, 100);
+    const gpx::Frame ac = gpx::makeAcceptFrame(rq, 42, 2, 101, 40, 101);
+    const gpx::Frame bt = gpx::latchToBatch(rq, {&st, &rq});
+    std::vector<gpx::Request> rs;
+    gpx::parseRequests(bt, &rs);
+    std::printf("{\"request\": \"%s\", \"stop\": \"%s\", \"accept\": \"%s\", \"batched\": \"%s\", \"batch_size\": %d, "
+                "\"parsed\": %zu, \"coordinator\": %d, \"hash\": %d}\n",
+                hex(rq).c_str(), hex(st).c_str(), hex(ac).c_str(), hex(bt).c_str(), gpx::batchSizeOf(bt), rs.size(),
+                gpx::roundRobinCoordinator("TESTPaxosApp7", {100, 101, 102}, 0), gpx::javaStringHash("hello"));
+    return 0;
   }
   std::vector<int32_t> ids;
   for (int i = 0; i < nNodes; i++) ids.push_back(100 + i);

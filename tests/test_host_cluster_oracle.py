@@ -69,3 +69,32 @@ def test_cluster_under_sanitizers(tmp_path):
         p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-600:]
         assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-600:]
+
+
+def test_cpp_frame_builders_match_the_python_restatement():
+    """gpx::makeRequestFrame / makeAcceptFrame / latchToBatch against gigapaxos_amd.wire's builders of
+    RequestPacket.toBytes / AcceptPacket.toBytes (written independently), String.hashCode and
+    roundRobinCoordinator against the oracle's."""
+    import json
+    import subprocess
+
+    from gigapaxos_amd import wire as W
+    from tests.oracle_binding import load_oracle
+
+    out = json.loads(subprocess.run([build_oracle_cluster(), "--dump-frames"], capture_output=True, text=True,
+                                    check=True).stdout)
+    rq = W.request(b"TESTPaxosApp7", 0, 0x1122334455667788, b"hello-value", entry_replica=101)
+    st = W.request(b"g", 3, -5, b"", stop=True, entry_replica=100)
+    assert out["request"] == rq.hex() and out["stop"] == st.hex()
+    import struct
+    acc = W.request(b"TESTPaxosApp7", 0, 0x1122334455667788, b"hello-value", entry_replica=101, ptype=W.WT_ACCEPT)
+    acc += struct.pack(">iiibibi", 42, 2, 101, 0, 40, 0, 101)  # AcceptPacket.toBytes's tail
+    assert out["accept"] == acc.hex()
+    assert out["batched"] == W.request(b"TESTPaxosApp7", 0, 0x1122334455667788, b"hello-value", entry_replica=101,
+                                       batched=[st, rq]).hex()
+    assert out["batch_size"] == 2 and out["parsed"] == 3
+    assert out["hash"] == 99162322  # "hello".hashCode()
+    import numpy as np
+    import ctypes as C
+    mem = np.array([100, 101, 102], np.int32)
+    assert out["coordinator"] == load_oracle().lib.orc_round_robin_coordinator(b"TESTPaxosApp7", mem.ctypes.data_as(C.c_void_p), 3, 0)
