@@ -315,8 +315,8 @@ int gpx_prepare_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const i
  * PaxosCoordinator.java:66-89) for the groups gpx_election_scan selected: a coordinator with a
  * lower ballot (or none) is replaced by a fresh PaxosCoordinatorState(bnum, myID, acceptor slot,
  * members, null) - nextProposalSlot = the acceptor's slot, nodeSlotNumbers = -1, no proposals -
- * whose prepare() arms waitforMyBallot.  gidx must be pairwise distinct.  e_status: GPX_EB_* (255 for
- * a missing group).  Host pointers.
+ * whose prepare() arms waitforMyBallot.  gidx must be pairwise distinct (GPX_EINVAL otherwise; the
+ * _dev twin cannot check and requires it).  e_status: GPX_EB_* (255 for a missing group).  Host pointers.
  */
 int gpx_election_begin(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
                        uint8_t* e_status);

@@ -114,6 +114,12 @@ def small_scenarios(lib):
     out.append(("window6", a[0][0].tolist(), a[0][1].tolist(), a[0][2].tolist(), a[1]))
     out.append(("dump6", e.dump(6).tolist()))
     out.append(("counters", [int(x) for x in e.counters()]))
+    # two records of one group in gpx_election_begin: refused whole
+    try:
+        e.election_begin([7, 7], [3, 4])
+        out.append(("dup", "accepted"))
+    except Exception as ex:  # GpxError rc = GPX_EINVAL
+        out.append(("dup", "rc=-1" in str(ex)))
     e.close()
     return out
 

@@ -72,6 +72,7 @@ def test_small_scenarios(oracle_lib):
     vk, em, st, lists = t["elected5"]
     assert vk == [V_RECORDED, V_ELECTED]
     assert lists[1] == [(5, E_CARRY, 51, PV_STOP), (6, E_CARRY, 52, 0), (7, E_NEWSTOP, 0, PV_STOP)]
+    assert t["dup"][0] is True
     vk, em, st, lists = t["window6"]
     # reply 0: slots 5 and 13 collide in a ring of 8 -> dropped whole; reply 2 is recorded and makes a
     # majority, but slots 5..14 do not fit 8 entries -> recorded, not elected
