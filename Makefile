@@ -15,7 +15,7 @@ $(LIB): $(wildcard $(CSRC)/*.hip $(CSRC)/*.h $(CSRC)/*.inc) include/gpx.h includ
 	cd $(CSRC) && $(HIPCC) --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -Wno-unused-result -o libgpx_hip.so gpx_engine.hip
 
 $(CLUSTER): $(HOST)/gpx_host.cpp $(HOST)/loopback_cluster.cpp $(HOST)/gpx_host.hpp $(LIB)
-	$(CXX) -O2 -std=c++17 -Wall -Wextra -Iinclude -o $@ $(HOST)/gpx_host.cpp $(HOST)/loopback_cluster.cpp \
+	$(CXX) -O2 -std=c++17 -pthread -Wall -Wextra -Iinclude -o $@ $(HOST)/gpx_host.cpp $(HOST)/loopback_cluster.cpp \
 	    -L$(CSRC) -lgpx_hip '-Wl,-rpath,$$ORIGIN/../csrc' -Wl,-rpath-link,/opt/rocm/lib
 
 oracle:

@@ -2,9 +2,17 @@
 // include/gpx_wire.h); this file moves frames, keeps request values and performs the upcalls.
 #include "gpx_host.hpp"
 
+#include <fcntl.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <thread>
 
 namespace gpx {
 
@@ -65,6 +73,84 @@ Frame makeSingleAcceptReply(const std::string& paxosID, int32_t version, int32_t
 }
 
 }  // namespace
+
+/* ---- loggers -------------------------------------------------------------------------------- */
+
+uint64_t DelayLogger::logBatch(const std::vector<const Frame*>& recs) {
+  for (const Frame* f : recs) records++, bytes += f->size();
+  pending_.push_back({next_, polls_});
+  return next_++;
+}
+uint64_t DelayLogger::durable() {
+  polls_++;
+  while (!pending_.empty() && polls_ - pending_.front().second > (uint64_t)delay_) {
+    durable_ = pending_.front().first;
+    pending_.pop_front();
+  }
+  return durable_;
+}
+
+struct FileLogger::Impl {
+  int fd = -1;
+  std::mutex mu;
+  std::condition_variable cv;
+  std::deque<std::pair<uint64_t, std::vector<uint8_t>>> queue; /* (ticket, the batch's bytes) */
+  std::atomic<uint64_t> durable{0};
+  uint64_t next = 1;
+  bool stop = false;
+  std::thread worker;
+  void run() {
+    for (;;) {
+      std::pair<uint64_t, std::vector<uint8_t>> job;
+      {
+        std::unique_lock<std::mutex> lk(mu);
+        cv.wait(lk, [&] { return stop || !queue.empty(); });
+        if (queue.empty()) return;
+        job = std::move(queue.front());
+        queue.pop_front();
+      }
+      size_t off = 0;
+      while (fd >= 0 && off < job.second.size()) {
+        const ssize_t w = ::write(fd, job.second.data() + off, job.second.size() - off);
+        if (w <= 0) break;
+        off += (size_t)w;
+      }
+      if (fd >= 0) ::fdatasync(fd);
+      durable.store(job.first, std::memory_order_release);
+    }
+  }
+};
+FileLogger::FileLogger(const std::string& path) : impl_(new Impl) {
+  impl_->fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+  impl_->worker = std::thread([this] { impl_->run(); });
+}
+FileLogger::~FileLogger() {
+  {
+    std::lock_guard<std::mutex> lk(impl_->mu);
+    impl_->stop = true;
+  }
+  impl_->cv.notify_all();
+  impl_->worker.join();
+  if (impl_->fd >= 0) ::close(impl_->fd);
+  delete impl_;
+}
+uint64_t FileLogger::logBatch(const std::vector<const Frame*>& recs) {
+  std::vector<uint8_t> bytes;
+  for (const Frame* f : recs) { /* length-prefixed records, one write + one fdatasync per batch */
+    const uint32_t n = (uint32_t)f->size();
+    for (int sft = 24; sft >= 0; sft -= 8) bytes.push_back((uint8_t)(n >> sft));
+    bytes.insert(bytes.end(), f->begin(), f->end());
+  }
+  uint64_t t;
+  {
+    std::lock_guard<std::mutex> lk(impl_->mu);
+    t = impl_->next++;
+    impl_->queue.emplace_back(t, std::move(bytes));
+  }
+  impl_->cv.notify_one();
+  return t;
+}
+uint64_t FileLogger::durable() { return impl_->durable.load(std::memory_order_acquire); }
 
 int32_t javaStringHash(const std::string& s) {
   uint32_t h = 0;
@@ -1069,12 +1155,29 @@ size_t PaxosManager::processRun() {
                "gpx_wire_pack_accept_replies"))
       return 0;
     stats_.engine_calls++;
+    /* the ACCEPTs that must be logged before their replies leave (toLog, PISM:1146-1149): one log
+     * batch; the replies of this call wait for it while the engine goes on with the next batches */
+    uint64_t ticket = 0;
+    if (opt_.logger) {
+      std::vector<const Frame*> tolog;
+      for (int32_t i = 0; i < nAll; i++)
+        if (st[(size_t)i] == GPX_S_OK && (rf[(size_t)i] & GPX_R_TOLOG)) tolog.push_back(src[(size_t)i]);
+      if (!tolog.empty()) {
+        ticket = opt_.logger->logBatch(tolog);
+        stats_.logged_accepts += (uint64_t)tolog.size();
+        stats_.log_batches++;
+      }
+    }
     for (int32_t f = 0; f < nf; f++) {
       Frame fr(out.begin() + fo[(size_t)f], out.begin() + fo[(size_t)f] + flen[(size_t)f]);
-      if (fd[(size_t)f] == myID_)
+      if (ticket) {
+        held_.push_back(Held{ticket, fd[(size_t)f], std::move(fr)});
+        stats_.held_replies++;
+      } else if (fd[(size_t)f] == myID_) {
         inbox_.push_back(std::move(fr));
-      else
+      } else {
         messenger_->send(fd[(size_t)f], std::move(fr));
+      }
     }
     for (int32_t i = 0; i < nAll; i++)
       if (unb[(size_t)i]) { /* e.g. a reply in a higher ballot than the sender's: back to the sender */
@@ -1163,8 +1266,29 @@ size_t PaxosManager::processRun() {
   return consumed;
 }
 
+size_t PaxosManager::releaseHeld() {
+  if (held_.empty()) return 0;
+  const uint64_t d = opt_.logger->durable();
+  size_t n = 0;
+  while (!held_.empty() && held_.front().ticket <= d) { /* log-batch order */
+    Held h = std::move(held_.front());
+    held_.pop_front();
+    if (h.dest == myID_)
+      inbox_.push_back(std::move(h.frame));
+    else
+      messenger_->send(h.dest, std::move(h.frame));
+    n++;
+  }
+  return n;
+}
+
 size_t PaxosManager::process() {
-  size_t consumed = processRun();
+  const size_t released = releaseHeld();
+  size_t consumed = processRun() + released;
+  if (consumed == 0 && !held_.empty()) { /* only the log write is outstanding: wait for it a little */
+    std::this_thread::sleep_for(std::chrono::microseconds(50));
+    consumed = 1;
+  }
   /* frames that found their group paused: bring the groups back (getInstance -> unpause), pausing
    * idle ones if the table is full, and queue the frames again.  A frame whose group cannot come
    * back yet (every row holds a group with work in flight) waits for a later pass. */

@@ -57,6 +57,45 @@ class Messenger {
   virtual void send(int32_t nodeID, Frame&& frame) = 0;
 };
 
+/* AbstractPaxosLogger's batched logging as the accept path sees it (AbstractPaxosLogger.java:656-716):
+ * the ACCEPTs of a batch that must be durable before their replies leave (GPX_R_TOLOG, PISM:1146-1149)
+ * are handed over in one piece; the replies of that batch are released when the batch is durable.
+ * The engine never waits: the next batches are processed while the log write is in flight. */
+class Logger {
+ public:
+  virtual ~Logger() = default;
+  virtual uint64_t logBatch(const std::vector<const Frame*>& records) = 0; /* returns the batch's ticket (> 0) */
+  virtual uint64_t durable() = 0;                                          /* highest ticket that is durable */
+};
+
+/* a log whose batches become durable a fixed number of polls later (deterministic: tests) */
+class DelayLogger : public Logger {
+ public:
+  explicit DelayLogger(int polls) : delay_(polls) {}
+  uint64_t logBatch(const std::vector<const Frame*>& records) override;
+  uint64_t durable() override;
+  uint64_t records = 0, bytes = 0;
+
+ private:
+  int delay_;
+  uint64_t next_ = 1, polls_ = 0;
+  std::deque<std::pair<uint64_t, uint64_t>> pending_; /* (ticket, poll it was logged at) */
+  uint64_t durable_ = 0;
+};
+
+/* an append-only file written and fdatasync'ed by its own thread */
+class FileLogger : public Logger {
+ public:
+  explicit FileLogger(const std::string& path);
+  ~FileLogger() override;
+  uint64_t logBatch(const std::vector<const Frame*>& records) override;
+  uint64_t durable() override;
+
+ private:
+  struct Impl;
+  Impl* impl_;
+};
+
 struct Options {
   int32_t maxGroups = 1 << 16; /* PC.PINSTANCES_CAPACITY */
   int32_t kmax = 3;            /* largest replica group */
@@ -69,6 +108,7 @@ struct Options {
    * of its next undecided slot asks the commit's coordinator for the missing decisions */
   int32_t syncGapThreshold = 2;
   int32_t decisionLogSlots = 64; /* executed decisions kept per group to answer such requests */
+  Logger* logger = nullptr; /* nullptr = logging off (DISABLE_LOGGING): replies leave at once */
   bool batchRequests = true;
   int32_t maxBatchSize = 2000;
   int32_t maxBatchBytes = 1 << 20;
@@ -79,6 +119,7 @@ struct Stats {
   uint64_t dropped_frames = 0, refused = 0, engine_calls = 0;
   uint64_t pauses = 0, unpauses = 0;
   uint64_t accepts_resent = 0, prepares_resent = 0;
+  uint64_t logged_accepts = 0, log_batches = 0, held_replies = 0;
   uint64_t sync_requests = 0, sync_decisions_sent = 0, sync_decisions_applied = 0;
   uint64_t batched_requests = 0; /* requests that rode in another request's proposal */
   uint64_t elections_started = 0, elections_won = 0, elections_lost = 0, prepares = 0, carried_over = 0,
@@ -187,6 +228,13 @@ class PaxosManager {
    * pvalues the PREPARE replies carried */
   std::map<std::pair<int32_t, int64_t>, Frame> preactive_, carried_;
   std::vector<int32_t> downNodes_;
+  struct Held { /* a reply waiting for its batch's log write */
+    uint64_t ticket;
+    int32_t dest;
+    Frame frame;
+  };
+  std::deque<Held> held_;
+  size_t releaseHeld();
   /* what the logger's getLoggedDecisions would return: the last decisions executed here */
   std::unordered_map<uint64_t, StoredAccept> decided_;
   std::unordered_map<uint64_t, uint64_t> syncAsked_; /* (gidx, slot) -> the pass a sync was last requested in */

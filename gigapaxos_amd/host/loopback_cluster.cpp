@@ -13,6 +13,9 @@
 // missed (two extra loss-free rounds at the end let the tail catch up).
 // --drop-accepts p: p of 1000 ACCEPT and BATCHED_ACCEPT_REPLY frames are lost; whenever the cluster
 // goes quiet with proposals outstanding the retransmission timers fire (PaxosManager::poke).
+// --log-delay n / --log-file prefix: logging on - the ACCEPTs that must be durable before their replies
+// leave go to a logger (durable n polls later / an fdatasync'ed file per node written by its own
+// thread); the replies of a batch wait for its log write, later batches are processed meanwhile.
 // --capacity c: the engines' group tables hold only c < groups rows: idle groups are paused (their
 // HotRestoreInfo kept by the manager) and come back when a packet or request names them.  The
 // table must hold the groups that are busy at the same time: use --active a (a < c) so that a
@@ -115,6 +118,8 @@ int main(int argc, char** argv) {
   uint64_t seed = 1;
   bool stopLast = false, entryAny = true;
   int killRound = -1, killNode = 0, burst = 1, capacity = 0, active = 0, dropCommits = 0, dropAccepts = 0;
+  int logDelay = -1;
+  std::string logFile;
   bool batching = true, dumpFrames = false;
   for (int i = 1; i < argc; i++) {
     auto is = [&](const char* f) { return std::strcmp(argv[i], f) == 0; };
@@ -133,6 +138,8 @@ int main(int argc, char** argv) {
     else if (is("--active") && i + 1 < argc) active = std::atoi(argv[++i]);
     else if (is("--drop-commits") && i + 1 < argc) dropCommits = std::atoi(argv[++i]);
     else if (is("--drop-accepts") && i + 1 < argc) dropAccepts = std::atoi(argv[++i]);
+    else if (is("--log-delay") && i + 1 < argc) logDelay = std::atoi(argv[++i]);
+    else if (is("--log-file") && i + 1 < argc) logFile = argv[++i];
     else if (is("--entry") && i + 1 < argc) entryAny = std::strcmp(argv[++i], "any") == 0;
     else {
       std::fprintf(stderr, "unknown argument %s\n", argv[i]);
@@ -168,8 +175,15 @@ int main(int argc, char** argv) {
   opt.kmax = nNodes < 3 ? 3 : nNodes;
   opt.maxBatch = std::max(1 << 16, 8 * G * burst);
   opt.batchRequests = batching;
+  std::vector<std::unique_ptr<gpx::Logger>> loggers;
   for (int i = 0; i < nNodes; i++) {
     apps.emplace_back(new HashChainApp());
+    opt.logger = nullptr;
+    if (!logFile.empty())
+      loggers.emplace_back(new gpx::FileLogger(logFile + "." + std::to_string(ids[(size_t)i])));
+    else if (logDelay >= 0)
+      loggers.emplace_back(new gpx::DelayLogger(logDelay));
+    if (!logFile.empty() || logDelay >= 0) opt.logger = loggers.back().get();
     pms.emplace_back(new gpx::PaxosManager(ids[(size_t)i], apps.back().get(), &net, opt));
     net.nodes[ids[(size_t)i]] = pms.back().get();
   }
@@ -292,12 +306,13 @@ int main(int argc, char** argv) {
                 ", \"refused\": %" PRIu64 ", \"dropped_frames\": %" PRIu64 ", \"engine_calls\": %" PRIu64
                 ", \"elections_started\": %" PRIu64 ", \"elections_won\": %" PRIu64 ", \"elections_lost\": %" PRIu64
                 ", \"prepares\": %" PRIu64 ", \"carried_over\": %" PRIu64 ", \"noops\": %" PRIu64 ", \"preactive\": %" PRIu64
+                ", \"logged_accepts\": %" PRIu64 ", \"log_batches\": %" PRIu64 ", \"held_replies\": %" PRIu64
                 ", \"accepts_resent\": %" PRIu64 ", \"sync_requests\": %" PRIu64 ", \"sync_decisions_sent\": %" PRIu64 ", \"sync_decisions_applied\": %" PRIu64 "}",
                 i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.pauses, s.unpauses,
                 pms[(size_t)i]->pausedCount(), s.proposed, s.batched_requests, s.forwarded,
                 s.accepts, s.votes, s.decisions, s.commits, s.executed, s.refused, s.dropped_frames, s.engine_calls,
                 s.elections_started, s.elections_won, s.elections_lost, s.prepares, s.carried_over, s.noops,
-                s.preactive, s.accepts_resent, s.sync_requests, s.sync_decisions_sent, s.sync_decisions_applied);
+                s.preactive, s.logged_accepts, s.log_batches, s.held_replies, s.accepts_resent, s.sync_requests, s.sync_decisions_sent, s.sync_decisions_applied);
   }
   std::printf("]}\n");
   return ok ? 0 : 1;

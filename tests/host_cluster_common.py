@@ -37,6 +37,9 @@ CASES = [
     # lost ACCEPTs / accept replies: the retransmission timers (gpx_poke_scan) and the forced sync
     ["--groups", "200", "--rounds", "10", "--drop-accepts", "150"],
     ["--groups", "300", "--rounds", "8", "--drop-accepts", "100", "--drop-commits", "100", "--nodes", "5", "--seed", "2"],
+    # logging on: accept replies wait for their batch's log write (durable three polls later)
+    ["--groups", "200", "--rounds", "6", "--log-delay", "3"],
+    ["--groups", "150", "--rounds", "6", "--log-delay", "5", "--kill-round", "3", "--burst", "2", "--seed", "12"],
 ]
 
 
@@ -52,7 +55,7 @@ def build_oracle_cluster():
     deps = srcs + [os.path.join(HOST, "gpx_host.hpp"), os.path.join(ROOT, "tests", "host_oracle_prefix.h"),
                    os.path.join(ROOT, "oracle", "libgpx_oracle.so")]
     if not os.path.exists(ORC_BIN) or os.path.getmtime(ORC_BIN) < max(os.path.getmtime(d) for d in deps):
-        subprocess.check_call(["g++", "-O2", "-std=c++17", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
                                "-include", os.path.join(ROOT, "tests", "host_oracle_prefix.h"), "-o", ORC_BIN]
                               + srcs + ["-L", os.path.join(ROOT, "oracle"), "-lgpx_oracle", "-Wl,-rpath,$ORIGIN"])
     return ORC_BIN

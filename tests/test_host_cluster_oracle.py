@@ -28,6 +28,10 @@ def test_cluster_invariants(case):
         for n in out["per_node"]:
             assert n["pauses"] >= out["groups"] - cap and n["unpauses"] > 0
             assert n["paused_now"] >= out["groups"] - cap
+    if "--log-delay" in args:
+        for n in out["per_node"]:
+            if n["alive"]:
+                assert n["logged_accepts"] > 0 and n["held_replies"] > 0 and n["log_batches"] > 0
     if "--drop-accepts" in args:
         assert out["frames_lost"] > 0 and sum(n["accepts_resent"] for n in out["per_node"]) > 0
     if "--drop-commits" in args:
@@ -59,13 +63,14 @@ def test_cluster_under_sanitizers(tmp_path):
     from tests.host_cluster_common import HOST, ROOT
 
     exe = str(tmp_path / "cluster_san")
-    subprocess.check_call(["g++", "-O0", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17",
+    subprocess.check_call(["g++", "-O0", "-pthread", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-std=c++17",
                            "-I", os.path.join(ROOT, "include"), "-include",
                            os.path.join(ROOT, "tests", "host_oracle_prefix.h"), "-o", exe,
                            os.path.join(HOST, "gpx_host.cpp"), os.path.join(HOST, "loopback_cluster.cpp"),
                            os.path.join(ROOT, "oracle", "gpx_oracle.cpp")])
     for args in (["--groups", "300", "--rounds", "8", "--kill-round", "3"],
-                 ["--groups", "50", "--rounds", "3", "--burst", "20", "--nodes", "5"]):
+                 ["--groups", "50", "--rounds", "3", "--burst", "20", "--nodes", "5"],
+                 ["--groups", "100", "--rounds", "4", "--log-file", str(tmp_path / "log")]):
         p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=300)
         assert p.returncode == 0, p.stderr[-600:]
         assert "runtime error" not in p.stderr and "AddressSanitizer" not in p.stderr, p.stderr[-600:]
@@ -98,3 +103,25 @@ def test_cpp_frame_builders_match_the_python_restatement():
     import ctypes as C
     mem = np.array([100, 101, 102], np.int32)
     assert out["coordinator"] == load_oracle().lib.orc_round_robin_coordinator(b"TESTPaxosApp7", mem.ctypes.data_as(C.c_void_p), 3, 0)
+
+
+def test_file_logger_same_outcome_and_durable_log(tmp_path):
+    """Logging to fdatasync'ed files written by their own threads: the replicas end in the same state
+    as with logging off (only the timing of replies changes), and every node's log holds the ACCEPTs
+    it had to make durable, length-prefixed."""
+    import struct
+
+    exe = build_oracle_cluster()
+    base = ["--groups", "120", "--rounds", "5", "--seed", "4"]
+    plain = run_cluster(exe, base)
+    logged = run_cluster(exe, base + ["--log-file", str(tmp_path / "wal")])
+    assert logged["ok"] is True and logged["state_digest"] == plain["state_digest"]
+    for n in logged["per_node"]:
+        data = (tmp_path / ("wal.%d" % n["id"])).read_bytes()
+        cnt, p = 0, 0
+        while p < len(data):
+            (ln,) = struct.unpack_from(">I", data, p)
+            assert data[p + 4:p + 12] == struct.pack(">ii", 90, 3)  # a PAXOS_PACKET of type ACCEPT
+            p += 4 + ln
+            cnt += 1
+        assert p == len(data) and cnt == n["logged_accepts"] == n["accepts"]
