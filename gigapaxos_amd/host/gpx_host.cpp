@@ -487,7 +487,8 @@ bool PaxosManager::unpause(const std::string& paxosID) {
   return true;
 }
 
-int64_t PaxosManager::propose(const std::string& paxosID, const std::string& value, bool stop) {
+int64_t PaxosManager::propose(const std::string& paxosID, const std::string& value, bool stop,
+                              ExecutedCallback callback) {
   auto it = pinstances_.find(paxosID);
   int32_t version = 0;
   if (it != pinstances_.end()) {
@@ -499,6 +500,7 @@ int64_t PaxosManager::propose(const std::string& paxosID, const std::string& val
   }
   const int64_t id = nextRequestID_++;
   requests_.push_back(makeRequestFrame(paxosID, version, id, value, stop, myID_));
+  if (callback) callbacks_[id] = std::move(callback);
   return id;
 }
 
@@ -532,6 +534,19 @@ void PaxosManager::executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* 
           for (int tries = 0; tries < 3 && !app_->execute(req, req.entryReplica != myID_); tries++) {
           }
           stats_.executed++;
+          if (req.entryReplica == myID_) { /* PaxosManager.executed: the entry replica answers its client */
+            auto cb = callbacks_.find(req.requestID);
+            if (cb != callbacks_.end()) {
+              cb->second(req);
+              callbacks_.erase(cb);
+              stats_.callbacks++;
+            }
+          }
+          /* consistentCheckpoint every CHECKPOINT_INTERVAL slots and on a stop (PISM:1711-1723, 2037-2041) */
+          if (&req == &reqs.back() && (req.stop || (opt_.checkpointInterval > 0 && slot % opt_.checkpointInterval == 0))) {
+            (void)app_->checkpoint(req.paxosID);
+            stats_.checkpoints++;
+          }
         }
       /* the decision stays available to replicas that missed its commit (the logger's job in the
        * reference), a bounded number of slots back */

@@ -17,6 +17,7 @@
 
 #include <cstdint>
 #include <deque>
+#include <functional>
 #include <map>
 #include <string>
 #include <unordered_map>
@@ -96,6 +97,10 @@ class FileLogger : public Logger {
   Impl* impl_;
 };
 
+/* PaxosManager.propose's callback (ExecutedCallback): runs at the entry replica once the request has
+ * been executed there */
+using ExecutedCallback = std::function<void(const Request&)>;
+
 struct Options {
   int32_t maxGroups = 1 << 16; /* PC.PINSTANCES_CAPACITY */
   int32_t kmax = 3;            /* largest replica group */
@@ -106,6 +111,7 @@ struct Options {
    * become ONE proposal, up to these limits (PC.MAX_BATCH_SIZE; min(NIO payload, log message size)) */
   /* PISM.syncLongDecisionGaps (PISM:1550-1570): a group whose newest commit is this many slots ahead
    * of its next undecided slot asks the commit's coordinator for the missing decisions */
+  int32_t checkpointInterval = 400; /* PC.CHECKPOINT_INTERVAL: app.checkpoint(name) every so many slots */
   int32_t syncGapThreshold = 2;
   int32_t decisionLogSlots = 64; /* executed decisions kept per group to answer such requests */
   Logger* logger = nullptr; /* nullptr = logging off (DISABLE_LOGGING): replies leave at once */
@@ -117,7 +123,7 @@ struct Options {
 struct Stats {
   uint64_t proposed = 0, forwarded = 0, accepts = 0, votes = 0, decisions = 0, commits = 0, executed = 0;
   uint64_t dropped_frames = 0, refused = 0, engine_calls = 0;
-  uint64_t pauses = 0, unpauses = 0;
+  uint64_t pauses = 0, unpauses = 0, checkpoints = 0, callbacks = 0;
   uint64_t accepts_resent = 0, prepares_resent = 0;
   uint64_t logged_accepts = 0, log_batches = 0, held_replies = 0;
   uint64_t sync_requests = 0, sync_decisions_sent = 0, sync_decisions_applied = 0;
@@ -142,7 +148,8 @@ class PaxosManager {
   int createPaxosInstances(const std::vector<std::string>& paxosIDs, const std::vector<int32_t>& members);
   /* PaxosManager.propose(paxosID, requestValue, callback) (PM:1206-1260): this node is the entry
    * replica; returns the request id, 0 if there is no such instance here */
-  int64_t propose(const std::string& paxosID, const std::string& requestValue, bool stop = false);
+  int64_t propose(const std::string& paxosID, const std::string& requestValue, bool stop = false,
+                  ExecutedCallback callback = nullptr);
   /* a byteified packet from the network (PaxosManager.handleIncomingPacket -> handlePaxosPacket) */
   void handleIncomingPacket(const uint8_t* frame, size_t len);
   void handleIncomingPacket(Frame&& frame);
@@ -228,6 +235,7 @@ class PaxosManager {
    * pvalues the PREPARE replies carried */
   std::map<std::pair<int32_t, int64_t>, Frame> preactive_, carried_;
   std::vector<int32_t> downNodes_;
+  std::unordered_map<int64_t, ExecutedCallback> callbacks_; /* my clients' requests, by request id */
   struct Held { /* a reply waiting for its batch's log write */
     uint64_t ticket;
     int32_t dest;

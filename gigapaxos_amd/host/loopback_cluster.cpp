@@ -175,6 +175,7 @@ int main(int argc, char** argv) {
   opt.kmax = nNodes < 3 ? 3 : nNodes;
   opt.maxBatch = std::max(1 << 16, 8 * G * burst);
   opt.batchRequests = batching;
+  opt.checkpointInterval = 4; /* small, so that short runs checkpoint too */
   std::vector<std::unique_ptr<gpx::Logger>> loggers;
   for (int i = 0; i < nNodes; i++) {
     apps.emplace_back(new HashChainApp());
@@ -216,7 +217,7 @@ int main(int argc, char** argv) {
       if (work == 0) break;
     }
   };
-  uint64_t sentKillRound = 0;
+  uint64_t sentKillRound = 0, acked = 0; /* acked: requests whose entry replica executed them */
   uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 1;
   uint64_t sent = 0;
   std::string value((size_t)valueBytes, 'x');
@@ -237,7 +238,7 @@ int main(int argc, char** argv) {
           if (ids[i] == c && alive[i]) entry = i;
       }
       const bool stop = stopLast && r == R - 1;
-      if (pms[entry]->propose(names[(size_t)g], value, stop)) {
+      if (pms[entry]->propose(names[(size_t)g], value, stop, [&acked](const gpx::Request&) { acked++; })) {
         sent++;
         if (r == killRound) sentKillRound++;
       }
@@ -297,18 +298,18 @@ int main(int argc, char** argv) {
     }
   }
   std::printf("{\"nodes\": %d, \"groups\": %d, \"rounds\": %d, \"requests\": %" PRIu64 ", \"executed_per_node\": %" PRIu64
-              ", \"state_digest\": \"%016" PRIx64 "\", \"frames\": %" PRIu64 ", \"bytes\": %" PRIu64 ", \"frames_lost\": %" PRIu64 ", \"ok\": %s, \"per_node\": [",
-              nNodes, G, R, sent, executed0, digest[0], net.frames, net.bytes, net.lost, ok ? "true" : "false");
+              ", \"state_digest\": \"%016" PRIx64 "\", \"frames\": %" PRIu64 ", \"bytes\": %" PRIu64 ", \"frames_lost\": %" PRIu64 ", \"client_acks\": %" PRIu64 ", \"ok\": %s, \"per_node\": [",
+              nNodes, G, R, sent, executed0, digest[0], net.frames, net.bytes, net.lost, acked, ok ? "true" : "false");
   for (int i = 0; i < nNodes; i++) {
     const gpx::Stats& s = pms[(size_t)i]->stats();
-    std::printf("%s{\"id\": %d, \"alive\": %s, \"pauses\": %" PRIu64 ", \"unpauses\": %" PRIu64 ", \"paused_now\": %zu, \"proposed\": %" PRIu64 ", \"batched_requests\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
+    std::printf("%s{\"id\": %d, \"alive\": %s, \"checkpoints\": %" PRIu64 ", \"pauses\": %" PRIu64 ", \"unpauses\": %" PRIu64 ", \"paused_now\": %zu, \"proposed\": %" PRIu64 ", \"batched_requests\": %" PRIu64 ", \"forwarded\": %" PRIu64 ", \"accepts\": %" PRIu64
                 ", \"votes\": %" PRIu64 ", \"decisions\": %" PRIu64 ", \"commits\": %" PRIu64 ", \"executed\": %" PRIu64
                 ", \"refused\": %" PRIu64 ", \"dropped_frames\": %" PRIu64 ", \"engine_calls\": %" PRIu64
                 ", \"elections_started\": %" PRIu64 ", \"elections_won\": %" PRIu64 ", \"elections_lost\": %" PRIu64
                 ", \"prepares\": %" PRIu64 ", \"carried_over\": %" PRIu64 ", \"noops\": %" PRIu64 ", \"preactive\": %" PRIu64
                 ", \"logged_accepts\": %" PRIu64 ", \"log_batches\": %" PRIu64 ", \"held_replies\": %" PRIu64
                 ", \"accepts_resent\": %" PRIu64 ", \"sync_requests\": %" PRIu64 ", \"sync_decisions_sent\": %" PRIu64 ", \"sync_decisions_applied\": %" PRIu64 "}",
-                i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.pauses, s.unpauses,
+                i ? ", " : "", pms[(size_t)i]->myID(), alive[(size_t)i] ? "true" : "false", s.checkpoints, s.pauses, s.unpauses,
                 pms[(size_t)i]->pausedCount(), s.proposed, s.batched_requests, s.forwarded,
                 s.accepts, s.votes, s.decisions, s.commits, s.executed, s.refused, s.dropped_frames, s.engine_calls,
                 s.elections_started, s.elections_won, s.elections_lost, s.prepares, s.carried_over, s.noops,

@@ -41,6 +41,8 @@ def test_cluster_invariants(case):
     burst = int(args[args.index("--burst") + 1]) if "--burst" in args else 1
     per_round = int(args[args.index("--active") + 1]) if "--active" in args else out["groups"]
     assert out["executed_per_node"] == out["requests"] == per_round * out["rounds"] * burst
+    assert out["client_acks"] == out["requests"]  # every entry replica answered its clients
+    assert all(n["checkpoints"] > 0 for n in out["per_node"]) or out["rounds"] * burst < 4 or "--active" in args
     for n in out["per_node"]:
         assert n["executed"] == out["requests"] and n["dropped_frames"] == 0 and n["refused"] == 0
     proposed = sum(n["proposed"] for n in out["per_node"])
