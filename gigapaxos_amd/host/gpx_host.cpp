@@ -550,6 +550,7 @@ void PaxosManager::executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* 
         }
       /* the decision stays available to replicas that missed its commit (the logger's job in the
        * reference), a bounded number of slots back */
+      syncAsked_.erase(key(xg[r], slot));
       decided_[key(xg[r], slot)] = std::move(a->second);
       decided_.erase(key(xg[r], (int32_t)((uint32_t)slot - (uint32_t)opt_.decisionLogSlots)));
       accepted_.erase(a); /* acceptedProposals.remove(slot) on execution (PaxosAcceptor.java:357-359) */
