@@ -61,6 +61,20 @@ def build_oracle_cluster():
     return ORC_BIN
 
 
+def build_hip_cluster():
+    """The product build of the cluster example (normally made by __graft_entry__.build()); rebuilt here
+    if it is missing or older than its sources.  Needs libgpx_hip.so (hipcc's output) to be there."""
+    srcs = [os.path.join(HOST, f) for f in ("gpx_host.cpp", "loopback_cluster.cpp")]
+    lib = os.path.join(ROOT, "gigapaxos_amd", "csrc", "libgpx_hip.so")
+    deps = srcs + [os.path.join(HOST, "gpx_host.hpp"), lib]
+    if not os.path.exists(HIP_BIN) or os.path.getmtime(HIP_BIN) < max(os.path.getmtime(d) for d in deps):
+        subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-Wall", "-Wextra", "-I", os.path.join(ROOT, "include"),
+                               "-o", HIP_BIN] + srcs +
+                              ["-L", os.path.dirname(lib), "-lgpx_hip", "-Wl,-rpath,$ORIGIN/../csrc",
+                               "-Wl,-rpath-link,/opt/rocm/lib"])
+    return HIP_BIN
+
+
 def run_cluster(binary, args, timeout=300):
     p = subprocess.run([binary] + list(args), capture_output=True, text=True, timeout=timeout)
     assert p.returncode == 0, (p.returncode, p.stdout[-400:], p.stderr[-400:])
