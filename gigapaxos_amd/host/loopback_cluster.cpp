@@ -159,7 +159,19 @@ int main(int argc, char** argv) {
     const gpx::Frame bt = gpx::latchToBatch(rq, {&st, &rq});
     std::vector<gpx::Request> rs;
     gpx::parseRequests(bt, &rs);
-    std::printf("{\"request\": \"%s\", \"stop\": \"%s\", \"accept\": \"%s\", \"batched\": \"%s\", \"batch_size\": %d, "
+    /* RequestPacket.main (RequestPacket.java:1531-1563): "asd999" latched with 25 more stop requests,
+     * to bytes and back */
+    std::vector<gpx::Frame> subs;
+    std::vector<const gpx::Frame*> subp;
+    for (int i = 0; i < 25; i++) subs.push_back(gpx::makeRequestFrame("pid", 0, 1000 + i, "asd" + std::to_string(i), true, 100));
+    for (auto& f : subs) subp.push_back(&f);
+    const gpx::Frame big = gpx::latchToBatch(gpx::makeRequestFrame("pid", 0, 999, "asd999", true, 100), subp);
+    std::vector<gpx::Request> back;
+    bool same = gpx::parseRequests(big, &back) && back.size() == 26 && back[0].requestValue == "asd999";
+    for (size_t i = 1; same && i < back.size(); i++)
+      same = back[i].requestValue == "asd" + std::to_string(i - 1) && back[i].stop && back[i].requestID == 999 + (int64_t)i;
+    std::printf("{\"rp_main\": \"%s\", \"rp_main_roundtrip\": %s, ", hex(big).c_str(), same ? "true" : "false");
+    std::printf("\"request\": \"%s\", \"stop\": \"%s\", \"accept\": \"%s\", \"batched\": \"%s\", \"batch_size\": %d, "
                 "\"parsed\": %zu, \"coordinator\": %d, \"hash\": %d}\n",
                 hex(rq).c_str(), hex(st).c_str(), hex(ac).c_str(), hex(bt).c_str(), gpx::batchSizeOf(bt), rs.size(),
                 gpx::roundRobinCoordinator("TESTPaxosApp7", {100, 101, 102}, 0), gpx::javaStringHash("hello"));

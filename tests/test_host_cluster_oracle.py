@@ -100,6 +100,20 @@ def test_cpp_frame_builders_match_the_python_restatement():
     assert out["batched"] == W.request(b"TESTPaxosApp7", 0, 0x1122334455667788, b"hello-value", entry_replica=101,
                                        batched=[st, rq]).hex()
     assert out["batch_size"] == 2 and out["parsed"] == 3
+    # RequestPacket.main: "asd999" + 25 latched stop requests survive bytes -> packets; the device-side
+    # walk of the same bytes (oracle restatement here) sees ONE proposal that is a stop
+    assert out["rp_main_roundtrip"] is True
+    subs = [W.request(b"pid", 0, 1000 + i, b"asd%d" % i, stop=True, entry_replica=100) for i in range(25)]
+    assert out["rp_main"] == W.request(b"pid", 0, 999, b"asd999", stop=True, entry_replica=100, batched=subs).hex()
+    from gigapaxos_amd import Engine, hri_create, S_OK
+    e = Engine(load_oracle(), 100, 4, kmax=3, window=8, max_batch=64)
+    we = W.WireEngine(e)
+    import numpy as np
+    assert (e.create_groups(np.arange(1), np.array([[100, 101, 102]], np.int32), 3, hri_create(1, 3, 100)) == S_OK).all()
+    assert (we.bind([b"pid"], [0]) == S_OK).all()
+    d = we.decode([bytes.fromhex(out["rp_main"])])
+    assert d.f_status.tolist() == [W.W_OK] and d.requests["is_stop"].tolist() == [1] and d.requests["req_id"].tolist() == [999]
+    e.close()
     assert out["hash"] == 99162322  # "hello".hashCode()
     import numpy as np
     import ctypes as C
