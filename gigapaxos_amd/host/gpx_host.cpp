@@ -414,13 +414,22 @@ bool PaxosManager::kill(const std::string& paxosID) {
   check(gpx_group_retire(engine_, 1, &g, GPX_RETIRE_KILL, nullptr, &st), "gpx_group_retire");
   check(gpx_names_unbind(engine_, 1, &g, &st), "gpx_names_unbind");
   check(gpx_rows_free(engine_, 1, &g), "gpx_rows_free");
-  for (auto a = accepted_.begin(); a != accepted_.end();)
-    a = (int32_t)(a->first >> 32) == g ? accepted_.erase(a) : std::next(a);
+  forgetRow(g);
+  decided_.erase(paxosID);
   rowName_[(size_t)g].clear();
-  liveAccepts_[(size_t)g] = 0;
   liveRows_--;
   pinstances_.erase(it);
   return true;
+}
+
+void PaxosManager::forgetRow(int32_t g) {
+  for (auto a = accepted_.begin(); a != accepted_.end();)
+    a = (int32_t)(a->first >> 32) == g ? accepted_.erase(a) : std::next(a);
+  for (auto a = syncAsked_.begin(); a != syncAsked_.end();)
+    a = (int32_t)(a->first >> 32) == g ? syncAsked_.erase(a) : std::next(a);
+  for (auto* m : {&preactive_, &carried_})
+    for (auto a = m->lower_bound({g, INT64_MIN}); a != m->end() && a->first.first == g;) a = m->erase(a);
+  liveAccepts_[(size_t)g] = 0;
 }
 
 bool PaxosManager::pause(const std::string& paxosID) {
@@ -438,6 +447,7 @@ bool PaxosManager::pause(const std::string& paxosID) {
   p.members = it->second.members;
   p.version = it->second.version;
   paused_[paxosID] = std::move(p);
+  forgetRow(g);
   rowName_[(size_t)g].clear();
   liveRows_--;
   pinstances_.erase(it);
@@ -551,8 +561,9 @@ void PaxosManager::executeRuns(int32_t nRuns, const int32_t* xg, const int32_t* 
       /* the decision stays available to replicas that missed its commit (the logger's job in the
        * reference), a bounded number of slots back */
       syncAsked_.erase(key(xg[r], slot));
-      decided_[key(xg[r], slot)] = std::move(a->second);
-      decided_.erase(key(xg[r], (int32_t)((uint32_t)slot - (uint32_t)opt_.decisionLogSlots)));
+      auto& log = decided_[rowName_[(size_t)xg[r]]];
+      log[slot] = std::move(a->second);
+      log.erase((int32_t)((uint32_t)slot - (uint32_t)opt_.decisionLogSlots));
       accepted_.erase(a); /* acceptedProposals.remove(slot) on execution (PaxosAcceptor.java:357-359) */
       liveAccepts_[(size_t)xg[r]]--;
     }
@@ -659,7 +670,10 @@ size_t PaxosManager::poke() {
         /* something is committed at or beyond my next slot and I have not executed it: the missing
          * slots below the newest commit, or - none missing - my next slot itself, whose commit may
          * be a placeholder without a value (requestMissingDecisions, PISM:2292-2300) */
-        if (gst[(size_t)i] != GPX_S_OK || jsub32(maxc[(size_t)i], first[(size_t)i]) < 0) continue;
+        if (gst[(size_t)i] != GPX_S_OK) continue;
+        /* ... or an accepted value is still waiting for its decision here: its commit may have been
+         * lost with nothing newer to reveal the gap */
+        if (jsub32(maxc[(size_t)i], first[(size_t)i]) < 0 && liveAccepts_[(size_t)live[(size_t)i]] == 0) continue;
         uint64_t mask = missing[(size_t)i];
         if (!mask) mask = 1;
         Frame f;
@@ -723,6 +737,21 @@ bool PaxosManager::handlePrepares(std::vector<Frame>& prepares) {
       put32(body, (int32_t)a->second.frame.size());
       body.insert(body.end(), a->second.frame.begin(), a->second.frame.end());
       cnt++;
+    }
+    /* ... plus what the reference reads back from its log (getLoggedAccepts, PISM:953-975): with
+     * GET_ACCEPTED_PVALUES_FROM_DISK an executed slot's accept leaves memory but not the log, and a
+     * candidate whose firstUndecidedSlot is at or below it must still hear about it - or it would
+     * fill the slot with something else */
+    if (!(rf[(size_t)i] & GPX_P_NACK)) {
+      auto lg = decided_.find(rowName_[(size_t)g[(size_t)i]]);
+      if (lg != decided_.end())
+        for (auto& kv : lg->second) {
+          if (jsub32(kv.first, fs[(size_t)i]) < 0) continue;
+          put32(body, kv.first), put32(body, kv.second.bnum), put32(body, kv.second.bcoord);
+          put32(body, (int32_t)kv.second.frame.size());
+          body.insert(body.end(), kv.second.frame.begin(), kv.second.frame.end());
+          cnt++;
+        }
     }
     putHeader(f, kTypePrepareReply, 0, rowName_[(size_t)g[(size_t)i]]);
     put32(f, myID_), put32(f, rb[(size_t)i]), put32(f, rc[(size_t)i]);
@@ -874,15 +903,16 @@ bool PaxosManager::handleSyncRequests(std::vector<Frame>& reqs) {
   for (auto& f : reqs) {
     const size_t idLen = f.size() > 12 ? f[12] : 0, p = 13 + idLen;
     if (f.size() < p + 8) continue;
-    auto it = pinstances_.find(std::string((const char*)&f[13], idLen));
-    if (it == pinstances_.end()) continue; /* (a paused group has nothing newer than the requester) */
+    const std::string name((const char*)&f[13], idLen);
+    auto lg = decided_.find(name); /* live or paused: the log is kept by name */
+    if (lg == decided_.end()) continue;
     const int32_t sender = get32(&f[p]), cnt = get32(&f[p + 4]);
     for (int32_t j = 0; j < cnt && p + 8 + 4 * (size_t)j + 4 <= f.size(); j++) {
       const int32_t slot = get32(&f[p + 8 + 4 * (size_t)j]);
-      auto d = decided_.find(key(it->second.gidx, slot));
-      if (d == decided_.end()) continue;
+      auto d = lg->second.find(slot);
+      if (d == lg->second.end()) continue;
       Frame out;
-      putHeader(out, kTypeDecision, 0, it->first);
+      putHeader(out, kTypeDecision, 0, name);
       put32(out, slot), put32(out, d->second.bnum), put32(out, d->second.bcoord);
       put32(out, (int32_t)((uint32_t)slot - 1u)); /* a median that is safe for anyone who lacks this slot */
       put32(out, (int32_t)d->second.frame.size());
@@ -933,7 +963,8 @@ bool PaxosManager::handleDecisions(std::vector<Frame>& decisions) {
   /* a decision for a slot already executed here left its value behind: drop it again */
   for (int32_t i = 0; i < n; i++) {
     auto a = accepted_.find(key(g[(size_t)i], sl[(size_t)i]));
-    if (a != accepted_.end() && decided_.count(key(g[(size_t)i], sl[(size_t)i]))) {
+    auto lg = decided_.find(rowName_[(size_t)g[(size_t)i]]);
+    if (a != accepted_.end() && lg != decided_.end() && lg->second.count(sl[(size_t)i])) {
       accepted_.erase(a);
       liveAccepts_[(size_t)g[(size_t)i]]--;
     }

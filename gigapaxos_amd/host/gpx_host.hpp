@@ -244,7 +244,10 @@ class PaxosManager {
   std::deque<Held> held_;
   size_t releaseHeld();
   /* what the logger's getLoggedDecisions would return: the last decisions executed here */
-  std::unordered_map<uint64_t, StoredAccept> decided_;
+  /* keyed by NAME: a group's log stays with it while it is paused (it can still answer sync requests)
+   * and never leaks to the next group that gets its row */
+  std::unordered_map<std::string, std::map<int32_t, StoredAccept>> decided_;
+  void forgetRow(int32_t gidx); /* host-side bookkeeping keyed by a row that is being vacated */
   std::unordered_map<uint64_t, uint64_t> syncAsked_; /* (gidx, slot) -> the pass a sync was last requested in */
   std::unordered_map<std::string, Paused> paused_;
   std::vector<uint64_t> lastActive_; /* per row: the pass that last touched the group */

@@ -40,6 +40,11 @@ CASES = [
     # logging on: accept replies wait for their batch's log write (durable three polls later)
     ["--groups", "200", "--rounds", "6", "--log-delay", "3"],
     ["--groups", "150", "--rounds", "6", "--log-delay", "5", "--kill-round", "3", "--burst", "2", "--seed", "12"],
+    # a node dies on a lossy network: the candidate must hear of slots a survivor has already executed
+    ["--groups", "7", "--rounds", "6", "--seed", "577593", "--kill-round", "1", "--kill-node", "0", "--drop-commits", "200",
+     "--drop-accepts", "150"],
+    ["--groups", "60", "--rounds", "6", "--seed", "2504", "--kill-round", "1", "--kill-node", "1", "--drop-commits", "200",
+     "--drop-accepts", "150", "--no-batching"],
 ]
 
 

@@ -141,3 +141,16 @@ def test_file_logger_same_outcome_and_durable_log(tmp_path):
             p += 4 + ln
             cnt += 1
         assert p == len(data) and cnt == n["logged_accepts"] == n["accepts"]
+
+
+def test_cluster_flag_fuzz():
+    """scripts/cluster_fuzz.py with a fixed seed: 150 random scenario mixes, all must converge."""
+    import os
+    import subprocess
+    import sys
+
+    from tests.host_cluster_common import ROOT
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "cluster_fuzz.py"), "11", "150"],
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stdout[-800:]
