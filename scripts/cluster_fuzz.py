@@ -14,8 +14,8 @@ random.seed(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bad = 0
 t0 = time.time()
 for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
-    nodes = random.choice([3, 3, 5])
-    G = random.choice([1, 7, 60, 300])
+    nodes = random.choice([3, 3, 5, 7])
+    G = random.choice([1, 7, 60, 300, 1500])
     R = random.choice([3, 6, 10])
     args = ["--nodes", str(nodes), "--groups", str(G), "--rounds", str(R), "--seed", str(random.randint(1, 10 ** 6))]
     if random.random() < 0.4: args += ["--burst", str(random.choice([2, 3, 7]))]
