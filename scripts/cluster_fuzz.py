@@ -9,7 +9,7 @@ import json, random, subprocess, sys, time
 import os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from tests.host_cluster_common import build_oracle_cluster  # noqa: E402
-exe = build_oracle_cluster()
+exe = os.environ.get("GPX_CLUSTER_EXE") or build_oracle_cluster()  # e.g. a sanitizer build
 random.seed(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bad = 0
 t0 = time.time()
@@ -31,7 +31,7 @@ for it in range(int(sys.argv[2]) if len(sys.argv) > 2 else 60):
     try:
         p = subprocess.run([exe] + args, capture_output=True, text=True, timeout=120)
         out = json.loads(p.stdout.strip().splitlines()[-1]) if p.stdout.strip() else None
-        ok = p.returncode == 0 and out and out["ok"]
+        ok = p.returncode == 0 and out and out["ok"] and "runtime error" not in p.stderr and "Sanitizer" not in p.stderr
     except subprocess.TimeoutExpired:
         ok, out, p = False, None, None
     if not ok:
