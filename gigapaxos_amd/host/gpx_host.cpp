@@ -758,10 +758,20 @@ bool PaxosManager::handlePrepares(std::vector<Frame>& prepares) {
     put32(f, (int32_t)((uint32_t)rg[(size_t)i] + 1u)); /* firstSlot = gcSlot + 1 */
     put32(f, cnt);
     f.insert(f.end(), body.begin(), body.end());
-    if (bc[(size_t)i] == myID_)
+    /* a PREPARE that raised my ballot is logged before its reply leaves (GPX_P_TOLOG, PISM:985-1000) */
+    if (opt_.logger && (rf[(size_t)i] & GPX_P_TOLOG)) {
+      Frame rec; /* what has to survive: the ballot promised for this group */
+      putHeader(rec, kTypePrepare, 0, rowName_[(size_t)g[(size_t)i]]);
+      put32(rec, rb[(size_t)i]), put32(rec, rc[(size_t)i]), put32(rec, fs[(size_t)i]);
+      const uint64_t ticket = opt_.logger->logBatch({&rec});
+      held_.push_back(Held{ticket, bc[(size_t)i], std::move(f)});
+      stats_.held_replies++;
+      stats_.log_batches++;
+    } else if (bc[(size_t)i] == myID_) {
       inbox_.push_back(std::move(f));
-    else
+    } else {
       messenger_->send(bc[(size_t)i], std::move(f)); /* to the PREPARE's sender */
+    }
   }
   return true;
 }
