@@ -43,7 +43,8 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--cpu-rounds", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=32, help="threads of the CPU baseline leg")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline leg (0 = every host core)")
+    ap.add_argument("--no-parity-check", action="store_true", help="skip the engine-vs-oracle replay of the CPU sample")
     ap.add_argument("--cpu-mt-passes", type=int, default=16, help="passes over the sample in the multi-threaded leg")
     ap.add_argument("--serial", action="store_true",
                     help="no cross-call pipelining: every kernel of every call in order on one stream")
@@ -203,6 +204,9 @@ def main():
             "bound": "hbm", "kernel": dom_name, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "traffic_raw_counters": traffic_raw,
+            "traffic_source": None if traffic is None else
+            "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
+            "(scripts/gpu_round.sh), not counted in this run",
             "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg),
             "pipeline_ms_per_step": round(pipe_ms, 4),
             "pipeline_achieved": round(pipe_achieved, 1),
@@ -212,6 +216,7 @@ def main():
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores ---
     cpu_baseline = None
+    parity_checked = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from tests.oracle_binding import load_oracle
 
@@ -223,27 +228,59 @@ def main():
         gnp = np.arange(G, dtype=np.int32)
         tc = time.perf_counter()
         ndec = 0
+        oracle_dec = []
         for r in range(cpu_rounds):
             eo.propose(gnp)
-            ndec += eo.accept_reply(*cols_cpu[r]).gidx.shape[0]
+            d = eo.accept_reply(*cols_cpu[r])
+            ndec += d.gidx.shape[0]
+            oracle_dec.append(d)
         tcpu = time.perf_counter() - tc
+        if not args.no_parity_check:
+            # what is timed is also what is checked: the same rounds through a fresh HIP engine
+            # (C-ABI, host pointers), decided stream / per-vote status / HotRestoreInfo rows against
+            # the oracle's (outside every timed region)
+            ep = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
+            assert (ep.create_groups(gnp, mem, K, hri_create(G, K, 100)) == S_OK).all()
+            ok = True
+            for r in range(cpu_rounds):
+                ep.propose(gnp)
+                d = ep.accept_reply(*cols_cpu[r])
+                ok = ok and d.as_tuple_array().shape == oracle_dec[r].as_tuple_array().shape \
+                    and bool((d.as_tuple_array() == oracle_dec[r].as_tuple_array()).all()) \
+                    and bool((d.status == oracle_dec[r].status).all())
+            ok = ok and ep.snapshot(gnp)[0].tobytes() == eo.snapshot(gnp)[0].tobytes()
+            ok = ok and ep.counters() == eo.counters()
+            ep.close()
+            parity_checked = {"rounds": cpu_rounds, "groups": G, "votes_per_round": int(cols_cpu[0][0].shape[0]),
+                              "compared": "decisions (gidx, slot, bnum, bcoord, median_cp, kind), per-vote status, "
+                                          "HotRestoreInfo rows of every group, counters", "ok": bool(ok)}
+            assert ok, "HIP engine and oracle disagree on the bench workload"
+        del oracle_dec
         single = {"decisions_per_sec": round(ndec / tcpu, 1),
                   "votes_per_sec": round(cols_cpu[0][0].shape[0] * cpu_rounds / tcpu, 1), "seconds": round(tcpu, 2)}
         # the same oracle on T host threads, thread t owning the groups with gidx % T == t (groups are
         # independent: what PaxosManager's demultiplexer thread pool exploits, PACKET_DEMULTIPLEXER_THREADS)
         import threading
 
-        T = max(1, min(args.cpu_threads, os.cpu_count() or 1))
+        T = max(1, (os.cpu_count() or 1) if args.cpu_threads <= 0 else min(args.cpu_threads, os.cpu_count() or 1))
         lib_o = load_oracle()
+        # one stable partition of every sample round by owner thread (gidx % T)
+        parts = []
+        for cols in cols_cpu:
+            key = cols[0] % T
+            order = np.argsort(key, kind="stable")
+            bounds = np.searchsorted(key[order], np.arange(T + 1))
+            parts.append((order, bounds))
         shards = []
         for t in range(T):
             gs = np.arange(t, G, T, dtype=np.int32)
-            es = Engine(lib_o, 100, gs.shape[0], kmax=K, window=8)
-            assert (es.create_groups(np.arange(gs.shape[0], dtype=np.int32), mem[gs], K,
-                                     hri_create(gs.shape[0], K, 100)) == S_OK).all()
+            es = Engine(lib_o, 100, max(1, gs.shape[0]), kmax=K, window=8)
+            if gs.shape[0]:
+                assert (es.create_groups(np.arange(gs.shape[0], dtype=np.int32), mem[gs], K,
+                                         hri_create(gs.shape[0], K, 100)) == S_OK).all()
             rounds_t = []
-            for cols in cols_cpu:
-                sel = (cols[0] % T) == t
+            for cols, (order, bounds) in zip(cols_cpu, parts):
+                sel = order[bounds[t]:bounds[t + 1]]
                 rounds_t.append([np.ascontiguousarray(cols[0][sel] // T)] +
                                 [np.ascontiguousarray(c[sel]) for c in cols[1:]])
             shards.append((es, np.arange(gs.shape[0], dtype=np.int32), rounds_t))
@@ -310,6 +347,7 @@ def main():
             "pipelined": not args.serial,
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
+            "parity_checked": parity_checked,
         }
         print(json.dumps(out))
     if world > 1:

@@ -1,0 +1,450 @@
+/*
+ * gpx_ar16.hip.h — the accept-reply back end on 16-byte vote records (round 2).
+ *
+ * Same pipeline shape as gpx_kernels.hip.h (k_hist -> scatter -> one workgroup per bucket, one
+ * lane per group -> emit), with half the bytes through the partition:
+ *
+ *   Vote16 {idx, slot, max_cp, meta}   meta = local group (14 bits) | ESC | acceptor << 16
+ *
+ * A vote's ballot is almost always the batch's common ballot (the ballot of record 0) and node ids
+ * almost always fit 16 bits: such a vote travels without ballot and with the acceptor inlined.
+ * Anything else sets ESC and the per-bucket kernel re-reads (bnum, bcoord, acceptor) of that vote
+ * from the caller's columns by arrival index - the columns are valid for the whole call - so the
+ * compact form loses nothing.
+ *
+ *   k_scatter_ar16   per tile: one 16-byte store per vote into its bucket region
+ *   k_bucket_ar16    per bucket: count per group (LDS atomics) -> scan -> votes placed GROUP-MAJOR
+ *                    in LDS (structure of arrays): lane l's votes are consecutive words, so the
+ *                    replay reads LDS at a near-constant stride across lanes instead of at random
+ *                    slots.  The arrival order of a group's <= 16 votes is a 64-bit nibble word in
+ *                    a register; longer segments are sorted cooperatively through global scratch.
+ *                    The replay itself is apply_ar_group (gpx_kernels.hip.h), unchanged: PISM.
+ *                    handleAcceptReply -> PaxosCoordinatorState.handleAcceptReplyMyBallot /
+ *                    HigherBallot (PaxosInstanceStateMachine.java:1248-1419, PCS:597-683).
+ *                    Outputs are staged as six dense COLUMNS per bucket (21 bytes per decision).
+ *   k_emit_dec16     per bucket: the staged columns -> the caller's columns, buckets in order.
+ */
+#pragma once
+#include "gpx_kernels.hip.h"
+
+struct __attribute__((aligned(16))) Vote16 {
+  int32_t idx, slot, maxcp;
+  uint32_t meta;
+};
+#define V16_LG_MASK 0x3fffu
+#define V16_ESC 0x4000u
+#define V16_MAX_SHIFT 10 /* one lane per group, at most 1024 lanes */
+
+/* staged outputs of the per-bucket kernel: six columns over the record index space (outputs of
+ * bucket b at [bucket_off[b], bucket_off[b] + bucket_nout[b])) */
+struct Stage16 {
+  int32_t *gidx, *slot, *bnum, *bcoord, *median;
+  uint8_t* kind;
+};
+/* the caller's vote columns the ESC path reads, and the batch's common ballot = ballot of vote 0 */
+struct VoteCols {
+  const int32_t *bnum, *bcoord, *acceptor;
+};
+
+__device__ __forceinline__ void put_vote16(const DevScratch& X, int32_t* lds, int32_t G, int32_t mask,
+                                           int32_t b0n, int32_t b0c, int64_t i, int32_t g, int32_t slot,
+                                           int32_t acc, int32_t maxcp, int32_t bn, int32_t bc) {
+  if ((uint32_t)g >= (uint32_t)G) return; /* status already says GPX_S_NOGROUP (k_hist) */
+  const int32_t pos = bucket_take(lds, g >> X.shift);
+  const bool esc = bn != b0n || bc != b0c || (uint32_t)acc > 0xffffu;
+  Vote16 v;
+  v.idx = (int32_t)i;
+  v.slot = slot;
+  v.maxcp = maxcp;
+  v.meta = (uint32_t)(g & mask) | (esc ? V16_ESC : ((uint32_t)acc << 16));
+  ((Vote16*)X.rec)[pos] = v; /* one 16-byte request per vote */
+}
+
+template <bool VEC>
+__global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ar16(
+    int32_t n, int32_t ntiles, int32_t G, DevScratch X, const int32_t* __restrict__ gidx,
+    const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord,
+    const int32_t* __restrict__ slot, const int32_t* __restrict__ acceptor,
+    const int32_t* __restrict__ max_cp) {
+  extern __shared__ int32_t lds[];
+  const int32_t tile = tile_of_block(ntiles);
+  if (tile >= ntiles) return;
+  const int32_t b0n = bnum[0], b0c = bcoord[0];
+  scatter_init(X, tile, lds);
+  const int64_t base = (int64_t)tile * GPX_TILE;
+  const int32_t mask = X.gb - 1;
+  if (VEC) {
+#pragma unroll
+    for (int j = 0; j < GPX_TILE_VECS; j++) {
+      const int64_t i0 = base + (int64_t)(j * GPX_FBLOCK + threadIdx.x) * 4;
+      if (i0 + 3 < n) {
+        const I4 g4 = *(const I4*)(gidx + i0), s4 = *(const I4*)(slot + i0);
+        const I4 a4 = *(const I4*)(acceptor + i0), m4 = *(const I4*)(max_cp + i0);
+        const I4 n4 = *(const I4*)(bnum + i0), c4 = *(const I4*)(bcoord + i0);
+        put_vote16(X, lds, G, mask, b0n, b0c, i0 + 0, g4.x, s4.x, a4.x, m4.x, n4.x, c4.x);
+        put_vote16(X, lds, G, mask, b0n, b0c, i0 + 1, g4.y, s4.y, a4.y, m4.y, n4.y, c4.y);
+        put_vote16(X, lds, G, mask, b0n, b0c, i0 + 2, g4.z, s4.z, a4.z, m4.z, n4.z, c4.z);
+        put_vote16(X, lds, G, mask, b0n, b0c, i0 + 3, g4.w, s4.w, a4.w, m4.w, n4.w, c4.w);
+      } else {
+        for (int q = 0; q < 4; q++) {
+          const int64_t i = i0 + q;
+          if (i < n)
+            put_vote16(X, lds, G, mask, b0n, b0c, i, gidx[i], slot[i], acceptor[i], max_cp[i], bnum[i],
+                       bcoord[i]);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < GPX_TILE_ITEMS; j++) {
+      const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
+      if (i < n)
+        put_vote16(X, lds, G, mask, b0n, b0c, i, gidx[i], slot[i], acceptor[i], max_cp[i], bnum[i],
+                   bcoord[i]);
+    }
+  }
+}
+
+/* dynamic LDS of k_bucket_ar16: lcnt[gb] | lcur[gb] | idx[L] | slot[L] | maxcp[L] | meta[L] */
+#define GPX_BUCKET16_LDS_BYTES(gb, lds_recs) ((size_t)(gb) * 8 + (size_t)(lds_recs) * 16)
+#define V16_NIB_MAX 16 /* a group's arrival order fits a 64-bit nibble word up to this many votes */
+
+/* One group's votes in arrival order, with GroupIter's interface (next / emit / c) so that
+ * apply_ar_group replays them unchanged.
+ *   LDSM: the bucket is staged in LDS, structure of arrays, this group's votes at words
+ *         [start, start + c); otherwise the votes are the Vote16 records in global memory (a bucket
+ *         beyond the LDS staging capacity) and `start` indexes the bucket's key array.
+ *   c <= 16 (and LDSM): arrival order = nibble word `order` (nibble d = position of the vote with
+ *         arrival rank d); a vote that produced an output is remembered in `omask` (bit d) and the
+ *         output parked in that vote's own words.
+ *   otherwise: keys (arrival idx << 32 | position) sorted ascending in global scratch; the
+ *         positions of votes with outputs are listed in keys[0 .. nout). */
+template <bool LDSM>
+struct VoteIter {
+  const int32_t* idxA;  /* LDS arrays (LDSM) */
+  int32_t *slotA, *cpA;
+  uint32_t* metaA;
+  Vote16* recG;              /* global records of the bucket (!LDSM) */
+  unsigned long long* keys;  /* sorted keys of this group (long / global mode) */
+  VoteCols in;
+  int32_t b0n, b0c;
+  int32_t start, c, done, nout;
+  bool nib;
+  unsigned long long order;
+  uint32_t omask;
+  uint32_t cur;
+  __device__ __forceinline__ bool next(Rec& out) {
+    if (done >= c) return false;
+    uint32_t p;
+    int32_t ix, sl, cp;
+    uint32_t meta;
+    if (LDSM) {
+      if (nib)
+        p = (uint32_t)start + (uint32_t)((order >> (4 * done)) & 15ull);
+      else
+        p = (uint32_t)keys[done];
+      ix = idxA[p];
+      sl = slotA[p];
+      cp = cpA[p];
+      meta = metaA[p];
+    } else {
+      p = (uint32_t)keys[done];
+      const Vote16 v = recG[p];
+      ix = v.idx;
+      sl = v.slot;
+      cp = v.maxcp;
+      meta = v.meta;
+    }
+    cur = p;
+    out.idx = ix;
+    out.a = sl;
+    out.c = cp;
+    if (meta & V16_ESC) {
+      out.b = in.acceptor[ix];
+      out.bnum = in.bnum[ix];
+      out.bcoord = in.bcoord[ix];
+    } else {
+      out.b = (int32_t)(meta >> 16);
+      out.bnum = b0n;
+      out.bcoord = b0c;
+    }
+    done++;
+    return true;
+  }
+  /* output of the CURRENT vote: (slot, median, kind) parked in the vote's own words; the ballot
+   * of a decision / preemption is the coordinator's own (x, y), constant per group per call */
+  __device__ __forceinline__ void emit(int32_t slot, int32_t, int32_t, int32_t z, int32_t kind) {
+    if (LDSM) {
+      slotA[cur] = slot;
+      cpA[cur] = z;
+      metaA[cur] = (uint32_t)kind;
+      if (nib)
+        omask |= 1u << (done - 1);
+      else
+        keys[nout] = cur; /* entry nout <= done - 1: consumed */
+    } else {
+      recG[cur].slot = slot;
+      recG[cur].maxcp = z;
+      recG[cur].meta = (uint32_t)kind;
+      keys[nout] = cur;
+    }
+    nout++;
+  }
+  /* q-th output of the group (after the replay) */
+  __device__ __forceinline__ void output(int32_t q, int32_t* slot, int32_t* median, int32_t* kind,
+                                         uint32_t* om) const {
+    uint32_t p;
+    if (LDSM && nib) {
+      const int d = __ffs((int)*om) - 1; /* arrival rank of the next vote with an output */
+      *om &= *om - 1;
+      p = (uint32_t)start + (uint32_t)((order >> (4 * d)) & 15ull);
+    } else {
+      p = (uint32_t)keys[q];
+    }
+    if (LDSM) {
+      *slot = slotA[p];
+      *median = cpA[p];
+      *kind = (int32_t)metaA[p];
+    } else {
+      *slot = recG[p].slot;
+      *median = recG[p].maxcp;
+      *kind = (int32_t)recG[p].meta;
+    }
+  }
+};
+
+/* arrival order of c <= 16 votes at idxA[start ..): nibble d = position of the vote with rank d */
+__device__ __forceinline__ unsigned long long arrival_order(const int32_t* idxA, int32_t start, int32_t c) {
+  unsigned long long order = 0;
+  if (c <= 4) {
+    const uint32_t inf = 0xffffffffu;
+    const uint32_t i0 = (uint32_t)idxA[start];
+    const uint32_t i1 = c > 1 ? (uint32_t)idxA[start + 1] : inf;
+    const uint32_t i2 = c > 2 ? (uint32_t)idxA[start + 2] : inf;
+    const uint32_t i3 = c > 3 ? (uint32_t)idxA[start + 3] : inf;
+    /* arrival indices are distinct; absent entries (inf) rank last and are never read */
+    const uint32_t r0 = (i1 < i0) + (i2 < i0) + (i3 < i0);
+    const uint32_t r1 = (i0 < i1) + (i2 < i1) + (i3 < i1);
+    const uint32_t r2 = (i0 < i2) + (i1 < i2) + (i3 < i2);
+    const uint32_t r3 = 6u - r0 - r1 - r2;
+    const uint32_t o = (1u << (4 * r1)) | (2u << (4 * r2)) | (3u << (4 * r3)); /* 0 << (4 * r0) */
+    order = o & 0xffffu;
+  } else {
+    for (int32_t t = 0; t < c; t++) {
+      const uint32_t it = (uint32_t)idxA[start + t];
+      int32_t r = 0;
+      for (int32_t u = 0; u < c; u++) r += (uint32_t)idxA[start + u] < it;
+      order |= (unsigned long long)t << (4 * r);
+    }
+  }
+  return order;
+}
+
+#ifndef GPX_AR16_WAVES
+#define GPX_AR16_WAVES 6
+#endif
+template <int KMAX>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(GPX_AR16_WAVES, 8))) void k_bucket_ar16(DevState S, DevScratch X, Stage16 O, VoteCols in,
+                                                      uint8_t* __restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  const int32_t b = blockIdx.x;
+  const int32_t boff = X.bucket_off[b];
+  const int32_t nb = X.bucket_off[b + 1] - boff;
+  if (threadIdx.x == 0) {
+    X.bucket_tot[b] = 0; /* ready for the next batch's k_hist */
+    if (nb == 0) X.bucket_nout[b] = 0;
+  }
+  if (nb == 0) return;
+  const int32_t gb = X.gb; /* == blockDim.x: one lane per group */
+  const int32_t l = (int32_t)threadIdx.x;
+  const int32_t g = (b << X.shift) + l;
+  /* coordinator state of a dense batch: issued now, consumed after the regrouping */
+  const bool pre = 2 * nb >= gb;
+  CoordPre<KMAX> P;
+  P.have_pe = false;
+  if (pre && g < S.G) coord_preload<KMAX>(S, g, P);
+  const int32_t L = X.lds_recs;
+  int32_t* lcnt = lds;
+  int32_t* lcur = lds + gb;
+  int32_t* idxA = lds + 2 * gb;
+  int32_t* slotA = idxA + L;
+  int32_t* cpA = slotA + L;
+  uint32_t* metaA = (uint32_t*)(cpA + L);
+  const bool in_lds = nb <= L;
+  Vote16* recG = (Vote16*)X.rec + boff;
+  unsigned long long* keysG = X.perm + boff;
+  lcnt[l] = 0;
+  __syncthreads();
+  /* A: votes per group.  The first four votes of a lane stay in registers for the placement. */
+  Vote16 r0, r1, r2, r3;
+  r0.meta = r1.meta = r2.meta = r3.meta = 0;
+  r0.idx = r1.idx = r2.idx = r3.idx = 0;
+  r0.slot = r1.slot = r2.slot = r3.slot = 0;
+  r0.maxcp = r1.maxcp = r2.maxcp = r3.maxcp = 0;
+  {
+    const int32_t j0 = l, j1 = gb + l, j2 = 2 * gb + l, j3 = 3 * gb + l;
+    if (j0 < nb) r0 = recG[j0];
+    if (j1 < nb) r1 = recG[j1];
+    if (j2 < nb) r2 = recG[j2];
+    if (j3 < nb) r3 = recG[j3];
+    if (j0 < nb) atomicAdd(&lcnt[r0.meta & V16_LG_MASK], 1);
+    if (j1 < nb) atomicAdd(&lcnt[r1.meta & V16_LG_MASK], 1);
+    if (j2 < nb) atomicAdd(&lcnt[r2.meta & V16_LG_MASK], 1);
+    if (j3 < nb) atomicAdd(&lcnt[r3.meta & V16_LG_MASK], 1);
+    for (int32_t j = 4 * gb + l; j < nb; j += gb) atomicAdd(&lcnt[recG[j].meta & V16_LG_MASK], 1);
+  }
+  __syncthreads();
+  if (pre && g < S.G) coord_preload_ring<KMAX>(S, g, P);
+  /* B: exclusive scan of the counts */
+  const int32_t c = lcnt[l];
+  int32_t tot_;
+  const int32_t start = block_exscan_rt(c, &tot_);
+  lcur[l] = start;
+  const int32_t any_long = __syncthreads_or(c > V16_NIB_MAX || !in_lds);
+  /* C: placement.  LDS: the vote itself, group-major; global mode: a key per vote. */
+  if (in_lds) {
+    auto place = [&](const Vote16& v) {
+      const int32_t p = atomicAdd(&lcur[v.meta & V16_LG_MASK], 1);
+      idxA[p] = v.idx;
+      slotA[p] = v.slot;
+      cpA[p] = v.maxcp;
+      metaA[p] = v.meta;
+    };
+    if (l < nb) place(r0);
+    if (gb + l < nb) place(r1);
+    if (2 * gb + l < nb) place(r2);
+    if (3 * gb + l < nb) place(r3);
+    for (int32_t j = 4 * gb + l; j < nb; j += gb) place(recG[j]);
+  } else {
+    for (int32_t j = l; j < nb; j += gb) {
+      const Vote16 v = recG[j];
+      const int32_t p = atomicAdd(&lcur[v.meta & V16_LG_MASK], 1);
+      keysG[p] = ((unsigned long long)(uint32_t)v.idx << 32) | (uint32_t)j;
+    }
+  }
+  __syncthreads();
+  /* D: segments that do not fit the nibble word (or a bucket in global mode): sorted keys in
+   * global scratch; rare, a single hot group is serial by contract */
+  if (any_long) {
+    if (in_lds && c > V16_NIB_MAX) {
+      for (int32_t t = 0; t < c; t++)
+        keysG[start + t] = ((unsigned long long)(uint32_t)idxA[start + t] << 32) | (uint32_t)(start + t);
+    } else if (!in_lds && c > 1 && c <= V16_NIB_MAX) { /* short segment in global mode: this lane */
+      unsigned long long* a = keysG + start;
+      for (int32_t i = 1; i < c; i++) {
+        const unsigned long long x = a[i];
+        int32_t p = i - 1;
+        while (p >= 0 && a[p] > x) {
+          a[p + 1] = a[p];
+          p--;
+        }
+        a[p + 1] = x;
+      }
+    }
+    __syncthreads();
+    for (int32_t q = 0; q < gb; q++) {
+      const int32_t cq = lcnt[q]; /* uniform */
+      if (cq > V16_NIB_MAX) sort_long_segment(keysG + (lcur[q] - cq), (uint32_t)cq);
+    }
+    __syncthreads();
+  }
+  /* E: replay, one lane per group */
+  int32_t nout = 0;
+  uint32_t omask = 0;
+  const bool live = c != 0 && g < S.G;
+  if (live && !pre) coord_preload<KMAX>(S, g, P);
+  if (in_lds) {
+    VoteIter<true> it;
+    it.idxA = idxA;
+    it.slotA = slotA;
+    it.cpA = cpA;
+    it.metaA = metaA;
+    it.recG = recG;
+    it.keys = keysG + start;
+    it.in = in;
+    it.b0n = in.bnum[0];
+    it.b0c = in.bcoord[0];
+    it.start = start;
+    it.c = c;
+    it.done = 0;
+    it.nout = 0;
+    it.nib = c <= V16_NIB_MAX;
+    it.order = 0;
+    it.omask = 0;
+    it.cur = 0;
+    if (live) {
+      if (it.nib) it.order = arrival_order(idxA, start, c);
+      apply_ar_group<KMAX>(S, X, g, it, status, P);
+    }
+    nout = it.nout;
+    omask = it.omask;
+    /* F: the bucket's outputs, group-major, as columns */
+    int32_t tout;
+    const int32_t ex = block_exscan_rt(nout, &tout);
+    for (int32_t q = 0; q < nout; q++) {
+      int32_t sl, md, kd;
+      it.output(q, &sl, &md, &kd, &omask);
+      const int64_t o = (int64_t)boff + ex + q;
+      O.gidx[o] = g;
+      O.slot[o] = sl;
+      O.bnum[o] = P.my_bnum;
+      O.bcoord[o] = P.my_bcoord;
+      O.median[o] = md;
+      O.kind[o] = (uint8_t)kd;
+    }
+    if (l == 0) X.bucket_nout[b] = tout;
+  } else {
+    VoteIter<false> it;
+    it.idxA = idxA;
+    it.slotA = slotA;
+    it.cpA = cpA;
+    it.metaA = metaA;
+    it.recG = recG;
+    it.keys = keysG + start;
+    it.in = in;
+    it.b0n = in.bnum[0];
+    it.b0c = in.bcoord[0];
+    it.start = start;
+    it.c = c;
+    it.done = 0;
+    it.nout = 0;
+    it.nib = false;
+    it.order = 0;
+    it.omask = 0;
+    it.cur = 0;
+    if (live) apply_ar_group<KMAX>(S, X, g, it, status, P);
+    nout = it.nout;
+    int32_t tout;
+    const int32_t ex = block_exscan_rt(nout, &tout);
+    for (int32_t q = 0; q < nout; q++) {
+      int32_t sl, md, kd;
+      it.output(q, &sl, &md, &kd, &omask);
+      const int64_t o = (int64_t)boff + ex + q;
+      O.gidx[o] = g;
+      O.slot[o] = sl;
+      O.bnum[o] = P.my_bnum;
+      O.bcoord[o] = P.my_bcoord;
+      O.median[o] = md;
+      O.kind[o] = (uint8_t)kd;
+    }
+    if (l == 0) X.bucket_nout[b] = tout;
+  }
+}
+
+/* staged columns -> the caller's columns, buckets in order */
+__global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec16(
+    DevScratch X, Stage16 O, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
+    int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
+    uint8_t* __restrict__ d_kind, int32_t* total_out, unsigned long long* acc) {
+  const int32_t out0 = emit_base(X, total_out, acc);
+  const int32_t nd = X.bucket_nout[blockIdx.x];
+  const int64_t src = X.bucket_off[blockIdx.x];
+  for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {
+    d_gidx[out0 + t] = O.gidx[src + t];
+    d_slot[out0 + t] = O.slot[src + t];
+    d_bnum[out0 + t] = O.bnum[src + t];
+    d_bcoord[out0 + t] = O.bcoord[src + t];
+    d_median[out0 + t] = O.median[src + t];
+    d_kind[out0 + t] = O.kind[src + t];
+  }
+}

@@ -17,6 +17,7 @@
 #include <initializer_list>
 
 #include "gpx_kernels.hip.h"
+#include "gpx_ar16.hip.h"
 #include "gpx_wire.hip.h"
 #include "gpx_elect.hip.h"
 
@@ -91,6 +92,10 @@ struct gpx_engine {
   int32_t lds_recs_max = 0;   /* staging capacity the engine was sized for (kmax records per group) */
   int32_t lds_recs_hw = 0;    /* ... and the most a workgroup can stage (oversized calls) */
   int bucket_threads = 256;
+  /* accept-reply back end on 16-byte vote records (gpx_ar16.hip.h): one lane per group, so only
+   * while a bucket has at most 1024 groups; GPX_AR_LEGACY=1 forces the 32-byte record path */
+  bool ar16 = false;
+  int32_t lds16_max = 0, lds16_hw = 0; /* LDS staging capacities (votes) of k_bucket_ar16 */
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
   /* wire codec (gpx_wire_host.inc): paxosID table, row free list, scratch - allocated on first use */
   DevNames N{};
@@ -259,24 +264,27 @@ int begin_front(gpx_engine* e, std::initializer_list<Range> touched) {
   return s;
 }
 /* front section done: the back end (on sB) may start once the records are partitioned */
-void begin_back(gpx_engine* e, int s, int32_t n) {
+void begin_back(gpx_engine* e, int s, int32_t n, bool v16 = false) {
   /* LDS staging area of the per-bucket kernel, sized for THIS batch: mean records per bucket
    * + 25 % + 128, so that a thin batch (e.g. one proposal per group on an engine sized for 5-vote
    * rounds) still gets many workgroups per CU.  Buckets above it take the global-memory path. */
   {
+    const int32_t rmax = v16 ? e->lds16_max : e->lds_recs_max;
+    const int32_t rhw = v16 ? e->lds16_hw : e->lds_recs_hw;
     int64_t want = (int64_t)n / std::max(1, e->X.nbk);
     want = (want + want / 4 + 128 + 63) / 64 * 64;
     /* a call that carries more than the round the engine was sized for (several slots per group in
      * one batch) may take the LDS the hardware allows rather than fall back to the global-memory
      * path for every bucket */
     const int64_t mean = (int64_t)n / std::max(1, e->X.nbk);
-    const bool oversized = mean + mean / 8 > e->lds_recs_max;
-    const int64_t cap = oversized ? e->lds_recs_hw : e->lds_recs_max;
+    const bool oversized = mean + mean / 8 > rmax;
+    const int64_t cap = oversized ? rhw : rmax;
     e->X.lds_recs = (int32_t)std::max<int64_t>(256, std::min<int64_t>(want, cap));
     /* beyond that too: nearly every bucket is regrouped in global memory - do not hold LDS it
      * will not use */
-    if (oversized && mean > e->lds_recs_hw + e->lds_recs_hw / 4) e->X.lds_recs = 256;
-    e->bucket_lds = GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs) + e->lds_pad;
+    if (oversized && mean > rhw + rhw / 4) e->X.lds_recs = 256;
+    e->bucket_lds = (v16 ? GPX_BUCKET16_LDS_BYTES(e->X.gb, e->X.lds_recs)
+                         : GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs)) + e->lds_pad;
   }
   if (e->pipeline) {
     HIPQ(hipEventRecord(e->fs[s].evF, e->sF));
@@ -334,6 +342,10 @@ int check_batch(gpx_engine* h, int32_t n) {
 template <int KMAX>
 void launch_bucket_ar(gpx_engine* e, uint8_t* status) {
   LAUNCH_B(e, "k_bucket_ar", (k_bucket_ar<KMAX>), e->S, e->X, status);
+}
+template <int KMAX>
+void launch_bucket_ar16(gpx_engine* e, const Stage16& O, const VoteCols& in, uint8_t* status) {
+  LAUNCH_B(e, "k_bucket_ar16", (k_bucket_ar16<KMAX>), e->S, e->X, O, in, status);
 }
 template <int KMAX>
 void launch_bucket_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t* bcoord,
@@ -435,6 +447,15 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     e->lds_recs_max = X.lds_recs;
     e->lds_recs_hw = (int32_t)std::max<int64_t>(want, std::min<int64_t>(lds_cap, (int64_t)GPX_BUCKET_ITEMS * e->bucket_threads));
   }
+  { /* 16-byte vote records: kmax votes per group of a full round + 25 %; the hardware limit beyond */
+    const int64_t cap16 = ((int64_t)160 * 1024 - 1024 - (int64_t)X.gb * 8) / 16;
+    int64_t want = (int64_t)cfg->kmax * X.gb;
+    want += want / 4 + 128;
+    e->lds16_max = (int32_t)std::min<int64_t>(want, cap16);
+    e->lds16_hw = (int32_t)cap16;
+    const char* leg = getenv("GPX_AR_LEGACY");
+    e->ar16 = X.shift <= V16_MAX_SHIFT && e->bucket_threads == X.gb && !(leg && atoi(leg));
+  }
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
   const size_t bucket_lds_hw = GPX_BUCKET_LDS_BYTES(X.gb, e->lds_recs_hw) + e->lds_pad;
@@ -450,6 +471,13 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
                          (const void*)k_bucket_prepare_reply<16, 64>};
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_hw));
+  }
+  if (e->ar16) {
+    const size_t hw16 = GPX_BUCKET16_LDS_BYTES(X.gb, e->lds16_hw) + e->lds_pad;
+    const void* fns[] = {(const void*)k_bucket_ar16<4>, (const void*)k_bucket_ar16<8>,
+                         (const void*)k_bucket_ar16<16>};
+    for (const void* f : fns)
+      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
   }
   { /* k_hist may take up to GPX_HSUB_MAX histograms of dynamic LDS */
     const int hl = GPX_HSUB_MAX * X.nbk * (int)sizeof(int32_t);
@@ -611,23 +639,49 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
                                  {max_cp, b4}, {status, (size_t)n}});
   front_hist(e, n, gidx, status, 1);
   const int ntiles = ntiles_for(n);
-  if (aligned16({gidx, bnum, bcoord, slot, acceptor, max_cp}))
-    LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
-             ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-  else
-    LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
-             ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-  begin_back(e, fs, n);
-  if (e->cfg.kmax <= 4)
-    launch_bucket_ar<4>(e, status);
-  else if (e->cfg.kmax <= 8)
-    launch_bucket_ar<8>(e, status);
-  else
-    launch_bucket_ar<16>(e, status);
-  LAUNCH(e, "k_emit_dec", k_emit_dec, e->X.nbk, e->X, d_gidx, d_slot, d_bnum, d_bcoord,
+  const bool vec = aligned16({gidx, bnum, bcoord, slot, acceptor, max_cp});
+  if (e->ar16) {
+    /* 16-byte vote records (gpx_ar16.hip.h); the back end may re-read bnum / bcoord / acceptor */
+    if (vec)
+      LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+    else
+      LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+    begin_back(e, fs, n, true);
+    const size_t N = (size_t)e->cfg.max_batch;
+    int32_t* o32 = (int32_t*)e->X.o_rec; /* N x 32 bytes: five int columns + one byte column */
+    const Stage16 O{o32, o32 + N, o32 + 2 * N, o32 + 3 * N, o32 + 4 * N, (uint8_t*)(o32 + 5 * N)};
+    const VoteCols in{bnum, bcoord, acceptor};
+    if (e->cfg.kmax <= 4)
+      launch_bucket_ar16<4>(e, O, in, status);
+    else if (e->cfg.kmax <= 8)
+      launch_bucket_ar16<8>(e, O, in, status);
+    else
+      launch_bucket_ar16<16>(e, O, in, status);
+    LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord,
            d_median_cp, d_kind, n_out, &e->X.counters[1]);
+  } else {
+    if (vec)
+      LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+    else
+      LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+    begin_back(e, fs, n);
+    if (e->cfg.kmax <= 4)
+      launch_bucket_ar<4>(e, status);
+    else if (e->cfg.kmax <= 8)
+      launch_bucket_ar<8>(e, status);
+    else
+      launch_bucket_ar<16>(e, status);
+    LAUNCH(e, "k_emit_dec", k_emit_dec, e->X.nbk, e->X, d_gidx, d_slot, d_bnum, d_bcoord,
+           d_median_cp, d_kind, n_out, &e->X.counters[1]);
+  }
+  /* the back end reads three input columns again (ESC votes): they count as buffers it touches */
   end_call(e, fs, {{d_gidx, b4}, {d_slot, b4}, {d_bnum, b4}, {d_bcoord, b4}, {d_median_cp, b4},
-                   {d_kind, (size_t)n}, {n_out, 4}, {status, (size_t)n}});
+                   {d_kind, (size_t)n}, {n_out, 4}, {status, (size_t)n}, {bnum, b4}, {bcoord, b4},
+                   {acceptor, b4}});
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }

@@ -996,9 +996,9 @@ __device__ __forceinline__ void coord_preload_ring(const DevState& S, int32_t g,
 /* PaxosInstanceStateMachine.handleAcceptReply (PISM:1248-1364) ->              */
 /* PaxosCoordinator.handleAcceptReply (PaxosCoordinator.java:210-250) ->        */
 /* PaxosCoordinatorState.handleAcceptReplyMyBallot / HigherBallot (:597-683)    */
-template <int KMAX>
+template <int KMAX, class IT>
 __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScratch& X, int32_t g,
-                                               GroupIter& it, uint8_t* __restrict__ status,
+                                               IT& it, uint8_t* __restrict__ status,
                                                const CoordPre<KMAX>& P) {
   const int32_t G = S.G;
   const uint32_t gf = P.gf;

@@ -1,0 +1,89 @@
+"""Full-size parity: the HIP engine against the CPU oracle at BASELINE.json's sizes — 1,000,000
+groups (3,907 buckets: the partition regime bench.py runs in), the config #3 / #4 / #5 streams, and
+4 M groups (buckets of 1024 groups).  Bit-exact: the decided (group, slot, ballot,
+medianCheckpointedSlot, kind) stream in order, every per-vote status, every HotRestoreInfo row and
+the counters.  Follows PaxosInstanceStateMachine.handleBatchedAcceptReply (PISM:1370-1419) ->
+PaxosCoordinatorState.handleAcceptReplyMyBallot (PCS:597-640) as restated in oracle/gpx_oracle.cpp."""
+import numpy as np
+import pytest
+
+from gigapaxos_amd import Engine, hri_create, streams, S_OK, S_NOGROUP, D_DECISION
+from tests.parity_common import make_pair, assert_same_state, churn_run
+
+pytestmark = pytest.mark.gpu
+
+
+def _same(dh, do, what):
+    a, b = dh.as_tuple_array(), do.as_tuple_array()
+    assert a.shape == b.shape, f"{what}: {a.shape} vs {b.shape}"
+    assert (a == b).all(), f"{what}: first difference at row {int(np.nonzero((a != b).any(1))[0][0])}"
+    assert (dh.status == do.status).all(), f"{what}: per-vote status"
+
+
+def _vote_stream_parity(hip_lib, oracle_lib, G, k, mix, R, big_ids=False):
+    members = list(range(100, 100 + k))
+    if big_ids:  # node ids outside 16 bits and negative: the 16-byte vote record's escape path
+        members = [-7, 100, 70000, 1 << 30, (1 << 31) - 1][:k]
+    me = members[1]
+    nv = G * k + (G * k // 50 if mix else 0)
+    eh, eo = make_pair(hip_lib, oracle_lib, me, G, k, 8, max_batch=nv + 4096)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, me)) == S_OK).all()
+    g = np.arange(G, dtype=np.int32)
+    for r in range(R):
+        for x, y in zip(eh.propose(g), eo.propose(g)):
+            assert (x == y).all()
+        cols = streams.vote_round(G, members, r, me, config_id=3 if k == 3 else 4, mix=mix)
+        dh, do = eh.accept_reply(*cols), eo.accept_reply(*cols)
+        _same(dh, do, f"round {r}")
+        if not mix:
+            assert dh.gidx.shape[0] == G and (dh.kind == D_DECISION).all()
+    sh, so = eh.snapshot(g)[0], eo.snapshot(g)[0]
+    assert sh.tobytes() == so.tobytes()
+    assert_same_state(eh, eo, np.random.default_rng(G + k).integers(0, G, 48))
+    assert eh.counters() == eo.counters()
+    eh.close()
+    eo.close()
+
+
+@pytest.mark.parametrize("k,mix", [(3, False), (3, True), (5, True)])
+def test_config3_config4_streams_1m_groups_vs_oracle(hip_lib, oracle_lib, k, mix):
+    """BASELINE config #3 (K = 3: clean and adversarial mix) and the config #4 stream (K = 5, mix)
+    at 1 M groups per engine: 3 M / 5 M shuffled votes per round against the oracle."""
+    _vote_stream_parity(hip_lib, oracle_lib, 1_000_000, k, mix, R=3)
+
+
+def test_config3_stream_4m_groups_vs_oracle(hip_lib, oracle_lib):
+    """4 M groups on one engine: buckets of 1024 groups (several partition levels / groups per lane
+    depending on the build) - same stream, same oracle."""
+    _vote_stream_parity(hip_lib, oracle_lib, 4_000_000, 3, True, R=2)
+
+
+def test_vote_stream_wide_node_ids_vs_oracle(hip_lib, oracle_lib):
+    """Node ids that do not fit the compact vote record (negative, > 65535, Integer.MAX_VALUE) and
+    ballots other than the batch's common one: the record's escape path re-reads the caller's
+    columns; decisions must not change."""
+    _vote_stream_parity(hip_lib, oracle_lib, 200_000, 5, True, R=3, big_ids=True)
+
+
+def test_config5_churn_1m_live_groups_vs_oracle(hip_lib, oracle_lib):
+    """BASELINE config #5's churn (create / delete mid-run, rows reused, late votes for retired
+    groups dropped) with 1 M live groups of 5 replicas on one engine."""
+    G_live, R, k = 1_000_000, 3, 5
+    cap = G_live + 4 * (G_live // 1000)
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, cap, k, 8, max_batch=(G_live + G_live // 500) * k + 4096)
+    (oh, oo), _ = churn_run([eh, eo], G_live, cap, R, k, seed=7, churn_frac=0.001)
+    for r, (a, b) in enumerate(zip(oh, oo)):
+        for x, y, nm in zip(a, b, ("decisions", "vote status", "propose out", "propose status",
+                                    "retired rows", "retire status", "create status")):
+            if isinstance(x, bytes):
+                assert x == y, f"round {r} {nm}"
+            else:
+                assert x.shape == y.shape and (x == y).all(), f"round {r} {nm}"
+        assert a[0].shape[0] == G_live
+        if r > 0:
+            assert (a[1] == S_NOGROUP).sum() == k * (G_live // 1000)
+    sh, so = eh.snapshot(np.arange(cap))[0], eo.snapshot(np.arange(cap))[0]
+    assert sh.tobytes() == so.tobytes()
+    assert eh.counters() == eo.counters()
