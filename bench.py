@@ -46,8 +46,9 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline leg (0 = every host core)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the engine-vs-oracle replay of the CPU sample")
     ap.add_argument("--cpu-mt-passes", type=int, default=16, help="passes over the sample in the multi-threaded leg")
-    ap.add_argument("--serial", action="store_true",
-                    help="no cross-call pipelining: every kernel of every call in order on one stream")
+    ap.add_argument("--pipelined", action="store_true",
+                    help="cross-call pipelining (front end of call N+1 beside the back end of call N on two "
+                         "streams); off by default: measured slower than one stream since round 2")
     args = ap.parse_args()
 
     import torch
@@ -80,7 +81,7 @@ def main():
     eng.set_stream(tstream.cuda_stream)
     # pipelined mode (include/gpx.h): the partition front end of call N+1 overlaps the per-bucket
     # back end of call N on two engine streams; group state is still updated in call order
-    eng.set_pipeline(not args.serial)
+    eng.set_pipeline(args.pipelined)
     mem = np.tile(np.array(members, np.int32), (G, 1))
     assert (eng.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
 
@@ -344,7 +345,7 @@ def main():
             "votes_per_sec": round(votes_total / elapsed, 1),
             "votes_per_sec_per_gpu": round(votes_total / elapsed / world, 1),
             "gpu_ms_per_step_rank0": round(gpu_ms / steps, 4),
-            "pipelined": not args.serial,
+            "pipelined": bool(args.pipelined),
             "roofline": roofline,
             "cpu_baseline": cpu_baseline,
             "parity_checked": parity_checked,

@@ -1,0 +1,132 @@
+/*
+ * gpx_direct.hip.h — ACCEPT and COMMIT batches that arrive grouped by group (round 2).
+ *
+ * Inside the pipeline a batch is usually the previous stage's output: ACCEPTs follow the proposal
+ * batch (gidx ascending), commits are the decisions, which leave the accept-reply call grouped by
+ * gidx ascending (include/gpx.h ORDER).  k_order_check<false> recognises such a batch on the device
+ * (gidx in range and non-decreasing) and these kernels then apply it WITHOUT the bucket partition:
+ * one lane per record; the lane of the first record of a group's run replays the whole run in array
+ * order through the same per-group functions as the per-bucket kernels (apply_accept_group /
+ * apply_commit_group: PISM.handleAccept PISM:1080-1166, handleBatchedCommit / handleCommittedRequest
+ * PISM:1432-1528 -> extractExecuteAndCheckpoint PISM:1619-1701).  Consecutive lanes own ascending
+ * groups, so the state accesses of a dense batch are coalesced.  Anything else falls back to the
+ * partition path, which is launched behind these kernels and returns at once for an ordered batch
+ * (device-side choice on *X.unsorted, like the proposal path).
+ *
+ * Compacted outputs (execution runs): a record produces at most one run; it is parked at the
+ * record's own index (st_count == 0: none) and counted per 1024-record chunk; k_emit_runs_direct
+ * compacts chunk by chunk - record order is already the output order (gidx ascending, a group's
+ * entries in array order).
+ */
+#pragma once
+#include "gpx_kernels.hip.h"
+
+#define GPX_DCHUNK_SHIFT 10
+#define GPX_DCHUNK (1 << GPX_DCHUNK_SHIFT)
+
+struct DirectStage {
+  int32_t *st_first, *st_count; /* [n] run parked at the record that produced it */
+  int32_t* chunk_cnt;           /* [ceil(n / 1024)] runs per chunk; zeroed before the call */
+};
+
+/* the run of records of one group in a gidx-ordered batch, with GroupIter's interface */
+struct RunIter {
+  const int32_t *gidx, *bnum, *bcoord, *slot, *median;
+  const uint8_t* flags;
+  DirectStage D;
+  int32_t n, i, g, cur, chunk, local;
+  __device__ __forceinline__ bool next(Rec& out) {
+    if (i >= n || gidx[i] != g) return false;
+    cur = i;
+    out.idx = i;
+    out.a = slot[i];
+    out.b = median[i];
+    out.c = flags ? (int32_t)flags[i] : 0;
+    out.bnum = bnum[i];
+    out.bcoord = bcoord[i];
+    D.st_count[i] = 0;
+    i++;
+    return true;
+  }
+  __device__ __forceinline__ void emit(int32_t, int32_t first, int32_t count, int32_t, int32_t) {
+    D.st_first[cur] = first;
+    D.st_count[cur] = count; /* > 0 */
+    if ((cur >> GPX_DCHUNK_SHIFT) == chunk)
+      local++;
+    else
+      atomicAdd(&D.chunk_cnt[cur >> GPX_DCHUNK_SHIFT], 1); /* a run reaching into the next chunk: rare */
+  }
+};
+
+template <bool COMMIT>
+__global__ __launch_bounds__(GPX_DCHUNK) void k_ac_direct(
+    DevState S, DevScratch X, int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
+    const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot, const int32_t* __restrict__ median,
+    const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
+    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status,
+    DirectStage D) {
+  if (*X.unsorted == X.epoch) return; /* not ordered: the partition path does it */
+  const int32_t i = (int32_t)blockIdx.x * GPX_DCHUNK + (int32_t)threadIdx.x;
+  int32_t local = 0;
+  if (i < n) {
+    const int32_t g = gidx[i];
+    if (i == 0 || gidx[i - 1] != g) { /* head of its group's run */
+      RunIter it;
+      it.gidx = gidx;
+      it.bnum = bnum;
+      it.bcoord = bcoord;
+      it.slot = slot;
+      it.median = median;
+      it.flags = flags;
+      it.D = D;
+      it.n = n;
+      it.i = i;
+      it.g = g;
+      it.cur = i;
+      it.chunk = (int32_t)blockIdx.x;
+      it.local = 0;
+      if (COMMIT)
+        apply_commit_group(S, X, g, it, status);
+      else
+        apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+      local = it.local;
+    }
+  }
+  /* this chunk's own runs: one atomic per workgroup */
+  __shared__ int32_t wsum[GPX_DCHUNK / 64];
+  int32_t x = local;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = x;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int32_t tot = 0;
+    for (int w = 0; w < GPX_DCHUNK / 64; w++) tot += wsum[w];
+    if (tot) atomicAdd(&D.chunk_cnt[blockIdx.x], tot);
+  }
+}
+
+/* parked runs -> the caller's dense columns, chunk by chunk in record order */
+__global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, int32_t n,
+                                                                const int32_t* __restrict__ gidx, DirectStage D,
+                                                                int32_t* __restrict__ x_gidx,
+                                                                int32_t* __restrict__ x_first,
+                                                                int32_t* __restrict__ x_count,
+                                                                int32_t* total_out) {
+  if (*X.unsorted == X.epoch) return; /* the partition path (k_emit_runs) writes the outputs */
+  const int32_t w = (int32_t)blockIdx.x;
+  int32_t before = 0;
+  for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) before += D.chunk_cnt[t];
+  int32_t pre;
+  block_exscan_n<GPX_DCHUNK>(before, &pre);
+  const int32_t i = w * GPX_DCHUNK + (int32_t)threadIdx.x;
+  const int32_t cnt = i < n ? D.st_count[i] : 0;
+  int32_t tot;
+  const int32_t ex = block_exscan_n<GPX_DCHUNK>(cnt != 0 ? 1 : 0, &tot);
+  if (cnt != 0) {
+    x_gidx[pre + ex] = gidx[i];
+    x_first[pre + ex] = D.st_first[i];
+    x_count[pre + ex] = cnt;
+  }
+  if (w == (int32_t)gridDim.x - 1 && threadIdx.x == 0 && total_out) *total_out = pre + tot;
+}

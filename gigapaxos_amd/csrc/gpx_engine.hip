@@ -18,6 +18,7 @@
 
 #include "gpx_kernels.hip.h"
 #include "gpx_ar16.hip.h"
+#include "gpx_direct.hip.h"
 #include "gpx_wire.hip.h"
 #include "gpx_elect.hip.h"
 
@@ -64,6 +65,7 @@ struct gpx_engine {
     int32_t *bucket_tot = nullptr, *tile_rel = nullptr, *bucket_off = nullptr;
     Rec* rec = nullptr;
     uint32_t* unsorted = nullptr;
+    int32_t* chunk_cnt = nullptr; /* direct path (gpx_direct.hip.h): runs per 1024-record chunk */
     hipEvent_t evF = nullptr, evB = nullptr;
     bool used = false;
   } fs[2];
@@ -306,7 +308,10 @@ void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, 
                 int check_order = 0) {
   const int ntiles = ntiles_for(n);
   /* one histogram workgroup per `hsub` scatter tiles: about one workgroup per CU */
-  int hsub = std::max(1, std::min(GPX_HSUB_MAX, (ntiles + 127) / 245));
+  /* (measured: 5 sub-tiles per histogram workgroup for 3 M votes - fewer returning atomics per bucket
+   * word, and the slices of a workgroup's sub-tiles are adjacent in every bucket region, which the
+   * scatter's L2 likes: k_scatter_ar16 53 -> 49 us) */
+  int hsub = std::max(1, std::min(GPX_HSUB_MAX, (ntiles + 75) / 150));
   if (const char* hs = getenv("GPX_HSUB")) hsub = std::max(1, std::min(GPX_HSUB_MAX, atoi(hs))); /* tuning */
   const int nsuper = (ntiles + hsub - 1) / hsub;
   const size_t lds = (size_t)hsub * e->X.nbk * sizeof(int32_t);
@@ -322,15 +327,17 @@ void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, 
 void launch_scatter_ac(gpx_engine* e, int32_t n, const int32_t* gidx, const int32_t* bnum,
                        const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
                        const uint8_t* flags, int32_t* r_bnum, int32_t* r_bcoord, int32_t* r_maxcp,
-                       uint8_t* r_flags) {
+                       uint8_t* r_flags, int32_t only_unsorted = 0) {
   const int ntiles = ntiles_for(n);
   const bool vec = aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)flags & 3);
   if (vec)
     LAUNCH_F(e, "k_scatter_ac", k_scatter_ac<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
-             e->S.G, e->X, gidx, bnum, bcoord, slot, median_cp, flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+             e->S.G, e->X, gidx, bnum, bcoord, slot, median_cp, flags, r_bnum, r_bcoord, r_maxcp, r_flags,
+             only_unsorted);
   else
     LAUNCH_F(e, "k_scatter_ac", k_scatter_ac<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
-             e->S.G, e->X, gidx, bnum, bcoord, slot, median_cp, flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+             e->S.G, e->X, gidx, bnum, bcoord, slot, median_cp, flags, r_bnum, r_bcoord, r_maxcp, r_flags,
+             only_unsorted);
 }
 
 int check_batch(gpx_engine* h, int32_t n) {
@@ -425,7 +432,10 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   /* buckets of 256 groups (one lane per group, whole bucket staged in LDS, 4 workgroups per
    * CU); beyond 1M groups the buckets grow so that there are at most GPX_MAX_BUCKETS */
   auto nbk_for = [&](int sh) { return (int64_t)((G + ((size_t)1 << sh) - 1) >> sh); };
-  X.shift = GPX_MIN_SHIFT;
+  /* 512 groups per bucket where the group count allows at least a few hundred buckets (measured on
+   * MI355X, 1 M groups: 3 M votes partition 10 % faster over 1,954 buckets than over 3,907 and the
+   * per-bucket kernels run as fast with 512 lanes as with 256); small tables keep 256 */
+  X.shift = nbk_for(GPX_MIN_SHIFT + 1) >= 256 ? GPX_MIN_SHIFT + 1 : GPX_MIN_SHIFT;
   while (nbk_for(X.shift) > GPX_MAX_BUCKETS) X.shift++;
   if (const char* sh = getenv("GPX_BUCKET_SHIFT")) { /* tuning knob */
     const int v = atoi(sh);
@@ -492,6 +502,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     A(f.bucket_off, (size_t)X.nbk + 1, true);
     A(f.rec, N, false);
     A(f.unsorted, 1, true);
+    A(f.chunk_cnt, N / GPX_DCHUNK + 2, true);
   }
   X.bucket_tot = e->fs[0].bucket_tot;
   X.tile_rel = e->fs[0].tile_rel;
@@ -702,9 +713,26 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {median_cp, b4},
                                  {a_flags, (size_t)n}, {r_bnum, b4}, {r_bcoord, b4}, {r_maxcp, b4},
                                  {r_flags, (size_t)n}, {status, (size_t)n}});
-  front_hist(e, n, gidx, status, 0);
-  launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+  /* a batch grouped by group (gidx non-decreasing, in range) is applied directly; anything else is
+   * partitioned first.  Device-side choice: both back ends are launched, one of them returns at once. */
+  const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
+  int32_t* st32 = (int32_t*)e->X.o_rec; /* the two paths never both stage outputs: shared scratch */
+  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt};
+  LAUNCH_F(e, "k_order_check", k_order_check<false>, (n + GPX_FBLOCK * 8 - 1) / (GPX_FBLOCK * 8), 0, n, gidx,
+           e->S.G, e->X, status, D.chunk_cnt, nchunks);
+  front_hist(e, n, gidx, status, 0, 2);
+  launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, 1);
   begin_back(e, fs, n);
+  {
+    LaunchScope _ls(e, "k_ac_direct");
+    hipLaunchKernelGGL(k_ac_direct<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
+                       bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D);
+  }
+  {
+    LaunchScope _ls(e, "k_emit_runs_direct");
+    hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
+                       x_gidx, x_first, x_count, n_runs);
+  }
   LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags,
            status);
   LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
@@ -728,9 +756,26 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const size_t b4 = (size_t)n * 4;
   const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {median_cp, b4},
                                  {c_kind, (size_t)n}, {status, (size_t)n}});
-  front_hist(e, n, gidx, status, 0);
-  launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, c_kind, nullptr, nullptr, nullptr, nullptr);
+  /* decisions leave the accept-reply call grouped by gidx: such a commit batch is applied directly */
+  const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
+  int32_t* st32 = (int32_t*)e->X.o_rec;
+  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt};
+  LAUNCH_F(e, "k_order_check", k_order_check<false>, (n + GPX_FBLOCK * 8 - 1) / (GPX_FBLOCK * 8), 0, n, gidx,
+           e->S.G, e->X, status, D.chunk_cnt, nchunks);
+  front_hist(e, n, gidx, status, 0, 2);
+  launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, c_kind, nullptr, nullptr, nullptr, nullptr, 1);
   begin_back(e, fs, n);
+  {
+    LaunchScope _ls(e, "k_ac_direct");
+    hipLaunchKernelGGL(k_ac_direct<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
+                       bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
+                       (int32_t*)nullptr, (uint8_t*)nullptr, status, D);
+  }
+  {
+    LaunchScope _ls(e, "k_emit_runs_direct");
+    hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
+                       x_gidx, x_first, x_count, n_runs);
+  }
   LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
   LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   end_call(e, fs, {{status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
@@ -749,7 +794,11 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   const size_t b4 = (size_t)n * 4;
   const int fs = begin_front(e, {{gidx, b4}, {is_stop, (size_t)n}, {handle, b4 * 2}, {slot, b4}, {bnum, b4},
                                  {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
-  front_hist(e, n, gidx, status, 0, 1);
+  /* order check + status prefill (one pass over gidx); the partition front end only does work for a
+   * batch that is NOT strictly ascending */
+  LAUNCH_F(e, "k_order_check", k_order_check<true>, (n + GPX_FBLOCK * 8 - 1) / (GPX_FBLOCK * 8), 0, n, gidx,
+           e->S.G, e->X, status, (int32_t*)nullptr, 0);
+  front_hist(e, n, gidx, status, 0, 2);
   const int ntiles = ntiles_for(n);
   LAUNCH_F(e, "k_scatter_pr", k_scatter_pr, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
            e->S.G, e->X,

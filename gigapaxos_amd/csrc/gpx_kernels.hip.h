@@ -303,6 +303,9 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
   const int32_t nsuper = (ntiles + hsub - 1) / hsub;
   const int32_t st = tile_of_block(nsuper);
   if (st >= nsuper) return;
+  /* check_order == 2: fallback pass of a proposal batch - k_propose_check has already judged the
+   * order; a strictly ascending batch is applied by k_propose_direct and needs no partition */
+  if (check_order == 2 && *X.unsorted != X.epoch) return;
   for (int32_t b = threadIdx.x; b < hsub * X.nbk; b += GPX_FBLOCK) lds[b] = 0;
   __syncthreads();
   const int64_t base = (int64_t)st * hsub * GPX_TILE;
@@ -310,7 +313,7 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
   int32_t bad = 0;
   for (int sub = 0; sub < hsub; sub++)
     bad += tile_histogram<VEC>(n, base + (int64_t)sub * GPX_TILE, gidx, G, X.shift, lds + sub * X.nbk);
-  if (check_order) {
+  if (check_order == 1) {
     /* strictly ascending, in-range gidx = every group at most once: such a batch needs no
      * regrouping (k_propose_direct); anything else marks the call's epoch in *X.unsorted */
     bool out_of_order = bad != 0;
@@ -486,10 +489,11 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ac(
     const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord,
     const int32_t* __restrict__ slot, const int32_t* __restrict__ median_cp,
     const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
-    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags) {
+    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, int32_t only_unsorted) {
   extern __shared__ int32_t lds[];
   const int32_t tile = tile_of_block(ntiles);
   if (tile >= ntiles) return;
+  if (only_unsorted && *X.unsorted != X.epoch) return; /* ordered batch: applied directly (gpx_direct.hip.h) */
   scatter_init(X, tile, lds);
   const int64_t base = (int64_t)tile * GPX_TILE;
   const int32_t mask = X.gb - 1;
@@ -946,6 +950,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_runs(DevScratch X, int32_t* 
                                                         int32_t* __restrict__ x_first,
                                                         int32_t* __restrict__ x_count,
                                                         int32_t* total_out) {
+  if (*X.unsorted != X.epoch) return; /* ordered batch: k_emit_runs_direct wrote the outputs */
   const int32_t out0 = emit_base(X, total_out, nullptr);
   const int32_t nd = X.bucket_nout[blockIdx.x];
   const Out* src = X.o_rec + X.bucket_off[blockIdx.x];
@@ -1006,9 +1011,12 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
     /* PaxosManager.java:1162-1194 / PaxosInstanceStateMachine.java:456-460: dropped */
     const uint8_t st = (gf & GF_EXISTS) ? GPX_S_STOPPED : GPX_S_NOGROUP;
     Rec r;
-    while (it.next(r))
+    unsigned long long nd = 0;
+    while (it.next(r)) {
       if (status) status[r.idx] = st;
-    atomicAdd(&X.counters[2], (unsigned long long)it.c); /* rare path */
+      nd++;
+    }
+    atomicAdd(&X.counters[2], nd); /* rare path */
     return;
   }
   const int32_t k = (int32_t)GF_K(gf);
@@ -1264,8 +1272,9 @@ __device__ __forceinline__ void acc_store(const DevState& S, int32_t g, uint32_t
 }
 
 /* PaxosInstanceStateMachine.handleAccept (PISM:1080-1166) */
+template <class IT>
 __device__ __forceinline__ void apply_accept_group(
-    const DevState& S, const DevScratch& X, int32_t g, GroupIter& it, int32_t* __restrict__ r_bnum,
+    const DevState& S, const DevScratch& X, int32_t g, IT& it, int32_t* __restrict__ r_bnum,
     int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
     uint8_t* __restrict__ status) {
   const uint32_t gf = S.g_flags[g];
@@ -1346,6 +1355,7 @@ __global__ __launch_bounds__(1024) void k_bucket_accept(
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
+  if (*X.unsorted != X.epoch) return; /* ordered batch: k_ac_direct did it; nothing was partitioned */
   if (!bucket_prepare(X, lds, &bv, []() {})) return;
   const int32_t g0 = blockIdx.x << X.shift;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
@@ -1364,8 +1374,9 @@ __global__ __launch_bounds__(1024) void k_bucket_accept(
 
 /* PaxosInstanceStateMachine.handleBatchedCommit (PISM:1480-1528) per slot and
  * handleCommittedRequest (:1432-1478) for full decisions */
+template <class IT>
 __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevScratch& X,
-                                                   int32_t g, GroupIter& it,
+                                                   int32_t g, IT& it,
                                                    uint8_t* __restrict__ status) {
   const uint32_t gf = S.g_flags[g];
   AccState a;
@@ -1416,6 +1427,7 @@ __global__ __launch_bounds__(1024) void k_bucket_commit(DevState S, DevScratch X
                                                         uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   BucketView bv;
+  if (*X.unsorted != X.epoch) return; /* ordered batch: k_ac_direct did it; nothing was partitioned */
   if (!bucket_prepare(X, lds, &bv, []() {})) return;
   const int32_t g0 = blockIdx.x << X.shift;
   for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
@@ -1589,6 +1601,51 @@ __global__ __launch_bounds__(1024) void k_bucket_propose(
   }
 }
 
+
+/* Order check of a batch: is the gidx column in range and strictly ascending (STRICT: every group at
+ * most once - proposals) or non-decreasing (the records of a group adjacent and groups ascending -
+ * what the previous stage of the pipeline emits: decisions leave grouped by gidx, ACCEPTs follow the
+ * proposal batch)?  Such a batch needs no partition.  Reads the column once (16-byte loads when
+ * aligned), pre-fills the status column and raises the call's epoch in *X.unsorted otherwise. */
+template <bool STRICT>
+__global__ __launch_bounds__(GPX_FBLOCK) void k_order_check(int32_t n, const int32_t* __restrict__ gidx,
+                                                           int32_t G, DevScratch X,
+                                                           uint8_t* __restrict__ status,
+                                                           int32_t* __restrict__ zero, int32_t nzero) {
+  const int64_t i0 = ((int64_t)blockIdx.x * GPX_FBLOCK + threadIdx.x) * 8;
+  if (zero && i0 / 8 < nzero) zero[i0 / 8] = 0; /* nzero <= ceil(n / 8): the grid covers it */
+  bool bad = false;
+  if (i0 < n) {
+    int32_t g[9];
+    const bool full = i0 + 8 < n; /* all eight and the successor of the last one exist */
+    if (full && !((uintptr_t)gidx & 15)) {
+      const I4 a = *(const I4*)(gidx + i0), b = *(const I4*)(gidx + i0 + 4);
+      g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
+      g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
+      g[8] = gidx[i0 + 8];
+    } else {
+#pragma unroll
+      for (int q = 0; q < 9; q++) g[q] = (i0 + q < n) ? gidx[i0 + q] : INT32_MAX;
+    }
+    unsigned long long stw = 0;
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (i0 + q < n) {
+        const bool oob = (uint32_t)g[q] >= (uint32_t)G;
+        bad |= oob || (i0 + q + 1 < n && (STRICT ? g[q] >= g[q + 1] : g[q] > g[q + 1]));
+        if (oob) stw |= (unsigned long long)GPX_S_NOGROUP << (8 * q);
+      }
+    }
+    if (!status) {
+    } else if (full && !((uintptr_t)status & 7)) {
+      *(unsigned long long*)(status + i0) = stw; /* GPX_S_OK == 0 */
+    } else {
+      for (int q = 0; q < 8; q++)
+        if (i0 + q < n) status[i0 + q] = (uint8_t)(stw >> (8 * q));
+    }
+  }
+  if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
+}
 
 /* Proposal batch whose gidx column is strictly ascending (every group at most once - what
  * RequestBatcher produces: one batched request per group per dequeue, RequestBatcher.java:79-81):

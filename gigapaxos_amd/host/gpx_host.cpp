@@ -10,8 +10,10 @@
 #include <chrono>
 #include <condition_variable>
 #include <cstdio>
+#include <cerrno>
 #include <cstring>
 #include <mutex>
+#include <stdexcept>
 #include <thread>
 
 namespace gpx {
@@ -31,6 +33,8 @@ void put64(Frame& f, int64_t v) {
   for (int s = 56; s >= 0; s -= 8) f.push_back((uint8_t)((uint64_t)v >> s));
 }
 int32_t jsub32(int32_t a, int32_t b) { return (int32_t)((uint32_t)a - (uint32_t)b); } /* Java int a - b */
+/* Ballot.compareTo (paxosutil/Ballot.java:60-73) */
+int32_t ballotCmp(int32_t n1, int32_t c1, int32_t n2, int32_t c2) { return n1 != n2 ? jsub32(n1, n2) : jsub32(c1, c2); }
 int32_t get32(const uint8_t* p) {
   return (int32_t)(((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]);
 }
@@ -96,6 +100,7 @@ struct FileLogger::Impl {
   std::condition_variable cv;
   std::deque<std::pair<uint64_t, std::vector<uint8_t>>> queue; /* (ticket, the batch's bytes) */
   std::atomic<uint64_t> durable{0};
+  std::atomic<bool> failed{false}; /* a write or fdatasync failed: nothing after it is durable */
   uint64_t next = 1;
   bool stop = false;
   std::thread worker;
@@ -109,19 +114,40 @@ struct FileLogger::Impl {
         job = std::move(queue.front());
         queue.pop_front();
       }
+      /* a batch is durable only when every byte was written AND fdatasync succeeded; EINTR is
+       * retried; any other failure latches `failed` and `durable` never moves again, so the manager
+       * stops releasing the replies it holds (reply-after-log, AbstractPaxosLogger.java:691-715) */
       size_t off = 0;
-      while (fd >= 0 && off < job.second.size()) {
+      bool ok = fd >= 0 && !failed.load(std::memory_order_acquire);
+      while (ok && off < job.second.size()) {
         const ssize_t w = ::write(fd, job.second.data() + off, job.second.size() - off);
-        if (w <= 0) break;
+        if (w < 0 && errno == EINTR) continue;
+        if (w <= 0) {
+          ok = false;
+          break;
+        }
         off += (size_t)w;
       }
-      if (fd >= 0) ::fdatasync(fd);
+      while (ok) {
+        if (::fdatasync(fd) == 0) break;
+        if (errno != EINTR) ok = false;
+      }
+      if (!ok) {
+        failed.store(true, std::memory_order_release);
+        continue; /* keep draining the queue so that the destructor can join; nothing becomes durable */
+      }
       durable.store(job.first, std::memory_order_release);
     }
   }
 };
 FileLogger::FileLogger(const std::string& path) : impl_(new Impl) {
   impl_->fd = ::open(path.c_str(), O_WRONLY | O_CREAT | O_APPEND, 0644);
+  if (impl_->fd < 0) {
+    const int err = errno;
+    delete impl_;
+    impl_ = nullptr;
+    throw std::runtime_error("FileLogger: cannot open " + path + ": " + std::strerror(err));
+  }
   impl_->worker = std::thread([this] { impl_->run(); });
 }
 FileLogger::~FileLogger() {
@@ -151,6 +177,7 @@ uint64_t FileLogger::logBatch(const std::vector<const Frame*>& recs) {
   return t;
 }
 uint64_t FileLogger::durable() { return impl_->durable.load(std::memory_order_acquire); }
+bool FileLogger::failed() const { return impl_->failed.load(std::memory_order_acquire); }
 
 int32_t javaStringHash(const std::string& s) {
   uint32_t h = 0;
@@ -427,7 +454,8 @@ void PaxosManager::forgetRow(int32_t g) {
     a = (int32_t)(a->first >> 32) == g ? accepted_.erase(a) : std::next(a);
   for (auto a = syncAsked_.begin(); a != syncAsked_.end();)
     a = (int32_t)(a->first >> 32) == g ? syncAsked_.erase(a) : std::next(a);
-  for (auto* m : {&preactive_, &carried_})
+  for (auto c = carried_.lower_bound({g, INT32_MIN}); c != carried_.end() && c->first.first == g;) c = carried_.erase(c);
+  for (auto* m : {&preactive_})
     for (auto a = m->lower_bound({g, INT64_MIN}); a != m->end() && a->first.first == g;) a = m->erase(a);
   liveAccepts_[(size_t)g] = 0;
 }
@@ -781,6 +809,7 @@ bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector
   std::vector<int32_t> g, acc, rb, rc, fs, off(1, 0), ps, pb, pc;
   std::vector<int64_t> ph;
   std::vector<uint8_t> pfl;
+  std::vector<Frame> pvFrames; /* frame of pvalue entry j (parallel to ps / pb / pc) */
   for (auto& f : replies) {
     const size_t idLen = f.size() > 12 ? f[12] : 0;
     size_t p = 13 + idLen;
@@ -808,7 +837,7 @@ bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector
         bool noop = false;
         const bool stop = frameIsStop(pv, &noop);
         pfl.push_back((uint8_t)((stop ? GPX_PV_STOP : 0) | (noop ? GPX_PV_NOOP : 0)));
-        carried_[{gi, rq.requestID}] = std::move(pv);
+        pvFrames.push_back(std::move(pv));
       }
       p += 16 + (size_t)len;
     }
@@ -827,10 +856,26 @@ bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector
              "gpx_prepare_reply_batch"))
     return false;
   stats_.engine_calls++;
+  auto purgeCarried = [&](int32_t gi) {
+    for (auto c = carried_.lower_bound({gi, INT32_MIN}); c != carried_.end() && c->first.first == gi;)
+      c = carried_.erase(c);
+  };
   for (int32_t i = 0; i < n; i++) {
     const int32_t gi = g[(size_t)i];
     const std::string& name = rowName_[(size_t)gi];
+    /* only a reply the engine counted contributes carried-over values: per slot the pvalue of the
+     * highest ballot, exactly the engine's rule (PCS:349-372); ignored / dropped replies leave nothing */
+    if (st[(size_t)i] == GPX_S_OK && (vk[(size_t)i] == GPX_V_RECORDED || vk[(size_t)i] == GPX_V_ELECTED)) {
+      for (int32_t q = off[(size_t)i]; q < off[(size_t)i + 1]; q++) {
+        auto ins = carried_.find({gi, ps[(size_t)q]});
+        if (ins == carried_.end())
+          carried_[{gi, ps[(size_t)q]}] = Carried{pb[(size_t)q], pc[(size_t)q], std::move(pvFrames[(size_t)q])};
+        else if (ballotCmp(pb[(size_t)q], pc[(size_t)q], ins->second.bnum, ins->second.bcoord) > 0)
+          ins->second = Carried{pb[(size_t)q], pc[(size_t)q], std::move(pvFrames[(size_t)q])};
+      }
+    }
     if (vk[(size_t)i] == GPX_V_PREEMPTED) {
+      purgeCarried(gi); /* the election is over: its carried-over values with it */
       /* hand the pre-active requests to the coordinator I deferred to (PISM:1042-1048) */
       for (int32_t j = 0; j < ec[(size_t)i]; j++) {
         auto pa = preactive_.find({gi, eh[(size_t)j * (size_t)n + (size_t)i]});
@@ -847,9 +892,9 @@ bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector
         Frame req;
         int64_t id = eh[q];
         if (ek[q] == GPX_E_CARRY) {
-          auto cf = carried_.find({gi, id});
+          auto cf = carried_.find({gi, es[q]}); /* by SLOT */
           if (cf == carried_.end()) continue;
-          req.assign(cf->second.begin(), cf->second.end() - (long)kAcceptTail); /* the request part */
+          req.assign(cf->second.frame.begin(), cf->second.frame.end() - (long)kAcceptTail); /* the request part */
           stats_.carried_over++;
         } else if (ek[q] == GPX_E_PREACTIVE) {
           auto pa = preactive_.find({gi, id});
@@ -866,8 +911,7 @@ bool PaxosManager::handlePrepareReplies(std::vector<Frame>& replies, std::vector
         }
         issueAccept(out, gi, req, id, stop, es[q], rb[(size_t)i], myID_, em[(size_t)i]);
       }
-      for (auto c = carried_.lower_bound({gi, INT64_MIN}); c != carried_.end() && c->first.first == gi;)
-        c = carried_.erase(c);
+      purgeCarried(gi);
       stats_.elections_won++;
     }
   }
@@ -999,11 +1043,16 @@ size_t PaxosManager::processRun() {
     frames.push_back(std::move(inbox_.front()));
     inbox_.pop_front();
   }
-  if (kind == 0 && inbox_.empty())
+  if (kind == 0 && inbox_.empty()) {
+    while (!deferred_.empty() && frames.size() < maxFrames) {
+      frames.push_back(std::move(deferred_.front()));
+      deferred_.pop_front();
+    }
     while (!requests_.empty() && frames.size() < maxFrames) {
       frames.push_back(std::move(requests_.front()));
       requests_.pop_front();
     }
+  }
   if (frames.empty()) return 0;
   pass_++;
   const size_t consumed = frames.size();
@@ -1157,8 +1206,13 @@ size_t PaxosManager::processRun() {
       } else if (st[(size_t)i] == GPX_S_FORWARD && bc[(size_t)i] != myID_) {
         messenger_->send(bc[(size_t)i], Frame(rf)); /* unicast to paxosState.getBallotCoord() */
         stats_.forwarded++;
+      } else if (st[(size_t)i] == GPX_S_WINDOW) {
+        /* the reference's myProposals is unbounded; the engine's window is not: the request waits
+         * for decisions to free a slot and is proposed again on a later pass - never dropped */
+        deferred_.push_back(std::move(rf));
+        stats_.deferred++;
       } else {
-        stats_.refused++;
+        stats_.refused++; /* STOPPED / NOGROUP / proposal after a stop: the reference drops these too */
       }
     }
   }
@@ -1240,7 +1294,10 @@ size_t PaxosManager::processRun() {
       if (unb[(size_t)i]) { /* e.g. a reply in a higher ballot than the sender's: back to the sender */
         Frame fr = makeSingleAcceptReply(rowName_[(size_t)g[(size_t)i]], 0, myID_, rb[(size_t)i], rc[(size_t)i],
                                          sl[(size_t)i], rm[(size_t)i], id[(size_t)i]);
-        if (snd[(size_t)i] == myID_)
+        if (ticket) { /* same rule as the packed frames: nothing of this call leaves before its log batch */
+          held_.push_back(Held{ticket, snd[(size_t)i], std::move(fr)});
+          stats_.held_replies++;
+        } else if (snd[(size_t)i] == myID_)
           inbox_.push_back(std::move(fr));
         else
           messenger_->send(snd[(size_t)i], std::move(fr));

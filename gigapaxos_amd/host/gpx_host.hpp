@@ -87,10 +87,13 @@ class DelayLogger : public Logger {
 /* an append-only file written and fdatasync'ed by its own thread */
 class FileLogger : public Logger {
  public:
+  /* throws std::runtime_error when the file cannot be opened */
   explicit FileLogger(const std::string& path);
   ~FileLogger() override;
   uint64_t logBatch(const std::vector<const Frame*>& records) override;
   uint64_t durable() override;
+  /* a write or fdatasync failed: durable() will not advance any more (held replies stay held) */
+  bool failed() const;
 
  private:
   struct Impl;
@@ -128,7 +131,7 @@ struct Stats {
   uint64_t logged_accepts = 0, log_batches = 0, held_replies = 0;
   uint64_t sync_requests = 0, sync_decisions_sent = 0, sync_decisions_applied = 0;
   uint64_t batched_requests = 0; /* requests that rode in another request's proposal */
-  uint64_t elections_started = 0, elections_won = 0, elections_lost = 0, prepares = 0, carried_over = 0,
+  uint64_t elections_started = 0, elections_won = 0, elections_lost = 0, prepares = 0, carried_over = 0, deferred = 0,
            noops = 0, preactive = 0;
 };
 
@@ -231,9 +234,19 @@ class PaxosManager {
   std::unordered_map<uint64_t, StoredAccept> accepted_;   /* (gidx, slot) -> the stored ACCEPT */
   std::deque<Frame> inbox_;                               /* frames from the network and from myself */
   std::deque<Frame> requests_;                            /* REQUEST frames of local clients */
+  std::deque<Frame> deferred_; /* requests the engine's proposal window had no room for: retried first */
   /* view change: request bytes by (gidx, requestID) - proposals made while not active, and the
    * pvalues the PREPARE replies carried */
-  std::map<std::pair<int32_t, int64_t>, Frame> preactive_, carried_;
+  std::map<std::pair<int32_t, int64_t>, Frame> preactive_; /* (gidx, request handle) -> request frame */
+  /* carryoverProposals' value side (PCS:271-391): per (gidx, SLOT) the stored ACCEPT frame of the
+   * highest ballot seen in the prepare replies of the running election - keyed by slot, not by
+   * request id: NO_OP and STOP pvalues share id 0 and one request can sit in two slots with
+   * different contents (alone / as a batch head) */
+  struct Carried {
+    int32_t bnum, bcoord;
+    Frame frame;
+  };
+  std::map<std::pair<int32_t, int32_t>, Carried> carried_;
   std::vector<int32_t> downNodes_;
   std::unordered_map<int64_t, ExecutedCallback> callbacks_; /* my clients' requests, by request id */
   struct Held { /* a reply waiting for its batch's log write */

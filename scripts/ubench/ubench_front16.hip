@@ -1,0 +1,174 @@
+// Microbenchmark (round 2): the partition front end for 16-byte vote records, 3 M votes over 1 M groups.
+//   A  reservation by returning atomics in k_hist (the engine's scheme), hsub = 3 / 8
+//   B  ORDERED reservation: per-tile count matrix (no atomics) -> column scan -> scatter; slices of
+//      consecutive tiles are adjacent in every bucket region, so the L2 can merge neighbouring votes
+//      written by tiles that run at the same time on one XCD
+// and the store cost in isolation (16-byte writes at precomputed positions: cursor order vs tile order).
+//   hipcc --offload-arch=gfx950 -O3 -o ubench_front16 ubench_front16.hip && ./ubench_front16
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdint>
+#include <cstdio>
+#include <vector>
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("err %s line %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+struct __attribute__((aligned(16))) I4 { int32_t x, y, z, w; };
+struct __attribute__((aligned(16))) V16 { int32_t idx, slot, cp; uint32_t meta; };
+#define NT 1024
+#define TILE 4096
+__device__ __forceinline__ uint32_t mix(uint32_t h) { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; }
+__device__ __forceinline__ int tile_of_block(int ntiles) { const int per = (ntiles + 7) >> 3; return (int)(blockIdx.x & 7) * per + (int)(blockIdx.x >> 3); }
+__global__ void k_setup(int n, int G, int* gidx, int* c1, int* c2, int* c3, int* c4, int* c5) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) { gidx[i] = mix(i * 2654435761u) % G; c1[i] = 0; c2[i] = 100; c3[i] = 7; c4[i] = 100 + i % 3; c5[i] = 6; }
+}
+__device__ __forceinline__ int wave_incscan(int v) { const int lane = threadIdx.x & 63; int x = v;
+  for (int d = 1; d < 64; d <<= 1) { int y = __shfl_up(x, d, 64); if (lane >= d) x += y; } return x; }
+__device__ __forceinline__ int block_exscan(int v, int* total) { __shared__ int ws[16]; const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int x = wave_incscan(v); if (lane == 63) ws[wid] = x; __syncthreads(); int base = 0, tot = 0;
+  for (int w = 0; w < NT / 64; w++) { int s = ws[w]; if (w < wid) base += s; tot += s; } __syncthreads(); *total = tot; return base + x - v; }
+
+// ---- A: engine scheme -----------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_hist_atomic(int n, int ntiles, const int* __restrict__ gidx, int shift, int nbk, int hsub, int* btot, int* tile_rel) {
+  extern __shared__ int lds[];
+  const int nsuper = (ntiles + hsub - 1) / hsub; const int st = tile_of_block(nsuper); if (st >= nsuper) return;
+  for (int b = threadIdx.x; b < hsub * nbk; b += NT) lds[b] = 0;
+  __syncthreads();
+  for (int sub = 0; sub < hsub; sub++) { const long i0 = ((long)(st * hsub + sub) * TILE) + threadIdx.x * 4;
+    if (i0 + 3 < n) { const I4 g = *(const I4*)(gidx + i0); atomicAdd(&lds[sub * nbk + (g.x >> shift)], 1); atomicAdd(&lds[sub * nbk + (g.y >> shift)], 1);
+      atomicAdd(&lds[sub * nbk + (g.z >> shift)], 1); atomicAdd(&lds[sub * nbk + (g.w >> shift)], 1); }
+    else for (int q = 0; q < 4; q++) if (i0 + q < n) atomicAdd(&lds[sub * nbk + (gidx[i0 + q] >> shift)], 1); }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbk; b += NT) { int tot = 0; for (int sub = 0; sub < hsub; sub++) tot += lds[sub * nbk + b];
+    int rel = tot ? atomicAdd(&btot[b], tot) : 0;
+    for (int sub = 0; sub < hsub; sub++) { const int tile = st * hsub + sub; if (tile < ntiles) tile_rel[(long)tile * nbk + b] = rel; rel += lds[sub * nbk + b]; } }
+}
+// ---- B: ordered reservation ------------------------------------------------------------------
+__global__ __launch_bounds__(NT) void k_hist_matrix(int n, int ntiles, const int* __restrict__ gidx, int shift, int nbk, int* cnt) {
+  extern __shared__ int lds[];
+  const int tile = tile_of_block(ntiles); if (tile >= ntiles) return;
+  for (int b = threadIdx.x; b < nbk; b += NT) lds[b] = 0;
+  __syncthreads();
+  const long i0 = (long)tile * TILE + threadIdx.x * 4;
+  if (i0 + 3 < n) { const I4 g = *(const I4*)(gidx + i0); atomicAdd(&lds[g.x >> shift], 1); atomicAdd(&lds[g.y >> shift], 1); atomicAdd(&lds[g.z >> shift], 1); atomicAdd(&lds[g.w >> shift], 1); }
+  else for (int q = 0; q < 4; q++) if (i0 + q < n) atomicAdd(&lds[gidx[i0 + q] >> shift], 1);
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbk; b += NT) cnt[(long)tile * nbk + b] = lds[b];
+}
+// hsub-tile variant of the matrix histogram: one workgroup per hsub tiles (fewer, fatter workgroups)
+__global__ __launch_bounds__(NT) void k_hist_matrix_h(int n, int ntiles, const int* __restrict__ gidx, int shift, int nbk, int hsub, int* cnt) {
+  extern __shared__ int lds[];
+  const int nsuper = (ntiles + hsub - 1) / hsub; const int st = tile_of_block(nsuper); if (st >= nsuper) return;
+  for (int b = threadIdx.x; b < hsub * nbk; b += NT) lds[b] = 0;
+  __syncthreads();
+  for (int sub = 0; sub < hsub; sub++) { const long i0 = ((long)(st * hsub + sub) * TILE) + threadIdx.x * 4;
+    if (i0 + 3 < n) { const I4 g = *(const I4*)(gidx + i0); atomicAdd(&lds[sub * nbk + (g.x >> shift)], 1); atomicAdd(&lds[sub * nbk + (g.y >> shift)], 1);
+      atomicAdd(&lds[sub * nbk + (g.z >> shift)], 1); atomicAdd(&lds[sub * nbk + (g.w >> shift)], 1); }
+    else for (int q = 0; q < 4; q++) if (i0 + q < n) atomicAdd(&lds[sub * nbk + (gidx[i0 + q] >> shift)], 1); }
+  __syncthreads();
+  for (int sub = 0; sub < hsub; sub++) { const int tile = st * hsub + sub; if (tile < ntiles) for (int b = threadIdx.x; b < nbk; b += NT) cnt[(long)tile * nbk + b] = lds[sub * nbk + b]; }
+}
+// column scan: workgroup = 64 buckets, wave w owns rows [w*rpw, (w+1)*rpw): exclusive prefix down each column in place, column total -> btot
+__global__ __launch_bounds__(NT) void k_scan_cols(int ntiles, int nbk, int* cnt, int* btot) {
+  __shared__ int part[16][64];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6; const int b = blockIdx.x * 64 + lane;
+  const int rpw = (ntiles + 15) / 16; const int r0 = w * rpw, r1 = min(ntiles, r0 + rpw);
+  int s = 0;
+  if (b < nbk) for (int r = r0; r < r1; r++) s += cnt[(long)r * nbk + b];
+  part[w][lane] = s;
+  __syncthreads();
+  int base = 0, tot = 0;
+  for (int q = 0; q < 16; q++) { int v = part[q][lane]; if (q < w) base += v; tot += v; }
+  if (b < nbk) { for (int r = r0; r < r1; r++) { const long o = (long)r * nbk + b; const int c = cnt[o]; cnt[o] = base; base += c; } if (w == 0) btot[b] = tot; }
+}
+__global__ __launch_bounds__(NT) void k_offsets(int nbk, const int* __restrict__ btot, int* boff) {
+  const int per = (nbk + NT - 1) / NT; int v[8]; int s = 0;
+  for (int q = 0; q < per; q++) { const int b = threadIdx.x * per + q; v[q] = b < nbk ? btot[b] : 0; s += v[q]; }
+  int tot; int ex = block_exscan(s, &tot);
+  for (int q = 0; q < per; q++) { const int b = threadIdx.x * per + q; if (b < nbk) { boff[b] = ex; ex += v[q]; } }
+  if (threadIdx.x == 0) boff[nbk] = tot;
+}
+// scatter; SCAN: every workgroup scans the bucket totals itself (engine), else reads boff
+template <bool SCAN>
+__global__ __launch_bounds__(NT) void k_scatter16(int n, int ntiles, int shift, int nbk, const int* __restrict__ btot, const int* __restrict__ boff,
+    const int* __restrict__ tile_rel, const int* __restrict__ gidx, const int* __restrict__ c1, const int* __restrict__ c2, const int* __restrict__ c3,
+    const int* __restrict__ c4, const int* __restrict__ c5, V16* out) {
+  extern __shared__ int lds[];
+  const int tile = tile_of_block(ntiles); if (tile >= ntiles) return;
+  const int* rel = tile_rel + (long)tile * nbk;
+  if (SCAN) { const int per = (nbk + NT - 1) / NT; const int b0 = threadIdx.x * per; int v[4], rl[4]; int s = 0;
+    for (int q = 0; q < 4; q++) { const bool on = q < per && b0 + q < nbk; v[q] = on ? btot[b0 + q] : 0; rl[q] = on ? rel[b0 + q] : 0; s += v[q]; }
+    int tot; int ex = block_exscan(s, &tot);
+    for (int q = 0; q < 4; q++) { const int b = b0 + q; if (q < per && b < nbk) { lds[b] = ex + rl[q]; ex += v[q]; } }
+  } else { for (int b = threadIdx.x; b < nbk; b += NT) lds[b] = boff[b] + rel[b]; }
+  __syncthreads();
+  const int mask = (1 << shift) - 1;
+  const long i0 = (long)tile * TILE + threadIdx.x * 4;
+  if (i0 + 3 < n) {
+    const I4 g = *(const I4*)(gidx + i0), a = *(const I4*)(c1 + i0), b = *(const I4*)(c2 + i0), c = *(const I4*)(c3 + i0), d = *(const I4*)(c4 + i0), e = *(const I4*)(c5 + i0);
+    const int gg[4] = {g.x, g.y, g.z, g.w}, aa[4] = {a.x, a.y, a.z, a.w}, bb[4] = {b.x, b.y, b.z, b.w}, cc[4] = {c.x, c.y, c.z, c.w}, dd[4] = {d.x, d.y, d.z, d.w}, ee[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) { const int p = atomicAdd(&lds[gg[q] >> shift], 1); V16 v; v.idx = (int)i0 + q; v.slot = cc[q]; v.cp = ee[q];
+      v.meta = (uint32_t)(gg[q] & mask) | ((aa[q] != 0 || bb[q] != 100) ? 0x4000u : ((uint32_t)dd[q] << 16)); out[p] = v; }
+  }
+}
+// store cost alone: 16-byte writes at precomputed positions
+__global__ void k_write16(int n, const int* __restrict__ pos, V16* out) { const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 + 3 < n) { const I4 p = *(const I4*)(pos + i0); const int pp[4] = {p.x, p.y, p.z, p.w}; for (int q = 0; q < 4; q++) { V16 v; v.idx = i0 + q; v.slot = 1; v.cp = 2; v.meta = 3; out[pp[q]] = v; } } }
+__global__ void k_pos_of(int n, const V16* __restrict__ part, int* pos) { const int j = blockIdx.x * blockDim.x + threadIdx.x; if (j < n) pos[part[j].idx] = j; }
+__global__ void k_check(int n, int shift, int nbk, const int* __restrict__ boff, const int* __restrict__ gidx, const V16* __restrict__ part, int* bad) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x; if (j >= n) return; const V16 v = part[j]; const int g = gidx[v.idx]; const int b = g >> shift;
+  if (j < boff[b] || j >= boff[b + 1] || (int)(v.meta & 0x3fff) != (g & ((1 << shift) - 1))) atomicAdd(bad, 1); }
+
+int main() {
+  const int n = 3000000, G = 1000000; const int ntiles = (n + TILE - 1) / TILE;
+  int *gidx, *c1, *c2, *c3, *c4, *c5, *btot, *boff, *rel, *pos, *bad; V16 *out; char* flushbuf;
+  CK(hipMalloc(&gidx, n * 4)); CK(hipMalloc(&c1, n * 4)); CK(hipMalloc(&c2, n * 4)); CK(hipMalloc(&c3, n * 4)); CK(hipMalloc(&c4, n * 4)); CK(hipMalloc(&c5, n * 4));
+  CK(hipMalloc(&pos, n * 4)); CK(hipMalloc(&out, (size_t)n * 16)); CK(hipMalloc(&btot, 8192 * 4)); CK(hipMalloc(&boff, 8192 * 4)); CK(hipMalloc(&bad, 4));
+  CK(hipMalloc(&rel, (size_t)ntiles * 4096 * 4)); CK(hipMalloc(&flushbuf, (size_t)1 << 30));
+  k_setup<<<(n + 255) / 256, 256>>>(n, G, gidx, c1, c2, c3, c4, c5); CK(hipDeviceSynchronize());
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto timeit = [&](const char* name, auto pre, auto f) { float best = 1e9;
+    for (int r = 0; r < 6; r++) { pre(); hipMemsetAsync(flushbuf, r, (size_t)1 << 30); hipEventRecord(e0); f(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (r) best = std::min(best, ms); }
+    printf("%-64s %8.1f us\n", name, best * 1e3); fflush(stdout); };
+  const int tg = 8 * ((ntiles + 7) / 8);
+  for (int shift : {8, 9, 10}) {
+    const int nbk = (G + (1 << shift) - 1) >> shift; char nm[160];
+    auto zero = [&] { hipMemsetAsync(btot, 0, 8192 * 4); };
+    for (int hsub : {3, 8}) {
+      if ((size_t)hsub * nbk * 4 > 150 * 1024) continue;
+      const int nsuper = (ntiles + hsub - 1) / hsub; const int hg = 8 * ((nsuper + 7) / 8);
+      hipFuncSetAttribute((const void*)k_hist_atomic, hipFuncAttributeMaxDynamicSharedMemorySize, hsub * nbk * 4);
+      snprintf(nm, 160, "A shift %2d nbk %4d hsub %d: k_hist (atomics)", shift, nbk, hsub);
+      timeit(nm, zero, [&] { k_hist_atomic<<<hg, NT, hsub * nbk * 4>>>(n, ntiles, gidx, shift, nbk, hsub, btot, rel); });
+      snprintf(nm, 160, "A shift %2d nbk %4d hsub %d: k_scatter16 (scan inside)", shift, nbk, hsub);
+      timeit(nm, [] {}, [&] { k_scatter16<true><<<tg, NT, nbk * 4>>>(n, ntiles, shift, nbk, btot, boff, rel, gidx, c1, c2, c3, c4, c5, out); });
+      snprintf(nm, 160, "A shift %2d nbk %4d hsub %d: hist + scatter back to back", shift, nbk, hsub);
+      timeit(nm, zero, [&] { k_hist_atomic<<<hg, NT, hsub * nbk * 4>>>(n, ntiles, gidx, shift, nbk, hsub, btot, rel);
+                             k_scatter16<true><<<tg, NT, nbk * 4>>>(n, ntiles, shift, nbk, btot, boff, rel, gidx, c1, c2, c3, c4, c5, out); });
+      k_offsets<<<1, NT>>>(nbk, btot, boff); hipMemsetAsync(bad, 0, 4); k_check<<<(n + 255) / 256, 256>>>(n, shift, nbk, boff, gidx, out, bad);
+      int hb = -1; CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost)); if (hb) printf("   !! %d misplaced votes\n", hb);
+      if (hsub == 3) { k_pos_of<<<(n + 255) / 256, 256>>>(n, out, pos); snprintf(nm, 160, "  shift %2d: 16-byte stores alone, cursor-order positions", shift);
+        timeit(nm, [] {}, [&] { k_write16<<<(n / 4 + 255) / 256, 256>>>(n, pos, out); }); }
+    }
+    for (int hsub : {1, 3}) {
+      const int nsuper = (ntiles + hsub - 1) / hsub; const int hg = 8 * ((nsuper + 7) / 8);
+      hipFuncSetAttribute((const void*)k_hist_matrix_h, hipFuncAttributeMaxDynamicSharedMemorySize, hsub * nbk * 4);
+      snprintf(nm, 160, "B shift %2d nbk %4d hsub %d: k_hist (count matrix, no atomics)", shift, nbk, hsub);
+      timeit(nm, [] {}, [&] { if (hsub == 1) k_hist_matrix<<<tg, NT, nbk * 4>>>(n, ntiles, gidx, shift, nbk, rel);
+                              else k_hist_matrix_h<<<hg, NT, hsub * nbk * 4>>>(n, ntiles, gidx, shift, nbk, hsub, rel); });
+    }
+    auto histB = [&] { k_hist_matrix_h<<<8 * (((ntiles + 2) / 3 + 7) / 8), NT, 3 * nbk * 4>>>(n, ntiles, gidx, shift, nbk, 3, rel); };
+    snprintf(nm, 160, "B shift %2d nbk %4d: k_scan_cols + k_offsets", shift, nbk);
+    timeit(nm, histB, [&] { k_scan_cols<<<(nbk + 63) / 64, NT>>>(ntiles, nbk, rel, btot); k_offsets<<<1, NT>>>(nbk, btot, boff); });
+    snprintf(nm, 160, "B shift %2d nbk %4d: k_scatter16 (offsets precomputed)", shift, nbk);
+    timeit(nm, [] {}, [&] { k_scatter16<false><<<tg, NT, nbk * 4>>>(n, ntiles, shift, nbk, btot, boff, rel, gidx, c1, c2, c3, c4, c5, out); });
+    snprintf(nm, 160, "B shift %2d nbk %4d: hist + scan + offsets + scatter back to back", shift, nbk);
+    timeit(nm, [] {}, [&] { histB(); k_scan_cols<<<(nbk + 63) / 64, NT>>>(ntiles, nbk, rel, btot); k_offsets<<<1, NT>>>(nbk, btot, boff);
+                            k_scatter16<false><<<tg, NT, nbk * 4>>>(n, ntiles, shift, nbk, btot, boff, rel, gidx, c1, c2, c3, c4, c5, out); });
+    hipMemsetAsync(bad, 0, 4); k_check<<<(n + 255) / 256, 256>>>(n, shift, nbk, boff, gidx, out, bad);
+    int hb = -1; CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost)); if (hb) printf("   !! %d misplaced votes\n", hb);
+    k_pos_of<<<(n + 255) / 256, 256>>>(n, out, pos); snprintf(nm, 160, "  shift %2d: 16-byte stores alone, tile-order positions", shift);
+    timeit(nm, [] {}, [&] { k_write16<<<(n / 4 + 255) / 256, 256>>>(n, pos, out); });
+  }
+  return 0;
+}

@@ -50,7 +50,8 @@ def create_mixed_groups(ea, eb, G, kmax, node_ids, rng, slot_base=1, my_id=None)
     return members, ks
 
 
-def fuzz(ea, eb, G, node_ids, rng, steps, batch, slot_base=1, span=40, my_id=None, p_stop=0.01):
+def fuzz(ea, eb, G, node_ids, rng, steps, batch, slot_base=1, span=40, my_id=None, p_stop=0.01,
+         ordered=False):
     """Random interleaving of propose / accept / accept_reply / commit batches with colliding
     slots, duplicate votes, stale and higher ballots, non-member acceptors, unknown groups."""
     my_id = ea.my_id if my_id is None else my_id
@@ -58,6 +59,14 @@ def fuzz(ea, eb, G, node_ids, rng, steps, batch, slot_base=1, span=40, my_id=Non
 
     def gids(n):
         g = rng.integers(0, G, n).astype(np.int32)
+        if ordered:
+            # grouped by group, groups ascending (what the previous pipeline stage emits): the engine
+            # applies such ACCEPT / COMMIT batches without partitioning them; one batch in eight keeps
+            # an out-of-range index, which sends it down the partition path instead
+            g.sort()
+            if rng.random() < 0.125:
+                g[rng.integers(0, n)] = rng.choice([-1, G, G + 5])
+            return g
         bad = rng.random(n) < 0.01
         g[bad] = rng.choice([-1, G, G + 5], size=int(bad.sum()))
         return g

@@ -25,6 +25,16 @@ def test_fuzz_mixed_ops(hip_lib, oracle_lib, kmax, seed):
     fuzz(eh, eo, G, nodes, rng, steps=250, batch=300)
 
 
+@pytest.mark.parametrize("kmax,G,seed", [(3, 48, 21), (5, 700, 22), (3, 5000, 23)])
+def test_fuzz_ordered_batches(hip_lib, oracle_lib, kmax, G, seed):
+    """Batches grouped by group (gidx non-decreasing): ACCEPT and COMMIT batches take the direct path
+    (gpx_direct.hip.h, no partition), runs of several records per group replayed in array order."""
+    rng = np.random.default_rng(seed)
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, kmax, 64)
+    create_mixed_groups(eh, eo, G, kmax, NODES, rng)
+    fuzz(eh, eo, G, NODES, rng, steps=160, batch=max(300, G), ordered=True)
+
+
 def test_fuzz_wraparound(hip_lib, oracle_lib):
     """slots straddle Integer.MAX_VALUE -> MIN_VALUE."""
     rng = np.random.default_rng(5)
