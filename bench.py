@@ -46,6 +46,8 @@ def main():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline leg (0 = every host core)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the engine-vs-oracle replay of the CPU sample")
     ap.add_argument("--cpu-mt-passes", type=int, default=16, help="passes over the sample in the multi-threaded leg")
+    ap.add_argument("--no-promise", action="store_true",
+                    help="do not declare the proposal batches ordered (gpx_engine_set_ordered_batches)")
     ap.add_argument("--pipelined", action="store_true",
                     help="cross-call pipelining (front end of call N+1 beside the back end of call N on two "
                          "streams); off by default: measured slower than one stream since round 2")
@@ -82,6 +84,11 @@ def main():
     # pipelined mode (include/gpx.h): the partition front end of call N+1 overlaps the per-bucket
     # back end of call N on two engine streams; group state is still updated in call order
     eng.set_pipeline(args.pipelined)
+    if not args.no_promise:
+        # the proposal batch is one request per group in gidx order (what RequestBatcher hands over):
+        # declared, verified on the device, so the partition path is not even launched for it
+        from gigapaxos_amd import ORDERED_PROPOSE
+        eng.set_ordered_batches(ORDERED_PROPOSE)
     mem = np.tile(np.array(members, np.int32), (G, 1))
     assert (eng.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
 
@@ -340,6 +347,7 @@ def main():
                             "stream%s; step = propose_batch(G) + accept_reply_batch(K*G votes), inputs resident in HBM"
                             % (K, "sorted" if args.sorted else "shuffled", " + adversarial mix" if args.mix else ""),
                 "groups_per_gpu": G, "replicas": K, "votes_per_step_per_gpu": nv,
+                "ordered_proposals_promise": not args.no_promise,
                 "parallelism": "groups sharded across GPUs, no collective on the decide path",
             },
             "votes_per_sec": round(votes_total / elapsed, 1),

@@ -22,6 +22,8 @@ KMAX_LIMIT = 16
 
 # status / kind constants (include/gpx.h)
 S_OK, S_NOGROUP, S_STOPPED, S_WINDOW, S_FORWARD, S_REFUSED, S_EXISTS, S_BUSY = range(8)
+S_UNORDERED = 9
+ORDERED_PROPOSE, ORDERED_ACCEPT, ORDERED_COMMIT = 1, 2, 4
 D_DECISION, D_PREEMPTED = 1, 2
 R_TOLOG, R_STORED = 1, 2
 A_STOP = 1
@@ -76,6 +78,7 @@ _SIGS = {
     "engine_destroy": [],
     "engine_sync": [],
     "engine_counters": [C.POINTER(C.c_uint64)],
+    "engine_set_ordered_batches": [C.c_int32],
     "host_register": [_VP, C.c_size_t],
     "host_unregister": [_VP],
     "group_create": [C.c_int32, _VP, _VP, _VP, _VP, _VP],
@@ -327,6 +330,11 @@ class Engine:
 
     def sync(self):
         self.lib.check(self.lib.fn["engine_sync"](self.h), "engine_sync")
+
+    def set_ordered_batches(self, mask: int):
+        """Promise (verified on the device) that later propose / accept / commit batches come grouped
+        by group, groups ascending: only the direct path is launched (gpx_engine_set_ordered_batches)."""
+        self.lib.check(self.lib.fn["engine_set_ordered_batches"](self.h, int(mask)), "engine_set_ordered_batches")
 
     # -- device-pointer path (batches already resident in HBM) ----------------------
     def set_stream(self, hip_stream_handle: int):

@@ -64,9 +64,22 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_direct(
     const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot, const int32_t* __restrict__ median,
     const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status,
-    DirectStage D) {
-  if (*X.unsorted == X.epoch) return; /* not ordered: the partition path does it */
+    DirectStage D, int32_t refuse) {
   const int32_t i = (int32_t)blockIdx.x * GPX_DCHUNK + (int32_t)threadIdx.x;
+  if (*X.unsorted == X.epoch) {
+    /* not ordered: the partition path does it - or, under the caller's GPX_ORDERED_* promise (no
+     * partition path launched), the batch is refused whole */
+    if (refuse && i < n) {
+      if (!COMMIT) {
+        r_bnum[i] = 0;
+        r_bcoord[i] = 0;
+        r_maxcp[i] = 0;
+        r_flags[i] = 0;
+      }
+      status[i] = GPX_S_UNORDERED;
+    }
+    return;
+  }
   int32_t local = 0;
   if (i < n) {
     const int32_t g = gidx[i];
@@ -112,8 +125,11 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, i
                                                                 int32_t* __restrict__ x_gidx,
                                                                 int32_t* __restrict__ x_first,
                                                                 int32_t* __restrict__ x_count,
-                                                                int32_t* total_out) {
-  if (*X.unsorted == X.epoch) return; /* the partition path (k_emit_runs) writes the outputs */
+                                                                int32_t* total_out, int32_t refuse) {
+  if (*X.unsorted == X.epoch) { /* the partition path (k_emit_runs) writes the outputs; refused: none */
+    if (refuse && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = 0;
+    return;
+  }
   const int32_t w = (int32_t)blockIdx.x;
   int32_t before = 0;
   for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) before += D.chunk_cnt[t];

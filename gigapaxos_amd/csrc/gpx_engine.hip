@@ -97,6 +97,7 @@ struct gpx_engine {
   /* accept-reply back end on 16-byte vote records (gpx_ar16.hip.h): one lane per group, so only
    * while a bucket has at most 1024 groups; GPX_AR_LEGACY=1 forces the 32-byte record path */
   bool ar16 = false;
+  int32_t ordered_mask = 0; /* gpx_engine_set_ordered_batches */
   int32_t lds16_max = 0, lds16_hw = 0; /* LDS staging capacities (votes) of k_bucket_ar16 */
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
   /* wire codec (gpx_wire_host.inc): paxosID table, row free list, scratch - allocated on first use */
@@ -196,6 +197,13 @@ int flush_profile(gpx_engine* e) {
   do {                                                                                            \
     LaunchScope _ls(e, name);                                                                     \
     hipLaunchKernelGGL(kernel, dim3(grid), dim3(GPX_FBLOCK), (size_t)(lds_bytes), (e)->stream,    \
+                       __VA_ARGS__);                                                              \
+  } while (0)
+
+#define LAUNCH_OC(e, name, kernel, grid, lds_bytes, ...)                                          \
+  do {                                                                                            \
+    LaunchScope _ls(e, name);                                                                     \
+    hipLaunchKernelGGL(kernel, dim3(grid), dim3(GPX_OC_BLOCK), (size_t)(lds_bytes), (e)->stream,  \
                        __VA_ARGS__);                                                              \
   } while (0)
 
@@ -566,6 +574,12 @@ int gpx_engine_set_pipeline(gpx_engine* h, int32_t on) {
   return GPX_OK;
 }
 
+int gpx_engine_set_ordered_batches(gpx_engine* h, int32_t mask) {
+  if (!h || (mask & ~(GPX_ORDERED_PROPOSE | GPX_ORDERED_ACCEPT | GPX_ORDERED_COMMIT))) return GPX_EINVAL;
+  h->ordered_mask = mask;
+  return GPX_OK;
+}
+
 int gpx_engine_fence(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
   if (h->pipeline && h->user_stream) {
@@ -718,24 +732,29 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec; /* the two paths never both stage outputs: shared scratch */
   const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt};
-  LAUNCH_F(e, "k_order_check", k_order_check<false>, (n + GPX_FBLOCK * 8 - 1) / (GPX_FBLOCK * 8), 0, n, gidx,
+  LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
            e->S.G, e->X, status, D.chunk_cnt, nchunks);
-  front_hist(e, n, gidx, status, 0, 2);
-  launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, 1);
+  const bool promised = (e->ordered_mask & GPX_ORDERED_ACCEPT) != 0;
+  if (!promised) {
+    front_hist(e, n, gidx, status, 0, 2);
+    launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, 1);
+  }
   begin_back(e, fs, n);
   {
     LaunchScope _ls(e, "k_ac_direct");
     hipLaunchKernelGGL(k_ac_direct<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
-                       bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D);
+                       bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D,
+                       promised ? 1 : 0);
   }
   {
     LaunchScope _ls(e, "k_emit_runs_direct");
     hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
-                       x_gidx, x_first, x_count, n_runs);
+                       x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
   }
-  LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags,
-           status);
-  LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+  if (!promised) {
+    LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+    LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+  }
   end_call(e, fs, {{r_bnum, b4}, {r_bcoord, b4}, {r_maxcp, b4}, {r_flags, (size_t)n},
                    {status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
   HIPCHK(hipGetLastError());
@@ -760,24 +779,29 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec;
   const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt};
-  LAUNCH_F(e, "k_order_check", k_order_check<false>, (n + GPX_FBLOCK * 8 - 1) / (GPX_FBLOCK * 8), 0, n, gidx,
+  LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
            e->S.G, e->X, status, D.chunk_cnt, nchunks);
-  front_hist(e, n, gidx, status, 0, 2);
-  launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, c_kind, nullptr, nullptr, nullptr, nullptr, 1);
+  const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
+  if (!promised) {
+    front_hist(e, n, gidx, status, 0, 2);
+    launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, c_kind, nullptr, nullptr, nullptr, nullptr, 1);
+  }
   begin_back(e, fs, n);
   {
     LaunchScope _ls(e, "k_ac_direct");
     hipLaunchKernelGGL(k_ac_direct<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
                        bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
-                       (int32_t*)nullptr, (uint8_t*)nullptr, status, D);
+                       (int32_t*)nullptr, (uint8_t*)nullptr, status, D, promised ? 1 : 0);
   }
   {
     LaunchScope _ls(e, "k_emit_runs_direct");
     hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
-                       x_gidx, x_first, x_count, n_runs);
+                       x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
   }
-  LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
-  LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+  if (!promised) {
+    LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
+    LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
+  }
   end_call(e, fs, {{status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
   HIPCHK(hipGetLastError());
   return GPX_OK;
@@ -796,28 +820,32 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
                                  {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
   /* order check + status prefill (one pass over gidx); the partition front end only does work for a
    * batch that is NOT strictly ascending */
-  LAUNCH_F(e, "k_order_check", k_order_check<true>, (n + GPX_FBLOCK * 8 - 1) / (GPX_FBLOCK * 8), 0, n, gidx,
+  LAUNCH_OC(e, "k_order_check", k_order_check<true>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
            e->S.G, e->X, status, (int32_t*)nullptr, 0);
-  front_hist(e, n, gidx, status, 0, 2);
-  const int ntiles = ntiles_for(n);
-  LAUNCH_F(e, "k_scatter_pr", k_scatter_pr, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles,
-           e->S.G, e->X,
-           gidx, is_stop, slot, bnum, bcoord, median_cp);
+  const bool promised = (e->ordered_mask & GPX_ORDERED_PROPOSE) != 0;
+  const int32_t refuse = promised ? 1 : 0;
+  if (!promised) {
+    front_hist(e, n, gidx, status, 0, 2);
+    const int ntiles = ntiles_for(n);
+    LAUNCH_F(e, "k_scatter_pr", k_scatter_pr, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G, e->X,
+             gidx, is_stop, slot, bnum, bcoord, median_cp);
+  }
   begin_back(e, fs, n);
   /* exactly one of the two back ends does the work (device-side choice on *X.unsorted, set by
-   * k_hist): strictly ascending batch -> k_propose_direct, anything else -> k_bucket_propose */
+   * k_order_check): strictly ascending batch -> k_propose_direct, anything else -> k_bucket_propose;
+   * under the GPX_ORDERED_PROPOSE promise only the direct one exists and the other case is refused */
   if (e->cfg.kmax <= 4) {
     LAUNCH(e, "k_propose_direct", k_propose_direct<4>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
-           bnum, bcoord, median_cp, status, handle);
-    launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status, handle);
+           bnum, bcoord, median_cp, status, handle, refuse);
+    if (!promised) launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status, handle);
   } else if (e->cfg.kmax <= 8) {
     LAUNCH(e, "k_propose_direct", k_propose_direct<8>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
-           bnum, bcoord, median_cp, status, handle);
-    launch_bucket_propose<8>(e, slot, bnum, bcoord, median_cp, status, handle);
+           bnum, bcoord, median_cp, status, handle, refuse);
+    if (!promised) launch_bucket_propose<8>(e, slot, bnum, bcoord, median_cp, status, handle);
   } else {
     LAUNCH(e, "k_propose_direct", k_propose_direct<16>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
-           bnum, bcoord, median_cp, status, handle);
-    launch_bucket_propose<16>(e, slot, bnum, bcoord, median_cp, status, handle);
+           bnum, bcoord, median_cp, status, handle, refuse);
+    if (!promised) launch_bucket_propose<16>(e, slot, bnum, bcoord, median_cp, status, handle);
   }
   end_call(e, fs, {{slot, b4}, {bnum, b4}, {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
   HIPCHK(hipGetLastError());

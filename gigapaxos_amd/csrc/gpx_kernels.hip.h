@@ -1607,12 +1607,13 @@ __global__ __launch_bounds__(1024) void k_bucket_propose(
  * what the previous stage of the pipeline emits: decisions leave grouped by gidx, ACCEPTs follow the
  * proposal batch)?  Such a batch needs no partition.  Reads the column once (16-byte loads when
  * aligned), pre-fills the status column and raises the call's epoch in *X.unsorted otherwise. */
+#define GPX_OC_BLOCK 256
 template <bool STRICT>
-__global__ __launch_bounds__(GPX_FBLOCK) void k_order_check(int32_t n, const int32_t* __restrict__ gidx,
+__global__ __launch_bounds__(GPX_OC_BLOCK) void k_order_check(int32_t n, const int32_t* __restrict__ gidx,
                                                            int32_t G, DevScratch X,
                                                            uint8_t* __restrict__ status,
                                                            int32_t* __restrict__ zero, int32_t nzero) {
-  const int64_t i0 = ((int64_t)blockIdx.x * GPX_FBLOCK + threadIdx.x) * 8;
+  const int64_t i0 = ((int64_t)blockIdx.x * GPX_OC_BLOCK + threadIdx.x) * 8;
   if (zero && i0 / 8 < nzero) zero[i0 / 8] = 0; /* nzero <= ceil(n / 8): the grid covers it */
   bool bad = false;
   if (i0 < n) {
@@ -1656,11 +1657,22 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_direct(
     DevState S, DevScratch X, int32_t n, const int32_t* __restrict__ gidx,
     const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
-    const int64_t* __restrict__ handle) {
-  if (*X.unsorted == X.epoch) return;
+    const int64_t* __restrict__ handle, int32_t refuse) {
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (*X.unsorted == X.epoch) {
+    /* not strictly ascending: the partition path applies it - or, under the caller's
+     * GPX_ORDERED_PROPOSE promise (no partition path launched), the batch is refused whole */
+    if (refuse && i < n) {
+      o_slot[i] = 0;
+      o_bnum[i] = 0;
+      o_bcoord[i] = 0;
+      o_median[i] = 0;
+      status[i] = GPX_S_UNORDERED;
+    }
+    return;
+  }
   if (i >= n) return;
-  const int32_t g = gidx[i]; /* in range: k_hist marks out-of-range batches unsorted */
+  const int32_t g = gidx[i]; /* in range: k_order_check marks out-of-range batches unordered */
   ProposePre<KMAX> P;
   propose_preload<KMAX>(S, g, P);
   propose_preload_ring<KMAX>(S, g, P);

@@ -43,6 +43,7 @@
 #ifndef GPX_H
 #define GPX_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -71,6 +72,7 @@ extern "C" {
 #define GPX_S_EXISTS 6  /* group_create on a live gidx */
 #define GPX_S_BUSY 7    /* group_retire(GPX_RETIRE_PAUSE) on a group that is not
                            caught up (PaxosInstanceStateMachine.java:2004-2035) */
+#define GPX_S_UNORDERED 9 /* the batch broke the gpx_engine_set_ordered_batches promise: refused whole */
 #define GPX_S_PREACTIVE 8 /* propose only: the coordinator here is still being elected; the
                             proposal got slot `slot` but no ACCEPT goes out yet
                             (PaxosCoordinatorState.java:254-261) */
@@ -164,6 +166,25 @@ int gpx_engine_sync(gpx_engine* h);
  */
 int gpx_engine_set_pipeline(gpx_engine* h, int32_t on);
 int gpx_engine_fence(gpx_engine* h);
+
+/*
+ * Promise about the batches of later calls (mask of GPX_ORDERED_*; 0 = none, the default).
+ * Inside the pipeline a batch is usually the previous stage's output and already GROUPED BY GROUP:
+ * RequestBatcher hands over one batched request per group (gidx strictly ascending), the ACCEPTs
+ * follow that proposal batch, the commits are the decisions, which leave gpx_accept_reply_batch
+ * grouped by gidx ascending (ORDER above).  The engine recognises such a batch on the device and
+ * applies it without partitioning it; without a promise it also has to launch the partition path,
+ * which then returns at once.  With GPX_ORDERED_PROPOSE (gidx in range and strictly ascending: every
+ * group at most once) / GPX_ORDERED_ACCEPT / GPX_ORDERED_COMMIT (gidx in range and non-decreasing:
+ * the records of a group adjacent, in their order) only the direct path is launched.  The promise is
+ * VERIFIED on the device: a batch that breaks it is refused whole - every record gets status
+ * GPX_S_UNORDERED, all outputs are zero, n_runs = 0, no state changes - exactly like a lost batch.
+ * Results of a batch that keeps the promise are identical with and without it.
+ */
+#define GPX_ORDERED_PROPOSE 1
+#define GPX_ORDERED_ACCEPT 2
+#define GPX_ORDERED_COMMIT 4
+int gpx_engine_set_ordered_batches(gpx_engine* h, int32_t mask);
 
 /*
  * replaces: PaxosManager.createPaxosInstance(Map nameStates, gms) batch create

@@ -386,6 +386,7 @@ struct Engine {
   gpx_config cfg;
   std::vector<std::unique_ptr<Group>> groups;
   uint64_t counters[3] = {0, 0, 0};
+  int32_t ordered_mask = 0; /* gpx_engine_set_ordered_batches: engine contract, not in the reference */
   /* PaxosManager.pinstances (paxosID -> instance), PaxosManager.java:1816-1832; wire oracle only */
   std::map<std::string, int32_t> name2row;
   std::vector<std::string> row2name;
@@ -458,6 +459,20 @@ int orc_engine_destroy(gpx_engine* h) {
   return GPX_OK;
 }
 int orc_engine_sync(gpx_engine*) { return GPX_OK; }
+int orc_engine_set_ordered_batches(gpx_engine* h, int32_t mask) {
+  if (!h || (mask & ~(GPX_ORDERED_PROPOSE | GPX_ORDERED_ACCEPT | GPX_ORDERED_COMMIT))) return GPX_EINVAL;
+  reinterpret_cast<Engine*>(h)->ordered_mask = mask;
+  return GPX_OK;
+}
+/* the promise of gpx_engine_set_ordered_batches: gidx in range and ascending (strictly: every group
+ * at most once) */
+static bool batch_keeps_order(const Engine* e, int32_t n, const int32_t* gidx, bool strict) {
+  for (int32_t i = 0; i < n; i++) {
+    if (gidx[i] < 0 || gidx[i] >= e->cfg.max_groups) return false;
+    if (i + 1 < n && (strict ? gidx[i] >= gidx[i + 1] : gidx[i] > gidx[i + 1])) return false;
+  }
+  return true;
+}
 int orc_host_register(gpx_engine* h, void* p, size_t n) { return h && p && n ? GPX_OK : GPX_EINVAL; }
 int orc_host_unregister(gpx_engine* h, void* p) { return h && p ? GPX_OK : GPX_EINVAL; }
 int orc_engine_counters(gpx_engine* h, uint64_t out[3]) {
@@ -645,6 +660,13 @@ int orc_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uin
                         int32_t* median_cp, uint8_t* status) {
   if (!h || n < 0) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);
+  if ((e->ordered_mask & GPX_ORDERED_PROPOSE) && !batch_keeps_order(e, n, gidx, true)) {
+    for (int32_t i = 0; i < n; i++) {
+      slot[i] = bnum[i] = bcoord[i] = median_cp[i] = 0;
+      status[i] = GPX_S_UNORDERED;
+    }
+    return GPX_OK;
+  }
   for (int32_t i = 0; i < n; i++) {
     slot[i] = bnum[i] = bcoord[i] = median_cp[i] = 0;
     Group* g = e->get(gidx[i]);
@@ -729,6 +751,15 @@ int orc_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   if (!h || n < 0) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);
   int32_t runs = 0;
+  if ((e->ordered_mask & GPX_ORDERED_ACCEPT) && !batch_keeps_order(e, n, gidx, false)) {
+    for (int32_t i = 0; i < n; i++) {
+      r_bnum[i] = r_bcoord[i] = r_maxcp[i] = 0;
+      r_flags[i] = 0;
+      status[i] = GPX_S_UNORDERED;
+    }
+    *n_runs = 0;
+    return GPX_OK;
+  }
   for (int32_t i = 0; i < n; i++) {
     r_bnum[i] = r_bcoord[i] = r_maxcp[i] = 0;
     r_flags[i] = 0;
@@ -854,6 +885,11 @@ int orc_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   if (!h || n < 0) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);
   int32_t runs = 0;
+  if ((e->ordered_mask & GPX_ORDERED_COMMIT) && !batch_keeps_order(e, n, gidx, false)) {
+    for (int32_t i = 0; i < n; i++) status[i] = GPX_S_UNORDERED;
+    *n_runs = 0;
+    return GPX_OK;
+  }
   for (int32_t i = 0; i < n; i++) {
     Group* g = e->get(gidx[i]);
     if (!g) {

@@ -18,13 +18,18 @@ import torch
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-from gigapaxos_amd import Engine, hri_create, load_hip, S_OK, C_HASVALUE  # noqa: E402
+from gigapaxos_amd import (Engine, hri_create, load_hip, S_OK, C_HASVALUE, ORDERED_PROPOSE,  # noqa: E402
+                           ORDERED_ACCEPT, ORDERED_COMMIT)
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--groups", type=int, default=1_000_000)
     ap.add_argument("--rounds", type=int, default=8)
+    ap.add_argument("--profile-rounds", type=int, default=4)
+    ap.add_argument("--no-promise", action="store_true",
+                    help="do not declare the batches ordered (gpx_engine_set_ordered_batches): the engine then "
+                         "also launches the partition path, which returns at once")
     args = ap.parse_args()
     G, K = args.groups, 3
     ids = [100, 101, 102]
@@ -37,6 +42,8 @@ def main():
         e = Engine(load_hip(), nid, G, kmax=K, window=8, max_batch=3 * G + 1024)
         assert (e.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
         e.set_stream(ts.cuda_stream)
+        if not args.no_promise:  # every batch here is the previous stage's output: grouped by group
+            e.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT)
         eng[nid] = e
     i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
     u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)  # noqa: E731
@@ -54,8 +61,9 @@ def main():
     perms = [torch.from_numpy(rng.permutation(3 * G)).to(dev) for _ in range(2)]
     acc_col = torch.cat([torch.full((G,), nid, dtype=torch.int32, device=dev) for nid in ids])
     t = {"propose": 0.0, "accept_x3": 0.0, "accept_reply": 0.0, "commit_x3": 0.0}
-    for r in range(args.rounds):
-        if r == 1:
+    timed = args.rounds - 1
+    for r in range(args.rounds + args.profile_rounds):
+        if r == args.rounds:  # per-kernel split in extra rounds: the events cost time, so not in the timed ones
             for e in eng.values():
                 e.profile(2)
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
@@ -88,18 +96,19 @@ def main():
         assert int(n_out) == G, int(n_out)
         for nid in ids:
             assert int(runs[nid][3]) == G and bool((runs[nid][2][:G] == 1).all())
-        if r > 0:
+        if 0 < r < args.rounds:
             t["propose"] += ev[0].elapsed_time(ev[1])
             t["accept_x3"] += ev[1].elapsed_time(ev[2])
             t["accept_reply"] += ev2b.elapsed_time(ev[3])
             t["commit_x3"] += ev[3].elapsed_time(ev[4])
-    k = args.rounds - 1
+    k = timed
     kern = {}
     for nid, e in eng.items():
         for name, (cnt, ms) in e.profile_read().items():
-            kern[name] = kern.get(name, 0.0) + ms * 1e3 / k
+            kern[name] = kern.get(name, 0.0) + ms * 1e3 / max(args.profile_rounds, 1)
     tot = sum(t.values()) / k
-    print(json.dumps({"groups": G, "replicas": K, "ms_per_round": round(tot, 4),
+    print(json.dumps({"groups": G, "replicas": K, "ordered_batches_promise": not args.no_promise,
+                      "ms_per_round": round(tot, 4),
                       "phases_ms": {a: round(b / k, 4) for a, b in t.items()},
                       "decided_and_executed_per_s": round(G / tot * 1e3, 1),
                       "kernels_us_per_round": {a: round(b, 1) for a, b in sorted(kern.items())}}))

@@ -1,0 +1,24 @@
+#!/bin/bash
+# Pins the oracle to the REFERENCE'S OWN CLASSES (VERDICT r1 "missing" #1).
+# Needs a JDK (javac + java) and the reference checkout; neither exists in the build image or on the
+# GPU box, so this has not been run yet - the first box with a JDK produces tests/golden/ref_*.npz,
+# which tests/test_ref_fixtures.py then checks on the oracle (CPU) and the engine (GPU).
+#   scripts/make_ref_fixtures.sh /path/to/gigapaxos
+set -e
+REF=${1:-/root/reference}
+HERE=$(cd "$(dirname "$0")/.." && pwd)
+command -v javac >/dev/null || { echo "no JDK on this box (javac not found): nothing generated"; exit 3; }
+WORK=${WORK:-/tmp/ref_fixtures}
+mkdir -p "$WORK/classes"
+# the reference's own sources for this path + its vendored jars; its build system (ant) is not used
+find "$REF/src/edu/umass/cs/gigapaxos" "$REF/src/edu/umass/cs/utils" "$REF/src/edu/umass/cs/nio" \
+     "$REF/src/edu/umass/cs/reconfiguration" "$REF/src/edu/umass/cs/protocoltask" "$REF/src/edu/umass/cs/txn" \
+     "$REF/src/org" -name '*.java' > "$WORK/sources.txt" 2>/dev/null || true
+javac -nowarn -d "$WORK/classes" -cp "$REF/lib/*" @"$WORK/sources.txt" "$HERE/scripts/ref_fixtures/RefFixtureDump.java"
+python "$HERE/scripts/ref_fixtures/make_stream.py" --outdir "$WORK"
+for f in "$WORK"/*.in; do
+  # assertions OFF: production behaviour, the engine's and the oracle's modelling assumption
+  java -da -Xms2g -cp "$WORK/classes:$REF/lib/*" edu.umass.cs.gigapaxos.RefFixtureDump "$f" "${f%.in}.out"
+done
+python "$HERE/scripts/ref_fixtures/make_stream.py" --outdir "$WORK" --collect
+echo "now run: python -m pytest tests/test_ref_fixtures.py -q"

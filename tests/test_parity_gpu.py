@@ -35,6 +35,38 @@ def test_fuzz_ordered_batches(hip_lib, oracle_lib, kmax, G, seed):
     fuzz(eh, eo, G, NODES, rng, steps=160, batch=max(300, G), ordered=True)
 
 
+def test_ordered_batches_promise(hip_lib, oracle_lib):
+    """gpx_engine_set_ordered_batches: with the promise only the direct path is launched; a batch
+    that keeps it gives the usual answers, one that breaks it is refused whole (GPX_S_UNORDERED, no
+    state change) - engine and oracle alike."""
+    from gigapaxos_amd import ORDERED_PROPOSE, ORDERED_ACCEPT, ORDERED_COMMIT, S_UNORDERED
+    rng = np.random.default_rng(31)
+    G, kmax = 900, 3
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, kmax, 64)
+    create_mixed_groups(eh, eo, G, kmax, NODES, rng)
+    for e in (eh, eo):
+        e.set_ordered_batches(ORDERED_ACCEPT | ORDERED_COMMIT)
+    fuzz(eh, eo, G, NODES, rng, steps=120, batch=1200, ordered=True)   # 1 batch in 8 carries a bad index
+    for e in (eh, eo):
+        e.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT)
+    for g in (np.arange(G, dtype=np.int32), np.arange(0, G, 7, dtype=np.int32),
+              np.array([5, 5, 9], np.int32), np.arange(G, dtype=np.int32)[::-1].copy(),
+              np.array([3, 900, 901], np.int32), np.array([7], np.int32)):
+        ra, rb = eh.propose(g), eo.propose(g)
+        for x, y, nm in zip(ra, rb, ("slot", "bnum", "bcoord", "median", "status")):
+            assert x.tolist() == y.tolist(), nm
+        strictly = bool((np.diff(g) > 0).all()) and g.max() < G
+        assert (ra[4] == S_UNORDERED).all() == (not strictly)
+    z = np.zeros(4, np.int32)
+    for e in (eh, eo):   # broken promise on the acceptor side: nothing happens
+        (rb_, rc_, rm_, rf_, st), runs = e.accept(np.array([4, 2, 2, 9], np.int32), z, np.full(4, 100, np.int32), z + 1, z)
+        assert (st == S_UNORDERED).all() and runs.gidx.shape[0] == 0 and not rb_.any() and not rf_.any()
+        st, runs = e.commit(np.array([4, 2, 2, 9], np.int32), z, np.full(4, 100, np.int32), z + 1, z)
+        assert (st == S_UNORDERED).all() and runs.gidx.shape[0] == 0
+    assert_same_state(eh, eo, range(G))
+    assert eh.counters() == eo.counters()
+
+
 def test_fuzz_wraparound(hip_lib, oracle_lib):
     """slots straddle Integer.MAX_VALUE -> MIN_VALUE."""
     rng = np.random.default_rng(5)
