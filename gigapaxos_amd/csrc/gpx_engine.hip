@@ -19,6 +19,7 @@
 #include "gpx_kernels.hip.h"
 #include "gpx_ar16.hip.h"
 #include "gpx_direct.hip.h"
+#include "gpx_small.hip.h"
 #include "gpx_wire.hip.h"
 #include "gpx_elect.hip.h"
 
@@ -98,6 +99,10 @@ struct gpx_engine {
    * while a bucket has at most 1024 groups; GPX_AR_LEGACY=1 forces the 32-byte record path */
   bool ar16 = false;
   int32_t ordered_mask = 0; /* gpx_engine_set_ordered_batches */
+  /* single-launch path of small accept-reply batches (gpx_small.hip.h); GPX_SMALL=0 turns it off */
+  bool small_on = true;
+  unsigned long long* small_tickets = nullptr;
+  uint32_t small_epoch = 0;
   int32_t lds16_max = 0, lds16_hw = 0; /* LDS staging capacities (votes) of k_bucket_ar16 */
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
   /* wire codec (gpx_wire_host.inc): paxosID table, row free list, scratch - allocated on first use */
@@ -490,6 +495,17 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_hw));
   }
+  {
+    const char* sm = getenv("GPX_SMALL");
+    e->small_on = !(sm && !atoi(sm));
+    if ((rc = dev_alloc(e, &e->small_tickets, GPX_SMALL_MAX_WG, true)) != GPX_OK) {
+      gpx_engine_destroy(e);
+      return rc;
+    }
+    const void* fns[] = {(const void*)k_small_ar<4>, (const void*)k_small_ar<8>, (const void*)k_small_ar<16>};
+    for (const void* f : fns)
+      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
+  }
   if (e->ar16) {
     const size_t hw16 = GPX_BUCKET16_LDS_BYTES(X.gb, e->lds16_hw) + e->lds_pad;
     const void* fns[] = {(const void*)k_bucket_ar16<4>, (const void*)k_bucket_ar16<8>,
@@ -662,6 +678,44 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
   const size_t b4 = (size_t)n * 4;
   const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {acceptor, b4},
                                  {max_cp, b4}, {status, (size_t)n}});
+  /* a batch of at most 65,536 votes: one launch, nothing partitioned through HBM (gpx_small.hip.h) */
+  if (e->small_on && n <= GPX_SMALL_MAX_N) {
+    const int64_t lds_free = 160 * 1024 - 2048 - 2 * (int64_t)((n + 7) & ~7);
+    const int64_t gw_max = std::min<int64_t>(GPX_SMALL_MAX_GW, lds_free / 8);
+    const int64_t G = e->S.G;
+    int64_t W = (G + gw_max - 1) / gw_max;
+    W = std::max<int64_t>(W, std::min<int64_t>(256, (G + 63) / 64)); /* spread a small table over the CUs */
+    if (W <= GPX_SMALL_MAX_WG) {
+      const int32_t gw = (int32_t)((G + W - 1) / W);
+      W = (G + gw - 1) / gw;
+      begin_back(e, fs, n);
+      if (++e->small_epoch == 0) { /* 2^32 calls: restart the tickets' epochs */
+        HIPQ(hipMemsetAsync(e->small_tickets, 0, GPX_SMALL_MAX_WG * sizeof(unsigned long long), e->stream));
+        e->small_epoch = 1;
+      }
+      const size_t N = (size_t)e->cfg.max_batch;
+      int32_t* o32 = (int32_t*)e->X.o_rec;
+      SmallArgs A{n, gw, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord,
+                  d_median_cp, d_kind, n_out, status,
+                  Stage16{o32, o32 + N, o32 + 2 * N, o32 + 3 * N, o32 + 4 * N, (uint8_t*)(o32 + 5 * N)},
+                  e->small_tickets, e->small_epoch};
+      const size_t lds = (size_t)gw * 8 + (size_t)((n + 7) & ~7) * 2;
+      {
+        LaunchScope _ls(e, "k_small_ar");
+        if (e->cfg.kmax <= 4)
+          hipLaunchKernelGGL(k_small_ar<4>, dim3((int)W), dim3(GPX_SMALL_NT), lds, e->stream, e->S, e->X, A);
+        else if (e->cfg.kmax <= 8)
+          hipLaunchKernelGGL(k_small_ar<8>, dim3((int)W), dim3(GPX_SMALL_NT), lds, e->stream, e->S, e->X, A);
+        else
+          hipLaunchKernelGGL(k_small_ar<16>, dim3((int)W), dim3(GPX_SMALL_NT), lds, e->stream, e->S, e->X, A);
+      }
+      end_call(e, fs, {{d_gidx, b4}, {d_slot, b4}, {d_bnum, b4}, {d_bcoord, b4}, {d_median_cp, b4},
+                       {d_kind, (size_t)n}, {n_out, 4}, {status, (size_t)n}, {bnum, b4}, {bcoord, b4},
+                       {acceptor, b4}, {slot, b4}, {max_cp, b4}, {gidx, b4}});
+      HIPCHK(hipGetLastError());
+      return GPX_OK;
+    }
+  }
   front_hist(e, n, gidx, status, 1);
   const int ntiles = ntiles_for(n);
   const bool vec = aligned16({gidx, bnum, bcoord, slot, acceptor, max_cp});

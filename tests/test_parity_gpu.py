@@ -12,6 +12,15 @@ from tests.parity_common import (make_pair, create_mixed_groups, fuzz, assert_sa
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["small-batch path", "partition path"])
+def _accept_reply_path(request, monkeypatch):
+    """Accept-reply batches of at most 65,536 votes take the single-launch path (gpx_small.hip.h) by
+    default; GPX_SMALL=0 (read at engine creation) sends them through the partition pipeline like the
+    big ones.  Every case of this file runs both ways."""
+    monkeypatch.setenv("GPX_SMALL", "1" if request.param.startswith("small") else "0")
+
+
 NODES = [100, 101, 102, 103, 104, 105, 106, 107]
 
 
