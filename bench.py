@@ -44,6 +44,7 @@ def main():
     ap.add_argument("--cpu-rounds", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline leg (0 = every host core)")
+    ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the engine-vs-oracle replay of the CPU sample")
     ap.add_argument("--cpu-mt-passes", type=int, default=16, help="passes over the sample in the multi-threaded leg")
     ap.add_argument("--no-promise", action="store_true",
@@ -222,6 +223,46 @@ def main():
             "kernels_ms_per_step": {k: round(v[1] / psteps, 4) for k, v in sorted(kstats.items())},
         }
 
+    # ---- end to end through the HOST-pointer entry points (what a JNI caller with direct ByteBuffers
+    # gets): every input column crosses PCIe in, every output column comes back; never `value` -------
+    end_to_end = None
+    if rank == 0 and world == 1 and not args.no_end_to_end:
+        from gigapaxos_amd._abi import _p
+        ee = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
+        assert (ee.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
+        e2e_rounds = 4
+        hcols = [[np.ascontiguousarray(c) for c in streams.vote_round(G, members, r, 100, config_id=cfg_id,
+                                                                        shuffled=not args.sorted, mix=args.mix)]
+                 for r in range(e2e_rounds)]
+        hg = np.arange(G, dtype=np.int32)
+        ho = [np.zeros(G, np.int32) for _ in range(4)] + [np.zeros(G, np.uint8)]
+        hd = [np.zeros(nv, np.int32) for _ in range(5)] + [np.zeros(nv, np.uint8)]
+        hno, hst = np.zeros(1, np.int32), np.zeros(nv, np.uint8)
+        pinned = [hg, hno, hst] + ho + hd + [c for cols in hcols for c in cols]
+        ee.host_register(*pinned)  # a JNI host registers its direct ByteBuffers once (gpx_host_register)
+        fn_p, fn_a = ee.lib.fn["propose_batch"], ee.lib.fn["accept_reply_batch"]
+
+        def host_step(r):
+            rc = fn_p(ee.h, G, _p(hg), None, _p(ho[0]), _p(ho[1]), _p(ho[2]), _p(ho[3]), _p(ho[4]))
+            c = hcols[r]
+            rc |= fn_a(ee.h, nv, _p(c[0]), _p(c[1]), _p(c[2]), _p(c[3]), _p(c[4]), _p(c[5]), _p(hd[0]), _p(hd[1]),
+                       _p(hd[2]), _p(hd[3]), _p(hd[4]), _p(hd[5]), _p(hno), _p(hst))
+            assert rc == 0
+        host_step(0)
+        te = time.perf_counter()
+        for r in range(1, e2e_rounds):
+            host_step(r)
+        te = (time.perf_counter() - te) / (e2e_rounds - 1)
+        assert args.mix or int(hno[0]) == G
+        pcie = G * 4 + G * 17 + nv * 24 + nv + int(hno[0]) * 21 + 4
+        end_to_end = {"ms_per_step": round(te * 1e3, 4), "decisions_per_sec": round(int(hno[0]) / te, 1),
+                      "votes_per_sec": round(nv / te, 1), "bytes_over_pcie_per_step": int(pcie),
+                      "pcie_GBps": round(pcie / te / 1e9, 1),
+                      "path": "gpx_propose_batch + gpx_accept_reply_batch with HOST pointers (registered memory): "
+                              "H2D of every input column, kernels, D2H of every output column, per call"}
+        ee.host_unregister(*pinned)
+        ee.close()
+
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores ---
     cpu_baseline = None
     parity_checked = None
@@ -355,6 +396,7 @@ def main():
             "gpu_ms_per_step_rank0": round(gpu_ms / steps, 4),
             "pipelined": bool(args.pipelined),
             "roofline": roofline,
+            "end_to_end": end_to_end,
             "cpu_baseline": cpu_baseline,
             "parity_checked": parity_checked,
         }

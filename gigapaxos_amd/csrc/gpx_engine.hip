@@ -23,6 +23,8 @@
 #include "gpx_wire.hip.h"
 #include "gpx_elect.hip.h"
 
+#define GPX_STAGE_N 32768 /* host-pointer calls up to this many records cross PCIe as one block each way */
+#define GPX_STAGE_BYTES ((size_t)GPX_STAGE_N * 48 + 4096)
 namespace {
 
 thread_local char g_err[256] = "";
@@ -99,6 +101,10 @@ struct gpx_engine {
    * while a bucket has at most 1024 groups; GPX_AR_LEGACY=1 forces the 32-byte record path */
   bool ar16 = false;
   int32_t ordered_mask = 0; /* gpx_engine_set_ordered_batches */
+  /* host-pointer calls of small batches: ONE staged H2D and ONE D2H per call (pinned host block <->
+   * device block) instead of a copy per column */
+  char *hs_in = nullptr, *hs_out = nullptr; /* pinned host */
+  char *ds_in = nullptr, *ds_out = nullptr; /* device */
   /* single-launch path of small accept-reply batches (gpx_small.hip.h); GPX_SMALL=0 turns it off */
   bool small_on = true;
   unsigned long long* small_tickets = nullptr;
@@ -374,6 +380,46 @@ void launch_bucket_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t*
            status, handle);
 }
 
+/* ---- staged host-pointer calls -------------------------------------------------------- */
+/* A small batch (at most GPX_STAGE_N records) crosses PCIe as ONE block each way: the caller's columns
+ * are packed into a pinned host block (a few KB .. 1 MB of memcpy), one hipMemcpyAsync takes it to the
+ * device, the _dev twin runs on slices of the device blocks, one hipMemcpyAsync brings every output
+ * column back (full capacity: counts are not known before), one stream wait.  A copy per column
+ * costs ~8 us of runtime each - 14 of them were most of a tiny call's ~130 us. */
+struct Stage {
+  gpx_engine* e;
+  size_t in_off = 0, out_off = 0;
+  explicit Stage(gpx_engine* e_) : e(e_) {}
+  static size_t a16(size_t b) { return (b + 15) & ~(size_t)15; }
+  /* packs one input column; returns its device address (null column -> null) */
+  template <typename T>
+  const T* in(const T* host, size_t count) {
+    if (!host) return nullptr;
+    const size_t b = count * sizeof(T);
+    memcpy(e->hs_in + in_off, host, b);
+    const T* d = (const T*)(e->ds_in + in_off);
+    in_off += a16(b);
+    return d;
+  }
+  /* reserves one output column; *host_view = where it will be in the pinned block after finish() */
+  template <typename T>
+  T* out(size_t count, const T** host_view) {
+    T* d = (T*)(e->ds_out + out_off);
+    *host_view = (const T*)(e->hs_out + out_off);
+    out_off += a16(count * sizeof(T));
+    return d;
+  }
+  int upload() {
+    if (in_off) HIPCHK(hipMemcpyAsync(e->ds_in, e->hs_in, in_off, hipMemcpyHostToDevice, e->sF));
+    return GPX_OK;
+  }
+  int finish() {
+    HIPCHK(hipMemcpyAsync(e->hs_out, e->ds_out, out_off, hipMemcpyDeviceToHost, e->sB));
+    HIPCHK(hipStreamSynchronize(e->sB));
+    return GPX_OK;
+  }
+};
+
 }  // namespace
 
 extern "C" {
@@ -502,6 +548,13 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
       gpx_engine_destroy(e);
       return rc;
     }
+    HIPCHK(hipHostMalloc((void**)&e->hs_in, GPX_STAGE_BYTES, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc((void**)&e->hs_out, GPX_STAGE_BYTES, hipHostMallocDefault));
+    if ((rc = dev_alloc(e, &e->ds_in, GPX_STAGE_BYTES, false)) != GPX_OK ||
+        (rc = dev_alloc(e, &e->ds_out, GPX_STAGE_BYTES, false)) != GPX_OK) {
+      gpx_engine_destroy(e);
+      return rc;
+    }
     const void* fns[] = {(const void*)k_small_ar<4>, (const void*)k_small_ar<8>, (const void*)k_small_ar<16>};
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
@@ -557,6 +610,8 @@ int gpx_engine_destroy(gpx_engine* h) {
     HIPQ(hipEventDestroy(pe.stop));
   }
   for (void* p : h->allocs) HIPQ(hipFree(p));
+  if (h->hs_in) HIPQ(hipHostFree(h->hs_in));
+  if (h->hs_out) HIPQ(hipHostFree(h->hs_out));
   if (h->arena) HIPQ(hipFree(h->arena));
   if (h->own_stream) HIPQ(hipStreamDestroy(h->own_stream));
   if (h->front_stream) HIPQ(hipStreamDestroy(h->front_stream));
@@ -934,6 +989,29 @@ int gpx_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uin
   if (n == 0) return GPX_OK;
   if (!gidx || !slot || !bnum || !bcoord || !median_cp || !status) return GPX_EINVAL;
   const size_t b4 = (size_t)n * 4;
+  if (n <= GPX_STAGE_N) { /* one block each way */
+    Stage st(h);
+    const int32_t* dg = st.in(gidx, (size_t)n);
+    const uint8_t* ds = st.in(is_stop, (size_t)n);
+    const int64_t* dh = st.in(handle, (size_t)n);
+    const int32_t *v_slot, *v_bnum, *v_bcoord, *v_med;
+    const uint8_t* v_st;
+    int32_t* o_slot = st.out<int32_t>((size_t)n, &v_slot);
+    int32_t* o_bnum = st.out<int32_t>((size_t)n, &v_bnum);
+    int32_t* o_bcoord = st.out<int32_t>((size_t)n, &v_bcoord);
+    int32_t* o_med = st.out<int32_t>((size_t)n, &v_med);
+    uint8_t* o_st = st.out<uint8_t>((size_t)n, &v_st);
+    if ((rc = st.upload()) != GPX_OK) return rc;
+    rc = propose_dev_impl(h, n, dg, ds, dh, o_slot, o_bnum, o_bcoord, o_med, o_st);
+    if (rc != GPX_OK) return rc;
+    if ((rc = st.finish()) != GPX_OK) return rc;
+    memcpy(slot, v_slot, b4);
+    memcpy(bnum, v_bnum, b4);
+    memcpy(bcoord, v_bcoord, b4);
+    memcpy(median_cp, v_med, b4);
+    memcpy(status, v_st, (size_t)n);
+    return GPX_OK;
+  }
   H2D(h->st_i32[0], gidx, b4);
   if (is_stop) H2D(h->st_u8[0], is_stop, (size_t)n);
   /* staging column of the 64-bit handles: allocated on first use */
@@ -969,6 +1047,41 @@ int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   *n_runs = 0;
   if (n == 0) return GPX_OK;
   const size_t b4 = (size_t)n * 4;
+  if (n <= GPX_STAGE_N) { /* one block each way */
+    Stage st(h);
+    const int32_t* dg = st.in(gidx, (size_t)n);
+    const int32_t* db = st.in(bnum, (size_t)n);
+    const int32_t* dc = st.in(bcoord, (size_t)n);
+    const int32_t* dsl = st.in(slot, (size_t)n);
+    const int32_t* dm = st.in(median_cp, (size_t)n);
+    const uint8_t* df = st.in(a_flags, (size_t)n);
+    const int32_t *v_rb, *v_rc, *v_rm, *v_xg, *v_xf, *v_xc, *v_nr;
+    const uint8_t *v_rf, *v_st;
+    int32_t* o_rb = st.out<int32_t>((size_t)n, &v_rb);
+    int32_t* o_rc = st.out<int32_t>((size_t)n, &v_rc);
+    int32_t* o_rm = st.out<int32_t>((size_t)n, &v_rm);
+    uint8_t* o_rf = st.out<uint8_t>((size_t)n, &v_rf);
+    uint8_t* o_st = st.out<uint8_t>((size_t)n, &v_st);
+    int32_t* o_xg = st.out<int32_t>((size_t)n, &v_xg);
+    int32_t* o_xf = st.out<int32_t>((size_t)n, &v_xf);
+    int32_t* o_xc = st.out<int32_t>((size_t)n, &v_xc);
+    int32_t* o_nr = st.out<int32_t>(4, &v_nr);
+    if ((rc = st.upload()) != GPX_OK) return rc;
+    rc = gpx_accept_batch_dev(h, n, dg, db, dc, dsl, dm, df, o_rb, o_rc, o_rm, o_rf, o_st, o_xg, o_xf, o_xc, o_nr);
+    if (rc != GPX_OK) return rc;
+    if ((rc = st.finish()) != GPX_OK) return rc;
+    memcpy(r_bnum, v_rb, b4);
+    memcpy(r_bcoord, v_rc, b4);
+    memcpy(r_maxcp, v_rm, b4);
+    memcpy(r_flags, v_rf, (size_t)n);
+    memcpy(status, v_st, (size_t)n);
+    *n_runs = v_nr[0];
+    const size_t m4 = (size_t)(*n_runs) * 4;
+    memcpy(x_gidx, v_xg, m4);
+    memcpy(x_first, v_xf, m4);
+    memcpy(x_count, v_xc, m4);
+    return GPX_OK;
+  }
   H2D(h->st_i32[0], gidx, b4);
   H2D(h->st_i32[1], bnum, b4);
   H2D(h->st_i32[2], bcoord, b4);
@@ -1008,6 +1121,39 @@ int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
   *n_out = 0;
   if (n == 0) return GPX_OK;
   const size_t b4 = (size_t)n * 4;
+  if (n <= GPX_STAGE_N) { /* one block each way */
+    Stage st(h);
+    const int32_t* dg = st.in(gidx, (size_t)n);
+    const int32_t* db = st.in(bnum, (size_t)n);
+    const int32_t* dc = st.in(bcoord, (size_t)n);
+    const int32_t* dsl = st.in(slot, (size_t)n);
+    const int32_t* da = st.in(acceptor, (size_t)n);
+    const int32_t* dm = st.in(max_cp, (size_t)n);
+    const int32_t *v_g, *v_s, *v_b, *v_c, *v_m, *v_no;
+    const uint8_t *v_k, *v_st;
+    int32_t* o_g = st.out<int32_t>((size_t)n, &v_g);
+    int32_t* o_s = st.out<int32_t>((size_t)n, &v_s);
+    int32_t* o_b = st.out<int32_t>((size_t)n, &v_b);
+    int32_t* o_c = st.out<int32_t>((size_t)n, &v_c);
+    int32_t* o_m = st.out<int32_t>((size_t)n, &v_m);
+    uint8_t* o_k = st.out<uint8_t>((size_t)n, &v_k);
+    uint8_t* o_st = st.out<uint8_t>((size_t)n, &v_st);
+    int32_t* o_no = st.out<int32_t>(4, &v_no);
+    if ((rc = st.upload()) != GPX_OK) return rc;
+    rc = gpx_accept_reply_batch_dev(h, n, dg, db, dc, dsl, da, dm, o_g, o_s, o_b, o_c, o_m, o_k, o_no, o_st);
+    if (rc != GPX_OK) return rc;
+    if ((rc = st.finish()) != GPX_OK) return rc;
+    *n_out = v_no[0];
+    const size_t m = (size_t)(*n_out);
+    memcpy(d_gidx, v_g, m * 4);
+    memcpy(d_slot, v_s, m * 4);
+    memcpy(d_bnum, v_b, m * 4);
+    memcpy(d_bcoord, v_c, m * 4);
+    memcpy(d_median_cp, v_m, m * 4);
+    memcpy(d_kind, v_k, m);
+    if (status) memcpy(status, v_st, (size_t)n);
+    return GPX_OK;
+  }
   H2D(h->st_i32[0], gidx, b4);
   H2D(h->st_i32[1], bnum, b4);
   H2D(h->st_i32[2], bcoord, b4);
@@ -1045,6 +1191,33 @@ int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   *n_runs = 0;
   if (n == 0) return GPX_OK;
   const size_t b4 = (size_t)n * 4;
+  if (n <= GPX_STAGE_N) { /* one block each way */
+    Stage st(h);
+    const int32_t* dg = st.in(gidx, (size_t)n);
+    const int32_t* db = st.in(bnum, (size_t)n);
+    const int32_t* dc = st.in(bcoord, (size_t)n);
+    const int32_t* dsl = st.in(slot, (size_t)n);
+    const int32_t* dm = st.in(median_cp, (size_t)n);
+    const uint8_t* dk = st.in(c_kind, (size_t)n);
+    const int32_t *v_xg, *v_xf, *v_xc, *v_nr;
+    const uint8_t* v_st;
+    uint8_t* o_st = st.out<uint8_t>((size_t)n, &v_st);
+    int32_t* o_xg = st.out<int32_t>((size_t)n, &v_xg);
+    int32_t* o_xf = st.out<int32_t>((size_t)n, &v_xf);
+    int32_t* o_xc = st.out<int32_t>((size_t)n, &v_xc);
+    int32_t* o_nr = st.out<int32_t>(4, &v_nr);
+    if ((rc = st.upload()) != GPX_OK) return rc;
+    rc = gpx_commit_batch_dev(h, n, dg, db, dc, dsl, dm, dk, o_st, o_xg, o_xf, o_xc, o_nr);
+    if (rc != GPX_OK) return rc;
+    if ((rc = st.finish()) != GPX_OK) return rc;
+    memcpy(status, v_st, (size_t)n);
+    *n_runs = v_nr[0];
+    const size_t m4 = (size_t)(*n_runs) * 4;
+    memcpy(x_gidx, v_xg, m4);
+    memcpy(x_first, v_xf, m4);
+    memcpy(x_count, v_xc, m4);
+    return GPX_OK;
+  }
   H2D(h->st_i32[0], gidx, b4);
   H2D(h->st_i32[1], bnum, b4);
   H2D(h->st_i32[2], bcoord, b4);

@@ -28,8 +28,8 @@ cat "$OUT/bench.json"
 tail -3 "$OUT/bench.err"
 # per-kernel traces are taken with --serial (no cross-call overlap: each kernel alone on the GPU, the
 # regime bench.py's own hipEvent pass measures); the pipelined default is traced once as well
-BENCH="python $REPO/bench.py --steps 10 --warmup 2 --profile-steps 0 --no-cpu-baseline"
-BENCH_PIPE="python $REPO/bench.py --steps 10 --warmup 2 --profile-steps 0 --no-cpu-baseline --pipelined"
+BENCH="python $REPO/bench.py --steps 10 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-end-to-end"
+BENCH_PIPE="python $REPO/bench.py --steps 10 --warmup 2 --profile-steps 0 --no-cpu-baseline --no-end-to-end --pipelined"
 cd /tmp
 timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/prof_kt" -o kt -- $BENCH >"$OUT/prof_kt.log" 2>&1
 echo "kt exit $?"
