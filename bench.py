@@ -47,6 +47,10 @@ def main():
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the engine-vs-oracle replay of the CPU sample")
     ap.add_argument("--cpu-mt-passes", type=int, default=16, help="passes over the sample in the multi-threaded leg")
+    ap.add_argument("--split-global", action="store_true",
+                    help="BASELINE config #4's shape: ONE space of --groups groups hash-sharded over the ranks "
+                         "(fmix32(gidx) %% world, gigapaxos_amd.sharding.ShardMap), each rank an independent "
+                         "engine over its shard: total work fixed -> strong scaling")
     ap.add_argument("--no-promise", action="store_true",
                     help="do not declare the proposal batches ordered (gpx_engine_set_ordered_batches)")
     ap.add_argument("--pipelined", action="store_true",
@@ -71,6 +75,12 @@ def main():
     from gigapaxos_amd import Engine, hri_create, load_hip, streams, S_OK
 
     G, K = args.groups, args.k
+    G_global = G
+    if args.split_global:
+        # this rank's shard of the one global space; its engine indexes the shard densely (ShardMap.local),
+        # its stream is generated for exactly its groups - shards are independent (PaxosManager.java:3170-3171)
+        from gigapaxos_amd.sharding import ShardMap
+        G = int(ShardMap(G_global, world).counts[rank])
     members = list(range(100, 100 + K))
     steps, warmup, psteps = args.steps, args.warmup, args.profile_steps
     rounds = warmup + steps + psteps
@@ -379,15 +389,19 @@ def main():
             "warmup": warmup,
             "ms_per_step": round(elapsed * 1e3 / steps, 4),
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if args.split_global else "weak",
             "vs_baseline": None,
             "dtype": "int32",
             "data": "synthetic",
             "config": {
-                "workload": "BASELINE config #3: 1M Paxos groups x %d replicas per GPU, synthetic %s accept-reply "
-                            "stream%s; step = propose_batch(G) + accept_reply_batch(K*G votes), inputs resident in HBM"
-                            % (K, "sorted" if args.sorted else "shuffled", " + adversarial mix" if args.mix else ""),
-                "groups_per_gpu": G, "replicas": K, "votes_per_step_per_gpu": nv,
+                "workload": ("BASELINE config #4: %d Paxos groups x %d replicas hash-sharded over %d GPU(s) "
+                             "(fmix32(gidx) %% n), independent shards" % (G_global, K, world) if args.split_global else
+                             "BASELINE config #3: %d Paxos groups x %d replicas per GPU" % (G, K)) +
+                            ", synthetic %s accept-reply stream%s; step = propose_batch(G) + accept_reply_batch(K*G "
+                            "votes), inputs resident in HBM"
+                            % ("sorted" if args.sorted else "shuffled", " + adversarial mix" if args.mix else ""),
+                "groups_per_gpu": G, "groups_total": G_global if args.split_global else G * world,
+                "replicas": K, "votes_per_step_per_gpu": nv,
                 "ordered_proposals_promise": not args.no_promise,
                 "parallelism": "groups sharded across GPUs, no collective on the decide path",
             },

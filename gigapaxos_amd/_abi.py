@@ -107,6 +107,7 @@ _DEV_SIGS = {
     "election_begin_dev": [C.c_int32] + [_VP] * 3,
     "propose_batch_h_dev": [C.c_int32] + [_VP] * 8,
     "prepare_reply_batch_dev": [C.c_int32] + [_VP] * 6 + [C.c_int32] + [_VP] * 13,
+    "route_batch_dev": [C.c_int32, C.c_int32, _VP, _VP, C.c_int32, C.c_int32, _VP, _VP],
     "profile_enable": [C.c_int32],
     "profile_read": [C.POINTER(GpxKernelStat), C.c_int32],
 }
@@ -354,6 +355,17 @@ class Engine:
         """Raw asynchronous call of gpx_<name>_dev with integer device addresses (0 = NULL)."""
         args = [_VP(int(p)) if p else None for p in ptrs]
         self.lib.check(self.lib.fn[name + "_dev"](self.h, int(n), *args), name + "_dev")
+
+    def route_dev(self, n: int, col_ptrs, g2l_ptr: int, n_groups_global: int, n_shards: int, out_ptrs,
+                  shard_off_ptr: int):
+        """gpx_route_batch_dev: stable partition of device columns by fmix32(gidx) % n_shards (integer
+        device addresses; col_ptrs[0] = the global group index column)."""
+        k = len(col_ptrs)
+        ins = (C.c_void_p * k)(*[int(p) for p in col_ptrs])
+        outs = (C.c_void_p * k)(*[int(p) for p in out_ptrs])
+        self.lib.check(self.lib.fn["route_batch_dev"](self.h, int(n), k, ins, _VP(int(g2l_ptr) or None),
+                                                      int(n_groups_global), int(n_shards), outs,
+                                                      _VP(int(shard_off_ptr))), "route_batch_dev")
 
     def profile(self, enable: int):
         """0 = off, 1 = on, 2 = on + reset accumulated stats."""

@@ -20,6 +20,7 @@
 #include "gpx_ar16.hip.h"
 #include "gpx_direct.hip.h"
 #include "gpx_small.hip.h"
+#include "gpx_route.hip.h"
 #include "gpx_wire.hip.h"
 #include "gpx_elect.hip.h"
 
@@ -105,6 +106,7 @@ struct gpx_engine {
    * device block) instead of a copy per column */
   char *hs_in = nullptr, *hs_out = nullptr; /* pinned host */
   char *ds_in = nullptr, *ds_out = nullptr; /* device */
+  int32_t* route_cnt = nullptr; /* gpx_route_batch_dev: [tiles][shards], allocated on first use */
   /* single-launch path of small accept-reply batches (gpx_small.hip.h); GPX_SMALL=0 turns it off */
   bool small_on = true;
   unsigned long long* small_tickets = nullptr;
@@ -715,6 +717,53 @@ int gpx_profile_read(gpx_engine* h, gpx_kernel_stat* out, int32_t cap) {
   return i;
 }
 
+/* ---- sharding ----------------------------------------------------------------------- */
+
+int gpx_route_batch_dev(gpx_engine* h, int32_t n, int32_t n_cols, const int32_t* const* cols,
+                        const int32_t* g2l, int32_t n_groups_global, int32_t n_shards,
+                        int32_t* const* out_cols, int32_t* shard_off) {
+  int rc = check_batch(h, n);
+  if (rc != GPX_OK) return rc;
+  if (!cols || !out_cols || !shard_off || n_cols < 1 || n_cols > GPX_ROUTE_MAX_COLS || n_shards < 1 ||
+      n_shards > GPX_ROUTE_MAX_SHARDS || n_groups_global <= 0)
+    return GPX_EINVAL;
+  gpx_engine* e = h;
+  e->stream = e->sB;
+  if (!e->route_cnt) {
+    const size_t tiles = ((size_t)e->cfg.max_batch + GPX_ROUTE_TILE - 1) / GPX_ROUTE_TILE;
+    rc = dev_alloc(e, &e->route_cnt, tiles * GPX_ROUTE_MAX_SHARDS, false);
+    if (rc != GPX_OK) return rc;
+  }
+  RouteCols C{};
+  C.ncols = n_cols;
+  for (int k = 0; k < n_cols; k++) {
+    if (!cols[k] || !out_cols[k]) return GPX_EINVAL;
+    C.in[k] = cols[k];
+    C.out[k] = out_cols[k];
+  }
+  const int ntiles = (n + GPX_ROUTE_TILE - 1) / GPX_ROUTE_TILE;
+  if (n == 0) {
+    HIPCHK(hipMemsetAsync(shard_off, 0, sizeof(int32_t) * (size_t)(n_shards + 1), e->stream));
+    return GPX_OK;
+  }
+  {
+    LaunchScope _ls(e, "k_route_count");
+    hipLaunchKernelGGL(k_route_count, dim3(ntiles), dim3(GPX_ROUTE_NT), 0, e->stream, n, cols[0], n_groups_global,
+                       n_shards, e->route_cnt);
+  }
+  {
+    LaunchScope _ls(e, "k_route_offsets");
+    hipLaunchKernelGGL(k_route_offsets, dim3(1), dim3(GPX_ROUTE_NT), 0, e->stream, ntiles, n_shards, e->route_cnt, shard_off);
+  }
+  {
+    LaunchScope _ls(e, "k_route_scatter");
+    hipLaunchKernelGGL(k_route_scatter, dim3(ntiles), dim3(GPX_ROUTE_NT), 0, e->stream, n, n_groups_global, n_shards,
+                       C, g2l, (const int32_t*)e->route_cnt, (const int32_t*)shard_off);
+  }
+  HIPCHK(hipGetLastError());
+  return GPX_OK;
+}
+
 /* ---- device-pointer data path ------------------------------------------------- */
 
 int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
@@ -736,7 +785,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
   /* a batch of at most 65,536 votes: one launch, nothing partitioned through HBM (gpx_small.hip.h) */
   if (e->small_on && n <= GPX_SMALL_MAX_N) {
     const int64_t lds_free = 160 * 1024 - 2048 - 2 * (int64_t)((n + 7) & ~7);
-    const int64_t gw_max = std::min<int64_t>(GPX_SMALL_MAX_GW, lds_free / 8);
+    const int64_t gw_max = std::min<int64_t>(GPX_SMALL_MAX_GW, (lds_free - 64) / 10);
     const int64_t G = e->S.G;
     int64_t W = (G + gw_max - 1) / gw_max;
     W = std::max<int64_t>(W, std::min<int64_t>(256, (G + 63) / 64)); /* spread a small table over the CUs */
@@ -754,7 +803,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
                   d_median_cp, d_kind, n_out, status,
                   Stage16{o32, o32 + N, o32 + 2 * N, o32 + 3 * N, o32 + 4 * N, (uint8_t*)(o32 + 5 * N)},
                   e->small_tickets, e->small_epoch};
-      const size_t lds = (size_t)gw * 8 + (size_t)((n + 7) & ~7) * 2;
+      const size_t lds = (size_t)gw * 8 + (size_t)((gw + 7) & ~7) * 2 + (size_t)((n + 7) & ~7) * 2;
       {
         LaunchScope _ls(e, "k_small_ar");
         if (e->cfg.kmax <= 4)

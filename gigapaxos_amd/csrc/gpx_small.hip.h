@@ -101,13 +101,16 @@ __global__ __launch_bounds__(GPX_SMALL_NT) void k_small_ar(DevState S, DevScratc
   const int32_t g0 = w * gw;
   int32_t* lcnt = lds;           /* [gw] votes of each of my groups; later: outputs */
   int32_t* lcur = lds + gw;      /* [gw] segment cursor / end */
-  uint16_t* seg = (uint16_t*)(lds + 2 * gw); /* [n] arrival indices, group-major */
+  uint16_t* glist = (uint16_t*)(lds + 2 * gw);       /* [gw] my groups that received votes, ascending */
+  uint16_t* seg = glist + ((gw + 7) & ~7);           /* [n] arrival indices, group-major */
   __shared__ int32_t s_any_long, s_tot;
   const int32_t nt = (int32_t)blockDim.x;
   for (int32_t l = threadIdx.x; l < gw; l += nt) lcnt[l] = 0;
   if (threadIdx.x == 0) s_any_long = 0;
   __syncthreads();
-  /* pass 1: count; workgroup w also writes the status of the w-th slice of the batch */
+  /* pass 1: count.  The status of a vote is written by the workgroup that owns its group (pass 2:
+   * GPX_S_OK, overwritten by the replay for a missing / stopped group - same workgroup, ordered by a
+   * barrier); a vote whose index is out of range has no owner: workgroup 0 marks it */
   const bool vec = !((uintptr_t)A.gidx & 15);
   int32_t bad = 0;
   for (int32_t i0 = (int32_t)threadIdx.x * 4; i0 < n; i0 += nt * 4) {
@@ -117,24 +120,23 @@ __global__ __launch_bounds__(GPX_SMALL_NT) void k_small_ar(DevState S, DevScratc
       g[0] = v.x, g[1] = v.y, g[2] = v.z, g[3] = v.w;
     } else {
 #pragma unroll
-      for (int q = 0; q < 4; q++) g[q] = i0 + q < n ? A.gidx[i0 + q] : -1;
+      for (int q = 0; q < 4; q++) g[q] = i0 + q < n ? A.gidx[i0 + q] : 0;
     }
 #pragma unroll
     for (int q = 0; q < 4; q++) {
+      if (i0 + q >= n) continue;
       const uint32_t lg = (uint32_t)(g[q] - g0);
-      if (lg < (uint32_t)gw && (uint32_t)g[q] < (uint32_t)S.G) atomicAdd(&lcnt[lg], 1);
+      const bool inr = (uint32_t)g[q] < (uint32_t)S.G;
+      if (lg < (uint32_t)gw && inr) atomicAdd(&lcnt[lg], 1);
+      if (w == 0 && !inr) { /* PaxosManager.java:1162-1194 */
+        if (A.status) A.status[i0 + q] = GPX_S_NOGROUP;
+        bad++;
+      }
     }
   }
-  {
-    const int32_t per = (n + (int32_t)gridDim.x - 1) / (int32_t)gridDim.x;
-    const int32_t lo = w * per, hi = min(n, lo + per);
-    for (int32_t i = lo + (int32_t)threadIdx.x; i < hi; i += nt) {
-      const bool oob = (uint32_t)A.gidx[i] >= (uint32_t)S.G;
-      if (A.status) A.status[i] = oob ? GPX_S_NOGROUP : GPX_S_OK; /* PaxosManager.java:1162-1194 */
-      bad += oob;
-    }
+  if (w == 0) {
     if (bad) atomicAdd(&X.counters[2], (unsigned long long)bad);
-    if (w == 0 && threadIdx.x == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
+    if (threadIdx.x == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
   }
   __syncthreads();
   /* scan: thread t owns `per` consecutive groups */
@@ -161,12 +163,16 @@ __global__ __launch_bounds__(GPX_SMALL_NT) void k_small_ar(DevState S, DevScratc
         g[0] = v.x, g[1] = v.y, g[2] = v.z, g[3] = v.w;
       } else {
 #pragma unroll
-        for (int q = 0; q < 4; q++) g[q] = i0 + q < n ? A.gidx[i0 + q] : -1;
+        for (int q = 0; q < 4; q++) g[q] = i0 + q < n ? A.gidx[i0 + q] : 0;
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
+        if (i0 + q >= n) continue;
         const uint32_t lg = (uint32_t)(g[q] - g0);
-        if (lg < (uint32_t)gw && (uint32_t)g[q] < (uint32_t)S.G) seg[atomicAdd(&lcur[lg], 1)] = (uint16_t)(i0 + q);
+        if (lg < (uint32_t)gw && (uint32_t)g[q] < (uint32_t)S.G) {
+          seg[atomicAdd(&lcur[lg], 1)] = (uint16_t)(i0 + q);
+          if (A.status) A.status[i0 + q] = GPX_S_OK;
+        }
       }
     }
   __syncthreads();
@@ -178,14 +184,25 @@ __global__ __launch_bounds__(GPX_SMALL_NT) void k_small_ar(DevState S, DevScratc
     }
     __syncthreads(); /* the replay below rewrites lcnt / lcur of its own groups */
   }
-  /* replay: lane t owns groups l0 .. l0 + per - 1 */
+  /* the groups that received votes, compacted in group order: a batch this small touches few of a
+   * workgroup's groups, and every lane should replay one of them rather than walk its own empty ones */
+  int32_t ne = 0;
+  for (int32_t q = 0; q < per; q++)
+    if (l0 + q < gw && lcnt[l0 + q] != 0) ne++;
+  int32_t nne;
+  int32_t nex = block_exscan_n<GPX_SMALL_NT>(ne, &nne);
+  for (int32_t q = 0; q < per; q++)
+    if (l0 + q < gw && lcnt[l0 + q] != 0) glist[nex++] = (uint16_t)(l0 + q);
+  __syncthreads();
+  /* replay: lane t owns the touched groups k0 .. k1 - 1 (usually one) */
+  const int32_t chunk = (nne + nt - 1) / nt;
+  const int32_t k0 = (int32_t)threadIdx.x * chunk, k1 = min(nne, k0 + chunk);
   int32_t my_out = 0;
-  for (int32_t q = 0; q < per; q++) {
-    const int32_t l = l0 + q;
-    if (l >= gw) break;
+  for (int32_t k = k0; k < k1; k++) {
+    const int32_t l = (int32_t)glist[k];
     const int32_t c = lcnt[l];
     int32_t nout = 0;
-    if (c != 0) {
+    {
       const int32_t g = g0 + l;
       const int32_t start = lcur[l] - c; /* the cursor ran to the segment's end during pass 2 */
       lcur[l] = start;                   /* from here on: the segment's start (read again when the outputs leave) */
@@ -242,14 +259,12 @@ __global__ __launch_bounds__(GPX_SMALL_NT) void k_small_ar(DevState S, DevScratc
   __syncthreads();
   const int32_t base = s_tot;
   int32_t o = base + oex;
-  for (int32_t q = 0; q < per; q++) {
-    const int32_t l = l0 + q;
-    if (l >= gw) break;
+  for (int32_t k = k0; k < k1; k++) {
+    const int32_t l = (int32_t)glist[k];
     const int32_t nout = lcnt[l];
-    if (!nout) continue;
     const uint16_t* sg = seg + lcur[l]; /* the outputs' votes are listed from the segment's first word on */
-    for (int32_t k = 0; k < nout; k++) {
-      const int32_t ix = (int32_t)sg[k];
+    for (int32_t q = 0; q < nout; q++) {
+      const int32_t ix = (int32_t)sg[q];
       A.d_gidx[o] = g0 + l;
       A.d_slot[o] = A.O.slot[ix];
       A.d_bnum[o] = A.O.bnum[ix];

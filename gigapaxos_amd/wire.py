@@ -350,6 +350,23 @@ def bar_frames_single_slot(name_rows, version, acceptor, bnum, bcoord, max_cp, s
     return f.reshape(-1), off
 
 
+def accept_frames_fixed(name_rows, version, slot, bnum, bcoord, median_cp, sender, value_len=64):
+    """n ACCEPT frames (AcceptPacket.toBytes) with a `value_len`-byte request value each, all the same
+    length; requestID = the frame's index.  Same layout as accept()."""
+    name_rows = np.asarray(name_rows, np.uint8)
+    n, L = name_rows.shape
+    tmpl = np.frombuffer(accept(b"x" * L, version, 0, 0, bnum, bcoord, median_cp, sender, b"v" * value_len), np.uint8)
+    f = np.tile(tmpl, (n, 1))
+    f[:, 13:13 + L] = name_rows
+    o = 13 + L
+    rid = np.arange(n, dtype=np.int64)
+    f[:, o:o + 4], f[:, o + 4:o + 8] = _be32_cols(rid >> 32), _be32_cols(rid & 0xFFFFFFFF)
+    t = tmpl.shape[0] - 22  # the slot / ballot / ... tail
+    f[:, t:t + 4] = _be32_cols(np.broadcast_to(np.asarray(slot, np.int64), (n,)))
+    off = np.arange(n + 1, dtype=np.int64) * tmpl.shape[0]
+    return f.reshape(-1), off
+
+
 def _dev_struct(cls, cap, ptrs):
     return cls(cap, *[_VP(int(p)) if p else None for p in ptrs])
 

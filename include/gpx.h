@@ -510,6 +510,25 @@ int gpx_gap_scan(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t threshol
                  int32_t sync_mode, int32_t size_limit, int32_t* first_slot,
                  int32_t* max_committed, uint64_t* missing, uint8_t* should_sync, uint8_t* status);
 
+/* ---- sharding across the GPUs of a node ------------------------------------------------------ */
+
+#define GPX_ROUTE_MAX_SHARDS 16
+#define GPX_ROUTE_MAX_COLS 8
+/*
+ * device = fmix32(gidx) % n_shards (murmur3 finaliser); "the host bins each batch by
+ * device".  This does the binning on the device for a batch already resident in HBM: a STABLE
+ * partition of n_cols int32 columns (cols[0] = the global group index) by shard - the records of a
+ * shard keep the batch's order, so the per-group ordering contract survives the routing - with the
+ * group index rewritten to the shard-local dense index through g2l ([n_groups_global] device table,
+ * NULL = keep the global index).  out_cols[k] receives column k, shard-major: shard s occupies
+ * [shard_off[s], shard_off[s + 1]) (shard_off: n_shards + 1 device ints).  An index outside
+ * [0, n_groups_global) goes to shard 0 as -1 (dropped there with GPX_S_NOGROUP).  cols / out_cols are
+ * HOST arrays of device pointers.  No group state is touched; runs on the engine's stream.
+ */
+int gpx_route_batch_dev(gpx_engine* h, int32_t n, int32_t n_cols, const int32_t* const* cols,
+                        const int32_t* g2l, int32_t n_groups_global, int32_t n_shards,
+                        int32_t* const* out_cols, int32_t* shard_off);
+
 /* ---- telemetry --------------------------------------------------------------- */
 
 /* cumulative counters since engine creation: votes, decisions, dropped records */

@@ -102,7 +102,26 @@ def main():
     eng.sync()
     kern = {kk: round(v[1] * 1e3, 1) for kk, v in eng.profile_read().items()}
     eng.profile(0)
+    # acceptor side: G ACCEPT frames carrying a 64-byte request value each (BASELINE config #2's request
+    # size): the frames of a 256-frame tile no longer fit one staging window
+    abuf, aoff = W.accept_frames_fixed(names[rng.permutation(G)], 0, 1, 0, 100, 0, 100, value_len=64)
+    d_abuf, d_aoff = torch.from_numpy(abuf).to(dev), torch.from_numpy(aoff).to(dev)
+    acols = [i32(G) for _ in range(5)] + [u8(G), i32(G), torch.empty(G, dtype=torch.int64, device=dev), i32(G)]
+    t_acc = 0.0
+    for r in range(args.rounds):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        W.decode_dev(we, G, P(d_abuf), P(d_aoff), P(fst), P(fg), P(ft), accepts=(G, [P(c) for c in acols]),
+                     counts_ptr=P(counts))
+        e1.record()
+        eng.sync()
+        torch.cuda.synchronize()
+        assert int(counts[2]) == G and int(counts[4]) == 0, counts.tolist()
+        if r > 0:
+            t_acc += e0.elapsed_time(e1)
     res = {
+        "accept_frames": G, "accept_frame_bytes": int(aoff[-1]), "accept_decode_ms": round(t_acc / k, 4),
+        "accept_decode_GBps_frame_bytes": round(int(aoff[-1]) / (t_acc / k) * 1e-6, 1),
         "groups": G, "frames_in": nfr, "frame_bytes_in": frame_bytes, "frames_out": G, "frame_bytes_out": out_bytes,
         "decode_ms": round(t_dec / k, 4), "accept_reply_ms": round(t_ar / k, 4), "pack_commits_ms": round(t_pack / k, 4),
         "decode_frames_per_s": round(nfr / (t_dec / k) * 1e3, 1),
