@@ -248,6 +248,39 @@ def hri_initial(n: int, k: int, coordinator) -> np.ndarray:
     return rows
 
 
+def hri_to_string(paxos_id: str, members, row) -> str:
+    """HotRestoreInfo.toString (paxosutil/HotRestoreInfo.java:102-122): the pipe-separated form the
+    reference keeps in its pause table - paxosID|version|[members]|accSlot|accBallot|accGCSlot|
+    coordBallot or null|nextProposalSlot|[nodeSlots] or null (Util.arrayOfIntToString, Ballot.toString)."""
+    members = [int(m) for m in members]
+    k = len(members)
+    arr = lambda a: "[" + ",".join(str(int(x)) for x in a) + "]"  # noqa: E731
+    coord = bool(row["has_coord"])
+    return "|".join([paxos_id, str(int(row["version"])), arr(members), str(int(row["acc_slot"])),
+                     "%d:%d" % (int(row["acc_bnum"]), int(row["acc_bcoord"])), str(int(row["acc_gc_slot"])),
+                     "%d:%d" % (int(row["coord_bnum"]), int(row["coord_bcoord"])) if coord else "null",
+                     str(int(row["next_proposal_slot"])),
+                     arr(row["node_slots"][:k]) if coord else "null"])
+
+
+def hri_from_string(s: str):
+    """HotRestoreInfo(String) (HotRestoreInfo.java:86-98): -> (paxosID, members, row)."""
+    t = s.split("|")
+    ints = lambda x: [int(v) for v in x.replace("[", "").replace("]", "").replace(" ", "").split(",")]  # noqa: E731
+    row = make_hri(1)
+    members = ints(t[2])
+    row["version"], row["acc_slot"], row["acc_gc_slot"] = int(t[1]), int(t[3]), int(t[5])
+    row["acc_bnum"], row["acc_bcoord"] = (int(v) for v in t[4].split(":"))
+    if t[6] != "null":
+        row["has_coord"] = 1
+        row["coord_bnum"], row["coord_bcoord"] = (int(v) for v in t[6].split(":"))
+    row["next_proposal_slot"] = int(t[7])
+    if t[8] != "null":
+        ns = ints(t[8])
+        row["node_slots"][0, :len(ns)] = ns
+    return t[0], members, row
+
+
 class Engine:
     """Host handle over one engine (`gpx_engine*`): the device-resident replacement of
     PaxosManager's name->PaxosInstanceStateMachine table for one node id."""

@@ -241,8 +241,13 @@ __device__ __forceinline__ unsigned long long arrival_order(const int32_t* idxA,
 }
 
 /* (Forcing 8 waves per SIMD through amdgpu_waves_per_eu spills to scratch and is 5x slower: measured.) */
+#ifdef GPX_AR16_WAVES
+#define GPX_AR16_ATTR __attribute__((amdgpu_waves_per_eu(GPX_AR16_WAVES, 8)))
+#else
+#define GPX_AR16_ATTR
+#endif
 template <int KMAX>
-__global__ __launch_bounds__(1024) void k_bucket_ar16(DevState S, DevScratch X, Stage16 O, VoteCols in,
+__global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16(DevState S, DevScratch X, Stage16 O, VoteCols in,
                                                       uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   const int32_t b = blockIdx.x;

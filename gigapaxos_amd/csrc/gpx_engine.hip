@@ -63,6 +63,7 @@ struct gpx_engine {
   hipStream_t sF = nullptr, sB = nullptr; /* the streams in force (equal unless pipelined) */
   hipStream_t stream = nullptr;           /* where the next launch goes: sF inside a front section, else sB */
   bool pipeline = false;
+  bool pipe_light = true; /* GPX_PIPE_FULL=1: the scatter on the front stream as well (round 1's scheme) */
   /* front-end scratch is double-buffered so that call N+1's front end can run beside call N's
    * back end; evF[s] = front end of the call using set s done, evB[s] = its back end done */
   struct FrontSet {
@@ -107,8 +108,8 @@ struct gpx_engine {
   char *hs_in = nullptr, *hs_out = nullptr; /* pinned host */
   char *ds_in = nullptr, *ds_out = nullptr; /* device */
   int32_t* route_cnt = nullptr; /* gpx_route_batch_dev: [tiles][shards], allocated on first use */
-  /* single-launch path of small accept-reply batches (gpx_small.hip.h); GPX_SMALL=0 turns it off */
-  bool small_on = true;
+  /* single-launch path of small accept-reply batches (gpx_small.hip.h); opt-in: GPX_SMALL=1 */
+  bool small_on = false;
   unsigned long long* small_tickets = nullptr;
   uint32_t small_epoch = 0;
   int32_t lds16_max = 0, lds16_hw = 0; /* LDS staging capacities (votes) of k_bucket_ar16 */
@@ -544,8 +545,14 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_hw));
   }
   {
+    /* Off unless GPX_SMALL=1: measured on MI355X it only TIES the partition pipeline at BASELINE
+     * config #2's size (30 k votes over 10 k groups: 33 us against 34 us) and loses at 65,536 votes
+     * over 1 M groups (90 us against 53 us: one 1024-lane workgroup per CU, each a chain of dependent
+     * round trips).  Kept, tested both ways, as the starting point for a fused small-batch back end. */
+    const char* pf = getenv("GPX_PIPE_FULL");
+    e->pipe_light = !(pf && atoi(pf));
     const char* sm = getenv("GPX_SMALL");
-    e->small_on = !(sm && !atoi(sm));
+    e->small_on = sm && atoi(sm);
     if ((rc = dev_alloc(e, &e->small_tickets, GPX_SMALL_MAX_WG, true)) != GPX_OK) {
       gpx_engine_destroy(e);
       return rc;
@@ -825,13 +832,17 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
   const bool vec = aligned16({gidx, bnum, bcoord, slot, acceptor, max_cp});
   if (e->ar16) {
     /* 16-byte vote records (gpx_ar16.hip.h); the back end may re-read bnum / bcoord / acceptor */
+    /* pipelined mode: only the histogram of call N+1 runs beside the back end of call N (an
+     * atomics-bound kernel beside bandwidth-bound ones); the scatter stays in stream order with the
+     * per-bucket kernels - overlapping it too made everything slower (measured) */
+    if (e->pipe_light) begin_back(e, fs, n, true);
     if (vec)
       LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
                ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
     else
       LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
                ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-    begin_back(e, fs, n, true);
+    if (!e->pipe_light) begin_back(e, fs, n, true);
     const size_t N = (size_t)e->cfg.max_batch;
     int32_t* o32 = (int32_t*)e->X.o_rec; /* N x 32 bytes: five int columns + one byte column */
     const Stage16 O{o32, o32 + N, o32 + 2 * N, o32 + 3 * N, o32 + 4 * N, (uint8_t*)(o32 + 5 * N)};

@@ -850,13 +850,21 @@ template <class WR>
 __device__ __forceinline__ int32_t pack_commit_frame(const DevState& S, const DevNames& N, const PackIn& P,
                                                      int32_t n, int32_t i, WR& w) {
   const int32_t g = P.gidx[i];
-  const int32_t idl = N.len(g);
+  /* the row's header and first 24 name bytes: one 32-byte sector, two 16-byte loads (a byte loop
+   * over global memory is a chain of dependent loads) */
+  const uint4* row = (const uint4*)N.row(g);
+  const uint4 r0 = row[0], r1 = row[1];
+  const int32_t idl = (int32_t)(r0.y & 0xffu);
+  const uint32_t nw[6] = {r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
   w.put32(GPX_WT_PAXOS_PACKET);       /* PaxosPacket.toBytes (PaxosPacket.java:461-476) */
   w.put32(GPX_WT_BATCHED_COMMIT);
   w.put32(S.g_version[g]);
   w.put8((uint32_t)idl);
   const uint8_t* nm = N.name(g);
-  for (int32_t b = 0; b < idl; b++) w.put8(nm[b]);
+#pragma unroll
+  for (int32_t b = 0; b < 24; b++)
+    if (b < idl) w.put8(nw[b >> 2] >> (8 * (b & 3)));
+  for (int32_t b = 24; b < idl; b++) w.put8(nm[b]);
   w.put32(P.bnum[i]);
   w.put32(P.bcoord[i]);
   /* medianCheckpointedSlot: addCommit keeps the later one when `b - cur > 0` (:104-112) */
@@ -1042,7 +1050,8 @@ __global__ __launch_bounds__(1024) void k_bucket_pack_ar(DevState S, DevScratch 
       const int32_t* pay = bv.pay + (int64_t)(uint32_t)k * bv.rs;
       const bool has_reply = P.status[ix] == GPX_S_OK;
       const int32_t rbn = pay[3 * bv.fs], rbc = pay[4 * bv.fs];
-      bool ok = has_reply && named && t < cc && (!P.sender || P.sender[ix] == rbc);
+      const bool coalescable = has_reply && named && (!P.sender || P.sender[ix] == rbc);
+      bool ok = coalescable && t < cc;
       int32_t q = -1;
       if (ok) {
         for (int32_t z = 0; z < nbal; z++)
@@ -1057,7 +1066,8 @@ __global__ __launch_bounds__(1024) void k_bucket_pack_ar(DevState S, DevScratch 
       /* remember the verdict in the record's third payload word (unused so far): ballot index
        * or -1 */
       const_cast<int32_t*>(pay)[2 * bv.fs] = ok ? q : -1;
-      if (P.unbatched) P.unbatched[ix] = (has_reply && !ok) ? 1 : 0;
+      /* 2 = coalescable but over a per-pass limit: the next pass packs it (gpx_wire.h) */
+      if (P.unbatched) P.unbatched[ix] = (coalescable && !ok) ? 2 : (has_reply && !ok) ? 1 : 0;
     }
     for (int32_t q = 0; q < nbal; q++) {
       int32_t m = 0; /* TreeMap size: distinct slots of this ballot */

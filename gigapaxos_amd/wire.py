@@ -71,7 +71,25 @@ _WIRE_DEV_SIGS = {
     "wire_pack_commits_dev": [C.c_int32, _VP] + [_VP] * 7 + [C.c_int64] + [_VP] * 5,
     "wire_pack_accept_replies_dev": [C.c_int32] + [_VP] * 10 + [C.c_int64] + [_VP] * 6,
 }
-WIRE_EXPORTED_SYMBOLS = list(_WIRE_SIGS) + list(_WIRE_DEV_SIGS)
+WIRE_EXPORTED_SYMBOLS = list(_WIRE_SIGS) + list(_WIRE_DEV_SIGS) + ["wire_plan_send"]
+
+
+def plan_send(lib: GpxLib, est, dest_key, max_payload=4 * 1024 * 1024, min_batch=3, batch_across_groups=True):
+    """gpx_wire_plan_send: PaxosPacketBatcher.dequeueImpl's payload bound + process() -> batch() over a
+    list of outgoing frames; returns (burst, envelope, position, n_bursts)."""
+    est = np.ascontiguousarray(est, np.int64)
+    dest_key = np.ascontiguousarray(dest_key, np.int64)
+    n = est.shape[0]
+    assert dest_key.shape[0] == n
+    burst, env, pos = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+    nb = np.zeros(1, np.int32)
+    f = getattr(lib.lib, lib.prefix + "wire_plan_send")
+    f.restype = C.c_int
+    f.argtypes = [C.c_int32, _VP, _VP, C.c_int64, C.c_int32, C.c_int32, _VP, _VP, _VP, _VP]
+    lib.check(f(n, est.ctypes.data, dest_key.ctypes.data, int(max_payload), int(min_batch),
+                int(bool(batch_across_groups)), burst.ctypes.data, env.ctypes.data, pos.ctypes.data,
+                nb.ctypes.data), "wire_plan_send")
+    return burst[:n], env[:n], pos[:n], int(nb[0])
 
 
 def bind_wire(lib: GpxLib):

@@ -193,10 +193,14 @@ int gpx_wire_pack_commits_dev(gpx_engine* h, int32_t n, const int32_t* n_dev,
  * (BatchedAcceptReply.java:49-54), then the TreeMap slot -> requestID (ascending, a repeated slot
  * keeps the last request id).  Frames leave grouped by gidx ascending, the ballots of one group in
  * first-appearance order; f_dest[f] = the ballot's coordinator, the node the frame goes to.
- * Engine limits: per call at most 256 replies and 4 distinct reply ballots of one group are
- * coalesced.  unbatched[i] (nullable) = 1 for every existing reply that was NOT packed (not
- * coalescable, over a limit, unnamed group): the host sends it as a plain ACCEPT_REPLY, which is
- * what the reference does with BATCHED_ACCEPT_REPLIES off.  frame_off is 4-byte aligned.
+ * Engine limits: one PASS coalesces at most 256 replies and 4 distinct reply ballots of one group
+ * (the reference's maps are unbounded).  The host-pointer call runs further passes over the replies
+ * that were over a limit, in array order, until none is left: their frames follow the first pass's
+ * (a group with 600 replies in one ballot leaves as three frames of 256 + 256 + 88 slots instead of
+ * the reference's one).  The _dev call runs ONE pass and marks such replies unbatched[i] = 2: the
+ * caller passes them again.  unbatched[i] (nullable) = 1 for an existing reply that can not be
+ * packed at all (not coalescable, unnamed group): the host sends it as a plain ACCEPT_REPLY, which
+ * is what the reference does with BATCHED_ACCEPT_REPLIES off.  frame_off is 4-byte aligned.
  */
 int gpx_wire_pack_accept_replies(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* slot,
                                  const int32_t* sender, const int64_t* req_id,
@@ -213,6 +217,32 @@ int gpx_wire_pack_accept_replies_dev(gpx_engine* h, int32_t n, const int32_t* gi
                                      int64_t cap_bytes, int64_t* frame_off, int32_t* frame_len,
                                      int32_t* f_gidx, int32_t* f_dest, int32_t* n_frames /* device */,
                                      int64_t* n_bytes /* device */);
+
+/* ---- what leaves together: the batcher's payload bound and cross-group batching ------------- */
+
+/*
+ * replaces: PaxosPacketBatcher.dequeueImpl's payload bound and process() -> batch()
+ * (PaxosPacketBatcher.java:182-209, 268-303) for the frames the pack calls produced.  Pure host
+ * function (no engine, no device work: the messenger that sends the frames walks them anyway).
+ * Frame f, in dequeue order (the reference drains accept replies, then commits, then accepts, then
+ * requests into ONE list under one running estimate), carries est[f] = RequestPacket.SIZE_ESTIMATE *
+ * Batched*.size() (a request: lengthEstimate()) and dest_key[f] = a key that is equal iff the
+ * recipient sets are equal (BATCHED_ACCEPT_REPLY: the coordinator id, f_dest; BATCHED_COMMIT /
+ * BATCHED_ACCEPT: an id of the group's member set).
+ *   dequeueImpl: frames are taken `while (lengthEstimate < max_payload)` - the test precedes the
+ *     add, so the frame that crosses the bound still leaves with this dequeue - burst[f] = the
+ *     dequeue (ConsumerTask iteration) frame f leaves in.
+ *   process(): a dequeue of MORE than min_batch tasks (PC.MIN_PP_BATCH_SIZE = 3) with
+ *     batch_across_groups (PC.BATCH_ACROSS_GROUPS = true) is regrouped by recipient set in
+ *     first-appearance order (LinkedHashMap<Set<Integer>, BatchedPaxosPacket>): envelope[f] = index
+ *     of its BatchedPaxosPacket inside the burst, position[f] = its index inside that packet;
+ *     otherwise every task is sent on its own: envelope[f] = -1, position[f] = 0.
+ * *n_bursts = number of dequeues.  (BatchedPaxosPacket itself is a JSON envelope: its bytes are the
+ * Java host's, PaxosPacket.java:443-476 has no byteified form for it.)
+ */
+int gpx_wire_plan_send(int32_t n_frames, const int64_t* est, const int64_t* dest_key,
+                       int64_t max_payload, int32_t min_batch, int32_t batch_across_groups,
+                       int32_t* burst, int32_t* envelope, int32_t* position, int32_t* n_bursts);
 
 #ifdef __cplusplus
 }

@@ -34,6 +34,7 @@
 #include <algorithm>
 #include <cstdint>
 #include <cstring>
+#include <deque>
 #include <initializer_list>
 #include <map>
 #include <memory>

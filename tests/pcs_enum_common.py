@@ -1,0 +1,106 @@
+"""The accept-reply tail of PaxosCoordinatorState.main (PaxosCoordinatorState.java:1173-1213) with its
+`Math.random() > 0.99` coin ENUMERATED: for every proposal still outstanding, every member answers
+once, slot by slot, member by member, either in the coordinator's own ballot or - the coin - in a
+higher one; main asserts after every reply that a non-null result has the right type and that the
+decided / preempted slot has left myProposals, and at the end that myProposals is empty.
+
+`model()` below follows the Java statement by statement (handleAcceptReplyMyBallot PCS:597-640,
+recordSlotNumber :809-825, WaitforUtility :51-68, getMedianMinus :859-875, handleAcceptReplyHigherBallot
+:661-675, and, because the engine is driven through gpx_accept_reply_batch = PISM.handleAcceptReply,
+PaxosCoordinator.handleAcceptReply :210-250 with nullifyCoordinatorIfPreemptedFully PISM:1361-1364); it is
+written here independently of oracle/gpx_oracle.cpp, so the test pins BOTH to the reference's text."""
+import itertools
+
+import numpy as np
+
+from gigapaxos_amd import Engine, hri_create, S_OK, D_DECISION, D_PREEMPTED
+
+
+def model(members, me, nprop, coins):
+    """coins[(slot_index, member_index)] = True -> the reply carries ballot (myBallotNum + 1, me).
+    Returns the list of (vote index, slot, bnum, bcoord, median, kind) outputs in arrival order."""
+    K = len(members)
+    my = (0, me)                       # createHRI: coordBallot (0, coordinator)
+    node_slots = [0] * K               # createHRI: new int[members.length]
+    proposals = {s: [False] * K for s in range(1, nprop + 1)}  # slot -> WaitforUtility.responded
+    coordinator = True
+    out = []
+    v = 0
+    for si, slot in enumerate(range(1, nprop + 1)):
+        for j in range(K):
+            ballot = (my[0] + 1, my[1]) if coins[(si, j)] else my
+            maxcp = -1                                           # main passes -1
+            if coordinator:
+                if ballot > my:                                  # Ballot.compareTo > 0
+                    if slot in proposals:                        # handleAcceptReplyHigherBallot
+                        del proposals[slot]
+                        out.append((v, slot, my[0], my[1], -1, D_PREEMPTED))
+                    if not proposals:                            # isPreemptedFully -> coordinator = null
+                        coordinator = False
+                else:                                            # == my ballot
+                    idx = -1
+                    for q in range(K):                           # getIndex: last match
+                        if members[q] == members[j]:
+                            idx = q
+                    if node_slots[idx] < maxcp:                  # recordSlotNumber, plain <
+                        node_slots[idx] = maxcp
+                    w = proposals.get(slot)
+                    if w is not None:
+                        w[idx] = True                            # updateHeardFrom
+                        if sum(w) > K // 2:                      # heardFromMajority
+                            srt = sorted(node_slots)             # getMedianMinus
+                            med = srt[K // 2 - 1] if K % 2 == 0 else srt[K // 2]
+                            del proposals[slot]
+                            out.append((v, slot, my[0], my[1], med, D_DECISION))
+            v += 1
+    return out, proposals, coordinator
+
+
+def run_all(lib, K, nprop):
+    """Every coin pattern for K members and nprop outstanding proposals through gpx_accept_reply_batch;
+    returns the number of patterns checked."""
+    members = list(range(21, 21 + 3 * K, 3))[:K]   # main: ascending ids starting at myID = 21
+    me = members[0]
+    keys = [(si, j) for si in range(nprop) for j in range(K)]
+    checked = 0
+    G = 1 << (len(keys))
+    # one engine, one group per pattern: all patterns in ONE batch (votes of a group keep their order)
+    e = Engine(lib, me, G, kmax=K, window=8, max_batch=G * len(keys) + 16)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    assert (e.create_groups(np.arange(G), mem, K, hri_create(G, K, me)) == S_OK).all()
+    for _ in range(nprop):
+        sl, bn, bc, md, st = e.propose(np.arange(G, dtype=np.int32))
+        assert (st == S_OK).all()
+    cols = [[] for _ in range(6)]
+    expect = []
+    for p, bits in enumerate(itertools.product((False, True), repeat=len(keys))):
+        coins = dict(zip(keys, bits))
+        out, left, coord = model(members, me, nprop, coins)
+        # main's own assertions on the model's run
+        assert not left or not coord                      # `assert (pcs.myProposals.isEmpty())`: every slot is
+        # decided or preempted unless the coordinator resigned first (PISM level; main calls PCS directly)
+        for (_, slot, _, _, _, kind) in out:
+            assert kind in (D_DECISION, D_PREEMPTED)
+        expect.append(out)
+        for si, slot in enumerate(range(1, nprop + 1)):
+            for j in range(K):
+                hb = coins[(si, j)]
+                for c, val in zip(cols, (p, 1 if hb else 0, me, slot, members[j], -1)):
+                    c.append(val)
+        checked += 1
+    # interleave the groups' votes (stable per group) so that the batch is not sorted by group
+    n = len(cols[0])
+    order = np.argsort(np.arange(n) % len(keys), kind="stable")
+    arrs = [np.array(c, np.int32)[order] for c in cols]
+    d = e.accept_reply(*arrs)
+    got = d.as_tuple_array()
+    gi = 0
+    for p, out in enumerate(expect):
+        rows = got[gi:gi + len(out)]
+        assert rows.shape[0] == len(out) and (rows[:, 0] == p).all(), f"pattern {p}: decision count"
+        want = np.array([(p,) + o[1:] for o in out], np.int32).reshape(-1, 6)
+        assert (rows == want).all(), f"pattern {p}: {rows.tolist()} != {want.tolist()}"
+        gi += len(out)
+    assert gi == got.shape[0]
+    e.close()
+    return checked

@@ -412,3 +412,38 @@ def test_prepare_acceptor_side(oracle_lib):
     assert st.tolist() == [S_STOPPED] and rows == [] and rb.tolist() == [0]
     assert e.dump(2).tolist()[:20] == e.dump(2).tolist()[:20]
     e.close()
+
+
+def test_hri_string_form_roundtrip(oracle_lib):
+    """HotRestoreInfoTest.testToStringAndBack (HotRestoreInfo.java:159-175) on the STRING form the
+    reference keeps in its pause table: the row an engine hands back on pause, written as
+    HotRestoreInfo.toString would (:102-122), parsed as HotRestoreInfo(String) does (:86-98), restores
+    the identical group - and the test's own literal."""
+    from gigapaxos_amd import hri_to_string, hri_from_string
+    rows = make_hri(1)
+    rows["version"], rows["acc_slot"], rows["acc_bnum"], rows["acc_bcoord"], rows["acc_gc_slot"] = 2, 5, 3, 4, 3
+    rows["has_coord"], rows["coord_bnum"], rows["coord_bcoord"], rows["next_proposal_slot"] = 1, 45, 67, 34
+    rows["node_slots"][0, :3] = [1, 3, 5]
+    str1 = hri_to_string("paxos0", [1, 4, 67], rows[0])
+    assert str1 == "paxos0|2|[1,4,67]|5|3:4|3|45:67|34|[1,3,5]"   # what the Java prints for hri1
+    name, members, back = hri_from_string(str1)
+    assert name == "paxos0" and members == [1, 4, 67] and back.tobytes() == rows.tobytes()
+    assert hri_to_string(name, members, back[0]) == str1
+    # through an engine: create from the parsed row, pause, the string of the returned row is the same
+    e = _mk(oracle_lib, 67, members, rows=back)
+    paused, st = e.retire_groups([0], RETIRE_PAUSE)
+    assert st.tolist() == [S_OK] and hri_to_string(name, members, paused[0]) == str1
+    # a node without the coordinator: coordBallot and nodeSlots are "null" (:114-121)
+    e2 = _mk(oracle_lib, 4, members, rows=back)
+    paused, _ = e2.retire_groups([0], RETIRE_PAUSE)
+    s2 = hri_to_string(name, members, paused[0])
+    assert s2 == "paxos0|2|[1,4,67]|5|3:4|3|null|-1|null"
+    assert hri_from_string(s2)[2].tobytes() == paused.tobytes()
+
+
+@pytest.mark.parametrize("K,nprop", [(3, 2), (4, 2), (5, 2), (3, 3)])
+def test_pcs_main_accept_reply_tail_every_coin(oracle_lib, K, nprop):
+    """PaxosCoordinatorState.main's accept-reply tail with Math.random enumerated (tests/pcs_enum_common.py):
+    2^(K * nprop) reply patterns, the oracle against a statement-by-statement Python reading of the Java."""
+    from tests.pcs_enum_common import run_all
+    assert run_all(oracle_lib, K, nprop) == 1 << (K * nprop)

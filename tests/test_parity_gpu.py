@@ -15,9 +15,9 @@ pytestmark = pytest.mark.gpu
 
 @pytest.fixture(autouse=True, params=["small-batch path", "partition path"])
 def _accept_reply_path(request, monkeypatch):
-    """Accept-reply batches of at most 65,536 votes take the single-launch path (gpx_small.hip.h) by
-    default; GPX_SMALL=0 (read at engine creation) sends them through the partition pipeline like the
-    big ones.  Every case of this file runs both ways."""
+    """Accept-reply batches of at most 65,536 votes can take a single-launch path (gpx_small.hip.h,
+    GPX_SMALL=1, read at engine creation; off by default: it does not beat the partition pipeline,
+    DESIGN.md) - every case of this file runs both ways."""
     monkeypatch.setenv("GPX_SMALL", "1" if request.param.startswith("small") else "0")
 
 
@@ -299,3 +299,10 @@ def test_propose_batch_orders(hip_lib, oracle_lib, order):
     assert sh.tobytes() == so.tobytes()
     assert_same_state(eh, eo, rng.integers(0, G, 48))
     assert eh.counters() == eo.counters()
+
+
+@pytest.mark.parametrize("K,nprop", [(3, 2), (5, 2)])
+def test_pcs_main_accept_reply_tail_every_coin_on_engine(hip_lib, K, nprop):
+    """The same enumeration (PaxosCoordinatorState.java:1173-1213, every coin) on the HIP engine."""
+    from tests.pcs_enum_common import run_all
+    assert run_all(hip_lib, K, nprop) == 1 << (K * nprop)

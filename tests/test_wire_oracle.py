@@ -266,3 +266,69 @@ def test_frame_level_cluster_executes_in_order(oracle_lib):
             slots = np.concatenate([np.arange(f, f + n) for _, f, n in runs])
             assert slots.tolist() == list(range(1, R + 1))
     c.close()
+
+
+def test_pack_accept_replies_beyond_the_per_pass_limits(oracle_lib):
+    """The reference's batcher maps are unbounded (PaxosPacketBatcher.java:121-137); the engine packs
+    256 replies / 4 ballots of a group per pass and runs further passes over the rest, so NOTHING is
+    left unbatched for that reason: 600 replies of one ballot leave as frames of 256 + 256 + 88 slots,
+    six ballots as 4 + 2 frames."""
+    e, we, names = make_engine(oracle_lib, k=3, my_id=101)
+    n = 600
+    g = np.full(n, 3, np.int32)
+    slot = np.arange(1, n + 1, dtype=np.int32)
+    z = np.zeros(n, np.int32)
+    frames, fg, fd, ub, _ = we.pack_accept_replies(g, slot, z, z + 100, z, np.zeros(n, np.uint8), z + 100)
+    assert not ub.any() and fg.tolist() == [3, 3, 3] and fd.tolist() == [100, 100, 100]
+    sizes = []
+    for f in frames:
+        hdr = 13 + f[12]
+        sizes.append(struct.unpack(">i", f[hdr + 29:hdr + 33])[0])
+        first = struct.unpack(">i", f[hdr + 33:hdr + 37])[0]
+        assert struct.unpack(">i", f[hdr + 12:hdr + 16])[0] == first   # the fixed part's slot = the pass's first reply
+    assert sizes == [256, 256, 88]
+    bn = np.arange(6, dtype=np.int32)
+    frames, fg, fd, ub, _ = we.pack_accept_replies(np.full(6, 3, np.int32), np.arange(1, 7), bn, np.full(6, 100), z[:6],
+                                                   np.zeros(6, np.uint8), np.full(6, 100))
+    assert not ub.any() and len(frames) == 6
+    got = [struct.unpack(">i", f[13 + f[12] + 4:13 + f[12] + 8])[0] for f in frames]
+    assert got == [0, 1, 2, 3, 4, 5]
+
+
+def test_plan_send_dequeue_bound_and_cross_group_batching(oracle_lib):
+    """PaxosPacketBatcher.dequeueImpl's payload bound (:182-209: `while (lengthEstimate < MAX)`, test
+    before add) and process() -> batch() (:268-303: more than MIN_PP_BATCH_SIZE = 3 tasks are regrouped by
+    recipient set in first-appearance order), worked out by hand from the Java - and the engine
+    library's own implementation of the same function (pure host code: runs without a GPU)."""
+    import __graft_entry__ as ge
+    from gigapaxos_amd._abi import GpxLib
+
+    ge.build()
+    libs = [oracle_lib, GpxLib(ge.HIP_SO, "gpx_", device_api=True)]
+    for lib in libs:
+        # five frames of estimate 10 under a bound of 25: 0 < 25, 10 < 25, 20 < 25 -> three leave (30 >= 25
+        # stops the loop AFTER the third); the next dequeue takes the other two.  3 tasks is not MORE
+        # than 3: sent one by one.
+        burst, env, pos, nb = W.plan_send(lib, [10] * 5, [7, 7, 8, 7, 8], max_payload=25)
+        assert nb == 2 and burst.tolist() == [0, 0, 0, 1, 1]
+        assert env.tolist() == [-1] * 5 and pos.tolist() == [0] * 5
+        # six frames in one dequeue (> 3 tasks): LinkedHashMap order of the recipient sets 5, 9, 2
+        burst, env, pos, nb = W.plan_send(lib, [1] * 6, [5, 9, 5, 2, 9, 5], max_payload=100)
+        assert nb == 1 and burst.tolist() == [0] * 6
+        assert env.tolist() == [0, 1, 0, 2, 1, 0] and pos.tolist() == [0, 0, 1, 0, 1, 2]
+        # BATCH_ACROSS_GROUPS off: never regrouped; a single frame above the bound still leaves alone
+        burst, env, pos, nb = W.plan_send(lib, [500, 1, 1, 1, 1], [1, 1, 1, 1, 1], max_payload=100,
+                                          batch_across_groups=False)
+        assert nb == 2 and burst.tolist() == [0, 1, 1, 1, 1] and env.tolist() == [-1] * 5
+        assert W.plan_send(lib, [], [])[3] == 0
+    # the two implementations agree on random inputs
+    rng = np.random.default_rng(3)
+    for _ in range(50):
+        n = int(rng.integers(0, 400))
+        est = rng.integers(1, 3000, n)
+        key = rng.integers(0, 6, n)
+        mp = int(rng.integers(1, 20000))
+        mb = int(rng.integers(0, 6))
+        a = W.plan_send(libs[0], est, key, mp, mb, True)
+        b = W.plan_send(libs[1], est, key, mp, mb, True)
+        assert all(np.array_equal(x, y) for x, y in zip(a[:3], b[:3])) and a[3] == b[3]
