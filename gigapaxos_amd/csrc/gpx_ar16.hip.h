@@ -105,6 +105,76 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ar16(
   }
 }
 
+/* ACCEPT / COMMIT records in the same 16 bytes: {idx, slot, median_cp, local group | ESC | flags << 16};
+ * the dense reply columns of dropped ACCEPTs are zeroed here, like k_scatter_ac does */
+__device__ __forceinline__ void put_ac16(const DevScratch& X, int32_t* lds, int32_t G, int32_t mask, int32_t b0n,
+                                         int32_t b0c, int64_t i, int32_t g, int32_t slot, int32_t median,
+                                         int32_t flags, int32_t bn, int32_t bc, int32_t* __restrict__ r_bnum,
+                                         int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp,
+                                         uint8_t* __restrict__ r_flags) {
+  if ((uint32_t)g >= (uint32_t)G) {
+    if (r_bnum) {
+      r_bnum[i] = 0;
+      r_bcoord[i] = 0;
+      r_maxcp[i] = 0;
+      r_flags[i] = 0;
+    }
+    return;
+  }
+  const int32_t pos = bucket_take(lds, g >> X.shift);
+  Vote16 v;
+  v.idx = (int32_t)i;
+  v.slot = slot;
+  v.maxcp = median;
+  v.meta = (uint32_t)(g & mask) | ((bn != b0n || bc != b0c) ? V16_ESC : 0u) | ((uint32_t)(flags & 0xff) << 16);
+  ((Vote16*)X.rec)[pos] = v;
+}
+template <bool VEC>
+__global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ac16(
+    int32_t n, int32_t ntiles, int32_t G, DevScratch X, const int32_t* __restrict__ gidx,
+    const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
+    const int32_t* __restrict__ median_cp, const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum,
+    int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags) {
+  extern __shared__ int32_t lds[];
+  const int32_t tile = tile_of_block(ntiles);
+  if (tile >= ntiles) return;
+  if (*X.unsorted != X.epoch) return; /* ordered batch: applied directly (gpx_direct.hip.h) */
+  const int32_t b0n = bnum[0], b0c = bcoord[0];
+  scatter_init(X, tile, lds);
+  const int64_t base = (int64_t)tile * GPX_TILE;
+  const int32_t mask = X.gb - 1;
+  if (VEC) {
+#pragma unroll
+    for (int j = 0; j < GPX_TILE_VECS; j++) {
+      const int64_t i0 = base + (int64_t)(j * GPX_FBLOCK + threadIdx.x) * 4;
+      if (i0 + 3 < n) {
+        const I4 g4 = *(const I4*)(gidx + i0), s4 = *(const I4*)(slot + i0), m4 = *(const I4*)(median_cp + i0);
+        const I4 n4 = *(const I4*)(bnum + i0), c4 = *(const I4*)(bcoord + i0);
+        const uint32_t f4 = flags ? *(const uint32_t*)(flags + i0) : 0u;
+        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 0, g4.x, s4.x, m4.x, (int32_t)(f4 & 0xffu), n4.x, c4.x, r_bnum, r_bcoord, r_maxcp, r_flags);
+        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 1, g4.y, s4.y, m4.y, (int32_t)((f4 >> 8) & 0xffu), n4.y, c4.y, r_bnum, r_bcoord, r_maxcp, r_flags);
+        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 2, g4.z, s4.z, m4.z, (int32_t)((f4 >> 16) & 0xffu), n4.z, c4.z, r_bnum, r_bcoord, r_maxcp, r_flags);
+        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 3, g4.w, s4.w, m4.w, (int32_t)(f4 >> 24), n4.w, c4.w, r_bnum, r_bcoord, r_maxcp, r_flags);
+      } else {
+        for (int q = 0; q < 4; q++) {
+          const int64_t i = i0 + q;
+          if (i < n)
+            put_ac16(X, lds, G, mask, b0n, b0c, i, gidx[i], slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0,
+                     bnum[i], bcoord[i], r_bnum, r_bcoord, r_maxcp, r_flags);
+        }
+      }
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < GPX_TILE_ITEMS; j++) {
+      const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
+      if (i < n)
+        put_ac16(X, lds, G, mask, b0n, b0c, i, gidx[i], slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0,
+                 bnum[i], bcoord[i], r_bnum, r_bcoord, r_maxcp, r_flags);
+    }
+  }
+}
+
 /* dynamic LDS of k_bucket_ar16: lcnt[gb] | lcur[gb] | idx[L] | slot[L] | maxcp[L] | meta[L] */
 #define GPX_BUCKET16_LDS_BYTES(gb, lds_recs) ((size_t)(gb) * 8 + (size_t)(lds_recs) * 16)
 #define V16_NIB_MAX 16 /* a group's arrival order fits a 64-bit nibble word up to this many votes */
@@ -119,7 +189,7 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ar16(
  *         output parked in that vote's own words.
  *   otherwise: keys (arrival idx << 32 | position) sorted ascending in global scratch; the
  *         positions of votes with outputs are listed in keys[0 .. nout). */
-template <bool LDSM>
+template <bool LDSM, bool AC = false>
 struct VoteIter {
   const int32_t* idxA;  /* LDS arrays (LDSM) */
   int32_t *slotA, *cpA;
@@ -158,22 +228,34 @@ struct VoteIter {
     cur = p;
     out.idx = ix;
     out.a = sl;
-    out.c = cp;
-    if (meta & V16_ESC) {
-      out.b = in.acceptor[ix];
-      out.bnum = in.bnum[ix];
-      out.bcoord = in.bcoord[ix];
+    if (AC) { /* ACCEPT / COMMIT record: {slot, median_cp, flags byte}; ESC = another ballot */
+      out.b = cp;
+      out.c = (int32_t)((meta >> 16) & 0xffu);
+      const bool esc = (meta & V16_ESC) != 0;
+      out.bnum = esc ? in.bnum[ix] : b0n;
+      out.bcoord = esc ? in.bcoord[ix] : b0c;
     } else {
-      out.b = (int32_t)(meta >> 16);
-      out.bnum = b0n;
-      out.bcoord = b0c;
+      out.c = cp;
+      if (meta & V16_ESC) {
+        out.b = in.acceptor[ix];
+        out.bnum = in.bnum[ix];
+        out.bcoord = in.bcoord[ix];
+      } else {
+        out.b = (int32_t)(meta >> 16);
+        out.bnum = b0n;
+        out.bcoord = b0c;
+      }
     }
     done++;
     return true;
   }
   /* output of the CURRENT vote: (slot, median, kind) parked in the vote's own words; the ballot
    * of a decision / preemption is the coordinator's own (x, y), constant per group per call */
-  __device__ __forceinline__ void emit(int32_t slot, int32_t, int32_t, int32_t z, int32_t kind) {
+  __device__ __forceinline__ void emit(int32_t slot, int32_t x, int32_t y, int32_t z, int32_t kind) {
+    if (AC) { /* an execution run (first, count): apply_accept_group / apply_commit_group emit(0, first, count, 0, 1) */
+      slot = x;
+      z = y;
+    }
     if (LDSM) {
       slotA[cur] = slot;
       cpA[cur] = z;
@@ -246,10 +328,20 @@ __device__ __forceinline__ unsigned long long arrival_order(const int32_t* idxA,
 #else
 #define GPX_AR16_ATTR
 #endif
-template <int KMAX>
-__global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16(DevState S, DevScratch X, Stage16 O, VoteCols in,
-                                                      uint8_t* __restrict__ status) {
+/* dense per-record outputs of the ACCEPT call (gpx_accept_batch: the ACCEPT_REPLY columns) */
+struct AcceptOut {
+  int32_t *r_bnum, *r_bcoord, *r_maxcp;
+  uint8_t* r_flags;
+};
+#define B16_AR 0     /* accept replies at the coordinator */
+#define B16_ACCEPT 1 /* ACCEPTs at an acceptor */
+#define B16_COMMIT 2 /* commits at every replica */
+template <int OP, int KMAX>
+__global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, DevScratch X, Stage16 O, VoteCols in,
+                                                   AcceptOut R, uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
+  constexpr bool AC = OP != B16_AR;
+  if (AC && *X.unsorted != X.epoch) return; /* ordered batch: k_ac_direct did it; nothing was partitioned */
   const int32_t b = blockIdx.x;
   const int32_t boff = X.bucket_off[b];
   const int32_t nb = X.bucket_off[b + 1] - boff;
@@ -262,9 +354,10 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16(DevState S, 
   const int32_t l = (int32_t)threadIdx.x;
   const int32_t g = (b << X.shift) + l;
   /* coordinator state of a dense batch: issued now, consumed after the regrouping */
-  const bool pre = 2 * nb >= gb;
+  const bool pre = !AC && 2 * nb >= gb;
   CoordPre<KMAX> P;
   P.have_pe = false;
+  P.my_bnum = P.my_bcoord = 0;
   if (pre && g < S.G) coord_preload<KMAX>(S, g, P);
   const int32_t L = X.lds_recs;
   int32_t* lcnt = lds;
@@ -355,9 +448,29 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16(DevState S, 
   int32_t nout = 0;
   uint32_t omask = 0;
   const bool live = c != 0 && g < S.G;
-  if (live && !pre) coord_preload<KMAX>(S, g, P);
+  if (!AC && live && !pre) coord_preload<KMAX>(S, g, P);
+  auto replay = [&](auto& it) {
+    if (OP == B16_AR)
+      apply_ar_group<KMAX>(S, X, g, it, status, P);
+    else if (OP == B16_ACCEPT)
+      apply_accept_group(S, X, g, it, R.r_bnum, R.r_bcoord, R.r_maxcp, R.r_flags, status);
+    else
+      apply_commit_group(S, X, g, it, status);
+  };
+  /* a bucket's outputs, group-major, as columns: decisions (six columns) or execution runs (gidx,
+   * first slot, count) */
+  auto put = [&](int64_t o, int32_t a, int32_t z, int32_t kd) {
+    O.gidx[o] = g;
+    O.slot[o] = a;
+    O.median[o] = z;
+    if (!AC) {
+      O.bnum[o] = P.my_bnum;
+      O.bcoord[o] = P.my_bcoord;
+      O.kind[o] = (uint8_t)kd;
+    }
+  };
   if (in_lds) {
-    VoteIter<true> it;
+    VoteIter<true, AC> it;
     it.idxA = idxA;
     it.slotA = slotA;
     it.cpA = cpA;
@@ -377,7 +490,7 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16(DevState S, 
     it.cur = 0;
     if (live) {
       if (it.nib) it.order = arrival_order(idxA, start, c);
-      apply_ar_group<KMAX>(S, X, g, it, status, P);
+      replay(it);
     }
     nout = it.nout;
     omask = it.omask;
@@ -387,17 +500,11 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16(DevState S, 
     for (int32_t q = 0; q < nout; q++) {
       int32_t sl, md, kd;
       it.output(q, &sl, &md, &kd, &omask);
-      const int64_t o = (int64_t)boff + ex + q;
-      O.gidx[o] = g;
-      O.slot[o] = sl;
-      O.bnum[o] = P.my_bnum;
-      O.bcoord[o] = P.my_bcoord;
-      O.median[o] = md;
-      O.kind[o] = (uint8_t)kd;
+      put((int64_t)boff + ex + q, sl, md, kd);
     }
     if (l == 0) X.bucket_nout[b] = tout;
   } else {
-    VoteIter<false> it;
+    VoteIter<false, AC> it;
     it.idxA = idxA;
     it.slotA = slotA;
     it.cpA = cpA;
@@ -415,20 +522,14 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16(DevState S, 
     it.order = 0;
     it.omask = 0;
     it.cur = 0;
-    if (live) apply_ar_group<KMAX>(S, X, g, it, status, P);
+    if (live) replay(it);
     nout = it.nout;
     int32_t tout;
     const int32_t ex = block_exscan_rt(nout, &tout);
     for (int32_t q = 0; q < nout; q++) {
       int32_t sl, md, kd;
       it.output(q, &sl, &md, &kd, &omask);
-      const int64_t o = (int64_t)boff + ex + q;
-      O.gidx[o] = g;
-      O.slot[o] = sl;
-      O.bnum[o] = P.my_bnum;
-      O.bcoord[o] = P.my_bcoord;
-      O.median[o] = md;
-      O.kind[o] = (uint8_t)kd;
+      put((int64_t)boff + ex + q, sl, md, kd);
     }
     if (l == 0) X.bucket_nout[b] = tout;
   }
@@ -449,5 +550,20 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec16(
     d_bcoord[out0 + t] = O.bcoord[src + t];
     d_median[out0 + t] = O.median[src + t];
     d_kind[out0 + t] = O.kind[src + t];
+  }
+}
+
+/* staged execution runs -> the caller's columns, buckets in order (partition path of ACCEPT / COMMIT) */
+__global__ __launch_bounds__(GPX_BLOCK) void k_emit_runs16(DevScratch X, Stage16 O, int32_t* __restrict__ x_gidx,
+                                                          int32_t* __restrict__ x_first,
+                                                          int32_t* __restrict__ x_count, int32_t* total_out) {
+  if (*X.unsorted != X.epoch) return; /* ordered batch: k_emit_runs_direct wrote the outputs */
+  const int32_t out0 = emit_base(X, total_out, nullptr);
+  const int32_t nd = X.bucket_nout[blockIdx.x];
+  const int64_t src = X.bucket_off[blockIdx.x];
+  for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {
+    x_gidx[out0 + t] = O.gidx[src + t];
+    x_first[out0 + t] = O.slot[src + t];
+    x_count[out0 + t] = O.median[src + t];
   }
 }

@@ -166,7 +166,12 @@ __device__ __forceinline__ void for_signed_order(int32_t lo, int32_t cnt, F f) {
  * build) the kernel faulted intermittently on the GPU box (SIGSEGV inside elect_group under rocgdb,
  * a silent abort outside it) with the same source that runs clean inlined. */
 template <int KMAX, int WMAX>
-__device__ __forceinline__ void elect_group(const DevState& S, const DevScratch& X, int32_t g,
+#ifdef GPX_ELECT_NOINLINE /* repro build of round 1's intermittent fault: scripts/repro_noinline_fault.sh */
+#define GPX_ELECT_INLINE __attribute__((noinline))
+#else
+#define GPX_ELECT_INLINE __forceinline__
+#endif
+__device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch& X, int32_t g,
                                          GroupIter& it, const PReplyIn& I, const PReplyOut& O) {
   const int32_t G = S.G, W = S.W, Wm = W - 1, n = O.n;
   uint32_t gf = S.g_flags[g];

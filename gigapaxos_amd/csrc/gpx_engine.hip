@@ -374,7 +374,7 @@ void launch_bucket_ar(gpx_engine* e, uint8_t* status) {
 }
 template <int KMAX>
 void launch_bucket_ar16(gpx_engine* e, const Stage16& O, const VoteCols& in, uint8_t* status) {
-  LAUNCH_B(e, "k_bucket_ar16", (k_bucket_ar16<KMAX>), e->S, e->X, O, in, status);
+  LAUNCH_B(e, "k_bucket_ar16", (k_bucket16<B16_AR, KMAX>), e->S, e->X, O, in, AcceptOut{}, status);
 }
 template <int KMAX>
 void launch_bucket_propose(gpx_engine* e, int32_t* slot, int32_t* bnum, int32_t* bcoord,
@@ -570,8 +570,9 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   if (e->ar16) {
     const size_t hw16 = GPX_BUCKET16_LDS_BYTES(X.gb, e->lds16_hw) + e->lds_pad;
-    const void* fns[] = {(const void*)k_bucket_ar16<4>, (const void*)k_bucket_ar16<8>,
-                         (const void*)k_bucket_ar16<16>};
+    const void* fns[] = {(const void*)k_bucket16<B16_AR, 4>, (const void*)k_bucket16<B16_AR, 8>,
+                         (const void*)k_bucket16<B16_AR, 16>, (const void*)k_bucket16<B16_ACCEPT, 4>,
+                         (const void*)k_bucket16<B16_COMMIT, 4>};
     for (const void* f : fns)
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
   }
@@ -904,11 +905,23 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
            e->S.G, e->X, status, D.chunk_cnt, nchunks);
   const bool promised = (e->ordered_mask & GPX_ORDERED_ACCEPT) != 0;
+  const size_t Nmax = (size_t)e->cfg.max_batch;
+  const Stage16 O16{st32, st32 + Nmax, st32 + 2 * Nmax, st32 + 3 * Nmax, st32 + 4 * Nmax, (uint8_t*)(st32 + 5 * Nmax)};
   if (!promised) {
     front_hist(e, n, gidx, status, 0, 2);
-    launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, 1);
+    if (e->ar16) {
+      const int ntiles = ntiles_for(n);
+      if (aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)a_flags & 3))
+        LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
+                 e->X, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+      else
+        LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
+                 e->X, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+    } else {
+      launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, 1);
+    }
   }
-  begin_back(e, fs, n);
+  begin_back(e, fs, n, e->ar16);
   {
     LaunchScope _ls(e, "k_ac_direct");
     hipLaunchKernelGGL(k_ac_direct<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
@@ -920,7 +933,13 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
                        x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
   }
-  if (!promised) {
+  if (!promised && e->ar16) {
+    /* unordered batch: 16-byte records through the partition (gpx_ar16.hip.h); the back end may
+     * re-read bnum / bcoord of records in another ballot than the batch's first */
+    LAUNCH_B(e, "k_bucket_accept16", (k_bucket16<B16_ACCEPT, 4>), e->S, e->X, O16, VoteCols{bnum, bcoord, nullptr},
+             AcceptOut{r_bnum, r_bcoord, r_maxcp, r_flags}, status);
+    LAUNCH(e, "k_emit_runs16", k_emit_runs16, e->X.nbk, e->X, O16, x_gidx, x_first, x_count, n_runs);
+  } else if (!promised) {
     LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags, status);
     LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   }
@@ -951,11 +970,25 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
            e->S.G, e->X, status, D.chunk_cnt, nchunks);
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
+  const size_t Nmax = (size_t)e->cfg.max_batch;
+  const Stage16 O16{st32, st32 + Nmax, st32 + 2 * Nmax, st32 + 3 * Nmax, st32 + 4 * Nmax, (uint8_t*)(st32 + 5 * Nmax)};
   if (!promised) {
     front_hist(e, n, gidx, status, 0, 2);
-    launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, c_kind, nullptr, nullptr, nullptr, nullptr, 1);
+    if (e->ar16) {
+      const int ntiles = ntiles_for(n);
+      if (aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)c_kind & 3))
+        LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
+                 e->X, gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
+                 (int32_t*)nullptr, (uint8_t*)nullptr);
+      else
+        LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
+                 e->X, gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
+                 (int32_t*)nullptr, (uint8_t*)nullptr);
+    } else {
+      launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, c_kind, nullptr, nullptr, nullptr, nullptr, 1);
+    }
   }
-  begin_back(e, fs, n);
+  begin_back(e, fs, n, e->ar16);
   {
     LaunchScope _ls(e, "k_ac_direct");
     hipLaunchKernelGGL(k_ac_direct<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
@@ -967,7 +1000,11 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
                        x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
   }
-  if (!promised) {
+  if (!promised && e->ar16) {
+    LAUNCH_B(e, "k_bucket_commit16", (k_bucket16<B16_COMMIT, 4>), e->S, e->X, O16, VoteCols{bnum, bcoord, nullptr},
+             AcceptOut{}, status);
+    LAUNCH(e, "k_emit_runs16", k_emit_runs16, e->X.nbk, e->X, O16, x_gidx, x_first, x_count, n_runs);
+  } else if (!promised) {
     LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
     LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   }

@@ -27,6 +27,9 @@ def main():
     ap.add_argument("--groups", type=int, default=1_000_000)
     ap.add_argument("--rounds", type=int, default=8)
     ap.add_argument("--profile-rounds", type=int, default=4)
+    ap.add_argument("--unordered", action="store_true",
+                    help="ACCEPT and COMMIT batches in a random record order (what an acceptor sees when the frames "
+                         "of many coordinators interleave): the partition path instead of the direct one")
     ap.add_argument("--no-promise", action="store_true",
                     help="do not declare the batches ordered (gpx_engine_set_ordered_batches): the engine then "
                          "also launches the partition path, which returns at once")
@@ -42,7 +45,7 @@ def main():
         e = Engine(load_hip(), nid, G, kmax=K, window=8, max_batch=3 * G + 1024)
         assert (e.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
         e.set_stream(ts.cuda_stream)
-        if not args.no_promise:  # every batch here is the previous stage's output: grouped by group
+        if not args.no_promise and not args.unordered:  # every batch here is the previous stage's output: grouped by group
             e.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT)
         eng[nid] = e
     i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
@@ -60,6 +63,9 @@ def main():
     rng = np.random.default_rng(0)
     perms = [torch.from_numpy(rng.permutation(3 * G)).to(dev) for _ in range(2)]
     acc_col = torch.cat([torch.full((G,), nid, dtype=torch.int32, device=dev) for nid in ids])
+    gperm = torch.from_numpy(rng.permutation(G)).to(dev) if args.unordered else None
+    a_in = [i32(G) for _ in range(5)]   # unordered ACCEPT batch: gidx, bnum, bcoord, slot, median
+    c_in = [i32(G) for _ in range(5)]   # unordered COMMIT batch: gidx, bnum, bcoord, slot, median
     t = {"propose": 0.0, "accept_x3": 0.0, "accept_reply": 0.0, "commit_x3": 0.0}
     timed = args.rounds - 1
     for r in range(args.rounds + args.profile_rounds):
@@ -69,25 +75,33 @@ def main():
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         ev[0].record()
         eng[100].call_dev("propose_batch", G, P(g_all), 0, P(p_slot), P(p_bnum), P(p_bcoord), P(p_med), P(p_st))
+        if gperm is not None:
+            for dst, src in zip(a_in, (g_all, p_bnum, p_bcoord, p_slot, p_med)):
+                dst.copy_(src[gperm])
         ev[1].record()
+        ag, ab, ac_, asl, am = (a_in if gperm is not None else (g_all, p_bnum, p_bcoord, p_slot, p_med))
         for nid in ids:
             rb, rc, rm, rf, st = rep[nid]
             xg, xf, xc, nr = runs[nid]
-            eng[nid].call_dev("accept_batch", G, P(g_all), P(p_bnum), P(p_bcoord), P(p_slot), P(p_med), 0,
+            eng[nid].call_dev("accept_batch", G, P(ag), P(ab), P(ac_), P(asl), P(am), 0,
                               P(rb), P(rc), P(rm), P(rf), P(st), P(xg), P(xf), P(xc), P(nr))
         ev[2].record()
         # the replies of the three acceptors, shuffled, as the coordinator's vote columns
         pm = perms[r & 1]
         cat = lambda k: torch.cat([rep[nid][k] for nid in ids])  # noqa: E731
-        v[0].copy_(g_all.repeat(3)[pm]); v[1].copy_(cat(0)[pm]); v[2].copy_(cat(1)[pm])
-        v[3].copy_(p_slot.repeat(3)[pm]); v[4].copy_(acc_col[pm]); v[5].copy_(cat(2)[pm])
+        v[0].copy_(ag.repeat(3)[pm]); v[1].copy_(cat(0)[pm]); v[2].copy_(cat(1)[pm])
+        v[3].copy_(asl.repeat(3)[pm]); v[4].copy_(acc_col[pm]); v[5].copy_(cat(2)[pm])
         ev2b = torch.cuda.Event(enable_timing=True)
         ev2b.record()
         eng[100].call_dev("accept_reply_batch", 3 * G, *[P(x) for x in v], *[P(x) for x in d], P(n_out), P(v_st))
+        if gperm is not None:
+            for dst, src in zip(c_in, (d[0], d[2], d[3], d[1], d[4])):
+                dst.copy_(src[:G][gperm])
         ev[3].record()
+        cg, cb, cc_, csl, cm = (c_in if gperm is not None else (d[0], d[2], d[3], d[1], d[4]))
         for nid in ids:
             xg, xf, xc, nr = runs[nid]
-            eng[nid].call_dev("commit_batch", G, P(d[0]), P(d[2]), P(d[3]), P(d[1]), P(d[4]), P(ckind), P(c_st),
+            eng[nid].call_dev("commit_batch", G, P(cg), P(cb), P(cc_), P(csl), P(cm), P(ckind), P(c_st),
                               P(xg), P(xf), P(xc), P(nr))
         ev[4].record()
         for e in eng.values():
@@ -107,7 +121,8 @@ def main():
         for name, (cnt, ms) in e.profile_read().items():
             kern[name] = kern.get(name, 0.0) + ms * 1e3 / max(args.profile_rounds, 1)
     tot = sum(t.values()) / k
-    print(json.dumps({"groups": G, "replicas": K, "ordered_batches_promise": not args.no_promise,
+    print(json.dumps({"groups": G, "replicas": K, "ordered_batches_promise": not args.no_promise and not args.unordered,
+                      "acceptor_batches": "unordered" if args.unordered else "grouped by group",
                       "ms_per_round": round(tot, 4),
                       "phases_ms": {a: round(b / k, 4) for a, b in t.items()},
                       "decided_and_executed_per_s": round(G / tot * 1e3, 1),
