@@ -611,12 +611,18 @@ void PaxosManager::issueAccept(std::vector<OutAccept>& out, int32_t gidx, const 
 
 size_t PaxosManager::nodeDown(int32_t nodeID) {
   if (!engine_) return 0;
+  /* lastCoordinatorLongDead (PISM:2090-2176): a node reported down again, or already down when another
+   * node fails, has been dead for long - any member may then run, not only the next in line (else a
+   * group whose next-in-line member is down too would never get a coordinator) */
+  std::vector<int32_t> longDead;
+  for (int32_t d : downNodes_) longDead.push_back(d);
   if (std::find(downNodes_.begin(), downNodes_.end(), nodeID) == downNodes_.end()) downNodes_.push_back(nodeID);
   /* checkRunForCoordinator's decision for every instance at once */
   const int32_t n = opt_.maxGroups;
   std::vector<uint8_t> run((size_t)n), st((size_t)n);
   std::vector<int32_t> pb((size_t)n), pf((size_t)n);
-  if (!check(gpx_election_scan(engine_, n, nullptr, downNodes_.data(), (int32_t)downNodes_.size(), nullptr, 0, 0,
+  if (!check(gpx_election_scan(engine_, n, nullptr, downNodes_.data(), (int32_t)downNodes_.size(),
+                               longDead.empty() ? nullptr : longDead.data(), (int32_t)longDead.size(), 0,
                                run.data(), pb.data(), pf.data(), st.data()),
              "gpx_election_scan"))
     return 0;
@@ -687,6 +693,27 @@ size_t PaxosManager::poke() {
   std::sort(live.begin(), live.end());
   const int32_t m = (int32_t)live.size();
   if (m > 0) {
+    /* stored ACCEPT values of slots below the acceptor's slot are garbage (late or re-sent ACCEPTs of
+     * executed slots, decisions the engine refused): the mirror of the engine's own cleanup at
+     * execution (PaxosAcceptor.java:357-359) - without it a group with such a leftover never pauses */
+    std::vector<gpx_hri> rows((size_t)m);
+    std::vector<uint8_t> rst((size_t)m);
+    if (check(gpx_group_snapshot(engine_, m, live.data(), rows.data(), rst.data()), "gpx_group_snapshot")) {
+      stats_.engine_calls++;
+      std::vector<int32_t> accSlot((size_t)opt_.maxGroups, 0);
+      std::vector<uint8_t> known((size_t)opt_.maxGroups, 0);
+      for (int32_t i = 0; i < m; i++)
+        if (rst[(size_t)i] == GPX_S_OK) accSlot[(size_t)live[(size_t)i]] = rows[(size_t)i].acc_slot, known[(size_t)live[(size_t)i]] = 1;
+      for (auto a = accepted_.begin(); a != accepted_.end();) {
+        const int32_t g = (int32_t)(a->first >> 32), slot = (int32_t)(uint32_t)a->first;
+        if (known[(size_t)g] && jsub32(slot, accSlot[(size_t)g]) < 0) {
+          a = accepted_.erase(a);
+          liveAccepts_[(size_t)g]--;
+        } else {
+          ++a;
+        }
+      }
+    }
     std::vector<int32_t> first((size_t)m), maxc((size_t)m);
     std::vector<uint64_t> missing((size_t)m);
     std::vector<uint8_t> sync((size_t)m), gst((size_t)m);

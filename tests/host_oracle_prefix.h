@@ -25,3 +25,4 @@
 #define gpx_request_batch orc_request_batch
 #define gpx_gap_scan orc_gap_scan
 #define gpx_poke_scan orc_poke_scan
+#define gpx_group_snapshot orc_group_snapshot
