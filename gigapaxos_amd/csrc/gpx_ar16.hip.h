@@ -49,8 +49,11 @@ struct VoteCols {
 __device__ __forceinline__ void put_vote16(const DevScratch& X, int32_t* lds, int32_t G, int32_t mask,
                                            int32_t b0n, int32_t b0c, int64_t i, int32_t g, int32_t slot,
                                            int32_t acc, int32_t maxcp, int32_t bn, int32_t bc) {
-  if ((uint32_t)g >= (uint32_t)G) return; /* status already says GPX_S_NOGROUP (k_hist) */
-  const int32_t pos = bucket_take(lds, g >> X.shift);
+  /* outside this pass's group range: another pass takes it, or (outside the table) the status already
+   * says GPX_S_NOGROUP (k_hist) */
+  if ((uint32_t)(g - X.g_base) >= (uint32_t)(X.g_end - X.g_base)) return;
+  (void)G;
+  const int32_t pos = bucket_take(lds, (g - X.g_base) >> X.shift);
   const bool esc = bn != b0n || bc != b0c || (uint32_t)acc > 0xffffu;
   Vote16 v;
   v.idx = (int32_t)i;
@@ -352,13 +355,13 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
   if (nb == 0) return;
   const int32_t gb = X.gb; /* == blockDim.x: one lane per group */
   const int32_t l = (int32_t)threadIdx.x;
-  const int32_t g = (b << X.shift) + l;
+  const int32_t g = X.g_base + (b << X.shift) + l;
   /* coordinator state of a dense batch: issued now, consumed after the regrouping */
   const bool pre = !AC && 2 * nb >= gb;
   CoordPre<KMAX> P;
   P.have_pe = false;
   P.my_bnum = P.my_bcoord = 0;
-  if (pre && g < S.G) coord_preload<KMAX>(S, g, P);
+  if (pre && g < X.g_end) coord_preload<KMAX>(S, g, P);
   const int32_t L = X.lds_recs;
   int32_t* lcnt = lds;
   int32_t* lcur = lds + gb;
@@ -390,7 +393,7 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
     for (int32_t j = 4 * gb + l; j < nb; j += gb) atomicAdd(&lcnt[recG[j].meta & V16_LG_MASK], 1);
   }
   __syncthreads();
-  if (pre && g < S.G) coord_preload_ring<KMAX>(S, g, P);
+  if (pre && g < X.g_end) coord_preload_ring<KMAX>(S, g, P);
   /* B: exclusive scan of the counts */
   const int32_t c = lcnt[l];
   int32_t tot_;
@@ -447,7 +450,7 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
   /* E: replay, one lane per group */
   int32_t nout = 0;
   uint32_t omask = 0;
-  const bool live = c != 0 && g < S.G;
+  const bool live = c != 0 && g < X.g_end;
   if (!AC && live && !pre) coord_preload<KMAX>(S, g, P);
   auto replay = [&](auto& it) {
     if (OP == B16_AR)
@@ -539,8 +542,23 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
 __global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec16(
     DevScratch X, Stage16 O, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
     int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
-    uint8_t* __restrict__ d_kind, int32_t* total_out, unsigned long long* acc) {
-  const int32_t out0 = emit_base(X, total_out, acc);
+    uint8_t* __restrict__ d_kind, int32_t* total_out, unsigned long long* acc, const int32_t* base_in,
+    int32_t* chain_out) {
+  /* base_in: outputs of the passes before this one (accept-reply calls over more than 4 M groups run
+   * one pass per group range, ranges ascending: the concatenation is still grouped by gidx ascending) */
+  const int32_t base0 = base_in ? *base_in : 0;
+  const int32_t b = blockIdx.x;
+  int32_t before = 0;
+  for (int32_t t = threadIdx.x; t < b; t += GPX_BLOCK) before += X.bucket_nout[t];
+  int32_t pre;
+  block_exscan(before, &pre);
+  const int32_t out0 = base0 + pre;
+  if (b == (int32_t)gridDim.x - 1 && threadIdx.x == 0) {
+    const int32_t tot = pre + X.bucket_nout[b];
+    if (total_out) *total_out = base0 + tot;
+    if (chain_out) *chain_out = base0 + tot; /* never the word base_in points at: later workgroups still read that */
+    if (acc) atomicAdd(acc, (unsigned long long)tot);
+  }
   const int32_t nd = X.bucket_nout[blockIdx.x];
   const int64_t src = X.bucket_off[blockIdx.x];
   for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {

@@ -63,7 +63,7 @@ struct gpx_engine {
   hipStream_t sF = nullptr, sB = nullptr; /* the streams in force (equal unless pipelined) */
   hipStream_t stream = nullptr;           /* where the next launch goes: sF inside a front section, else sB */
   bool pipeline = false;
-  bool pipe_light = true; /* GPX_PIPE_FULL=1: the scatter on the front stream as well (round 1's scheme) */
+  bool pipe_light = false; /* GPX_PIPE_LIGHT=1: only the histogram overlaps (measured: no better) */
   /* front-end scratch is double-buffered so that call N+1's front end can run beside call N's
    * back end; evF[s] = front end of the call using set s done, evB[s] = its back end done */
   struct FrontSet {
@@ -113,6 +113,12 @@ struct gpx_engine {
   unsigned long long* small_tickets = nullptr;
   uint32_t small_epoch = 0;
   int32_t lds16_max = 0, lds16_hw = 0; /* LDS staging capacities (votes) of k_bucket_ar16 */
+  /* accept-reply calls partition at most 4 M groups per pass (4096 buckets of 1024 groups): a bigger
+   * table is covered by ar_passes passes over ascending group ranges, each skipping the other ranges'
+   * votes; shift16 / nbk16 = the bucket geometry of those passes (== X's when one pass suffices) */
+  int32_t ar_passes = 1, shift16 = 0, nbk16 = 0;
+  bool ac16 = false;          /* ACCEPT / COMMIT partition path on 16-byte records too (single pass only) */
+  int32_t* ar_chain = nullptr; /* [2] running output count between passes */
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
   /* wire codec (gpx_wire_host.inc): paxosID table, row free list, scratch - allocated on first use */
   DevNames N{};
@@ -505,6 +511,8 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   X.gb = 1 << X.shift;
   X.nbk = (int32_t)nbk_for(X.shift);
+  X.g_base = 0;
+  X.g_end = cfg->max_groups;
   e->bucket_threads = std::min(1024, X.gb);
   /* LDS staging capacity: the expected kmax * gb records of a full round + ~7 sigma, within
    * 8 records per thread and the CU's 160 KiB; 960 (K <= 3, gb 256) keeps 4 workgroups per CU */
@@ -526,7 +534,28 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     e->lds16_max = (int32_t)std::min<int64_t>(want, cap16);
     e->lds16_hw = (int32_t)cap16;
     const char* leg = getenv("GPX_AR_LEGACY");
-    e->ar16 = X.shift <= V16_MAX_SHIFT && e->bucket_threads == X.gb && !(leg && atoi(leg));
+    e->ar16 = !(leg && atoi(leg));
+    e->ac16 = e->ar16 && X.shift <= V16_MAX_SHIFT && e->bucket_threads == X.gb;
+    if (X.shift <= V16_MAX_SHIFT) {
+      e->shift16 = X.shift;
+      e->nbk16 = X.nbk;
+      e->ar_passes = 1;
+    } else { /* more than 4 M groups: passes over ranges of 4096 x 1024 groups */
+      e->shift16 = V16_MAX_SHIFT;
+      const int64_t range = (int64_t)GPX_MAX_BUCKETS << V16_MAX_SHIFT;
+      e->ar_passes = (int32_t)(((int64_t)G + range - 1) / range);
+      e->nbk16 = GPX_MAX_BUCKETS;
+      const int64_t gb16 = (int64_t)1 << V16_MAX_SHIFT;
+      const int64_t cap16b = ((int64_t)160 * 1024 - 1024 - gb16 * 8) / 16;
+      int64_t want16 = (int64_t)cfg->kmax * gb16;
+      want16 += want16 / 4 + 128;
+      e->lds16_max = (int32_t)std::min<int64_t>(want16, cap16b);
+      e->lds16_hw = (int32_t)cap16b;
+    }
+    if ((rc = dev_alloc(e, &e->ar_chain, 2, true)) != GPX_OK) {
+      gpx_engine_destroy(e);
+      return rc;
+    }
   }
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
@@ -549,8 +578,8 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
      * config #2's size (30 k votes over 10 k groups: 33 us against 34 us) and loses at 65,536 votes
      * over 1 M groups (90 us against 53 us: one 1024-lane workgroup per CU, each a chain of dependent
      * round trips).  Kept, tested both ways, as the starting point for a fused small-batch back end. */
-    const char* pf = getenv("GPX_PIPE_FULL");
-    e->pipe_light = !(pf && atoi(pf));
+    const char* pf = getenv("GPX_PIPE_LIGHT");
+    e->pipe_light = pf && atoi(pf);
     const char* sm = getenv("GPX_SMALL");
     e->small_on = sm && atoi(sm);
     if ((rc = dev_alloc(e, &e->small_tickets, GPX_SMALL_MAX_WG, true)) != GPX_OK) {
@@ -569,7 +598,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
   }
   if (e->ar16) {
-    const size_t hw16 = GPX_BUCKET16_LDS_BYTES(X.gb, e->lds16_hw) + e->lds_pad;
+    const size_t hw16 = GPX_BUCKET16_LDS_BYTES((size_t)1 << e->shift16, e->lds16_hw) + e->lds_pad;
     const void* fns[] = {(const void*)k_bucket16<B16_AR, 4>, (const void*)k_bucket16<B16_AR, 8>,
                          (const void*)k_bucket16<B16_AR, 16>, (const void*)k_bucket16<B16_ACCEPT, 4>,
                          (const void*)k_bucket16<B16_COMMIT, 4>};
@@ -577,16 +606,17 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
       HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
   }
   { /* k_hist may take up to GPX_HSUB_MAX histograms of dynamic LDS */
-    const int hl = GPX_HSUB_MAX * X.nbk * (int)sizeof(int32_t);
+    const int hl = GPX_HSUB_MAX * std::max(X.nbk, e->nbk16) * (int)sizeof(int32_t);
     if (hl > 64 * 1024) {
       HIPCHK(hipFuncSetAttribute((const void*)k_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, hl));
       HIPCHK(hipFuncSetAttribute((const void*)k_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, hl));
     }
   }
+  const size_t nbk_alloc = (size_t)std::max(X.nbk, e->nbk16); /* accept-reply passes may use more, smaller buckets */
   for (auto& f : e->fs) { /* double-buffered front-end scratch */
-    A(f.bucket_tot, (size_t)X.nbk, true);
-    A(f.tile_rel, ((N + GPX_TILE - 1) / GPX_TILE) * (size_t)X.nbk, false);
-    A(f.bucket_off, (size_t)X.nbk + 1, true);
+    A(f.bucket_tot, nbk_alloc, true);
+    A(f.tile_rel, ((N + GPX_TILE - 1) / GPX_TILE) * nbk_alloc, false);
+    A(f.bucket_off, nbk_alloc + 1, true);
     A(f.rec, N, false);
     A(f.unsorted, 1, true);
     A(f.chunk_cnt, N / GPX_DCHUNK + 2, true);
@@ -600,7 +630,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.rank2, N, false);
   A(X.perm, N, false);
   A(X.o_rec, N, false);
-  A(X.bucket_nout, (size_t)X.nbk, true);
+  A(X.bucket_nout, nbk_alloc, true);
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
@@ -828,35 +858,64 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
       return GPX_OK;
     }
   }
-  front_hist(e, n, gidx, status, 1);
   const int ntiles = ntiles_for(n);
   const bool vec = aligned16({gidx, bnum, bcoord, slot, acceptor, max_cp});
   if (e->ar16) {
-    /* 16-byte vote records (gpx_ar16.hip.h); the back end may re-read bnum / bcoord / acceptor */
-    /* pipelined mode: only the histogram of call N+1 runs beside the back end of call N (an
-     * atomics-bound kernel beside bandwidth-bound ones); the scatter stays in stream order with the
-     * per-bucket kernels - overlapping it too made everything slower (measured) */
-    if (e->pipe_light) begin_back(e, fs, n, true);
-    if (vec)
-      LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
-               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-    else
-      LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
-               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-    if (!e->pipe_light) begin_back(e, fs, n, true);
+    /* 16-byte vote records (gpx_ar16.hip.h); the back end may re-read bnum / bcoord / acceptor.
+     * One pass per range of at most 4 M groups (ranges ascending, so the concatenated outputs stay
+     * grouped by gidx ascending); a table of up to 4 M groups is one pass over everything. */
+    const DevScratch X0 = e->X;
+    const int threads0 = e->bucket_threads;
+    const int32_t passes = e->ar_passes;
     const size_t N = (size_t)e->cfg.max_batch;
     int32_t* o32 = (int32_t*)e->X.o_rec; /* N x 32 bytes: five int columns + one byte column */
     const Stage16 O{o32, o32 + N, o32 + 2 * N, o32 + 3 * N, o32 + 4 * N, (uint8_t*)(o32 + 5 * N)};
     const VoteCols in{bnum, bcoord, acceptor};
-    if (e->cfg.kmax <= 4)
-      launch_bucket_ar16<4>(e, O, in, status);
-    else if (e->cfg.kmax <= 8)
-      launch_bucket_ar16<8>(e, O, in, status);
-    else
-      launch_bucket_ar16<16>(e, O, in, status);
-    LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord,
-           d_median_cp, d_kind, n_out, &e->X.counters[1]);
+    for (int32_t p = 0; p < passes; p++) {
+      e->X.shift = e->shift16;
+      e->X.gb = 1 << e->shift16;
+      e->X.nbk = e->nbk16;
+      e->bucket_threads = e->X.gb;
+      if (passes > 1) {
+        const int64_t range = (int64_t)e->nbk16 << e->shift16;
+        e->X.g_base = (int32_t)(p * range);
+        e->X.g_end = (int32_t)std::min<int64_t>(e->S.G, (p + 1) * range);
+        e->X.nbk = (int32_t)((e->X.g_end - e->X.g_base + e->X.gb - 1) >> e->shift16);
+        /* several passes: everything in stream order on the back-end stream; LDS sized for a pass */
+        if (p == 0) begin_back(e, fs, n / passes, true);
+      }
+      /* status prefill, vote and out-of-table counters: once, by the first pass */
+      front_hist(e, n, gidx, p == 0 ? status : nullptr, p == 0 ? 1 : -1);
+      /* pipelined mode, GPX_PIPE_LIGHT=1: only the histogram of call N+1 runs beside the back end of
+       * call N; measured on MI355X: 0.164 ms per step against 0.160 with the scatter overlapped too
+       * and 0.140 on ONE stream - the kernels of this pipeline fill the chip, overlap only adds
+       * contention, so one stream is the default everywhere */
+      if (passes == 1 && e->pipe_light) begin_back(e, fs, n, true);
+      if (vec)
+        LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+                 ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+      else
+        LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+                 ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+      if (passes == 1 && !e->pipe_light) begin_back(e, fs, n, true);
+      if (e->cfg.kmax <= 4)
+        launch_bucket_ar16<4>(e, O, in, status);
+      else if (e->cfg.kmax <= 8)
+        launch_bucket_ar16<8>(e, O, in, status);
+      else
+        launch_bucket_ar16<16>(e, O, in, status);
+      LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord,
+             d_median_cp, d_kind, n_out, &e->X.counters[1],
+             (const int32_t*)(p > 0 ? e->ar_chain + (p & 1) : nullptr),
+             passes > 1 ? e->ar_chain + ((p + 1) & 1) : (int32_t*)nullptr);
+      /* what begin_back computed for this call survives the restore below */
+      const int32_t lds_recs = e->X.lds_recs;
+      e->X = X0;
+      e->X.lds_recs = lds_recs;
+      e->bucket_threads = threads0;
+    }
   } else {
+    front_hist(e, n, gidx, status, 1);
     if (vec)
       LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
                ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
@@ -909,7 +968,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const Stage16 O16{st32, st32 + Nmax, st32 + 2 * Nmax, st32 + 3 * Nmax, st32 + 4 * Nmax, (uint8_t*)(st32 + 5 * Nmax)};
   if (!promised) {
     front_hist(e, n, gidx, status, 0, 2);
-    if (e->ar16) {
+    if (e->ac16) {
       const int ntiles = ntiles_for(n);
       if (aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)a_flags & 3))
         LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
@@ -921,7 +980,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
       launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, 1);
     }
   }
-  begin_back(e, fs, n, e->ar16);
+  begin_back(e, fs, n, e->ac16);
   {
     LaunchScope _ls(e, "k_ac_direct");
     hipLaunchKernelGGL(k_ac_direct<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
@@ -933,7 +992,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
                        x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
   }
-  if (!promised && e->ar16) {
+  if (!promised && e->ac16) {
     /* unordered batch: 16-byte records through the partition (gpx_ar16.hip.h); the back end may
      * re-read bnum / bcoord of records in another ballot than the batch's first */
     LAUNCH_B(e, "k_bucket_accept16", (k_bucket16<B16_ACCEPT, 4>), e->S, e->X, O16, VoteCols{bnum, bcoord, nullptr},
@@ -974,7 +1033,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const Stage16 O16{st32, st32 + Nmax, st32 + 2 * Nmax, st32 + 3 * Nmax, st32 + 4 * Nmax, (uint8_t*)(st32 + 5 * Nmax)};
   if (!promised) {
     front_hist(e, n, gidx, status, 0, 2);
-    if (e->ar16) {
+    if (e->ac16) {
       const int ntiles = ntiles_for(n);
       if (aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)c_kind & 3))
         LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
@@ -988,7 +1047,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
       launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, c_kind, nullptr, nullptr, nullptr, nullptr, 1);
     }
   }
-  begin_back(e, fs, n, e->ar16);
+  begin_back(e, fs, n, e->ac16);
   {
     LaunchScope _ls(e, "k_ac_direct");
     hipLaunchKernelGGL(k_ac_direct<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
@@ -1000,7 +1059,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
                        x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
   }
-  if (!promised && e->ar16) {
+  if (!promised && e->ac16) {
     LAUNCH_B(e, "k_bucket_commit16", (k_bucket16<B16_COMMIT, 4>), e->S, e->X, O16, VoteCols{bnum, bcoord, nullptr},
              AcceptOut{}, status);
     LAUNCH(e, "k_emit_runs16", k_emit_runs16, e->X.nbk, e->X, O16, x_gidx, x_first, x_count, n_runs);

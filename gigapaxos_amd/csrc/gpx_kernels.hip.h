@@ -136,7 +136,10 @@ struct DevState {
 #define CO_PRESENT 0x100
 
 struct DevScratch {
-  int32_t shift, nbk, gb; /* bucket = gidx >> shift; nbk buckets of gb = 1 << shift groups */
+  int32_t shift, nbk, gb; /* bucket = (gidx - g_base) >> shift; nbk buckets of gb = 1 << shift groups */
+  int32_t g_base, g_end;  /* groups this pass partitions: [g_base, g_end), g_base a multiple of gb; the
+                           * whole table except for accept-reply calls over more than 4 M groups, which
+                           * run one pass per 4 M-group range (records of other ranges are skipped) */
   int32_t lds_recs;       /* a bucket with at most this many records is regrouped entirely in LDS */
   int32_t* bucket_tot;    /* [nbk] records per bucket of the current batch (k_hist; re-zeroed by k_bucket_*) */
   int32_t* tile_rel;      /* [ntiles][nbk] start of each tile's slice inside each bucket region (k_hist) */
@@ -247,8 +250,15 @@ __device__ __forceinline__ int32_t bucket_take(int32_t* lds, int32_t b) {
 template <bool VEC>
 __device__ __forceinline__ int32_t tile_histogram(int32_t n, int64_t base,
                                                   const int32_t* __restrict__ gidx, int32_t G,
-                                                  int32_t shift, int32_t* lds) {
+                                                  int32_t shift, int32_t* lds, int32_t g_base, int32_t g_end) {
   int32_t bad = 0;
+  const uint32_t span = (uint32_t)(g_end - g_base);
+  auto one = [&](int32_t g) {
+    if ((uint32_t)(g - g_base) < span)
+      bucket_count(lds, (g - g_base) >> shift);
+    else if ((uint32_t)g >= (uint32_t)G)
+      bad++;
+  };
   if (VEC) {
 #pragma unroll
     for (int j = 0; j < GPX_TILE_VECS; j++) {
@@ -257,35 +267,17 @@ __device__ __forceinline__ int32_t tile_histogram(int32_t n, int64_t base,
         const I4 g4 = *(const I4*)(gidx + i0);
         const int32_t gg[4] = {g4.x, g4.y, g4.z, g4.w};
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          if ((uint32_t)gg[q] < (uint32_t)G)
-            bucket_count(lds, gg[q] >> shift);
-          else
-            bad++;
-        }
+        for (int q = 0; q < 4; q++) one(gg[q]);
       } else {
-        for (int q = 0; q < 4; q++) {
-          if (i0 + q < n) {
-            const int32_t g = gidx[i0 + q];
-            if ((uint32_t)g < (uint32_t)G)
-              bucket_count(lds, g >> shift);
-            else
-              bad++;
-          }
-        }
+        for (int q = 0; q < 4; q++)
+          if (i0 + q < n) one(gidx[i0 + q]);
       }
     }
   } else {
 #pragma unroll
     for (int j = 0; j < GPX_TILE_ITEMS; j++) {
       const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
-      if (i < n) {
-        const int32_t g = gidx[i];
-        if ((uint32_t)g < (uint32_t)G)
-          bucket_count(lds, g >> shift);
-        else
-          bad++;
-      }
+      if (i < n) one(gidx[i]);
     }
   }
   return bad;
@@ -312,7 +304,7 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_hist(int32_t n, int32_t ntiles,
   const int64_t end = base + (int64_t)hsub * GPX_TILE;
   int32_t bad = 0;
   for (int sub = 0; sub < hsub; sub++)
-    bad += tile_histogram<VEC>(n, base + (int64_t)sub * GPX_TILE, gidx, G, X.shift, lds + sub * X.nbk);
+    bad += tile_histogram<VEC>(n, base + (int64_t)sub * GPX_TILE, gidx, G, X.shift, lds + sub * X.nbk, X.g_base, X.g_end);
   if (check_order == 1) {
     /* strictly ascending, in-range gidx = every group at most once: such a batch needs no
      * regrouping (k_propose_direct); anything else marks the call's epoch in *X.unsorted */

@@ -60,6 +60,13 @@ def test_config3_stream_4m_groups_vs_oracle(hip_lib, oracle_lib):
     _vote_stream_parity(hip_lib, oracle_lib, 4_000_000, 3, True, R=2)
 
 
+def test_config3_stream_5m_groups_two_range_passes_vs_oracle(hip_lib, oracle_lib):
+    """More than 4 M groups on one engine: the accept-reply call runs one pass per range of 4 M groups
+    (4096 buckets of 1024 groups), each pass skipping the other range's votes, outputs chained - the
+    decided stream must still be the oracle's, grouped by gidx ascending."""
+    _vote_stream_parity(hip_lib, oracle_lib, 5_000_000, 3, True, R=2)
+
+
 def test_vote_stream_wide_node_ids_vs_oracle(hip_lib, oracle_lib):
     """Node ids that do not fit the compact vote record (negative, > 65535, Integer.MAX_VALUE) and
     ballots other than the batch's common one: the record's escape path re-reads the caller's
