@@ -114,9 +114,11 @@ __device__ __forceinline__ void put_ac16(const DevScratch& X, int32_t* lds, int3
                                          int32_t b0c, int64_t i, int32_t g, int32_t slot, int32_t median,
                                          int32_t flags, int32_t bn, int32_t bc, int32_t* __restrict__ r_bnum,
                                          int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp,
-                                         uint8_t* __restrict__ r_flags) {
+                                         uint8_t* __restrict__ r_flags, I4* __restrict__ r_packed) {
   if ((uint32_t)g >= (uint32_t)G) {
-    if (r_bnum) {
+    if (r_packed) {
+      r_packed[i] = mk4(0, 0, 0, 0);
+    } else if (r_bnum) {
       r_bnum[i] = 0;
       r_bcoord[i] = 0;
       r_maxcp[i] = 0;
@@ -137,7 +139,8 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ac16(
     int32_t n, int32_t ntiles, int32_t G, DevScratch X, const int32_t* __restrict__ gidx,
     const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
     const int32_t* __restrict__ median_cp, const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum,
-    int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags) {
+    int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
+    I4* __restrict__ r_packed) {
   extern __shared__ int32_t lds[];
   const int32_t tile = tile_of_block(ntiles);
   if (tile >= ntiles) return;
@@ -154,16 +157,16 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ac16(
         const I4 g4 = *(const I4*)(gidx + i0), s4 = *(const I4*)(slot + i0), m4 = *(const I4*)(median_cp + i0);
         const I4 n4 = *(const I4*)(bnum + i0), c4 = *(const I4*)(bcoord + i0);
         const uint32_t f4 = flags ? *(const uint32_t*)(flags + i0) : 0u;
-        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 0, g4.x, s4.x, m4.x, (int32_t)(f4 & 0xffu), n4.x, c4.x, r_bnum, r_bcoord, r_maxcp, r_flags);
-        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 1, g4.y, s4.y, m4.y, (int32_t)((f4 >> 8) & 0xffu), n4.y, c4.y, r_bnum, r_bcoord, r_maxcp, r_flags);
-        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 2, g4.z, s4.z, m4.z, (int32_t)((f4 >> 16) & 0xffu), n4.z, c4.z, r_bnum, r_bcoord, r_maxcp, r_flags);
-        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 3, g4.w, s4.w, m4.w, (int32_t)(f4 >> 24), n4.w, c4.w, r_bnum, r_bcoord, r_maxcp, r_flags);
+        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 0, g4.x, s4.x, m4.x, (int32_t)(f4 & 0xffu), n4.x, c4.x, r_bnum, r_bcoord, r_maxcp, r_flags, r_packed);
+        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 1, g4.y, s4.y, m4.y, (int32_t)((f4 >> 8) & 0xffu), n4.y, c4.y, r_bnum, r_bcoord, r_maxcp, r_flags, r_packed);
+        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 2, g4.z, s4.z, m4.z, (int32_t)((f4 >> 16) & 0xffu), n4.z, c4.z, r_bnum, r_bcoord, r_maxcp, r_flags, r_packed);
+        put_ac16(X, lds, G, mask, b0n, b0c, i0 + 3, g4.w, s4.w, m4.w, (int32_t)(f4 >> 24), n4.w, c4.w, r_bnum, r_bcoord, r_maxcp, r_flags, r_packed);
       } else {
         for (int q = 0; q < 4; q++) {
           const int64_t i = i0 + q;
           if (i < n)
             put_ac16(X, lds, G, mask, b0n, b0c, i, gidx[i], slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0,
-                     bnum[i], bcoord[i], r_bnum, r_bcoord, r_maxcp, r_flags);
+                     bnum[i], bcoord[i], r_bnum, r_bcoord, r_maxcp, r_flags, r_packed);
         }
       }
     }
@@ -173,7 +176,7 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ac16(
       const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
       if (i < n)
         put_ac16(X, lds, G, mask, b0n, b0c, i, gidx[i], slot[i], median_cp[i], flags ? (int32_t)flags[i] : 0,
-                 bnum[i], bcoord[i], r_bnum, r_bcoord, r_maxcp, r_flags);
+                 bnum[i], bcoord[i], r_bnum, r_bcoord, r_maxcp, r_flags, r_packed);
     }
   }
 }
@@ -335,6 +338,7 @@ __device__ __forceinline__ unsigned long long arrival_order(const int32_t* idxA,
 struct AcceptOut {
   int32_t *r_bnum, *r_bcoord, *r_maxcp;
   uint8_t* r_flags;
+  I4* r_packed; /* [n] scratch rows: set for the partition path (records at random arrival indices) */
 };
 #define B16_AR 0     /* accept replies at the coordinator */
 #define B16_ACCEPT 1 /* ACCEPTs at an acceptor */
@@ -456,7 +460,7 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
     if (OP == B16_AR)
       apply_ar_group<KMAX>(S, X, g, it, status, P);
     else if (OP == B16_ACCEPT)
-      apply_accept_group(S, X, g, it, R.r_bnum, R.r_bcoord, R.r_maxcp, R.r_flags, status);
+      apply_accept_group(S, X, g, it, R.r_bnum, R.r_bcoord, R.r_maxcp, R.r_flags, status, R.r_packed);
     else
       apply_commit_group(S, X, g, it, status);
   };
@@ -584,4 +588,21 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_runs16(DevScratch X, Stage16
     x_first[out0 + t] = O.slot[src + t];
     x_count[out0 + t] = O.median[src + t];
   }
+}
+
+/* packed ACCEPT_REPLY rows -> the caller's four columns (streaming; the partition path of an
+ * unordered ACCEPT batch wrote one 16-byte row per record at its arrival index) */
+__global__ __launch_bounds__(GPX_BLOCK) void k_unpack_replies(DevScratch X, int32_t n, const I4* __restrict__ rows,
+                                                             int32_t* __restrict__ r_bnum,
+                                                             int32_t* __restrict__ r_bcoord,
+                                                             int32_t* __restrict__ r_maxcp,
+                                                             uint8_t* __restrict__ r_flags) {
+  if (*X.unsorted != X.epoch) return; /* ordered batch: k_ac_direct wrote the columns itself */
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  if (i >= n) return;
+  const I4 r = rows[i];
+  r_bnum[i] = r.x;
+  r_bcoord[i] = r.y;
+  r_maxcp[i] = r.z;
+  r_flags[i] = (uint8_t)r.w;
 }

@@ -119,6 +119,7 @@ struct gpx_engine {
   int32_t ar_passes = 1, shift16 = 0, nbk16 = 0;
   bool ac16 = false;          /* ACCEPT / COMMIT partition path on 16-byte records too (single pass only) */
   int32_t* ar_chain = nullptr; /* [2] running output count between passes */
+  I4* reply_rows = nullptr;    /* [max_batch] packed ACCEPT_REPLY rows of the partition path (first use) */
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
   /* wire codec (gpx_wire_host.inc): paxosID table, row free list, scratch - allocated on first use */
   DevNames N{};
@@ -965,6 +966,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
            e->S.G, e->X, status, D.chunk_cnt, nchunks);
   const bool promised = (e->ordered_mask & GPX_ORDERED_ACCEPT) != 0;
   const size_t Nmax = (size_t)e->cfg.max_batch;
+  if (!promised && e->ac16 && !e->reply_rows && (rc = dev_alloc(e, &e->reply_rows, Nmax, false)) != GPX_OK) return rc;
   const Stage16 O16{st32, st32 + Nmax, st32 + 2 * Nmax, st32 + 3 * Nmax, st32 + 4 * Nmax, (uint8_t*)(st32 + 5 * Nmax)};
   if (!promised) {
     front_hist(e, n, gidx, status, 0, 2);
@@ -972,10 +974,12 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
       const int ntiles = ntiles_for(n);
       if (aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)a_flags & 3))
         LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
-                 e->X, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+                 e->X, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags,
+                 e->reply_rows);
       else
         LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
-                 e->X, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags);
+                 e->X, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags,
+                 e->reply_rows);
     } else {
       launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, 1);
     }
@@ -996,7 +1000,9 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     /* unordered batch: 16-byte records through the partition (gpx_ar16.hip.h); the back end may
      * re-read bnum / bcoord of records in another ballot than the batch's first */
     LAUNCH_B(e, "k_bucket_accept16", (k_bucket16<B16_ACCEPT, 4>), e->S, e->X, O16, VoteCols{bnum, bcoord, nullptr},
-             AcceptOut{r_bnum, r_bcoord, r_maxcp, r_flags}, status);
+             AcceptOut{r_bnum, r_bcoord, r_maxcp, r_flags, e->reply_rows}, status);
+    LAUNCH(e, "k_unpack_replies", k_unpack_replies, grid_for(n), e->X, n, (const I4*)e->reply_rows, r_bnum, r_bcoord,
+           r_maxcp, r_flags);
     LAUNCH(e, "k_emit_runs16", k_emit_runs16, e->X.nbk, e->X, O16, x_gidx, x_first, x_count, n_runs);
   } else if (!promised) {
     LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags, status);
@@ -1038,11 +1044,11 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
       if (aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)c_kind & 3))
         LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
                  e->X, gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
-                 (int32_t*)nullptr, (uint8_t*)nullptr);
+                 (int32_t*)nullptr, (uint8_t*)nullptr, (I4*)nullptr);
       else
         LAUNCH_F(e, "k_scatter_ac16", k_scatter_ac16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G,
                  e->X, gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
-                 (int32_t*)nullptr, (uint8_t*)nullptr);
+                 (int32_t*)nullptr, (uint8_t*)nullptr, (I4*)nullptr);
     } else {
       launch_scatter_ac(e, n, gidx, bnum, bcoord, slot, median_cp, c_kind, nullptr, nullptr, nullptr, nullptr, 1);
     }

@@ -1264,11 +1264,27 @@ __device__ __forceinline__ void acc_store(const DevState& S, int32_t g, uint32_t
 }
 
 /* PaxosInstanceStateMachine.handleAccept (PISM:1080-1166) */
+/* the ACCEPT_REPLY of record ix: four dense columns - or, when r_packed is set, ONE 16-byte row
+ * {bnum, bcoord, maxcp, flags} (k_unpack_replies turns the rows into the columns afterwards): in an
+ * unordered batch ix is a random position and four 4-byte stores per record cost four random accesses */
+__device__ __forceinline__ void put_reply(int32_t ix, int32_t bn, int32_t bc, int32_t mcp, int32_t fl,
+                                          int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
+                                          int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
+                                          I4* __restrict__ r_packed) {
+  if (r_packed) {
+    r_packed[ix] = mk4(bn, bc, mcp, fl);
+  } else {
+    r_bnum[ix] = bn;
+    r_bcoord[ix] = bc;
+    r_maxcp[ix] = mcp;
+    r_flags[ix] = (uint8_t)fl;
+  }
+}
 template <class IT>
 __device__ __forceinline__ void apply_accept_group(
     const DevState& S, const DevScratch& X, int32_t g, IT& it, int32_t* __restrict__ r_bnum,
     int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
-    uint8_t* __restrict__ status) {
+    uint8_t* __restrict__ status, I4* __restrict__ r_packed = nullptr) {
   const uint32_t gf = S.g_flags[g];
   AccState a;
   a.slot = a.bnum = a.bcoord = a.gc = 0;
@@ -1283,10 +1299,7 @@ __device__ __forceinline__ void apply_accept_group(
     const int32_t slot = r.a, median = r.b, ix = r.idx;
     const bool stop = (r.c & GPX_A_STOP) != 0;
     if (!exists || a.stopped) {
-      r_bnum[ix] = 0;
-      r_bcoord[ix] = 0;
-      r_maxcp[ix] = 0;
-      r_flags[ix] = 0;
+      put_reply(ix, 0, 0, 0, 0, r_bnum, r_bcoord, r_maxcp, r_flags, r_packed);
       status[ix] = exists ? GPX_S_STOPPED : GPX_S_NOGROUP;
       n_drop++;
       continue;
@@ -1301,10 +1314,7 @@ __device__ __forceinline__ void apply_accept_group(
     const bool ballot_ok = ballot_cmp(r.bnum, r.bcoord, a.bnum, a.bcoord) >= 0;
     const bool will_store = ballot_ok && jsub(slot, a.gc) > 0;
     if (will_store && live && ar.x != slot) {
-      r_bnum[ix] = 0;
-      r_bcoord[ix] = 0;
-      r_maxcp[ix] = 0;
-      r_flags[ix] = 0;
+      put_reply(ix, 0, 0, 0, 0, r_bnum, r_bcoord, r_maxcp, r_flags, r_packed);
       status[ix] = GPX_S_WINDOW; /* ring slot held by another live accepted slot */
       n_drop++;
       continue;
@@ -1319,14 +1329,13 @@ __device__ __forceinline__ void apply_accept_group(
     }
     acc_gc(S, g, a, median);
     /* reply (myID, ballot, slot, getSlot()-1)  (:1139-1143) */
-    r_bnum[ix] = a.bnum;
-    r_bcoord[ix] = a.bcoord;
-    r_maxcp[ix] = jsub(a.slot, 1);
+    const int32_t rep_bnum = a.bnum, rep_bcoord = a.bcoord, rep_maxcp = jsub(a.slot, 1);
     /* toLog (:1146-1149) */
     const bool to_log = ballot_cmp(r.bnum, r.bcoord, a.bnum, a.bcoord) >= 0 &&
                         jsub(slot, a.gc) > 0 &&
                         (!have_prev || ballot_cmp(ar.y, ar.z, r.bnum, r.bcoord) < 0);
-    r_flags[ix] = (uint8_t)((to_log ? GPX_R_TOLOG : 0) | (will_store ? GPX_R_STORED : 0));
+    put_reply(ix, rep_bnum, rep_bcoord, rep_maxcp, (to_log ? GPX_R_TOLOG : 0) | (will_store ? GPX_R_STORED : 0),
+              r_bnum, r_bcoord, r_maxcp, r_flags, r_packed);
     /* status[ix] stays GPX_S_OK (prefilled by k_hist) */
     /* might release some meta-commits (:1158-1161) */
     Dec rd = Dec{0, 0, 0, 0, false, false};

@@ -6,7 +6,8 @@ REPO=$(pwd)
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-BENCH="python $REPO/bench.py --steps 4 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-end-to-end"
+# GPX_PMC_CMD: another command to count (e.g. "python $REPO/scripts/bench_wire.py --rounds 3")
+BENCH=${GPX_PMC_CMD:-"python $REPO/bench.py --steps 4 --warmup 1 --profile-steps 0 --no-cpu-baseline --no-end-to-end"}
 cd /tmp
 i=0
 while read -r group; do
