@@ -213,7 +213,10 @@ def main():
         traffic = traffic_raw = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            cands = [(int(k.split("@")[1]), v) for k, v in pmc.items() if k.split("@")[0].split("<")[0] == dom_name]
+            # the engine's profile labels name the launch (k_bucket_ar16), rocprofv3 the kernel (k_bucket16<0, 4>)
+            alias = {"k_bucket_ar16": "k_bucket16", "k_bucket_accept16": "k_bucket16", "k_bucket_commit16": "k_bucket16"}
+            kname = alias.get(dom_name, dom_name)
+            cands = [(int(k.split("@")[1]), v) for k, v in pmc.items() if k.split("@")[0].split("<")[0] == kname]
             if cands and G == 1_000_000 and K == 3 and not args.mix and not args.sorted:
                 _, v = max(cands, key=lambda kv: kv[0])
                 traffic, traffic_raw = int(v["hbm_bytes_corrected"]), int(v["hbm_bytes_raw"])

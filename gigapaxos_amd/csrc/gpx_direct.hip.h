@@ -35,6 +35,7 @@ struct RunIter {
   const uint8_t* flags;
   DirectStage D;
   int32_t n, i, g, cur, chunk, local;
+  bool count_chunks = true; /* k_ac_direct counts runs per chunk; the single-launch kernel reads the parking */
   __device__ __forceinline__ bool next(Rec& out) {
     if (i >= n || gidx[i] != g) return false;
     cur = i;
@@ -51,6 +52,7 @@ struct RunIter {
   __device__ __forceinline__ void emit(int32_t, int32_t first, int32_t count, int32_t, int32_t) {
     D.st_first[cur] = first;
     D.st_count[cur] = count; /* > 0 */
+    if (!count_chunks) return;
     if ((cur >> GPX_DCHUNK_SHIFT) == chunk)
       local++;
     else
@@ -145,4 +147,108 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, i
     x_count[pre + ex] = cnt;
   }
   if (w == (int32_t)gridDim.x - 1 && threadIdx.x == 0 && total_out) *total_out = pre + tot;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* Small ordered batches in ONE launch.  A batch of at most 65,536 records is L2-resident: every
+ * workgroup reads the whole gidx column itself to judge the order (so no k_order_check launch), applies
+ * its 1024-record chunk like k_ac_direct / k_propose_direct, and places its execution runs behind those
+ * of the chunks before it with a ticket per workgroup (so no k_emit_runs_direct launch either): the
+ * workgroups before it were dispatched earlier, they are running or done - no deadlock.  BASELINE
+ * config #2's round (10 k groups: every kernel sits on the launch floor) goes from 24 launches to 12.
+ * The verdict "not ordered" is published in *X.unsorted for the partition path launched behind it (or,
+ * under the GPX_ORDERED_* promise, the batch is refused whole). */
+#define GPX_SMALL_DIRECT_MAX_N 65536
+
+template <bool COMMIT>
+__global__ __launch_bounds__(GPX_DCHUNK) void k_ac_small(
+    DevState S, DevScratch X, int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
+    const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot, const int32_t* __restrict__ median,
+    const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
+    int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status, DirectStage D,
+    int32_t* __restrict__ x_gidx, int32_t* __restrict__ x_first, int32_t* __restrict__ x_count,
+    int32_t* __restrict__ n_runs, unsigned long long* __restrict__ tickets, uint32_t epoch, int32_t refuse) {
+  __shared__ int32_t s_before;
+  const int32_t w = (int32_t)blockIdx.x;
+  const int32_t i = w * GPX_DCHUNK + (int32_t)threadIdx.x;
+  const bool ordered = small_batch_ordered<false>(n, gidx, S.G);
+  if (!ordered) {
+    if (w == 0 && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
+    if (i < n) {
+      if (refuse) {
+        if (!COMMIT) {
+          r_bnum[i] = 0;
+          r_bcoord[i] = 0;
+          r_maxcp[i] = 0;
+          r_flags[i] = 0;
+        }
+        status[i] = GPX_S_UNORDERED;
+      } else {
+        status[i] = (uint32_t)gidx[i] < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
+      }
+    }
+    if (refuse && w == 0 && threadIdx.x == 0 && n_runs) *n_runs = 0;
+    return;
+  }
+  int32_t have = 0, first = 0, count = 0;
+  if (i < n) {
+    status[i] = GPX_S_OK;
+    const int32_t g = gidx[i];
+    if (i == 0 || gidx[i - 1] != g) { /* head of its group's run: replays the run in array order */
+      RunIter it;
+      it.gidx = gidx;
+      it.bnum = bnum;
+      it.bcoord = bcoord;
+      it.slot = slot;
+      it.median = median;
+      it.flags = flags;
+      it.D = D;
+      it.n = n;
+      it.i = i;
+      it.g = g;
+      it.cur = i;
+      it.chunk = -1; /* every run is parked at its record and counted below */
+      it.local = 0;
+      it.count_chunks = false;
+      if (COMMIT)
+        apply_commit_group(S, X, g, it, status);
+      else
+        apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+    }
+  }
+  /* the runs parked at THIS chunk's records (by this workgroup's heads, or by a head of an earlier
+   * chunk whose run reaches in here: it parked them before it published its ticket, and this
+   * workgroup reads the parking only after it has seen that ticket) */
+  if (threadIdx.x == 0) s_before = 0;
+  __syncthreads();
+  int32_t before = 0;
+  for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) {
+    unsigned long long v;
+    do {
+      v = __hip_atomic_load(&tickets[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((uint32_t)(v >> 32) != epoch);
+    before += (int32_t)(uint32_t)v;
+  }
+  if (before) atomicAdd(&s_before, before);
+  __syncthreads();
+  if (i < n) {
+    count = __hip_atomic_load(&D.st_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    have = count != 0;
+    first = have ? D.st_first[i] : 0;
+  }
+  int32_t tot;
+  const int32_t ex = block_exscan_n<GPX_DCHUNK>(have, &tot);
+  /* my ticket = runs parked in my chunk; it may only be published when every head that can still
+   * park a run in THIS chunk is done: those are heads of this or earlier chunks - earlier chunks have
+   * published (seen above), this chunk's heads finished before the barrier */
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&tickets[w], ((unsigned long long)epoch << 32) | (uint32_t)tot, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  const int32_t base = s_before;
+  if (have) {
+    x_gidx[base + ex] = gidx[i];
+    x_first[base + ex] = first;
+    x_count[base + ex] = count;
+  }
+  if (w == (int32_t)gridDim.x - 1 && threadIdx.x == 0 && n_runs) *n_runs = base + tot;
 }

@@ -962,14 +962,30 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec; /* the two paths never both stage outputs: shared scratch */
   const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt};
-  LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
-           e->S.G, e->X, status, D.chunk_cnt, nchunks);
+  /* at most 65,536 records on one stream: order check, direct application and run compaction in ONE
+   * launch (k_ac_small: tickets instead of chunk counters) */
+  const bool fused = n <= GPX_SMALL_DIRECT_MAX_N && !e->pipeline;
   const bool promised = (e->ordered_mask & GPX_ORDERED_ACCEPT) != 0;
+  if (!fused)
+    LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
+              e->S.G, e->X, status, D.chunk_cnt, nchunks);
+  /* fused: FIRST in the stream - the partition path launched behind it reads its verdict */
+  if (fused) {
+    if (++e->small_epoch == 0) {
+      HIPQ(hipMemsetAsync(e->small_tickets, 0, GPX_SMALL_MAX_WG * sizeof(unsigned long long), e->stream));
+      e->small_epoch = 1;
+    }
+    LaunchScope _ls(e, "k_ac_small");
+    hipLaunchKernelGGL(k_ac_small<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
+                       bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, x_gidx,
+                       x_first, x_count, n_runs, e->small_tickets, e->small_epoch, promised ? 1 : 0);
+  }
+
   const size_t Nmax = (size_t)e->cfg.max_batch;
   if (!promised && e->ac16 && !e->reply_rows && (rc = dev_alloc(e, &e->reply_rows, Nmax, false)) != GPX_OK) return rc;
   const Stage16 O16{st32, st32 + Nmax, st32 + 2 * Nmax, st32 + 3 * Nmax, st32 + 4 * Nmax, (uint8_t*)(st32 + 5 * Nmax)};
   if (!promised) {
-    front_hist(e, n, gidx, status, 0, 2);
+    front_hist(e, n, gidx, fused ? nullptr : status, 0, 2);
     if (e->ac16) {
       const int ntiles = ntiles_for(n);
       if (aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)a_flags & 3))
@@ -985,16 +1001,18 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     }
   }
   begin_back(e, fs, n, e->ac16);
-  {
-    LaunchScope _ls(e, "k_ac_direct");
-    hipLaunchKernelGGL(k_ac_direct<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
-                       bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D,
-                       promised ? 1 : 0);
-  }
-  {
-    LaunchScope _ls(e, "k_emit_runs_direct");
-    hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
-                       x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
+  if (!fused) {
+    {
+      LaunchScope _ls(e, "k_ac_direct");
+      hipLaunchKernelGGL(k_ac_direct<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
+                         bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D,
+                         promised ? 1 : 0);
+    }
+    {
+      LaunchScope _ls(e, "k_emit_runs_direct");
+      hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
+                         x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
+    }
   }
   if (!promised && e->ac16) {
     /* unordered batch: 16-byte records through the partition (gpx_ar16.hip.h); the back end may
@@ -1032,13 +1050,27 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec;
   const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt};
-  LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
-           e->S.G, e->X, status, D.chunk_cnt, nchunks);
+  const bool fused = n <= GPX_SMALL_DIRECT_MAX_N && !e->pipeline; /* one launch: k_ac_small */
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
+  if (!fused)
+    LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
+              e->S.G, e->X, status, D.chunk_cnt, nchunks);
+  if (fused) {
+    if (++e->small_epoch == 0) {
+      HIPQ(hipMemsetAsync(e->small_tickets, 0, GPX_SMALL_MAX_WG * sizeof(unsigned long long), e->stream));
+      e->small_epoch = 1;
+    }
+    LaunchScope _ls(e, "k_ac_small");
+    hipLaunchKernelGGL(k_ac_small<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
+                       bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                       (uint8_t*)nullptr, status, D, x_gidx, x_first, x_count, n_runs, e->small_tickets,
+                       e->small_epoch, promised ? 1 : 0);
+  }
+
   const size_t Nmax = (size_t)e->cfg.max_batch;
   const Stage16 O16{st32, st32 + Nmax, st32 + 2 * Nmax, st32 + 3 * Nmax, st32 + 4 * Nmax, (uint8_t*)(st32 + 5 * Nmax)};
   if (!promised) {
-    front_hist(e, n, gidx, status, 0, 2);
+    front_hist(e, n, gidx, fused ? nullptr : status, 0, 2);
     if (e->ac16) {
       const int ntiles = ntiles_for(n);
       if (aligned16({gidx, bnum, bcoord, slot, median_cp}) && !((uintptr_t)c_kind & 3))
@@ -1054,16 +1086,18 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     }
   }
   begin_back(e, fs, n, e->ac16);
-  {
-    LaunchScope _ls(e, "k_ac_direct");
-    hipLaunchKernelGGL(k_ac_direct<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
-                       bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
-                       (int32_t*)nullptr, (uint8_t*)nullptr, status, D, promised ? 1 : 0);
-  }
-  {
-    LaunchScope _ls(e, "k_emit_runs_direct");
-    hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
-                       x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
+  if (!fused) {
+    {
+      LaunchScope _ls(e, "k_ac_direct");
+      hipLaunchKernelGGL(k_ac_direct<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
+                         bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
+                         (int32_t*)nullptr, (uint8_t*)nullptr, status, D, promised ? 1 : 0);
+    }
+    {
+      LaunchScope _ls(e, "k_emit_runs_direct");
+      hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
+                         x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
+    }
   }
   if (!promised && e->ac16) {
     LAUNCH_B(e, "k_bucket_commit16", (k_bucket16<B16_COMMIT, 4>), e->S, e->X, O16, VoteCols{bnum, bcoord, nullptr},
@@ -1089,14 +1123,29 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   const size_t b4 = (size_t)n * 4;
   const int fs = begin_front(e, {{gidx, b4}, {is_stop, (size_t)n}, {handle, b4 * 2}, {slot, b4}, {bnum, b4},
                                  {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
-  /* order check + status prefill (one pass over gidx); the partition front end only does work for a
-   * batch that is NOT strictly ascending */
-  LAUNCH_OC(e, "k_order_check", k_order_check<true>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
-           e->S.G, e->X, status, (int32_t*)nullptr, 0);
   const bool promised = (e->ordered_mask & GPX_ORDERED_PROPOSE) != 0;
   const int32_t refuse = promised ? 1 : 0;
+  /* at most 65,536 requests on one stream: order check and direct application in one launch */
+  const bool fused = n <= GPX_SMALL_DIRECT_MAX_N && !e->pipeline;
+  if (fused) {
+    e->stream = e->sB;
+    if (e->cfg.kmax <= 4)
+      LAUNCH(e, "k_propose_small", k_propose_small<4>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot, bnum, bcoord,
+             median_cp, status, handle, refuse);
+    else if (e->cfg.kmax <= 8)
+      LAUNCH(e, "k_propose_small", k_propose_small<8>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot, bnum, bcoord,
+             median_cp, status, handle, refuse);
+    else
+      LAUNCH(e, "k_propose_small", k_propose_small<16>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot, bnum, bcoord,
+             median_cp, status, handle, refuse);
+  }
+  /* order check + status prefill (one pass over gidx); the partition front end only does work for a
+   * batch that is NOT strictly ascending */
+  if (!fused)
+  LAUNCH_OC(e, "k_order_check", k_order_check<true>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
+           e->S.G, e->X, status, (int32_t*)nullptr, 0);
   if (!promised) {
-    front_hist(e, n, gidx, status, 0, 2);
+    front_hist(e, n, gidx, fused ? nullptr : status, 0, 2);
     const int ntiles = ntiles_for(n);
     LAUNCH_F(e, "k_scatter_pr", k_scatter_pr, tile_grid(ntiles), (size_t)e->X.nbk * 4, n, ntiles, e->S.G, e->X,
              gidx, is_stop, slot, bnum, bcoord, median_cp);
@@ -1106,16 +1155,19 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
    * k_order_check): strictly ascending batch -> k_propose_direct, anything else -> k_bucket_propose;
    * under the GPX_ORDERED_PROPOSE promise only the direct one exists and the other case is refused */
   if (e->cfg.kmax <= 4) {
-    LAUNCH(e, "k_propose_direct", k_propose_direct<4>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
-           bnum, bcoord, median_cp, status, handle, refuse);
+    if (!fused)
+      LAUNCH(e, "k_propose_direct", k_propose_direct<4>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
+             bnum, bcoord, median_cp, status, handle, refuse);
     if (!promised) launch_bucket_propose<4>(e, slot, bnum, bcoord, median_cp, status, handle);
   } else if (e->cfg.kmax <= 8) {
-    LAUNCH(e, "k_propose_direct", k_propose_direct<8>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
-           bnum, bcoord, median_cp, status, handle, refuse);
+    if (!fused)
+      LAUNCH(e, "k_propose_direct", k_propose_direct<8>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
+             bnum, bcoord, median_cp, status, handle, refuse);
     if (!promised) launch_bucket_propose<8>(e, slot, bnum, bcoord, median_cp, status, handle);
   } else {
-    LAUNCH(e, "k_propose_direct", k_propose_direct<16>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
-           bnum, bcoord, median_cp, status, handle, refuse);
+    if (!fused)
+      LAUNCH(e, "k_propose_direct", k_propose_direct<16>, grid_for(n), e->S, e->X, n, gidx, is_stop, slot,
+             bnum, bcoord, median_cp, status, handle, refuse);
     if (!promised) launch_bucket_propose<16>(e, slot, bnum, bcoord, median_cp, status, handle);
   }
   end_call(e, fs, {{slot, b4}, {bnum, b4}, {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});

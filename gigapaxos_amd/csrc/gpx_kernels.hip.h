@@ -1685,6 +1685,64 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_direct(
   apply_propose_group<KMAX, OneRec>(S, X, g, it, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
 }
 
+/* Proposal batch of at most 65,536 requests in ONE launch: every workgroup judges the order of the whole
+ * (L2-resident) gidx column itself, then applies its records like k_propose_direct - no k_order_check
+ * launch.  Not strictly ascending: *X.unsorted is raised for the partition path launched behind it, or
+ * (GPX_ORDERED_PROPOSE promise) the batch is refused whole. */
+/* is the whole gidx column in range and ascending?  Every lane of every workgroup ends up with the same
+ * verdict (the column is read by all of them: at most 256 KB, L2-resident) */
+template <bool STRICT>
+__device__ __forceinline__ bool small_batch_ordered(int32_t n, const int32_t* __restrict__ gidx, int32_t G) {
+  bool bad = false;
+  for (int32_t i0 = (int32_t)threadIdx.x * 4; i0 < n; i0 += (int32_t)blockDim.x * 4) {
+    int32_t g[5];
+#pragma unroll
+    for (int q = 0; q < 5; q++) g[q] = i0 + q < n ? gidx[i0 + q] : INT32_MAX;
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (i0 + q < n)
+        bad |= (uint32_t)g[q] >= (uint32_t)G || (i0 + q + 1 < n && (STRICT ? g[q] >= g[q + 1] : g[q] > g[q + 1]));
+  }
+  return !__syncthreads_or(bad);
+}
+
+template <int KMAX>
+__global__ __launch_bounds__(GPX_BLOCK) void k_propose_small(
+    DevState S, DevScratch X, int32_t n, const int32_t* __restrict__ gidx,
+    const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
+    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
+    const int64_t* __restrict__ handle, int32_t refuse) {
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  const bool ordered = small_batch_ordered<true>(n, gidx, S.G);
+  if (!ordered) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
+    if (i < n) {
+      if (refuse) {
+        o_slot[i] = 0;
+        o_bnum[i] = 0;
+        o_bcoord[i] = 0;
+        o_median[i] = 0;
+        status[i] = GPX_S_UNORDERED;
+      } else {
+        status[i] = (uint32_t)gidx[i] < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
+      }
+    }
+    return;
+  }
+  if (i >= n) return;
+  status[i] = GPX_S_OK;
+  const int32_t g = gidx[i];
+  ProposePre<KMAX> P;
+  propose_preload<KMAX>(S, g, P);
+  propose_preload_ring<KMAX>(S, g, P);
+  OneRec it;
+  it.idx = i;
+  it.a = is_stop ? (int32_t)(is_stop[i] & 1) : 0;
+  it.c = 1;
+  it.done = 0;
+  apply_propose_group<KMAX, OneRec>(S, X, g, it, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
+}
+
 /* ------------------------------------------------------------------------- */
 /* view change, acceptor side                                                   */
 /* PISM.handlePrepare (PISM:900-1006) -> PaxosAcceptor.handlePrepare (PaxosAcceptor.java:239-273).
