@@ -36,6 +36,9 @@ struct RunIter {
   DirectStage D;
   int32_t n, i, g, cur, chunk, local;
   bool count_chunks = true; /* k_ac_direct counts runs per chunk; the single-launch kernel reads the parking */
+  uint8_t* st = nullptr;    /* single-launch kernel: no status prefill pass ran - the lane that replays a
+                             * record marks it OK before it judges it (a prefill by the record's own lane
+                             * would race with the head's verdict, across waves and across workgroups) */
   __device__ __forceinline__ bool next(Rec& out) {
     if (i >= n || gidx[i] != g) return false;
     cur = i;
@@ -46,6 +49,7 @@ struct RunIter {
     out.bnum = bnum[i];
     out.bcoord = bcoord[i];
     D.st_count[i] = 0;
+    if (st) st[i] = GPX_S_OK;
     i++;
     return true;
   }
@@ -192,7 +196,6 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_small(
   }
   int32_t have = 0, first = 0, count = 0;
   if (i < n) {
-    status[i] = GPX_S_OK;
     const int32_t g = gidx[i];
     if (i == 0 || gidx[i - 1] != g) { /* head of its group's run: replays the run in array order */
       RunIter it;
@@ -210,17 +213,40 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_small(
       it.chunk = -1; /* every run is parked at its record and counted below */
       it.local = 0;
       it.count_chunks = false;
+      it.st = status;
       if (COMMIT)
         apply_commit_group(S, X, g, it, status);
       else
         apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
     }
   }
-  /* the runs parked at THIS chunk's records (by this workgroup's heads, or by a head of an earlier
-   * chunk whose run reaches in here: it parked them before it published its ticket, and this
-   * workgroup reads the parking only after it has seen that ticket) */
+  /* the runs parked at THIS chunk's records: by this workgroup's heads, or by a head of an earlier
+   * chunk whose run reaches in here.  Two rounds of flags, neither a chain: (1) "my heads are done"
+   * (depends on nothing), (2) "runs parked in my chunk" (depends on round 1 of the chunks before
+   * me).  A workgroup waits for ALL earlier flags of a round, never for a flag that itself waits on
+   * the same round - so the depth is 2 global round trips whatever the number of chunks. */
+  unsigned long long* const done = tickets + GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK;
   if (threadIdx.x == 0) s_before = 0;
-  __syncthreads();
+  __syncthreads(); /* this chunk's heads have parked */
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&done[w], (unsigned long long)epoch << 32, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) {
+    unsigned long long v;
+    do {
+      v = __hip_atomic_load(&done[t], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((uint32_t)(v >> 32) != epoch);
+  }
+  __syncthreads(); /* every head that can park a run in this chunk has */
+  if (i < n) {
+    count = __hip_atomic_load(&D.st_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    have = count != 0;
+    first = have ? D.st_first[i] : 0;
+  }
+  int32_t tot;
+  const int32_t ex = block_exscan_n<GPX_DCHUNK>(have, &tot);
+  if (threadIdx.x == 0)
+    __hip_atomic_store(&tickets[w], ((unsigned long long)epoch << 32) | (uint32_t)tot, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
   int32_t before = 0;
   for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) {
     unsigned long long v;
@@ -231,19 +257,6 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_small(
   }
   if (before) atomicAdd(&s_before, before);
   __syncthreads();
-  if (i < n) {
-    count = __hip_atomic_load(&D.st_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    have = count != 0;
-    first = have ? D.st_first[i] : 0;
-  }
-  int32_t tot;
-  const int32_t ex = block_exscan_n<GPX_DCHUNK>(have, &tot);
-  /* my ticket = runs parked in my chunk; it may only be published when every head that can still
-   * park a run in THIS chunk is done: those are heads of this or earlier chunks - earlier chunks have
-   * published (seen above), this chunk's heads finished before the barrier */
-  if (threadIdx.x == 0)
-    __hip_atomic_store(&tickets[w], ((unsigned long long)epoch << 32) | (uint32_t)tot, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_AGENT);
   const int32_t base = s_before;
   if (have) {
     x_gidx[base + ex] = gidx[i];

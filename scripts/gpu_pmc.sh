@@ -25,4 +25,4 @@ GRBM_GUI_ACTIVE GRBM_TA_BUSY
 GROUPS
 cd "$REPO"
 python scripts/pmc_table.py "$OUT/pmc_table.txt" $(find "$OUT" -name '*_results.db' | sort) | head -150
-find "$OUT" -name '*.db' -size +8M -delete
+find "$OUT" \( -name '*.db' -o -name '*.csv' -size +256k \) -delete

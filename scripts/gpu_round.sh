@@ -53,5 +53,5 @@ fi
 KTP=$(find "$OUT/prof_kt_pipe" -name '*_results.db' | head -1)
 [ -n "$KTP" ] && python scripts/rocprof_summary.py "$KTP" "$KTP" "$KTP" "$OUT/rocprof_summary_pipelined.txt" /dev/null | head -12
 # keep the merge-back small: drop the raw databases, keep csv/txt/json
-find "$OUT" -name '*.db' -size +8M -delete
+find "$OUT" \( -name '*.db' -o -name '*.csv' -size +256k \) -delete
 du -sh "$OUT"

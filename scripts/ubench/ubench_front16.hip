@@ -111,9 +111,77 @@ __global__ __launch_bounds__(NT) void k_scatter16(int n, int ntiles, int shift, 
       v.meta = (uint32_t)(gg[q] & mask) | ((aa[q] != 0 || bb[q] != 100) ? 0x4000u : ((uint32_t)dd[q] << 16)); out[p] = v; }
   }
 }
+
+// ---- C: sort the tile by bucket in LDS, write each bucket's run of votes as one contiguous piece -----------
+// k_hist_tot: bucket totals only (no per-tile matrix); k_scatter_sorted<T>: LDS counting sort of T votes, space for
+// the tile's run in each bucket claimed with one returning atomic per non-empty (tile, bucket), lanes write the
+// sorted tile in order (neighbouring lanes -> neighbouring 16-byte words of one run)
+__global__ __launch_bounds__(NT) void k_hist_tot(int n, int ntiles, const int* __restrict__ gidx, int shift, int nbk, int hsub, int* btot) {
+  extern __shared__ int lds[];
+  const int nsuper = (ntiles + hsub - 1) / hsub; const int st = tile_of_block(nsuper); if (st >= nsuper) return;
+  for (int b = threadIdx.x; b < nbk; b += NT) lds[b] = 0;
+  __syncthreads();
+  for (int sub = 0; sub < hsub; sub++) { const long i0 = ((long)(st * hsub + sub) * TILE) + threadIdx.x * 4;
+    if (i0 + 3 < n) { const I4 g = *(const I4*)(gidx + i0); atomicAdd(&lds[g.x >> shift], 1); atomicAdd(&lds[g.y >> shift], 1); atomicAdd(&lds[g.z >> shift], 1); atomicAdd(&lds[g.w >> shift], 1); }
+    else for (int q = 0; q < 4; q++) if (i0 + q < n) atomicAdd(&lds[gidx[i0 + q] >> shift], 1); }
+  __syncthreads();
+  for (int b = threadIdx.x; b < nbk; b += NT) if (lds[b]) atomicAdd(&btot[b], lds[b]);
+}
+template <int T>
+__global__ __launch_bounds__(NT) void k_scatter_sorted(int n, int shift, int nbk, const int* __restrict__ boff, int* __restrict__ cursor,
+    const int* __restrict__ gidx, const int* __restrict__ c1, const int* __restrict__ c2, const int* __restrict__ c3,
+    const int* __restrict__ c4, const int* __restrict__ c5, V16* out) {
+  extern __shared__ int lds[];
+  constexpr int R4 = T / (NT * 4);
+  int* cnt = lds;                       // [nbk] count -> local base -> (global - local) delta
+  V16* recs = (V16*)(lds + ((nbk + 3) & ~3));
+  const int ntl = (n + T - 1) / T; const int tile = tile_of_block(ntl); if (tile >= ntl) return;
+  for (int b = threadIdx.x; b < nbk; b += NT) cnt[b] = 0;
+  __syncthreads();
+  int rk[R4 * 4], bb[R4 * 4];
+#pragma unroll
+  for (int k = 0; k < R4; k++) { const long i0 = (long)tile * T + (k * NT + threadIdx.x) * 4;
+    if (i0 + 3 < n) { const I4 g = *(const I4*)(gidx + i0); const int gg[4] = {g.x, g.y, g.z, g.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) { bb[k * 4 + q] = gg[q] >> shift; rk[k * 4 + q] = atomicAdd(&cnt[bb[k * 4 + q]], 1); } }
+    else { for (int q = 0; q < 4; q++) { bb[k * 4 + q] = -1; if (i0 + q < n) { bb[k * 4 + q] = gidx[i0 + q] >> shift; rk[k * 4 + q] = atomicAdd(&cnt[bb[k * 4 + q]], 1); } } } }
+  __syncthreads();
+  // exclusive scan of the counts; claim the global run of every non-empty bucket
+  const int per = (nbk + NT - 1) / NT; const int b0 = threadIdx.x * per; int v[4], dl[4]; int s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { v[q] = (q < per && b0 + q < nbk) ? cnt[b0 + q] : 0; s += v[q]; }
+  int tot; int ex = block_exscan(s, &tot);
+#pragma unroll
+  for (int q = 0; q < 4; q++) if (q < per && b0 + q < nbk) { cnt[b0 + q] = ex; dl[q] = v[q] ? boff[b0 + q] + atomicAdd(&cursor[b0 + q], v[q]) - ex : 0; ex += v[q]; }
+  __syncthreads();
+  const int mask = (1 << shift) - 1;
+#pragma unroll
+  for (int k = 0; k < R4; k++) { const long i0 = (long)tile * T + (k * NT + threadIdx.x) * 4;
+    if (i0 + 3 < n) {
+      const I4 g = *(const I4*)(gidx + i0), a = *(const I4*)(c1 + i0), b = *(const I4*)(c2 + i0), c = *(const I4*)(c3 + i0), d = *(const I4*)(c4 + i0), e = *(const I4*)(c5 + i0);
+      const int gg[4] = {g.x, g.y, g.z, g.w}, aa[4] = {a.x, a.y, a.z, a.w}, b2[4] = {b.x, b.y, b.z, b.w}, cc[4] = {c.x, c.y, c.z, c.w}, dd[4] = {d.x, d.y, d.z, d.w}, ee[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) { V16 r; r.idx = (bb[k * 4 + q] << 13) | (int)(i0 + q - (long)tile * T); r.slot = cc[q]; r.cp = ee[q];
+        r.meta = (uint32_t)(gg[q] & mask) | ((aa[q] != 0 || b2[q] != 100) ? 0x4000u : ((uint32_t)dd[q] << 16)); recs[cnt[bb[k * 4 + q]] + rk[k * 4 + q]] = r; } }
+    else for (int q = 0; q < 4; q++) if (i0 + q < n) { V16 r; r.idx = (bb[k * 4 + q] << 13) | (int)(i0 + q - (long)tile * T); r.slot = c3[i0 + q]; r.cp = c5[i0 + q];
+        r.meta = (uint32_t)(gidx[i0 + q] & mask) | ((uint32_t)c4[i0 + q] << 16); recs[cnt[bb[k * 4 + q]] + rk[k * 4 + q]] = r; } }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < 4; q++) if (q < per && b0 + q < nbk) cnt[b0 + q] = dl[q];
+  __syncthreads();
+  const int nt = min(T, n - tile * T);
+  for (int j = threadIdx.x; j < nt; j += NT) { V16 r = recs[j]; const int b = r.idx >> 13; r.idx = tile * T + (r.idx & 8191); out[cnt[b] + j] = r; }
+}
 // store cost alone: 16-byte writes at precomputed positions
 __global__ void k_write16(int n, const int* __restrict__ pos, V16* out) { const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i0 + 3 < n) { const I4 p = *(const I4*)(pos + i0); const int pp[4] = {p.x, p.y, p.z, p.w}; for (int q = 0; q < 4; q++) { V16 v; v.idx = i0 + q; v.slot = 1; v.cp = 2; v.meta = 3; out[pp[q]] = v; } } }
+// the same 48 MB as 64-byte chunks (4 votes of one bucket flushed together from a write-combining buffer):
+// chunk c goes to position cpos[c] (in chunks); 4 adjacent lanes write its four 16-byte quarters
+__global__ void k_write64(int nchunks, const int* __restrict__ cpos, V16* out) { const int t = blockIdx.x * blockDim.x + threadIdx.x; const int c = t >> 2;
+  if (c < nchunks) { V16 v; v.idx = t; v.slot = 1; v.cp = 2; v.meta = 3; out[(size_t)cpos[c] * 4 + (t & 3)] = v; } }
+__global__ void k_write128(int nchunks, const int* __restrict__ cpos, V16* out) { const int t = blockIdx.x * blockDim.x + threadIdx.x; const int c = t >> 3;
+  if (c < nchunks) { V16 v; v.idx = t; v.slot = 1; v.cp = 2; v.meta = 3; out[(size_t)cpos[c] * 8 + (t & 7)] = v; } }
+__global__ void k_perm(int n, int* p) { const int i = blockIdx.x * blockDim.x + threadIdx.x; if (i < n) p[i] = (int)(((unsigned long long)i * 2654435761ull) % (unsigned long long)n); }
 __global__ void k_pos_of(int n, const V16* __restrict__ part, int* pos) { const int j = blockIdx.x * blockDim.x + threadIdx.x; if (j < n) pos[part[j].idx] = j; }
 __global__ void k_check(int n, int shift, int nbk, const int* __restrict__ boff, const int* __restrict__ gidx, const V16* __restrict__ part, int* bad) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x; if (j >= n) return; const V16 v = part[j]; const int g = gidx[v.idx]; const int b = g >> shift;
@@ -123,15 +191,22 @@ int main() {
   const int n = 3000000, G = 1000000; const int ntiles = (n + TILE - 1) / TILE;
   int *gidx, *c1, *c2, *c3, *c4, *c5, *btot, *boff, *rel, *pos, *bad; V16 *out; char* flushbuf;
   CK(hipMalloc(&gidx, n * 4)); CK(hipMalloc(&c1, n * 4)); CK(hipMalloc(&c2, n * 4)); CK(hipMalloc(&c3, n * 4)); CK(hipMalloc(&c4, n * 4)); CK(hipMalloc(&c5, n * 4));
-  CK(hipMalloc(&pos, n * 4)); CK(hipMalloc(&out, (size_t)n * 16)); CK(hipMalloc(&btot, 8192 * 4)); CK(hipMalloc(&boff, 8192 * 4)); CK(hipMalloc(&bad, 4));
+  CK(hipMalloc(&pos, n * 4)); CK(hipMalloc(&out, (size_t)n * 16)); CK(hipMalloc(&btot, 8192 * 4)); CK(hipMalloc(&boff, 8192 * 4)); CK(hipMalloc(&bad, 4)); int* cur; CK(hipMalloc(&cur, 8192 * 4));
   CK(hipMalloc(&rel, (size_t)ntiles * 4096 * 4)); CK(hipMalloc(&flushbuf, (size_t)1 << 30));
   k_setup<<<(n + 255) / 256, 256>>>(n, G, gidx, c1, c2, c3, c4, c5); CK(hipDeviceSynchronize());
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
   auto timeit = [&](const char* name, auto pre, auto f) { float best = 1e9;
     for (int r = 0; r < 6; r++) { pre(); hipMemsetAsync(flushbuf, r, (size_t)1 << 30); hipEventRecord(e0); f(); hipEventRecord(e1); hipEventSynchronize(e1); float ms; hipEventElapsedTime(&ms, e0, e1); if (r) best = std::min(best, ms); }
     printf("%-64s %8.1f us\n", name, best * 1e3); fflush(stdout); };
+  { // random 64- and 128-byte chunk writes of the same 48 MB: what write combining per bucket could buy
+    const int n64 = n / 4, n128 = n / 8; // 750001 is prime-ish enough for a multiplicative permutation
+    k_perm<<<(n64 + 255) / 256, 256>>>(n64, pos); CK(hipDeviceSynchronize());
+    timeit("48 MB as 0.75 M random 64-byte chunks (4 lanes x 16 B)", [] {}, [&] { k_write64<<<(n + 255) / 256, 256>>>(n64, pos, out); });
+    k_perm<<<(n128 + 255) / 256, 256>>>(n128, pos); CK(hipDeviceSynchronize());
+    timeit("48 MB as 0.375 M random 128-byte chunks (8 lanes x 16 B)", [] {}, [&] { k_write128<<<(n + 255) / 256, 256>>>(n128, pos, out); });
+  }
   const int tg = 8 * ((ntiles + 7) / 8);
-  for (int shift : {8, 9, 10}) {
+  for (int shift : {9, 10, 11}) {
     const int nbk = (G + (1 << shift) - 1) >> shift; char nm[160];
     auto zero = [&] { hipMemsetAsync(btot, 0, 8192 * 4); };
     for (int hsub : {3, 8}) {
@@ -149,6 +224,21 @@ int main() {
       int hb = -1; CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost)); if (hb) printf("   !! %d misplaced votes\n", hb);
       if (hsub == 3) { k_pos_of<<<(n + 255) / 256, 256>>>(n, out, pos); snprintf(nm, 160, "  shift %2d: 16-byte stores alone, cursor-order positions", shift);
         timeit(nm, [] {}, [&] { k_write16<<<(n / 4 + 255) / 256, 256>>>(n, pos, out); }); }
+    }
+    { // C: LDS tile sort + contiguous runs
+      auto zero2 = [&] { hipMemsetAsync(btot, 0, 8192 * 4); hipMemsetAsync(cur, 0, 8192 * 4); };
+      const int hs = 5; const int nsuper = (ntiles + hs - 1) / hs; const int hg = 8 * ((nsuper + 7) / 8);
+      snprintf(nm, 160, "C shift %2d nbk %4d: k_hist_tot (bucket totals only)", shift, nbk);
+      timeit(nm, zero2, [&] { k_hist_tot<<<hg, NT, nbk * 4>>>(n, ntiles, gidx, shift, nbk, hs, btot); });
+      k_offsets<<<1, NT>>>(nbk, btot, boff); CK(hipDeviceSynchronize());
+      auto runC = [&](auto kern, int T, const char* tag) {
+        const size_t sh = (size_t)((nbk + 3) & ~3) * 4 + (size_t)T * 16; hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        const int ntl = (n + T - 1) / T; const int g = 8 * ((ntl + 7) / 8);
+        snprintf(nm, 160, "C shift %2d nbk %4d: k_scatter_sorted<%s> (%zu KB LDS)", shift, nbk, tag, sh >> 10);
+        timeit(nm, [&] { hipMemsetAsync(cur, 0, 8192 * 4); }, [&] { kern<<<g, NT, sh>>>(n, shift, nbk, boff, cur, gidx, c1, c2, c3, c4, c5, out); });
+        hipMemsetAsync(bad, 0, 4); k_check<<<(n + 255) / 256, 256>>>(n, shift, nbk, boff, gidx, out, bad);
+        int hb2 = -1; hipMemcpy(&hb2, bad, 4, hipMemcpyDeviceToHost); if (hb2) printf("   !! %d misplaced votes\n", hb2); };
+      runC(k_scatter_sorted<4096>, 4096, "4096"); runC(k_scatter_sorted<8192>, 8192, "8192");
     }
     for (int hsub : {1, 3}) {
       const int nsuper = (ntiles + hsub - 1) / hsub; const int hg = 8 * ((nsuper + 7) / 8);
