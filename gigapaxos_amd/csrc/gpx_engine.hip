@@ -129,6 +129,10 @@ struct gpx_engine {
   int32_t *w_cnt = nullptr, *w_tile = nullptr, *w_err = nullptr, *w_gidx = nullptr, *w_aux = nullptr;
   int8_t* w_cls = nullptr;
   long long* w_tile_b = nullptr;
+  unsigned long long* w_look = nullptr; /* [4][tiles] look-back words of the one-launch decode */
+  uint32_t* w_ticket = nullptr;
+  uint32_t w_epoch = 0;
+  bool wire_legacy = false;
   uint8_t* w_stage = nullptr;      /* staging of BATCHED_ACCEPT_REPLY frames, 188 B per reply */
   long long* w_bucket_bytes = nullptr;
   int32_t* w_ones = nullptr;       /* a column of ones (gpx_request_batch without weights) */
@@ -1481,7 +1485,7 @@ int gpx_group_create(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
     H2D_B(d_k, k + o, (size_t)c);
     H2D_B(d_r, rows + o, (size_t)c * sizeof(gpx_hri));
     LAUNCH(h, "k_group_create", k_group_create, grid_for(c), h->S, c, (const int32_t*)d_g,
-           (const int32_t*)d_m, (const uint8_t*)d_k, (const gpx_hri*)d_r, d_s);
+           (const int32_t*)d_m, (const uint8_t*)d_k, (const gpx_hri*)d_r, d_s, h->N.rows);
     if (status) D2H(status + o, d_s, (size_t)c);
     HIPCHK(hipStreamSynchronize(h->sB));
   }
@@ -1510,7 +1514,7 @@ static int retire_impl(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mo
     const int32_t c = std::min(chunk, n - o);
     H2D_B(d_g, gidx + o, (size_t)c * 4);
     LAUNCH(h, "k_group_retire", k_group_retire, grid_for(c), h->S, c, (const int32_t*)d_g, mode, d_r,
-           d_s);
+           d_s, h->N.rows);
     if (rows) D2H(rows + o, d_r, (size_t)c * sizeof(gpx_hri));
     if (status) D2H(status + o, d_s, (size_t)c);
     HIPCHK(hipStreamSynchronize(h->sB));

@@ -2011,6 +2011,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_gap_scan(DevState S, int32_t n,
 
 /* ------------------------------------------------------------------------- */
 /* lifecycle                                                                    */
+/* name rows of the wire codec (gpx_wire.hip.h: NM_STRIDE / NM_EXISTS / NM_VERSION, checked there) */
+#define GPX_NAME_ROW_STRIDE 160
+#define GPX_NAME_ROW_EXISTS 5
+#define GPX_NAME_ROW_VERSION 8
 
 /* PaxosInstanceStateMachine.hotRestore (PISM:677-690), PaxosAcceptor.hotRestore
  * (PaxosAcceptor.java:128-134), PaxosCoordinator.hotRestore (PaxosCoordinator.java:122-131) */
@@ -2019,7 +2023,8 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_group_create(DevState S, int32_t 
                                                            const int32_t* __restrict__ members,
                                                            const uint8_t* __restrict__ kk,
                                                            const gpx_hri* __restrict__ rows,
-                                                           uint8_t* __restrict__ status) {
+                                                           uint8_t* __restrict__ status,
+                                                           uint8_t* __restrict__ name_rows) {
   int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (i >= n) return;
   const int32_t g = gidx[i];
@@ -2054,6 +2059,11 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_group_create(DevState S, int32_t 
     S.com_flags[o] = 0;
   }
   S.g_flags[g] = GF_EXISTS | (coord ? GF_HASCOORD : 0u) | ((uint32_t)k << 8);
+  if (name_rows) { /* the wire codec's copy of (exists, version) in the group's name row (gpx_wire.hip.h) */
+    uint8_t* nr = name_rows + (int64_t)g * GPX_NAME_ROW_STRIDE;
+    *(int32_t*)(nr + GPX_NAME_ROW_VERSION) = r.version;
+    nr[GPX_NAME_ROW_EXISTS] = 1;
+  }
   status[i] = GPX_S_OK;
 }
 
@@ -2083,7 +2093,8 @@ __device__ __forceinline__ void fill_hri_dev(const DevState& S, int32_t g, uint3
 __global__ __launch_bounds__(GPX_BLOCK) void k_group_retire(DevState S, int32_t n,
                                                            const int32_t* __restrict__ gidx,
                                                            int32_t mode, gpx_hri* __restrict__ rows,
-                                                           uint8_t* __restrict__ status) {
+                                                           uint8_t* __restrict__ status,
+                                                           uint8_t* __restrict__ name_rows) {
   int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (i >= n) return;
   const int32_t g = gidx[i];
@@ -2110,6 +2121,9 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_group_retire(DevState S, int32_t 
     }
   }
   if (rows) fill_hri_dev(S, g, gf, &rows[i]);
-  if (mode != 2) S.g_flags[g] = 0;
+  if (mode != 2) {
+    S.g_flags[g] = 0;
+    if (name_rows) name_rows[(int64_t)g * GPX_NAME_ROW_STRIDE + GPX_NAME_ROW_EXISTS] = 0;
+  }
   if (status) status[i] = GPX_S_OK;
 }

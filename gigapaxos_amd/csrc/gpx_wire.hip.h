@@ -10,11 +10,26 @@
 #include "gpx_kernels.hip.h"
 #include "../../include/gpx_wire.h"
 
-/* One row per group: int32 String.hashCode | uint8 length (0 = no name) | 3 pad | name bytes.
- * Header and the first 24 name bytes share one 32-byte sector: a lookup of a short paxosID costs
- * the table probe plus ONE row access. */
-#define NM_STRIDE 144
-#define NM_NAME 8 /* offset of the name bytes inside a row */
+/* One row per group (160 bytes, so the first 32 never straddle a 64-byte line):
+ *   int32 String.hashCode | uint8 length (0 = no name) | uint8 group exists | 2 pad | int32 version |
+ *   name bytes.
+ * "exists" and "version" are COPIES of the engine's g_flags & GF_EXISTS / g_version, kept by the only
+ * kernels that change them (k_group_create, k_group_retire) and by k_names_bind: the header, the
+ * instance test of PaxosManager.handlePaxosPacket (getInstance + version, PaxosManager.java:1153-
+ * 1162) and the first 20 name bytes are ONE 32-byte access - a frame's lookup costs the table probe
+ * plus that (round 2 counters: the separate g_flags / g_version reads were two more random HBM lines
+ * per frame, 3.7 lines per frame in all, and the random-access rate is what bounds the decode).
+ * A table slot holds row + 1 in its low 25 bits and 6 bits of the name's hash above them, so a probe
+ * that lands on another name's slot almost never reads that name's row. */
+#define NM_STRIDE 160
+#define NM_EXISTS 5
+#define NM_VERSION 8
+#define NM_NAME 12 /* offset of the name bytes inside a row */
+#define NM_HOT 20  /* name bytes inside the row's first 32 */
+#define NM_ROW_BITS 25
+#define NM_ROW_MASK ((1 << NM_ROW_BITS) - 1)
+static_assert(NM_STRIDE == GPX_NAME_ROW_STRIDE && NM_EXISTS == GPX_NAME_ROW_EXISTS && NM_VERSION == GPX_NAME_ROW_VERSION,
+              "k_group_create / k_group_retire write the name rows");
 #define GPX_W_MAX_DEPTH 6   /* nesting of batched RequestPackets the walker follows */
 #define GPX_W_MAX_SEG 256   /* rows of one group a BATCHED_COMMIT frame may span (>= 2 * window) */
 
@@ -27,6 +42,14 @@ struct DevNames {
   __device__ __forceinline__ int32_t hash(int32_t g) const { return *(const int32_t*)row(g); }
   __device__ __forceinline__ int32_t len(int32_t g) const { return (int32_t)row(g)[4]; }
   __device__ __forceinline__ const uint8_t* name(int32_t g) const { return row(g) + NM_NAME; }
+  /* table slot of row g whose name hashes to h (String.hashCode): never 0, never negative */
+  /* (a table of more than 2^25 slots - more than 16 M groups - keeps plain row + 1) */
+  __device__ __forceinline__ int32_t row_mask() const { return cap > NM_ROW_MASK ? 0x7fffffff : NM_ROW_MASK; }
+  __device__ __forceinline__ int32_t slot_of(int32_t g, int32_t h) const {
+    const uint32_t fp = cap > NM_ROW_MASK ? 0u : ((uint32_t)h * 0x9e3779b1u) >> 26;
+    return (int32_t)((uint32_t)(g + 1) | (fp << NM_ROW_BITS));
+  }
+  __device__ __forceinline__ int32_t slot_row(int32_t v) const { return (v & row_mask()) - 1; }
 };
 
 /* Frame bytes are parsed either in place (generic pointer) or from the LDS staging area.  The
@@ -61,26 +84,33 @@ __device__ __forceinline__ bool w_bytes_eq(const uint8_t* a, BP b, int32_t n) {
  * and its first 24 name bytes (zero padded by k_names_bind) arrive with two 16-byte loads of one
  * 32-byte sector, so a probe step costs one table read plus one row read. */
 template <class BP>
-__device__ __forceinline__ int32_t names_find(const DevNames& N, BP p, int32_t len, int32_t hash) {
+__device__ __forceinline__ int32_t names_find(const DevNames& N, BP p, int32_t len, int32_t hash,
+                                              bool* exists = nullptr, int32_t* version = nullptr) {
   if (!N.tab) return -1;
-  uint32_t q[6] = {0, 0, 0, 0, 0, 0};
+  uint32_t q[5] = {0, 0, 0, 0, 0};
 #pragma unroll
-  for (int32_t i = 0; i < 24; i++)
+  for (int32_t i = 0; i < NM_HOT; i++)
     if (i < len) q[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
   const uint32_t mask = (uint32_t)N.cap - 1u;
   uint32_t s = w_fmix32((uint32_t)hash) & mask;
+  const int32_t rmask = N.row_mask();
+  const int32_t want = N.slot_of(0, hash) & ~rmask; /* the hash bits of a matching slot */
   for (int32_t probe = 0; probe < N.cap; probe++) {
     const int32_t v = N.tab[s];
     if (v == 0) return -1;
-    if (v > 0) {
-      const int32_t g = v - 1;
+    if (v > 0 && (v & ~rmask) == want) {
+      const int32_t g = N.slot_row(v);
       const uint4* r = (const uint4*)N.row(g);
       const uint4 r0 = r[0], r1 = r[1];
-      if ((int32_t)r0.x == hash && (int32_t)(r0.y & 0xffu) == len && r0.z == q[0] && r0.w == q[1] &&
-          r1.x == q[2] && r1.y == q[3] && r1.z == q[4] && r1.w == q[5]) {
+      if ((int32_t)r0.x == hash && (int32_t)(r0.y & 0xffu) == len && r0.w == q[0] && r1.x == q[1] &&
+          r1.y == q[2] && r1.z == q[3] && r1.w == q[4]) {
         bool same = true;
-        for (int32_t i = 24; i < len && same; i++) same = N.name(g)[i] == p[i];
-        if (same) return g;
+        for (int32_t i = NM_HOT; i < len && same; i++) same = N.name(g)[i] == p[i];
+        if (same) {
+          if (exists) *exists = ((r0.y >> 8) & 0xffu) != 0;
+          if (version) *version = (int32_t)r0.z;
+          return g;
+        }
       }
     }
     s = (s + 1) & mask;
@@ -88,7 +118,7 @@ __device__ __forceinline__ int32_t names_find(const DevNames& N, BP p, int32_t l
   return -1;
 }
 
-__global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevNames N, int32_t G, int32_t n,
+__global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevState S, DevNames N, int32_t G, int32_t n,
                                                          const uint8_t* __restrict__ names,
                                                          const int32_t* __restrict__ name_off,
                                                          const int32_t* __restrict__ gidx,
@@ -109,8 +139,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevNames N, int32_t G,
   const int32_t h = w_java_hash(p, len);
   uint8_t* row = N.row(g);
   for (int32_t b = 0; b < len; b++) row[NM_NAME + b] = p[b];
-  for (int32_t b = len; b < 24; b++) row[NM_NAME + b] = 0; /* names_find compares 24 padded bytes */
+  for (int32_t b = len; b < NM_HOT; b++) row[NM_NAME + b] = 0; /* names_find compares NM_HOT padded bytes */
   *(int32_t*)row = h;
+  row[NM_EXISTS] = (g < S.G && (S.g_flags[g] & GF_EXISTS)) ? 1 : 0;
+  *(int32_t*)(row + NM_VERSION) = g < S.G ? S.g_version[g] : 0;
   row[4] = (uint8_t)len;
   __threadfence(); /* the row is complete before the table can point at it */
   const uint32_t mask = (uint32_t)N.cap - 1u;
@@ -118,15 +150,15 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevNames N, int32_t G,
   for (int32_t probe = 0; probe < N.cap; probe++) {
     int32_t v = N.tab[s];
     if (v == 0) {
-      v = atomicCAS(&N.tab[s], 0, g + 1);
+      v = atomicCAS(&N.tab[s], 0, N.slot_of(g, h));
       if (v == 0) {
         status[i] = GPX_S_OK;
         return;
       }
       __threadfence();
     }
-    if (v > 0 && v - 1 != g) {
-      const int32_t o = v - 1;
+    if (v > 0 && N.slot_row(v) != g) {
+      const int32_t o = N.slot_row(v);
       if (N.hash(o) == h && N.len(o) == len && w_bytes_eq(N.name(o), p, len)) {
         N.row(g)[4] = 0; /* name already bound to another row */
         status[i] = GPX_S_EXISTS;
@@ -153,7 +185,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_unbind(DevNames N, int32_t 
   uint32_t s = w_fmix32((uint32_t)N.hash(g)) & mask;
   for (int32_t probe = 0; probe < N.cap; probe++) {
     const int32_t v = N.tab[s];
-    if (v == g + 1) {
+    if (v > 0 && N.slot_row(v) == g) {
       N.tab[s] = -1; /* tombstone: later probes walk over it */
       break;
     }
@@ -171,7 +203,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_reinsert(DevNames N, int32_
   const uint32_t mask = (uint32_t)N.cap - 1u;
   uint32_t s = w_fmix32((uint32_t)N.hash(g)) & mask;
   for (int32_t probe = 0; probe < N.cap; probe++) {
-    if (N.tab[s] == 0 && atomicCAS(&N.tab[s], 0, g + 1) == 0) return;
+    if (N.tab[s] == 0 && atomicCAS(&N.tab[s], 0, N.slot_of(g, N.hash(g))) == 0) return;
     s = (s + 1) & mask;
   }
 }
@@ -431,14 +463,24 @@ __device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, W
   f.type = t;
   /* getInstance(paxosID) and the version check */
   int32_t g = -1;
-  if (idl > 0) g = names_find(N, p + 13, idl, w_java_hash(p + 13, idl));
-  if (g < 0 || !(S.g_flags[g] & GF_EXISTS)) {
+  bool exists = false;
+  int32_t gver = 0;
+#ifdef GPX_WD_NOLOOKUP
+  if (idl > 0) {
+    g = (int32_t)(w_fmix32((uint32_t)w_java_hash(p + 13, idl)) & (uint32_t)(S.G - 1));
+    exists = true;
+    gver = version;
+  }
+#else
+  if (idl > 0) g = names_find(N, p + 13, idl, w_java_hash(p + 13, idl), &exists, &gver);
+#endif
+  if (g < 0 || !exists) {
     f.st = GPX_W_NOGROUP;
     f.cnt = 0;
     return;
   }
   f.gidx = g;
-  if (S.g_version[g] != version) {
+  if (gver != version) {
     f.st = GPX_W_VERSION;
     f.cnt = 0;
     return;
@@ -475,6 +517,50 @@ struct WireScratch {
 #ifndef GPX_WIRE_WINDOWS
 #define GPX_WIRE_WINDOWS 0
 #endif
+#define GPX_W_STAGE_WORDS (GPX_W_STAGE_BYTES / 4 + 4 + 1) /* + the lead of an unaligned tile + one readable word */
+/* Copy the bytes [a0, a0 + nbytes) (a0 dword-aligned) into the 16-byte-aligned staging area with
+ * 16-byte loads, FOUR in flight per lane before the first is stored: a lane's loads of a plain
+ * `lds[w] = src[w]` loop wait for one another (17 dependent HBM round trips for a 17 KB tile - that
+ * loop, not the name lookups, was most of round 2's 230 us scan).  LDS byte lead + k = byte k, where
+ * lead = a0 & 15 keeps 16-byte chunks aligned on both sides; nothing before a0 or past the last byte
+ * is read.  Returns lead; the caller's barrier follows. */
+__device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64_t nbytes) {
+  const uintptr_t a16 = a0 & ~(uintptr_t)15;
+  const int32_t lead = (int32_t)(a0 - a16);
+  const int32_t total = lead + (int32_t)nbytes;
+  const int32_t c_lo = (lead + 15) >> 4, c_hi = total >> 4; /* whole chunks inside [lead, total) */
+  const uint4* src16 = (const uint4*)a16;
+  uint4* dst16 = (uint4*)lds;
+  for (int32_t c0 = c_lo; c0 < c_hi; c0 += 4 * GPX_BLOCK) {
+    uint4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t c = c0 + k * GPX_BLOCK + (int32_t)threadIdx.x;
+      if (c < c_hi) v[k] = src16[c];
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int32_t c = c0 + k * GPX_BLOCK + (int32_t)threadIdx.x;
+      if (c < c_hi) dst16[c] = v[k];
+    }
+  }
+  /* the words before the first whole chunk and after the last one, then the tail bytes */
+  const uint32_t* src = (const uint32_t*)a16;
+  const int32_t w_hi = total >> 2;
+  const int32_t head_end = c_lo * 4 < w_hi ? c_lo * 4 : w_hi;
+  {
+    const int32_t w = (lead >> 2) + (int32_t)threadIdx.x;
+    if (w < head_end) lds[w] = src[w];
+  }
+  {
+    const int32_t t_lo = c_hi * 4 > head_end ? c_hi * 4 : head_end;
+    const int32_t w = t_lo + (int32_t)threadIdx.x;
+    if (w < w_hi) lds[w] = src[w];
+  }
+  if ((int32_t)threadIdx.x < (total & 3))
+    ((uint8_t*)lds)[(w_hi << 2) + threadIdx.x] = ((const uint8_t*)src)[(w_hi << 2) + threadIdx.x];
+  return lead;
+}
 template <class F>
 __device__ __forceinline__ void wire_for_frame(const uint8_t* __restrict__ frames,
                                                const int64_t* __restrict__ frame_off, int32_t nf,
@@ -492,13 +578,9 @@ __device__ __forceinline__ void wire_for_frame(const uint8_t* __restrict__ frame
   /* one window only: a tile that does not fit is parsed in place (the windowed loop below costs the
    * parsers twice the registers; measured before choosing the default) */
   if (span >= 0 && span <= GPX_W_STAGE_BYTES) {
-    const uint32_t* src = (const uint32_t*)a0;
-    const int32_t nw = (int32_t)(span >> 2);
-    for (int32_t w = threadIdx.x; w < nw; w += GPX_BLOCK) lds[w] = src[w];
-    if ((int32_t)threadIdx.x < (int32_t)(span & 3))
-      ((uint8_t*)lds)[(nw << 2) + threadIdx.x] = ((const uint8_t*)src)[(nw << 2) + threadIdx.x];
+    const int32_t lead = wire_stage(lds, a0, span);
     __syncthreads();
-    if (!done) fn(true, r0);
+    if (!done) fn(true, r0 + lead);
     return;
   }
   if (!done) fn(false, f0);
@@ -534,7 +616,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_scan(DevState S, DevNames N,
                                                         int32_t* __restrict__ f_gidx,
                                                         int32_t* __restrict__ f_type,
                                                         gpx_wire_counts* counts) {
-  __shared__ uint32_t stage[GPX_W_STAGE_BYTES / 4 + 1];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[GPX_W_STAGE_WORDS];
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   WFrame f;
   f.st = GPX_W_OK;
@@ -599,9 +681,8 @@ __device__ __forceinline__ int32_t w_next_slot(BP e, int32_t n, int32_t stride, 
  * Nothing is validated again: pass 1 left the frame's class, group row, list order and tail. */
 /* the records of one frame, written at its class offset */
 template <class BP>
-__device__ __forceinline__ void wire_emit(const WireScratch& W, const WireOut& O, int32_t i, BP p,
+__device__ __forceinline__ void wire_emit(const WireOut& O, int32_t i, BP p, int32_t g, int64_t tail,
                                           int32_t flags, int32_t cls, int32_t cnt, int32_t off) {
-  const int32_t g = W.gidx[i];
   const int64_t hdr = 13 + (int64_t)p[12];
   const bool ascending = (flags & 8) != 0;
   if (cls == 0) {
@@ -643,7 +724,7 @@ __device__ __forceinline__ void wire_emit(const WireScratch& W, const WireOut& O
       if (O.C.frame) O.C.frame[o] = i;
     }
   } else if (cls == 2) {
-    const BP t = p + W.aux[i];
+    const BP t = p + tail;
     O.A.gidx[off] = g;
     O.A.slot[off] = w_be32(t);
     O.A.bnum[off] = w_be32(t + 4);
@@ -666,7 +747,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_unpack(WireScratch W, WireOu
                                                           const int64_t* __restrict__ frame_off,
                                                           uint8_t* __restrict__ f_status,
                                                           gpx_wire_counts* counts) {
-  __shared__ uint32_t stage[GPX_W_STAGE_BYTES / 4 + 1];
+  __shared__ __attribute__((aligned(16))) uint32_t stage[GPX_W_STAGE_WORDS];
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   const bool live = i < nf && f_status[i] == GPX_W_OK;
   const int32_t flags = live ? (int32_t)W.cls[i] : 7;
@@ -692,10 +773,195 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_unpack(WireScratch W, WireOu
   wire_for_frame(frames, frame_off, nf, stage, i, [&](bool staged, int64_t pos) {
     if (!emit) return;
     if (staged)
-      wire_emit<LdsBytes>(W, O, i, (LdsBytes)stage + pos, flags, cls, cnt, off);
+      wire_emit<LdsBytes>(O, i, (LdsBytes)stage + pos, W.gidx[i], W.aux[i], flags, cls, cnt, off);
     else
-      wire_emit<GenBytes>(W, O, i, frames + pos, flags, cls, cnt, off);
+      wire_emit<GenBytes>(O, i, frames + pos, W.gidx[i], W.aux[i], flags, cls, cnt, off);
   });
+}
+
+/* ------------------------------------------------------------------------- */
+/* decode in ONE launch: parse, place and emit while the tile's bytes are still in LDS.
+ * The class offsets of a tile (records of every earlier frame, per class) come from a decoupled
+ * look-back over per-tile words {epoch | state | count}: a tile publishes its own counts (AGGREGATE)
+ * as soon as it has parsed, then wave c of the workgroup walks back over class c's words, 64 tiles
+ * per step, until it meets a tile that already knows its inclusive PREFIX.  Tiles are handed out by a
+ * ticket, so every tile a workgroup waits for has been taken by a workgroup that is running (or
+ * done): no deadlock whatever the dispatch order.  A word carries its count AND its state, and
+ * nothing else travels between tiles, so the loads and stores are RELAXED agent-scope atomics: with
+ * release / acquire every store wrote the XCD's L2 back and every poll invalidated it - measured 15x
+ * slower than the three-launch form.  Frames are read from HBM once (the three-launch
+ * form above reads them twice and keeps 13 bytes of per-frame scratch in between). */
+struct WireLook {
+  unsigned long long* state; /* [4][ntiles]  epoch << 40 | state << 38 | count */
+  uint32_t* ticket;          /* next tile; the workgroup that draws the last one puts 0 back */
+  uint32_t epoch;            /* 24 bits, never 0 (the words are zeroed when it wraps) */
+};
+#define WL_AGG 1ull
+#define WL_PRE 2ull
+#define WL_VAL_MASK ((1ull << 38) - 1)
+__device__ __forceinline__ unsigned long long wl_word(uint32_t epoch, unsigned long long st, uint32_t v) {
+  return ((unsigned long long)epoch << 40) | (st << 38) | (unsigned long long)v;
+}
+/* exclusive prefix of class words before `tile`; called by one whole wave.  Polling is what this
+ * costs: ~6,000 waves spinning on 64 words each flood the L2 request path (measured: four words per
+ * lane made the kernel 35 % slower), so a wave first waits on ONE word - its nearest predecessor's,
+ * published last of all it needs in the usual case - and only then reads 64 at a time. */
+__device__ __forceinline__ uint32_t wl_lookback(const unsigned long long* __restrict__ st, int32_t tile,
+                                                 uint32_t epoch) {
+  const int32_t lane = (int32_t)(threadIdx.x & 63);
+  for (;;) { /* the nearest predecessor has parsed */
+    const unsigned long long v = __hip_atomic_load(&st[tile - 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if ((uint32_t)(v >> 40) == epoch) break;
+    __builtin_amdgcn_s_sleep(8);
+  }
+  uint32_t excl = 0;
+  for (int32_t hi = tile - 1; hi >= 0; hi -= 64) {
+    const int32_t j = hi - lane; /* lane 0 = the nearest predecessor */
+    unsigned long long v = 0;
+    bool need = j >= 0;
+    unsigned long long pre_mask;
+    for (;;) {
+      if (need) {
+        v = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((uint32_t)(v >> 40) == epoch) need = false;
+      }
+      /* the walk stops at the nearest tile with a PREFIX: only lanes nearer than it must be valid */
+      pre_mask = __ballot(!need && j >= 0 && ((v >> 38) & 3ull) == WL_PRE);
+      const unsigned long long wait_mask = __ballot(need);
+      if (pre_mask) {
+        const unsigned long long nearer = (pre_mask & (0ull - pre_mask)) - 1ull;
+        if ((wait_mask & nearer) == 0) break;
+      } else if (wait_mask == 0) {
+        break;
+      }
+      __builtin_amdgcn_s_sleep(8);
+    }
+    const int32_t first_pre = pre_mask ? (__ffsll((long long)pre_mask) - 1) : 64;
+    uint32_t x = (j >= 0 && lane <= first_pre) ? (uint32_t)(v & WL_VAL_MASK) : 0u;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    excl += x;
+    if (pre_mask) break;
+  }
+  return excl;
+}
+
+__global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames N, WireLook K, WireOut O,
+                                                           int32_t nf, int32_t ntiles,
+                                                           const uint8_t* __restrict__ frames,
+                                                           const int64_t* __restrict__ frame_off,
+                                                           uint8_t* __restrict__ f_status,
+                                                           int32_t* __restrict__ f_gidx,
+                                                           int32_t* __restrict__ f_type,
+                                                           gpx_wire_counts* counts) {
+  __shared__ __attribute__((aligned(16))) uint32_t stage[GPX_W_STAGE_WORDS];
+  __shared__ int32_t s_tile;
+  __shared__ uint32_t s_tot[4], s_base[4];
+  if (threadIdx.x == 0) {
+    const uint32_t t = atomicAdd(K.ticket, 1u);
+    if (t == (uint32_t)ntiles - 1u) *K.ticket = 0u; /* every tile is taken: ready for the next call */
+    s_tile = (int32_t)t;
+  }
+  __syncthreads();
+  const int32_t tile = s_tile;
+  const int32_t i = tile * GPX_BLOCK + (int32_t)threadIdx.x;
+  /* stage the tile (one window; a frame that does not lie inside it is read in place) */
+  const int32_t t0 = tile * GPX_BLOCK;
+  const int32_t t1 = t0 + GPX_BLOCK < nf ? t0 + GPX_BLOCK : nf;
+  const int64_t b0 = frame_off[t0], b1 = frame_off[t1];
+  const uintptr_t a0 = (uintptr_t)(frames + b0) & ~(uintptr_t)3;
+  const int64_t span = (int64_t)((uintptr_t)(frames + b1) - a0);
+  const bool live = i < nf;
+  const int64_t f0 = live ? frame_off[i] : b0, f1 = live ? frame_off[i + 1] : b0;
+  const int64_t r0 = (int64_t)((uintptr_t)(frames + f0) - a0), r1 = (int64_t)((uintptr_t)(frames + f1) - a0);
+  const int64_t nbytes = span < 0 ? 0 : (span < GPX_W_STAGE_BYTES ? span : GPX_W_STAGE_BYTES);
+#ifdef GPX_WD_NOSTAGE /* ablation builds (scripts/ubench/wire_ablation.sh): never shipped */
+  const int32_t lead = 0;
+#else
+  const int32_t lead = wire_stage(stage, a0, nbytes);
+#endif
+  __syncthreads();
+  const bool staged = live && r0 >= 0 && r1 >= r0 && r1 <= nbytes;
+  WFrame f;
+  f.st = GPX_W_OK;
+  f.cnt = 0;
+  f.cls = -1;
+  f.gidx = -1;
+  f.type = -1;
+  f.tail = 0;
+  f.ascending = true;
+  f.stop = false;
+#ifdef GPX_WD_NOPARSE
+  if (live) {
+    f.cls = 0;
+    f.cnt = 1;
+    f.gidx = i & (S.G - 1);
+    f.type = GPX_WT_BATCHED_ACCEPT_REPLY;
+  }
+#else
+  if (live) {
+    if (staged)
+      w_parse<LdsBytes>(S, N, (LdsBytes)stage + r0 + lead, f1 - f0, f);
+    else
+      w_parse<GenBytes>(S, N, frames + f0, f1 - f0, f);
+  }
+#endif
+  const int32_t cls = (live && f.st == GPX_W_OK) ? f.cls : -1;
+  const int32_t cnt = cls >= 0 ? f.cnt : 0;
+  /* records of this tile per class; my offset inside the tile */
+  int32_t off = 0;
+#pragma unroll
+  for (int c = 0; c < 4; c++) {
+    int32_t tot;
+    const int32_t ex = block_exscan(cls == c ? cnt : 0, &tot);
+    if (cls == c) off = ex;
+    if (threadIdx.x == 0) s_tot[c] = (uint32_t)tot;
+  }
+  __syncthreads();
+  { /* wave c: class c's words */
+    const int32_t c = (int32_t)(threadIdx.x >> 6);
+    unsigned long long* st = K.state + (int64_t)c * ntiles;
+    const uint32_t mine = s_tot[c];
+    if ((threadIdx.x & 63) == 0)
+      __hip_atomic_store(&st[tile], wl_word(K.epoch, tile == 0 ? WL_PRE : WL_AGG, mine), __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+#ifdef GPX_WD_NOLOOKBACK
+    const uint32_t excl = (uint32_t)tile * GPX_BLOCK;
+#else
+    const uint32_t excl = tile == 0 ? 0u : wl_lookback(st, tile, K.epoch);
+#endif
+    if ((threadIdx.x & 63) == 0) {
+      if (tile != 0)
+        __hip_atomic_store(&st[tile], wl_word(K.epoch, WL_PRE, excl + mine), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      s_base[c] = excl;
+      if (tile == ntiles - 1) (&counts->n_votes)[c] = (int32_t)(excl + mine);
+    }
+  }
+  __syncthreads();
+  bool over = false;
+  if (cls >= 0) {
+    off += (int32_t)s_base[cls];
+    const int32_t cap = cls == 0 ? O.V.cap : cls == 1 ? O.C.cap : cls == 2 ? O.A.cap : O.R.cap;
+    over = (int64_t)off + cnt > cap;
+  }
+  if (live) {
+    f_status[i] = over ? (uint8_t)GPX_W_CAPACITY : (uint8_t)f.st;
+    if (f_gidx) f_gidx[i] = f.gidx;
+    if (f_type) f_type[i] = f.type;
+  }
+  int32_t bad;
+  block_exscan((live && (f.st != GPX_W_OK || over)) ? 1 : 0, &bad);
+  if (threadIdx.x == 0 && bad) atomicAdd(&counts->n_bad_frames, bad);
+#ifndef GPX_WD_NOEMIT
+  if (cls >= 0 && !over) {
+    const int32_t flags = (cls & 7) | (f.ascending ? 8 : 0) | (f.stop ? 16 : 0);
+    if (staged)
+      wire_emit<LdsBytes>(O, i, (LdsBytes)stage + r0 + lead, f.gidx, f.tail, flags, cls, cnt, off);
+    else
+      wire_emit<GenBytes>(O, i, frames + f0, f.gidx, f.tail, flags, cls, cnt, off);
+  }
+#endif
 }
 
 /* ------------------------------------------------------------------------- */
@@ -780,7 +1046,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N,
   int32_t size = 0;
   if (i < n && pack_is_head(P, X, n, i)) {
     const int32_t g = P.gidx[i];
-    if ((uint32_t)g < (uint32_t)S.G && (S.g_flags[g] & GF_EXISTS) && N.tab && N.len(g) != 0) {
+    if ((uint32_t)g < (uint32_t)S.G && N.tab && N.len(g) != 0 && N.row(g)[NM_EXISTS]) {
       /* TreeSet of the slots of this (group, ballot) */
       int32_t m = 0;
       for (int32_t j = i; j < n && j - i < GPX_W_MAX_SEG && P.gidx[j] == g; j++) {
@@ -850,21 +1116,21 @@ template <class WR>
 __device__ __forceinline__ int32_t pack_commit_frame(const DevState& S, const DevNames& N, const PackIn& P,
                                                      int32_t n, int32_t i, WR& w) {
   const int32_t g = P.gidx[i];
-  /* the row's header and first 24 name bytes: one 32-byte sector, two 16-byte loads (a byte loop
-   * over global memory is a chain of dependent loads) */
+  /* the row's header (with its copy of the group's version) and first 20 name bytes: one 32-byte
+   * access, two 16-byte loads (a byte loop over global memory is a chain of dependent loads) */
   const uint4* row = (const uint4*)N.row(g);
   const uint4 r0 = row[0], r1 = row[1];
   const int32_t idl = (int32_t)(r0.y & 0xffu);
-  const uint32_t nw[6] = {r0.z, r0.w, r1.x, r1.y, r1.z, r1.w};
+  const uint32_t nw[5] = {r0.w, r1.x, r1.y, r1.z, r1.w};
   w.put32(GPX_WT_PAXOS_PACKET);       /* PaxosPacket.toBytes (PaxosPacket.java:461-476) */
   w.put32(GPX_WT_BATCHED_COMMIT);
-  w.put32(S.g_version[g]);
+  w.put32(r0.z);
   w.put8((uint32_t)idl);
   const uint8_t* nm = N.name(g);
 #pragma unroll
-  for (int32_t b = 0; b < 24; b++)
+  for (int32_t b = 0; b < NM_HOT; b++)
     if (b < idl) w.put8(nw[b >> 2] >> (8 * (b & 3)));
-  for (int32_t b = 24; b < idl; b++) w.put8(nm[b]);
+  for (int32_t b = NM_HOT; b < idl; b++) w.put8(nm[b]);
   w.put32(P.bnum[i]);
   w.put32(P.bcoord[i]);
   /* medianCheckpointedSlot: addCommit keeps the later one when `b - cur > 0` (:104-112) */
@@ -1041,7 +1307,7 @@ __global__ __launch_bounds__(1024) void k_bucket_pack_ar(DevState S, DevScratch 
         keys[p + 1] = x;
       }
     }
-    const bool named = (S.g_flags[g] & GF_EXISTS) && N.tab && N.len(g) != 0;
+    const bool named = N.tab && N.len(g) != 0 && N.row(g)[NM_EXISTS];
     const int32_t cc = c < GPX_W_BAR_MAX_RECS ? c : GPX_W_BAR_MAX_RECS;
     int32_t nbal = 0, bn[GPX_W_BAR_MAX_BALLOTS], bc[GPX_W_BAR_MAX_BALLOTS];
     for (int32_t t = 0; t < c; t++) {

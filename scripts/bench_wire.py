@@ -18,6 +18,8 @@ sys.path.insert(0, ROOT)
 from gigapaxos_amd import Engine, hri_create, load_hip, S_OK  # noqa: E402
 from gigapaxos_amd import wire as W  # noqa: E402
 
+NOCHECK = os.environ.get("GPX_BENCH_NOCHECK") == "1"  # ablation builds (scripts/ubench/wire_ablation.sh) decode wrong on purpose
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -81,7 +83,7 @@ def main():
         ev[3].record()
         eng.sync()
         torch.cuda.synchronize()
-        assert int(counts[0]) == nfr and int(counts[4]) == 0 and int(n_out) == G and int(nfo) == G
+        assert NOCHECK or (int(counts[0]) == nfr and int(counts[4]) == 0 and int(n_out) == G and int(nfo) == G)
         if r > 0:
             t_dec += ev[0].elapsed_time(ev[1])
             t_ar += ev[1].elapsed_time(ev[2])
@@ -116,7 +118,7 @@ def main():
         e1.record()
         eng.sync()
         torch.cuda.synchronize()
-        assert int(counts[2]) == G and int(counts[4]) == 0, counts.tolist()
+        assert NOCHECK or (int(counts[2]) == G and int(counts[4]) == 0), counts.tolist()
         if r > 0:
             t_acc += e0.elapsed_time(e1)
     res = {

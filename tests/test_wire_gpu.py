@@ -12,6 +12,14 @@ from tests.wire_common import make_wire_pair, random_frames, assert_same_decode
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["one-launch decode", "three-launch decode"])
+def _decode_path(request, monkeypatch):
+    """gpx_wire_decode runs as ONE launch (k_wire_decode1: look-back over the tiles) or, with
+    GPX_WIRE_LEGACY=1 (read when the engine first decodes), as scan / offsets / unpack - every case
+    of this file runs both ways."""
+    monkeypatch.setenv("GPX_WIRE_LEGACY", "1" if request.param.startswith("three") else "0")
+
+
 @pytest.mark.parametrize("name", [n for n in dir(scen) if n.startswith("test_") and "oracle_lib" in
                                   getattr(scen, n).__code__.co_varnames[:getattr(scen, n).__code__.co_argcount]])
 def test_oracle_scenarios_on_the_engine(hip_lib, name):
@@ -29,6 +37,23 @@ def test_decode_fuzz(hip_lib, oracle_lib, seed, damage):
     # tight capacities: overflow is reported frame by frame, never written
     frames = random_frames(names, 500, rng, 0.0)
     assert_same_decode(wh.decode(frames, 40, 30, 20, 10), wo.decode(frames, 40, 30, 20, 10), "tight")
+
+
+def test_decode_many_tiles(hip_lib, oracle_lib):
+    """A burst of 420,000 frames of every class (damaged ones included) = 1,641 tiles of 256 frames,
+    more than the chip holds at once: the one-launch decode's offsets come from a look-back over
+    tiles that are still running (gpx_wire.hip.h, k_wire_decode1) - same records, same order, same
+    counts as the oracle, call after call (the look-back words carry the call's epoch)."""
+    rng = np.random.default_rng(77)
+    ((eh, wh), (eo, wo)), names = make_wire_pair(hip_lib, oracle_lib, 1500, 3, rng, max_batch=1 << 19)
+    for rep, damage in ((140, 0.2), (97, 0.0)):
+        buf, off = W.concat_frames(random_frames(names, 3000, rng, damage))
+        big = np.tile(buf, rep)
+        boff = (off[None, :-1] + (np.arange(rep, dtype=np.int64) * off[-1])[:, None]).reshape(-1)
+        boff = np.concatenate([boff, np.array([off[-1] * rep], np.int64)])
+        a, b = wh.decode(None, buf_off=(big, boff)), wo.decode(None, buf_off=(big, boff))
+        assert_same_decode(a, b, f"x{rep}")
+        assert a.counts["n_votes"] + a.counts["n_commits"] + a.counts["n_accepts"] + a.counts["n_requests"] > 3000 * rep // 4
 
 
 def test_names_churn_and_table_rebuild(hip_lib, oracle_lib):
