@@ -94,3 +94,67 @@ def test_config5_churn_1m_live_groups_vs_oracle(hip_lib, oracle_lib):
     sh, so = eh.snapshot(np.arange(cap))[0], eo.snapshot(np.arange(cap))[0]
     assert sh.tobytes() == so.tobytes()
     assert eh.counters() == eo.counters()
+
+
+@pytest.mark.parametrize("order", ["grouped by group", "shuffled"])
+def test_full_round_1m_groups_vs_oracle(hip_lib, oracle_lib, order):
+    """The whole pipeline on one replica at 1 M groups: propose -> its own ACCEPTs (handleAccept,
+    PISM:1080-1166) -> the accept replies of two acceptors (majority of 3) -> the decisions back as
+    commits (handleBatchedCommit / extractExecuteAndCheckpoint, PISM:1480-1528, 1619-1701), two
+    rounds.  Batches grouped by group take the direct kernels, shuffled ones (plus duplicates and
+    records of a ballot that lost) the partition path (k_bucket16<ACCEPT / COMMIT>, 1,954 buckets):
+    reply columns, execution runs, decisions, statuses, HotRestoreInfo rows and counters bit for bit."""
+    G, k, R = 1_000_000, 3, 2
+    rng = np.random.default_rng(5)
+    members = [100, 101, 102]
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=2 * G + 8192)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 100)) == S_OK).all()
+    g = np.arange(G, dtype=np.int32)
+    for r in range(R):
+        ph, po = eh.propose(g), eo.propose(g)
+        for x, y in zip(ph, po):
+            assert (x == y).all()
+        slot, bnum, bcoord, median = ph[0], ph[1], ph[2], ph[3]
+        ag, asl, abn, abc, amed = g, slot, bnum, bcoord, median
+        if order == "shuffled":  # + 2 % duplicates and 1 % ACCEPTs of a lower ballot (refused: NACK)
+            extra = rng.integers(0, G, G // 50)
+            low = rng.integers(0, G, G // 100)
+            ag = np.concatenate([g, g[extra], g[low]])
+            asl = np.concatenate([slot, slot[extra], slot[low]])
+            abn = np.concatenate([bnum, bnum[extra], bnum[low] - 1])
+            abc = np.concatenate([bcoord, bcoord[extra], bcoord[low]])
+            amed = np.concatenate([median, median[extra], median[low]])
+            p = rng.permutation(ag.shape[0])
+            ag, asl, abn, abc, amed = ag[p], asl[p], abn[p], abc[p], amed[p]
+        fl = np.zeros(ag.shape[0], np.uint8)
+        (rh, xh), (ro, xo) = eh.accept(ag, abn, abc, asl, amed, fl), eo.accept(ag, abn, abc, asl, amed, fl)
+        for x, y, nm in zip(rh, ro, ("r_bnum", "r_bcoord", "r_maxcp", "r_flags", "status")):
+            assert (x == y).all(), f"round {r} accept {nm}"
+        assert (xh.as_tuple_array() == xo.as_tuple_array()).all()
+        # votes of acceptors 100 and 101, interleaved at random
+        vg = np.concatenate([g, g])
+        vs = np.concatenate([slot, slot])
+        va = np.concatenate([np.full(G, 100, np.int32), np.full(G, 101, np.int32)])
+        p = rng.permutation(2 * G)
+        vg, vs, va = vg[p], vs[p], va[p]
+        vb, vc = np.concatenate([bnum, bnum])[p], np.concatenate([bcoord, bcoord])[p]
+        mcp = np.full(2 * G, r, np.int32)
+        dh, do = eh.accept_reply(vg, vb, vc, vs, va, mcp), eo.accept_reply(vg, vb, vc, vs, va, mcp)
+        _same(dh, do, f"round {r} decisions")
+        assert dh.gidx.shape[0] == G
+        cg, cs, cb, cc, cm = dh.gidx, dh.slot, dh.bnum, dh.bcoord, dh.median_cp
+        ck = np.zeros(G, np.uint8)
+        if order == "shuffled":
+            p = rng.permutation(G)
+            cg, cs, cb, cc, cm = cg[p], cs[p], cb[p], cc[p], cm[p]
+        (sh, ch), (so, co) = eh.commit(cg, cb, cc, cs, cm, ck), eo.commit(cg, cb, cc, cs, cm, ck)
+        assert (sh == so).all(), f"round {r} commit status"
+        assert (ch.as_tuple_array() == co.as_tuple_array()).all(), f"round {r} execution runs"
+        assert ch.as_tuple_array().shape[0] == G
+    sh, so = eh.snapshot(g)[0], eo.snapshot(g)[0]
+    assert sh.tobytes() == so.tobytes()
+    assert eh.counters() == eo.counters()
+    eh.close()
+    eo.close()
