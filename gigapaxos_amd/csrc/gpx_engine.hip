@@ -133,6 +133,7 @@ struct gpx_engine {
   uint32_t* w_ticket = nullptr;
   uint32_t w_epoch = 0;
   bool wire_legacy = false;
+  bool pack_fused = false; /* GPX_PACK_FUSED=1: k_pack_commits1 instead of scan / offsets / write */
   uint8_t* w_stage = nullptr;      /* staging of BATCHED_ACCEPT_REPLY frames, 188 B per reply */
   long long* w_bucket_bytes = nullptr;
   int32_t* w_ones = nullptr;       /* a column of ones (gpx_request_batch without weights) */

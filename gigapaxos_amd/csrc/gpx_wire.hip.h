@@ -806,7 +806,7 @@ __device__ __forceinline__ unsigned long long wl_word(uint32_t epoch, unsigned l
  * costs: ~6,000 waves spinning on 64 words each flood the L2 request path (measured: four words per
  * lane made the kernel 35 % slower), so a wave first waits on ONE word - its nearest predecessor's,
  * published last of all it needs in the usual case - and only then reads 64 at a time. */
-__device__ __forceinline__ uint32_t wl_lookback(const unsigned long long* __restrict__ st, int32_t tile,
+__device__ __forceinline__ unsigned long long wl_lookback64(const unsigned long long* __restrict__ st, int32_t tile,
                                                  uint32_t epoch) {
   const int32_t lane = (int32_t)(threadIdx.x & 63);
   for (;;) { /* the nearest predecessor has parsed */
@@ -814,7 +814,7 @@ __device__ __forceinline__ uint32_t wl_lookback(const unsigned long long* __rest
     if ((uint32_t)(v >> 40) == epoch) break;
     __builtin_amdgcn_s_sleep(8);
   }
-  uint32_t excl = 0;
+  unsigned long long excl = 0;
   for (int32_t hi = tile - 1; hi >= 0; hi -= 64) {
     const int32_t j = hi - lane; /* lane 0 = the nearest predecessor */
     unsigned long long v = 0;
@@ -837,13 +837,22 @@ __device__ __forceinline__ uint32_t wl_lookback(const unsigned long long* __rest
       __builtin_amdgcn_s_sleep(8);
     }
     const int32_t first_pre = pre_mask ? (__ffsll((long long)pre_mask) - 1) : 64;
-    uint32_t x = (j >= 0 && lane <= first_pre) ? (uint32_t)(v & WL_VAL_MASK) : 0u;
+    unsigned long long x = (j >= 0 && lane <= first_pre) ? (v & WL_VAL_MASK) : 0ull;
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+    for (int d = 32; d >= 1; d >>= 1) {
+      const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, d, 64);
+      const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), d, 64);
+      x += ((unsigned long long)hi << 32) | lo;
+    }
     excl += x;
     if (pre_mask) break;
   }
   return excl;
+}
+
+__device__ __forceinline__ uint32_t wl_lookback(const unsigned long long* __restrict__ st, int32_t tile,
+                                                 uint32_t epoch) {
+  return (uint32_t)wl_lookback64(st, tile, epoch);
 }
 
 __global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames N, WireLook K, WireOut O,
@@ -1039,10 +1048,9 @@ struct BEWriter {
 };
 
 /* pass 1: frame sizes of the head rows */
-__global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N, PackIn P,
-                                                        PackScratch X) {
-  const int32_t n = pack_rows(P);
-  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+/* padded frame size of row i if it opens a frame, else 0 */
+__device__ __forceinline__ int32_t pack_frame_size(const DevState& S, const DevNames& N, const PackIn& P,
+                                                   const PackScratch& X, int32_t n, int32_t i) {
   int32_t size = 0;
   if (i < n && pack_is_head(P, X, n, i)) {
     const int32_t g = P.gidx[i];
@@ -1064,6 +1072,14 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N,
       size = (13 + N.len(g) + 12 + 4 * (m + 1 + gs + 1) + 3) & ~3;
     }
   }
+  return size;
+}
+
+__global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N, PackIn P,
+                                                        PackScratch X) {
+  const int32_t n = pack_rows(P);
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  const int32_t size = pack_frame_size(S, N, P, X, n, i);
   if (i < n) X.size[i] = size;
   int32_t tb, tf;
   block_exscan(size, &tb);
@@ -1232,6 +1248,100 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_write(DevState S, DevNames N
       len = pack_commit_frame(S, N, P, n, i, w);
       const int32_t pad = size - ((len + 3) & ~3); /* frames are 4-byte aligned: nothing to clear */
       (void)pad;
+    } else {
+      BEWriter w;
+      w.init(out + off);
+      len = pack_commit_frame(S, N, P, n, i, w);
+    }
+    frame_off[fi] = off;
+    frame_len[fi] = len;
+    f_gidx[fi] = P.gidx[i];
+  }
+  if (staged) {
+    __syncthreads();
+    uint32_t* dst = (uint32_t*)(out + tile0); /* tile0 is a multiple of 4 */
+    for (int32_t wi = threadIdx.x; wi < (tb >> 2); wi += GPX_BLOCK) dst[wi] = stage[wi];
+  }
+}
+
+/* The three passes in ONE launch: sizes, look-back over the tiles for (bytes, frames, refused
+ * blocks) - waves 0, 1, 2 of the workgroup walk one word array each (wl_lookback) - frames built in LDS
+ * and flushed at the tile's byte offset.  X.err / X.size / X.tile_* are not used: a block of rows that
+ * exceeds GPX_W_MAX_SEG travels as the third look-back count (a flag in global memory written by one
+ * workgroup and read by the last would need an ordering the relaxed words do not give). */
+__global__ __launch_bounds__(GPX_BLOCK) void k_pack_commits1(DevState S, DevNames N, PackIn P, WireLook K,
+                                                            int32_t ntiles, uint8_t* __restrict__ out,
+                                                            long long cap_bytes,
+                                                            long long* __restrict__ frame_off,
+                                                            int32_t* __restrict__ frame_len,
+                                                            int32_t* __restrict__ f_gidx,
+                                                            int32_t* __restrict__ n_frames,
+                                                            long long* __restrict__ n_bytes) {
+  __shared__ uint32_t stage[GPX_PACK_STAGE_BYTES / 4];
+  __shared__ int32_t s_tile, s_err;
+  __shared__ uint32_t s_tot[3];
+  __shared__ unsigned long long s_base[3];
+  if (threadIdx.x == 0) {
+    const uint32_t t = atomicAdd(K.ticket, 1u);
+    if (t == (uint32_t)ntiles - 1u) *K.ticket = 0u;
+    s_tile = (int32_t)t;
+    s_err = 0;
+  }
+  __syncthreads();
+  const int32_t tile = s_tile;
+  const int32_t n = pack_rows(P);
+  const int32_t i = tile * GPX_BLOCK + (int32_t)threadIdx.x;
+  PackScratch X;
+  X.err = &s_err; /* pack_is_head's refusal flag: this workgroup's share */
+  X.size = nullptr;
+  X.tile_b = nullptr;
+  X.tile_f = nullptr;
+  X.ntiles = ntiles;
+  const int32_t size = pack_frame_size(S, N, P, X, n, i);
+  int32_t tb, tf;
+  const int32_t eb = block_exscan(size, &tb);
+  const int32_t ef = block_exscan(size ? 1 : 0, &tf);
+  if (threadIdx.x == 0) {
+    s_tot[0] = (uint32_t)tb;
+    s_tot[1] = (uint32_t)tf;
+    s_tot[2] = s_err ? 1u : 0u;
+  }
+  __syncthreads();
+  {
+    const int32_t c = (int32_t)(threadIdx.x >> 6);
+    if (c < 3) {
+      unsigned long long* st = K.state + (int64_t)c * ntiles;
+      const uint32_t mine = s_tot[c];
+      if ((threadIdx.x & 63) == 0)
+        __hip_atomic_store(&st[tile], wl_word(K.epoch, tile == 0 ? WL_PRE : WL_AGG, mine), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+      const unsigned long long excl = tile == 0 ? 0ull : wl_lookback64(st, tile, K.epoch);
+      if ((threadIdx.x & 63) == 0) {
+        if (tile != 0)
+          __hip_atomic_store(&st[tile],
+                             ((unsigned long long)K.epoch << 40) | (WL_PRE << 38) | ((excl + mine) & WL_VAL_MASK),
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_base[c] = excl;
+      }
+    }
+  }
+  __syncthreads();
+  const long long tile0 = (long long)s_base[0];
+  if (tile == ntiles - 1 && threadIdx.x == 0) {
+    *n_frames = (s_base[2] + s_tot[2]) ? -1 : (int32_t)(s_base[1] + s_tot[1]);
+    *n_bytes = tile0 + tb;
+  }
+  const bool staged = tb <= GPX_PACK_STAGE_BYTES && tile0 + tb <= cap_bytes; /* workgroup-uniform */
+  const long long off = tile0 + eb;
+  const int32_t fi = (int32_t)s_base[1] + ef;
+  if (size && (staged || off + size <= cap_bytes)) { /* else: the host sees n_bytes > cap_bytes */
+    int32_t len;
+    if (staged) {
+      BEWriterLds w;
+      w.w = stage + (eb >> 2);
+      w.acc = 0;
+      w.k = 0;
+      len = pack_commit_frame(S, N, P, n, i, w);
     } else {
       BEWriter w;
       w.init(out + off);

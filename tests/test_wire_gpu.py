@@ -15,9 +15,12 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["one-launch decode", "three-launch decode"])
 def _decode_path(request, monkeypatch):
     """gpx_wire_decode runs as ONE launch (k_wire_decode1: look-back over the tiles) or, with
-    GPX_WIRE_LEGACY=1 (read when the engine first decodes), as scan / offsets / unpack - every case
-    of this file runs both ways."""
+    GPX_WIRE_LEGACY=1 (read when the engine first touches the wire path), as scan / offsets / unpack;
+    gpx_wire_pack_commits runs as scan / offsets / write or, with GPX_PACK_FUSED=1, as ONE launch
+    (k_pack_commits1; slower, kept as the measured alternative) - every case of this file runs both
+    ways."""
     monkeypatch.setenv("GPX_WIRE_LEGACY", "1" if request.param.startswith("three") else "0")
+    monkeypatch.setenv("GPX_PACK_FUSED", "0" if request.param.startswith("three") else "1")
 
 
 @pytest.mark.parametrize("name", [n for n in dir(scen) if n.startswith("test_") and "oracle_lib" in
@@ -117,6 +120,42 @@ def test_pack_commits_matches_oracle_and_roundtrips(hip_lib, oracle_lib):
         want = sorted(zip(dh.gidx[dh.kind == D_DECISION].tolist(), dh.slot[dh.kind == D_DECISION].tolist()))
         got = sorted(zip(dec.commits["gidx"].tolist(), dec.commits["slot"].tolist()))
         assert got == want
+
+
+def test_pack_commits_many_tiles(hip_lib, oracle_lib):
+    """300,000 groups' decisions (two slots for every third group, preemptions that open no frame) =
+    1,5xx tiles of 256 rows: the one-launch encoder's byte and frame offsets come from a look-back
+    over tiles still running (k_pack_commits1) - bytes, frame order and totals identical to the
+    oracle's; a block of more than 256 consecutive rows of one group is refused by both."""
+    from gigapaxos_amd import GpxError
+    from gigapaxos_amd._abi import Decisions
+    G, k = 300_000, 3
+    rng = np.random.default_rng(12)
+    mem = np.tile(np.array([100, 101, 102], np.int32), (G, 1))
+    names = [bytes(r) for r in W.fixed_names(np.arange(G))]
+    pair = []
+    for lib in (hip_lib, oracle_lib):
+        e = Engine(lib, 100, G, kmax=k, window=8, max_batch=1 << 19)
+        we = W.WireEngine(e)
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 100)) == S_OK).all()
+        assert (we.bind(names, np.arange(G)) == S_OK).all()
+        pair.append(we)
+    reps = 1 + (np.arange(G) % 3 == 0)
+    gidx = np.repeat(np.arange(G, dtype=np.int32), reps)
+    n = gidx.shape[0]
+    slot = (7 + np.arange(n) % 2).astype(np.int32)
+    kind = np.where(rng.random(n) < 0.03, 1, D_DECISION).astype(np.uint8)  # 1 = PREEMPTED: no frame
+    dec = Decisions(gidx, slot, np.zeros(n, np.int32), np.full(n, 100, np.int32),
+                    rng.integers(0, 5, n).astype(np.int32), kind, np.zeros(0, np.uint8))
+    (fh, gh, nbh), (fo, go, nbo) = [we.pack_commits(dec) for we in pair]
+    assert nbh == nbo and gh.tolist() == go.tolist() and len(fh) > G * 9 // 10
+    assert fh == fo
+    hot = Decisions(np.full(300, 5, np.int32), np.arange(300, dtype=np.int32), np.zeros(300, np.int32),
+                    np.full(300, 100, np.int32), np.zeros(300, np.int32), np.full(300, D_DECISION, np.uint8),
+                    np.zeros(0, np.uint8))
+    for we in pair:
+        with pytest.raises(GpxError):
+            we.pack_commits(hot)
 
 
 @pytest.mark.parametrize("seed", [1, 2])
