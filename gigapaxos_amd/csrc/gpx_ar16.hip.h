@@ -361,7 +361,11 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
   const int32_t l = (int32_t)threadIdx.x;
   const int32_t g = X.g_base + (b << X.shift) + l;
   /* coordinator state of a dense batch: issued now, consumed after the regrouping */
+#ifdef GPX_B16_NOPRELOAD /* tuning build: state fetched after the regrouping (fewer live registers) */
+  const bool pre = false;
+#else
   const bool pre = !AC && 2 * nb >= gb;
+#endif
   CoordPre<KMAX> P;
   P.have_pe = false;
   P.my_bnum = P.my_bcoord = 0;
