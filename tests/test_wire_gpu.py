@@ -122,6 +122,19 @@ def test_pack_commits_matches_oracle_and_roundtrips(hip_lib, oracle_lib):
         assert got == want
 
 
+@pytest.mark.parametrize("lead", [1, 2, 3, 4, 7, 12, 13])
+def test_decode_burst_at_any_byte_offset(hip_lib, oracle_lib, lead):
+    """The burst need not start on a 16-byte (or even 4-byte) boundary: the staging copy aligns its
+    16-byte loads on the address and shifts the LDS image by the same lead (wire_stage), and never
+    reads before the first frame's dword."""
+    rng = np.random.default_rng(40 + lead)
+    ((eh, wh), (eo, wo)), names = make_wire_pair(hip_lib, oracle_lib, 600, 3, rng)
+    buf, off = W.concat_frames(random_frames(names, 1500, rng, 0.1))
+    shifted = np.concatenate([rng.integers(0, 256, lead).astype(np.uint8), buf])
+    assert_same_decode(wh.decode(None, buf_off=(shifted, off + lead)), wo.decode(None, buf_off=(shifted, off + lead)),
+                       f"lead {lead}")
+
+
 def test_pack_commits_many_tiles(hip_lib, oracle_lib):
     """300,000 groups' decisions (two slots for every third group, preemptions that open no frame) =
     1,5xx tiles of 256 rows: the one-launch encoder's byte and frame offsets come from a look-back
