@@ -24,6 +24,7 @@ from tests.oracle_binding import load_oracle  # noqa: E402
 from tests.parity_common import make_pair, create_mixed_groups, fuzz  # noqa: E402
 from tests.election_common import fuzz_run  # noqa: E402
 from tests.failover_common import failover_run  # noqa: E402
+from tests.wire_common import make_wire_pair, random_frames, assert_same_decode  # noqa: E402
 
 NODES = [100, 101, 102, 103, 104, 105, 106, 107]
 
@@ -45,11 +46,21 @@ def main():
         nodes = NODES if kmax <= 8 else list(range(100, 120))
         base = int(rng.choice([1, (1 << 31) - 20]))
         batch = int(rng.choice([50, 400, 3000]))
-        print("seed", seed, "kmax", kmax, "W", W, "G", G, "base", base, "batch", batch, flush=True)
+        # round 2: batches grouped by group half of the time (direct / single-launch kernels), the ordered-
+        # batches promise on some of those, the single-launch accept-reply path on a third of the seeds
+        ordered = bool(rng.random() < 0.5)
+        promise = int(rng.choice([0, 0, 2, 4, 6])) if ordered else 0
+        os.environ["GPX_SMALL"] = "1" if seed % 3 == 0 else "0"
+        os.environ["GPX_AR_LEGACY"] = "1" if seed % 7 == 0 else "0"
+        print("seed", seed, "kmax", kmax, "W", W, "G", G, "base", base, "batch", batch, "ordered", ordered,
+              "promise", promise, "small", os.environ["GPX_SMALL"], flush=True)
         eh, eo = make_pair(hip, orc, 100, G, kmax, W)
         create_mixed_groups(eh, eo, G, kmax, nodes, rng, slot_base=base)
+        if promise:
+            eh.set_ordered_batches(promise), eo.set_ordered_batches(promise)
         try:
-            fuzz(eh, eo, G, nodes, rng, steps=120, batch=batch, slot_base=base, span=W - 3)  # inside the window: the oracle has none
+            fuzz(eh, eo, G, nodes, rng, steps=120, batch=batch, slot_base=base, span=W - 3,  # inside the window: the oracle has none
+                 ordered=ordered)
         except AssertionError as ex:
             print("  MISMATCH", ex, flush=True)
             done.setdefault("mismatch", 0)
@@ -64,6 +75,14 @@ def main():
         b = fuzz_run(orc, seed, G=Ge, k=k, W=We, steps=50, slot0=s0)
         assert a == b, ("election fuzz", seed)
         done["election"] += 1
+        if seed % 2 == 0:  # wire frames, damaged ones included: decode as one launch or as three
+            os.environ["GPX_WIRE_LEGACY"] = "1" if seed % 4 == 0 else "0"
+            ((ewh, wh), (ewo, wo)), names = make_wire_pair(hip, orc, int(rng.choice([200, 1500])), 3, rng)
+            for _ in range(3):
+                frames = random_frames(names, int(rng.choice([300, 5000])), rng, float(rng.choice([0.0, 0.3, 0.7])))
+                assert_same_decode(wh.decode(frames), wo.decode(frames), f"seed {seed}")
+            ewh.close(), ewo.close()
+            done["wire"] = done.get("wire", 0) + 1
         if seed % 4 == 0:
             Gf = int(rng.choice([150, 900]))
             fa = failover_run(hip, G=Gf, seed=seed, window=We)
