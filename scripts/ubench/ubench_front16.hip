@@ -175,6 +175,10 @@ __global__ __launch_bounds__(NT) void k_scatter_sorted(int n, int shift, int nbk
 // store cost alone: 16-byte writes at precomputed positions
 __global__ void k_write16(int n, const int* __restrict__ pos, V16* out) { const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i0 + 3 < n) { const I4 p = *(const I4*)(pos + i0); const int pp[4] = {p.x, p.y, p.z, p.w}; for (int q = 0; q < 4; q++) { V16 v; v.idx = i0 + q; v.slot = 1; v.cp = 2; v.meta = 3; out[pp[q]] = v; } } }
+// the same stores with the non-temporal hint (nt: streamed through L2 without allocation)
+__global__ void k_write16_nt(int n, const int* __restrict__ pos, V16* out) { const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i0 + 3 < n) { const I4 p = *(const I4*)(pos + i0); const int pp[4] = {p.x, p.y, p.z, p.w}; for (int q = 0; q < 4; q++) { int* d = (int*)&out[pp[q]];
+    __builtin_nontemporal_store(i0 + q, d); __builtin_nontemporal_store(1, d + 1); __builtin_nontemporal_store(2, d + 2); __builtin_nontemporal_store(3, d + 3); } } }
 // the same 48 MB as 64-byte chunks (4 votes of one bucket flushed together from a write-combining buffer):
 // chunk c goes to position cpos[c] (in chunks); 4 adjacent lanes write its four 16-byte quarters
 __global__ void k_write64(int nchunks, const int* __restrict__ cpos, V16* out) { const int t = blockIdx.x * blockDim.x + threadIdx.x; const int c = t >> 2;
@@ -223,7 +227,9 @@ int main() {
       k_offsets<<<1, NT>>>(nbk, btot, boff); hipMemsetAsync(bad, 0, 4); k_check<<<(n + 255) / 256, 256>>>(n, shift, nbk, boff, gidx, out, bad);
       int hb = -1; CK(hipMemcpy(&hb, bad, 4, hipMemcpyDeviceToHost)); if (hb) printf("   !! %d misplaced votes\n", hb);
       if (hsub == 3) { k_pos_of<<<(n + 255) / 256, 256>>>(n, out, pos); snprintf(nm, 160, "  shift %2d: 16-byte stores alone, cursor-order positions", shift);
-        timeit(nm, [] {}, [&] { k_write16<<<(n / 4 + 255) / 256, 256>>>(n, pos, out); }); }
+        timeit(nm, [] {}, [&] { k_write16<<<(n / 4 + 255) / 256, 256>>>(n, pos, out); });
+        snprintf(nm, 160, "  shift %2d: the same stores, non-temporal", shift);
+        timeit(nm, [] {}, [&] { k_write16_nt<<<(n / 4 + 255) / 256, 256>>>(n, pos, out); }); }
     }
     { // C: LDS tile sort + contiguous runs
       auto zero2 = [&] { hipMemsetAsync(btot, 0, 8192 * 4); hipMemsetAsync(cur, 0, 8192 * 4); };
