@@ -166,7 +166,12 @@ __device__ __forceinline__ int32_t ballot_cmp(int32_t n1, int32_t c1, int32_t n2
 
 /* ------------------------------------------------------------------------- */
 /* block-wide exclusive scan of one int per thread (256 threads = 4 waves)     */
+/* Inclusive scan over the 64 lanes of a wave with DPP moves (one VALU op per step): four row_shr steps
+ * scan each row of 16 lanes, row_bcast:15 carries a row's total into the next row (rows 1 and 3), row_bcast:31
+ * carries lane 31's into rows 2 and 3.  __shfl_up compiles to ds_bpermute + waitcnt + select per step:
+ * the scans were a sixth of k_bucket16's instructions. */
 __device__ __forceinline__ int32_t wave_incscan(int32_t v) {
+#ifdef GPX_SCAN_SHFL /* the portable form, kept for comparison builds */
   const int lane = threadIdx.x & 63;
   int32_t x = v;
 #pragma unroll
@@ -175,6 +180,16 @@ __device__ __forceinline__ int32_t wave_incscan(int32_t v) {
     if (lane >= d) x += y;
   }
   return x;
+#else
+  int32_t x = v;
+  x += __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true); /* row_shr:1, lanes without a source get 0 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true); /* row_shr:2 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true); /* row_shr:4 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true); /* row_shr:8 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1 and 3 */
+  x += __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false); /* row_bcast:31 into rows 2 and 3 */
+  return x;
+#endif
 }
 template <int NT>
 __device__ __forceinline__ int32_t block_exscan_n(int32_t v, int32_t* total) {
@@ -595,7 +610,9 @@ __device__ void sort_long_segment(unsigned long long* a, uint32_t c) {
   }
 }
 
-/* block-wide exclusive scan for a runtime block size (<= 1024 threads) */
+/* block-wide exclusive scan for a runtime block size (<= 1024 threads): the wave totals (at most 16)
+ * are scanned by every wave itself - one LDS read, one wave scan, two lane reads - instead of a loop
+ * over a runtime number of waves */
 __device__ __forceinline__ int32_t block_exscan_rt(int32_t v, int32_t* total) {
   __shared__ int32_t wsum[16];
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -603,15 +620,12 @@ __device__ __forceinline__ int32_t block_exscan_rt(int32_t v, int32_t* total) {
   const int32_t x = wave_incscan(v);
   if (lane == 63) wsum[wid] = x;
   __syncthreads();
-  int32_t base = 0, tot = 0;
-  for (int w = 0; w < nw; w++) {
-    int32_t s = wsum[w];
-    if (w < wid) base += s;
-    tot += s;
-  }
+  const int32_t ps = wave_incscan(lane < nw ? wsum[lane] : 0);
+  const int32_t tot = __shfl(ps, nw - 1, 64);
+  const int32_t base = __shfl(ps, wid > 0 ? wid - 1 : 0, 64);
   __syncthreads();
   *total = tot;
-  return base + x - v;
+  return (wid > 0 ? base : 0) + x - v;
 }
 
 /* What one workgroup sees of its bucket after regrouping: the bucket's records (bucket-relative
