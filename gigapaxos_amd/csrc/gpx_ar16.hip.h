@@ -37,9 +37,16 @@ struct __attribute__((aligned(16))) Vote16 {
 
 /* staged outputs of the per-bucket kernel: six columns over the record index space (outputs of
  * bucket b at [bucket_off[b], bucket_off[b] + bucket_nout[b])) */
-struct Stage16 {
-  int32_t *gidx, *slot, *bnum, *bcoord, *median;
-  uint8_t* kind;
+struct Stage16 { /* one block of six columns n apart (five of int32, one of bytes): ONE pointer in the kernel's
+                  * argument registers instead of six - the per-bucket kernel is short of SGPRs */
+  int32_t* base;
+  int64_t n;
+  __host__ __device__ __forceinline__ int32_t* gidx() const { return base; }
+  __host__ __device__ __forceinline__ int32_t* slot() const { return base + n; }
+  __host__ __device__ __forceinline__ int32_t* bnum() const { return base + 2 * n; }
+  __host__ __device__ __forceinline__ int32_t* bcoord() const { return base + 3 * n; }
+  __host__ __device__ __forceinline__ int32_t* median() const { return base + 4 * n; }
+  __host__ __device__ __forceinline__ uint8_t* kind() const { return (uint8_t*)(base + 5 * n); }
 };
 /* the caller's vote columns the ESC path reads, and the batch's common ballot = ballot of vote 0 */
 struct VoteCols {
@@ -479,13 +486,13 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
   /* a bucket's outputs, group-major, as columns: decisions (six columns) or execution runs (gidx,
    * first slot, count) */
   auto put = [&](int64_t o, int32_t a, int32_t z, int32_t kd) {
-    O.gidx[o] = g;
-    O.slot[o] = a;
-    O.median[o] = z;
+    O.gidx()[o] = g;
+    O.slot()[o] = a;
+    O.median()[o] = z;
     if (!AC) {
-      O.bnum[o] = P.my_bnum;
-      O.bcoord[o] = P.my_bcoord;
-      O.kind[o] = (uint8_t)kd;
+      O.bnum()[o] = P.my_bnum;
+      O.bcoord()[o] = P.my_bcoord;
+      O.kind()[o] = (uint8_t)kd;
     }
   };
   if (in_lds) {
@@ -578,12 +585,12 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec16(
   const int32_t nd = X.bucket_nout[blockIdx.x];
   const int64_t src = X.bucket_off[blockIdx.x];
   for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {
-    d_gidx[out0 + t] = O.gidx[src + t];
-    d_slot[out0 + t] = O.slot[src + t];
-    d_bnum[out0 + t] = O.bnum[src + t];
-    d_bcoord[out0 + t] = O.bcoord[src + t];
-    d_median[out0 + t] = O.median[src + t];
-    d_kind[out0 + t] = O.kind[src + t];
+    d_gidx[out0 + t] = O.gidx()[src + t];
+    d_slot[out0 + t] = O.slot()[src + t];
+    d_bnum[out0 + t] = O.bnum()[src + t];
+    d_bcoord[out0 + t] = O.bcoord()[src + t];
+    d_median[out0 + t] = O.median()[src + t];
+    d_kind[out0 + t] = O.kind()[src + t];
   }
 }
 
@@ -596,9 +603,9 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_runs16(DevScratch X, Stage16
   const int32_t nd = X.bucket_nout[blockIdx.x];
   const int64_t src = X.bucket_off[blockIdx.x];
   for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {
-    x_gidx[out0 + t] = O.gidx[src + t];
-    x_first[out0 + t] = O.slot[src + t];
-    x_count[out0 + t] = O.median[src + t];
+    x_gidx[out0 + t] = O.gidx()[src + t];
+    x_first[out0 + t] = O.slot()[src + t];
+    x_count[out0 + t] = O.median()[src + t];
   }
 }
 

@@ -845,7 +845,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
       int32_t* o32 = (int32_t*)e->X.o_rec;
       SmallArgs A{n, gw, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord,
                   d_median_cp, d_kind, n_out, status,
-                  Stage16{o32, o32 + N, o32 + 2 * N, o32 + 3 * N, o32 + 4 * N, (uint8_t*)(o32 + 5 * N)},
+                  Stage16{o32, (int64_t)N},
                   e->small_tickets, e->small_epoch};
       const size_t lds = (size_t)gw * 8 + (size_t)((gw + 7) & ~7) * 2 + (size_t)((n + 7) & ~7) * 2;
       {
@@ -875,7 +875,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     const int32_t passes = e->ar_passes;
     const size_t N = (size_t)e->cfg.max_batch;
     int32_t* o32 = (int32_t*)e->X.o_rec; /* N x 32 bytes: five int columns + one byte column */
-    const Stage16 O{o32, o32 + N, o32 + 2 * N, o32 + 3 * N, o32 + 4 * N, (uint8_t*)(o32 + 5 * N)};
+    const Stage16 O{o32, (int64_t)N};
     const VoteCols in{bnum, bcoord, acceptor};
     for (int32_t p = 0; p < passes; p++) {
       e->X.shift = e->shift16;
@@ -988,7 +988,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
 
   const size_t Nmax = (size_t)e->cfg.max_batch;
   if (!promised && e->ac16 && !e->reply_rows && (rc = dev_alloc(e, &e->reply_rows, Nmax, false)) != GPX_OK) return rc;
-  const Stage16 O16{st32, st32 + Nmax, st32 + 2 * Nmax, st32 + 3 * Nmax, st32 + 4 * Nmax, (uint8_t*)(st32 + 5 * Nmax)};
+  const Stage16 O16{st32, (int64_t)Nmax};
   if (!promised) {
     front_hist(e, n, gidx, fused ? nullptr : status, 0, 2);
     if (e->ac16) {
@@ -1073,7 +1073,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   }
 
   const size_t Nmax = (size_t)e->cfg.max_batch;
-  const Stage16 O16{st32, st32 + Nmax, st32 + 2 * Nmax, st32 + 3 * Nmax, st32 + 4 * Nmax, (uint8_t*)(st32 + 5 * Nmax)};
+  const Stage16 O16{st32, (int64_t)Nmax};
   if (!promised) {
     front_hist(e, n, gidx, fused ? nullptr : status, 0, 2);
     if (e->ac16) {

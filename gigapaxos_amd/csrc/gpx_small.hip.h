@@ -56,11 +56,11 @@ struct SmallIter {
     return true;
   }
   __device__ __forceinline__ void emit(int32_t slot_, int32_t x, int32_t y, int32_t z, int32_t kind) {
-    O.slot[cur] = slot_;
-    O.bnum[cur] = x;
-    O.bcoord[cur] = y;
-    O.median[cur] = z;
-    O.kind[cur] = (uint8_t)kind;
+    O.slot()[cur] = slot_;
+    O.bnum()[cur] = x;
+    O.bcoord()[cur] = y;
+    O.median()[cur] = z;
+    O.kind()[cur] = (uint8_t)kind;
     seg[nout++] = (uint16_t)cur; /* entry nout <= done - 1: consumed */
   }
 };
@@ -266,11 +266,11 @@ __global__ __launch_bounds__(GPX_SMALL_NT) void k_small_ar(DevState S, DevScratc
     for (int32_t q = 0; q < nout; q++) {
       const int32_t ix = (int32_t)sg[q];
       A.d_gidx[o] = g0 + l;
-      A.d_slot[o] = A.O.slot[ix];
-      A.d_bnum[o] = A.O.bnum[ix];
-      A.d_bcoord[o] = A.O.bcoord[ix];
-      A.d_median[o] = A.O.median[ix];
-      A.d_kind[o] = A.O.kind[ix];
+      A.d_slot[o] = A.O.slot()[ix];
+      A.d_bnum[o] = A.O.bnum()[ix];
+      A.d_bcoord[o] = A.O.bcoord()[ix];
+      A.d_median[o] = A.O.median()[ix];
+      A.d_kind[o] = A.O.kind()[ix];
       o++;
     }
   }
