@@ -847,6 +847,13 @@ struct GroupIter {
  * (k even ? k/2-1 : k/2) in signed ascending order.  Rank selection, ties by index. */
 template <int KMAX>
 __device__ __forceinline__ int32_t median_minus(const int32_t (&ns)[KMAX], int32_t k) {
+  /* the VALUE at a rank does not depend on how ties are ordered: three members (the usual group) are
+   * one v_med3_i32 instead of nine ranked compares */
+  if (KMAX >= 3 && k == 3) {
+    const int32_t lo = ns[0] < ns[1] ? ns[0] : ns[1], hi = ns[0] < ns[1] ? ns[1] : ns[0];
+    const int32_t m = hi < ns[2] ? hi : ns[2];
+    return lo > m ? lo : m;
+  }
   const int32_t target = (k % 2 == 0) ? (k / 2 - 1) : (k / 2);
   int32_t res = 0;
 #pragma unroll
