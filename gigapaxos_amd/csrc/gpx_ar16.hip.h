@@ -516,7 +516,84 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
     it.cur = 0;
     if (live) {
       if (it.nib) it.order = arrival_order(idxA, start, c);
-      replay(it);
+      /* Steady state of a coordinator: every vote of the group answers ONE outstanding slot at the
+       * group's current ballot (which is also the batch's common ballot).  When that holds for every
+       * group of the wave, the replay is a straight line per vote - member bit, nodeSlotNumbers max,
+       * majority test - with exactly the effects of apply_ar_group's cmp == 0 branch
+       * (handleAcceptReplyMyBallot, PCS:597-640); one group that needs anything else (another ballot or
+       * slot, an escaped vote, no coordinator, a view change in progress, more than eight votes) sends
+       * the whole wave down the general path, so mixed batches cost what they did. */
+      bool fast = false;
+      int32_t s0 = 0;
+      if (OP == B16_AR) {
+        bool el = c <= 8 && (P.gf & (GF_EXISTS | GF_STOPPED | GF_HASCOORD | GF_PREPARING)) == (GF_EXISTS | GF_HASCOORD) &&
+                  it.b0n == P.my_bnum && it.b0c == P.my_bcoord;
+        if (el) {
+          for (int32_t i = 0; i < c; i++) {
+            const uint32_t p = (uint32_t)start + (uint32_t)((it.order >> (4 * i)) & 15ull);
+            const int32_t sl = slotA[p];
+            if (i == 0) s0 = sl;
+            el = el && !(metaA[p] & V16_ESC) && sl == s0;
+          }
+        }
+        const int32_t d = jsub(P.next, s0);
+        el = el && d >= 1 && d <= S.W;
+        fast = __all(el);
+      }
+      if (fast) {
+        if (OP == B16_AR) {
+          const int32_t G = S.G, k = (int32_t)GF_K(P.gf);
+          int32_t mem[KMAX], ns[KMAX];
+#pragma unroll
+          for (int j = 0; j < KMAX; j++) {
+            mem[j] = (j < k) ? P.mem[j] : 0;
+            ns[j] = (j < k) ? P.ns[j] : 0;
+          }
+          const int64_t off = (int64_t)(s0 & (S.W - 1)) * G + g;
+          const uint32_t e0 = (P.have_pe && s0 == jsub(P.next, 1)) ? P.pe : S.p_ring[off];
+          uint32_t e = e0;
+          int32_t pcount = P.pcount;
+          bool ns_dirty = false;
+          for (int32_t i = 0; i < c; i++) {
+            {
+              const uint32_t p = (uint32_t)start + (uint32_t)((it.order >> (4 * i)) & 15ull);
+              const int32_t acc = (int32_t)(metaA[p] >> 16), maxcp = cpA[p];
+              int32_t midx = -1;
+#pragma unroll
+              for (int q = 0; q < KMAX; q++) {
+                if (q < k && mem[q] == acc) {
+                  midx = q; /* WaitforUtility.getIndex: last match */
+                  if (ns[q] < maxcp) { /* recordSlotNumber :809-825 (plain <) */
+                    ns[q] = maxcp;
+                    ns_dirty = true;
+                  }
+                }
+              }
+              if (e & PR_PRESENT) {
+                if (midx >= 0) e |= (1u << midx);       /* updateHeardFrom :51-62 */
+                if (__popc(e & 0xffffu) > k / 2) {     /* heardFromMajority :64-68 */
+                  slotA[p] = s0;                       /* the decision, parked in the vote's own words */
+                  cpA[p] = median_minus<KMAX>(ns, k);
+                  metaA[p] = (uint32_t)GPX_D_DECISION;
+                  it.omask |= 1u << i;
+                  it.nout++;
+                  e = 0;
+                  pcount--;
+                }
+              }
+            }
+          }
+          if (e != e0) S.p_ring[off] = e;
+          if (ns_dirty) {
+#pragma unroll
+            for (int q = 0; q < KMAX; q++)
+              if (q < k) S.node_slots[(int64_t)q * G + g] = ns[q];
+          }
+          if (pcount != P.pcount) S.c_pcount[g] = pcount;
+        }
+      } else {
+        replay(it);
+      }
     }
     nout = it.nout;
     omask = it.omask;
