@@ -21,7 +21,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gigapaxos_amd import load_hip  # noqa: E402
 from tests.oracle_binding import load_oracle  # noqa: E402
-from tests.parity_common import make_pair, create_mixed_groups, fuzz  # noqa: E402
+from tests.parity_common import make_pair, create_mixed_groups, fuzz, steady_state_run  # noqa: E402
 from tests.election_common import fuzz_run  # noqa: E402
 from tests.failover_common import failover_run  # noqa: E402
 from tests.wire_common import make_wire_pair, random_frames, assert_same_decode  # noqa: E402
@@ -75,6 +75,10 @@ def main():
         b = fuzz_run(orc, seed, G=Ge, k=k, W=We, steps=50, slot0=s0)
         assert a == b, ("election fuzz", seed)
         done["election"] += 1
+        if seed % 2 == 1:  # the coordinator's steady state (k_bucket_ar16's straight-line replay) with fresh seeds
+            os.environ["GPX_SMALL"] = "0"
+            steady_state_run(hip, orc, int(rng.choice([3, 4, 5, 8])), seed, NODES, G=int(rng.choice([700, 6000])))
+            done["steady"] = done.get("steady", 0) + 1
         if seed % 2 == 0:  # wire frames, damaged ones included: decode as one launch or as three
             os.environ["GPX_WIRE_LEGACY"] = "1" if seed % 4 == 0 else "0"
             ((ewh, wh), (ewo, wo)), names = make_wire_pair(hip, orc, int(rng.choice([200, 1500])), 3, rng)

@@ -192,3 +192,53 @@ def churn_run(engines, G_live, cap, R, k, seed, churn_frac=0.01):
         free.extend(int(v) for v in victims)
         ghost = victims
     return outs, live
+
+
+def steady_state_run(lib_a, lib_b, kmax, seed, node_ids, G=6000, rounds=6):
+    """Accept-reply batches in the coordinator's steady state (every group's votes answer one outstanding
+    slot at the current ballot), with the variety that must not matter: 1..4 (1..10) votes per group,
+    duplicates, non-members, older outstanding slots, group sizes kmax-2..kmax, and from round 4 on a few
+    votes of another ballot."""
+    rng = np.random.default_rng(seed)
+    nodes = list(node_ids)[:kmax]
+    eh, eo = make_pair(lib_a, lib_b, 100, G, kmax, 8, max_batch=1 << 16)
+    ks = rng.integers(max(1, kmax - 2), kmax + 1, G).astype(np.uint8)          # group sizes kmax-2 .. kmax
+    mem = np.zeros((G, kmax), np.int32)
+    for k in np.unique(ks):
+        mem[ks == k, :k] = np.array(nodes[:k], np.int32)                         # node 100 first: it coordinates
+    for e in (eh, eo):
+        st = e.create_groups(np.arange(G), mem, ks, hri_create(G, kmax, 100))
+        assert (st == S_OK).all()
+    g = np.arange(G, dtype=np.int32)
+    nonmember = 7777
+    decided = 0
+    for r in range(rounds):
+        for _ in range(2 if r % 2 else 1):                                       # one or two slots outstanding
+            for x, y in zip(eh.propose(g), eo.propose(g)):
+                assert (x == y).all()
+        rows, _ = eo.snapshot(g)
+        newest = rows["next_proposal_slot"].astype(np.int32) - 1
+        target = np.where((rng.random(G) < 0.3) & (r % 2 == 1), newest - 1, newest).astype(np.int32)
+        c = rng.integers(1, 11 if kmax >= 5 else 5, G)                           # 1..4 (1..10) votes per group: past the path's limit of 8 too
+        gi = np.repeat(g, c)
+        n = gi.shape[0]
+        pick = rng.integers(0, kmax + 1, n)                                      # column kmax = a node that is no member
+        acc = np.where(pick < ks[gi], mem[gi, np.minimum(pick, kmax - 1)], nonmember).astype(np.int32)
+        cols = [gi, np.zeros(n, np.int32), np.full(n, 100, np.int32), target[gi],
+                acc, rng.integers(-1, 9, n).astype(np.int32)]
+        if r >= 4:                                                               # a few votes of a higher / lower ballot
+            odd = rng.integers(0, n, 20)
+            cols[1][odd] = rng.choice([0, 1], 20)
+            cols[2][odd] = rng.choice([99, 101], 20)
+        order = rng.permutation(n)
+        cols = [np.ascontiguousarray(x[order]) for x in cols]
+        dh, do = eh.accept_reply(*cols), eo.accept_reply(*cols)
+        assert (dh.as_tuple_array() == do.as_tuple_array()).all(), f"round {r}"
+        assert (dh.status == do.status).all(), f"round {r} status"
+        decided += dh.gidx.shape[0]
+    assert decided > (G if kmax <= 5 else 100)
+    sh, so = eh.snapshot(g)[0], eo.snapshot(g)[0]
+    assert sh.tobytes() == so.tobytes()
+    assert eh.counters() == eo.counters()
+    eh.close()
+    eo.close()
