@@ -520,24 +520,48 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
        * group's current ballot (which is also the batch's common ballot).  When that holds for every
        * group of the wave, the replay is a straight line per vote - member bit, nodeSlotNumbers max,
        * majority test - with exactly the effects of apply_ar_group's cmp == 0 branch
-       * (handleAcceptReplyMyBallot, PCS:597-640); one group that needs anything else (another ballot or
-       * slot, an escaped vote, no coordinator, a view change in progress, more than eight votes) sends
-       * the whole wave down the general path, so mixed batches cost what they did. */
+       * (handleAcceptReplyMyBallot, PCS:597-640); votes of a lower ballot are stepped over, as the
+       * reference ignores them.  One group that needs anything else (a HIGHER ballot, a second slot, no
+       * coordinator, a view change in progress, more than eight votes) sends the whole wave down the
+       * general path. */
       bool fast = false;
       int32_t s0 = 0;
+      uint32_t skip = 0; /* votes of a LOWER ballot: ignored (PaxosCoordinator.java:241-247), whatever their slot */
+      int32_t nvote = c; /* votes the straight-line replay walks */
+      bool esc = false;  /* this group has an escaped vote */
       if (OP == B16_AR) {
+        /* a group that coordinates nothing (preempted, or never the coordinator) ignores every vote
+         * (PaxosCoordinator.java:196-198: c == null) */
+        const bool idle = (P.gf & (GF_EXISTS | GF_STOPPED | GF_HASCOORD)) == GF_EXISTS;
         bool el = c <= 8 && (P.gf & (GF_EXISTS | GF_STOPPED | GF_HASCOORD | GF_PREPARING)) == (GF_EXISTS | GF_HASCOORD) &&
                   it.b0n == P.my_bnum && it.b0c == P.my_bcoord;
-        if (el) {
+        if (idle) {
+          el = true;
+          nvote = 0;
+        } else if (el) {
+          bool have = false;
           for (int32_t i = 0; i < c; i++) {
             const uint32_t p = (uint32_t)start + (uint32_t)((it.order >> (4 * i)) & 15ull);
+            if (metaA[p] & V16_ESC) { /* another ballot than the batch's, or a node id beyond 16 bits */
+              esc = true;
+              const int32_t ix = idxA[p];
+              const int32_t cmp = ballot_cmp(in.bnum[ix], in.bcoord[ix], P.my_bnum, P.my_bcoord);
+              if (cmp < 0) {
+                skip |= 1u << i;
+                continue;
+              }
+              el = el && cmp == 0; /* a higher ballot preempts: general path */
+            }
             const int32_t sl = slotA[p];
-            if (i == 0) s0 = sl;
-            el = el && !(metaA[p] & V16_ESC) && sl == s0;
+            if (!have) s0 = sl;
+            have = true;
+            el = el && sl == s0;
+          }
+          if (have) {
+            const int32_t d = jsub(P.next, s0);
+            el = el && d >= 1 && d <= S.W;
           }
         }
-        const int32_t d = jsub(P.next, s0);
-        el = el && d >= 1 && d <= S.W;
         fast = __all(el);
       }
       if (fast) {
@@ -554,33 +578,42 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
           uint32_t e = e0;
           int32_t pcount = P.pcount;
           bool ns_dirty = false;
-          for (int32_t i = 0; i < c; i++) {
-            {
-              const uint32_t p = (uint32_t)start + (uint32_t)((it.order >> (4 * i)) & 15ull);
-              const int32_t acc = (int32_t)(metaA[p] >> 16), maxcp = cpA[p];
-              int32_t midx = -1;
+          auto vote = [&](int32_t i, uint32_t p, int32_t acc, int32_t maxcp) {
+            int32_t midx = -1;
 #pragma unroll
-              for (int q = 0; q < KMAX; q++) {
-                if (q < k && mem[q] == acc) {
-                  midx = q; /* WaitforUtility.getIndex: last match */
-                  if (ns[q] < maxcp) { /* recordSlotNumber :809-825 (plain <) */
-                    ns[q] = maxcp;
-                    ns_dirty = true;
-                  }
+            for (int q = 0; q < KMAX; q++) {
+              if (q < k && mem[q] == acc) {
+                midx = q; /* WaitforUtility.getIndex: last match */
+                if (ns[q] < maxcp) { /* recordSlotNumber :809-825 (plain <) */
+                  ns[q] = maxcp;
+                  ns_dirty = true;
                 }
               }
-              if (e & PR_PRESENT) {
-                if (midx >= 0) e |= (1u << midx);       /* updateHeardFrom :51-62 */
-                if (__popc(e & 0xffffu) > k / 2) {     /* heardFromMajority :64-68 */
-                  slotA[p] = s0;                       /* the decision, parked in the vote's own words */
-                  cpA[p] = median_minus<KMAX>(ns, k);
-                  metaA[p] = (uint32_t)GPX_D_DECISION;
-                  it.omask |= 1u << i;
-                  it.nout++;
-                  e = 0;
-                  pcount--;
-                }
+            }
+            if (e & PR_PRESENT) {
+              if (midx >= 0) e |= (1u << midx);       /* updateHeardFrom :51-62 */
+              if (__popc(e & 0xffffu) > k / 2) {     /* heardFromMajority :64-68 */
+                slotA[p] = s0;                       /* the decision, parked in the vote's own words */
+                cpA[p] = median_minus<KMAX>(ns, k);
+                metaA[p] = (uint32_t)GPX_D_DECISION;
+                it.omask |= 1u << i;
+                it.nout++;
+                e = 0;
+                pcount--;
               }
+            }
+          };
+          if (!__any(esc)) { /* the wave holds no escaped vote at all: nothing to step over, acceptors in the records */
+            for (int32_t i = 0; i < nvote; i++) {
+              const uint32_t p = (uint32_t)start + (uint32_t)((it.order >> (4 * i)) & 15ull);
+              vote(i, p, (int32_t)(metaA[p] >> 16), cpA[p]);
+            }
+          } else {
+            for (int32_t i = 0; i < nvote; i++) {
+              if ((skip >> i) & 1u) continue;
+              const uint32_t p = (uint32_t)start + (uint32_t)((it.order >> (4 * i)) & 15ull);
+              const uint32_t meta = metaA[p];
+              vote(i, p, (meta & V16_ESC) ? in.acceptor[idxA[p]] : (int32_t)(meta >> 16), cpA[p]);
             }
           }
           if (e != e0) S.p_ring[off] = e;

@@ -2,7 +2,7 @@
 OUT=gpurun_out/r3a
 mkdir -p $OUT
 timeout 900 python -m pytest tests/test_parity_gpu.py tests/test_fullsize_gpu.py -m gpu -x -q > $OUT/pytest_fast.log 2>&1; echo "pytest exit $?" >> $OUT/pytest_fast.log; tail -4 $OUT/pytest_fast.log | cut -c1-300
-for args in "" "--mix" "--k 5" "--k 5 --mix"; do
+for args in "" "" "--mix" "--k 5" "--k 5 --mix"; do
     timeout 300 python bench.py $args --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('[$args]', d['ms_per_step'], {k: round(v*1e3,1) for k,v in d['roofline']['kernels_ms_per_step'].items()})"
