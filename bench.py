@@ -68,6 +68,8 @@ def main():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    torch.zeros(1, device=dev)  # wake the device before the HIP library's own runtime looks for it
+    torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)

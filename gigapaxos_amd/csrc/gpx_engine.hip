@@ -6,6 +6,7 @@
  *   hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -o libgpx_hip.so gpx_engine.hip
  */
 #include <hip/hip_runtime.h>
+#include <unistd.h>
 
 #include <cstdio>
 #include <cstdlib>
@@ -448,10 +449,19 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   if (cfg->max_groups <= 0 || cfg->kmax < 1 || cfg->kmax > GPX_KMAX_LIMIT || cfg->max_batch <= 0)
     return GPX_EINVAL;
   if (cfg->window < 4 || cfg->window > 64 || (cfg->window & (cfg->window - 1))) return GPX_EINVAL;
+  /* A GPU that has just been powered up (fresh box, "device(s) in a low-power state") can answer the
+   * first runtime call with hipErrorNoDevice for a moment - seen once on the MI355X pool: wait for it
+   * for up to ~6 s before giving up. */
   int ndev = 0;
-  HIPCHK(hipGetDeviceCount(&ndev));
-  if (ndev <= 0) {
-    snprintf(g_err, sizeof(g_err), "no HIP device visible");
+  hipError_t de = hipErrorNoDevice;
+  for (int attempt = 0; attempt < 30; attempt++) {
+    de = hipGetDeviceCount(&ndev);
+    if (de == hipSuccess && ndev > 0) break;
+    (void)hipGetLastError();
+    usleep(200 * 1000);
+  }
+  if (de != hipSuccess || ndev <= 0) {
+    snprintf(g_err, sizeof(g_err), "no HIP device visible (%s)", de == hipSuccess ? "count 0" : hipGetErrorString(de));
     return GPX_EDEVICE;
   }
   gpx_engine* e = new gpx_engine();

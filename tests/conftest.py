@@ -27,6 +27,8 @@ def hip_lib():
 
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
+    torch.zeros(1, device="cuda:0")  # wake the device before the HIP library's own runtime looks for it
+    torch.cuda.synchronize()
     from gigapaxos_amd import load_hip
 
     return load_hip()
