@@ -390,7 +390,6 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
   lcnt[l] = 0;
   __syncthreads();
   /* A: votes per group.  The first four votes of a lane stay in registers for the placement. */
-#ifndef GPX_B16_REREAD
   Vote16 r0, r1, r2, r3;
   r0.meta = r1.meta = r2.meta = r3.meta = 0;
   r0.idx = r1.idx = r2.idx = r3.idx = 0;
@@ -408,9 +407,6 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
     if (j3 < nb) atomicAdd(&lcnt[r3.meta & V16_LG_MASK], 1);
     for (int32_t j = 4 * gb + l; j < nb; j += gb) atomicAdd(&lcnt[recG[j].meta & V16_LG_MASK], 1);
   }
-#else /* experiment: count from the meta words only, re-read the votes (L2) for the placement */
-  for (int32_t j = l; j < nb; j += gb) atomicAdd(&lcnt[recG[j].meta & V16_LG_MASK], 1);
-#endif
   __syncthreads();
   if (pre && g < X.g_end) coord_preload_ring<KMAX>(S, g, P);
   /* B: exclusive scan of the counts */
@@ -428,15 +424,11 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
       cpA[p] = v.maxcp;
       metaA[p] = v.meta;
     };
-#ifndef GPX_B16_REREAD
     if (l < nb) place(r0);
     if (gb + l < nb) place(r1);
     if (2 * gb + l < nb) place(r2);
     if (3 * gb + l < nb) place(r3);
     for (int32_t j = 4 * gb + l; j < nb; j += gb) place(recG[j]);
-#else
-    for (int32_t j = l; j < nb; j += gb) place(recG[j]);
-#endif
   } else {
     for (int32_t j = l; j < nb; j += gb) {
       const Vote16 v = recG[j];
