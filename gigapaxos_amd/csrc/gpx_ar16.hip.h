@@ -352,8 +352,8 @@ struct AcceptOut {
 #define B16_ACCEPT 1 /* ACCEPTs at an acceptor */
 #define B16_COMMIT 2 /* commits at every replica */
 template <int OP, int KMAX>
-__global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, DevScratch X, Stage16 O, VoteCols in,
-                                                   AcceptOut R, uint8_t* __restrict__ status) {
+__device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratch& X, const Stage16& O, const VoteCols& in,
+                                              const AcceptOut& R, uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   constexpr bool AC = OP != B16_AR;
   if (AC && *X.unsorted != X.epoch) return; /* ordered batch: k_ac_direct did it; nothing was partitioned */
@@ -662,6 +662,19 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
     }
     if (l == 0) X.bucket_nout[b] = tout;
   }
+}
+
+template <int OP, int KMAX>
+__global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, DevScratch X, Stage16 O, VoteCols in,
+                                                   AcceptOut R, uint8_t* __restrict__ status) {
+  bucket16_body<OP, KMAX>(S, X, O, in, R, status);
+}
+/* Five replicas (BASELINE config #4): the KMAX = 5 body needs 82 VGPRs left to itself - two over the step
+ * to 5 waves per SIMD = two workgroups per CU instead of three; held to 6 waves it gives up two registers
+ * to scratch instead. */
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_k5(
+    DevState S, DevScratch X, Stage16 O, VoteCols in, AcceptOut R, uint8_t* __restrict__ status) {
+  bucket16_body<B16_AR, 5>(S, X, O, in, R, status);
 }
 
 /* staged columns -> the caller's columns, buckets in order */

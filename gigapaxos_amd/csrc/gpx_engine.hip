@@ -615,7 +615,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   if (e->ar16) {
     const size_t hw16 = GPX_BUCKET16_LDS_BYTES((size_t)1 << e->shift16, e->lds16_hw) + e->lds_pad;
-    const void* fns[] = {(const void*)k_bucket16<B16_AR, 4>, (const void*)k_bucket16<B16_AR, 8>,
+    const void* fns[] = {(const void*)k_bucket16<B16_AR, 4>, (const void*)k_bucket_ar16_k5, (const void*)k_bucket16<B16_AR, 8>,
                          (const void*)k_bucket16<B16_AR, 16>, (const void*)k_bucket16<B16_ACCEPT, 4>,
                          (const void*)k_bucket16<B16_COMMIT, 4>};
     for (const void* f : fns)
@@ -916,6 +916,8 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
       if (passes == 1 && !e->pipe_light) begin_back(e, fs, n, true);
       if (e->cfg.kmax <= 4)
         launch_bucket_ar16<4>(e, O, in, status);
+      else if (e->cfg.kmax <= 5) /* five replicas (BASELINE config #4): its own kernel, held to 80 VGPRs */
+        LAUNCH_B(e, "k_bucket_ar16", k_bucket_ar16_k5, e->S, e->X, O, in, AcceptOut{}, status);
       else if (e->cfg.kmax <= 8)
         launch_bucket_ar16<8>(e, O, in, status);
       else
