@@ -16,12 +16,14 @@ import numpy as np
 from gigapaxos_amd import Engine, hri_create, S_OK, D_DECISION, D_PREEMPTED
 
 
-def model(members, me, nprop, coins):
+def model(members, me, nprop, coins, maxcps=None, init_node_slots=None):
     """coins[(slot_index, member_index)] = True -> the reply carries ballot (myBallotNum + 1, me).
+    maxcps[(slot_index, member_index)] = the reply's maxCheckpointedSlot (main passes -1 everywhere);
+    init_node_slots = nodeSlotNumbers at the start (createHRI: zeros).
     Returns the list of (vote index, slot, bnum, bcoord, median, kind) outputs in arrival order."""
     K = len(members)
     my = (0, me)                       # createHRI: coordBallot (0, coordinator)
-    node_slots = [0] * K               # createHRI: new int[members.length]
+    node_slots = list(init_node_slots) if init_node_slots is not None else [0] * K  # createHRI: new int[members.length]
     proposals = {s: [False] * K for s in range(1, nprop + 1)}  # slot -> WaitforUtility.responded
     coordinator = True
     out = []
@@ -29,7 +31,7 @@ def model(members, me, nprop, coins):
     for si, slot in enumerate(range(1, nprop + 1)):
         for j in range(K):
             ballot = (my[0] + 1, my[1]) if coins[(si, j)] else my
-            maxcp = -1                                           # main passes -1
+            maxcp = -1 if maxcps is None else maxcps[(si, j)]    # main passes -1
             if coordinator:
                 if ballot > my:                                  # Ballot.compareTo > 0
                     if slot in proposals:                        # handleAcceptReplyHigherBallot
@@ -53,7 +55,7 @@ def model(members, me, nprop, coins):
                             del proposals[slot]
                             out.append((v, slot, my[0], my[1], med, D_DECISION))
             v += 1
-    return out, proposals, coordinator
+    return out, proposals, coordinator, node_slots
 
 
 def run_all(lib, K, nprop):
@@ -75,7 +77,7 @@ def run_all(lib, K, nprop):
     expect = []
     for p, bits in enumerate(itertools.product((False, True), repeat=len(keys))):
         coins = dict(zip(keys, bits))
-        out, left, coord = model(members, me, nprop, coins)
+        out, left, coord, _ = model(members, me, nprop, coins)
         # main's own assertions on the model's run
         assert not left or not coord                      # `assert (pcs.myProposals.isEmpty())`: every slot is
         # decided or preempted unless the coordinator resigned first (PISM level; main calls PCS directly)
@@ -104,3 +106,73 @@ def run_all(lib, K, nprop):
     assert gi == got.shape[0]
     e.close()
     return checked
+
+
+MAXCP_CHOICES = ("-1", "0", "slot-1", "slot")
+
+
+def run_maxcp(lib, K, nprop, init_node_slots, sample=None, seed=0):
+    """The same replay with recordSlotNumber (PCS:809-825) and a non-trivial getMedianMinus (PCS:859-875) in
+    play: every vote also draws its maxCheckpointedSlot from {-1, 0, slot - 1, slot} and nodeSlotNumbers
+    starts from `init_node_slots` (a hot-restored coordinator, PaxosCoordinator.java:122-131) - 8^(K * nprop)
+    patterns, all of them or a seeded `sample`.  Checks the decided stream AND the final nodeSlotNumbers /
+    coordinator flag of every group (late votes change the median of later decisions: PCS:607 runs before
+    the pstate == null test of :618).  Returns the number of patterns checked."""
+    members = list(range(21, 21 + 3 * K, 3))[:K]
+    me = members[0]
+    keys = [(si, j) for si in range(nprop) for j in range(K)]
+    nk = len(keys)
+    total = 8 ** nk
+    if sample is not None and sample < total:
+        picks = np.random.default_rng(seed).choice(total, size=sample, replace=False)
+    else:
+        picks = np.arange(total)
+    G = int(picks.shape[0])
+    e = Engine(lib, me, G, kmax=K, window=8, max_batch=G * nk + 16)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    rows = hri_create(G, K, me)
+    rows["node_slots"][:, :K] = np.array(init_node_slots, np.int32)
+    assert (e.create_groups(np.arange(G), mem, K, rows) == S_OK).all()
+    for _ in range(nprop):
+        assert (e.propose(np.arange(G, dtype=np.int32))[4] == S_OK).all()
+    cols = [np.zeros(G * nk, np.int32) for _ in range(6)]
+    expect, final = [], []
+    for p, code in enumerate(picks.tolist()):
+        coins, maxcps = {}, {}
+        for key in keys:                                   # one octal digit per vote: coin * 4 + maxcp choice
+            d = code & 7
+            code >>= 3
+            coins[key] = bool(d >> 2)
+            slot = key[0] + 1
+            maxcps[key] = (-1, 0, slot - 1, slot)[d & 3]
+        out, left, coord, ns = model(members, me, nprop, coins, maxcps, init_node_slots)
+        expect.append(out)
+        final.append((coord, ns))
+        for v, key in enumerate(keys):
+            i = p * nk + v
+            cols[0][i] = p
+            cols[1][i] = 1 if coins[key] else 0
+            cols[2][i] = me
+            cols[3][i] = key[0] + 1
+            cols[4][i] = members[key[1]]
+            cols[5][i] = maxcps[key]
+    order = np.argsort(np.arange(G * nk) % nk, kind="stable")  # interleave the groups, stable per group
+    d = e.accept_reply(*[c[order] for c in cols])
+    got = d.as_tuple_array()
+    gi = 0
+    for p, out in enumerate(expect):
+        rows_p = got[gi:gi + len(out)]
+        want = np.array([(p,) + o[1:] for o in out], np.int32).reshape(-1, 6)
+        assert rows_p.shape == want.shape and (rows_p == want).all(), \
+            f"pattern {int(picks[p])}: {rows_p.tolist()} != {want.tolist()}"
+        gi += len(out)
+    assert gi == got.shape[0]
+    snap, st = e.snapshot(np.arange(G))
+    assert (st == S_OK).all()
+    want_coord = np.array([1 if c else 0 for c, _ in final], np.int32)
+    assert (snap["has_coord"] == want_coord).all()
+    want_ns = np.array([ns for _, ns in final], np.int32)
+    live = want_coord == 1                                  # HotRestoreInfo shows nodeSlots of a live coordinator only
+    assert (snap["node_slots"][:, :K][live] == want_ns[live]).all()
+    e.close()
+    return G

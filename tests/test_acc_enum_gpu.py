@@ -1,0 +1,40 @@
+"""The acceptor side of the HIP engine against an independent Python reading of the Java
+(tests/acc_enum_common.py: PaxosAcceptor.java:302-385, 462-506; PaxosInstanceStateMachine.java:1080-1166,
+1432-1528, 1619-1701), bounded exhaustive: every sequence of ACCEPT / DECISION / batched-commit ops of
+length <= 2 over 300 ops, every length-3 sequence over 90 ops, every length-4 sequence over 22 ops,
+seeded random sequences of length 5 and 6 - one group per sequence, a group's consecutive same-call ops in
+one batch, batches both interleaved (partition path) and grouped by group (direct path)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_acceptor_side_enumerated_against_java_reading_gpu(hip_lib):
+    import tests.acc_enum_common as A
+    for k in A.COVERAGE:
+        A.COVERAGE[k] = 0
+    n = A.run_plan(hip_lib, scale=1.0)
+    n += A.run_plan(hip_lib, scale=0.05, from_disk=(False,))
+    assert n > 8_000_000
+    assert all(v > 0 for v in A.COVERAGE.values()), A.COVERAGE
+
+
+def test_acceptor_side_enumerated_under_the_ordered_promise(hip_lib):
+    """The same readings with gpx_engine_set_ordered_batches(ACCEPT | COMMIT): grouped batches keep the
+    promise, so only the direct kernels run (no partition path launched behind them)."""
+    import tests.acc_enum_common as A
+    n = A.run_plan(hip_lib, scale=0.1, orders=("grouped",), promise=True)
+    assert n > 400_000
+
+
+@pytest.mark.parametrize("K,nprop,init,sample", [(3, 2, [1, 0, 2], None), (4, 1, [2, 0, 1, 0], None),
+                                                 (5, 1, [0, 2, 1, 0, 3], None), (4, 2, [0, 1, 0, 2], 200_000),
+                                                 (3, 3, [2, 1, 0], 200_000), (5, 2, [3, 0, 1, 2, 0], 200_000)])
+def test_pcs_accept_reply_tail_with_checkpoint_slots_enumerated_on_engine(hip_lib, K, nprop, init, sample):
+    """PaxosCoordinatorState.main's accept-reply tail (PCS:1173-1213) with the coin AND every vote's
+    maxCheckpointedSlot in {-1, 0, slot - 1, slot} enumerated, nodeSlotNumbers starting non-zero: recordSlotNumber
+    (PCS:809-825, plain <) and getMedianMinus (PCS:859-875) against tests/pcs_enum_common.py's reading of the
+    Java - decided stream, final nodeSlotNumbers and coordinator flag of every pattern."""
+    from tests.pcs_enum_common import run_maxcp
+    n = run_maxcp(hip_lib, K, nprop, init, sample=sample, seed=K * 10 + nprop)
+    assert n == (sample if sample else 8 ** (K * nprop))

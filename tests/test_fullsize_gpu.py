@@ -96,6 +96,53 @@ def test_config5_churn_1m_live_groups_vs_oracle(hip_lib, oracle_lib):
     assert eh.counters() == eo.counters()
 
 
+def _churn_across_ranges(hip_lib, oracle_lib, G_live, k, R, seed):
+    """Config #5 on ONE engine whose table needs several group-range passes per accept-reply call
+    (more than 4 M groups: 4096 buckets of 1024 groups per pass).  The free list holds exactly one
+    round's worth of rows, so the rows retired in round r are re-created at the end of round r + 1
+    and vote again (slot 1) in round r + 2: late votes reach retired rows of EVERY range while
+    fresh and re-created rows live in other ranges (the first fresh rows sit at the top of the
+    table = the last range; re-created ones wherever the victims were).  Reference behaviour: a
+    packet for a killed instance is dropped (PaxosManager.java:1162-1194,
+    PaxosInstanceStateMachine.java:441-447); a re-created one starts from its createHRI row
+    (HotRestoreInfo.java:145-157)."""
+    n_ret = max(1, int(G_live * 0.001))
+    cap = G_live + n_ret
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, cap, k, 8, max_batch=(G_live + n_ret) * k + 4096)
+    (oh, oo), live = churn_run([eh, eo], G_live, cap, R, k, seed=seed, churn_frac=0.001)
+    range_of = lambda g: np.asarray(g) >> 22  # noqa: E731  (4 M groups per pass)
+    for r, (a, b) in enumerate(zip(oh, oo)):
+        for x, y, nm in zip(a, b, ("decisions", "vote status", "propose out", "propose status",
+                                    "retired rows", "retire status", "create status")):
+            if isinstance(x, bytes):
+                assert x == y, f"round {r} {nm}"
+            else:
+                assert x.shape == y.shape and (x == y).all(), f"round {r} {nm}"
+        assert a[0].shape[0] == G_live, f"round {r}: one decision per live group"
+        assert (np.diff(a[0][:, 0]) > 0).all(), f"round {r}: decisions grouped by gidx ascending across the passes"
+        assert len(np.unique(range_of(a[0][:, 0]))) == (cap + (1 << 22) - 1) >> 22
+        if r > 0:
+            assert (a[1] == S_NOGROUP).sum() == k * n_ret  # the late votes, every range
+        if r >= 2:
+            assert (a[0][:, 1] == 1).sum() >= n_ret  # re-created rows decide their slot 1 again
+    sh, so = eh.snapshot(np.arange(cap))[0], eo.snapshot(np.arange(cap))[0]
+    assert sh.tobytes() == so.tobytes()
+    assert eh.counters() == eo.counters()
+    eh.close()
+    eo.close()
+
+
+def test_config5_churn_10m_live_groups_three_range_passes_vs_oracle(hip_lib, oracle_lib):
+    """BASELINE config #5 at the size it states: 10,000,000 live groups (K = 3) on one engine, three
+    group-range passes per accept-reply call, 0.1 % retire / create per round, three rounds."""
+    _churn_across_ranges(hip_lib, oracle_lib, 10_000_000, 3, R=3, seed=11)
+
+
+def test_config5_churn_5m_live_groups_k5_two_range_passes_vs_oracle(hip_lib, oracle_lib):
+    """The same with five replicas (config #4's group size): 5,000,000 live groups, two passes."""
+    _churn_across_ranges(hip_lib, oracle_lib, 5_000_000, 5, R=3, seed=12)
+
+
 @pytest.mark.parametrize("order", ["grouped by group", "shuffled"])
 def test_full_round_1m_groups_vs_oracle(hip_lib, oracle_lib, order):
     """The whole pipeline on one replica at 1 M groups: propose -> its own ACCEPTs (handleAccept,

@@ -447,3 +447,32 @@ def test_pcs_main_accept_reply_tail_every_coin(oracle_lib, K, nprop):
     2^(K * nprop) reply patterns, the oracle against a statement-by-statement Python reading of the Java."""
     from tests.pcs_enum_common import run_all
     assert run_all(oracle_lib, K, nprop) == 1 << (K * nprop)
+
+
+def test_acceptor_side_enumerated_against_java_reading(oracle_lib):
+    """The acceptor side (handleAccept, handleBatchedCommit, handleCommittedRequest,
+    extractExecuteAndCheckpoint, putAndRemoveNextExecutable, reconstructDecision, executed, both garbage
+    collectors: PaxosAcceptor.java:302-385, 462-506; PISM:1080-1166, 1432-1528, 1619-1701) as a
+    statement-by-statement Python reading of the Java (tests/acc_enum_common.py, written from the
+    reference, not from the oracle): every op sequence of length <= 2 over 300 ops, a seeded 30 % of the
+    length-3 / length-4 sequences over smaller alphabets (the GPU test runs all of them) and seeded random
+    sequences of length 5 and 6 - every reply, status, execution run, final row and (sampled) the maps."""
+    import tests.acc_enum_common as A
+    for k in A.COVERAGE:
+        A.COVERAGE[k] = 0
+    n = A.run_plan(oracle_lib, scale=0.3)
+    n += A.run_plan(oracle_lib, scale=0.03, from_disk=(False,))  # GET_ACCEPTED_PVALUES_FROM_DISK = false
+    assert n > 2_000_000
+    assert all(v > 0 for v in A.COVERAGE.values()), A.COVERAGE
+
+
+@pytest.mark.parametrize("K,nprop,init,sample", [(3, 1, [0, 0, 0], None), (3, 2, [1, 0, 2], None), (4, 1, [2, 0, 1, 0], None),
+                                                 (5, 1, [0, 2, 1, 0, 3], None), (4, 2, [0, 1, 0, 2], 60_000),
+                                                 (3, 3, [2, 1, 0], 60_000)])
+def test_pcs_accept_reply_tail_with_checkpoint_slots_enumerated(oracle_lib, K, nprop, init, sample):
+    """The enumeration above with recordSlotNumber and a non-trivial median in play: every vote also draws
+    its maxCheckpointedSlot from {-1, 0, slot - 1, slot}, nodeSlotNumbers starts non-zero (8^(K * nprop)
+    patterns, or a seeded sample of them)."""
+    from tests.pcs_enum_common import run_maxcp
+    n = run_maxcp(oracle_lib, K, nprop, init, sample=sample, seed=K * 10 + nprop)
+    assert n == (sample if sample else 8 ** (K * nprop))
