@@ -39,6 +39,10 @@ def main():
     ap.add_argument("--groups", type=int, default=1_000_000, help="groups per GPU")
     ap.add_argument("--k", type=int, default=3, help="replicas per group")
     ap.add_argument("--sorted", action="store_true", help="votes sorted by group instead of shuffled")
+    ap.add_argument("--runs", action="store_true",
+                    help="side figure, not the headline: the votes as K ascending runs (the acceptors' replies "
+                         "concatenated, what a coordinator really receives) under the GPX_ORDERED_REPLY_RUNS "
+                         "promise - the sorted-runs path, no partition")
     ap.add_argument("--mix", action="store_true", help="adversarial mix (dups / stale / higher ballot)")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--cpu-rounds", type=int, default=8)
@@ -53,9 +57,6 @@ def main():
                          "engine over its shard: total work fixed -> strong scaling")
     ap.add_argument("--no-promise", action="store_true",
                     help="do not declare the proposal batches ordered (gpx_engine_set_ordered_batches)")
-    ap.add_argument("--pipelined", action="store_true",
-                    help="cross-call pipelining (front end of call N+1 beside the back end of call N on two "
-                         "streams); off by default: measured slower than one stream since round 2")
     args = ap.parse_args()
 
     import torch
@@ -87,6 +88,8 @@ def main():
     steps, warmup, psteps = args.steps, args.warmup, args.profile_steps
     rounds = warmup + steps + psteps
     nv_round = G * K + (G * K // 100 + G * K // 200 + G * K // 1000 if args.mix else 0)
+    if args.runs and args.mix:
+        nv_round = G * K + G * K // 40  # duplicates are drawn per vote: a little slack
     eng = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
     # a dedicated (non-default) torch stream carries every engine launch, so torch.cuda.Event
     # and the engine's own hipEvents observe the same stream
@@ -94,14 +97,11 @@ def main():
     torch.cuda.set_stream(tstream)
     assert tstream.cuda_stream != 0
     eng.set_stream(tstream.cuda_stream)
-    # pipelined mode (include/gpx.h): the partition front end of call N+1 overlaps the per-bucket
-    # back end of call N on two engine streams; group state is still updated in call order
-    eng.set_pipeline(args.pipelined)
     if not args.no_promise:
         # the proposal batch is one request per group in gidx order (what RequestBatcher hands over):
         # declared, verified on the device, so the partition path is not even launched for it
-        from gigapaxos_amd import ORDERED_PROPOSE
-        eng.set_ordered_batches(ORDERED_PROPOSE)
+        from gigapaxos_amd import ORDERED_PROPOSE, ORDERED_REPLY_RUNS
+        eng.set_ordered_batches(ORDERED_PROPOSE | (ORDERED_REPLY_RUNS if args.runs else 0))
     mem = np.tile(np.array(members, np.int32), (G, 1))
     assert (eng.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
 
@@ -114,7 +114,8 @@ def main():
     pool_n = min(rounds, 8)
     pool = []
     for r in range(pool_n):
-        cols = streams.vote_round(G, members, r, 100, config_id=cfg_id, shuffled=not args.sorted, mix=args.mix)
+        cols = (streams.vote_round_runs(G, members, r, 100, config_id=cfg_id, mix=args.mix) if args.runs else
+                streams.vote_round(G, members, r, 100, config_id=cfg_id, shuffled=not args.sorted, mix=args.mix))
         pool.append([torch.from_numpy(c).to(dev) for c in cols])
     nv = int(pool[0][0].shape[0])
     vote_cols = []
@@ -153,7 +154,6 @@ def main():
     ev0.record()
     for r in range(warmup, warmup + steps):
         step(r)
-    eng.fence()  # order the caller's stream (and ev1) behind everything submitted
     ev1.record()
     eng.sync()
     torch.cuda.synchronize()
@@ -188,9 +188,7 @@ def main():
     roofline = None
     kstats = {}
     if psteps > 0:
-        # per-kernel durations are taken WITHOUT cross-call overlap (each kernel alone on the GPU)
         eng.sync()
-        eng.set_pipeline(False)
         eng.profile(2)
         for r in range(warmup + steps, rounds):
             step(r)
@@ -413,7 +411,6 @@ def main():
             "votes_per_sec": round(votes_total / elapsed, 1),
             "votes_per_sec_per_gpu": round(votes_total / elapsed / world, 1),
             "gpu_ms_per_step_rank0": round(gpu_ms / steps, 4),
-            "pipelined": bool(args.pipelined),
             "roofline": roofline,
             "end_to_end": end_to_end,
             "cpu_baseline": cpu_baseline,

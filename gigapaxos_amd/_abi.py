@@ -24,6 +24,7 @@ KMAX_LIMIT = 16
 S_OK, S_NOGROUP, S_STOPPED, S_WINDOW, S_FORWARD, S_REFUSED, S_EXISTS, S_BUSY = range(8)
 S_UNORDERED = 9
 ORDERED_PROPOSE, ORDERED_ACCEPT, ORDERED_COMMIT = 1, 2, 4
+ORDERED_REPLY_RUNS, TRY_REPLY_RUNS = 8, 16
 D_DECISION, D_PREEMPTED = 1, 2
 R_TOLOG, R_STORED = 1, 2
 A_STOP = 1
@@ -97,8 +98,6 @@ _SIGS = {
 }
 _DEV_SIGS = {
     "engine_set_stream": [_VP],
-    "engine_set_pipeline": [C.c_int32],
-    "engine_fence": [],
     "propose_batch_dev": [C.c_int32] + [_VP] * 7,
     "accept_batch_dev": [C.c_int32] + [_VP] * 15,
     "accept_reply_batch_dev": [C.c_int32] + [_VP] * 14,
@@ -367,7 +366,9 @@ class Engine:
 
     def set_ordered_batches(self, mask: int):
         """Promise (verified on the device) that later propose / accept / commit batches come grouped
-        by group, groups ascending: only the direct path is launched (gpx_engine_set_ordered_batches)."""
+        by group, groups ascending: only the direct path is launched (gpx_engine_set_ordered_batches).
+        ORDERED_REPLY_RUNS: accept-reply batches are a few ascending runs (the acceptors' replies
+        concatenated); TRY_REPLY_RUNS: a hint, checked on the device, any other batch is partitioned."""
         self.lib.check(self.lib.fn["engine_set_ordered_batches"](self.h, int(mask)), "engine_set_ordered_batches")
 
     # -- device-pointer path (batches already resident in HBM) ----------------------
@@ -375,14 +376,6 @@ class Engine:
         """Run the *_dev calls on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
         self.lib.check(self.lib.fn["engine_set_stream"](self.h, _VP(hip_stream_handle or None)),
                        "engine_set_stream")
-
-    def set_pipeline(self, on: bool):
-        """Overlap the streaming front end of call N+1 with the back end of call N (*_dev calls)."""
-        self.lib.check(self.lib.fn["engine_set_pipeline"](self.h, int(bool(on))), "engine_set_pipeline")
-
-    def fence(self):
-        """Pipelined mode: order later work on the caller's stream behind everything submitted."""
-        self.lib.check(self.lib.fn["engine_fence"](self.h), "engine_fence")
 
     def call_dev(self, name: str, n: int, *ptrs):
         """Raw asynchronous call of gpx_<name>_dev with integer device addresses (0 = NULL)."""

@@ -79,6 +79,7 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ar16(
   extern __shared__ int32_t lds[];
   const int32_t tile = tile_of_block(ntiles);
   if (tile >= ntiles) return;
+  if (X.gate && *X.unsorted != X.epoch) return; /* a few sorted runs: k_ar_runs did it (gpx_runs.hip.h) */
   const int32_t b0n = bnum[0], b0c = bcoord[0];
   scatter_init(X, tile, lds);
   const int64_t base = (int64_t)tile * GPX_TILE;
@@ -191,6 +192,7 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ac16(
 /* dynamic LDS of k_bucket_ar16: lcnt[gb] | lcur[gb] | idx[L] | slot[L] | maxcp[L] | meta[L] */
 #define GPX_BUCKET16_LDS_BYTES(gb, lds_recs) ((size_t)(gb) * 8 + (size_t)(lds_recs) * 16)
 #define V16_NIB_MAX 16 /* a group's arrival order fits a 64-bit nibble word up to this many votes */
+#define V16_LANE_SORT 96 /* longer LDS-staged segments, up to this many votes, are ordered by their own lane */
 
 /* One group's votes in arrival order, with GroupIter's interface (next / emit / c) so that
  * apply_ar_group replays them unchanged.
@@ -356,7 +358,8 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
                                               const AcceptOut& R, uint8_t* __restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   constexpr bool AC = OP != B16_AR;
-  if (AC && *X.unsorted != X.epoch) return; /* ordered batch: k_ac_direct did it; nothing was partitioned */
+  /* ordered batch: k_ac_direct did it (a few sorted runs of votes: k_ar_runs); nothing was partitioned */
+  if ((AC || X.gate) && *X.unsorted != X.epoch) return;
   const int32_t b = blockIdx.x;
   const int32_t boff = X.bucket_off[b];
   const int32_t nb = X.bucket_off[b + 1] - boff;
@@ -438,10 +441,21 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     }
   }
   __syncthreads();
-  /* D: segments that do not fit the nibble word (or a bucket in global mode): sorted keys in
-   * global scratch; rare, a single hot group is serial by contract */
+  /* D: segments that do not fit the nibble word (or a bucket in global mode): sorted keys in global
+   * scratch.  A segment of up to V16_LANE_SORT votes staged in LDS is ordered by ITS OWN lane (rank by
+   * counting over the arrival indices in LDS: a call that brings many rounds of votes at once has 17+
+   * votes in most groups, and taking those groups one at a time through the cooperative sort below was
+   * the 13x cliff at 2^24 votes per call of round 2's batch sweep); only a really hot group - serial by
+   * contract, like the Java monitor - is sorted by the whole workgroup. */
   if (any_long) {
-    if (in_lds && c > V16_NIB_MAX) {
+    if (in_lds && c > V16_NIB_MAX && c <= V16_LANE_SORT) {
+      for (int32_t t = 0; t < c; t++) {
+        const uint32_t it_ = (uint32_t)idxA[start + t];
+        int32_t r = 0;
+        for (int32_t u = 0; u < c; u++) r += (uint32_t)idxA[start + u] < it_;
+        keysG[start + r] = ((unsigned long long)it_ << 32) | (uint32_t)(start + t);
+      }
+    } else if (in_lds && c > V16_LANE_SORT) {
       for (int32_t t = 0; t < c; t++)
         keysG[start + t] = ((unsigned long long)(uint32_t)idxA[start + t] << 32) | (uint32_t)(start + t);
     } else if (!in_lds && c > 1 && c <= V16_NIB_MAX) { /* short segment in global mode: this lane */
@@ -456,12 +470,15 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
         a[p + 1] = x;
       }
     }
-    __syncthreads();
-    for (int32_t q = 0; q < gb; q++) {
-      const int32_t cq = lcnt[q]; /* uniform */
-      if (cq > V16_NIB_MAX) sort_long_segment(keysG + (lcur[q] - cq), (uint32_t)cq);
+    const int32_t coop = __syncthreads_or(in_lds ? c > V16_LANE_SORT : c > V16_NIB_MAX);
+    if (coop) {
+      const int32_t lim = in_lds ? V16_LANE_SORT : V16_NIB_MAX;
+      for (int32_t q = 0; q < gb; q++) {
+        const int32_t cq = lcnt[q]; /* uniform */
+        if (cq > lim) sort_long_segment(keysG + (lcur[q] - cq), (uint32_t)cq);
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   /* E: replay, one lane per group */
   int32_t nout = 0;
@@ -685,6 +702,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec16(
     int32_t* chain_out) {
   /* base_in: outputs of the passes before this one (accept-reply calls over more than 4 M groups run
    * one pass per group range, ranges ascending: the concatenation is still grouped by gidx ascending) */
+  if (X.gate && *X.unsorted != X.epoch) return; /* k_emit_dec_runs wrote the outputs (gpx_runs.hip.h) */
   const int32_t base0 = base_in ? *base_in : 0;
   const int32_t b = blockIdx.x;
   int32_t before = 0;

@@ -14,9 +14,18 @@
  * (device-side choice on *X.unsorted, like the proposal path).
  *
  * Compacted outputs (execution runs): a record produces at most one run; it is parked at the
- * record's own index (st_count == 0: none) and counted per 1024-record chunk; k_emit_runs_direct
- * compacts chunk by chunk - record order is already the output order (gidx ascending, a group's
- * entries in array order).
+ * record's own index (tag[i] == the call's epoch: record i holds one) and counted per 1024-record
+ * chunk; k_emit_runs_direct compacts chunk by chunk - record order is already the output order (gidx
+ * ascending, a group's entries in array order).
+ *
+ * Round 3: the kernel is bound by dependent round trips, not by bytes (profiles/
+ * r03_pmc_full_round_ordered_before.txt: 92 MB of traffic for 81 MB algorithmic, SQ_WAIT_ANY 77 % of the
+ * wave cycles), so its loads go out in three waves instead of one after the other: the lane's neighbours
+ * in gidx and its own record columns; then the group's acceptor state together with the ring entry of the
+ * record's slot (one 16-byte entry = accepted pvalue + both rings' flags, AccView); then whatever the
+ * garbage collection looks at.  No per-record clearing store (an epoch tag says which records hold a
+ * run), 256-thread workgroups (finer tail), and a commit that is executable at once is never written
+ * to the committed ring and read back (acc_eec).
  */
 #pragma once
 #include "gpx_kernels.hip.h"
@@ -24,8 +33,11 @@
 #define GPX_DCHUNK_SHIFT 10
 #define GPX_DCHUNK (1 << GPX_DCHUNK_SHIFT)
 
+#define GPX_DBLOCK 256 /* threads of a k_ac_direct workgroup: GPX_DCHUNK / GPX_DBLOCK of them per chunk */
+
 struct DirectStage {
   int32_t *st_first, *st_count; /* [n] run parked at the record that produced it */
+  uint32_t* tag;                /* [n] == the call's epoch: record i holds a parked run */
   int32_t* chunk_cnt;           /* [ceil(n / 1024)] runs per chunk; zeroed before the call */
 };
 
@@ -34,13 +46,33 @@ struct RunIter {
   const int32_t *gidx, *bnum, *bcoord, *slot, *median;
   const uint8_t* flags;
   DirectStage D;
+  uint32_t epoch;
   int32_t n, i, g, cur, chunk, local;
   bool count_chunks = true; /* k_ac_direct counts runs per chunk; the single-launch kernel reads the parking */
   uint8_t* st = nullptr;    /* single-launch kernel: no status prefill pass ran - the lane that replays a
                              * record marks it OK before it judges it (a prefill by the record's own lane
                              * would race with the head's verdict, across waves and across workgroups) */
+  /* the head's own record, fetched by the kernel ahead of the group state; g_next = gidx[head + 1]
+   * (or ~g at the end of the batch): a run of one record never touches memory here */
+  bool have_first = false;
+  int32_t f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
+  int32_t head = -2, g_next = 0;
   __device__ __forceinline__ bool next(Rec& out) {
-    if (i >= n || gidx[i] != g) return false;
+    if (have_first) {
+      have_first = false;
+      out.idx = i;
+      out.a = f_a;
+      out.b = f_b;
+      out.c = f_c;
+      out.bnum = f_bnum;
+      out.bcoord = f_bcoord;
+      cur = i;
+      if (st) st[i] = GPX_S_OK;
+      i++;
+      return true;
+    }
+    if (i >= n) return false;
+    if ((i == head + 1 ? g_next : gidx[i]) != g) return false;
     cur = i;
     out.idx = i;
     out.a = slot[i];
@@ -48,14 +80,14 @@ struct RunIter {
     out.c = flags ? (int32_t)flags[i] : 0;
     out.bnum = bnum[i];
     out.bcoord = bcoord[i];
-    D.st_count[i] = 0;
     if (st) st[i] = GPX_S_OK;
     i++;
     return true;
   }
-  __device__ __forceinline__ void emit(int32_t, int32_t first, int32_t count, int32_t, int32_t) {
-    D.st_first[cur] = first;
+  __device__ __forceinline__ void emit(int32_t, int32_t first_slot, int32_t count, int32_t, int32_t) {
+    D.st_first[cur] = first_slot;
     D.st_count[cur] = count; /* > 0 */
+    D.tag[cur] = epoch;
     if (!count_chunks) return;
     if ((cur >> GPX_DCHUNK_SHIFT) == chunk)
       local++;
@@ -65,13 +97,13 @@ struct RunIter {
 };
 
 template <bool COMMIT>
-__global__ __launch_bounds__(GPX_DCHUNK) void k_ac_direct(
+__global__ __launch_bounds__(GPX_DBLOCK) void k_ac_direct(
     DevState S, DevScratch X, int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
     const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot, const int32_t* __restrict__ median,
     const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status,
     DirectStage D, int32_t refuse) {
-  const int32_t i = (int32_t)blockIdx.x * GPX_DCHUNK + (int32_t)threadIdx.x;
+  const int32_t i = (int32_t)blockIdx.x * GPX_DBLOCK + (int32_t)threadIdx.x;
   if (*X.unsorted == X.epoch) {
     /* not ordered: the partition path does it - or, under the caller's GPX_ORDERED_* promise (no
      * partition path launched), the batch is refused whole */
@@ -88,8 +120,16 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_direct(
   }
   int32_t local = 0;
   if (i < n) {
+    /* wave 1 of loads: the neighbours in gidx and this record's columns (independent of each other) */
     const int32_t g = gidx[i];
-    if (i == 0 || gidx[i - 1] != g) { /* head of its group's run */
+    const int32_t g_prev = i > 0 ? gidx[i - 1] : ~g;
+    const int32_t g_next = i + 1 < n ? gidx[i + 1] : ~g;
+    const int32_t f_a = slot[i], f_b = median[i], f_c = flags ? (int32_t)flags[i] : 0;
+    const int32_t f_bnum = bnum[i], f_bcoord = bcoord[i];
+    if (g_prev != g) { /* head of its group's run */
+      /* wave 2: the group's acceptor state and the ring entry of this record's slot */
+      AccPre P;
+      acc_preload(S, g, f_a, P);
       RunIter it;
       it.gidx = gidx;
       it.bnum = bnum;
@@ -98,21 +138,30 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_direct(
       it.median = median;
       it.flags = flags;
       it.D = D;
+      it.epoch = X.epoch;
       it.n = n;
       it.i = i;
       it.g = g;
       it.cur = i;
-      it.chunk = (int32_t)blockIdx.x;
+      it.chunk = i >> GPX_DCHUNK_SHIFT;
       it.local = 0;
+      it.have_first = true;
+      it.f_a = f_a;
+      it.f_b = f_b;
+      it.f_c = f_c;
+      it.f_bnum = f_bnum;
+      it.f_bcoord = f_bcoord;
+      it.head = i;
+      it.g_next = g_next;
       if (COMMIT)
-        apply_commit_group(S, X, g, it, status);
+        apply_commit_group(S, X, g, it, status, P);
       else
-        apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+        apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status, nullptr, P);
       local = it.local;
     }
   }
-  /* this chunk's own runs: one atomic per workgroup */
-  __shared__ int32_t wsum[GPX_DCHUNK / 64];
+  /* this workgroup's runs inside its own chunk: one atomic per workgroup */
+  __shared__ int32_t wsum[GPX_DBLOCK / 64];
   int32_t x = local;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
@@ -120,8 +169,8 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_direct(
   __syncthreads();
   if (threadIdx.x == 0) {
     int32_t tot = 0;
-    for (int w = 0; w < GPX_DCHUNK / 64; w++) tot += wsum[w];
-    if (tot) atomicAdd(&D.chunk_cnt[blockIdx.x], tot);
+    for (int w = 0; w < GPX_DBLOCK / 64; w++) tot += wsum[w];
+    if (tot) atomicAdd(&D.chunk_cnt[((int64_t)blockIdx.x * GPX_DBLOCK) >> GPX_DCHUNK_SHIFT], tot);
   }
 }
 
@@ -142,7 +191,7 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, i
   int32_t pre;
   block_exscan_n<GPX_DCHUNK>(before, &pre);
   const int32_t i = w * GPX_DCHUNK + (int32_t)threadIdx.x;
-  const int32_t cnt = i < n ? D.st_count[i] : 0;
+  const int32_t cnt = (i < n && D.tag[i] == X.epoch) ? D.st_count[i] : 0;
   int32_t tot;
   const int32_t ex = block_exscan_n<GPX_DCHUNK>(cnt != 0 ? 1 : 0, &tot);
   if (cnt != 0) {
@@ -210,6 +259,7 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_small(
       it.i = i;
       it.g = g;
       it.cur = i;
+      it.epoch = X.epoch;
       it.chunk = -1; /* every run is parked at its record and counted below */
       it.local = 0;
       it.count_chunks = false;
@@ -238,9 +288,9 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_small(
   }
   __syncthreads(); /* every head that can park a run in this chunk has */
   if (i < n) {
-    count = __hip_atomic_load(&D.st_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    have = count != 0;
-    first = have ? D.st_first[i] : 0;
+    have = __hip_atomic_load(&D.tag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X.epoch;
+    count = have ? __hip_atomic_load(&D.st_count[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
+    first = have ? __hip_atomic_load(&D.st_first[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
   }
   int32_t tot;
   const int32_t ex = block_exscan_n<GPX_DCHUNK>(have, &tot);

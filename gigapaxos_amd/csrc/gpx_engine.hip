@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <unistd.h>
 
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -20,7 +21,7 @@
 #include "gpx_kernels.hip.h"
 #include "gpx_ar16.hip.h"
 #include "gpx_direct.hip.h"
-#include "gpx_small.hip.h"
+#include "gpx_runs.hip.h"
 #include "gpx_route.hip.h"
 #include "gpx_wire.hip.h"
 #include "gpx_elect.hip.h"
@@ -57,31 +58,20 @@ struct gpx_engine {
   int device = 0;
   DevState S{};
   DevScratch X{};
-  hipStream_t own_stream = nullptr;   /* back-end stream when the caller gave none */
-  hipStream_t front_stream = nullptr; /* pipelined mode: streaming front end (k_hist, k_scatter_*) */
-  hipStream_t back_stream = nullptr;  /* pipelined mode: per-bucket back end (k_bucket_*, k_emit_*) */
-  hipStream_t user_stream = nullptr;  /* gpx_engine_set_stream */
-  hipStream_t sF = nullptr, sB = nullptr; /* the streams in force (equal unless pipelined) */
-  hipStream_t stream = nullptr;           /* where the next launch goes: sF inside a front section, else sB */
-  bool pipeline = false;
-  bool pipe_light = false; /* GPX_PIPE_LIGHT=1: only the histogram overlaps (measured: no better) */
-  /* front-end scratch is double-buffered so that call N+1's front end can run beside call N's
-   * back end; evF[s] = front end of the call using set s done, evB[s] = its back end done */
+  hipStream_t own_stream = nullptr;  /* when the caller gave none */
+  hipStream_t user_stream = nullptr; /* gpx_engine_set_stream */
+  /* ONE stream carries every launch of a call (round 2 measured the two-stream overlap of call N + 1's
+   * partition with call N's per-bucket kernels: slower, every kernel of the pipeline fills the chip - the
+   * mode is gone, scripts/experiments/r03_removed_alternatives.patch); sF / sB / stream all name it */
+  hipStream_t sF = nullptr, sB = nullptr, stream = nullptr;
+  /* scratch of the partition front end and of the direct / runs paths */
   struct FrontSet {
     int32_t *bucket_tot = nullptr, *tile_rel = nullptr, *bucket_off = nullptr;
     Rec* rec = nullptr;
     uint32_t* unsorted = nullptr;
-    int32_t* chunk_cnt = nullptr; /* direct path (gpx_direct.hip.h): runs per 1024-record chunk */
-    hipEvent_t evF = nullptr, evB = nullptr;
-    bool used = false;
-  } fs[2];
-  hipEvent_t ev_in = nullptr;
+    int32_t* chunk_cnt = nullptr; /* direct / runs paths: outputs per 1024-record chunk */
+  } fs[1];
   uint64_t call_seq = 0;
-  struct Range {
-    const void* p;
-    size_t n;
-  };
-  std::vector<Range> last_outputs; /* buffers the previous call's back end writes */
   std::vector<void*> allocs;
   /* device staging for the host-pointer entry points */
   int32_t* st_i32[12] = {};
@@ -100,19 +90,22 @@ struct gpx_engine {
   int32_t lds_recs_max = 0;   /* staging capacity the engine was sized for (kmax records per group) */
   int32_t lds_recs_hw = 0;    /* ... and the most a workgroup can stage (oversized calls) */
   int bucket_threads = 256;
-  /* accept-reply back end on 16-byte vote records (gpx_ar16.hip.h): one lane per group, so only
-   * while a bucket has at most 1024 groups; GPX_AR_LEGACY=1 forces the 32-byte record path */
-  bool ar16 = false;
   int32_t ordered_mask = 0; /* gpx_engine_set_ordered_batches */
+  int32_t env_mask = 0;     /* GPX_TRY_RUNS=1 (test switch): GPX_TRY_REPLY_RUNS on every engine, whatever the caller sets */
   /* host-pointer calls of small batches: ONE staged H2D and ONE D2H per call (pinned host block <->
    * device block) instead of a copy per column */
   char *hs_in = nullptr, *hs_out = nullptr; /* pinned host */
   char *ds_in = nullptr, *ds_out = nullptr; /* device */
   int32_t* route_cnt = nullptr; /* gpx_route_batch_dev: [tiles][shards], allocated on first use */
-  /* single-launch path of small accept-reply batches (gpx_small.hip.h); opt-in: GPX_SMALL=1 */
-  bool small_on = false;
+  /* tickets of the single-launch kernels for small ordered batches (k_ac_small) */
   unsigned long long* small_tickets = nullptr;
   uint32_t small_epoch = 0;
+  /* [max_batch] == a call's epoch: record i of that call holds a parked output (direct and sorted-runs
+   * paths: no per-record clearing store, no clearing pass) */
+  uint32_t* rec_tag = nullptr;
+  /* accept replies as a few sorted runs (gpx_runs.hip.h): allocated on first use */
+  RunsInfo* runs_info = nullptr; /* [2], used alternately */
+  uint64_t runs_seq = 0;
   int32_t lds16_max = 0, lds16_hw = 0; /* LDS staging capacities (votes) of k_bucket_ar16 */
   /* accept-reply calls partition at most 4 M groups per pass (4096 buckets of 1024 groups): a bigger
    * table is covered by ar_passes passes over ascending group ranges, each skipping the other ranges'
@@ -134,7 +127,6 @@ struct gpx_engine {
   uint32_t* w_ticket = nullptr;
   uint32_t w_epoch = 0;
   bool wire_legacy = false;
-  bool pack_fused = false; /* GPX_PACK_FUSED=1: k_pack_commits1 instead of scan / offsets / write */
   uint8_t* w_stage = nullptr;      /* staging of BATCHED_ACCEPT_REPLY frames, 188 B per reply */
   long long* w_bucket_bytes = nullptr;
   int32_t* w_ones = nullptr;       /* a column of ones (gpx_request_batch without weights) */
@@ -243,100 +235,44 @@ inline bool aligned16(std::initializer_list<const void*> ps) {
   return true;
 }
 
-using Range = gpx_engine::Range;
-inline bool ranges_overlap(std::initializer_list<Range> a, const std::vector<Range>& b) {
-  for (const Range& x : a) {
-    if (!x.p || !x.n) continue;
-    for (const Range& y : b) {
-      if (!y.p || !y.n) continue;
-      const char *x0 = (const char*)x.p, *y0 = (const char*)y.p;
-      if (x0 < y0 + y.n && y0 < x0 + x.n) return true;
-    }
-  }
-  return false;
-}
-
 void apply_streams(gpx_engine* e) {
-  if (e->pipeline) {
-    e->sF = e->front_stream;
-    e->sB = e->back_stream;
-  } else {
-    e->sF = e->sB = e->user_stream ? e->user_stream : e->own_stream;
-  }
-  e->stream = e->sB;
+  e->sF = e->sB = e->stream = e->user_stream ? e->user_stream : e->own_stream;
 }
 
-/* Opens the front section of a batch call: picks the scratch set, points e->X at it, orders the
- * front stream behind (a) whatever the caller enqueued on its own stream so far (input producers),
- * (b) the back end of the call that used this scratch set before (two calls ago), (c) the previous
- * call's back end when this call reads, or writes early, a buffer that back end writes.
- * `touched` = this call's inputs and the outputs its front end already writes (status prefill,
- * zeroed rows of dropped records). */
-int begin_front(gpx_engine* e, std::initializer_list<Range> touched) {
-  const int s = (int)(e->call_seq & 1);
-  gpx_engine::FrontSet& f = e->fs[s];
-  e->X.bucket_tot = f.bucket_tot;
-  e->X.tile_rel = f.tile_rel;
-  e->X.bucket_off = f.bucket_off;
-  e->X.rec = f.rec;
-  e->X.unsorted = f.unsorted;
-  /* per-scratch-set epoch (the word is only ever raised to the epoch of a call using this set) */
+/* Opens a batch call: the call's epoch (what *X.unsorted is compared with). */
+int begin_front(gpx_engine* e) {
   e->X.epoch = (uint32_t)(e->call_seq + 1);
   if (e->X.epoch == 0) { /* 2^32 calls: restart the epochs from cleared words */
-    HIPQ(hipStreamSynchronize(e->sF));
-    HIPQ(hipStreamSynchronize(e->sB));
-    for (auto& fx : e->fs) HIPQ(hipMemset(fx.unsorted, 0, sizeof(uint32_t)));
+    HIPQ(hipStreamSynchronize(e->stream));
+    HIPQ(hipMemset(e->fs[0].unsorted, 0, sizeof(uint32_t)));
+    HIPQ(hipMemset(e->rec_tag, 0, sizeof(uint32_t) * (size_t)e->cfg.max_batch));
     e->X.epoch = 1;
+    e->call_seq = 0;
   }
-  e->stream = e->sF;
-  if (e->pipeline) {
-    if (e->user_stream) {
-      HIPQ(hipEventRecord(e->ev_in, e->user_stream));
-      HIPQ(hipStreamWaitEvent(e->sF, e->ev_in, 0));
-    }
-    if (f.used) HIPQ(hipStreamWaitEvent(e->sF, f.evB, 0));
-    gpx_engine::FrontSet& prev = e->fs[s ^ 1];
-    if (prev.used && ranges_overlap(touched, e->last_outputs)) HIPQ(hipStreamWaitEvent(e->sF, prev.evB, 0));
-  }
-  return s;
+  return 0;
 }
-/* front section done: the back end (on sB) may start once the records are partitioned */
-void begin_back(gpx_engine* e, int s, int32_t n, bool v16 = false) {
-  /* LDS staging area of the per-bucket kernel, sized for THIS batch: mean records per bucket
-   * + 25 % + 128, so that a thin batch (e.g. one proposal per group on an engine sized for 5-vote
-   * rounds) still gets many workgroups per CU.  Buckets above it take the global-memory path. */
-  {
-    const int32_t rmax = v16 ? e->lds16_max : e->lds_recs_max;
-    const int32_t rhw = v16 ? e->lds16_hw : e->lds_recs_hw;
-    int64_t want = (int64_t)n / std::max(1, e->X.nbk);
-    want = (want + want / 4 + 128 + 63) / 64 * 64;
-    /* a call that carries more than the round the engine was sized for (several slots per group in
-     * one batch) may take the LDS the hardware allows rather than fall back to the global-memory
-     * path for every bucket */
-    const int64_t mean = (int64_t)n / std::max(1, e->X.nbk);
-    const bool oversized = mean + mean / 8 > rmax;
-    const int64_t cap = oversized ? rhw : rmax;
-    e->X.lds_recs = (int32_t)std::max<int64_t>(256, std::min<int64_t>(want, cap));
-    /* beyond that too: nearly every bucket is regrouped in global memory - do not hold LDS it
-     * will not use */
-    if (oversized && mean > rhw + rhw / 4) e->X.lds_recs = 256;
-    e->bucket_lds = (v16 ? GPX_BUCKET16_LDS_BYTES(e->X.gb, e->X.lds_recs)
-                         : GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs)) + e->lds_pad;
-  }
-  if (e->pipeline) {
-    HIPQ(hipEventRecord(e->fs[s].evF, e->sF));
-    HIPQ(hipStreamWaitEvent(e->sB, e->fs[s].evF, 0));
-  }
-  e->stream = e->sB;
+/* LDS staging area of the per-bucket kernel, sized for THIS batch: mean records per bucket
+ * + 25 % + 128, so that a thin batch (e.g. one proposal per group on an engine sized for 5-vote
+ * rounds) still gets many workgroups per CU.  Buckets above it take the global-memory path. */
+void begin_back(gpx_engine* e, int, int32_t n, bool v16 = false) {
+  const int32_t rmax = v16 ? e->lds16_max : e->lds_recs_max;
+  const int32_t rhw = v16 ? e->lds16_hw : e->lds_recs_hw;
+  int64_t want = (int64_t)n / std::max(1, e->X.nbk);
+  want = (want + want / 4 + 128 + 63) / 64 * 64;
+  /* a call that carries more than the round the engine was sized for (several slots per group in
+   * one batch) may take the LDS the hardware allows rather than fall back to the global-memory
+   * path for every bucket */
+  const int64_t mean = (int64_t)n / std::max(1, e->X.nbk);
+  const bool oversized = mean + mean / 8 > rmax;
+  const int64_t cap = oversized ? rhw : rmax;
+  e->X.lds_recs = (int32_t)std::max<int64_t>(256, std::min<int64_t>(want, cap));
+  /* beyond that too: nearly every bucket is regrouped in global memory - do not hold LDS it
+   * will not use */
+  if (oversized && mean > rhw + rhw / 4) e->X.lds_recs = 256;
+  e->bucket_lds = (v16 ? GPX_BUCKET16_LDS_BYTES(e->X.gb, e->X.lds_recs)
+                       : GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs)) + e->lds_pad;
 }
-void end_call(gpx_engine* e, int s, std::initializer_list<Range> outputs) {
-  if (e->pipeline) {
-    HIPQ(hipEventRecord(e->fs[s].evB, e->sB));
-    e->fs[s].used = true;
-    e->last_outputs.assign(outputs.begin(), outputs.end());
-  }
-  e->call_seq++;
-}
+void end_call(gpx_engine* e, int) { e->call_seq++; }
 
 /* bucket partition front end, part 1: per-bucket record counts of the batch */
 void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, int is_votes,
@@ -381,10 +317,6 @@ int check_batch(gpx_engine* h, int32_t n) {
   return GPX_OK;
 }
 
-template <int KMAX>
-void launch_bucket_ar(gpx_engine* e, uint8_t* status) {
-  LAUNCH_B(e, "k_bucket_ar", (k_bucket_ar<KMAX>), e->S, e->X, status);
-}
 template <int KMAX>
 void launch_bucket_ar16(gpx_engine* e, const Stage16& O, const VoteCols& in, uint8_t* status) {
   LAUNCH_B(e, "k_bucket_ar16", (k_bucket16<B16_AR, KMAX>), e->S, e->X, O, in, AcceptOut{}, status);
@@ -466,20 +398,24 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   gpx_engine* e = new gpx_engine();
   e->cfg = *cfg;
+  /* a failing runtime call inside creation gives back everything allocated so far */
+#define HIPCHK_CREATE(expr)                                                                  \
+  do {                                                                                       \
+    hipError_t _e = (expr);                                                                  \
+    if (_e != hipSuccess) {                                                                  \
+      snprintf(g_err, sizeof(g_err), "%s:%d %s -> %s", __FILE__, __LINE__, #expr,            \
+               hipGetErrorString(_e));                                                       \
+      gpx_engine_destroy(e);                                                                 \
+      return GPX_EDEVICE;                                                                    \
+    }                                                                                        \
+  } while (0)
   if (cfg->device >= 0) {
-    HIPCHK(hipSetDevice(cfg->device));
+    HIPCHK_CREATE(hipSetDevice(cfg->device));
     e->device = cfg->device;
   } else {
-    HIPCHK(hipGetDevice(&e->device));
+    HIPCHK_CREATE(hipGetDevice(&e->device));
   }
-  HIPCHK(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&e->front_stream, hipStreamNonBlocking));
-  HIPCHK(hipStreamCreateWithFlags(&e->back_stream, hipStreamNonBlocking));
-  HIPCHK(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming));
-  for (auto& f : e->fs) {
-    HIPCHK(hipEventCreateWithFlags(&f.evF, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&f.evB, hipEventDisableTiming));
-  }
+  HIPCHK_CREATE(hipStreamCreateWithFlags(&e->own_stream, hipStreamNonBlocking));
   apply_streams(e);
   const size_t G = (size_t)cfg->max_groups, W = (size_t)cfg->window, K = (size_t)cfg->kmax;
   const size_t N = (size_t)cfg->max_batch;
@@ -509,9 +445,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(S.node_slots, K * G, true);
   A(S.p_ring, W * G, true);
   A(S.acc_ring, W * G, true);
-  A(S.acc_flags, W * G, true);
   A(S.com_ring, W * G, true);
-  A(S.com_flags, W * G, true);
   DevScratch& X = e->X;
   /* buckets of 256 groups (one lane per group, whole bucket staged in LDS, 4 workgroups per
    * CU); beyond 1M groups the buckets grow so that there are at most GPX_MAX_BUCKETS */
@@ -549,9 +483,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     want += want / 4 + 128;
     e->lds16_max = (int32_t)std::min<int64_t>(want, cap16);
     e->lds16_hw = (int32_t)cap16;
-    const char* leg = getenv("GPX_AR_LEGACY");
-    e->ar16 = !(leg && atoi(leg));
-    e->ac16 = e->ar16 && X.shift <= V16_MAX_SHIFT && e->bucket_threads == X.gb;
+    e->ac16 = X.shift <= V16_MAX_SHIFT && e->bucket_threads == X.gb;
     if (X.shift <= V16_MAX_SHIFT) {
       e->shift16 = X.shift;
       e->nbk16 = X.nbk;
@@ -574,11 +506,12 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     }
   }
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
+  if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
+  e->ordered_mask = e->env_mask;
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
   const size_t bucket_lds_hw = GPX_BUCKET_LDS_BYTES(X.gb, e->lds_recs_hw) + e->lds_pad;
   if (bucket_lds_hw > 64 * 1024) { /* more dynamic LDS than the default limit: opt in per kernel */
-    const void* fns[] = {(const void*)k_bucket_ar<4>,      (const void*)k_bucket_ar<8>,
-                         (const void*)k_bucket_ar<16>,     (const void*)k_bucket_propose<4>,
+    const void* fns[] = {(const void*)k_bucket_propose<4>,
                          (const void*)k_bucket_propose<8>, (const void*)k_bucket_propose<16>,
                          (const void*)k_bucket_accept,     (const void*)k_bucket_commit,
                          (const void*)k_bucket_pack_ar,    (const void*)k_bucket_reqbatch,
@@ -587,45 +520,38 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
                          (const void*)k_bucket_prepare_reply<8, 64>,
                          (const void*)k_bucket_prepare_reply<16, 64>};
     for (const void* f : fns)
-      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_hw));
+      HIPCHK_CREATE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_hw));
   }
   {
-    /* Off unless GPX_SMALL=1: measured on MI355X it only TIES the partition pipeline at BASELINE
-     * config #2's size (30 k votes over 10 k groups: 33 us against 34 us) and loses at 65,536 votes
-     * over 1 M groups (90 us against 53 us: one 1024-lane workgroup per CU, each a chain of dependent
-     * round trips).  Kept, tested both ways, as the starting point for a fused small-batch back end. */
-    const char* pf = getenv("GPX_PIPE_LIGHT");
-    e->pipe_light = pf && atoi(pf);
-    const char* sm = getenv("GPX_SMALL");
-    e->small_on = sm && atoi(sm);
-    if ((rc = dev_alloc(e, &e->small_tickets, GPX_SMALL_MAX_WG, true)) != GPX_OK) {
+    if ((rc = dev_alloc(e, &e->small_tickets, 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK), true)) != GPX_OK) {
       gpx_engine_destroy(e);
       return rc;
     }
-    HIPCHK(hipHostMalloc((void**)&e->hs_in, GPX_STAGE_BYTES, hipHostMallocDefault));
-    HIPCHK(hipHostMalloc((void**)&e->hs_out, GPX_STAGE_BYTES, hipHostMallocDefault));
+    if (hipHostMalloc((void**)&e->hs_in, GPX_STAGE_BYTES, hipHostMallocDefault) != hipSuccess ||
+        hipHostMalloc((void**)&e->hs_out, GPX_STAGE_BYTES, hipHostMallocDefault) != hipSuccess) {
+      snprintf(g_err, sizeof(g_err), "hipHostMalloc(%zu) failed", (size_t)GPX_STAGE_BYTES);
+      gpx_engine_destroy(e);
+      return GPX_ENOMEM;
+    }
     if ((rc = dev_alloc(e, &e->ds_in, GPX_STAGE_BYTES, false)) != GPX_OK ||
         (rc = dev_alloc(e, &e->ds_out, GPX_STAGE_BYTES, false)) != GPX_OK) {
       gpx_engine_destroy(e);
       return rc;
     }
-    const void* fns[] = {(const void*)k_small_ar<4>, (const void*)k_small_ar<8>, (const void*)k_small_ar<16>};
-    for (const void* f : fns)
-      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
   }
-  if (e->ar16) {
+  {
     const size_t hw16 = GPX_BUCKET16_LDS_BYTES((size_t)1 << e->shift16, e->lds16_hw) + e->lds_pad;
     const void* fns[] = {(const void*)k_bucket16<B16_AR, 4>, (const void*)k_bucket_ar16_k5, (const void*)k_bucket16<B16_AR, 8>,
                          (const void*)k_bucket16<B16_AR, 16>, (const void*)k_bucket16<B16_ACCEPT, 4>,
                          (const void*)k_bucket16<B16_COMMIT, 4>};
     for (const void* f : fns)
-      HIPCHK(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
+      HIPCHK_CREATE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
   }
   { /* k_hist may take up to GPX_HSUB_MAX histograms of dynamic LDS */
     const int hl = GPX_HSUB_MAX * std::max(X.nbk, e->nbk16) * (int)sizeof(int32_t);
     if (hl > 64 * 1024) {
-      HIPCHK(hipFuncSetAttribute((const void*)k_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, hl));
-      HIPCHK(hipFuncSetAttribute((const void*)k_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, hl));
+      HIPCHK_CREATE(hipFuncSetAttribute((const void*)k_hist<true>, hipFuncAttributeMaxDynamicSharedMemorySize, hl));
+      HIPCHK_CREATE(hipFuncSetAttribute((const void*)k_hist<false>, hipFuncAttributeMaxDynamicSharedMemorySize, hl));
     }
   }
   const size_t nbk_alloc = (size_t)std::max(X.nbk, e->nbk16); /* accept-reply passes may use more, smaller buckets */
@@ -647,12 +573,14 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.perm, N, false);
   A(X.o_rec, N, false);
   A(X.bucket_nout, nbk_alloc, true);
+  A(e->rec_tag, N, true);
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
   A(e->st_count, 4, true);
 #undef A
-  HIPCHK(hipDeviceSynchronize());
+  HIPCHK_CREATE(hipDeviceSynchronize());
+#undef HIPCHK_CREATE
   *out = e;
   return GPX_OK;
 }
@@ -670,13 +598,6 @@ int gpx_engine_destroy(gpx_engine* h) {
   if (h->hs_out) HIPQ(hipHostFree(h->hs_out));
   if (h->arena) HIPQ(hipFree(h->arena));
   if (h->own_stream) HIPQ(hipStreamDestroy(h->own_stream));
-  if (h->front_stream) HIPQ(hipStreamDestroy(h->front_stream));
-  if (h->back_stream) HIPQ(hipStreamDestroy(h->back_stream));
-  if (h->ev_in) HIPQ(hipEventDestroy(h->ev_in));
-  for (auto& f : h->fs) {
-    if (f.evF) HIPQ(hipEventDestroy(f.evF));
-    if (f.evB) HIPQ(hipEventDestroy(f.evB));
-  }
   delete h;
   return GPX_OK;
 }
@@ -690,30 +611,11 @@ int gpx_engine_set_stream(gpx_engine* h, void* hip_stream) {
   return GPX_OK;
 }
 
-int gpx_engine_set_pipeline(gpx_engine* h, int32_t on) {
-  if (!h) return GPX_EINVAL;
-  HIPCHK(hipStreamSynchronize(h->sF));
-  HIPCHK(hipStreamSynchronize(h->sB));
-  h->pipeline = on != 0;
-  for (auto& f : h->fs) f.used = false;
-  h->last_outputs.clear();
-  apply_streams(h);
-  return GPX_OK;
-}
-
 int gpx_engine_set_ordered_batches(gpx_engine* h, int32_t mask) {
-  if (!h || (mask & ~(GPX_ORDERED_PROPOSE | GPX_ORDERED_ACCEPT | GPX_ORDERED_COMMIT))) return GPX_EINVAL;
-  h->ordered_mask = mask;
-  return GPX_OK;
-}
-
-int gpx_engine_fence(gpx_engine* h) {
-  if (!h) return GPX_EINVAL;
-  if (h->pipeline && h->user_stream) {
-    /* everything submitted so far completes before later work on the caller's stream */
-    HIPCHK(hipEventRecord(h->ev_in, h->sB));
-    HIPCHK(hipStreamWaitEvent(h->user_stream, h->ev_in, 0));
-  }
+  if (!h || (mask & ~(GPX_ORDERED_PROPOSE | GPX_ORDERED_ACCEPT | GPX_ORDERED_COMMIT | GPX_ORDERED_REPLY_RUNS |
+                      GPX_TRY_REPLY_RUNS)))
+    return GPX_EINVAL;
+  h->ordered_mask = mask | h->env_mask;
   return GPX_OK;
 }
 
@@ -820,6 +722,79 @@ int gpx_route_batch_dev(gpx_engine* h, int32_t n, int32_t n_cols, const int32_t*
 
 /* ---- device-pointer data path ------------------------------------------------- */
 
+/* the partition pipeline of an accept-reply batch: k_hist, k_scatter_ar16, k_bucket_ar16, k_emit_dec16, one
+ * pass per range of groups; e->ar_chain holds the number of outputs written so far between the passes */
+static void ar_partition(gpx_engine* e, int32_t n, const int32_t* gidx, const int32_t* bnum, const int32_t* bcoord,
+                         const int32_t* slot, const int32_t* acceptor, const int32_t* max_cp, int32_t* d_gidx,
+                         int32_t* d_slot, int32_t* d_bnum, int32_t* d_bcoord, int32_t* d_median_cp,
+                         uint8_t* d_kind, int32_t* n_out, uint8_t* status) {
+  const int ntiles = ntiles_for(n);
+  const bool vec = aligned16({gidx, bnum, bcoord, slot, acceptor, max_cp});
+  /* 16-byte vote records (gpx_ar16.hip.h); the back end may re-read bnum / bcoord / acceptor.
+   * One pass per range of at most 4 M groups (ranges ascending, so the concatenated outputs stay
+   * grouped by gidx ascending); a table of up to 4 M groups is one pass over everything. */
+  const DevScratch X0 = e->X;
+  const int threads0 = e->bucket_threads;
+  /* passes over ascending group ranges: as many as the table needs (at most 4096 buckets of at most 1024
+   * groups per pass) and as many as keep a bucket's expected votes inside what one workgroup can stage in
+   * LDS - a call that brings many rounds of votes at once (more than ~19 per group) would otherwise regroup
+   * every bucket in global memory, an order of magnitude slower than reading the columns once more */
+  const int64_t NB = ((int64_t)e->S.G + ((int64_t)1 << e->shift16) - 1) >> e->shift16;
+  int64_t want_passes = e->ar_passes;
+  {
+    const double m = (double)n / (double)NB;
+    const int64_t pc = (int64_t)((m + 5.0 * sqrt(m)) / (double)e->lds16_hw) + 1;
+    want_passes = std::min<int64_t>(NB, std::max<int64_t>(want_passes, pc));
+  }
+  const int64_t bpp = (NB + want_passes - 1) / want_passes; /* buckets per pass, <= GPX_MAX_BUCKETS */
+  const int32_t passes = (int32_t)((NB + bpp - 1) / bpp);
+  const size_t N = (size_t)e->cfg.max_batch;
+  int32_t* o32 = (int32_t*)e->X.o_rec; /* N x 32 bytes: five int columns + one byte column */
+  const Stage16 O{o32, (int64_t)N};
+  const VoteCols in{bnum, bcoord, acceptor};
+  for (int32_t p = 0; p < passes; p++) {
+    e->X.shift = e->shift16;
+    e->X.gb = 1 << e->shift16;
+    e->X.nbk = e->nbk16;
+    e->bucket_threads = e->X.gb;
+    if (passes > 1) {
+      const int64_t range = bpp << e->shift16;
+      e->X.g_base = (int32_t)(p * range);
+      e->X.g_end = (int32_t)std::min<int64_t>(e->S.G, (p + 1) * range);
+      e->X.nbk = (int32_t)((e->X.g_end - e->X.g_base + e->X.gb - 1) >> e->shift16);
+    }
+    /* LDS staging sized for what one pass sees */
+    if (p == 0) begin_back(e, 0, n / passes, true);
+    /* status prefill, vote and out-of-table counters: once, by the first pass */
+    front_hist(e, n, gidx, p == 0 ? status : nullptr, p == 0 ? 1 : -1, e->X.gate ? 2 : 0);
+    if (vec)
+      LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+    else
+      LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
+               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
+    if (e->cfg.kmax <= 4)
+      launch_bucket_ar16<4>(e, O, in, status);
+    else if (e->cfg.kmax <= 5) /* five replicas (BASELINE config #4): its own kernel, held to 80 VGPRs */
+      LAUNCH_B(e, "k_bucket_ar16", k_bucket_ar16_k5, e->S, e->X, O, in, AcceptOut{}, status);
+    else if (e->cfg.kmax <= 8)
+      launch_bucket_ar16<8>(e, O, in, status);
+    else
+      launch_bucket_ar16<16>(e, O, in, status);
+    LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord,
+           d_median_cp, d_kind, n_out, &e->X.counters[1],
+           (const int32_t*)(p > 0 ? e->ar_chain + (p & 1) : nullptr),
+           passes > 1 ? e->ar_chain + ((p + 1) & 1) : (int32_t*)nullptr);
+    /* what begin_back computed for this call survives the restore below */
+    const int32_t lds_recs = e->X.lds_recs;
+    const int32_t gate = e->X.gate;
+    e->X = X0;
+    e->X.lds_recs = lds_recs;
+    e->X.gate = gate;
+    e->bucket_threads = threads0;
+  }
+}
+
 int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
                                const int32_t* bnum, const int32_t* bcoord, const int32_t* slot,
                                const int32_t* acceptor, const int32_t* max_cp, int32_t* d_gidx,
@@ -833,127 +808,57 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     return GPX_OK;
   }
   gpx_engine* e = h;
-  const size_t b4 = (size_t)n * 4;
-  const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {acceptor, b4},
-                                 {max_cp, b4}, {status, (size_t)n}});
-  /* a batch of at most 65,536 votes: one launch, nothing partitioned through HBM (gpx_small.hip.h) */
-  if (e->small_on && n <= GPX_SMALL_MAX_N) {
-    const int64_t lds_free = 160 * 1024 - 2048 - 2 * (int64_t)((n + 7) & ~7);
-    const int64_t gw_max = std::min<int64_t>(GPX_SMALL_MAX_GW, (lds_free - 64) / 10);
-    const int64_t G = e->S.G;
-    int64_t W = (G + gw_max - 1) / gw_max;
-    W = std::max<int64_t>(W, std::min<int64_t>(256, (G + 63) / 64)); /* spread a small table over the CUs */
-    if (W <= GPX_SMALL_MAX_WG) {
-      const int32_t gw = (int32_t)((G + W - 1) / W);
-      W = (G + gw - 1) / gw;
-      begin_back(e, fs, n);
-      if (++e->small_epoch == 0) { /* 2^32 calls: restart the tickets' epochs */
-        HIPQ(hipMemsetAsync(e->small_tickets, 0, GPX_SMALL_MAX_WG * sizeof(unsigned long long), e->stream));
-        e->small_epoch = 1;
-      }
-      const size_t N = (size_t)e->cfg.max_batch;
-      int32_t* o32 = (int32_t*)e->X.o_rec;
-      SmallArgs A{n, gw, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord,
-                  d_median_cp, d_kind, n_out, status,
-                  Stage16{o32, (int64_t)N},
-                  e->small_tickets, e->small_epoch};
-      const size_t lds = (size_t)gw * 8 + (size_t)((gw + 7) & ~7) * 2 + (size_t)((n + 7) & ~7) * 2;
-      {
-        LaunchScope _ls(e, "k_small_ar");
-        if (e->cfg.kmax <= 4)
-          hipLaunchKernelGGL(k_small_ar<4>, dim3((int)W), dim3(GPX_SMALL_NT), lds, e->stream, e->S, e->X, A);
-        else if (e->cfg.kmax <= 8)
-          hipLaunchKernelGGL(k_small_ar<8>, dim3((int)W), dim3(GPX_SMALL_NT), lds, e->stream, e->S, e->X, A);
-        else
-          hipLaunchKernelGGL(k_small_ar<16>, dim3((int)W), dim3(GPX_SMALL_NT), lds, e->stream, e->S, e->X, A);
-      }
-      end_call(e, fs, {{d_gidx, b4}, {d_slot, b4}, {d_bnum, b4}, {d_bcoord, b4}, {d_median_cp, b4},
-                       {d_kind, (size_t)n}, {n_out, 4}, {status, (size_t)n}, {bnum, b4}, {bcoord, b4},
-                       {acceptor, b4}, {slot, b4}, {max_cp, b4}, {gidx, b4}});
+  const int fs = begin_front(e);
+  e->X.gate = 0;
+  /* (i) a few sorted runs - the concatenated replies of the acceptors (gpx_runs.hip.h): no partition.
+   * GPX_ORDERED_REPLY_RUNS: the caller promises that shape, only this path is launched and a batch that
+   * breaks the promise is refused whole; GPX_TRY_REPLY_RUNS: a hint - the shape is checked on the device and
+   * the partition pipeline, launched behind, takes any other batch (its kernels return at once otherwise). */
+  const bool runs_promised = (e->ordered_mask & GPX_ORDERED_REPLY_RUNS) != 0;
+  const bool runs_try = runs_promised || (e->ordered_mask & GPX_TRY_REPLY_RUNS) != 0;
+  if (runs_try) {
+    const size_t N = (size_t)e->cfg.max_batch;
+    if (!e->runs_info && (rc = dev_alloc(e, &e->runs_info, 2, true)) != GPX_OK) return rc;
+    RunsInfo* info = e->runs_info + (e->runs_seq & 1);
+    RunsInfo* next_info = e->runs_info + ((e->runs_seq + 1) & 1);
+    e->runs_seq++;
+    const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
+    const RunsStage st{Stage16{(int32_t*)e->X.o_rec, (int64_t)N}, e->rec_tag, e->fs[0].chunk_cnt,
+                       Stage16{(int32_t*)e->X.rec, (int64_t)N}};
+    const int32_t refuse = runs_promised ? 1 : 0;
+    LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx, e->S.G,
+              e->X, status, info, next_info, st.chunk_cnt, nchunks);
+    {
+      LaunchScope _ls(e, "k_ar_runs");
+      if (e->cfg.kmax <= 4)
+        hipLaunchKernelGGL(k_ar_runs<4>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
+                           bcoord, slot, acceptor, max_cp, status, st, info, refuse);
+      else if (e->cfg.kmax <= 8)
+        hipLaunchKernelGGL(k_ar_runs<8>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
+                           bcoord, slot, acceptor, max_cp, status, st, info, refuse);
+      else
+        hipLaunchKernelGGL(k_ar_runs<16>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
+                           bcoord, slot, acceptor, max_cp, status, st, info, refuse);
+    }
+    {
+      LaunchScope _ls(e, "k_emit_dec_runs");
+      hipLaunchKernelGGL(k_emit_dec_runs, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, st, info,
+                         d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, &e->X.counters[1], refuse);
+    }
+    LAUNCH(e, "k_merge_runs", k_merge_runs, 512, e->X, n, st, (const RunsInfo*)info, d_gidx, d_slot, d_bnum,
+           d_bcoord, d_median_cp, d_kind);
+    if (runs_promised) {
+      end_call(e, fs);
       HIPCHK(hipGetLastError());
       return GPX_OK;
     }
+    e->X.gate = 1; /* the partition kernels below run only if k_runs_check raised *X.unsorted */
   }
-  const int ntiles = ntiles_for(n);
-  const bool vec = aligned16({gidx, bnum, bcoord, slot, acceptor, max_cp});
-  if (e->ar16) {
-    /* 16-byte vote records (gpx_ar16.hip.h); the back end may re-read bnum / bcoord / acceptor.
-     * One pass per range of at most 4 M groups (ranges ascending, so the concatenated outputs stay
-     * grouped by gidx ascending); a table of up to 4 M groups is one pass over everything. */
-    const DevScratch X0 = e->X;
-    const int threads0 = e->bucket_threads;
-    const int32_t passes = e->ar_passes;
-    const size_t N = (size_t)e->cfg.max_batch;
-    int32_t* o32 = (int32_t*)e->X.o_rec; /* N x 32 bytes: five int columns + one byte column */
-    const Stage16 O{o32, (int64_t)N};
-    const VoteCols in{bnum, bcoord, acceptor};
-    for (int32_t p = 0; p < passes; p++) {
-      e->X.shift = e->shift16;
-      e->X.gb = 1 << e->shift16;
-      e->X.nbk = e->nbk16;
-      e->bucket_threads = e->X.gb;
-      if (passes > 1) {
-        const int64_t range = (int64_t)e->nbk16 << e->shift16;
-        e->X.g_base = (int32_t)(p * range);
-        e->X.g_end = (int32_t)std::min<int64_t>(e->S.G, (p + 1) * range);
-        e->X.nbk = (int32_t)((e->X.g_end - e->X.g_base + e->X.gb - 1) >> e->shift16);
-        /* several passes: everything in stream order on the back-end stream; LDS sized for a pass */
-        if (p == 0) begin_back(e, fs, n / passes, true);
-      }
-      /* status prefill, vote and out-of-table counters: once, by the first pass */
-      front_hist(e, n, gidx, p == 0 ? status : nullptr, p == 0 ? 1 : -1);
-      /* pipelined mode, GPX_PIPE_LIGHT=1: only the histogram of call N+1 runs beside the back end of
-       * call N; measured on MI355X: 0.164 ms per step against 0.160 with the scatter overlapped too
-       * and 0.140 on ONE stream - the kernels of this pipeline fill the chip, overlap only adds
-       * contention, so one stream is the default everywhere */
-      if (passes == 1 && e->pipe_light) begin_back(e, fs, n, true);
-      if (vec)
-        LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
-                 ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-      else
-        LAUNCH_F(e, "k_scatter_ar16", k_scatter_ar16<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
-                 ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-      if (passes == 1 && !e->pipe_light) begin_back(e, fs, n, true);
-      if (e->cfg.kmax <= 4)
-        launch_bucket_ar16<4>(e, O, in, status);
-      else if (e->cfg.kmax <= 5) /* five replicas (BASELINE config #4): its own kernel, held to 80 VGPRs */
-        LAUNCH_B(e, "k_bucket_ar16", k_bucket_ar16_k5, e->S, e->X, O, in, AcceptOut{}, status);
-      else if (e->cfg.kmax <= 8)
-        launch_bucket_ar16<8>(e, O, in, status);
-      else
-        launch_bucket_ar16<16>(e, O, in, status);
-      LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord,
-             d_median_cp, d_kind, n_out, &e->X.counters[1],
-             (const int32_t*)(p > 0 ? e->ar_chain + (p & 1) : nullptr),
-             passes > 1 ? e->ar_chain + ((p + 1) & 1) : (int32_t*)nullptr);
-      /* what begin_back computed for this call survives the restore below */
-      const int32_t lds_recs = e->X.lds_recs;
-      e->X = X0;
-      e->X.lds_recs = lds_recs;
-      e->bucket_threads = threads0;
-    }
-  } else {
-    front_hist(e, n, gidx, status, 1);
-    if (vec)
-      LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<true>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
-               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-    else
-      LAUNCH_F(e, "k_scatter_ar", k_scatter_ar<false>, tile_grid(ntiles), (size_t)e->X.nbk * 4, n,
-               ntiles, e->S.G, e->X, gidx, bnum, bcoord, slot, acceptor, max_cp);
-    begin_back(e, fs, n);
-    if (e->cfg.kmax <= 4)
-      launch_bucket_ar<4>(e, status);
-    else if (e->cfg.kmax <= 8)
-      launch_bucket_ar<8>(e, status);
-    else
-      launch_bucket_ar<16>(e, status);
-    LAUNCH(e, "k_emit_dec", k_emit_dec, e->X.nbk, e->X, d_gidx, d_slot, d_bnum, d_bcoord,
-           d_median_cp, d_kind, n_out, &e->X.counters[1]);
-  }
-  /* the back end reads three input columns again (ESC votes): they count as buffers it touches */
-  end_call(e, fs, {{d_gidx, b4}, {d_slot, b4}, {d_bnum, b4}, {d_bcoord, b4}, {d_median_cp, b4},
-                   {d_kind, (size_t)n}, {n_out, 4}, {status, (size_t)n}, {bnum, b4}, {bcoord, b4},
-                   {acceptor, b4}});
+  /* (ii) the partition pipeline */
+  ar_partition(e, n, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp,
+               d_kind, n_out, status);
+  e->X.gate = 0;
+  end_call(e, fs);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -971,17 +876,15 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   }
   gpx_engine* e = h;
   const size_t b4 = (size_t)n * 4;
-  const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {median_cp, b4},
-                                 {a_flags, (size_t)n}, {r_bnum, b4}, {r_bcoord, b4}, {r_maxcp, b4},
-                                 {r_flags, (size_t)n}, {status, (size_t)n}});
+  const int fs = begin_front(e);
   /* a batch grouped by group (gidx non-decreasing, in range) is applied directly; anything else is
    * partitioned first.  Device-side choice: both back ends are launched, one of them returns at once. */
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec; /* the two paths never both stage outputs: shared scratch */
-  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt};
+  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt};
   /* at most 65,536 records on one stream: order check, direct application and run compaction in ONE
    * launch (k_ac_small: tickets instead of chunk counters) */
-  const bool fused = n <= GPX_SMALL_DIRECT_MAX_N && !e->pipeline;
+  const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
   const bool promised = (e->ordered_mask & GPX_ORDERED_ACCEPT) != 0;
   if (!fused)
     LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
@@ -989,7 +892,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   /* fused: FIRST in the stream - the partition path launched behind it reads its verdict */
   if (fused) {
     if (++e->small_epoch == 0) {
-      HIPQ(hipMemsetAsync(e->small_tickets, 0, GPX_SMALL_MAX_WG * sizeof(unsigned long long), e->stream));
+      HIPQ(hipMemsetAsync(e->small_tickets, 0, 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK) * sizeof(unsigned long long), e->stream));
       e->small_epoch = 1;
     }
     LaunchScope _ls(e, "k_ac_small");
@@ -1021,7 +924,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   if (!fused) {
     {
       LaunchScope _ls(e, "k_ac_direct");
-      hipLaunchKernelGGL(k_ac_direct<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
+      hipLaunchKernelGGL(k_ac_direct<false>, dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, n, gidx,
                          bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D,
                          promised ? 1 : 0);
     }
@@ -1043,8 +946,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     LAUNCH_B(e, "k_bucket_accept", k_bucket_accept, e->S, e->X, r_bnum, r_bcoord, r_maxcp, r_flags, status);
     LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   }
-  end_call(e, fs, {{r_bnum, b4}, {r_bcoord, b4}, {r_maxcp, b4}, {r_flags, (size_t)n},
-                   {status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
+  end_call(e, fs);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -1061,20 +963,19 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   }
   gpx_engine* e = h;
   const size_t b4 = (size_t)n * 4;
-  const int fs = begin_front(e, {{gidx, b4}, {bnum, b4}, {bcoord, b4}, {slot, b4}, {median_cp, b4},
-                                 {c_kind, (size_t)n}, {status, (size_t)n}});
+  const int fs = begin_front(e);
   /* decisions leave the accept-reply call grouped by gidx: such a commit batch is applied directly */
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec;
-  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt};
-  const bool fused = n <= GPX_SMALL_DIRECT_MAX_N && !e->pipeline; /* one launch: k_ac_small */
+  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt};
+  const bool fused = n <= GPX_SMALL_DIRECT_MAX_N; /* one launch: k_ac_small */
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
   if (!fused)
     LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
               e->S.G, e->X, status, D.chunk_cnt, nchunks);
   if (fused) {
     if (++e->small_epoch == 0) {
-      HIPQ(hipMemsetAsync(e->small_tickets, 0, GPX_SMALL_MAX_WG * sizeof(unsigned long long), e->stream));
+      HIPQ(hipMemsetAsync(e->small_tickets, 0, 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK) * sizeof(unsigned long long), e->stream));
       e->small_epoch = 1;
     }
     LaunchScope _ls(e, "k_ac_small");
@@ -1106,7 +1007,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   if (!fused) {
     {
       LaunchScope _ls(e, "k_ac_direct");
-      hipLaunchKernelGGL(k_ac_direct<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx,
+      hipLaunchKernelGGL(k_ac_direct<true>, dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, n, gidx,
                          bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr,
                          (int32_t*)nullptr, (uint8_t*)nullptr, status, D, promised ? 1 : 0);
     }
@@ -1124,7 +1025,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     LAUNCH_B(e, "k_bucket_commit", k_bucket_commit, e->S, e->X, status);
     LAUNCH(e, "k_emit_runs", k_emit_runs, e->X.nbk, e->X, x_gidx, x_first, x_count, n_runs);
   }
-  end_call(e, fs, {{status, (size_t)n}, {x_gidx, b4}, {x_first, b4}, {x_count, b4}, {n_runs, 4}});
+  end_call(e, fs);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -1138,12 +1039,11 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   if (n == 0) return GPX_OK;
   gpx_engine* e = h;
   const size_t b4 = (size_t)n * 4;
-  const int fs = begin_front(e, {{gidx, b4}, {is_stop, (size_t)n}, {handle, b4 * 2}, {slot, b4}, {bnum, b4},
-                                 {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
+  const int fs = begin_front(e);
   const bool promised = (e->ordered_mask & GPX_ORDERED_PROPOSE) != 0;
   const int32_t refuse = promised ? 1 : 0;
   /* at most 65,536 requests on one stream: order check and direct application in one launch */
-  const bool fused = n <= GPX_SMALL_DIRECT_MAX_N && !e->pipeline;
+  const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
   if (fused) {
     e->stream = e->sB;
     if (e->cfg.kmax <= 4)
@@ -1187,7 +1087,7 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
              bnum, bcoord, median_cp, status, handle, refuse);
     if (!promised) launch_bucket_propose<16>(e, slot, bnum, bcoord, median_cp, status, handle);
   }
-  end_call(e, fs, {{slot, b4}, {bnum, b4}, {bcoord, b4}, {median_cp, b4}, {status, (size_t)n}});
+  end_call(e, fs);
   HIPCHK(hipGetLastError());
   return GPX_OK;
 }
@@ -1591,22 +1491,25 @@ int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
       int32_t slot, a, b, c;
       uint8_t f;
     };
-    auto read_ring = [&](const I4* ring, const uint8_t* flags, std::vector<Ent>& out) -> int {
+    /* both rings' flag bytes live in the accepted ring's fourth word (AccView): bits 0-7 / 8-15 */
+    auto read_ring = [&](const I4* ring, int shift, std::vector<Ent>& out) -> int {
       for (int32_t x = 0; x < S.W; x++) {
-        uint8_t f = 0;
-        HIPCHK(rd8(flags, (int64_t)x * S.G + gidx, &f));
+        I4 fe;
+        HIPCHK(hipMemcpy(&fe, S.acc_ring + ((int64_t)x * S.G + gidx), sizeof(I4), hipMemcpyDeviceToHost));
+        const uint8_t f = (uint8_t)(((uint32_t)fe.w >> shift) & 0xffu);
         if (!(f & RF_PRESENT)) continue;
-        I4 r;
-        HIPCHK(hipMemcpy(&r, ring + ((int64_t)x * S.G + gidx), sizeof(I4), hipMemcpyDeviceToHost));
+        I4 r = fe;
+        if (ring != S.acc_ring)
+          HIPCHK(hipMemcpy(&r, ring + ((int64_t)x * S.G + gidx), sizeof(I4), hipMemcpyDeviceToHost));
         out.push_back(Ent{r.x, r.y, r.z, r.w, f});
       }
       std::sort(out.begin(), out.end(), [](const Ent& p, const Ent& q) { return p.slot < q.slot; });
       return GPX_OK;
     };
     std::vector<Ent> acc, com;
-    int rc = read_ring(S.acc_ring, S.acc_flags, acc);
+    int rc = read_ring(S.acc_ring, 0, acc);
     if (rc != GPX_OK) return rc;
-    rc = read_ring(S.com_ring, S.com_flags, com);
+    rc = read_ring(S.com_ring, CF_SHIFT, com);
     if (rc != GPX_OK) return rc;
     w.push_back((int32_t)acc.size());
     for (auto& en : acc) {

@@ -122,10 +122,10 @@ struct DevState {
   int32_t* members;                               /* [kmax][G] */
   int32_t* node_slots;                            /* [kmax][G] nodeSlotNumbers */
   uint32_t* p_ring;                               /* [W][G] myProposals */
-  I4* acc_ring;                                   /* [W][G] acceptedProposals {slot,bnum,bcoord,-} */
-  uint8_t* acc_flags;                             /* [W][G] */
+  I4* acc_ring;                                   /* [W][G] acceptedProposals {slot, bnum, bcoord, flags}: flags bits
+                                                   * 0-7 = this entry's RF_*, bits 8-15 = the RF_* of com_ring's
+                                                   * entry at the same index (AccView) */
   I4* com_ring;                                   /* [W][G] committedRequests {slot,bnum,bcoord,median} */
-  uint8_t* com_flags;                             /* [W][G] */
   /* view change, coordinator side; allocated by the first gpx_election_begin (null before: no
    * group can be GF_PREPARING then) */
   uint32_t* c_wait;   /* [G] waitforMyBallot: members heard from */
@@ -153,6 +153,8 @@ struct DevScratch {
   uint32_t* unsorted;           /* [1] = `epoch` iff the current batch's gidx column is NOT strictly
                                  * ascending and in range (k_hist); stale values mean "sorted" */
   uint32_t epoch;               /* call number, > 0 */
+  int32_t gate;                 /* accept-reply partition kernels launched BEHIND the sorted-runs path
+                                 * (gpx_runs.hip.h): they run only if k_runs_check raised *unsorted */
 };
 
 /* Java int subtraction (wraps) */
@@ -443,48 +445,6 @@ __device__ __forceinline__ void put_rec(const DevScratch& X, int32_t* lds, int32
    * (non-temporal stores measured: 2.6x slower - the L2 merges neighbouring records of a slice
    * before they reach HBM) */
   store_rec_pair(X.rec, pos, mk4((int32_t)i, g & mask, a, b), mk4(c, bnum, bcoord, 0));
-}
-
-/* accept-reply votes */
-template <bool VEC>
-__global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_ar(
-    int32_t n, int32_t ntiles, int32_t G, DevScratch X, const int32_t* __restrict__ gidx,
-    const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord,
-    const int32_t* __restrict__ slot, const int32_t* __restrict__ acceptor,
-    const int32_t* __restrict__ max_cp) {
-  extern __shared__ int32_t lds[];
-  const int32_t tile = tile_of_block(ntiles);
-  if (tile >= ntiles) return;
-  scatter_init(X, tile, lds);
-  const int64_t base = (int64_t)tile * GPX_TILE;
-  const int32_t mask = X.gb - 1;
-  if (VEC) {
-#pragma unroll
-    for (int j = 0; j < GPX_TILE_VECS; j++) {
-      const int64_t i0 = base + (int64_t)(j * GPX_FBLOCK + threadIdx.x) * 4;
-      if (i0 + 3 < n) {
-        const I4 g4 = *(const I4*)(gidx + i0), s4 = *(const I4*)(slot + i0);
-        const I4 a4 = *(const I4*)(acceptor + i0), m4 = *(const I4*)(max_cp + i0);
-        const I4 n4 = *(const I4*)(bnum + i0), c4 = *(const I4*)(bcoord + i0);
-        put_rec(X, lds, G, mask, i0 + 0, g4.x, s4.x, a4.x, m4.x, n4.x, c4.x);
-        put_rec(X, lds, G, mask, i0 + 1, g4.y, s4.y, a4.y, m4.y, n4.y, c4.y);
-        put_rec(X, lds, G, mask, i0 + 2, g4.z, s4.z, a4.z, m4.z, n4.z, c4.z);
-        put_rec(X, lds, G, mask, i0 + 3, g4.w, s4.w, a4.w, m4.w, n4.w, c4.w);
-      } else {
-        for (int q = 0; q < 4; q++) {
-          const int64_t i = i0 + q;
-          if (i < n)
-            put_rec(X, lds, G, mask, i, gidx[i], slot[i], acceptor[i], max_cp[i], bnum[i], bcoord[i]);
-        }
-      }
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < GPX_TILE_ITEMS; j++) {
-      const int64_t i = base + j * GPX_FBLOCK + threadIdx.x;
-      if (i < n) put_rec(X, lds, G, mask, i, gidx[i], slot[i], acceptor[i], max_cp[i], bnum[i], bcoord[i]);
-    }
-  }
 }
 
 /* accepts / commits (and every other call whose record is {a, b, c, ballot}); for accepts also
@@ -1123,38 +1083,73 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
   if (!has_coord && (gf & GF_HASCOORD)) S.g_flags[g] = gf & ~(GF_HASCOORD | GF_PREPARING);
 }
 
+/* The coordinator's STEADY STATE as straight-line code: every vote of the group answers ONE outstanding slot
+ * s0 at the group's current ballot, the coordinator exists, is active and its acceptor is not stopped.  Then
+ * only the cmp == 0 branch of apply_ar_group can run (handleAcceptReplyMyBallot, PCS:597-640): member bit,
+ * nodeSlotNumbers max (recordSlotNumber, plain <, PCS:809-825), majority test, getMedianMinus on the deciding
+ * vote; later votes of the slot only move nodeSlotNumbers (PCS:607 runs before the pstate == null test).
+ * Shared by the per-bucket kernel's wave-uniform fast path and the sorted-runs kernel. */
 template <int KMAX>
-__global__ __launch_bounds__(1024) void k_bucket_ar(DevState S, DevScratch X,
-                                                    uint8_t* __restrict__ status) {
-  extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  BucketView bv;
-  const int32_t g0 = blockIdx.x << X.shift;
-  /* dense batch (at least one record per two groups of this bucket) and one lane per group:
-   * fetch every group's coordinator state now */
-  const int32_t nb_ = X.bucket_off[blockIdx.x + 1] - X.bucket_off[blockIdx.x];
-  const bool pre = (int32_t)blockDim.x == X.gb && 2 * nb_ >= X.gb;
-  const int32_t gme = g0 + (int32_t)threadIdx.x;
-  CoordPre<KMAX> P;
-  P.have_pe = false;
-  if (pre && gme < S.G) coord_preload<KMAX>(S, gme, P);
-  if (!bucket_prepare(X, lds, &bv, [&]() {
-        if (pre && gme < S.G) coord_preload_ring<KMAX>(S, gme, P);
-      }))
-    return;
-  for (int32_t l = threadIdx.x; l < X.gb; l += (int32_t)blockDim.x) {
-    const int32_t c = bv.lcnt[l];
-    int32_t nout = 0;
-    if (c != 0 && g0 + l < S.G) {
-      GroupIter it;
-      it.init(bv, l, c);
-      if (!pre) coord_preload<KMAX>(S, g0 + l, P);
-      apply_ar_group<KMAX>(S, X, g0 + l, it, status, P);
-      nout = it.nout;
-    }
-    bv.lcnt[l] = nout; /* the group's record count is no longer needed: now its output count */
+struct SteadyGroup {
+  int32_t mem[KMAX], ns[KMAX];
+  int32_t k, pcount, pcount0;
+  uint32_t e, e0;
+  bool ns_dirty;
+  /* eligibility of the GROUP (the caller checks its votes: one slot s0, the coordinator's ballot) */
+  static __device__ __forceinline__ bool group_ok(const CoordPre<KMAX>& P) {
+    return (P.gf & (GF_EXISTS | GF_STOPPED | GF_HASCOORD | GF_PREPARING)) == (GF_EXISTS | GF_HASCOORD);
   }
-  bucket_emit(X, bv);
-}
+  static __device__ __forceinline__ bool slot_ok(const DevState& S, const CoordPre<KMAX>& P, int32_t s0) {
+    const int32_t d = jsub(P.next, s0);
+    return d >= 1 && d <= S.W;
+  }
+  __device__ __forceinline__ void init(const DevState& S, int32_t g, const CoordPre<KMAX>& P, int32_t s0) {
+    k = (int32_t)GF_K(P.gf);
+#pragma unroll
+    for (int j = 0; j < KMAX; j++) {
+      mem[j] = (j < k) ? P.mem[j] : 0;
+      ns[j] = (j < k) ? P.ns[j] : 0;
+    }
+    const int64_t off = (int64_t)(s0 & (S.W - 1)) * S.G + g;
+    e0 = (P.have_pe && s0 == jsub(P.next, 1)) ? P.pe : S.p_ring[off];
+    e = e0;
+    pcount = pcount0 = P.pcount;
+    ns_dirty = false;
+  }
+  /* one vote; true when it completes the majority: *median = the decision's medianCheckpointedSlot */
+  __device__ __forceinline__ bool vote(int32_t acc, int32_t maxcp, int32_t* median) {
+    int32_t midx = -1;
+#pragma unroll
+    for (int q = 0; q < KMAX; q++) {
+      if (q < k && mem[q] == acc) {
+        midx = q; /* WaitforUtility.getIndex: last match */
+        if (ns[q] < maxcp) { /* recordSlotNumber :809-825 (plain <) */
+          ns[q] = maxcp;
+          ns_dirty = true;
+        }
+      }
+    }
+    if (e & PR_PRESENT) {
+      if (midx >= 0) e |= (1u << midx);   /* updateHeardFrom :51-62 */
+      if (__popc(e & 0xffffu) > k / 2) { /* heardFromMajority :64-68 */
+        *median = median_minus<KMAX>(ns, k);
+        e = 0;
+        pcount--;
+        return true;
+      }
+    }
+    return false;
+  }
+  __device__ __forceinline__ void finish(const DevState& S, int32_t g, int32_t s0) {
+    if (e != e0) S.p_ring[(int64_t)(s0 & (S.W - 1)) * S.G + g] = e;
+    if (ns_dirty) {
+#pragma unroll
+      for (int q = 0; q < KMAX; q++)
+        if (q < k) S.node_slots[(int64_t)q * S.G + g] = ns[q];
+    }
+    if (pcount != pcount0) S.c_pcount[g] = pcount;
+  }
+};
 
 /* ------------------------------------------------------------------------- */
 /* acceptor helpers (one lane owns the group: plain loads/stores)               */
@@ -1164,25 +1159,94 @@ struct AccState {
   bool stopped;
 };
 
+/* One lane's view of its group's accepted ring.  Entry w = {slot, bnum, bcoord, flags}: the flag word carries
+ * BOTH flag bytes of ring index w - bits 0-7 of acceptedProposals' entry (RF_PRESENT | RF_STOP), bits 8-15 of
+ * committedRequests' entry (RF_PRESENT | RF_STOP | RF_HASVALUE; its other four words live in com_ring) - so
+ * one 16-byte load answers "what did I accept for this slot" and "is a commit waiting there" together (round
+ * 2 kept two separate byte arrays: two more loads, and byte stores, per record).  Two entries are cached in
+ * registers, stores go straight through: the record's own slot and the one the garbage collection or the
+ * execution loop looks at stay at hand instead of costing a dependent round trip each time. */
+#define AF_MASK 0xffu
+#define CF_SHIFT 8
+#define CF_MASK 0xff00u
+struct AccView {
+  I4* ring;
+  int64_t G;
+  int32_t g;
+  /* two cached entries as plain scalars, updated with selects only: anything that makes the compiler
+   * take the address of a cached word (an if / else between the two copies) sends the whole view to
+   * scratch memory */
+  int32_t w0, x0, y0, z0, f0; /* ring index (-1 = none) and the entry's four words */
+  int32_t w1, x1, y1, z1, f1;
+  __device__ __forceinline__ void init(const DevState& S, int32_t g_) {
+    ring = S.acc_ring;
+    G = S.G;
+    g = g_;
+    w0 = w1 = -1;
+    x0 = y0 = z0 = f0 = 0;
+    x1 = y1 = z1 = f1 = 0;
+  }
+  /* an entry the caller fetched ahead of time */
+  __device__ __forceinline__ void preset(int32_t w, const I4& v) {
+    w0 = w;
+    x0 = v.x;
+    y0 = v.y;
+    z0 = v.z;
+    f0 = v.w;
+  }
+  __device__ __forceinline__ void put(int32_t w, const I4& v) {
+    const bool in0 = w == w0 || w0 < 0;
+    w0 = in0 ? w : w0;
+    x0 = in0 ? v.x : x0;
+    y0 = in0 ? v.y : y0;
+    z0 = in0 ? v.z : z0;
+    f0 = in0 ? v.w : f0;
+    w1 = in0 ? w1 : w;
+    x1 = in0 ? x1 : v.x;
+    y1 = in0 ? y1 : v.y;
+    z1 = in0 ? z1 : v.z;
+    f1 = in0 ? f1 : v.w;
+  }
+  __device__ __forceinline__ I4 rd(int32_t w) {
+    const bool h0 = w == w0, h1 = w == w1;
+    I4 v = mk4(h0 ? x0 : x1, h0 ? y0 : y1, h0 ? z0 : z1, h0 ? f0 : f1);
+    if (!(h0 || h1)) {
+      v = ring[(int64_t)w * G + g];
+      put(w, v);
+    }
+    return v;
+  }
+  __device__ __forceinline__ void wr(int32_t w, const I4& v) {
+    ring[(int64_t)w * G + g] = v;
+    put(w, v);
+  }
+  /* only the flag word (the entry must have been read: it is cached) */
+  __device__ __forceinline__ void wr_flags(int32_t w, int32_t f) {
+    ((int32_t*)&ring[(int64_t)w * G + g])[3] = f;
+    f0 = (w == w0) ? f : f0;
+    f1 = (w == w1 && w != w0) ? f : f1;
+  }
+};
+
 /* PaxosAcceptor.garbageCollectAccepted (PaxosAcceptor.java:476-494).
  * garbageCollectDecisions (:496-506) can never find anything: committedRequests only ever
  * holds slots >= _slot (put only if slot - _slot >= 0, :341; removed on execution) and it
  * only drops slots < gcSlot <= _slot - 1. */
-__device__ __forceinline__ void acc_gc(const DevState& S, int32_t g, AccState& a, int32_t gcSlot) {
+__device__ __forceinline__ void acc_gc(const DevState& S, AccView& V, AccState& a, int32_t gcSlot) {
   if (jsub(a.slot, gcSlot) <= 0) gcSlot = jsub(a.slot, 1);
   const int32_t delta = jsub(gcSlot, a.gc);
   if (delta > 0) {
     const int32_t Wm = S.W - 1;
     if (delta >= S.W) {
       for (int32_t w = 0; w < S.W; w++) {
-        const int64_t o = (int64_t)w * S.G + g;
-        if ((S.acc_flags[o] & RF_PRESENT) && jsub(S.acc_ring[o].x, gcSlot) <= 0) S.acc_flags[o] = 0;
+        const I4 e = V.rd(w);
+        if ((e.w & RF_PRESENT) && jsub(e.x, gcSlot) <= 0) V.wr_flags(w, e.w & ~(int32_t)AF_MASK);
       }
     } else {
       /* live accepted slots are all > a.gc: only (a.gc, gcSlot] can die */
       for (int32_t s = (int32_t)((uint32_t)a.gc + 1u);; s = (int32_t)((uint32_t)s + 1u)) {
-        const int64_t o = (int64_t)(s & Wm) * S.G + g;
-        if ((S.acc_flags[o] & RF_PRESENT) && S.acc_ring[o].x == s) S.acc_flags[o] = 0;
+        const I4 e = V.rd(s & Wm);
+        if ((e.w & RF_PRESENT) && e.x == s) V.wr_flags(s & Wm, e.w & ~(int32_t)AF_MASK);
         if (s == gcSlot) break;
       }
     }
@@ -1195,21 +1259,22 @@ struct Dec {
   bool has_value, stop;
 };
 
-/* PaxosAcceptor.reconstructDecision (PaxosAcceptor.java:369-385).
+/* PaxosAcceptor.reconstructDecision (PaxosAcceptor.java:369-385) for a slot whose ring index holds a
+ * commit (the caller has tested the commit's RF_PRESENT bit).
  * Written branch-free on purpose.  The natural nested-if form (return early per failed test,
  * assign *out inside the two succeeding branches) was MISCOMPILED by hipcc (ROCm 7.2, -O3,
  * gfx950) once inlined into the accept kernel: after CFG structurization the median of the
  * "placeholder + matching accept" path was replaced by the failing paths' value (an undefined
  * register, or 0 when *out was pre-zeroed) — the isolated function's LLVM IR was correct, the
  * kernel's ISA was not.  Found by the parity fuzz; the select form below has no merge to get
- * wrong.  All four loads are always in bounds (same ring index for both rings). */
-__device__ __forceinline__ bool acc_reconstruct(const DevState& S, int32_t g, int32_t slot,
+ * wrong.  The loads are always in bounds (same ring index for both rings). */
+__device__ __forceinline__ bool acc_reconstruct(const DevState& S, AccView& V, int32_t g, int32_t slot,
                                                 Dec* out) {
-  const int64_t o = (int64_t)(slot & (S.W - 1)) * S.G + g;
-  const uint32_t cf = S.com_flags[o];
-  const uint32_t af = S.acc_flags[o];
-  const I4 cr = S.com_ring[o];
-  const I4 ar = S.acc_ring[o];
+  const int32_t w = slot & (S.W - 1);
+  const I4 ar = V.rd(w);
+  const uint32_t cf = ((uint32_t)ar.w >> CF_SHIFT) & 0xffu;
+  const uint32_t af = (uint32_t)ar.w & AF_MASK;
+  const I4 cr = S.com_ring[(int64_t)w * S.G + g];
   const bool committed = (cf & RF_PRESENT) && cr.x == slot;
   const bool hasv = (cf & RF_HASVALUE) != 0;
   const bool acc_ok = (af & RF_PRESENT) && ar.x == slot && ballot_cmp(ar.y, ar.z, cr.y, cr.z) == 0;
@@ -1227,39 +1292,57 @@ __device__ __forceinline__ bool acc_reconstruct(const DevState& S, int32_t g, in
 /* PaxosInstanceStateMachine.extractExecuteAndCheckpoint (PISM:1619-1701) around
  * PaxosAcceptor.putAndRemoveNextExecutable (PaxosAcceptor.java:325-366) and executed (:462-474).
  * Returns the number of slots executed in order starting at the entry value of a.slot. */
-__device__ __forceinline__ int32_t acc_eec(const DevState& S, int32_t g, AccState& a,
+__device__ __forceinline__ int32_t acc_eec(const DevState& S, AccView& V, int32_t g, AccState& a,
                                            const Dec& d) {
   int32_t count = 0;
   const int32_t Wm = S.W - 1;
   const bool from_disk = (S.flags & GPX_F_ACCEPTS_FROM_DISK) != 0;
   while (!a.stopped) {
-    acc_gc(S, g, a, d.median);
+    acc_gc(S, V, a, d.median);
+    /* the usual commit - a decision WITH its value for exactly the next slot - is put into
+     * committedRequests and taken out again by the same call (:343-353): nothing needs storing */
+    bool direct = false;
     if (jsub(d.slot, a.slot) >= 0) {
       /* don't overwrite an existing decision that has a value (:343-346) */
-      const int64_t o = (int64_t)(d.slot & Wm) * S.G + g;
-      const uint8_t cf = S.com_flags[o];
-      const bool same = (cf & RF_PRESENT) && S.com_ring[o].x == d.slot;
+      const int32_t wd = d.slot & Wm;
+      const I4 e = V.rd(wd);
+      const uint32_t cf = ((uint32_t)e.w >> CF_SHIFT) & 0xffu;
+      bool same = false;
+      if (cf & RF_PRESENT) same = S.com_ring[(int64_t)wd * S.G + g].x == d.slot;
       if (!same || !(cf & RF_HASVALUE)) {
-        S.com_ring[o] = mk4(d.slot, d.bnum, d.bcoord, d.median);
-        S.com_flags[o] =
-            (uint8_t)(RF_PRESENT | (d.has_value ? RF_HASVALUE : 0) | (d.stop ? RF_STOP : 0));
+        if (d.slot == a.slot && d.has_value) {
+          direct = true;
+          if (cf) V.wr_flags(wd, e.w & ~(int32_t)CF_MASK); /* what it replaces goes with it */
+        } else {
+          S.com_ring[(int64_t)wd * S.G + g] = mk4(d.slot, d.bnum, d.bcoord, d.median);
+          const uint32_t nf = RF_PRESENT | (d.has_value ? RF_HASVALUE : 0u) | (d.stop ? RF_STOP : 0u);
+          V.wr_flags(wd, (int32_t)(((uint32_t)e.w & ~CF_MASK) | (nf << CF_SHIFT)));
+        }
       }
     }
-    Dec nx = Dec{0, 0, 0, 0, false, false};
-    /* nothing committed in the next slot's ring entry (the usual end of the loop): the one flag
-     * byte says so without the three other loads of acc_reconstruct */
-    if (!(S.com_flags[(int64_t)(a.slot & Wm) * S.G + g] & RF_PRESENT)) break;
-    if (!acc_reconstruct(S, g, a.slot, &nx)) break;
-    /* committedRequests.remove(_slot); executed(slot, isStop) */
-    const int64_t o0 = (int64_t)(a.slot & Wm) * S.G + g;
-    S.com_flags[o0] = 0;
+    Dec nx = d;
+    const int32_t wx = a.slot & Wm;
+    if (!direct) {
+      /* nothing committed in the next slot's ring entry (the usual end of the loop) */
+      const I4 e2 = V.rd(wx);
+      if (!(((uint32_t)e2.w >> CF_SHIFT) & RF_PRESENT)) break;
+      nx = Dec{0, 0, 0, 0, false, false};
+      if (!acc_reconstruct(S, V, g, a.slot, &nx)) break;
+      /* committedRequests.remove(_slot) */
+      V.wr_flags(wx, V.rd(wx).w & ~(int32_t)CF_MASK);
+    }
+    /* executed(slot, isStop) */
     a.slot = (int32_t)((uint32_t)a.slot + 1u);
     if (nx.stop) a.stopped = true;
     if (a.stopped)
-      for (int32_t w = 0; w < S.W; w++) S.com_flags[(int64_t)w * S.G + g] = 0;
+      for (int32_t w = 0; w < S.W; w++) { /* committedRequests.clear() (:468-469) */
+        const I4 e = V.rd(w);
+        if ((uint32_t)e.w & CF_MASK) V.wr_flags(w, e.w & ~(int32_t)CF_MASK);
+      }
     if (from_disk) {
       /* acceptedProposals.remove(nextExecutable.slot) (:357-359) */
-      if ((S.acc_flags[o0] & RF_PRESENT) && S.acc_ring[o0].x == nx.slot) S.acc_flags[o0] = 0;
+      const I4 e = V.rd(wx);
+      if ((e.w & RF_PRESENT) && e.x == nx.slot) V.wr_flags(wx, e.w & ~(int32_t)AF_MASK);
     }
     count++;
     if (nx.stop) break;
@@ -1267,12 +1350,60 @@ __device__ __forceinline__ int32_t acc_eec(const DevState& S, int32_t g, AccStat
   return count;
 }
 
-__device__ __forceinline__ void acc_load(const DevState& S, int32_t g, uint32_t gf, AccState& a) {
-  a.slot = S.a_slot[g];
-  a.bnum = S.a_bnum[g];
-  a.bcoord = S.a_bcoord[g];
-  a.gc = S.a_gc[g];
-  a.stopped = (gf & GF_STOPPED) != 0;
+/* acceptor state of one group, fetched ahead of the replay by kernels that know their group early
+ * (k_ac_direct: the loads go out together instead of one dependent round trip after the other) */
+struct AccPre {
+  uint32_t gf;
+  int32_t slot, bnum, bcoord, gc;
+  int32_t w;  /* ring index of the first record's slot; -2 = nothing was fetched ahead (acc_begin loads) */
+  int32_t ex, ey, ez, ew; /* that ring entry */
+};
+__device__ __forceinline__ AccPre acc_nopre() {
+  AccPre P;
+  P.gf = 0;
+  P.slot = P.bnum = P.bcoord = P.gc = 0;
+  P.w = -2;
+  P.ex = P.ey = P.ez = P.ew = 0;
+  return P;
+}
+__device__ __forceinline__ void acc_preload(const DevState& S, int32_t g, int32_t first_slot, AccPre& P) {
+  P.gf = S.g_flags[g];
+  P.slot = S.a_slot[g];
+  P.bnum = S.a_bnum[g];
+  P.bcoord = S.a_bcoord[g];
+  P.gc = S.a_gc[g];
+  P.w = first_slot & (S.W - 1);
+  const I4 e = S.acc_ring[(int64_t)P.w * S.G + g];
+  P.ex = e.x;
+  P.ey = e.y;
+  P.ez = e.z;
+  P.ew = e.w;
+}
+__device__ __forceinline__ void acc_begin(const DevState& S, int32_t g, const AccPre& pre, uint32_t& gf,
+                                          AccState& a, AccView& V) {
+  V.init(S, g);
+  a.slot = a.bnum = a.bcoord = a.gc = 0;
+  a.stopped = false;
+  if (pre.w != -2) {
+    gf = pre.gf;
+    if (gf & GF_EXISTS) {
+      a.slot = pre.slot;
+      a.bnum = pre.bnum;
+      a.bcoord = pre.bcoord;
+      a.gc = pre.gc;
+      a.stopped = (gf & GF_STOPPED) != 0;
+      V.preset(pre.w, mk4(pre.ex, pre.ey, pre.ez, pre.ew));
+    }
+  } else {
+    gf = S.g_flags[g];
+    if (gf & GF_EXISTS) {
+      a.slot = S.a_slot[g];
+      a.bnum = S.a_bnum[g];
+      a.bcoord = S.a_bcoord[g];
+      a.gc = S.a_gc[g];
+      a.stopped = (gf & GF_STOPPED) != 0;
+    }
+  }
 }
 __device__ __forceinline__ void acc_store(const DevState& S, int32_t g, uint32_t gf,
                                           const AccState& a, const AccState& a0) {
@@ -1305,13 +1436,12 @@ template <class IT>
 __device__ __forceinline__ void apply_accept_group(
     const DevState& S, const DevScratch& X, int32_t g, IT& it, int32_t* __restrict__ r_bnum,
     int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
-    uint8_t* __restrict__ status, I4* __restrict__ r_packed = nullptr) {
-  const uint32_t gf = S.g_flags[g];
+    uint8_t* __restrict__ status, I4* __restrict__ r_packed = nullptr, const AccPre pre = acc_nopre()) {
+  uint32_t gf;
   AccState a;
-  a.slot = a.bnum = a.bcoord = a.gc = 0;
-  a.stopped = false;
+  AccView V;
+  acc_begin(S, g, pre, gf, a, V);
   const bool exists = (gf & GF_EXISTS) != 0;
-  if (exists) acc_load(S, g, gf, a);
   const AccState a0 = a;
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
@@ -1325,11 +1455,10 @@ __device__ __forceinline__ void apply_accept_group(
       n_drop++;
       continue;
     }
-    const int64_t o = (int64_t)(slot & Wm) * S.G + g;
+    const int32_t w = slot & Wm;
     /* PValuePacket prev = paxosState.getAccept(accept.slot)  (:1122, before accepting) */
-    const uint8_t af = S.acc_flags[o];
-    const I4 ar = S.acc_ring[o];
-    const bool live = (af & RF_PRESENT) != 0;
+    const I4 ar = V.rd(w);
+    const bool live = (ar.w & RF_PRESENT) != 0;
     const bool have_prev = live && ar.x == slot;
     /* PaxosAcceptor.acceptAndUpdateBallot (PaxosAcceptor.java:302-322) */
     const bool ballot_ok = ballot_cmp(r.bnum, r.bcoord, a.bnum, a.bcoord) >= 0;
@@ -1343,12 +1472,11 @@ __device__ __forceinline__ void apply_accept_group(
     if (ballot_ok) {
       a.bnum = r.bnum;
       a.bcoord = r.bcoord;
-      if (will_store) {
-        S.acc_ring[o] = mk4(slot, r.bnum, r.bcoord, 0);
-        S.acc_flags[o] = (uint8_t)(RF_PRESENT | (stop ? RF_STOP : 0));
-      }
+      if (will_store)
+        V.wr(w, mk4(slot, r.bnum, r.bcoord,
+                    (int32_t)(((uint32_t)ar.w & CF_MASK) | RF_PRESENT | (stop ? (uint32_t)RF_STOP : 0u))));
     }
-    acc_gc(S, g, a, median);
+    acc_gc(S, V, a, median);
     /* reply (myID, ballot, slot, getSlot()-1)  (:1139-1143) */
     const int32_t rep_bnum = a.bnum, rep_bcoord = a.bcoord, rep_maxcp = jsub(a.slot, 1);
     /* toLog (:1146-1149) */
@@ -1360,9 +1488,9 @@ __device__ __forceinline__ void apply_accept_group(
     /* status[ix] stays GPX_S_OK (prefilled by k_hist) */
     /* might release some meta-commits (:1158-1161) */
     Dec rd = Dec{0, 0, 0, 0, false, false};
-    if ((S.com_flags[o] & RF_PRESENT) && acc_reconstruct(S, g, slot, &rd)) {
+    if ((((uint32_t)V.rd(w).w >> CF_SHIFT) & RF_PRESENT) && acc_reconstruct(S, V, g, slot, &rd)) {
       const int32_t first = a.slot;
-      const int32_t cnt_exec = acc_eec(S, g, a, rd);
+      const int32_t cnt_exec = acc_eec(S, V, g, a, rd);
       if (cnt_exec > 0) {
         it.emit(0, first, cnt_exec, 0, 1);
       }
@@ -1399,13 +1527,12 @@ __global__ __launch_bounds__(1024) void k_bucket_accept(
 template <class IT>
 __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevScratch& X,
                                                    int32_t g, IT& it,
-                                                   uint8_t* __restrict__ status) {
-  const uint32_t gf = S.g_flags[g];
+                                                   uint8_t* __restrict__ status, const AccPre pre = acc_nopre()) {
+  uint32_t gf;
   AccState a;
-  a.slot = a.bnum = a.bcoord = a.gc = 0;
-  a.stopped = false;
+  AccView V;
+  acc_begin(S, g, pre, gf, a, V);
   const bool exists = (gf & GF_EXISTS) != 0;
-  if (exists) acc_load(S, g, gf, a);
   const AccState a0 = a;
   const int32_t Wm = S.W - 1;
   unsigned long long n_drop = 0;
@@ -1427,16 +1554,14 @@ __device__ __forceinline__ void apply_commit_group(const DevState& S, const DevS
       d = Dec{r.bnum, r.bcoord, slot, median, true, (kind & GPX_C_STOP) != 0};
     } else {
       /* accept != null && accept.ballot.equals(batchedCommit.ballot) (:1492) */
-      const int64_t o = (int64_t)(slot & Wm) * S.G + g;
-      const uint8_t af = S.acc_flags[o];
-      const I4 ar = S.acc_ring[o];
-      if ((af & RF_PRESENT) && ar.x == slot && ballot_cmp(ar.y, ar.z, r.bnum, r.bcoord) == 0)
-        d = Dec{ar.y, ar.z, slot, median, true, (af & RF_STOP) != 0};
+      const I4 ar = V.rd(slot & Wm);
+      if ((ar.w & RF_PRESENT) && ar.x == slot && ballot_cmp(ar.y, ar.z, r.bnum, r.bcoord) == 0)
+        d = Dec{ar.y, ar.z, slot, median, true, (ar.w & RF_STOP) != 0};
       else
         d = Dec{r.bnum, r.bcoord, slot, median, false, false}; /* placeholder (:1510-1520) */
     }
     const int32_t first = a.slot;
-    const int32_t cnt_exec = acc_eec(S, g, a, d);
+    const int32_t cnt_exec = acc_eec(S, V, g, a, d);
     if (cnt_exec > 0) {
       it.emit(0, first, cnt_exec, 0, 1);
     }
@@ -1817,8 +1942,8 @@ __global__ __launch_bounds__(1024) void k_bucket_prepare(DevState S, DevScratch 
         /* pruneAcceptedProposals: keep slot - firstUndecidedSlot >= 0 (:283-293) */
         for (int32_t w = 0; w < S.W; w++) {
           const int64_t o = (int64_t)w * S.G + g;
-          if (!(S.acc_flags[o] & RF_PRESENT)) continue;
           const I4 a = S.acc_ring[o];
+          if (!(a.w & RF_PRESENT)) continue;
           if (jsub(a.x, first) < 0) continue;
           mask |= 1ull << w;
           const int64_t q = (int64_t)w * O.n + ix;
@@ -2002,7 +2127,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_gap_scan(DevState S, int32_t n,
   if (!stopped)
     for (int32_t w = 0; w < S.W; w++) {
       const int64_t o = (int64_t)w * S.G + g;
-      if ((S.com_flags[o] & RF_PRESENT) && jsub(S.com_ring[o].x, maxc) > 0) maxc = S.com_ring[o].x;
+      if ((((uint32_t)S.acc_ring[o].w >> CF_SHIFT) & RF_PRESENT) && jsub(S.com_ring[o].x, maxc) > 0) maxc = S.com_ring[o].x;
     }
   max_committed[i] = maxc;
   /* shouldSync (PISM:2341-2364), DISABLE_SYNC_DECISIONS = false */
@@ -2022,9 +2147,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_gap_scan(DevState S, int32_t n,
   for (int32_t s = slot; jsub(s, maxc) < 0 && jsub(s, limit) < 0 && j < 64;
        s = (int32_t)((uint32_t)s + 1u), j++) {
     const int64_t o = (int64_t)(s & Wm) * S.G + g;
-    const uint8_t cf = S.com_flags[o];
+    const I4 ae = S.acc_ring[o];
+    const uint32_t cf = ((uint32_t)ae.w >> CF_SHIFT) & 0xffu;
     const bool have = (cf & RF_PRESENT) && S.com_ring[o].x == s;
-    const bool acc = (S.acc_flags[o] & RF_PRESENT) && S.acc_ring[o].x == s;
+    const bool acc = (ae.w & RF_PRESENT) && ae.x == s;
     if (!have || (!(cf & RF_HASVALUE) && !acc)) m |= 1ull << j;
   }
   missing[i] = m;
@@ -2076,8 +2202,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_group_create(DevState S, int32_t 
   for (int32_t w = 0; w < S.W; w++) {
     const int64_t o = (int64_t)w * S.G + g;
     S.p_ring[o] = 0;
-    S.acc_flags[o] = 0;
-    S.com_flags[o] = 0;
+    S.acc_ring[o] = mk4(0, 0, 0, 0);
   }
   S.g_flags[g] = GF_EXISTS | (coord ? GF_HASCOORD : 0u) | ((uint32_t)k << 8);
   if (name_rows) { /* the wire codec's copy of (exists, version) in the group's name row (gpx_wire.hip.h) */
@@ -2132,8 +2257,9 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_group_retire(DevState S, int32_t 
     const bool from_disk = (S.flags & GPX_F_ACCEPTS_FROM_DISK) != 0;
     for (int32_t w = 0; w < S.W; w++) {
       const int64_t o = (int64_t)w * S.G + g;
-      if (S.com_flags[o] & RF_PRESENT) caught = false;
-      if (!from_disk && (S.acc_flags[o] & RF_PRESENT)) caught = false;
+      const int32_t fl = S.acc_ring[o].w;
+      if (((uint32_t)fl >> CF_SHIFT) & RF_PRESENT) caught = false;
+      if (!from_disk && (fl & RF_PRESENT)) caught = false;
     }
     if ((gf & GF_HASCOORD) && S.c_pcount[g] != 0) caught = false;
     if (!caught) {

@@ -1264,99 +1264,6 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_write(DevState S, DevNames N
   }
 }
 
-/* The three passes in ONE launch: sizes, look-back over the tiles for (bytes, frames, refused
- * blocks) - waves 0, 1, 2 of the workgroup walk one word array each (wl_lookback) - frames built in LDS
- * and flushed at the tile's byte offset.  X.err / X.size / X.tile_* are not used: a block of rows that
- * exceeds GPX_W_MAX_SEG travels as the third look-back count (a flag in global memory written by one
- * workgroup and read by the last would need an ordering the relaxed words do not give). */
-__global__ __launch_bounds__(GPX_BLOCK) void k_pack_commits1(DevState S, DevNames N, PackIn P, WireLook K,
-                                                            int32_t ntiles, uint8_t* __restrict__ out,
-                                                            long long cap_bytes,
-                                                            long long* __restrict__ frame_off,
-                                                            int32_t* __restrict__ frame_len,
-                                                            int32_t* __restrict__ f_gidx,
-                                                            int32_t* __restrict__ n_frames,
-                                                            long long* __restrict__ n_bytes) {
-  __shared__ uint32_t stage[GPX_PACK_STAGE_BYTES / 4];
-  __shared__ int32_t s_tile, s_err;
-  __shared__ uint32_t s_tot[3];
-  __shared__ unsigned long long s_base[3];
-  if (threadIdx.x == 0) {
-    const uint32_t t = atomicAdd(K.ticket, 1u);
-    if (t == (uint32_t)ntiles - 1u) *K.ticket = 0u;
-    s_tile = (int32_t)t;
-    s_err = 0;
-  }
-  __syncthreads();
-  const int32_t tile = s_tile;
-  const int32_t n = pack_rows(P);
-  const int32_t i = tile * GPX_BLOCK + (int32_t)threadIdx.x;
-  PackScratch X;
-  X.err = &s_err; /* pack_is_head's refusal flag: this workgroup's share */
-  X.size = nullptr;
-  X.tile_b = nullptr;
-  X.tile_f = nullptr;
-  X.ntiles = ntiles;
-  const int32_t size = pack_frame_size(S, N, P, X, n, i);
-  int32_t tb, tf;
-  const int32_t eb = block_exscan(size, &tb);
-  const int32_t ef = block_exscan(size ? 1 : 0, &tf);
-  if (threadIdx.x == 0) {
-    s_tot[0] = (uint32_t)tb;
-    s_tot[1] = (uint32_t)tf;
-    s_tot[2] = s_err ? 1u : 0u;
-  }
-  __syncthreads();
-  {
-    const int32_t c = (int32_t)(threadIdx.x >> 6);
-    if (c < 3) {
-      unsigned long long* st = K.state + (int64_t)c * ntiles;
-      const uint32_t mine = s_tot[c];
-      if ((threadIdx.x & 63) == 0)
-        __hip_atomic_store(&st[tile], wl_word(K.epoch, tile == 0 ? WL_PRE : WL_AGG, mine), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      const unsigned long long excl = tile == 0 ? 0ull : wl_lookback64(st, tile, K.epoch);
-      if ((threadIdx.x & 63) == 0) {
-        if (tile != 0)
-          __hip_atomic_store(&st[tile],
-                             ((unsigned long long)K.epoch << 40) | (WL_PRE << 38) | ((excl + mine) & WL_VAL_MASK),
-                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        s_base[c] = excl;
-      }
-    }
-  }
-  __syncthreads();
-  const long long tile0 = (long long)s_base[0];
-  if (tile == ntiles - 1 && threadIdx.x == 0) {
-    *n_frames = (s_base[2] + s_tot[2]) ? -1 : (int32_t)(s_base[1] + s_tot[1]);
-    *n_bytes = tile0 + tb;
-  }
-  const bool staged = tb <= GPX_PACK_STAGE_BYTES && tile0 + tb <= cap_bytes; /* workgroup-uniform */
-  const long long off = tile0 + eb;
-  const int32_t fi = (int32_t)s_base[1] + ef;
-  if (size && (staged || off + size <= cap_bytes)) { /* else: the host sees n_bytes > cap_bytes */
-    int32_t len;
-    if (staged) {
-      BEWriterLds w;
-      w.w = stage + (eb >> 2);
-      w.acc = 0;
-      w.k = 0;
-      len = pack_commit_frame(S, N, P, n, i, w);
-    } else {
-      BEWriter w;
-      w.init(out + off);
-      len = pack_commit_frame(S, N, P, n, i, w);
-    }
-    frame_off[fi] = off;
-    frame_len[fi] = len;
-    f_gidx[fi] = P.gidx[i];
-  }
-  if (staged) {
-    __syncthreads();
-    uint32_t* dst = (uint32_t*)(out + tile0); /* tile0 is a multiple of 4 */
-    for (int32_t wi = threadIdx.x; wi < (tb >> 2); wi += GPX_BLOCK) dst[wi] = stage[wi];
-  }
-}
 
 /* ------------------------------------------------------------------------- */
 /* encode: accept replies -> BATCHED_ACCEPT_REPLY frames                         */

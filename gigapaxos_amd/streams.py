@@ -73,3 +73,41 @@ def fmix32(h):
 
 def shard_of(gidx, n_shards: int):
     return (fmix32(gidx) % np.uint32(n_shards)).astype(np.int32)
+
+
+def vote_round_runs(num_groups: int, members, rnd: int, coordinator: int, config_id: int = 3, mix: bool = False,
+                    groups=None, drop: float = 0.0):
+    """The same round as the coordinator of a real cluster sees it: the replies of acceptor 0, then those of
+    acceptor 1, ... - every acceptor's replies grouped by group, groups ascending (the order they leave
+    gpx_accept_batch in), i.e. len(members) ascending runs.  mix: 1 % duplicated votes (adjacent to the
+    original, as a retransmitted frame would sit), 0.5 % stale-ballot and 0.1 % higher-ballot votes inside
+    the runs; drop: fraction of every acceptor's replies that is missing (lost frames: the runs differ)."""
+    members = np.asarray(members, np.int32)
+    k = members.shape[0]
+    rng = _rng(config_id ^ 0x5A, rnd)
+    g = np.arange(num_groups, dtype=np.int32) if groups is None else np.sort(np.asarray(groups, np.int32))
+    s = rnd + 1
+    cols = [[] for _ in range(6)]
+    for j in range(k):
+        gj = g
+        if drop > 0.0:
+            gj = g[rng.random(g.shape[0]) >= drop]
+        n = gj.shape[0]
+        bnum = np.zeros(n, np.int32)
+        bcoord = np.full(n, coordinator, np.int32)
+        if mix:
+            dup = rng.random(n) < 0.01
+            rep = np.ones(n, np.int64)
+            rep[dup] = 2
+            gj = np.repeat(gj, rep)
+            n = gj.shape[0]
+            bnum = np.zeros(n, np.int32)
+            bcoord = np.full(n, coordinator, np.int32)
+            stale = rng.random(n) < 0.005
+            bcoord[stale] -= 1
+            higher = rng.random(n) < 0.001
+            bnum[higher] = 1
+        for c, v in zip(cols, (gj, bnum, bcoord, np.full(n, s, np.int32), np.full(n, members[j], np.int32),
+                               np.full(n, s - 1, np.int32))):
+            c.append(v)
+    return tuple(np.ascontiguousarray(np.concatenate(c)) for c in cols)

@@ -37,8 +37,8 @@
  *     fully concurrent.
  *   - the plain entry points take HOST pointers (what a JNI direct ByteBuffer
  *     gives); the *_dev twins take DEVICE pointers, run asynchronously on the
- *     engine's stream and leave counts in device memory (used when the batch is
- *     already resident in HBM).
+ *     engine's stream (gpx_engine_set_stream) and leave counts in device memory
+ *     (used when the batch is already resident in HBM).
  */
 #ifndef GPX_H
 #define GPX_H
@@ -150,24 +150,6 @@ int gpx_host_unregister(gpx_engine* h, void* ptr);
 /* block until everything submitted to the engine has finished */
 int gpx_engine_sync(gpx_engine* h);
 /*
- * Pipelined mode (off by default).  A batch call has a streaming front end (partition of the
- * batch by group bucket: reads only the input columns) and a per-bucket back end (the state
- * machine proper).  With pipelining on, the *_dev calls run the front end of call N+1 beside the
- * back end of call N on two engine-owned streams (front-end scratch is double-buffered); group
- * state is still updated strictly in call order.  Stream contract in this mode:
- *   - inputs may be produced by work already enqueued on the caller's stream
- *     (gpx_engine_set_stream): the front end waits for it;
- *   - a call whose inputs (or early-written outputs) overlap the previous call's outputs is
- *     detected and not overlapped;
- *   - outputs are complete after gpx_engine_sync, or, for later work on the caller's stream,
- *     after gpx_engine_fence.
- * With pipelining off every *_dev call is simply enqueued on the caller's (or the engine's
- * own) stream and gpx_engine_fence is a no-op.
- */
-int gpx_engine_set_pipeline(gpx_engine* h, int32_t on);
-int gpx_engine_fence(gpx_engine* h);
-
-/*
  * Promise about the batches of later calls (mask of GPX_ORDERED_*; 0 = none, the default).
  * Inside the pipeline a batch is usually the previous stage's output and already GROUPED BY GROUP:
  * RequestBatcher hands over one batched request per group (gidx strictly ascending), the ACCEPTs
@@ -184,6 +166,23 @@ int gpx_engine_fence(gpx_engine* h);
 #define GPX_ORDERED_PROPOSE 1
 #define GPX_ORDERED_ACCEPT 2
 #define GPX_ORDERED_COMMIT 4
+/*
+ * Accept replies.  What reaches a coordinator is the concatenation of what each acceptor sent, and an
+ * acceptor's replies leave gpx_accept_batch in the order of the ACCEPT batch - grouped by group, groups
+ * ascending: the vote batch is a few ASCENDING RUNS (one per acceptor), the shape the reference walks as one
+ * TreeMap per acceptor, group and ballot (PISM.handleBatchedAcceptReply, PaxosInstanceStateMachine.java:
+ * 1370-1419).  The engine applies such a batch without partitioning it: every group's votes are found in
+ * every run and replayed in array order (run 0's before run 1's: arrival order).
+ *   GPX_ORDERED_REPLY_RUNS  promise: gidx in range and at most GPX_REPLY_RUNS_MAX non-decreasing runs.
+ *                           Verified on the device; a batch that breaks it is refused whole (every vote
+ *                           GPX_S_UNORDERED, n_out = 0, no state change), like the other promises.
+ *   GPX_TRY_REPLY_RUNS      hint, not a promise: the shape is checked on the device and any other batch
+ *                           goes through the partition pipeline as before (a few idle launches dearer).
+ * Results are identical on every path.
+ */
+#define GPX_ORDERED_REPLY_RUNS 8
+#define GPX_TRY_REPLY_RUNS 16
+#define GPX_REPLY_RUNS_MAX 16 /* = GPX_KMAX_LIMIT acceptors */
 int gpx_engine_set_ordered_batches(gpx_engine* h, int32_t mask);
 
 /*

@@ -461,7 +461,9 @@ int orc_engine_destroy(gpx_engine* h) {
 }
 int orc_engine_sync(gpx_engine*) { return GPX_OK; }
 int orc_engine_set_ordered_batches(gpx_engine* h, int32_t mask) {
-  if (!h || (mask & ~(GPX_ORDERED_PROPOSE | GPX_ORDERED_ACCEPT | GPX_ORDERED_COMMIT))) return GPX_EINVAL;
+  if (!h || (mask & ~(GPX_ORDERED_PROPOSE | GPX_ORDERED_ACCEPT | GPX_ORDERED_COMMIT | GPX_ORDERED_REPLY_RUNS |
+                      GPX_TRY_REPLY_RUNS)))
+    return GPX_EINVAL;
   reinterpret_cast<Engine*>(h)->ordered_mask = mask;
   return GPX_OK;
 }
@@ -471,6 +473,16 @@ static bool batch_keeps_order(const Engine* e, int32_t n, const int32_t* gidx, b
   for (int32_t i = 0; i < n; i++) {
     if (gidx[i] < 0 || gidx[i] >= e->cfg.max_groups) return false;
     if (i + 1 < n && (strict ? gidx[i] >= gidx[i + 1] : gidx[i] > gidx[i + 1])) return false;
+  }
+  return true;
+}
+/* the promise GPX_ORDERED_REPLY_RUNS: gidx in range and at most GPX_REPLY_RUNS_MAX non-decreasing runs (the
+ * concatenated replies of the acceptors).  GPX_TRY_REPLY_RUNS is only a hint to the engine: nothing to do. */
+static bool batch_is_few_runs(const Engine* e, int32_t n, const int32_t* gidx) {
+  int32_t descents = 0;
+  for (int32_t i = 0; i < n; i++) {
+    if (gidx[i] < 0 || gidx[i] >= e->cfg.max_groups) return false;
+    if (i + 1 < n && gidx[i] > gidx[i + 1] && ++descents > GPX_REPLY_RUNS_MAX - 1) return false;
   }
   return true;
 }
@@ -823,6 +835,12 @@ int orc_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
   if (!h || n < 0) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);
   int32_t out = 0;
+  if ((e->ordered_mask & GPX_ORDERED_REPLY_RUNS) && !batch_is_few_runs(e, n, gidx)) {
+    if (status)
+      for (int32_t i = 0; i < n; i++) status[i] = GPX_S_UNORDERED;
+    *n_out = 0;
+    return GPX_OK;
+  }
   for (int32_t i = 0; i < n; i++) {
     e->counters[0]++;
     Group* g = e->get(gidx[i]);

@@ -5,7 +5,10 @@ Three engines = the three replicas of every group (BASELINE config #2's shape at
 all on one GPU, columns resident in HBM.  One round =
   coordinator: propose(G)                       -> ACCEPT (slot, ballot) per group
   3 acceptors: accept(G) each                   -> replies
-  coordinator: accept_reply(3 G shuffled votes) -> G decisions
+  coordinator: accept_reply(3 G votes)          -> G decisions.  The votes are the three acceptors' reply
+               columns CONCATENATED - three ascending runs, what a coordinator really receives (each acceptor's
+               replies leave gpx_accept_batch grouped by group): the sorted-runs path, no partition
+               (gpx_runs.hip.h); --shuffled-replies shuffles them as round 2's bench did (partition pipeline)
   3 replicas:  commit(G) each                   -> in-order execution runs
 Per-phase GPU time with torch events; per-kernel split from the engines' hipEvent profile."""
 import argparse
@@ -19,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gigapaxos_amd import (Engine, hri_create, load_hip, S_OK, C_HASVALUE, ORDERED_PROPOSE,  # noqa: E402
-                           ORDERED_ACCEPT, ORDERED_COMMIT)
+                           ORDERED_ACCEPT, ORDERED_COMMIT, ORDERED_REPLY_RUNS)
 
 
 def main():
@@ -30,6 +33,8 @@ def main():
     ap.add_argument("--unordered", action="store_true",
                     help="ACCEPT and COMMIT batches in a random record order (what an acceptor sees when the frames "
                          "of many coordinators interleave): the partition path instead of the direct one")
+    ap.add_argument("--shuffled-replies", action="store_true",
+                    help="the 3 G votes in a random order (round 2's bench): the partition pipeline")
     ap.add_argument("--no-promise", action="store_true",
                     help="do not declare the batches ordered (gpx_engine_set_ordered_batches): the engine then "
                          "also launches the partition path, which returns at once")
@@ -46,7 +51,8 @@ def main():
         assert (e.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
         e.set_stream(ts.cuda_stream)
         if not args.no_promise and not args.unordered:  # every batch here is the previous stage's output: grouped by group
-            e.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT)
+            e.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT |
+                                  (0 if args.shuffled_replies else ORDERED_REPLY_RUNS))
         eng[nid] = e
     i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
     u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)  # noqa: E731
@@ -86,11 +92,15 @@ def main():
             eng[nid].call_dev("accept_batch", G, P(ag), P(ab), P(ac_), P(asl), P(am), 0,
                               P(rb), P(rc), P(rm), P(rf), P(st), P(xg), P(xf), P(xc), P(nr))
         ev[2].record()
-        # the replies of the three acceptors, shuffled, as the coordinator's vote columns
-        pm = perms[r & 1]
+        # the replies of the three acceptors as the coordinator's vote columns: concatenated, or shuffled
         cat = lambda k: torch.cat([rep[nid][k] for nid in ids])  # noqa: E731
-        v[0].copy_(ag.repeat(3)[pm]); v[1].copy_(cat(0)[pm]); v[2].copy_(cat(1)[pm])
-        v[3].copy_(asl.repeat(3)[pm]); v[4].copy_(acc_col[pm]); v[5].copy_(cat(2)[pm])
+        if args.shuffled_replies or args.unordered:
+            pm = perms[r & 1]
+            v[0].copy_(ag.repeat(3)[pm]); v[1].copy_(cat(0)[pm]); v[2].copy_(cat(1)[pm])
+            v[3].copy_(asl.repeat(3)[pm]); v[4].copy_(acc_col[pm]); v[5].copy_(cat(2)[pm])
+        else:
+            v[0].copy_(ag.repeat(3)); v[1].copy_(cat(0)); v[2].copy_(cat(1))
+            v[3].copy_(asl.repeat(3)); v[4].copy_(acc_col); v[5].copy_(cat(2))
         ev2b = torch.cuda.Event(enable_timing=True)
         ev2b.record()
         eng[100].call_dev("accept_reply_batch", 3 * G, *[P(x) for x in v], *[P(x) for x in d], P(n_out), P(v_st))
@@ -123,6 +133,7 @@ def main():
     tot = sum(t.values()) / k
     print(json.dumps({"groups": G, "replicas": K, "ordered_batches_promise": not args.no_promise and not args.unordered,
                       "acceptor_batches": "unordered" if args.unordered else "grouped by group",
+                      "replies": "shuffled" if (args.shuffled_replies or args.unordered) else "three ascending runs",
                       "ms_per_round": round(tot, 4),
                       "phases_ms": {a: round(b / k, 4) for a, b in t.items()},
                       "decided_and_executed_per_s": round(G / tot * 1e3, 1),

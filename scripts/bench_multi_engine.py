@@ -35,7 +35,6 @@ def main():
         e = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=K * G + 1024)
         assert (e.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
         e.set_stream(ts.cuda_stream)
-        e.set_pipeline(1)
         engs.append(e)
     g_all = torch.arange(G, dtype=torch.int32, device=dev)
     gen = torch.Generator(device=dev)
@@ -64,8 +63,6 @@ def main():
             e.call_dev("propose_batch", G, P(g_all), 0, *[P(x) for x in o["p"]])
             e.call_dev("accept_reply_batch", K * G, P(v_g), P(v_bn), P(v_bc), P(v_slot), P(v_acc), P(v_cp),
                        *[P(x) for x in o["d"]], P(o["n"]), P(o["st"]))
-        for e in engs:
-            e.fence()
     ev1.record()
     for e in engs:
         e.sync()

@@ -39,9 +39,7 @@ def test_hip_library_exports_every_declared_symbol():
 
 def test_oracle_exports_matching_symbols(oracle_lib):
     for name in _declared():
-        if name.endswith("_dev") or name in ("gpx_engine_set_stream", "gpx_engine_set_pipeline",
-                                              "gpx_engine_fence", "gpx_profile_enable",
-                                              "gpx_profile_read"):
+        if name.endswith("_dev") or name in ("gpx_engine_set_stream", "gpx_profile_enable", "gpx_profile_read"):
             continue
         assert hasattr(oracle_lib.lib, "orc_" + name[4:]), name
 

@@ -67,6 +67,33 @@ def test_config3_stream_5m_groups_two_range_passes_vs_oracle(hip_lib, oracle_lib
     _vote_stream_parity(hip_lib, oracle_lib, 5_000_000, 3, True, R=2)
 
 
+def test_16m_votes_in_one_call_vs_oracle(hip_lib, oracle_lib):
+    """A call that brings many rounds of votes at once - six slots outstanding per group, 16,000,000 votes over
+    1 M groups in ONE gpx_accept_reply_batch: most groups have 17+ votes in the batch (segments past the
+    nibble word: ordered by their own lane, a hot group by the workgroup) and the buckets fill the LDS staging
+    to the brim.  Round 2's batch sweep fell off a 13x cliff here; the answers must be the oracle's."""
+    G, k, R = 1_000_000, 3, 6
+    members = [100, 101, 102]
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=16_000_000 + 4096)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 100)) == S_OK).all()
+    g = np.arange(G, dtype=np.int32)
+    for r in range(R):
+        for x, y in zip(eh.propose(g), eo.propose(g)):
+            assert (x == y).all()
+    rounds = [streams.vote_round(G, members, r, 100, config_id=3, mix=(r == 2)) for r in range(R)]
+    cols = [np.ascontiguousarray(np.concatenate([rd[c] for rd in rounds])[:16_000_000]) for c in range(6)]
+    cols[0][123_456:123_456 + 3000] = 777           # and one hot group: 3000 more votes in a row
+    dh, do = eh.accept_reply(*cols), eo.accept_reply(*cols)
+    _same(dh, do, "16 M votes")
+    assert dh.gidx.shape[0] > 5 * G
+    assert eh.snapshot(g)[0].tobytes() == eo.snapshot(g)[0].tobytes()
+    assert eh.counters() == eo.counters()
+    eh.close()
+    eo.close()
+
+
 def test_vote_stream_wide_node_ids_vs_oracle(hip_lib, oracle_lib):
     """Node ids that do not fit the compact vote record (negative, > 65535, Integer.MAX_VALUE) and
     ballots other than the batch's common one: the record's escape path re-reads the caller's

@@ -13,12 +13,13 @@ from tests.parity_common import (make_pair, create_mixed_groups, fuzz, assert_sa
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["small-batch path", "partition path"])
+@pytest.fixture(autouse=True, params=["partition path", "sorted-runs hint"])
 def _accept_reply_path(request, monkeypatch):
-    """Accept-reply batches of at most 65,536 votes can take a single-launch path (gpx_small.hip.h,
-    GPX_SMALL=1, read at engine creation; off by default: it does not beat the partition pipeline,
-    DESIGN.md) - every case of this file runs both ways."""
-    monkeypatch.setenv("GPX_SMALL", "1" if request.param.startswith("small") else "0")
+    """Accept-reply batches go through the partition pipeline or, with the GPX_TRY_REPLY_RUNS hint (here set
+    for every engine through the test switch GPX_TRY_RUNS=1, read at engine creation), first through the
+    sorted-runs check (gpx_runs.hip.h): a batch that happens to be a few ascending runs is applied without
+    partition, any other falls back behind it - every case of this file runs both ways."""
+    monkeypatch.setenv("GPX_TRY_RUNS", "1" if request.param.startswith("sorted") else "0")
 
 
 NODES = [100, 101, 102, 103, 104, 105, 106, 107]
