@@ -251,6 +251,7 @@ def main():
         ho = [np.zeros(G, np.int32) for _ in range(4)] + [np.zeros(G, np.uint8)]
         hd = [np.zeros(nv, np.int32) for _ in range(5)] + [np.zeros(nv, np.uint8)]
         hno, hst = np.zeros(1, np.int32), np.zeros(nv, np.uint8)
+        pinned_rounds = hcols
         pinned = [hg, hno, hst] + ho + hd + [c for cols in hcols for c in cols]
         ee.host_register(*pinned)  # a JNI host registers its direct ByteBuffers once (gpx_host_register)
         fn_p, fn_a = ee.lib.fn["propose_batch"], ee.lib.fn["accept_reply_batch"]
@@ -265,14 +266,72 @@ def main():
         te = time.perf_counter()
         for r in range(1, e2e_rounds):
             host_step(r)
-        te = (time.perf_counter() - te) / (e2e_rounds - 1)
+        te_sync = (time.perf_counter() - te) / (e2e_rounds - 1)
         assert args.mix or int(hno[0]) == G
-        pcie = G * 4 + G * 17 + nv * 24 + nv + int(hno[0]) * 21 + 4
-        end_to_end = {"ms_per_step": round(te * 1e3, 4), "decisions_per_sec": round(int(hno[0]) / te, 1),
-                      "votes_per_sec": round(nv / te, 1), "bytes_over_pcie_per_step": int(pcie),
-                      "pcie_GBps": round(pcie / te / 1e9, 1),
-                      "path": "gpx_propose_batch + gpx_accept_reply_batch with HOST pointers (registered memory): "
-                              "H2D of every input column, kernels, D2H of every output column, per call"}
+        # the asynchronous calls (gpx_*_batch_async + gpx_engine_wait): two steps in flight, so the inputs of step
+        # r + 1 travel to the device while the outputs of step r travel back - both directions of the link busy;
+        # in the clean stream every vote carries the ballot (0, 100): the common-ballot form, 16 B per vote
+        import ctypes as C
+        fn_pa, fn_aa, fn_w = (ee.lib.fn[k] for k in ("propose_batch_async", "accept_reply_batch_async", "engine_wait"))
+        ring = []
+        for _ in range(2):
+            o = [np.zeros(G, np.int32) for _ in range(4)] + [np.zeros(G, np.uint8)]
+            d = [np.zeros(nv, np.int32) for _ in range(5)] + [np.zeros(nv, np.uint8)]
+            no, st = np.zeros(1, np.int32), np.zeros(nv, np.uint8)
+            ee.host_register(*(o + d + [no, st]))
+            ring.append((o, d, no, st))
+        common = not args.mix
+
+        def submit(r):
+            o, d, no, st = ring[r & 1]
+            c = hcols[r % e2e_rounds]
+            tp, ta = C.c_uint64(0), C.c_uint64(0)
+            rc = fn_pa(ee.h, G, _p(hg), None, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), C.byref(tp))
+            rc |= fn_aa(ee.h, nv, _p(c[0]), None if common else _p(c[1]), None if common else _p(c[2]), 0, 100, _p(c[3]),
+                        _p(c[4]), _p(c[5]), _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(d[4]), _p(d[5]), _p(no), _p(st),
+                        C.byref(ta))
+            assert rc == 0
+            return tp, ta
+
+        def wait(t):
+            assert fn_w(ee.h, t[0]) == 0 and fn_w(ee.h, t[1]) == 0
+        n_async = 6
+        # slot / max_cp of the host rounds are only right for the first e2e_rounds rounds of an engine: a fresh one
+        ee.close()
+        ee = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
+        assert (ee.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
+        hcols = [[np.ascontiguousarray(c) for c in streams.vote_round(G, members, r, 100, config_id=cfg_id,
+                                                                        shuffled=not args.sorted, mix=args.mix)]
+                 for r in range(n_async)]
+        ee.host_unregister(*[c for cols_ in pinned_rounds for c in cols_])
+        pinned_rounds = hcols
+        ee.host_register(*[c for cols_ in hcols for c in cols_])
+        e2e_rounds = n_async
+        prev = submit(0)
+        wait(prev)  # warm: allocations of the async sets
+        te = time.perf_counter()
+        prev = submit(1)
+        for r in range(2, n_async):
+            cur = submit(r)
+            wait(prev)
+            prev = cur
+        wait(prev)
+        te = (time.perf_counter() - te) / (n_async - 1)
+        n_dec = int(ring[(n_async - 1) & 1][2][0])
+        assert args.mix or n_dec == G
+        b_in = G * 4 + nv * (16 if common else 24)
+        b_out = G * 17 + nv + n_dec * 21 + 4
+        end_to_end = {"ms_per_step": round(te * 1e3, 4), "decisions_per_sec": round(n_dec / te, 1),
+                      "votes_per_sec": round(nv / te, 1), "bytes_over_pcie_per_step": int(b_in + b_out),
+                      "pcie_in_GBps": round(b_in / te / 1e9, 1), "pcie_out_GBps": round(b_out / te / 1e9, 1),
+                      "common_ballot_form": bool(common),
+                      "synchronous_calls_ms_per_step": round(te_sync * 1e3, 4),
+                      "path": "gpx_propose_batch_async + gpx_accept_reply_batch_async + gpx_engine_wait with HOST "
+                              "pointers (registered memory), two steps in flight: H2D of step r + 1 beside the kernels "
+                              "and the D2H of step r; synchronous_calls_ms_per_step = the plain calls, one after the other"}
+        for o, d, no, st in ring:
+            ee.host_unregister(*(o + d + [no, st]))
+        pinned = [hg, hno, hst] + ho + hd + [c for cols_ in pinned_rounds for c in cols_]
         ee.host_unregister(*pinned)
         ee.close()
 

@@ -107,6 +107,12 @@ _DEV_SIGS = {
     "propose_batch_h_dev": [C.c_int32] + [_VP] * 8,
     "prepare_reply_batch_dev": [C.c_int32] + [_VP] * 6 + [C.c_int32] + [_VP] * 13,
     "route_batch_dev": [C.c_int32, C.c_int32, _VP, _VP, C.c_int32, C.c_int32, _VP, _VP],
+    # asynchronous host-pointer calls (HIP library only: the oracle has nothing to overlap)
+    "propose_batch_async": [C.c_int32] + [_VP] * 7 + [C.POINTER(C.c_uint64)],
+    "accept_batch_async": [C.c_int32] + [_VP] * 15 + [C.POINTER(C.c_uint64)],
+    "accept_reply_batch_async": [C.c_int32] + [_VP] * 3 + [C.c_int32, C.c_int32] + [_VP] * 11 + [C.POINTER(C.c_uint64)],
+    "commit_batch_async": [C.c_int32] + [_VP] * 11 + [C.POINTER(C.c_uint64)],
+    "engine_wait": [C.c_uint64],
     "profile_enable": [C.c_int32],
     "profile_read": [C.POINTER(GpxKernelStat), C.c_int32],
 }
@@ -401,6 +407,88 @@ class Engine:
         buf = (GpxKernelStat * 32)()
         nk = self.lib.check(self.lib.fn["profile_read"](self.h, buf, 32), "profile_read")
         return {buf[i].name.decode(): (int(buf[i].launches), float(buf[i].total_ms)) for i in range(min(nk, 32))}
+
+    # -- asynchronous host-pointer path (gpx_*_batch_async / gpx_engine_wait) -------------------------
+    class Pending:
+        """A submitted call: keeps every buffer alive until wait()."""
+
+        def __init__(self, eng, ticket, bufs, finish):
+            self.eng, self.ticket, self.bufs, self.finish = eng, ticket, bufs, finish
+
+        def wait(self):
+            self.eng.lib.check(self.eng.lib.fn["engine_wait"](self.eng.h, C.c_uint64(self.ticket)), "engine_wait")
+            return self.finish()
+
+    def propose_async(self, gidx, is_stop=None):
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        is_stop = _u8(is_stop, n)
+        slot, bnum, bcoord, median = (np.zeros(n, np.int32) for _ in range(4))
+        status = np.zeros(n, np.uint8)
+        t = C.c_uint64(0)
+        self.lib.check(self.lib.fn["propose_batch_async"](self.h, n, _p(gidx), _p(is_stop), _p(slot), _p(bnum), _p(bcoord),
+                                                          _p(median), _p(status), C.byref(t)), "propose_batch_async")
+        return Engine.Pending(self, t.value, (gidx, is_stop), lambda: (slot, bnum, bcoord, median, status))
+
+    def accept_reply_async(self, gidx, bnum, bcoord, slot, acceptor, max_cp, common_ballot=None):
+        """bnum / bcoord None + common_ballot = (bnum, bcoord): every vote carries that ballot."""
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        slot, acceptor, max_cp = (_i32(x, n) for x in (slot, acceptor, max_cp))
+        if bnum is not None:
+            bnum, bcoord = _i32(bnum, n), _i32(bcoord, n)
+        cb = common_ballot or (0, 0)
+        cap = max(n, 1)
+        dg, ds, db, dc, dm = (np.zeros(cap, np.int32) for _ in range(5))
+        dk = np.zeros(cap, np.uint8)
+        status = np.zeros(n, np.uint8)
+        no = np.zeros(1, np.int32)
+        t = C.c_uint64(0)
+        self.lib.check(self.lib.fn["accept_reply_batch_async"](
+            self.h, n, _p(gidx), _p(bnum), _p(bcoord), int(cb[0]), int(cb[1]), _p(slot), _p(acceptor), _p(max_cp),
+            _p(dg), _p(ds), _p(db), _p(dc), _p(dm), _p(dk), _p(no), _p(status), C.byref(t)), "accept_reply_batch_async")
+
+        def finish():
+            m = int(no[0])
+            return Decisions(dg[:m], ds[:m], db[:m], dc[:m], dm[:m], dk[:m], status)
+        return Engine.Pending(self, t.value, (gidx, bnum, bcoord, slot, acceptor, max_cp), finish)
+
+    def accept_async(self, gidx, bnum, bcoord, slot, median_cp, a_flags=None):
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        bnum, bcoord, slot, median_cp = (_i32(x, n) for x in (bnum, bcoord, slot, median_cp))
+        a_flags = _u8(a_flags, n)
+        r_bnum, r_bcoord, r_maxcp = (np.zeros(n, np.int32) for _ in range(3))
+        r_flags, status = np.zeros(n, np.uint8), np.zeros(n, np.uint8)
+        xg, xf, xc = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+        nr = np.zeros(1, np.int32)
+        t = C.c_uint64(0)
+        self.lib.check(self.lib.fn["accept_batch_async"](
+            self.h, n, _p(gidx), _p(bnum), _p(bcoord), _p(slot), _p(median_cp), _p(a_flags), _p(r_bnum), _p(r_bcoord),
+            _p(r_maxcp), _p(r_flags), _p(status), _p(xg), _p(xf), _p(xc), _p(nr), C.byref(t)), "accept_batch_async")
+
+        def finish():
+            m = int(nr[0])
+            return (r_bnum, r_bcoord, r_maxcp, r_flags, status), ExecRuns(xg[:m], xf[:m], xc[:m])
+        return Engine.Pending(self, t.value, (gidx, bnum, bcoord, slot, median_cp, a_flags), finish)
+
+    def commit_async(self, gidx, bnum, bcoord, slot, median_cp, c_kind=None):
+        gidx = _i32(gidx)
+        n = gidx.shape[0]
+        bnum, bcoord, slot, median_cp = (_i32(x, n) for x in (bnum, bcoord, slot, median_cp))
+        c_kind = _u8(c_kind, n)
+        status = np.zeros(n, np.uint8)
+        xg, xf, xc = (np.zeros(max(n, 1), np.int32) for _ in range(3))
+        nr = np.zeros(1, np.int32)
+        t = C.c_uint64(0)
+        self.lib.check(self.lib.fn["commit_batch_async"](
+            self.h, n, _p(gidx), _p(bnum), _p(bcoord), _p(slot), _p(median_cp), _p(c_kind), _p(status), _p(xg), _p(xf),
+            _p(xc), _p(nr), C.byref(t)), "commit_batch_async")
+
+        def finish():
+            m = int(nr[0])
+            return status, ExecRuns(xg[:m], xf[:m], xc[:m])
+        return Engine.Pending(self, t.value, (gidx, bnum, bcoord, slot, median_cp, c_kind), finish)
 
     # -- data path ---------------------------------------------------------------
     def propose(self, gidx, is_stop=None, handle=None):

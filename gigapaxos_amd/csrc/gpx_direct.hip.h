@@ -186,6 +186,8 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, i
     return;
   }
   const int32_t w = (int32_t)blockIdx.x;
+  /* no run parked in this chunk (every chunk of an ACCEPT batch that released no commit): nothing to place */
+  if (D.chunk_cnt[w] == 0 && w != (int32_t)gridDim.x - 1) return;
   int32_t before = 0;
   for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) before += D.chunk_cnt[t];
   int32_t pre;
@@ -206,8 +208,9 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, i
 /* Small ordered batches in ONE launch.  A batch of at most 65,536 records is L2-resident: every
  * workgroup reads the whole gidx column itself to judge the order (so no k_order_check launch), applies
  * its 1024-record chunk like k_ac_direct / k_propose_direct, and places its execution runs behind those
- * of the chunks before it with a ticket per workgroup (so no k_emit_runs_direct launch either): the
- * workgroups before it were dispatched earlier, they are running or done - no deadlock.  BASELINE
+ * of the chunks before it with a ticket per workgroup (so no k_emit_runs_direct launch either): chunks are
+ * handed out by an atomic counter, so the chunks before a workgroup's own belong to workgroups that have
+ * started - they are running or done, no deadlock whatever the dispatch order.  BASELINE
  * config #2's round (10 k groups: every kernel sits on the launch floor) goes from 24 launches to 12.
  * The verdict "not ordered" is published in *X.unsorted for the partition path launched behind it (or,
  * under the GPX_ORDERED_* promise, the batch is refused whole). */
@@ -220,9 +223,15 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_small(
     const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status, DirectStage D,
     int32_t* __restrict__ x_gidx, int32_t* __restrict__ x_first, int32_t* __restrict__ x_count,
-    int32_t* __restrict__ n_runs, unsigned long long* __restrict__ tickets, uint32_t epoch, int32_t refuse) {
+    int32_t* __restrict__ n_runs, unsigned long long* __restrict__ tickets, uint32_t epoch, int32_t refuse,
+    uint32_t* __restrict__ draw, uint32_t draw_base) {
   __shared__ int32_t s_before;
-  const int32_t w = (int32_t)blockIdx.x;
+  __shared__ int32_t s_w;
+  /* the chunk is DRAWN, not read off blockIdx: a workgroup that waits below only ever waits for chunks
+   * whose workgroups have already started - no assumption about the order workgroups are dispatched in */
+  if (threadIdx.x == 0) s_w = (int32_t)(atomicAdd(draw, 1u) - draw_base);
+  __syncthreads();
+  const int32_t w = s_w;
   const int32_t i = w * GPX_DCHUNK + (int32_t)threadIdx.x;
   const bool ordered = small_batch_ordered<false>(n, gidx, S.G);
   if (!ordered) {

@@ -100,6 +100,8 @@ struct gpx_engine {
   /* tickets of the single-launch kernels for small ordered batches (k_ac_small) */
   unsigned long long* small_tickets = nullptr;
   uint32_t small_epoch = 0;
+  uint32_t* small_draw = nullptr; /* chunk tickets drawn so far by every k_ac_small launch (never reset) */
+  uint32_t small_drawn = 0;       /* ... as the host counts them: a launch's chunks are draw - small_drawn */
   /* [max_batch] == a call's epoch: record i of that call holds a parked output (direct and sorted-runs
    * paths: no per-record clearing store, no clearing pass) */
   uint32_t* rec_tag = nullptr;
@@ -115,6 +117,26 @@ struct gpx_engine {
   int32_t* ar_chain = nullptr; /* [2] running output count between passes */
   I4* reply_rows = nullptr;    /* [max_batch] packed ACCEPT_REPLY rows of the partition path (first use) */
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
+  /* asynchronous host-pointer calls (gpx_*_batch_async / gpx_engine_wait): GPX_ASYNC_DEPTH sets of device
+   * columns, each with its own copy-out stream; one copy-in stream; allocated on first use */
+  struct AsyncSet {
+    int32_t* i32[11] = {};
+    uint8_t* u8[3] = {};
+    int32_t* cnt = nullptr;   /* device: the call's output count */
+    int32_t* h_cnt = nullptr; /* pinned host copy of it */
+    hipStream_t s_out = nullptr;
+    hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_cnt = nullptr;
+    bool ready = false, busy = false;
+    uint64_t ticket = 0;
+    int ncols = 0;              /* compacted int32 output columns still to fetch (count-dependent) */
+    int32_t* host_col[6] = {};  /* ... their host destinations and device sources */
+    const int32_t* dev_col[6] = {};
+    uint8_t* host_kind = nullptr; /* accept replies: d_kind */
+    const uint8_t* dev_kind = nullptr;
+    int32_t* host_count = nullptr; /* n_out / n_runs of the caller */
+  } as[GPX_ASYNC_DEPTH];
+  hipStream_t s_in = nullptr;
+  uint64_t async_seq = 0;
   /* wire codec (gpx_wire_host.inc): paxosID table, row free list, scratch - allocated on first use */
   DevNames N{};
   int64_t nm_tomb = 0;
@@ -382,15 +404,17 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     return GPX_EINVAL;
   if (cfg->window < 4 || cfg->window > 64 || (cfg->window & (cfg->window - 1))) return GPX_EINVAL;
   /* A GPU that has just been powered up (fresh box, "device(s) in a low-power state") can answer the
-   * first runtime call with hipErrorNoDevice for a moment - seen once on the MI355X pool: wait for it
-   * for up to ~6 s before giving up. */
+   * first runtime call with hipErrorNoDevice for a moment - seen once on the MI355X pool.  Wait for it, but
+   * only where a ROCm driver is present at all (/dev/kfd): a host without a GPU fails at once. */
   int ndev = 0;
   hipError_t de = hipErrorNoDevice;
-  for (int attempt = 0; attempt < 30; attempt++) {
+  const int attempts = access("/dev/kfd", F_OK) == 0 ? 15 : 1;
+  for (int attempt = 0; attempt < attempts; attempt++) {
     de = hipGetDeviceCount(&ndev);
     if (de == hipSuccess && ndev > 0) break;
     (void)hipGetLastError();
-    usleep(200 * 1000);
+    if (de != hipErrorNoDevice && de != hipSuccess) break; /* not the transient answer */
+    if (attempt + 1 < attempts) usleep(200 * 1000);
   }
   if (de != hipSuccess || ndev <= 0) {
     snprintf(g_err, sizeof(g_err), "no HIP device visible (%s)", de == hipSuccess ? "count 0" : hipGetErrorString(de));
@@ -523,7 +547,8 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
       HIPCHK_CREATE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bucket_lds_hw));
   }
   {
-    if ((rc = dev_alloc(e, &e->small_tickets, 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK), true)) != GPX_OK) {
+    if ((rc = dev_alloc(e, &e->small_tickets, 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK), true)) != GPX_OK ||
+        (rc = dev_alloc(e, &e->small_draw, 1, true)) != GPX_OK) {
       gpx_engine_destroy(e);
       return rc;
     }
@@ -597,6 +622,15 @@ int gpx_engine_destroy(gpx_engine* h) {
   if (h->hs_in) HIPQ(hipHostFree(h->hs_in));
   if (h->hs_out) HIPQ(hipHostFree(h->hs_out));
   if (h->arena) HIPQ(hipFree(h->arena));
+  for (auto& a : h->as) {
+    if (a.s_out) HIPQ(hipStreamSynchronize(a.s_out));
+    if (a.h_cnt) HIPQ(hipHostFree(a.h_cnt));
+    if (a.ev_in) HIPQ(hipEventDestroy(a.ev_in));
+    if (a.ev_k) HIPQ(hipEventDestroy(a.ev_k));
+    if (a.ev_cnt) HIPQ(hipEventDestroy(a.ev_cnt));
+    if (a.s_out) HIPQ(hipStreamDestroy(a.s_out));
+  }
+  if (h->s_in) HIPQ(hipStreamDestroy(h->s_in));
   if (h->own_stream) HIPQ(hipStreamDestroy(h->own_stream));
   delete h;
   return GPX_OK;
@@ -823,11 +857,13 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     RunsInfo* next_info = e->runs_info + ((e->runs_seq + 1) & 1);
     e->runs_seq++;
     const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
-    const RunsStage st{Stage16{(int32_t*)e->X.o_rec, (int64_t)N}, e->rec_tag, e->fs[0].chunk_cnt,
-                       Stage16{(int32_t*)e->X.rec, (int64_t)N}};
+    /* outputs are parked in the caller's own columns (n entries each: gpx.h); the staging block is only used
+     * by batches that are not REGULAR (gpx_runs.hip.h) */
+    const RunsStage st{DecCols{d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind}, e->rec_tag, e->fs[0].chunk_cnt,
+                       Stage16{(int32_t*)e->X.o_rec, (int64_t)N}};
     const int32_t refuse = runs_promised ? 1 : 0;
-    LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx, e->S.G,
-              e->X, status, info, next_info, st.chunk_cnt, nchunks);
+    LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
+              gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks);
     {
       LaunchScope _ls(e, "k_ar_runs");
       if (e->cfg.kmax <= 4)
@@ -842,11 +878,10 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     }
     {
       LaunchScope _ls(e, "k_emit_dec_runs");
-      hipLaunchKernelGGL(k_emit_dec_runs, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, st, info,
-                         d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, &e->X.counters[1], refuse);
+      hipLaunchKernelGGL(k_emit_dec_runs, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, st, info, n_out,
+                         &e->X.counters[1], refuse);
     }
-    LAUNCH(e, "k_merge_runs", k_merge_runs, 512, e->X, n, st, (const RunsInfo*)info, d_gidx, d_slot, d_bnum,
-           d_bcoord, d_median_cp, d_kind);
+    LAUNCH(e, "k_merge_runs", k_merge_runs, 256, e->X, n, st, (const RunsInfo*)info);
     if (runs_promised) {
       end_call(e, fs);
       HIPCHK(hipGetLastError());
@@ -898,7 +933,9 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     LaunchScope _ls(e, "k_ac_small");
     hipLaunchKernelGGL(k_ac_small<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
                        bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, x_gidx,
-                       x_first, x_count, n_runs, e->small_tickets, e->small_epoch, promised ? 1 : 0);
+                       x_first, x_count, n_runs, e->small_tickets, e->small_epoch, promised ? 1 : 0, e->small_draw,
+                       e->small_drawn);
+    e->small_drawn += (uint32_t)nchunks;
   }
 
   const size_t Nmax = (size_t)e->cfg.max_batch;
@@ -982,7 +1019,8 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     hipLaunchKernelGGL(k_ac_small<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
                        bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
                        (uint8_t*)nullptr, status, D, x_gidx, x_first, x_count, n_runs, e->small_tickets,
-                       e->small_epoch, promised ? 1 : 0);
+                       e->small_epoch, promised ? 1 : 0, e->small_draw, e->small_drawn);
+    e->small_drawn += (uint32_t)nchunks;
   }
 
   const size_t Nmax = (size_t)e->cfg.max_batch;
@@ -1371,6 +1409,242 @@ int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   }
   return GPX_OK;
 }
+
+} /* extern "C" */
+
+/* ---- asynchronous host-pointer data path ---------------------------------------------- */
+/* (include/gpx.h: inputs on a copy-in stream, kernels on the engine's stream behind them, dense outputs and
+ * the count on the set's copy-out stream; gpx_engine_wait fetches exactly `count` compacted entries) */
+
+namespace {
+
+int async_begin(gpx_engine* e, int32_t n, gpx_engine::AsyncSet** out) {
+  int rc = check_batch(e, n);
+  if (rc != GPX_OK) return rc;
+  gpx_engine::AsyncSet& a = e->as[e->async_seq % GPX_ASYNC_DEPTH];
+  if (a.busy) return GPX_EBUSY;
+  if (!e->s_in) HIPCHK(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+  if (!a.ready) {
+    const size_t N = (size_t)e->cfg.max_batch;
+    for (auto& p : a.i32)
+      if ((rc = dev_alloc(e, &p, N, false)) != GPX_OK) return rc;
+    for (auto& p : a.u8)
+      if ((rc = dev_alloc(e, &p, N, false)) != GPX_OK) return rc;
+    if ((rc = dev_alloc(e, &a.cnt, 4, true)) != GPX_OK) return rc;
+    HIPCHK(hipHostMalloc((void**)&a.h_cnt, 64, hipHostMallocDefault));
+    HIPCHK(hipStreamCreateWithFlags(&a.s_out, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&a.ev_in, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&a.ev_k, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&a.ev_cnt, hipEventDisableTiming));
+    a.ready = true;
+  }
+  a.ncols = 0;
+  a.host_kind = nullptr;
+  a.dev_kind = nullptr;
+  a.host_count = nullptr;
+  a.h_cnt[0] = 0;
+  *out = &a;
+  return GPX_OK;
+}
+/* inputs are on their way: the kernels (engine stream) wait for them */
+int async_inputs_done(gpx_engine* e, gpx_engine::AsyncSet& a) {
+  HIPCHK(hipEventRecord(a.ev_in, e->s_in));
+  HIPCHK(hipStreamWaitEvent(e->sB, a.ev_in, 0));
+  return GPX_OK;
+}
+/* kernels are queued: the copy-out stream waits for them */
+int async_kernels_done(gpx_engine* e, gpx_engine::AsyncSet& a) {
+  HIPCHK(hipEventRecord(a.ev_k, e->sB));
+  HIPCHK(hipStreamWaitEvent(a.s_out, a.ev_k, 0));
+  return GPX_OK;
+}
+int async_submit(gpx_engine* e, gpx_engine::AsyncSet& a, bool with_count, gpx_ticket* ticket) {
+  if (with_count) HIPCHK(hipMemcpyAsync(a.h_cnt, a.cnt, sizeof(int32_t), hipMemcpyDeviceToHost, a.s_out));
+  HIPCHK(hipEventRecord(a.ev_cnt, a.s_out));
+  a.busy = true;
+  a.ticket = ++e->async_seq; /* > 0; the next call takes the next set */
+  *ticket = a.ticket;
+  return GPX_OK;
+}
+#define A_IN(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->s_in))
+#define A_OUT(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, a.s_out))
+
+}  // namespace
+
+extern "C" {
+
+int gpx_propose_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop, int32_t* slot,
+                            int32_t* bnum, int32_t* bcoord, int32_t* median_cp, uint8_t* status,
+                            gpx_ticket* ticket) {
+  if (!h || !ticket || (n > 0 && (!gidx || !slot || !bnum || !bcoord || !median_cp || !status))) return GPX_EINVAL;
+  gpx_engine::AsyncSet* ap = nullptr;
+  int rc = async_begin(h, n, &ap);
+  if (rc != GPX_OK) return rc;
+  gpx_engine::AsyncSet& a = *ap;
+  if (n > 0) {
+    const size_t b4 = (size_t)n * 4;
+    A_IN(a.i32[0], gidx, b4);
+    if (is_stop) A_IN(a.u8[0], is_stop, (size_t)n);
+    if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
+    rc = propose_dev_impl(h, n, a.i32[0], is_stop ? a.u8[0] : nullptr, nullptr, a.i32[1], a.i32[2], a.i32[3],
+                          a.i32[4], a.u8[1]);
+    if (rc != GPX_OK) return rc;
+    if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
+    A_OUT(slot, a.i32[1], b4);
+    A_OUT(bnum, a.i32[2], b4);
+    A_OUT(bcoord, a.i32[3], b4);
+    A_OUT(median_cp, a.i32[4], b4);
+    A_OUT(status, a.u8[1], (size_t)n);
+  }
+  return async_submit(h, a, false, ticket);
+}
+
+int gpx_accept_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                           const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                           const uint8_t* a_flags, int32_t* r_bnum, int32_t* r_bcoord, int32_t* r_maxcp,
+                           uint8_t* r_flags, uint8_t* status, int32_t* x_gidx, int32_t* x_first,
+                           int32_t* x_count, int32_t* n_runs, gpx_ticket* ticket) {
+  if (!h || !ticket || !n_runs) return GPX_EINVAL;
+  if (n > 0 && (!gidx || !bnum || !bcoord || !slot || !median_cp || !r_bnum || !r_bcoord || !r_maxcp || !r_flags ||
+                !status || !x_gidx || !x_first || !x_count))
+    return GPX_EINVAL;
+  gpx_engine::AsyncSet* ap = nullptr;
+  int rc = async_begin(h, n, &ap);
+  if (rc != GPX_OK) return rc;
+  gpx_engine::AsyncSet& a = *ap;
+  a.host_count = n_runs;
+  *n_runs = 0;
+  if (n > 0) {
+    const size_t b4 = (size_t)n * 4;
+    A_IN(a.i32[0], gidx, b4);
+    A_IN(a.i32[1], bnum, b4);
+    A_IN(a.i32[2], bcoord, b4);
+    A_IN(a.i32[3], slot, b4);
+    A_IN(a.i32[4], median_cp, b4);
+    if (a_flags) A_IN(a.u8[0], a_flags, (size_t)n);
+    if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
+    rc = gpx_accept_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a_flags ? a.u8[0] : nullptr,
+                              a.i32[5], a.i32[6], a.i32[7], a.u8[1], a.u8[2], a.i32[8], a.i32[9], a.i32[10], a.cnt);
+    if (rc != GPX_OK) return rc;
+    if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
+    A_OUT(r_bnum, a.i32[5], b4);
+    A_OUT(r_bcoord, a.i32[6], b4);
+    A_OUT(r_maxcp, a.i32[7], b4);
+    A_OUT(r_flags, a.u8[1], (size_t)n);
+    A_OUT(status, a.u8[2], (size_t)n);
+    a.ncols = 3;
+    a.host_col[0] = x_gidx, a.host_col[1] = x_first, a.host_col[2] = x_count;
+    a.dev_col[0] = a.i32[8], a.dev_col[1] = a.i32[9], a.dev_col[2] = a.i32[10];
+  }
+  return async_submit(h, a, n > 0, ticket);
+}
+
+int gpx_accept_reply_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                                 const int32_t* bcoord, int32_t common_bnum, int32_t common_bcoord,
+                                 const int32_t* slot, const int32_t* acceptor, const int32_t* max_cp,
+                                 int32_t* d_gidx, int32_t* d_slot, int32_t* d_bnum, int32_t* d_bcoord,
+                                 int32_t* d_median_cp, uint8_t* d_kind, int32_t* n_out, uint8_t* status,
+                                 gpx_ticket* ticket) {
+  if (!h || !ticket || !n_out || (bnum == nullptr) != (bcoord == nullptr)) return GPX_EINVAL;
+  if (n > 0 && (!gidx || !slot || !acceptor || !max_cp || !d_gidx || !d_slot || !d_bnum || !d_bcoord ||
+                !d_median_cp || !d_kind))
+    return GPX_EINVAL;
+  gpx_engine::AsyncSet* ap = nullptr;
+  int rc = async_begin(h, n, &ap);
+  if (rc != GPX_OK) return rc;
+  gpx_engine::AsyncSet& a = *ap;
+  a.host_count = n_out;
+  *n_out = 0;
+  if (n > 0) {
+    const size_t b4 = (size_t)n * 4;
+    A_IN(a.i32[0], gidx, b4);
+    if (bnum) {
+      A_IN(a.i32[1], bnum, b4);
+      A_IN(a.i32[2], bcoord, b4);
+    } else { /* one ballot for the whole batch: the two columns are made on the device */
+      hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(n)), dim3(GPX_BLOCK), 0, h->s_in, n, common_bnum, a.i32[1]);
+      hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(n)), dim3(GPX_BLOCK), 0, h->s_in, n, common_bcoord, a.i32[2]);
+    }
+    A_IN(a.i32[3], slot, b4);
+    A_IN(a.i32[4], acceptor, b4);
+    A_IN(a.i32[5], max_cp, b4);
+    if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
+    rc = gpx_accept_reply_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a.i32[5], a.i32[6],
+                                    a.i32[7], a.i32[8], a.i32[9], a.i32[10], a.u8[0], a.cnt, a.u8[1]);
+    if (rc != GPX_OK) return rc;
+    if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
+    if (status) A_OUT(status, a.u8[1], (size_t)n);
+    a.ncols = 5;
+    int32_t* hc[5] = {d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp};
+    for (int k = 0; k < 5; k++) {
+      a.host_col[k] = hc[k];
+      a.dev_col[k] = a.i32[6 + k];
+    }
+    a.host_kind = d_kind;
+    a.dev_kind = a.u8[0];
+  }
+  return async_submit(h, a, n > 0, ticket);
+}
+
+int gpx_commit_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                           const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                           const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx, int32_t* x_first,
+                           int32_t* x_count, int32_t* n_runs, gpx_ticket* ticket) {
+  if (!h || !ticket || !n_runs) return GPX_EINVAL;
+  if (n > 0 && (!gidx || !bnum || !bcoord || !slot || !median_cp || !status || !x_gidx || !x_first || !x_count))
+    return GPX_EINVAL;
+  gpx_engine::AsyncSet* ap = nullptr;
+  int rc = async_begin(h, n, &ap);
+  if (rc != GPX_OK) return rc;
+  gpx_engine::AsyncSet& a = *ap;
+  a.host_count = n_runs;
+  *n_runs = 0;
+  if (n > 0) {
+    const size_t b4 = (size_t)n * 4;
+    A_IN(a.i32[0], gidx, b4);
+    A_IN(a.i32[1], bnum, b4);
+    A_IN(a.i32[2], bcoord, b4);
+    A_IN(a.i32[3], slot, b4);
+    A_IN(a.i32[4], median_cp, b4);
+    if (c_kind) A_IN(a.u8[0], c_kind, (size_t)n);
+    if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
+    rc = gpx_commit_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], c_kind ? a.u8[0] : nullptr,
+                              a.u8[1], a.i32[5], a.i32[6], a.i32[7], a.cnt);
+    if (rc != GPX_OK) return rc;
+    if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
+    A_OUT(status, a.u8[1], (size_t)n);
+    a.ncols = 3;
+    a.host_col[0] = x_gidx, a.host_col[1] = x_first, a.host_col[2] = x_count;
+    a.dev_col[0] = a.i32[5], a.dev_col[1] = a.i32[6], a.dev_col[2] = a.i32[7];
+  }
+  return async_submit(h, a, n > 0, ticket);
+}
+
+int gpx_engine_wait(gpx_engine* h, gpx_ticket ticket) {
+  if (!h) return GPX_EINVAL;
+  for (auto& a : h->as) {
+    if (!a.busy || a.ticket != ticket) continue;
+    HIPCHK(hipEventSynchronize(a.ev_cnt)); /* dense outputs and the count are on the host */
+    if (a.host_count) {
+      const int32_t m = a.ncols ? a.h_cnt[0] : 0;
+      *a.host_count = m;
+      if (m > 0) { /* exactly m compacted entries, not the capacity */
+        for (int k = 0; k < a.ncols; k++) A_OUT(a.host_col[k], a.dev_col[k], (size_t)m * 4);
+        if (a.host_kind) A_OUT(a.host_kind, a.dev_kind, (size_t)m);
+        HIPCHK(hipStreamSynchronize(a.s_out));
+      }
+    }
+    a.busy = false;
+    return GPX_OK;
+  }
+  return GPX_EBUSY; /* unknown, or already waited for */
+}
+
+} /* extern "C" */
+#undef A_IN
+#undef A_OUT
+
+extern "C" {
 
 /* ---- lifecycle ------------------------------------------------------------------ */
 

@@ -15,16 +15,19 @@
  *                   the group, first record there) owns the group: it finds the group's votes in the
  *                   later runs (same offset as in its own run if the runs are alike - the usual case -
  *                   otherwise a binary search) and replays them in ARRAY order - run 0's votes before run
- *                   1's: exactly arrival order - through apply_ar_group, i.e. PISM.handleAcceptReply ->
- *                   PaxosCoordinatorState.handleAcceptReplyMyBallot / HigherBallot (PCS:597-683) unchanged.
- *                   Consecutive lanes of run 0 own ascending groups: coalesced state accesses.  The q-th
- *                   output of a group is parked at the array index of the group's q-th vote.
- *   k_emit_dec_runs parked outputs -> dense columns in record order.  When every output was parked
- *                   inside run 0 (the usual case: every group has a vote in run 0) that IS the contract's
- *                   order, grouped by gidx ascending.
- *   k_merge_runs    otherwise (a group absent from run 0, or more outputs than votes in run 0): the
- *                   compacted outputs are up to GPX_RUNS_MAX ascending segments; every entry computes its
- *                   rank in their merge (binary searches) and moves there.  Returns at once when not needed.
+ *                   1's: exactly arrival order.  Consecutive lanes of run 0 own ascending groups: coalesced
+ *                   state accesses.  The q-th output of a group is PARKED IN THE CALLER'S OUTPUT COLUMNS at
+ *                   the array index of the group's q-th vote (the columns hold n entries: gpx.h).
+ *                   REGULAR batch - every record of run 0 is a group in the coordinator's steady state
+ *                   whose votes sit at the same offset in every run, and every one of them decided: the
+ *                   decision of record i of run 0 is parked at index i, i.e. the columns already hold the
+ *                   decisions dense and in gidx order.  Nothing is left to do.
+ *   k_emit_dec_runs regular: publishes n_out and returns.  Otherwise: the parked outputs -> a dense
+ *                   staging block in record order ...
+ *   k_merge_runs    ... and from there back into the caller's columns: a plain copy when everything was
+ *                   parked inside run 0 (record order IS gidx order), else (a group absent from run 0, or
+ *                   more outputs than votes in run 0) the staged outputs are up to GPX_RUNS_MAX ascending
+ *                   segments and every entry computes its rank in their merge (binary searches).
  */
 #pragma once
 #include "gpx_ar16.hip.h"
@@ -38,64 +41,94 @@ struct RunsInfo {
   int32_t n_desc;                  /* descents found so far (atomic) */
   int32_t need_merge;              /* an output was parked outside run 0 */
   int32_t total;                   /* outputs of the call (k_emit_dec_runs) */
-  int32_t pad;
+  int32_t fast_dec;                /* decisions parked by the straight-line path (atomic, one add per workgroup) */
+  int32_t general_used;            /* a group went through the general replay, or a straight-line one did not decide */
+  int32_t pad[3];
   int32_t start[GPX_RUNS_MAX + 1]; /* start[0] = 0; the others in the order the atomics gave: sorted by the readers */
-  int32_t seg_off[GPX_RUNS_MAX + 1]; /* compacted outputs parked before each run start (k_emit_dec_runs) */
+  int32_t seg_off[GPX_RUNS_MAX + 1]; /* staged outputs parked before each run start (k_emit_dec_runs) */
+};
+
+/* the caller's decision columns (also the parking area) */
+struct DecCols {
+  int32_t *gidx, *slot, *bnum, *bcoord, *median;
+  uint8_t* kind;
+  __device__ __forceinline__ void put(int64_t i, int32_t g, int32_t sl, int32_t bn, int32_t bc, int32_t md,
+                                      int32_t kd) const {
+    gidx[i] = g;
+    slot[i] = sl;
+    bnum[i] = bn;
+    bcoord[i] = bc;
+    median[i] = md;
+    kind[i] = (uint8_t)kd;
+  }
 };
 
 struct RunsStage {
-  Stage16 O;          /* parked outputs, by record index */
+  DecCols D;          /* the caller's columns: parked outputs by record index, then the final outputs */
   uint32_t* tag;      /* [n] == epoch: record i holds a parked output */
   int32_t* chunk_cnt; /* [ceil(n / 1024)] parked outputs per chunk; zeroed by k_runs_check */
-  Stage16 T;          /* compacted outputs awaiting the merge */
+  Stage16 T;          /* dense staging between k_emit_dec_runs and k_merge_runs (irregular batches only) */
 };
 
 /* order check of a vote batch: at most GPX_RUNS_MAX ascending runs, every index in range */
+#define GPX_RC_ITEMS 16 /* records per lane */
 __global__ __launch_bounds__(GPX_OC_BLOCK) void k_runs_check(int32_t n, const int32_t* __restrict__ gidx, int32_t G,
                                                           DevScratch X, uint8_t* __restrict__ status,
                                                           RunsInfo* __restrict__ info, RunsInfo* __restrict__ next_info,
                                                           int32_t* __restrict__ zero, int32_t nzero) {
-  const int64_t i0 = ((int64_t)blockIdx.x * GPX_OC_BLOCK + threadIdx.x) * 8;
-  if (zero && i0 / 8 < nzero) zero[i0 / 8] = 0; /* nzero <= ceil(n / 8): the grid covers it */
+  const int64_t t = (int64_t)blockIdx.x * GPX_OC_BLOCK + threadIdx.x;
+  const int64_t i0 = t * GPX_RC_ITEMS;
+  for (int64_t z = t; z < nzero; z += (int64_t)gridDim.x * GPX_OC_BLOCK) zero[z] = 0;
   if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(RunsInfo) / 4)) ((int32_t*)next_info)[threadIdx.x] = 0;
   bool bad = false;
   uint32_t desc = 0; /* bit q: gidx[i0 + q] > gidx[i0 + q + 1] */
   if (i0 < n) {
-    int32_t g[9];
-    const bool full = i0 + 8 < n;
+    int32_t g[GPX_RC_ITEMS + 1];
+    const bool full = i0 + GPX_RC_ITEMS < n;
     if (full && !((uintptr_t)gidx & 15)) {
-      const I4 a = *(const I4*)(gidx + i0), b = *(const I4*)(gidx + i0 + 4);
-      g[0] = a.x; g[1] = a.y; g[2] = a.z; g[3] = a.w;
-      g[4] = b.x; g[5] = b.y; g[6] = b.z; g[7] = b.w;
-      g[8] = gidx[i0 + 8];
+#pragma unroll
+      for (int v = 0; v < GPX_RC_ITEMS / 4; v++) {
+        const I4 a = *(const I4*)(gidx + i0 + 4 * v);
+        g[4 * v] = a.x;
+        g[4 * v + 1] = a.y;
+        g[4 * v + 2] = a.z;
+        g[4 * v + 3] = a.w;
+      }
+      g[GPX_RC_ITEMS] = gidx[i0 + GPX_RC_ITEMS];
     } else {
 #pragma unroll
-      for (int q = 0; q < 9; q++) g[q] = (i0 + q < n) ? gidx[i0 + q] : INT32_MAX;
+      for (int q = 0; q <= GPX_RC_ITEMS; q++) g[q] = (i0 + q < n) ? gidx[i0 + q] : INT32_MAX;
     }
-    unsigned long long stw = 0;
+    unsigned long long stw0 = 0, stw1 = 0;
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < GPX_RC_ITEMS; q++) {
       if (i0 + q < n) {
         const bool oob = (uint32_t)g[q] >= (uint32_t)G;
         bad |= oob;
         if (i0 + q + 1 < n && g[q] > g[q + 1]) desc |= 1u << q;
-        if (oob) stw |= (unsigned long long)GPX_S_NOGROUP << (8 * q);
+        if (oob) {
+          if (q < 8)
+            stw0 |= (unsigned long long)GPX_S_NOGROUP << (8 * q);
+          else
+            stw1 |= (unsigned long long)GPX_S_NOGROUP << (8 * (q - 8));
+        }
       }
     }
     if (!status) {
     } else if (full && !((uintptr_t)status & 7)) {
-      *(unsigned long long*)(status + i0) = stw; /* GPX_S_OK == 0 */
+      *(unsigned long long*)(status + i0) = stw0; /* GPX_S_OK == 0 */
+      *(unsigned long long*)(status + i0 + 8) = stw1;
     } else {
-      for (int q = 0; q < 8; q++)
-        if (i0 + q < n) status[i0 + q] = (uint8_t)(stw >> (8 * q));
+      for (int q = 0; q < GPX_RC_ITEMS; q++)
+        if (i0 + q < n) status[i0 + q] = (uint8_t)((q < 8 ? stw0 >> (8 * q) : stw1 >> (8 * (q - 8))) & 0xffu);
     }
   }
-  /* a shuffled batch has ~1000 descents per workgroup: judged here, without touching the shared counter */
+  /* a shuffled batch has thousands of descents per workgroup: judged here, without touching the shared counter */
   const int32_t nd = __syncthreads_count(desc != 0);
   bad = __syncthreads_or(bad) || nd > GPX_RUNS_MAX - 1;
   if (!bad && desc) {
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < GPX_RC_ITEMS; q++) {
       if ((desc >> q) & 1u) {
         const int32_t k = atomicAdd(&info->n_desc, 1);
         if (k < GPX_RUNS_MAX - 1)
@@ -122,6 +155,17 @@ __device__ __forceinline__ int32_t runs_load(const RunsInfo* __restrict__ info, 
   __syncthreads();
   return nd + 1;
 }
+/* length of run 0 without sorting: the smallest start (n if there is one run) */
+__device__ __forceinline__ int32_t runs_len0(const RunsInfo* __restrict__ info, int32_t n) {
+  const int32_t nd = min(info->n_desc, GPX_RUNS_MAX - 1);
+  int32_t m = n;
+  for (int32_t q = 1; q <= nd; q++) m = min(m, info->start[q]);
+  return m;
+}
+/* REGULAR: only the straight-line path parked outputs, one per record of run 0 (header) */
+__device__ __forceinline__ bool runs_regular(const RunsInfo* __restrict__ info, int32_t n) {
+  return !info->general_used && info->fast_dec == runs_len0(info, n);
+}
 
 /* first record of group g in run [lo, hi) (ascending gidx), -1 if the run does not hold it; `hint` = where
  * it is if this run looks like the one the caller comes from */
@@ -143,6 +187,25 @@ __device__ __forceinline__ int32_t runs_find(const int32_t* __restrict__ gidx, i
       b = m;
   }
   return (a < hi && gidx[a] == g) ? a : -1;
+}
+
+/* does run [lo, hi) hold group g at all? (the ownership test of the later runs' lanes: one load when the
+ * runs are alike) */
+__device__ __forceinline__ bool runs_has(const int32_t* __restrict__ gidx, int32_t lo, int32_t hi, int32_t g,
+                                         int32_t hint) {
+  if (lo >= hi) return false;
+  const int32_t p = min(max(hint, lo), hi - 1);
+  const int32_t v = gidx[p];
+  if (v == g) return true;
+  int32_t a = v < g ? p + 1 : lo, b = v < g ? hi : p;
+  while (a < b) {
+    const int32_t m = a + ((b - a) >> 1);
+    if (gidx[m] < g)
+      a = m + 1;
+    else
+      b = m;
+  }
+  return a < hi && gidx[a] == g;
 }
 
 /* walks the votes of one group over the runs in array order */
@@ -183,26 +246,21 @@ struct RunsIter {
   __device__ __forceinline__ void emit(int32_t sl, int32_t x, int32_t y, int32_t z, int32_t kind) {
     pk.locate(gidx, rs, R, g); /* always there: outputs <= votes consumed */
     const int32_t i = pk.p++;
-    st.O.slot()[i] = sl;
-    st.O.bnum()[i] = x;
-    st.O.bcoord()[i] = y;
-    st.O.median()[i] = z;
-    st.O.kind()[i] = (uint8_t)kind;
+    st.D.put(i, g, sl, x, y, z, kind);
     st.tag[i] = epoch;
     if ((i >> GPX_DCHUNK_SHIFT) == chunk)
       local++;
     else
       atomicAdd(&st.chunk_cnt[i >> GPX_DCHUNK_SHIFT], 1);
-    if (i >= rs[1]) info->need_merge = 1; /* parked outside run 0: the compaction alone does not give gidx order */
+    if (i >= rs[1]) info->need_merge = 1; /* parked outside run 0: record order alone is not gidx order */
   }
 };
 
-/* The usual batch: the runs are ALIKE - every group of run 0 has exactly one vote in every run, at the same
- * offset - and the coordinator is in its steady state (SteadyGroup: all those votes answer one outstanding
- * slot at the current ballot).  A wave of run 0 whose 64 groups all look like that fetches everything it
- * needs up front (the three neighbours of the expected position in every run and the vote columns there:
- * independent loads, all in flight together) and replays from registers in a straight line; anything else
- * walks the runs with RunsIter through apply_ar_group. */
+/* The usual group: exactly one vote in every run, at the same offset as in run 0, and the coordinator in its
+ * steady state (SteadyGroup: those votes answer one outstanding slot at the current ballot).  A lane of run 0
+ * fetches everything up front (the three neighbours of the expected position in every run and the vote
+ * columns there: independent loads, all in flight together), then the state, and replays from registers in a
+ * straight line; any other group walks the runs with RunsIter through apply_ar_group. */
 #define GPX_RUNS_FAST 5 /* runs held in registers (five replicas: BASELINE config #4) */
 
 template <int KMAX>
@@ -216,7 +274,7 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ar_runs(DevState S, DevScratch X
                                                        uint8_t* __restrict__ status, RunsStage st,
                                                        RunsInfo* __restrict__ info, int32_t refuse) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
-  __shared__ int32_t wsum[GPX_DCHUNK / 64];
+  __shared__ int32_t wsum[GPX_DCHUNK / 64], wfast[GPX_DCHUNK / 64];
   const int32_t i = (int32_t)blockIdx.x * GPX_DCHUNK + (int32_t)threadIdx.x;
   if (*X.unsorted == X.epoch) {
     /* not a few sorted runs: the partition pipeline launched behind does it - or, under the
@@ -226,25 +284,28 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ar_runs(DevState S, DevScratch X
   }
   const int32_t R = runs_load(info, n, rs);
   if (i == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
-  int32_t local = 0;
+  int32_t local = 0, fast_dec = 0;
   const bool active = i < n;
   const int32_t g = active ? gidx[i] : 0;
   int32_t r = 0;
   for (int32_t q = 1; q < R; q++) r += rs[q] <= i;
   const int32_t o = i - rs[r];
+  const bool in0 = active && r == 0;
   bool done = !active;
   CoordPre<KMAX> P;
   bool have_p = false;
-  if (R <= GPX_RUNS_FAST) {
+  /* the lanes of the later runs (two thirds of a three-replica batch) skip the speculative fetches: they
+   * only test whether an earlier run holds their group */
+  if (R <= GPX_RUNS_FAST && __any(in0)) {
     int32_t sl[GPX_RUNS_FAST], ac[GPX_RUNS_FAST], cp[GPX_RUNS_FAST], bn[GPX_RUNS_FAST], bc[GPX_RUNS_FAST];
-    bool ok = active && r == 0;
+    bool ok = in0;
 #pragma unroll
     for (int q = 0; q < GPX_RUNS_FAST; q++) {
       sl[q] = ac[q] = cp[q] = bn[q] = bc[q] = 0;
-      if (q < R) {
+      if (q < R && in0) {
         const int64_t pq = (int64_t)rs[q] + o;
-        const bool inb = active && pq < rs[q + 1];
-        const int32_t pc = inb ? (int32_t)pq : (active ? i : 0); /* a valid index whatever happens */
+        const bool inb = pq < rs[q + 1];
+        const int32_t pc = inb ? (int32_t)pq : i; /* a valid index whatever happens */
         const int32_t gq = gidx[pc];
         const int32_t gp = (inb && o > 0) ? gidx[pc - 1] : ~g;
         const int32_t gn = (inb && pq + 1 < rs[q + 1]) ? gidx[pc + 1] : ~g;
@@ -256,52 +317,50 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ar_runs(DevState S, DevScratch X
         bc[q] = bcoord[pc];
       }
     }
-    if (__all(!active || ok)) { /* every lane owns its group and knows where its votes are */
-      if (active) {
-        coord_preload<KMAX>(S, g, P);
-        coord_preload_ring<KMAX>(S, g, P);
-        have_p = true;
-      }
-      bool el = active && SteadyGroup<KMAX>::group_ok(P) && SteadyGroup<KMAX>::slot_ok(S, P, sl[0]);
+    if (ok) { /* this lane owns its group and knows where its votes are */
+      coord_preload<KMAX>(S, g, P);
+      coord_preload_ring<KMAX>(S, g, P);
+      have_p = true;
+      bool el = SteadyGroup<KMAX>::group_ok(P) && SteadyGroup<KMAX>::slot_ok(S, P, sl[0]);
 #pragma unroll
       for (int q = 0; q < GPX_RUNS_FAST; q++)
         if (q < R) el = el && sl[q] == sl[0] && bn[q] == P.my_bnum && bc[q] == P.my_bcoord;
-      if (__all(!active || el)) {
-        if (active) {
-          SteadyGroup<KMAX> sg;
-          sg.init(S, g, P, sl[0]);
-          bool dec = false;
-          int32_t dmed = 0;
+      if (el) {
+        SteadyGroup<KMAX> sg;
+        sg.init(S, g, P, sl[0]);
+        bool dec = false;
+        int32_t dmed = 0;
 #pragma unroll
-          for (int q = 0; q < GPX_RUNS_FAST; q++) {
-            if (q < R) {
-              int32_t med;
-              if (sg.vote(ac[q], cp[q], &med)) {
-                dec = true;
-                dmed = med;
-              }
+        for (int q = 0; q < GPX_RUNS_FAST; q++) {
+          if (q < R) {
+            int32_t med;
+            if (sg.vote(ac[q], cp[q], &med)) {
+              dec = true;
+              dmed = med;
             }
           }
-          sg.finish(S, g, sl[0]);
-          if (dec) { /* the group's first (only) output: parked at its first vote = this lane's record */
-            st.O.slot()[i] = sl[0];
-            st.O.bnum()[i] = P.my_bnum;
-            st.O.bcoord()[i] = P.my_bcoord;
-            st.O.median()[i] = dmed;
-            st.O.kind()[i] = (uint8_t)GPX_D_DECISION;
-            st.tag[i] = X.epoch;
-            local = 1;
-          }
+        }
+        sg.finish(S, g, sl[0]);
+        if (dec) { /* the group's first (only) output: parked at its first vote = this lane's record */
+          st.D.put(i, g, sl[0], P.my_bnum, P.my_bcoord, dmed, GPX_D_DECISION);
+          st.tag[i] = X.epoch;
+          local = 1;
+          fast_dec = 1;
+        } else {
+          info->general_used = 1; /* a hole in run 0: the columns are not dense */
         }
         done = true;
       }
     }
   }
   if (!done) {
-    bool owner = i == rs[r] || gidx[i - 1] != g; /* first record of g in its run */
-    for (int32_t q = 0; owner && q < r; q++) /* ... and no earlier run holds g */
-      owner = runs_find(gidx, rs[q], rs[q + 1], g, rs[q] + o) < 0;
+    /* the owner of a group: no earlier run holds it (tested first: one load for a lane of an alike later
+     * run), and it is the group's first record in its run */
+    bool owner = true;
+    for (int32_t q = 0; owner && q < r; q++) owner = !runs_has(gidx, rs[q], rs[q + 1], g, rs[q] + o);
+    owner = owner && (i == rs[r] || gidx[i - 1] != g);
     if (owner) {
+      info->general_used = 1;
       RunsIter it;
       it.gidx = gidx;
       it.bnum = bnum;
@@ -327,34 +386,53 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ar_runs(DevState S, DevScratch X
       local = it.local;
     }
   }
-  /* this chunk's own parked outputs: one atomic per workgroup */
-  int32_t x = local;
+  /* this chunk's own parked outputs and straight-line decisions: one atomic each per workgroup */
+  int32_t x = local, y = fast_dec;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = x;
+  for (int d = 32; d >= 1; d >>= 1) {
+    x += __shfl_xor(x, d, 64);
+    y += __shfl_xor(y, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    wsum[threadIdx.x >> 6] = x;
+    wfast[threadIdx.x >> 6] = y;
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
-    int32_t tot = 0;
-    for (int w = 0; w < GPX_DCHUNK / 64; w++) tot += wsum[w];
+    int32_t tot = 0, totf = 0;
+    for (int w = 0; w < GPX_DCHUNK / 64; w++) {
+      tot += wsum[w];
+      totf += wfast[w];
+    }
     if (tot) atomicAdd(&st.chunk_cnt[blockIdx.x], tot);
+    if (totf) atomicAdd(&info->fast_dec, totf);
   }
 }
 
-/* parked outputs -> dense columns, chunk by chunk in record order: the caller's columns, or the merge's
- * input when an output was parked outside run 0 */
-__global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int32_t n, const int32_t* __restrict__ gidx,
-                                                             RunsStage st, RunsInfo* __restrict__ info,
-                                                             int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
-                                                             int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord,
-                                                             int32_t* __restrict__ d_median, uint8_t* __restrict__ d_kind,
-                                                             int32_t* total_out, unsigned long long* acc, int32_t refuse) {
+/* regular batch: the caller's columns are final already - publish the count.  Otherwise: parked outputs ->
+ * the dense staging block, chunk by chunk in record order */
+__global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int32_t n, RunsStage st,
+                                                             RunsInfo* __restrict__ info, int32_t* total_out,
+                                                             unsigned long long* acc, int32_t refuse) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
   if (*X.unsorted == X.epoch) { /* the partition pipeline (k_emit_dec16) writes the outputs; refused: none */
     if (refuse && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = 0;
     return;
   }
-  const int32_t R = runs_load(info, n, rs);
+  if (runs_regular(info, n)) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      const int32_t total = info->fast_dec;
+      if (total_out) *total_out = total;
+      if (acc) atomicAdd(acc, (unsigned long long)total);
+    }
+    return;
+  }
   const int32_t w = (int32_t)blockIdx.x;
+  const bool merge = info->need_merge != 0;
+  /* nothing parked in this chunk (the chunks of the later runs, usually): nothing to place - only the last
+   * chunk (the total) and, before a merge, the chunks that hold a run start (segment bounds) go on */
+  if (!merge && st.chunk_cnt[w] == 0 && w != (int32_t)gridDim.x - 1) return;
+  const int32_t R = runs_load(info, n, rs);
   int32_t before = 0;
   for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) before += st.chunk_cnt[t];
   int32_t pre;
@@ -363,27 +441,17 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int3
   const bool have = i < n && st.tag[i] == X.epoch;
   int32_t tot;
   const int32_t ex = block_exscan_n<GPX_DCHUNK>(have ? 1 : 0, &tot);
-  const bool merge = info->need_merge != 0;
   const int64_t o = (int64_t)pre + ex;
   if (i < n) /* outputs parked before each run start (the merge's segment bounds) */
     for (int32_t q = 1; q < R; q++)
       if (rs[q] == i) info->seg_off[q] = (int32_t)o;
   if (have) {
-    if (!merge) {
-      d_gidx[o] = gidx[i];
-      d_slot[o] = st.O.slot()[i];
-      d_bnum[o] = st.O.bnum()[i];
-      d_bcoord[o] = st.O.bcoord()[i];
-      d_median[o] = st.O.median()[i];
-      d_kind[o] = st.O.kind()[i];
-    } else {
-      st.T.gidx()[o] = gidx[i];
-      st.T.slot()[o] = st.O.slot()[i];
-      st.T.bnum()[o] = st.O.bnum()[i];
-      st.T.bcoord()[o] = st.O.bcoord()[i];
-      st.T.median()[o] = st.O.median()[i];
-      st.T.kind()[o] = st.O.kind()[i];
-    }
+    st.T.gidx()[o] = st.D.gidx[i];
+    st.T.slot()[o] = st.D.slot[i];
+    st.T.bnum()[o] = st.D.bnum[i];
+    st.T.bcoord()[o] = st.D.bcoord[i];
+    st.T.median()[o] = st.D.median[i];
+    st.T.kind()[o] = st.D.kind[i];
   }
   if (w == (int32_t)gridDim.x - 1 && threadIdx.x == 0) {
     const int32_t total = pre + tot;
@@ -409,33 +477,31 @@ __device__ __forceinline__ int32_t seg_bound(const int32_t* __restrict__ a, int3
   return x - lo;
 }
 
-/* the compacted outputs are R segments (one per run the outputs were parked in), each ascending by
- * (gidx, vote order); the contract's order is their merge, a group's entries of an earlier segment first */
+/* irregular batch: the staged outputs back into the caller's columns.  Parked inside run 0 only: record order
+ * is gidx order - a copy.  Otherwise the staged outputs are R segments (one per run the outputs were parked
+ * in), each ascending by (gidx, vote order); the contract's order is their merge, a group's entries of an
+ * earlier segment first. */
 __global__ __launch_bounds__(GPX_BLOCK) void k_merge_runs(DevScratch X, int32_t n, RunsStage st,
-                                                         const RunsInfo* __restrict__ info,
-                                                         int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
-                                                         int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord,
-                                                         int32_t* __restrict__ d_median, uint8_t* __restrict__ d_kind) {
-  if (*X.unsorted == X.epoch || !info->need_merge) return;
+                                                         const RunsInfo* __restrict__ info) {
+  if (*X.unsorted == X.epoch || runs_regular(info, n)) return;
   const int32_t R = min(info->n_desc, GPX_RUNS_MAX - 1) + 1;
   const int32_t total = info->total;
+  const bool merge = info->need_merge != 0;
   const int32_t* tg = st.T.gidx();
   for (int32_t t = blockIdx.x * GPX_BLOCK + threadIdx.x; t < total; t += gridDim.x * GPX_BLOCK) {
     const int32_t g = tg[t];
-    int32_t a = 0;
-    for (int32_t q = 1; q < R; q++) a += info->seg_off[q] <= t;
-    /* runs without parked outputs give empty segments (equal offsets): `a` is the last segment starting at or before t */
-    int32_t rank = t - info->seg_off[a];
-    for (int32_t b = 0; b < R; b++) {
-      if (b == a) continue;
-      const int32_t lo = info->seg_off[b], hi = info->seg_off[b + 1];
-      rank += b < a ? seg_bound<true>(tg, lo, hi, g) : seg_bound<false>(tg, lo, hi, g);
+    int32_t rank = t;
+    if (merge) {
+      int32_t a = 0;
+      for (int32_t q = 1; q < R; q++) a += info->seg_off[q] <= t;
+      /* runs without parked outputs give empty segments (equal offsets): `a` is the last segment starting at or before t */
+      rank = t - info->seg_off[a];
+      for (int32_t b = 0; b < R; b++) {
+        if (b == a) continue;
+        const int32_t lo = info->seg_off[b], hi = info->seg_off[b + 1];
+        rank += b < a ? seg_bound<true>(tg, lo, hi, g) : seg_bound<false>(tg, lo, hi, g);
+      }
     }
-    d_gidx[rank] = g;
-    d_slot[rank] = st.T.slot()[t];
-    d_bnum[rank] = st.T.bnum()[t];
-    d_bcoord[rank] = st.T.bcoord()[t];
-    d_median[rank] = st.T.median()[t];
-    d_kind[rank] = st.T.kind()[t];
+    st.D.put(rank, g, st.T.slot()[t], st.T.bnum()[t], st.T.bcoord()[t], st.T.median()[t], st.T.kind()[t]);
   }
 }

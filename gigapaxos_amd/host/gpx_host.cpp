@@ -1070,10 +1070,13 @@ size_t PaxosManager::processRun() {
     frames.push_back(std::move(inbox_.front()));
     inbox_.pop_front();
   }
+  size_t fromDeferred = 0; /* retries of requests the proposal window had no room for */
+  redeferred_ = 0;
   if (kind == 0 && inbox_.empty()) {
     while (!deferred_.empty() && frames.size() < maxFrames) {
       frames.push_back(std::move(deferred_.front()));
       deferred_.pop_front();
+      fromDeferred++;
     }
     while (!requests_.empty() && frames.size() < maxFrames) {
       frames.push_back(std::move(requests_.front()));
@@ -1238,6 +1241,7 @@ size_t PaxosManager::processRun() {
          * for decisions to free a slot and is proposed again on a later pass - never dropped */
         deferred_.push_back(std::move(rf));
         stats_.deferred++;
+        redeferred_++;
       } else {
         stats_.refused++; /* STOPPED / NOGROUP / proposal after a stop: the reference drops these too */
       }
@@ -1404,7 +1408,10 @@ size_t PaxosManager::processRun() {
       if (i == 0 || c.gidx[(size_t)i] != c.gidx[(size_t)i - 1]) sg.push_back(c.gidx[(size_t)i]), sb.push_back(c.bcoord[(size_t)i]);
     syncGaps(sg, sb);
   }
-  return consumed;
+  /* a retry that the window refused again is not progress: a caller that loops while there is work
+   * (and fires its retransmission timers only when there is none) would spin on it for ever when the
+   * ACCEPTs or replies that would free the window were lost */
+  return consumed - std::min(consumed, std::min(fromDeferred, redeferred_));
 }
 
 size_t PaxosManager::releaseHeld() {

@@ -36,7 +36,10 @@ JFN(jlong, create)(JNIEnv* env, jclass c, jint myId, jint maxGroups, jint kmax, 
   (void)env, (void)c;
   gpx_config cfg = {myId, maxGroups, kmax, window, maxBatch, device, GPX_F_ACCEPTS_FROM_DISK, 0};
   gpx_engine* h = 0;
-  return gpx_engine_create(&cfg, &h) == GPX_OK ? (jlong)(intptr_t)h : 0;
+  /* a handle (never negative as a jlong: a user-space pointer) or the negative GPX_E* code; the text is in
+   * lastError() */
+  const int rc = gpx_engine_create(&cfg, &h);
+  return rc == GPX_OK ? (jlong)(intptr_t)h : (jlong)rc;
 }
 JFN(jint, destroy)(JNIEnv* env, jclass c, jlong h) {
   (void)env, (void)c;
@@ -49,7 +52,11 @@ JFN(jstring, lastError)(JNIEnv* env, jclass c) {
 /* pins a direct ByteBuffer for DMA once, after allocation (gpx_host_register) */
 JFN(jint, hostRegister)(JNIEnv* env, jclass c, jlong h, jobject buf) {
   (void)c;
-  return gpx_host_register(H(h), B(buf), (size_t)(*env)->GetDirectBufferCapacity(env, buf));
+  if (!buf) return GPX_EINVAL;
+  void* p = (*env)->GetDirectBufferAddress(env, buf); /* NULL for a heap (non-direct) buffer */
+  const jlong cap = (*env)->GetDirectBufferCapacity(env, buf); /* -1 for one */
+  if (!p || cap <= 0) return GPX_EINVAL;
+  return gpx_host_register(H(h), p, (size_t)cap);
 }
 /* PaxosManager.createPaxosInstance(Map, ...) batch create (PaxosManager.java:664-691) */
 JFN(jint, groupCreate)(JNIEnv* env, jclass c, jlong h, jint n, jobject gidx, jobject members, jobject k,
@@ -89,6 +96,50 @@ JFN(jint, acceptReplyBatch)(JNIEnv* env, jclass c, jlong h, jint n, jobject gidx
   return gpx_accept_reply_batch(H(h), n, B(gidx), B(bnum), B(bcoord), B(slot), B(acceptor), B(maxCp),
                                 B(dGidx), B(dSlot), B(dBnum), B(dBcoord), B(dMedian), B(dKind), B(nOut),
                                 B(status));
+}
+/* The asynchronous twins (include/gpx.h): the call returns once its copies and kernels are queued; every
+ * buffer stays untouched until engineWait(ticket) returns.  A ticket comes back through a one-element direct
+ * LongBuffer. */
+JFN(jint, proposeBatchAsync)(JNIEnv* env, jclass c, jlong h, jint n, jobject gidx, jobject isStop, jobject slot,
+                             jobject bnum, jobject bcoord, jobject medianCp, jobject status, jobject ticket) {
+  (void)c;
+  return gpx_propose_batch_async(H(h), n, B(gidx), B(isStop), B(slot), B(bnum), B(bcoord), B(medianCp), B(status),
+                                 (gpx_ticket*)B(ticket));
+}
+/* bnum == null && bcoord == null: every vote carries (commonBnum, commonBcoord) */
+JFN(jint, acceptReplyBatchAsync)(JNIEnv* env, jclass c, jlong h, jint n, jobject gidx, jobject bnum,
+                                 jobject bcoord, jint commonBnum, jint commonBcoord, jobject slot,
+                                 jobject acceptor, jobject maxCp, jobject dGidx, jobject dSlot, jobject dBnum,
+                                 jobject dBcoord, jobject dMedian, jobject dKind, jobject nOut, jobject status,
+                                 jobject ticket) {
+  (void)c;
+  return gpx_accept_reply_batch_async(H(h), n, B(gidx), B(bnum), B(bcoord), commonBnum, commonBcoord, B(slot),
+                                      B(acceptor), B(maxCp), B(dGidx), B(dSlot), B(dBnum), B(dBcoord), B(dMedian),
+                                      B(dKind), B(nOut), B(status), (gpx_ticket*)B(ticket));
+}
+JFN(jint, acceptBatchAsync)(JNIEnv* env, jclass c, jlong h, jint n, jobject gidx, jobject bnum, jobject bcoord,
+                            jobject slot, jobject medianCp, jobject aFlags, jobject rBnum, jobject rBcoord,
+                            jobject rMaxCp, jobject rFlags, jobject status, jobject xGidx, jobject xFirst,
+                            jobject xCount, jobject nRuns, jobject ticket) {
+  (void)c;
+  return gpx_accept_batch_async(H(h), n, B(gidx), B(bnum), B(bcoord), B(slot), B(medianCp), B(aFlags), B(rBnum),
+                                B(rBcoord), B(rMaxCp), B(rFlags), B(status), B(xGidx), B(xFirst), B(xCount),
+                                B(nRuns), (gpx_ticket*)B(ticket));
+}
+JFN(jint, commitBatchAsync)(JNIEnv* env, jclass c, jlong h, jint n, jobject gidx, jobject bnum, jobject bcoord,
+                            jobject slot, jobject medianCp, jobject cKind, jobject status, jobject xGidx,
+                            jobject xFirst, jobject xCount, jobject nRuns, jobject ticket) {
+  (void)c;
+  return gpx_commit_batch_async(H(h), n, B(gidx), B(bnum), B(bcoord), B(slot), B(medianCp), B(cKind), B(status),
+                                B(xGidx), B(xFirst), B(xCount), B(nRuns), (gpx_ticket*)B(ticket));
+}
+JFN(jint, engineWait)(JNIEnv* env, jclass c, jlong h, jlong ticket) {
+  (void)env, (void)c;
+  return gpx_engine_wait(H(h), (gpx_ticket)ticket);
+}
+JFN(jint, setOrderedBatches)(JNIEnv* env, jclass c, jlong h, jint mask) {
+  (void)env, (void)c;
+  return gpx_engine_set_ordered_batches(H(h), mask);
 }
 /* PISM.handleBatchedCommit / handleCommittedRequest (PISM:1432-1528) */
 JFN(jint, commitBatch)(JNIEnv* env, jclass c, jlong h, jint n, jobject gidx, jobject bnum, jobject bcoord,

@@ -293,6 +293,53 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
                          const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx,
                          int32_t* x_first, int32_t* x_count, int32_t* n_runs);
 
+/* ---- data path (host pointers, ASYNCHRONOUS: copies in, kernels and copies out overlap across calls) ---- */
+/*
+ * The plain host-pointer calls above are synchronous: H2D of every input column, the kernels, D2H of the
+ * outputs, one after the other, and the caller waits - a 3 M-vote accept-reply call is 95 % PCIe time and
+ * uses one direction of the link at a time.  The *_async twins return as soon as the work is QUEUED:
+ *   - inputs go to the device on a copy stream of their own, the kernels wait for them on the engine's
+ *     stream (calls are applied in submission order, like every other call), the dense outputs and the
+ *     output COUNT come back on a third stream;
+ *   - gpx_engine_wait(ticket) blocks until that call is through, then fetches exactly *n_out / *n_runs
+ *     entries of the compacted outputs (never the full capacity) and fills in the count.
+ * While call N's outputs travel to the host, call N + 1's inputs travel to the device and its kernels run:
+ * both directions of the link are busy.  Up to GPX_ASYNC_DEPTH calls may be in flight; one more returns
+ * GPX_EBUSY (wait for the oldest ticket first).  EVERY buffer of a call - inputs and outputs - must stay
+ * valid and untouched until its gpx_engine_wait returns (a JNI caller keeps a ring of direct ByteBuffers),
+ * and should be pinned (gpx_host_register): the runtime copies pageable memory synchronously, which
+ * serialises everything again.  Tickets may be waited for in any order; gpx_engine_destroy and
+ * gpx_engine_sync complete the device work but not the host-side fetch of a ticket nobody waited for.
+ * Results are those of the synchronous calls.
+ *
+ * gpx_accept_reply_batch_async takes bnum == NULL && bcoord == NULL to say "every vote of this batch
+ * carries the ballot (common_bnum, common_bcoord)" - what a coordinator in its steady state receives
+ * (PISM.handleBatchedAcceptReply unpacks one ballot per BatchedAcceptReply, PaxosInstanceStateMachine.java:
+ * 1380-1387): 16 instead of 24 bytes per vote cross the link.
+ */
+#define GPX_ASYNC_DEPTH 4
+#define GPX_EBUSY (-5) /* GPX_ASYNC_DEPTH calls in flight, or the ticket is unknown / already waited for */
+typedef uint64_t gpx_ticket;
+int gpx_propose_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop, int32_t* slot,
+                            int32_t* bnum, int32_t* bcoord, int32_t* median_cp, uint8_t* status,
+                            gpx_ticket* ticket);
+int gpx_accept_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                           const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                           const uint8_t* a_flags, int32_t* r_bnum, int32_t* r_bcoord, int32_t* r_maxcp,
+                           uint8_t* r_flags, uint8_t* status, int32_t* x_gidx, int32_t* x_first,
+                           int32_t* x_count, int32_t* n_runs, gpx_ticket* ticket);
+int gpx_accept_reply_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                                 const int32_t* bcoord, int32_t common_bnum, int32_t common_bcoord,
+                                 const int32_t* slot, const int32_t* acceptor, const int32_t* max_cp,
+                                 int32_t* d_gidx, int32_t* d_slot, int32_t* d_bnum, int32_t* d_bcoord,
+                                 int32_t* d_median_cp, uint8_t* d_kind, int32_t* n_out, uint8_t* status,
+                                 gpx_ticket* ticket);
+int gpx_commit_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
+                           const int32_t* bcoord, const int32_t* slot, const int32_t* median_cp,
+                           const uint8_t* c_kind, uint8_t* status, int32_t* x_gidx, int32_t* x_first,
+                           int32_t* x_count, int32_t* n_runs, gpx_ticket* ticket);
+int gpx_engine_wait(gpx_engine* h, gpx_ticket ticket);
+
 /* ---- view change, acceptor side ------------------------------------------------ */
 
 #define GPX_P_NACK 1  /* the acceptor's ballot is higher than the prepare's: no pvalues returned */

@@ -37,6 +37,10 @@ CASES = [
     # lost ACCEPTs / accept replies: the retransmission timers (gpx_poke_scan) and the forced sync
     ["--groups", "200", "--rounds", "10", "--drop-accepts", "150"],
     ["--groups", "300", "--rounds", "8", "--drop-accepts", "100", "--drop-commits", "100", "--nodes", "5", "--seed", "2"],
+    # a burst longer than the engine's proposal window, unbatched, on a network that loses ACCEPTs and replies:
+    # window-refused requests are retried, and a retry that is refused again must not count as progress - the
+    # retransmission timers (which only fire when there is no work) are what frees the window
+    ["--groups", "20", "--rounds", "3", "--burst", "24", "--no-batching", "--drop-accepts", "200", "--seed", "13"],
     # logging on: accept replies wait for their batch's log write (durable three polls later)
     ["--groups", "200", "--rounds", "6", "--log-delay", "3"],
     ["--groups", "150", "--rounds", "6", "--log-delay", "5", "--kill-round", "3", "--burst", "2", "--seed", "12"],

@@ -39,7 +39,8 @@ def test_hip_library_exports_every_declared_symbol():
 
 def test_oracle_exports_matching_symbols(oracle_lib):
     for name in _declared():
-        if name.endswith("_dev") or name in ("gpx_engine_set_stream", "gpx_profile_enable", "gpx_profile_read"):
+        if name.endswith(("_dev", "_async")) or name in ("gpx_engine_set_stream", "gpx_profile_enable", "gpx_profile_read",
+                                                          "gpx_engine_wait"):
             continue
         assert hasattr(oracle_lib.lib, "orc_" + name[4:]), name
 
@@ -58,3 +59,13 @@ def test_engine_create_rejects_bad_config_without_gpu():
                 GpxConfig(100, 8, 3, 6, 16, -1, 1, 0), GpxConfig(100, 8, 3, 128, 16, -1, 1, 0)):
         assert lib.gpx_engine_create(ctypes.byref(bad), ctypes.byref(h)) == -1
     assert lib.gpx_engine_create(None, ctypes.byref(h)) == -1
+
+
+def test_jni_shim_compiles_against_the_headers(tmp_path):
+    """gigapaxos_amd/jni/gpx_jni.c with GPX_HAVE_JNI, against a minimal stand-in of jni.h (the image has no
+    JDK): every call in the shim matches its prototype in include/*.h (arity and pointer types; -Werror)."""
+    import subprocess
+
+    shim = os.path.join(ROOT, "gigapaxos_amd", "jni", "gpx_jni.c")
+    subprocess.check_call(["gcc", "-fsyntax-only", "-Wall", "-Werror", "-DGPX_HAVE_JNI", "-I",
+                           os.path.join(ROOT, "tests", "jni_stub"), "-I", os.path.join(ROOT, "include"), shim])

@@ -41,7 +41,7 @@ def test_reply_runs_1m_groups_vs_oracle(hip_lib, oracle_lib, k, mode):
         dh, do = eh.accept_reply(*cols), eo.accept_reply(*cols)
         _same(dh, do, f"round {r}")
         assert (np.diff(dh.gidx) >= 0).all()
-        if not mix:
+        if not mix and drop == 0.0:
             assert dh.gidx.shape[0] == G and (dh.kind == D_DECISION).all()
     sh, so = eh.snapshot(g)[0], eo.snapshot(g)[0]
     assert sh.tobytes() == so.tobytes()
