@@ -165,6 +165,22 @@ __device__ __forceinline__ void for_signed_order(int32_t lo, int32_t cnt, F f) {
  * __forceinline__ like every other per-group function here: as a __noinline__ call (an earlier
  * build) the kernel faulted intermittently on the GPU box (SIGSEGV inside elect_group under rocgdb,
  * a silent abort outside it) with the same source that runs clean inlined. */
+/* GPX_ELECT_BOUNDS (debug build, scripts/repro_noinline_fault.sh): every index into the per-lane arrays of
+ * elect_group is checked - a violation prints its source line and traps, which the runtime reports as an
+ * exception of the kernel, not as a memory fault: tells an out-of-bounds scratch index (ours) from a fault
+ * in the call / scratch machinery (the toolchain's) */
+#ifdef GPX_ELECT_BOUNDS
+#define EI(i) elect_idx((int32_t)(i), WMAX, __LINE__)
+__device__ __forceinline__ int32_t elect_idx(int32_t i, int32_t lim, int line) {
+  if ((uint32_t)i >= (uint32_t)lim) {
+    printf("elect_group: index %d outside [0, %d) at gpx_elect.hip.h:%d\n", i, lim, line);
+    __builtin_trap();
+  }
+  return i;
+}
+#else
+#define EI(i) (i)
+#endif
 template <int KMAX, int WMAX>
 #ifdef GPX_ELECT_NOINLINE /* repro build of round 1's intermittent fault: scripts/repro_noinline_fault.sh */
 #define GPX_ELECT_INLINE __attribute__((noinline))
@@ -242,11 +258,11 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
           if (!co_loaded) {
             for (int32_t w = 0; w < W; w++) {
               const I4 v = S.co_ring[(int64_t)w * G + g];
-              cs[w] = v.x;
-              cb[w] = v.y;
-              cc[w] = v.z;
-              cf[w] = v.w;
-              ch[w] = S.co_handle[(int64_t)w * G + g];
+              cs[EI(w)] = v.x;
+              cb[EI(w)] = v.y;
+              cc[EI(w)] = v.z;
+              cf[EI(w)] = v.w;
+              ch[EI(w)] = S.co_handle[(int64_t)w * G + g];
               if (v.w & CO_PRESENT) cmask |= 1ull << w;
             }
             co_loaded = true;
@@ -261,11 +277,11 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
             for (int32_t j = 0; j < m; j++) {
               const int32_t s = I.pv_slot[o + j], x = s & Wm;
               if ((nm >> x) & 1ull) {
-                if (claimed[x] != s) clash = true;
-              } else if (((cmask >> x) & 1ull) && cs[x] != s) {
+                if (claimed[EI(x)] != s) clash = true;
+              } else if (((cmask >> x) & 1ull) && cs[EI(x)] != s) {
                 clash = true;
               }
-              claimed[x] = s;
+              claimed[EI(x)] = s;
               nm |= 1ull << x;
             }
           }
@@ -291,12 +307,12 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
             for (int32_t j = 0; j < m; j++) {
               const int32_t s = I.pv_slot[o + j], x = s & Wm;
               const int32_t bn = I.pv_bnum[o + j], bc = I.pv_bcoord[o + j];
-              if (!((cmask >> x) & 1ull) || ballot_cmp(bn, bc, cb[x], cc[x]) > 0) {
-                cs[x] = s;
-                cb[x] = bn;
-                cc[x] = bc;
-                cf[x] = CO_PRESENT | (I.pv_flags ? (int32_t)(I.pv_flags[o + j] & (GPX_PV_STOP | GPX_PV_NOOP)) : 0);
-                ch[x] = I.pv_handle ? I.pv_handle[o + j] : 0;
+              if (!((cmask >> x) & 1ull) || ballot_cmp(bn, bc, cb[EI(x)], cc[EI(x)]) > 0) {
+                cs[EI(x)] = s;
+                cb[EI(x)] = bn;
+                cc[EI(x)] = bc;
+                cf[EI(x)] = CO_PRESENT | (I.pv_flags ? (int32_t)(I.pv_flags[o + j] & (GPX_PV_STOP | GPX_PV_NOOP)) : 0);
+                ch[EI(x)] = I.pv_handle ? I.pv_handle[o + j] : 0;
                 cmask |= 1ull << x;
                 co_dirty |= 1ull << x;
               }
@@ -318,7 +334,7 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
                 bool any = false;
                 for (int32_t w = 0; w < W; w++)
                   if ((cmask >> w) & 1ull) {
-                    if (!any || jsub(cs[w], maxCarry) > 0) maxCarry = cs[w];
+                    if (!any || jsub(cs[EI(w)], maxCarry) > 0) maxCarry = cs[EI(w)];
                     any = true;
                   }
 #pragma unroll
@@ -340,9 +356,9 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
                     const int32_t d = jsub(cur, pre_lo);
                     uint32_t en = 0;
                     int64_t hn = 0;
-                    if (((cmask >> x) & 1ull) && cs[x] == cur) {
-                      en = FE_MAKE(GPX_E_CARRY, cf[x] & GPX_PV_STOP); /* received pvalues dominate */
-                      hn = ch[x];
+                    if (((cmask >> x) & 1ull) && cs[EI(x)] == cur) {
+                      en = FE_MAKE(GPX_E_CARRY, cf[EI(x)] & GPX_PV_STOP); /* received pvalues dominate */
+                      hn = ch[EI(x)];
                     } else if (!(d >= 0 && d < pcount)) {
                       en = FE_MAKE(GPX_E_NOOP, 0); /* neither received nor pre-active */
                     } else {
@@ -350,15 +366,15 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
                       const uint32_t pe = S.p_ring[po];
                       const int64_t ph = S.p_handle[po];
                       bool dup = false; /* isDuplicate: RequestPacket.equals over the carry-overs */
-                      for (int32_t w = 0; w < W; w++) dup |= ((cmask >> w) & 1ull) && ch[w] == ph;
+                      for (int32_t w = 0; w < W; w++) dup |= ((cmask >> w) & 1ull) && ch[EI(w)] == ph;
                       if (!dup) {
                         en = FE_MAKE(GPX_E_PREACTIVE, pe & PR_STOP);
                         hn = ph;
                       }
                       removed |= 1ull << d; /* remove even if duplicate */
                     }
-                    fe[pos] = en;
-                    fh[pos] = hn;
+                    fe[EI(pos)] = en;
+                    fh[EI(pos)] = hn;
                     if (en & FE_PRESENT) {
                       stop_exists |= (en & FE_STOP) != 0;
                     }
@@ -369,8 +385,8 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
                   auto append = [&](uint32_t en, int64_t hn) {
                     if (pos > 0 && last_stop) return; /* nothing goes after a stop */
                     if (pos < W) {
-                      fe[pos] = en;
-                      fh[pos] = hn;
+                      fe[EI(pos)] = en;
+                      fh[EI(pos)] = hn;
                     }
                     pos++;
                     stop_exists |= (en & FE_STOP) != 0;
@@ -389,9 +405,9 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
                     for (int32_t d = 1; d <= pcount; d++) S.p_ring[(int64_t)(jsub(next, d) & Wm) * G + g] = 0;
                     int32_t live = 0;
                     for (int32_t j = 0; j < pos; j++)
-                      if (fe[j] & FE_PRESENT) {
+                      if (fe[EI(j)] & FE_PRESENT) {
                         const int32_t s = (int32_t)((uint32_t)lo + (uint32_t)j);
-                        S.p_ring[(int64_t)(s & Wm) * G + g] = PR_PRESENT | ((fe[j] & FE_STOP) ? PR_STOP : 0u);
+                        S.p_ring[(int64_t)(s & Wm) * G + g] = PR_PRESENT | ((fe[EI(j)] & FE_STOP) ? PR_STOP : 0u);
                         live++;
                       }
                     next = (int32_t)((uint32_t)lo + (uint32_t)pos);
@@ -399,12 +415,12 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
                     prop_dirty = true;
                     /* spawnCommandersForProposals: TreeMap order */
                     for_signed_order(lo, pos, [&](int32_t j) {
-                      if (!(fe[j] & FE_PRESENT)) return;
+                      if (!(fe[EI(j)] & FE_PRESENT)) return;
                       const int64_t q = (int64_t)ecount * n + ix;
                       O.e_slot[q] = (int32_t)((uint32_t)lo + (uint32_t)j);
-                      O.e_kind[q] = (uint8_t)FE_KIND(fe[j]);
-                      O.e_handle[q] = fh[j];
-                      O.e_flags[q] = (fe[j] & FE_STOP) ? GPX_PV_STOP : 0;
+                      O.e_kind[q] = (uint8_t)FE_KIND(fe[EI(j)]);
+                      O.e_handle[q] = fh[EI(j)];
+                      O.e_flags[q] = (fe[EI(j)] & FE_STOP) ? GPX_PV_STOP : 0;
                       ecount++;
                     });
                   }
@@ -430,8 +446,8 @@ __device__ GPX_ELECT_INLINE void elect_group(const DevState& S, const DevScratch
   if (co_dirty) {
     for (int32_t w = 0; w < W; w++)
       if ((co_dirty >> w) & 1ull) {
-        S.co_ring[(int64_t)w * G + g] = I4{cs[w], cb[w], cc[w], cf[w]};
-        S.co_handle[(int64_t)w * G + g] = ch[w];
+        S.co_ring[(int64_t)w * G + g] = I4{cs[EI(w)], cb[EI(w)], cc[EI(w)], cf[EI(w)]};
+        S.co_handle[(int64_t)w * G + g] = ch[EI(w)];
       }
   }
   if (ns_dirty) {

@@ -867,13 +867,13 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     {
       LaunchScope _ls(e, "k_ar_runs");
       if (e->cfg.kmax <= 4)
-        hipLaunchKernelGGL(k_ar_runs<4>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
+        hipLaunchKernelGGL(k_ar_runs<4>, dim3((n + GPX_RBLOCK - 1) / GPX_RBLOCK), dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum,
                            bcoord, slot, acceptor, max_cp, status, st, info, refuse);
       else if (e->cfg.kmax <= 8)
-        hipLaunchKernelGGL(k_ar_runs<8>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
+        hipLaunchKernelGGL(k_ar_runs<8>, dim3((n + GPX_RBLOCK - 1) / GPX_RBLOCK), dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum,
                            bcoord, slot, acceptor, max_cp, status, st, info, refuse);
       else
-        hipLaunchKernelGGL(k_ar_runs<16>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->S, e->X, n, gidx, bnum,
+        hipLaunchKernelGGL(k_ar_runs<16>, dim3((n + GPX_RBLOCK - 1) / GPX_RBLOCK), dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum,
                            bcoord, slot, acceptor, max_cp, status, st, info, refuse);
     }
     {

@@ -262,9 +262,12 @@ struct RunsIter {
  * columns there: independent loads, all in flight together), then the state, and replays from registers in a
  * straight line; any other group walks the runs with RunsIter through apply_ar_group. */
 #define GPX_RUNS_FAST 5 /* runs held in registers (five replicas: BASELINE config #4) */
+/* 256-thread workgroups: with 1024 (the chunk) the kernel's 65 VGPRs leave room for ONE workgroup per CU -
+ * four waves per SIMD, each a chain of three dependent load waves - and the kernel took 87 us per 3 M votes */
+#define GPX_RBLOCK 256
 
 template <int KMAX>
-__global__ __launch_bounds__(GPX_DCHUNK) void k_ar_runs(DevState S, DevScratch X, int32_t n,
+__global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X, int32_t n,
                                                        const int32_t* __restrict__ gidx,
                                                        const int32_t* __restrict__ bnum,
                                                        const int32_t* __restrict__ bcoord,
@@ -274,8 +277,9 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ar_runs(DevState S, DevScratch X
                                                        uint8_t* __restrict__ status, RunsStage st,
                                                        RunsInfo* __restrict__ info, int32_t refuse) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
-  __shared__ int32_t wsum[GPX_DCHUNK / 64], wfast[GPX_DCHUNK / 64];
-  const int32_t i = (int32_t)blockIdx.x * GPX_DCHUNK + (int32_t)threadIdx.x;
+  __shared__ int32_t wsum[GPX_RBLOCK / 64], wfast[GPX_RBLOCK / 64];
+  const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
+  const int32_t my_chunk = (int32_t)(((int64_t)blockIdx.x * GPX_RBLOCK) >> GPX_DCHUNK_SHIFT);
   if (*X.unsorted == X.epoch) {
     /* not a few sorted runs: the partition pipeline launched behind does it - or, under the
      * GPX_ORDERED_REPLY_RUNS promise (no partition pipeline launched), the batch is refused whole */
@@ -376,7 +380,7 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ar_runs(DevState S, DevScratch X
       it.st = st;
       it.info = info;
       it.epoch = X.epoch;
-      it.chunk = (int32_t)blockIdx.x;
+      it.chunk = my_chunk;
       it.local = 0;
       if (!have_p) {
         coord_preload<KMAX>(S, g, P);
@@ -400,11 +404,11 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ar_runs(DevState S, DevScratch X
   __syncthreads();
   if (threadIdx.x == 0) {
     int32_t tot = 0, totf = 0;
-    for (int w = 0; w < GPX_DCHUNK / 64; w++) {
+    for (int w = 0; w < GPX_RBLOCK / 64; w++) {
       tot += wsum[w];
       totf += wfast[w];
     }
-    if (tot) atomicAdd(&st.chunk_cnt[blockIdx.x], tot);
+    if (tot) atomicAdd(&st.chunk_cnt[my_chunk], tot);
     if (totf) atomicAdd(&info->fast_dec, totf);
   }
 }

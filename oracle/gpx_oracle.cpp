@@ -449,6 +449,10 @@ const char* orc_last_error(void) { return g_err; }
 int orc_engine_create(const gpx_config* cfg, gpx_engine** out) {
   if (!cfg || !out || cfg->max_groups <= 0 || cfg->kmax < 1 || cfg->kmax > GPX_KMAX_LIMIT)
     return GPX_EINVAL;
+  /* window: the engine's ring size W (a power of two) - the three refusals it implies (GPX_S_WINDOW of a
+   * proposal, an ACCEPT, a commit) are restated below so that engine == oracle holds at the limits too;
+   * window = 0 (oracle only) = no limits: the reference's unbounded maps, for the known-answer tests */
+  if (cfg->window < 0 || (cfg->window & (cfg->window - 1))) return GPX_EINVAL;
   Engine* e = new Engine();
   e->cfg = *cfg;
   e->groups.resize((size_t)cfg->max_groups);
@@ -702,7 +706,8 @@ int orc_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uin
         const PaxosCoordinatorState& c = *g->coordinator;
         auto prev = c.myProposals.find(jsub(c.nextProposalSlotNumber, 1));
         const bool after_stop = prev != c.myProposals.end() && prev->second.stop;
-        if (!after_stop && c.myProposals.count(jsub(c.nextProposalSlotNumber, e->cfg.window))) {
+        if (!after_stop && e->cfg.window > 0 &&
+            c.myProposals.count(jsub(c.nextProposalSlotNumber, e->cfg.window))) {
           status[i] = GPX_S_WINDOW;
           e->counters[2]++;
           continue;
@@ -788,6 +793,22 @@ int orc_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
       continue;
     }
     Accepted accept{Ballot{bnum[i], bcoord[i]}, slot[i], a_flags && (a_flags[i] & GPX_A_STOP)};
+    {
+      /* engine limit, not in the reference (whose map is unbounded): acceptedProposals is a ring of `window`
+       * entries indexed by slot & (window - 1) - an ACCEPT that would be stored where ANOTHER live accepted
+       * slot sits is dropped whole (GPX_S_WINDOW: no ballot change, no reply), like a lost packet */
+      const PaxosAcceptor& pa = g->paxosState;
+      const bool will_store = accept.ballot.compareTo(pa.getBallot()) >= 0 && jsub(accept.slot, pa.acceptedGCSlot) > 0;
+      bool clash = false;
+      if (will_store && e->cfg.window > 0)
+        for (const auto& kv : pa.acceptedProposals)
+          clash |= kv.first != accept.slot && ((kv.first ^ accept.slot) & (e->cfg.window - 1)) == 0;
+      if (clash) {
+        status[i] = GPX_S_WINDOW;
+        e->counters[2]++;
+        continue;
+      }
+    }
     /* :1122 PValuePacket prev = paxosState.getAccept(accept.slot) — BEFORE accepting */
     bool havePrev = false;
     Ballot prevBallot;
@@ -918,6 +939,13 @@ int orc_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
     }
     if (g->paxosState.stopped) {
       status[i] = GPX_S_STOPPED;
+      e->counters[2]++;
+      continue;
+    }
+    /* engine limit (not in the reference): committedRequests is a ring of `window` slots from the next slot
+     * to execute - a commit further ahead is dropped (GPX_S_WINDOW), like a lost packet */
+    if (e->cfg.window > 0 && jsub(slot[i], g->paxosState._slot) >= e->cfg.window) {
+      status[i] = GPX_S_WINDOW;
       e->counters[2]++;
       continue;
     }

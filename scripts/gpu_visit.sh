@@ -13,6 +13,8 @@
 #   py:SCRIPT[:ARGS]      python scripts/SCRIPT ARGS -> TAG/SCRIPT[_N].out
 #   pmc:SCRIPT[:ARGS[:LABEL]]  FETCH_SIZE / WRITE_SIZE / SQ / TCC passes of python scripts/SCRIPT ARGS -> pmc table
 #   pmclite:SCRIPT[:ARGS] FETCH_SIZE / WRITE_SIZE passes only
+#   ktpy:SCRIPT[:ARGS[:LABEL]]  rocprofv3 --kernel-trace --stats of python scripts/SCRIPT ARGS -> per-kernel summary
+#   sh:SCRIPT[:ARGS]      bash scripts/SCRIPT ARGS
 #   reffix                scripts/make_ref_fixtures.sh when a JDK exists (row c of SURVEY 8)
 TAG=${1:-visit}
 shift
@@ -119,6 +121,21 @@ for step in "$@"; do
     ;;
   pmclite)
     pmc_passes "pmc_${c:-${a%.py}}" "python $REPO/scripts/$a $(sp "$b")" FETCH_SIZE WRITE_SIZE
+    ;;
+  ktpy)
+    L=${c:-${a%.py}}
+    cd /tmp
+    timeout 600 rocprofv3 --kernel-trace --stats -d "$OUT/kt_$L" -o kt -- python $REPO/scripts/$a $(sp "$b") >"$OUT/kt_$L.log" 2>&1
+    echo "kt exit $?"
+    cd "$REPO"
+    KT=$(find "$OUT/kt_$L" -name '*_results.db' | head -1)
+    [ -n "$KT" ] && python scripts/rocprof_summary.py "$KT" "$KT" "$KT" "$OUT/kt_${L}_summary.txt" /dev/null | head -40
+    ;;
+  sh)
+    f=$(uniq_name "${a%.sh}" out)
+    timeout 1200 bash "scripts/$a" $(sp "$b") >"$f" 2>&1
+    echo "$a exit $?"
+    tail -25 "$f" | cut -c1-300
     ;;
   reffix)
     if command -v javac >/dev/null 2>&1; then

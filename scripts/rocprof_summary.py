@@ -20,7 +20,7 @@ import sys
 
 
 def short(name):
-    m = re.match(r"(?:void )?([A-Za-z_0-9]+(?:<[0-9]+>)?)", name)
+    m = re.match(r"(?:void )?([A-Za-z_0-9]+(?:<[0-9a-z, ]+>)?)", name)
     return m.group(1) if m else name[:40]
 
 

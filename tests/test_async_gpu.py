@@ -23,7 +23,7 @@ def test_async_rounds_match_oracle(hip_lib, oracle_lib, G, k):
     votes (every other round without ballot columns: the common-ballot form) -> commits; the oracle goes through
     the synchronous calls."""
     members = list(range(100, 100 + k))
-    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=G * k + 4096)
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=G * k + G * k // 40 + 4096)
     mem = np.tile(np.array(members, np.int32), (G, 1))
     for e in (eh, eo):
         assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 100)) == S_OK).all()

@@ -40,7 +40,10 @@ def test_cluster_invariants(case):
         assert sum(n["sync_decisions_applied"] for n in out["per_node"]) > 0
     burst = int(args[args.index("--burst") + 1]) if "--burst" in args else 1
     per_round = int(args[args.index("--active") + 1]) if "--active" in args else out["groups"]
-    assert out["executed_per_node"] == out["requests"] == per_round * out["rounds"] * burst
+    # bursts longer than the engine's window on a lossy network end with one catch-up request per group
+    # (loopback_cluster.cpp: a lagging replica can lose both the ACCEPT and the commit of a group's last slot)
+    extra = out["groups"] if burst > 8 and ("--drop-accepts" in args or "--drop-commits" in args) else 0
+    assert out["executed_per_node"] == out["requests"] == per_round * out["rounds"] * burst + extra
     assert out["client_acks"] == out["requests"]  # every entry replica answered its clients
     assert all(n["checkpoints"] > 0 for n in out["per_node"]) or out["rounds"] * burst < 4 or "--active" in args
     for n in out["per_node"]:

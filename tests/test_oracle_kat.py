@@ -198,7 +198,9 @@ def test_acceptor_monotone_ballot_property(oracle_lib):
     rows["acc_bnum"] = 22
     rows["acc_bcoord"] = 1
     rows["acc_gc_slot"] = -1
-    e = _mk(oracle_lib, 9, [9, 10, 11], rows=rows)
+    # window = 0: the ORACLE without the engine's ring limits - the reference's unbounded maps, which is what
+    # testAcceptor runs on (slots all over the int range would collide in any ring)
+    e = _mk(oracle_lib, 9, [9, 10, 11], window=0, rows=rows)
     rng = np.random.default_rng(3)
     n = 100000
     bnum = rng.integers(0, 2**31 - 1, n).astype(np.int32)

@@ -164,11 +164,13 @@ def test_window_overflow_statuses(hip_lib, oracle_lib):
     z = np.zeros(5, np.int32)
     (rb, rc, rm, rf, st), _ = eh.accept(np.ones(5, np.int32), z, np.full(5, 100, np.int32), slots, z)
     assert st.tolist() == [S_OK, S_OK, S_OK, S_WINDOW, S_WINDOW]
-    eo.accept(np.ones(3, np.int32), z[:3], np.full(3, 100, np.int32), slots[:3], z[:3])
+    (_, _, _, _, sto), _ = eo.accept(np.ones(5, np.int32), z, np.full(5, 100, np.int32), slots, z)
+    assert sto.tolist() == st.tolist()  # the oracle keeps the same ring rule (round 3)
     st, _ = eh.commit(np.ones(3, np.int32), z[:3], np.full(3, 100, np.int32),
                       np.array([5, 4, 2], np.int32), z[:3])
     assert st.tolist() == [S_WINDOW, S_OK, S_OK]
-    eo.commit(np.ones(2, np.int32), z[:2], np.full(2, 100, np.int32), np.array([4, 2], np.int32), z[:2])
+    sto, _ = eo.commit(np.ones(3, np.int32), z[:3], np.full(3, 100, np.int32), np.array([5, 4, 2], np.int32), z[:3])
+    assert sto.tolist() == st.tolist()
     assert_same_state(eh, eo, range(2))
 
 
