@@ -41,9 +41,8 @@ struct RunsInfo {
   int32_t n_desc;                  /* descents found so far (atomic) */
   int32_t need_merge;              /* an output was parked outside run 0 */
   int32_t total;                   /* outputs of the call (k_emit_dec_runs) */
-  int32_t fast_dec;                /* decisions parked by the straight-line path (atomic, one add per workgroup) */
   int32_t general_used;            /* a group went through the general replay, or a straight-line one did not decide */
-  int32_t pad[3];
+  int32_t pad[4];
   int32_t start[GPX_RUNS_MAX + 1]; /* start[0] = 0; the others in the order the atomics gave: sorted by the readers */
   int32_t seg_off[GPX_RUNS_MAX + 1]; /* staged outputs parked before each run start (k_emit_dec_runs) */
 };
@@ -162,9 +161,13 @@ __device__ __forceinline__ int32_t runs_len0(const RunsInfo* __restrict__ info, 
   for (int32_t q = 1; q <= nd; q++) m = min(m, info->start[q]);
   return m;
 }
-/* REGULAR: only the straight-line path parked outputs, one per record of run 0 (header) */
+/* REGULAR: only the straight-line path parked outputs, one per record of run 0 (header).  No counter is
+ * needed for that (a counter every workgroup adds to is a chain of same-address atomics: it made the kernel
+ * 2.5x slower): a record of run 0 is either a straight-line lane - which raises general_used when it does
+ * not decide - or belongs to a group whose owner took the general replay, which raises it too. */
 __device__ __forceinline__ bool runs_regular(const RunsInfo* __restrict__ info, int32_t n) {
-  return !info->general_used && info->fast_dec == runs_len0(info, n);
+  (void)n;
+  return !info->general_used;
 }
 
 /* first record of group g in run [lo, hi) (ascending gidx), -1 if the run does not hold it; `hint` = where
@@ -277,7 +280,7 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
                                                        uint8_t* __restrict__ status, RunsStage st,
                                                        RunsInfo* __restrict__ info, int32_t refuse) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
-  __shared__ int32_t wsum[GPX_RBLOCK / 64], wfast[GPX_RBLOCK / 64];
+  __shared__ int32_t wsum[GPX_RBLOCK / 64];
   const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
   const int32_t my_chunk = (int32_t)(((int64_t)blockIdx.x * GPX_RBLOCK) >> GPX_DCHUNK_SHIFT);
   if (*X.unsorted == X.epoch) {
@@ -288,7 +291,7 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
   }
   const int32_t R = runs_load(info, n, rs);
   if (i == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
-  int32_t local = 0, fast_dec = 0;
+  int32_t local = 0;
   const bool active = i < n;
   const int32_t g = active ? gidx[i] : 0;
   int32_t r = 0;
@@ -349,7 +352,6 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
           st.D.put(i, g, sl[0], P.my_bnum, P.my_bcoord, dmed, GPX_D_DECISION);
           st.tag[i] = X.epoch;
           local = 1;
-          fast_dec = 1;
         } else {
           info->general_used = 1; /* a hole in run 0: the columns are not dense */
         }
@@ -390,26 +392,16 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       local = it.local;
     }
   }
-  /* this chunk's own parked outputs and straight-line decisions: one atomic each per workgroup */
-  int32_t x = local, y = fast_dec;
+  /* this chunk's own parked outputs: one atomic per workgroup */
+  int32_t x = local;
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    x += __shfl_xor(x, d, 64);
-    y += __shfl_xor(y, d, 64);
-  }
-  if ((threadIdx.x & 63) == 0) {
-    wsum[threadIdx.x >> 6] = x;
-    wfast[threadIdx.x >> 6] = y;
-  }
+  for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = x;
   __syncthreads();
   if (threadIdx.x == 0) {
-    int32_t tot = 0, totf = 0;
-    for (int w = 0; w < GPX_RBLOCK / 64; w++) {
-      tot += wsum[w];
-      totf += wfast[w];
-    }
+    int32_t tot = 0;
+    for (int w = 0; w < GPX_RBLOCK / 64; w++) tot += wsum[w];
     if (tot) atomicAdd(&st.chunk_cnt[my_chunk], tot);
-    if (totf) atomicAdd(&info->fast_dec, totf);
   }
 }
 
@@ -425,7 +417,7 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int3
   }
   if (runs_regular(info, n)) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
-      const int32_t total = info->fast_dec;
+      const int32_t total = runs_len0(info, n); /* one decision per record of run 0 */
       if (total_out) *total_out = total;
       if (acc) atomicAdd(acc, (unsigned long long)total);
     }
