@@ -419,19 +419,28 @@ class Engine:
             self.eng.lib.check(self.eng.lib.fn["engine_wait"](self.eng.h, C.c_uint64(self.ticket)), "engine_wait")
             return self.finish()
 
-    def propose_async(self, gidx, is_stop=None):
+    def propose_async(self, gidx, is_stop=None, pin_outputs=False):
         gidx = _i32(gidx)
         n = gidx.shape[0]
         is_stop = _u8(is_stop, n)
         slot, bnum, bcoord, median = (np.zeros(n, np.int32) for _ in range(4))
         status = np.zeros(n, np.uint8)
+        outs = (slot, bnum, bcoord, median, status)
+        if pin_outputs:
+            self.host_register(*outs)
         t = C.c_uint64(0)
         self.lib.check(self.lib.fn["propose_batch_async"](self.h, n, _p(gidx), _p(is_stop), _p(slot), _p(bnum), _p(bcoord),
                                                           _p(median), _p(status), C.byref(t)), "propose_batch_async")
-        return Engine.Pending(self, t.value, (gidx, is_stop), lambda: (slot, bnum, bcoord, median, status))
+        def finish():
+            if pin_outputs:
+                self.host_unregister(*outs)
+            return slot, bnum, bcoord, median, status
+        return Engine.Pending(self, t.value, (gidx, is_stop), finish)
 
-    def accept_reply_async(self, gidx, bnum, bcoord, slot, acceptor, max_cp, common_ballot=None):
-        """bnum / bcoord None + common_ballot = (bnum, bcoord): every vote carries that ballot."""
+    def accept_reply_async(self, gidx, bnum, bcoord, slot, acceptor, max_cp, common_ballot=None, pin_outputs=False):
+        """bnum / bcoord None + common_ballot = (bnum, bcoord): every vote carries that ballot.
+        pin_outputs: the output arrays are registered (gpx_host_register) for the call - the engine then writes
+        the compacted outputs there itself, without a host round trip for the count."""
         gidx = _i32(gidx)
         n = gidx.shape[0]
         slot, acceptor, max_cp = (_i32(x, n) for x in (slot, acceptor, max_cp))
@@ -443,12 +452,17 @@ class Engine:
         dk = np.zeros(cap, np.uint8)
         status = np.zeros(n, np.uint8)
         no = np.zeros(1, np.int32)
+        outs = (dg, ds, db, dc, dm, dk, no, status)
+        if pin_outputs:
+            self.host_register(*outs)
         t = C.c_uint64(0)
         self.lib.check(self.lib.fn["accept_reply_batch_async"](
             self.h, n, _p(gidx), _p(bnum), _p(bcoord), int(cb[0]), int(cb[1]), _p(slot), _p(acceptor), _p(max_cp),
             _p(dg), _p(ds), _p(db), _p(dc), _p(dm), _p(dk), _p(no), _p(status), C.byref(t)), "accept_reply_batch_async")
 
         def finish():
+            if pin_outputs:
+                self.host_unregister(*outs)
             m = int(no[0])
             return Decisions(dg[:m], ds[:m], db[:m], dc[:m], dm[:m], dk[:m], status)
         return Engine.Pending(self, t.value, (gidx, bnum, bcoord, slot, acceptor, max_cp), finish)

@@ -127,6 +127,7 @@ struct gpx_engine {
     hipStream_t s_out = nullptr;
     hipEvent_t ev_in = nullptr, ev_k = nullptr, ev_cnt = nullptr;
     bool ready = false, busy = false;
+    bool direct = false; /* the compacted outputs were written to the caller's buffers by k_copy_out */
     uint64_t ticket = 0;
     int ncols = 0;              /* compacted int32 output columns still to fetch (count-dependent) */
     int32_t* host_col[6] = {};  /* ... their host destinations and device sources */
@@ -137,6 +138,9 @@ struct gpx_engine {
   } as[GPX_ASYNC_DEPTH];
   hipStream_t s_in = nullptr;
   uint64_t async_seq = 0;
+  bool async_in_engine = false, async_fill_memset = false; /* experiments: GPX_ASYNC_IN, GPX_ASYNC_FILL */
+  bool async_no_direct = false; /* GPX_ASYNC_DIRECT=0: compacted outputs fetched by gpx_engine_wait even from registered memory */
+  bool async_kernel_in = false; /* GPX_ASYNC_COPYIN=kernel (experiment): inputs read by k_copy_in from registered memory */
   /* wire codec (gpx_wire_host.inc): paxosID table, row free list, scratch - allocated on first use */
   DevNames N{};
   int64_t nm_tomb = 0;
@@ -1416,14 +1420,98 @@ int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
 /* (include/gpx.h: inputs on a copy-in stream, kernels on the engine's stream behind them, dense outputs and
  * the count on the set's copy-out stream; gpx_engine_wait fetches exactly `count` compacted entries) */
 
+/* Compacted outputs of an asynchronous call straight into the caller's (registered, device-mapped) host
+ * buffers: the count is known on the DEVICE when this runs, so exactly `count` entries cross the link without
+ * a host round trip for the count in between - the copy-out of call N is on its way while the host is still
+ * queueing call N + 1.  Plain coalesced 4-byte stores (posted PCIe writes). */
+struct CopyOut {
+  int ncols, nb;
+  const int32_t* src[6];
+  int32_t* dst[6];
+  const uint8_t* bsrc[2]; /* byte columns */
+  uint8_t* bdst[2];
+  int32_t* count_dst; /* the caller's n_out / n_runs, or null */
+  int32_t fixed_n;    /* entries to copy when there is no device count (dense per-record outputs) */
+};
+__global__ __launch_bounds__(256) void k_copy_out(const int32_t* __restrict__ count, CopyOut C) {
+  const int32_t m = count ? *count : C.fixed_n;
+  if (C.count_dst && blockIdx.x == 0 && threadIdx.x == 0) *C.count_dst = m;
+  for (int32_t i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < C.ncols) C.dst[k][i] = C.src[k][i];
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (k < C.nb) C.bdst[k][i] = C.bsrc[k][i];
+  }
+}
+
+/* ... and the other way (experiment, GPX_ASYNC_COPYIN=kernel): the input columns read straight out of the
+ * caller's registered host buffers by a kernel on the copy-in stream.  Measured on the MI355X box
+ * (scripts/bench_async_path.py, profiles/r03_async_variants.txt): slower than the runtime's DMA copies - 2.0 ms
+ * per step against 1.45 ms - so the default stays hipMemcpyAsync per column. */
+struct CopyIn {
+  int32_t n;
+  int ncols;
+  const int32_t* src[6];
+  int32_t* dst[6];
+  const uint8_t* bsrc; /* one byte column (flags), or null */
+  uint8_t* bdst;
+};
+__global__ __launch_bounds__(256) void k_copy_in(CopyIn C) {
+  const int64_t nv = C.n >> 2; /* whole 16-byte vectors; the device columns are 16-byte aligned */
+  for (int k = 0; k < 6; k++) {
+    if (k >= C.ncols) break;
+    const int32_t* __restrict__ s = C.src[k];
+    int32_t* __restrict__ d = C.dst[k];
+    if (!((uintptr_t)s & 15)) {
+      for (int64_t v = (int64_t)blockIdx.x * 256 + threadIdx.x; v < nv; v += (int64_t)gridDim.x * 256)
+        ((I4*)d)[v] = ((const I4*)s)[v];
+      for (int64_t i = (nv << 2) + (int64_t)blockIdx.x * 256 + threadIdx.x; i < C.n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+    } else {
+      for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < C.n; i += (int64_t)gridDim.x * 256) d[i] = s[i];
+    }
+  }
+  if (C.bsrc)
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < C.n; i += (int64_t)gridDim.x * 256) C.bdst[i] = C.bsrc[i];
+}
+
 namespace {
+
+/* the device address of a host buffer the caller registered (gpx_host_register), or null */
+void* mapped_host(void* p) {
+  if (!p) return nullptr;
+  hipPointerAttribute_t at;
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  if (at.type != hipMemoryTypeHost) return nullptr;
+  void* d = nullptr;
+  if (hipHostGetDevicePointer(&d, p, 0) != hipSuccess) {
+    (void)hipGetLastError();
+    return nullptr;
+  }
+  return d;
+}
 
 int async_begin(gpx_engine* e, int32_t n, gpx_engine::AsyncSet** out) {
   int rc = check_batch(e, n);
   if (rc != GPX_OK) return rc;
   gpx_engine::AsyncSet& a = e->as[e->async_seq % GPX_ASYNC_DEPTH];
   if (a.busy) return GPX_EBUSY;
-  if (!e->s_in) HIPCHK(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+  if (!e->s_in) {
+    /* GPX_ASYNC_IN=engine (experiment): inputs on the engine's own stream instead of a copy stream */
+    const char* v = getenv("GPX_ASYNC_IN");
+    e->async_in_engine = v && !strcmp(v, "engine");
+    const char* f = getenv("GPX_ASYNC_FILL");
+    e->async_fill_memset = f && !strcmp(f, "memset");
+    const char* dd = getenv("GPX_ASYNC_DIRECT");
+    e->async_no_direct = dd && !strcmp(dd, "0");
+    const char* ci = getenv("GPX_ASYNC_COPYIN");
+    e->async_kernel_in = ci && !strcmp(ci, "kernel");
+    HIPCHK(hipStreamCreateWithFlags(&e->s_in, hipStreamNonBlocking));
+  }
   if (!a.ready) {
     const size_t N = (size_t)e->cfg.max_batch;
     for (auto& p : a.i32)
@@ -1446,8 +1534,35 @@ int async_begin(gpx_engine* e, int32_t n, gpx_engine::AsyncSet** out) {
   *out = &a;
   return GPX_OK;
 }
+/* queues the input columns of a call: a DMA copy per column (from pageable memory the runtime stages it) */
+int async_inputs(gpx_engine* e, int32_t n, int ncols, const int32_t* const* hsrc, int32_t* const* ddst,
+                 const uint8_t* hb, uint8_t* db) {
+  hipStream_t st = e->async_in_engine ? e->sB : e->s_in;
+  CopyIn C{};
+  C.n = n;
+  C.ncols = ncols;
+  bool ok = e->async_kernel_in;
+  for (int k = 0; k < ncols && ok; k++) {
+    C.src[k] = (const int32_t*)mapped_host((void*)hsrc[k]);
+    C.dst[k] = ddst[k];
+    ok = C.src[k] != nullptr;
+  }
+  if (ok && hb) {
+    C.bsrc = (const uint8_t*)mapped_host((void*)hb);
+    C.bdst = db;
+    ok = C.bsrc != nullptr;
+  }
+  if (ok) {
+    hipLaunchKernelGGL(k_copy_in, dim3(1024), dim3(256), 0, st, C);
+    return GPX_OK;
+  }
+  for (int k = 0; k < ncols; k++) HIPCHK(hipMemcpyAsync(ddst[k], hsrc[k], (size_t)n * 4, hipMemcpyHostToDevice, st));
+  if (hb) HIPCHK(hipMemcpyAsync(db, hb, (size_t)n, hipMemcpyHostToDevice, st));
+  return GPX_OK;
+}
 /* inputs are on their way: the kernels (engine stream) wait for them */
 int async_inputs_done(gpx_engine* e, gpx_engine::AsyncSet& a) {
+  if (e->async_in_engine) return GPX_OK;
   HIPCHK(hipEventRecord(a.ev_in, e->s_in));
   HIPCHK(hipStreamWaitEvent(e->sB, a.ev_in, 0));
   return GPX_OK;
@@ -1458,15 +1573,64 @@ int async_kernels_done(gpx_engine* e, gpx_engine::AsyncSet& a) {
   HIPCHK(hipStreamWaitEvent(a.s_out, a.ev_k, 0));
   return GPX_OK;
 }
+/* dense per-record outputs (n entries each): one k_copy_out into registered memory, else a copy per column */
+int async_dense_out(gpx_engine* e, gpx_engine::AsyncSet& a, int32_t n, int ncols, int32_t* const* hdst,
+                    const int32_t* const* dsrc, int nb, uint8_t* const* hb, const uint8_t* const* db) {
+  CopyOut C{};
+  C.ncols = ncols;
+  C.nb = nb;
+  C.fixed_n = n;
+  bool ok = !e->async_no_direct;
+  for (int k = 0; k < ncols && ok; k++) {
+    C.src[k] = dsrc[k];
+    C.dst[k] = (int32_t*)mapped_host(hdst[k]);
+    ok = C.dst[k] != nullptr;
+  }
+  for (int k = 0; k < nb && ok; k++) {
+    C.bsrc[k] = db[k];
+    C.bdst[k] = (uint8_t*)mapped_host(hb[k]);
+    ok = C.bdst[k] != nullptr;
+  }
+  if (ok) {
+    hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(256), 0, a.s_out, (const int32_t*)nullptr, C);
+    return GPX_OK;
+  }
+  for (int k = 0; k < ncols; k++) HIPCHK(hipMemcpyAsync(hdst[k], dsrc[k], (size_t)n * 4, hipMemcpyDeviceToHost, a.s_out));
+  for (int k = 0; k < nb; k++) HIPCHK(hipMemcpyAsync(hb[k], db[k], (size_t)n, hipMemcpyDeviceToHost, a.s_out));
+  return GPX_OK;
+}
+
 int async_submit(gpx_engine* e, gpx_engine::AsyncSet& a, bool with_count, gpx_ticket* ticket) {
-  if (with_count) HIPCHK(hipMemcpyAsync(a.h_cnt, a.cnt, sizeof(int32_t), hipMemcpyDeviceToHost, a.s_out));
+  a.direct = false;
+  if (with_count && a.ncols > 0 && !e->async_no_direct) {
+    /* every compacted output column in registered memory: a kernel writes exactly `count` entries there */
+    CopyOut C{};
+    C.ncols = a.ncols;
+    bool ok = true;
+    for (int k = 0; k < a.ncols && ok; k++) {
+      C.src[k] = a.dev_col[k];
+      C.dst[k] = (int32_t*)mapped_host(a.host_col[k]);
+      ok = C.dst[k] != nullptr;
+    }
+    if (ok && a.host_kind) {
+      C.nb = 1;
+      C.bsrc[0] = a.dev_kind;
+      C.bdst[0] = (uint8_t*)mapped_host(a.host_kind);
+      ok = C.bdst[0] != nullptr;
+    }
+    C.count_dst = ok ? (int32_t*)mapped_host(a.host_count) : nullptr;
+    if (ok && C.count_dst) {
+      hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(256), 0, a.s_out, (const int32_t*)a.cnt, C);
+      a.direct = true;
+    }
+  }
+  if (with_count && !a.direct) HIPCHK(hipMemcpyAsync(a.h_cnt, a.cnt, sizeof(int32_t), hipMemcpyDeviceToHost, a.s_out));
   HIPCHK(hipEventRecord(a.ev_cnt, a.s_out));
   a.busy = true;
   a.ticket = ++e->async_seq; /* > 0; the next call takes the next set */
   *ticket = a.ticket;
   return GPX_OK;
 }
-#define A_IN(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->s_in))
 #define A_OUT(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, a.s_out))
 
 }  // namespace
@@ -1483,18 +1647,23 @@ int gpx_propose_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const
   gpx_engine::AsyncSet& a = *ap;
   if (n > 0) {
     const size_t b4 = (size_t)n * 4;
-    A_IN(a.i32[0], gidx, b4);
-    if (is_stop) A_IN(a.u8[0], is_stop, (size_t)n);
+    {
+      const int32_t* hs[1] = {gidx};
+      int32_t* dd[1] = {a.i32[0]};
+      if ((rc = async_inputs(h, n, 1, hs, dd, is_stop, a.u8[0])) != GPX_OK) return rc;
+    }
     if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
     rc = propose_dev_impl(h, n, a.i32[0], is_stop ? a.u8[0] : nullptr, nullptr, a.i32[1], a.i32[2], a.i32[3],
                           a.i32[4], a.u8[1]);
     if (rc != GPX_OK) return rc;
     if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
-    A_OUT(slot, a.i32[1], b4);
-    A_OUT(bnum, a.i32[2], b4);
-    A_OUT(bcoord, a.i32[3], b4);
-    A_OUT(median_cp, a.i32[4], b4);
-    A_OUT(status, a.u8[1], (size_t)n);
+    {
+      int32_t* hd[4] = {slot, bnum, bcoord, median_cp};
+      const int32_t* ds[4] = {a.i32[1], a.i32[2], a.i32[3], a.i32[4]};
+      uint8_t* hb[1] = {status};
+      const uint8_t* db[1] = {a.u8[1]};
+      if ((rc = async_dense_out(h, a, n, 4, hd, ds, 1, hb, db)) != GPX_OK) return rc;
+    }
   }
   return async_submit(h, a, false, ticket);
 }
@@ -1516,22 +1685,23 @@ int gpx_accept_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const 
   *n_runs = 0;
   if (n > 0) {
     const size_t b4 = (size_t)n * 4;
-    A_IN(a.i32[0], gidx, b4);
-    A_IN(a.i32[1], bnum, b4);
-    A_IN(a.i32[2], bcoord, b4);
-    A_IN(a.i32[3], slot, b4);
-    A_IN(a.i32[4], median_cp, b4);
-    if (a_flags) A_IN(a.u8[0], a_flags, (size_t)n);
+    {
+      const int32_t* hs[5] = {gidx, bnum, bcoord, slot, median_cp};
+      int32_t* dd[5] = {a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4]};
+      if ((rc = async_inputs(h, n, 5, hs, dd, a_flags, a.u8[0])) != GPX_OK) return rc;
+    }
     if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
     rc = gpx_accept_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a_flags ? a.u8[0] : nullptr,
                               a.i32[5], a.i32[6], a.i32[7], a.u8[1], a.u8[2], a.i32[8], a.i32[9], a.i32[10], a.cnt);
     if (rc != GPX_OK) return rc;
     if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
-    A_OUT(r_bnum, a.i32[5], b4);
-    A_OUT(r_bcoord, a.i32[6], b4);
-    A_OUT(r_maxcp, a.i32[7], b4);
-    A_OUT(r_flags, a.u8[1], (size_t)n);
-    A_OUT(status, a.u8[2], (size_t)n);
+    {
+      int32_t* hd[3] = {r_bnum, r_bcoord, r_maxcp};
+      const int32_t* ds[3] = {a.i32[5], a.i32[6], a.i32[7]};
+      uint8_t* hb[2] = {r_flags, status};
+      const uint8_t* db[2] = {a.u8[1], a.u8[2]};
+      if ((rc = async_dense_out(h, a, n, 3, hd, ds, 2, hb, db)) != GPX_OK) return rc;
+    }
     a.ncols = 3;
     a.host_col[0] = x_gidx, a.host_col[1] = x_first, a.host_col[2] = x_count;
     a.dev_col[0] = a.i32[8], a.dev_col[1] = a.i32[9], a.dev_col[2] = a.i32[10];
@@ -1557,23 +1727,33 @@ int gpx_accept_reply_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, 
   *n_out = 0;
   if (n > 0) {
     const size_t b4 = (size_t)n * 4;
-    A_IN(a.i32[0], gidx, b4);
     if (bnum) {
-      A_IN(a.i32[1], bnum, b4);
-      A_IN(a.i32[2], bcoord, b4);
+      const int32_t* hs[6] = {gidx, bnum, bcoord, slot, acceptor, max_cp};
+      int32_t* dd[6] = {a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a.i32[5]};
+      if ((rc = async_inputs(h, n, 6, hs, dd, nullptr, nullptr)) != GPX_OK) return rc;
     } else { /* one ballot for the whole batch: the two columns are made on the device */
-      hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(n)), dim3(GPX_BLOCK), 0, h->s_in, n, common_bnum, a.i32[1]);
-      hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(n)), dim3(GPX_BLOCK), 0, h->s_in, n, common_bcoord, a.i32[2]);
+      const int32_t* hs[4] = {gidx, slot, acceptor, max_cp};
+      int32_t* dd[4] = {a.i32[0], a.i32[3], a.i32[4], a.i32[5]};
+      if ((rc = async_inputs(h, n, 4, hs, dd, nullptr, nullptr)) != GPX_OK) return rc;
+      hipStream_t fs = h->async_in_engine ? h->sB : h->s_in;
+      if (h->async_fill_memset) {
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.i32[1], common_bnum, (size_t)n, fs));
+        HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.i32[2], common_bcoord, (size_t)n, fs));
+      } else {
+        hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(n)), dim3(GPX_BLOCK), 0, fs, n, common_bnum, a.i32[1]);
+        hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(n)), dim3(GPX_BLOCK), 0, fs, n, common_bcoord, a.i32[2]);
+      }
     }
-    A_IN(a.i32[3], slot, b4);
-    A_IN(a.i32[4], acceptor, b4);
-    A_IN(a.i32[5], max_cp, b4);
     if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
     rc = gpx_accept_reply_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a.i32[5], a.i32[6],
                                     a.i32[7], a.i32[8], a.i32[9], a.i32[10], a.u8[0], a.cnt, a.u8[1]);
     if (rc != GPX_OK) return rc;
     if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
-    if (status) A_OUT(status, a.u8[1], (size_t)n);
+    if (status) {
+      uint8_t* hb[1] = {status};
+      const uint8_t* db[1] = {a.u8[1]};
+      if ((rc = async_dense_out(h, a, n, 0, nullptr, nullptr, 1, hb, db)) != GPX_OK) return rc;
+    }
     a.ncols = 5;
     int32_t* hc[5] = {d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp};
     for (int k = 0; k < 5; k++) {
@@ -1601,18 +1781,21 @@ int gpx_commit_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const 
   *n_runs = 0;
   if (n > 0) {
     const size_t b4 = (size_t)n * 4;
-    A_IN(a.i32[0], gidx, b4);
-    A_IN(a.i32[1], bnum, b4);
-    A_IN(a.i32[2], bcoord, b4);
-    A_IN(a.i32[3], slot, b4);
-    A_IN(a.i32[4], median_cp, b4);
-    if (c_kind) A_IN(a.u8[0], c_kind, (size_t)n);
+    {
+      const int32_t* hs[5] = {gidx, bnum, bcoord, slot, median_cp};
+      int32_t* dd[5] = {a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4]};
+      if ((rc = async_inputs(h, n, 5, hs, dd, c_kind, a.u8[0])) != GPX_OK) return rc;
+    }
     if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
     rc = gpx_commit_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], c_kind ? a.u8[0] : nullptr,
                               a.u8[1], a.i32[5], a.i32[6], a.i32[7], a.cnt);
     if (rc != GPX_OK) return rc;
     if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
-    A_OUT(status, a.u8[1], (size_t)n);
+    {
+      uint8_t* hb[1] = {status};
+      const uint8_t* db[1] = {a.u8[1]};
+      if ((rc = async_dense_out(h, a, n, 0, nullptr, nullptr, 1, hb, db)) != GPX_OK) return rc;
+    }
     a.ncols = 3;
     a.host_col[0] = x_gidx, a.host_col[1] = x_first, a.host_col[2] = x_count;
     a.dev_col[0] = a.i32[5], a.dev_col[1] = a.i32[6], a.dev_col[2] = a.i32[7];
@@ -1625,7 +1808,7 @@ int gpx_engine_wait(gpx_engine* h, gpx_ticket ticket) {
   for (auto& a : h->as) {
     if (!a.busy || a.ticket != ticket) continue;
     HIPCHK(hipEventSynchronize(a.ev_cnt)); /* dense outputs and the count are on the host */
-    if (a.host_count) {
+    if (a.host_count && !a.direct) {
       const int32_t m = a.ncols ? a.h_cnt[0] : 0;
       *a.host_count = m;
       if (m > 0) { /* exactly m compacted entries, not the capacity */
@@ -1641,7 +1824,6 @@ int gpx_engine_wait(gpx_engine* h, gpx_ticket ticket) {
 }
 
 } /* extern "C" */
-#undef A_IN
 #undef A_OUT
 
 extern "C" {

@@ -61,8 +61,11 @@ def test_async_rounds_match_oracle(hip_lib, oracle_lib, G, k):
     eo.close()
 
 
-def test_async_pipeline_of_vote_batches(hip_lib, oracle_lib):
-    """The bench's shape: a stream of (propose, votes) steps kept two steps deep from pinned buffers."""
+@pytest.mark.parametrize("pin_outputs", [False, True])
+def test_async_pipeline_of_vote_batches(hip_lib, oracle_lib, pin_outputs):
+    """The bench's shape: a stream of (propose, votes) steps kept two steps deep from pinned buffers; with the
+    outputs pinned too the engine writes the decisions into them itself (k_copy_out: exactly n_out entries, no
+    host round trip for the count)."""
     G, k, R = 200_000, 3, 6
     members = [100, 101, 102]
     eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=G * k + 4096)
@@ -76,7 +79,8 @@ def test_async_pipeline_of_vote_batches(hip_lib, oracle_lib):
     pend = []
     got = []
     for r in range(R):
-        pend.append((eh.propose_async(g), eh.accept_reply_async(*rounds[r])))
+        pend.append((eh.propose_async(g, pin_outputs=pin_outputs),
+                     eh.accept_reply_async(*rounds[r], pin_outputs=pin_outputs)))
         if len(pend) == 2:
             tp, tv = pend.pop(0)
             tp.wait()
