@@ -100,14 +100,18 @@ def main():
     ap.add_argument("--groups", type=int, default=1_000_000)
     ap.add_argument("--k", type=int, default=3)
     ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--repeats", type=int, default=2)
+    ap.add_argument("--common-first", action="store_true")
     a = ap.parse_args()
     pinned = None if a.no_pin else pin_to_gpu_numa_node(0)
     out = {"env": {k: os.environ.get(k) for k in ("GPX_ASYNC_IN", "GPX_ASYNC_FILL", "GPX_ASYNC_DIRECT", "GPX_ASYNC_COPYIN")},
            "pinned_to_gpu_numa_node": pinned is not None}
     out["sync"] = run(1, False, a.groups, a.k, a.steps, sync=True)
-    for depth in (1, 2):
-        for common in (False, True):
-            out["async depth %d%s" % (depth, " common ballot" if common else "")] = run(depth, common, a.groups, a.k, a.steps)
+    for rep in range(a.repeats):  # repeats: the first configuration to touch a fresh set of device columns pays for it
+        for depth in (1, 2):
+            for common in ((True, False) if a.common_first else (False, True)):
+                out["async depth %d%s #%d" % (depth, " common ballot" if common else "", rep)] = \
+                    run(depth, common, a.groups, a.k, a.steps)
     print(json.dumps(out))
 
 
