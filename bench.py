@@ -405,63 +405,76 @@ def main():
         single = {"decisions_per_sec": round(ndec / tcpu, 1),
                   "votes_per_sec": round(cols_cpu[0][0].shape[0] * cpu_rounds / tcpu, 1), "seconds": round(tcpu, 2)}
         # the same oracle on T host threads, thread t owning the groups with gidx % T == t (groups are
-        # independent: what PaxosManager's demultiplexer thread pool exploits, PACKET_DEMULTIPLEXER_THREADS)
+        # independent: what PaxosManager's demultiplexer thread pool exploits, PACKET_DEMULTIPLEXER_THREADS).
+        # The baseline is the BEST the host does: T swept over {32, 64, 128, all cores} (std::map nodes of very
+        # many threads fight over the memory system: fewer threads can be faster), every figure in the line.
         import threading
 
-        T = max(1, (os.cpu_count() or 1) if args.cpu_threads <= 0 else min(args.cpu_threads, os.cpu_count() or 1))
+        ncpu = os.cpu_count() or 1
         lib_o = load_oracle()
-        # one stable partition of every sample round by owner thread (gidx % T)
-        parts = []
-        for cols in cols_cpu:
-            key = cols[0] % T
-            order = np.argsort(key, kind="stable")
-            bounds = np.searchsorted(key[order], np.arange(T + 1))
-            parts.append((order, bounds))
-        shards = []
-        for t in range(T):
-            gs = np.arange(t, G, T, dtype=np.int32)
-            es = Engine(lib_o, 100, max(1, gs.shape[0]), kmax=K, window=8)
-            if gs.shape[0]:
-                assert (es.create_groups(np.arange(gs.shape[0], dtype=np.int32), mem[gs], K,
-                                         hri_create(gs.shape[0], K, 100)) == S_OK).all()
-            rounds_t = []
-            for cols, (order, bounds) in zip(cols_cpu, parts):
-                sel = order[bounds[t]:bounds[t + 1]]
-                rounds_t.append([np.ascontiguousarray(cols[0][sel] // T)] +
-                                [np.ascontiguousarray(c[sel]) for c in cols[1:]])
-            shards.append((es, np.arange(gs.shape[0], dtype=np.int32), rounds_t))
-        counts_t = [0] * T
 
-        passes = max(1, args.cpu_mt_passes)  # the sample's rounds again with slot / max_cp moved on
+        def mt_leg(T, passes):
+            parts = []  # one stable partition of every sample round by owner thread (gidx % T)
+            for cols in cols_cpu:
+                key = cols[0] % T
+                order = np.argsort(key, kind="stable")
+                bounds = np.searchsorted(key[order], np.arange(T + 1))
+                parts.append((order, bounds))
+            shards = []
+            for t in range(T):
+                gs = np.arange(t, G, T, dtype=np.int32)
+                es = Engine(lib_o, 100, max(1, gs.shape[0]), kmax=K, window=8)
+                if gs.shape[0]:
+                    assert (es.create_groups(np.arange(gs.shape[0], dtype=np.int32), mem[gs], K,
+                                             hri_create(gs.shape[0], K, 100)) == S_OK).all()
+                rounds_t = []
+                for cols, (order, bounds) in zip(cols_cpu, parts):
+                    sel = order[bounds[t]:bounds[t + 1]]
+                    rounds_t.append([np.ascontiguousarray(cols[0][sel] // T)] +
+                                    [np.ascontiguousarray(c[sel]) for c in cols[1:]])
+                shards.append((es, np.arange(gs.shape[0], dtype=np.int32), rounds_t))
+            counts_t = [0] * T
 
-        def work(t):
-            es, gl, rounds_t = shards[t]
-            for _ in range(passes):
-                for cols in rounds_t:
-                    es.propose(gl)
-                    counts_t[t] += es.accept_reply(*cols).gidx.shape[0]
-                for cols in rounds_t:
-                    cols[3] += cpu_rounds
-                    cols[5] += cpu_rounds
+            def work(t):
+                es, gl, rounds_t = shards[t]
+                for _ in range(passes):  # the sample's rounds again with slot / max_cp moved on
+                    for cols in rounds_t:
+                        es.propose(gl)
+                        counts_t[t] += es.accept_reply(*cols).gidx.shape[0]
+                    for cols in rounds_t:
+                        cols[3] += cpu_rounds
+                        cols[5] += cpu_rounds
 
-        threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
-        tm = time.perf_counter()
-        for th in threads:
-            th.start()
-        for th in threads:
-            th.join()
-        tmt = time.perf_counter() - tm
-        for es, _, _ in shards:
-            es.close()
-        assert args.mix or sum(counts_t) == ndec * passes
+            threads = [threading.Thread(target=work, args=(t,)) for t in range(T)]
+            tm = time.perf_counter()
+            for th in threads:
+                th.start()
+            for th in threads:
+                th.join()
+            tmt = time.perf_counter() - tm
+            for es, _, _ in shards:
+                es.close()
+            assert args.mix or sum(counts_t) == ndec * passes
+            return sum(counts_t) / tmt, tmt
+
+        if args.cpu_threads > 0:
+            sweep_T = [max(1, min(args.cpu_threads, ncpu))]
+        else:
+            sweep_T = sorted({t for t in (32, 64, 128, ncpu) if t <= ncpu} or {ncpu})
+        passes = max(1, args.cpu_mt_passes // max(1, len(sweep_T) // 2))
+        sweep = {}
+        for T in sweep_T:
+            sweep[T] = mt_leg(T, passes)
+        best_T = max(sweep, key=lambda t: sweep[t][0])
         cpu_baseline = {
-            "value": round(sum(counts_t) / tmt, 1), "unit": "decisions/s", "cores": T, "kind": "port",
-            "votes_per_sec": round(cols_cpu[0][0].shape[0] * cpu_rounds * passes / tmt, 1),
-            "host_cores_available": os.cpu_count(),
-            "sample": f"{cpu_rounds * passes} rounds of the same workload ({G} groups, {cols_cpu[0][0].shape[0]} votes/round), "
-                      f"C++ oracle (std::map restatement of the Java; not the JVM) on {T} threads, groups "
-                      f"partitioned gidx % {T}",
-            "seconds": round(tmt, 2),
+            "value": round(sweep[best_T][0], 1), "unit": "decisions/s", "cores": best_T, "kind": "port",
+            "votes_per_sec": round(sweep[best_T][0] * cols_cpu[0][0].shape[0] / max(ndec / cpu_rounds, 1), 1),
+            "host_cores_available": ncpu,
+            "threads_sweep_decisions_per_sec": {str(t): round(v[0], 1) for t, v in sorted(sweep.items())},
+            "sample": f"{cpu_rounds * passes} rounds of the same workload ({G} groups, {cols_cpu[0][0].shape[0]} votes/round) "
+                      f"per thread count, C++ oracle (std::map restatement of the Java; not the JVM), groups partitioned "
+                      f"gidx % T; value = the best of T in {sorted(sweep)}",
+            "seconds": round(sum(v[1] for v in sweep.values()), 2),
             "single_thread": single,
         }
         eo.close()

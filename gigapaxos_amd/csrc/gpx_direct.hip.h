@@ -39,6 +39,14 @@ struct DirectStage {
   int32_t *st_first, *st_count; /* [n] run parked at the record that produced it */
   uint32_t* tag;                /* [n] == the call's epoch: record i holds a parked run */
   int32_t* chunk_cnt;           /* [ceil(n / 1024)] runs per chunk; zeroed before the call */
+  /* COMMIT batches park their runs in the CALLER'S columns (n entries each: gpx.h) at the record's own index:
+   * when every record executed something - the steady state: one commit, one slot executed - the columns are
+   * final as they stand, run i belongs to record i, and nothing is left to compact (k_emit_runs_direct<true>
+   * sees that the chunk counts add up to n).  Otherwise the parked runs go through st_gidx / st_first /
+   * st_count (dense staging) and k_copy_runs brings them back. */
+  int32_t *x_gidx, *x_first, *x_count;
+  int32_t* st_gidx;
+  int32_t* st_total; /* [1] runs staged by k_emit_runs_direct<true> */
 };
 
 /* the run of records of one group in a gidx-ordered batch, with GroupIter's interface */
@@ -54,6 +62,7 @@ struct RunIter {
                              * would race with the head's verdict, across waves and across workgroups) */
   /* the head's own record, fetched by the kernel ahead of the group state; g_next = gidx[head + 1]
    * (or ~g at the end of the batch): a run of one record never touches memory here */
+  bool inplace = false; /* park runs in the caller's columns (k_ac_direct<COMMIT>) */
   bool have_first = false;
   int32_t f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
   int32_t head = -2, g_next = 0;
@@ -85,8 +94,14 @@ struct RunIter {
     return true;
   }
   __device__ __forceinline__ void emit(int32_t, int32_t first_slot, int32_t count, int32_t, int32_t) {
-    D.st_first[cur] = first_slot;
-    D.st_count[cur] = count; /* > 0 */
+    if (inplace) {
+      D.x_gidx[cur] = g;
+      D.x_first[cur] = first_slot;
+      D.x_count[cur] = count;
+    } else {
+      D.st_first[cur] = first_slot;
+      D.st_count[cur] = count; /* > 0 */
+    }
     D.tag[cur] = epoch;
     if (!count_chunks) return;
     if ((cur >> GPX_DCHUNK_SHIFT) == chunk)
@@ -145,6 +160,7 @@ __global__ __launch_bounds__(GPX_DBLOCK) void k_ac_direct(
       it.cur = i;
       it.chunk = i >> GPX_DCHUNK_SHIFT;
       it.local = 0;
+      it.inplace = COMMIT;
       it.have_first = true;
       it.f_a = f_a;
       it.f_b = f_b;
@@ -174,7 +190,9 @@ __global__ __launch_bounds__(GPX_DBLOCK) void k_ac_direct(
   }
 }
 
-/* parked runs -> the caller's dense columns, chunk by chunk in record order */
+/* parked runs -> the caller's dense columns, chunk by chunk in record order.  INPLACE (commit batches): the
+ * runs are parked in those very columns - all n records hold one: done; else -> dense staging. */
+template <bool INPLACE>
 __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, int32_t n,
                                                                 const int32_t* __restrict__ gidx, DirectStage D,
                                                                 int32_t* __restrict__ x_gidx,
@@ -186,6 +204,16 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, i
     return;
   }
   const int32_t w = (int32_t)blockIdx.x;
+  if (INPLACE) {
+    int32_t all = 0;
+    for (int32_t t = threadIdx.x; t < (int32_t)gridDim.x; t += GPX_DCHUNK) all += D.chunk_cnt[t];
+    int32_t total;
+    block_exscan_n<GPX_DCHUNK>(all, &total);
+    if (total == n) { /* one run per record, each at its record's index: the columns are final */
+      if (w == 0 && threadIdx.x == 0 && total_out) *total_out = n;
+      return;
+    }
+  }
   /* no run parked in this chunk (every chunk of an ACCEPT batch that released no commit): nothing to place */
   if (D.chunk_cnt[w] == 0 && w != (int32_t)gridDim.x - 1) return;
   int32_t before = 0;
@@ -193,15 +221,42 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, i
   int32_t pre;
   block_exscan_n<GPX_DCHUNK>(before, &pre);
   const int32_t i = w * GPX_DCHUNK + (int32_t)threadIdx.x;
-  const int32_t cnt = (i < n && D.tag[i] == X.epoch) ? D.st_count[i] : 0;
+  const bool have = i < n && D.tag[i] == X.epoch;
   int32_t tot;
-  const int32_t ex = block_exscan_n<GPX_DCHUNK>(cnt != 0 ? 1 : 0, &tot);
-  if (cnt != 0) {
-    x_gidx[pre + ex] = gidx[i];
-    x_first[pre + ex] = D.st_first[i];
-    x_count[pre + ex] = cnt;
+  const int32_t ex = block_exscan_n<GPX_DCHUNK>(have ? 1 : 0, &tot);
+  if (have) {
+    if (INPLACE) { /* source and destination are the same columns: through the staging block */
+      D.st_gidx[pre + ex] = x_gidx[i];
+      D.st_first[pre + ex] = x_first[i];
+      D.st_count[pre + ex] = x_count[i];
+    } else {
+      x_gidx[pre + ex] = gidx[i];
+      x_first[pre + ex] = D.st_first[i];
+      x_count[pre + ex] = D.st_count[i];
+    }
   }
-  if (w == (int32_t)gridDim.x - 1 && threadIdx.x == 0 && total_out) *total_out = pre + tot;
+  if (w == (int32_t)gridDim.x - 1 && threadIdx.x == 0) {
+    if (total_out) *total_out = pre + tot;
+    if (INPLACE) *D.st_total = pre + tot;
+  }
+}
+
+/* commit batches that were not one-run-per-record: the staged runs back into the caller's columns */
+__global__ __launch_bounds__(GPX_BLOCK) void k_copy_runs(DevScratch X, int32_t n, int32_t nchunks, DirectStage D,
+                                                        int32_t* __restrict__ x_gidx, int32_t* __restrict__ x_first,
+                                                        int32_t* __restrict__ x_count) {
+  if (*X.unsorted == X.epoch) return;
+  int32_t all = 0;
+  for (int32_t t = threadIdx.x; t < nchunks; t += GPX_BLOCK) all += D.chunk_cnt[t];
+  int32_t total;
+  block_exscan(all, &total);
+  if (total == n) return; /* k_emit_runs_direct<true> found the columns final */
+  const int32_t m = *D.st_total;
+  for (int32_t t = blockIdx.x * GPX_BLOCK + threadIdx.x; t < m; t += gridDim.x * GPX_BLOCK) {
+    x_gidx[t] = D.st_gidx[t];
+    x_first[t] = D.st_first[t];
+    x_count[t] = D.st_count[t];
+  }
 }
 
 /* ------------------------------------------------------------------------------------------------ */

@@ -590,7 +590,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     A(f.bucket_off, nbk_alloc + 1, true);
     A(f.rec, N, false);
     A(f.unsorted, 1, true);
-    A(f.chunk_cnt, N / GPX_DCHUNK + 2, true);
+    A(f.chunk_cnt, N / GPX_DCHUNK + 4, true); /* + st_total of the commit path behind the counts */
   }
   X.bucket_tot = e->fs[0].bucket_tot;
   X.tile_rel = e->fs[0].tile_rel;
@@ -920,7 +920,8 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
    * partitioned first.  Device-side choice: both back ends are launched, one of them returns at once. */
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec; /* the two paths never both stage outputs: shared scratch */
-  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt};
+  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt, x_gidx, x_first, x_count,
+                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + nchunks + 1};
   /* at most 65,536 records on one stream: order check, direct application and run compaction in ONE
    * launch (k_ac_small: tickets instead of chunk counters) */
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
@@ -971,7 +972,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     }
     {
       LaunchScope _ls(e, "k_emit_runs_direct");
-      hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
+      hipLaunchKernelGGL(k_emit_runs_direct<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
                          x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
     }
   }
@@ -1008,7 +1009,8 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   /* decisions leave the accept-reply call grouped by gidx: such a commit batch is applied directly */
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec;
-  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt};
+  const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt, x_gidx, x_first, x_count,
+                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + nchunks + 1};
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N; /* one launch: k_ac_small */
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
   if (!fused)
@@ -1055,9 +1057,10 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     }
     {
       LaunchScope _ls(e, "k_emit_runs_direct");
-      hipLaunchKernelGGL(k_emit_runs_direct, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
+      hipLaunchKernelGGL(k_emit_runs_direct<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
                          x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
     }
+    LAUNCH(e, "k_copy_runs", k_copy_runs, 256, e->X, n, nchunks, D, x_gidx, x_first, x_count);
   }
   if (!promised && e->ac16) {
     LAUNCH_B(e, "k_bucket_commit16", (k_bucket16<B16_COMMIT, 4>), e->S, e->X, O16, VoteCols{bnum, bcoord, nullptr},
