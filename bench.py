@@ -249,7 +249,7 @@ def main():
             "traffic_raw_counters": traffic_raw,
             "traffic_source": None if traffic is None else
             "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
-            "(scripts/gpu_round.sh), not counted in this run",
+            "(scripts/gpu_visit.sh TAG traffic), not counted in this run",
             "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg),
             "pipeline_ms_per_step": round(pipe_ms, 4),
             "pipeline_achieved": round(pipe_achieved, 1),
@@ -317,7 +317,7 @@ def main():
 
         def wait(t):
             assert fn_w(ee.h, t[0]) == 0 and fn_w(ee.h, t[1]) == 0
-        n_async = 6
+        n_async = 10
         # slot / max_cp of the host rounds are only right for the first e2e_rounds rounds of an engine: a fresh one
         ee.close()
         ee = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)

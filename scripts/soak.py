@@ -46,14 +46,13 @@ def main():
         nodes = NODES if kmax <= 8 else list(range(100, 120))
         base = int(rng.choice([1, (1 << 31) - 20]))
         batch = int(rng.choice([50, 400, 3000]))
-        # round 2: batches grouped by group half of the time (direct / single-launch kernels), the ordered-
-        # batches promise on some of those, the single-launch accept-reply path on a third of the seeds
+        # batches grouped by group half of the time (direct / single-launch kernels), the ordered-batches
+        # promise on some of those, the sorted-runs hint for accept replies on a third of the seeds
         ordered = bool(rng.random() < 0.5)
         promise = int(rng.choice([0, 0, 2, 4, 6])) if ordered else 0
-        os.environ["GPX_SMALL"] = "1" if seed % 3 == 0 else "0"
-        os.environ["GPX_AR_LEGACY"] = "1" if seed % 7 == 0 else "0"
+        os.environ["GPX_TRY_RUNS"] = "1" if seed % 3 == 0 else "0"
         print("seed", seed, "kmax", kmax, "W", W, "G", G, "base", base, "batch", batch, "ordered", ordered,
-              "promise", promise, "small", os.environ["GPX_SMALL"], flush=True)
+              "promise", promise, "try_runs", os.environ["GPX_TRY_RUNS"], flush=True)
         eh, eo = make_pair(hip, orc, 100, G, kmax, W)
         create_mixed_groups(eh, eo, G, kmax, nodes, rng, slot_base=base)
         if promise:
@@ -76,7 +75,7 @@ def main():
         assert a == b, ("election fuzz", seed)
         done["election"] += 1
         if seed % 2 == 1:  # the coordinator's steady state (k_bucket_ar16's straight-line replay) with fresh seeds
-            os.environ["GPX_SMALL"] = "0"
+            os.environ["GPX_TRY_RUNS"] = "0"
             steady_state_run(hip, orc, int(rng.choice([3, 4, 5, 8])), seed, NODES, G=int(rng.choice([700, 6000])))
             done["steady"] = done.get("steady", 0) + 1
         if seed % 2 == 0:  # wire frames, damaged ones included: decode as one launch or as three

@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench every library build under scratch/variants/ (tuning aid; see scripts/gpu_round.sh for the judged run)
+# bench every library build under scratch/variants/ (tuning aid; see scripts/gpu_visit.sh for the judged run)
 #   sweep_variants.sh [bench.py flags]      env: SWEEP_ENV="A=1 B=2" extra environment per run
 for f in scratch/variants/*.so; do
   echo "== $f $* $SWEEP_ENV"

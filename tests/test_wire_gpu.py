@@ -15,12 +15,9 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True, params=["one-launch decode", "three-launch decode"])
 def _decode_path(request, monkeypatch):
     """gpx_wire_decode runs as ONE launch (k_wire_decode1: look-back over the tiles) or, with
-    GPX_WIRE_LEGACY=1 (read when the engine first touches the wire path), as scan / offsets / unpack;
-    gpx_wire_pack_commits runs as scan / offsets / write or, with GPX_PACK_FUSED=1, as ONE launch
-    (k_pack_commits1; slower, kept as the measured alternative) - every case of this file runs both
-    ways."""
+    GPX_WIRE_LEGACY=1 (read when the engine first touches the wire path), as scan / offsets / unpack -
+    every case of this file runs both ways."""
     monkeypatch.setenv("GPX_WIRE_LEGACY", "1" if request.param.startswith("three") else "0")
-    monkeypatch.setenv("GPX_PACK_FUSED", "0" if request.param.startswith("three") else "1")
 
 
 @pytest.mark.parametrize("name", [n for n in dir(scen) if n.startswith("test_") and "oracle_lib" in
