@@ -153,6 +153,7 @@ struct gpx_engine {
   uint32_t* w_ticket = nullptr;
   uint32_t w_epoch = 0;
   bool wire_legacy = false;
+  int wire_tile = 512; /* frames per workgroup of k_wire_decode1 (GPX_WD_TILE = 256 / 512) */
   uint8_t* w_stage = nullptr;      /* staging of BATCHED_ACCEPT_REPLY frames, 188 B per reply */
   long long* w_bucket_bytes = nullptr;
   int32_t* w_ones = nullptr;       /* a column of ones (gpx_request_batch without weights) */
@@ -1857,7 +1858,7 @@ int gpx_group_create(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
     H2D_B(d_k, k + o, (size_t)c);
     H2D_B(d_r, rows + o, (size_t)c * sizeof(gpx_hri));
     LAUNCH(h, "k_group_create", k_group_create, grid_for(c), h->S, c, (const int32_t*)d_g,
-           (const int32_t*)d_m, (const uint8_t*)d_k, (const gpx_hri*)d_r, d_s, h->N.rows);
+           (const int32_t*)d_m, (const uint8_t*)d_k, (const gpx_hri*)d_r, d_s, NameCopies{h->N.rows, (uint8_t*)h->N.tab});
     if (status) D2H(status + o, d_s, (size_t)c);
     HIPCHK(hipStreamSynchronize(h->sB));
   }
@@ -1886,7 +1887,7 @@ static int retire_impl(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mo
     const int32_t c = std::min(chunk, n - o);
     H2D_B(d_g, gidx + o, (size_t)c * 4);
     LAUNCH(h, "k_group_retire", k_group_retire, grid_for(c), h->S, c, (const int32_t*)d_g, mode, d_r,
-           d_s, h->N.rows);
+           d_s, NameCopies{h->N.rows, (uint8_t*)h->N.tab});
     if (rows) D2H(rows + o, d_r, (size_t)c * sizeof(gpx_hri));
     if (status) D2H(status + o, d_s, (size_t)c);
     HIPCHK(hipStreamSynchronize(h->sB));

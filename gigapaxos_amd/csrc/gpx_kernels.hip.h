@@ -2158,10 +2158,31 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_gap_scan(DevState S, int32_t n,
 
 /* ------------------------------------------------------------------------- */
 /* lifecycle                                                                    */
-/* name rows of the wire codec (gpx_wire.hip.h: NM_STRIDE / NM_EXISTS / NM_VERSION, checked there) */
+/* name rows and table entries of the wire codec (gpx_wire.hip.h: NM_* / NameEnt, checked there): a named
+ * group's (exists, version) live in its row AND in the table entry the frames' lookups read */
 #define GPX_NAME_ROW_STRIDE 160
 #define GPX_NAME_ROW_EXISTS 5
 #define GPX_NAME_ROW_VERSION 8
+#define GPX_NAME_ROW_SLOT 144
+#define GPX_NAME_ENT_BYTES 32
+struct NameCopies {
+  uint8_t* rows; /* null: no wire codec in use */
+  uint8_t* tab;
+  __device__ __forceinline__ void set(int32_t g, bool exists, bool set_version, int32_t version) const {
+    if (!rows) return;
+    uint8_t* nr = rows + (int64_t)g * GPX_NAME_ROW_STRIDE;
+    if (set_version) *(int32_t*)(nr + GPX_NAME_ROW_VERSION) = version;
+    nr[GPX_NAME_ROW_EXISTS] = exists ? 1 : 0;
+    if (nr[4] != 0) { /* the name is bound: its table entry carries the copies too */
+      const int32_t s = *(const int32_t*)(nr + GPX_NAME_ROW_SLOT);
+      if (s >= 0) {
+        uint8_t* e = tab + (int64_t)s * GPX_NAME_ENT_BYTES;
+        if (set_version) *(int32_t*)(e + 12) = version;
+        e[9] = exists ? 1 : 0; /* meta = length | exists << 8 */
+      }
+    }
+  }
+};
 
 /* PaxosInstanceStateMachine.hotRestore (PISM:677-690), PaxosAcceptor.hotRestore
  * (PaxosAcceptor.java:128-134), PaxosCoordinator.hotRestore (PaxosCoordinator.java:122-131) */
@@ -2171,7 +2192,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_group_create(DevState S, int32_t 
                                                            const uint8_t* __restrict__ kk,
                                                            const gpx_hri* __restrict__ rows,
                                                            uint8_t* __restrict__ status,
-                                                           uint8_t* __restrict__ name_rows) {
+                                                           NameCopies names) {
   int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (i >= n) return;
   const int32_t g = gidx[i];
@@ -2205,11 +2226,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_group_create(DevState S, int32_t 
     S.acc_ring[o] = mk4(0, 0, 0, 0);
   }
   S.g_flags[g] = GF_EXISTS | (coord ? GF_HASCOORD : 0u) | ((uint32_t)k << 8);
-  if (name_rows) { /* the wire codec's copy of (exists, version) in the group's name row (gpx_wire.hip.h) */
-    uint8_t* nr = name_rows + (int64_t)g * GPX_NAME_ROW_STRIDE;
-    *(int32_t*)(nr + GPX_NAME_ROW_VERSION) = r.version;
-    nr[GPX_NAME_ROW_EXISTS] = 1;
-  }
+  names.set(g, true, true, r.version); /* the wire codec's copies of (exists, version) (gpx_wire.hip.h) */
   status[i] = GPX_S_OK;
 }
 
@@ -2240,7 +2257,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_group_retire(DevState S, int32_t 
                                                            const int32_t* __restrict__ gidx,
                                                            int32_t mode, gpx_hri* __restrict__ rows,
                                                            uint8_t* __restrict__ status,
-                                                           uint8_t* __restrict__ name_rows) {
+                                                           NameCopies names) {
   int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (i >= n) return;
   const int32_t g = gidx[i];
@@ -2270,7 +2287,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_group_retire(DevState S, int32_t 
   if (rows) fill_hri_dev(S, g, gf, &rows[i]);
   if (mode != 2) {
     S.g_flags[g] = 0;
-    if (name_rows) name_rows[(int64_t)g * GPX_NAME_ROW_STRIDE + GPX_NAME_ROW_EXISTS] = 0;
+    names.set(g, false, false, 0);
   }
   if (status) status[i] = GPX_S_OK;
 }

@@ -10,46 +10,64 @@
 #include "gpx_kernels.hip.h"
 #include "../../include/gpx_wire.h"
 
-/* One row per group (160 bytes, so the first 32 never straddle a 64-byte line):
+/* One row per group (160 bytes):
  *   int32 String.hashCode | uint8 length (0 = no name) | uint8 group exists | 2 pad | int32 version |
- *   name bytes.
+ *   name bytes (up to 127) | ... | int32 table slot of the name at byte 144 (-1: none).
  * "exists" and "version" are COPIES of the engine's g_flags & GF_EXISTS / g_version, kept by the only
- * kernels that change them (k_group_create, k_group_retire) and by k_names_bind: the header, the
- * instance test of PaxosManager.handlePaxosPacket (getInstance + version, PaxosManager.java:1153-
- * 1162) and the first 20 name bytes are ONE 32-byte access - a frame's lookup costs the table probe
- * plus that (round 2 counters: the separate g_flags / g_version reads were two more random HBM lines
- * per frame, 3.7 lines per frame in all, and the random-access rate is what bounds the decode).
- * A table slot holds row + 1 in its low 25 bits and 6 bits of the name's hash above them, so a probe
- * that lands on another name's slot almost never reads that name's row. */
+ * kernels that change them (k_group_create, k_group_retire) and by k_names_bind.
+ * The TABLE is open addressing over 32-byte entries (NameEnt) that carry everything a frame's lookup
+ * needs: row + 1, the name's hashCode, its length, the group's exists / version copies and the first 16
+ * name bytes - the instance test of PaxosManager.handlePaxosPacket (getInstance + version,
+ * PaxosManager.java:1153-1162) is ONE aligned 32-byte access for a name of up to 16 bytes (longer names
+ * compare their tail in the row).  Why it matters: the decode is bound by the number of HBM
+ * transactions - round 2's layout (4-byte slots -> 32 hot bytes of the row) cost two random lines per
+ * frame, 4 M of the 6.1 M HBM reads of a 2 M-frame burst, and decode, like the vote scatter, runs at the
+ * chip's ~35-40 G random HBM transactions per second. */
 #define NM_STRIDE 160
 #define NM_EXISTS 5
 #define NM_VERSION 8
 #define NM_NAME 12 /* offset of the name bytes inside a row */
-#define NM_HOT 20  /* name bytes inside the row's first 32 */
-#define NM_ROW_BITS 25
-#define NM_ROW_MASK ((1 << NM_ROW_BITS) - 1)
-static_assert(NM_STRIDE == GPX_NAME_ROW_STRIDE && NM_EXISTS == GPX_NAME_ROW_EXISTS && NM_VERSION == GPX_NAME_ROW_VERSION,
-              "k_group_create / k_group_retire write the name rows");
+#define NM_SLOT 144 /* offset of the row's table slot index */
+#define NM_HOT 16  /* name bytes inside a table entry */
+struct __attribute__((aligned(32))) NameEnt {
+  int32_t v;        /* 0 empty, -1 tombstone, else row + 1 */
+  int32_t hash;     /* String.hashCode of the name */
+  uint32_t meta;    /* length | exists << 8 */
+  int32_t version;
+  uint32_t name[4]; /* first NM_HOT bytes, zero padded */
+};
+static_assert(sizeof(NameEnt) == GPX_NAME_ENT_BYTES && NM_STRIDE == GPX_NAME_ROW_STRIDE && NM_EXISTS == GPX_NAME_ROW_EXISTS &&
+                  NM_VERSION == GPX_NAME_ROW_VERSION && NM_SLOT == GPX_NAME_ROW_SLOT,
+              "k_group_create / k_group_retire write the name rows and table entries");
 #define GPX_W_MAX_DEPTH 6   /* nesting of batched RequestPackets the walker follows */
 #define GPX_W_MAX_SEG 256   /* rows of one group a BATCHED_COMMIT frame may span (>= 2 * window) */
 
 /* device mirror of PaxosManager.pinstances' key side: open addressing over the paxosID bytes */
 struct DevNames {
-  int32_t cap;    /* table slots, power of two, >= 2 * G */
-  int32_t* tab;   /* 0 empty, -1 tombstone, else row + 1 */
+  int32_t cap;    /* table entries, power of two, >= 2 * G */
+  NameEnt* tab;
   uint8_t* rows;  /* [G][NM_STRIDE] */
   __device__ __forceinline__ uint8_t* row(int32_t g) const { return rows + (int64_t)g * NM_STRIDE; }
   __device__ __forceinline__ int32_t hash(int32_t g) const { return *(const int32_t*)row(g); }
   __device__ __forceinline__ int32_t len(int32_t g) const { return (int32_t)row(g)[4]; }
   __device__ __forceinline__ const uint8_t* name(int32_t g) const { return row(g) + NM_NAME; }
-  /* table slot of row g whose name hashes to h (String.hashCode): never 0, never negative */
-  /* (a table of more than 2^25 slots - more than 16 M groups - keeps plain row + 1) */
-  __device__ __forceinline__ int32_t row_mask() const { return cap > NM_ROW_MASK ? 0x7fffffff : NM_ROW_MASK; }
-  __device__ __forceinline__ int32_t slot_of(int32_t g, int32_t h) const {
-    const uint32_t fp = cap > NM_ROW_MASK ? 0u : ((uint32_t)h * 0x9e3779b1u) >> 26;
-    return (int32_t)((uint32_t)(g + 1) | (fp << NM_ROW_BITS));
+  __device__ __forceinline__ int32_t& slot(int32_t g) const { return *(int32_t*)(row(g) + NM_SLOT); }
+  /* the rest of entry s, from row g (which holds the whole name and the group's copies) */
+  __device__ __forceinline__ void fill(int32_t s, int32_t g) const {
+    const uint8_t* r = row(g);
+    NameEnt* e = tab + s;
+    uint32_t q[4] = {0, 0, 0, 0};
+    const int32_t len = (int32_t)r[4];
+    for (int32_t i = 0; i < NM_HOT && i < len; i++) q[i >> 2] |= (uint32_t)r[NM_NAME + i] << (8 * (i & 3));
+    e->hash = *(const int32_t*)r;
+    e->meta = (uint32_t)len | ((uint32_t)r[NM_EXISTS] << 8);
+    e->version = *(const int32_t*)(r + NM_VERSION);
+    e->name[0] = q[0];
+    e->name[1] = q[1];
+    e->name[2] = q[2];
+    e->name[3] = q[3];
+    slot(g) = s;
   }
-  __device__ __forceinline__ int32_t slot_row(int32_t v) const { return (v & row_mask()) - 1; }
 };
 
 /* Frame bytes are parsed either in place (generic pointer) or from the LDS staging area.  The
@@ -80,37 +98,33 @@ __device__ __forceinline__ bool w_bytes_eq(const uint8_t* a, BP b, int32_t n) {
   return true;
 }
 /* MultiArrayMap.get(paxosID) (PaxosManager.getInstance, PaxosManager.java:1816-1832): row or -1.
- * The first 24 name bytes of the probe are packed into six dwords once; a candidate row's header
- * and its first 24 name bytes (zero padded by k_names_bind) arrive with two 16-byte loads of one
- * 32-byte sector, so a probe step costs one table read plus one row read. */
+ * The first 16 name bytes of the probe are packed into four dwords once; a candidate entry arrives with
+ * two 16-byte loads of one aligned 32-byte block and decides by itself unless the name is longer than
+ * 16 bytes (then the tail is compared in the row). */
 template <class BP>
 __device__ __forceinline__ int32_t names_find(const DevNames& N, BP p, int32_t len, int32_t hash,
                                               bool* exists = nullptr, int32_t* version = nullptr) {
   if (!N.tab) return -1;
-  uint32_t q[5] = {0, 0, 0, 0, 0};
+  uint32_t q[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int32_t i = 0; i < NM_HOT; i++)
     if (i < len) q[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
   const uint32_t mask = (uint32_t)N.cap - 1u;
   uint32_t s = w_fmix32((uint32_t)hash) & mask;
-  const int32_t rmask = N.row_mask();
-  const int32_t want = N.slot_of(0, hash) & ~rmask; /* the hash bits of a matching slot */
   for (int32_t probe = 0; probe < N.cap; probe++) {
-    const int32_t v = N.tab[s];
+    const uint4* e = (const uint4*)(N.tab + s);
+    const uint4 e0 = e[0], e1 = e[1];
+    const int32_t v = (int32_t)e0.x;
     if (v == 0) return -1;
-    if (v > 0 && (v & ~rmask) == want) {
-      const int32_t g = N.slot_row(v);
-      const uint4* r = (const uint4*)N.row(g);
-      const uint4 r0 = r[0], r1 = r[1];
-      if ((int32_t)r0.x == hash && (int32_t)(r0.y & 0xffu) == len && r0.w == q[0] && r1.x == q[1] &&
-          r1.y == q[2] && r1.z == q[3] && r1.w == q[4]) {
-        bool same = true;
-        for (int32_t i = NM_HOT; i < len && same; i++) same = N.name(g)[i] == p[i];
-        if (same) {
-          if (exists) *exists = ((r0.y >> 8) & 0xffu) != 0;
-          if (version) *version = (int32_t)r0.z;
-          return g;
-        }
+    if (v > 0 && (int32_t)e0.y == hash && (int32_t)(e0.z & 0xffu) == len && e1.x == q[0] && e1.y == q[1] &&
+        e1.z == q[2] && e1.w == q[3]) {
+      const int32_t g = v - 1;
+      bool same = true;
+      for (int32_t i = NM_HOT; i < len && same; i++) same = N.name(g)[i] == p[i];
+      if (same) {
+        if (exists) *exists = ((e0.z >> 8) & 0xffu) != 0;
+        if (version) *version = (int32_t)e0.w;
+        return g;
       }
     }
     s = (s + 1) & mask;
@@ -139,7 +153,6 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevState S, DevNames N
   const int32_t h = w_java_hash(p, len);
   uint8_t* row = N.row(g);
   for (int32_t b = 0; b < len; b++) row[NM_NAME + b] = p[b];
-  for (int32_t b = len; b < NM_HOT; b++) row[NM_NAME + b] = 0; /* names_find compares NM_HOT padded bytes */
   *(int32_t*)row = h;
   row[NM_EXISTS] = (g < S.G && (S.g_flags[g] & GF_EXISTS)) ? 1 : 0;
   *(int32_t*)(row + NM_VERSION) = g < S.G ? S.g_version[g] : 0;
@@ -148,17 +161,18 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevState S, DevNames N
   const uint32_t mask = (uint32_t)N.cap - 1u;
   uint32_t s = w_fmix32((uint32_t)h) & mask;
   for (int32_t probe = 0; probe < N.cap; probe++) {
-    int32_t v = N.tab[s];
+    int32_t v = N.tab[s].v;
     if (v == 0) {
-      v = atomicCAS(&N.tab[s], 0, N.slot_of(g, h));
-      if (v == 0) {
+      v = atomicCAS(&N.tab[s].v, 0, g + 1);
+      if (v == 0) { /* the entry is this row's: the rest of it (readers are later kernels) */
+        N.fill((int32_t)s, g);
         status[i] = GPX_S_OK;
         return;
       }
       __threadfence();
     }
-    if (v > 0 && N.slot_row(v) != g) {
-      const int32_t o = N.slot_row(v);
+    if (v > 0 && v - 1 != g) {
+      const int32_t o = v - 1;
       if (N.hash(o) == h && N.len(o) == len && w_bytes_eq(N.name(o), p, len)) {
         N.row(g)[4] = 0; /* name already bound to another row */
         status[i] = GPX_S_EXISTS;
@@ -181,17 +195,9 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_unbind(DevNames N, int32_t 
     if (status) status[i] = GPX_S_NOGROUP;
     return;
   }
-  const uint32_t mask = (uint32_t)N.cap - 1u;
-  uint32_t s = w_fmix32((uint32_t)N.hash(g)) & mask;
-  for (int32_t probe = 0; probe < N.cap; probe++) {
-    const int32_t v = N.tab[s];
-    if (v > 0 && N.slot_row(v) == g) {
-      N.tab[s] = -1; /* tombstone: later probes walk over it */
-      break;
-    }
-    if (v == 0) break;
-    s = (s + 1) & mask;
-  }
+  const int32_t s = N.slot(g);
+  if (s >= 0 && s < N.cap && N.tab[s].v == g + 1) N.tab[s].v = -1; /* tombstone: later probes walk over it */
+  N.slot(g) = -1;
   N.row(g)[4] = 0;
   if (status) status[i] = GPX_S_OK;
 }
@@ -203,7 +209,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_reinsert(DevNames N, int32_
   const uint32_t mask = (uint32_t)N.cap - 1u;
   uint32_t s = w_fmix32((uint32_t)N.hash(g)) & mask;
   for (int32_t probe = 0; probe < N.cap; probe++) {
-    if (N.tab[s] == 0 && atomicCAS(&N.tab[s], 0, N.slot_of(g, N.hash(g))) == 0) return;
+    if (N.tab[s].v == 0 && atomicCAS(&N.tab[s].v, 0, g + 1) == 0) {
+      N.fill((int32_t)s, g);
+      return;
+    }
     s = (s + 1) & mask;
   }
 }
@@ -357,6 +366,9 @@ struct WFrame {
   bool ascending;
   bool stop;
   int64_t req_id, tail;             /* ACCEPT: byte position of the slot / ballot tail */
+#ifdef GPX_WD_TRACE
+  unsigned long long t_pre;
+#endif
 };
 
 /* strictly ascending signed order = what TreeMap / TreeSet iteration put on the wire */
@@ -472,6 +484,10 @@ __device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, W
     gver = version;
   }
 #else
+#ifdef GPX_WD_TRACE
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); /* the parse's own loads are back */
+  f.t_pre = wall_clock64();
+#endif
   if (idl > 0) g = names_find(N, p + 13, idl, w_java_hash(p + 13, idl), &exists, &gver);
 #endif
   if (g < 0 || !exists) {
@@ -518,47 +534,57 @@ struct WireScratch {
 #define GPX_WIRE_WINDOWS 0
 #endif
 #define GPX_W_STAGE_WORDS (GPX_W_STAGE_BYTES / 4 + 4 + 1) /* + the lead of an unaligned tile + one readable word */
-/* Copy the bytes [a0, a0 + nbytes) (a0 dword-aligned) into the 16-byte-aligned staging area with
- * 16-byte loads, FOUR in flight per lane before the first is stored: a lane's loads of a plain
- * `lds[w] = src[w]` loop wait for one another (17 dependent HBM round trips for a 17 KB tile - that
- * loop, not the name lookups, was most of round 2's 230 us scan).  LDS byte lead + k = byte k, where
- * lead = a0 & 15 keeps 16-byte chunks aligned on both sides; nothing before a0 or past the last byte
- * is read.  Returns lead; the caller's barrier follows. */
+/* Copy the bytes [a0, a0 + nbytes) (a0 dword-aligned) into the 16-byte-aligned staging area.  EVERY load
+ * of a lane - its (up to seven) 16-byte chunks, the odd words before the first and after the last whole
+ * chunk, a tail byte - is issued before the first is stored, so the copy is ONE memory round trip (the
+ * timeline of round 3, scripts/ubench/wire_trace.sh: with four chunks in flight per pass and the odd
+ * words in passes of their own the staging of a 512-frame tile was five dependent round trips, 12 of
+ * the tile's 47 us).  LDS byte lead + k = byte k, where lead = a0 & 15 keeps 16-byte chunks aligned on
+ * both sides; nothing before a0 or past the last byte is read.  Returns lead; the caller's barrier
+ * follows. */
+template <int BLOCK = GPX_BLOCK>
 __device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64_t nbytes) {
+  constexpr int NCH = GPX_W_STAGE_BYTES / 16 / GPX_BLOCK + 1; /* chunks per lane of a full staging area */
   const uintptr_t a16 = a0 & ~(uintptr_t)15;
   const int32_t lead = (int32_t)(a0 - a16);
   const int32_t total = lead + (int32_t)nbytes;
   const int32_t c_lo = (lead + 15) >> 4, c_hi = total >> 4; /* whole chunks inside [lead, total) */
   const uint4* src16 = (const uint4*)a16;
   uint4* dst16 = (uint4*)lds;
-  for (int32_t c0 = c_lo; c0 < c_hi; c0 += 4 * GPX_BLOCK) {
-    uint4 v[4];
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int32_t c = c0 + k * GPX_BLOCK + (int32_t)threadIdx.x;
-      if (c < c_hi) v[k] = src16[c];
-    }
-#pragma unroll
-    for (int k = 0; k < 4; k++) {
-      const int32_t c = c0 + k * GPX_BLOCK + (int32_t)threadIdx.x;
-      if (c < c_hi) dst16[c] = v[k];
-    }
-  }
-  /* the words before the first whole chunk and after the last one, then the tail bytes */
   const uint32_t* src = (const uint32_t*)a16;
   const int32_t w_hi = total >> 2;
   const int32_t head_end = c_lo * 4 < w_hi ? c_lo * 4 : w_hi;
-  {
-    const int32_t w = (lead >> 2) + (int32_t)threadIdx.x;
-    if (w < head_end) lds[w] = src[w];
+  const int32_t hw = (lead >> 2) + (int32_t)threadIdx.x;                     /* a word before the first whole chunk */
+  const int32_t t_lo = c_hi * 4 > head_end ? c_hi * 4 : head_end;
+  const int32_t tw = t_lo + (int32_t)threadIdx.x;                            /* a word after the last one */
+  const bool tbyte = (int32_t)threadIdx.x < (total & 3);                     /* a tail byte */
+  for (int32_t c0 = c_lo; c0 < c_hi; c0 += NCH * BLOCK) {                    /* one pass for a staging area's worth */
+    uint4 v[NCH];
+    uint32_t hv = 0, tv = 0;
+    uint8_t bv = 0;
+    const bool odd = c0 == c_lo;
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+      const int32_t c = c0 + k * BLOCK + (int32_t)threadIdx.x;
+      if (c < c_hi) v[k] = src16[c];
+    }
+    if (odd && hw < head_end) hv = src[hw];
+    if (odd && tw < w_hi) tv = src[tw];
+    if (odd && tbyte) bv = ((const uint8_t*)src)[(w_hi << 2) + threadIdx.x];
+#pragma unroll
+    for (int k = 0; k < NCH; k++) {
+      const int32_t c = c0 + k * BLOCK + (int32_t)threadIdx.x;
+      if (c < c_hi) dst16[c] = v[k];
+    }
+    if (odd && hw < head_end) lds[hw] = hv;
+    if (odd && tw < w_hi) lds[tw] = tv;
+    if (odd && tbyte) ((uint8_t*)lds)[(w_hi << 2) + threadIdx.x] = bv;
   }
-  {
-    const int32_t t_lo = c_hi * 4 > head_end ? c_hi * 4 : head_end;
-    const int32_t w = t_lo + (int32_t)threadIdx.x;
-    if (w < w_hi) lds[w] = src[w];
+  if (c_lo >= c_hi) { /* less than one whole chunk: only the odd words */
+    if (hw < head_end) lds[hw] = src[hw];
+    if (tw < w_hi) lds[tw] = src[tw];
+    if (tbyte) ((uint8_t*)lds)[(w_hi << 2) + threadIdx.x] = ((const uint8_t*)src)[(w_hi << 2) + threadIdx.x];
   }
-  if ((int32_t)threadIdx.x < (total & 3))
-    ((uint8_t*)lds)[(w_hi << 2) + threadIdx.x] = ((const uint8_t*)src)[(w_hi << 2) + threadIdx.x];
   return lead;
 }
 template <class F>
@@ -795,7 +821,19 @@ struct WireLook {
   unsigned long long* state; /* [4][ntiles]  epoch << 40 | state << 38 | count */
   uint32_t* ticket;          /* next tile; the workgroup that draws the last one puts 0 back */
   uint32_t epoch;            /* 24 bits, never 0 (the words are zeroed when it wraps) */
+#ifdef GPX_WD_TRACE /* timeline build (scripts/ubench/wire_trace.sh): never shipped */
+  unsigned long long* trace; /* [ntiles][8] wall_clock64 stamps of thread 0 */
+#endif
 };
+#ifdef GPX_WD_TRACE
+#define WD_STAMP(k)                                                              \
+  do {                                                                           \
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  \
+    if (threadIdx.x == 0) K.trace[(int64_t)tile * 8 + (k)] = wall_clock64();     \
+  } while (0)
+#else
+#define WD_STAMP(k) do { } while (0)
+#endif
 #define WL_AGG 1ull
 #define WL_PRE 2ull
 #define WL_VAL_MASK ((1ull << 38) - 1)
@@ -855,7 +893,8 @@ __device__ __forceinline__ uint32_t wl_lookback(const unsigned long long* __rest
   return (uint32_t)wl_lookback64(st, tile, epoch);
 }
 
-__global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames N, WireLook K, WireOut O,
+template <int WB>
+__global__ __launch_bounds__(WB) void k_wire_decode1(DevState S, DevNames N, WireLook K, WireOut O,
                                                            int32_t nf, int32_t ntiles,
                                                            const uint8_t* __restrict__ frames,
                                                            const int64_t* __restrict__ frame_off,
@@ -863,9 +902,13 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames
                                                            int32_t* __restrict__ f_gidx,
                                                            int32_t* __restrict__ f_type,
                                                            gpx_wire_counts* counts) {
-  __shared__ __attribute__((aligned(16))) uint32_t stage[GPX_W_STAGE_WORDS];
+  constexpr int64_t STAGE_BYTES = (int64_t)GPX_W_STAGE_BYTES * (WB / GPX_BLOCK); /* 96 bytes per frame */
+  __shared__ __attribute__((aligned(16))) uint32_t stage[STAGE_BYTES / 4 + 4 + 1];
   __shared__ int32_t s_tile;
   __shared__ uint32_t s_tot[4], s_base[4];
+#ifdef GPX_WD_TRACE
+  const unsigned long long t_entry = wall_clock64();
+#endif
   if (threadIdx.x == 0) {
     const uint32_t t = atomicAdd(K.ticket, 1u);
     if (t == (uint32_t)ntiles - 1u) *K.ticket = 0u; /* every tile is taken: ready for the next call */
@@ -873,23 +916,28 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames
   }
   __syncthreads();
   const int32_t tile = s_tile;
-  const int32_t i = tile * GPX_BLOCK + (int32_t)threadIdx.x;
+#ifdef GPX_WD_TRACE
+  if (threadIdx.x == 0) K.trace[(int64_t)tile * 8] = t_entry;
+#endif
+  WD_STAMP(1); /* ticket drawn */
+  const int32_t i = tile * WB + (int32_t)threadIdx.x;
   /* stage the tile (one window; a frame that does not lie inside it is read in place) */
-  const int32_t t0 = tile * GPX_BLOCK;
-  const int32_t t1 = t0 + GPX_BLOCK < nf ? t0 + GPX_BLOCK : nf;
+  const int32_t t0 = tile * WB;
+  const int32_t t1 = t0 + WB < nf ? t0 + WB : nf;
   const int64_t b0 = frame_off[t0], b1 = frame_off[t1];
   const uintptr_t a0 = (uintptr_t)(frames + b0) & ~(uintptr_t)3;
   const int64_t span = (int64_t)((uintptr_t)(frames + b1) - a0);
   const bool live = i < nf;
   const int64_t f0 = live ? frame_off[i] : b0, f1 = live ? frame_off[i + 1] : b0;
   const int64_t r0 = (int64_t)((uintptr_t)(frames + f0) - a0), r1 = (int64_t)((uintptr_t)(frames + f1) - a0);
-  const int64_t nbytes = span < 0 ? 0 : (span < GPX_W_STAGE_BYTES ? span : GPX_W_STAGE_BYTES);
+  const int64_t nbytes = span < 0 ? 0 : (span < STAGE_BYTES ? span : STAGE_BYTES);
 #ifdef GPX_WD_NOSTAGE /* ablation builds (scripts/ubench/wire_ablation.sh): never shipped */
   const int32_t lead = 0;
 #else
-  const int32_t lead = wire_stage(stage, a0, nbytes);
+  const int32_t lead = wire_stage<WB>(stage, a0, nbytes);
 #endif
   __syncthreads();
+  WD_STAMP(2); /* tile staged */
   const bool staged = live && r0 >= 0 && r1 >= r0 && r1 <= nbytes;
   WFrame f;
   f.st = GPX_W_OK;
@@ -915,6 +963,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames
       w_parse<GenBytes>(S, N, frames + f0, f1 - f0, f);
   }
 #endif
+  WD_STAMP(3); /* thread 0 parsed and looked up */
+#ifdef GPX_WD_TRACE
+  if (threadIdx.x == 0) K.trace[(int64_t)tile * 8 + 7] = f.t_pre; /* ... and when its lookup began */
+#endif
   const int32_t cls = (live && f.st == GPX_W_OK) ? f.cls : -1;
   const int32_t cnt = cls >= 0 ? f.cnt : 0;
   /* records of this tile per class; my offset inside the tile */
@@ -922,12 +974,13 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames
 #pragma unroll
   for (int c = 0; c < 4; c++) {
     int32_t tot;
-    const int32_t ex = block_exscan(cls == c ? cnt : 0, &tot);
+    const int32_t ex = block_exscan_n<WB>(cls == c ? cnt : 0, &tot);
     if (cls == c) off = ex;
     if (threadIdx.x == 0) s_tot[c] = (uint32_t)tot;
   }
   __syncthreads();
-  { /* wave c: class c's words */
+  WD_STAMP(4); /* every lane parsed, tile counts known */
+  if (threadIdx.x < 256) { /* wave c: class c's words */
     const int32_t c = (int32_t)(threadIdx.x >> 6);
     unsigned long long* st = K.state + (int64_t)c * ntiles;
     const uint32_t mine = s_tot[c];
@@ -935,7 +988,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames
       __hip_atomic_store(&st[tile], wl_word(K.epoch, tile == 0 ? WL_PRE : WL_AGG, mine), __ATOMIC_RELAXED,
                          __HIP_MEMORY_SCOPE_AGENT);
 #ifdef GPX_WD_NOLOOKBACK
-    const uint32_t excl = (uint32_t)tile * GPX_BLOCK;
+    const uint32_t excl = (uint32_t)tile * WB;
 #else
     const uint32_t excl = tile == 0 ? 0u : wl_lookback(st, tile, K.epoch);
 #endif
@@ -948,6 +1001,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames
     }
   }
   __syncthreads();
+  WD_STAMP(5); /* look-back done */
   bool over = false;
   if (cls >= 0) {
     off += (int32_t)s_base[cls];
@@ -960,7 +1014,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames
     if (f_type) f_type[i] = f.type;
   }
   int32_t bad;
-  block_exscan((live && (f.st != GPX_W_OK || over)) ? 1 : 0, &bad);
+  block_exscan_n<WB>((live && (f.st != GPX_W_OK || over)) ? 1 : 0, &bad);
   if (threadIdx.x == 0 && bad) atomicAdd(&counts->n_bad_frames, bad);
 #ifndef GPX_WD_NOEMIT
   if (cls >= 0 && !over) {
@@ -970,6 +1024,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_wire_decode1(DevState S, DevNames
     else
       wire_emit<GenBytes>(O, i, frames + f0, f.gidx, f.tail, flags, cls, cnt, off);
   }
+#endif
+#ifdef GPX_WD_TRACE
+  __syncthreads();
+  WD_STAMP(6); /* records written */
 #endif
 }
 
