@@ -47,6 +47,11 @@ struct DirectStage {
   int32_t *x_gidx, *x_first, *x_count;
   int32_t* st_gidx;
   int32_t* st_total; /* [1] runs staged by k_emit_runs_direct<true> */
+  /* [1] == the call's epoch: the cheap answer does not hold.  ACCEPT batches: some record parked a run (the
+   * usual batch releases no commit: nothing to emit).  COMMIT batches: some record parked NO run (the usual
+   * batch executes one slot per commit: the caller's columns are final as parked).  Plain stores of one
+   * value, no atomics; the emit kernels of a usual batch read this word and return. */
+  uint32_t* mark;
 };
 
 /* the run of records of one group in a gidx-ordered batch, with GroupIter's interface */
@@ -63,10 +68,15 @@ struct RunIter {
   /* the head's own record, fetched by the kernel ahead of the group state; g_next = gidx[head + 1]
    * (or ~g at the end of the batch): a run of one record never touches memory here */
   bool inplace = false; /* park runs in the caller's columns (k_ac_direct<COMMIT>) */
+  int32_t pend = -1;    /* inplace: the record handed out last has not parked a run yet */
   bool have_first = false;
   int32_t f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
   int32_t head = -2, g_next = 0;
   __device__ __forceinline__ bool next(Rec& out) {
+    if (inplace) {
+      if (pend >= 0) D.mark[0] = epoch; /* a commit that executed nothing: the columns have a hole */
+      pend = i;
+    }
     if (have_first) {
       have_first = false;
       out.idx = i;
@@ -80,8 +90,10 @@ struct RunIter {
       i++;
       return true;
     }
-    if (i >= n) return false;
-    if ((i == head + 1 ? g_next : gidx[i]) != g) return false;
+    if (i >= n || (i == head + 1 ? g_next : gidx[i]) != g) {
+      pend = -1; /* no record handed out */
+      return false;
+    }
     cur = i;
     out.idx = i;
     out.a = slot[i];
@@ -98,9 +110,11 @@ struct RunIter {
       D.x_gidx[cur] = g;
       D.x_first[cur] = first_slot;
       D.x_count[cur] = count;
+      pend = -1;
     } else {
       D.st_first[cur] = first_slot;
       D.st_count[cur] = count; /* > 0 */
+      D.mark[0] = epoch;
     }
     D.tag[cur] = epoch;
     if (!count_chunks) return;
@@ -173,6 +187,7 @@ __global__ __launch_bounds__(GPX_DBLOCK) void k_ac_direct(
         apply_commit_group(S, X, g, it, status, P);
       else
         apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status, nullptr, P);
+      if (it.pend >= 0) D.mark[0] = X.epoch; /* the replay stopped on a record without a run */
       local = it.local;
     }
   }
@@ -192,65 +207,57 @@ __global__ __launch_bounds__(GPX_DBLOCK) void k_ac_direct(
 
 /* parked runs -> the caller's dense columns, chunk by chunk in record order.  INPLACE (commit batches): the
  * runs are parked in those very columns - all n records hold one: done; else -> dense staging. */
+#define GPX_EMIT_GRID 256 /* persistent workgroups of the emit kernels: a usual batch has nothing for them to do */
 template <bool INPLACE>
-__global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, int32_t n,
+__global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, int32_t n, int32_t nchunks,
                                                                 const int32_t* __restrict__ gidx, DirectStage D,
                                                                 int32_t* __restrict__ x_gidx,
                                                                 int32_t* __restrict__ x_first,
                                                                 int32_t* __restrict__ x_count,
                                                                 int32_t* total_out, int32_t refuse) {
-  if (*X.unsorted == X.epoch) { /* the partition path (k_emit_runs) writes the outputs; refused: none */
+  const bool unsorted = *X.unsorted == X.epoch, marked = *D.mark == X.epoch; /* one round trip */
+  if (unsorted) { /* the partition path (k_emit_runs) writes the outputs; refused: none */
     if (refuse && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = 0;
     return;
   }
-  const int32_t w = (int32_t)blockIdx.x;
-  if (INPLACE) {
-    int32_t all = 0;
-    for (int32_t t = threadIdx.x; t < (int32_t)gridDim.x; t += GPX_DCHUNK) all += D.chunk_cnt[t];
-    int32_t total;
-    block_exscan_n<GPX_DCHUNK>(all, &total);
-    if (total == n) { /* one run per record, each at its record's index: the columns are final */
-      if (w == 0 && threadIdx.x == 0 && total_out) *total_out = n;
-      return;
-    }
+  if (!marked) { /* ACCEPT: no run anywhere.  COMMIT: one run per record, each at its record's index: final */
+    if (blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = INPLACE ? n : 0;
+    return;
   }
-  /* no run parked in this chunk (every chunk of an ACCEPT batch that released no commit): nothing to place */
-  if (D.chunk_cnt[w] == 0 && w != (int32_t)gridDim.x - 1) return;
-  int32_t before = 0;
-  for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) before += D.chunk_cnt[t];
-  int32_t pre;
-  block_exscan_n<GPX_DCHUNK>(before, &pre);
-  const int32_t i = w * GPX_DCHUNK + (int32_t)threadIdx.x;
-  const bool have = i < n && D.tag[i] == X.epoch;
-  int32_t tot;
-  const int32_t ex = block_exscan_n<GPX_DCHUNK>(have ? 1 : 0, &tot);
-  if (have) {
-    if (INPLACE) { /* source and destination are the same columns: through the staging block */
-      D.st_gidx[pre + ex] = x_gidx[i];
-      D.st_first[pre + ex] = x_first[i];
-      D.st_count[pre + ex] = x_count[i];
-    } else {
-      x_gidx[pre + ex] = gidx[i];
-      x_first[pre + ex] = D.st_first[i];
-      x_count[pre + ex] = D.st_count[i];
+  for (int32_t w = (int32_t)blockIdx.x; w < nchunks; w += (int32_t)gridDim.x) {
+    /* no run parked in this chunk: nothing to place (the last chunk publishes the total) */
+    if (D.chunk_cnt[w] == 0 && w != nchunks - 1) continue;
+    int32_t before = 0;
+    for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) before += D.chunk_cnt[t];
+    int32_t pre;
+    block_exscan_n<GPX_DCHUNK>(before, &pre);
+    const int32_t i = w * GPX_DCHUNK + (int32_t)threadIdx.x;
+    const bool have = i < n && D.tag[i] == X.epoch;
+    int32_t tot;
+    const int32_t ex = block_exscan_n<GPX_DCHUNK>(have ? 1 : 0, &tot);
+    if (have) {
+      if (INPLACE) { /* source and destination are the same columns: through the staging block */
+        D.st_gidx[pre + ex] = x_gidx[i];
+        D.st_first[pre + ex] = x_first[i];
+        D.st_count[pre + ex] = x_count[i];
+      } else {
+        x_gidx[pre + ex] = gidx[i];
+        x_first[pre + ex] = D.st_first[i];
+        x_count[pre + ex] = D.st_count[i];
+      }
     }
-  }
-  if (w == (int32_t)gridDim.x - 1 && threadIdx.x == 0) {
-    if (total_out) *total_out = pre + tot;
-    if (INPLACE) *D.st_total = pre + tot;
+    if (w == nchunks - 1 && threadIdx.x == 0) {
+      if (total_out) *total_out = pre + tot;
+      if (INPLACE) *D.st_total = pre + tot;
+    }
   }
 }
 
 /* commit batches that were not one-run-per-record: the staged runs back into the caller's columns */
-__global__ __launch_bounds__(GPX_BLOCK) void k_copy_runs(DevScratch X, int32_t n, int32_t nchunks, DirectStage D,
-                                                        int32_t* __restrict__ x_gidx, int32_t* __restrict__ x_first,
-                                                        int32_t* __restrict__ x_count) {
-  if (*X.unsorted == X.epoch) return;
-  int32_t all = 0;
-  for (int32_t t = threadIdx.x; t < nchunks; t += GPX_BLOCK) all += D.chunk_cnt[t];
-  int32_t total;
-  block_exscan(all, &total);
-  if (total == n) return; /* k_emit_runs_direct<true> found the columns final */
+__global__ __launch_bounds__(GPX_BLOCK) void k_copy_runs(DevScratch X, DirectStage D, int32_t* __restrict__ x_gidx,
+                                                        int32_t* __restrict__ x_first, int32_t* __restrict__ x_count) {
+  const bool unsorted = *X.unsorted == X.epoch, marked = *D.mark == X.epoch;
+  if (unsorted || !marked) return; /* k_emit_runs_direct<true> found the columns final */
   const int32_t m = *D.st_total;
   for (int32_t t = blockIdx.x * GPX_BLOCK + threadIdx.x; t < m; t += gridDim.x * GPX_BLOCK) {
     x_gidx[t] = D.st_gidx[t];

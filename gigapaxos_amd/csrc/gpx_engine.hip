@@ -883,7 +883,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     }
     {
       LaunchScope _ls(e, "k_emit_dec_runs");
-      hipLaunchKernelGGL(k_emit_dec_runs, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, st, info, n_out,
+      hipLaunchKernelGGL(k_emit_dec_runs, dim3(std::min(nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, nchunks, st, info, n_out,
                          &e->X.counters[1], refuse);
     }
     LAUNCH(e, "k_merge_runs", k_merge_runs, 256, e->X, n, st, (const RunsInfo*)info);
@@ -922,7 +922,8 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec; /* the two paths never both stage outputs: shared scratch */
   const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt, x_gidx, x_first, x_count,
-                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + nchunks + 1};
+                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + nchunks + 1,
+                      (uint32_t*)(e->fs[fs].chunk_cnt + nchunks + 2)};
   /* at most 65,536 records on one stream: order check, direct application and run compaction in ONE
    * launch (k_ac_small: tickets instead of chunk counters) */
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
@@ -973,7 +974,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     }
     {
       LaunchScope _ls(e, "k_emit_runs_direct");
-      hipLaunchKernelGGL(k_emit_runs_direct<false>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
+      hipLaunchKernelGGL(k_emit_runs_direct<false>, dim3(std::min(nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, nchunks, gidx, D,
                          x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
     }
   }
@@ -1011,7 +1012,8 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec;
   const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt, x_gidx, x_first, x_count,
-                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + nchunks + 1};
+                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + nchunks + 1,
+                      (uint32_t*)(e->fs[fs].chunk_cnt + nchunks + 2)};
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N; /* one launch: k_ac_small */
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
   if (!fused)
@@ -1058,10 +1060,10 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     }
     {
       LaunchScope _ls(e, "k_emit_runs_direct");
-      hipLaunchKernelGGL(k_emit_runs_direct<true>, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, gidx, D,
+      hipLaunchKernelGGL(k_emit_runs_direct<true>, dim3(std::min(nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, nchunks, gidx, D,
                          x_gidx, x_first, x_count, n_runs, promised ? 1 : 0);
     }
-    LAUNCH(e, "k_copy_runs", k_copy_runs, 256, e->X, n, nchunks, D, x_gidx, x_first, x_count);
+    LAUNCH(e, "k_copy_runs", k_copy_runs, 256, e->X, D, x_gidx, x_first, x_count);
   }
   if (!promised && e->ac16) {
     LAUNCH_B(e, "k_bucket_commit16", (k_bucket16<B16_COMMIT, 4>), e->S, e->X, O16, VoteCols{bnum, bcoord, nullptr},

@@ -407,15 +407,16 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
 
 /* regular batch: the caller's columns are final already - publish the count.  Otherwise: parked outputs ->
  * the dense staging block, chunk by chunk in record order */
-__global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int32_t n, RunsStage st,
+__global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int32_t n, int32_t nchunks, RunsStage st,
                                                              RunsInfo* __restrict__ info, int32_t* total_out,
                                                              unsigned long long* acc, int32_t refuse) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
-  if (*X.unsorted == X.epoch) { /* the partition pipeline (k_emit_dec16) writes the outputs; refused: none */
+  const bool unsorted = *X.unsorted == X.epoch, regular = runs_regular(info, n); /* one round trip */
+  if (unsorted) { /* the partition pipeline (k_emit_dec16) writes the outputs; refused: none */
     if (refuse && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = 0;
     return;
   }
-  if (runs_regular(info, n)) {
+  if (regular) {
     if (blockIdx.x == 0 && threadIdx.x == 0) {
       const int32_t total = runs_len0(info, n); /* one decision per record of run 0 */
       if (total_out) *total_out = total;
@@ -423,12 +424,12 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int3
     }
     return;
   }
-  const int32_t w = (int32_t)blockIdx.x;
   const bool merge = info->need_merge != 0;
+  const int32_t R = runs_load(info, n, rs);
+  for (int32_t w = (int32_t)blockIdx.x; w < nchunks; w += (int32_t)gridDim.x) { /* persistent workgroups: GPX_EMIT_GRID */
   /* nothing parked in this chunk (the chunks of the later runs, usually): nothing to place - only the last
    * chunk (the total) and, before a merge, the chunks that hold a run start (segment bounds) go on */
-  if (!merge && st.chunk_cnt[w] == 0 && w != (int32_t)gridDim.x - 1) return;
-  const int32_t R = runs_load(info, n, rs);
+  if (!merge && st.chunk_cnt[w] == 0 && w != nchunks - 1) continue;
   int32_t before = 0;
   for (int32_t t = threadIdx.x; t < w; t += GPX_DCHUNK) before += st.chunk_cnt[t];
   int32_t pre;
@@ -449,13 +450,14 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int3
     st.T.median()[o] = st.D.median[i];
     st.T.kind()[o] = st.D.kind[i];
   }
-  if (w == (int32_t)gridDim.x - 1 && threadIdx.x == 0) {
+  if (w == nchunks - 1 && threadIdx.x == 0) {
     const int32_t total = pre + tot;
     info->total = total;
     info->seg_off[0] = 0;
     info->seg_off[R] = total;
     if (total_out) *total_out = total;
     if (acc) atomicAdd(acc, (unsigned long long)total);
+  }
   }
 }
 
@@ -479,7 +481,8 @@ __device__ __forceinline__ int32_t seg_bound(const int32_t* __restrict__ a, int3
  * earlier segment first. */
 __global__ __launch_bounds__(GPX_BLOCK) void k_merge_runs(DevScratch X, int32_t n, RunsStage st,
                                                          const RunsInfo* __restrict__ info) {
-  if (*X.unsorted == X.epoch || runs_regular(info, n)) return;
+  const bool unsorted = *X.unsorted == X.epoch, regular = runs_regular(info, n); /* one round trip */
+  if (unsorted || regular) return;
   const int32_t R = min(info->n_desc, GPX_RUNS_MAX - 1) + 1;
   const int32_t total = info->total;
   const bool merge = info->need_merge != 0;
