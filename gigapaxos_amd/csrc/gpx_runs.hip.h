@@ -299,6 +299,9 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
   const int32_t o = i - rs[r];
   const bool in0 = active && r == 0;
   bool done = !active;
+  /* a lane of a later run (two thirds of a three-replica batch) usually finds its group at the same offset of
+   * run 0 and has nothing to do: that word is fetched together with the lane's own, not after it */
+  if (active && r > 0 && o < rs[1] && gidx[o] == g) done = true;
   CoordPre<KMAX> P;
   bool have_p = false;
   /* the lanes of the later runs (two thirds of a three-replica batch) skip the speculative fetches: they
