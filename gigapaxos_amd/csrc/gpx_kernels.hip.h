@@ -2164,7 +2164,9 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_gap_scan(DevState S, int32_t n,
 #define GPX_NAME_ROW_EXISTS 5
 #define GPX_NAME_ROW_VERSION 8
 #define GPX_NAME_ROW_SLOT 144
-#define GPX_NAME_ENT_BYTES 32
+#define GPX_NAME_BUCKET_BYTES 128 /* four entries: 32 bytes of keys, four payloads of 24 bytes */
+#define GPX_NAME_BUCKET_KEYS 32
+#define GPX_NAME_PAYLOAD_BYTES 24
 struct NameCopies {
   uint8_t* rows; /* null: no wire codec in use */
   uint8_t* tab;
@@ -2176,9 +2178,9 @@ struct NameCopies {
     if (nr[4] != 0) { /* the name is bound: its table entry carries the copies too */
       const int32_t s = *(const int32_t*)(nr + GPX_NAME_ROW_SLOT);
       if (s >= 0) {
-        uint8_t* e = tab + (int64_t)s * GPX_NAME_ENT_BYTES;
-        if (set_version) *(int32_t*)(e + 12) = version;
-        e[9] = exists ? 1 : 0; /* meta = length | exists << 8 */
+        uint8_t* e = tab + (int64_t)(s >> 2) * GPX_NAME_BUCKET_BYTES + GPX_NAME_BUCKET_KEYS + (s & 3) * GPX_NAME_PAYLOAD_BYTES;
+        if (set_version) *(int32_t*)(e + 4) = version;
+        e[1] = exists ? 1 : 0; /* payload = {length | exists << 8, version, name[4]} */
       }
     }
   }

@@ -15,28 +15,30 @@
  *   name bytes (up to 127) | ... | int32 table slot of the name at byte 144 (-1: none).
  * "exists" and "version" are COPIES of the engine's g_flags & GF_EXISTS / g_version, kept by the only
  * kernels that change them (k_group_create, k_group_retire) and by k_names_bind.
- * The TABLE is open addressing over 32-byte entries (NameEnt) that carry everything a frame's lookup
- * needs: row + 1, the name's hashCode, its length, the group's exists / version copies and the first 16
- * name bytes - the instance test of PaxosManager.handlePaxosPacket (getInstance + version,
- * PaxosManager.java:1153-1162) is ONE aligned 32-byte access for a name of up to 16 bytes (longer names
- * compare their tail in the row).  Why it matters: the decode is bound by the number of HBM
- * transactions - round 2's layout (4-byte slots -> 32 hot bytes of the row) cost two random lines per
- * frame, 4 M of the 6.1 M HBM reads of a 2 M-frame burst, and decode, like the vote scatter, runs at the
- * chip's ~35-40 G random HBM transactions per second. */
+ * The TABLE is open addressing over 128-byte BUCKETS - one cache line each - of four entries: four keys
+ * {row + 1, String.hashCode} in the first 32 bytes, then four payloads {length | exists << 8, version, the
+ * first 16 name bytes} of 24 bytes.  A lookup reads the keys of its home bucket (one line from HBM: one
+ * round trip) and, for a key whose hash matches, that entry's payload (the same line: an L1 hit); with
+ * at most one entry per bucket on average, 99.6 % of the names are in their home bucket, so the
+ * instance test of PaxosManager.handlePaxosPacket (getInstance + version, PaxosManager.java:1153-1162)
+ * is one HBM access for almost every frame of a WAVE - which is what counts: round 3's timeline
+ * (scripts/ubench/wire_trace.sh) showed the entry's round trip at 2 us and the wave's wait for its lane
+ * with the LONGEST probe sequence at 9 us under linear probing over single entries at load 0.5 (a
+ * sequence of four or five entries somewhere among 64 lanes is the rule).  Names longer than 16 bytes
+ * compare their tail in the row.  Inserts take the first empty way in probe order and never reuse a
+ * tombstone, so a lookup ends at the first bucket that still has an empty way. */
 #define NM_STRIDE 160
 #define NM_EXISTS 5
 #define NM_VERSION 8
 #define NM_NAME 12 /* offset of the name bytes inside a row */
-#define NM_SLOT 144 /* offset of the row's table slot index */
+#define NM_SLOT 144 /* offset of the row's table entry index (bucket * 4 + way) */
 #define NM_HOT 16  /* name bytes inside a table entry */
-struct __attribute__((aligned(32))) NameEnt {
-  int32_t v;        /* 0 empty, -1 tombstone, else row + 1 */
-  int32_t hash;     /* String.hashCode of the name */
-  uint32_t meta;    /* length | exists << 8 */
-  int32_t version;
-  uint32_t name[4]; /* first NM_HOT bytes, zero padded */
-};
-static_assert(sizeof(NameEnt) == GPX_NAME_ENT_BYTES && NM_STRIDE == GPX_NAME_ROW_STRIDE && NM_EXISTS == GPX_NAME_ROW_EXISTS &&
+#define NM_WAYS 4
+#define NM_BUCKET 128 /* bytes */
+#define NM_KEYS 32    /* bytes of keys at the head of a bucket */
+#define NM_PAYLOAD 24 /* bytes per payload */
+static_assert(NM_BUCKET == GPX_NAME_BUCKET_BYTES && NM_KEYS == GPX_NAME_BUCKET_KEYS && NM_PAYLOAD == GPX_NAME_PAYLOAD_BYTES &&
+                  NM_STRIDE == GPX_NAME_ROW_STRIDE && NM_EXISTS == GPX_NAME_ROW_EXISTS &&
                   NM_VERSION == GPX_NAME_ROW_VERSION && NM_SLOT == GPX_NAME_ROW_SLOT,
               "k_group_create / k_group_retire write the name rows and table entries");
 #define GPX_W_MAX_DEPTH 6   /* nesting of batched RequestPackets the walker follows */
@@ -44,28 +46,36 @@ static_assert(sizeof(NameEnt) == GPX_NAME_ENT_BYTES && NM_STRIDE == GPX_NAME_ROW
 
 /* device mirror of PaxosManager.pinstances' key side: open addressing over the paxosID bytes */
 struct DevNames {
-  int32_t cap;    /* table entries, power of two, >= 2 * G */
-  NameEnt* tab;
+  int32_t cap;    /* table entries = 4 * buckets; buckets a power of two >= G */
+  uint8_t* tab;   /* [cap / 4][NM_BUCKET] */
   uint8_t* rows;  /* [G][NM_STRIDE] */
   __device__ __forceinline__ uint8_t* row(int32_t g) const { return rows + (int64_t)g * NM_STRIDE; }
   __device__ __forceinline__ int32_t hash(int32_t g) const { return *(const int32_t*)row(g); }
   __device__ __forceinline__ int32_t len(int32_t g) const { return (int32_t)row(g)[4]; }
   __device__ __forceinline__ const uint8_t* name(int32_t g) const { return row(g) + NM_NAME; }
   __device__ __forceinline__ int32_t& slot(int32_t g) const { return *(int32_t*)(row(g) + NM_SLOT); }
+  __device__ __forceinline__ uint32_t bmask() const { return ((uint32_t)cap >> 2) - 1u; }
+  __device__ __forceinline__ uint8_t* bucket(uint32_t b) const { return tab + (int64_t)b * NM_BUCKET; }
+  __device__ __forceinline__ int32_t* key(int32_t s) const { /* {row + 1 (0 empty, -1 tombstone), hashCode} */
+    return (int32_t*)(bucket((uint32_t)s >> 2) + (s & 3) * 8);
+  }
+  __device__ __forceinline__ uint32_t* payload(int32_t s) const { /* {length | exists << 8, version, name[4]} */
+    return (uint32_t*)(bucket((uint32_t)s >> 2) + NM_KEYS + (s & 3) * NM_PAYLOAD);
+  }
   /* the rest of entry s, from row g (which holds the whole name and the group's copies) */
   __device__ __forceinline__ void fill(int32_t s, int32_t g) const {
     const uint8_t* r = row(g);
-    NameEnt* e = tab + s;
     uint32_t q[4] = {0, 0, 0, 0};
     const int32_t len = (int32_t)r[4];
     for (int32_t i = 0; i < NM_HOT && i < len; i++) q[i >> 2] |= (uint32_t)r[NM_NAME + i] << (8 * (i & 3));
-    e->hash = *(const int32_t*)r;
-    e->meta = (uint32_t)len | ((uint32_t)r[NM_EXISTS] << 8);
-    e->version = *(const int32_t*)(r + NM_VERSION);
-    e->name[0] = q[0];
-    e->name[1] = q[1];
-    e->name[2] = q[2];
-    e->name[3] = q[3];
+    key(s)[1] = *(const int32_t*)r;
+    uint32_t* pl = payload(s);
+    pl[0] = (uint32_t)len | ((uint32_t)r[NM_EXISTS] << 8);
+    pl[1] = *(const uint32_t*)(r + NM_VERSION);
+    pl[2] = q[0];
+    pl[3] = q[1];
+    pl[4] = q[2];
+    pl[5] = q[3];
     slot(g) = s;
   }
 };
@@ -97,39 +107,101 @@ __device__ __forceinline__ bool w_bytes_eq(const uint8_t* a, BP b, int32_t n) {
     if (a[i] != b[i]) return false;
   return true;
 }
-/* MultiArrayMap.get(paxosID) (PaxosManager.getInstance, PaxosManager.java:1816-1832): row or -1.
- * The first 16 name bytes of the probe are packed into four dwords once; a candidate entry arrives with
- * two 16-byte loads of one aligned 32-byte block and decides by itself unless the name is longer than
- * 16 bytes (then the tail is compared in the row). */
+/* one whole bucket in registers: eight 16-byte loads of one 128-byte line, all requested together (the
+ * payload as a second, dependent access - even of the same line - was a second round trip for the wave: the
+ * L1 holds 128 lines, the CU's waves have 1,500 in flight) */
+struct NameKeys {
+  uint4 q[8];
+  template <int W>
+  __device__ __forceinline__ int32_t v() const { return (int32_t)(W == 0 ? q[0].x : W == 1 ? q[0].z : W == 2 ? q[1].x : q[1].z); }
+  template <int W>
+  __device__ __forceinline__ int32_t h() const { return (int32_t)(W == 0 ? q[0].y : W == 1 ? q[0].w : W == 2 ? q[1].y : q[1].w); }
+  /* dword D (0 .. 5) of payload W: dword 8 + 6 W + D of the bucket */
+  template <int I>
+  __device__ __forceinline__ uint32_t dw() const {
+    return (I & 3) == 0 ? q[I >> 2].x : (I & 3) == 1 ? q[I >> 2].y : (I & 3) == 2 ? q[I >> 2].z : q[I >> 2].w;
+  }
+};
+__device__ __forceinline__ NameKeys names_keys(const DevNames& N, uint32_t b) {
+  const uint4* kp = (const uint4*)N.bucket(b);
+  NameKeys K;
+#pragma unroll
+  for (int i = 0; i < 8; i++) K.q[i] = kp[i];
+  return K;
+}
+/* way W of the bucket in K: -2 not this name, else its row (exists / version filled in) */
+template <int W, class BP>
+__device__ __forceinline__ int32_t names_way(const DevNames& N, const NameKeys& K, BP p, int32_t len, int32_t hash,
+                                             const uint32_t* q, bool* exists, int32_t* version) {
+  const int32_t v = K.v<W>();
+  if (!(v > 0 && K.h<W>() == hash)) return -2;
+  const uint32_t meta = K.dw<8 + 6 * W>();
+  const int32_t ver = (int32_t)K.dw<8 + 6 * W + 1>();
+  if ((int32_t)(meta & 0xffu) != len || K.dw<8 + 6 * W + 2>() != q[0] || K.dw<8 + 6 * W + 3>() != q[1] ||
+      K.dw<8 + 6 * W + 4>() != q[2] || K.dw<8 + 6 * W + 5>() != q[3])
+    return -2;
+  const int32_t g = v - 1;
+  /* written BEFORE the tail is compared (a caller looks at them only when a row comes back): with the two
+   * stores behind the loop, hipcc 7.2 dropped them for names longer than 16 bytes - the decode fuzz caught it */
+  if (exists) *exists = ((meta >> 8) & 0xffu) != 0;
+  if (version) *version = ver;
+  for (int32_t i = NM_HOT; i < len; i++)
+    if (N.name(g)[i] != p[i]) return -2;
+  return g;
+}
+/* MultiArrayMap.get(paxosID) (PaxosManager.getInstance, PaxosManager.java:1816-1832): row or -1, walking the
+ * buckets from b on; `first` = bucket b if the caller already has it.  The first 16 name bytes of the probe
+ * are packed into four dwords once. */
 template <class BP>
-__device__ __forceinline__ int32_t names_find(const DevNames& N, BP p, int32_t len, int32_t hash,
-                                              bool* exists = nullptr, int32_t* version = nullptr) {
-  if (!N.tab) return -1;
+__device__ __forceinline__ int32_t names_walk(const DevNames& N, BP p, int32_t len, int32_t hash, uint32_t b,
+                                              const NameKeys* first, bool* exists, int32_t* version) {
   uint32_t q[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int32_t i = 0; i < NM_HOT; i++)
     if (i < len) q[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
-  const uint32_t mask = (uint32_t)N.cap - 1u;
-  uint32_t s = w_fmix32((uint32_t)hash) & mask;
-  for (int32_t probe = 0; probe < N.cap; probe++) {
-    const uint4* e = (const uint4*)(N.tab + s);
-    const uint4 e0 = e[0], e1 = e[1];
-    const int32_t v = (int32_t)e0.x;
-    if (v == 0) return -1;
-    if (v > 0 && (int32_t)e0.y == hash && (int32_t)(e0.z & 0xffu) == len && e1.x == q[0] && e1.y == q[1] &&
-        e1.z == q[2] && e1.w == q[3]) {
-      const int32_t g = v - 1;
-      bool same = true;
-      for (int32_t i = NM_HOT; i < len && same; i++) same = N.name(g)[i] == p[i];
-      if (same) {
-        if (exists) *exists = ((e0.z >> 8) & 0xffu) != 0;
-        if (version) *version = (int32_t)e0.w;
-        return g;
-      }
-    }
-    s = (s + 1) & mask;
+  const uint32_t bm = N.bmask();
+  for (uint32_t probe = 0; probe <= bm; probe++) {
+    const NameKeys K = (probe == 0 && first) ? *first : names_keys(N, b);
+    int32_t g;
+    if ((g = names_way<0>(N, K, p, len, hash, q, exists, version)) != -2) return g;
+    if ((g = names_way<1>(N, K, p, len, hash, q, exists, version)) != -2) return g;
+    if ((g = names_way<2>(N, K, p, len, hash, q, exists, version)) != -2) return g;
+    if ((g = names_way<3>(N, K, p, len, hash, q, exists, version)) != -2) return g;
+    /* inserts take the first empty way in probe order: the name is not beyond an empty way */
+    if (K.v<0>() == 0 || K.v<1>() == 0 || K.v<2>() == 0 || K.v<3>() == 0) return -1;
+    b = (b + 1) & bm;
   }
   return -1;
+}
+template <class BP>
+__device__ __forceinline__ int32_t names_find(const DevNames& N, BP p, int32_t len, int32_t hash,
+                                              bool* exists = nullptr, int32_t* version = nullptr) {
+  if (!N.tab) return -1;
+  return names_walk(N, p, len, hash, w_fmix32((uint32_t)hash) & N.bmask(), nullptr, exists, version);
+}
+
+/* names_find in two halves: the keys of the home bucket are REQUESTED here and judged there, so that
+ * whatever the caller does in between overlaps the round trip */
+struct NameProbe {
+  NameKeys K;
+  uint32_t b;
+  bool armed;
+};
+template <class BP>
+__device__ __forceinline__ NameProbe names_probe(const DevNames& N, BP p, int32_t len, int32_t hash) {
+  NameProbe q;
+  q.armed = N.tab != nullptr && len > 0;
+  q.b = w_fmix32((uint32_t)hash) & N.bmask();
+#pragma unroll
+  for (int i = 0; i < 8; i++) q.K.q[i] = make_uint4(0, 0, 0, 0);
+  if (q.armed) q.K = names_keys(N, q.b);
+  return q;
+}
+template <class BP>
+__device__ __forceinline__ int32_t names_probe_finish(const DevNames& N, const NameProbe& q, BP p, int32_t len,
+                                                      int32_t hash, bool* exists, int32_t* version) {
+  if (!q.armed) return -1;
+  return names_walk(N, p, len, hash, q.b, &q.K, exists, version);
 }
 
 __global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevState S, DevNames N, int32_t G, int32_t n,
@@ -159,11 +231,11 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevState S, DevNames N
   row[4] = (uint8_t)len;
   __threadfence(); /* the row is complete before the table can point at it */
   const uint32_t mask = (uint32_t)N.cap - 1u;
-  uint32_t s = w_fmix32((uint32_t)h) & mask;
+  uint32_t s = (w_fmix32((uint32_t)h) & N.bmask()) << 2; /* way 0 of the home bucket; then way by way, bucket by bucket */
   for (int32_t probe = 0; probe < N.cap; probe++) {
-    int32_t v = N.tab[s].v;
+    int32_t v = N.key((int32_t)s)[0];
     if (v == 0) {
-      v = atomicCAS(&N.tab[s].v, 0, g + 1);
+      v = atomicCAS(&N.key((int32_t)s)[0], 0, g + 1);
       if (v == 0) { /* the entry is this row's: the rest of it (readers are later kernels) */
         N.fill((int32_t)s, g);
         status[i] = GPX_S_OK;
@@ -196,7 +268,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_unbind(DevNames N, int32_t 
     return;
   }
   const int32_t s = N.slot(g);
-  if (s >= 0 && s < N.cap && N.tab[s].v == g + 1) N.tab[s].v = -1; /* tombstone: later probes walk over it */
+  if (s >= 0 && s < N.cap && N.key(s)[0] == g + 1) N.key(s)[0] = -1; /* tombstone: later probes walk over it */
   N.slot(g) = -1;
   N.row(g)[4] = 0;
   if (status) status[i] = GPX_S_OK;
@@ -207,9 +279,9 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_names_reinsert(DevNames N, int32_
   const int32_t g = blockIdx.x * GPX_BLOCK + threadIdx.x;
   if (g >= G || N.len(g) == 0) return;
   const uint32_t mask = (uint32_t)N.cap - 1u;
-  uint32_t s = w_fmix32((uint32_t)N.hash(g)) & mask;
+  uint32_t s = (w_fmix32((uint32_t)N.hash(g)) & N.bmask()) << 2;
   for (int32_t probe = 0; probe < N.cap; probe++) {
-    if (N.tab[s].v == 0 && atomicCAS(&N.tab[s].v, 0, g + 1) == 0) {
+    if (N.key((int32_t)s)[0] == 0 && atomicCAS(&N.key((int32_t)s)[0], 0, g + 1) == 0) {
       N.fill((int32_t)s, g);
       return;
     }
@@ -367,7 +439,7 @@ struct WFrame {
   bool stop;
   int64_t req_id, tail;             /* ACCEPT: byte position of the slot / ballot tail */
 #ifdef GPX_WD_TRACE
-  unsigned long long t_pre;
+  unsigned long long t_pre, t_hash, t_load;
 #endif
 };
 
@@ -398,7 +470,7 @@ __device__ __forceinline__ int32_t w_list_distinct(BP e, int32_t n, int32_t stri
 /* PaxosPacketDemultiplexerFast.toPaxosPacket (paxosutil/PaxosPacketDemultiplexerFast.java:66-103)
  * + the four ByteBuffer constructors + PaxosManager.handlePaxosPacket's getInstance / version test
  * (PaxosManager.java:1153-1162), for one frame. */
-template <class BP>
+template <class BP, bool LOOKUP = true>
 __device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, WFrame& f) {
   f.st = GPX_W_MALFORMED;
   f.type = -1;
@@ -473,6 +545,10 @@ __device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, W
     f.cnt = 1;
   }
   f.type = t;
+  if (!LOOKUP) { /* the caller looks the name up itself (k_wire_decode1 overlaps it with its look-back) */
+    f.st = GPX_W_OK;
+    return;
+  }
   /* getInstance(paxosID) and the version check */
   int32_t g = -1;
   bool exists = false;
@@ -487,8 +563,18 @@ __device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, W
 #ifdef GPX_WD_TRACE
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); /* the parse's own loads are back */
   f.t_pre = wall_clock64();
-#endif
+  if (idl > 0) {
+    const int32_t hh = w_java_hash(p + 13, idl);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    f.t_hash = wall_clock64();
+    const NameProbe np = names_probe(N, p + 13, idl, hh);
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    f.t_load = wall_clock64();
+    g = names_probe_finish(N, np, p + 13, idl, hh, &exists, &gver);
+  }
+#else
   if (idl > 0) g = names_find(N, p + 13, idl, w_java_hash(p + 13, idl), &exists, &gver);
+#endif
 #endif
   if (g < 0 || !exists) {
     f.st = GPX_W_NOGROUP;
@@ -499,6 +585,9 @@ __device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, W
   if (gver != version) {
     f.st = GPX_W_VERSION;
     f.cnt = 0;
+#ifdef GPX_WD_DBGVER
+    f.gidx = 1000000 + gver * 1000 + version;
+#endif
     return;
   }
   f.st = GPX_W_OK;
@@ -829,7 +918,7 @@ struct WireLook {
 #define WD_STAMP(k)                                                              \
   do {                                                                           \
     asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                  \
-    if (threadIdx.x == 0) K.trace[(int64_t)tile * 8 + (k)] = wall_clock64();     \
+    if (threadIdx.x == 0) K.trace[(int64_t)tile * 16 + (k)] = wall_clock64();     \
   } while (0)
 #else
 #define WD_STAMP(k) do { } while (0)
@@ -844,6 +933,9 @@ __device__ __forceinline__ unsigned long long wl_word(uint32_t epoch, unsigned l
  * costs: ~6,000 waves spinning on 64 words each flood the L2 request path (measured: four words per
  * lane made the kernel 35 % slower), so a wave first waits on ONE word - its nearest predecessor's,
  * published last of all it needs in the usual case - and only then reads 64 at a time. */
+#ifndef GPX_WL_WIDE
+#define GPX_WL_WIDE 1 /* words per lane and round trip (4 = 256 tiles per step: measured slower) */
+#endif
 __device__ __forceinline__ unsigned long long wl_lookback64(const unsigned long long* __restrict__ st, int32_t tile,
                                                  uint32_t epoch) {
   const int32_t lane = (int32_t)(threadIdx.x & 63);
@@ -853,37 +945,50 @@ __device__ __forceinline__ unsigned long long wl_lookback64(const unsigned long 
     __builtin_amdgcn_s_sleep(8);
   }
   unsigned long long excl = 0;
-  for (int32_t hi = tile - 1; hi >= 0; hi -= 64) {
-    const int32_t j = hi - lane; /* lane 0 = the nearest predecessor */
-    unsigned long long v = 0;
-    bool need = j >= 0;
-    unsigned long long pre_mask;
-    for (;;) {
-      if (need) {
-        v = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(v >> 40) == epoch) need = false;
-      }
-      /* the walk stops at the nearest tile with a PREFIX: only lanes nearer than it must be valid */
-      pre_mask = __ballot(!need && j >= 0 && ((v >> 38) & 3ull) == WL_PRE);
-      const unsigned long long wait_mask = __ballot(need);
-      if (pre_mask) {
-        const unsigned long long nearer = (pre_mask & (0ull - pre_mask)) - 1ull;
-        if ((wait_mask & nearer) == 0) break;
-      } else if (wait_mask == 0) {
-        break;
-      }
-      __builtin_amdgcn_s_sleep(8);
-    }
-    const int32_t first_pre = pre_mask ? (__ffsll((long long)pre_mask) - 1) : 64;
-    unsigned long long x = (j >= 0 && lane <= first_pre) ? (v & WL_VAL_MASK) : 0ull;
+  for (int32_t hi0 = tile - 1; hi0 >= 0; hi0 -= 64 * GPX_WL_WIDE) {
+    /* GPX_WL_WIDE x 64 words requested together (the older ones are published long since: one round trip for
+     * 256 tiles; the walk's rate - tiles per round trip - is what bounds the whole kernel) */
+    unsigned long long vv[GPX_WL_WIDE];
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, d, 64);
-      const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), d, 64);
-      x += ((unsigned long long)hi << 32) | lo;
+    for (int k = 0; k < GPX_WL_WIDE; k++) {
+      const int32_t j = hi0 - 64 * k - lane;
+      vv[k] = j >= 0 ? __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
     }
-    excl += x;
-    if (pre_mask) break;
+#pragma unroll
+    for (int k = 0; k < GPX_WL_WIDE; k++) {
+      const int32_t hi = hi0 - 64 * k;
+      if (hi < 0) break;
+      const int32_t j = hi - lane; /* lane 0 = the nearest predecessor of this sub-step */
+      unsigned long long v = vv[k];
+      bool need = j >= 0 && (uint32_t)(v >> 40) != epoch;
+      unsigned long long pre_mask;
+      for (;;) {
+        /* the walk stops at the nearest tile with a PREFIX: only lanes nearer than it must be valid */
+        pre_mask = __ballot(!need && j >= 0 && ((v >> 38) & 3ull) == WL_PRE);
+        const unsigned long long wait_mask = __ballot(need);
+        if (pre_mask) {
+          const unsigned long long nearer = (pre_mask & (0ull - pre_mask)) - 1ull;
+          if ((wait_mask & nearer) == 0) break;
+        } else if (wait_mask == 0) {
+          break;
+        }
+        __builtin_amdgcn_s_sleep(8);
+        if (need) {
+          v = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((uint32_t)(v >> 40) == epoch) need = false;
+        }
+      }
+      const int32_t first_pre = pre_mask ? (__ffsll((long long)pre_mask) - 1) : 64;
+      unsigned long long x = (j >= 0 && lane <= first_pre) ? (v & WL_VAL_MASK) : 0ull;
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)x, d, 64);
+        const uint32_t hi32 = (uint32_t)__shfl_xor((int)(uint32_t)(x >> 32), d, 64);
+        x += ((unsigned long long)hi32 << 32) | lo;
+      }
+      excl += x;
+      if (pre_mask) return excl;
+    }
   }
   return excl;
 }
@@ -894,7 +999,7 @@ __device__ __forceinline__ uint32_t wl_lookback(const unsigned long long* __rest
 }
 
 template <int WB>
-__global__ __launch_bounds__(WB) void k_wire_decode1(DevState S, DevNames N, WireLook K, WireOut O,
+__global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(6))) void k_wire_decode1(DevState S, DevNames N, WireLook K, WireOut O,
                                                            int32_t nf, int32_t ntiles,
                                                            const uint8_t* __restrict__ frames,
                                                            const int64_t* __restrict__ frame_off,
@@ -917,7 +1022,7 @@ __global__ __launch_bounds__(WB) void k_wire_decode1(DevState S, DevNames N, Wir
   __syncthreads();
   const int32_t tile = s_tile;
 #ifdef GPX_WD_TRACE
-  if (threadIdx.x == 0) K.trace[(int64_t)tile * 8] = t_entry;
+  if (threadIdx.x == 0) K.trace[(int64_t)tile * 16] = t_entry;
 #endif
   WD_STAMP(1); /* ticket drawn */
   const int32_t i = tile * WB + (int32_t)threadIdx.x;
@@ -955,6 +1060,33 @@ __global__ __launch_bounds__(WB) void k_wire_decode1(DevState S, DevNames N, Wir
     f.gidx = i & (S.G - 1);
     f.type = GPX_WT_BATCHED_ACCEPT_REPLY;
   }
+#elif defined(GPX_WD_EARLY)
+  /* EXPERIMENT: counts published before the name lookup (as if every name resolved), the lookup's round trip
+   * under the look-back; a frame whose lookup fails leaves a hole (not shipped like this) */
+  NameProbe np;
+  np.armed = false;
+  int32_t nm_len = 0, nm_hash = 0, nm_ver = 0;
+  if (live) {
+    if (staged) {
+      const LdsBytes p = (LdsBytes)stage + r0 + lead;
+      w_parse<LdsBytes, false>(S, N, p, f1 - f0, f);
+      if (f.st == GPX_W_OK) {
+        nm_len = f.hdr - 13;
+        nm_ver = w_be32(p + 8);
+        nm_hash = w_java_hash(p + 13, nm_len);
+        np = names_probe(N, p + 13, nm_len, nm_hash);
+      }
+    } else {
+      const GenBytes p = frames + f0;
+      w_parse<GenBytes, false>(S, N, p, f1 - f0, f);
+      if (f.st == GPX_W_OK) {
+        nm_len = f.hdr - 13;
+        nm_ver = w_be32(p + 8);
+        nm_hash = w_java_hash(p + 13, nm_len);
+        np = names_probe(N, p + 13, nm_len, nm_hash);
+      }
+    }
+  }
 #else
   if (live) {
     if (staged)
@@ -965,10 +1097,14 @@ __global__ __launch_bounds__(WB) void k_wire_decode1(DevState S, DevNames N, Wir
 #endif
   WD_STAMP(3); /* thread 0 parsed and looked up */
 #ifdef GPX_WD_TRACE
-  if (threadIdx.x == 0) K.trace[(int64_t)tile * 8 + 7] = f.t_pre; /* ... and when its lookup began */
+  if (threadIdx.x == 0) { /* ... and when its lookup began, its hash was known, its table entry had arrived */
+    K.trace[(int64_t)tile * 16 + 7] = f.t_pre;
+    K.trace[(int64_t)tile * 16 + 8] = f.t_hash;
+    K.trace[(int64_t)tile * 16 + 9] = f.t_load;
+  }
 #endif
-  const int32_t cls = (live && f.st == GPX_W_OK) ? f.cls : -1;
-  const int32_t cnt = cls >= 0 ? f.cnt : 0;
+  int32_t cls = (live && f.st == GPX_W_OK) ? f.cls : -1;
+  int32_t cnt = cls >= 0 ? f.cnt : 0;
   /* records of this tile per class; my offset inside the tile */
   int32_t off = 0;
 #pragma unroll
@@ -1000,6 +1136,24 @@ __global__ __launch_bounds__(WB) void k_wire_decode1(DevState S, DevNames N, Wir
       if (tile == ntiles - 1) (&counts->n_votes)[c] = (int32_t)(excl + mine);
     }
   }
+#ifdef GPX_WD_EARLY
+  if (live && f.st == GPX_W_OK) { /* the lookup's answer; a failure leaves this frame's positions unwritten */
+    bool ex = false;
+    int32_t gver = 0;
+    const int32_t g = staged ? names_probe_finish(N, np, (LdsBytes)stage + r0 + lead + 13, nm_len, nm_hash, &ex, &gver)
+                             : names_probe_finish(N, np, frames + f0 + 13, nm_len, nm_hash, &ex, &gver);
+    if (g < 0 || !ex) {
+      f.st = GPX_W_NOGROUP;
+    } else {
+      f.gidx = g;
+      if (gver != nm_ver) f.st = GPX_W_VERSION;
+    }
+    if (f.st != GPX_W_OK) {
+      cls = -1;
+      cnt = 0;
+    }
+  }
+#endif
   __syncthreads();
   WD_STAMP(5); /* look-back done */
   bool over = false;

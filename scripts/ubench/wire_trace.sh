@@ -8,8 +8,8 @@ cd "$(dirname "$0")/../.."
 V=scripts/ubench/variants
 if [ "$1" = build ]; then
   mkdir -p $V
-  for v in "" NOLOOKBACK NOLOOKUP; do
-    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w -DGPX_WD_TRACE ${v:+-DGPX_WD_$v} -o $V/libgpx_TRACE$v.so gigapaxos_amd/csrc/gpx_engine.hip &
+  for v in "" EARLY; do
+    hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w -DGPX_WD_TRACE ${v:+-DGPX_WD_$v} -o $V/libgpx_TRACE$(echo "$v" | sed "s/ -DGPX_//g; s/=//g").so gigapaxos_amd/csrc/gpx_engine.hip &
   done
   wait
   ls -la $V/libgpx_TRACE*.so
