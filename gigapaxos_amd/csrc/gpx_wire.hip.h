@@ -142,7 +142,7 @@ __device__ __forceinline__ int32_t names_way(const DevNames& N, const NameKeys& 
     return -2;
   const int32_t g = v - 1;
   /* written BEFORE the tail is compared (a caller looks at them only when a row comes back): with the two
-   * stores behind the loop, hipcc 7.2 dropped them for names longer than 16 bytes - the decode fuzz caught it */
+   * stores behind the loop they were lost for names longer than 16 bytes (hipcc 7.2; the decode fuzz caught it) */
   if (exists) *exists = ((meta >> 8) & 0xffu) != 0;
   if (version) *version = ver;
   for (int32_t i = NM_HOT; i < len; i++)
@@ -150,18 +150,20 @@ __device__ __forceinline__ int32_t names_way(const DevNames& N, const NameKeys& 
   return g;
 }
 /* MultiArrayMap.get(paxosID) (PaxosManager.getInstance, PaxosManager.java:1816-1832): row or -1, walking the
- * buckets from b on; `first` = bucket b if the caller already has it.  The first 16 name bytes of the probe
- * are packed into four dwords once. */
+ * buckets from the name's home bucket on.  The first 16 name bytes of the probe are packed into four dwords
+ * once. */
 template <class BP>
-__device__ __forceinline__ int32_t names_walk(const DevNames& N, BP p, int32_t len, int32_t hash, uint32_t b,
-                                              const NameKeys* first, bool* exists, int32_t* version) {
+__device__ __forceinline__ int32_t names_find(const DevNames& N, BP p, int32_t len, int32_t hash,
+                                              bool* exists = nullptr, int32_t* version = nullptr) {
+  if (!N.tab) return -1;
+  uint32_t b = w_fmix32((uint32_t)hash) & N.bmask();
   uint32_t q[4] = {0, 0, 0, 0};
 #pragma unroll
   for (int32_t i = 0; i < NM_HOT; i++)
     if (i < len) q[i >> 2] |= (uint32_t)p[i] << (8 * (i & 3));
   const uint32_t bm = N.bmask();
   for (uint32_t probe = 0; probe <= bm; probe++) {
-    const NameKeys K = (probe == 0 && first) ? *first : names_keys(N, b);
+    const NameKeys K = names_keys(N, b);
     int32_t g;
     if ((g = names_way<0>(N, K, p, len, hash, q, exists, version)) != -2) return g;
     if ((g = names_way<1>(N, K, p, len, hash, q, exists, version)) != -2) return g;
@@ -173,37 +175,6 @@ __device__ __forceinline__ int32_t names_walk(const DevNames& N, BP p, int32_t l
   }
   return -1;
 }
-template <class BP>
-__device__ __forceinline__ int32_t names_find(const DevNames& N, BP p, int32_t len, int32_t hash,
-                                              bool* exists = nullptr, int32_t* version = nullptr) {
-  if (!N.tab) return -1;
-  return names_walk(N, p, len, hash, w_fmix32((uint32_t)hash) & N.bmask(), nullptr, exists, version);
-}
-
-/* names_find in two halves: the keys of the home bucket are REQUESTED here and judged there, so that
- * whatever the caller does in between overlaps the round trip */
-struct NameProbe {
-  NameKeys K;
-  uint32_t b;
-  bool armed;
-};
-template <class BP>
-__device__ __forceinline__ NameProbe names_probe(const DevNames& N, BP p, int32_t len, int32_t hash) {
-  NameProbe q;
-  q.armed = N.tab != nullptr && len > 0;
-  q.b = w_fmix32((uint32_t)hash) & N.bmask();
-#pragma unroll
-  for (int i = 0; i < 8; i++) q.K.q[i] = make_uint4(0, 0, 0, 0);
-  if (q.armed) q.K = names_keys(N, q.b);
-  return q;
-}
-template <class BP>
-__device__ __forceinline__ int32_t names_probe_finish(const DevNames& N, const NameProbe& q, BP p, int32_t len,
-                                                      int32_t hash, bool* exists, int32_t* version) {
-  if (!q.armed) return -1;
-  return names_walk(N, p, len, hash, q.b, &q.K, exists, version);
-}
-
 __global__ __launch_bounds__(GPX_BLOCK) void k_names_bind(DevState S, DevNames N, int32_t G, int32_t n,
                                                          const uint8_t* __restrict__ names,
                                                          const int32_t* __restrict__ name_off,
@@ -439,7 +410,7 @@ struct WFrame {
   bool stop;
   int64_t req_id, tail;             /* ACCEPT: byte position of the slot / ballot tail */
 #ifdef GPX_WD_TRACE
-  unsigned long long t_pre, t_hash, t_load;
+  unsigned long long t_pre;
 #endif
 };
 
@@ -470,7 +441,7 @@ __device__ __forceinline__ int32_t w_list_distinct(BP e, int32_t n, int32_t stri
 /* PaxosPacketDemultiplexerFast.toPaxosPacket (paxosutil/PaxosPacketDemultiplexerFast.java:66-103)
  * + the four ByteBuffer constructors + PaxosManager.handlePaxosPacket's getInstance / version test
  * (PaxosManager.java:1153-1162), for one frame. */
-template <class BP, bool LOOKUP = true>
+template <class BP>
 __device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, WFrame& f) {
   f.st = GPX_W_MALFORMED;
   f.type = -1;
@@ -545,10 +516,6 @@ __device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, W
     f.cnt = 1;
   }
   f.type = t;
-  if (!LOOKUP) { /* the caller looks the name up itself (k_wire_decode1 overlaps it with its look-back) */
-    f.st = GPX_W_OK;
-    return;
-  }
   /* getInstance(paxosID) and the version check */
   int32_t g = -1;
   bool exists = false;
@@ -563,18 +530,8 @@ __device__ void w_parse(const DevState& S, const DevNames& N, BP p, int64_t L, W
 #ifdef GPX_WD_TRACE
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); /* the parse's own loads are back */
   f.t_pre = wall_clock64();
-  if (idl > 0) {
-    const int32_t hh = w_java_hash(p + 13, idl);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    f.t_hash = wall_clock64();
-    const NameProbe np = names_probe(N, p + 13, idl, hh);
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    f.t_load = wall_clock64();
-    g = names_probe_finish(N, np, p + 13, idl, hh, &exists, &gver);
-  }
-#else
-  if (idl > 0) g = names_find(N, p + 13, idl, w_java_hash(p + 13, idl), &exists, &gver);
 #endif
+  if (idl > 0) g = names_find(N, p + 13, idl, w_java_hash(p + 13, idl), &exists, &gver);
 #endif
   if (g < 0 || !exists) {
     f.st = GPX_W_NOGROUP;
@@ -1060,33 +1017,6 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(6))) void k_
     f.gidx = i & (S.G - 1);
     f.type = GPX_WT_BATCHED_ACCEPT_REPLY;
   }
-#elif defined(GPX_WD_EARLY)
-  /* EXPERIMENT: counts published before the name lookup (as if every name resolved), the lookup's round trip
-   * under the look-back; a frame whose lookup fails leaves a hole (not shipped like this) */
-  NameProbe np;
-  np.armed = false;
-  int32_t nm_len = 0, nm_hash = 0, nm_ver = 0;
-  if (live) {
-    if (staged) {
-      const LdsBytes p = (LdsBytes)stage + r0 + lead;
-      w_parse<LdsBytes, false>(S, N, p, f1 - f0, f);
-      if (f.st == GPX_W_OK) {
-        nm_len = f.hdr - 13;
-        nm_ver = w_be32(p + 8);
-        nm_hash = w_java_hash(p + 13, nm_len);
-        np = names_probe(N, p + 13, nm_len, nm_hash);
-      }
-    } else {
-      const GenBytes p = frames + f0;
-      w_parse<GenBytes, false>(S, N, p, f1 - f0, f);
-      if (f.st == GPX_W_OK) {
-        nm_len = f.hdr - 13;
-        nm_ver = w_be32(p + 8);
-        nm_hash = w_java_hash(p + 13, nm_len);
-        np = names_probe(N, p + 13, nm_len, nm_hash);
-      }
-    }
-  }
 #else
   if (live) {
     if (staged)
@@ -1097,14 +1027,10 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(6))) void k_
 #endif
   WD_STAMP(3); /* thread 0 parsed and looked up */
 #ifdef GPX_WD_TRACE
-  if (threadIdx.x == 0) { /* ... and when its lookup began, its hash was known, its table entry had arrived */
-    K.trace[(int64_t)tile * 16 + 7] = f.t_pre;
-    K.trace[(int64_t)tile * 16 + 8] = f.t_hash;
-    K.trace[(int64_t)tile * 16 + 9] = f.t_load;
-  }
+  if (threadIdx.x == 0) K.trace[(int64_t)tile * 16 + 7] = f.t_pre; /* ... and when its lookup began */
 #endif
-  int32_t cls = (live && f.st == GPX_W_OK) ? f.cls : -1;
-  int32_t cnt = cls >= 0 ? f.cnt : 0;
+  const int32_t cls = (live && f.st == GPX_W_OK) ? f.cls : -1;
+  const int32_t cnt = cls >= 0 ? f.cnt : 0;
   /* records of this tile per class; my offset inside the tile */
   int32_t off = 0;
 #pragma unroll
@@ -1136,24 +1062,6 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(6))) void k_
       if (tile == ntiles - 1) (&counts->n_votes)[c] = (int32_t)(excl + mine);
     }
   }
-#ifdef GPX_WD_EARLY
-  if (live && f.st == GPX_W_OK) { /* the lookup's answer; a failure leaves this frame's positions unwritten */
-    bool ex = false;
-    int32_t gver = 0;
-    const int32_t g = staged ? names_probe_finish(N, np, (LdsBytes)stage + r0 + lead + 13, nm_len, nm_hash, &ex, &gver)
-                             : names_probe_finish(N, np, frames + f0 + 13, nm_len, nm_hash, &ex, &gver);
-    if (g < 0 || !ex) {
-      f.st = GPX_W_NOGROUP;
-    } else {
-      f.gidx = g;
-      if (gver != nm_ver) f.st = GPX_W_VERSION;
-    }
-    if (f.st != GPX_W_OK) {
-      cls = -1;
-      cnt = 0;
-    }
-  }
-#endif
   __syncthreads();
   WD_STAMP(5); /* look-back done */
   bool over = false;

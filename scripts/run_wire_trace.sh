@@ -1,2 +1,2 @@
 #!/bin/bash
-TILES=${TILES:-512} VARIANTS="${VARIANTS:-EARLY}" bash "$(dirname "$0")/ubench/wire_trace.sh" run
+TILES=${TILES:-512} VARIANTS="${VARIANTS:-}" bash "$(dirname "$0")/ubench/wire_trace.sh" run

@@ -8,7 +8,7 @@ cd "$(dirname "$0")/../.."
 V=scripts/ubench/variants
 if [ "$1" = build ]; then
   mkdir -p $V
-  for v in "" EARLY; do
+  for v in "" NOLOOKBACK NOLOOKUP; do
     hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -shared -w -DGPX_WD_TRACE ${v:+-DGPX_WD_$v} -o $V/libgpx_TRACE$(echo "$v" | sed "s/ -DGPX_//g; s/=//g").so gigapaxos_amd/csrc/gpx_engine.hip &
   done
   wait

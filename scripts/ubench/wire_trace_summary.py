@@ -13,8 +13,7 @@ us = (t - t0) / 100.0
 n = us.shape[0]
 print(f"tiles {n}  kernel span {us[:, 6].max():.1f} us  (first entry -> last tile written)")
 names = [("entry -> ticket", 0, 1), ("ticket -> staged", 1, 2), ("staged -> own lookup begins (own parse)", 2, 7),
-         ("own lookup", 7, 3), ("  of it: String.hashCode over the name in LDS", 7, 8), ("  of it: the table entry's round trip", 8, 9),
-         ("  of it: compare", 9, 3), ("own parse done -> all lanes parsed + scans", 3, 4), ("look-back", 4, 5),
+         ("own lookup", 7, 3), ("own parse done -> all lanes parsed + scans", 3, 4), ("look-back", 4, 5),
          ("emit", 5, 6), ("whole tile life", 0, 6)]
 for name, a, b in names:
     d = us[:, b] - us[:, a]
