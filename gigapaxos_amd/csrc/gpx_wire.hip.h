@@ -1195,11 +1195,62 @@ __device__ __forceinline__ int32_t pack_frame_size(const DevState& S, const DevN
   return size;
 }
 
+/* What a row that is ALONE for its group (the usual decision batch: one decided slot per group) needs,
+ * requested in two waves of independent loads - its neighbours' groups and its own kind first, then the
+ * group's name row header, flags and members - instead of the five or six dependent round trips of the
+ * general walk (round 3's decode timeline: a round trip costs 4-5 us under load, the bytes nothing). */
+struct PackAlone {
+  int32_t g, idl, gs, k;
+  bool alone, frame; /* frame: the row opens a frame (a DECISION of an existing, named group) */
+  uint4 r0, r1;      /* MEMBERS: the first 32 bytes of the group's name row */
+};
+template <bool MEMBERS>
+__device__ __forceinline__ PackAlone pack_alone(const DevState& S, const DevNames& N, const PackIn& P, int32_t n,
+                                                int32_t i, int32_t* mem /* [GPX_KMAX_LIMIT] or null */) {
+  PackAlone A;
+  A.g = -1;
+  A.idl = A.gs = A.k = 0;
+  A.alone = A.frame = false;
+  A.r0 = A.r1 = make_uint4(0, 0, 0, 0);
+  if (i >= n) return A;
+  const int32_t g = P.gidx[i];
+  const int32_t gp = i > 0 ? P.gidx[i - 1] : ~g, gn = i + 1 < n ? P.gidx[i + 1] : ~g;
+  const int32_t kind = (int32_t)P.kind[i];
+  A.g = g;
+  A.alone = gp != g && gn != g;
+  if (!A.alone || kind != GPX_D_DECISION || (uint32_t)g >= (uint32_t)S.G || !N.tab) return A;
+  uint32_t hdr; /* length | exists << 8 */
+  if (MEMBERS) { /* the writer wants the header's neighbours too: version and the first name bytes */
+    const uint4* row = (const uint4*)N.row(g);
+    A.r0 = row[0];
+    A.r1 = row[1];
+    hdr = A.r0.y;
+  } else {
+    hdr = *(const uint32_t*)(N.row(g) + 4);
+  }
+  const uint32_t gf = S.g_flags[g];
+  int32_t mm[GPX_KMAX_LIMIT];
+#pragma unroll
+  for (int q = 0; q < GPX_KMAX_LIMIT; q++) mm[q] = q < S.kmax ? S.members[(int64_t)q * S.G + g] : 0;
+  A.idl = (int32_t)(hdr & 0xffu);
+  A.frame = A.idl != 0 && ((hdr >> 8) & 0xffu) != 0;
+  A.k = (int32_t)GF_K(gf);
+#pragma unroll
+  for (int q = 0; q < GPX_KMAX_LIMIT; q++) {
+    A.gs += (q < A.k && mm[q] != S.my_id) ? 1 : 0;
+    if (MEMBERS) mem[q] = mm[q];
+  }
+  return A;
+}
+
 __global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N, PackIn P,
                                                         PackScratch X) {
   const int32_t n = pack_rows(P);
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  const int32_t size = pack_frame_size(S, N, P, X, n, i);
+  const PackAlone A = pack_alone<false>(S, N, P, n, i, nullptr);
+  /* alone: one slot, (13 + idLen) + 12 + 4 (1 + 1 + g + 1) as in pack_frame_size */
+  const int32_t size = A.alone ? (A.frame ? (13 + A.idl + 12 + 4 * (1 + 1 + A.gs + 1) + 3) & ~3 : 0)
+                               : pack_frame_size(S, N, P, X, n, i);
   if (i < n) X.size[i] = size;
   int32_t tb, tf;
   block_exscan(size, &tb);
@@ -1207,42 +1258,6 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N,
   if (threadIdx.x == 0) {
     X.tile_b[blockIdx.x] = tb;
     X.tile_f[blockIdx.x] = tf;
-  }
-}
-
-/* pass 2 (one workgroup): exclusive scan of the tile totals; totals to the caller */
-__global__ __launch_bounds__(GPX_FBLOCK) void k_pack_offsets(PackIn P, PackScratch X,
-                                                            int32_t* n_frames, long long* n_bytes) {
-  const int32_t n = pack_rows(P);
-  const int32_t nt = (n + GPX_BLOCK - 1) / GPX_BLOCK;
-  __shared__ long long run_b;
-  __shared__ int32_t run_f;
-  if (threadIdx.x == 0) {
-    run_b = 0;
-    run_f = 0;
-  }
-  __syncthreads();
-  for (int32_t t0 = 0; t0 < nt; t0 += GPX_FBLOCK) {
-    const int32_t t = t0 + (int32_t)threadIdx.x;
-    const int32_t vb = t < nt ? (int32_t)X.tile_b[t] : 0; /* one tile: < 256 * 1 KiB */
-    const int32_t vf = t < nt ? X.tile_f[t] : 0;
-    int32_t tb, tf;
-    const int32_t eb = block_exscan_n<GPX_FBLOCK>(vb, &tb);
-    const int32_t ef = block_exscan_n<GPX_FBLOCK>(vf, &tf);
-    if (t < nt) {
-      X.tile_b[t] = run_b + eb;
-      X.tile_f[t] = run_f + ef;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      run_b += tb;
-      run_f += tf;
-    }
-    __syncthreads();
-  }
-  if (threadIdx.x == 0) {
-    *n_frames = *X.err ? -1 : run_f;
-    *n_bytes = run_b;
   }
 }
 
@@ -1306,6 +1321,35 @@ __device__ __forceinline__ int32_t pack_commit_frame(const DevState& S, const De
   return 13 + idl + 12 + 4 * (m + 1 + gs + 1);
 }
 
+/* the frame of a row that is alone for its group, from what pack_alone and the caller already hold */
+template <class WR>
+__device__ __forceinline__ int32_t pack_commit_frame_alone(const DevState& S, const DevNames& N, const PackAlone& A,
+                                                           const int32_t* mem, uint4 r0, uint4 r1, int32_t bnum,
+                                                           int32_t bcoord, int32_t median, int32_t slot, WR& w) {
+  const int32_t idl = A.idl;
+  const uint32_t nw[4] = {r0.w, r1.x, r1.y, r1.z};
+  w.put32(GPX_WT_PAXOS_PACKET); /* PaxosPacket.toBytes (PaxosPacket.java:461-476) */
+  w.put32(GPX_WT_BATCHED_COMMIT);
+  w.put32(r0.z);
+  w.put8((uint32_t)idl);
+  const uint8_t* nm = N.name(A.g);
+#pragma unroll
+  for (int32_t b = 0; b < NM_HOT; b++)
+    if (b < idl) w.put8(nw[b >> 2] >> (8 * (b & 3)));
+  for (int32_t b = NM_HOT; b < idl; b++) w.put8(nm[b]);
+  w.put32(bnum);
+  w.put32(bcoord);
+  w.put32(median);
+  w.put32(1);
+  w.put32(slot);
+  w.put32(A.gs);
+#pragma unroll
+  for (int q = 0; q < GPX_KMAX_LIMIT; q++)
+    if (q < A.k && mem[q] != S.my_id) w.put32(mem[q]);
+  w.flush();
+  return 13 + idl + 12 + 4 * (1 + 1 + A.gs + 1);
+}
+
 /* the same accumulator over an LDS staging area */
 struct BEWriterLds {
   uint32_t* w;
@@ -1346,18 +1390,72 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_write(DevState S, DevNames N
                                                          long long cap_bytes,
                                                          long long* __restrict__ frame_off,
                                                          int32_t* __restrict__ frame_len,
-                                                         int32_t* __restrict__ f_gidx) {
+                                                         int32_t* __restrict__ f_gidx, int32_t* __restrict__ n_frames,
+                                                         long long* __restrict__ n_bytes) {
   __shared__ uint32_t stage[GPX_PACK_STAGE_BYTES / 4];
+  __shared__ long long s_b[GPX_BLOCK / 64];
+  __shared__ int32_t s_f[GPX_BLOCK / 64];
   const int32_t n = pack_rows(P);
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  const int32_t size = i < n ? X.size[i] : 0;
+  /* requested first, all independent of one another: the row's own columns, its frame size, the totals of
+   * the tiles before this one ... */
+  const bool in = i < n;
+  const int32_t a_bnum = in ? P.bnum[i] : 0, a_bcoord = in ? P.bcoord[i] : 0, a_median = in ? P.median[i] : 0;
+  const int32_t a_slot = in ? P.slot[i] : 0;
+  const int32_t size = in ? X.size[i] : 0;
+  /* (this tile's base = the bytes and frames of the tiles before it; a separate one-workgroup scan kernel
+   * used to turn k_pack_scan's totals into bases: 10 us of the call) */
+  long long bb = 0;
+  int32_t bf = 0;
+  for (int32_t t0 = threadIdx.x; t0 < (int32_t)blockIdx.x; t0 += 8 * GPX_BLOCK) { /* eight pairs in flight */
+    long long vb[8];
+    int32_t vf[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int32_t t = t0 + k * GPX_BLOCK;
+      const bool ok = t < (int32_t)blockIdx.x;
+      vb[k] = ok ? X.tile_b[t] : 0;
+      vf[k] = ok ? X.tile_f[t] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      bb += vb[k];
+      bf += vf[k];
+    }
+  }
+  /* ... then what an alone row's frame is made of (pack_alone: the second wave of loads) */
+  int32_t mem[GPX_KMAX_LIMIT];
+  const PackAlone A = pack_alone<true>(S, N, P, n, i, mem);
+  const bool fast = A.alone && A.frame;
+  const uint4 r0 = A.r0, r1 = A.r1;
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bb, d, 64);
+    const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)((unsigned long long)bb >> 32), d, 64);
+    bb += (long long)(((unsigned long long)hi << 32) | lo);
+    bf += __shfl_xor(bf, d, 64);
+  }
+  if ((threadIdx.x & 63) == 0) {
+    s_b[threadIdx.x >> 6] = bb;
+    s_f[threadIdx.x >> 6] = bf;
+  }
   int32_t tb, tf;
-  const int32_t eb = block_exscan(size, &tb);
+  const int32_t eb = block_exscan(size, &tb); /* (its barriers publish s_b / s_f) */
   const int32_t ef = block_exscan(size ? 1 : 0, &tf);
-  const long long tile0 = X.tile_b[blockIdx.x];
+  long long tile0 = 0;
+  int32_t frame0 = 0;
+#pragma unroll
+  for (int w = 0; w < GPX_BLOCK / 64; w++) {
+    tile0 += s_b[w];
+    frame0 += s_f[w];
+  }
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { /* totals to the caller */
+    *n_frames = *X.err ? -1 : frame0 + tf;
+    *n_bytes = tile0 + tb;
+  }
   const bool staged = tb <= GPX_PACK_STAGE_BYTES && tile0 + tb <= cap_bytes; /* workgroup-uniform */
   const long long off = tile0 + eb;
-  const int32_t fi = X.tile_f[blockIdx.x] + ef;
+  const int32_t fi = frame0 + ef;
   if (size && (staged || off + size <= cap_bytes)) { /* else: the host sees n_bytes > cap_bytes */
     int32_t len;
     if (staged) {
@@ -1365,13 +1463,13 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_pack_write(DevState S, DevNames N
       w.w = stage + (eb >> 2);
       w.acc = 0;
       w.k = 0;
-      len = pack_commit_frame(S, N, P, n, i, w);
-      const int32_t pad = size - ((len + 3) & ~3); /* frames are 4-byte aligned: nothing to clear */
-      (void)pad;
+      len = fast ? pack_commit_frame_alone(S, N, A, mem, r0, r1, a_bnum, a_bcoord, a_median, a_slot, w)
+                 : pack_commit_frame(S, N, P, n, i, w);
     } else {
       BEWriter w;
       w.init(out + off);
-      len = pack_commit_frame(S, N, P, n, i, w);
+      len = fast ? pack_commit_frame_alone(S, N, A, mem, r0, r1, a_bnum, a_bcoord, a_median, a_slot, w)
+                 : pack_commit_frame(S, N, P, n, i, w);
     }
     frame_off[fi] = off;
     frame_len[fi] = len;
