@@ -125,8 +125,13 @@ struct RunIter {
   }
 };
 
+#ifdef GPX_AC_WAVES /* occupancy sweep builds (scripts/ac_occupancy_sweep.sh): never shipped */
+#define GPX_AC_ATTR __attribute__((amdgpu_waves_per_eu(GPX_AC_WAVES)))
+#else
+#define GPX_AC_ATTR
+#endif
 template <bool COMMIT>
-__global__ __launch_bounds__(GPX_DBLOCK) void k_ac_direct(
+__global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_direct(
     DevState S, DevScratch X, int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
     const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot, const int32_t* __restrict__ median,
     const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
