@@ -364,6 +364,19 @@ def plan(scale=1.0, seed=2024):
     return out
 
 
+def run_long_random(lib, n, lengths=(8, 12), seed=77, orders=("interleaved", "grouped"), inits=("create", "initial")):
+    """Seeded random op sequences far longer than the exhaustive plans reach (a group lives through many
+    accept / commit / placeholder / stop interleavings): n sequences per length."""
+    rng = np.random.default_rng(seed)
+    total = 0
+    for L in lengths:
+        idx = rng.integers(0, len(WIDE), (n, L))
+        seqs = [tuple(WIDE[i] for i in row) for row in idx.tolist()]
+        for i, order in enumerate(orders):
+            total += run_sequences(lib, seqs, init=inits[i % len(inits)], order=order)
+    return total
+
+
 def run_plan(lib, scale=1.0, orders=("interleaved", "grouped"), inits=("create", "initial"), from_disk=(True,),
              promise=False):
     total = 0

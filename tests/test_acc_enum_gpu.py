@@ -19,6 +19,12 @@ def test_acceptor_side_enumerated_against_java_reading_gpu(hip_lib):
     assert all(v > 0 for v in A.COVERAGE.values()), A.COVERAGE
 
 
+def test_acceptor_side_long_random_sequences_gpu(hip_lib):
+    """Seeded random sequences of 8 and 12 ops per group, 120,000 groups per length, both batch orders."""
+    import tests.acc_enum_common as A
+    assert A.run_long_random(hip_lib, 120_000) > 4_000_000
+
+
 def test_acceptor_side_enumerated_under_the_ordered_promise(hip_lib):
     """The same readings with gpx_engine_set_ordered_batches(ACCEPT | COMMIT): grouped batches keep the
     promise, so only the direct kernels run (no partition path launched behind them)."""

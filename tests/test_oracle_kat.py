@@ -468,6 +468,13 @@ def test_acceptor_side_enumerated_against_java_reading(oracle_lib):
     assert all(v > 0 for v in A.COVERAGE.values()), A.COVERAGE
 
 
+def test_acceptor_side_long_random_sequences_against_java_reading(oracle_lib):
+    """The same reading over seeded random sequences of 8 and 12 ops per group (the exhaustive plans stop at 4,
+    the random ones above at 6)."""
+    import tests.acc_enum_common as A
+    assert A.run_long_random(oracle_lib, 30_000) > 1_000_000
+
+
 @pytest.mark.parametrize("K,nprop,init,sample", [(3, 1, [0, 0, 0], None), (3, 2, [1, 0, 2], None), (4, 1, [2, 0, 1, 0], None),
                                                  (5, 1, [0, 2, 1, 0, 3], None), (4, 2, [0, 1, 0, 2], 60_000),
                                                  (3, 3, [2, 1, 0], 60_000)])
