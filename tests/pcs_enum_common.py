@@ -176,3 +176,100 @@ def run_maxcp(lib, K, nprop, init_node_slots, sample=None, seed=0):
     assert (snap["node_slots"][:, :K][live] == want_ns[live]).all()
     e.close()
     return G
+
+
+def model_stream(members, me, nprop, votes, init_node_slots=None):
+    """The same reading driven by an ARBITRARY vote stream instead of main's slot-by-slot, member-by-member loop:
+    votes = [(slot, member index, ballot kind, maxCheckpointedSlot)], ballot kind -1 / 0 / +1 = lower than /
+    equal to / higher than the coordinator's ballot (PaxosCoordinator.handleAcceptReply :210-250: a lower ballot
+    is only logged), any slot (never proposed, decided or preempted long ago), duplicates, any order.
+    Returns (outputs, outstanding slots, coordinator alive, nodeSlotNumbers)."""
+    K = len(members)
+    my = (0, me)
+    node_slots = list(init_node_slots) if init_node_slots is not None else [0] * K
+    proposals = {s: [False] * K for s in range(1, nprop + 1)}
+    coordinator = True
+    out = []
+    for v, (slot, j, bkind, maxcp) in enumerate(votes):
+        if not coordinator:                                      # PaxosCoordinator.handleAcceptReply(c == null)
+            continue
+        if bkind > 0:                                            # ballot.compareTo(getBallot()) > 0
+            if slot in proposals:                                # handleAcceptReplyHigherBallot: myProposals.remove
+                del proposals[slot]
+                out.append((v, slot, my[0], my[1], -1, D_PREEMPTED))
+            if not proposals:                                    # PISM.nullifyCoordinatorIfPreemptedFully (:1361-1364)
+                coordinator = False
+        elif bkind == 0:                                         # handleAcceptReplyMyBallot
+            for i in range(K):                                   # recordSlotNumber: every i with members[i] == acceptor
+                if members[i] == members[j] and node_slots[i] < maxcp:
+                    node_slots[i] = maxcp
+            w = proposals.get(slot)
+            if w is not None:
+                idx = -1
+                for q in range(K):                               # WaitforUtility.getIndex: last match
+                    if members[q] == members[j]:
+                        idx = q
+                w[idx] = True                                    # updateHeardFrom
+                if sum(w) > K // 2:                              # heardFromMajority
+                    srt = sorted(node_slots)                     # getMedianMinus
+                    med = srt[K // 2 - 1] if K % 2 == 0 else srt[K // 2]
+                    del proposals[slot]
+                    out.append((v, slot, my[0], my[1], med, D_DECISION))
+        # else: a reply to a lower ballot: nothing happens
+    return out, proposals, coordinator, node_slots
+
+
+def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower=0.08):
+    """n_groups coordinators with nprop outstanding proposals each, every one fed its own random stream of
+    n_votes accept replies (any member, any slot in [0, nprop + 1], lower / own / higher ballots, checkpoint
+    slots -1 .. nprop) - all in ONE gpx_accept_reply_batch call, the groups interleaved; the decided stream,
+    the coordinator's survival and nodeSlotNumbers of every group against model_stream."""
+    rng = np.random.default_rng(seed)
+    members = list(range(21, 21 + 3 * K, 3))[:K]
+    me = members[0]
+    init = [int(x) for x in rng.integers(0, 2, K)]
+    G = n_groups
+    e = Engine(lib, me, G, kmax=K, window=8, max_batch=G * n_votes + 16)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    rows = hri_create(G, K, me)
+    rows["node_slots"][:, :K] = np.array(init, np.int32)
+    assert (e.create_groups(np.arange(G), mem, K, rows) == S_OK).all()
+    for _ in range(nprop):
+        assert (e.propose(np.arange(G, dtype=np.int32))[4] == S_OK).all()
+    n = G * n_votes
+    slot = rng.integers(0, nprop + 2, n).astype(np.int32)
+    mj = rng.integers(0, K, n).astype(np.int32)
+    u = rng.random(n)
+    bkind = np.where(u < p_higher, 1, np.where(u < p_higher + p_lower, -1, 0)).astype(np.int32)
+    maxcp = rng.integers(-1, nprop + 1, n).astype(np.int32)
+    gcol = np.repeat(np.arange(G, dtype=np.int32), n_votes)
+    bnum = np.where(bkind > 0, 1, 0).astype(np.int32)
+    bcoord = np.where(bkind < 0, me - 1, me).astype(np.int32)
+    acc = np.array(members, np.int32)[mj]
+    expect, final = [], []
+    for p in range(G):
+        lo = p * n_votes
+        votes = list(zip(slot[lo:lo + n_votes].tolist(), mj[lo:lo + n_votes].tolist(), bkind[lo:lo + n_votes].tolist(),
+                         maxcp[lo:lo + n_votes].tolist()))
+        out, _, coord, ns = model_stream(members, me, nprop, votes, init)
+        expect.append(out)
+        final.append((coord, ns))
+    order = np.argsort(np.arange(n) % n_votes, kind="stable")    # interleave the groups, stable per group
+    d = e.accept_reply(gcol[order], bnum[order], bcoord[order], slot[order], acc[order], maxcp[order])
+    got = d.as_tuple_array()
+    gi = 0
+    for p, out in enumerate(expect):
+        rows_p = got[gi:gi + len(out)]
+        want = np.array([(p,) + o[1:] for o in out], np.int32).reshape(-1, 6)
+        assert rows_p.shape == want.shape and (rows_p == want).all(), f"group {p}: {rows_p.tolist()} != {want.tolist()}"
+        gi += len(out)
+    assert gi == got.shape[0]
+    snap, st = e.snapshot(np.arange(G))
+    assert (st == S_OK).all()
+    want_coord = np.array([1 if c else 0 for c, _ in final], np.int32)
+    assert (snap["has_coord"] == want_coord).all()
+    want_ns = np.array([ns for _, ns in final], np.int32)
+    live = want_coord == 1
+    assert (snap["node_slots"][:, :K][live] == want_ns[live]).all()
+    e.close()
+    return G

@@ -44,3 +44,17 @@ def test_pcs_accept_reply_tail_with_checkpoint_slots_enumerated_on_engine(hip_li
     from tests.pcs_enum_common import run_maxcp
     n = run_maxcp(hip_lib, K, nprop, init, sample=sample, seed=K * 10 + nprop)
     assert n == (sample if sample else 8 ** (K * nprop))
+
+
+@pytest.mark.parametrize("hint", [False, True], ids=["partition path", "sorted-runs hint"])
+@pytest.mark.parametrize("K,nprop,G,nv", [(3, 3, 200_000, 24), (5, 4, 100_000, 40), (4, 2, 100_000, 16), (3, 6, 60_000, 60),
+                                          (5, 3, 150_000, 9)])
+def test_pcs_accept_replies_in_any_order_on_engine(hip_lib, monkeypatch, K, nprop, G, nv, hint):
+    """Random accept-reply streams per group (any member, any slot, duplicates, lower / own / higher ballots,
+    checkpoint slots) against tests/pcs_enum_common.model_stream - the reading of
+    PaxosCoordinator.handleAcceptReply (:210-250) and PCS:597-683, 809-825 - in one batch of up to 4 M votes.
+    The batch holds the groups' v-th votes one after the other, i.e. it is nv ascending runs: with the hint
+    (GPX_TRY_RUNS=1) the cases of at most 16 votes per group go through k_ar_runs' general replay."""
+    from tests.pcs_enum_common import run_streams
+    monkeypatch.setenv("GPX_TRY_RUNS", "1" if hint else "0")
+    assert run_streams(hip_lib, K, nprop, G, nv, seed=K * 100 + nprop) == G

@@ -468,6 +468,16 @@ def test_acceptor_side_enumerated_against_java_reading(oracle_lib):
     assert all(v > 0 for v in A.COVERAGE.values()), A.COVERAGE
 
 
+@pytest.mark.parametrize("K,nprop,G,nv", [(3, 3, 60_000, 24), (5, 4, 30_000, 40), (4, 2, 30_000, 16), (3, 6, 20_000, 60)])
+def test_pcs_accept_replies_in_any_order_against_java_reading(oracle_lib, K, nprop, G, nv):
+    """The coordinator side beyond PaxosCoordinatorState.main's loop: every group gets its own random stream of
+    accept replies - any member, any slot (outstanding, decided long ago, never proposed), duplicates, lower /
+    own / higher ballots, checkpoint slots - against tests/pcs_enum_common.model_stream, the same
+    statement-by-statement reading of PaxosCoordinator.handleAcceptReply (:210-250) and PCS:597-683, 809-825."""
+    from tests.pcs_enum_common import run_streams
+    assert run_streams(oracle_lib, K, nprop, G, nv, seed=K * 100 + nprop) == G
+
+
 def test_acceptor_side_long_random_sequences_against_java_reading(oracle_lib):
     """The same reading over seeded random sequences of 8 and 12 ops per group (the exhaustive plans stop at 4,
     the random ones above at 6)."""
