@@ -1,0 +1,201 @@
+"""The WHOLE round - propose -> ACCEPT at every replica -> accept replies -> decision -> BATCHED_COMMIT ->
+in-order execution - against the two independent Python readings of the Java put together:
+
+  coordinator: PCS.propose + initCommander (PaxosCoordinatorState.java:233-263, 841-851: the ACCEPT carries
+               getMajorityCommittedSlot() = getMedianMinus(nodeSlotNumbers) :859-875) and the accept-reply side of
+               tests/pcs_enum_common.model_stream (PaxosCoordinator.java:210-250, PCS:597-683, 809-825)
+  acceptors:   tests/acc_enum_common.Acceptor (PaxosAcceptor.java:302-385, 462-506; PISM:1080-1166, 1432-1528,
+               1619-1701); an ACCEPT_REPLY's maxCheckpointedSlot is what that replica reports (PISM:1137-1140)
+
+Neither is written from oracle/gpx_oracle.cpp.  Three replicas per group, replica 0 the coordinator of every
+group; per round every group proposes once or twice, every message (ACCEPT, reply, commit) of every replica is
+lost with some probability, lost ACCEPTs and commits are sent again a round later (an ACCEPT that arrives after
+its commit's placeholder: reconstructDecision; commits out of order: runs of several slots), replies reach the
+coordinator in random order.  The libraries
+(three engines behind the C-ABI: the oracle on the CPU, the HIP engine on the GPU) get the same traffic as
+batches; every propose result, reply word, status, decision, execution run and final HotRestoreInfo row must
+equal the model's."""
+import numpy as np
+
+from gigapaxos_amd import Engine, hri_create, S_OK, D_DECISION, D_PREEMPTED
+from tests.acc_enum_common import Acceptor, PValue
+
+NODES = [100, 101, 102]
+K = 3
+WINDOW = 16
+
+
+class Coordinator:
+    """PaxosCoordinatorState as created by createHRI: ballot (0, me), active, nextProposalSlot 1."""
+
+    def __init__(self, me):
+        self.my = (0, me)
+        self.next = 1
+        self.node_slots = [0] * K
+        self.proposals = {}           # slot -> WaitforUtility.responded
+        self.alive = True
+
+    def median(self):                 # getMedianMinus
+        srt = sorted(self.node_slots)
+        return srt[K // 2 - 1] if K % 2 == 0 else srt[K // 2]
+
+    def propose(self):
+        """PCS.propose (:233-263) of a non-stop request by an active coordinator -> (slot, bnum, bcoord, median)"""
+        slot = self.next
+        self.next += 1
+        self.proposals[slot] = [False] * K
+        return (slot, self.my[0], self.my[1], self.median())     # initCommander: AcceptPacket(.., median)
+
+    def reply(self, slot, j, ballot, maxcp):
+        """one ACCEPT_REPLY of member j -> None | (slot, bnum, bcoord, median, kind)"""
+        if not self.alive:
+            return None
+        if ballot > self.my:
+            out = None
+            if slot in self.proposals:
+                del self.proposals[slot]
+                out = (slot, self.my[0], self.my[1], -1, D_PREEMPTED)
+            if not self.proposals:
+                self.alive = False
+            return out
+        if ballot < self.my:
+            return None
+        if self.node_slots[j] < maxcp:                           # recordSlotNumber (plain <), before the pstate test
+            self.node_slots[j] = maxcp
+        w = self.proposals.get(slot)
+        if w is None:
+            return None
+        w[j] = True
+        if sum(w) > K // 2:
+            del self.proposals[slot]
+            return (slot, self.my[0], self.my[1], self.median(), D_DECISION)
+        return None
+
+
+def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3):
+    """Returns the number of records compared."""
+    rng = np.random.default_rng(seed)
+    eng = [Engine(lib, NODES[a], G, kmax=K, window=WINDOW, max_batch=8 * G + 64) for a in range(K)]
+    mem = np.tile(np.array(NODES, np.int32), (G, 1))
+    for e in eng:
+        assert (e.create_groups(np.arange(G), mem, K, hri_create(G, K, NODES[0])) == S_OK).all()
+    coord = [Coordinator(NODES[0]) for _ in range(G)]
+    acc = [[Acceptor(1, (0, NODES[0]), -1) for _ in range(G)] for _ in range(K)]
+    pending = [[] for _ in range(K)]        # per replica: ACCEPTs lost on their way, to be sent again
+    pending_c = [[] for _ in range(K)]      # ... and commits
+    checked = 0
+
+    def check_runs(runs, want, what):
+        got = runs.as_tuple_array()
+        exp = np.array(want, np.int32).reshape(-1, 3)
+        assert got.shape == exp.shape and (got == exp).all(), f"{what}: execution runs\n{got[:8]}\n{exp[:8]}"
+
+    for r in range(rounds):
+        accepts = []                        # (g, slot, bnum, bcoord, median) of this round, in proposal order
+        for rep in range(2):
+            gs = np.arange(G, dtype=np.int32) if rep == 0 else np.nonzero(rng.random(G) < p_double)[0].astype(np.int32)
+            # keep the coordinator's window: at most WINDOW - 2 outstanding proposals per group
+            # ... and the acceptors' (the engine's rings hold WINDOW slots from the slowest replica's next slot on; the
+            # Java's maps are unbounded: the model has no such limit, so the traffic stays inside it)
+            gs = np.array([g for g in gs.tolist() if coord[g].alive and len(coord[g].proposals) < WINDOW - 2 and
+                           coord[g].next - min(acc[a][g]._slot for a in range(K)) < WINDOW - 2], np.int32)
+            if gs.shape[0] == 0:
+                continue
+            sl, bn, bc, md, st = eng[0].propose(gs)
+            for i, g in enumerate(gs.tolist()):
+                want = coord[g].propose()
+                assert (int(sl[i]), int(bn[i]), int(bc[i]), int(md[i]), int(st[i])) == want + (S_OK,), f"round {r}: propose {g}"
+                accepts.append((g,) + want)
+            checked += gs.shape[0]
+        votes = []                          # (g, slot, member, bnum, bcoord, maxcp)
+        for a in range(K):
+            todo = pending[a] + accepts     # the retransmissions first, then this round's
+            pending[a] = []
+            lost = rng.random(len(todo)) < p_drop
+            send = [t for t, l in zip(todo, lost) if not l]
+            pending[a] = [t for t, l in zip(todo, lost) if l]
+            if not send:
+                continue
+            # a group's ACCEPTs keep their slot order, the groups are shuffled among each other
+            by_group = {}
+            for t in send:
+                by_group.setdefault(t[0], []).append(t)
+            seq = []
+            keys = list(by_group)
+            rng.shuffle(keys)
+            cursors = {g: 0 for g in keys}
+            live = keys[:]
+            while live:                      # round robin over the shuffled groups: interleaved, per-group order kept
+                nxt = []
+                for g in live:
+                    seq.append(by_group[g][cursors[g]])
+                    cursors[g] += 1
+                    if cursors[g] < len(by_group[g]):
+                        nxt.append(g)
+                live = nxt
+            cols = np.array(seq, np.int32)
+            (rb, rc, rm, rf, st), runs = eng[a].accept(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4])
+            want_runs = []
+            for i, (g, slot, bnum, bcoord, median) in enumerate(seq):
+                status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((bnum, bcoord), slot, median, True, False))
+                assert (int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i])) == (status, wb, wc, wm, wf), \
+                    f"round {r} replica {a}: ACCEPT {seq[i]}"
+                if run is not None:
+                    want_runs.append((g, i, run[0], run[1]))
+                if status == S_OK:
+                    votes.append((g, slot, a, wb, wc, wm))
+            want_runs.sort(key=lambda t: (t[0], t[1]))
+            check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} accept")
+            checked += len(seq)
+        # the replies reach the coordinator in random order, some never
+        votes = [v for v in votes if rng.random() >= p_drop]
+        perm = rng.permutation(len(votes))
+        votes = [votes[i] for i in perm]
+        decisions = []
+        if votes:
+            cols = np.array(votes, np.int32)
+            d = eng[0].accept_reply(cols[:, 0], cols[:, 3], cols[:, 4], cols[:, 1], np.array(NODES, np.int32)[cols[:, 2]], cols[:, 5])
+            want = []
+            for i, (g, slot, a, wb, wc, wm) in enumerate(votes):
+                out = coord[g].reply(slot, a, (wb, wc), wm)
+                if out is not None:
+                    want.append((g, i) + out)
+            want.sort(key=lambda t: (t[0], t[1]))
+            exp = np.array([(t[0],) + t[2:] for t in want], np.int32).reshape(-1, 6)
+            got = d.as_tuple_array()
+            assert got.shape == exp.shape and (got == exp).all(), f"round {r}: decisions"
+            decisions = [t for t in want if t[6] == D_DECISION]
+            checked += len(votes)
+        # BATCHED_COMMITs to every replica, some lost
+        for a in range(K):
+            todo = pending_c[a] + [(t[0], t[2], t[3], t[4], t[5]) for t in decisions]  # g, slot, bnum, bcoord, median
+            lost = rng.random(len(todo)) < p_drop
+            send = [t for t, l in zip(todo, lost) if not l]
+            pending_c[a] = [t for t, l in zip(todo, lost) if l]     # sent again next round (sync of missing decisions)
+            if not send:
+                continue
+            cols = np.array(send, np.int32)
+            st, runs = eng[a].commit(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4])
+            want_runs = []
+            for i, (g, slot, bnum, bcoord, median) in enumerate(cols.tolist()):
+                status, run = acc[a][g].handleBatchedCommitSlot((bnum, bcoord), slot, median)
+                assert int(st[i]) == status, f"round {r} replica {a}: commit {cols[i]}"
+                if run is not None:
+                    want_runs.append((g, i, run[0], run[1]))
+            want_runs.sort(key=lambda t: (t[0], t[1]))
+            check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} commit")
+            checked += len(send)
+    # final rows: acceptor side of every replica, coordinator side of replica 0
+    for a in range(K):
+        snap, st = eng[a].snapshot(np.arange(G))
+        assert (st == S_OK).all()
+        want = np.array([acc[a][g].row() for g in range(G)], np.int32)
+        got = np.stack([snap["acc_slot"], snap["acc_bnum"], snap["acc_bcoord"], snap["acc_gc_slot"]], axis=1)
+        assert (got == want).all(), f"replica {a}: acceptor rows"
+    snap, _ = eng[0].snapshot(np.arange(G))
+    assert (snap["next_proposal_slot"] == np.array([c.next for c in coord], np.int32)).all()
+    assert (snap["node_slots"][:, :K] == np.array([c.node_slots for c in coord], np.int32)).all()
+    executed = sum(acc[a][g]._slot - 1 for a in range(K) for g in range(G))
+    for e in eng:
+        e.close()
+    return checked, executed
