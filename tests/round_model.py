@@ -20,15 +20,14 @@ import numpy as np
 from gigapaxos_amd import Engine, hri_create, S_OK, D_DECISION, D_PREEMPTED
 from tests.acc_enum_common import Acceptor, PValue
 
-NODES = [100, 101, 102]
-K = 3
 WINDOW = 16
 
 
 class Coordinator:
     """PaxosCoordinatorState as created by createHRI: ballot (0, me), active, nextProposalSlot 1."""
 
-    def __init__(self, me):
+    def __init__(self, me, K):
+        self.K = K
         self.my = (0, me)
         self.next = 1
         self.node_slots = [0] * K
@@ -36,6 +35,7 @@ class Coordinator:
         self.alive = True
 
     def median(self):                 # getMedianMinus
+        K = self.K
         srt = sorted(self.node_slots)
         return srt[K // 2 - 1] if K % 2 == 0 else srt[K // 2]
 
@@ -43,7 +43,7 @@ class Coordinator:
         """PCS.propose (:233-263) of a non-stop request by an active coordinator -> (slot, bnum, bcoord, median)"""
         slot = self.next
         self.next += 1
-        self.proposals[slot] = [False] * K
+        self.proposals[slot] = [False] * self.K
         return (slot, self.my[0], self.my[1], self.median())     # initCommander: AcceptPacket(.., median)
 
     def reply(self, slot, j, ballot, maxcp):
@@ -66,20 +66,22 @@ class Coordinator:
         if w is None:
             return None
         w[j] = True
-        if sum(w) > K // 2:
+        if sum(w) > self.K // 2:
             del self.proposals[slot]
             return (slot, self.my[0], self.my[1], self.median(), D_DECISION)
         return None
 
 
-def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3):
-    """Returns the number of records compared."""
+def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3):
+    """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
+    slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
+    NODES = list(range(100, 100 + K))
     eng = [Engine(lib, NODES[a], G, kmax=K, window=WINDOW, max_batch=8 * G + 64) for a in range(K)]
     mem = np.tile(np.array(NODES, np.int32), (G, 1))
     for e in eng:
         assert (e.create_groups(np.arange(G), mem, K, hri_create(G, K, NODES[0])) == S_OK).all()
-    coord = [Coordinator(NODES[0]) for _ in range(G)]
+    coord = [Coordinator(NODES[0], K) for _ in range(G)]
     acc = [[Acceptor(1, (0, NODES[0]), -1) for _ in range(G)] for _ in range(K)]
     pending = [[] for _ in range(K)]        # per replica: ACCEPTs lost on their way, to be sent again
     pending_c = [[] for _ in range(K)]      # ... and commits

@@ -478,13 +478,14 @@ def test_pcs_accept_replies_in_any_order_against_java_reading(oracle_lib, K, npr
     assert run_streams(oracle_lib, K, nprop, G, nv, seed=K * 100 + nprop) == G
 
 
-@pytest.mark.parametrize("G,rounds,seed,p_drop", [(3000, 20, 2, 0.2), (4000, 16, 3, 0.05), (1500, 30, 4, 0.35)])
-def test_whole_round_against_the_two_java_readings_together(oracle_lib, G, rounds, seed, p_drop):
+@pytest.mark.parametrize("G,rounds,seed,p_drop,K", [(3000, 20, 2, 0.2, 3), (4000, 16, 3, 0.05, 3), (1500, 30, 4, 0.35, 3),
+                                                    (2000, 20, 5, 0.2, 5), (1500, 16, 6, 0.1, 4)])
+def test_whole_round_against_the_two_java_readings_together(oracle_lib, G, rounds, seed, p_drop, K):
     """propose -> ACCEPT x 3 -> accept replies -> decision -> BATCHED_COMMIT x 3 -> execution with lost and
     retransmitted messages, three oracle engines against tests/round_model.py (the coordinator reading and the
     acceptor reading of the Java composed; neither written from the oracle)."""
     from tests.round_model import run_rounds
-    checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop)
+    checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K)
     assert checked > G * rounds * 3 and executed > G * rounds // 5
 
 
