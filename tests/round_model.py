@@ -72,7 +72,7 @@ class Coordinator:
         return None
 
 
-def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3):
+def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0):
     """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
     slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
@@ -110,8 +110,21 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3):
                 accepts.append((g,) + want)
             checked += gs.shape[0]
         votes = []                          # (g, slot, member, bnum, bcoord, maxcp)
+        rival = []
+        if p_rival > 0.0:
+            # a rival (node 101, ballot (1, 101)) pushes an ACCEPT of its own for the group's newest slot at the
+            # replicas it reaches: their ballots rise, the coordinator's later ACCEPTs there are answered with the
+            # higher ballot (PaxosAcceptor.acceptAndUpdateBallot :302-322), which preempts its proposals and, once
+            # none is left, makes it resign (PCS:661-683, PISM:1361-1364)
+            for g in np.nonzero(rng.random(G) < p_rival)[0].tolist():
+                if coord[g].next > 1:
+                    rival.append((g, coord[g].next - 1, 1, NODES[1], -1))
         for a in range(K):
-            todo = pending[a] + accepts     # the retransmissions first, then this round's
+            # (never at replica 0: once the coordinator's OWN acceptor has adopted the rival's ballot,
+            # PISM.handleProposal forwards requests to the rival instead of proposing them, PISM:827, 854-886 -
+            # the model stops at the seam it restates)
+            mine = [t for t in rival if a != 0 and rng.random() < 0.6 and t[1] - acc[a][t[0]]._slot >= 0]
+            todo = pending[a] + accepts + mine  # the retransmissions first, then this round's, then the rival's
             pending[a] = []
             lost = rng.random(len(todo)) < p_drop
             send = [t for t, l in zip(todo, lost) if not l]
@@ -144,7 +157,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3):
                     f"round {r} replica {a}: ACCEPT {seq[i]}"
                 if run is not None:
                     want_runs.append((g, i, run[0], run[1]))
-                if status == S_OK:
+                if status == S_OK and (bnum, bcoord) == (0, NODES[0]):   # the rival's replies go to the rival
                     votes.append((g, slot, a, wb, wc, wm))
             want_runs.sort(key=lambda t: (t[0], t[1]))
             check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} accept")
@@ -195,9 +208,12 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3):
         got = np.stack([snap["acc_slot"], snap["acc_bnum"], snap["acc_bcoord"], snap["acc_gc_slot"]], axis=1)
         assert (got == want).all(), f"replica {a}: acceptor rows"
     snap, _ = eng[0].snapshot(np.arange(G))
-    assert (snap["next_proposal_slot"] == np.array([c.next for c in coord], np.int32)).all()
-    assert (snap["node_slots"][:, :K] == np.array([c.node_slots for c in coord], np.int32)).all()
+    alive = np.array([c.alive for c in coord])
+    assert ((snap["has_coord"] != 0) == alive).all(), "coordinators that resigned"
+    assert (snap["next_proposal_slot"][alive] == np.array([c.next for c in coord], np.int32)[alive]).all()
+    assert (snap["node_slots"][:, :K][alive] == np.array([c.node_slots for c in coord], np.int32)[alive]).all()
     executed = sum(acc[a][g]._slot - 1 for a in range(K) for g in range(G))
     for e in eng:
         e.close()
+    run_rounds.resigned = int((~alive).sum())
     return checked, executed

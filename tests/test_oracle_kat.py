@@ -478,15 +478,19 @@ def test_pcs_accept_replies_in_any_order_against_java_reading(oracle_lib, K, npr
     assert run_streams(oracle_lib, K, nprop, G, nv, seed=K * 100 + nprop) == G
 
 
-@pytest.mark.parametrize("G,rounds,seed,p_drop,K", [(3000, 20, 2, 0.2, 3), (4000, 16, 3, 0.05, 3), (1500, 30, 4, 0.35, 3),
-                                                    (2000, 20, 5, 0.2, 5), (1500, 16, 6, 0.1, 4)])
-def test_whole_round_against_the_two_java_readings_together(oracle_lib, G, rounds, seed, p_drop, K):
+@pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival", [(3000, 20, 2, 0.2, 3, 0.0), (4000, 16, 3, 0.05, 3, 0.0),
+                                                            (1500, 30, 4, 0.35, 3, 0.0), (2000, 20, 5, 0.2, 5, 0.0),
+                                                            (1500, 16, 6, 0.1, 4, 0.0), (3000, 20, 21, 0.1, 3, 0.03),
+                                                            (2000, 16, 22, 0.2, 5, 0.05)])
+def test_whole_round_against_the_two_java_readings_together(oracle_lib, G, rounds, seed, p_drop, K, p_rival):
     """propose -> ACCEPT x 3 -> accept replies -> decision -> BATCHED_COMMIT x 3 -> execution with lost and
-    retransmitted messages, three oracle engines against tests/round_model.py (the coordinator reading and the
-    acceptor reading of the Java composed; neither written from the oracle)."""
+    retransmitted messages - and, in the last cases, a rival's ACCEPTs in a higher ballot: NACKs, preempted
+    proposals, coordinators that resign - three (four, five) oracle engines against tests/round_model.py (the
+    coordinator reading and the acceptor reading of the Java composed; neither written from the oracle)."""
     from tests.round_model import run_rounds
-    checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K)
+    checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival)
     assert checked > G * rounds * 3 and executed > G * rounds // 5
+    assert (run_rounds.resigned > G // 10) == (p_rival > 0.0)  # a rival's higher ballot preempts, and only that
 
 
 def test_acceptor_side_long_random_sequences_against_java_reading(oracle_lib):
