@@ -7,6 +7,9 @@ in-order execution - against the two independent Python readings of the Java put
   acceptors:   tests/acc_enum_common.Acceptor (PaxosAcceptor.java:302-385, 462-506; PISM:1080-1166, 1432-1528,
                1619-1701); an ACCEPT_REPLY's maxCheckpointedSlot is what that replica reports (PISM:1137-1140)
 
+  requests:    PISM.handleProposal's choice (PISM:817-888): propose iff PaxosCoordinator.exists(coordinator,
+               paxosState.getBallot()) (PaxosCoordinator.java:168-174), else forward to getBallotCoord()
+
 Neither is written from oracle/gpx_oracle.cpp.  Three replicas per group, replica 0 the coordinator of every
 group; per round every group proposes once or twice, every message (ACCEPT, reply, commit) of every replica is
 lost with some probability, lost ACCEPTs and commits are sent again a round later (an ACCEPT that arrives after
@@ -17,7 +20,7 @@ batches; every propose result, reply word, status, decision, execution run and f
 equal the model's."""
 import numpy as np
 
-from gigapaxos_amd import Engine, hri_create, S_OK, D_DECISION, D_PREEMPTED
+from gigapaxos_amd import Engine, hri_create, S_OK, S_FORWARD, D_DECISION, D_PREEMPTED
 from tests.acc_enum_common import Acceptor, PValue
 
 WINDOW = 16
@@ -85,6 +88,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     acc = [[Acceptor(1, (0, NODES[0]), -1) for _ in range(G)] for _ in range(K)]
     pending = [[] for _ in range(K)]        # per replica: ACCEPTs lost on their way, to be sent again
     pending_c = [[] for _ in range(K)]      # ... and commits
+    forwarded = 0
     checked = 0
 
     def check_runs(runs, want, what):
@@ -99,15 +103,22 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             # keep the coordinator's window: at most WINDOW - 2 outstanding proposals per group
             # ... and the acceptors' (the engine's rings hold WINDOW slots from the slowest replica's next slot on; the
             # Java's maps are unbounded: the model has no such limit, so the traffic stays inside it)
-            gs = np.array([g for g in gs.tolist() if coord[g].alive and len(coord[g].proposals) < WINDOW - 2 and
+            gs = np.array([g for g in gs.tolist() if len(coord[g].proposals) < WINDOW - 2 and
                            coord[g].next - min(acc[a][g]._slot for a in range(K)) < WINDOW - 2], np.int32)
             if gs.shape[0] == 0:
                 continue
             sl, bn, bc, md, st = eng[0].propose(gs)
             for i, g in enumerate(gs.tolist()):
-                want = coord[g].propose()
-                assert (int(sl[i]), int(bn[i]), int(bc[i]), int(md[i]), int(st[i])) == want + (S_OK,), f"round {r}: propose {g}"
-                accepts.append((g,) + want)
+                # PISM.handleProposal (:817-888): propose iff PaxosCoordinator.exists(coordinator, paxosState.getBallot())
+                # (PaxosCoordinator.java:168-174: there is one and its ballot is not below the local acceptor's),
+                # else the request is unicast to paxosState.getBallotCoord()
+                if coord[g].alive and coord[g].my >= acc[0][g].ballot:
+                    want = coord[g].propose()
+                    assert (int(sl[i]), int(bn[i]), int(bc[i]), int(md[i]), int(st[i])) == want + (S_OK,), f"round {r}: propose {g}"
+                    accepts.append((g,) + want)
+                else:
+                    forwarded += 1
+                    assert (int(bn[i]), int(bc[i]), int(st[i])) == acc[0][g].ballot + (S_FORWARD,), f"round {r}: forward {g}"
             checked += gs.shape[0]
         votes = []                          # (g, slot, member, bnum, bcoord, maxcp)
         rival = []
@@ -120,10 +131,9 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                 if coord[g].next > 1:
                     rival.append((g, coord[g].next - 1, 1, NODES[1], -1))
         for a in range(K):
-            # (never at replica 0: once the coordinator's OWN acceptor has adopted the rival's ballot,
-            # PISM.handleProposal forwards requests to the rival instead of proposing them, PISM:827, 854-886 -
-            # the model stops at the seam it restates)
-            mine = [t for t in rival if a != 0 and rng.random() < 0.6 and t[1] - acc[a][t[0]]._slot >= 0]
+            # (at replica 0 as well: once the coordinator's OWN acceptor has adopted the rival's ballot, requests
+            # are forwarded to the rival instead of being proposed)
+            mine = [t for t in rival if rng.random() < (0.25 if a == 0 else 0.6) and t[1] - acc[a][t[0]]._slot >= 0]
             todo = pending[a] + accepts + mine  # the retransmissions first, then this round's, then the rival's
             pending[a] = []
             lost = rng.random(len(todo)) < p_drop
@@ -216,4 +226,5 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     for e in eng:
         e.close()
     run_rounds.resigned = int((~alive).sum())
+    run_rounds.forwarded = forwarded
     return checked, executed
