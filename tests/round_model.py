@@ -10,6 +10,8 @@ in-order execution - against the two independent Python readings of the Java put
   requests:    PISM.handleProposal's choice (PISM:817-888): propose iff PaxosCoordinator.exists(coordinator,
                paxosState.getBallot()) (PaxosCoordinator.java:168-174), else forward to getBallotCoord()
 
+               and the stopped test of PISM.handlePaxosMessage (:456-460) in front of every message
+
 Neither is written from oracle/gpx_oracle.cpp.  Three replicas per group, replica 0 the coordinator of every
 group; per round every group proposes once or twice, every message (ACCEPT, reply, commit) of every replica is
 lost with some probability, lost ACCEPTs and commits are sent again a round later (an ACCEPT that arrives after
@@ -20,7 +22,7 @@ batches; every propose result, reply word, status, decision, execution run and f
 equal the model's."""
 import numpy as np
 
-from gigapaxos_amd import Engine, hri_create, S_OK, S_FORWARD, D_DECISION, D_PREEMPTED
+from gigapaxos_amd import Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STOPPED, A_STOP, D_DECISION, D_PREEMPTED
 from tests.acc_enum_common import Acceptor, PValue
 
 WINDOW = 16
@@ -35,6 +37,7 @@ class Coordinator:
         self.next = 1
         self.node_slots = [0] * K
         self.proposals = {}           # slot -> WaitforUtility.responded
+        self.stops = set()            # outstanding proposals that are stop requests
         self.alive = True
 
     def median(self):                 # getMedianMinus
@@ -42,11 +45,16 @@ class Coordinator:
         srt = sorted(self.node_slots)
         return srt[K // 2 - 1] if K % 2 == 0 else srt[K // 2]
 
-    def propose(self):
-        """PCS.propose (:233-263) of a non-stop request by an active coordinator -> (slot, bnum, bcoord, median)"""
+    def propose(self, stop=False):
+        """PCS.propose (:233-263) by an active coordinator -> (slot, bnum, bcoord, median), or None: "no point
+        enqueuing anything after stop" (:235-239: the previous proposal is still outstanding and is a stop)"""
+        if (self.next - 1) in self.proposals and (self.next - 1) in self.stops:
+            return None
         slot = self.next
         self.next += 1
         self.proposals[slot] = [False] * self.K
+        if stop:
+            self.stops.add(slot)
         return (slot, self.my[0], self.my[1], self.median())     # initCommander: AcceptPacket(.., median)
 
     def reply(self, slot, j, ballot, maxcp):
@@ -57,6 +65,7 @@ class Coordinator:
             out = None
             if slot in self.proposals:
                 del self.proposals[slot]
+                self.stops.discard(slot)
                 out = (slot, self.my[0], self.my[1], -1, D_PREEMPTED)
             if not self.proposals:
                 self.alive = False
@@ -71,11 +80,12 @@ class Coordinator:
         w[j] = True
         if sum(w) > self.K // 2:
             del self.proposals[slot]
+            self.stops.discard(slot)
             return (slot, self.my[0], self.my[1], self.median(), D_DECISION)
         return None
 
 
-def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0):
+def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0):
     """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
     slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
@@ -88,7 +98,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     acc = [[Acceptor(1, (0, NODES[0]), -1) for _ in range(G)] for _ in range(K)]
     pending = [[] for _ in range(K)]        # per replica: ACCEPTs lost on their way, to be sent again
     pending_c = [[] for _ in range(K)]      # ... and commits
-    forwarded = 0
+    forwarded = refused = stopped_props = 0
     checked = 0
 
     def check_runs(runs, want, what):
@@ -107,15 +117,24 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                            coord[g].next - min(acc[a][g]._slot for a in range(K)) < WINDOW - 2], np.int32)
             if gs.shape[0] == 0:
                 continue
-            sl, bn, bc, md, st = eng[0].propose(gs)
+            stop_req = (rng.random(gs.shape[0]) < p_stop).astype(np.uint8)
+            sl, bn, bc, md, st = eng[0].propose(gs, stop_req)
             for i, g in enumerate(gs.tolist()):
+                if acc[0][g].stopped:                               # PISM.handlePaxosMessage :456-460
+                    stopped_props += 1
+                    assert int(st[i]) == S_STOPPED, f"round {r}: proposal to a stopped instance {g}"
+                    continue
                 # PISM.handleProposal (:817-888): propose iff PaxosCoordinator.exists(coordinator, paxosState.getBallot())
                 # (PaxosCoordinator.java:168-174: there is one and its ballot is not below the local acceptor's),
                 # else the request is unicast to paxosState.getBallotCoord()
                 if coord[g].alive and coord[g].my >= acc[0][g].ballot:
-                    want = coord[g].propose()
+                    want = coord[g].propose(bool(stop_req[i]))
+                    if want is None:
+                        refused += 1
+                        assert int(st[i]) == S_REFUSED, f"round {r}: proposal after a stop {g}"
+                        continue
                     assert (int(sl[i]), int(bn[i]), int(bc[i]), int(md[i]), int(st[i])) == want + (S_OK,), f"round {r}: propose {g}"
-                    accepts.append((g,) + want)
+                    accepts.append((g,) + want + (int(stop_req[i]),))
                 else:
                     forwarded += 1
                     assert (int(bn[i]), int(bc[i]), int(st[i])) == acc[0][g].ballot + (S_FORWARD,), f"round {r}: forward {g}"
@@ -129,7 +148,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             # none is left, makes it resign (PCS:661-683, PISM:1361-1364)
             for g in np.nonzero(rng.random(G) < p_rival)[0].tolist():
                 if coord[g].next > 1:
-                    rival.append((g, coord[g].next - 1, 1, NODES[1], -1))
+                    rival.append((g, coord[g].next - 1, 1, NODES[1], -1, 0))
         for a in range(K):
             # (at replica 0 as well: once the coordinator's OWN acceptor has adopted the rival's ballot, requests
             # are forwarded to the rival instead of being proposed)
@@ -159,10 +178,11 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                         nxt.append(g)
                 live = nxt
             cols = np.array(seq, np.int32)
-            (rb, rc, rm, rf, st), runs = eng[a].accept(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4])
+            (rb, rc, rm, rf, st), runs = eng[a].accept(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4],
+                                                       (cols[:, 5] * A_STOP).astype(np.uint8))
             want_runs = []
-            for i, (g, slot, bnum, bcoord, median) in enumerate(seq):
-                status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((bnum, bcoord), slot, median, True, False))
+            for i, (g, slot, bnum, bcoord, median, stop) in enumerate(seq):
+                status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((bnum, bcoord), slot, median, True, bool(stop)))
                 assert (int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i])) == (status, wb, wc, wm, wf), \
                     f"round {r} replica {a}: ACCEPT {seq[i]}"
                 if run is not None:
@@ -182,6 +202,10 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             d = eng[0].accept_reply(cols[:, 0], cols[:, 3], cols[:, 4], cols[:, 1], np.array(NODES, np.int32)[cols[:, 2]], cols[:, 5])
             want = []
             for i, (g, slot, a, wb, wc, wm) in enumerate(votes):
+                if acc[0][g].stopped:                               # PISM.handlePaxosMessage :456-460: dropped
+                    assert int(d.status[i]) == S_STOPPED, f"round {r}: vote for a stopped instance {g}"
+                    continue
+                assert int(d.status[i]) == S_OK
                 out = coord[g].reply(slot, a, (wb, wc), wm)
                 if out is not None:
                     want.append((g, i) + out)
@@ -227,4 +251,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
         e.close()
     run_rounds.resigned = int((~alive).sum())
     run_rounds.forwarded = forwarded
+    run_rounds.refused = refused
+    run_rounds.stopped_props = stopped_props
+    run_rounds.stopped = sum(acc[a][g].stopped for a in range(K) for g in range(G))
     return checked, executed

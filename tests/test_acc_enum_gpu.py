@@ -63,11 +63,14 @@ def test_pcs_accept_replies_in_any_order_on_engine(hip_lib, monkeypatch, K, npro
 @pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival", [(20_000, 24, 12, 0.15, 3, 0.0), (8_000, 30, 13, 0.35, 3, 0.0),
                                                             (30_000, 12, 14, 0.0, 3, 0.0), (10_000, 20, 15, 0.2, 5, 0.0),
                                                             (6_000, 16, 16, 0.1, 4, 0.0), (15_000, 20, 31, 0.1, 3, 0.03),
-                                                            (8_000, 16, 32, 0.2, 5, 0.05)])
+                                                            (8_000, 16, 32, 0.2, 5, 0.05), (12_000, 24, 51, 0.1, 3, -0.02),
+                                                            (8_000, 20, 52, 0.15, 5, 0.03)])
 def test_whole_round_against_the_two_java_readings_together_on_engine(hip_lib, G, rounds, seed, p_drop, K, p_rival):
     """tests/round_model.py on three HIP engines: the whole round with lost and retransmitted messages against
     the coordinator reading and the acceptor reading of the Java composed."""
     from tests.round_model import run_rounds
-    checked, executed = run_rounds(hip_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival)
+    p_stop = 0.02 if seed > 50 else 0.0   # the last two cases: STOP requests among the proposals
+    checked, executed = run_rounds(hip_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=max(p_rival, 0.0), p_stop=p_stop)
     assert checked > G * rounds * 3 and executed > G * rounds // 5
     assert (run_rounds.resigned > G // 10) == (p_rival > 0.0)
+    assert (run_rounds.stopped > G // 4 and run_rounds.refused > 0 and run_rounds.stopped_props > G) == (p_stop > 0.0)

@@ -481,16 +481,20 @@ def test_pcs_accept_replies_in_any_order_against_java_reading(oracle_lib, K, npr
 @pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival", [(3000, 20, 2, 0.2, 3, 0.0), (4000, 16, 3, 0.05, 3, 0.0),
                                                             (1500, 30, 4, 0.35, 3, 0.0), (2000, 20, 5, 0.2, 5, 0.0),
                                                             (1500, 16, 6, 0.1, 4, 0.0), (3000, 20, 21, 0.1, 3, 0.03),
-                                                            (2000, 16, 22, 0.2, 5, 0.05)])
+                                                            (2000, 16, 22, 0.2, 5, 0.05), (3000, 24, 41, 0.1, 3, -0.02),
+                                                            (2000, 20, 42, 0.15, 5, 0.03)])
 def test_whole_round_against_the_two_java_readings_together(oracle_lib, G, rounds, seed, p_drop, K, p_rival):
     """propose -> ACCEPT x 3 -> accept replies -> decision -> BATCHED_COMMIT x 3 -> execution with lost and
     retransmitted messages - and, in the last cases, a rival's ACCEPTs in a higher ballot: NACKs, preempted
-    proposals, coordinators that resign - three (four, five) oracle engines against tests/round_model.py (the
+    proposals, coordinators that resign, requests forwarded; STOP requests: proposals refused behind an
+    outstanding stop, instances that stop and drop everything after - three (four, five) oracle engines against tests/round_model.py (the
     coordinator reading and the acceptor reading of the Java composed; neither written from the oracle)."""
     from tests.round_model import run_rounds
-    checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival)
+    p_stop = 0.02 if seed > 40 else 0.0   # the last two cases: 2 % of the requests are STOP requests (p_rival < 0: no rival)
+    checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=max(p_rival, 0.0), p_stop=p_stop)
     assert checked > G * rounds * 3 and executed > G * rounds // 5
     assert (run_rounds.resigned > G // 10) == (p_rival > 0.0)  # a rival's higher ballot preempts, and only that
+    assert (run_rounds.stopped > G // 4 and run_rounds.refused > 0 and run_rounds.stopped_props > G) == (p_stop > 0.0)
 
 
 def test_acceptor_side_long_random_sequences_against_java_reading(oracle_lib):
