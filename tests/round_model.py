@@ -22,7 +22,8 @@ batches; every propose result, reply word, status, decision, execution run and f
 equal the model's."""
 import numpy as np
 
-from gigapaxos_amd import Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STOPPED, A_STOP, D_DECISION, D_PREEMPTED
+from gigapaxos_amd import (Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STOPPED, A_STOP, C_HASVALUE, C_STOP, D_DECISION,
+                           D_PREEMPTED)
 from tests.acc_enum_common import Acceptor, PValue
 
 WINDOW = 16
@@ -99,6 +100,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     pending = [[] for _ in range(K)]        # per replica: ACCEPTs lost on their way, to be sent again
     pending_c = [[] for _ in range(K)]      # ... and commits
     forwarded = refused = stopped_props = 0
+    stop_slots = set()                      # (group, slot) of the proposals that are STOP requests
     checked = 0
 
     def check_runs(runs, want, what):
@@ -135,6 +137,8 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                         continue
                     assert (int(sl[i]), int(bn[i]), int(bc[i]), int(md[i]), int(st[i])) == want + (S_OK,), f"round {r}: propose {g}"
                     accepts.append((g,) + want + (int(stop_req[i]),))
+                    if stop_req[i]:
+                        stop_slots.add((g, want[0]))
                 else:
                     forwarded += 1
                     assert (int(bn[i]), int(bc[i]), int(st[i])) == acc[0][g].ballot + (S_FORWARD,), f"round {r}: forward {g}"
@@ -215,19 +219,24 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             assert got.shape == exp.shape and (got == exp).all(), f"round {r}: decisions"
             decisions = [t for t in want if t[6] == D_DECISION]
             checked += len(votes)
-        # BATCHED_COMMITs to every replica, some lost
+        # BATCHED_COMMITs to every replica, some lost; a lost one comes again a round later as a full DECISION (its
+        # request value with it: what a replica gets back when it asks for missing decisions, PISM:1432-1478)
         for a in range(K):
-            todo = pending_c[a] + [(t[0], t[2], t[3], t[4], t[5]) for t in decisions]  # g, slot, bnum, bcoord, median
+            todo = pending_c[a] + [(t[0], t[2], t[3], t[4], t[5], 0) for t in decisions]  # g, slot, bnum, bcoord, median, kind
             lost = rng.random(len(todo)) < p_drop
             send = [t for t, l in zip(todo, lost) if not l]
-            pending_c[a] = [t for t, l in zip(todo, lost) if l]     # sent again next round (sync of missing decisions)
+            pending_c[a] = [t[:5] + (C_HASVALUE | (C_STOP if (t[0], t[1]) in stop_slots else 0),)
+                            for t, l in zip(todo, lost) if l]
             if not send:
                 continue
             cols = np.array(send, np.int32)
-            st, runs = eng[a].commit(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4])
+            st, runs = eng[a].commit(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4], cols[:, 5].astype(np.uint8))
             want_runs = []
-            for i, (g, slot, bnum, bcoord, median) in enumerate(cols.tolist()):
-                status, run = acc[a][g].handleBatchedCommitSlot((bnum, bcoord), slot, median)
+            for i, (g, slot, bnum, bcoord, median, kind) in enumerate(cols.tolist()):
+                if kind & C_HASVALUE:
+                    status, run = acc[a][g].handleDecision((bnum, bcoord), slot, median, bool(kind & C_STOP))
+                else:
+                    status, run = acc[a][g].handleBatchedCommitSlot((bnum, bcoord), slot, median)
                 assert int(st[i]) == status, f"round {r} replica {a}: commit {cols[i]}"
                 if run is not None:
                     want_runs.append((g, i, run[0], run[1]))
