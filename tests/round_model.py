@@ -7,6 +7,8 @@ in-order execution - against the two independent Python readings of the Java put
   acceptors:   tests/acc_enum_common.Acceptor (PaxosAcceptor.java:302-385, 462-506; PISM:1080-1166, 1432-1528,
                1619-1701); an ACCEPT_REPLY's maxCheckpointedSlot is what that replica reports (PISM:1137-1140)
 
+  gaps:        getMaxCommittedSlot / getMissingCommittedSlots (PaxosAcceptor.java:405-438) and PISM.shouldSync
+               (PISM:2341-2364) of every replica at the end, against gpx_gap_scan
   requests:    PISM.handleProposal's choice (PISM:817-888): propose iff PaxosCoordinator.exists(coordinator,
                paxosState.getBallot()) (PaxosCoordinator.java:168-174), else forward to getBallotCoord()
 
@@ -84,6 +86,63 @@ class Coordinator:
             self.stops.discard(slot)
             return (slot, self.my[0], self.my[1], self.median(), D_DECISION)
         return None
+
+
+def max_committed_slot(a):
+    """PaxosAcceptor.getMaxCommittedSlot (PaxosAcceptor.java:425-438; no slot near Integer.MAX_VALUE here)"""
+    if a.stopped or not a.committed:
+        return a._slot - 1
+    return max(a.committed)
+
+
+def missing_committed_slots(a, size_limit):
+    """PaxosAcceptor.getMissingCommittedSlots (:405-423): None for a stopped instance"""
+    if a.stopped:
+        return None
+    missing = []
+    maxc = max_committed_slot(a)
+    i = a._slot
+    while i - maxc < 0 and i - (a._slot + size_limit) < 0:
+        # no commit, or a meta-commit without its accept
+        if i not in a.committed or (not a.committed[i].has_value and i not in a.accepted):
+            missing.append(i)
+        i += 1
+    return missing
+
+
+def should_sync(a, threshold, mode):
+    """PISM.shouldSync(getMaxCommittedSlot(), threshold, syncMode) (PISM:2341-2364); mode 0 default, 1 SYNC_TO_PAUSE,
+    2 FORCE_SYNC"""
+    max_decision = max_committed_slot(a)
+    expected = a._slot
+    nontrivial = max_decision - expected >= threshold // 100
+    small = threshold <= 1
+    return (max_decision - expected >= threshold or (expected in (0, 1) and (nontrivial or small)) or
+            (nontrivial and mode == 1) or mode == 2)
+
+
+def check_gaps(eng, acc, G, what):
+    """gpx_gap_scan of every replica against the three readings above; returns the number of groups with a gap"""
+    from gigapaxos_amd import wire as W
+    gaps = 0
+    for a, e in enumerate(eng):
+        we = W.WireEngine(e)
+        for threshold, mode, limit in ((2, 0, 64), (1, 0, 64), (300, 1, 5), (4, 2, 64), (3, 0, 2)):
+            first, maxc, missing, sync, st = W.gap_scan(we, np.arange(G, dtype=np.int32), threshold, mode, limit)
+            for g in range(G):
+                m = acc[a][g]
+                want = missing_committed_slots(m, limit)
+                if want is None:
+                    assert int(st[g]) == S_STOPPED and int(missing[g]) == 0, f"{what} replica {a} group {g}: stopped"
+                    continue
+                mask = 0
+                for s_ in want:
+                    mask |= 1 << (s_ - m._slot)
+                gaps += bool(want) and threshold == 2
+                assert (int(st[g]), int(first[g]), int(maxc[g]), int(missing[g]), int(sync[g])) == \
+                    (S_OK, m._slot, max_committed_slot(m), mask, int(should_sync(m, threshold, mode))), \
+                    f"{what} replica {a} group {g}: gap scan ({threshold}, {mode}, {limit})"
+    return gaps
 
 
 def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0):
@@ -243,6 +302,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             want_runs.sort(key=lambda t: (t[0], t[1]))
             check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} commit")
             checked += len(send)
+    run_rounds.gaps = check_gaps(eng, acc, G, "final")
     # final rows: acceptor side of every replica, coordinator side of replica 0
     for a in range(K):
         snap, st = eng[a].snapshot(np.arange(G))
