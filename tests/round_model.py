@@ -145,17 +145,20 @@ def check_gaps(eng, acc, G, what):
     return gaps
 
 
-def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0):
+def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True):
     """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
     slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
     NODES = list(range(100, 100 + K))
-    eng = [Engine(lib, NODES[a], G, kmax=K, window=WINDOW, max_batch=8 * G + 64) for a in range(K)]
+    # from_disk = PaxosAcceptor.GET_ACCEPTED_PVALUES_FROM_DISK (:75-76) = the engine's GPX_F_ACCEPTS_FROM_DISK: an executed
+    # slot's accept leaves acceptedProposals at once (true) or only when garbage collection reaches it (false)
+    eng = [Engine(lib, NODES[a], G, kmax=K, window=WINDOW, max_batch=8 * G + 64, flags=1 if from_disk else 0)
+           for a in range(K)]
     mem = np.tile(np.array(NODES, np.int32), (G, 1))
     for e in eng:
         assert (e.create_groups(np.arange(G), mem, K, hri_create(G, K, NODES[0])) == S_OK).all()
     coord = [Coordinator(NODES[0], K) for _ in range(G)]
-    acc = [[Acceptor(1, (0, NODES[0]), -1) for _ in range(G)] for _ in range(K)]
+    acc = [[Acceptor(1, (0, NODES[0]), -1, from_disk=from_disk) for _ in range(G)] for _ in range(K)]
     pending = [[] for _ in range(K)]        # per replica: ACCEPTs lost on their way, to be sent again
     pending_c = [[] for _ in range(K)]      # ... and commits
     forwarded = refused = stopped_props = 0
@@ -174,8 +177,11 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             # keep the coordinator's window: at most WINDOW - 2 outstanding proposals per group
             # ... and the acceptors' (the engine's rings hold WINDOW slots from the slowest replica's next slot on; the
             # Java's maps are unbounded: the model has no such limit, so the traffic stays inside it)
+            # (with accepts kept in memory - from_disk false - an executed slot's accept holds its ring entry until
+            # garbage collection reaches it: the oldest live slot of a replica is then acceptedGCSlot + 1)
             gs = np.array([g for g in gs.tolist() if len(coord[g].proposals) < WINDOW - 2 and
-                           coord[g].next - min(acc[a][g]._slot for a in range(K)) < WINDOW - 2], np.int32)
+                           coord[g].next - min(min(acc[a][g]._slot, acc[a][g]._slot if from_disk else acc[a][g].acceptedGCSlot + 1)
+                                               for a in range(K)) < WINDOW - 2], np.int32)
             if gs.shape[0] == 0:
                 continue
             stop_req = (rng.random(gs.shape[0]) < p_stop).astype(np.uint8)

@@ -491,7 +491,8 @@ def test_whole_round_against_the_two_java_readings_together(oracle_lib, G, round
     coordinator reading and the acceptor reading of the Java composed; neither written from the oracle)."""
     from tests.round_model import run_rounds
     p_stop = 0.02 if seed > 40 else 0.0   # the last two cases: 2 % of the requests are STOP requests (p_rival < 0: no rival)
-    checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=max(p_rival, 0.0), p_stop=p_stop)
+    checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=max(p_rival, 0.0), p_stop=p_stop,
+                                   from_disk=seed % 2 == 0)   # odd seeds: GET_ACCEPTED_PVALUES_FROM_DISK = false
     assert checked > G * rounds * 3 and executed > G * rounds // 5
     assert (run_rounds.resigned > G // 10) == (p_rival > 0.0)  # a rival's higher ballot preempts, and only that
     assert (run_rounds.stopped > G // 4 and run_rounds.refused > 0 and run_rounds.stopped_props > G) == (p_stop > 0.0)
