@@ -9,6 +9,8 @@ in-order execution - against the two independent Python readings of the Java put
 
   gaps:        getMaxCommittedSlot / getMissingCommittedSlots (PaxosAcceptor.java:405-438) and PISM.shouldSync
                (PISM:2341-2364) of every replica at the end, against gpx_gap_scan
+  prepares:    PISM.handlePrepare -> PaxosAcceptor.handlePrepare (PaxosAcceptor.java:239-293) of every replica at
+               the end (ballots below / at / above the acceptor's), against gpx_prepare_batch
   requests:    PISM.handleProposal's choice (PISM:817-888): propose iff PaxosCoordinator.exists(coordinator,
                paxosState.getBallot()) (PaxosCoordinator.java:168-174), else forward to getBallotCoord()
 
@@ -26,6 +28,8 @@ import numpy as np
 
 from gigapaxos_amd import (Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STOPPED, A_STOP, C_HASVALUE, C_STOP, D_DECISION,
                            D_PREEMPTED)
+
+P_NACK, P_TOLOG = 1, 2   # GPX_P_NACK, GPX_P_TOLOG (include/gpx.h)
 from tests.acc_enum_common import Acceptor, PValue
 
 WINDOW = 16
@@ -143,6 +147,48 @@ def check_gaps(eng, acc, G, what):
                     (S_OK, m._slot, max_committed_slot(m), mask, int(should_sync(m, threshold, mode))), \
                     f"{what} replica {a} group {g}: gap scan ({threshold}, {mode}, {limit})"
     return gaps
+
+
+def handle_prepare(a, ballot, first_undecided):
+    """PISM.handlePrepare (PISM:900-1006) -> PaxosAcceptor.handlePrepare (PaxosAcceptor.java:239-273) with
+    pruneAcceptedProposals (:283-293) and getMaxGCSlotFirstUndecidedSlot (:275-280):
+    -> None (stopped) | (reply ballot, gc slot, nack, to_log, [(slot, accepted ballot)] ascending)"""
+    if a.stopped:
+        return None
+    prev = a.ballot
+    if ballot > a.ballot:                                  # strictly greater: adopt
+        a.ballot = ballot
+    nack = a.ballot > ballot                               # "send pvalues only if not NACKing"
+    pvalues = [] if nack else sorted((s, pv.ballot) for s, pv in a.accepted.items() if s - first_undecided >= 0)
+    gc = first_undecided - 1 if a.acceptedGCSlot - (first_undecided - 1) < 0 else a.acceptedGCSlot
+    return (a.ballot, gc, nack, prev < a.ballot, pvalues)  # LogMessagingTask iff my ballot got upgraded (:975-983)
+
+
+def check_prepares(eng, acc, G, nodes, rng):
+    """gpx_prepare_batch of every replica - two PREPAREs per group, ballots below / equal to / above the acceptor's,
+    firstUndecidedSlot around its slot - against handle_prepare; returns the number of pvalues carried"""
+    carried = 0
+    for a, e in enumerate(eng):
+        for _ in range(2):
+            pick = rng.integers(0, 4, G)
+            bnum = np.array([0, 0, 1, 2], np.int32)[pick]
+            bcoord = np.array([nodes[0] - 1, nodes[0], nodes[1], nodes[-1]], np.int32)[pick]
+            first = np.array([acc[a][g]._slot for g in range(G)], np.int32) + rng.integers(-2, 3, G).astype(np.int32)
+            (rb, rc, rg, rf, st), rows = e.prepare(np.arange(G, dtype=np.int32), bnum, bcoord, first)
+            want_rows = []
+            for g in range(G):
+                out = handle_prepare(acc[a][g], (int(bnum[g]), int(bcoord[g])), int(first[g]))
+                if out is None:
+                    assert int(st[g]) == S_STOPPED, f"replica {a} group {g}: PREPARE to a stopped instance"
+                    continue
+                ballot, gc, nack, to_log, pv = out
+                assert (int(st[g]), int(rb[g]), int(rc[g]), int(rg[g]), int(rf[g])) == \
+                    (S_OK, ballot[0], ballot[1], gc, (P_NACK if nack else 0) | (P_TOLOG if to_log else 0)), \
+                    f"replica {a} group {g}: PREPARE ({bnum[g]}, {bcoord[g]}) first {first[g]}"
+                want_rows += [(g, s_, b[0], b[1]) for s_, b in pv]
+            assert rows == want_rows, f"replica {a}: accepted pvalues of the prepare replies"
+            carried += len(want_rows)
+    return carried
 
 
 def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True):
@@ -309,6 +355,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} commit")
             checked += len(send)
     run_rounds.gaps = check_gaps(eng, acc, G, "final")
+    run_rounds.carried = check_prepares(eng, acc, G, NODES, rng)   # (raises acceptor ballots: the final rows below see it)
     # final rows: acceptor side of every replica, coordinator side of replica 0
     for a in range(K):
         snap, st = eng[a].snapshot(np.arange(G))

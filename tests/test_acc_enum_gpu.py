@@ -60,8 +60,8 @@ def test_pcs_accept_replies_in_any_order_on_engine(hip_lib, monkeypatch, K, npro
     assert run_streams(hip_lib, K, nprop, G, nv, seed=K * 100 + nprop) == G
 
 
-@pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival", [(20_000, 24, 12, 0.15, 3, 0.0), (8_000, 30, 13, 0.35, 3, 0.0),
-                                                            (30_000, 12, 14, 0.0, 3, 0.0), (10_000, 20, 15, 0.2, 5, 0.0),
+@pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival", [(12_000, 20, 12, 0.15, 3, 0.0), (8_000, 30, 13, 0.35, 3, 0.0),
+                                                            (20_000, 10, 14, 0.0, 3, 0.0), (8_000, 16, 15, 0.2, 5, 0.0),
                                                             (6_000, 16, 16, 0.1, 4, 0.0), (15_000, 20, 31, 0.1, 3, 0.03),
                                                             (8_000, 16, 32, 0.2, 5, 0.05), (12_000, 24, 51, 0.1, 3, -0.02),
                                                             (8_000, 20, 52, 0.15, 5, 0.03)])
