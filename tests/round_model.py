@@ -11,6 +11,10 @@ in-order execution - against the two independent Python readings of the Java put
                (PISM:2341-2364) of every replica at the end, against gpx_gap_scan
   prepares:    PISM.handlePrepare -> PaxosAcceptor.handlePrepare (PaxosAcceptor.java:239-293) of every replica at
                the end (ballots below / at / above the acceptor's), against gpx_prepare_batch
+  failover:    (failover=True) node 0 gone, replica 1 runs for coordinator of every group: makeCoordinator, the
+               PREPAREs at the survivors, PISM.handlePrepareReply -> PaxosCoordinator.handlePrepareReply ->
+               isPrepareAcceptedByMajority / combinePValuesOntoProposals / spawnCommandersForProposals (PCS:271-587;
+               Candidate below), the view change's ACCEPTs at the survivors
   requests:    PISM.handleProposal's choice (PISM:817-888): propose iff PaxosCoordinator.exists(coordinator,
                paxosState.getBallot()) (PaxosCoordinator.java:168-174), else forward to getBallotCoord()
 
@@ -191,7 +195,152 @@ def check_prepares(eng, acc, G, nodes, rng):
     return carried
 
 
-def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True):
+def value_handle(slot, ballot):
+    """the caller's 64-bit key of the request value of an accepted pvalue (any injective function will do)"""
+    return (slot << 24) | (ballot[0] << 12) | (ballot[1] & 0xfff)
+
+
+class Candidate:
+    """A coordinator being elected: PaxosCoordinator.makeCoordinator (PaxosCoordinator.java:66-89) ->
+    new PaxosCoordinatorState(bnum, me, acceptor slot, members, null) (PCS:168-181: nodeSlotNumbers = -1) -> prepare();
+    then PISM.handlePrepareReply (PISM:1008-1068) -> PaxosCoordinator.handlePrepareReply (:264-310) ->
+    isPreemptable, canIgnorePrepareReply, isPrepareAcceptedByMajority, combinePValuesOntoProposals,
+    spawnCommandersForProposals, setCoordinatorActive (PCS:271-587) - without pre-active proposals and stop
+    requests (reproposePreemptedProposals and processStop have nothing to do then)."""
+
+    def __init__(self, K, ballot, slot):
+        self.K = K
+        self.my = ballot
+        self.next = slot
+        self.node_slots = [-1] * K
+        self.carry = {}                 # carryoverProposals: slot -> (ballot, handle)
+        self.heard = [False] * K        # waitforMyBallot
+        self.active = False
+        self.exists = True
+        self.proposals = {}
+
+    def median(self):
+        srt = sorted(self.node_slots)
+        return srt[self.K // 2 - 1] if self.K % 2 == 0 else srt[self.K // 2]
+
+    def prepare_reply(self, j, rballot, gc, pvalues):
+        """-> ('ignored' | 'recorded' | 'preempted' | 'elected', median, [(slot, 'carry' | 'noop', handle)])"""
+        if not self.exists:
+            return ("ignored", 0, [])
+        if not self.active and rballot > self.my:          # getPreActivesIfPreempted: resign
+            self.exists = False
+            return ("preempted", 0, [])
+        if self.active or rballot < self.my or self.heard[j]:   # canIgnorePrepareReply (waitforMyBallot == null once active)
+            return ("ignored", 0, [])
+        min_slot = gc + 1                                  # PrepareReplyPacket.getMinSlot: firstSlot or a lower accepted slot
+        for s_, _, _ in pvalues:
+            if s_ - min_slot < 0:
+                min_slot = s_
+        if self.node_slots[j] - min_slot < 0:              # recordSlotNumber(preply)
+            self.node_slots[j] = min_slot
+        for s_, b, h in pvalues:                           # the pvalue of the highest ballot per slot
+            if s_ not in self.carry or b > self.carry[s_][0]:
+                self.carry[s_] = (b, h)
+        self.heard[j] = True
+        if sum(self.heard) <= self.K // 2:
+            return ("recorded", 0, [])
+        if self.carry:                                     # combinePValuesOntoProposals
+            max_carry = max(self.carry)
+            max_min = max(self.node_slots)                 # getMaxMinCarryoverSlot
+            for cur in range(max_min, max_carry + 1):
+                self.proposals[cur] = ("carry", self.carry[cur][1]) if cur in self.carry else ("noop", 0)
+            self.next = max_carry + 1
+        self.active = True                                 # spawnCommandersForProposals + setCoordinatorActive
+        return ("elected", self.median(), [(s_,) + self.proposals[s_] for s_ in sorted(self.proposals)])
+
+
+def check_failover(eng, acc, G, nodes, rng, K, p_drop):
+    """Node 0 is gone.  Replica 1 runs for coordinator of every group it still serves: gpx_election_begin, the
+    PREPAREs at the survivors (handle_prepare above), their replies at the candidate (Candidate above), the
+    ACCEPTs of the view change at the survivors (Acceptor.handleAccept) - every output against the readings.
+    Returns (groups elected, ACCEPTs of the view change, carried, no-ops)."""
+    from tests.election_common import EB_PREPARING, V_IGNORED, V_RECORDED, V_ELECTED, V_PREEMPTED, E_CARRY, E_NOOP
+    vmap = {"ignored": V_IGNORED, "recorded": V_RECORDED, "elected": V_ELECTED, "preempted": V_PREEMPTED}
+    gs = np.array([g for g in range(G) if not acc[1][g].stopped], np.int32)
+    bnum = np.array([acc[1][g].ballot[0] + 1 for g in gs.tolist()], np.int32)
+    assert (eng[1].election_begin(gs, bnum) == EB_PREPARING).all()
+    cand = {g: Candidate(K, (int(b), nodes[1]), acc[1][g]._slot) for g, b in zip(gs.tolist(), bnum.tolist())}
+    first = np.array([cand[g].next for g in gs.tolist()], np.int32)
+    survivors = list(range(1, K))
+    order = survivors[:]
+    rng.shuffle(order)
+    elected = {}
+    for a in order:                                        # the PREPARE at replica a, its reply at the candidate
+        keep = rng.random(gs.shape[0]) >= p_drop
+        sub, sb, sf = gs[keep], bnum[keep], first[keep]
+        if sub.shape[0] == 0:
+            continue
+        (rb, rc, rg, rf, st), rows = eng[a].prepare(sub, sb, np.full(sub.shape[0], nodes[1], np.int32), sf)
+        pvs = [[] for _ in range(sub.shape[0])]
+        want_rows = []
+        replies = []
+        for i, g in enumerate(sub.tolist()):
+            out = handle_prepare(acc[a][g], (int(sb[i]), nodes[1]), int(sf[i]))
+            if out is None:
+                assert int(st[i]) == S_STOPPED
+                continue
+            ballot, gc, nack, to_log, pv = out
+            assert (int(st[i]), int(rb[i]), int(rc[i]), int(rg[i]), int(rf[i])) == \
+                (S_OK, ballot[0], ballot[1], gc, (P_NACK if nack else 0) | (P_TOLOG if to_log else 0)), f"failover: PREPARE at replica {a} group {g}"
+            want_rows += [(i, s_, b[0], b[1]) for s_, b in pv]
+            pvs[i] = [(s_, b[0], b[1], value_handle(s_, b), 0) for s_, b in pv]
+            replies.append(i)
+        assert rows == want_rows, f"failover: pvalues of replica {a}'s prepare replies"
+        idx = np.array(replies, np.int64)
+        if idx.shape[0] == 0:
+            continue
+        (vk, em, rst), lists = eng[1].prepare_reply(sub[idx], np.full(idx.shape[0], nodes[a], np.int32), rb[idx], rc[idx],
+                                                    rg[idx] + 1, [pvs[i] for i in replies])
+        for q, i in enumerate(replies):
+            g = int(sub[i])
+            kind, med, lst = cand[g].prepare_reply(a, (int(rb[i]), int(rc[i])), int(rg[i]),
+                                                   [(s_, (b0, b1), h) for s_, b0, b1, h, _ in pvs[i]])
+            assert int(rst[q]) == S_OK and int(vk[q]) == vmap[kind], f"failover: reply of replica {a} for group {g}: {kind}"
+            if kind == "elected":
+                assert int(em[q]) == med, f"failover: median of group {g}"
+                got = [(s_, k_, h if k_ == E_CARRY else 0) for s_, k_, h, _ in lists[q]]
+                assert got == [(s_, E_CARRY if k_ == "carry" else E_NOOP, h) for s_, k_, h in lst], f"failover: ACCEPTs of group {g}"
+                elected[g] = (med, lst)
+    # the ACCEPTs of the view change at the survivors, in the new ballot
+    n_acc = n_carry = n_noop = 0
+    for a in survivors:
+        recs = [(g, s_, cand[g].my[0], cand[g].my[1], med) for g, (med, lst) in elected.items() for s_, _, _ in lst]
+        n_carry += sum(k_ == "carry" for _, (_, lst) in elected.items() for _, k_, _ in lst) if a == 1 else 0
+        n_noop += sum(k_ == "noop" for _, (_, lst) in elected.items() for _, k_, _ in lst) if a == 1 else 0
+        if not recs:
+            continue
+        cols = np.array(recs, np.int32)
+        (rb, rc, rm, rf, st), runs = eng[a].accept(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4])
+        want_runs = []
+        for i, (g, s_, b0, b1, med) in enumerate(recs):
+            status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((b0, b1), s_, med, True, False))
+            assert (int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i])) == (status, wb, wc, wm, wf), \
+                f"failover: ACCEPT {recs[i]} at replica {a}"
+            if run is not None:
+                want_runs.append((g, i, run[0], run[1]))
+        want_runs.sort(key=lambda t: (t[0], t[1]))
+        got = runs.as_tuple_array()
+        exp = np.array([(g, f, c) for g, _, f, c in want_runs], np.int32).reshape(-1, 3)
+        assert got.shape == exp.shape and (got == exp).all(), f"failover: execution runs at replica {a}"
+        n_acc += len(recs)
+    # the new coordinators' rows
+    eg = np.array(sorted(elected), np.int32)
+    if eg.shape[0]:
+        snap, st = eng[1].snapshot(eg)
+        assert (st == S_OK).all() and (snap["has_coord"] == 1).all()
+        assert (snap["coord_bnum"] == np.array([cand[g].my[0] for g in eg.tolist()], np.int32)).all()
+        assert (snap["coord_bcoord"] == nodes[1]).all()
+        assert (snap["next_proposal_slot"] == np.array([cand[g].next for g in eg.tolist()], np.int32)).all()
+        assert (snap["node_slots"][:, :K] == np.array([cand[g].node_slots for g in eg.tolist()], np.int32)).all()
+    return len(elected), n_acc, n_carry, n_noop
+
+
+def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True, failover=False):
     """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
     slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
@@ -355,6 +504,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} commit")
             checked += len(send)
     run_rounds.gaps = check_gaps(eng, acc, G, "final")
+    run_rounds.failover = check_failover(eng, acc, G, NODES, rng, K, p_drop) if failover else None
     run_rounds.carried = check_prepares(eng, acc, G, NODES, rng)   # (raises acceptor ballots: the final rows below see it)
     # final rows: acceptor side of every replica, coordinator side of replica 0
     for a in range(K):

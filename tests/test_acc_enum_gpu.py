@@ -75,3 +75,14 @@ def test_whole_round_against_the_two_java_readings_together_on_engine(hip_lib, G
     assert checked > G * rounds * 3 and executed > G * rounds // 5
     assert (run_rounds.resigned > G // 10) == (p_rival > 0.0)
     assert (run_rounds.stopped > G // 4 and run_rounds.refused > 0 and run_rounds.stopped_props > G) == (p_stop > 0.0)
+
+
+@pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival,p_stop", [(6000, 12, 81, 0.1, 3, 0.0, 0.0), (4000, 16, 82, 0.15, 5, 0.03, 0.02)])
+def test_view_change_after_lossy_rounds_against_java_reading_on_engine(hip_lib, G, rounds, seed, p_drop, K, p_rival, p_stop):
+    """tests/round_model.py with failover=True on HIP engines: node 0 dead, replica 1 elected in every group it can
+    win - election_begin, prepare, prepare_reply, the view change's ACCEPTs - against the Candidate reading."""
+    from tests.round_model import run_rounds
+    run_rounds(hip_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop, from_disk=seed % 2 == 0,
+               failover=True)
+    elected, accepts, carried, noops = run_rounds.failover
+    assert elected > G // 5 and carried > G // 8 and accepts == (carried + noops) * (K - 1)

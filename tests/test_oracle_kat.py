@@ -498,6 +498,21 @@ def test_whole_round_against_the_two_java_readings_together(oracle_lib, G, round
     assert (run_rounds.stopped > G // 4 and run_rounds.refused > 0 and run_rounds.stopped_props > G) == (p_stop > 0.0)
 
 
+@pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival,p_stop", [(3000, 12, 71, 0.1, 3, 0.0, 0.0), (2500, 20, 72, 0.15, 3, 0.0, 0.02),
+                                                                   (2000, 16, 73, 0.2, 5, 0.03, 0.0), (2000, 14, 74, 0.3, 4, 0.0, 0.0)])
+def test_view_change_after_lossy_rounds_against_java_reading(oracle_lib, G, rounds, seed, p_drop, K, p_rival, p_stop):
+    """After the lossy rounds of tests/round_model.py node 0 is declared dead and replica 1 runs for coordinator of
+    every group: gpx_election_begin, the PREPAREs at the survivors, gpx_prepare_reply_batch (recorded / elected,
+    the carried-over pvalue of the highest ballot per slot, no-ops in the holes, the median), the view change's
+    ACCEPTs at the survivors and the new coordinators' rows - against a Python reading of
+    PaxosCoordinator.makeCoordinator / handlePrepareReply and PCS:271-587 (Candidate in round_model.py)."""
+    from tests.round_model import run_rounds
+    run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop, from_disk=seed % 2 == 0,
+               failover=True)
+    elected, accepts, carried, noops = run_rounds.failover
+    assert elected > G // 5 and carried > G // 8 and accepts == (carried + noops) * (K - 1)
+
+
 def test_acceptor_side_long_random_sequences_against_java_reading(oracle_lib):
     """The same reading over seeded random sequences of 8 and 12 ops per group (the exhaustive plans stop at 4,
     the random ones above at 6)."""
