@@ -34,6 +34,7 @@ from gigapaxos_amd import (Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STO
                            D_PREEMPTED)
 
 P_NACK, P_TOLOG = 1, 2   # GPX_P_NACK, GPX_P_TOLOG (include/gpx.h)
+PV_STOP = 1              # GPX_PV_STOP
 from tests.acc_enum_common import Acceptor, PValue
 
 WINDOW = 16
@@ -156,14 +157,14 @@ def check_gaps(eng, acc, G, what):
 def handle_prepare(a, ballot, first_undecided):
     """PISM.handlePrepare (PISM:900-1006) -> PaxosAcceptor.handlePrepare (PaxosAcceptor.java:239-273) with
     pruneAcceptedProposals (:283-293) and getMaxGCSlotFirstUndecidedSlot (:275-280):
-    -> None (stopped) | (reply ballot, gc slot, nack, to_log, [(slot, accepted ballot)] ascending)"""
+    -> None (stopped) | (reply ballot, gc slot, nack, to_log, [(slot, accepted ballot, is stop)] ascending)"""
     if a.stopped:
         return None
     prev = a.ballot
     if ballot > a.ballot:                                  # strictly greater: adopt
         a.ballot = ballot
     nack = a.ballot > ballot                               # "send pvalues only if not NACKing"
-    pvalues = [] if nack else sorted((s, pv.ballot) for s, pv in a.accepted.items() if s - first_undecided >= 0)
+    pvalues = [] if nack else sorted((s, pv.ballot, pv.stop) for s, pv in a.accepted.items() if s - first_undecided >= 0)
     gc = first_undecided - 1 if a.acceptedGCSlot - (first_undecided - 1) < 0 else a.acceptedGCSlot
     return (a.ballot, gc, nack, prev < a.ballot, pvalues)  # LogMessagingTask iff my ballot got upgraded (:975-983)
 
@@ -189,7 +190,7 @@ def check_prepares(eng, acc, G, nodes, rng):
                 assert (int(st[g]), int(rb[g]), int(rc[g]), int(rg[g]), int(rf[g])) == \
                     (S_OK, ballot[0], ballot[1], gc, (P_NACK if nack else 0) | (P_TOLOG if to_log else 0)), \
                     f"replica {a} group {g}: PREPARE ({bnum[g]}, {bcoord[g]}) first {first[g]}"
-                want_rows += [(g, s_, b[0], b[1]) for s_, b in pv]
+                want_rows += [(g, s_, b[0], b[1]) for s_, b, _ in pv]
             assert rows == want_rows, f"replica {a}: accepted pvalues of the prepare replies"
             carried += len(want_rows)
     return carried
@@ -205,8 +206,9 @@ class Candidate:
     new PaxosCoordinatorState(bnum, me, acceptor slot, members, null) (PCS:168-181: nodeSlotNumbers = -1) -> prepare();
     then PISM.handlePrepareReply (PISM:1008-1068) -> PaxosCoordinator.handlePrepareReply (:264-310) ->
     isPreemptable, canIgnorePrepareReply, isPrepareAcceptedByMajority, combinePValuesOntoProposals,
-    spawnCommandersForProposals, setCoordinatorActive (PCS:271-587) - without pre-active proposals and stop
-    requests (reproposePreemptedProposals and processStop have nothing to do then)."""
+    reproposePreemptedProposals, spawnCommandersForProposals, setCoordinatorActive (PCS:271-587), with pre-active
+    proposals (PCS.propose while not active, :233-263) - without stop requests (processStop has nothing to do
+    then)."""
 
     def __init__(self, K, ballot, slot):
         self.K = K
@@ -217,14 +219,24 @@ class Candidate:
         self.heard = [False] * K        # waitforMyBallot
         self.active = False
         self.exists = True
-        self.proposals = {}
+        self.proposals = {}             # myProposals: slot -> (kind, handle)
 
     def median(self):
         srt = sorted(self.node_slots)
         return srt[self.K // 2 - 1] if self.K % 2 == 0 else srt[self.K // 2]
 
+    def propose(self, handle, stop=False, kind="preactive"):
+        """PCS.propose while not active (:233-263): the proposal gets the next slot, no ACCEPT goes out - or
+        nothing at all behind a stop (:235-239) -> slot | None"""
+        if (self.next - 1) in self.proposals and self.proposals[self.next - 1][2]:
+            return None
+        slot = self.next
+        self.next += 1
+        self.proposals[slot] = (kind, handle, stop)
+        return slot
+
     def prepare_reply(self, j, rballot, gc, pvalues):
-        """-> ('ignored' | 'recorded' | 'preempted' | 'elected', median, [(slot, 'carry' | 'noop', handle)])"""
+        """-> ('ignored' | 'recorded' | 'preempted' | 'elected', median, [(slot, 'carry' | 'noop' | 'preactive', handle)])"""
         if not self.exists:
             return ("ignored", 0, [])
         if not self.active and rballot > self.my:          # getPreActivesIfPreempted: resign
@@ -233,40 +245,93 @@ class Candidate:
         if self.active or rballot < self.my or self.heard[j]:   # canIgnorePrepareReply (waitforMyBallot == null once active)
             return ("ignored", 0, [])
         min_slot = gc + 1                                  # PrepareReplyPacket.getMinSlot: firstSlot or a lower accepted slot
-        for s_, _, _ in pvalues:
+        for s_, _, _, _ in pvalues:
             if s_ - min_slot < 0:
                 min_slot = s_
         if self.node_slots[j] - min_slot < 0:              # recordSlotNumber(preply)
             self.node_slots[j] = min_slot
-        for s_, b, h in pvalues:                           # the pvalue of the highest ballot per slot
+        for s_, b, h, stop in pvalues:                     # the pvalue of the highest ballot per slot
             if s_ not in self.carry or b > self.carry[s_][0]:
-                self.carry[s_] = (b, h)
+                self.carry[s_] = (b, h, stop)
         self.heard[j] = True
         if sum(self.heard) <= self.K // 2:
             return ("recorded", 0, [])
-        if self.carry:                                     # combinePValuesOntoProposals
+        if self.carry:                                     # combinePValuesOntoProposals (nothing to do without carry-overs)
             max_carry = max(self.carry)
             max_min = max(self.node_slots)                 # getMaxMinCarryoverSlot
+            pre = self.proposals                           # preActives = this.myProposals
+            self.proposals = {}
+            carried = {h for _, h, _ in self.carry.values()}
             for cur in range(max_min, max_carry + 1):
-                self.proposals[cur] = ("carry", self.carry[cur][1]) if cur in self.carry else ("noop", 0)
+                if cur in self.carry:                      # received pvalues dominate pre-active proposals
+                    self.proposals[cur] = ("carry", self.carry[cur][1], self.carry[cur][2])
+                elif cur not in pre:                       # no-op if neither received nor pre-active
+                    self.proposals[cur] = ("noop", 0, False)
+                else:                                      # stick with the pre-active unless a carry-over IS that request
+                    if pre[cur][1] not in carried:         # isDuplicate: RequestPacket.equals = same handle
+                        self.proposals[cur] = pre[cur]
+                    del pre[cur]
             self.next = max_carry + 1
+            for slot in sorted(pre):                       # reproposePreemptedProposals: TreeMap order, this.propose(..)
+                self.propose(pre[slot][1], pre[slot][2])   # (nothing behind a stop)
+            # processStop (:470-535).  Its two conversions compare the ballots of a stop and of a later request; every
+            # proposal was re-stamped with MY ballot when it entered myProposals (ProposalStateAtCoordinator,
+            # PCS:153-157), so the ballots are equal and only `assert (false)` is reached - a no-op in production.
+            # What acts is the end: a stop somewhere but not last -> one more stop request behind everything.
+            if any(st for _, _, st in self.proposals.values()) and not self.proposals[self.next - 1][2]:
+                self.propose(0, True, "newstop")
         self.active = True                                 # spawnCommandersForProposals + setCoordinatorActive
         return ("elected", self.median(), [(s_,) + self.proposals[s_] for s_ in sorted(self.proposals)])
 
 
-def check_failover(eng, acc, G, nodes, rng, K, p_drop):
+def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0):
     """Node 0 is gone.  Replica 1 runs for coordinator of every group it still serves: gpx_election_begin, the
     PREPAREs at the survivors (handle_prepare above), their replies at the candidate (Candidate above), the
     ACCEPTs of the view change at the survivors (Acceptor.handleAccept) - every output against the readings.
     Returns (groups elected, ACCEPTs of the view change, carried, no-ops)."""
-    from tests.election_common import EB_PREPARING, V_IGNORED, V_RECORDED, V_ELECTED, V_PREEMPTED, E_CARRY, E_NOOP
+    from tests.election_common import (EB_PREPARING, V_IGNORED, V_RECORDED, V_ELECTED, V_PREEMPTED, E_CARRY, E_NOOP,
+                                       E_PREACTIVE, E_NEWSTOP, S_PREACTIVE)
+    kmap = {"carry": E_CARRY, "noop": E_NOOP, "preactive": E_PREACTIVE, "newstop": E_NEWSTOP}
     vmap = {"ignored": V_IGNORED, "recorded": V_RECORDED, "elected": V_ELECTED, "preempted": V_PREEMPTED}
     gs = np.array([g for g in range(G) if not acc[1][g].stopped], np.int32)
     bnum = np.array([acc[1][g].ballot[0] + 1 for g in gs.tolist()], np.int32)
     assert (eng[1].election_begin(gs, bnum) == EB_PREPARING).all()
     cand = {g: Candidate(K, (int(b), nodes[1]), acc[1][g]._slot) for g, b in zip(gs.tolist(), bnum.tolist())}
-    first = np.array([cand[g].next for g in gs.tolist()], np.int32)
+    first = np.array([cand[g].next for g in gs.tolist()], np.int32)   # PreparePacket(ballot, paxosState.getSlot())
     survivors = list(range(1, K))
+    # client requests reach the candidate before it is elected: pre-active proposals (PCS.propose while not active);
+    # some of them ARE requests a survivor has already accepted from the dead coordinator (forwarded again by their
+    # clients): combinePValuesOntoProposals must not propose those twice
+    fresh = 1 << 40
+    n_pre = n_dup = 0
+    for rep_ in range(2):
+        sel = np.nonzero(rng.random(gs.shape[0]) < 0.35)[0]
+        # (the engine keeps a proposal list of at most WINDOW slots and refuses a view change that needs more,
+        # GPX_S_WINDOW; the Java's maps are unbounded: pre-active proposals only where the list stays shorter)
+        span = {g: max([s_ - cand[g].next + 1 for a in survivors for s_ in acc[a][g].accepted] + [0]) for g in gs[sel].tolist()}
+        sel = np.array([i for i in sel.tolist() if span[int(gs[i])] + 4 <= WINDOW], np.int64)
+        if sel.shape[0] == 0:
+            continue
+        hs = []
+        for g in gs[sel].tolist():
+            known = [value_handle(s_, pv.ballot) for a in survivors for s_, pv in acc[a][g].accepted.items()
+                     if s_ - cand[g].next >= 0 and not acc[a][g].stopped]
+            if known and rng.random() < 0.4:
+                hs.append(known[int(rng.integers(0, len(known)))])
+                n_dup += 1
+            else:
+                fresh += 1
+                hs.append(fresh)
+        stops = (rng.random(sel.shape[0]) < p_stop * 5).astype(np.uint8)
+        sl, bn, bc, md, st = eng[1].propose(gs[sel], stops, handle=np.array(hs, np.int64))
+        for i, g in enumerate(gs[sel].tolist()):
+            want = cand[g].propose(hs[i], bool(stops[i]))
+            if want is None:
+                assert int(st[i]) == S_REFUSED, f"failover: pre-active proposal behind a stop, group {g}"
+                continue
+            assert (int(sl[i]), int(bn[i]), int(bc[i]), int(st[i])) == (want,) + cand[g].my + (S_PREACTIVE,), \
+                f"failover: pre-active proposal of group {g}"
+        n_pre += sel.shape[0]
     order = survivors[:]
     rng.shuffle(order)
     elected = {}
@@ -287,8 +352,8 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop):
             ballot, gc, nack, to_log, pv = out
             assert (int(st[i]), int(rb[i]), int(rc[i]), int(rg[i]), int(rf[i])) == \
                 (S_OK, ballot[0], ballot[1], gc, (P_NACK if nack else 0) | (P_TOLOG if to_log else 0)), f"failover: PREPARE at replica {a} group {g}"
-            want_rows += [(i, s_, b[0], b[1]) for s_, b in pv]
-            pvs[i] = [(s_, b[0], b[1], value_handle(s_, b), 0) for s_, b in pv]
+            want_rows += [(i, s_, b[0], b[1]) for s_, b, _ in pv]
+            pvs[i] = [(s_, b[0], b[1], value_handle(s_, b), PV_STOP if stop else 0) for s_, b, stop in pv]
             replies.append(i)
         assert rows == want_rows, f"failover: pvalues of replica {a}'s prepare replies"
         idx = np.array(replies, np.int64)
@@ -299,26 +364,28 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop):
         for q, i in enumerate(replies):
             g = int(sub[i])
             kind, med, lst = cand[g].prepare_reply(a, (int(rb[i]), int(rc[i])), int(rg[i]),
-                                                   [(s_, (b0, b1), h) for s_, b0, b1, h, _ in pvs[i]])
-            assert int(rst[q]) == S_OK and int(vk[q]) == vmap[kind], f"failover: reply of replica {a} for group {g}: {kind}"
+                                                   [(s_, (b0, b1), h, bool(fl)) for s_, b0, b1, h, fl in pvs[i]])
+            assert int(rst[q]) == S_OK and int(vk[q]) == vmap[kind], \
+                f"failover: reply of replica {a} for group {g}: {kind} {lst} - status {int(rst[q])} kind {int(vk[q])} {lists[q]}"
             if kind == "elected":
                 assert int(em[q]) == med, f"failover: median of group {g}"
-                got = [(s_, k_, h if k_ == E_CARRY else 0) for s_, k_, h, _ in lists[q]]
-                assert got == [(s_, E_CARRY if k_ == "carry" else E_NOOP, h) for s_, k_, h in lst], f"failover: ACCEPTs of group {g}"
+                got = [(s_, k_, h if k_ in (E_CARRY, E_PREACTIVE) else 0, bool(fl & PV_STOP)) for s_, k_, h, fl in lists[q]]
+                assert got == [(s_, kmap[k_], h, stop) for s_, k_, h, stop in lst], f"failover: ACCEPTs of group {g}: {got} != {lst}"
                 elected[g] = (med, lst)
     # the ACCEPTs of the view change at the survivors, in the new ballot
     n_acc = n_carry = n_noop = 0
     for a in survivors:
-        recs = [(g, s_, cand[g].my[0], cand[g].my[1], med) for g, (med, lst) in elected.items() for s_, _, _ in lst]
-        n_carry += sum(k_ == "carry" for _, (_, lst) in elected.items() for _, k_, _ in lst) if a == 1 else 0
-        n_noop += sum(k_ == "noop" for _, (_, lst) in elected.items() for _, k_, _ in lst) if a == 1 else 0
+        recs = [(g, s_, cand[g].my[0], cand[g].my[1], med, int(stop)) for g, (med, lst) in elected.items() for s_, _, _, stop in lst]
+        n_carry += sum(k_ == "carry" for _, (_, lst) in elected.items() for _, k_, _, _ in lst) if a == 1 else 0
+        n_noop += sum(k_ != "carry" for _, (_, lst) in elected.items() for _, k_, _, _ in lst) if a == 1 else 0
         if not recs:
             continue
         cols = np.array(recs, np.int32)
-        (rb, rc, rm, rf, st), runs = eng[a].accept(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4])
+        (rb, rc, rm, rf, st), runs = eng[a].accept(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4],
+                                                   (cols[:, 5] * A_STOP).astype(np.uint8))
         want_runs = []
-        for i, (g, s_, b0, b1, med) in enumerate(recs):
-            status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((b0, b1), s_, med, True, False))
+        for i, (g, s_, b0, b1, med, stop) in enumerate(recs):
+            status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((b0, b1), s_, med, True, bool(stop)))
             assert (int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i])) == (status, wb, wc, wm, wf), \
                 f"failover: ACCEPT {recs[i]} at replica {a}"
             if run is not None:
@@ -337,6 +404,8 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop):
         assert (snap["coord_bcoord"] == nodes[1]).all()
         assert (snap["next_proposal_slot"] == np.array([cand[g].next for g in eg.tolist()], np.int32)).all()
         assert (snap["node_slots"][:, :K] == np.array([cand[g].node_slots for g in eg.tolist()], np.int32)).all()
+    check_failover.preactive = (n_pre, n_dup, sum(k_ == "preactive" for _, (_, lst) in elected.items() for _, k_, _, _ in lst))
+    check_failover.newstops = sum(k_ == "newstop" for _, (_, lst) in elected.items() for _, k_, _, _ in lst)
     return len(elected), n_acc, n_carry, n_noop
 
 
@@ -504,7 +573,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} commit")
             checked += len(send)
     run_rounds.gaps = check_gaps(eng, acc, G, "final")
-    run_rounds.failover = check_failover(eng, acc, G, NODES, rng, K, p_drop) if failover else None
+    run_rounds.failover = check_failover(eng, acc, G, NODES, rng, K, p_drop, p_stop) if failover else None
     run_rounds.carried = check_prepares(eng, acc, G, NODES, rng)   # (raises acceptor ballots: the final rows below see it)
     # final rows: acceptor side of every replica, coordinator side of replica 0
     for a in range(K):

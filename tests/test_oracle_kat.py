@@ -504,8 +504,9 @@ def test_view_change_after_lossy_rounds_against_java_reading(oracle_lib, G, roun
     """After the lossy rounds of tests/round_model.py node 0 is declared dead and replica 1 runs for coordinator of
     every group: gpx_election_begin, the PREPAREs at the survivors, gpx_prepare_reply_batch (recorded / elected,
     the carried-over pvalue of the highest ballot per slot, no-ops in the holes, the median), the view change's
-    ACCEPTs at the survivors and the new coordinators' rows - against a Python reading of
-    PaxosCoordinator.makeCoordinator / handlePrepareReply and PCS:271-587 (Candidate in round_model.py)."""
+    ACCEPTs at the survivors and the new coordinators' rows - with pre-active proposals (some of them duplicates of
+    carried requests) and stop requests - against a Python reading of PaxosCoordinator.makeCoordinator /
+    handlePrepareReply and PCS:233-263, 271-587 (Candidate in round_model.py)."""
     from tests.round_model import run_rounds
     run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop, from_disk=seed % 2 == 0,
                failover=True)
