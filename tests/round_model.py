@@ -391,6 +391,7 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0):
                 elected[g] = (med, lst)
     # the ACCEPTs of the view change at the survivors, in the new ballot
     n_acc = n_carry = n_noop = 0
+    votes = []                                             # their replies, on the way to the new coordinator
     for a in survivors:
         recs = [(g, s_, cand[g].my[0], cand[g].my[1], med, int(stop)) for g, (med, lst) in elected.items() for s_, _, _, stop in lst]
         n_carry += sum(k_ == "carry" for _, (_, lst) in elected.items() for _, k_, _, _ in lst) if a == 1 else 0
@@ -407,6 +408,8 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0):
                 f"failover: ACCEPT {recs[i]} at replica {a}"
             if run is not None:
                 want_runs.append((g, i, run[0], run[1]))
+            if status == S_OK:
+                votes.append((g, s_, a, wb, wc, wm))
         want_runs.sort(key=lambda t: (t[0], t[1]))
         got = runs.as_tuple_array()
         exp = np.array([(g, f, c) for g, _, f, c in want_runs], np.int32).reshape(-1, 3)
@@ -424,20 +427,23 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0):
     check_failover.preactive = (n_pre, n_dup, sum(k_ == "preactive" for _, (_, lst) in elected.items() for _, k_, _, _ in lst))
     check_failover.newstops = sum(k_ == "newstop" for _, (_, lst) in elected.items() for _, k_, _, _ in lst)
     check_failover.preempted = (len(preempted), sum(preempted.values()))
+    check_failover.votes = votes
+    check_failover.elected = {g: cand[g] for g in elected}
     pg = np.array(sorted(preempted), np.int32)
     if pg.shape[0]:                                        # PISM.handlePrepareReply: this.coordinator = null
         assert (eng[1].snapshot(pg)[0]["has_coord"] == 0).all()
     return len(elected), n_acc, n_carry, n_noop
 
 
-def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True, failover=False):
+def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True, failover=False,
+               rounds_after=0):
     """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
     slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
     NODES = list(range(100, 100 + K))
     # from_disk = PaxosAcceptor.GET_ACCEPTED_PVALUES_FROM_DISK (:75-76) = the engine's GPX_F_ACCEPTS_FROM_DISK: an executed
     # slot's accept leaves acceptedProposals at once (true) or only when garbage collection reaches it (false)
-    eng = [Engine(lib, NODES[a], G, kmax=K, window=WINDOW, max_batch=8 * G + 64, flags=1 if from_disk else 0)
+    eng = [Engine(lib, NODES[a], G, kmax=K, window=WINDOW, max_batch=32 * G + 64, flags=1 if from_disk else 0)
            for a in range(K)]
     mem = np.tile(np.array(NODES, np.int32), (G, 1))
     for e in eng:
@@ -455,146 +461,171 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
         exp = np.array(want, np.int32).reshape(-1, 3)
         assert got.shape == exp.shape and (got == exp).all(), f"{what}: execution runs\n{got[:8]}\n{exp[:8]}"
 
-    for r in range(rounds):
-        accepts = []                        # (g, slot, bnum, bcoord, median) of this round, in proposal order
-        for rep in range(2):
-            gs = np.arange(G, dtype=np.int32) if rep == 0 else np.nonzero(rng.random(G) < p_double)[0].astype(np.int32)
-            # keep the coordinator's window: at most WINDOW - 2 outstanding proposals per group
-            # ... and the acceptors' (the engine's rings hold WINDOW slots from the slowest replica's next slot on; the
-            # Java's maps are unbounded: the model has no such limit, so the traffic stays inside it)
-            # (with accepts kept in memory - from_disk false - an executed slot's accept holds its ring entry until
-            # garbage collection reaches it: the oldest live slot of a replica is then acceptedGCSlot + 1)
-            gs = np.array([g for g in gs.tolist() if len(coord[g].proposals) < WINDOW - 2 and
-                           coord[g].next - min(min(acc[a][g]._slot, acc[a][g]._slot if from_disk else acc[a][g].acceptedGCSlot + 1)
-                                               for a in range(K)) < WINDOW - 2], np.int32)
-            if gs.shape[0] == 0:
-                continue
-            stop_req = (rng.random(gs.shape[0]) < p_stop).astype(np.uint8)
-            sl, bn, bc, md, st = eng[0].propose(gs, stop_req)
-            for i, g in enumerate(gs.tolist()):
-                if acc[0][g].stopped:                               # PISM.handlePaxosMessage :456-460
-                    stopped_props += 1
-                    assert int(st[i]) == S_STOPPED, f"round {r}: proposal to a stopped instance {g}"
+    def play(rounds_, ci, replicas, coord, p_rival_, first_votes, tag):
+        """rounds_ rounds with replica ci as the coordinator of every group that has one in `coord` (None: no
+        proposals there), messages only among `replicas`; first_votes = accept replies already on their way"""
+        nonlocal checked, forwarded, refused, stopped_props
+        for r_ in range(rounds_):
+            r = f"{tag}{r_}"
+            accepts = []                        # (g, slot, bnum, bcoord, median) of this round, in proposal order
+            for rep in range(2):
+                gs = np.arange(G, dtype=np.int32) if rep == 0 else np.nonzero(rng.random(G) < p_double)[0].astype(np.int32)
+                # keep the coordinator's window: at most WINDOW - 2 outstanding proposals per group
+                # ... and the acceptors' (the engine's rings hold WINDOW slots from the slowest replica's next slot on; the
+                # Java's maps are unbounded: the model has no such limit, so the traffic stays inside it)
+                # (with accepts kept in memory - from_disk false - an executed slot's accept holds its ring entry until
+                # garbage collection reaches it: the oldest live slot of a replica is then acceptedGCSlot + 1)
+                # (the oldest outstanding proposal too: its ring entry is the one slot next - WINDOW would need)
+                gs = np.array([g for g in gs.tolist() if coord[g] is not None and len(coord[g].proposals) < WINDOW - 2 and
+                               coord[g].next - min(coord[g].proposals, default=coord[g].next) < WINDOW - 1 and
+                               coord[g].next - min(min(acc[a][g]._slot, acc[a][g]._slot if from_disk else acc[a][g].acceptedGCSlot + 1)
+                                                   for a in replicas) < WINDOW - 2], np.int32)
+                if gs.shape[0] == 0:
                     continue
-                # PISM.handleProposal (:817-888): propose iff PaxosCoordinator.exists(coordinator, paxosState.getBallot())
-                # (PaxosCoordinator.java:168-174: there is one and its ballot is not below the local acceptor's),
-                # else the request is unicast to paxosState.getBallotCoord()
-                if coord[g].alive and coord[g].my >= acc[0][g].ballot:
-                    want = coord[g].propose(bool(stop_req[i]))
-                    if want is None:
-                        refused += 1
-                        assert int(st[i]) == S_REFUSED, f"round {r}: proposal after a stop {g}"
+                stop_req = (rng.random(gs.shape[0]) < p_stop).astype(np.uint8)
+                sl, bn, bc, md, st = eng[ci].propose(gs, stop_req)
+                for i, g in enumerate(gs.tolist()):
+                    if acc[ci][g].stopped:                              # PISM.handlePaxosMessage :456-460
+                        stopped_props += 1
+                        assert int(st[i]) == S_STOPPED, f"round {r}: proposal to a stopped instance {g}"
                         continue
-                    assert (int(sl[i]), int(bn[i]), int(bc[i]), int(md[i]), int(st[i])) == want + (S_OK,), f"round {r}: propose {g}"
-                    accepts.append((g,) + want + (int(stop_req[i]),))
-                    if stop_req[i]:
-                        stop_slots.add((g, want[0]))
-                else:
-                    forwarded += 1
-                    assert (int(bn[i]), int(bc[i]), int(st[i])) == acc[0][g].ballot + (S_FORWARD,), f"round {r}: forward {g}"
-            checked += gs.shape[0]
-        votes = []                          # (g, slot, member, bnum, bcoord, maxcp)
-        rival = []
-        if p_rival > 0.0:
-            # a rival (node 101, ballot (1, 101)) pushes an ACCEPT of its own for the group's newest slot at the
-            # replicas it reaches: their ballots rise, the coordinator's later ACCEPTs there are answered with the
-            # higher ballot (PaxosAcceptor.acceptAndUpdateBallot :302-322), which preempts its proposals and, once
-            # none is left, makes it resign (PCS:661-683, PISM:1361-1364)
-            for g in np.nonzero(rng.random(G) < p_rival)[0].tolist():
-                if coord[g].next > 1:
-                    rival.append((g, coord[g].next - 1, 1, NODES[1], -1, 0))
-        for a in range(K):
-            # (at replica 0 as well: once the coordinator's OWN acceptor has adopted the rival's ballot, requests
-            # are forwarded to the rival instead of being proposed)
-            mine = [t for t in rival if rng.random() < (0.25 if a == 0 else 0.6) and t[1] - acc[a][t[0]]._slot >= 0]
-            todo = pending[a] + accepts + mine  # the retransmissions first, then this round's, then the rival's
-            pending[a] = []
-            lost = rng.random(len(todo)) < p_drop
-            send = [t for t, l in zip(todo, lost) if not l]
-            pending[a] = [t for t, l in zip(todo, lost) if l]
-            if not send:
-                continue
-            # a group's ACCEPTs keep their slot order, the groups are shuffled among each other
-            by_group = {}
-            for t in send:
-                by_group.setdefault(t[0], []).append(t)
-            seq = []
-            keys = list(by_group)
-            rng.shuffle(keys)
-            cursors = {g: 0 for g in keys}
-            live = keys[:]
-            while live:                      # round robin over the shuffled groups: interleaved, per-group order kept
-                nxt = []
-                for g in live:
-                    seq.append(by_group[g][cursors[g]])
-                    cursors[g] += 1
-                    if cursors[g] < len(by_group[g]):
-                        nxt.append(g)
-                live = nxt
-            cols = np.array(seq, np.int32)
-            (rb, rc, rm, rf, st), runs = eng[a].accept(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4],
-                                                       (cols[:, 5] * A_STOP).astype(np.uint8))
-            want_runs = []
-            for i, (g, slot, bnum, bcoord, median, stop) in enumerate(seq):
-                status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((bnum, bcoord), slot, median, True, bool(stop)))
-                assert (int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i])) == (status, wb, wc, wm, wf), \
-                    f"round {r} replica {a}: ACCEPT {seq[i]}"
-                if run is not None:
-                    want_runs.append((g, i, run[0], run[1]))
-                if status == S_OK and (bnum, bcoord) == (0, NODES[0]):   # the rival's replies go to the rival
-                    votes.append((g, slot, a, wb, wc, wm))
-            want_runs.sort(key=lambda t: (t[0], t[1]))
-            check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} accept")
-            checked += len(seq)
-        # the replies reach the coordinator in random order, some never
-        votes = [v for v in votes if rng.random() >= p_drop]
-        perm = rng.permutation(len(votes))
-        votes = [votes[i] for i in perm]
-        decisions = []
-        if votes:
-            cols = np.array(votes, np.int32)
-            d = eng[0].accept_reply(cols[:, 0], cols[:, 3], cols[:, 4], cols[:, 1], np.array(NODES, np.int32)[cols[:, 2]], cols[:, 5])
-            want = []
-            for i, (g, slot, a, wb, wc, wm) in enumerate(votes):
-                if acc[0][g].stopped:                               # PISM.handlePaxosMessage :456-460: dropped
-                    assert int(d.status[i]) == S_STOPPED, f"round {r}: vote for a stopped instance {g}"
+                    # PISM.handleProposal (:817-888): propose iff PaxosCoordinator.exists(coordinator, paxosState.getBallot())
+                    # (PaxosCoordinator.java:168-174: there is one and its ballot is not below the local acceptor's),
+                    # else the request is unicast to paxosState.getBallotCoord()
+                    if coord[g].alive and coord[g].my >= acc[ci][g].ballot:
+                        want = coord[g].propose(bool(stop_req[i]))
+                        if want is None:
+                            refused += 1
+                            assert int(st[i]) == S_REFUSED, f"round {r}: proposal after a stop {g}"
+                            continue
+                        assert (int(sl[i]), int(bn[i]), int(bc[i]), int(md[i]), int(st[i])) == want + (S_OK,), \
+                            f"round {r}: propose {g}: {(int(sl[i]), int(bn[i]), int(bc[i]), int(md[i]), int(st[i]))} != {want}"
+                        accepts.append((g,) + want + (int(stop_req[i]),))
+                        if stop_req[i]:
+                            stop_slots.add((g, want[0]))
+                    else:
+                        forwarded += 1
+                        assert (int(bn[i]), int(bc[i]), int(st[i])) == acc[ci][g].ballot + (S_FORWARD,), f"round {r}: forward {g}"
+                checked += gs.shape[0]
+            votes = first_votes if r_ == 0 else []   # (g, slot, member, bnum, bcoord, maxcp)
+            rival = []
+            if p_rival_ > 0.0:
+                # a rival (node 101, ballot (1, 101)) pushes an ACCEPT of its own for the group's newest slot at the
+                # replicas it reaches: their ballots rise, the coordinator's later ACCEPTs there are answered with the
+                # higher ballot (PaxosAcceptor.acceptAndUpdateBallot :302-322), which preempts its proposals and, once
+                # none is left, makes it resign (PCS:661-683, PISM:1361-1364)
+                for g in np.nonzero(rng.random(G) < p_rival_)[0].tolist():
+                    if coord[g] is not None and coord[g].next > 1:
+                        rival.append((g, coord[g].next - 1, 1, NODES[1], -1, 0))
+            for a in replicas:
+                # (at replica 0 as well: once the coordinator's OWN acceptor has adopted the rival's ballot, requests
+                # are forwarded to the rival instead of being proposed)
+                mine = [t for t in rival if rng.random() < (0.25 if a == 0 else 0.6) and t[1] - acc[a][t[0]]._slot >= 0]
+                todo = pending[a] + accepts + mine  # the retransmissions first, then this round's, then the rival's
+                pending[a] = []
+                lost = rng.random(len(todo)) < p_drop
+                send = [t for t, l in zip(todo, lost) if not l]
+                pending[a] = [t for t, l in zip(todo, lost) if l]
+                if not send:
                     continue
-                assert int(d.status[i]) == S_OK
-                out = coord[g].reply(slot, a, (wb, wc), wm)
-                if out is not None:
-                    want.append((g, i) + out)
-            want.sort(key=lambda t: (t[0], t[1]))
-            exp = np.array([(t[0],) + t[2:] for t in want], np.int32).reshape(-1, 6)
-            got = d.as_tuple_array()
-            assert got.shape == exp.shape and (got == exp).all(), f"round {r}: decisions"
-            decisions = [t for t in want if t[6] == D_DECISION]
-            checked += len(votes)
-        # BATCHED_COMMITs to every replica, some lost; a lost one comes again a round later as a full DECISION (its
-        # request value with it: what a replica gets back when it asks for missing decisions, PISM:1432-1478)
-        for a in range(K):
-            todo = pending_c[a] + [(t[0], t[2], t[3], t[4], t[5], 0) for t in decisions]  # g, slot, bnum, bcoord, median, kind
-            lost = rng.random(len(todo)) < p_drop
-            send = [t for t, l in zip(todo, lost) if not l]
-            pending_c[a] = [t[:5] + (C_HASVALUE | (C_STOP if (t[0], t[1]) in stop_slots else 0),)
-                            for t, l in zip(todo, lost) if l]
-            if not send:
-                continue
-            cols = np.array(send, np.int32)
-            st, runs = eng[a].commit(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4], cols[:, 5].astype(np.uint8))
-            want_runs = []
-            for i, (g, slot, bnum, bcoord, median, kind) in enumerate(cols.tolist()):
-                if kind & C_HASVALUE:
-                    status, run = acc[a][g].handleDecision((bnum, bcoord), slot, median, bool(kind & C_STOP))
-                else:
-                    status, run = acc[a][g].handleBatchedCommitSlot((bnum, bcoord), slot, median)
-                assert int(st[i]) == status, f"round {r} replica {a}: commit {cols[i]}"
-                if run is not None:
-                    want_runs.append((g, i, run[0], run[1]))
-            want_runs.sort(key=lambda t: (t[0], t[1]))
-            check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} commit")
-            checked += len(send)
+                # a group's ACCEPTs keep their slot order, the groups are shuffled among each other
+                by_group = {}
+                for t in send:
+                    by_group.setdefault(t[0], []).append(t)
+                seq = []
+                keys = list(by_group)
+                rng.shuffle(keys)
+                cursors = {g: 0 for g in keys}
+                live = keys[:]
+                while live:                      # round robin over the shuffled groups: interleaved, per-group order kept
+                    nxt = []
+                    for g in live:
+                        seq.append(by_group[g][cursors[g]])
+                        cursors[g] += 1
+                        if cursors[g] < len(by_group[g]):
+                            nxt.append(g)
+                    live = nxt
+                cols = np.array(seq, np.int32)
+                (rb, rc, rm, rf, st), runs = eng[a].accept(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4],
+                                                           (cols[:, 5] * A_STOP).astype(np.uint8))
+                want_runs = []
+                for i, (g, slot, bnum, bcoord, median, stop) in enumerate(seq):
+                    status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((bnum, bcoord), slot, median, True, bool(stop)))
+                    assert (int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i])) == (status, wb, wc, wm, wf), \
+                        f"round {r} replica {a}: ACCEPT {seq[i]}"
+                    if run is not None:
+                        want_runs.append((g, i, run[0], run[1]))
+                    if status == S_OK and coord[g] is not None and (bnum, bcoord) == coord[g].my:   # (the rival's replies go to the rival)
+                        votes.append((g, slot, a, wb, wc, wm))
+                want_runs.sort(key=lambda t: (t[0], t[1]))
+                check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} accept")
+                checked += len(seq)
+            # the replies reach the coordinator in random order, some never
+            votes = [v for v in votes if rng.random() >= p_drop]
+            perm = rng.permutation(len(votes))
+            votes = [votes[i] for i in perm]
+            decisions = []
+            if votes:
+                cols = np.array(votes, np.int32)
+                d = eng[ci].accept_reply(cols[:, 0], cols[:, 3], cols[:, 4], cols[:, 1], np.array(NODES, np.int32)[cols[:, 2]], cols[:, 5])
+                want = []
+                for i, (g, slot, a, wb, wc, wm) in enumerate(votes):
+                    if acc[ci][g].stopped:                              # PISM.handlePaxosMessage :456-460: dropped
+                        assert int(d.status[i]) == S_STOPPED, f"round {r}: vote for a stopped instance {g}"
+                        continue
+                    assert int(d.status[i]) == S_OK
+                    out = coord[g].reply(slot, a, (wb, wc), wm)
+                    if out is not None:
+                        want.append((g, i) + out)
+                want.sort(key=lambda t: (t[0], t[1]))
+                exp = np.array([(t[0],) + t[2:] for t in want], np.int32).reshape(-1, 6)
+                got = d.as_tuple_array()
+                assert got.shape == exp.shape and (got == exp).all(), f"round {r}: decisions"
+                decisions = [t for t in want if t[6] == D_DECISION]
+                checked += len(votes)
+            # BATCHED_COMMITs to every replica, some lost; a lost one comes again a round later as a full DECISION (its
+            # request value with it: what a replica gets back when it asks for missing decisions, PISM:1432-1478)
+            for a in replicas:
+                todo = pending_c[a] + [(t[0], t[2], t[3], t[4], t[5], 0) for t in decisions]  # g, slot, bnum, bcoord, median, kind
+                lost = rng.random(len(todo)) < p_drop
+                send = [t for t, l in zip(todo, lost) if not l]
+                pending_c[a] = [t[:5] + (C_HASVALUE | (C_STOP if (t[0], t[1]) in stop_slots else 0),)
+                                for t, l in zip(todo, lost) if l]
+                if not send:
+                    continue
+                cols = np.array(send, np.int32)
+                st, runs = eng[a].commit(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4], cols[:, 5].astype(np.uint8))
+                want_runs = []
+                for i, (g, slot, bnum, bcoord, median, kind) in enumerate(cols.tolist()):
+                    if kind & C_HASVALUE:
+                        status, run = acc[a][g].handleDecision((bnum, bcoord), slot, median, bool(kind & C_STOP))
+                    else:
+                        status, run = acc[a][g].handleBatchedCommitSlot((bnum, bcoord), slot, median)
+                    assert int(st[i]) == status, f"round {r} replica {a}: commit {cols[i]}"
+                    if run is not None:
+                        want_runs.append((g, i, run[0], run[1]))
+                want_runs.sort(key=lambda t: (t[0], t[1]))
+                check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} commit")
+                checked += len(send)
+
+    play(rounds, 0, list(range(K)), coord, p_rival, [], "round ")
     run_rounds.gaps = check_gaps(eng, acc, G, "final")
     run_rounds.failover = check_failover(eng, acc, G, NODES, rng, K, p_drop, p_stop) if failover else None
+    coord2 = None
+    if failover and rounds_after:
+        # the new coordinators (replica 1) go on: the replies to the view change's ACCEPTs, decisions, commits,
+        # executions, new proposals - among the survivors
+        coord2 = [None] * G
+        for g, cd in check_failover.elected.items():
+            c2 = Coordinator(NODES[1], K)
+            c2.my, c2.next, c2.node_slots = cd.my, cd.next, list(cd.node_slots)
+            c2.proposals = {s_: [False] * K for s_ in cd.proposals}
+            c2.stops = {s_ for s_, (_, _, stop) in cd.proposals.items() if stop}
+            stop_slots.update((g, s_) for s_ in c2.stops)
+            coord2[g] = c2
+        before = checked
+        play(rounds_after, 1, list(range(1, K)), coord2, 0.0, check_failover.votes, "after the view change ")
+        run_rounds.after = checked - before
     run_rounds.carried = check_prepares(eng, acc, G, NODES, rng)   # (raises acceptor ballots: the final rows below see it)
     # final rows: acceptor side of every replica, coordinator side of replica 0
     for a in range(K):
@@ -608,6 +639,14 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     assert ((snap["has_coord"] != 0) == alive).all(), "coordinators that resigned"
     assert (snap["next_proposal_slot"][alive] == np.array([c.next for c in coord], np.int32)[alive]).all()
     assert (snap["node_slots"][:, :K][alive] == np.array([c.node_slots for c in coord], np.int32)[alive]).all()
+    if coord2 is not None:
+        eg = np.array([g for g in range(G) if coord2[g] is not None], np.int32)
+        if eg.shape[0]:
+            snap1, _ = eng[1].snapshot(eg)
+            alive2 = np.array([coord2[g].alive for g in eg.tolist()])
+            assert ((snap1["has_coord"] != 0) == alive2).all(), "new coordinators that resigned"
+            assert (snap1["next_proposal_slot"][alive2] == np.array([coord2[g].next for g in eg.tolist()], np.int32)[alive2]).all()
+            assert (snap1["node_slots"][:, :K][alive2] == np.array([coord2[g].node_slots for g in eg.tolist()], np.int32)[alive2]).all()
     executed = sum(acc[a][g]._slot - 1 for a in range(K) for g in range(G))
     for e in eng:
         e.close()

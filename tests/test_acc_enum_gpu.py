@@ -83,6 +83,7 @@ def test_view_change_after_lossy_rounds_against_java_reading_on_engine(hip_lib, 
     win - election_begin, prepare, prepare_reply, the view change's ACCEPTs - against the Candidate reading."""
     from tests.round_model import run_rounds
     run_rounds(hip_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop, from_disk=seed % 2 == 0,
-               failover=True)
+               failover=True, rounds_after=6)     # ... and six more rounds under the new coordinators
+    assert run_rounds.after > G * 6
     elected, accepts, carried, noops = run_rounds.failover
     assert elected > G // 5 and carried > G // 8 and accepts == (carried + noops) * (K - 1)

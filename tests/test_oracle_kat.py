@@ -509,7 +509,8 @@ def test_view_change_after_lossy_rounds_against_java_reading(oracle_lib, G, roun
     handlePrepareReply and PCS:233-263, 271-587 (Candidate in round_model.py)."""
     from tests.round_model import run_rounds
     run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop, from_disk=seed % 2 == 0,
-               failover=True)
+               failover=True, rounds_after=8)     # ... and eight more rounds under the new coordinators
+    assert run_rounds.after > G * 8
     elected, accepts, carried, noops = run_rounds.failover
     assert elected > G // 5 and carried > G // 8 and accepts == (carried + noops) * (K - 1)
 
