@@ -915,7 +915,6 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     return GPX_OK;
   }
   gpx_engine* e = h;
-  const size_t b4 = (size_t)n * 4;
   const int fs = begin_front(e);
   /* a batch grouped by group (gidx non-decreasing, in range) is applied directly; anything else is
    * partitioned first.  Device-side choice: both back ends are launched, one of them returns at once. */
@@ -1006,7 +1005,6 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     return GPX_OK;
   }
   gpx_engine* e = h;
-  const size_t b4 = (size_t)n * 4;
   const int fs = begin_front(e);
   /* decisions leave the accept-reply call grouped by gidx: such a commit batch is applied directly */
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
@@ -1086,7 +1084,6 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   if (rc != GPX_OK) return rc;
   if (n == 0) return GPX_OK;
   gpx_engine* e = h;
-  const size_t b4 = (size_t)n * 4;
   const int fs = begin_front(e);
   const bool promised = (e->ordered_mask & GPX_ORDERED_PROPOSE) != 0;
   const int32_t refuse = promised ? 1 : 0;
@@ -1652,7 +1649,6 @@ int gpx_propose_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const
   if (rc != GPX_OK) return rc;
   gpx_engine::AsyncSet& a = *ap;
   if (n > 0) {
-    const size_t b4 = (size_t)n * 4;
     {
       const int32_t* hs[1] = {gidx};
       int32_t* dd[1] = {a.i32[0]};
@@ -1690,7 +1686,6 @@ int gpx_accept_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const 
   a.host_count = n_runs;
   *n_runs = 0;
   if (n > 0) {
-    const size_t b4 = (size_t)n * 4;
     {
       const int32_t* hs[5] = {gidx, bnum, bcoord, slot, median_cp};
       int32_t* dd[5] = {a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4]};
@@ -1732,7 +1727,6 @@ int gpx_accept_reply_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, 
   a.host_count = n_out;
   *n_out = 0;
   if (n > 0) {
-    const size_t b4 = (size_t)n * 4;
     if (bnum) {
       const int32_t* hs[6] = {gidx, bnum, bcoord, slot, acceptor, max_cp};
       int32_t* dd[6] = {a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a.i32[5]};
@@ -1786,7 +1780,6 @@ int gpx_commit_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const 
   a.host_count = n_runs;
   *n_runs = 0;
   if (n > 0) {
-    const size_t b4 = (size_t)n * 4;
     {
       const int32_t* hs[5] = {gidx, bnum, bcoord, slot, median_cp};
       int32_t* dd[5] = {a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4]};
@@ -1920,9 +1913,6 @@ int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
   const DevState& S = h->S;
   auto rd32 = [&](const void* base, int64_t idx, int32_t* out) -> hipError_t {
     return hipMemcpy(out, (const char*)base + idx * 4, 4, hipMemcpyDeviceToHost);
-  };
-  auto rd8 = [&](const void* base, int64_t idx, uint8_t* out) -> hipError_t {
-    return hipMemcpy(out, (const char*)base + idx, 1, hipMemcpyDeviceToHost);
   };
   if (gidx < 0 || gidx >= S.G) {
     if (cap < 1) return GPX_ECAPACITY;
