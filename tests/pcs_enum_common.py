@@ -200,16 +200,18 @@ def model_stream(members, me, nprop, votes, init_node_slots=None):
             if not proposals:                                    # PISM.nullifyCoordinatorIfPreemptedFully (:1361-1364)
                 coordinator = False
         elif bkind == 0:                                         # handleAcceptReplyMyBallot
+            acceptor = members[j] if j >= 0 else -7              # j < 0: a node that is no member of the group
             for i in range(K):                                   # recordSlotNumber: every i with members[i] == acceptor
-                if members[i] == members[j] and node_slots[i] < maxcp:
+                if members[i] == acceptor and node_slots[i] < maxcp:
                     node_slots[i] = maxcp
             w = proposals.get(slot)
             if w is not None:
                 idx = -1
                 for q in range(K):                               # WaitforUtility.getIndex: last match
-                    if members[q] == members[j]:
+                    if members[q] == acceptor:
                         idx = q
-                w[idx] = True                                    # updateHeardFrom
+                if 0 <= idx < K:                                 # updateHeardFrom (WaitforUtility.java:51-62)
+                    w[idx] = True
                 if sum(w) > K // 2:                              # heardFromMajority
                     srt = sorted(node_slots)                     # getMedianMinus
                     med = srt[K // 2 - 1] if K % 2 == 0 else srt[K // 2]
@@ -219,7 +221,7 @@ def model_stream(members, me, nprop, votes, init_node_slots=None):
     return out, proposals, coordinator, node_slots
 
 
-def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower=0.08):
+def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower=0.08, p_stranger=0.0):
     """n_groups coordinators with nprop outstanding proposals each, every one fed its own random stream of
     n_votes accept replies (any member, any slot in [0, nprop + 1], lower / own / higher ballots, checkpoint
     slots -1 .. nprop) - all in ONE gpx_accept_reply_batch call, the groups interleaved; the decided stream,
@@ -239,13 +241,15 @@ def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower
     n = G * n_votes
     slot = rng.integers(0, nprop + 2, n).astype(np.int32)
     mj = rng.integers(0, K, n).astype(np.int32)
+    if p_stranger > 0.0:                                         # votes of a node that is no member (index -1)
+        mj[rng.random(n) < p_stranger] = -1
     u = rng.random(n)
     bkind = np.where(u < p_higher, 1, np.where(u < p_higher + p_lower, -1, 0)).astype(np.int32)
     maxcp = rng.integers(-1, nprop + 1, n).astype(np.int32)
     gcol = np.repeat(np.arange(G, dtype=np.int32), n_votes)
     bnum = np.where(bkind > 0, 1, 0).astype(np.int32)
     bcoord = np.where(bkind < 0, me - 1, me).astype(np.int32)
-    acc = np.array(members, np.int32)[mj]
+    acc = np.where(mj >= 0, np.array(members, np.int32)[np.maximum(mj, 0)], -7).astype(np.int32)
     expect, final = [], []
     for p in range(G):
         lo = p * n_votes

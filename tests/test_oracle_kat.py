@@ -476,6 +476,8 @@ def test_pcs_accept_replies_in_any_order_against_java_reading(oracle_lib, K, npr
     statement-by-statement reading of PaxosCoordinator.handleAcceptReply (:210-250) and PCS:597-683, 809-825."""
     from tests.pcs_enum_common import run_streams
     assert run_streams(oracle_lib, K, nprop, G, nv, seed=K * 100 + nprop) == G
+    # ... and with 5 % of the votes from a node that is no member of the group (WaitforUtility.getIndex = -1)
+    assert run_streams(oracle_lib, K, nprop, G // 2, nv, seed=K * 100 + nprop + 7, p_stranger=0.05) == G // 2
 
 
 @pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival", [(3000, 20, 2, 0.2, 3, 0.0), (4000, 16, 3, 0.05, 3, 0.0),
