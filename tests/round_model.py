@@ -15,6 +15,10 @@ in-order execution - against the two independent Python readings of the Java put
                PREPAREs at the survivors, PISM.handlePrepareReply -> PaxosCoordinator.handlePrepareReply ->
                isPrepareAcceptedByMajority / combinePValuesOntoProposals / spawnCommandersForProposals (PCS:271-587;
                Candidate below), the view change's ACCEPTs at the survivors
+  pauses:      (p_pause > 0) PISM.tryPause (PISM:2004-2035) of random instances between rounds: refused unless
+               PaxosAcceptor.caughtUp (PaxosAcceptor.java:451-459) and PaxosCoordinator.caughtUp (PaxosCoordinator.java:
+               369-371, PCS:758-761); the HotRestoreInfo of the others, and the instance hotRestore (PISM:677-690)
+               makes of it again, which then plays on
   requests:    PISM.handleProposal's choice (PISM:817-888): propose iff PaxosCoordinator.exists(coordinator,
                paxosState.getBallot()) (PaxosCoordinator.java:168-174), else forward to getBallotCoord()
 
@@ -30,8 +34,8 @@ batches; every propose result, reply word, status, decision, execution run and f
 equal the model's."""
 import numpy as np
 
-from gigapaxos_amd import (Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STOPPED, A_STOP, C_HASVALUE, C_STOP, D_DECISION,
-                           D_PREEMPTED)
+from gigapaxos_amd import (Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STOPPED, S_BUSY, A_STOP, C_HASVALUE, C_STOP,
+                           D_DECISION, D_PREEMPTED, RETIRE_PAUSE)
 
 P_NACK, P_TOLOG = 1, 2   # GPX_P_NACK, GPX_P_TOLOG (include/gpx.h)
 PV_STOP = 1              # GPX_PV_STOP
@@ -436,7 +440,7 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0):
 
 
 def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True, failover=False,
-               rounds_after=0):
+               rounds_after=0, p_pause=0.0):
     """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
     slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
@@ -453,6 +457,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     pending = [[] for _ in range(K)]        # per replica: ACCEPTs lost on their way, to be sent again
     pending_c = [[] for _ in range(K)]      # ... and commits
     forwarded = refused = stopped_props = 0
+    paused = paused_coord = busy = relogged = 0
     stop_slots = set()                      # (group, slot) of the proposals that are STOP requests
     checked = 0
 
@@ -461,10 +466,53 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
         exp = np.array(want, np.int32).reshape(-1, 3)
         assert got.shape == exp.shape and (got == exp).all(), f"{what}: execution runs\n{got[:8]}\n{exp[:8]}"
 
+    def pause(r, ci, replicas, coord):
+        """PaxosManager's deactivation of idle instances: tryPause, and (here: at once) the restore from what it left"""
+        nonlocal checked, paused, paused_coord, busy, relogged
+        for a in replicas:
+            gs = [g for g in np.nonzero(rng.random(G) < p_pause)[0].tolist()
+                  if not acc[a][g].stopped and (a != ci or coord[g] is not None)]
+            if not gs:
+                continue
+            rows, st = eng[a].retire_groups(np.array(gs, np.int32), RETIRE_PAUSE)
+            back = []
+            for i, g in enumerate(gs):
+                m = acc[a][g]
+                c = coord[g] if a == ci and coord[g].alive else None        # PaxosCoordinator.caughtUp: c == null || ...
+                caught = not m.committed and (not m.accepted or from_disk) and (c is None or not c.proposals)
+                if not caught:
+                    busy += 1
+                    assert int(st[i]) == S_BUSY, f"round {r} replica {a}: pause of group {g} that is not caught up"
+                    continue
+                assert int(st[i]) == S_OK, f"round {r} replica {a}: pause of group {g}"
+                row = rows[i]
+                assert (int(row["acc_slot"]), int(row["acc_bnum"]), int(row["acc_bcoord"]), int(row["acc_gc_slot"])) == \
+                    tuple(m.row()), f"round {r} replica {a} group {g}: acceptor part of the HotRestoreInfo"
+                if c is None:                                               # getBallotIfActive & co. (PISM:2015-2018)
+                    assert (int(row["has_coord"]), int(row["next_proposal_slot"])) == (0, -1)
+                else:
+                    assert (int(row["has_coord"]), int(row["coord_bnum"]), int(row["coord_bcoord"]), int(row["next_proposal_slot"]),
+                            row["node_slots"][:K].tolist()) == (1, c.my[0], c.my[1], c.next, c.node_slots), \
+                        f"round {r} group {g}: coordinator part of the HotRestoreInfo"
+                    paused_coord += 1
+                back.append(i)
+                # "pause/unpause will lose acceptedProposals state, which is okay iff we always return accepted pvalues
+                # from disk" (PaxosAcceptor.java:453-457).  The disk is the host's; here the coordinator's retransmission
+                # brings the ACCEPTs back (same ballot, same slot: accepted again, or refused if the ballot rose since)
+                for s_, pv in sorted(m.accepted.items()):
+                    pending[a].append((g, s_, pv.ballot[0], pv.ballot[1], pv.median, int(pv.stop)))
+                    relogged += 1
+                m.accepted = {}
+            if back:
+                bi = np.array(back)
+                assert (eng[a].create_groups(np.array(gs, np.int32)[bi], mem[:len(back)], K, rows[bi]) == S_OK).all()
+                paused += len(back)
+            checked += len(gs)
+
     def play(rounds_, ci, replicas, coord, p_rival_, first_votes, tag):
         """rounds_ rounds with replica ci as the coordinator of every group that has one in `coord` (None: no
         proposals there), messages only among `replicas`; first_votes = accept replies already on their way"""
-        nonlocal checked, forwarded, refused, stopped_props
+        nonlocal checked, forwarded, refused, stopped_props, paused, busy, relogged
         for r_ in range(rounds_):
             r = f"{tag}{r_}"
             accepts = []                        # (g, slot, bnum, bcoord, median) of this round, in proposal order
@@ -607,6 +655,8 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                 want_runs.sort(key=lambda t: (t[0], t[1]))
                 check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} commit")
                 checked += len(send)
+            if p_pause > 0.0:
+                pause(r, ci, replicas, coord)
 
     play(rounds, 0, list(range(K)), coord, p_rival, [], "round ")
     run_rounds.gaps = check_gaps(eng, acc, G, "final")
@@ -655,4 +705,5 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     run_rounds.refused = refused
     run_rounds.stopped_props = stopped_props
     run_rounds.stopped = sum(acc[a][g].stopped for a in range(K) for g in range(G))
+    run_rounds.paused, run_rounds.paused_coord, run_rounds.busy, run_rounds.relogged = paused, paused_coord, busy, relogged
     return checked, executed

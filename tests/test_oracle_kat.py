@@ -517,6 +517,26 @@ def test_view_change_after_lossy_rounds_against_java_reading(oracle_lib, G, roun
     assert elected > G // 5 and carried > G // 8 and accepts == (carried + noops) * (K - 1)
 
 
+@pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival,p_stop,failover", [
+    (1500, 14, 82, 0.15, 3, 0.03, 0.0, False), (1500, 14, 81, 0.1, 3, 0.0, 0.0, False), (1200, 12, 86, 0.2, 5, 0.0, 0.02, False),
+    (1500, 12, 84, 0.1, 4, 0.0, 0.0, True), (1500, 12, 88, 0.25, 3, 0.02, 0.01, True)])
+def test_pause_and_hot_restore_between_rounds_against_java_reading(oracle_lib, G, rounds, seed, p_drop, K, p_rival, p_stop, failover):
+    """PISM.tryPause of 15 % of the instances of every replica after every round of tests/round_model.py: GPX_S_BUSY
+    unless PaxosAcceptor.caughtUp and PaxosCoordinator.caughtUp say so (no pending decision, no accept held in
+    memory unless accepts come from disk, no outstanding proposal), else the HotRestoreInfo row - acceptor part and,
+    for an active coordinator, ballot / nextProposalSlot / nodeSlotNumbers - and gpx_group_create from that row
+    (hotRestore, PISM:677-690), after which the instance plays on like one that never left (odd seeds:
+    GET_ACCEPTED_PVALUES_FROM_DISK false, where an acceptor is only caught up once garbage collection has passed)."""
+    from tests.round_model import run_rounds
+    checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop,
+                                   from_disk=seed % 2 == 0, failover=failover, rounds_after=8 if failover else 0, p_pause=0.15)
+    assert executed > G * rounds // 5 and run_rounds.busy > G
+    if seed % 2 == 0:
+        assert run_rounds.paused > G and run_rounds.paused_coord > G // 4 and run_rounds.relogged > G // 10
+    else:
+        assert run_rounds.paused > 0
+
+
 def test_acceptor_side_long_random_sequences_against_java_reading(oracle_lib):
     """The same reading over seeded random sequences of 8 and 12 ops per group (the exhaustive plans stop at 4,
     the random ones above at 6)."""
