@@ -19,6 +19,10 @@ in-order execution - against the two independent Python readings of the Java put
                PaxosAcceptor.caughtUp (PaxosAcceptor.java:451-459) and PaxosCoordinator.caughtUp (PaxosCoordinator.java:
                369-371, PCS:758-761); the HotRestoreInfo of the others, and the instance hotRestore (PISM:677-690)
                makes of it again, which then plays on
+  pokes:       (pokes=True) PISM.pokeLocalCoordinator (PISM:2268-2279) -> reissueAcceptIfWaitingTooLong
+               (PaxosCoordinator.java:334-350) -> isCommandering / reInitCommander / initCommander (PCS:741-750, 841-851)
+               minus the clock, after every round, against gpx_poke_scan: the one ACCEPT an active coordinator sends
+               again is the one for its acceptor's next slot, with the median as it is NOW
   requests:    PISM.handleProposal's choice (PISM:817-888): propose iff PaxosCoordinator.exists(coordinator,
                paxosState.getBallot()) (PaxosCoordinator.java:168-174), else forward to getBallotCoord()
 
@@ -440,7 +444,7 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0):
 
 
 def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True, failover=False,
-               rounds_after=0, p_pause=0.0):
+               rounds_after=0, p_pause=0.0, pokes=False):
     """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
     slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
@@ -457,7 +461,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     pending = [[] for _ in range(K)]        # per replica: ACCEPTs lost on their way, to be sent again
     pending_c = [[] for _ in range(K)]      # ... and commits
     forwarded = refused = stopped_props = 0
-    paused = paused_coord = busy = relogged = 0
+    paused = paused_coord = busy = relogged = poked = 0
     stop_slots = set()                      # (group, slot) of the proposals that are STOP requests
     checked = 0
 
@@ -465,6 +469,21 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
         got = runs.as_tuple_array()
         exp = np.array(want, np.int32).reshape(-1, 3)
         assert got.shape == exp.shape and (got == exp).all(), f"{what}: execution runs\n{got[:8]}\n{exp[:8]}"
+
+    def poke(r, ci, coord):
+        nonlocal checked, poked
+        gs = np.array([g for g in range(G) if coord[g] is not None], np.int32)
+        pk, sl, bn, bc, md, fl, hd, st = eng[ci].poke_scan(gs)
+        for i, g in enumerate(gs.tolist()):
+            c, s_ = coord[g], acc[ci][g]._slot
+            want = (0, 0, 0, 0, 0, 0, 0)                                  # GPX_POKE_NONE
+            if c.alive and s_ in c.proposals:                            # isActive() && isCommandering(slot)
+                want = (1, s_, c.my[0], c.my[1], c.median(), PV_STOP if s_ in c.stops else 0,
+                        sum(1 << j for j, heard in enumerate(c.proposals[s_]) if heard))
+                poked += 1
+            assert (int(pk[i]), int(sl[i]), int(bn[i]), int(bc[i]), int(md[i]), int(fl[i]), int(hd[i])) == want and \
+                int(st[i]) == S_OK, f"round {r}: poke of group {g}"
+        checked += gs.shape[0]
 
     def pause(r, ci, replicas, coord):
         """PaxosManager's deactivation of idle instances: tryPause, and (here: at once) the restore from what it left"""
@@ -655,6 +674,8 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                 want_runs.sort(key=lambda t: (t[0], t[1]))
                 check_runs(runs, [(g, f, c) for g, _, f, c in want_runs], f"round {r} replica {a} commit")
                 checked += len(send)
+            if pokes:
+                poke(r, ci, coord)
             if p_pause > 0.0:
                 pause(r, ci, replicas, coord)
 
@@ -706,4 +727,5 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     run_rounds.stopped_props = stopped_props
     run_rounds.stopped = sum(acc[a][g].stopped for a in range(K) for g in range(G))
     run_rounds.paused, run_rounds.paused_coord, run_rounds.busy, run_rounds.relogged = paused, paused_coord, busy, relogged
+    run_rounds.poked = poked
     return checked, executed

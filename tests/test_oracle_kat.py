@@ -526,11 +526,14 @@ def test_pause_and_hot_restore_between_rounds_against_java_reading(oracle_lib, G
     memory unless accepts come from disk, no outstanding proposal), else the HotRestoreInfo row - acceptor part and,
     for an active coordinator, ballot / nextProposalSlot / nodeSlotNumbers - and gpx_group_create from that row
     (hotRestore, PISM:677-690), after which the instance plays on like one that never left (odd seeds:
-    GET_ACCEPTED_PVALUES_FROM_DISK false, where an acceptor is only caught up once garbage collection has passed)."""
+    GET_ACCEPTED_PVALUES_FROM_DISK false, where an acceptor is only caught up once garbage collection has passed).
+    After every round also gpx_poke_scan of the coordinators against PISM.pokeLocalCoordinator's reading: the ACCEPT
+    for the acceptor's next slot, if the coordinator still waits for it, with the median as it is now and the members
+    heard so far."""
     from tests.round_model import run_rounds
     checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop,
-                                   from_disk=seed % 2 == 0, failover=failover, rounds_after=8 if failover else 0, p_pause=0.15)
-    assert executed > G * rounds // 5 and run_rounds.busy > G
+                                   from_disk=seed % 2 == 0, failover=failover, rounds_after=8 if failover else 0, p_pause=0.15, pokes=True)
+    assert executed > G * rounds // 5 and run_rounds.busy > G and run_rounds.poked > G
     if seed % 2 == 0:
         assert run_rounds.paused > G and run_rounds.paused_coord > G // 4 and run_rounds.relogged > G // 10
     else:

@@ -101,3 +101,47 @@ def test_pack_of_random_batches_against_java_reading(oracle_lib, G, seed):
         n_frames += len(frames)
     e.close()
     assert n_frames > 3 * G
+
+
+def plan_send_reading(est, key, max_payload, min_batch, across):
+    """PaxosPacketBatcher.dequeueImpl (PaxosPacketBatcher.java:182-209: four `while (lengthEstimate < MAX && next !=
+    null)` loops over the accept replies, commits, accepts and requests share one running estimate = one loop over the
+    frames in that order, the test before the add) and process() -> batch() (:268-303: `tasks.length >
+    MIN_PP_BATCH_SIZE` tasks are regrouped in a LinkedHashMap keyed by the recipient set)"""
+    n = len(est)
+    burst, env, pos = [0] * n, [-1] * n, [0] * n
+    i = b = 0
+    while i < n:
+        length, tasks = 0, []
+        while i < n and length < max_payload:
+            tasks.append(i)
+            length += int(est[i])
+            i += 1
+        if across and len(tasks) > min_batch:
+            grouped = {}
+            for f in tasks:
+                grouped.setdefault(int(key[f]), []).append(f)
+            for e_idx, fs in enumerate(grouped.values()):
+                for p_idx, f in enumerate(fs):
+                    env[f], pos[f] = e_idx, p_idx
+        for f in tasks:
+            burst[f] = b
+        b += 1
+    return burst, env, pos, b
+
+
+def test_plan_send_against_java_reading(oracle_lib):
+    """gpx_wire_plan_send of the oracle AND of the engine library (pure host code: it runs here) against the reading"""
+    import __graft_entry__ as ge
+    from gigapaxos_amd._abi import GpxLib
+    ge.build()
+    rng = np.random.default_rng(5)
+    for lib in (oracle_lib, GpxLib(ge.HIP_SO, "gpx_", device_api=True)):
+        for _ in range(300):
+            n = int(rng.integers(0, 600))
+            est = rng.integers(1, int(rng.choice([3, 300, 30_000])), n)
+            key = rng.integers(0, int(rng.choice([1, 3, 50])), n)
+            mp, mb, across = int(rng.choice([1, 50, 5000, 4 << 20])), int(rng.integers(0, 6)), bool(rng.random() < 0.8)
+            burst, env, pos, nb = W.plan_send(lib, est, key, mp, mb, across)
+            want = plan_send_reading(est, key, mp, mb, across)
+            assert (burst.tolist(), env.tolist(), pos.tolist(), nb) == want, (n, mp, mb, across)
