@@ -154,6 +154,7 @@ struct gpx_engine {
   uint32_t w_epoch = 0;
   bool wire_legacy = false;
   int wire_tile = 512; /* frames per workgroup of k_wire_decode1 (GPX_WD_TILE = 256 / 512) */
+  bool wire_stage1 = false; /* GPX_WD_STAGE1=1: the staging loop with all chunk loads in flight (gpx_wire.hip.h, wire_stage) */
   uint8_t* w_stage = nullptr;      /* staging of BATCHED_ACCEPT_REPLY frames, 188 B per reply */
   long long* w_bucket_bytes = nullptr;
   int32_t* w_ones = nullptr;       /* a column of ones (gpx_request_batch without weights) */

@@ -588,7 +588,13 @@ struct WireScratch {
  * the tile's 47 us).  LDS byte lead + k = byte k, where lead = a0 & 15 keeps 16-byte chunks aligned on
  * both sides; nothing before a0 or past the last byte is read.  Returns lead; the caller's barrier
  * follows. */
-template <int BLOCK = GPX_BLOCK>
+/* INFLIGHT (round 3, found by reading the ISA after the round's GPU minutes were spent - profiles/
+ * r03_wire_stage_isa.txt): hipcc 7.2 keeps v[] in SCRATCH when its elements are only assigned under the bounds
+ * test, and waits for every chunk before the next load: seven round trips instead of the one the loop is written
+ * for (the timeline's "ticket -> staged" never moved off 11-12 us).  With the elements zeroed first the seven loads
+ * are issued back to back and one wait precedes the stores.  Not yet measured or parity-run on a GPU: a template
+ * switch, off by default (GPX_WD_STAGE1=1 selects it for k_wire_decode1). */
+template <int BLOCK = GPX_BLOCK, bool INFLIGHT = false>
 __device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64_t nbytes) {
   constexpr int NCH = GPX_W_STAGE_BYTES / 16 / GPX_BLOCK + 1; /* chunks per lane of a full staging area */
   const uintptr_t a16 = a0 & ~(uintptr_t)15;
@@ -612,6 +618,7 @@ __device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64
 #pragma unroll
     for (int k = 0; k < NCH; k++) {
       const int32_t c = c0 + k * BLOCK + (int32_t)threadIdx.x;
+      if (INFLIGHT) v[k] = make_uint4(0u, 0u, 0u, 0u);
       if (c < c_hi) v[k] = src16[c];
     }
     if (odd && hw < head_end) hv = src[hw];
@@ -955,7 +962,7 @@ __device__ __forceinline__ uint32_t wl_lookback(const unsigned long long* __rest
   return (uint32_t)wl_lookback64(st, tile, epoch);
 }
 
-template <int WB>
+template <int WB, bool INFLIGHT = false>
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(6))) void k_wire_decode1(DevState S, DevNames N, WireLook K, WireOut O,
                                                            int32_t nf, int32_t ntiles,
                                                            const uint8_t* __restrict__ frames,
@@ -996,7 +1003,7 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(6))) void k_
 #ifdef GPX_WD_NOSTAGE /* ablation builds (scripts/ubench/wire_ablation.sh): never shipped */
   const int32_t lead = 0;
 #else
-  const int32_t lead = wire_stage<WB>(stage, a0, nbytes);
+  const int32_t lead = wire_stage<WB, INFLIGHT>(stage, a0, nbytes);
 #endif
   __syncthreads();
   WD_STAMP(2); /* tile staged */

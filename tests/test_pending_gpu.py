@@ -35,3 +35,21 @@ def test_request_batcher_and_election_scan_against_java_reading(hip_lib):
     from tests import test_host_rows_oracle as T
     T.test_request_batcher_random_bursts_against_java_reading(hip_lib)
     T.test_election_scan_random_groups_against_java_reading(hip_lib)
+
+
+def test_decode_with_all_staging_loads_in_flight(hip_lib, oracle_lib, monkeypatch):
+    """k_wire_decode1<WB, INFLIGHT = true> (GPX_WD_STAGE1=1; gpx_wire.hip.h wire_stage, profiles/r03_wire_stage_isa.txt):
+    the decode fuzz against the oracle and the reading with the variant selected"""
+    import numpy as np
+    from tests.wire_common import make_wire_pair, random_frames, assert_same_decode
+    from tests import test_wire_model as T
+    monkeypatch.setenv("GPX_WD_STAGE1", "1")
+    for tile in ("512", "256"):
+        monkeypatch.setenv("GPX_WD_TILE", tile)
+        rng = np.random.default_rng(5)
+        ((eh, wh), (eo, wo)), names = make_wire_pair(hip_lib, oracle_lib, 1500, 3, rng)
+        for burst, damage in enumerate((0.0, 0.3, 0.6)):
+            frames = random_frames(names, 3000, rng, damage)
+            assert_same_decode(wh.decode(frames), wo.decode(frames), f"tile {tile} burst {burst}")
+        eh.close(), eo.close()
+        T.test_decode_of_damaged_bursts_against_java_reading(hip_lib, 2000, 30_000, 12, 0.5)
