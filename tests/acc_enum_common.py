@@ -378,12 +378,14 @@ def run_long_random(lib, n, lengths=(8, 12), seed=77, orders=("interleaved", "gr
 
 
 def run_plan(lib, scale=1.0, orders=("interleaved", "grouped"), inits=("create", "initial"), from_disk=(True,),
-             promise=False):
+             promise=False, skip=(), both_inits_below=200_000):
     total = 0
     for name, seqs in plan(scale):
+        if name in skip:
+            continue
         for i, order in enumerate(orders):
             # every batch order sees both initial rows on the short plans; the long ones alternate
-            for init in (inits if len(seqs) < 200_000 else (inits[i % len(inits)],)):
+            for init in (inits if len(seqs) < both_inits_below else (inits[i % len(inits)],)):
                 for fd in from_disk:
                     total += run_sequences(lib, seqs, init=init, order=order, from_disk=fd, promise=promise)
     return total
