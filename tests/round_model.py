@@ -185,7 +185,7 @@ def check_prepares(eng, acc, G, nodes, rng):
         for _ in range(2):
             pick = rng.integers(0, 4, G)
             bnum = np.array([0, 0, 1, 2], np.int32)[pick]
-            bcoord = np.array([nodes[0] - 1, nodes[0], nodes[1], nodes[-1]], np.int32)[pick]
+            bcoord = np.array([nodes[0] - 1, nodes[0], nodes[1 % len(nodes)], nodes[-1]], np.int32)[pick]
             first = np.array([acc[a][g]._slot for g in range(G)], np.int32) + rng.integers(-2, 3, G).astype(np.int32)
             (rb, rc, rg, rf, st), rows = e.prepare(np.arange(G, dtype=np.int32), bnum, bcoord, first)
             want_rows = []

@@ -542,6 +542,22 @@ def test_pause_and_hot_restore_between_rounds_against_java_reading(oracle_lib, G
         assert run_rounds.paused > 0
 
 
+@pytest.mark.parametrize("K,kw", [(1, dict()), (1, dict(p_stop=0.02, from_disk=False)), (2, dict(p_rival=0.03)),
+                                  (2, dict(failover=True, rounds_after=6)), (7, dict(failover=True, rounds_after=4, p_stop=0.01)),
+                                  (16, dict(p_rival=0.02))])
+def test_whole_round_with_unusual_group_sizes(oracle_lib, K, kw):
+    """The round model (pauses and pokes included) for groups of one member (its own vote decides), of two (both
+    must vote; after a failure the survivor can never be elected - and is not), of seven, and of sixteen = the
+    engine's GPX_KMAX_LIMIT."""
+    from tests.round_model import run_rounds
+    kw = dict(kw)
+    kw.setdefault("from_disk", True)
+    checked, executed = run_rounds(oracle_lib, 800, 14, 90 + K, p_drop=0.12, K=K, p_pause=0.1, pokes=True, **kw)
+    assert checked > 50_000 and executed > 4000
+    if K == 2 and kw.get("failover"):
+        assert run_rounds.failover[0] == 0        # nobody elected: one survivor of two is no majority
+
+
 def test_acceptor_side_long_random_sequences_against_java_reading(oracle_lib):
     """The same reading over seeded random sequences of 8 and 12 ops per group (the exhaustive plans stop at 4,
     the random ones above at 6)."""
