@@ -53,3 +53,11 @@ def test_decode_with_all_staging_loads_in_flight(hip_lib, oracle_lib, monkeypatc
             assert_same_decode(wh.decode(frames), wo.decode(frames), f"tile {tile} burst {burst}")
         eh.close(), eo.close()
         T.test_decode_of_damaged_bursts_against_java_reading(hip_lib, 2000, 30_000, 12, 0.5)
+
+
+@pytest.mark.parametrize("K,kw", [(1, dict()), (2, dict(p_rival=0.03)), (2, dict(failover=True, rounds_after=6)), (16, dict(p_rival=0.02))])
+def test_whole_round_with_unusual_group_sizes(hip_lib, K, kw):
+    """tests/test_oracle_kat.py::test_whole_round_with_unusual_group_sizes on the engine"""
+    from tests.round_model import run_rounds
+    checked, executed = run_rounds(hip_lib, 6000, 14, 90 + K, p_drop=0.12, K=K, from_disk=True, p_pause=0.1, pokes=True, **kw)
+    assert checked > 400_000
