@@ -25,8 +25,10 @@ def build_oracle():
 def load_oracle() -> GpxLib:
     global _lib
     if _lib is None:
-        build_oracle()
-        _lib = GpxLib(ORACLE_SO, "orc_", device_api=False)
+        so = os.environ.get("GPX_ORACLE_SO")   # scripts/oracle_mutants.py: a deliberately broken oracle, to see the tests fail
+        if not so:
+            so = build_oracle()
+        _lib = GpxLib(so, "orc_", device_api=False)
         L = _lib.lib
         L.orc_ballot_compare.argtypes = [C.c_int32] * 4
         L.orc_ballot_compare.restype = C.c_int
