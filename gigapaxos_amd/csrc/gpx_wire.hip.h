@@ -601,17 +601,9 @@ __device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64
   const int32_t lead = (int32_t)(a0 - a16);
   const int32_t total = lead + (int32_t)nbytes;
   const int32_t c_lo = (lead + 15) >> 4, c_hi = total >> 4; /* whole chunks inside [lead, total) */
-  /* (INFLIGHT also tells the compiler that the burst lies in global memory: an address made from an integer is
-   * generic, and generic loads count against the LDS counter too - every LDS wait then waits for them as well) */
-  typedef const __attribute__((address_space(1))) uint4* GlobalU4;
-  typedef const __attribute__((address_space(1))) uint32_t* GlobalU32;
-  typedef const __attribute__((address_space(1))) uint8_t* GlobalU8;
-  typename std::conditional<INFLIGHT, GlobalU4, const uint4*>::type src16 =
-      (typename std::conditional<INFLIGHT, GlobalU4, const uint4*>::type)a16;
+  const uint4* src16 = (const uint4*)a16;
   uint4* dst16 = (uint4*)lds;
-  typename std::conditional<INFLIGHT, GlobalU32, const uint32_t*>::type src =
-      (typename std::conditional<INFLIGHT, GlobalU32, const uint32_t*>::type)a16;
-  typedef typename std::conditional<INFLIGHT, GlobalU8, const uint8_t*>::type SrcU8;
+  const uint32_t* src = (const uint32_t*)a16;
   const int32_t w_hi = total >> 2;
   const int32_t head_end = c_lo * 4 < w_hi ? c_lo * 4 : w_hi;
   const int32_t hw = (lead >> 2) + (int32_t)threadIdx.x;                     /* a word before the first whole chunk */
@@ -626,12 +618,22 @@ __device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64
 #pragma unroll
     for (int k = 0; k < NCH; k++) {
       const int32_t c = c0 + k * BLOCK + (int32_t)threadIdx.x;
-      if (INFLIGHT) v[k] = make_uint4(0u, 0u, 0u, 0u);
-      if (c < c_hi) v[k] = src16[c];
+      if (INFLIGHT) {
+        /* (also: the burst lies in GLOBAL memory - an address made from an integer is generic, and generic loads
+         * count against the LDS counter too, so that every LDS wait waits for them as well) */
+        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+        v[k] = make_uint4(0u, 0u, 0u, 0u);
+        if (c < c_hi) {
+          const u32x4 t = ((const __attribute__((address_space(1))) u32x4*)a16)[c];
+          v[k] = make_uint4(t.x, t.y, t.z, t.w);
+        }
+      } else if (c < c_hi) {
+        v[k] = src16[c];
+      }
     }
     if (odd && hw < head_end) hv = src[hw];
     if (odd && tw < w_hi) tv = src[tw];
-    if (odd && tbyte) bv = ((SrcU8)src)[(w_hi << 2) + threadIdx.x];
+    if (odd && tbyte) bv = ((const uint8_t*)src)[(w_hi << 2) + threadIdx.x];
 #pragma unroll
     for (int k = 0; k < NCH; k++) {
       const int32_t c = c0 + k * BLOCK + (int32_t)threadIdx.x;
@@ -644,7 +646,7 @@ __device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64
   if (c_lo >= c_hi) { /* less than one whole chunk: only the odd words */
     if (hw < head_end) lds[hw] = src[hw];
     if (tw < w_hi) lds[tw] = src[tw];
-    if (tbyte) ((uint8_t*)lds)[(w_hi << 2) + threadIdx.x] = ((SrcU8)src)[(w_hi << 2) + threadIdx.x];
+    if (tbyte) ((uint8_t*)lds)[(w_hi << 2) + threadIdx.x] = ((const uint8_t*)src)[(w_hi << 2) + threadIdx.x];
   }
   return lead;
 }
