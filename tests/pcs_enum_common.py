@@ -221,7 +221,7 @@ def model_stream(members, me, nprop, votes, init_node_slots=None):
     return out, proposals, coordinator, node_slots
 
 
-def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower=0.08, p_stranger=0.0):
+def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower=0.08, p_stranger=0.0, p_extreme=0.0):
     """n_groups coordinators with nprop outstanding proposals each, every one fed its own random stream of
     n_votes accept replies (any member, any slot in [0, nprop + 1], lower / own / higher ballots, checkpoint
     slots -1 .. nprop) - all in ONE gpx_accept_reply_batch call, the groups interleaved; the decided stream,
@@ -246,6 +246,9 @@ def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower
     u = rng.random(n)
     bkind = np.where(u < p_higher, 1, np.where(u < p_higher + p_lower, -1, 0)).astype(np.int32)
     maxcp = rng.integers(-1, nprop + 1, n).astype(np.int32)
+    if p_extreme > 0.0:      # checkpoint slots half the int range apart: recordSlotNumber compares with a PLAIN < (PCS:809-825)
+        pick = rng.random(n) < p_extreme
+        maxcp[pick] = rng.choice(np.array([-2**31, -2**31 + 1, -2**30, 2**30, 2**31 - 2, 2**31 - 1], np.int64), size=int(pick.sum())).astype(np.int32)
     gcol = np.repeat(np.arange(G, dtype=np.int32), n_votes)
     bnum = np.where(bkind > 0, 1, 0).astype(np.int32)
     bcoord = np.where(bkind < 0, me - 1, me).astype(np.int32)

@@ -61,3 +61,10 @@ def test_whole_round_with_unusual_group_sizes(hip_lib, K, kw):
     from tests.round_model import run_rounds
     checked, executed = run_rounds(hip_lib, 6000, 14, 90 + K, p_drop=0.12, K=K, from_disk=True, p_pause=0.1, pokes=True, **kw)
     assert checked > 400_000
+
+
+def test_accept_replies_with_checkpoint_slots_half_the_int_range_apart(hip_lib):
+    """recordSlotNumber's plain < (PCS:809-825) under checkpoint slots near INT_MIN / INT_MAX, any vote order"""
+    from tests.pcs_enum_common import run_streams
+    for K, nprop, G, nv in ((3, 3, 50_000, 24), (5, 4, 25_000, 40), (4, 2, 25_000, 16)):
+        assert run_streams(hip_lib, K, nprop, G, nv, seed=K * 100 + nprop + 9, p_extreme=0.1) == G
