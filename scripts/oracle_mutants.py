@@ -5,7 +5,7 @@
 reading of the reference (no hand-computed known answers, no golden fixtures): a mutant that survives marks a rule
 the readings do not pin.  CPU only; test infrastructure like everything around oracle/.
 
-  python scripts/oracle_mutants.py [-k substring] > profiles/rNN_oracle_mutants.txt"""
+  python scripts/oracle_mutants.py [-k substring | --skip N] > profiles/rNN_oracle_mutants.txt"""
 import os
 import shutil
 import subprocess
@@ -57,17 +57,41 @@ MUTANTS = [
     ("NACKs are coalesced too", "inc", "      const bool coalescable = has_reply && named && (!sender || sender[i] == r_bcoord[i]);", "      const bool coalescable = has_reply && named;"),
     ("paxosID length is read as unsigned", "inc", "  const int8_t idLen = (int8_t)b.get();", "  const int32_t idLen = (int32_t)b.get();"),
     ("a null paxosID is fine in an accept reply", "inc", "        if (!pkt.hdr.has_id) throw JNullPointer();", "        if (false) throw JNullPointer();"),
-    ("digest length 0 still reads a digest", "inc", "  if (digestLength > 0) b.getBytes(digestLength);", "  if (digestLength >= 0) b.getBytes(digestLength);"),
+    ("a negative digest length throws instead of being skipped", "inc", "  if (digestLength > 0) b.getBytes(digestLength);", "  if (digestLength != 0) b.getBytes(digestLength);"),
     ("nested stop requests are not seen", "inc", "    r.stop_any = r.stop_any || nested.stop_any;", "    r.stop_any = r.stop_any;"),
     ("version mismatch is ignored", "inc", "      else if (grp->version != pkt.hdr.version) {", "      else if (false) {"),
     ("election: long dead alone is enough (the node need not be down)", "inc", "      else if (!nodeUp && longDead)", "      else if (longDead)"),
     ("election: my own ballot does not count as mine", "inc", "      if (cur.coord == e->cfg.my_id)\n        why = GPX_RUN_MINE;\n      else if", "      if (false)\n        why = GPX_RUN_MINE;\n      else if"),
+    # second batch
+    ("garbage collection of decisions also drops the decision AT the slot", "cpp", "      if (jsub(slot, it->first) > 0)\n        it = committedRequests.erase(it);", "      if (jsub(slot, it->first) >= 0)\n        it = committedRequests.erase(it);"),
+    ("reconstructDecision does not compare the accept's ballot with the commit's", "cpp", "      if (a != acceptedProposals.end() && a->second.ballot.equals(c->second.ballot)) {", "      if (a != acceptedProposals.end()) {"),
+    ("a placeholder replaces a decision that has its value", "cpp", "      if (c == committedRequests.end() || !c->second.hasValue)\n        committedRequests[decision->slot] = *decision;", "      committedRequests[decision->slot] = *decision;"),
+    ("a stopped instance keeps its pending decisions", "cpp", "    if (stopped) committedRequests.clear();", "    if (false) committedRequests.clear();"),
+    ("accepts stay in memory although they come from disk", "cpp", "    if (haveNext && fromDisk) acceptedProposals.erase(next->slot);", "    if (false) acceptedProposals.erase(next->slot);"),
+    ("a decision below the next slot is stored", "cpp", "    if (jsub(decision->slot, _slot) >= 0) {\n      auto c = committedRequests.find(decision->slot);", "    if (true) {\n      auto c = committedRequests.find(decision->slot);"),
+    ("canIgnorePrepareReply: <= instead of <", "cpp", "    if (b.compareTo(myBallot) < 0) return true;\n    bool member = false;", "    if (b.compareTo(myBallot) <= 0) return true;\n    bool member = false;"),
+    ("a second PREPARE_REPLY of the same acceptor is recorded again", "cpp", "    if (!member || (idx >= 0 && waitforMyBallot->responded[idx])) return true;", "    if (!member) return true;"),
+    ("getMinSlot recorded with a plain <", "cpp", "      if (members[i] == acceptor && jsub(nodeSlotNumbers[i], minSlot) < 0) nodeSlotNumbers[i] = minSlot;", "      if (members[i] == acceptor && nodeSlotNumbers[i] > minSlot) nodeSlotNumbers[i] = minSlot;"),
+    ("holes among the carried pvalues are not filled with no-ops", "cpp", "      } else if (pa == preActives.end()) {\n        ProposalState ps{false, WaitforUtility(&members)};\n        ps.kind = GPX_E_NOOP;\n        myProposals.emplace(cur, ps);", "      } else if (pa == preActives.end()) {"),
+    ("duplicates of carried requests are proposed again", "cpp", "        if (!dup) myProposals.emplace(cur, pa->second);", "        myProposals.emplace(cur, pa->second);"),
+    ("no stop is appended when a stop is not last", "cpp", "      if (last != myProposals.end() && !last->second.stop) {", "      if (false) {"),
+    ("a coordinator with proposals left resigns on a higher ballot", "cpp", "    if (c && Ballot{bnum[i], bcoord[i]}.compareTo(c->myBallot) > 0 && c->preemptedFully())", "    if (c && Ballot{bnum[i], bcoord[i]}.compareTo(c->myBallot) > 0)"),
+    ("RequestBatcher: >= instead of > on the size limit", "inc", "        if (nsize > max_size) break;", "        if (nsize >= max_size) break;"),
+    ("RequestBatcher: >= instead of > on the byte limit", "inc", "        if (nbytes > max_bytes) break;", "        if (nbytes >= max_bytes) break;"),
+    ("dequeueImpl: the bound is tested after the add", "inc", "    while (lengthEstimate < max_payload && !pending.empty()) {", "    while (lengthEstimate <= max_payload && !pending.empty()) {"),
+    ("process(): >= MIN_PP_BATCH_SIZE tasks are regrouped", "inc", "(int32_t)pkts.size() > min_batch) {", "(int32_t)pkts.size() >= min_batch) {"),
+    ("shouldSync: > instead of >= threshold", "inc", "    should_sync[i] = ((gap >= threshold) ||", "    should_sync[i] = ((gap > threshold) ||"),
+    ("a meta-commit without its accept is not missing", "inc", "          (!c->second.hasValue && !a.acceptedProposals.count(s)))", "          false)"),
+    ("handlePrepare adopts an equal ballot as an upgrade (logs again)", "inc", "    if (prep.compareTo(prev) > 0) {\n      a.ballotNum = prep.num;", "    if (prep.compareTo(prev) >= 0) {\n      a.ballotNum = prep.num;"),
+    ("prepare replies carry accepted pvalues below firstUndecidedSlot", "inc", "        if (jsub(kv.first, first_slot[i]) < 0) continue;", "        if (false) continue;"),
+    ("a BatchedCommit's slots keep their wire order", "inc", "          if (i > 0 && !(prev < s)) ascending = false;\n          prev = s;\n          pkt.c_slots.insert(s);", "          if (i > 0 && !(prev < s)) ascending = false;\n          prev = s;\n          if (pkt.c_slots.empty() || *pkt.c_slots.rbegin() < s) pkt.c_slots.insert(s);"),
     ("poke: any outstanding proposal, not the acceptor's next slot", "inc", "      auto p = c->myProposals.find(s); /* isCommandering(slot) */", "      auto p = c->myProposals.begin(); /* isCommandering(slot) */"),
 ]
 
 
 def main():
     pick = sys.argv[2] if len(sys.argv) > 2 and sys.argv[1] == "-k" else None
+    skip = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[1] == "--skip" else 0     # --skip N: leave out the first N
     text = {k: open(p).read() for k, p in SRC.items()}
     work = tempfile.mkdtemp(prefix="gpx_mutants_")
     os.makedirs(os.path.join(work, "include"))
@@ -78,7 +102,7 @@ def main():
     print("# scripts/oracle_mutants.py: one deliberate fault in the oracle per line; the tests run are ONLY those that hold")
     print("# the oracle to an independent Python reading of the Java (tests/round_model.py, acc_enum_common.py,")
     print("# pcs_enum_common.py, wire_model.py, test_host_rows_oracle.py).  killed = some reading noticed.")
-    for what, f, old, new in MUTANTS:
+    for what, f, old, new in MUTANTS[skip:]:
         if pick and pick not in what:
             continue
         assert text[f].count(old) == 1, f"mutation site not unique / not found: {what}"

@@ -292,7 +292,7 @@ class Candidate:
         return ("elected", self.median(), [(s_,) + self.proposals[s_] for s_ in sorted(self.proposals)])
 
 
-def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0):
+def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0, p_dup_reply=0.0):
     """Node 0 is gone.  Replica 1 runs for coordinator of every group it still serves: gpx_election_begin, the
     PREPAREs at the survivors (handle_prepare above), their replies at the candidate (Candidate above), the
     ACCEPTs of the view change at the survivors (Acceptor.handleAccept) - every output against the readings.
@@ -397,6 +397,21 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0):
                 got = [(s_, k_, h if k_ in (E_CARRY, E_PREACTIVE) else 0, bool(fl & PV_STOP)) for s_, k_, h, fl in lists[q]]
                 assert got == [(s_, kmap[k_], h, stop) for s_, k_, h, stop in lst], f"failover: ACCEPTs of group {g}: {got} != {lst}"
                 elected[g] = (med, lst)
+        if p_dup_reply > 0.0:
+            # a retransmitted PREPARE_REPLY: canIgnorePrepareReply (PCS:285-316) - the acceptor has answered already,
+            # or the election is over either way (waitforMyBallot == null / the coordinator is gone)
+            dup = [i for i in replies if rng.random() < p_dup_reply]
+            if dup:
+                di = np.array(dup, np.int64)
+                (vk, em, rst), lists = eng[1].prepare_reply(sub[di], np.full(di.shape[0], nodes[a], np.int32), rb[di], rc[di],
+                                                            rg[di] + 1, [pvs[i] for i in dup])
+                for q, i in enumerate(dup):
+                    g = int(sub[i])
+                    kind, _, _ = cand[g].prepare_reply(a, (int(rb[i]), int(rc[i])), int(rg[i]),
+                                                       [(s_, (b0, b1), h, bool(fl)) for s_, b0, b1, h, fl in pvs[i]])
+                    assert kind == "ignored" and int(rst[q]) == S_OK and int(vk[q]) == V_IGNORED and lists[q] == [], \
+                        f"failover: repeated reply of replica {a} for group {g}"
+                check_failover.dup_replies = getattr(check_failover, "dup_replies", 0) + len(dup)
     # the ACCEPTs of the view change at the survivors, in the new ballot
     n_acc = n_carry = n_noop = 0
     votes = []                                             # their replies, on the way to the new coordinator
@@ -444,7 +459,7 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0):
 
 
 def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True, failover=False,
-               rounds_after=0, p_pause=0.0, pokes=False):
+               rounds_after=0, p_pause=0.0, pokes=False, p_dup_reply=0.0):
     """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
     slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
@@ -681,7 +696,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
 
     play(rounds, 0, list(range(K)), coord, p_rival, [], "round ")
     run_rounds.gaps = check_gaps(eng, acc, G, "final")
-    run_rounds.failover = check_failover(eng, acc, G, NODES, rng, K, p_drop, p_stop) if failover else None
+    run_rounds.failover = check_failover(eng, acc, G, NODES, rng, K, p_drop, p_stop, p_dup_reply) if failover else None
     coord2 = None
     if failover and rounds_after:
         # the new coordinators (replica 1) go on: the replies to the view change's ACCEPTs, decisions, commits,

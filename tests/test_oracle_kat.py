@@ -536,7 +536,8 @@ def test_pause_and_hot_restore_between_rounds_against_java_reading(oracle_lib, G
     heard so far."""
     from tests.round_model import run_rounds
     checked, executed = run_rounds(oracle_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop,
-                                   from_disk=seed % 2 == 0, failover=failover, rounds_after=8 if failover else 0, p_pause=0.15, pokes=True)
+                                   from_disk=seed % 2 == 0, failover=failover, rounds_after=8 if failover else 0, p_pause=0.15, pokes=True,
+                                   p_dup_reply=0.3)   # (failover cases: three in ten PREPARE_REPLYs arrive twice)
     assert executed > G * rounds // 5 and run_rounds.busy > G and run_rounds.poked > G
     if seed % 2 == 0:
         assert run_rounds.paused > G and run_rounds.paused_coord > G // 4 and run_rounds.relogged > G // 10

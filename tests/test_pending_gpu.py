@@ -16,7 +16,7 @@ def test_pause_and_hot_restore_between_rounds(hip_lib, G, rounds, seed, p_drop, 
     """tests/test_oracle_kat.py::test_pause_and_hot_restore_between_rounds_against_java_reading on the engine"""
     from tests.round_model import run_rounds
     run_rounds(hip_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop, from_disk=seed % 2 == 0,
-               failover=failover, rounds_after=6 if failover else 0, p_pause=0.15, pokes=True)
+               failover=failover, rounds_after=6 if failover else 0, p_pause=0.15, pokes=True, p_dup_reply=0.3)
     assert run_rounds.busy > G and run_rounds.paused > (G if seed % 2 == 0 else 0)
 
 
