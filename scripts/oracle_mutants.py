@@ -85,6 +85,15 @@ MUTANTS = [
     ("handlePrepare adopts an equal ballot as an upgrade (logs again)", "inc", "    if (prep.compareTo(prev) > 0) {\n      a.ballotNum = prep.num;", "    if (prep.compareTo(prev) >= 0) {\n      a.ballotNum = prep.num;"),
     ("prepare replies carry accepted pvalues below firstUndecidedSlot", "inc", "        if (jsub(kv.first, first_slot[i]) < 0) continue;", "        if (false) continue;"),
     ("a BatchedCommit's slots keep their wire order", "inc", "          if (i > 0 && !(prev < s)) ascending = false;\n          prev = s;\n          pkt.c_slots.insert(s);", "          if (i > 0 && !(prev < s)) ascending = false;\n          prev = s;\n          if (pkt.c_slots.empty() || *pkt.c_slots.rbegin() < s) pkt.c_slots.insert(s);"),
+    # third batch
+    ("the first int of a frame is not checked", "inc", "    if (first != GPX_WT_PAXOS_PACKET) return GPX_W_MALFORMED; /* type == null -> fatal */", "    if (false) return GPX_W_MALFORMED; /* type == null -> fatal */"),
+    ("PREEMPTED (13) is not a packet type", "inc", "case 9: case 13: case 21:", "case 9: case 21:"),
+    ("a BatchedCommit's group includes this node", "inc", "      if (m != e->cfg.my_id) grp.insert(m);", "      grp.insert(m);"),
+    ("a BatchedAcceptReply carries the LAST reply's maxCheckpointedSlot", "inc", "          bar->slots[slot[i]] = req_id ? req_id[i] : 0; /* addAcceptReply: slots.put */", "          { bar->slots[slot[i]] = req_id ? req_id[i] : 0; bar->maxcp = r_maxcp[i]; } /* addAcceptReply: slots.put */"),
+    ("getNextCoordinator: the coordinator itself is next", "inc", "        next = g->members[(q + 1) % g->members.size()];", "        next = g->members[q % g->members.size()];"),
+    ("getMaxCommittedSlot of a stopped instance looks at its decisions", "inc", "    if (!a.stopped && !a.committedRequests.empty()) {", "    if (!a.committedRequests.empty()) {"),
+    ("getMissingCommittedSlots ignores the size limit", "inc", "    for (int32_t s = slot; jsub(s, maxc) < 0 && jsub(s, limit) < 0 && j < 64;", "    for (int32_t s = slot; jsub(s, maxc) < 0 && j < 64;"),
+    ("the ACCEPT's sender is read before its median", "inc", "        pkt.median = b.getInt();\n        b.get(); /* noCoalesce */\n        pkt.sender = b.getInt();", "        pkt.sender = b.getInt();\n        b.get(); /* noCoalesce */\n        pkt.median = b.getInt();"),
     ("poke: any outstanding proposal, not the acceptor's next slot", "inc", "      auto p = c->myProposals.find(s); /* isCommandering(slot) */", "      auto p = c->myProposals.begin(); /* isCommandering(slot) */"),
 ]
 
