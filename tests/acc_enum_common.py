@@ -37,6 +37,29 @@ COORD = 100  # coordinator id of every ballot used here (ballots differ in their
 GET_ACCEPTED_PVALUES_FROM_DISK = True  # PaxosAcceptor.java:75-76 (the engine's GPX_F_ACCEPTS_FROM_DISK)
 
 
+class I32(int):
+    """a Java int: + and - wrap to 32 bits, comparisons are signed.  With slots of this type the reading below - which
+    keeps every `a - b < 0` of the Java as written - computes what the Java computes at the int wrap too."""
+
+    @staticmethod
+    def _w(x):
+        return I32(((int(x) + 2**31) % 2**32) - 2**31)
+
+    def __add__(self, o):
+        return I32._w(int(self) + int(o))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return I32._w(int(self) - int(o))
+
+    def __rsub__(self, o):
+        return I32._w(int(o) - int(self))
+
+    def __neg__(self):
+        return I32._w(-int(self))
+
+
 def ballot_cmp(b1, b2):
     """Ballot.compareTo: by ballotNumber, then coordinatorID."""
     if b1[0] != b2[0]:
@@ -239,7 +262,7 @@ def _segments(seq):
     return segs
 
 
-def run_sequences(lib, seqs, init="create", order="interleaved", from_disk=True, sample_dumps=64, promise=False):
+def run_sequences(lib, seqs, init="create", order="interleaved", from_disk=True, sample_dumps=64, promise=False, base=0):
     """One group per sequence.  Phase p of a group = its p-th run of same-call ops; phase p of all groups
     goes out as ONE batch per call type, a group's records in sequence order (so a group has several
     records per batch wherever its sequence repeats a call).  order = 'interleaved' (records of different
@@ -250,12 +273,18 @@ def run_sequences(lib, seqs, init="create", order="interleaved", from_disk=True,
     e = Engine(lib, COORD + 1, G, kmax=3, window=8, max_batch=max(1 << 16, 8 * G), flags=flags)
     members = np.tile(np.array([COORD, COORD + 1, COORD + 2], np.int32), (G, 1))
     rows = (hri_create if init == "create" else hri_initial)(G, 3, COORD)
+    if base:
+        # the same sequences with every slot (the ops', the medians', the instance's own) moved by `base`, Java ints
+        # wrapping: the instance is restored (HotRestoreInfo) at slot 1 + base
+        seqs = [tuple((k, I32(sl) + base, bn, I32(md) + base, st) for k, sl, bn, md, st in sq) for sq in seqs]
+        rows["acc_slot"] = int(I32(1) + base)
+        rows["acc_gc_slot"] = int(I32(-1 if init == "create" else 0) + base)
     assert (e.create_groups(np.arange(G), members, 3, rows) == S_OK).all()
     if promise:
         from gigapaxos_amd import ORDERED_ACCEPT, ORDERED_COMMIT
         e.set_ordered_batches(ORDERED_ACCEPT | ORDERED_COMMIT)
     gc0 = -1 if init == "create" else 0
-    models = [Acceptor(1, (0, COORD), gc0, from_disk) for _ in range(G)]
+    models = [Acceptor(I32(1) + base if base else 1, (0, COORD), I32(gc0) + base if base else gc0, from_disk) for _ in range(G)]
     segs = [_segments(s) for s in seqs]
     nphase = max(len(s) for s in segs)
     checked = 0
@@ -326,9 +355,12 @@ def run_sequences(lib, seqs, init="create", order="interleaved", from_disk=True,
         nc = d[pos]
         com = [tuple(d[pos + 1 + 6 * i: pos + 7 + 6 * i]) for i in range(nc)]
         assert (a_slot, a_bn, a_bc, a_gc, stopped) == m.row() + (1 if m.stopped else 0,), (seqs[g], d)
-        assert acc == [(s, v.ballot[0], v.ballot[1], 1 if v.stop else 0) for s, v in sorted(m.accepted.items())], (seqs[g], acc)
-        assert com == [(s, v.ballot[0], v.ballot[1], v.median, 1 if v.has_value else 0, 1 if (v.stop and v.has_value) else 0)
-                       for s, v in sorted(m.committed.items())], (seqs[g], com)
+        key = lambda t: int(I32(t[0]) - m._slot)   # noqa: E731  (the maps in order of distance from the next slot: at the wrap too)
+        if not base:
+            assert acc == sorted(acc) and com == sorted(com)   # (the dump lists them by slot)
+        assert sorted(acc, key=key) == sorted([(s, v.ballot[0], v.ballot[1], 1 if v.stop else 0) for s, v in m.accepted.items()], key=key), (seqs[g], acc)
+        assert sorted(com, key=key) == sorted([(s, v.ballot[0], v.ballot[1], v.median, 1 if v.has_value else 0, 1 if (v.stop and v.has_value) else 0)
+                                               for s, v in m.committed.items()], key=key), (seqs[g], com)
     e.close()
     return checked
 

@@ -561,6 +561,25 @@ def test_whole_round_with_unusual_group_sizes(oracle_lib, K, kw):
         assert run_rounds.failover[0] == 0        # nobody elected: one survivor of two is no majority
 
 
+@pytest.mark.parametrize("base", [2**31 - 3, 2**31 - 2, 2**31 - 1, -2**31 + 1, 12345])
+def test_acceptor_side_at_the_int_wrap_against_java_reading(oracle_lib, base):
+    """The acceptor reading with Java ints (tests/acc_enum_common.I32: + and - wrap, comparisons signed; every
+    `a - b < 0` of the Java is kept as written) for instances restored at slot 1 + base, so that the slots of the
+    ops, the medians, the next slot and the GC slot cross Integer.MAX_VALUE -> MIN_VALUE inside the sequences:
+    pairs, and random sequences of 4 and 8 ops, both batch orders."""
+    import tests.acc_enum_common as A
+    rng = np.random.default_rng(base % 1000)
+    n = 0
+    for L, count in ((2, None), (4, 8000), (8, 4000)):
+        if count is None:
+            seqs = [(a, b) for a in A.WIDE[::3] for b in A.WIDE[::5]]
+        else:
+            seqs = [tuple(A.WIDE[i] for i in row) for row in rng.integers(0, len(A.WIDE), (count, L)).tolist()]
+        for order, init in (("interleaved", "create"), ("grouped", "initial")):
+            n += A.run_sequences(oracle_lib, seqs, init=init, order=order, base=base)
+    assert n > 100_000
+
+
 def test_acceptor_side_long_random_sequences_against_java_reading(oracle_lib):
     """The same reading over seeded random sequences of 8 and 12 ops per group (the exhaustive plans stop at 4,
     the random ones above at 6)."""

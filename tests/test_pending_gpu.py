@@ -68,3 +68,16 @@ def test_accept_replies_with_checkpoint_slots_half_the_int_range_apart(hip_lib):
     from tests.pcs_enum_common import run_streams
     for K, nprop, G, nv in ((3, 3, 50_000, 24), (5, 4, 25_000, 40), (4, 2, 25_000, 16)):
         assert run_streams(hip_lib, K, nprop, G, nv, seed=K * 100 + nprop + 9, p_extreme=0.1) == G
+
+
+@pytest.mark.parametrize("base", [2**31 - 3, 2**31 - 1, -2**31 + 1])
+def test_acceptor_side_at_the_int_wrap(hip_lib, base):
+    """tests/test_oracle_kat.py::test_acceptor_side_at_the_int_wrap_against_java_reading on the engine, more sequences"""
+    import numpy as np
+    import tests.acc_enum_common as A
+    rng = np.random.default_rng(base % 1000)
+    for L, count in ((2, None), (4, 60_000), (8, 40_000)):
+        seqs = ([(a, b) for a in A.WIDE for b in A.WIDE[::2]] if count is None else
+                [tuple(A.WIDE[i] for i in row) for row in rng.integers(0, len(A.WIDE), (count, L)).tolist()])
+        for order, init in (("interleaved", "create"), ("grouped", "initial")):
+            A.run_sequences(hip_lib, seqs, init=init, order=order, base=base)
