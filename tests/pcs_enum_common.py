@@ -178,7 +178,7 @@ def run_maxcp(lib, K, nprop, init_node_slots, sample=None, seed=0):
     return G
 
 
-def model_stream(members, me, nprop, votes, init_node_slots=None):
+def model_stream(members, me, nprop, votes, init_node_slots=None, base=0):
     """The same reading driven by an ARBITRARY vote stream instead of main's slot-by-slot, member-by-member loop:
     votes = [(slot, member index, ballot kind, maxCheckpointedSlot)], ballot kind -1 / 0 / +1 = lower than /
     equal to / higher than the coordinator's ballot (PaxosCoordinator.handleAcceptReply :210-250: a lower ballot
@@ -188,6 +188,9 @@ def model_stream(members, me, nprop, votes, init_node_slots=None):
     my = (0, me)
     node_slots = list(init_node_slots) if init_node_slots is not None else [0] * K
     proposals = {s: [False] * K for s in range(1, nprop + 1)}
+    if base:                                                     # a coordinator restored at nextProposalSlot 1 + base (Java ints wrap)
+        from tests.acc_enum_common import I32
+        proposals = {int(I32(s) + base): w for s, w in proposals.items()}
     coordinator = True
     out = []
     for v, (slot, j, bkind, maxcp) in enumerate(votes):
@@ -221,7 +224,7 @@ def model_stream(members, me, nprop, votes, init_node_slots=None):
     return out, proposals, coordinator, node_slots
 
 
-def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower=0.08, p_stranger=0.0, p_extreme=0.0):
+def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower=0.08, p_stranger=0.0, p_extreme=0.0, base=0):
     """n_groups coordinators with nprop outstanding proposals each, every one fed its own random stream of
     n_votes accept replies (any member, any slot in [0, nprop + 1], lower / own / higher ballots, checkpoint
     slots -1 .. nprop) - all in ONE gpx_accept_reply_batch call, the groups interleaved; the decided stream,
@@ -235,6 +238,10 @@ def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower
     mem = np.tile(np.array(members, np.int32), (G, 1))
     rows = hri_create(G, K, me)
     rows["node_slots"][:, :K] = np.array(init, np.int32)
+    if base:     # the instance and its coordinator restored at slot 1 + base: the proposals' slots cross the int wrap
+        from tests.acc_enum_common import I32
+        rows["acc_slot"] = rows["next_proposal_slot"] = int(I32(1) + base)
+        rows["acc_gc_slot"] = int(I32(-1) + base)
     assert (e.create_groups(np.arange(G), mem, K, rows) == S_OK).all()
     for _ in range(nprop):
         assert (e.propose(np.arange(G, dtype=np.int32))[4] == S_OK).all()
@@ -249,6 +256,9 @@ def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower
     if p_extreme > 0.0:      # checkpoint slots half the int range apart: recordSlotNumber compares with a PLAIN < (PCS:809-825)
         pick = rng.random(n) < p_extreme
         maxcp[pick] = rng.choice(np.array([-2**31, -2**31 + 1, -2**30, 2**30, 2**31 - 2, 2**31 - 1], np.int64), size=int(pick.sum())).astype(np.int32)
+    if base:
+        slot = (slot.astype(np.int64) + base + 2**31) % 2**32 - 2**31
+        slot = slot.astype(np.int32)
     gcol = np.repeat(np.arange(G, dtype=np.int32), n_votes)
     bnum = np.where(bkind > 0, 1, 0).astype(np.int32)
     bcoord = np.where(bkind < 0, me - 1, me).astype(np.int32)
@@ -258,7 +268,7 @@ def run_streams(lib, K, nprop, n_groups, n_votes, seed=0, p_higher=0.03, p_lower
         lo = p * n_votes
         votes = list(zip(slot[lo:lo + n_votes].tolist(), mj[lo:lo + n_votes].tolist(), bkind[lo:lo + n_votes].tolist(),
                          maxcp[lo:lo + n_votes].tolist()))
-        out, _, coord, ns = model_stream(members, me, nprop, votes, init)
+        out, _, coord, ns = model_stream(members, me, nprop, votes, init, base)
         expect.append(out)
         final.append((coord, ns))
     order = np.argsort(np.arange(n) % n_votes, kind="stable")    # interleave the groups, stable per group

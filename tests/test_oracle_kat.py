@@ -482,6 +482,9 @@ def test_pcs_accept_replies_in_any_order_against_java_reading(oracle_lib, K, npr
     assert run_streams(oracle_lib, K, nprop, G // 2, nv, seed=K * 100 + nprop + 7, p_stranger=0.05) == G // 2
     # ... and checkpoint slots half the int range apart: recordSlotNumber's plain < is not Ballot's wraparound compare
     assert run_streams(oracle_lib, K, nprop, G // 4, nv, seed=K * 100 + nprop + 9, p_extreme=0.1) == G // 4
+    # ... and coordinators restored at nextProposalSlot 1 + base: the proposals' slots cross Integer.MAX_VALUE
+    for base in (2**31 - 3, 2**31 - 1):
+        assert run_streams(oracle_lib, K, nprop, G // 8, nv, seed=K * 100 + nprop + 11, p_extreme=0.05, base=base) == G // 8
 
 
 @pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival", [(3000, 20, 2, 0.2, 3, 0.0), (4000, 16, 3, 0.05, 3, 0.0),

@@ -68,6 +68,8 @@ def test_accept_replies_with_checkpoint_slots_half_the_int_range_apart(hip_lib):
     from tests.pcs_enum_common import run_streams
     for K, nprop, G, nv in ((3, 3, 50_000, 24), (5, 4, 25_000, 40), (4, 2, 25_000, 16)):
         assert run_streams(hip_lib, K, nprop, G, nv, seed=K * 100 + nprop + 9, p_extreme=0.1) == G
+        for base in (2**31 - 3, 2**31 - 1):      # coordinators whose proposals cross Integer.MAX_VALUE
+            assert run_streams(hip_lib, K, nprop, G // 2, nv, seed=K * 100 + nprop + 11, p_extreme=0.05, base=base) == G // 2
 
 
 @pytest.mark.parametrize("base", [2**31 - 3, 2**31 - 1, -2**31 + 1])
