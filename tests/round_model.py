@@ -43,7 +43,7 @@ from gigapaxos_amd import (Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STO
 
 P_NACK, P_TOLOG = 1, 2   # GPX_P_NACK, GPX_P_TOLOG (include/gpx.h)
 PV_STOP = 1              # GPX_PV_STOP
-from tests.acc_enum_common import Acceptor, PValue
+from tests.acc_enum_common import Acceptor, PValue, I32
 
 WINDOW = 16
 
@@ -106,10 +106,17 @@ class Coordinator:
 
 
 def max_committed_slot(a):
-    """PaxosAcceptor.getMaxCommittedSlot (PaxosAcceptor.java:425-438; no slot near Integer.MAX_VALUE here)"""
+    """PaxosAcceptor.getMaxCommittedSlot (PaxosAcceptor.java:425-438): TreeMap.lastKey() is the largest key in SIGNED
+    order; only when that is Integer.MAX_VALUE does the Java walk the keys with the wraparound compare"""
     if a.stopped or not a.committed:
         return a._slot - 1
-    return max(a.committed)
+    max_slot = max(a.committed)
+    if max_slot == 2**31 - 1:
+        max_slot = a._slot - 1
+        for i in sorted(a.committed):
+            if i - max_slot > 0:
+                max_slot = i
+    return max_slot
 
 
 def missing_committed_slots(a, size_limit):
@@ -168,6 +175,7 @@ def handle_prepare(a, ballot, first_undecided):
     -> None (stopped) | (reply ballot, gc slot, nack, to_log, [(slot, accepted ballot, is stop)] ascending)"""
     if a.stopped:
         return None
+    first_undecided = type(a._slot)(first_undecided)       # (a Java int where the instance's slots are: acc_enum_common.I32)
     prev = a.ballot
     if ballot > a.ballot:                                  # strictly greater: adopt
         a.ballot = ballot
@@ -459,7 +467,7 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0, p_dup_reply=0
 
 
 def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0, p_stop=0.0, from_disk=True, failover=False,
-               rounds_after=0, p_pause=0.0, pokes=False, p_dup_reply=0.0):
+               rounds_after=0, p_pause=0.0, pokes=False, p_dup_reply=0.0, base=0):
     """K replicas per group (nodes 100 .. 100 + K - 1, node 100 the coordinator).  Returns (records compared,
     slots executed over all replicas)."""
     rng = np.random.default_rng(seed)
@@ -469,10 +477,25 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
     eng = [Engine(lib, NODES[a], G, kmax=K, window=WINDOW, max_batch=32 * G + 64, flags=1 if from_disk else 0)
            for a in range(K)]
     mem = np.tile(np.array(NODES, np.int32), (G, 1))
+    rows0 = hri_create(G, K, NODES[0])
+    first_slot = 1
+    if base:
+        # every instance restored (HotRestoreInfo) at slot 1 + base, Java ints wrapping (acc_enum_common.I32): with base
+        # just below 2^31 the slots, the checkpoint slots and the medians cross Integer.MAX_VALUE during the rounds
+        # (recordSlotNumber's plain < freezes nodeSlotNumbers at the wrap - PCS:809-825, the Java's own behaviour - and with
+        # them the medians and every acceptedGCSlot: a retransmitted ACCEPT of an executed slot is then never collected.
+        # The Java's map is unbounded; the engine's ring is not, so here the traffic stops WINDOW slots after the last GC)
+        assert not failover, "the view-change reading is written for small slots"
+        first_slot = I32(1) + base
+        rows0["acc_slot"] = rows0["next_proposal_slot"] = int(first_slot)
+        rows0["acc_gc_slot"] = int(first_slot - 2)
     for e in eng:
-        assert (e.create_groups(np.arange(G), mem, K, hri_create(G, K, NODES[0])) == S_OK).all()
+        assert (e.create_groups(np.arange(G), mem, K, rows0) == S_OK).all()
     coord = [Coordinator(NODES[0], K) for _ in range(G)]
-    acc = [[Acceptor(1, (0, NODES[0]), -1, from_disk=from_disk) for _ in range(G)] for _ in range(K)]
+    acc = [[Acceptor(first_slot, (0, NODES[0]), first_slot - 2, from_disk=from_disk) for _ in range(G)] for _ in range(K)]
+    for c in coord:
+        c.next = first_slot
+    J = type(first_slot)        # what a slot read back from a batch column becomes again: int, or the Java int (I32)
     pending = [[] for _ in range(K)]        # per replica: ACCEPTs lost on their way, to be sent again
     pending_c = [[] for _ in range(K)]      # ... and commits
     forwarded = refused = stopped_props = 0
@@ -558,10 +581,12 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                 # (with accepts kept in memory - from_disk false - an executed slot's accept holds its ring entry until
                 # garbage collection reaches it: the oldest live slot of a replica is then acceptedGCSlot + 1)
                 # (the oldest outstanding proposal too: its ring entry is the one slot next - WINDOW would need)
+                # (written as distances from the next proposal slot, a - b, so that they hold at the int wrap as well)
                 gs = np.array([g for g in gs.tolist() if coord[g] is not None and len(coord[g].proposals) < WINDOW - 2 and
-                               coord[g].next - min(coord[g].proposals, default=coord[g].next) < WINDOW - 1 and
-                               coord[g].next - min(min(acc[a][g]._slot, acc[a][g]._slot if from_disk else acc[a][g].acceptedGCSlot + 1)
-                                                   for a in replicas) < WINDOW - 2], np.int32)
+                               all(coord[g].next - s_ < WINDOW - 1 for s_ in coord[g].proposals) and
+                               all(coord[g].next - acc[a][g]._slot < WINDOW - 2 and
+                                   ((from_disk and not base) or coord[g].next - (acc[a][g].acceptedGCSlot + 1) < WINDOW - 2) for a in replicas)],
+                              np.int32)
                 if gs.shape[0] == 0:
                     continue
                 stop_req = (rng.random(gs.shape[0]) < p_stop).astype(np.uint8)
@@ -597,8 +622,8 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                 # higher ballot (PaxosAcceptor.acceptAndUpdateBallot :302-322), which preempts its proposals and, once
                 # none is left, makes it resign (PCS:661-683, PISM:1361-1364)
                 for g in np.nonzero(rng.random(G) < p_rival_)[0].tolist():
-                    if coord[g] is not None and coord[g].next > 1:
-                        rival.append((g, coord[g].next - 1, 1, NODES[1], -1, 0))
+                    if coord[g] is not None and coord[g].next - first_slot > 0:
+                        rival.append((g, coord[g].next - 1, 1, NODES[1], first_slot - 2, 0))
             for a in replicas:
                 # (at replica 0 as well: once the coordinator's OWN acceptor has adopted the rival's ballot, requests
                 # are forwarded to the rival instead of being proposed)
@@ -632,9 +657,10 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                                                            (cols[:, 5] * A_STOP).astype(np.uint8))
                 want_runs = []
                 for i, (g, slot, bnum, bcoord, median, stop) in enumerate(seq):
+                    slot, median = J(slot), J(median)
                     status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((bnum, bcoord), slot, median, True, bool(stop)))
                     assert (int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i])) == (status, wb, wc, wm, wf), \
-                        f"round {r} replica {a}: ACCEPT {seq[i]}"
+                        f"round {r} replica {a}: ACCEPT {seq[i]}: got {(int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i]))}, the reading gives {(status, wb, wc, wm, wf)}"
                     if run is not None:
                         want_runs.append((g, i, run[0], run[1]))
                     if status == S_OK and coord[g] is not None and (bnum, bcoord) == coord[g].my:   # (the rival's replies go to the rival)
@@ -679,6 +705,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                 st, runs = eng[a].commit(cols[:, 0], cols[:, 2], cols[:, 3], cols[:, 1], cols[:, 4], cols[:, 5].astype(np.uint8))
                 want_runs = []
                 for i, (g, slot, bnum, bcoord, median, kind) in enumerate(cols.tolist()):
+                    slot, median = J(slot), J(median)
                     if kind & C_HASVALUE:
                         status, run = acc[a][g].handleDecision((bnum, bcoord), slot, median, bool(kind & C_STOP))
                     else:
@@ -733,7 +760,7 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
             assert ((snap1["has_coord"] != 0) == alive2).all(), "new coordinators that resigned"
             assert (snap1["next_proposal_slot"][alive2] == np.array([coord2[g].next for g in eg.tolist()], np.int32)[alive2]).all()
             assert (snap1["node_slots"][:, :K][alive2] == np.array([coord2[g].node_slots for g in eg.tolist()], np.int32)[alive2]).all()
-    executed = sum(acc[a][g]._slot - 1 for a in range(K) for g in range(G))
+    executed = sum(int(acc[a][g]._slot - first_slot) for a in range(K) for g in range(G))
     for e in eng:
         e.close()
     run_rounds.resigned = int((~alive).sum())

@@ -564,6 +564,21 @@ def test_whole_round_with_unusual_group_sizes(oracle_lib, K, kw):
         assert run_rounds.failover[0] == 0        # nobody elected: one survivor of two is no majority
 
 
+@pytest.mark.parametrize("base,K,kw", [(2**31 - 6, 3, dict()), (2**31 - 20, 3, dict(p_rival=0.03)), (2**31 - 10, 3, dict(p_stop=0.02, from_disk=False)),
+                                       (-2**31 + 1, 4, dict()), (2**31 - 12, 5, dict(p_pause=0.15, pokes=True))])
+def test_whole_round_across_the_int_wrap(oracle_lib, base, K, kw):
+    """The round model with Java ints (acc_enum_common.I32) for instances restored at slot 1 + base: proposals,
+    ACCEPTs, replies with their checkpoint slots, medians, decisions, commits, execution runs, gap scans and PREPAREs
+    while the slots cross Integer.MAX_VALUE.  What the Java does there is part of the contract: recordSlotNumber's
+    plain < (PCS:809-825) stops recording checkpoint slots once they turn negative, so the medians - and with them
+    every acceptedGCSlot - freeze at the wrap; the reading and the oracle agree on that too."""
+    from tests.round_model import run_rounds
+    kw = dict(kw)
+    kw.setdefault("from_disk", True)
+    checked, executed = run_rounds(oracle_lib, 1200, 16, 7, p_drop=0.12, K=K, base=base, **kw)
+    assert checked > 150_000 and executed > 30_000
+
+
 @pytest.mark.parametrize("base", [2**31 - 3, 2**31 - 2, 2**31 - 1, -2**31 + 1, 12345])
 def test_acceptor_side_at_the_int_wrap_against_java_reading(oracle_lib, base):
     """The acceptor reading with Java ints (tests/acc_enum_common.I32: + and - wrap, comparisons signed; every

@@ -83,3 +83,14 @@ def test_acceptor_side_at_the_int_wrap(hip_lib, base):
                 [tuple(A.WIDE[i] for i in row) for row in rng.integers(0, len(A.WIDE), (count, L)).tolist()])
         for order, init in (("interleaved", "create"), ("grouped", "initial")):
             A.run_sequences(hip_lib, seqs, init=init, order=order, base=base)
+
+
+@pytest.mark.parametrize("base,K,kw", [(2**31 - 6, 3, dict()), (2**31 - 20, 3, dict(p_rival=0.03)), (2**31 - 10, 3, dict(p_stop=0.02, from_disk=False)),
+                                       (2**31 - 12, 5, dict(p_pause=0.15, pokes=True))])
+def test_whole_round_across_the_int_wrap(hip_lib, base, K, kw):
+    """tests/test_oracle_kat.py::test_whole_round_across_the_int_wrap on the engine"""
+    from tests.round_model import run_rounds
+    kw = dict(kw)
+    kw.setdefault("from_disk", True)
+    checked, executed = run_rounds(hip_lib, 10_000, 16, 7, p_drop=0.12, K=K, base=base, **kw)
+    assert checked > 1_000_000
