@@ -24,6 +24,8 @@ READINGS = [
     "tests/test_oracle_kat.py::test_pcs_main_accept_reply_tail_every_coin",
     "tests/test_oracle_kat.py::test_pcs_accept_reply_tail_with_checkpoint_slots_enumerated",
     "tests/test_oracle_kat.py::test_pcs_accept_replies_in_any_order_against_java_reading",
+    "tests/test_oracle_kat.py::test_acceptor_side_at_the_int_wrap_against_java_reading",
+    "tests/test_oracle_kat.py::test_whole_round_across_the_int_wrap",
     "tests/test_oracle_kat.py::test_whole_round_with_unusual_group_sizes",
     "tests/test_oracle_kat.py::test_pause_and_hot_restore_between_rounds_against_java_reading",
     "tests/test_oracle_kat.py::test_view_change_after_lossy_rounds_against_java_reading",
@@ -94,6 +96,12 @@ MUTANTS = [
     ("getMaxCommittedSlot of a stopped instance looks at its decisions", "inc", "    if (!a.stopped && !a.committedRequests.empty()) {", "    if (!a.committedRequests.empty()) {"),
     ("getMissingCommittedSlots ignores the size limit", "inc", "    for (int32_t s = slot; jsub(s, maxc) < 0 && jsub(s, limit) < 0 && j < 64;", "    for (int32_t s = slot; jsub(s, maxc) < 0 && j < 64;"),
     ("the ACCEPT's sender is read before its median", "inc", "        pkt.median = b.getInt();\n        b.get(); /* noCoalesce */\n        pkt.sender = b.getInt();", "        pkt.sender = b.getInt();\n        b.get(); /* noCoalesce */\n        pkt.median = b.getInt();"),
+    # fourth batch: plain comparisons where the Java subtracts (visible only where slots cross Integer.MAX_VALUE)
+    ("a decision is stored iff its slot >= the next slot, compared plainly", "cpp", "    if (jsub(decision->slot, _slot) >= 0) {\n      auto c = committedRequests.find(decision->slot);", "    if (decision->slot >= _slot) {\n      auto c = committedRequests.find(decision->slot);"),
+    ("the GC slot is clamped to the next slot with a plain compare", "cpp", "    if (jsub(_slot, gcSlot) <= 0) gcSlot = jsub(_slot, 1);", "    if (_slot <= gcSlot) gcSlot = jsub(_slot, 1);"),
+    ("accepted pvalues are collected with a plain compare", "cpp", "        if (jsub(it->first, gcSlot) <= 0)\n          it = acceptedProposals.erase(it);", "        if (it->first <= gcSlot)\n          it = acceptedProposals.erase(it);"),
+    ("an ACCEPT is stored iff its slot > the GC slot, compared plainly", "cpp", "      if (jsub(accept.slot, acceptedGCSlot) > 0) {", "      if (accept.slot > acceptedGCSlot) {"),
+    ("the next proposal slot does not wrap (saturates)", "cpp", "    nextProposalSlotNumber = (int32_t)((uint32_t)nextProposalSlotNumber + 1u);\n    ProposalState ps{stop, WaitforUtility(&members)};", "    nextProposalSlotNumber = nextProposalSlotNumber == INT32_MAX ? INT32_MAX : nextProposalSlotNumber + 1;\n    ProposalState ps{stop, WaitforUtility(&members)};"),
     ("poke: any outstanding proposal, not the acceptor's next slot", "inc", "      auto p = c->myProposals.find(s); /* isCommandering(slot) */", "      auto p = c->myProposals.begin(); /* isCommandering(slot) */"),
 ]
 
