@@ -217,6 +217,17 @@ def value_handle(slot, ballot):
     return (slot << 24) | (ballot[0] << 12) | (ballot[1] & 0xfff)
 
 
+def wraparound_max(values):
+    """`if (maxSlot == null) maxSlot = cur; if (cur - maxSlot > 0) maxSlot = cur;` over the values in their order"""
+    best = None
+    for v in values:
+        if best is None:
+            best = v
+        if v - best > 0:
+            best = v
+    return best
+
+
 class Candidate:
     """A coordinator being elected: PaxosCoordinator.makeCoordinator (PaxosCoordinator.java:66-89) ->
     new PaxosCoordinatorState(bnum, me, acceptor slot, members, null) (PCS:168-181: nodeSlotNumbers = -1) -> prepare();
@@ -253,6 +264,7 @@ class Candidate:
 
     def prepare_reply(self, j, rballot, gc, pvalues):
         """-> ('ignored' | 'recorded' | 'preempted' | 'elected', median, [(slot, 'carry' | 'noop' | 'preactive', handle)])"""
+        gc = type(self.next)(gc)                           # (a Java int where the instance's slots are)
         if not self.exists:
             return ("ignored", 0, [])
         if not self.active and rballot > self.my:          # getPreActivesIfPreempted: the election is lost; the
@@ -273,12 +285,14 @@ class Candidate:
         if sum(self.heard) <= self.K // 2:
             return ("recorded", 0, [])
         if self.carry:                                     # combinePValuesOntoProposals (nothing to do without carry-overs)
-            max_carry = max(self.carry)
-            max_min = max(self.node_slots)                 # getMaxMinCarryoverSlot
+            max_carry = wraparound_max(sorted(self.carry))     # getMaxPValueSlot (PCS:903-914) over the TreeMap's keys
+            max_min = wraparound_max(self.node_slots)          # getMaxMinCarryoverSlot (PCS:921-931)
             pre = self.proposals                           # preActives = this.myProposals
             self.proposals = {}
             carried = {h for _, h, _ in self.carry.values()}
-            for cur in range(max_min, max_carry + 1):
+            cur = type(self.next)(max_min) - 1
+            while (cur + 1) - max_carry <= 0:              # for (curSlot = maxMin; curSlot - maxCarryoverSlot <= 0; curSlot++)
+                cur = cur + 1
                 if cur in self.carry:                      # received pvalues dominate pre-active proposals
                     self.proposals[cur] = ("carry", self.carry[cur][1], self.carry[cur][2])
                 elif cur not in pre:                       # no-op if neither received nor pre-active
@@ -434,6 +448,7 @@ def check_failover(eng, acc, G, nodes, rng, K, p_drop, p_stop=0.0, p_dup_reply=0
                                                    (cols[:, 5] * A_STOP).astype(np.uint8))
         want_runs = []
         for i, (g, s_, b0, b1, med, stop) in enumerate(recs):
+            s_, med = type(acc[a][g]._slot)(s_), type(acc[a][g]._slot)(med)
             status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((b0, b1), s_, med, True, bool(stop)))
             assert (int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i])) == (status, wb, wc, wm, wf), \
                 f"failover: ACCEPT {recs[i]} at replica {a}"
@@ -485,7 +500,13 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
         # (recordSlotNumber's plain < freezes nodeSlotNumbers at the wrap - PCS:809-825, the Java's own behaviour - and with
         # them the medians and every acceptedGCSlot: a retransmitted ACCEPT of an executed slot is then never collected.
         # The Java's map is unbounded; the engine's ring is not, so here the traffic stops WINDOW slots after the last GC)
-        assert not failover, "the view-change reading is written for small slots"
+        # No view change here: the Java's own is not sane at the wrap.  nodeSlotNumbers starts at the sentinel -1
+        # (PCS:168-181) and getMaxMinCarryoverSlot compares with it by subtraction: a reply whose minimum slot is
+        # exactly Integer.MAX_VALUE loses against -1 (MAX_VALUE - (-1) overflows), and combinePValuesOntoProposals then
+        # walks from -1 to the highest carried slot - two billion no-ops; past the wrap every (negative) slot loses
+        # against the sentinel and the carried pvalues are dropped.  (The libraries refuse such a view change with
+        # GPX_S_WINDOW, include/gpx.h; this reading would walk the two billion slots.)
+        assert not failover, "the reference's view change assumes 0 <= slot < Integer.MAX_VALUE"
         first_slot = I32(1) + base
         rows0["acc_slot"] = rows0["next_proposal_slot"] = int(first_slot)
         rows0["acc_gc_slot"] = int(first_slot - 2)
