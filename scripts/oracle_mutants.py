@@ -20,6 +20,7 @@ SRC = {"cpp": os.path.join(ROOT, "oracle", "gpx_oracle.cpp"), "inc": os.path.joi
 READINGS = [
     "tests/test_host_rows_oracle.py::test_request_batcher_random_bursts_against_java_reading",
     "tests/test_host_rows_oracle.py::test_election_scan_random_groups_against_java_reading",
+    "tests/test_election_oracle.py::test_election_begin_sequences_against_java_reading",
     "tests/test_wire_model.py",
     "tests/test_oracle_kat.py::test_pcs_main_accept_reply_tail_every_coin",
     "tests/test_oracle_kat.py::test_pcs_accept_reply_tail_with_checkpoint_slots_enumerated",
@@ -102,6 +103,9 @@ MUTANTS = [
     ("accepted pvalues are collected with a plain compare", "cpp", "        if (jsub(it->first, gcSlot) <= 0)\n          it = acceptedProposals.erase(it);", "        if (it->first <= gcSlot)\n          it = acceptedProposals.erase(it);"),
     ("an ACCEPT is stored iff its slot > the GC slot, compared plainly", "cpp", "      if (jsub(accept.slot, acceptedGCSlot) > 0) {", "      if (accept.slot > acceptedGCSlot) {"),
     ("the next proposal slot does not wrap (saturates)", "cpp", "    nextProposalSlotNumber = (int32_t)((uint32_t)nextProposalSlotNumber + 1u);\n    ProposalState ps{stop, WaitforUtility(&members)};", "    nextProposalSlotNumber = nextProposalSlotNumber == INT32_MAX ? INT32_MAX : nextProposalSlotNumber + 1;\n    ProposalState ps{stop, WaitforUtility(&members)};"),
+    # fifth batch: makeCoordinator
+    ("makeCoordinator replaces a coordinator of the SAME ballot too", "inc", "    if (!c || c->myBallot.compareTo(nb) < 0) {", "    if (!c || c->myBallot.compareTo(nb) <= 0) {"),
+    ("the PREPARE of an ACTIVE coordinator of the same ballot is sent again", "inc", "    } else if (c->myBallot.compareTo(nb) == 0 && !c->active) {", "    } else if (c->myBallot.compareTo(nb) == 0) {"),
     ("poke: any outstanding proposal, not the acceptor's next slot", "inc", "      auto p = c->myProposals.find(s); /* isCommandering(slot) */", "      auto p = c->myProposals.begin(); /* isCommandering(slot) */"),
 ]
 

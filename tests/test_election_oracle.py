@@ -105,3 +105,58 @@ def test_half_range_boundary_is_refused(oracle_lib):
     # group 1 (member 0 answered): elected, slot Integer.MAX_VALUE carried over
     assert vk == [V_RECORDED, V_RECORDED, V_RECORDED, V_ELECTED] and st == [S_OK, S_WINDOW, S_OK, S_OK]
     assert lists[3] == [(2 ** 31 - 1, E_CARRY, 8, 0)]
+
+
+def test_election_begin_sequences_against_java_reading(oracle_lib):
+    """PaxosCoordinator.makeCoordinator (PaxosCoordinator.java:66-89) read on its own: a coordinator that is missing
+    or has a LOWER ballot is replaced by a fresh PaxosCoordinatorState (active at once iff the ballot number is 0,
+    else it prepares); the SAME ballot, not yet active: the PREPARE is sent again; anything else: nothing.  Random
+    sequences of election_begin calls with ballot numbers 0..3 and completed elections in between, per group, against
+    that reading: the status of every call, which groups have an active coordinator (HotRestoreInfo), and what
+    gpx_poke_scan says is waiting (the PREPARE of a coordinator that is not active)."""
+    import numpy as np
+    from gigapaxos_amd import Engine, hri_create
+    me, members = 101, [100, 101, 102]
+    rng = np.random.default_rng(17)
+    G = 3000
+    e = Engine(oracle_lib, me, G, kmax=3, window=8, max_batch=1 << 14)
+    coord0 = rng.choice(members, G).astype(np.int32)
+    assert (e.create_groups(np.arange(G), np.tile(np.array(members, np.int32), (G, 1)), 3, hri_create(G, 3, coord0)) == S_OK).all()
+    c = [((0, me), True) if coord0[g] == me else None for g in range(G)]       # hotRestore: a coordinator only where it is me
+    seen = set()
+    for step in range(12):
+        gs = np.nonzero(rng.random(G) < 0.6)[0].astype(np.int32)
+        bn = rng.integers(0, 4, gs.shape[0]).astype(np.int32)
+        st = e.election_begin(gs, bn)
+        for i, g in enumerate(gs.tolist()):
+            new = (int(bn[i]), me)
+            if c[g] is None or c[g][0] < new:
+                c[g] = (new, new[0] == 0)
+                want = EB_ACTIVE if new[0] == 0 else EB_PREPARING
+            elif c[g][0] == new and not c[g][1]:
+                want = EB_RESEND
+            else:
+                want = EB_UNCHANGED
+            assert int(st[i]) == want, (step, g, new, c[g])
+            seen.add(want)
+        # some of the running elections complete: two members answer in the candidate's ballot
+        run = np.array([g for g in range(G) if c[g] is not None and not c[g][1] and rng.random() < 0.5], np.int32)
+        for k, acceptor in enumerate((100, 102)):
+            if run.shape[0] == 0:
+                break
+            rb = np.array([c[g][0][0] for g in run.tolist()], np.int32)
+            (vk, em, rst), lists = e.prepare_reply(run, np.full(run.shape[0], acceptor, np.int32), rb, np.full(run.shape[0], me, np.int32),
+                                                   np.ones(run.shape[0], np.int32))
+            assert (rst == S_OK).all() and (vk == (V_RECORDED if k == 0 else V_ELECTED)).all()
+        for g in run.tolist():
+            c[g] = (c[g][0], True)
+        snap, _ = e.snapshot(np.arange(G))
+        active = np.array([x is not None and x[1] for x in c])
+        assert ((snap["has_coord"] != 0) == active).all()
+        assert (snap["coord_bnum"][active] == np.array([x[0][0] for x in c if x is not None and x[1]], np.int32)).all()
+        pk, sl, pbn, pbc, md, fl, hd, pst = e.poke_scan()
+        waiting = np.array([x is not None and not x[1] for x in c])
+        assert ((pk == 2) == waiting).all() and (pk[~waiting] == 0).all()         # GPX_POKE_PREPARE / GPX_POKE_NONE
+        assert (pbn[waiting] == np.array([x[0][0] for x in c if x is not None and not x[1]], np.int32)).all() and (pbc[waiting] == me).all()
+    assert seen == {EB_PREPARING, EB_ACTIVE, EB_RESEND, EB_UNCHANGED}
+    e.close()

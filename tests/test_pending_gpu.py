@@ -94,3 +94,8 @@ def test_whole_round_across_the_int_wrap(hip_lib, base, K, kw):
     kw.setdefault("from_disk", True)
     checked, executed = run_rounds(hip_lib, 10_000, 16, 7, p_drop=0.12, K=K, base=base, **kw)
     assert checked > 1_000_000
+
+
+def test_election_begin_sequences_against_java_reading(hip_lib):
+    from tests import test_election_oracle as T
+    T.test_election_begin_sequences_against_java_reading(hip_lib)
