@@ -38,7 +38,7 @@ batches; every propose result, reply word, status, decision, execution run and f
 equal the model's."""
 import numpy as np
 
-from gigapaxos_amd import (Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STOPPED, S_BUSY, A_STOP, C_HASVALUE, C_STOP,
+from gigapaxos_amd import (Engine, hri_create, S_OK, S_FORWARD, S_REFUSED, S_STOPPED, S_BUSY, S_WINDOW, A_STOP, C_HASVALUE, C_STOP,
                            D_DECISION, D_PREEMPTED, RETIRE_PAUSE)
 
 P_NACK, P_TOLOG = 1, 2   # GPX_P_NACK, GPX_P_TOLOG (include/gpx.h)
@@ -727,6 +727,12 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                 want_runs = []
                 for i, (g, slot, bnum, bcoord, median, kind) in enumerate(cols.tolist()):
                     slot, median = J(slot), J(median)
+                    if not acc[a][g].stopped and slot - acc[a][g]._slot >= WINDOW:
+                        # the engine's limit, not the Java's (include/gpx.h): decisions are kept for `window` slots from the
+                        # next one to execute; a commit further ahead is dropped like a lost packet - and comes again
+                        assert int(st[i]) == S_WINDOW, f"round {r} replica {a}: commit {cols[i]} beyond the window"
+                        pending_c[a].append((g, slot, bnum, bcoord, median, C_HASVALUE | (C_STOP if (g, slot) in stop_slots else 0)))
+                        continue
                     if kind & C_HASVALUE:
                         status, run = acc[a][g].handleDecision((bnum, bcoord), slot, median, bool(kind & C_STOP))
                     else:
