@@ -679,6 +679,16 @@ def run_rounds(lib, G, rounds, seed, p_drop=0.12, p_double=0.3, K=3, p_rival=0.0
                 want_runs = []
                 for i, (g, slot, bnum, bcoord, median, stop) in enumerate(seq):
                     slot, median = J(slot), J(median)
+                    m_ = acc[a][g]
+                    if (not m_.stopped and (bnum, bcoord) >= m_.ballot and slot - m_.acceptedGCSlot > 0 and
+                            any(k_ != slot and ((int(k_) ^ int(slot)) & (WINDOW - 1)) == 0 for k_ in m_.accepted)):
+                        # the engine's limit, not the Java's (include/gpx.h): accepted pvalues live in a ring of `window`
+                        # entries; an ACCEPT that would be stored where another live slot sits is dropped whole, like a
+                        # lost packet - the coordinator's comes again, the rival's does not
+                        assert int(st[i]) == S_WINDOW, f"round {r} replica {a}: ACCEPT {seq[i]} into an occupied ring entry"
+                        if coord[g] is not None and (bnum, bcoord) == coord[g].my:
+                            pending[a].append(seq[i])
+                        continue
                     status, wb, wc, wm, wf, run = acc[a][g].handleAccept(PValue((bnum, bcoord), slot, median, True, bool(stop)))
                     assert (int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i])) == (status, wb, wc, wm, wf), \
                         f"round {r} replica {a}: ACCEPT {seq[i]}: got {(int(st[i]), int(rb[i]), int(rc[i]), int(rm[i]), int(rf[i]))}, the reading gives {(status, wb, wc, wm, wf)}"
