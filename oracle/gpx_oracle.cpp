@@ -19,7 +19,13 @@
  * known-answer assertions the reference's own self-tests make
  * (WaitforUtility.main, PaxosCoordinatorState.main's accept-reply section,
  * PaxosAcceptor.testAcceptor's monotone-ballot property, HotRestoreInfoTest),
- * re-expressed in tests/test_oracle_kat.py against this file.
+ * re-expressed in tests/test_oracle_kat.py against this file.  Beyond those: every row of
+ * SURVEY.md 8 is read from the Java a second time, in Python and not from this file
+ * (tests/acc_enum_common.py, pcs_enum_common.py, round_model.py, wire_model.py);
+ * this file and the engine are both held to those readings, and scripts/oracle_mutants.py shows
+ * that they notice a wrong oracle (66 single-fault copies of this file: 62 noticed, 4 equivalent).
+ * Two readings of the same text can share a misreading: the status above stands until a JVM
+ * produces reference outputs (scripts/make_ref_fixtures.sh).
  *
  * Modelling assumptions (same as the engine, stated in DESIGN.md):
  *   - steady state: no wall-clock event fires (no checkRunForCoordinator election,
