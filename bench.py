@@ -52,6 +52,162 @@ def alg_bytes_per_vote(k: int) -> float:
     return 48.0 + 4.0 * k + 20.0 / k
 
 
+STRONG_GROUPS, STRONG_K = 1_000_000, 5  # BASELINE config #4: the ONE group space the metric is quoted on
+
+
+def launch_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher around it: re-run this command line under
+    torch.distributed.run, N ranks on this node, rendezvous on 127.0.0.1 (the container hostname may not resolve).
+    Rank 0's JSON line goes to this process's stdout unchanged."""
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+class CoordinatorLeg:
+    """One timed measurement of the coordinator hot path on this rank's engine: set-up (engine, groups, the
+    synthetic accept-reply rounds resident in HBM), then run_timed() = the driver's contract (warm-up, barrier +
+    synchronize on both sides, exactly `steps` steps, MAX over ranks)."""
+
+    def __init__(self, args, torch, dist, dev, local_rank, rank, world, groups, K, split_global, rounds, mix=None,
+                 order=None):
+        from gigapaxos_amd import Engine, hri_create, load_hip, streams, S_OK
+        self.torch, self.dist, self.world, self.rank, self.dev = torch, dist, world, rank, dev
+        mix = args.mix if mix is None else mix
+        self.mix, self.K, self.rounds = mix, K, rounds
+        G = G_global = groups
+        if split_global:
+            # this rank's shard of the one global space; its engine indexes the shard densely (ShardMap.local),
+            # its stream is generated for exactly its groups - shards are independent (PaxosManager.java:3170-3171)
+            from gigapaxos_amd.sharding import ShardMap
+            G = int(ShardMap(G_global, world).counts[rank])
+        self.G, self.G_global = G, G_global
+        self.members = members = list(range(100, 100 + K))
+        nv_round = G * K + (G * K // 100 + G * K // 200 + G * K // 1000 if mix else 0)
+        if args.runs and mix:
+            nv_round = G * K + G * K // 40  # duplicates are drawn per vote: a little slack
+        self.nv_round = nv_round
+        self.eng = eng = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
+        # a dedicated (non-default) torch stream carries every engine launch, so torch.cuda.Event
+        # and the engine's own hipEvents observe the same stream
+        self.tstream = tstream = torch.cuda.Stream(device=dev)
+        torch.cuda.set_stream(tstream)
+        assert tstream.cuda_stream != 0
+        eng.set_stream(tstream.cuda_stream)
+        if not args.no_promise:
+            # the proposal batch is one request per group in gidx order (what RequestBatcher hands over):
+            # declared, verified on the device, so the partition path is not even launched for it
+            from gigapaxos_amd import ORDERED_PROPOSE, ORDERED_REPLY_RUNS
+            eng.set_ordered_batches(ORDERED_PROPOSE | (ORDERED_REPLY_RUNS if args.runs else 0))
+        self.mem = mem = np.tile(np.array(members, np.int32), (G, 1))
+        assert (eng.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
+
+        # ---- synthetic stream, resident in HBM before timing ------------------------------
+        # rank r owns shard r of a (world*G)-group space; streams are seeded per (config, rank, round)
+        self.cfg_id = cfg_id = (3 if K == 3 else 4) + 16 * rank
+        # A pool of independently shuffled rounds supplies (gidx, ballot, acceptor); the two columns that
+        # depend on the round number - slot = r + 1 and max_cp = r for every vote of round r - are
+        # filled on the device, so any --steps fits in memory and start-up time.
+        pool_n = min(rounds, 8)
+        pool = []
+        for r in range(pool_n):
+            cols = (streams.vote_round_runs(G, members, r, 100, config_id=cfg_id, mix=mix) if args.runs else
+                    streams.vote_round(G, members, r, 100, config_id=cfg_id, shuffled=not args.sorted, mix=mix))
+            pool.append([torch.from_numpy(c).to(dev) for c in cols])
+        self.nv = nv = int(pool[0][0].shape[0])
+        vote_cols = []
+        for r in range(rounds):
+            c = pool[r % pool_n]
+            slot_r = c[3] if r < pool_n else torch.full((nv,), r + 1, dtype=torch.int32, device=dev)
+            maxcp_r = c[5] if r < pool_n else torch.full((nv,), r, dtype=torch.int32, device=dev)
+            vote_cols.append([c[0], c[1], c[2], slot_r, c[4], maxcp_r])
+        g_all = torch.arange(G, dtype=torch.int32, device=dev)
+        i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
+        u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)  # noqa: E731
+        p_slot, p_bnum, p_bcoord, p_med, p_st = i32(G), i32(G), i32(G), i32(G), u8(G)
+        d_g, d_s, d_b, d_c, d_m, d_k = i32(nv), i32(nv), i32(nv), i32(nv), i32(nv), u8(nv)
+        v_st = u8(nv)
+        self.n_out = n_out = torch.zeros(rounds, dtype=torch.int32, device=dev)
+        self.p_st, self.d_k, self.d_s = p_st, d_k, d_s
+        P = lambda t: t.data_ptr()  # noqa: E731
+
+        def step(r):
+            eng.call_dev("propose_batch", G, P(g_all), 0, P(p_slot), P(p_bnum), P(p_bcoord), P(p_med), P(p_st))
+            c = vote_cols[r]
+            eng.call_dev("accept_reply_batch", nv, P(c[0]), P(c[1]), P(c[2]), P(c[3]), P(c[4]), P(c[5]),
+                         P(d_g), P(d_s), P(d_b), P(d_c), P(d_m), P(d_k), n_out[r:].data_ptr(), P(v_st))
+        self.step = step
+        self._keep = (vote_cols, g_all, p_slot, p_bnum, p_bcoord, p_med, d_g, d_b, d_c, d_m, v_st)
+
+    def barrier(self):
+        if self.world > 1:
+            self.dist.barrier()
+
+    def run_timed(self, warmup, steps):
+        torch, dist, eng, step, dev, world, G = self.torch, self.dist, self.eng, self.step, self.dev, self.world, self.G
+        for r in range(warmup):
+            step(r)
+        eng.sync()
+        torch.cuda.synchronize()
+        self.barrier()
+        torch.cuda.synchronize()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0 = time.perf_counter()
+        ev0.record()
+        for r in range(warmup, warmup + steps):
+            step(r)
+        ev1.record()
+        eng.sync()
+        torch.cuda.synchronize()
+        elapsed = time.perf_counter() - t0  # this rank's K steps, all ranks started together; MAX below
+        self.barrier()
+        torch.cuda.synchronize()
+        self.gpu_ms = ev0.elapsed_time(ev1)
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+        self.elapsed = elapsed
+
+        # ---- checks outside the timed region ----------------------------------------------
+        counts = self.n_out[: warmup + steps].cpu().numpy()
+        if not self.mix:
+            assert (counts == G).all(), f"expected {G} decisions per round, got {counts[:8]}"
+            assert bool((self.p_st == 0).all()) and bool((self.d_k[:G] == 1).all()) \
+                and bool((self.d_s[:G] == warmup + steps).all())
+        decisions_local = int(counts[warmup:].sum())
+        self.shard_counters = None
+        if world > 1:
+            t = torch.tensor([decisions_local], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            self.decisions_total = int(t.item())
+            # optional telemetry exchange: shard load counters over RCCL (not on the decide path)
+            ctr = torch.tensor(eng.counters(), dtype=torch.int64, device=dev)
+            allc = [torch.zeros_like(ctr) for _ in range(world)]
+            dist.all_gather(allc, ctr)
+            self.shard_counters = [c.tolist() for c in allc]
+            t = torch.tensor([self.nv * steps], dtype=torch.int64, device=dev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            self.votes_total = int(t.item())
+        else:
+            self.decisions_total = decisions_local
+            self.votes_total = self.nv * steps
+
+    def close(self):
+        self.eng.sync()
+        self.eng.close()
+        self._keep = None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -76,16 +232,49 @@ def main():
                     help="BASELINE config #4's shape: ONE space of --groups groups hash-sharded over the ranks "
                          "(fmix32(gidx) %% world, gigapaxos_amd.sharding.ShardMap), each rank an independent "
                          "engine over its shard: total work fixed -> strong scaling")
+    ap.add_argument("--dry-run-ranks", action="store_true",
+                    help="launcher check: start the ranks (gloo), agree on the world, print n_gpus; no engine, no GPU")
+    ap.add_argument("--no-strong-leg", action="store_true",
+                    help="N > 1 only: skip the second timed leg on BASELINE config #4's fixed space (the `strong` object)")
     ap.add_argument("--no-promise", action="store_true",
                     help="do not declare the proposal batches ordered (gpx_engine_set_ordered_batches)")
     args = ap.parse_args()
 
+    world_env = os.environ.get("WORLD_SIZE")
+    if world_env is None and args.gpus > 1:
+        # `python bench.py --gpus N` by hand: become the launcher the driver would have used, one rank per GPU
+        # (torch.distributed.run, rendezvous on 127.0.0.1); the ranks re-enter main() with WORLD_SIZE set
+        return launch_ranks(args.gpus)
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world_env is not None and args.gpus != world:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: the launcher starts one rank per GPU")
+
     import torch
     import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.dry_run_ranks:
+        # launcher check without an engine or a GPU (tests/test_bench_launcher.py): the ranks rendezvous over
+        # gloo, agree on the world, and rank 0 prints the line's launcher-dependent fields
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if world > 1:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+            t = torch.tensor([rank + 1], dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            assert int(t.item()) == world * (world + 1) // 2
+            from gigapaxos_amd.sharding import ShardMap
+            shard_groups = [int(c) for c in ShardMap(STRONG_GROUPS, world).counts]
+            dist.barrier()
+            dist.destroy_process_group()
+        else:
+            shard_groups = [STRONG_GROUPS]
+        if rank == 0:
+            print(json.dumps({"metric": "decided_ops_per_sec", "n_gpus": world, "dry_run_ranks": True,
+                              "ranks_started": world, "steps": args.steps, "warmup": args.warmup,
+                              "scaling": "strong" if args.split_global else "weak",
+                              "strong_shard_groups": shard_groups}))
+        return 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
     torch.cuda.set_device(local_rank)
@@ -98,112 +287,14 @@ def main():
 
     from gigapaxos_amd import Engine, hri_create, load_hip, streams, S_OK
 
-    G, K = args.groups, args.k
-    G_global = G
-    if args.split_global:
-        # this rank's shard of the one global space; its engine indexes the shard densely (ShardMap.local),
-        # its stream is generated for exactly its groups - shards are independent (PaxosManager.java:3170-3171)
-        from gigapaxos_amd.sharding import ShardMap
-        G = int(ShardMap(G_global, world).counts[rank])
-    members = list(range(100, 100 + K))
+    K = args.k
     steps, warmup, psteps = args.steps, args.warmup, args.profile_steps
-    rounds = warmup + steps + psteps
-    nv_round = G * K + (G * K // 100 + G * K // 200 + G * K // 1000 if args.mix else 0)
-    if args.runs and args.mix:
-        nv_round = G * K + G * K // 40  # duplicates are drawn per vote: a little slack
-    eng = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
-    # a dedicated (non-default) torch stream carries every engine launch, so torch.cuda.Event
-    # and the engine's own hipEvents observe the same stream
-    tstream = torch.cuda.Stream(device=dev)
-    torch.cuda.set_stream(tstream)
-    assert tstream.cuda_stream != 0
-    eng.set_stream(tstream.cuda_stream)
-    if not args.no_promise:
-        # the proposal batch is one request per group in gidx order (what RequestBatcher hands over):
-        # declared, verified on the device, so the partition path is not even launched for it
-        from gigapaxos_amd import ORDERED_PROPOSE, ORDERED_REPLY_RUNS
-        eng.set_ordered_batches(ORDERED_PROPOSE | (ORDERED_REPLY_RUNS if args.runs else 0))
-    mem = np.tile(np.array(members, np.int32), (G, 1))
-    assert (eng.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
-
-    # ---- synthetic stream, resident in HBM before timing ------------------------------
-    # rank r owns shard r of a (world*G)-group space; streams are seeded per (config, rank, round)
-    cfg_id = (3 if K == 3 else 4) + 16 * rank
-    # A pool of independently shuffled rounds supplies (gidx, ballot, acceptor); the two columns that
-    # depend on the round number - slot = r + 1 and max_cp = r for every vote of round r - are
-    # filled on the device, so any --steps fits in memory and start-up time.
-    pool_n = min(rounds, 8)
-    pool = []
-    for r in range(pool_n):
-        cols = (streams.vote_round_runs(G, members, r, 100, config_id=cfg_id, mix=args.mix) if args.runs else
-                streams.vote_round(G, members, r, 100, config_id=cfg_id, shuffled=not args.sorted, mix=args.mix))
-        pool.append([torch.from_numpy(c).to(dev) for c in cols])
-    nv = int(pool[0][0].shape[0])
-    vote_cols = []
-    for r in range(rounds):
-        c = pool[r % pool_n]
-        slot_r = c[3] if r < pool_n else torch.full((nv,), r + 1, dtype=torch.int32, device=dev)
-        maxcp_r = c[5] if r < pool_n else torch.full((nv,), r, dtype=torch.int32, device=dev)
-        vote_cols.append([c[0], c[1], c[2], slot_r, c[4], maxcp_r])
-    g_all = torch.arange(G, dtype=torch.int32, device=dev)
-    i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
-    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)  # noqa: E731
-    p_slot, p_bnum, p_bcoord, p_med, p_st = i32(G), i32(G), i32(G), i32(G), u8(G)
-    d_g, d_s, d_b, d_c, d_m, d_k = i32(nv), i32(nv), i32(nv), i32(nv), i32(nv), u8(nv)
-    v_st = u8(nv)
-    n_out = torch.zeros(rounds, dtype=torch.int32, device=dev)
-    P = lambda t: t.data_ptr()  # noqa: E731
-
-    def step(r):
-        eng.call_dev("propose_batch", G, P(g_all), 0, P(p_slot), P(p_bnum), P(p_bcoord), P(p_med), P(p_st))
-        c = vote_cols[r]
-        eng.call_dev("accept_reply_batch", nv, P(c[0]), P(c[1]), P(c[2]), P(c[3]), P(c[4]), P(c[5]),
-                     P(d_g), P(d_s), P(d_b), P(d_c), P(d_m), P(d_k), n_out[r:].data_ptr(), P(v_st))
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-
-    for r in range(warmup):
-        step(r)
-    eng.sync()
-    torch.cuda.synchronize()
-    barrier()
-    torch.cuda.synchronize()
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    ev0.record()
-    for r in range(warmup, warmup + steps):
-        step(r)
-    ev1.record()
-    eng.sync()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0  # this rank's K steps, all ranks started together; MAX below
-    barrier()
-    torch.cuda.synchronize()
-    gpu_ms = ev0.elapsed_time(ev1)
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- checks outside the timed region ----------------------------------------------
-    counts = n_out[: warmup + steps].cpu().numpy()
-    if not args.mix:
-        assert (counts == G).all(), f"expected {G} decisions per round, got {counts[:8]}"
-        assert bool((p_st == 0).all()) and bool((d_k[:G] == 1).all()) and bool((d_s[:G] == warmup + steps).all())
-    decisions_local = int(counts[warmup:].sum())
-    if world > 1:
-        t = torch.tensor([decisions_local], dtype=torch.int64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
-        decisions_total = int(t.item())
-        # optional telemetry exchange: shard load counters over RCCL (not on the decide path)
-        ctr = torch.tensor(eng.counters(), dtype=torch.int64, device=dev)
-        allc = [torch.zeros_like(ctr) for _ in range(world)]
-        dist.all_gather(allc, ctr)
-    else:
-        decisions_total = decisions_local
-    votes_total = nv * steps * world
+    leg = CoordinatorLeg(args, torch, dist, dev, local_rank, rank, world, args.groups, K, args.split_global,
+                         rounds=warmup + steps + psteps)
+    leg.run_timed(warmup, steps)
+    eng, step, rounds = leg.eng, leg.step, leg.rounds
+    G, G_global, nv, nv_round, members, mem, cfg_id = leg.G, leg.G_global, leg.nv, leg.nv_round, leg.members, leg.mem, leg.cfg_id
+    elapsed, gpu_ms, decisions_total, votes_total = leg.elapsed, leg.gpu_ms, leg.decisions_total, leg.votes_total
 
     # ---- per-kernel timing with hipEvents on the launch stream (profile pass) ---------
     roofline = None
@@ -256,6 +347,22 @@ def main():
             "pipeline_frac": round(pipe_achieved / HBM_PEAK_GBS, 4),
             "kernels_ms_per_step": {k: round(v[1] / psteps, 4) for k, v in sorted(kstats.items())},
         }
+
+    # ---- N > 1: the shape BASELINE's metric is quoted on - ONE space of 1 M groups, 5 replicas, hash-sharded over
+    # the ranks (config #4): total work fixed, so this is the strong-scaling figure beside the weak `value` -------
+    strong = None
+    if world > 1 and not args.split_global and not args.no_strong_leg:
+        leg.close()
+        sleg = CoordinatorLeg(args, torch, dist, dev, local_rank, rank, world, STRONG_GROUPS, STRONG_K, True,
+                              rounds=warmup + steps, mix=False)
+        sleg.run_timed(warmup, steps)
+        strong = {"value": round(sleg.decisions_total / sleg.elapsed, 1), "unit": "decisions/s",
+                  "ms_per_step": round(sleg.elapsed * 1e3 / steps, 4), "scaling": "strong",
+                  "votes_per_sec": round(sleg.votes_total / sleg.elapsed, 1),
+                  "groups_total": STRONG_GROUPS, "replicas": STRONG_K, "groups_rank0": sleg.G,
+                  "workload": "BASELINE config #4: %d Paxos groups x %d replicas hash-sharded over %d GPUs "
+                              "(fmix32(gidx) %% n), independent shards, same step" % (STRONG_GROUPS, STRONG_K, world)}
+        sleg.close()
 
     # ---- end to end through the HOST-pointer entry points (what a JNI caller with direct ByteBuffers
     # gets): every input column crosses PCIe in, every output column comes back; never `value` -------
@@ -509,6 +616,7 @@ def main():
             "votes_per_sec_per_gpu": round(votes_total / elapsed / world, 1),
             "gpu_ms_per_step_rank0": round(gpu_ms / steps, 4),
             "roofline": roofline,
+            "strong": strong,
             "end_to_end": end_to_end,
             "cpu_baseline": cpu_baseline,
             "parity_checked": parity_checked,
@@ -519,4 +627,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)
