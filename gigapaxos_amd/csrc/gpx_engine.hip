@@ -28,6 +28,11 @@
 
 #define GPX_STAGE_N 32768 /* host-pointer calls up to this many records cross PCIe as one block each way */
 #define GPX_STAGE_BYTES ((size_t)GPX_STAGE_N * 48 + 4096)
+/* e->fs[].chunk_cnt: one count per 1024-record chunk of the largest batch, then DirectStage's st_total and mark.
+ * Their words do not move with the batch size: a word that once held a chunk count can never be read as a mark. */
+#define GPX_CHUNK_CNT_TOTAL(N) ((size_t)(N) / GPX_DCHUNK + 4)
+#define GPX_CHUNK_CNT_MARK(N) ((size_t)(N) / GPX_DCHUNK + 5)
+#define GPX_CHUNK_CNT_WORDS(N) ((size_t)(N) / GPX_DCHUNK + 8)
 namespace {
 
 thread_local char g_err[256] = "";
@@ -135,9 +140,13 @@ struct gpx_engine {
     uint8_t* host_kind = nullptr; /* accept replies: d_kind */
     const uint8_t* dev_kind = nullptr;
     int32_t* host_count = nullptr; /* n_out / n_runs of the caller */
+    int32_t n = 0;                 /* records of the call: the capacity of every output column (gpx.h) */
   } as[GPX_ASYNC_DEPTH];
   hipStream_t s_in = nullptr;
   uint64_t async_seq = 0;
+  /* host blocks registered through gpx_host_register (base, bytes): the extent check of mapped_host, the
+   * drain before gpx_host_unregister, and what gpx_engine_destroy still has to unregister */
+  std::vector<std::pair<char*, size_t>> registered;
   bool async_in_engine = false, async_fill_memset = false; /* experiments: GPX_ASYNC_IN, GPX_ASYNC_FILL */
   bool async_no_direct = false; /* GPX_ASYNC_DIRECT=0: compacted outputs fetched by gpx_engine_wait even from registered memory */
   bool async_kernel_in = false; /* GPX_ASYNC_COPYIN=kernel (experiment): inputs read by k_copy_in from registered memory */
@@ -146,15 +155,12 @@ struct gpx_engine {
   int64_t nm_tomb = 0;
   std::vector<int32_t> free_rows;
   bool free_init = false;
-  int32_t *w_cnt = nullptr, *w_tile = nullptr, *w_err = nullptr, *w_gidx = nullptr, *w_aux = nullptr;
-  int8_t* w_cls = nullptr;
+  int32_t *w_cnt = nullptr, *w_tile = nullptr, *w_err = nullptr;
   long long* w_tile_b = nullptr;
   unsigned long long* w_look = nullptr; /* [4][tiles] look-back words of the one-launch decode */
   uint32_t* w_ticket = nullptr;
   uint32_t w_epoch = 0;
-  bool wire_legacy = false;
   int wire_tile = 512; /* frames per workgroup of k_wire_decode1 (GPX_WD_TILE = 256 / 512) */
-  bool wire_stage1 = false; /* GPX_WD_STAGE1=1: the staging loop with all chunk loads in flight (gpx_wire.hip.h, wire_stage) */
   uint8_t* w_stage = nullptr;      /* staging of BATCHED_ACCEPT_REPLY frames, 188 B per reply */
   long long* w_bucket_bytes = nullptr;
   int32_t* w_ones = nullptr;       /* a column of ones (gpx_request_batch without weights) */
@@ -592,7 +598,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     A(f.bucket_off, nbk_alloc + 1, true);
     A(f.rec, N, false);
     A(f.unsorted, 1, true);
-    A(f.chunk_cnt, N / GPX_DCHUNK + 4, true); /* + st_total of the commit path behind the counts */
+    A(f.chunk_cnt, GPX_CHUNK_CNT_WORDS(N), true); /* the counts, then st_total and mark at FIXED words behind them */
   }
   X.bucket_tot = e->fs[0].bucket_tot;
   X.tile_rel = e->fs[0].tile_rel;
@@ -616,10 +622,23 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   return GPX_OK;
 }
 
+/* every stream a call of this engine may have queued work on: the engine's stream, the copy-in stream and the
+ * copy-out stream of every asynchronous set.  After this nothing of the engine is in flight. */
+static void drain_all(gpx_engine* h) {
+  if (h->s_in) HIPQ(hipStreamSynchronize(h->s_in));
+  if (h->sF) HIPQ(hipStreamSynchronize(h->sF));
+  if (h->sB && h->sB != h->sF) HIPQ(hipStreamSynchronize(h->sB));
+  for (auto& a : h->as)
+    if (a.s_out) HIPQ(hipStreamSynchronize(a.s_out));
+}
+
 int gpx_engine_destroy(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
-  if (h->sF) HIPQ(hipStreamSynchronize(h->sF));
-  if (h->sB) HIPQ(hipStreamSynchronize(h->sB));
+  /* first: nothing in flight - copies queued for a ticket nobody waited for read the AsyncSet columns and
+   * write through the caller's registered mappings; only then may either go away */
+  drain_all(h);
+  for (auto& r : h->registered) HIPQ(hipHostUnregister(r.first));
+  h->registered.clear();
   for (auto& pe : h->pending) {
     HIPQ(hipEventDestroy(pe.start));
     HIPQ(hipEventDestroy(pe.stop));
@@ -629,7 +648,6 @@ int gpx_engine_destroy(gpx_engine* h) {
   if (h->hs_out) HIPQ(hipHostFree(h->hs_out));
   if (h->arena) HIPQ(hipFree(h->arena));
   for (auto& a : h->as) {
-    if (a.s_out) HIPQ(hipStreamSynchronize(a.s_out));
     if (a.h_cnt) HIPQ(hipHostFree(a.h_cnt));
     if (a.ev_in) HIPQ(hipEventDestroy(a.ev_in));
     if (a.ev_k) HIPQ(hipEventDestroy(a.ev_k));
@@ -638,6 +656,7 @@ int gpx_engine_destroy(gpx_engine* h) {
   }
   if (h->s_in) HIPQ(hipStreamDestroy(h->s_in));
   if (h->own_stream) HIPQ(hipStreamDestroy(h->own_stream));
+  (void)hipGetLastError();
   delete h;
   return GPX_OK;
 }
@@ -662,11 +681,22 @@ int gpx_engine_set_ordered_batches(gpx_engine* h, int32_t mask) {
 int gpx_host_register(gpx_engine* h, void* ptr, size_t bytes) {
   if (!h || !ptr || !bytes) return GPX_EINVAL;
   HIPCHK(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+  h->registered.emplace_back((char*)ptr, bytes);
   return GPX_OK;
 }
+/* An asynchronous call may still be writing through the block's device mapping (k_copy_out on a set's copy-out
+ * stream) or reading it (the copy-in stream's DMA): the mapping is only taken away once every stream of the
+ * engine has drained.  The tickets stay valid - gpx_engine_wait on them returns at once afterwards. */
 int gpx_host_unregister(gpx_engine* h, void* ptr) {
   if (!h || !ptr) return GPX_EINVAL;
+  drain_all(h);
+  HIPCHK(hipGetLastError());
   HIPCHK(hipHostUnregister(ptr));
+  for (size_t i = 0; i < h->registered.size(); i++)
+    if (h->registered[i].first == (char*)ptr) {
+      h->registered.erase(h->registered.begin() + (long)i);
+      break;
+    }
   return GPX_OK;
 }
 
@@ -674,6 +704,11 @@ int gpx_engine_sync(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
   HIPCHK(hipStreamSynchronize(h->sF));
   HIPCHK(hipStreamSynchronize(h->sB));
+  /* the asynchronous calls' copy streams too: "completes the device work" includes their copies (the tickets
+   * still have to be waited for - gpx_engine_wait hands over the counts) */
+  if (h->s_in) HIPCHK(hipStreamSynchronize(h->s_in));
+  for (auto& a : h->as)
+    if (a.s_out) HIPCHK(hipStreamSynchronize(a.s_out));
   return GPX_OK;
 }
 
@@ -922,8 +957,8 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec; /* the two paths never both stage outputs: shared scratch */
   const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt, x_gidx, x_first, x_count,
-                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + nchunks + 1,
-                      (uint32_t*)(e->fs[fs].chunk_cnt + nchunks + 2)};
+                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + GPX_CHUNK_CNT_TOTAL(e->cfg.max_batch),
+                      (uint32_t*)(e->fs[fs].chunk_cnt + GPX_CHUNK_CNT_MARK(e->cfg.max_batch))};
   /* at most 65,536 records on one stream: order check, direct application and run compaction in ONE
    * launch (k_ac_small: tickets instead of chunk counters) */
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
@@ -1011,8 +1046,8 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const int nchunks = (n + GPX_DCHUNK - 1) / GPX_DCHUNK;
   int32_t* st32 = (int32_t*)e->X.o_rec;
   const DirectStage D{st32, st32 + (size_t)e->cfg.max_batch, e->rec_tag, e->fs[fs].chunk_cnt, x_gidx, x_first, x_count,
-                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + nchunks + 1,
-                      (uint32_t*)(e->fs[fs].chunk_cnt + nchunks + 2)};
+                      st32 + 2 * (size_t)e->cfg.max_batch, e->fs[fs].chunk_cnt + GPX_CHUNK_CNT_TOTAL(e->cfg.max_batch),
+                      (uint32_t*)(e->fs[fs].chunk_cnt + GPX_CHUNK_CNT_MARK(e->cfg.max_batch))};
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N; /* one launch: k_ac_small */
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
   if (!fused)
@@ -1482,9 +1517,17 @@ __global__ __launch_bounds__(256) void k_copy_in(CopyIn C) {
 
 namespace {
 
-/* the device address of a host buffer the caller registered (gpx_host_register), or null */
-void* mapped_host(void* p) {
+/* the device address of a host buffer of `bytes` bytes the caller registered, or null (the caller then takes the
+ * copy path, which works for any host memory).  A buffer inside a block registered through gpx_host_register
+ * must fit in that block: a kernel running over the end of a mapping faults on the GPU.  Pinned memory the
+ * caller got elsewhere (hipHostMalloc, its own hipHostRegister) is accepted on the runtime's word. */
+void* mapped_host(gpx_engine* e, void* p, size_t bytes) {
   if (!p) return nullptr;
+  for (auto& r : e->registered)
+    if ((char*)p >= r.first && (char*)p < r.first + r.second) {
+      if ((char*)p + bytes > r.first + r.second) return nullptr;
+      break;
+    }
   hipPointerAttribute_t at;
   if (hipPointerGetAttributes(&at, p) != hipSuccess) {
     (void)hipGetLastError();
@@ -1497,6 +1540,16 @@ void* mapped_host(void* p) {
     return nullptr;
   }
   return d;
+}
+
+/* an asynchronous call failed after some of its copies or kernels were queued: no ticket will be issued, so the
+ * caller has nothing to wait on - wait here, so that it may reuse its buffers and the set's columns are quiet */
+int async_fail(gpx_engine* e, gpx_engine::AsyncSet& a, int rc) {
+  if (e->s_in) HIPQ(hipStreamSynchronize(e->s_in));
+  HIPQ(hipStreamSynchronize(e->sB));
+  if (a.s_out) HIPQ(hipStreamSynchronize(a.s_out));
+  (void)hipGetLastError();
+  return rc;
 }
 
 int async_begin(gpx_engine* e, int32_t n, gpx_engine::AsyncSet** out) {
@@ -1531,6 +1584,7 @@ int async_begin(gpx_engine* e, int32_t n, gpx_engine::AsyncSet** out) {
     a.ready = true;
   }
   a.ncols = 0;
+  a.n = n;
   a.host_kind = nullptr;
   a.dev_kind = nullptr;
   a.host_count = nullptr;
@@ -1547,12 +1601,12 @@ int async_inputs(gpx_engine* e, int32_t n, int ncols, const int32_t* const* hsrc
   C.ncols = ncols;
   bool ok = e->async_kernel_in;
   for (int k = 0; k < ncols && ok; k++) {
-    C.src[k] = (const int32_t*)mapped_host((void*)hsrc[k]);
+    C.src[k] = (const int32_t*)mapped_host(e, (void*)hsrc[k], (size_t)n * 4);
     C.dst[k] = ddst[k];
     ok = C.src[k] != nullptr;
   }
   if (ok && hb) {
-    C.bsrc = (const uint8_t*)mapped_host((void*)hb);
+    C.bsrc = (const uint8_t*)mapped_host(e, (void*)hb, (size_t)n);
     C.bdst = db;
     ok = C.bsrc != nullptr;
   }
@@ -1587,12 +1641,12 @@ int async_dense_out(gpx_engine* e, gpx_engine::AsyncSet& a, int32_t n, int ncols
   bool ok = !e->async_no_direct;
   for (int k = 0; k < ncols && ok; k++) {
     C.src[k] = dsrc[k];
-    C.dst[k] = (int32_t*)mapped_host(hdst[k]);
+    C.dst[k] = (int32_t*)mapped_host(e, hdst[k], (size_t)n * 4);
     ok = C.dst[k] != nullptr;
   }
   for (int k = 0; k < nb && ok; k++) {
     C.bsrc[k] = db[k];
-    C.bdst[k] = (uint8_t*)mapped_host(hb[k]);
+    C.bdst[k] = (uint8_t*)mapped_host(e, hb[k], (size_t)n);
     ok = C.bdst[k] != nullptr;
   }
   if (ok) {
@@ -1613,16 +1667,16 @@ int async_submit(gpx_engine* e, gpx_engine::AsyncSet& a, bool with_count, gpx_ti
     bool ok = true;
     for (int k = 0; k < a.ncols && ok; k++) {
       C.src[k] = a.dev_col[k];
-      C.dst[k] = (int32_t*)mapped_host(a.host_col[k]);
+      C.dst[k] = (int32_t*)mapped_host(e, a.host_col[k], (size_t)a.n * 4);
       ok = C.dst[k] != nullptr;
     }
     if (ok && a.host_kind) {
       C.nb = 1;
       C.bsrc[0] = a.dev_kind;
-      C.bdst[0] = (uint8_t*)mapped_host(a.host_kind);
+      C.bdst[0] = (uint8_t*)mapped_host(e, a.host_kind, (size_t)a.n);
       ok = C.bdst[0] != nullptr;
     }
-    C.count_dst = ok ? (int32_t*)mapped_host(a.host_count) : nullptr;
+    C.count_dst = ok ? (int32_t*)mapped_host(e, a.host_count, 4) : nullptr;
     if (ok && C.count_dst) {
       hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(256), 0, a.s_out, (const int32_t*)a.cnt, C);
       a.direct = true;
@@ -1653,22 +1707,23 @@ int gpx_propose_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const
     {
       const int32_t* hs[1] = {gidx};
       int32_t* dd[1] = {a.i32[0]};
-      if ((rc = async_inputs(h, n, 1, hs, dd, is_stop, a.u8[0])) != GPX_OK) return rc;
+      if ((rc = async_inputs(h, n, 1, hs, dd, is_stop, a.u8[0])) != GPX_OK) return async_fail(h, a, rc);
     }
-    if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
+    if ((rc = async_inputs_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     rc = propose_dev_impl(h, n, a.i32[0], is_stop ? a.u8[0] : nullptr, nullptr, a.i32[1], a.i32[2], a.i32[3],
                           a.i32[4], a.u8[1]);
-    if (rc != GPX_OK) return rc;
-    if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
+    if (rc != GPX_OK) return async_fail(h, a, rc);
+    if ((rc = async_kernels_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     {
       int32_t* hd[4] = {slot, bnum, bcoord, median_cp};
       const int32_t* ds[4] = {a.i32[1], a.i32[2], a.i32[3], a.i32[4]};
       uint8_t* hb[1] = {status};
       const uint8_t* db[1] = {a.u8[1]};
-      if ((rc = async_dense_out(h, a, n, 4, hd, ds, 1, hb, db)) != GPX_OK) return rc;
+      if ((rc = async_dense_out(h, a, n, 4, hd, ds, 1, hb, db)) != GPX_OK) return async_fail(h, a, rc);
     }
   }
-  return async_submit(h, a, false, ticket);
+  rc = async_submit(h, a, false, ticket);
+  return rc == GPX_OK ? rc : async_fail(h, a, rc);
 }
 
 int gpx_accept_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
@@ -1690,25 +1745,26 @@ int gpx_accept_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const 
     {
       const int32_t* hs[5] = {gidx, bnum, bcoord, slot, median_cp};
       int32_t* dd[5] = {a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4]};
-      if ((rc = async_inputs(h, n, 5, hs, dd, a_flags, a.u8[0])) != GPX_OK) return rc;
+      if ((rc = async_inputs(h, n, 5, hs, dd, a_flags, a.u8[0])) != GPX_OK) return async_fail(h, a, rc);
     }
-    if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
+    if ((rc = async_inputs_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     rc = gpx_accept_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a_flags ? a.u8[0] : nullptr,
                               a.i32[5], a.i32[6], a.i32[7], a.u8[1], a.u8[2], a.i32[8], a.i32[9], a.i32[10], a.cnt);
-    if (rc != GPX_OK) return rc;
-    if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
+    if (rc != GPX_OK) return async_fail(h, a, rc);
+    if ((rc = async_kernels_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     {
       int32_t* hd[3] = {r_bnum, r_bcoord, r_maxcp};
       const int32_t* ds[3] = {a.i32[5], a.i32[6], a.i32[7]};
       uint8_t* hb[2] = {r_flags, status};
       const uint8_t* db[2] = {a.u8[1], a.u8[2]};
-      if ((rc = async_dense_out(h, a, n, 3, hd, ds, 2, hb, db)) != GPX_OK) return rc;
+      if ((rc = async_dense_out(h, a, n, 3, hd, ds, 2, hb, db)) != GPX_OK) return async_fail(h, a, rc);
     }
     a.ncols = 3;
     a.host_col[0] = x_gidx, a.host_col[1] = x_first, a.host_col[2] = x_count;
     a.dev_col[0] = a.i32[8], a.dev_col[1] = a.i32[9], a.dev_col[2] = a.i32[10];
   }
-  return async_submit(h, a, n > 0, ticket);
+  rc = async_submit(h, a, n > 0, ticket);
+  return rc == GPX_OK ? rc : async_fail(h, a, rc);
 }
 
 int gpx_accept_reply_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
@@ -1731,11 +1787,11 @@ int gpx_accept_reply_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, 
     if (bnum) {
       const int32_t* hs[6] = {gidx, bnum, bcoord, slot, acceptor, max_cp};
       int32_t* dd[6] = {a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a.i32[5]};
-      if ((rc = async_inputs(h, n, 6, hs, dd, nullptr, nullptr)) != GPX_OK) return rc;
+      if ((rc = async_inputs(h, n, 6, hs, dd, nullptr, nullptr)) != GPX_OK) return async_fail(h, a, rc);
     } else { /* one ballot for the whole batch: the two columns are made on the device */
       const int32_t* hs[4] = {gidx, slot, acceptor, max_cp};
       int32_t* dd[4] = {a.i32[0], a.i32[3], a.i32[4], a.i32[5]};
-      if ((rc = async_inputs(h, n, 4, hs, dd, nullptr, nullptr)) != GPX_OK) return rc;
+      if ((rc = async_inputs(h, n, 4, hs, dd, nullptr, nullptr)) != GPX_OK) return async_fail(h, a, rc);
       hipStream_t fs = h->async_in_engine ? h->sB : h->s_in;
       if (h->async_fill_memset) {
         HIPCHK(hipMemsetD32Async((hipDeviceptr_t)a.i32[1], common_bnum, (size_t)n, fs));
@@ -1745,15 +1801,15 @@ int gpx_accept_reply_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, 
         hipLaunchKernelGGL(k_fill_i32, dim3(grid_for(n)), dim3(GPX_BLOCK), 0, fs, n, common_bcoord, a.i32[2]);
       }
     }
-    if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
+    if ((rc = async_inputs_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     rc = gpx_accept_reply_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a.i32[5], a.i32[6],
                                     a.i32[7], a.i32[8], a.i32[9], a.i32[10], a.u8[0], a.cnt, a.u8[1]);
-    if (rc != GPX_OK) return rc;
-    if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
+    if (rc != GPX_OK) return async_fail(h, a, rc);
+    if ((rc = async_kernels_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     if (status) {
       uint8_t* hb[1] = {status};
       const uint8_t* db[1] = {a.u8[1]};
-      if ((rc = async_dense_out(h, a, n, 0, nullptr, nullptr, 1, hb, db)) != GPX_OK) return rc;
+      if ((rc = async_dense_out(h, a, n, 0, nullptr, nullptr, 1, hb, db)) != GPX_OK) return async_fail(h, a, rc);
     }
     a.ncols = 5;
     int32_t* hc[5] = {d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp};
@@ -1764,7 +1820,8 @@ int gpx_accept_reply_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, 
     a.host_kind = d_kind;
     a.dev_kind = a.u8[0];
   }
-  return async_submit(h, a, n > 0, ticket);
+  rc = async_submit(h, a, n > 0, ticket);
+  return rc == GPX_OK ? rc : async_fail(h, a, rc);
 }
 
 int gpx_commit_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
@@ -1784,23 +1841,24 @@ int gpx_commit_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const 
     {
       const int32_t* hs[5] = {gidx, bnum, bcoord, slot, median_cp};
       int32_t* dd[5] = {a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4]};
-      if ((rc = async_inputs(h, n, 5, hs, dd, c_kind, a.u8[0])) != GPX_OK) return rc;
+      if ((rc = async_inputs(h, n, 5, hs, dd, c_kind, a.u8[0])) != GPX_OK) return async_fail(h, a, rc);
     }
-    if ((rc = async_inputs_done(h, a)) != GPX_OK) return rc;
+    if ((rc = async_inputs_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     rc = gpx_commit_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], c_kind ? a.u8[0] : nullptr,
                               a.u8[1], a.i32[5], a.i32[6], a.i32[7], a.cnt);
-    if (rc != GPX_OK) return rc;
-    if ((rc = async_kernels_done(h, a)) != GPX_OK) return rc;
+    if (rc != GPX_OK) return async_fail(h, a, rc);
+    if ((rc = async_kernels_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     {
       uint8_t* hb[1] = {status};
       const uint8_t* db[1] = {a.u8[1]};
-      if ((rc = async_dense_out(h, a, n, 0, nullptr, nullptr, 1, hb, db)) != GPX_OK) return rc;
+      if ((rc = async_dense_out(h, a, n, 0, nullptr, nullptr, 1, hb, db)) != GPX_OK) return async_fail(h, a, rc);
     }
     a.ncols = 3;
     a.host_col[0] = x_gidx, a.host_col[1] = x_first, a.host_col[2] = x_count;
     a.dev_col[0] = a.i32[5], a.dev_col[1] = a.i32[6], a.dev_col[2] = a.i32[7];
   }
-  return async_submit(h, a, n > 0, ticket);
+  rc = async_submit(h, a, n > 0, ticket);
+  return rc == GPX_OK ? rc : async_fail(h, a, rc);
 }
 
 int gpx_engine_wait(gpx_engine* h, gpx_ticket ticket) {

@@ -2122,13 +2122,32 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_gap_scan(DevState S, int32_t n,
   const int32_t slot = S.a_slot[g];
   first_slot[i] = slot;
   const bool stopped = (gf & GF_STOPPED) != 0;
-  /* getMaxCommittedSlot: stopped or empty -> getSlot() - 1; else the wraparound-aware maximum */
+  /* getMaxCommittedSlot (PaxosAcceptor.java:425-438): stopped or empty -> getSlot() - 1; else
+   * committedRequests.lastKey() - the largest key in SIGNED order (a TreeMap<Integer, ..>) - and only when that key
+   * is Integer.MAX_VALUE itself does the Java walk the keys with the wraparound compare.  Keys on both sides of the
+   * wrap without MAX_VALUE among them therefore give the key BEFORE the wrap: reproduced, not repaired. */
   int32_t maxc = jsub(slot, 1);
-  if (!stopped)
+  if (!stopped) {
+    bool any = false;
+    int32_t last = INT32_MIN, wrapmax = maxc;
     for (int32_t w = 0; w < S.W; w++) {
       const int64_t o = (int64_t)w * S.G + g;
-      if ((((uint32_t)S.acc_ring[o].w >> CF_SHIFT) & RF_PRESENT) && jsub(S.com_ring[o].x, maxc) > 0) maxc = S.com_ring[o].x;
+      if (!(((uint32_t)S.acc_ring[o].w >> CF_SHIFT) & RF_PRESENT)) continue;
+      const int32_t key = S.com_ring[o].x;
+      any = true;
+      last = key > last ? key : last;
     }
+    if (any && last == INT32_MAX) {
+      /* for (int i : keySet()) if (i - maxSlot > 0) maxSlot = i;  keys ascending in signed order: with at most W
+       * keys inside one window of W slots the walk ends at the wraparound-aware maximum whatever the order */
+      for (int32_t w = 0; w < S.W; w++) {
+        const int64_t o = (int64_t)w * S.G + g;
+        if ((((uint32_t)S.acc_ring[o].w >> CF_SHIFT) & RF_PRESENT) && jsub(S.com_ring[o].x, wrapmax) > 0) wrapmax = S.com_ring[o].x;
+      }
+      last = wrapmax;
+    }
+    if (any) maxc = last;
+  }
   max_committed[i] = maxc;
   /* shouldSync (PISM:2341-2364), DISABLE_SYNC_DECISIONS = false */
   const int32_t gap = jsub(maxc, slot);

@@ -558,15 +558,6 @@ struct WireOut {
   gpx_wire_requests R;
 };
 
-struct WireScratch {
-  int32_t* cnt;   /* [frames] records of each frame */
-  int8_t* cls;    /* [frames] class (bits 0-2, 7 = none) | slot list ascending << 3 | stop << 4 */
-  int32_t* gidx;  /* [frames] group row of each frame */
-  int32_t* aux;   /* [frames] ACCEPT: byte position of the slot / ballot tail */
-  int32_t* tile;  /* [4][ntiles] records per class per 256-frame tile, then exclusive bases */
-  int32_t ntiles;
-};
-
 /* The 256 frames of a workgroup's tile are contiguous in the burst: copy their bytes to LDS with
  * coalesced dword loads and let every lane parse its frame from there (a lane walking ~70 bytes
  * of its own frame in global memory touches a different cache line than its neighbours on every
@@ -588,13 +579,14 @@ struct WireScratch {
  * the tile's 47 us).  LDS byte lead + k = byte k, where lead = a0 & 15 keeps 16-byte chunks aligned on
  * both sides; nothing before a0 or past the last byte is read.  Returns lead; the caller's barrier
  * follows. */
-/* INFLIGHT (round 3, found by reading the ISA after the round's GPU minutes were spent - profiles/
- * r03_wire_stage_isa.txt): hipcc 7.2 keeps v[] in SCRATCH when its elements are only assigned under the bounds
- * test, and waits for every chunk before the next load: seven round trips instead of the one the loop is written
- * for (the timeline's "ticket -> staged" never moved off 11-12 us).  With the elements zeroed first the seven loads
- * are issued back to back and one wait precedes the stores.  Not yet measured or parity-run on a GPU: a template
- * switch, off by default (GPX_WD_STAGE1=1 selects it for k_wire_decode1). */
-template <int BLOCK = GPX_BLOCK, bool INFLIGHT = false>
+/* The chunk array is ZEROED before the loads (round 3 ISA reading, profiles/r03_wire_stage_isa.txt; measured in round
+ * 4, profiles/r04_pending_visit.txt): hipcc 7.2 keeps v[] in SCRATCH when its elements are only assigned under the
+ * bounds test, and waits for every chunk before the next load - seven round trips instead of the one the loop is
+ * written for.  With the elements zeroed first the seven loads are issued back to back and one wait precedes the
+ * stores: decode of 2 M frames 0.248 -> 0.197 ms.  (Also: the burst lies in GLOBAL memory - an address made from an
+ * integer is generic, and generic loads count against the LDS counter too, so that every LDS wait waits for them as
+ * well: the loads name address space 1.) */
+template <int BLOCK = GPX_BLOCK>
 __device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64_t nbytes) {
   constexpr int NCH = GPX_W_STAGE_BYTES / 16 / GPX_BLOCK + 1; /* chunks per lane of a full staging area */
   const uintptr_t a16 = a0 & ~(uintptr_t)15;
@@ -618,17 +610,11 @@ __device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64
 #pragma unroll
     for (int k = 0; k < NCH; k++) {
       const int32_t c = c0 + k * BLOCK + (int32_t)threadIdx.x;
-      if (INFLIGHT) {
-        /* (also: the burst lies in GLOBAL memory - an address made from an integer is generic, and generic loads
-         * count against the LDS counter too, so that every LDS wait waits for them as well) */
-        typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-        v[k] = make_uint4(0u, 0u, 0u, 0u);
-        if (c < c_hi) {
-          const u32x4 t = ((const __attribute__((address_space(1))) u32x4*)a16)[c];
-          v[k] = make_uint4(t.x, t.y, t.z, t.w);
-        }
-      } else if (c < c_hi) {
-        v[k] = src16[c];
+      typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+      v[k] = make_uint4(0u, 0u, 0u, 0u);
+      if (c < c_hi) {
+        const u32x4 t = ((const __attribute__((address_space(1))) u32x4*)a16)[c];
+        v[k] = make_uint4(t.x, t.y, t.z, t.w);
       }
     }
     if (odd && hw < head_end) hv = src[hw];
@@ -650,111 +636,6 @@ __device__ __forceinline__ int32_t wire_stage(uint32_t* lds, uintptr_t a0, int64
   }
   return lead;
 }
-template <class F>
-__device__ __forceinline__ void wire_for_frame(const uint8_t* __restrict__ frames,
-                                               const int64_t* __restrict__ frame_off, int32_t nf,
-                                               uint32_t* lds, int32_t i, F fn) {
-  const int32_t t0 = (int32_t)blockIdx.x * GPX_BLOCK;
-  const int32_t t1 = t0 + GPX_BLOCK < nf ? t0 + GPX_BLOCK : nf;
-  const int64_t b0 = frame_off[t0], b1 = frame_off[t1];
-  const uintptr_t a0 = (uintptr_t)(frames + b0) & ~(uintptr_t)3; /* dword-aligned start */
-  const int64_t span = (int64_t)((uintptr_t)(frames + b1) - a0);
-  const bool live = i < nf;
-  const int64_t f0 = live ? frame_off[i] : b0, f1 = live ? frame_off[i + 1] : b0;
-  const int64_t r0 = (int64_t)((uintptr_t)(frames + f0) - a0), r1 = (int64_t)((uintptr_t)(frames + f1) - a0);
-  bool done = !live;
-#if !GPX_WIRE_WINDOWS
-  /* one window only: a tile that does not fit is parsed in place (the windowed loop below costs the
-   * parsers twice the registers; measured before choosing the default) */
-  if (span >= 0 && span <= GPX_W_STAGE_BYTES) {
-    const int32_t lead = wire_stage(lds, a0, span);
-    __syncthreads();
-    if (!done) fn(true, r0 + lead);
-    return;
-  }
-  if (!done) fn(false, f0);
-  return;
-#endif
-  const int64_t H = GPX_W_STAGE_BYTES / 2;
-  /* span < 0 (offsets not ascending): no window, every frame in place - its parser checks the bounds */
-  for (int64_t ws = 0; ws < span; ws += H) { /* one pass when the tile fits a window */
-    const int64_t we = ws + GPX_W_STAGE_BYTES < span ? ws + GPX_W_STAGE_BYTES : span;
-    const uint32_t* src = (const uint32_t*)(a0 + ws);
-    const int64_t nb = we - ws;
-    const int32_t nw = (int32_t)(nb >> 2);
-    for (int32_t w = threadIdx.x; w < nw; w += GPX_BLOCK) lds[w] = src[w];
-    if ((int32_t)threadIdx.x < (int32_t)(nb & 3)) /* tail bytes one by one: never read past b1 */
-      ((uint8_t*)lds)[(nw << 2) + threadIdx.x] = ((const uint8_t*)src)[(nw << 2) + threadIdx.x];
-    __syncthreads();
-    if (!done && r0 >= ws && r1 <= we) {
-      fn(true, r0 - ws);
-      done = true;
-    }
-    if (we >= span) break;
-    __syncthreads(); /* the next window overwrites the staging area */
-  }
-  if (!done) fn(false, f0); /* longer than half a window */
-}
-
-/* pass 1: parse every frame, count its records; per-tile totals per class */
-__global__ __launch_bounds__(GPX_BLOCK) void k_wire_scan(DevState S, DevNames N, WireScratch W,
-                                                        int32_t nf,
-                                                        const uint8_t* __restrict__ frames,
-                                                        const int64_t* __restrict__ frame_off,
-                                                        uint8_t* __restrict__ f_status,
-                                                        int32_t* __restrict__ f_gidx,
-                                                        int32_t* __restrict__ f_type,
-                                                        gpx_wire_counts* counts) {
-  __shared__ __attribute__((aligned(16))) uint32_t stage[GPX_W_STAGE_WORDS];
-  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  WFrame f;
-  f.st = GPX_W_OK;
-  f.cnt = 0;
-  f.cls = -1;
-  wire_for_frame(frames, frame_off, nf, stage, i, [&](bool staged, int64_t pos) {
-    const int64_t L = frame_off[i + 1] - frame_off[i];
-    if (staged)
-      w_parse<LdsBytes>(S, N, (LdsBytes)stage + pos, L, f);
-    else
-      w_parse<GenBytes>(S, N, frames + pos, L, f);
-  });
-  if (i < nf) {
-    f_status[i] = (uint8_t)f.st;
-    if (f_gidx) f_gidx[i] = f.gidx;
-    if (f_type) f_type[i] = f.type;
-    W.cnt[i] = f.cnt;
-    W.cls[i] = (int8_t)((f.cls & 7) | (f.ascending ? 8 : 0) | (f.stop ? 16 : 0));
-    W.gidx[i] = f.gidx;
-    W.aux[i] = (int32_t)f.tail;
-  }
-  int32_t tot;
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    block_exscan((i < nf && f.cls == c && f.st == GPX_W_OK) ? f.cnt : 0, &tot);
-    if (threadIdx.x == 0) W.tile[(int64_t)c * W.ntiles + blockIdx.x] = tot;
-  }
-  block_exscan((i < nf && f.st != GPX_W_OK) ? 1 : 0, &tot);
-  if (threadIdx.x == 0 && tot) atomicAdd(&counts->n_bad_frames, tot);
-}
-
-/* pass 2 (one workgroup per class): exclusive scan of the tile totals; the class totals */
-__global__ __launch_bounds__(GPX_FBLOCK) void k_wire_offsets(WireScratch W, gpx_wire_counts* counts) {
-  {
-    const int c = (int)blockIdx.x;
-    int32_t run = 0;
-    for (int32_t t0 = 0; t0 < W.ntiles; t0 += GPX_FBLOCK) {
-      const int32_t t = t0 + (int32_t)threadIdx.x;
-      int32_t* q = &W.tile[(int64_t)c * W.ntiles + t];
-      const int32_t v = t < W.ntiles ? *q : 0;
-      int32_t tot;
-      const int32_t ex = block_exscan_n<GPX_FBLOCK>(v, &tot);
-      if (t < W.ntiles) *q = run + ex;
-      run += tot;
-    }
-    if (threadIdx.x == 0) (&counts->n_votes)[c] = run;
-  }
-}
-
 /* the r-th smallest distinct slot of a non-ascending list: smallest value greater than `last` */
 template <class BP>
 __device__ __forceinline__ int32_t w_next_slot(BP e, int32_t n, int32_t stride, int64_t last) {
@@ -766,7 +647,7 @@ __device__ __forceinline__ int32_t w_next_slot(BP e, int32_t n, int32_t stride, 
   return (int32_t)best;
 }
 
-/* pass 3: every frame writes its records at its class offset (frame order; slots ascending).
+/* every frame writes its records at its class offset (frame order; slots ascending).
  * Nothing is validated again: pass 1 left the frame's class, group row, list order and tail. */
 /* the records of one frame, written at its class offset */
 template <class BP>
@@ -831,44 +712,6 @@ __device__ __forceinline__ void wire_emit(const WireOut& O, int32_t i, BP p, int
   }
 }
 
-__global__ __launch_bounds__(GPX_BLOCK) void k_wire_unpack(WireScratch W, WireOut O, int32_t nf,
-                                                          const uint8_t* __restrict__ frames,
-                                                          const int64_t* __restrict__ frame_off,
-                                                          uint8_t* __restrict__ f_status,
-                                                          gpx_wire_counts* counts) {
-  __shared__ __attribute__((aligned(16))) uint32_t stage[GPX_W_STAGE_WORDS];
-  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  const bool live = i < nf && f_status[i] == GPX_W_OK;
-  const int32_t flags = live ? (int32_t)W.cls[i] : 7;
-  const int32_t cls = (flags & 7) == 7 ? -1 : (flags & 7);
-  const int32_t cnt = live ? W.cnt[i] : 0;
-  int32_t off = 0;
-#pragma unroll
-  for (int c = 0; c < 4; c++) {
-    int32_t tot;
-    const int32_t ex = block_exscan(cls == c ? cnt : 0, &tot);
-    if (cls == c) off = W.tile[(int64_t)c * W.ntiles + blockIdx.x] + ex;
-  }
-  bool over = false;
-  if (live) {
-    const int32_t cap = cls == 0 ? O.V.cap : cls == 1 ? O.C.cap : cls == 2 ? O.A.cap : O.R.cap;
-    over = (int64_t)off + cnt > cap;
-    if (over) f_status[i] = GPX_W_CAPACITY;
-  }
-  int32_t tot;
-  block_exscan(over ? 1 : 0, &tot);
-  if (threadIdx.x == 0 && tot) atomicAdd(&counts->n_bad_frames, tot);
-  const bool emit = live && !over;
-  wire_for_frame(frames, frame_off, nf, stage, i, [&](bool staged, int64_t pos) {
-    if (!emit) return;
-    if (staged)
-      wire_emit<LdsBytes>(O, i, (LdsBytes)stage + pos, W.gidx[i], W.aux[i], flags, cls, cnt, off);
-    else
-      wire_emit<GenBytes>(O, i, frames + pos, W.gidx[i], W.aux[i], flags, cls, cnt, off);
-  });
-}
-
-/* ------------------------------------------------------------------------- */
 /* decode in ONE launch: parse, place and emit while the tile's bytes are still in LDS.
  * The class offsets of a tile (records of every earlier frame, per class) come from a decoupled
  * look-back over per-tile words {epoch | state | count}: a tile publishes its own counts (AGGREGATE)
@@ -972,7 +815,7 @@ __device__ __forceinline__ uint32_t wl_lookback(const unsigned long long* __rest
   return (uint32_t)wl_lookback64(st, tile, epoch);
 }
 
-template <int WB, bool INFLIGHT = false>
+template <int WB>
 __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(6))) void k_wire_decode1(DevState S, DevNames N, WireLook K, WireOut O,
                                                            int32_t nf, int32_t ntiles,
                                                            const uint8_t* __restrict__ frames,
@@ -1013,7 +856,7 @@ __global__ __launch_bounds__(WB) __attribute__((amdgpu_waves_per_eu(6))) void k_
 #ifdef GPX_WD_NOSTAGE /* ablation builds (scripts/ubench/wire_ablation.sh): never shipped */
   const int32_t lead = 0;
 #else
-  const int32_t lead = wire_stage<WB, INFLIGHT>(stage, a0, nbytes);
+  const int32_t lead = wire_stage<WB>(stage, a0, nbytes);
 #endif
   __syncthreads();
   WD_STAMP(2); /* tile staged */

@@ -1072,6 +1072,7 @@ size_t PaxosManager::processRun() {
   }
   size_t fromDeferred = 0; /* retries of requests the proposal window had no room for */
   redeferred_ = 0;
+  const size_t firstDeferred = frames.size(); /* frames[firstDeferred .. firstDeferred + fromDeferred) are the retries */
   if (kind == 0 && inbox_.empty()) {
     while (!deferred_.empty() && frames.size() < maxFrames) {
       frames.push_back(std::move(deferred_.front()));
@@ -1176,7 +1177,11 @@ size_t PaxosManager::processRun() {
     std::vector<int64_t> pid(q.id.begin(), q.id.begin() + nQ);
     std::vector<Frame> latched; /* owns the batched frames */
     std::vector<Frame*> pframe((size_t)nQ);
-    for (int32_t i = 0; i < nQ; i++) pframe[(size_t)i] = &frames[(size_t)q.frame[(size_t)i]];
+    std::vector<uint8_t> pretry((size_t)nQ); /* the proposal is a retry out of deferred_ (a batch: its leader is) */
+    for (int32_t i = 0; i < nQ; i++) {
+      pframe[(size_t)i] = &frames[(size_t)q.frame[(size_t)i]];
+      pretry[(size_t)i] = (size_t)q.frame[(size_t)i] - firstDeferred < fromDeferred;
+    }
     int32_t nP = nQ;
     if (opt_.batchRequests && nQ > 1) {
       std::vector<int32_t> est((size_t)nQ), leader((size_t)nQ), bg((size_t)nQ), bl((size_t)nQ), bcnt((size_t)nQ),
@@ -1202,6 +1207,7 @@ size_t PaxosManager::processRun() {
       std::vector<uint8_t> ns;
       std::vector<int64_t> ni;
       std::vector<Frame*> nf;
+      std::vector<uint8_t> nr;
       for (int32_t b = 0; b < nB; b++) {
         const int32_t l = bl[(size_t)b];
         Frame* fr = pframe[(size_t)l];
@@ -1211,10 +1217,11 @@ size_t PaxosManager::processRun() {
           stats_.batched_requests += (uint64_t)(bsize[(size_t)b] - weight[(size_t)l]);
         }
         ng.push_back(bg[(size_t)b]), ns.push_back(bstop[(size_t)b]), ni.push_back(q.id[(size_t)l]), nf.push_back(fr);
+        nr.push_back(pretry[(size_t)l]);
       }
       for (int32_t i = 0; i < nQ; i++) /* requests for groups this node does not have: dropped */
         if (leader[(size_t)i] < 0) stats_.refused++;
-      pg.swap(ng), pstop.swap(ns), pid.swap(ni), pframe.swap(nf);
+      pg.swap(ng), pstop.swap(ns), pid.swap(ni), pframe.swap(nf), pretry.swap(nr);
       nP = nB;
     }
     std::vector<int32_t> slot((size_t)nP), bn((size_t)nP), bc((size_t)nP), med((size_t)nP);
@@ -1241,7 +1248,8 @@ size_t PaxosManager::processRun() {
          * for decisions to free a slot and is proposed again on a later pass - never dropped */
         deferred_.push_back(std::move(rf));
         stats_.deferred++;
-        redeferred_++;
+        if (pretry[(size_t)i]) redeferred_++; /* only a retry refused AGAIN is "no progress"; a fresh request deferred
+                                                for the first time left the queue it came from */
       } else {
         stats_.refused++; /* STOPPED / NOGROUP / proposal after a stop: the reference drops these too */
       }

@@ -235,7 +235,7 @@ class PaxosManager {
   std::deque<Frame> inbox_;                               /* frames from the network and from myself */
   std::deque<Frame> requests_;                            /* REQUEST frames of local clients */
   std::deque<Frame> deferred_; /* requests the engine's proposal window had no room for: retried first */
-  size_t redeferred_ = 0;      /* ... and how many of this pass's proposals went (back) there */
+  size_t redeferred_ = 0;      /* ... and how many of this pass's RETRIES went back there */
   /* view change: request bytes by (gidx, requestID) - proposals made while not active, and the
    * pvalues the PREPARE replies carried */
   std::map<std::pair<int32_t, int64_t>, Frame> preactive_; /* (gidx, request handle) -> request frame */

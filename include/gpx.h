@@ -146,8 +146,16 @@ int gpx_engine_set_stream(gpx_engine* h, void* hip_stream);
  * allocating them.  Purely an optimisation: unregistered pointers keep working.
  */
 int gpx_host_register(gpx_engine* h, void* ptr, size_t bytes);
+/*
+ * Takes the pinning away again.  Waits first for everything the engine has in flight (its stream, the
+ * asynchronous calls' copy-in stream and every copy-out stream): a call whose ticket was not waited for may still
+ * be reading the block or writing through its device mapping.  Tickets stay valid.  gpx_engine_destroy
+ * unregisters whatever is still registered through this engine (after the same wait).  An output buffer that
+ * lies inside a registered block must fit in it with its full capacity (n entries): a buffer that runs over the
+ * block's end is treated as unregistered memory (the copy path).
+ */
 int gpx_host_unregister(gpx_engine* h, void* ptr);
-/* block until everything submitted to the engine has finished */
+/* block until everything submitted to the engine has finished: its stream and the asynchronous calls' copy streams */
 int gpx_engine_sync(gpx_engine* h);
 /*
  * Promise about the batches of later calls (mask of GPX_ORDERED_*; 0 = none, the default).

@@ -80,8 +80,8 @@ def main():
             os.environ["GPX_TRY_RUNS"] = "0"
             steady_state_run(hip, orc, int(rng.choice([3, 4, 5, 8])), seed, NODES, G=int(rng.choice([700, 6000])))
             done["steady"] = done.get("steady", 0) + 1
-        if seed % 2 == 0:  # wire frames, damaged ones included: decode as one launch or as three
-            os.environ["GPX_WIRE_LEGACY"] = "1" if seed % 4 == 0 else "0"
+        if seed % 2 == 0:  # wire frames, damaged ones included: tiles of 512 or of 256 frames
+            os.environ["GPX_WD_TILE"] = "256" if seed % 4 == 0 else "512"
             ((ewh, wh), (ewo, wo)), names = make_wire_pair(hip, orc, int(rng.choice([200, 1500])), 3, rng)
             for _ in range(3):
                 frames = random_frames(names, int(rng.choice([300, 5000])), rng, float(rng.choice([0.0, 0.3, 0.7])))

@@ -12,13 +12,11 @@ from tests.wire_common import make_wire_pair, random_frames, assert_same_decode
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(autouse=True, params=["one-launch decode", "three-launch decode", "one-launch decode, 256-frame tiles"])
+@pytest.fixture(autouse=True, params=["512-frame tiles", "256-frame tiles"])
 def _decode_path(request, monkeypatch):
-    """gpx_wire_decode runs as ONE launch (k_wire_decode1: look-back over tiles of 512 frames, or of 256 with
-    GPX_WD_TILE=256) or, with GPX_WIRE_LEGACY=1, as scan / offsets / unpack (both read when the engine first
-    touches the wire path) - every case of this file runs all three ways."""
-    monkeypatch.setenv("GPX_WIRE_LEGACY", "1" if request.param.startswith("three") else "0")
-    monkeypatch.setenv("GPX_WD_TILE", "256" if request.param.endswith("256-frame tiles") else "512")
+    """gpx_wire_decode is ONE launch (k_wire_decode1: look-back over tiles of 512 frames, or of 256 with
+    GPX_WD_TILE=256, read when the engine first touches the wire path) - every case of this file runs both ways."""
+    monkeypatch.setenv("GPX_WD_TILE", "256" if request.param.startswith("256") else "512")
 
 
 @pytest.mark.parametrize("name", [n for n in dir(scen) if n.startswith("test_") and "oracle_lib" in
