@@ -5,7 +5,7 @@ from ._abi import (  # noqa: F401
     Engine, GpxLib, GpxError, load_hip, hri_create, hri_initial, make_hri, HRI_DTYPE,
     hri_to_string, hri_from_string,
     S_OK, S_NOGROUP, S_STOPPED, S_WINDOW, S_FORWARD, S_REFUSED, S_EXISTS, S_BUSY, S_UNORDERED,
-    ORDERED_PROPOSE, ORDERED_ACCEPT, ORDERED_COMMIT, ORDERED_REPLY_RUNS, TRY_REPLY_RUNS,
+    ORDERED_PROPOSE, ORDERED_ACCEPT, ORDERED_COMMIT, ORDERED_REPLY_RUNS, TRY_REPLY_RUNS, LAZY_OUTPUTS,
     D_DECISION, D_PREEMPTED, R_TOLOG, R_STORED, A_STOP, C_HASVALUE, C_STOP,
     F_ACCEPTS_FROM_DISK, RETIRE_PAUSE, RETIRE_KILL,
 )

@@ -25,6 +25,7 @@ S_OK, S_NOGROUP, S_STOPPED, S_WINDOW, S_FORWARD, S_REFUSED, S_EXISTS, S_BUSY = r
 S_UNORDERED = 9
 ORDERED_PROPOSE, ORDERED_ACCEPT, ORDERED_COMMIT = 1, 2, 4
 ORDERED_REPLY_RUNS, TRY_REPLY_RUNS = 8, 16
+LAZY_OUTPUTS = 32
 D_DECISION, D_PREEMPTED = 1, 2
 R_TOLOG, R_STORED = 1, 2
 A_STOP = 1
@@ -113,6 +114,7 @@ _DEV_SIGS = {
     "accept_reply_batch_async": [C.c_int32] + [_VP] * 3 + [C.c_int32, C.c_int32] + [_VP] * 11 + [C.POINTER(C.c_uint64)],
     "commit_batch_async": [C.c_int32] + [_VP] * 11 + [C.POINTER(C.c_uint64)],
     "engine_wait": [C.c_uint64],
+    "compact_last_dev": [],
     "profile_enable": [C.c_int32],
     "profile_read": [C.POINTER(GpxKernelStat), C.c_int32],
 }
@@ -382,6 +384,10 @@ class Engine:
         """Run the *_dev calls on this hipStream_t (e.g. torch.cuda.current_stream().cuda_stream)."""
         self.lib.check(self.lib.fn["engine_set_stream"](self.h, _VP(hip_stream_handle or None)),
                        "engine_set_stream")
+
+    def compact_last_dev(self):
+        """GPX_LAZY_OUTPUTS: make the most recent *_dev call's parked outputs dense (gpx_compact_last_dev)."""
+        self.lib.check(self.lib.fn["compact_last_dev"](self.h), "compact_last_dev")
 
     def call_dev(self, name: str, n: int, *ptrs):
         """Raw asynchronous call of gpx_<name>_dev with integer device addresses (0 = NULL)."""

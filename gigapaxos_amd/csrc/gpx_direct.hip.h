@@ -68,13 +68,21 @@ struct RunIter {
   /* the head's own record, fetched by the kernel ahead of the group state; g_next = gidx[head + 1]
    * (or ~g at the end of the batch): a run of one record never touches memory here */
   bool inplace = false; /* park runs in the caller's columns (k_ac_direct<COMMIT>) */
+  /* k_ac_one: "the cheap answer does not hold" is collected per workgroup and travels with the arrival counters
+   * instead of being stored to D.mark by every lane that notices */
+  bool mark_local = false, irregular = false;
   int32_t pend = -1;    /* inplace: the record handed out last has not parked a run yet */
   bool have_first = false;
   int32_t f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
   int32_t head = -2, g_next = 0;
   __device__ __forceinline__ bool next(Rec& out) {
     if (inplace) {
-      if (pend >= 0) D.mark[0] = epoch; /* a commit that executed nothing: the columns have a hole */
+      if (pend >= 0) { /* a commit that executed nothing: the columns have a hole */
+        if (mark_local)
+          irregular = true;
+        else
+          D.mark[0] = epoch;
+      }
       pend = i;
     }
     if (have_first) {
@@ -114,7 +122,10 @@ struct RunIter {
     } else {
       D.st_first[cur] = first_slot;
       D.st_count[cur] = count; /* > 0 */
-      D.mark[0] = epoch;
+      if (mark_local)
+        irregular = true;
+      else
+        D.mark[0] = epoch;
     }
     D.tag[cur] = epoch;
     if (!count_chunks) return;
@@ -219,8 +230,10 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_runs_direct(DevScratch X, i
                                                                 int32_t* __restrict__ x_gidx,
                                                                 int32_t* __restrict__ x_first,
                                                                 int32_t* __restrict__ x_count,
-                                                                int32_t* total_out, int32_t refuse) {
+                                                                int32_t* total_out, int32_t refuse,
+                                                                int32_t published = 0) {
   const bool unsorted = *X.unsorted == X.epoch, marked = *D.mark == X.epoch; /* one round trip */
+  if (published && !marked) return; /* k_ac_one's last workgroup has written the regular batch's count */
   if (unsorted) { /* the partition path (k_emit_runs) writes the outputs; refused: none */
     if (refuse && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = 0;
     return;
@@ -300,50 +313,51 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_small(
   __syncthreads();
   const int32_t w = s_w;
   const int32_t i = w * GPX_DCHUNK + (int32_t)threadIdx.x;
-  const bool ordered = small_batch_ordered<false>(n, gidx, S.G);
-  if (!ordered) {
+  const uint32_t first_bad = small_batch_first_bad<false>(n, gidx, S.G);
+  if (first_bad != 0xffffffffu && !refuse) { /* no promise: the partition path launched behind takes the whole batch */
     if (w == 0 && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
-    if (i < n) {
-      if (refuse) {
-        if (!COMMIT) {
-          r_bnum[i] = 0;
-          r_bcoord[i] = 0;
-          r_maxcp[i] = 0;
-          r_flags[i] = 0;
-        }
-        status[i] = GPX_S_UNORDERED;
-      } else {
-        status[i] = (uint32_t)gidx[i] < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
-      }
-    }
-    if (refuse && w == 0 && threadIdx.x == 0 && n_runs) *n_runs = 0;
+    if (i < n) status[i] = (uint32_t)gidx[i] < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
     return;
   }
   int32_t have = 0, first = 0, count = 0;
   if (i < n) {
     const int32_t g = gidx[i];
-    if (i == 0 || gidx[i - 1] != g) { /* head of its group's run: replays the run in array order */
-      RunIter it;
-      it.gidx = gidx;
-      it.bnum = bnum;
-      it.bcoord = bcoord;
-      it.slot = slot;
-      it.median = median;
-      it.flags = flags;
-      it.D = D;
-      it.n = n;
-      it.i = i;
-      it.g = g;
-      it.cur = i;
-      it.epoch = X.epoch;
-      it.chunk = -1; /* every run is parked at its record and counted below */
-      it.local = 0;
-      it.count_chunks = false;
-      it.st = status;
-      if (COMMIT)
-        apply_commit_group(S, X, g, it, status);
-      else
-        apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+    if (i == 0 || gidx[i - 1] != g) { /* first record of its group's run: answers for the whole run */
+      if ((uint32_t)i >= first_bad) {
+        /* GPX_ORDERED_* broken: runs from the first violation on are refused (the first violation is always a
+         * run start: gpx_one.hip.h) */
+        for (int32_t j = i; j < n && gidx[j] == g; j++) {
+          if (!COMMIT) {
+            r_bnum[j] = 0;
+            r_bcoord[j] = 0;
+            r_maxcp[j] = 0;
+            r_flags[j] = 0;
+          }
+          status[j] = GPX_S_UNORDERED;
+        }
+      } else { /* replays the run in array order */
+        RunIter it;
+        it.gidx = gidx;
+        it.bnum = bnum;
+        it.bcoord = bcoord;
+        it.slot = slot;
+        it.median = median;
+        it.flags = flags;
+        it.D = D;
+        it.n = n;
+        it.i = i;
+        it.g = g;
+        it.cur = i;
+        it.epoch = X.epoch;
+        it.chunk = -1; /* every run is parked at its record and counted below */
+        it.local = 0;
+        it.count_chunks = false;
+        it.st = status;
+        if (COMMIT)
+          apply_commit_group(S, X, g, it, status);
+        else
+          apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+      }
     }
   }
   /* the runs parked at THIS chunk's records: by this workgroup's heads, or by a head of an earlier

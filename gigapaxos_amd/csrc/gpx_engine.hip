@@ -21,6 +21,7 @@
 #include "gpx_kernels.hip.h"
 #include "gpx_ar16.hip.h"
 #include "gpx_direct.hip.h"
+#include "gpx_one.hip.h"
 #include "gpx_runs.hip.h"
 #include "gpx_route.hip.h"
 #include "gpx_wire.hip.h"
@@ -110,6 +111,22 @@ struct gpx_engine {
   /* [max_batch] == a call's epoch: record i of that call holds a parked output (direct and sorted-runs
    * paths: no per-record clearing store, no clearing pass) */
   uint32_t* rec_tag = nullptr;
+  /* ordered batches in one launch (gpx_one.hip.h): order words, arrival counters, the call counter of their epochs */
+  unsigned long long* one_ord = nullptr;
+  uint32_t *one_done1 = nullptr, *one_done0 = nullptr;
+  uint32_t one_epoch = 0;
+  /* GPX_LAZY_OUTPUTS: what gpx_compact_last_dev needs to finish the most recent call (kind 0: nothing pending) */
+  struct LastCall {
+    int kind = 0; /* 1 ACCEPT, 2 COMMIT (k_ac_one), 3 accept replies (k_ar_runs) */
+    int32_t n = 0, nchunks = 0;
+    DevScratch X{};
+    const int32_t* gidx = nullptr;
+    DirectStage D{};
+    int32_t *x_gidx = nullptr, *x_first = nullptr, *x_count = nullptr, *count = nullptr;
+    RunsStage rs{};
+    RunsInfo* info = nullptr;
+  } last;
+  int lazy_override = -1; /* 1: the host-pointer twins compact on demand themselves; 0: asynchronous calls need dense columns */
   /* accept replies as a few sorted runs (gpx_runs.hip.h): allocated on first use */
   RunsInfo* runs_info = nullptr; /* [2], used alternately */
   uint64_t runs_seq = 0;
@@ -307,6 +324,43 @@ void begin_back(gpx_engine* e, int, int32_t n, bool v16 = false) {
                        : GPX_BUCKET_LDS_BYTES(e->X.gb, e->X.lds_recs)) + e->lds_pad;
 }
 void end_call(gpx_engine* e, int) { e->call_seq++; }
+
+/* control words of a one-launch ordered batch (gpx_one.hip.h); a fresh 30-bit epoch per launch */
+OneCtl one_ctl(gpx_engine* e) {
+  if (++e->one_epoch >= (1u << 30)) {
+    HIPQ(hipMemsetAsync(e->one_ord, 0, ((size_t)e->cfg.max_batch / GPX_BLOCK + 2) * sizeof(unsigned long long), e->stream));
+    e->one_epoch = 1;
+  }
+  return OneCtl{e->one_ord, e->one_done1, e->one_done0, e->one_epoch};
+}
+/* are the compacted outputs of this call left parked when the batch is unusual (GPX_LAZY_OUTPUTS)? */
+bool lazy_outputs(const gpx_engine* e) {
+  if (e->lazy_override >= 0) return e->lazy_override != 0;
+  return (e->ordered_mask & GPX_LAZY_OUTPUTS) != 0;
+}
+/* the compaction pass of an ordered ACCEPT / COMMIT batch that went through k_ac_one: a usual batch has nothing
+ * for it to do (D.mark is not raised) */
+void launch_one_compaction(gpx_engine* e, const gpx_engine::LastCall& L) {
+  const DevScratch X0 = e->X;
+  e->X = L.X;
+  {
+    LaunchScope _ls(e, "k_one_count");
+    hipLaunchKernelGGL(k_one_count, dim3(L.nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, L.n, L.D);
+  }
+  if (L.kind == 2) {
+    {
+      LaunchScope _ls(e, "k_emit_runs_direct");
+      hipLaunchKernelGGL(k_emit_runs_direct<true>, dim3(std::min(L.nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, L.n,
+                         L.nchunks, L.gidx, L.D, L.x_gidx, L.x_first, L.x_count, L.count, 0, 1);
+    }
+    LAUNCH(e, "k_copy_runs", k_copy_runs, 256, e->X, L.D, L.x_gidx, L.x_first, L.x_count);
+  } else {
+    LaunchScope _ls(e, "k_emit_runs_direct");
+    hipLaunchKernelGGL(k_emit_runs_direct<false>, dim3(std::min(L.nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, L.n,
+                       L.nchunks, L.gidx, L.D, L.x_gidx, L.x_first, L.x_count, L.count, 0, 1);
+  }
+  e->X = X0;
+}
 
 /* bucket partition front end, part 1: per-bucket record counts of the batch */
 void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, int is_votes,
@@ -611,6 +665,9 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.o_rec, N, false);
   A(X.bucket_nout, nbk_alloc, true);
   A(e->rec_tag, N, true);
+  A(e->one_ord, N / GPX_BLOCK + 2, true);
+  A(e->one_done1, N / GPX_BLOCK / 64 + 2, true);
+  A(e->one_done0, 1, true);
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
@@ -672,7 +729,7 @@ int gpx_engine_set_stream(gpx_engine* h, void* hip_stream) {
 
 int gpx_engine_set_ordered_batches(gpx_engine* h, int32_t mask) {
   if (!h || (mask & ~(GPX_ORDERED_PROPOSE | GPX_ORDERED_ACCEPT | GPX_ORDERED_COMMIT | GPX_ORDERED_REPLY_RUNS |
-                      GPX_TRY_REPLY_RUNS)))
+                      GPX_TRY_REPLY_RUNS | GPX_LAZY_OUTPUTS)))
     return GPX_EINVAL;
   h->ordered_mask = mask | h->env_mask;
   return GPX_OK;
@@ -905,24 +962,34 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     const int32_t refuse = runs_promised ? 1 : 0;
     LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
               gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks);
+    const OneCtl C = one_ctl(e);
     {
       LaunchScope _ls(e, "k_ar_runs");
+      const dim3 grid((n + GPX_RBLOCK - 1) / GPX_RBLOCK);
       if (e->cfg.kmax <= 4)
-        hipLaunchKernelGGL(k_ar_runs<4>, dim3((n + GPX_RBLOCK - 1) / GPX_RBLOCK), dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum,
-                           bcoord, slot, acceptor, max_cp, status, st, info, refuse);
+        hipLaunchKernelGGL(k_ar_runs<4>, grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, bcoord, slot, acceptor, max_cp,
+                           status, st, info, refuse, C, n_out, &e->X.counters[1]);
       else if (e->cfg.kmax <= 8)
-        hipLaunchKernelGGL(k_ar_runs<8>, dim3((n + GPX_RBLOCK - 1) / GPX_RBLOCK), dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum,
-                           bcoord, slot, acceptor, max_cp, status, st, info, refuse);
+        hipLaunchKernelGGL(k_ar_runs<8>, grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, bcoord, slot, acceptor, max_cp,
+                           status, st, info, refuse, C, n_out, &e->X.counters[1]);
       else
-        hipLaunchKernelGGL(k_ar_runs<16>, dim3((n + GPX_RBLOCK - 1) / GPX_RBLOCK), dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum,
-                           bcoord, slot, acceptor, max_cp, status, st, info, refuse);
+        hipLaunchKernelGGL(k_ar_runs<16>, grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, bcoord, slot, acceptor, max_cp,
+                           status, st, info, refuse, C, n_out, &e->X.counters[1]);
     }
-    {
-      LaunchScope _ls(e, "k_emit_dec_runs");
-      hipLaunchKernelGGL(k_emit_dec_runs, dim3(std::min(nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, nchunks, st, info, n_out,
-                         &e->X.counters[1], refuse);
+    /* a REGULAR batch is finished: k_ar_runs' last workgroup has published its count.  The compaction pass of any
+     * other batch follows at once - or, under the promise with GPX_LAZY_OUTPUTS, when the caller asks for it */
+    e->last.kind = 0;
+    if (runs_promised && lazy_outputs(e)) {
+      gpx_engine::LastCall& L = e->last;
+      L.kind = 3, L.n = n, L.nchunks = nchunks, L.X = e->X, L.rs = st, L.info = info, L.count = n_out;
+    } else {
+      {
+        LaunchScope _ls(e, "k_emit_dec_runs");
+        hipLaunchKernelGGL(k_emit_dec_runs, dim3(std::min(nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, nchunks, st, info, n_out,
+                           &e->X.counters[1], refuse, 1);
+      }
+      LAUNCH(e, "k_merge_runs", k_merge_runs, 256, e->X, n, st, (const RunsInfo*)info);
     }
-    LAUNCH(e, "k_merge_runs", k_merge_runs, 256, e->X, n, st, (const RunsInfo*)info);
     if (runs_promised) {
       end_call(e, fs);
       HIPCHK(hipGetLastError());
@@ -963,6 +1030,26 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
    * launch (k_ac_small: tickets instead of chunk counters) */
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
   const bool promised = (e->ordered_mask & GPX_ORDERED_ACCEPT) != 0;
+  e->last.kind = 0;
+  if (promised && !fused) {
+    /* the promise and more than 65,536 records: order check, application and the usual batch's count in ONE launch
+     * (gpx_one.hip.h); the compaction pass follows unless the caller asked for lazy outputs */
+    {
+      LaunchScope _ls(e, "k_ac_one");
+      hipLaunchKernelGGL(k_ac_one<false>, dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, one_ctl(e), n,
+                         gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, n_runs);
+    }
+    gpx_engine::LastCall& L = e->last;
+    L.kind = 1, L.n = n, L.nchunks = nchunks, L.X = e->X, L.gidx = gidx, L.D = D;
+    L.x_gidx = x_gidx, L.x_first = x_first, L.x_count = x_count, L.count = n_runs;
+    if (!lazy_outputs(e)) {
+      launch_one_compaction(e, L);
+      L.kind = 0;
+    }
+    end_call(e, fs);
+    HIPCHK(hipGetLastError());
+    return GPX_OK;
+  }
   if (!fused)
     LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
               e->S.G, e->X, status, D.chunk_cnt, nchunks);
@@ -1050,6 +1137,25 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
                       (uint32_t*)(e->fs[fs].chunk_cnt + GPX_CHUNK_CNT_MARK(e->cfg.max_batch))};
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N; /* one launch: k_ac_small */
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
+  e->last.kind = 0;
+  if (promised && !fused) { /* one launch (gpx_one.hip.h), like the ACCEPT call */
+    {
+      LaunchScope _ls(e, "k_ac_one");
+      hipLaunchKernelGGL(k_ac_one<true>, dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, one_ctl(e), n,
+                         gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                         (uint8_t*)nullptr, status, D, n_runs);
+    }
+    gpx_engine::LastCall& L = e->last;
+    L.kind = 2, L.n = n, L.nchunks = nchunks, L.X = e->X, L.gidx = gidx, L.D = D;
+    L.x_gidx = x_gidx, L.x_first = x_first, L.x_count = x_count, L.count = n_runs;
+    if (!lazy_outputs(e)) {
+      launch_one_compaction(e, L);
+      L.kind = 0;
+    }
+    end_call(e, fs);
+    HIPCHK(hipGetLastError());
+    return GPX_OK;
+  }
   if (!fused)
     LAUNCH_OC(e, "k_order_check", k_order_check<false>, (n + GPX_OC_BLOCK * 8 - 1) / (GPX_OC_BLOCK * 8), 0, n, gidx,
               e->S.G, e->X, status, D.chunk_cnt, nchunks);
@@ -1112,6 +1218,28 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   return GPX_OK;
 }
 
+int gpx_compact_last_dev(gpx_engine* h) {
+  if (!h) return GPX_EINVAL;
+  gpx_engine* e = h;
+  gpx_engine::LastCall& L = e->last;
+  if (L.kind == 1 || L.kind == 2) {
+    launch_one_compaction(e, L);
+  } else if (L.kind == 3) {
+    const DevScratch X0 = e->X;
+    e->X = L.X;
+    {
+      LaunchScope _ls(e, "k_emit_dec_runs");
+      hipLaunchKernelGGL(k_emit_dec_runs, dim3(std::min(L.nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, L.n, L.nchunks,
+                         L.rs, L.info, L.count, &e->X.counters[1], 1, 1);
+    }
+    LAUNCH(e, "k_merge_runs", k_merge_runs, 256, e->X, L.n, L.rs, (const RunsInfo*)L.info);
+    e->X = X0;
+  }
+  L.kind = 0;
+  HIPCHK(hipGetLastError());
+  return GPX_OK;
+}
+
 /* handle: device pointer or null (gpx_propose_batch_h) */
 static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
                             const int64_t* handle, int32_t* slot, int32_t* bnum, int32_t* bcoord,
@@ -1125,6 +1253,22 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   const int32_t refuse = promised ? 1 : 0;
   /* at most 65,536 requests on one stream: order check and direct application in one launch */
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
+  if (promised && !fused) { /* order check and application in one launch (gpx_one.hip.h) */
+    e->stream = e->sB;
+    const OneCtl C = one_ctl(e);
+    if (e->cfg.kmax <= 4)
+      LAUNCH(e, "k_propose_one", k_propose_one<4>, grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
+             status, handle);
+    else if (e->cfg.kmax <= 8)
+      LAUNCH(e, "k_propose_one", k_propose_one<8>, grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
+             status, handle);
+    else
+      LAUNCH(e, "k_propose_one", k_propose_one<16>, grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
+             status, handle);
+    end_call(e, fs);
+    HIPCHK(hipGetLastError());
+    return GPX_OK;
+  }
   if (fused) {
     e->stream = e->sB;
     if (e->cfg.kmax <= 4)
@@ -1300,12 +1444,22 @@ int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   H2D(h->st_i32[3], slot, b4);
   H2D(h->st_i32[4], median_cp, b4);
   if (a_flags) H2D(h->st_u8[0], a_flags, (size_t)n);
+  h->lazy_override = 1; /* the count comes to the host anyway: compaction only for a batch that needs it */
   rc = gpx_accept_batch_dev(h, n, h->st_i32[0], h->st_i32[1], h->st_i32[2], h->st_i32[3],
                             h->st_i32[4], a_flags ? h->st_u8[0] : nullptr, h->st_i32[5],
                             h->st_i32[6], h->st_i32[7], h->st_u8[1], h->st_u8[2], h->st_i32[8],
                             h->st_i32[9], h->st_i32[10], h->st_count);
+  h->lazy_override = -1;
   if (rc != GPX_OK) return rc;
   D2H(n_runs, h->st_count, 4);
+  if (h->last.kind) {
+    HIPCHK(hipStreamSynchronize(h->sB));
+    if (*n_runs < 0) {
+      if ((rc = gpx_compact_last_dev(h)) != GPX_OK) return rc;
+      D2H(n_runs, h->st_count, 4);
+    }
+    h->last.kind = 0;
+  }
   D2H(r_bnum, h->st_i32[5], b4);
   D2H(r_bcoord, h->st_i32[6], b4);
   D2H(r_maxcp, h->st_i32[7], b4);
@@ -1372,14 +1526,24 @@ int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
   H2D(h->st_i32[3], slot, b4);
   H2D(h->st_i32[4], acceptor, b4);
   H2D(h->st_i32[5], max_cp, b4);
+  h->lazy_override = 1; /* the count comes to the host anyway: compaction only for a batch that needs it */
   rc = gpx_accept_reply_batch_dev(h, n, h->st_i32[0], h->st_i32[1], h->st_i32[2], h->st_i32[3],
                                   h->st_i32[4], h->st_i32[5], h->st_i32[6], h->st_i32[7],
                                   h->st_i32[8], h->st_i32[9], h->st_i32[10], h->st_u8[0],
                                   h->st_count, h->st_u8[1]);
+  h->lazy_override = -1;
   if (rc != GPX_OK) return rc;
   D2H(n_out, h->st_count, 4);
   if (status) D2H(status, h->st_u8[1], (size_t)n);
   HIPCHK(hipStreamSynchronize(h->sB));
+  if (h->last.kind) {
+    if (*n_out < 0) {
+      if ((rc = gpx_compact_last_dev(h)) != GPX_OK) return rc;
+      D2H(n_out, h->st_count, 4);
+      HIPCHK(hipStreamSynchronize(h->sB));
+    }
+    h->last.kind = 0;
+  }
   const size_t m = (size_t)(*n_out);
   if (m) {
     D2H(d_gidx, h->st_i32[6], m * 4);
@@ -1436,11 +1600,21 @@ int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   H2D(h->st_i32[3], slot, b4);
   H2D(h->st_i32[4], median_cp, b4);
   if (c_kind) H2D(h->st_u8[0], c_kind, (size_t)n);
+  h->lazy_override = 1;
   rc = gpx_commit_batch_dev(h, n, h->st_i32[0], h->st_i32[1], h->st_i32[2], h->st_i32[3],
                             h->st_i32[4], c_kind ? h->st_u8[0] : nullptr, h->st_u8[1],
                             h->st_i32[5], h->st_i32[6], h->st_i32[7], h->st_count);
+  h->lazy_override = -1;
   if (rc != GPX_OK) return rc;
   D2H(n_runs, h->st_count, 4);
+  if (h->last.kind) {
+    HIPCHK(hipStreamSynchronize(h->sB));
+    if (*n_runs < 0) {
+      if ((rc = gpx_compact_last_dev(h)) != GPX_OK) return rc;
+      D2H(n_runs, h->st_count, 4);
+    }
+    h->last.kind = 0;
+  }
   D2H(status, h->st_u8[1], (size_t)n);
   HIPCHK(hipStreamSynchronize(h->sB));
   const size_t m4 = (size_t)(*n_runs) * 4;
@@ -1748,8 +1922,10 @@ int gpx_accept_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const 
       if ((rc = async_inputs(h, n, 5, hs, dd, a_flags, a.u8[0])) != GPX_OK) return async_fail(h, a, rc);
     }
     if ((rc = async_inputs_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
+    h->lazy_override = 0; /* k_copy_out reads the count on the device: dense columns, always */
     rc = gpx_accept_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a_flags ? a.u8[0] : nullptr,
                               a.i32[5], a.i32[6], a.i32[7], a.u8[1], a.u8[2], a.i32[8], a.i32[9], a.i32[10], a.cnt);
+    h->lazy_override = -1;
     if (rc != GPX_OK) return async_fail(h, a, rc);
     if ((rc = async_kernels_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     {
@@ -1802,8 +1978,10 @@ int gpx_accept_reply_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, 
       }
     }
     if ((rc = async_inputs_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
+    h->lazy_override = 0; /* k_copy_out reads the count on the device: dense columns, always */
     rc = gpx_accept_reply_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], a.i32[5], a.i32[6],
                                     a.i32[7], a.i32[8], a.i32[9], a.i32[10], a.u8[0], a.cnt, a.u8[1]);
+    h->lazy_override = -1;
     if (rc != GPX_OK) return async_fail(h, a, rc);
     if ((rc = async_kernels_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     if (status) {
@@ -1844,8 +2022,10 @@ int gpx_commit_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const 
       if ((rc = async_inputs(h, n, 5, hs, dd, c_kind, a.u8[0])) != GPX_OK) return async_fail(h, a, rc);
     }
     if ((rc = async_inputs_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
+    h->lazy_override = 0; /* k_copy_out reads the count on the device: dense columns, always */
     rc = gpx_commit_batch_dev(h, n, a.i32[0], a.i32[1], a.i32[2], a.i32[3], a.i32[4], c_kind ? a.u8[0] : nullptr,
                               a.u8[1], a.i32[5], a.i32[6], a.i32[7], a.cnt);
+    h->lazy_override = -1;
     if (rc != GPX_OK) return async_fail(h, a, rc);
     if ((rc = async_kernels_done(h, a)) != GPX_OK) return async_fail(h, a, rc);
     {

@@ -1228,16 +1228,22 @@ struct AccView {
   }
 };
 
-/* PaxosAcceptor.garbageCollectAccepted (PaxosAcceptor.java:476-494).
- * garbageCollectDecisions (:496-506) can never find anything: committedRequests only ever
- * holds slots >= _slot (put only if slot - _slot >= 0, :341; removed on execution) and it
- * only drops slots < gcSlot <= _slot - 1. */
+/* PaxosAcceptor.garbageCollectAccepted (PaxosAcceptor.java:476-494) and, at its end, garbageCollectDecisions
+ * (:496-506).  In ordinary operation garbageCollectDecisions finds nothing: committedRequests only holds slots
+ * >= _slot (put only if slot - _slot >= 0, :341; removed on execution) and it drops slots "before" gcSlot <=
+ * _slot - 1.  But both methods compare by SUBTRACTION, and a gcSlot that lies nearly half the int range behind
+ * _slot - a stale medianCheckpointedSlot of a retransmitted ACCEPT after the slots have crossed
+ * Integer.MAX_VALUE (median 0 against slots near -2^31) - makes `gcSlot - key > 0` true for keys AHEAD of _slot:
+ * the Java then drops committed (and accepted) slots it still needs.  Reproduced, not repaired (`far` below;
+ * found on the GPU by the whole round across the wrap against the Java reading, round 4). */
 __device__ __forceinline__ void acc_gc(const DevState& S, AccView& V, AccState& a, int32_t gcSlot) {
   if (jsub(a.slot, gcSlot) <= 0) gcSlot = jsub(a.slot, 1);
   const int32_t delta = jsub(gcSlot, a.gc);
+  /* key - gcSlot (key in [_slot - W, _slot + W)) may overflow: the narrow walks below do not hold */
+  const bool far = jsub(a.slot, gcSlot) > INT32_MAX - 2 * S.W;
   if (delta > 0) {
     const int32_t Wm = S.W - 1;
-    if (delta >= S.W) {
+    if (delta >= S.W || far) {
       for (int32_t w = 0; w < S.W; w++) {
         const I4 e = V.rd(w);
         if ((e.w & RF_PRESENT) && jsub(e.x, gcSlot) <= 0) V.wr_flags(w, e.w & ~(int32_t)AF_MASK);
@@ -1251,6 +1257,13 @@ __device__ __forceinline__ void acc_gc(const DevState& S, AccView& V, AccState& 
       }
     }
     a.gc = gcSlot;
+  }
+  if (far && jsub(gcSlot, a.slot) < 0) { /* garbageCollectDecisions(gcSlot): "can only GC executed decisions" */
+    for (int32_t w = 0; w < S.W; w++) {
+      const I4 e = V.rd(w);
+      if ((((uint32_t)e.w >> CF_SHIFT) & RF_PRESENT) && jsub(gcSlot, S.com_ring[(int64_t)w * S.G + V.g].x) > 0)
+        V.wr_flags(w, e.w & ~(int32_t)CF_MASK);
+    }
   }
 }
 
@@ -1837,19 +1850,32 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_direct(
  * (GPX_ORDERED_PROPOSE promise) the batch is refused whole. */
 /* is the whole gidx column in range and ascending?  Every lane of every workgroup ends up with the same
  * verdict (the column is read by all of them: at most 256 KB, L2-resident) */
+/* first index that breaks the order - out of range, or a descent (STRICT: a non-ascent) INTO it - or 0xffffffff */
 template <bool STRICT>
-__device__ __forceinline__ bool small_batch_ordered(int32_t n, const int32_t* __restrict__ gidx, int32_t G) {
-  bool bad = false;
+__device__ __forceinline__ uint32_t small_batch_first_bad(int32_t n, const int32_t* __restrict__ gidx, int32_t G) {
+  __shared__ uint32_t s_first_bad;
+  if (threadIdx.x == 0) s_first_bad = 0xffffffffu;
+  uint32_t mine = 0xffffffffu;
   for (int32_t i0 = (int32_t)threadIdx.x * 4; i0 < n; i0 += (int32_t)blockDim.x * 4) {
     int32_t g[5];
+    g[0] = i0 > 0 ? gidx[i0 - 1] : INT32_MIN;
 #pragma unroll
-    for (int q = 0; q < 5; q++) g[q] = i0 + q < n ? gidx[i0 + q] : INT32_MAX;
+    for (int q = 0; q < 4; q++) g[q + 1] = i0 + q < n ? gidx[i0 + q] : INT32_MAX;
 #pragma unroll
-    for (int q = 0; q < 4; q++)
-      if (i0 + q < n)
-        bad |= (uint32_t)g[q] >= (uint32_t)G || (i0 + q + 1 < n && (STRICT ? g[q] >= g[q + 1] : g[q] > g[q + 1]));
+    for (int q = 3; q >= 0; q--)
+      if (i0 + q < n && ((uint32_t)g[q + 1] >= (uint32_t)G ||
+                         (i0 + q > 0 && (STRICT ? g[q] >= g[q + 1] : g[q] > g[q + 1]))))
+        mine = min(mine, (uint32_t)(i0 + q));
   }
-  return !__syncthreads_or(bad);
+  if (__syncthreads_or(mine != 0xffffffffu)) {
+    if (mine != 0xffffffffu) atomicMin(&s_first_bad, mine);
+    __syncthreads();
+  }
+  return s_first_bad;
+}
+template <bool STRICT>
+__device__ __forceinline__ bool small_batch_ordered(int32_t n, const int32_t* __restrict__ gidx, int32_t G) {
+  return small_batch_first_bad<STRICT>(n, gidx, G) == 0xffffffffu;
 }
 
 template <int KMAX>
@@ -1859,23 +1885,21 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_small(
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
     const int64_t* __restrict__ handle, int32_t refuse) {
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
-  const bool ordered = small_batch_ordered<true>(n, gidx, S.G);
-  if (!ordered) {
+  const uint32_t first_bad = small_batch_first_bad<true>(n, gidx, S.G);
+  if (first_bad != 0xffffffffu && !refuse) { /* no promise: the partition path launched behind takes the whole batch */
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
-    if (i < n) {
-      if (refuse) {
-        o_slot[i] = 0;
-        o_bnum[i] = 0;
-        o_bcoord[i] = 0;
-        o_median[i] = 0;
-        status[i] = GPX_S_UNORDERED;
-      } else {
-        status[i] = (uint32_t)gidx[i] < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
-      }
-    }
+    if (i < n) status[i] = (uint32_t)gidx[i] < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
     return;
   }
   if (i >= n) return;
+  if ((uint32_t)i >= first_bad) { /* GPX_ORDERED_PROPOSE broken: refused from the first violation on (gpx.h) */
+    o_slot[i] = 0;
+    o_bnum[i] = 0;
+    o_bcoord[i] = 0;
+    o_median[i] = 0;
+    status[i] = GPX_S_UNORDERED;
+    return;
+  }
   status[i] = GPX_S_OK;
   const int32_t g = gidx[i];
   ProposePre<KMAX> P;

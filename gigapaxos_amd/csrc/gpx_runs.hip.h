@@ -32,6 +32,7 @@
 #pragma once
 #include "gpx_ar16.hip.h"
 #include "gpx_direct.hip.h"
+#include "gpx_one.hip.h"
 
 #define GPX_RUNS_MAX 16 /* PC.MAX_GROUP_SIZE acceptors: PaxosConfig.java:532 */
 
@@ -278,7 +279,8 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
                                                        const int32_t* __restrict__ acceptor,
                                                        const int32_t* __restrict__ maxcp,
                                                        uint8_t* __restrict__ status, RunsStage st,
-                                                       RunsInfo* __restrict__ info, int32_t refuse) {
+                                                       RunsInfo* __restrict__ info, int32_t refuse, OneCtl C,
+                                                       int32_t* __restrict__ n_out, unsigned long long* __restrict__ acc) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
   __shared__ int32_t wsum[GPX_RBLOCK / 64];
   const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
@@ -287,11 +289,16 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
     /* not a few sorted runs: the partition pipeline launched behind does it - or, under the
      * GPX_ORDERED_REPLY_RUNS promise (no partition pipeline launched), the batch is refused whole */
     if (refuse && i < n && status) status[i] = GPX_S_UNORDERED;
+    if (threadIdx.x == 0) { /* arrive all the same: the counters must be back at zero, and a refused batch has no output */
+      bool any = false;
+      if (one_arrive(C, (int32_t)blockIdx.x, (int32_t)gridDim.x, false, &any) && refuse && n_out) *n_out = 0;
+    }
     return;
   }
   const int32_t R = runs_load(info, n, rs);
   if (i == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
   int32_t local = 0;
+  bool irregular = false; /* this lane saw why the columns are not dense as parked (travels with the arrival counters) */
   const bool active = i < n;
   const int32_t g = active ? gidx[i] : 0;
   int32_t r = 0;
@@ -357,6 +364,7 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
           local = 1;
         } else {
           info->general_used = 1; /* a hole in run 0: the columns are not dense */
+          irregular = true;
         }
         done = true;
       }
@@ -370,6 +378,7 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
     owner = owner && (i == rs[r] || gidx[i - 1] != g);
     if (owner) {
       info->general_used = 1;
+      irregular = true;
       RunsIter it;
       it.gidx = gidx;
       it.bnum = bnum;
@@ -399,12 +408,30 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
   int32_t x = local;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);
-  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = x;
+  const bool wave_irregular = __any(irregular) != 0;
+  if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = x | (wave_irregular ? (int32_t)0x40000000 : 0);
   __syncthreads();
   if (threadIdx.x == 0) {
     int32_t tot = 0;
-    for (int w = 0; w < GPX_RBLOCK / 64; w++) tot += wsum[w];
+    bool wg_irregular = false;
+    for (int w = 0; w < GPX_RBLOCK / 64; w++) {
+      tot += wsum[w] & 0x3fffffff;
+      wg_irregular |= (wsum[w] & 0x40000000) != 0;
+    }
     if (tot) atomicAdd(&st.chunk_cnt[my_chunk], tot);
+    /* the last workgroup to finish publishes the REGULAR batch's count - one decision per record of run 0, dense
+     * as parked - so that no other kernel has to run for it; otherwise -1: k_emit_dec_runs / k_merge_runs follow
+     * (at once, or on gpx_compact_last_dev under GPX_LAZY_OUTPUTS) */
+    bool any = false;
+    if (one_arrive(C, (int32_t)blockIdx.x, (int32_t)gridDim.x, wg_irregular, &any)) {
+      if (any) {
+        if (n_out) *n_out = -1;
+      } else {
+        const int32_t total = runs_len0(info, n);
+        if (n_out) *n_out = total;
+        if (acc) atomicAdd(acc, (unsigned long long)total);
+      }
+    }
   }
 }
 
@@ -412,9 +439,11 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
  * the dense staging block, chunk by chunk in record order */
 __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int32_t n, int32_t nchunks, RunsStage st,
                                                              RunsInfo* __restrict__ info, int32_t* total_out,
-                                                             unsigned long long* acc, int32_t refuse) {
+                                                             unsigned long long* acc, int32_t refuse,
+                                                             int32_t published = 0) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
   const bool unsorted = *X.unsorted == X.epoch, regular = runs_regular(info, n); /* one round trip */
+  if (published && regular && !unsorted) return; /* k_ar_runs' last workgroup has written the count */
   if (unsorted) { /* the partition pipeline (k_emit_dec16) writes the outputs; refused: none */
     if (refuse && blockIdx.x == 0 && threadIdx.x == 0 && total_out) *total_out = 0;
     return;

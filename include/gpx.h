@@ -72,7 +72,7 @@ extern "C" {
 #define GPX_S_EXISTS 6  /* group_create on a live gidx */
 #define GPX_S_BUSY 7    /* group_retire(GPX_RETIRE_PAUSE) on a group that is not
                            caught up (PaxosInstanceStateMachine.java:2004-2035) */
-#define GPX_S_UNORDERED 9 /* the batch broke the gpx_engine_set_ordered_batches promise: refused whole */
+#define GPX_S_UNORDERED 9 /* the batch broke the gpx_engine_set_ordered_batches promise at or before this record: refused */
 #define GPX_S_PREACTIVE 8 /* propose only: the coordinator here is still being elected; the
                             proposal got slot `slot` but no ACCEPT goes out yet
                             (PaxosCoordinatorState.java:254-261) */
@@ -166,14 +166,31 @@ int gpx_engine_sync(gpx_engine* h);
  * applies it without partitioning it; without a promise it also has to launch the partition path,
  * which then returns at once.  With GPX_ORDERED_PROPOSE (gidx in range and strictly ascending: every
  * group at most once) / GPX_ORDERED_ACCEPT / GPX_ORDERED_COMMIT (gidx in range and non-decreasing:
- * the records of a group adjacent, in their order) only the direct path is launched.  The promise is
- * VERIFIED on the device: a batch that breaks it is refused whole - every record gets status
- * GPX_S_UNORDERED, all outputs are zero, n_runs = 0, no state changes - exactly like a lost batch.
+ * the records of a group adjacent, in their order) only the direct path is launched - one kernel per call.
+ * The promise is VERIFIED on the device, inside that kernel: the FIRST VIOLATION of a batch is the first index
+ * that is out of range or whose gidx is lower than (PROPOSE: not higher than) its predecessor's.  The records
+ * before it are applied as usual; the records from it on are refused - status GPX_S_UNORDERED, all their outputs
+ * zero, no state change - exactly like a lost tail of the batch (the caller sends them again, in order).  A group's
+ * records never lie on both sides (equal neighbours are no violation), so no group is applied in part.  (Until
+ * round 4 such a batch was refused whole, which took a launch of its own for the verdict; applying the verified
+ * prefix keeps the guarantee that matters - nothing is applied out of order, nothing silently - without it.)
  * Results of a batch that keeps the promise are identical with and without it.
  */
 #define GPX_ORDERED_PROPOSE 1
 #define GPX_ORDERED_ACCEPT 2
 #define GPX_ORDERED_COMMIT 4
+/*
+ * Output form of the *_dev calls (mask bit, not a promise).  The compacted outputs of a call - execution runs,
+ * decisions - are first PARKED at the indices of the records that produced them; a usual batch leaves them dense
+ * already (every commit executes one slot: run i belongs to record i; ACCEPTs release nothing; every group of a
+ * vote batch decides once), and only an unusual one needs a compaction pass.  By default the engine launches that
+ * pass behind every call (it returns at once for a usual batch) so that the columns are ALWAYS dense and
+ * *n_runs / *n_out >= 0 - at 5-6 us per idle launch.  With GPX_LAZY_OUTPUTS it does not: *n_runs / *n_out < 0
+ * then says "this batch's outputs are still parked" and the caller - who reads the count anyway - calls
+ * gpx_compact_last_dev, which makes the columns of the engine's most recent call dense and rewrites the count
+ * (>= 0).  No other batch call may come in between.  The host-pointer calls do this themselves.
+ */
+#define GPX_LAZY_OUTPUTS 32
 /*
  * Accept replies.  What reaches a coordinator is the concatenation of what each acceptor sent, and an
  * acceptor's replies leave gpx_accept_batch in the order of the ACCEPT batch - grouped by group, groups
@@ -192,6 +209,10 @@ int gpx_engine_sync(gpx_engine* h);
 #define GPX_TRY_REPLY_RUNS 16
 #define GPX_REPLY_RUNS_MAX 16 /* = GPX_KMAX_LIMIT acceptors */
 int gpx_engine_set_ordered_batches(gpx_engine* h, int32_t mask);
+/* GPX_LAZY_OUTPUTS: compacts the outputs of the engine's most recent gpx_accept_batch_dev / gpx_commit_batch_dev /
+ * gpx_accept_reply_batch_dev call in place (the same device columns) and rewrites its count word; a no-op when they
+ * are dense already.  Asynchronous, on the engine's stream. */
+int gpx_compact_last_dev(gpx_engine* h);
 
 /*
  * replaces: PaxosManager.createPaxosInstance(Map nameStates, gms) batch create

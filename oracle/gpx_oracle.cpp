@@ -478,13 +478,15 @@ int orc_engine_set_ordered_batches(gpx_engine* h, int32_t mask) {
   return GPX_OK;
 }
 /* the promise of gpx_engine_set_ordered_batches: gidx in range and ascending (strictly: every group
- * at most once) */
-static bool batch_keeps_order(const Engine* e, int32_t n, const int32_t* gidx, bool strict) {
+ * at most once).  Returns the first index that breaks it - out of range, or a descent (strict: a non-ascent)
+ * INTO it - or n: the records before that index are applied, the records from it on are refused
+ * (GPX_S_UNORDERED), include/gpx.h.  An engine contract, not in the reference. */
+static int32_t batch_first_unordered(const Engine* e, int32_t n, const int32_t* gidx, bool strict) {
   for (int32_t i = 0; i < n; i++) {
-    if (gidx[i] < 0 || gidx[i] >= e->cfg.max_groups) return false;
-    if (i + 1 < n && (strict ? gidx[i] >= gidx[i + 1] : gidx[i] > gidx[i + 1])) return false;
+    if (gidx[i] < 0 || gidx[i] >= e->cfg.max_groups) return i;
+    if (i > 0 && (strict ? gidx[i - 1] >= gidx[i] : gidx[i - 1] > gidx[i])) return i;
   }
-  return true;
+  return n;
 }
 /* the promise GPX_ORDERED_REPLY_RUNS: gidx in range and at most GPX_REPLY_RUNS_MAX non-decreasing runs (the
  * concatenated replies of the acceptors).  GPX_TRY_REPLY_RUNS is only a hint to the engine: nothing to do. */
@@ -683,12 +685,11 @@ int orc_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uin
                         int32_t* median_cp, uint8_t* status) {
   if (!h || n < 0) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);
-  if ((e->ordered_mask & GPX_ORDERED_PROPOSE) && !batch_keeps_order(e, n, gidx, true)) {
-    for (int32_t i = 0; i < n; i++) {
-      slot[i] = bnum[i] = bcoord[i] = median_cp[i] = 0;
-      status[i] = GPX_S_UNORDERED;
-    }
-    return GPX_OK;
+  const int32_t n_all = n;
+  if (e->ordered_mask & GPX_ORDERED_PROPOSE) n = batch_first_unordered(e, n, gidx, true);
+  for (int32_t i = n; i < n_all; i++) {
+    slot[i] = bnum[i] = bcoord[i] = median_cp[i] = 0;
+    status[i] = GPX_S_UNORDERED;
   }
   for (int32_t i = 0; i < n; i++) {
     slot[i] = bnum[i] = bcoord[i] = median_cp[i] = 0;
@@ -775,14 +776,12 @@ int orc_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   if (!h || n < 0) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);
   int32_t runs = 0;
-  if ((e->ordered_mask & GPX_ORDERED_ACCEPT) && !batch_keeps_order(e, n, gidx, false)) {
-    for (int32_t i = 0; i < n; i++) {
-      r_bnum[i] = r_bcoord[i] = r_maxcp[i] = 0;
-      r_flags[i] = 0;
-      status[i] = GPX_S_UNORDERED;
-    }
-    *n_runs = 0;
-    return GPX_OK;
+  const int32_t n_all = n;
+  if (e->ordered_mask & GPX_ORDERED_ACCEPT) n = batch_first_unordered(e, n, gidx, false);
+  for (int32_t i = n; i < n_all; i++) {
+    r_bnum[i] = r_bcoord[i] = r_maxcp[i] = 0;
+    r_flags[i] = 0;
+    status[i] = GPX_S_UNORDERED;
   }
   for (int32_t i = 0; i < n; i++) {
     r_bnum[i] = r_bcoord[i] = r_maxcp[i] = 0;
@@ -931,11 +930,9 @@ int orc_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   if (!h || n < 0) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);
   int32_t runs = 0;
-  if ((e->ordered_mask & GPX_ORDERED_COMMIT) && !batch_keeps_order(e, n, gidx, false)) {
-    for (int32_t i = 0; i < n; i++) status[i] = GPX_S_UNORDERED;
-    *n_runs = 0;
-    return GPX_OK;
-  }
+  const int32_t n_all = n;
+  if (e->ordered_mask & GPX_ORDERED_COMMIT) n = batch_first_unordered(e, n, gidx, false);
+  for (int32_t i = n; i < n_all; i++) status[i] = GPX_S_UNORDERED;
   for (int32_t i = 0; i < n; i++) {
     Group* g = e->get(gidx[i]);
     if (!g) {

@@ -22,7 +22,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from gigapaxos_amd import (Engine, hri_create, load_hip, S_OK, C_HASVALUE, ORDERED_PROPOSE,  # noqa: E402
-                           ORDERED_ACCEPT, ORDERED_COMMIT, ORDERED_REPLY_RUNS)
+                           ORDERED_ACCEPT, ORDERED_COMMIT, ORDERED_REPLY_RUNS, LAZY_OUTPUTS)
 
 
 def main():
@@ -38,6 +38,9 @@ def main():
     ap.add_argument("--no-promise", action="store_true",
                     help="do not declare the batches ordered (gpx_engine_set_ordered_batches): the engine then "
                          "also launches the partition path, which returns at once")
+    ap.add_argument("--dense-always", action="store_true",
+                    help="do not set GPX_LAZY_OUTPUTS: the compaction pass is launched behind every call (it finds "
+                         "nothing to do in these rounds); default: lazy, the counts are read once per round anyway")
     args = ap.parse_args()
     G, K = args.groups, 3
     ids = [100, 101, 102]
@@ -52,7 +55,8 @@ def main():
         e.set_stream(ts.cuda_stream)
         if not args.no_promise and not args.unordered:  # every batch here is the previous stage's output: grouped by group
             e.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT |
-                                  (0 if args.shuffled_replies else ORDERED_REPLY_RUNS))
+                                  (0 if args.shuffled_replies else ORDERED_REPLY_RUNS) |
+                                  (0 if args.dense_always else LAZY_OUTPUTS))
         eng[nid] = e
     i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
     u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)  # noqa: E731
@@ -132,6 +136,7 @@ def main():
             kern[name] = kern.get(name, 0.0) + ms * 1e3 / max(args.profile_rounds, 1)
     tot = sum(t.values()) / k
     print(json.dumps({"groups": G, "replicas": K, "ordered_batches_promise": not args.no_promise and not args.unordered,
+                      "lazy_outputs": not args.dense_always and not args.no_promise and not args.unordered,
                       "acceptor_batches": "unordered" if args.unordered else "grouped by group",
                       "replies": "shuffled" if (args.shuffled_replies or args.unordered) else "three ascending runs",
                       "ms_per_round": round(tot, 4),

@@ -4,7 +4,7 @@ same inputs; the first call whose results differ is reported with the records of
 records of that group, and both engines' gpx_group_dump of it.  Not a test: tests compare the engine with the Python
 readings; this finds WHERE the engine leaves the oracle when such a comparison has failed.
 
-  python scripts/debug/tee_engines.py wrap 0        # tests/test_pending_gpu.py::test_whole_round_across_the_int_wrap case 0
+  python scripts/debug/tee_engines.py wrap 0        # tests/test_acc_enum_gpu.py::test_whole_round_across_the_int_wrap case 0
 """
 import dataclasses
 import os

@@ -172,6 +172,98 @@ __global__ __launch_bounds__(NT) void k_scatter_sorted(int n, int shift, int nbk
   const int nt = min(T, n - tile * T);
   for (int j = threadIdx.x; j < nt; j += NT) { V16 r = recs[j]; const int b = r.idx >> 13; r.idx = tile * T + (r.idx & 8191); out[cnt[b] + j] = r; }
 }
+
+// ---- D (round 4, VERDICT r3 item 5 "C'"): NO histogram pass and NO reservation at all.  One workgroup sorts T
+// votes by bucket in LDS (counting sort on 8-byte records {tile offset | local group | escape, slot delta | cp delta |
+// acceptor delta}) and writes the run of every bucket into a FIXED slot of SLOT records owned by (bucket, workgroup):
+// slot address = ((b * nwg + w) * SLOT) records.  Lanes write the sorted tile in order, so a run leaves as one or
+// two full 64-byte lines; a count byte per (bucket, workgroup) goes to cntm[b][w]; records that do not fit their slot
+// go to an overflow list (returning atomic: rare for any stream that is not skewed).  The per-bucket kernel would
+// read its nwg counts (coalesced), scan them and fetch exactly the used records: k_read_slots below does that
+// (sum of the payload words per bucket, as a stand-in for the regrouping) to time the read side as well.
+struct __attribute__((aligned(8))) V8 { uint32_t a, b; };
+template <int T, int SLOT>
+__global__ __launch_bounds__(NT) void k_scatter_slots(int n, int shift, int nbk, int nwg, const int* __restrict__ gidx,
+    const int* __restrict__ c1, const int* __restrict__ c2, const int* __restrict__ c3, const int* __restrict__ c4,
+    const int* __restrict__ c5, V8* out, uint8_t* __restrict__ cntm, V16* __restrict__ ovf, int* __restrict__ ovf_n,
+    uint8_t* __restrict__ status) {
+  extern __shared__ int lds[];
+  constexpr int R4 = T / (NT * 4);
+  int* cnt = lds;                        // [nbk] count -> local base
+  V8* recs = (V8*)(lds + ((nbk + 3) & ~3));
+  const int w = tile_of_block(nwg); if (w >= nwg) return;
+  for (int b = threadIdx.x; b < nbk; b += NT) cnt[b] = 0;
+  __syncthreads();
+  int rk[R4 * 4], bb[R4 * 4];
+#pragma unroll
+  for (int k = 0; k < R4; k++) { const long i0 = (long)w * T + (k * NT + threadIdx.x) * 4;
+    if (i0 + 3 < n) { const I4 g = *(const I4*)(gidx + i0); const int gg[4] = {g.x, g.y, g.z, g.w};
+      *(uint32_t*)(status + i0) = 0u;    // status prefill (k_hist's job today)
+#pragma unroll
+      for (int q = 0; q < 4; q++) { bb[k * 4 + q] = gg[q] >> shift; rk[k * 4 + q] = atomicAdd(&cnt[bb[k * 4 + q]], 1); } }
+    else { for (int q = 0; q < 4; q++) { bb[k * 4 + q] = -1; if (i0 + q < n) { status[i0 + q] = 0; bb[k * 4 + q] = gidx[i0 + q] >> shift; rk[k * 4 + q] = atomicAdd(&cnt[bb[k * 4 + q]], 1); } } } }
+  __syncthreads();
+  // exclusive scan of the counts -> local bases; the count matrix row of this workgroup
+  const int per = (nbk + NT - 1) / NT; const int b0 = threadIdx.x * per; int v[4]; int s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) { v[q] = (q < per && b0 + q < nbk) ? cnt[b0 + q] : 0; s += v[q]; }
+  int tot; int ex = block_exscan(s, &tot);
+#pragma unroll
+  for (int q = 0; q < 4; q++) if (q < per && b0 + q < nbk) { cnt[b0 + q] = ex; ex += v[q]; cntm[(long)(b0 + q) * nwg + w] = (uint8_t)min(v[q], 255); }
+  __syncthreads();
+  const int mask = (1 << shift) - 1;
+#pragma unroll
+  for (int k = 0; k < R4; k++) { const long i0 = (long)w * T + (k * NT + threadIdx.x) * 4;
+    if (i0 + 3 < n) {
+      const I4 g = *(const I4*)(gidx + i0), a = *(const I4*)(c1 + i0), b = *(const I4*)(c2 + i0), c = *(const I4*)(c3 + i0), d = *(const I4*)(c4 + i0), e = *(const I4*)(c5 + i0);
+      const int gg[4] = {g.x, g.y, g.z, g.w}, aa[4] = {a.x, a.y, a.z, a.w}, b2[4] = {b.x, b.y, b.z, b.w}, cc[4] = {c.x, c.y, c.z, c.w}, dd[4] = {d.x, d.y, d.z, d.w}, ee[4] = {e.x, e.y, e.z, e.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) { V8 r; const uint32_t off = (uint32_t)(i0 + q - (long)w * T);
+        const uint32_t dslot = (uint32_t)(cc[q] - 7), dcp = (uint32_t)(cc[q] - 1 - ee[q]), dacc = (uint32_t)(dd[q] - 100);
+        const bool esc = aa[q] != 0 || b2[q] != 100 || dslot > 255u || dcp > 255u || dacc > 255u;
+        r.a = off | ((uint32_t)(gg[q] & mask) << 14) | (esc ? 0x80000000u : 0u) | ((uint32_t)bb[k * 4 + q] << 24 & 0u);
+        r.b = (dslot & 255u) | ((dcp & 255u) << 8) | ((dacc & 255u) << 16);
+        recs[cnt[bb[k * 4 + q]] + rk[k * 4 + q]] = r; (void)r; } }
+    else for (int q = 0; q < 4; q++) if (i0 + q < n) { V8 r; r.a = (uint32_t)(i0 + q - (long)w * T) | ((uint32_t)(gidx[i0 + q] & mask) << 14); r.b = 0;
+        recs[cnt[bb[k * 4 + q]] + rk[k * 4 + q]] = r; } }
+  __syncthreads();
+  // the sorted tile leaves in order: lane j of the tile owns sorted record j; its bucket = upper bound over the bases
+  // (the record does not carry it: 8 bytes are full) - found with the rank it was written at: walk per BUCKET instead:
+  // thread t copies the runs of buckets b0 .. b0 + per - 1 ... would be uncoalesced; instead every 8 lanes take one
+  // bucket (one 64-byte line per step)
+  const int nt = min(T, n - w * T); (void)nt;
+  for (int b = threadIdx.x >> 3; b < nbk; b += NT >> 3) {
+    const int base = cnt[b]; const int c = (b + 1 < nbk ? cnt[b + 1] : tot) - base;
+    V8* slot = out + ((long)b * nwg + w) * SLOT;
+    for (int j = threadIdx.x & 7; j < c; j += 8) {
+      if (j < SLOT) slot[j] = recs[base + j];
+      else { const int p = atomicAdd(ovf_n, 1); V16 o; o.idx = w * T + (int)(recs[base + j].a & 16383u); o.slot = b; o.cp = (int)recs[base + j].b; o.meta = recs[base + j].a; ovf[p] = o; }
+    }
+  }
+}
+// read side of D: bucket b reads its nwg counts, scans them, fetches exactly the used records (8 lanes per slot)
+template <int SLOT>
+__global__ __launch_bounds__(512) void k_read_slots(int nbk, int nwg, const V8* __restrict__ in, const uint8_t* __restrict__ cntm, unsigned long long* sink) {
+  __shared__ unsigned int acc;
+  const int b = blockIdx.x; if (threadIdx.x == 0) acc = 0; __syncthreads();
+  unsigned int x = 0;
+  for (int w = threadIdx.x >> 3; w < nwg; w += 512 >> 3) {
+    const int c = min((int)cntm[(long)b * nwg + w], SLOT);
+    const V8* slot = in + ((long)b * nwg + w) * SLOT;
+    for (int j = threadIdx.x & 7; j < c; j += 8) { const V8 r = slot[j]; x += r.a ^ r.b; }
+  }
+  atomicAdd(&acc, x); __syncthreads();
+  if (threadIdx.x == 0) sink[b] = acc;
+}
+// ... and of the 16-byte records the engine reads today: bucket b reads its contiguous region
+__global__ __launch_bounds__(512) void k_read_region(int nbk, const int* __restrict__ boff, const V16* __restrict__ in, unsigned long long* sink) {
+  __shared__ unsigned int acc;
+  const int b = blockIdx.x; if (threadIdx.x == 0) acc = 0; __syncthreads();
+  unsigned int x = 0;
+  for (int j = boff[b] + threadIdx.x; j < boff[b + 1]; j += 512) { const V16 r = in[j]; x += r.idx ^ r.slot ^ r.cp ^ r.meta; }
+  atomicAdd(&acc, x); __syncthreads();
+  if (threadIdx.x == 0) sink[b] = acc;
+}
 // store cost alone: 16-byte writes at precomputed positions
 __global__ void k_write16(int n, const int* __restrict__ pos, V16* out) { const int i0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
   if (i0 + 3 < n) { const I4 p = *(const I4*)(pos + i0); const int pp[4] = {p.x, p.y, p.z, p.w}; for (int q = 0; q < 4; q++) { V16 v; v.idx = i0 + q; v.slot = 1; v.cp = 2; v.meta = 3; out[pp[q]] = v; } } }
@@ -245,6 +337,26 @@ int main() {
         hipMemsetAsync(bad, 0, 4); k_check<<<(n + 255) / 256, 256>>>(n, shift, nbk, boff, gidx, out, bad);
         int hb2 = -1; hipMemcpy(&hb2, bad, 4, hipMemcpyDeviceToHost); if (hb2) printf("   !! %d misplaced votes\n", hb2); };
       runC(k_scatter_sorted<4096>, 4096, "4096"); runC(k_scatter_sorted<8192>, 8192, "8192");
+    }
+
+    { // D: slotted scatter, no histogram
+      static V8* out8 = nullptr; static uint8_t *cntm = nullptr, *stat = nullptr; static V16* ovf = nullptr; static int* ovf_n = nullptr; static unsigned long long* sink = nullptr;
+      if (!out8) { CK(hipMalloc(&out8, (size_t)4096 * 512 * 32 * 8)); CK(hipMalloc(&cntm, (size_t)4096 * 512)); CK(hipMalloc(&stat, n)); CK(hipMalloc(&ovf, (size_t)n * 16)); CK(hipMalloc(&ovf_n, 4)); CK(hipMalloc(&sink, 8192 * 8)); }
+      auto runD = [&](auto kern, auto rkern, int T, int SLOT, const char* tag) {
+        const int nwg = (n + T - 1) / T; const size_t sh = (size_t)((nbk + 3) & ~3) * 4 + (size_t)T * 8;
+        hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)sh);
+        const int g = 8 * ((nwg + 7) / 8);
+        snprintf(nm, 160, "D shift %2d nbk %4d: k_scatter_slots<%s> (%zu KB LDS, %d workgroups)", shift, nbk, tag, sh >> 10, nwg);
+        timeit(nm, [&] { hipMemsetAsync(ovf_n, 0, 4); }, [&] { kern<<<g, NT, sh>>>(n, shift, nbk, nwg, gidx, c1, c2, c3, c4, c5, out8, cntm, ovf, ovf_n, stat); });
+        int ho = -1; hipMemcpy(&ho, ovf_n, 4, hipMemcpyDeviceToHost); printf("      overflow records: %d of %d; slot area %.1f MB\n", ho, n, (double)nbk * nwg * SLOT * 8 / 1e6);
+        snprintf(nm, 160, "D shift %2d nbk %4d: k_read_slots<%s> (the per-bucket kernel's loads)", shift, nbk, tag);
+        timeit(nm, [] {}, [&] { rkern<<<nbk, 512>>>(nbk, nwg, out8, cntm, sink); }); };
+      runD(k_scatter_slots<16384, 16>, k_read_slots<16>, 16384, 16, "16384, 16");
+      runD(k_scatter_slots<16384, 24>, k_read_slots<24>, 16384, 24, "16384, 24");
+      runD(k_scatter_slots<8192, 16>, k_read_slots<16>, 8192, 16, "8192, 16");
+      runD(k_scatter_slots<12288, 16>, k_read_slots<16>, 12288, 16, "12288, 16");
+      snprintf(nm, 160, "  shift %2d nbk %4d: k_read_region (16-byte records, today's loads)", shift, nbk);
+      timeit(nm, [] {}, [&] { k_read_region<<<nbk, 512>>>(nbk, boff, out, sink); });
     }
     for (int hsub : {1, 3}) {
       const int nsuper = (ntiles + hsub - 1) / hsub; const int hg = 8 * ((nsuper + 7) / 8);

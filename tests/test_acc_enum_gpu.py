@@ -87,3 +87,63 @@ def test_view_change_after_lossy_rounds_against_java_reading_on_engine(hip_lib, 
     assert run_rounds.after > G * 6
     elected, accepts, carried, noops = run_rounds.failover
     assert elected > G // 5 and carried > G // 8 and accepts == (carried + noops) * (K - 1)
+
+
+# ---- round 4: the legs staged at the end of round 3 (tests/test_pending_gpu.py then), first run on a GPU in round 4.
+# They found two places where the engine left the Java at the int wrap (gap scan's lastKey(), garbageCollectDecisions
+# under a median half the int range behind: gpx_kernels.hip.h k_gap_scan / acc_gc) - fixed, now regular cases.
+
+@pytest.mark.parametrize("G,rounds,seed,p_drop,K,p_rival,p_stop,failover", [
+    (20_000, 14, 82, 0.15, 3, 0.03, 0.0, False), (12_000, 12, 84, 0.1, 4, 0.0, 0.0, True), (12_000, 12, 81, 0.1, 3, 0.0, 0.0, False)])
+def test_pause_and_hot_restore_between_rounds(hip_lib, G, rounds, seed, p_drop, K, p_rival, p_stop, failover):
+    """tests/test_oracle_kat.py::test_pause_and_hot_restore_between_rounds_against_java_reading on the engine
+    (PaxosInstanceStateMachine.java:677-690, 2004-2035; HotRestoreInfo.java:145-157; pokes, repeated PREPARE_REPLYs)"""
+    from tests.round_model import run_rounds
+    run_rounds(hip_lib, G, rounds, seed, p_drop=p_drop, K=K, p_rival=p_rival, p_stop=p_stop, from_disk=seed % 2 == 0,
+               failover=failover, rounds_after=6 if failover else 0, p_pause=0.15, pokes=True, p_dup_reply=0.3)
+    assert run_rounds.busy > G and run_rounds.paused > (G if seed % 2 == 0 else 0)
+
+
+@pytest.mark.parametrize("K,kw", [(1, dict()), (2, dict(p_rival=0.03)), (2, dict(failover=True, rounds_after=6)), (16, dict(p_rival=0.02))])
+def test_whole_round_with_unusual_group_sizes(hip_lib, K, kw):
+    """tests/test_oracle_kat.py::test_whole_round_with_unusual_group_sizes on the engine: K = 1, 2 and
+    PaxosConfig.java:532's MAX_GROUP_SIZE = 16 (WaitforUtility.java:64-68)"""
+    from tests.round_model import run_rounds
+    checked, executed = run_rounds(hip_lib, 6000, 14, 90 + K, p_drop=0.12, K=K, from_disk=True, p_pause=0.1, pokes=True, **kw)
+    assert checked > 400_000
+
+
+def test_accept_replies_with_checkpoint_slots_half_the_int_range_apart(hip_lib):
+    """recordSlotNumber's plain < (PCS:809-825) under checkpoint slots near INT_MIN / INT_MAX, any vote order"""
+    from tests.pcs_enum_common import run_streams
+    for K, nprop, G, nv in ((3, 3, 50_000, 24), (5, 4, 25_000, 40), (4, 2, 25_000, 16)):
+        assert run_streams(hip_lib, K, nprop, G, nv, seed=K * 100 + nprop + 9, p_extreme=0.1) == G
+        for base in (2**31 - 3, 2**31 - 1):      # coordinators whose proposals cross Integer.MAX_VALUE
+            assert run_streams(hip_lib, K, nprop, G // 2, nv, seed=K * 100 + nprop + 11, p_extreme=0.05, base=base) == G // 2
+
+
+@pytest.mark.parametrize("base", [2**31 - 3, 2**31 - 1, -2**31 + 1])
+def test_acceptor_side_at_the_int_wrap(hip_lib, base):
+    """tests/test_oracle_kat.py::test_acceptor_side_at_the_int_wrap_against_java_reading on the engine, more sequences
+    (PaxosAcceptor.java:315, 341, 415-416, 481-489)"""
+    import numpy as np
+    import tests.acc_enum_common as A
+    rng = np.random.default_rng(base % 1000)
+    for L, count in ((2, None), (4, 60_000), (8, 40_000)):
+        seqs = ([(a, b) for a in A.WIDE for b in A.WIDE[::2]] if count is None else
+                [tuple(A.WIDE[i] for i in row) for row in rng.integers(0, len(A.WIDE), (count, L)).tolist()])
+        for order, init in (("interleaved", "create"), ("grouped", "initial")):
+            A.run_sequences(hip_lib, seqs, init=init, order=order, base=base)
+
+
+@pytest.mark.parametrize("base,K,kw", [(2**31 - 6, 3, dict()), (2**31 - 20, 3, dict(p_rival=0.03)), (2**31 - 10, 3, dict(p_stop=0.02, from_disk=False)),
+                                       (2**31 - 12, 5, dict(p_pause=0.15, pokes=True))])
+def test_whole_round_across_the_int_wrap(hip_lib, base, K, kw):
+    """tests/test_oracle_kat.py::test_whole_round_across_the_int_wrap on the engine.  Case 0 is the one that found
+    garbageCollectDecisions: the first slot's ACCEPT (median 0) retransmitted after the slots wrapped drops the
+    committed slot -2^31 + 1 in the Java (0 - key > 0), and so must the engine."""
+    from tests.round_model import run_rounds
+    kw = dict(kw)
+    kw.setdefault("from_disk", True)
+    checked, executed = run_rounds(hip_lib, 10_000, 16, 7, p_drop=0.12, K=K, base=base, **kw)
+    assert checked > 1_000_000

@@ -51,3 +51,9 @@ def test_failover_end_to_end_parity(hip_lib, oracle_lib, G, seed, window):
     assert a.keys() == b.keys()
     for key in a:
         assert a[key] == b[key], key
+
+
+def test_election_begin_sequences_against_java_reading(hip_lib):
+    """makeCoordinator's begin sequences (PaxosInstanceStateMachine.java:2090-2279) against the Python reading"""
+    from tests import test_election_oracle as T
+    T.test_election_begin_sequences_against_java_reading(hip_lib)

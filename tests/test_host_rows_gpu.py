@@ -37,3 +37,11 @@ def test_election_scan_known_answer(hip_lib):
 @pytest.mark.parametrize("seed", [0, 1])
 def test_election_scan_matches_oracle(hip_lib, oracle_lib, seed):
     assert H.election_run(hip_lib, seed) == H.election_run(oracle_lib, seed)
+
+
+def test_request_batcher_and_election_scan_against_java_reading(hip_lib):
+    """the Python readings of RequestBatcher.dequeueImpl (RequestBatcher.java:182-239) and checkRunForCoordinator
+    (PaxosInstanceStateMachine.java:2090-2279) on the engine"""
+    from tests import test_host_rows_oracle as T
+    T.test_request_batcher_random_bursts_against_java_reading(hip_lib)
+    T.test_election_scan_random_groups_against_java_reading(hip_lib)

@@ -1,0 +1,220 @@
+"""Ordered batches in ONE launch (gpx_one.hip.h, round 4): the order check travels inside the work kernel as a
+look-back over per-workgroup words, a broken promise refuses the batch from its first violation on, and the
+compaction pass of an unusual batch runs only when it is needed (GPX_LAZY_OUTPUTS / gpx_compact_last_dev).
+Engine against the oracle on batches of more than 65,536 records - the one-launch kernels' regime."""
+import numpy as np
+import pytest
+
+from gigapaxos_amd import (Engine, hri_create, S_OK, S_UNORDERED, ORDERED_PROPOSE, ORDERED_ACCEPT, ORDERED_COMMIT,
+                           ORDERED_REPLY_RUNS, LAZY_OUTPUTS, C_HASVALUE, streams)
+from tests.parity_common import make_pair, assert_same_state, create_mixed_groups, fuzz
+
+pytestmark = pytest.mark.gpu
+NODES = [100, 101, 102]
+
+
+@pytest.mark.parametrize("seed,G,batch", [(41, 150_000, 220_000), (42, 70_000, 400_000)])
+def test_large_ordered_batches_under_the_promise(hip_lib, oracle_lib, seed, G, batch):
+    """parity_common.fuzz with grouped batches of up to `batch` records under PROPOSE | ACCEPT | COMMIT: k_propose_one /
+    k_ac_one for the batches above 65,536 records, k_*_small below; one batch in eight carries an index out of range
+    (refused from there on), runs of several records per group, commits that execute nothing or several slots."""
+    rng = np.random.default_rng(seed)
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, 3, 64, max_batch=batch + 64)
+    create_mixed_groups(eh, eo, G, 3, NODES, rng)
+    for e in (eh, eo):
+        e.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT)
+    fuzz(eh, eo, G, NODES, rng, steps=36, batch=batch, ordered=True)
+    assert_same_state(eh, eo, rng.integers(0, G, 400))
+    assert eh.counters() == eo.counters()
+    eh.close(), eo.close()
+
+
+@pytest.mark.parametrize("where", ["descent", "out of range", "repeated group", "first record", "last record"])
+def test_broken_promise_refuses_from_the_first_violation(hip_lib, oracle_lib, where):
+    """One violation planted in a batch of 300,000 grouped records: everything before it is applied, everything from it
+    on carries GPX_S_UNORDERED and zero outputs - ACCEPT, COMMIT and PROPOSE, engine and oracle alike."""
+    G, n = 200_000, 300_000
+    rng = np.random.default_rng(len(where))
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, 3, 8, max_batch=n + 64)
+    mem = np.tile(np.array(NODES, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, 3, hri_create(G, 3, 100)) == S_OK).all()
+        e.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT)
+    g = np.sort(rng.integers(0, G, n)).astype(np.int32)
+    v = {"first record": 0, "last record": n - 1}.get(where, int(rng.integers(70_000, n - 70_000)))
+    if where == "descent":
+        g[v] = g[v - 1] - 1
+    elif where == "repeated group":      # the group of record v - 3000 comes again after other groups
+        g[v] = g[v - 3000]
+        assert g[v] < g[v - 1]
+    else:
+        g[v] = G + 3 if where != "first record" else -1
+    first = int(np.nonzero((g < 0) | (g >= G) | np.concatenate([[False], np.diff(g) < 0]))[0][0])
+    # ACCEPT: slots 1, 2, .. per group in array order
+    slot = np.ones(n, np.int32)
+    same = np.concatenate([[False], g[1:] == g[:-1]])
+    run = np.zeros(n, np.int64)
+    for i in np.nonzero(same)[0]:
+        run[i] = run[i - 1] + 1
+    slot += run.astype(np.int32)
+    z = np.zeros(n, np.int32)
+    bc = np.full(n, 100, np.int32)
+    out = []
+    for e in (eh, eo):
+        (rb, rc, rm, rf, st), runs = e.accept(g, z, bc, slot, z)
+        assert (st[first:] == S_UNORDERED).all() and not (st[:first] == S_UNORDERED).any()
+        assert not rb[first:].any() and not rc[first:].any() and not rf[first:].any()
+        st2, runs2 = e.commit(g, z, bc, slot, z)
+        assert (st2[first:] == S_UNORDERED).all() and not (st2[:first] == S_UNORDERED).any()
+        gp = np.unique(g[(g >= 0) & (g < G)])
+        if where == "descent":
+            gp = np.concatenate([gp[:1000], gp[999:2000]])       # a non-ascent for the strict promise
+        pr = e.propose(gp.astype(np.int32))
+        out.append([x.tolist() for x in (rb, rc, rm, rf, st, runs.as_tuple_array(), st2, runs2.as_tuple_array()) + tuple(pr)])
+    assert out[0] == out[1]
+    assert_same_state(eh, eo, np.concatenate([rng.integers(0, G, 300), g[max(0, v - 3):v + 3].clip(0, G - 1)]))
+    assert eh.counters() == eo.counters()
+    eh.close(), eo.close()
+
+
+def _dev(torch, a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_lazy_outputs_on_the_device_path(hip_lib, oracle_lib):
+    """GPX_LAZY_OUTPUTS through the *_dev calls: a usual batch comes back dense with its count and no compaction kernel
+    runs (the engine's launch profile says so); an unusual one comes back with a negative count and
+    gpx_compact_last_dev makes it the oracle's."""
+    import torch
+    G = 200_000
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, 3, 8, max_batch=3 * G + 64)
+    mem = np.tile(np.array(NODES, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, 3, hri_create(G, 3, 100)) == S_OK).all()
+    eh.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT | ORDERED_REPLY_RUNS | LAZY_OUTPUTS)
+    eo.set_ordered_batches(ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT | ORDERED_REPLY_RUNS)
+    g = np.arange(G, dtype=np.int32)
+    z, bc = np.zeros(G, np.int32), np.full(G, 100, np.int32)
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device="cuda")  # noqa: E731
+    u8 = lambda n: torch.zeros(n, dtype=torch.uint8, device="cuda")  # noqa: E731
+    P = lambda t: t.data_ptr()  # noqa: E731
+
+    def accept_dev(gg, slot, median):
+        n = gg.shape[0]
+        cols = [_dev(torch, c) for c in (gg, np.zeros(n, np.int32), np.full(n, 100, np.int32), slot, median)]
+        fl = u8(n)
+        o = [i32(n) for _ in range(3)] + [u8(n), u8(n)] + [i32(n) for _ in range(3)] + [i32(1)]
+        eh.call_dev("accept_batch", n, *[P(c) for c in cols], P(fl), *[P(t) for t in o])
+        torch.cuda.synchronize()
+        return o
+
+    def commit_dev(gg, slot, median, kind):
+        n = gg.shape[0]
+        cols = [_dev(torch, c) for c in (gg, np.zeros(n, np.int32), np.full(n, 100, np.int32), slot, median)]
+        o = [u8(n)] + [i32(n) for _ in range(3)] + [i32(1)]
+        eh.call_dev("commit_batch", n, *[P(c) for c in cols], P(_dev(torch, kind)), *[P(t) for t in o])
+        torch.cuda.synchronize()
+        return o
+
+    def runs_of(o, k):
+        m = int(o[-1].item())
+        return np.stack([o[k].cpu().numpy()[:m], o[k + 1].cpu().numpy()[:m], o[k + 2].cpu().numpy()[:m]], axis=1)
+
+    eh.profile(2)
+    # 1) usual ACCEPT batch: nothing released, count 0, no compaction launched
+    o = accept_dev(g, np.ones(G, np.int32), z)
+    (rb, rc, rm, rf, st), runs = eo.accept(g, z, bc, np.ones(G, np.int32), z)
+    assert int(o[-1].item()) == 0 and runs.gidx.shape[0] == 0
+    assert (o[0].cpu().numpy() == rb).all() and (o[2].cpu().numpy() == rm).all() and (o[4].cpu().numpy() == st).all()
+    # 2) usual COMMIT batch: one run per record, dense as parked
+    kind = np.full(G, C_HASVALUE, np.uint8)
+    o = commit_dev(g, np.ones(G, np.int32), z, kind)
+    st2, runs2 = eo.commit(g, z, bc, np.ones(G, np.int32), z, kind)
+    assert int(o[-1].item()) == G and (runs_of(o, 1) == runs2.as_tuple_array()).all() and (o[0].cpu().numpy() == st2).all()
+    prof = eh.profile_read()
+    assert "k_ac_one" in prof and "k_emit_runs_direct" not in prof and "k_copy_runs" not in prof and "k_order_check" not in prof, prof
+    # 3) unusual COMMIT batch: slot 3 before slot 2 for a third of the groups (executes nothing), slot 2 for the rest
+    sl = np.where(g % 3 == 0, 3, 2).astype(np.int32)
+    o = commit_dev(g, sl, z, kind)
+    st3, runs3 = eo.commit(g, z, bc, sl, z, kind)
+    assert int(o[-1].item()) < 0
+    eh.compact_last_dev()
+    torch.cuda.synchronize()
+    assert int(o[-1].item()) == runs3.gidx.shape[0] and (runs_of(o, 1) == runs3.as_tuple_array()).all()
+    assert (o[0].cpu().numpy() == st3).all()
+    # 4) ... and the missing slot 2 arrives for those groups: two slots execute per commit
+    gg = g[g % 3 == 0]
+    o = commit_dev(gg, np.full(gg.shape[0], 2, np.int32), np.zeros(gg.shape[0], np.int32), kind[:gg.shape[0]])
+    st4, runs4 = eo.commit(gg, np.zeros(gg.shape[0], np.int32), np.full(gg.shape[0], 100, np.int32),
+                           np.full(gg.shape[0], 2, np.int32), np.zeros(gg.shape[0], np.int32), kind[:gg.shape[0]])
+    if gg.shape[0] > 65536:   # one run per record: REGULAR whatever the run's length
+        assert int(o[-1].item()) == gg.shape[0]
+    else:
+        assert int(o[-1].item()) >= 0
+    assert (runs_of(o, 1) == runs4.as_tuple_array()).all() and (runs4.count == 2).all()
+    # 5) unusual ACCEPT batch: placeholders (commits without value) wait for their ACCEPTs, which then release them
+    ph = np.zeros(G, np.uint8)
+    o = commit_dev(g, np.full(G, 4, np.int32), z, ph)
+    st5, runs5 = eo.commit(g, z, bc, np.full(G, 4, np.int32), z, ph)
+    assert int(o[-1].item()) < 0
+    eh.compact_last_dev()
+    torch.cuda.synchronize()
+    assert int(o[-1].item()) == 0 and runs5.gidx.shape[0] == 0
+    o = accept_dev(g, np.full(G, 4, np.int32), z)
+    (rb, rc, rm, rf, st6), runs6 = eo.accept(g, z, bc, np.full(G, 4, np.int32), z)
+    assert int(o[-1].item()) < 0
+    eh.compact_last_dev()
+    torch.cuda.synchronize()
+    assert (runs_of(o, 5) == runs6.as_tuple_array()).all() and runs6.gidx.shape[0] > G // 4
+    assert (o[4].cpu().numpy() == st6).all() and (o[3].cpu().numpy() == rf).all()
+    assert_same_state(eh, eo, np.random.default_rng(5).integers(0, G, 300))
+    assert eh.counters() == eo.counters()
+    eh.close(), eo.close()
+
+
+@pytest.mark.parametrize("K", [3, 5])
+def test_lazy_reply_runs(hip_lib, oracle_lib, K):
+    """Accept replies as K ascending runs under ORDERED_REPLY_RUNS | LAZY_OUTPUTS: the regular round's count is
+    published by k_ar_runs itself; a round with lost votes comes back negative and is compacted on demand."""
+    import torch
+    G = 150_000
+    members = list(range(100, 100 + K))
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, K, 8, max_batch=K * G + 64)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, K, hri_create(G, K, 100)) == S_OK).all()
+    eh.set_ordered_batches(ORDERED_PROPOSE | ORDERED_REPLY_RUNS | LAZY_OUTPUTS)
+    eo.set_ordered_batches(ORDERED_PROPOSE | ORDERED_REPLY_RUNS)
+    g = np.arange(G, dtype=np.int32)
+    P = lambda t: t.data_ptr()  # noqa: E731
+    rng = np.random.default_rng(K)
+    for r in range(4):
+        for x, y in zip(eh.propose(g), eo.propose(g)):
+            assert (x == y).all()
+        cols = streams.vote_round_runs(G, members, r, 100, config_id=3)
+        if r % 2 == 1:     # lost votes: some groups do not decide, some runs are shorter than others
+            keep = rng.random(cols[0].shape[0]) > 0.2
+            cols = [np.ascontiguousarray(c[keep]) for c in cols]
+        n = cols[0].shape[0]
+        d = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(5)] + [torch.zeros(n, dtype=torch.uint8, device="cuda")]
+        no, st = torch.zeros(1, dtype=torch.int32, device="cuda"), torch.zeros(n, dtype=torch.uint8, device="cuda")
+        dc = [_dev(torch, c) for c in cols]
+        eh.profile(2)
+        eh.call_dev("accept_reply_batch", n, *[P(c) for c in dc], *[P(t) for t in d], P(no), P(st))
+        torch.cuda.synchronize()
+        prof = eh.profile_read()
+        assert "k_emit_dec_runs" not in prof and "k_merge_runs" not in prof, prof
+        do = eo.accept_reply(*cols)
+        if r % 2 == 0:
+            assert int(no.item()) == G
+        else:
+            assert int(no.item()) < 0
+            eh.compact_last_dev()
+            torch.cuda.synchronize()
+        m = int(no.item())
+        got = np.stack([t.cpu().numpy()[:m].astype(np.int32) for t in d], axis=1)
+        assert got.shape == do.as_tuple_array().shape and (got == do.as_tuple_array()).all(), f"round {r}"
+        assert (st.cpu().numpy() == do.status).all()
+    assert_same_state(eh, eo, rng.integers(0, G, 300))
+    assert eh.counters() == eo.counters()
+    eh.close(), eo.close()

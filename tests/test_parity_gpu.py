@@ -47,8 +47,8 @@ def test_fuzz_ordered_batches(hip_lib, oracle_lib, kmax, G, seed):
 
 def test_ordered_batches_promise(hip_lib, oracle_lib):
     """gpx_engine_set_ordered_batches: with the promise only the direct path is launched; a batch
-    that keeps it gives the usual answers, one that breaks it is refused whole (GPX_S_UNORDERED, no
-    state change) - engine and oracle alike."""
+    that keeps it gives the usual answers, one that breaks it is applied up to its first violation and refused from
+    there on (GPX_S_UNORDERED, no state change) - engine and oracle alike."""
     from gigapaxos_amd import ORDERED_PROPOSE, ORDERED_ACCEPT, ORDERED_COMMIT, S_UNORDERED
     rng = np.random.default_rng(31)
     G, kmax = 900, 3
@@ -65,14 +65,18 @@ def test_ordered_batches_promise(hip_lib, oracle_lib):
         ra, rb = eh.propose(g), eo.propose(g)
         for x, y, nm in zip(ra, rb, ("slot", "bnum", "bcoord", "median", "status")):
             assert x.tolist() == y.tolist(), nm
-        strictly = bool((np.diff(g) > 0).all()) and g.max() < G
-        assert (ra[4] == S_UNORDERED).all() == (not strictly)
+        bad = np.nonzero((g < 0) | (g >= G) | np.concatenate([[False], np.diff(g) <= 0]))[0]
+        v = int(bad[0]) if bad.shape[0] else g.shape[0]    # the first violation: refused from there on, applied before
+        assert (ra[4][v:] == S_UNORDERED).all() and not (ra[4][:v] == S_UNORDERED).any()
     z = np.zeros(4, np.int32)
-    for e in (eh, eo):   # broken promise on the acceptor side: nothing happens
+    res = []
+    for e in (eh, eo):   # broken promise on the acceptor side: the records before the first violation are applied
         (rb_, rc_, rm_, rf_, st), runs = e.accept(np.array([4, 2, 2, 9], np.int32), z, np.full(4, 100, np.int32), z + 1, z)
-        assert (st == S_UNORDERED).all() and runs.gidx.shape[0] == 0 and not rb_.any() and not rf_.any()
-        st, runs = e.commit(np.array([4, 2, 2, 9], np.int32), z, np.full(4, 100, np.int32), z + 1, z)
-        assert (st == S_UNORDERED).all() and runs.gidx.shape[0] == 0
+        assert (st[1:] == S_UNORDERED).all() and st[0] != S_UNORDERED and not rb_[1:].any() and not rf_[1:].any()
+        st2, runs2 = e.commit(np.array([4, 4, 2, 9], np.int32), z, np.full(4, 100, np.int32), z + 1, z)
+        assert (st2[2:] == S_UNORDERED).all() and not (st2[:2] == S_UNORDERED).any()
+        res.append([x.tolist() for x in (rb_, rc_, rm_, rf_, st, runs.as_tuple_array(), st2, runs2.as_tuple_array())])
+    assert res[0] == res[1]
     assert_same_state(eh, eo, range(G))
     assert eh.counters() == eo.counters()
 

@@ -219,3 +219,12 @@ def test_frame_level_cluster_matches_oracle(hip_lib, oracle_lib):
         assert ch.executed(nid).tolist() == co.executed(nid).tolist()
         sh, so = ch.eng[nid].snapshot(np.arange(G))[0], co.eng[nid].snapshot(np.arange(G))[0]
         assert sh.tobytes() == so.tobytes()
+
+
+def test_wire_codec_against_java_reading(hip_lib):
+    """tests/test_wire_model.py (the Python reading of BatchedAcceptReply.java:103-173, BatchedCommit.java:156-215,
+    PaxosPacketDemultiplexerFast.java:66-103) on the engine, on each decode tiling (the autouse fixture)"""
+    from tests import test_wire_model as T
+    T.test_decode_of_damaged_bursts_against_java_reading(hip_lib, 2000, 30_000, 12, 0.5)
+    T.test_decode_of_damaged_bursts_against_java_reading(hip_lib, 50, 20_000, 13, 0.9)
+    T.test_pack_of_random_batches_against_java_reading(hip_lib, 3000, 22)
