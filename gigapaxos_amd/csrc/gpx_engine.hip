@@ -112,9 +112,9 @@ struct gpx_engine {
    * paths: no per-record clearing store, no clearing pass) */
   uint32_t* rec_tag = nullptr;
   /* ordered batches in one launch (gpx_one.hip.h): order words, arrival counters, the call counter of their epochs */
-  unsigned long long* one_ord = nullptr;
-  uint32_t *one_done1 = nullptr, *one_done0 = nullptr;
+  unsigned long long* one_words = nullptr; /* the verdict word of k_one_check (gpx_one.hip.h) */
   uint32_t one_epoch = 0;
+  uint32_t* runs_arrive = nullptr; /* k_runs_check's arrival counters (first use) */
   /* GPX_LAZY_OUTPUTS: what gpx_compact_last_dev needs to finish the most recent call (kind 0: nothing pending) */
   struct LastCall {
     int kind = 0; /* 1 ACCEPT, 2 COMMIT (k_ac_one), 3 accept replies (k_ar_runs) */
@@ -325,13 +325,13 @@ void begin_back(gpx_engine* e, int, int32_t n, bool v16 = false) {
 }
 void end_call(gpx_engine* e, int) { e->call_seq++; }
 
-/* control words of a one-launch ordered batch (gpx_one.hip.h); a fresh 30-bit epoch per launch */
+/* the verdict word of an ordered batch (gpx_one.hip.h) and a fresh, ascending epoch for it */
 OneCtl one_ctl(gpx_engine* e) {
-  if (++e->one_epoch >= (1u << 30)) {
-    HIPQ(hipMemsetAsync(e->one_ord, 0, ((size_t)e->cfg.max_batch / GPX_BLOCK + 2) * sizeof(unsigned long long), e->stream));
+  if (++e->one_epoch == 0) { /* 2^32 launches: start the epochs again from a cleared word */
+    HIPQ(hipMemsetAsync(e->one_words, 0, sizeof(unsigned long long), e->stream));
     e->one_epoch = 1;
   }
-  return OneCtl{e->one_ord, e->one_done1, e->one_done0, e->one_epoch};
+  return OneCtl{e->one_words, e->one_epoch};
 }
 /* are the compacted outputs of this call left parked when the batch is unusual (GPX_LAZY_OUTPUTS)? */
 bool lazy_outputs(const gpx_engine* e) {
@@ -665,9 +665,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.o_rec, N, false);
   A(X.bucket_nout, nbk_alloc, true);
   A(e->rec_tag, N, true);
-  A(e->one_ord, N / GPX_BLOCK + 2, true);
-  A(e->one_done1, N / GPX_BLOCK / 64 + 2, true);
-  A(e->one_done0, 1, true);
+  A(e->one_words, 16, true);
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
@@ -960,21 +958,24 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     const RunsStage st{DecCols{d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind}, e->rec_tag, e->fs[0].chunk_cnt,
                        Stage16{(int32_t*)e->X.o_rec, (int64_t)N}};
     const int32_t refuse = runs_promised ? 1 : 0;
+    if (!e->runs_arrive &&
+        (rc = dev_alloc(e, &e->runs_arrive, 32 * (2 + N / ((size_t)GPX_OC_BLOCK * GPX_RC_ITEMS) / 16 + 1), true)) != GPX_OK)
+      return rc;
     LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
-              gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks);
-    const OneCtl C = one_ctl(e);
+              gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
+              refuse);
     {
       LaunchScope _ls(e, "k_ar_runs");
       const dim3 grid((n + GPX_RBLOCK - 1) / GPX_RBLOCK);
       if (e->cfg.kmax <= 4)
         hipLaunchKernelGGL(k_ar_runs<4>, grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, bcoord, slot, acceptor, max_cp,
-                           status, st, info, refuse, C, n_out, &e->X.counters[1]);
+                           status, st, info, refuse, n_out);
       else if (e->cfg.kmax <= 8)
         hipLaunchKernelGGL(k_ar_runs<8>, grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, bcoord, slot, acceptor, max_cp,
-                           status, st, info, refuse, C, n_out, &e->X.counters[1]);
+                           status, st, info, refuse, n_out);
       else
         hipLaunchKernelGGL(k_ar_runs<16>, grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, bcoord, slot, acceptor, max_cp,
-                           status, st, info, refuse, C, n_out, &e->X.counters[1]);
+                           status, st, info, refuse, n_out);
     }
     /* a REGULAR batch is finished: k_ar_runs' last workgroup has published its count.  The compaction pass of any
      * other batch follows at once - or, under the promise with GPX_LAZY_OUTPUTS, when the caller asks for it */
@@ -1032,11 +1033,17 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const bool promised = (e->ordered_mask & GPX_ORDERED_ACCEPT) != 0;
   e->last.kind = 0;
   if (promised && !fused) {
-    /* the promise and more than 65,536 records: order check, application and the usual batch's count in ONE launch
-     * (gpx_one.hip.h); the compaction pass follows unless the caller asked for lazy outputs */
+    /* the promise and more than 65,536 records: the verdict (k_one_check, which also writes the usual batch's
+     * count) and ONE work kernel (gpx_one.hip.h); the compaction pass follows unless the caller asked for lazy outputs */
     {
+      const OneCtl C = one_ctl(e);
+      {
+        LaunchScope _lc(e, "k_one_check");
+        hipLaunchKernelGGL(k_one_check<false>, dim3((n + GPX_DBLOCK * 8 - 1) / (GPX_DBLOCK * 8)), dim3(GPX_DBLOCK), 0, e->stream, n, gidx,
+                           e->S.G, C, n_runs, 0);
+      }
       LaunchScope _ls(e, "k_ac_one");
-      hipLaunchKernelGGL(k_ac_one<false>, dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, one_ctl(e), n,
+      hipLaunchKernelGGL(k_ac_one<false>, dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, C, n,
                          gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, n_runs);
     }
     gpx_engine::LastCall& L = e->last;
@@ -1138,10 +1145,16 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N; /* one launch: k_ac_small */
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
   e->last.kind = 0;
-  if (promised && !fused) { /* one launch (gpx_one.hip.h), like the ACCEPT call */
+  if (promised && !fused) { /* check + one work kernel (gpx_one.hip.h), like the ACCEPT call */
     {
+      const OneCtl C = one_ctl(e);
+      {
+        LaunchScope _lc(e, "k_one_check");
+        hipLaunchKernelGGL(k_one_check<false>, dim3((n + GPX_DBLOCK * 8 - 1) / (GPX_DBLOCK * 8)), dim3(GPX_DBLOCK), 0, e->stream, n, gidx,
+                           e->S.G, C, n_runs, n);
+      }
       LaunchScope _ls(e, "k_ac_one");
-      hipLaunchKernelGGL(k_ac_one<true>, dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, one_ctl(e), n,
+      hipLaunchKernelGGL(k_ac_one<true>, dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, C, n,
                          gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
                          (uint8_t*)nullptr, status, D, n_runs);
     }
@@ -1253,9 +1266,14 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   const int32_t refuse = promised ? 1 : 0;
   /* at most 65,536 requests on one stream: order check and direct application in one launch */
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
-  if (promised && !fused) { /* order check and application in one launch (gpx_one.hip.h) */
+  if (promised && !fused) { /* the verdict, then the application without a status prefill pass (gpx_one.hip.h) */
     e->stream = e->sB;
     const OneCtl C = one_ctl(e);
+    {
+      LaunchScope _lc(e, "k_one_check");
+      hipLaunchKernelGGL(k_one_check<true>, dim3((n + GPX_DBLOCK * 8 - 1) / (GPX_DBLOCK * 8)), dim3(GPX_DBLOCK), 0, e->stream, n, gidx, e->S.G,
+                         C, (int32_t*)nullptr, 0);
+    }
     if (e->cfg.kmax <= 4)
       LAUNCH(e, "k_propose_one", k_propose_one<4>, grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
              status, handle);

@@ -1,146 +1,90 @@
 /*
- * gpx_one.hip.h — ordered PROPOSE / ACCEPT / COMMIT batches in ONE launch (round 4).
+ * gpx_one.hip.h — ordered PROPOSE / ACCEPT / COMMIT batches: a check kernel and ONE work kernel (round 4).
  *
  * Under the gpx_engine_set_ordered_batches promise a batch of more than 65,536 records used to cost three or
  * four dependent launches: k_order_check (the verdict), the direct kernel (the work), k_emit_runs_direct and
  * k_copy_runs (which find nothing to do for a usual batch).  On this chip a dependent launch costs 5-6 us whatever
  * it does - the previous kernel's dirty lines leave the XCDs' L2s first - and they were 113 of the full round's
- * 279 us (profiles/r03_bench_full_round.json).  Here the verdict travels INSIDE the work kernel:
+ * 279 us by round 3's per-kernel profile (profiles/r03_bench_full_round.json).  Round 4's form is TWO launches:
  *
- *   order      every workgroup checks its own 256 records against their left neighbours (words it loads anyway)
- *              and publishes the first violating index it saw; a decoupled look-back over per-workgroup words
- *              {epoch, state, first bad index} - MIN instead of the usual sum - tells it the first violation of
- *              the whole PREFIX before it.  A record is applied iff it lies before the batch's first violation:
- *              the run of a group never straddles that index (equal neighbours are no violation), and a second
- *              run of the same group can only start behind a descent, i.e. behind the first violation - so no
- *              two lanes ever own the same group, without a global verdict.  The words wait for the
- *              predecessors' first LOADS, not for their work: the group state is requested before the wait.
- *              Promise broken: records from the first violation on are refused (GPX_S_UNORDERED, outputs zero,
- *              no state change), the records before it are applied - include/gpx.h.
- *   workgroups are taken in blockIdx order.  A workgroup only waits for lower block indices, and the dispatcher
- *              hands those out first (per XCD, in order): the lowest unfinished workgroup is always resident and
- *              waits for nobody.  (A ticket per workgroup - the wire decode's way - is a chain of same-address
- *              atomics at 16 ns each: 3,907 of them are 62 us, twice this kernel.)  The wait is BOUNDED all the
- *              same: a workgroup that gives up declares the batch broken at its own first record, which keeps
- *              "a prefix is applied, the rest refused" - a lost tail, never a hang.
- *   outputs    execution runs are parked at their records' indices and tagged, as in gpx_direct.hip.h.  The last
- *              workgroup to finish (two-level arrival counters) knows whether the batch was REGULAR - ACCEPTs
- *              released no commit; every COMMIT executed exactly one run - and publishes n_runs: the usual case
- *              needs no compaction at all.  Otherwise it raises D.mark and writes n_runs = -1: the compaction
- *              kernels (k_one_count, k_emit_runs_direct, k_copy_runs) follow at once (the default) or when the
- *              caller asks for dense columns (GPX_LAZY_OUTPUTS, gpx_compact_last_dev).
+ *   order      k_one_check reads the gidx column (eight records per lane) and leaves the batch's FIRST VIOLATION -
+ *              the first index that is out of range or lower than its predecessor (PROPOSE: not higher) - in one
+ *              word tagged with the launch's epoch; a batch that keeps its promise costs it no atomic.  It also
+ *              writes the REGULAR batch's output count.  The work kernel, launched behind it, reads that word and
+ *              applies a run of equal gidx iff it starts before the first violation (which is always a run start:
+ *              an index out of range starts a run of its own, a descent starts a new group): the records before
+ *              the first violation are applied, the records from it on are refused (GPX_S_UNORDERED, outputs
+ *              zero, no state change) - include/gpx.h.  A second run of a group can only start behind a descent,
+ *              so no two lanes ever own the same group.  No status prefill pass: the lane that replays a record
+ *              marks it.
+ *   outputs    execution runs are parked at their records' indices and tagged, as in gpx_direct.hip.h.  The
+ *              regular count - ACCEPTs release no commit: 0; every COMMIT executes exactly one run: n, dense as
+ *              parked - is in place already; a workgroup that sees otherwise overwrites it with -1 and raises
+ *              D.mark.  The usual batch needs no compaction and no other kernel; for the unusual one the
+ *              compaction kernels (k_one_count, k_emit_runs_direct, k_copy_runs) follow at once (the default) or
+ *              when the caller asks for dense columns (GPX_LAZY_OUTPUTS, gpx_compact_last_dev).
+ *
+ * A dependent launch that finds nothing to do costs ~2 us on this chip (not the 5-6 us the event-bracketed kernel
+ * profile of round 3 suggested: bench_full_round.py with and without the idle compaction launches, profiles/
+ * r04_full_round_*.json).  Fusing the VERDICT into the work kernel was built twice and measured slower than the
+ * kernel boundary it replaces: (1) a decoupled look-back over per-workgroup words (MIN of first violations): 2,048
+ * workgroups start together and the "prefix known" front moves 64 workgroups per atomic round trip - k_propose_one
+ * 39 us against 18 + 6; (2) checker workgroups at the head of the grid publishing one verdict word the others wait
+ * for: three memory-side round trips (checker word, collection, verdict) before the first store - an ACCEPT call 32.0
+ * us against 29.1 for the three launches of round 3.  Also measured on the way: "last workgroup to finish" by arrival
+ * counters - device-scope atomics on one cache line are serial at ~16 ns each whatever the address, and the
+ * workgroups alive at one time share two or three lines of counters: 3,907 arrivals = 62 us per launch.
+ * (profiles/r04_full_round_lookback_attempt.json, r04_full_round_checker_workgroups.json)
  */
 #pragma once
 #include "gpx_direct.hip.h"
 
-#define ONE_AGG 1ull
-#define ONE_PRE 2ull
 #define ONE_NONE 0xffffffffu
-#define ONE_SPIN_LIMIT (1u << 18) /* polls of one look-back step before the workgroup gives up (~ a second) */
 
 struct OneCtl {
-  unsigned long long* ord; /* [workgroups] epoch << 34 | state << 32 | first violating index (ONE_NONE: none) */
-  uint32_t* done1;         /* [workgroups / 64 + 1] arrivals per 64 workgroups | irregular ones << 16; zero between calls */
-  uint32_t* done0;         /* [1] ... of the groups of 64 */
-  uint32_t epoch;          /* 30 bits, never 0 (the words are cleared when it wraps) */
+  unsigned long long* verdict; /* [1] epoch << 32 | (ONE_NONE - first violating index); another epoch: no violation */
+  uint32_t epoch;              /* ascending, never 0: a word of an older launch never needs clearing */
 };
 
-__device__ __forceinline__ unsigned long long one_word(uint32_t epoch, unsigned long long st, uint32_t v) {
-  return ((unsigned long long)epoch << 34) | (st << 32) | (unsigned long long)v;
+/* the batch's first violation (ONE_NONE: none), as k_one_check left it */
+__device__ __forceinline__ uint32_t one_first_bad(const OneCtl& C) {
+  const unsigned long long v = *C.verdict;
+  return (uint32_t)(v >> 32) == C.epoch ? ONE_NONE - (uint32_t)v : ONE_NONE;
 }
 
-/* first violating index among the workgroups before `w` (ONE_NONE: the prefix keeps the order); called by one
- * whole wave.  The walk stops at the nearest workgroup that already knows its inclusive prefix. */
-__device__ __forceinline__ uint32_t one_lookback_min(const unsigned long long* __restrict__ st, int32_t w,
-                                                     uint32_t epoch, bool* timed_out) {
-  const int32_t lane = (int32_t)(threadIdx.x & 63);
-  uint32_t acc = ONE_NONE;
-  uint32_t spins = 0;
-  for (int32_t hi = w - 1; hi >= 0; hi -= 64) {
-    const int32_t j = hi - lane; /* lane 0 = the nearest predecessor of this step */
-    unsigned long long v = j >= 0 ? __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    bool need = j >= 0 && (uint32_t)(v >> 34) != epoch;
-    unsigned long long pre_mask;
-    for (;;) {
-      pre_mask = __ballot(!need && j >= 0 && ((v >> 32) & 3ull) == ONE_PRE);
-      const unsigned long long wait_mask = __ballot(need);
-      if (pre_mask) {
-        const unsigned long long nearer = (pre_mask & (0ull - pre_mask)) - 1ull;
-        if ((wait_mask & nearer) == 0) break;
-      } else if (wait_mask == 0) {
-        break;
-      }
-      if (++spins > ONE_SPIN_LIMIT) {
-        *timed_out = true;
-        return acc;
-      }
-      __builtin_amdgcn_s_sleep(4);
-      if (need) {
-        v = __hip_atomic_load(&st[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((uint32_t)(v >> 34) == epoch) need = false;
-      }
-    }
-    const int32_t first_pre = pre_mask ? (__ffsll((long long)pre_mask) - 1) : 64;
-    uint32_t x = (j >= 0 && lane <= first_pre) ? (uint32_t)v : ONE_NONE;
+/* The verdict: the first index that is out of range or lower (STRICT: not higher) than its predecessor.  Eight
+ * records per lane (16-byte loads); a workgroup that finds a violation raises the word with one atomicMax -
+ * (epoch, ONE_NONE - index): a newer launch beats an older word, a lower index a higher one - so a batch that keeps
+ * its promise costs no atomic at all.  Thread 0 of the grid also writes the REGULAR batch's output count; the work
+ * kernel overwrites it with -1 when the batch turns out otherwise (launched behind: the order is the stream's). */
+template <bool STRICT>
+__global__ __launch_bounds__(GPX_DBLOCK) void k_one_check(int32_t n, const int32_t* __restrict__ gidx, int32_t G, OneCtl C,
+                                                         int32_t* __restrict__ count_out, int32_t regular_count) {
+  __shared__ uint32_t s_bad;
+  const int64_t i0 = ((int64_t)blockIdx.x * GPX_DBLOCK + threadIdx.x) * 8;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && count_out) *count_out = regular_count;
+  if (threadIdx.x == 0) s_bad = ONE_NONE;
+  uint32_t mine = ONE_NONE;
+  if (i0 < n) {
+    int32_t g[9];
+    g[0] = i0 > 0 ? gidx[i0 - 1] : INT32_MIN;
+    if (i0 + 7 < n && !((uintptr_t)gidx & 15)) {
+      const I4 a = *(const I4*)(gidx + i0), b = *(const I4*)(gidx + i0 + 4);
+      g[1] = a.x, g[2] = a.y, g[3] = a.z, g[4] = a.w, g[5] = b.x, g[6] = b.y, g[7] = b.z, g[8] = b.w;
+    } else {
 #pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) {
-      const uint32_t y = (uint32_t)__shfl_xor((int)x, d, 64);
-      x = y < x ? y : x;
+      for (int q = 0; q < 8; q++) g[q + 1] = i0 + q < n ? gidx[i0 + q] : INT32_MAX;
     }
-    acc = x < acc ? x : acc;
-    if (pre_mask) return acc;
+#pragma unroll
+    for (int q = 7; q >= 0; q--)
+      if (i0 + q < n && ((uint32_t)g[q + 1] >= (uint32_t)G || (i0 + q > 0 && (STRICT ? g[q] >= g[q + 1] : g[q] > g[q + 1]))))
+        mine = (uint32_t)(i0 + q);
   }
-  return acc;
-}
-
-/* The batch's first violation as far as workgroup `w` can know it (its own records and everything before them):
- * `bad` = this lane's record breaks the order (out of range, or a descent into it).  Every thread of the
- * workgroup must call it; contains barriers.  s_bad: one shared word. */
-__device__ __forceinline__ uint32_t one_prefix_verdict(const OneCtl& C, int32_t w, int32_t i, bool bad, uint32_t* s_bad) {
-  if (threadIdx.x == 0) *s_bad = ONE_NONE;
-  const bool any_bad = __syncthreads_or(bad); /* also orders the store above */
-  if (any_bad) {
-    if (bad) atomicMin(s_bad, (uint32_t)i);
+  if (__syncthreads_or(mine != ONE_NONE)) { /* (also orders the store of s_bad above) */
+    if (mine != ONE_NONE) atomicMin(&s_bad, mine);
     __syncthreads();
+    if (threadIdx.x == 0) atomicMax(C.verdict, ((unsigned long long)C.epoch << 32) | (unsigned long long)(ONE_NONE - s_bad));
   }
-  if (threadIdx.x < 64) {
-    const uint32_t local = *s_bad;
-    uint32_t incl = local;
-    if (w > 0) {
-      if (threadIdx.x == 0)
-        __hip_atomic_store(&C.ord[w], one_word(C.epoch, ONE_AGG, local), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      bool timed_out = false;
-      const uint32_t before = one_lookback_min(C.ord, w, C.epoch, &timed_out);
-      incl = before < incl ? before : incl;
-      if (timed_out) { /* gave up: the batch counts as broken from this workgroup's first record on */
-        const uint32_t mine = (uint32_t)w * (uint32_t)blockDim.x;
-        incl = mine < incl ? mine : incl;
-      }
-    }
-    if (threadIdx.x == 0) {
-      __hip_atomic_store(&C.ord[w], one_word(C.epoch, ONE_PRE, incl), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_bad = incl;
-    }
-  }
-  __syncthreads();
-  return *s_bad;
-}
-
-/* Arrival of workgroup `w` of `nwg`; true in thread 0 of the LAST workgroup to arrive, with *any_irregular = some
- * workgroup reported `irregular`.  The counters are back at zero when it returns true.  Thread 0 only. */
-__device__ __forceinline__ bool one_arrive(const OneCtl& C, int32_t w, int32_t nwg, bool irregular, bool* any_irregular) {
-  const int32_t grp = w >> 6;
-  const uint32_t size1 = (uint32_t)min(64, nwg - (grp << 6));
-  const uint32_t old1 = atomicAdd(&C.done1[grp], 1u + (irregular ? 0x10000u : 0u));
-  if ((old1 & 0xffffu) + 1u != size1) return false;
-  const bool irr1 = irregular || (old1 >> 16) != 0;
-  __hip_atomic_store(&C.done1[grp], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  const uint32_t ngrp = (uint32_t)((nwg + 63) >> 6);
-  const uint32_t old0 = atomicAdd(C.done0, 1u + (irr1 ? 0x10000u : 0u));
-  if ((old0 & 0xffffu) + 1u != ngrp) return false;
-  *any_irregular = irr1 || (old0 >> 16) != 0;
-  __hip_atomic_store(C.done0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  return true;
 }
 
 template <bool COMMIT>
@@ -150,12 +94,11 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
     const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status, DirectStage D,
     int32_t* __restrict__ n_runs) {
-  __shared__ uint32_t s_bad;
-  const int32_t w = (int32_t)blockIdx.x;
-  const int32_t i = w * GPX_DBLOCK + (int32_t)threadIdx.x;
+  const int32_t i = (int32_t)blockIdx.x * GPX_DBLOCK + (int32_t)threadIdx.x;
+  const uint32_t first_bad = one_first_bad(C);
   /* wave 1 of loads: the neighbours in gidx and this record's columns */
   int32_t g = 0, g_prev = 0, g_next = 0, f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
-  bool bad = false, head = false, runstart = false;
+  bool head = false, runstart = false;
   if (i < n) {
     g = gidx[i];
     g_prev = i > 0 ? gidx[i - 1] : ~g;
@@ -163,22 +106,18 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
     f_a = slot[i], f_b = median[i], f_c = flags ? (int32_t)flags[i] : 0;
     f_bnum = bnum[i], f_bcoord = bcoord[i];
     const bool oob = (uint32_t)g >= (uint32_t)S.G;
-    bad = oob || (i > 0 && g_prev > g);
     runstart = g_prev != g; /* first record of a run of equal gidx: this lane answers for the whole run */
     head = runstart && !oob;
   }
-  /* wave 2, requested BEFORE the verdict is waited for: the group's acceptor state and the ring entry of this
-   * record's slot (a head whose run turns out to lie behind the first violation has loaded them in vain) */
+  /* wave 2: the group's acceptor state and the ring entry of this record's slot */
   AccPre P = acc_nopre();
-  if (head) acc_preload(S, g, f_a, P);
-  const uint32_t first_bad = one_prefix_verdict(C, w, i, bad, &s_bad);
+  if (head) acc_preload(S, g, f_a, P); /* (not made to wait for the verdict word: a refused head has loaded in vain) */
   bool irregular = false;
   if (runstart) {
     if ((uint32_t)i >= first_bad) {
       /* refused: the promise was broken at or before this run.  The first violation is always a run start (an
        * index out of range starts a run of its own, a descent starts a new group), so "runs that start at or
-       * behind it" are exactly "records at or behind it" - and a workgroup that gave up waiting names its own
-       * first record, which may lie inside a run: that run belongs to its head, refused or applied as a whole */
+       * behind it" are exactly "records at or behind it" */
       int32_t j = i;
       for (;;) {
         if (!COMMIT) {
@@ -226,17 +165,10 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
       irregular = it.irregular || it.pend >= 0; /* pend: the replay stopped on a commit without a run */
     }
   }
-  const bool wg_irregular = __syncthreads_or(irregular);
-  if (threadIdx.x == 0) {
-    bool any = false;
-    if (one_arrive(C, w, (int32_t)gridDim.x, wg_irregular, &any)) {
-      if (any) {
-        D.mark[0] = X.epoch; /* the compaction kernels have work */
-        if (n_runs) *n_runs = -1;
-      } else if (n_runs) {
-        *n_runs = COMMIT ? n : 0; /* one run per commit, each parked at its record's index: dense as they stand */
-      }
-    }
+  /* a usual batch is finished: k_one_check wrote its count.  Any workgroup that saw otherwise says so */
+  if (__syncthreads_or(irregular) && threadIdx.x == 0) {
+    __hip_atomic_store(D.mark, X.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* the compaction kernels have work */
+    if (n_runs) __hip_atomic_store(n_runs, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -255,25 +187,15 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_one(
     const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
     const int64_t* __restrict__ handle) {
-  __shared__ uint32_t s_bad;
-  const int32_t w = (int32_t)blockIdx.x;
-  const int32_t i = w * GPX_BLOCK + (int32_t)threadIdx.x;
-  int32_t g = 0;
-  bool bad = false, live = false;
-  if (i < n) {
-    g = gidx[i];
-    const int32_t g_prev = i > 0 ? gidx[i - 1] : -1;
-    const bool oob = (uint32_t)g >= (uint32_t)S.G;
-    bad = oob || (i > 0 && g_prev >= g);
-    live = !oob;
-  }
+  const int32_t i = (int32_t)blockIdx.x * GPX_BLOCK + (int32_t)threadIdx.x;
+  if (i >= n) return;
+  const uint32_t first_bad = one_first_bad(C);
+  const int32_t g = gidx[i];
   ProposePre<KMAX> P;
-  if (live) {
+  if ((uint32_t)g < (uint32_t)S.G) { /* requested without waiting for the verdict word */
     propose_preload<KMAX>(S, g, P);
     propose_preload_ring<KMAX>(S, g, P);
   }
-  const uint32_t first_bad = one_prefix_verdict(C, w, i, bad, &s_bad);
-  if (i >= n) return;
   if ((uint32_t)i >= first_bad) {
     o_slot[i] = 0;
     o_bnum[i] = 0;

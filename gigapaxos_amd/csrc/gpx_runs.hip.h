@@ -75,7 +75,9 @@ struct RunsStage {
 __global__ __launch_bounds__(GPX_OC_BLOCK) void k_runs_check(int32_t n, const int32_t* __restrict__ gidx, int32_t G,
                                                           DevScratch X, uint8_t* __restrict__ status,
                                                           RunsInfo* __restrict__ info, RunsInfo* __restrict__ next_info,
-                                                          int32_t* __restrict__ zero, int32_t nzero) {
+                                                          int32_t* __restrict__ zero, int32_t nzero,
+                                                          uint32_t* __restrict__ arrive, int32_t* __restrict__ n_out,
+                                                          unsigned long long* __restrict__ acc, int32_t refuse) {
   const int64_t t = (int64_t)blockIdx.x * GPX_OC_BLOCK + threadIdx.x;
   const int64_t i0 = t * GPX_RC_ITEMS;
   for (int64_t z = t; z < nzero; z += (int64_t)gridDim.x * GPX_OC_BLOCK) zero[z] = 0;
@@ -132,13 +134,48 @@ __global__ __launch_bounds__(GPX_OC_BLOCK) void k_runs_check(int32_t n, const in
       if ((desc >> q) & 1u) {
         const int32_t k = atomicAdd(&info->n_desc, 1);
         if (k < GPX_RUNS_MAX - 1)
-          info->start[k + 1] = (int32_t)(i0 + q + 1);
+          __hip_atomic_store(&info->start[k + 1], (int32_t)(i0 + q + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else
           bad = true;
       }
     }
   }
-  if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
+  const bool wg_bad = __syncthreads_or(bad);
+  const bool wg_desc = nd != 0; /* this workgroup recorded run starts (every thread knows: __syncthreads_count above) */
+  if (threadIdx.x == 0) {
+    if (wg_bad) atomicMax(X.unsorted, X.epoch);
+    /* The LAST workgroup to finish publishes what the whole check found, so that the usual batch needs no other
+     * kernel for its count: a REGULAR batch decides once per record of run 0 (k_ar_runs overwrites the count with -1
+     * when the batch turns out otherwise), a refused one has no output.  Arrival counters: 16 workgroups share one,
+     * 128 bytes apart (device-scope atomics on one cache line are serial at ~16 ns each: gpx_one.hip.h), then one
+     * for the groups of 16.  A workgroup that recorded a run start fences first: the last one reads them all. */
+    if (wg_desc || wg_bad) __threadfence(); /* ... and one that raised *X.unsorted */
+    const int32_t nwg = (int32_t)gridDim.x, grp = (int32_t)blockIdx.x >> 4;
+    const uint32_t size1 = (uint32_t)min(16, nwg - (grp << 4));
+    bool last = false;
+    if (atomicAdd(&arrive[32 * (1 + grp)], 1u) + 1u == size1) {
+      __hip_atomic_store(&arrive[32 * (1 + grp)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (atomicAdd(&arrive[0], 1u) + 1u == (uint32_t)((nwg + 15) >> 4)) {
+        __hip_atomic_store(&arrive[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        last = true;
+      }
+    }
+    if (last && n_out) {
+      __threadfence();
+      const bool unsorted = __hip_atomic_load(X.unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X.epoch;
+      if (!unsorted) {
+        const int32_t nd = min(__hip_atomic_load(&info->n_desc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), GPX_RUNS_MAX - 1);
+        int32_t len0 = n;
+        for (int32_t q = 1; q <= nd; q++)
+          len0 = min(len0, __hip_atomic_load(&info->start[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        *n_out = len0;
+        info->total = len0; /* what was counted already (k_emit_dec_runs adds the difference for an irregular batch) */
+        if (acc) atomicAdd(acc, (unsigned long long)len0);
+      } else if (refuse) {
+        *n_out = 0;
+      }
+    }
+  }
 }
 
 /* the run starts of the call, ascending, in LDS: rs[0 .. R], rs[R] = n; returns R (every thread).  The
@@ -279,8 +316,8 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
                                                        const int32_t* __restrict__ acceptor,
                                                        const int32_t* __restrict__ maxcp,
                                                        uint8_t* __restrict__ status, RunsStage st,
-                                                       RunsInfo* __restrict__ info, int32_t refuse, OneCtl C,
-                                                       int32_t* __restrict__ n_out, unsigned long long* __restrict__ acc) {
+                                                       RunsInfo* __restrict__ info, int32_t refuse,
+                                                       int32_t* __restrict__ n_out) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
   __shared__ int32_t wsum[GPX_RBLOCK / 64];
   const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
@@ -289,11 +326,7 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
     /* not a few sorted runs: the partition pipeline launched behind does it - or, under the
      * GPX_ORDERED_REPLY_RUNS promise (no partition pipeline launched), the batch is refused whole */
     if (refuse && i < n && status) status[i] = GPX_S_UNORDERED;
-    if (threadIdx.x == 0) { /* arrive all the same: the counters must be back at zero, and a refused batch has no output */
-      bool any = false;
-      if (one_arrive(C, (int32_t)blockIdx.x, (int32_t)gridDim.x, false, &any) && refuse && n_out) *n_out = 0;
-    }
-    return;
+    return; /* (k_runs_check's last workgroup wrote n_out = 0 for the refused batch) */
   }
   const int32_t R = runs_load(info, n, rs);
   if (i == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
@@ -419,19 +452,10 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       wg_irregular |= (wsum[w] & 0x40000000) != 0;
     }
     if (tot) atomicAdd(&st.chunk_cnt[my_chunk], tot);
-    /* the last workgroup to finish publishes the REGULAR batch's count - one decision per record of run 0, dense
-     * as parked - so that no other kernel has to run for it; otherwise -1: k_emit_dec_runs / k_merge_runs follow
-     * (at once, or on gpx_compact_last_dev under GPX_LAZY_OUTPUTS) */
-    bool any = false;
-    if (one_arrive(C, (int32_t)blockIdx.x, (int32_t)gridDim.x, wg_irregular, &any)) {
-      if (any) {
-        if (n_out) *n_out = -1;
-      } else {
-        const int32_t total = runs_len0(info, n);
-        if (n_out) *n_out = total;
-        if (acc) atomicAdd(acc, (unsigned long long)total);
-      }
-    }
+    /* a REGULAR batch is finished: k_runs_check's last workgroup wrote its count (one decision per record of run 0,
+     * dense as parked).  A workgroup that saw otherwise says so: k_emit_dec_runs / k_merge_runs follow (at once, or
+     * on gpx_compact_last_dev under GPX_LAZY_OUTPUTS) */
+    if (wg_irregular && n_out) __hip_atomic_store(n_out, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
@@ -484,11 +508,12 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_emit_dec_runs(DevScratch X, int3
   }
   if (w == nchunks - 1 && threadIdx.x == 0) {
     const int32_t total = pre + tot;
+    const int32_t counted = published ? info->total : 0; /* k_runs_check counted a regular batch's decisions already */
     info->total = total;
     info->seg_off[0] = 0;
     info->seg_off[R] = total;
     if (total_out) *total_out = total;
-    if (acc) atomicAdd(acc, (unsigned long long)total);
+    if (acc) atomicAdd(acc, (unsigned long long)(long long)(total - counted));
   }
   }
 }

@@ -1015,12 +1015,14 @@ struct BEWriter {
       k = 0;
     }
   }
-  __device__ __forceinline__ void put32(int32_t v) { /* ByteBuffer.putInt */
-    const uint32_t u = (uint32_t)v;
-    put8(u >> 24);
-    put8(u >> 16);
-    put8(u >> 8);
-    put8(u);
+  /* ByteBuffer.putInt at any byte offset: one funnel shift and one word out (round 4; until then four put8 -
+   * everything behind the 13-byte header and the name is unaligned) */
+  __device__ __forceinline__ void put32(int32_t v) { putraw32(__builtin_bswap32((uint32_t)v)); }
+  /* four bytes that are already in memory order (a word of the name) */
+  __device__ __forceinline__ void putraw32(uint32_t u) {
+    const unsigned long long wide = (unsigned long long)acc | ((unsigned long long)u << (8 * k));
+    *w++ = (uint32_t)wide;
+    acc = (uint32_t)(wide >> 32); /* the k bytes that did not fit */
   }
   __device__ __forceinline__ void flush() {
     if (k) *w = acc;
@@ -1194,8 +1196,15 @@ __device__ __forceinline__ int32_t pack_commit_frame_alone(const DevState& S, co
   w.put8((uint32_t)idl);
   const uint8_t* nm = N.name(A.g);
 #pragma unroll
-  for (int32_t b = 0; b < NM_HOT; b++)
-    if (b < idl) w.put8(nw[b >> 2] >> (8 * (b & 3)));
+  for (int32_t b = 0; b < NM_HOT; b += 4) { /* whole words of the name while they last, then its odd bytes */
+    if (b + 4 <= idl) {
+      w.putraw32(nw[b >> 2]);
+    } else {
+#pragma unroll
+      for (int32_t q = 0; q < 4; q++)
+        if (b + q < idl) w.put8(nw[b >> 2] >> (8 * q));
+    }
+  }
   for (int32_t b = NM_HOT; b < idl; b++) w.put8(nm[b]);
   w.put32(bnum);
   w.put32(bcoord);
@@ -1223,16 +1232,11 @@ struct BEWriterLds {
       k = 0;
     }
   }
-  __device__ __forceinline__ void put32(int32_t v) {
-    const uint32_t u = (uint32_t)v;
-    if (k == 0) { /* aligned: one word */
-      *w++ = __builtin_bswap32(u);
-      return;
-    }
-    put8(u >> 24);
-    put8(u >> 16);
-    put8(u >> 8);
-    put8(u);
+  __device__ __forceinline__ void put32(int32_t v) { putraw32(__builtin_bswap32((uint32_t)v)); }
+  __device__ __forceinline__ void putraw32(uint32_t u) { /* as BEWriter's */
+    const unsigned long long wide = (unsigned long long)acc | ((unsigned long long)u << (8 * k));
+    *w++ = (uint32_t)wide;
+    acc = (uint32_t)(wide >> 32);
   }
   __device__ __forceinline__ void flush() {
     if (k) *w = acc;

@@ -11,6 +11,46 @@ if ROOT not in sys.path:
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_fast: the subset of the GPU suite to run after every kernel change (about a minute "
+                                       "and a half: one case per kernel family at full size, one fuzz seed each, the "
+                                       "enumeration samples); the whole -m gpu suite takes a quarter of an hour")
+
+
+# node-id fragments of the gpu_fast subset (every GPU test file contributes; chosen by measured duration, round 4:
+# profiles/r04_gpu_fast_durations.txt)
+GPU_FAST = [
+    "test_fullsize_gpu.py::test_config3_config4_streams_1m_groups_vs_oracle[3-True]",      # partition pipeline, 1 M groups, mix
+    "test_fullsize_gpu.py::test_config3_config4_streams_1m_groups_vs_oracle[5-True]",      # ... K = 5
+    "test_runs_gpu.py::test_reply_runs_1m_groups_vs_oracle[3-8]",                          # sorted runs, promise
+    "test_runs_gpu.py::test_reply_runs_fuzz[5-5000-42",                                    # ... hint, fuzz
+    "test_one_gpu.py::test_lazy_outputs_on_the_device_path",                               # k_ac_one + lazy compaction
+    "test_one_gpu.py::test_lazy_reply_runs[3]",
+    "test_one_gpu.py::test_broken_promise_refuses_from_the_first_violation[descent]",
+    "test_one_gpu.py::test_broken_promise_refuses_from_the_first_violation[repeated group]",
+    "test_parity_gpu.py::test_fuzz_mixed_ops[partition path-3-1]", "test_parity_gpu.py::test_fuzz_mixed_ops[sorted-runs hint-16-4]",
+    "test_parity_gpu.py::test_fuzz_ordered_batches[partition path-5-700-22]",
+    "test_parity_gpu.py::test_ordered_batches_promise", "test_parity_gpu.py::test_fuzz_wraparound[partition path]",
+    "test_parity_gpu.py::test_steady_state_votes_fast_path[partition path-5-53]", "test_parity_gpu.py::test_hot_group_long_segments[partition path-4096]",
+    "test_parity_gpu.py::test_config2_10k_groups_full_pipeline", "test_parity_gpu.py::test_propose_batch_orders[partition path",
+    "test_edges_gpu.py::test_empty_batches_and_capacity", "test_edges_gpu.py::test_tile_boundary_batch_sizes[4097]",
+    "test_edges_gpu.py::test_tile_boundary_batch_sizes[12288]", "test_edges_gpu.py::test_unaligned_device_columns",
+    "test_wire_gpu.py::test_decode_fuzz[512-frame tiles-2-0.3]", "test_wire_gpu.py::test_wire_codec_against_java_reading[256-frame tiles]",
+    "test_acc_enum_gpu.py::test_acceptor_side_enumerated_under_the_ordered_promise",
+    "test_acc_enum_gpu.py::test_pcs_accept_replies_in_any_order_on_engine[4-2-100000-16-False]",
+    "test_acc_enum_gpu.py::test_whole_round_against_the_two_java_readings_together_on_engine[6000-16-16-0.1-4-0.0]",
+    "test_acc_enum_gpu.py::test_whole_round_with_unusual_group_sizes[1-kw0]",
+    "test_election_gpu.py::test_election_fuzz_parity[1-", "test_election_gpu.py::test_failover_end_to_end_parity[200-0-8]",
+    "test_host_rows_gpu.py::test_gap_detection_matches_oracle[0]", "test_host_rows_gpu.py::test_request_batcher_matches_oracle[1-True]",
+    "test_route_gpu.py::test_route_matches_shard_map[8-300000-100000]",
+    "test_async_gpu.py::test_async_rounds_match_oracle[300000-3]",
+    "test_host_cluster_gpu.py::test_cluster_matches_oracle_build[0]",
+]
+
+
+def pytest_collection_modifyitems(config, items):
+    for it in items:
+        if any(frag in it.nodeid for frag in GPU_FAST):
+            it.add_marker(pytest.mark.gpu_fast)
 
 
 @pytest.fixture(scope="session")

@@ -97,3 +97,45 @@ def test_async_pipeline_of_vote_batches(hip_lib, oracle_lib, pin_outputs):
     assert eh.snapshot(g)[0].tobytes() == eo.snapshot(g)[0].tobytes()
     eh.close()
     eo.close()
+
+
+def test_unregister_with_a_ticket_in_flight_then_pageable_copies(hip_lib, oracle_lib):
+    """gpx_host_unregister while an asynchronous call still writes through the block's device
+    mapping (k_copy_out on the set's copy-out stream) - the call must drain the engine's streams first, so that the
+    outputs are complete when it returns, the ticket can still be waited for, and the freed range can be used for
+    large pageable copies at once (the SIGABRT of profiles/r03_pytest_gpu_abort_incident.log was torch's first big
+    pageable H2D copy after such traffic).  Then gpx_engine_destroy with registered blocks and a ticket nobody
+    waited for: it unregisters what is left itself."""
+    import torch
+    G, k = 400_000, 3
+    members = [100, 101, 102]
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=G * k + 4096)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 100)) == S_OK).all()
+    g = np.arange(G, dtype=np.int32)
+    for r in range(3):
+        cols = streams.vote_round(G, members, r, 100)
+        eo.propose(g)
+        do = eo.accept_reply(*cols)
+        eh.propose_async(g).wait()
+        eh.host_register(*cols)
+        tv = eh.accept_reply_async(*cols, pin_outputs=True)     # outputs registered: k_copy_out writes them
+        # take the INPUT registrations away at once, the call still in flight ...
+        eh.host_unregister(*cols)
+        # ... then big pageable copies through the same process (what test_route_gpu.py does first)
+        big = torch.from_numpy(np.arange(8_000_000, dtype=np.int64))
+        assert int(big.cuda().sum().item()) == 8_000_000 * (8_000_000 - 1) // 2
+        _same(tv.wait(), do, f"round {r}")                       # the ticket is still good; finish() unregisters the outputs
+    # a ticket nobody waits for and blocks still registered at destroy
+    cols = streams.vote_round(G, members, 3, 100)
+    eh.propose_async(g).wait()
+    eh.host_register(*cols)
+    pending = eh.accept_reply_async(*cols)                       # (keeps the call's buffers alive until the engine is gone)
+    eh.close()                                                   # drains, unregisters cols itself
+    del pending
+    big = torch.from_numpy(np.arange(4_000_000, dtype=np.int64))
+    assert int(big.cuda().sum().item()) == 4_000_000 * (4_000_000 - 1) // 2
+    t = torch.from_numpy(cols[0])                                # the range is ordinary pageable memory again
+    assert int(t.cuda().sum().item()) == int(cols[0].astype(np.int64).sum())
+    eo.close()
