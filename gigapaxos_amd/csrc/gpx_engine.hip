@@ -23,6 +23,7 @@
 #include "gpx_direct.hip.h"
 #include "gpx_one.hip.h"
 #include "gpx_runs.hip.h"
+#include "gpx_small.hip.h"
 #include "gpx_route.hip.h"
 #include "gpx_wire.hip.h"
 #include "gpx_elect.hip.h"
@@ -115,6 +116,9 @@ struct gpx_engine {
   unsigned long long* one_words = nullptr; /* the verdict word of k_one_check (gpx_one.hip.h) */
   uint32_t one_epoch = 0;
   uint32_t* runs_arrive = nullptr; /* k_runs_check's arrival counters (first use) */
+  /* small accept-reply calls in one launch (gpx_small.hip.h): votes a workgroup is sized for (GPX_SAR_VOTES_PER_WG,
+   * tuning), 0 = the path is off (GPX_SAR_VOTES_PER_WG=0: every call takes the partition pipeline) */
+  int32_t sar_votes_per_wg = 1024;
   /* GPX_LAZY_OUTPUTS: what gpx_compact_last_dev needs to finish the most recent call (kind 0: nothing pending) */
   struct LastCall {
     int kind = 0; /* 1 ACCEPT, 2 COMMIT (k_ac_one), 3 accept replies (k_ar_runs) */
@@ -597,6 +601,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
+  if (const char* sv = getenv("GPX_SAR_VOTES_PER_WG")) e->sar_votes_per_wg = std::max(0, std::min(GPX_SAR_CAP, atoi(sv)));
   e->ordered_mask = e->env_mask;
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
   const size_t bucket_lds_hw = GPX_BUCKET_LDS_BYTES(X.gb, e->lds_recs_hw) + e->lds_pad;
@@ -959,31 +964,49 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
                        Stage16{(int32_t*)e->X.o_rec, (int64_t)N}};
     const int32_t refuse = runs_promised ? 1 : 0;
     if (!e->runs_arrive &&
-        (rc = dev_alloc(e, &e->runs_arrive, 32 * (2 + N / ((size_t)GPX_OC_BLOCK * GPX_RC_ITEMS) / 16 + 1), true)) != GPX_OK)
+        (rc = dev_alloc(e, &e->runs_arrive,
+                        /* k_runs_check: one workgroup per 4,096 records; k_ar_runs<.., SMALL>: up to 256 workgroups */
+                        32 * (2 + std::max<size_t>(N / ((size_t)GPX_OC_BLOCK * GPX_RC_ITEMS), GPX_SMALL_RUNS_MAX / GPX_RBLOCK) / 16 + 1),
+                        true)) != GPX_OK)
       return rc;
-    LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
-              gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
-              refuse);
+    const bool small = n <= GPX_SMALL_RUNS_MAX; /* one launch: every workgroup judges the (L2-resident) column itself */
+    if (!small)
+      LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
+                gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
+                refuse);
     {
-      LaunchScope _ls(e, "k_ar_runs");
+      LaunchScope _ls(e, small ? "k_ar_runs_small" : "k_ar_runs");
       const dim3 grid((n + GPX_RBLOCK - 1) / GPX_RBLOCK);
+#define GPX_LAUNCH_AR_RUNS(KM)                                                                                              \
+  do {                                                                                                                      \
+    if (small)                                                                                                              \
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ar_runs<KM, true>), grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, \
+                         bcoord, slot, acceptor, max_cp, status, st, info, refuse, n_out, next_info, e->runs_arrive,        \
+                         &e->X.counters[1]);                                                                                \
+    else                                                                                                                    \
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ar_runs<KM, false>), grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, \
+                         bcoord, slot, acceptor, max_cp, status, st, info, refuse, n_out, (RunsInfo*)nullptr,               \
+                         (uint32_t*)nullptr, (unsigned long long*)nullptr);                                                 \
+  } while (0)
       if (e->cfg.kmax <= 4)
-        hipLaunchKernelGGL(k_ar_runs<4>, grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, bcoord, slot, acceptor, max_cp,
-                           status, st, info, refuse, n_out);
+        GPX_LAUNCH_AR_RUNS(4);
       else if (e->cfg.kmax <= 8)
-        hipLaunchKernelGGL(k_ar_runs<8>, grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, bcoord, slot, acceptor, max_cp,
-                           status, st, info, refuse, n_out);
+        GPX_LAUNCH_AR_RUNS(8);
       else
-        hipLaunchKernelGGL(k_ar_runs<16>, grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, bcoord, slot, acceptor, max_cp,
-                           status, st, info, refuse, n_out);
+        GPX_LAUNCH_AR_RUNS(16);
+#undef GPX_LAUNCH_AR_RUNS
     }
     /* a REGULAR batch is finished: k_ar_runs' last workgroup has published its count.  The compaction pass of any
      * other batch follows at once - or, under the promise with GPX_LAZY_OUTPUTS, when the caller asks for it */
     e->last.kind = 0;
     if (runs_promised && lazy_outputs(e)) {
       gpx_engine::LastCall& L = e->last;
-      L.kind = 3, L.n = n, L.nchunks = nchunks, L.X = e->X, L.rs = st, L.info = info, L.count = n_out;
+      L.kind = small ? 4 : 3, L.n = n, L.nchunks = nchunks, L.X = e->X, L.rs = st, L.info = info, L.count = n_out;
     } else {
+      if (small) {
+        LaunchScope _ls(e, "k_runs_count");
+        hipLaunchKernelGGL(k_runs_count, dim3(nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, st, (const RunsInfo*)info);
+      }
       {
         LaunchScope _ls(e, "k_emit_dec_runs");
         hipLaunchKernelGGL(k_emit_dec_runs, dim3(std::min(nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, n, nchunks, st, info, n_out,
@@ -998,9 +1021,35 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     }
     e->X.gate = 1; /* the partition kernels below run only if k_runs_check raised *X.unsorted */
   }
-  /* (ii) the partition pipeline */
-  ar_partition(e, n, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp,
-               d_kind, n_out, status);
+  if (n <= GPX_SAR_MAX_N && e->S.G <= GPX_SAR_MAX_G && e->sar_votes_per_wg > 0) {
+    /* (ii) a small call, whatever its order: ONE launch (gpx_small.hip.h) */
+    const int W = std::max(1, std::min({GPX_SAR_MAX_WG, (n + e->sar_votes_per_wg - 1) / e->sar_votes_per_wg, (int)e->S.G}));
+    if (++e->small_epoch == 0) {
+      HIPQ(hipMemsetAsync(e->small_tickets, 0, 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK) * sizeof(unsigned long long), e->stream));
+      e->small_epoch = 1;
+    }
+    e->last.kind = 0; /* dense outputs, always */
+    static_assert(GPX_SAR_MAX_WG <= 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK), "one ticket per workgroup");
+    {
+      LaunchScope _ls(e, "k_ar_small");
+#define GPX_LAUNCH_AR_SMALL(KM)                                                                                          \
+  hipLaunchKernelGGL(k_ar_small<KM>, dim3(W), dim3(GPX_SAR_BLOCK), GPX_SAR_LDS_BYTES, e->stream, e->S, e->X, n, gidx, bnum, \
+                     bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, status, \
+                     e->small_tickets, e->small_epoch, e->small_draw, e->small_drawn, W, e->X.gate)
+      if (e->cfg.kmax <= 4)
+        GPX_LAUNCH_AR_SMALL(4);
+      else if (e->cfg.kmax <= 8)
+        GPX_LAUNCH_AR_SMALL(8);
+      else
+        GPX_LAUNCH_AR_SMALL(16);
+#undef GPX_LAUNCH_AR_SMALL
+    }
+    e->small_drawn += (uint32_t)W;
+  } else {
+    /* (iii) the partition pipeline */
+    ar_partition(e, n, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp,
+                 d_kind, n_out, status);
+  }
   e->X.gate = 0;
   end_call(e, fs);
   HIPCHK(hipGetLastError());
@@ -1237,9 +1286,13 @@ int gpx_compact_last_dev(gpx_engine* h) {
   gpx_engine::LastCall& L = e->last;
   if (L.kind == 1 || L.kind == 2) {
     launch_one_compaction(e, L);
-  } else if (L.kind == 3) {
+  } else if (L.kind == 3 || L.kind == 4) {
     const DevScratch X0 = e->X;
     e->X = L.X;
+    if (L.kind == 4) { /* a small call counted nothing per chunk (k_ar_runs<.., SMALL>) */
+      LaunchScope _ls(e, "k_runs_count");
+      hipLaunchKernelGGL(k_runs_count, dim3(L.nchunks), dim3(GPX_DCHUNK), 0, e->stream, e->X, L.n, L.rs, (const RunsInfo*)L.info);
+    }
     {
       LaunchScope _ls(e, "k_emit_dec_runs");
       hipLaunchKernelGGL(k_emit_dec_runs, dim3(std::min(L.nchunks, GPX_EMIT_GRID)), dim3(GPX_DCHUNK), 0, e->stream, e->X, L.n, L.nchunks,

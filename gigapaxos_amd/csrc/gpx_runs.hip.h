@@ -273,9 +273,12 @@ struct RunsIter {
   RunsInfo* info;
   uint32_t epoch;
   int32_t chunk, local;
+  uint8_t* st_ok = nullptr;  /* small calls: no prefill pass ran - the replaying lane marks a vote OK before it judges it */
+  bool count_chunks = true;  /* ... and nothing is counted per chunk (k_runs_count does it for the batch that needs it) */
   __device__ __forceinline__ bool next(Rec& out) {
     if (!rd.locate(gidx, rs, R, g)) return false;
     const int32_t i = rd.p++;
+    if (st_ok) st_ok[i] = GPX_S_OK;
     out.idx = i;
     out.a = slot[i];
     out.b = acceptor[i];
@@ -289,10 +292,12 @@ struct RunsIter {
     const int32_t i = pk.p++;
     st.D.put(i, g, sl, x, y, z, kind);
     st.tag[i] = epoch;
-    if ((i >> GPX_DCHUNK_SHIFT) == chunk)
+    if (!count_chunks) {
+    } else if ((i >> GPX_DCHUNK_SHIFT) == chunk) {
       local++;
-    else
+    } else {
       atomicAdd(&st.chunk_cnt[i >> GPX_DCHUNK_SHIFT], 1);
+    }
     if (i >= rs[1]) info->need_merge = 1; /* parked outside run 0: record order alone is not gidx order */
   }
 };
@@ -307,7 +312,15 @@ struct RunsIter {
  * four waves per SIMD, each a chain of three dependent load waves - and the kernel took 87 us per 3 M votes */
 #define GPX_RBLOCK 256
 
-template <int KMAX>
+/* SMALL (round 4): a call of at most GPX_SMALL_RUNS_MAX votes in ONE launch - the shape a coordinator really sees
+ * most often: the replies of a few acceptors, each frame at most 2,048 slots (BatchedAcceptReply.java:27).  The
+ * gidx column is L2-resident, so every workgroup judges it itself (in range, at most 16 ascending runs: no
+ * k_runs_check launch, every workgroup arrives at the same run starts), the lane that replays a vote marks its
+ * status (no prefill pass), nothing is counted per chunk, and the LAST workgroup to finish (at most 256 of them:
+ * two levels of arrival counters, 16 workgroups per counter, a cache line apart) publishes the count - or -1 for a
+ * batch that needs the compaction pass - and leaves the run starts in `info` for that pass. */
+#define GPX_SMALL_RUNS_MAX 65536
+template <int KMAX, bool SMALL = false>
 __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X, int32_t n,
                                                        const int32_t* __restrict__ gidx,
                                                        const int32_t* __restrict__ bnum,
@@ -317,18 +330,81 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
                                                        const int32_t* __restrict__ maxcp,
                                                        uint8_t* __restrict__ status, RunsStage st,
                                                        RunsInfo* __restrict__ info, int32_t refuse,
-                                                       int32_t* __restrict__ n_out) {
+                                                       int32_t* __restrict__ n_out, RunsInfo* __restrict__ next_info = nullptr,
+                                                       uint32_t* __restrict__ arrive = nullptr,
+                                                       unsigned long long* __restrict__ acc = nullptr) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
   __shared__ int32_t wsum[GPX_RBLOCK / 64];
+  __shared__ int32_t s_nd, s_start[GPX_RUNS_MAX];
   const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
   const int32_t my_chunk = (int32_t)(((int64_t)blockIdx.x * GPX_RBLOCK) >> GPX_DCHUNK_SHIFT);
-  if (*X.unsorted == X.epoch) {
-    /* not a few sorted runs: the partition pipeline launched behind does it - or, under the
-     * GPX_ORDERED_REPLY_RUNS promise (no partition pipeline launched), the batch is refused whole */
-    if (refuse && i < n && status) status[i] = GPX_S_UNORDERED;
-    return; /* (k_runs_check's last workgroup wrote n_out = 0 for the refused batch) */
+  int32_t R;
+  if (SMALL) {
+    /* every workgroup reads the whole column: eight 16-byte loads in flight per lane and round */
+    if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(RunsInfo) / 4)) ((int32_t*)next_info)[threadIdx.x] = 0;
+    if (threadIdx.x == 0) s_nd = 0;
+    __syncthreads();
+    bool bad = false;
+    const bool vec = !((uintptr_t)gidx & 15);
+    for (int32_t r0 = 0; r0 < n; r0 += 8 * 4 * GPX_RBLOCK) {
+      int32_t gg[8][5];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int32_t i0 = r0 + (k * GPX_RBLOCK + (int32_t)threadIdx.x) * 4;
+        gg[k][0] = (i0 > 0 && i0 < n) ? gidx[i0 - 1] : INT32_MIN;
+        if (vec && i0 + 3 < n) {
+          const I4 v = *(const I4*)(gidx + i0);
+          gg[k][1] = v.x, gg[k][2] = v.y, gg[k][3] = v.z, gg[k][4] = v.w;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; q++) gg[k][q + 1] = i0 + q < n ? gidx[i0 + q] : INT32_MAX;
+        }
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int32_t i0 = r0 + (k * GPX_RBLOCK + (int32_t)threadIdx.x) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          if (i0 + q >= n) continue;
+          bad |= (uint32_t)gg[k][q + 1] >= (uint32_t)S.G;
+          if (i0 + q > 0 && gg[k][q] > gg[k][q + 1]) { /* a descent: a run starts here */
+            const int32_t k2 = atomicAdd(&s_nd, 1);
+            if (k2 < GPX_RUNS_MAX - 1)
+              s_start[k2 + 1] = i0 + q;
+            else
+              bad = true;
+          }
+        }
+      }
+    }
+    if (__syncthreads_or(bad)) { /* not a few ascending runs in range */
+      if (refuse) {
+        if (i < n && status) status[i] = GPX_S_UNORDERED;
+        if (i == 0 && n_out) *n_out = 0;
+      } else if (i == 0) {
+        atomicMax(X.unsorted, X.epoch); /* the partition pipeline launched behind takes the batch */
+      }
+      return;
+    }
+    const int32_t nd = s_nd;
+    if (threadIdx.x <= (unsigned)nd) { /* rank sort of at most 16 distinct values (runs_load's) */
+      const int32_t v = threadIdx.x == 0 ? 0 : s_start[threadIdx.x];
+      int32_t rk = 0;
+      for (int32_t q = 1; q <= nd; q++) rk += s_start[q] < v;
+      rs[threadIdx.x == 0 ? 0 : rk + 1] = v;
+    }
+    if (threadIdx.x == 0) rs[nd + 1] = n;
+    __syncthreads();
+    R = nd + 1;
+  } else {
+    if (*X.unsorted == X.epoch) {
+      /* not a few sorted runs: the partition pipeline launched behind does it - or, under the
+       * GPX_ORDERED_REPLY_RUNS promise (no partition pipeline launched), the batch is refused whole */
+      if (refuse && i < n && status) status[i] = GPX_S_UNORDERED;
+      return; /* (k_runs_check's last workgroup wrote n_out = 0 for the refused batch) */
+    }
+    R = runs_load(info, n, rs);
   }
-  const int32_t R = runs_load(info, n, rs);
   if (i == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
   int32_t local = 0;
   bool irregular = false; /* this lane saw why the columns are not dense as parked (travels with the arrival counters) */
@@ -391,6 +467,11 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
           }
         }
         sg.finish(S, g, sl[0]);
+        if (SMALL && status) {
+#pragma unroll
+          for (int q = 0; q < GPX_RUNS_FAST; q++)
+            if (q < R) status[rs[q] + o] = GPX_S_OK; /* this lane's votes: one per run, at its own offset */
+        }
         if (dec) { /* the group's first (only) output: parked at its first vote = this lane's record */
           st.D.put(i, g, sl[0], P.my_bnum, P.my_bcoord, dmed, GPX_D_DECISION);
           st.tag[i] = X.epoch;
@@ -429,6 +510,10 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       it.epoch = X.epoch;
       it.chunk = my_chunk;
       it.local = 0;
+      if (SMALL) {
+        it.st_ok = status;
+        it.count_chunks = false;
+      }
       if (!have_p) {
         coord_preload<KMAX>(S, g, P);
         coord_preload_ring<KMAX>(S, g, P);
@@ -451,12 +536,45 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       tot += wsum[w] & 0x3fffffff;
       wg_irregular |= (wsum[w] & 0x40000000) != 0;
     }
-    if (tot) atomicAdd(&st.chunk_cnt[my_chunk], tot);
-    /* a REGULAR batch is finished: k_runs_check's last workgroup wrote its count (one decision per record of run 0,
-     * dense as parked).  A workgroup that saw otherwise says so: k_emit_dec_runs / k_merge_runs follow (at once, or
-     * on gpx_compact_last_dev under GPX_LAZY_OUTPUTS) */
-    if (wg_irregular && n_out) __hip_atomic_store(n_out, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (!SMALL) {
+      if (tot) atomicAdd(&st.chunk_cnt[my_chunk], tot);
+      /* a REGULAR batch is finished: k_runs_check's last workgroup wrote its count (one decision per record of run
+       * 0, dense as parked).  A workgroup that saw otherwise says so: k_emit_dec_runs / k_merge_runs follow (at
+       * once, or on gpx_compact_last_dev under GPX_LAZY_OUTPUTS) */
+      if (wg_irregular && n_out) __hip_atomic_store(n_out, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      const int32_t nwg = (int32_t)gridDim.x, grp = (int32_t)blockIdx.x >> 4;
+      const uint32_t size1 = (uint32_t)min(16, nwg - (grp << 4));
+      bool last = false, any = wg_irregular;
+      const uint32_t old1 = atomicAdd(&arrive[32 * (1 + grp)], 1u + (wg_irregular ? 0x10000u : 0u));
+      if ((old1 & 0xffffu) + 1u == size1) {
+        any |= (old1 >> 16) != 0;
+        __hip_atomic_store(&arrive[32 * (1 + grp)], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t old0 = atomicAdd(&arrive[0], 1u + (any ? 0x10000u : 0u));
+        if ((old0 & 0xffffu) + 1u == (uint32_t)((nwg + 15) >> 4)) {
+          any |= (old0 >> 16) != 0;
+          __hip_atomic_store(&arrive[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          last = true;
+        }
+      }
+      if (last) { /* what the compaction pass reads (it runs behind this kernel, if at all) and the count */
+        info->n_desc = R - 1;
+        for (int32_t q = 1; q < R; q++) info->start[q] = rs[q];
+        info->general_used = any ? 1 : 0;
+        info->total = any ? 0 : rs[1];
+        if (n_out) *n_out = any ? -1 : rs[1];
+        if (!any && acc) atomicAdd(acc, (unsigned long long)rs[1]);
+      }
+    }
   }
+}
+
+/* small calls, irregular batches only: parked outputs per 1024-record chunk (k_ar_runs<.., SMALL> counts nothing) */
+__global__ __launch_bounds__(GPX_DCHUNK) void k_runs_count(DevScratch X, int32_t n, RunsStage st, const RunsInfo* __restrict__ info) {
+  if (!info->general_used || *X.unsorted == X.epoch) return;
+  const int32_t i = (int32_t)blockIdx.x * GPX_DCHUNK + (int32_t)threadIdx.x;
+  const int32_t c = __syncthreads_count(i < n && st.tag[i] == X.epoch);
+  if (threadIdx.x == 0) st.chunk_cnt[blockIdx.x] = c;
 }
 
 /* regular batch: the caller's columns are final already - publish the count.  Otherwise: parked outputs ->

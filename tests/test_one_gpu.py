@@ -171,12 +171,12 @@ def test_lazy_outputs_on_the_device_path(hip_lib, oracle_lib):
     eh.close(), eo.close()
 
 
-@pytest.mark.parametrize("K", [3, 5])
-def test_lazy_reply_runs(hip_lib, oracle_lib, K):
+@pytest.mark.parametrize("K,G", [(3, 150_000), (5, 150_000), (3, 20_000), (5, 9_000)])
+def test_lazy_reply_runs(hip_lib, oracle_lib, K, G):
     """Accept replies as K ascending runs under ORDERED_REPLY_RUNS | LAZY_OUTPUTS: the regular round's count is
-    published by k_ar_runs itself; a round with lost votes comes back negative and is compacted on demand."""
+    published without a compaction launch (by k_runs_check; calls of at most 65,536 votes: by the ONE kernel they
+    take, k_ar_runs<.., SMALL>); a round with lost votes comes back negative and is compacted on demand."""
     import torch
-    G = 150_000
     members = list(range(100, 100 + K))
     eh, eo = make_pair(hip_lib, oracle_lib, 100, G, K, 8, max_batch=K * G + 64)
     mem = np.tile(np.array(members, np.int32), (G, 1))
@@ -203,6 +203,7 @@ def test_lazy_reply_runs(hip_lib, oracle_lib, K):
         torch.cuda.synchronize()
         prof = eh.profile_read()
         assert "k_emit_dec_runs" not in prof and "k_merge_runs" not in prof, prof
+        assert (list(prof) == ["k_ar_runs_small"]) == (n <= 65536), prof
         do = eo.accept_reply(*cols)
         if r % 2 == 0:
             assert int(no.item()) == G
