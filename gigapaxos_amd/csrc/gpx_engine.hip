@@ -176,8 +176,10 @@ struct gpx_engine {
   int64_t nm_tomb = 0;
   std::vector<int32_t> free_rows;
   bool free_init = false;
-  int32_t *w_cnt = nullptr, *w_tile = nullptr, *w_err = nullptr;
-  long long* w_tile_b = nullptr;
+  /* k_pack_one (gpx_wire.hip.h): one ticket per tile of 256 rows, the tiles drawn so far and the launch's epoch */
+  unsigned long long* w_pack_ticket = nullptr;
+  uint32_t* w_pack_draw = nullptr;
+  uint32_t w_pack_drawn = 0, w_pack_epoch = 0;
   unsigned long long* w_look = nullptr; /* [4][tiles] look-back words of the one-launch decode */
   uint32_t* w_ticket = nullptr;
   uint32_t w_epoch = 0;

@@ -22,6 +22,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--groups", type=int, default=1_000_000)
     ap.add_argument("--rounds", type=int, default=6)
+    ap.add_argument("--min-log2", type=int, default=16)
+    ap.add_argument("--max-log2", type=int, default=24)
     args = ap.parse_args()
     G, K, R = args.groups, 3, args.rounds
     ids = [100, 101, 102]
@@ -51,7 +53,7 @@ def main():
     n_out = torch.zeros(1, dtype=torch.int32, device=dev)
     v_st = torch.empty(N, dtype=torch.uint8, device=dev)
     p = [torch.empty(G, dtype=torch.int32, device=dev) for _ in range(4)] + [torch.empty(G, dtype=torch.uint8, device=dev)]
-    for lb in range(16, 25):
+    for lb in range(args.min_log2, args.max_log2 + 1):
         B = 1 << lb
         e = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=max(B, G) + 1024)
         assert (e.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()

@@ -129,7 +129,7 @@ def test_acceptor_side_at_the_int_wrap(hip_lib, base):
     import numpy as np
     import tests.acc_enum_common as A
     rng = np.random.default_rng(base % 1000)
-    for L, count in ((2, None), (4, 60_000), (8, 40_000)):
+    for L, count in ((2, None), (4, 30_000), (8, 20_000)):
         seqs = ([(a, b) for a in A.WIDE for b in A.WIDE[::2]] if count is None else
                 [tuple(A.WIDE[i] for i in row) for row in rng.integers(0, len(A.WIDE), (count, L)).tolist()])
         for order, init in (("interleaved", "create"), ("grouped", "initial")):
@@ -145,5 +145,5 @@ def test_whole_round_across_the_int_wrap(hip_lib, base, K, kw):
     from tests.round_model import run_rounds
     kw = dict(kw)
     kw.setdefault("from_disk", True)
-    checked, executed = run_rounds(hip_lib, 10_000, 16, 7, p_drop=0.12, K=K, base=base, **kw)
-    assert checked > 1_000_000
+    checked, executed = run_rounds(hip_lib, 5_000, 16, 7, p_drop=0.12, K=K, base=base, **kw)
+    assert checked > 500_000
