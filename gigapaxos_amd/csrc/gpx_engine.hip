@@ -645,6 +645,11 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     for (const void* f : fns)
       HIPCHK_CREATE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
   }
+  { /* the one-launch small accept-reply kernel stages 80 KiB (gpx_small.hip.h) */
+    const void* fns[] = {(const void*)k_ar_small<4>, (const void*)k_ar_small<8>, (const void*)k_ar_small<16>};
+    for (const void* f : fns)
+      HIPCHK_CREATE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GPX_SAR_LDS_BYTES));
+  }
   { /* k_hist may take up to GPX_HSUB_MAX histograms of dynamic LDS */
     const int hl = GPX_HSUB_MAX * std::max(X.nbk, e->nbk16) * (int)sizeof(int32_t);
     if (hl > 64 * 1024) {
@@ -932,6 +937,30 @@ static void ar_partition(gpx_engine* e, int32_t n, const int32_t* gidx, const in
   }
 }
 
+#ifdef GPX_SAR_TRACE
+/* timeline build: the stamps of the call's workgroups (256 x 16 words) cleared before the launch, written to
+ * GPX_SAR_TRACE_FILE after it (every call: the last one wins) */
+static unsigned long long* sar_trace_dev = nullptr;
+static void sar_trace_begin(gpx_engine* e) {
+  if (!sar_trace_dev) {
+    HIPQ(hipMalloc(&sar_trace_dev, 256 * 16 * sizeof(unsigned long long)));
+    HIPQ(hipMemcpyToSymbol(HIP_SYMBOL(g_sar_trace), &sar_trace_dev, sizeof(sar_trace_dev)));
+  }
+  HIPQ(hipMemsetAsync(sar_trace_dev, 0, 256 * 16 * sizeof(unsigned long long), e->stream));
+}
+static void sar_trace_end(gpx_engine* e) {
+  const char* tf = getenv("GPX_SAR_TRACE_FILE");
+  if (!tf) return;
+  HIPQ(hipStreamSynchronize(e->stream));
+  std::vector<unsigned long long> tr(256 * 16);
+  HIPQ(hipMemcpy(tr.data(), sar_trace_dev, tr.size() * 8, hipMemcpyDeviceToHost));
+  if (FILE* fp = fopen(tf, "wb")) {
+    fwrite(tr.data(), 8, tr.size(), fp);
+    fclose(fp);
+  }
+}
+#endif
+
 int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
                                const int32_t* bnum, const int32_t* bcoord, const int32_t* slot,
                                const int32_t* acceptor, const int32_t* max_cp, int32_t* d_gidx,
@@ -976,6 +1005,9 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
       LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
                 gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
                 refuse);
+#ifdef GPX_SAR_TRACE
+    if (small) sar_trace_begin(e);
+#endif
     {
       LaunchScope _ls(e, small ? "k_ar_runs_small" : "k_ar_runs");
       const dim3 grid((n + GPX_RBLOCK - 1) / GPX_RBLOCK);
@@ -998,6 +1030,9 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
         GPX_LAUNCH_AR_RUNS(16);
 #undef GPX_LAUNCH_AR_RUNS
     }
+#ifdef GPX_SAR_TRACE
+    if (small && runs_promised) sar_trace_end(e);
+#endif
     /* a REGULAR batch is finished: k_ar_runs' last workgroup has published its count.  The compaction pass of any
      * other batch follows at once - or, under the promise with GPX_LAZY_OUTPUTS, when the caller asks for it */
     e->last.kind = 0;
@@ -1031,6 +1066,9 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
       e->small_epoch = 1;
     }
     e->last.kind = 0; /* dense outputs, always */
+#ifdef GPX_SAR_TRACE
+    if (!e->X.gate) sar_trace_begin(e);
+#endif
     static_assert(GPX_SAR_MAX_WG <= 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK), "one ticket per workgroup");
     {
       LaunchScope _ls(e, "k_ar_small");
@@ -1046,6 +1084,9 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
         GPX_LAUNCH_AR_SMALL(16);
 #undef GPX_LAUNCH_AR_SMALL
     }
+#ifdef GPX_SAR_TRACE
+    if (!e->X.gate) sar_trace_end(e);
+#endif
     e->small_drawn += (uint32_t)W;
   } else {
     /* (iii) the partition pipeline */

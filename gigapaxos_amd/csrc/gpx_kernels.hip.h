@@ -33,6 +33,18 @@
 
 #include "../../include/gpx.h"
 
+/* timeline build (-DGPX_SAR_TRACE, scripts/ubench/sar_trace.sh; never shipped): wall-clock stamps of thread 0 of
+ * every workgroup of the last small call */
+#ifdef GPX_SAR_TRACE
+__device__ unsigned long long* g_sar_trace = nullptr;
+#define SAR_STAMP(wg, k)                                                                             \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && g_sar_trace) g_sar_trace[(size_t)(wg) * 16 + (k)] = wall_clock64();        \
+  } while (0)
+#else
+#define SAR_STAMP(wg, k) do { } while (0)
+#endif
+
 /* Plain aggregates for packed records and ring entries (not HIP's int4: plain structs give the
  * same dwordx4 accesses and keep the code independent of the vector-type accessor proxies). */
 struct __attribute__((aligned(16))) I4 {
@@ -946,7 +958,9 @@ struct CoordPre {
   uint32_t gf;
   int32_t my_bnum, my_bcoord, next, pcount;
   int32_t mem[KMAX], ns[KMAX];
-  uint32_t pe; /* speculative: myProposals entry of slot next - 1 (the usual outstanding slot) */
+  uint32_t pe; /* speculative: myProposals entry of slot pe_slot = next - 1 (the usual outstanding slot), or of the
+                * group's first vote's slot (coord_preload_ring_at) */
+  int32_t pe_slot;
   bool have_pe;
 };
 template <int KMAX>
@@ -963,11 +977,21 @@ __device__ __forceinline__ void coord_preload(const DevState& S, int32_t g, Coor
     P.ns[j] = (j < S.kmax) ? S.node_slots[(int64_t)j * G + g] : 0;
   }
   P.pe = 0;
+  P.pe_slot = 0;
   P.have_pe = false;
 }
 template <int KMAX>
 __device__ __forceinline__ void coord_preload_ring(const DevState& S, int32_t g, CoordPre<KMAX>& P) {
-  P.pe = S.p_ring[(int64_t)(jsub(P.next, 1) & (S.W - 1)) * S.G + g];
+  P.pe_slot = jsub(P.next, 1);
+  P.pe = S.p_ring[(int64_t)(P.pe_slot & (S.W - 1)) * S.G + g];
+  P.have_pe = true;
+}
+/* the ring entry of a slot the caller already knows (its first vote's): requested TOGETHER with coord_preload's
+ * loads, not behind `next` - one round trip instead of two (the entry of any slot value lies inside the ring) */
+template <int KMAX>
+__device__ __forceinline__ void coord_preload_ring_at(const DevState& S, int32_t g, int32_t slot, CoordPre<KMAX>& P) {
+  P.pe_slot = slot;
+  P.pe = S.p_ring[(int64_t)(slot & (S.W - 1)) * S.G + g];
   P.have_pe = true;
 }
 
@@ -1009,7 +1033,7 @@ __device__ __forceinline__ void apply_ar_group(const DevState& S, const DevScrat
   bool ns_dirty = false;
   /* one-entry write-back register cache over this group's myProposals ring: the K votes of one
    * slot (the normal case) cost one load and one store instead of K dependent round trips */
-  int64_t pc_off = P.have_pe ? ((int64_t)(jsub(next, 1) & Wm) * G + g) : -1;
+  int64_t pc_off = P.have_pe ? ((int64_t)(P.pe_slot & Wm) * G + g) : -1;
   uint32_t pc_val = P.pe;
   bool pc_dirty = false;
   auto pr_load = [&](int64_t off) -> uint32_t {

@@ -339,42 +339,51 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
   const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
   const int32_t my_chunk = (int32_t)(((int64_t)blockIdx.x * GPX_RBLOCK) >> GPX_DCHUNK_SHIFT);
   int32_t R;
+#ifdef GPX_SAR_TRACE
+  if (SMALL) SAR_STAMP(blockIdx.x, 0);
+#endif
   if (SMALL) {
-    /* every workgroup reads the whole column: eight 16-byte loads in flight per lane and round */
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(RunsInfo) / 4)) ((int32_t*)next_info)[threadIdx.x] = 0;
     if (threadIdx.x == 0) s_nd = 0;
     __syncthreads();
+    /* Straight-line per entry (the first build branched per entry: 12.6 of the kernel's 13.8 us at 30,000 votes,
+     * profiles/r04_sar_trace_1.txt): 16 entries and their predecessors in flight per lane, none behind a branch (an
+     * index outside the batch is clamped for the load); only a lane that saw a descent - there are at most 15 in a
+     * batch that keeps the shape - goes back over its entries to record the run starts */
     bool bad = false;
-    const bool vec = !((uintptr_t)gidx & 15);
-    for (int32_t r0 = 0; r0 < n; r0 += 8 * 4 * GPX_RBLOCK) {
-      int32_t gg[8][5];
+    for (int32_t r0 = 0; r0 < n; r0 += 16 * GPX_RBLOCK) {
+      int32_t gg[16], gp[16];
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int32_t i0 = r0 + (k * GPX_RBLOCK + (int32_t)threadIdx.x) * 4;
-        gg[k][0] = (i0 > 0 && i0 < n) ? gidx[i0 - 1] : INT32_MIN;
-        if (vec && i0 + 3 < n) {
-          const I4 v = *(const I4*)(gidx + i0);
-          gg[k][1] = v.x, gg[k][2] = v.y, gg[k][3] = v.z, gg[k][4] = v.w;
-        } else {
-#pragma unroll
-          for (int q = 0; q < 4; q++) gg[k][q + 1] = i0 + q < n ? gidx[i0 + q] : INT32_MAX;
-        }
+      for (int k = 0; k < 16; k++) {
+        const int32_t i1 = r0 + k * GPX_RBLOCK + (int32_t)threadIdx.x;
+        gg[k] = gidx[min(i1, n - 1)];
+        gp[k] = gidx[max(min(i1, n - 1) - 1, 0)];
       }
+      uint32_t dm = 0;
 #pragma unroll
-      for (int k = 0; k < 8; k++) {
-        const int32_t i0 = r0 + (k * GPX_RBLOCK + (int32_t)threadIdx.x) * 4;
+      for (int k = 0; k < 16; k++) {
+        const int32_t i1 = r0 + k * GPX_RBLOCK + (int32_t)threadIdx.x;
+        const bool valid = i1 < n;
+        bad |= valid && (uint32_t)gg[k] >= (uint32_t)S.G;
+        dm |= (valid && i1 > 0 && gp[k] > gg[k]) ? (1u << k) : 0u; /* a descent: a run starts here */
+      }
+      /* a shuffled batch (the GPX_TRY_REPLY_RUNS hint on a batch that is no few runs) has a descent at every other
+       * entry: judged per wave, without touching the shared counter */
+      int32_t wd = __popc(dm);
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          if (i0 + q >= n) continue;
-          bad |= (uint32_t)gg[k][q + 1] >= (uint32_t)S.G;
-          if (i0 + q > 0 && gg[k][q] > gg[k][q + 1]) { /* a descent: a run starts here */
-            const int32_t k2 = atomicAdd(&s_nd, 1);
-            if (k2 < GPX_RUNS_MAX - 1)
-              s_start[k2 + 1] = i0 + q;
-            else
-              bad = true;
-          }
-        }
+      for (int d = 32; d >= 1; d >>= 1) wd += __shfl_xor(wd, d, 64);
+      if (wd > GPX_RUNS_MAX - 1) {
+        bad = true;
+        dm = 0;
+      }
+      while (dm) {
+        const int k = __ffs((int)dm) - 1;
+        dm &= dm - 1;
+        const int32_t k2 = atomicAdd(&s_nd, 1);
+        if (k2 < GPX_RUNS_MAX - 1)
+          s_start[k2 + 1] = r0 + k * GPX_RBLOCK + (int32_t)threadIdx.x;
+        else
+          bad = true;
       }
     }
     if (__syncthreads_or(bad)) { /* not a few ascending runs in range */
@@ -396,6 +405,9 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
     if (threadIdx.x == 0) rs[nd + 1] = n;
     __syncthreads();
     R = nd + 1;
+#ifdef GPX_SAR_TRACE
+    SAR_STAMP(blockIdx.x, 1); /* column judged, run starts sorted */
+#endif
   } else {
     if (*X.unsorted == X.epoch) {
       /* not a few sorted runs: the partition pipeline launched behind does it - or, under the
@@ -484,6 +496,9 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       }
     }
   }
+#ifdef GPX_SAR_TRACE
+  if (SMALL) SAR_STAMP(blockIdx.x, 2); /* straight-line replay done (thread 0) */
+#endif
   if (!done) {
     /* the owner of a group: no earlier run holds it (tested first: one load for a lane of an alike later
      * run), and it is the group's first record in its run */
@@ -529,6 +544,9 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
   const bool wave_irregular = __any(irregular) != 0;
   if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = x | (wave_irregular ? (int32_t)0x40000000 : 0);
   __syncthreads();
+#ifdef GPX_SAR_TRACE
+  if (SMALL) SAR_STAMP(blockIdx.x, 3); /* every lane done */
+#endif
   if (threadIdx.x == 0) {
     int32_t tot = 0;
     bool wg_irregular = false;

@@ -47,30 +47,32 @@
 #define GPX_SAR_VPT 2                               /* votes a thread carries through the regrouping */
 #define GPX_SAR_CAP (GPX_SAR_BLOCK * GPX_SAR_VPT)   /* votes staged per pass */
 #define GPX_SAR_MAX_WG 128
-#define GPX_SAR_LDS_BYTES ((2 * GPX_SAR_BLOCK + 6 * GPX_SAR_CAP) * 4)
+#define GPX_SAR_ROUND (32 * GPX_SAR_BLOCK)          /* column entries one scan round covers: 32 per lane */
+#define GPX_SAR_ROUNDS (GPX_SAR_MAX_N / GPX_SAR_ROUND)
+#define GPX_SAR_LDS_BYTES ((2 * GPX_SAR_BLOCK + 9 * GPX_SAR_CAP) * 4)
+#define GPX_SAR_LONG 0xffffffffu /* gA: this sorted position belongs to a lane that replays its votes itself */
 
-/* One lane's votes in (group, arrival) order, with GroupIter's interface (next / emit) for apply_ar_group.  Ranks
- * [done, c) are the CURRENT group's votes; positions come from the nibble word (at most 16 votes in the lane) or
- * from the lane's sorted keys (key << 32 | position) in global scratch. */
+/* One group's votes in arrival order, with GroupIter's interface (next / emit) for apply_ar_group.  Ranks
+ * [done, c) are the group's votes; rank r's position in the LDS arrays is
+ *   perm: ranks[r] (the balanced replay: one thread per group, the lanes published their sorted positions),
+ *   else: the low word of keys[r], the lane's sorted keys (key << 32 | position) in global scratch (a lane with
+ *         more than 16 votes replays its own, group by group; its outputs' positions come back in keys[0 .. nout)). */
 struct SmallArIter {
-  const int32_t* keyA;
+  int32_t* keyA;
   int32_t *slotA, *cpA;
   uint32_t* metaA;
   int32_t *xA, *yA;
-  unsigned long long* keys;
+  const int32_t* ranks;     /* perm: positions of this group's votes, by rank */
+  unsigned long long* keys; /* !perm: the lane's sorted keys, by rank */
   VoteCols in;
   int32_t b0n, b0c;
-  int32_t start, c, done, nout;
-  bool nib;
-  unsigned long long order;
+  int32_t c, done, nout, relg;
+  bool perm;
   uint32_t omask;
   uint32_t cur;
-  __device__ __forceinline__ uint32_t pos(int32_t r) const {
-    return nib ? (uint32_t)start + (uint32_t)((order >> (4 * r)) & 15ull) : (uint32_t)keys[r];
-  }
   __device__ __forceinline__ bool next(Rec& out) {
     if (done >= c) return false;
-    const uint32_t p = pos(done);
+    const uint32_t p = perm ? (uint32_t)ranks[done] : (uint32_t)keys[done];
     const int32_t ix = (int32_t)((uint32_t)keyA[p] & GPX_SAR_IDX_MASK);
     const uint32_t meta = metaA[p];
     cur = p;
@@ -89,18 +91,19 @@ struct SmallArIter {
     done++;
     return true;
   }
-  /* output of the CURRENT vote, parked in the vote's own words (the key stays: it names the group) */
+  /* output of the CURRENT vote, parked in the vote's own words; its key word now names the group (relative to the
+   * pass's first group): the vote is consumed, nobody needs its arrival index any more */
   __device__ __forceinline__ void emit(int32_t slot, int32_t x, int32_t y, int32_t z, int32_t kind) {
     slotA[cur] = slot;
     cpA[cur] = z;
     metaA[cur] = (uint32_t)kind;
     xA[cur] = x;
     yA[cur] = y;
-    if (nib)
+    keyA[cur] = relg;
+    if (perm)
       omask |= 1u << (done - 1);
     else
-      keys[nout] = cur; /* entry nout <= done - 1: consumed */
-    nout++;
+      keys[nout++] = cur; /* entry nout <= done - 1: consumed */
   }
 };
 
@@ -114,12 +117,19 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
     unsigned long long* __restrict__ tickets, uint32_t epoch, uint32_t* __restrict__ draw, uint32_t draw_base,
     int32_t W, int32_t gate) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  __shared__ int32_t s_w, s_nb, s_lower, s_before;
+  __shared__ int32_t s_w, s_lower, s_before;
   const int32_t t = (int32_t)threadIdx.x;
+#ifdef GPX_SAR_TRACE
+  const unsigned long long t_entry = wall_clock64();
+#endif
   /* the range is DRAWN, not read off blockIdx (k_ac_small): always, so that the host's count of draws stays true */
   if (t == 0) s_w = (int32_t)(atomicAdd(draw, 1u) - draw_base);
   __syncthreads();
   const int32_t w = s_w;
+#ifdef GPX_SAR_TRACE
+  if (t == 0 && g_sar_trace) g_sar_trace[(size_t)w * 16] = t_entry;
+#endif
+  SAR_STAMP(w, 1); /* drawn */
   /* launched behind the sorted-runs attempt (GPX_TRY_REPLY_RUNS): only a batch it gave up on is this kernel's */
   if (gate && *X.unsorted != X.epoch) return;
   int32_t* lcnt = lds;
@@ -130,6 +140,9 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
   uint32_t* metaA = (uint32_t*)(cpA + GPX_SAR_CAP);
   int32_t* xA = (int32_t*)(metaA + GPX_SAR_CAP);
   int32_t* yA = xA + GPX_SAR_CAP;
+  int32_t* permA = yA + GPX_SAR_CAP;             /* sorted position -> position in the arrays above */
+  uint32_t* gA = (uint32_t*)(permA + GPX_SAR_CAP); /* sorted position -> group (relative to the pass's first), or LONG */
+  uint32_t* outA = gA + GPX_SAR_CAP;             /* sorted position of a group's first vote -> its outputs */
   int32_t* idxS = xA; /* the collected arrival indices: read before the placement, xA is written by the replay */
   const int32_t G = S.G;
   const int32_t RG = (int32_t)(((int64_t)G + W - 1) / W);
@@ -137,7 +150,25 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
   const int32_t hi = (int32_t)min((int64_t)G, (int64_t)lo + RG);
   const int32_t b0n = bnum[0], b0c = bcoord[0];
   const VoteCols in{bnum, bcoord, acceptor};
-  const bool vec = !((uintptr_t)gidx & 15);
+
+  /* This workgroup's SLICE of the batch (arrival indices): votes outside the table are marked and counted here,
+   * once per call (PaxosManager.java:1162-1194) - every vote lies in exactly one slice, whatever its group. */
+  {
+    const int32_t slice = (n + W - 1) / W;
+    const int32_t s0 = (int32_t)min((int64_t)n, (int64_t)w * slice), s1 = (int32_t)min((int64_t)n, (int64_t)s0 + slice);
+    int32_t bad = 0;
+    for (int32_t i = s0 + t; i < s1; i += GPX_SAR_BLOCK) {
+      if ((uint32_t)gidx[i] >= (uint32_t)G) {
+        bad++;
+        if (status) status[i] = GPX_S_NOGROUP;
+      }
+    }
+    if (__any(bad != 0)) {
+#pragma unroll
+      for (int d = 32; d >= 1; d >>= 1) bad += __shfl_xor(bad, d, 64);
+      if ((t & 63) == 0) atomicAdd(&X.counters[2], (unsigned long long)bad);
+    }
+  }
 
   /* sum of the tickets before this workgroup's (each depends on its own workgroup only) */
   auto wait_earlier = [&]() -> int32_t {
@@ -158,83 +189,80 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
 
   int32_t running = 0; /* outputs of this workgroup's earlier passes */
   int32_t base = -1;   /* outputs of the workgroups before this one (once known) */
-  bool published = false, first_scan = true;
+  bool published = false;
   int32_t cur = lo, ghi = hi, ilo = 0, ihi = n;
   int32_t span_hint = hi - lo; /* width of the next range to try (narrowed by a pass that overflowed) */
   while (cur < hi) {
-    /* ---- collect: the votes of groups [cur, ghi) with arrival index in [ilo, ihi) ---- */
-    if (t == 0) {
-      s_nb = 0;
-      s_lower = 0;
-    }
+    /* ---- collect: the votes of groups [cur, ghi) with arrival index in [ilo, ihi).  Straight-line per entry (a
+     * compare and a mask bit: the first build branched per entry and spent 19 of its 66 us here,
+     * profiles/r04_sar_trace_1.txt): thread t reads entries k * 1024 + t of every round of 32,768, bit k of the
+     * round's mask word says "mine" ---- */
+    if (t == 0) s_lower = 0;
     lcnt[t] = 0;
     __syncthreads();
+    uint32_t* mkS = (uint32_t*)keyA; /* [rounds][1024] mask words (keyA and slotA are free until the placement) */
+    int32_t lower = 0, mine = 0;
     {
       const uint32_t gspan = (uint32_t)(ghi - cur);
-      const bool do_bad = w == 0 && first_scan; /* votes outside the table: marked and counted once per call */
-      int32_t lower = 0, bad = 0;
-      for (int32_t r0 = 0; r0 < n; r0 += 8 * 4 * GPX_SAR_BLOCK) {
-        int32_t gg[8][4];
+      const uint32_t ispan = (uint32_t)(ihi - ilo);
+#pragma unroll 1
+      for (int r = 0; r < GPX_SAR_ROUNDS; r++) {
+        const int32_t r0 = r * GPX_SAR_ROUND;
+        if (r0 >= n) break; /* uniform */
+        uint32_t mk = 0;
+        {
+          /* 32 coalesced dword loads in flight, none of them behind a branch (an index behind the batch's end is
+           * clamped for the load and the entry then counts as INT32_MIN: in no range, below no group) */
+          int32_t gg[32];
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int32_t i0 = r0 + (k * GPX_SAR_BLOCK + t) * 4;
-          if (vec && i0 + 3 < n) {
-            const I4 v = *(const I4*)(gidx + i0);
-            gg[k][0] = v.x, gg[k][1] = v.y, gg[k][2] = v.z, gg[k][3] = v.w;
-          } else {
+          for (int k = 0; k < 32; k++) gg[k] = gidx[min(r0 + k * GPX_SAR_BLOCK + t, n - 1)];
 #pragma unroll
-            for (int q = 0; q < 4; q++) gg[k][q] = i0 + q < n ? gidx[i0 + q] : 0;
+          for (int k = 0; k < 32; k++) {
+            const int32_t i = r0 + k * GPX_SAR_BLOCK + t;
+            const int32_t g = i < n ? gg[k] : INT32_MIN;
+            const bool inr = (uint32_t)(g - cur) < gspan;
+            const bool inw = (uint32_t)(i - ilo) < ispan;
+            mk |= (inr && inw) ? (1u << k) : 0u;
+            /* the votes that come before this pass's in (group, arrival) order: its slice of the key scratch */
+            lower += (((uint32_t)g < (uint32_t)cur) || (inr && i < ilo)) ? 1 : 0;
           }
         }
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-          const int32_t i0 = r0 + (k * GPX_SAR_BLOCK + t) * 4;
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int32_t i = i0 + q;
-            if (i >= n) continue;
-            const int32_t g = gg[k][q];
-            if ((uint32_t)(g - cur) < gspan) {
-              if (i >= ilo && i < ihi) {
-                const int32_t p = atomicAdd(&s_nb, 1);
-                if (p < GPX_SAR_CAP) idxS[p] = i;
-              } else if (i < ilo) {
-                lower++;
-              }
-            } else if ((uint32_t)g < (uint32_t)cur) {
-              lower++;
-            } else if (do_bad && (uint32_t)g >= (uint32_t)G) {
-              bad++;
-              if (status) status[i] = GPX_S_NOGROUP; /* PaxosManager.java:1162-1194 */
-            }
-          }
-        }
-      }
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) {
-        lower += __shfl_xor(lower, d, 64);
-        bad += __shfl_xor(bad, d, 64);
-      }
-      if ((t & 63) == 0) {
-        if (lower) atomicAdd(&s_lower, lower);
-        if (bad) atomicAdd(&X.counters[2], (unsigned long long)bad);
+        mkS[r * GPX_SAR_BLOCK + t] = mk; /* (read back by this thread only) */
+        mine += __popc(mk);
       }
     }
-    first_scan = false;
-    __syncthreads();
-    const int32_t nb = s_nb, boff = s_lower;
-    __syncthreads(); /* (thread 0 resets the two words at the top of the next pass) */
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) lower += __shfl_xor(lower, d, 64);
+    if ((t & 63) == 0 && lower) atomicAdd(&s_lower, lower);
+    int32_t nb;
+    int32_t ex0 = block_exscan_rt(mine, &nb); /* (its barriers also publish s_lower) */
+    const int32_t boff = s_lower;
+    SAR_STAMP(w, 2); /* column scanned */
     if (nb > GPX_SAR_CAP) {
       /* more than one pass stages: narrow the range (aiming at half the capacity), or - one group alone - take
-       * the next GPX_SAR_CAP arrival indices */
+       * the next window of arrival indices */
       if (ghi - cur > 1) {
         ghi = cur + (int32_t)max((int64_t)1, (int64_t)(ghi - cur) * GPX_SAR_CAP / nb / 2);
         span_hint = ghi - cur;
       } else { /* (a window of GPX_SAR_CAP indices always fits: the estimate only ever shrinks towards it) */
         ihi = ilo + (int32_t)max((int64_t)GPX_SAR_CAP, (int64_t)(ihi - ilo) * GPX_SAR_CAP / nb / 2);
       }
+      __syncthreads(); /* (thread 0 resets s_lower at the top of the next pass) */
       continue;
     }
+    uint32_t mkr[GPX_SAR_ROUNDS]; /* (all four read before the first index is stored: idxS lies elsewhere, but keep it so) */
+#pragma unroll
+    for (int r = 0; r < GPX_SAR_ROUNDS; r++) mkr[r] = r * GPX_SAR_ROUND < n ? mkS[r * GPX_SAR_BLOCK + t] : 0u;
+#pragma unroll
+    for (int r = 0; r < GPX_SAR_ROUNDS; r++) {
+      uint32_t m = mkr[r];
+      while (m) {
+        const int e = __ffs((int)m) - 1;
+        m &= m - 1;
+        idxS[ex0++] = r * GPX_SAR_ROUND + e * GPX_SAR_BLOCK + t;
+      }
+    }
+    __syncthreads();
     const bool last = ghi == hi && ihi == n;
     const uint32_t width = ((uint32_t)(ghi - cur) + GPX_SAR_BLOCK - 1) / GPX_SAR_BLOCK; /* groups per lane */
     unsigned long long* keysG = X.perm + boff; /* [boff, boff + nb): nobody else's (header) */
@@ -264,6 +292,7 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
       }
     }
     __syncthreads();
+    SAR_STAMP(w, 3); /* votes gathered */
     const int32_t c = lcnt[t];
     int32_t tot_;
     const int32_t start = block_exscan_rt(c, &tot_);
@@ -280,6 +309,7 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
       }
     }
     __syncthreads();
+    SAR_STAMP(w, 4); /* placed */
     /* D: lanes with more than 16 votes: sorted keys in global scratch (bucket16_body's regimes) */
     if (any_long) {
       if (c > V16_NIB_MAX && c <= V16_LANE_SORT) {
@@ -301,48 +331,106 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
         __syncthreads();
       }
     }
-    /* ---- E: replay, one lane per `width` groups, group by group ---- */
-    SmallArIter it;
-    it.keyA = keyA;
-    it.slotA = slotA;
-    it.cpA = cpA;
-    it.metaA = metaA;
-    it.xA = xA;
-    it.yA = yA;
-    it.keys = keysG + start;
-    it.in = in;
-    it.b0n = b0n;
-    it.b0c = b0c;
-    it.start = start;
-    it.c = 0;
-    it.done = 0;
-    it.nout = 0;
-    it.nib = c <= V16_NIB_MAX;
-    it.order = 0;
-    it.omask = 0;
-    it.cur = 0;
-    const int32_t g_lane = cur + t * (int32_t)width; /* (only lanes with votes use it: those lie inside the range) */
+    /* ---- E: replay.  A lane's range holds `width` groups, and in a thin batch over a large table most of a
+     * lane's votes belong to DIFFERENT groups - replayed by the lane one after the other that was 30 of the first
+     * build's 66 us (every group is two or three dependent round trips).  So the lanes only publish their votes in
+     * (group, arrival) order - E1: sorted position -> position, group - and every group gets a thread of its own -
+     * E2: thread t takes the groups whose first vote has sorted position t or t + 1024.  A lane with more than 16
+     * votes (a hot group) keeps them and replays them itself (E3). ---- */
+    const uint32_t rel_lane = (uint32_t)t * width;
+    unsigned long long order = 0;
     if (c > 0) {
-      if (it.nib) it.order = arrival_order(keyA, start, c);
-      int32_t r = 0;
-      while (r < c) {
-        const uint32_t gk = (uint32_t)keyA[it.pos(r)] >> GPX_SAR_IDX_BITS;
-        int32_t r2 = r + 1;
-        while (r2 < c && ((uint32_t)keyA[it.pos(r2)] >> GPX_SAR_IDX_BITS) == gk) r2++;
-        const int32_t g = g_lane + (int32_t)gk;
-        CoordPre<KMAX> P;
-        coord_preload<KMAX>(S, g, P);
-        coord_preload_ring<KMAX>(S, g, P);
-        it.done = r;
-        it.c = r2;
-        apply_ar_group<KMAX>(S, X, g, it, status, P);
-        r = r2;
+      if (c <= V16_NIB_MAX) {
+        order = arrival_order(keyA, start, c);
+        for (int32_t r = 0; r < c; r++) {
+          const int32_t p = start + (int32_t)((order >> (4 * r)) & 15ull);
+          permA[start + r] = p;
+          gA[start + r] = rel_lane + ((uint32_t)keyA[p] >> GPX_SAR_IDX_BITS);
+          outA[start + r] = 0;
+        }
+      } else {
+        for (int32_t r = 0; r < c; r++) {
+          gA[start + r] = GPX_SAR_LONG;
+          outA[start + r] = 0;
+        }
       }
     }
-    /* ---- F: this pass's outputs, lane-major = gidx ascending, into the caller's columns ---- */
-    const int32_t nout = it.nout;
+    __syncthreads();
+    /* E2 (jobs 0 .. VPT - 1: the group whose first vote has sorted position job * 1024 + t) and E3 (then: the
+     * groups of this thread's own lane, if it kept them) through ONE replay site */
+    {
+      SmallArIter it;
+      it.keyA = keyA;
+      it.slotA = slotA;
+      it.cpA = cpA;
+      it.metaA = metaA;
+      it.xA = xA;
+      it.yA = yA;
+      it.in = in;
+      it.b0n = b0n;
+      it.b0c = b0c;
+      it.nout = 0;
+      it.cur = 0;
+      const bool longlane = c > V16_NIB_MAX;
+      int32_t job = 0, r = 0;
+#pragma unroll 1
+      for (;;) {
+        int32_t g, q = 0, first;
+        if (job < GPX_SAR_VPT) {
+          q = job * GPX_SAR_BLOCK + t;
+          job++;
+          if (q >= nb) continue;
+          const uint32_t gq = gA[q];
+          if (gq == GPX_SAR_LONG || (q > 0 && gA[q - 1] == gq)) continue;
+          int32_t q2 = q + 1;
+          while (q2 < nb && gA[q2] == gq) q2++; /* (at most 16: one lane's votes) */
+          it.perm = true;
+          it.ranks = permA + q;
+          it.keys = nullptr;
+          it.done = 0;
+          it.c = q2 - q;
+          it.relg = (int32_t)gq;
+          it.omask = 0;
+          first = permA[q];
+        } else if (longlane && r < c) {
+          it.perm = false;
+          it.ranks = nullptr;
+          it.keys = keysG + start;
+          const uint32_t gk = (uint32_t)keyA[(uint32_t)it.keys[r]] >> GPX_SAR_IDX_BITS;
+          int32_t r2 = r + 1;
+          while (r2 < c && ((uint32_t)keyA[(uint32_t)it.keys[r2]] >> GPX_SAR_IDX_BITS) == gk) r2++;
+          it.done = r;
+          it.c = r2;
+          it.relg = (int32_t)(rel_lane + gk);
+          first = (int32_t)(uint32_t)it.keys[r];
+          r = r2;
+        } else {
+          break;
+        }
+        g = cur + it.relg;
+        CoordPre<KMAX> P;
+        coord_preload<KMAX>(S, g, P);
+        coord_preload_ring_at<KMAX>(S, g, slotA[first], P);
+        apply_ar_group<KMAX>(S, X, g, it, status, P);
+        if (it.perm) outA[q] = it.omask; /* bit r: the group's r-th vote produced an output */
+      }
+      if (longlane) outA[start] = 0x80000000u | (uint32_t)it.nout; /* its outputs: positions keysG[start .. start + nout) */
+    }
+    SAR_STAMP(w, 5); /* thread 0 replayed */
+    __syncthreads();
+    /* ---- F: this pass's outputs in sorted-position order = gidx ascending, a group's in arrival order, into the
+     * caller's columns: thread t takes sorted positions 2 t and 2 t + 1 ---- */
+    uint32_t ow[GPX_SAR_VPT];
+    int32_t nout = 0;
+#pragma unroll
+    for (int j = 0; j < GPX_SAR_VPT; j++) {
+      const int32_t q = GPX_SAR_VPT * t + j;
+      ow[j] = q < nb ? outA[q] : 0u;
+      nout += (ow[j] & 0x80000000u) ? (int32_t)(ow[j] & 0xffffu) : __popc(ow[j]);
+    }
     int32_t tout;
     const int32_t ex = block_exscan_rt(nout, &tout);
+    SAR_STAMP(w, 6); /* every thread replayed */
     if (last) {
       if (t == 0)
         __hip_atomic_store(&tickets[w], ((unsigned long long)epoch << 32) | (uint32_t)(running + tout), __ATOMIC_RELEASE,
@@ -351,27 +439,36 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
     }
     if (tout > 0) {
       if (base < 0) base = wait_earlier();
-      uint32_t om = it.omask;
-      for (int32_t q = 0; q < nout; q++) {
-        uint32_t p;
-        if (it.nib) {
-          const int d = __ffs((int)om) - 1; /* rank of the next vote with an output */
-          om &= om - 1;
-          p = (uint32_t)start + (uint32_t)((it.order >> (4 * d)) & 15ull);
-        } else {
-          p = (uint32_t)it.keys[q];
-        }
-        const int64_t o = (int64_t)base + running + ex + q;
-        d_gidx[o] = g_lane + (int32_t)((uint32_t)keyA[p] >> GPX_SAR_IDX_BITS);
+      SAR_STAMP(w, 7); /* earlier tickets in */
+      int64_t o = (int64_t)base + running + ex;
+      auto put = [&](uint32_t p) {
+        d_gidx[o] = cur + keyA[p]; /* (emit left the group there) */
         d_slot[o] = slotA[p];
         d_bnum[o] = xA[p];
         d_bcoord[o] = yA[p];
         d_median[o] = cpA[p];
         d_kind[o] = (uint8_t)metaA[p];
+        o++;
+      };
+#pragma unroll
+      for (int j = 0; j < GPX_SAR_VPT; j++) {
+        const int32_t q = GPX_SAR_VPT * t + j;
+        if (ow[j] & 0x80000000u) {
+          const int32_t no = (int32_t)(ow[j] & 0xffffu);
+          for (int32_t i = 0; i < no; i++) put((uint32_t)(X.perm + boff)[q + i]);
+        } else {
+          uint32_t om = ow[j];
+          while (om) {
+            const int d = __ffs((int)om) - 1;
+            om &= om - 1;
+            put((uint32_t)permA[q + d]);
+          }
+        }
       }
     }
     running += tout;
     __syncthreads(); /* the next pass stages over these words */
+    SAR_STAMP(w, 8); /* outputs written */
     if (ihi < n) { /* the same group's next window of arrival indices */
       ilo = ihi;
       ihi = n;

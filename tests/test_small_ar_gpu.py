@@ -157,7 +157,7 @@ def test_runs_hint_in_front_of_the_small_path(hip_lib, oracle_lib):
     on to k_ar_small launched behind it (which returns at once for the other)."""
     G, K = 20_000, 3
     members = [100, 101, 102]
-    eh, eo = _pair(hip_lib, oracle_lib, G, K, K * G + 64)
+    eh, eo = _pair(hip_lib, oracle_lib, G, K, K * G + 4096)
     mem = np.tile(np.array(members, np.int32), (G, 1))
     g = np.arange(G, dtype=np.int32)
     for e in (eh, eo):
