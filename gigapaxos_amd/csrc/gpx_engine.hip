@@ -119,6 +119,10 @@ struct gpx_engine {
   /* small accept-reply calls in one launch (gpx_small.hip.h): votes a workgroup is sized for (GPX_SAR_VOTES_PER_WG,
    * tuning), 0 = the path is off (GPX_SAR_VOTES_PER_WG=0: every call takes the partition pipeline) */
   int32_t sar_votes_per_wg = 1024;
+  /* ... calls of at most this many votes take it (GPX_SAR_MAX_N): beyond, every workgroup re-reading the whole gidx
+   * column and gathering its votes at random costs more than the partition pipeline's four launches */
+  int32_t sar_max_n = 32768;
+  int32_t sar_prefetch = 1; /* GPX_SAR_PREFETCH (tuning) */
   /* GPX_LAZY_OUTPUTS: what gpx_compact_last_dev needs to finish the most recent call (kind 0: nothing pending) */
   struct LastCall {
     int kind = 0; /* 1 ACCEPT, 2 COMMIT (k_ac_one), 3 accept replies (k_ar_runs) */
@@ -176,10 +180,8 @@ struct gpx_engine {
   int64_t nm_tomb = 0;
   std::vector<int32_t> free_rows;
   bool free_init = false;
-  /* k_pack_one (gpx_wire.hip.h): one ticket per tile of 256 rows, the tiles drawn so far and the launch's epoch */
-  unsigned long long* w_pack_ticket = nullptr;
-  uint32_t* w_pack_draw = nullptr;
-  uint32_t w_pack_drawn = 0, w_pack_epoch = 0;
+  int32_t *w_cnt = nullptr, *w_tile = nullptr, *w_err = nullptr;
+  long long* w_tile_b = nullptr;
   unsigned long long* w_look = nullptr; /* [4][tiles] look-back words of the one-launch decode */
   uint32_t* w_ticket = nullptr;
   uint32_t w_epoch = 0;
@@ -604,6 +606,8 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
   if (const char* sv = getenv("GPX_SAR_VOTES_PER_WG")) e->sar_votes_per_wg = std::max(0, std::min(GPX_SAR_CAP, atoi(sv)));
+  if (const char* sv = getenv("GPX_SAR_MAX_N")) e->sar_max_n = std::max(0, std::min(GPX_SAR_MAX_N, atoi(sv)));
+  if (const char* sv = getenv("GPX_SAR_PREFETCH")) e->sar_prefetch = atoi(sv) ? 1 : 0;
   e->ordered_mask = e->env_mask;
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
   const size_t bucket_lds_hw = GPX_BUCKET_LDS_BYTES(X.gb, e->lds_recs_hw) + e->lds_pad;
@@ -996,8 +1000,9 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     const int32_t refuse = runs_promised ? 1 : 0;
     if (!e->runs_arrive &&
         (rc = dev_alloc(e, &e->runs_arrive,
-                        /* k_runs_check: one workgroup per 4,096 records; k_ar_runs<.., SMALL>: up to 256 workgroups */
-                        32 * (2 + std::max<size_t>(N / ((size_t)GPX_OC_BLOCK * GPX_RC_ITEMS), GPX_SMALL_RUNS_MAX / GPX_RBLOCK) / 16 + 1),
+                        /* k_runs_check: one workgroup per 4,096 records; k_ar_runs<.., SMALL>: the counters of 256 workgroups, then a ticket each */
+                        std::max<size_t>(32 * (2 + N / ((size_t)GPX_OC_BLOCK * GPX_RC_ITEMS) / 16 + 1),
+                                         GPX_SMALL_RUNS_TICKETS + GPX_SMALL_RUNS_MAX / GPX_RBLOCK),
                         true)) != GPX_OK)
       return rc;
     const bool small = n <= GPX_SMALL_RUNS_MAX; /* one launch: every workgroup judges the (L2-resident) column itself */
@@ -1058,7 +1063,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     }
     e->X.gate = 1; /* the partition kernels below run only if k_runs_check raised *X.unsorted */
   }
-  if (n <= GPX_SAR_MAX_N && e->S.G <= GPX_SAR_MAX_G && e->sar_votes_per_wg > 0) {
+  if (n <= e->sar_max_n && e->S.G <= GPX_SAR_MAX_G && e->sar_votes_per_wg > 0) {
     /* (ii) a small call, whatever its order: ONE launch (gpx_small.hip.h) */
     const int W = std::max(1, std::min({GPX_SAR_MAX_WG, (n + e->sar_votes_per_wg - 1) / e->sar_votes_per_wg, (int)e->S.G}));
     if (++e->small_epoch == 0) {
@@ -1075,7 +1080,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
 #define GPX_LAUNCH_AR_SMALL(KM)                                                                                          \
   hipLaunchKernelGGL(k_ar_small<KM>, dim3(W), dim3(GPX_SAR_BLOCK), GPX_SAR_LDS_BYTES, e->stream, e->S, e->X, n, gidx, bnum, \
                      bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, status, \
-                     e->small_tickets, e->small_epoch, e->small_draw, e->small_drawn, W, e->X.gate)
+                     e->small_tickets, e->small_epoch, W, e->X.gate, e->sar_prefetch)
       if (e->cfg.kmax <= 4)
         GPX_LAUNCH_AR_SMALL(4);
       else if (e->cfg.kmax <= 8)
@@ -1087,7 +1092,6 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
 #ifdef GPX_SAR_TRACE
     if (!e->X.gate) sar_trace_end(e);
 #endif
-    e->small_drawn += (uint32_t)W;
   } else {
     /* (iii) the partition pipeline */
     ar_partition(e, n, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp,

@@ -313,13 +313,14 @@ struct RunsIter {
 #define GPX_RBLOCK 256
 
 /* SMALL (round 4): a call of at most GPX_SMALL_RUNS_MAX votes in ONE launch - the shape a coordinator really sees
- * most often: the replies of a few acceptors, each frame at most 2,048 slots (BatchedAcceptReply.java:27).  The
- * gidx column is L2-resident, so every workgroup judges it itself (in range, at most 16 ascending runs: no
- * k_runs_check launch, every workgroup arrives at the same run starts), the lane that replays a vote marks its
- * status (no prefill pass), nothing is counted per chunk, and the LAST workgroup to finish (at most 256 of them:
- * two levels of arrival counters, 16 workgroups per counter, a cache line apart) publishes the count - or -1 for a
- * batch that needs the compaction pass - and leaves the run starts in `info` for that pass. */
+ * most often: the replies of a few acceptors, each frame at most 2,048 slots (BatchedAcceptReply.java:27).  No
+ * k_runs_check launch: every workgroup judges its own 256 records and all of them (at most 256, resident together)
+ * exchange the verdict through epoch tickets (below); the lane that replays a vote marks its status (no prefill
+ * pass), nothing is counted per chunk, and the LAST workgroup to finish (two levels of arrival counters, 16
+ * workgroups per counter, a cache line apart) publishes the count - or -1 for a batch that needs the compaction
+ * pass - and leaves the run starts in `info` for that pass. */
 #define GPX_SMALL_RUNS_MAX 65536
+#define GPX_SMALL_RUNS_TICKETS (32 * 18) /* words of runs_arrive in front of the small kernel's tickets (the arrival counters) */
 template <int KMAX, bool SMALL = false>
 __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X, int32_t n,
                                                        const int32_t* __restrict__ gidx,
@@ -335,7 +336,6 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
                                                        unsigned long long* __restrict__ acc = nullptr) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
   __shared__ int32_t wsum[GPX_RBLOCK / 64];
-  __shared__ int32_t s_nd, s_start[GPX_RUNS_MAX];
   const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
   const int32_t my_chunk = (int32_t)(((int64_t)blockIdx.x * GPX_RBLOCK) >> GPX_DCHUNK_SHIFT);
   int32_t R;
@@ -343,68 +343,49 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
   if (SMALL) SAR_STAMP(blockIdx.x, 0);
 #endif
   if (SMALL) {
+    /* The verdict without a kernel of its own AND without every workgroup reading the whole column (the second
+     * build did: 12 of its 18 us at 30,000 votes, profiles/r04_sar_trace_2.txt): a workgroup judges its OWN 256
+     * records - in range; a descent = a run start, appended to info->start as k_runs_check does - raises
+     * *X.unsorted for a batch that is no few runs in range, publishes a ticket (the call's epoch) and waits for the
+     * tickets of ALL workgroups (at most 256 of them, all resident: one load per lane) - then every workgroup reads
+     * the same verdict and the same run starts. */
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(RunsInfo) / 4)) ((int32_t*)next_info)[threadIdx.x] = 0;
-    if (threadIdx.x == 0) s_nd = 0;
-    __syncthreads();
-    /* Straight-line per entry (the first build branched per entry: 12.6 of the kernel's 13.8 us at 30,000 votes,
-     * profiles/r04_sar_trace_1.txt): 16 entries and their predecessors in flight per lane, none behind a branch (an
-     * index outside the batch is clamped for the load); only a lane that saw a descent - there are at most 15 in a
-     * batch that keeps the shape - goes back over its entries to record the run starts */
-    bool bad = false;
-    for (int32_t r0 = 0; r0 < n; r0 += 16 * GPX_RBLOCK) {
-      int32_t gg[16], gp[16];
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const int32_t i1 = r0 + k * GPX_RBLOCK + (int32_t)threadIdx.x;
-        gg[k] = gidx[min(i1, n - 1)];
-        gp[k] = gidx[max(min(i1, n - 1) - 1, 0)];
+    uint32_t* const tick = arrive + GPX_SMALL_RUNS_TICKETS;
+    {
+      bool bad = false, desc = false;
+      if (i < n) {
+        const int32_t gi = gidx[i];
+        const int32_t gp = i > 0 ? gidx[i - 1] : INT32_MIN;
+        bad = (uint32_t)gi >= (uint32_t)S.G;
+        desc = gp > gi;
       }
-      uint32_t dm = 0;
-#pragma unroll
-      for (int k = 0; k < 16; k++) {
-        const int32_t i1 = r0 + k * GPX_RBLOCK + (int32_t)threadIdx.x;
-        const bool valid = i1 < n;
-        bad |= valid && (uint32_t)gg[k] >= (uint32_t)S.G;
-        dm |= (valid && i1 > 0 && gp[k] > gg[k]) ? (1u << k) : 0u; /* a descent: a run starts here */
-      }
-      /* a shuffled batch (the GPX_TRY_REPLY_RUNS hint on a batch that is no few runs) has a descent at every other
-       * entry: judged per wave, without touching the shared counter */
-      int32_t wd = __popc(dm);
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) wd += __shfl_xor(wd, d, 64);
-      if (wd > GPX_RUNS_MAX - 1) {
-        bad = true;
-        dm = 0;
-      }
-      while (dm) {
-        const int k = __ffs((int)dm) - 1;
-        dm &= dm - 1;
-        const int32_t k2 = atomicAdd(&s_nd, 1);
-        if (k2 < GPX_RUNS_MAX - 1)
-          s_start[k2 + 1] = r0 + k * GPX_RBLOCK + (int32_t)threadIdx.x;
+      const int32_t nd_wg = __syncthreads_count(desc);
+      bad = __syncthreads_or(bad) || nd_wg > GPX_RUNS_MAX - 1;
+      if (!bad && desc) {
+        const int32_t k = atomicAdd(&info->n_desc, 1);
+        if (k < GPX_RUNS_MAX - 1)
+          __hip_atomic_store(&info->start[k + 1], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else
           bad = true;
       }
+      if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
+      /* (the barrier above orders this workgroup's run starts and its verdict before its ticket) */
+      if (threadIdx.x == 0) __hip_atomic_store(&tick[blockIdx.x], X.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      if (threadIdx.x < gridDim.x)
+        while (__hip_atomic_load(&tick[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != X.epoch) {
+        }
+      __syncthreads();
     }
-    if (__syncthreads_or(bad)) { /* not a few ascending runs in range */
+    if (__hip_atomic_load(X.unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X.epoch) {
+      /* not a few ascending runs in range: refused whole under the promise, else the partition pipeline (or the
+       * one-launch kernel of small calls) launched behind takes the batch */
       if (refuse) {
         if (i < n && status) status[i] = GPX_S_UNORDERED;
         if (i == 0 && n_out) *n_out = 0;
-      } else if (i == 0) {
-        atomicMax(X.unsorted, X.epoch); /* the partition pipeline launched behind takes the batch */
       }
       return;
     }
-    const int32_t nd = s_nd;
-    if (threadIdx.x <= (unsigned)nd) { /* rank sort of at most 16 distinct values (runs_load's) */
-      const int32_t v = threadIdx.x == 0 ? 0 : s_start[threadIdx.x];
-      int32_t rk = 0;
-      for (int32_t q = 1; q <= nd; q++) rk += s_start[q] < v;
-      rs[threadIdx.x == 0 ? 0 : rk + 1] = v;
-    }
-    if (threadIdx.x == 0) rs[nd + 1] = n;
-    __syncthreads();
-    R = nd + 1;
+    R = runs_load(info, n, rs);
 #ifdef GPX_SAR_TRACE
     SAR_STAMP(blockIdx.x, 1); /* column judged, run starts sorted */
 #endif

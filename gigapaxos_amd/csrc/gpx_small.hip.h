@@ -8,8 +8,7 @@
  * 42 us per 65,536 votes (profiles/r03_batch_sweep.json) - the launch floor, not the work.  Here the whole call
  * is one kernel of W <= 128 workgroups:
  *
- *   range     workgroup w (a drawn ticket, as in k_ac_small: a workgroup only ever waits for workgroups that
- *             have started) owns the groups [w * RG, (w + 1) * RG), RG = ceil(G / W).
+ *   range     workgroup w owns the groups [w * RG, (w + 1) * RG), RG = ceil(G / W).
  *   collect   every workgroup reads the WHOLE gidx column (n <= 131,072 ints: it is L2-resident after the first
  *             reader; eight 16-byte loads in flight per lane) and keeps the arrival indices of the votes of its
  *             range in LDS; it also counts the votes of lower ranges - its slice of the key scratch.
@@ -114,22 +113,15 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
     const int32_t* __restrict__ max_cp, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
     int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
     uint8_t* __restrict__ d_kind, int32_t* __restrict__ n_out, uint8_t* __restrict__ status,
-    unsigned long long* __restrict__ tickets, uint32_t epoch, uint32_t* __restrict__ draw, uint32_t draw_base,
-    int32_t W, int32_t gate) {
+    unsigned long long* __restrict__ tickets, uint32_t epoch, int32_t W, int32_t gate, int32_t prefetch) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
-  __shared__ int32_t s_w, s_lower, s_before;
+  __shared__ int32_t s_lower, s_before;
+  __shared__ int32_t s_pf[64]; /* where the prefetches' words land (never read) */
   const int32_t t = (int32_t)threadIdx.x;
-#ifdef GPX_SAR_TRACE
-  const unsigned long long t_entry = wall_clock64();
-#endif
-  /* the range is DRAWN, not read off blockIdx (k_ac_small): always, so that the host's count of draws stays true */
-  if (t == 0) s_w = (int32_t)(atomicAdd(draw, 1u) - draw_base);
-  __syncthreads();
-  const int32_t w = s_w;
-#ifdef GPX_SAR_TRACE
-  if (t == 0 && g_sar_trace) g_sar_trace[(size_t)w * 16] = t_entry;
-#endif
-  SAR_STAMP(w, 1); /* drawn */
+  /* The range is read off blockIdx: a workgroup waits (for the tickets of lower ranges) only after its own work,
+   * and the at most 128 workgroups of a call are all resident at once (one per CU), whatever order they start in. */
+  const int32_t w = (int32_t)blockIdx.x;
+  SAR_STAMP(w, 0);
   /* launched behind the sorted-runs attempt (GPX_TRY_REPLY_RUNS): only a batch it gave up on is this kernel's */
   if (gate && *X.unsorted != X.epoch) return;
   int32_t* lcnt = lds;
@@ -151,24 +143,22 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
   const int32_t b0n = bnum[0], b0c = bcoord[0];
   const VoteCols in{bnum, bcoord, acceptor};
 
-  /* This workgroup's SLICE of the batch (arrival indices): votes outside the table are marked and counted here,
-   * once per call (PaxosManager.java:1162-1194) - every vote lies in exactly one slice, whatever its group. */
-  {
-    const int32_t slice = (n + W - 1) / W;
-    const int32_t s0 = (int32_t)min((int64_t)n, (int64_t)w * slice), s1 = (int32_t)min((int64_t)n, (int64_t)s0 + slice);
-    int32_t bad = 0;
-    for (int32_t i = s0 + t; i < s1; i += GPX_SAR_BLOCK) {
-      if ((uint32_t)gidx[i] >= (uint32_t)G) {
-        bad++;
-        if (status) status[i] = GPX_S_NOGROUP;
-      }
-    }
-    if (__any(bad != 0)) {
-#pragma unroll
-      for (int d = 32; d >= 1; d >>= 1) bad += __shfl_xor(bad, d, 64);
-      if ((t & 63) == 0) atomicAdd(&X.counters[2], (unsigned long long)bad);
-    }
-  }
+  /* This workgroup's SLICE of the batch (arrival indices): votes outside the table are marked and counted there,
+   * once per call (PaxosManager.java:1162-1194) - every vote lies in exactly one slice, whatever its group.  The
+   * slice's first 2,048 entries are requested here and looked at behind the first scan (no round trip of their own) */
+  const int32_t slice = (n + W - 1) / W;
+  const int32_t sl0 = (int32_t)min((int64_t)n, (int64_t)w * slice), sl1 = (int32_t)min((int64_t)n, (int64_t)sl0 + slice);
+  const int32_t sg0 = gidx[min(sl0 + t, n - 1)], sg1 = gidx[min(sl0 + GPX_SAR_BLOCK + t, n - 1)];
+  bool slice_done = false;
+  const uint32_t pf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)s_pf;
+  /* a load nobody waits for: the word goes to s_pf by LDS DMA (no register to protect), the line and its
+   * translation are warm when the real load comes a few microseconds later.  (Invisible to the compiler's wait
+   * counters, which only makes its waits longer than it thinks; the kernel ends behind a vmcnt(0).  M0 is a reserved
+   * register the compiler loads right in front of every use of its own, so writing it here disturbs nothing.) */
+  auto touch = [&](const void* p) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 1\n\tglobal_load_lds_dword %0, off" ::"v"(p), "s"(pf_lds) : "memory"); /* (the
+                                                      * nop: an M0 write needs a wait state before an LDS-DMA instruction reads it) */
+  };
 
   /* sum of the tickets before this workgroup's (each depends on its own workgroup only) */
   auto wait_earlier = [&]() -> int32_t {
@@ -238,6 +228,29 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
     int32_t ex0 = block_exscan_rt(mine, &nb); /* (its barriers also publish s_lower) */
     const int32_t boff = s_lower;
     SAR_STAMP(w, 2); /* column scanned */
+    if (!slice_done) {
+      slice_done = true;
+      int32_t bad = 0;
+      if (sl0 + t < sl1 && (uint32_t)sg0 >= (uint32_t)G) {
+        bad++;
+        if (status) status[sl0 + t] = GPX_S_NOGROUP;
+      }
+      if (sl0 + GPX_SAR_BLOCK + t < sl1 && (uint32_t)sg1 >= (uint32_t)G) {
+        bad++;
+        if (status) status[sl0 + GPX_SAR_BLOCK + t] = GPX_S_NOGROUP;
+      }
+      for (int32_t i = sl0 + 2 * GPX_SAR_BLOCK + t; i < sl1; i += GPX_SAR_BLOCK) { /* (a slice of more than 2,048 votes: a call capped at few workgroups) */
+        if ((uint32_t)gidx[i] >= (uint32_t)G) {
+          bad++;
+          if (status) status[i] = GPX_S_NOGROUP;
+        }
+      }
+      if (__any(bad != 0)) {
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) bad += __shfl_xor(bad, d, 64);
+        if ((t & 63) == 0) atomicAdd(&X.counters[2], (unsigned long long)bad);
+      }
+    }
     if (nb > GPX_SAR_CAP) {
       /* more than one pass stages: narrow the range (aiming at half the capacity), or - one group alone - take
        * the next window of arrival indices */
@@ -259,7 +272,14 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
       while (m) {
         const int e = __ffs((int)m) - 1;
         m &= m - 1;
-        idxS[ex0++] = r * GPX_SAR_ROUND + e * GPX_SAR_BLOCK + t;
+        const int32_t i = r * GPX_SAR_ROUND + e * GPX_SAR_BLOCK + t;
+        idxS[ex0++] = i;
+        if (prefetch) { /* this vote's columns and its group's state: read a few microseconds from now, by other lanes */
+          const int32_t g = gidx[i]; /* (the L1 has it) */
+          touch(slot + i), touch(max_cp + i), touch(acceptor + i), touch(bnum + i), touch(bcoord + i);
+          touch(S.g_flags + g), touch(S.c_bnum + g), touch(S.c_bcoord + g), touch(S.c_next + g), touch(S.c_pcount + g);
+          for (int32_t q = 0; q < S.kmax; q++) touch(S.members + (int64_t)q * G + g), touch(S.node_slots + (int64_t)q * G + g);
+        }
       }
     }
     __syncthreads();
@@ -288,6 +308,7 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
         const bool esc = bn != b0n || bc != b0c || (uint32_t)ac > 0xffffu;
         vm[j] = esc ? V16_ESC : ((uint32_t)ac << 16);
         atomicAdd(&lcnt[lb], 1);
+        if (prefetch) touch(S.p_ring + (int64_t)(sl & (S.W - 1)) * G + g);
         if (status) status[i] = GPX_S_OK; /* no prefill pass ran; apply_ar_group overwrites it for a vote it drops */
       }
     }
@@ -482,6 +503,7 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
   if (!published && t == 0) /* an empty range (more workgroups than groups) */
     __hip_atomic_store(&tickets[w], ((unsigned long long)epoch << 32) | (uint32_t)running, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* no prefetch outlives the workgroup's LDS */
   if (w == 0 && t == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
   if (w == W - 1) { /* the call's count */
     if (base < 0) base = wait_earlier();

@@ -963,19 +963,12 @@ struct PackIn {
   const uint8_t* kind;
 };
 struct PackScratch {
-  /* One launch (round 4; until then k_pack_scan wrote every row's frame size and per-tile totals, k_pack_write read
-   * them back: two launches that each fetched the rows' group state): a tile's workgroup DRAWS its tile number (it
-   * then only ever waits for tiles whose workgroups have started), sizes its frames, publishes
-   *   ticket[tile] = epoch << 44 | err << 43 | frames << 32 | bytes
-   * builds its frames in LDS while the earlier tiles publish theirs, sums their tickets (every one depends on
-   * its own workgroup only: no chain) and flushes. */
-  unsigned long long* ticket; /* [ntiles] */
-  uint32_t* draw;             /* [1] tiles drawn so far by every launch (never reset) */
-  uint32_t draw_base;         /* ... as the host counts them */
-  uint32_t epoch;             /* 1 .. 2^20 - 1 */
+  int32_t* err;      /* [1] set when one group's block of rows exceeds GPX_W_MAX_SEG */
+  int32_t* size;     /* [rows] padded frame size of a head row, else 0 */
+  long long* tile_b; /* [ntiles] bytes per tile, then exclusive bases */
+  int32_t* tile_f;   /* [ntiles] frames per tile, then exclusive bases */
   int32_t ntiles;
 };
-#define GPX_PACK_EPOCH_BITS 20
 
 __device__ __forceinline__ int32_t pack_rows(const PackIn& P) {
   int32_t n = P.n;
@@ -991,7 +984,8 @@ __device__ __forceinline__ bool pack_same(const PackIn& P, int32_t i, int32_t j)
 /* Row i opens a frame iff it is the first DECISION of its (group, ballot) inside the group's block
  * of rows (PaxosPacketBatcher.enqueueImpl(BatchedCommit): one entry per paxosID and ballot,
  * PaxosPacketBatcher.java:139-156). */
-__device__ __forceinline__ bool pack_is_head(const PackIn& P, int32_t n, int32_t i, bool& err) {
+__device__ __forceinline__ bool pack_is_head(const PackIn& P, const PackScratch& X, int32_t n,
+                                             int32_t i) {
   const int32_t g = P.gidx[i];
   bool head = P.kind[i] == GPX_D_DECISION; /* allCoalescableDecisions (:451-457) */
   int32_t j = i - 1;
@@ -999,7 +993,7 @@ __device__ __forceinline__ bool pack_is_head(const PackIn& P, int32_t n, int32_t
     if (pack_same(P, i, j)) head = false;
   /* contract: the engine emits at most `window` rows per group and call; a longer block is
    * refused (bounded work per lane whatever the caller passes) */
-  if (j >= 0 && i - j >= GPX_W_MAX_SEG && P.gidx[j] == g) err = true;
+  if (j >= 0 && i - j >= GPX_W_MAX_SEG && P.gidx[j] == g) *X.err = 1;
   return head;
 }
 
@@ -1038,9 +1032,9 @@ struct BEWriter {
 /* pass 1: frame sizes of the head rows */
 /* padded frame size of row i if it opens a frame, else 0 */
 __device__ __forceinline__ int32_t pack_frame_size(const DevState& S, const DevNames& N, const PackIn& P,
-                                                   int32_t n, int32_t i, bool& err) {
+                                                   const PackScratch& X, int32_t n, int32_t i) {
   int32_t size = 0;
-  if (i < n && pack_is_head(P, n, i, err)) {
+  if (i < n && pack_is_head(P, X, n, i)) {
     const int32_t g = P.gidx[i];
     if ((uint32_t)g < (uint32_t)S.G && N.tab && N.len(g) != 0 && N.row(g)[NM_EXISTS]) {
       /* TreeSet of the slots of this (group, ballot) */
@@ -1109,6 +1103,24 @@ __device__ __forceinline__ PackAlone pack_alone(const DevState& S, const DevName
     if (MEMBERS) mem[q] = mm[q];
   }
   return A;
+}
+
+__global__ __launch_bounds__(GPX_BLOCK) void k_pack_scan(DevState S, DevNames N, PackIn P,
+                                                        PackScratch X) {
+  const int32_t n = pack_rows(P);
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  const PackAlone A = pack_alone<false>(S, N, P, n, i, nullptr);
+  /* alone: one slot, (13 + idLen) + 12 + 4 (1 + 1 + g + 1) as in pack_frame_size */
+  const int32_t size = A.alone ? (A.frame ? (13 + A.idl + 12 + 4 * (1 + 1 + A.gs + 1) + 3) & ~3 : 0)
+                               : pack_frame_size(S, N, P, X, n, i);
+  if (i < n) X.size[i] = size;
+  int32_t tb, tf;
+  block_exscan(size, &tb);
+  block_exscan(size ? 1 : 0, &tf);
+  if (threadIdx.x == 0) {
+    X.tile_b[blockIdx.x] = tb;
+    X.tile_f[blockIdx.x] = tf;
+  }
 }
 
 /* BatchedCommit.toBytes (BatchedCommit.java:184-215) of head row i through a big-endian writer;
@@ -1231,116 +1243,106 @@ struct BEWriterLds {
   }
 };
 
-/* The frames of a tile are contiguous in the output (offsets are prefix sums): every lane builds its frame in
- * LDS, then the workgroup flushes the tile with coalesced dword stores - a lane writing its own ~56-byte frame to
- * global memory word by word issues 14 stores that each touch a different sector than its neighbours' (measured:
- * 238 us per 1 M frames, 0.24 TB/s).  A tile bigger than the staging area (long names, many slots) is written in
- * place once its base is known. */
+/* pass 3: the frames of a tile are contiguous in the output (offsets are prefix sums): every lane
+ * builds its frame in LDS, then the workgroup flushes the tile with coalesced dword stores - a lane
+ * writing its own ~56-byte frame to global memory word by word issues 14 stores that each touch a
+ * different sector than its neighbours' (measured: 238 us per 1 M frames, 0.24 TB/s).  A tile
+ * bigger than the staging area (long names, many slots) is written in place as before. */
 #define GPX_PACK_STAGE_BYTES (24 * 1024)
-__global__ __launch_bounds__(GPX_BLOCK) void k_pack_one(DevState S, DevNames N, PackIn P, PackScratch X,
-                                                       uint8_t* __restrict__ out, long long cap_bytes,
-                                                       long long* __restrict__ frame_off,
-                                                       int32_t* __restrict__ frame_len,
-                                                       int32_t* __restrict__ f_gidx, int32_t* __restrict__ n_frames,
-                                                       long long* __restrict__ n_bytes) {
+__global__ __launch_bounds__(GPX_BLOCK) void k_pack_write(DevState S, DevNames N, PackIn P,
+                                                         PackScratch X, uint8_t* __restrict__ out,
+                                                         long long cap_bytes,
+                                                         long long* __restrict__ frame_off,
+                                                         int32_t* __restrict__ frame_len,
+                                                         int32_t* __restrict__ f_gidx, int32_t* __restrict__ n_frames,
+                                                         long long* __restrict__ n_bytes) {
   __shared__ uint32_t stage[GPX_PACK_STAGE_BYTES / 4];
   __shared__ long long s_b[GPX_BLOCK / 64];
   __shared__ int32_t s_f[GPX_BLOCK / 64];
-  __shared__ int32_t s_tile;
-  if (threadIdx.x == 0) s_tile = (int32_t)(atomicAdd(X.draw, 1u) - X.draw_base);
-  __syncthreads();
-  const int32_t tile = s_tile;
   const int32_t n = pack_rows(P);
-  const int32_t i = tile * GPX_BLOCK + (int32_t)threadIdx.x;
-  /* requested first, all independent of one another: the row's own columns ... */
+  const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  /* requested first, all independent of one another: the row's own columns, its frame size, the totals of
+   * the tiles before this one ... */
   const bool in = i < n;
   const int32_t a_bnum = in ? P.bnum[i] : 0, a_bcoord = in ? P.bcoord[i] : 0, a_median = in ? P.median[i] : 0;
   const int32_t a_slot = in ? P.slot[i] : 0;
+  const int32_t size = in ? X.size[i] : 0;
+  /* (this tile's base = the bytes and frames of the tiles before it; a separate one-workgroup scan kernel
+   * used to turn k_pack_scan's totals into bases: 10 us of the call) */
+  long long bb = 0;
+  int32_t bf = 0;
+  for (int32_t t0 = threadIdx.x; t0 < (int32_t)blockIdx.x; t0 += 8 * GPX_BLOCK) { /* eight pairs in flight */
+    long long vb[8];
+    int32_t vf[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      const int32_t t = t0 + k * GPX_BLOCK;
+      const bool ok = t < (int32_t)blockIdx.x;
+      vb[k] = ok ? X.tile_b[t] : 0;
+      vf[k] = ok ? X.tile_f[t] : 0;
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+      bb += vb[k];
+      bf += vf[k];
+    }
+  }
   /* ... then what an alone row's frame is made of (pack_alone: the second wave of loads) */
   int32_t mem[GPX_KMAX_LIMIT];
   const PackAlone A = pack_alone<true>(S, N, P, n, i, mem);
   const bool fast = A.alone && A.frame;
-  bool err = false;
-  /* alone: one slot, (13 + idLen) + 12 + 4 (1 + 1 + g + 1) as in pack_frame_size */
-  const int32_t size = A.alone ? (A.frame ? (13 + A.idl + 12 + 4 * (1 + 1 + A.gs + 1) + 3) & ~3 : 0)
-                               : pack_frame_size(S, N, P, n, i, err);
-  int32_t tb, tf;
-  const int32_t eb = block_exscan(size, &tb);
-  const int32_t ef = block_exscan(size ? 1 : 0, &tf);
-  const bool terr = __syncthreads_or(err) != 0;
-  if (threadIdx.x == 0)
-    __hip_atomic_store(&X.ticket[tile],
-                       ((unsigned long long)X.epoch << 44) | ((unsigned long long)(terr ? 1 : 0) << 43) |
-                           ((unsigned long long)(uint32_t)tf << 32) | (unsigned long long)(uint32_t)tb,
-                       __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-  /* the frame, built in LDS at its offset inside the tile: needs no base */
-  const bool staged = tb <= GPX_PACK_STAGE_BYTES; /* workgroup-uniform */
-  int32_t len = 0;
-  if (size && staged) {
-    BEWriterLds w;
-    w.w = stage + (eb >> 2);
-    w.acc = 0;
-    w.k = 0;
-    len = fast ? pack_commit_frame_alone(S, N, A, mem, A.r0, A.r1, a_bnum, a_bcoord, a_median, a_slot, w)
-               : pack_commit_frame(S, N, P, n, i, w);
-  }
-  /* this tile's base = the bytes and frames of the tiles before it (and whether one of them saw an over-long
-   * block of rows) */
-  long long bb = 0;
-  int32_t bf = 0, be = 0;
-  for (int32_t q = (int32_t)threadIdx.x; q < tile; q += GPX_BLOCK) {
-    unsigned long long v;
-    do {
-      v = __hip_atomic_load(&X.ticket[q], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    } while ((uint32_t)(v >> 44) != X.epoch);
-    bb += (long long)(uint32_t)v;
-    bf += (int32_t)((v >> 32) & 0x7ffu);
-    be |= (int32_t)((v >> 43) & 1u);
-  }
+  const uint4 r0 = A.r0, r1 = A.r1;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) {
     const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)bb, d, 64);
     const uint32_t hi = (uint32_t)__shfl_xor((int)(uint32_t)((unsigned long long)bb >> 32), d, 64);
     bb += (long long)(((unsigned long long)hi << 32) | lo);
     bf += __shfl_xor(bf, d, 64);
-    be |= __shfl_xor(be, d, 64);
   }
   if ((threadIdx.x & 63) == 0) {
     s_b[threadIdx.x >> 6] = bb;
-    s_f[threadIdx.x >> 6] = bf | (be << 30); /* (frames of one call < 2^30) */
+    s_f[threadIdx.x >> 6] = bf;
   }
-  __syncthreads(); /* (also: every frame of the tile is in the staging area) */
+  int32_t tb, tf;
+  const int32_t eb = block_exscan(size, &tb); /* (its barriers publish s_b / s_f) */
+  const int32_t ef = block_exscan(size ? 1 : 0, &tf);
   long long tile0 = 0;
   int32_t frame0 = 0;
-  bool err_before = false;
 #pragma unroll
   for (int w = 0; w < GPX_BLOCK / 64; w++) {
     tile0 += s_b[w];
-    frame0 += s_f[w] & 0x3fffffff;
-    err_before |= (s_f[w] & 0x40000000) != 0;
+    frame0 += s_f[w];
   }
-  if (tile == X.ntiles - 1 && threadIdx.x == 0) { /* totals to the caller */
-    *n_frames = (err_before || terr) ? -1 : frame0 + tf;
+  if (blockIdx.x == gridDim.x - 1 && threadIdx.x == 0) { /* totals to the caller */
+    *n_frames = *X.err ? -1 : frame0 + tf;
     *n_bytes = tile0 + tb;
   }
+  const bool staged = tb <= GPX_PACK_STAGE_BYTES && tile0 + tb <= cap_bytes; /* workgroup-uniform */
   const long long off = tile0 + eb;
   const int32_t fi = frame0 + ef;
-  if (size && !staged && off + size <= cap_bytes) { /* a tile beyond the staging area: in place */
-    BEWriter w;
-    w.init(out + off);
-    len = fast ? pack_commit_frame_alone(S, N, A, mem, A.r0, A.r1, a_bnum, a_bcoord, a_median, a_slot, w)
-               : pack_commit_frame(S, N, P, n, i, w);
-  }
-  if (size && off + size <= cap_bytes) { /* else: the host sees n_bytes > cap_bytes */
+  if (size && (staged || off + size <= cap_bytes)) { /* else: the host sees n_bytes > cap_bytes */
+    int32_t len;
+    if (staged) {
+      BEWriterLds w;
+      w.w = stage + (eb >> 2);
+      w.acc = 0;
+      w.k = 0;
+      len = fast ? pack_commit_frame_alone(S, N, A, mem, r0, r1, a_bnum, a_bcoord, a_median, a_slot, w)
+                 : pack_commit_frame(S, N, P, n, i, w);
+    } else {
+      BEWriter w;
+      w.init(out + off);
+      len = fast ? pack_commit_frame_alone(S, N, A, mem, r0, r1, a_bnum, a_bcoord, a_median, a_slot, w)
+                 : pack_commit_frame(S, N, P, n, i, w);
+    }
     frame_off[fi] = off;
     frame_len[fi] = len;
-    f_gidx[fi] = A.g;
+    f_gidx[fi] = P.gidx[i];
   }
-  if (staged) { /* the tile, as far as the caller's buffer reaches (whole words: both are multiples of 4) */
-    const long long room = cap_bytes - tile0;
-    const int32_t words = (int32_t)((room < 0 ? 0 : (room < (long long)tb ? room : (long long)tb)) >> 2);
+  if (staged) {
+    __syncthreads();
     uint32_t* dst = (uint32_t*)(out + tile0); /* tile0 is a multiple of 4 */
-    for (int32_t wi = threadIdx.x; wi < words; wi += GPX_BLOCK) dst[wi] = stage[wi];
+    for (int32_t wi = threadIdx.x; wi < (tb >> 2); wi += GPX_BLOCK) dst[wi] = stage[wi];
   }
 }
 

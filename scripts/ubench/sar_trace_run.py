@@ -13,9 +13,10 @@ from gigapaxos_amd import Engine, hri_create, load_hip, streams, S_OK, ORDERED_R
 
 TRACE = "/tmp/sar_trace.bin"
 os.environ["GPX_SAR_TRACE_FILE"] = TRACE
-NAMES = {"k_ar_small": ["entry", "drawn", "column scanned", "votes gathered", "placed", "lane 0 replayed", "all replayed",
+os.environ.setdefault("GPX_SAR_MAX_N", "131072")  # time the kernel at every size, whatever the engine's crossover
+NAMES = {"k_ar_small": ["entry", "(drawn: first build)", "column scanned", "votes gathered", "placed", "lane 0 replayed", "all replayed",
                          "earlier tickets in", "outputs written"],
-         "k_ar_runs_small": ["entry", "column judged", "lane 0 straight-line done", "all lanes done"]}
+         "k_ar_runs_small": ["entry", "verdict exchanged", "lane 0 straight-line done", "all lanes done"]}
 
 
 def summary(kernel):

@@ -14,23 +14,28 @@ pytestmark = pytest.mark.gpu
 
 
 class sar_env:
-    """GPX_SAR_VOTES_PER_WG is read when an engine is created: votes a workgroup of k_ar_small is sized for (0 = off)."""
+    """GPX_SAR_VOTES_PER_WG / GPX_SAR_MAX_N are read when an engine is created: votes a workgroup of k_ar_small is sized
+    for (0 = the path is off), and the largest call that takes it."""
 
     def __init__(self, v):
         self.v = v
 
     def __enter__(self):
-        self.old = os.environ.get("GPX_SAR_VOTES_PER_WG")
+        self.old = {k: os.environ.get(k) for k in ("GPX_SAR_VOTES_PER_WG", "GPX_SAR_MAX_N")}
         if self.v is None:
             os.environ.pop("GPX_SAR_VOTES_PER_WG", None)
         else:
             os.environ["GPX_SAR_VOTES_PER_WG"] = str(self.v)
+        # the engine's crossover to the partition pipeline (32,768 votes by default) lifted to the kernel's own limit:
+        # these tests are about the kernel
+        os.environ["GPX_SAR_MAX_N"] = "131072"
 
     def __exit__(self, *a):
-        if self.old is None:
-            os.environ.pop("GPX_SAR_VOTES_PER_WG", None)
-        else:
-            os.environ["GPX_SAR_VOTES_PER_WG"] = self.old
+        for k, v in self.old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
 
 
 def _pair(hip_lib, oracle_lib, G, K, max_batch, per_wg=None, window=8):
