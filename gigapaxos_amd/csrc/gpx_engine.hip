@@ -117,12 +117,12 @@ struct gpx_engine {
   uint32_t one_epoch = 0;
   uint32_t* runs_arrive = nullptr; /* k_runs_check's arrival counters (first use) */
   /* small accept-reply calls in one launch (gpx_small.hip.h): votes a workgroup is sized for (GPX_SAR_VOTES_PER_WG,
-   * tuning), 0 = the path is off (GPX_SAR_VOTES_PER_WG=0: every call takes the partition pipeline) */
-  int32_t sar_votes_per_wg = 1024;
+   * tuning; a little under the kernel's 1,024 lanes, so that a workgroup rarely holds a second vote per thread),
+   * 0 = the path is off (GPX_SAR_VOTES_PER_WG=0: every call takes the partition pipeline) */
+  int32_t sar_votes_per_wg = 896;
   /* ... calls of at most this many votes take it (GPX_SAR_MAX_N): beyond, every workgroup re-reading the whole gidx
    * column and gathering its votes at random costs more than the partition pipeline's four launches */
   int32_t sar_max_n = 32768;
-  int32_t sar_prefetch = 1; /* GPX_SAR_PREFETCH (tuning) */
   /* GPX_LAZY_OUTPUTS: what gpx_compact_last_dev needs to finish the most recent call (kind 0: nothing pending) */
   struct LastCall {
     int kind = 0; /* 1 ACCEPT, 2 COMMIT (k_ac_one), 3 accept replies (k_ar_runs) */
@@ -607,7 +607,6 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
   if (const char* sv = getenv("GPX_SAR_VOTES_PER_WG")) e->sar_votes_per_wg = std::max(0, std::min(GPX_SAR_CAP, atoi(sv)));
   if (const char* sv = getenv("GPX_SAR_MAX_N")) e->sar_max_n = std::max(0, std::min(GPX_SAR_MAX_N, atoi(sv)));
-  if (const char* sv = getenv("GPX_SAR_PREFETCH")) e->sar_prefetch = atoi(sv) ? 1 : 0;
   e->ordered_mask = e->env_mask;
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
   const size_t bucket_lds_hw = GPX_BUCKET_LDS_BYTES(X.gb, e->lds_recs_hw) + e->lds_pad;
@@ -1080,7 +1079,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
 #define GPX_LAUNCH_AR_SMALL(KM)                                                                                          \
   hipLaunchKernelGGL(k_ar_small<KM>, dim3(W), dim3(GPX_SAR_BLOCK), GPX_SAR_LDS_BYTES, e->stream, e->S, e->X, n, gidx, bnum, \
                      bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, status, \
-                     e->small_tickets, e->small_epoch, W, e->X.gate, e->sar_prefetch)
+                     e->small_tickets, e->small_epoch, W, e->X.gate)
       if (e->cfg.kmax <= 4)
         GPX_LAUNCH_AR_SMALL(4);
       else if (e->cfg.kmax <= 8)

@@ -113,10 +113,9 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
     const int32_t* __restrict__ max_cp, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
     int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
     uint8_t* __restrict__ d_kind, int32_t* __restrict__ n_out, uint8_t* __restrict__ status,
-    unsigned long long* __restrict__ tickets, uint32_t epoch, int32_t W, int32_t gate, int32_t prefetch) {
+    unsigned long long* __restrict__ tickets, uint32_t epoch, int32_t W, int32_t gate) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   __shared__ int32_t s_lower, s_before;
-  __shared__ int32_t s_pf[64]; /* where the prefetches' words land (never read) */
   const int32_t t = (int32_t)threadIdx.x;
   /* The range is read off blockIdx: a workgroup waits (for the tickets of lower ranges) only after its own work,
    * and the at most 128 workgroups of a call are all resident at once (one per CU), whatever order they start in. */
@@ -150,16 +149,6 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
   const int32_t sl0 = (int32_t)min((int64_t)n, (int64_t)w * slice), sl1 = (int32_t)min((int64_t)n, (int64_t)sl0 + slice);
   const int32_t sg0 = gidx[min(sl0 + t, n - 1)], sg1 = gidx[min(sl0 + GPX_SAR_BLOCK + t, n - 1)];
   bool slice_done = false;
-  const uint32_t pf_lds = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)s_pf;
-  /* a load nobody waits for: the word goes to s_pf by LDS DMA (no register to protect), the line and its
-   * translation are warm when the real load comes a few microseconds later.  (Invisible to the compiler's wait
-   * counters, which only makes its waits longer than it thinks; the kernel ends behind a vmcnt(0).  M0 is a reserved
-   * register the compiler loads right in front of every use of its own, so writing it here disturbs nothing.) */
-  auto touch = [&](const void* p) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 1\n\tglobal_load_lds_dword %0, off" ::"v"(p), "s"(pf_lds) : "memory"); /* (the
-                                                      * nop: an M0 write needs a wait state before an LDS-DMA instruction reads it) */
-  };
-
   /* sum of the tickets before this workgroup's (each depends on its own workgroup only) */
   auto wait_earlier = [&]() -> int32_t {
     if (t == 0) s_before = 0;
@@ -272,14 +261,7 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
       while (m) {
         const int e = __ffs((int)m) - 1;
         m &= m - 1;
-        const int32_t i = r * GPX_SAR_ROUND + e * GPX_SAR_BLOCK + t;
-        idxS[ex0++] = i;
-        if (prefetch) { /* this vote's columns and its group's state: read a few microseconds from now, by other lanes */
-          const int32_t g = gidx[i]; /* (the L1 has it) */
-          touch(slot + i), touch(max_cp + i), touch(acceptor + i), touch(bnum + i), touch(bcoord + i);
-          touch(S.g_flags + g), touch(S.c_bnum + g), touch(S.c_bcoord + g), touch(S.c_next + g), touch(S.c_pcount + g);
-          for (int32_t q = 0; q < S.kmax; q++) touch(S.members + (int64_t)q * G + g), touch(S.node_slots + (int64_t)q * G + g);
-        }
+        idxS[ex0++] = r * GPX_SAR_ROUND + e * GPX_SAR_BLOCK + t;
       }
     }
     __syncthreads();
@@ -290,26 +272,34 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
     /* ---- regroup: A count per lane, B scan, C placement lane-major ---- */
     int32_t vl[GPX_SAR_VPT], vk[GPX_SAR_VPT], vs[GPX_SAR_VPT], vc[GPX_SAR_VPT];
     uint32_t vm[GPX_SAR_VPT];
+    {
+      /* every load of both votes in flight before the first is looked at: the indices are clamped (a lane without a
+       * vote loads somebody's and drops it), so nothing here stands behind a branch */
+      int32_t vi[GPX_SAR_VPT], vg[GPX_SAR_VPT], va[GPX_SAR_VPT], vbn[GPX_SAR_VPT], vbc[GPX_SAR_VPT];
 #pragma unroll
-    for (int j = 0; j < GPX_SAR_VPT; j++) {
-      const int32_t p = j * GPX_SAR_BLOCK + t;
-      vl[j] = -1;
-      vk[j] = vs[j] = vc[j] = 0;
-      vm[j] = 0;
-      if (p < nb) {
-        const int32_t i = idxS[p];
-        const int32_t g = gidx[i], sl = slot[i], cp = max_cp[i], ac = acceptor[i], bn = bnum[i], bc = bcoord[i];
-        const uint32_t rel = (uint32_t)(g - cur);
-        const uint32_t lb = rel / width;
-        vl[j] = (int32_t)lb;
-        vk[j] = (int32_t)(((rel - lb * width) << GPX_SAR_IDX_BITS) | (uint32_t)i);
-        vs[j] = sl;
-        vc[j] = cp;
-        const bool esc = bn != b0n || bc != b0c || (uint32_t)ac > 0xffffu;
-        vm[j] = esc ? V16_ESC : ((uint32_t)ac << 16);
-        atomicAdd(&lcnt[lb], 1);
-        if (prefetch) touch(S.p_ring + (int64_t)(sl & (S.W - 1)) * G + g);
-        if (status) status[i] = GPX_S_OK; /* no prefill pass ran; apply_ar_group overwrites it for a vote it drops */
+      for (int j = 0; j < GPX_SAR_VPT; j++) vi[j] = idxS[min(j * GPX_SAR_BLOCK + t, max(nb - 1, 0))];
+      if (nb == 0) vi[0] = vi[1] = 0; /* (uniform; idxS holds nothing) */
+#pragma unroll
+      for (int j = 0; j < GPX_SAR_VPT; j++) {
+        const int32_t i = vi[j];
+        vg[j] = gidx[i], vs[j] = slot[i], vc[j] = max_cp[i], va[j] = acceptor[i], vbn[j] = bnum[i], vbc[j] = bcoord[i];
+      }
+#pragma unroll
+      for (int j = 0; j < GPX_SAR_VPT; j++) {
+        vl[j] = -1;
+        vk[j] = 0;
+        vm[j] = 0;
+        if (j * GPX_SAR_BLOCK + t < nb) {
+          const int32_t i = vi[j];
+          const uint32_t rel = (uint32_t)(vg[j] - cur);
+          const uint32_t lb = rel / width;
+          vl[j] = (int32_t)lb;
+          vk[j] = (int32_t)(((rel - lb * width) << GPX_SAR_IDX_BITS) | (uint32_t)i);
+          const bool esc = vbn[j] != b0n || vbc[j] != b0c || (uint32_t)va[j] > 0xffffu;
+          vm[j] = esc ? V16_ESC : ((uint32_t)va[j] << 16);
+          atomicAdd(&lcnt[lb], 1);
+          if (status) status[i] = GPX_S_OK; /* no prefill pass ran; apply_ar_group overwrites it for a vote it drops */
+        }
       }
     }
     __syncthreads();
@@ -503,7 +493,6 @@ __global__ __launch_bounds__(GPX_SAR_BLOCK) void k_ar_small(
   if (!published && t == 0) /* an empty range (more workgroups than groups) */
     __hip_atomic_store(&tickets[w], ((unsigned long long)epoch << 32) | (uint32_t)running, __ATOMIC_RELEASE,
                        __HIP_MEMORY_SCOPE_AGENT);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); /* no prefetch outlives the workgroup's LDS */
   if (w == 0 && t == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
   if (w == W - 1) { /* the call's count */
     if (base < 0) base = wait_earlier();
