@@ -116,13 +116,9 @@ struct gpx_engine {
   unsigned long long* one_words = nullptr; /* the verdict word of k_one_check (gpx_one.hip.h) */
   uint32_t one_epoch = 0;
   uint32_t* runs_arrive = nullptr; /* k_runs_check's arrival counters (first use) */
-  /* small accept-reply calls in one launch (gpx_small.hip.h): votes a workgroup is sized for (GPX_SAR_VOTES_PER_WG,
-   * tuning; a little under the kernel's 1,024 lanes, so that a workgroup rarely holds a second vote per thread),
-   * 0 = the path is off (GPX_SAR_VOTES_PER_WG=0: every call takes the partition pipeline) */
-  int32_t sar_votes_per_wg = 896;
-  /* ... calls of at most this many votes take it (GPX_SAR_MAX_N): beyond, every workgroup re-reading the whole gidx
-   * column and gathering its votes at random costs more than the partition pipeline's four launches */
-  int32_t sar_max_n = 32768;
+  /* accept-reply calls of at most this many votes, in any order, take ONE launch of one workgroup (gpx_small.hip.h;
+   * GPX_SAR_MAX_N: tuning, 0 = every call takes the partition pipeline) */
+  int32_t sar_max_n = GPX_SAR_MAX_N;
   /* GPX_LAZY_OUTPUTS: what gpx_compact_last_dev needs to finish the most recent call (kind 0: nothing pending) */
   struct LastCall {
     int kind = 0; /* 1 ACCEPT, 2 COMMIT (k_ac_one), 3 accept replies (k_ar_runs) */
@@ -605,7 +601,6 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
-  if (const char* sv = getenv("GPX_SAR_VOTES_PER_WG")) e->sar_votes_per_wg = std::max(0, std::min(GPX_SAR_CAP, atoi(sv)));
   if (const char* sv = getenv("GPX_SAR_MAX_N")) e->sar_max_n = std::max(0, std::min(GPX_SAR_MAX_N, atoi(sv)));
   e->ordered_mask = e->env_mask;
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
@@ -649,7 +644,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
       HIPCHK_CREATE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
   }
   { /* the one-launch small accept-reply kernel stages 80 KiB (gpx_small.hip.h) */
-    const void* fns[] = {(const void*)k_ar_small<4>, (const void*)k_ar_small<8>, (const void*)k_ar_small<16>};
+    const void* fns[] = {(const void*)k_ar_tiny<4>, (const void*)k_ar_tiny<8>, (const void*)k_ar_tiny<16>};
     for (const void* f : fns)
       HIPCHK_CREATE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GPX_SAR_LDS_BYTES));
   }
@@ -985,6 +980,33 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
    * the partition pipeline, launched behind, takes any other batch (its kernels return at once otherwise). */
   const bool runs_promised = (e->ordered_mask & GPX_ORDERED_REPLY_RUNS) != 0;
   const bool runs_try = runs_promised || (e->ordered_mask & GPX_TRY_REPLY_RUNS) != 0;
+  /* (0) a tiny call, whatever its order: ONE launch of one workgroup (gpx_small.hip.h).  Not under the
+   * GPX_ORDERED_REPLY_RUNS promise, whose breach must be refused: this kernel would apply such a batch. */
+  if (!runs_promised && n <= e->sar_max_n && e->S.G <= GPX_SAR_MAX_G) {
+    e->last.kind = 0; /* dense outputs, always */
+#ifdef GPX_SAR_TRACE
+    sar_trace_begin(e);
+#endif
+    {
+      LaunchScope _ls(e, "k_ar_tiny");
+#define GPX_LAUNCH_AR_TINY(KM)                                                                                          \
+  hipLaunchKernelGGL(k_ar_tiny<KM>, dim3(1), dim3(GPX_SAR_BLOCK), GPX_SAR_LDS_BYTES, e->stream, e->S, e->X, n, gidx, bnum, \
+                     bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, status)
+      if (e->cfg.kmax <= 4)
+        GPX_LAUNCH_AR_TINY(4);
+      else if (e->cfg.kmax <= 8)
+        GPX_LAUNCH_AR_TINY(8);
+      else
+        GPX_LAUNCH_AR_TINY(16);
+#undef GPX_LAUNCH_AR_TINY
+    }
+#ifdef GPX_SAR_TRACE
+    sar_trace_end(e);
+#endif
+    end_call(e, fs);
+    HIPCHK(hipGetLastError());
+    return GPX_OK;
+  }
   if (runs_try) {
     const size_t N = (size_t)e->cfg.max_batch;
     if (!e->runs_info && (rc = dev_alloc(e, &e->runs_info, 2, true)) != GPX_OK) return rc;
@@ -1062,36 +1084,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     }
     e->X.gate = 1; /* the partition kernels below run only if k_runs_check raised *X.unsorted */
   }
-  if (n <= e->sar_max_n && e->S.G <= GPX_SAR_MAX_G && e->sar_votes_per_wg > 0) {
-    /* (ii) a small call, whatever its order: ONE launch (gpx_small.hip.h) */
-    const int W = std::max(1, std::min({GPX_SAR_MAX_WG, (n + e->sar_votes_per_wg - 1) / e->sar_votes_per_wg, (int)e->S.G}));
-    if (++e->small_epoch == 0) {
-      HIPQ(hipMemsetAsync(e->small_tickets, 0, 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK) * sizeof(unsigned long long), e->stream));
-      e->small_epoch = 1;
-    }
-    e->last.kind = 0; /* dense outputs, always */
-#ifdef GPX_SAR_TRACE
-    if (!e->X.gate) sar_trace_begin(e);
-#endif
-    static_assert(GPX_SAR_MAX_WG <= 2 * (GPX_SMALL_DIRECT_MAX_N / GPX_DCHUNK), "one ticket per workgroup");
-    {
-      LaunchScope _ls(e, "k_ar_small");
-#define GPX_LAUNCH_AR_SMALL(KM)                                                                                          \
-  hipLaunchKernelGGL(k_ar_small<KM>, dim3(W), dim3(GPX_SAR_BLOCK), GPX_SAR_LDS_BYTES, e->stream, e->S, e->X, n, gidx, bnum, \
-                     bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, status, \
-                     e->small_tickets, e->small_epoch, W, e->X.gate)
-      if (e->cfg.kmax <= 4)
-        GPX_LAUNCH_AR_SMALL(4);
-      else if (e->cfg.kmax <= 8)
-        GPX_LAUNCH_AR_SMALL(8);
-      else
-        GPX_LAUNCH_AR_SMALL(16);
-#undef GPX_LAUNCH_AR_SMALL
-    }
-#ifdef GPX_SAR_TRACE
-    if (!e->X.gate) sar_trace_end(e);
-#endif
-  } else {
+  {
     /* (iii) the partition pipeline */
     ar_partition(e, n, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp,
                  d_kind, n_out, status);

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Runs a few small accept-reply calls on the -DGPX_SAR_TRACE build and prints, per kernel stamp, when the
+"""Runs a few tiny / small accept-reply calls on the -DGPX_SAR_TRACE build and prints, per kernel stamp, when the
 workgroups of the LAST call of each shape passed it (us after the first workgroup's entry)."""
 import os
 import sys
@@ -13,9 +13,7 @@ from gigapaxos_amd import Engine, hri_create, load_hip, streams, S_OK, ORDERED_R
 
 TRACE = "/tmp/sar_trace.bin"
 os.environ["GPX_SAR_TRACE_FILE"] = TRACE
-os.environ.setdefault("GPX_SAR_MAX_N", "131072")  # time the kernel at every size, whatever the engine's crossover
-NAMES = {"k_ar_small": ["entry", "(drawn: first build)", "column scanned", "votes gathered", "placed", "lane 0 replayed", "all replayed",
-                         "earlier tickets in", "outputs written"],
+NAMES = {"k_ar_tiny": ["entry", "", "", "votes loaded", "placed", "thread 0 replayed", "all replayed", "", "outputs written"],
          "k_ar_runs_small": ["entry", "verdict exchanged", "lane 0 straight-line done", "all lanes done"]}
 
 
@@ -36,7 +34,7 @@ def summary(kernel):
 def main():
     dev = torch.device("cuda:0")
     P = lambda t: t.data_ptr()  # noqa: E731
-    for G, n, runs in ((1_000_000, 65536, False), (10_000, 30_000, False), (10_000, 30_000, True), (1_000_000, 8192, False)):
+    for G, n, runs in ((1_000_000, 1024, False), (10_000, 1024, False), (10_000, 30_000, True), (1_000_000, 256, False)):
         K, members = 3, [100, 101, 102]
         e = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=max(n, G) + 1024)
         mem = np.tile(np.array(members, np.int32), (G, 1))
@@ -55,7 +53,7 @@ def main():
             e.call_dev("accept_reply_batch", nn, *[P(c) for c in dc], *[P(t) for t in d], P(no), P(st))
             torch.cuda.synchronize()
         print(f"G = {G}, {nn} votes, {'ascending runs' if runs else 'shuffled'}: n_out = {int(no)}")
-        summary("k_ar_runs_small" if runs else "k_ar_small")
+        summary("k_ar_runs_small" if runs else "k_ar_tiny")
         e.close()
 
 

@@ -45,10 +45,10 @@ GPU_FAST = [
     "test_route_gpu.py::test_route_matches_shard_map[8-300000-100000]",
     "test_async_gpu.py::test_async_rounds_match_oracle[300000-3]",
     "test_host_cluster_gpu.py::test_cluster_matches_oracle_build[0]",
-    "test_small_ar_gpu.py::test_small_calls_vs_oracle[30000-3-65536-None]",                # k_ar_small: one pass per workgroup
-    "test_small_ar_gpu.py::test_small_calls_vs_oracle[100000-3-40000-64]", "test_small_ar_gpu.py::test_small_calls_vs_oracle[7-3-5000-None]",
-    "test_small_ar_gpu.py::test_skewed_small_calls[None-two bands and a hot group]",       # ... passes and windows
-    "test_small_ar_gpu.py::test_small_call_fuzz[5-3000-2-32]", "test_small_ar_gpu.py::test_runs_hint_in_front_of_the_small_path",
+    "test_small_ar_gpu.py::test_small_calls_vs_oracle[30000-3-1024-True]",                 # k_ar_tiny
+    "test_small_ar_gpu.py::test_small_calls_vs_oracle[1000000-5-512-True]", "test_small_ar_gpu.py::test_small_calls_vs_oracle[7-3-1024-True]",
+    "test_small_ar_gpu.py::test_skewed_small_calls[1024-",                                 # ... hot groups: a lane's own replay
+    "test_small_ar_gpu.py::test_small_call_fuzz[5-3000-2]", "test_small_ar_gpu.py::test_runs_hint_and_small_calls",
 ]
 
 
