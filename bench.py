@@ -407,8 +407,7 @@ def main():
             o = [np.zeros(G, np.int32) for _ in range(4)] + [np.zeros(G, np.uint8)]
             d = [np.zeros(nv, np.int32) for _ in range(5)] + [np.zeros(nv, np.uint8)]
             no, st = np.zeros(1, np.int32), np.zeros(nv, np.uint8)
-            ee.host_register(*(o + d + [no, st]))
-            ring.append((o, d, no, st))
+            ring.append((o, d, no, st))  # (pinned below, through the engine that uses them)
         common = not args.mix
 
         def submit(r):
@@ -432,9 +431,11 @@ def main():
         hcols = [[np.ascontiguousarray(c) for c in streams.vote_round(G, members, r, 100, config_id=cfg_id,
                                                                         shuffled=not args.sorted, mix=args.mix)]
                  for r in range(n_async)]
-        ee.host_unregister(*[c for cols_ in pinned_rounds for c in cols_])
+        # (gpx_engine_destroy took away every pinning made through the first engine: round 4's unregister-on-destroy)
         pinned_rounds = hcols
-        ee.host_register(*[c for cols_ in hcols for c in cols_])
+        ee.host_register(hg, *[c for cols_ in hcols for c in cols_])
+        for o, d, no, st in ring:
+            ee.host_register(*(o + d + [no, st]))
         e2e_rounds = n_async
         for t in [submit(0), submit(0)]:  # warm: all four sets of device columns allocated (the repeated
             wait(t)                       # round only brings late votes; one more slot stays outstanding)
@@ -460,8 +461,7 @@ def main():
                               "and the D2H of step r; synchronous_calls_ms_per_step = the plain calls, one after the other"}
         for o, d, no, st in ring:
             ee.host_unregister(*(o + d + [no, st]))
-        pinned = [hg, hno, hst] + ho + hd + [c for cols_ in pinned_rounds for c in cols_]
-        ee.host_unregister(*pinned)
+        ee.host_unregister(hg, *[c for cols_ in pinned_rounds for c in cols_])
         ee.close()
         end_to_end["host_thread_pinned_to_gpu_numa_node"] = prev_affinity is not None
         if prev_affinity is not None:
