@@ -313,51 +313,72 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_ac_small(
   __syncthreads();
   const int32_t w = s_w;
   const int32_t i = w * GPX_DCHUNK + (int32_t)threadIdx.x;
+  /* wave 1 of loads, as in k_ac_one: the neighbours in gidx and this record's columns; wave 2: the group's
+   * acceptor state and the ring entry of this record's slot - both requested BEFORE the verdict is worked out (round 4:
+   * until then the replay fetched them one dependent round trip after the other, behind the scan of the column:
+   * five or six of the kernel's twelve round trips) */
+  int32_t g = 0, g_prev = 0, g_next = 0, f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
+  bool runstart = false;
+  AccPre P = acc_nopre();
+  if (i < n) {
+    g = gidx[i];
+    g_prev = i > 0 ? gidx[i - 1] : ~g;
+    g_next = i + 1 < n ? gidx[i + 1] : ~g;
+    f_a = slot[i], f_b = median[i], f_c = flags ? (int32_t)flags[i] : 0;
+    f_bnum = bnum[i], f_bcoord = bcoord[i];
+    runstart = g_prev != g; /* first record of its group's run: answers for the whole run */
+    if (runstart && (uint32_t)g < (uint32_t)S.G) acc_preload(S, g, f_a, P); /* (a refused head has loaded in vain) */
+  }
   const uint32_t first_bad = small_batch_first_bad<false>(n, gidx, S.G);
   if (first_bad != 0xffffffffu && !refuse) { /* no promise: the partition path launched behind takes the whole batch */
     if (w == 0 && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
-    if (i < n) status[i] = (uint32_t)gidx[i] < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
+    if (i < n) status[i] = (uint32_t)g < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
     return;
   }
   int32_t have = 0, first = 0, count = 0;
-  if (i < n) {
-    const int32_t g = gidx[i];
-    if (i == 0 || gidx[i - 1] != g) { /* first record of its group's run: answers for the whole run */
-      if ((uint32_t)i >= first_bad) {
-        /* GPX_ORDERED_* broken: runs from the first violation on are refused (the first violation is always a
-         * run start: gpx_one.hip.h) */
-        for (int32_t j = i; j < n && gidx[j] == g; j++) {
-          if (!COMMIT) {
-            r_bnum[j] = 0;
-            r_bcoord[j] = 0;
-            r_maxcp[j] = 0;
-            r_flags[j] = 0;
-          }
-          status[j] = GPX_S_UNORDERED;
+  if (runstart) {
+    if ((uint32_t)i >= first_bad) {
+      /* GPX_ORDERED_* broken: runs from the first violation on are refused (the first violation is always a
+       * run start: gpx_one.hip.h) */
+      for (int32_t j = i; j < n && (j == i || gidx[j] == g); j++) {
+        if (!COMMIT) {
+          r_bnum[j] = 0;
+          r_bcoord[j] = 0;
+          r_maxcp[j] = 0;
+          r_flags[j] = 0;
         }
-      } else { /* replays the run in array order */
-        RunIter it;
-        it.gidx = gidx;
-        it.bnum = bnum;
-        it.bcoord = bcoord;
-        it.slot = slot;
-        it.median = median;
-        it.flags = flags;
-        it.D = D;
-        it.n = n;
-        it.i = i;
-        it.g = g;
-        it.cur = i;
-        it.epoch = X.epoch;
-        it.chunk = -1; /* every run is parked at its record and counted below */
-        it.local = 0;
-        it.count_chunks = false;
-        it.st = status;
-        if (COMMIT)
-          apply_commit_group(S, X, g, it, status);
-        else
-          apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status);
+        status[j] = GPX_S_UNORDERED;
       }
+    } else { /* replays the run in array order */
+      RunIter it;
+      it.gidx = gidx;
+      it.bnum = bnum;
+      it.bcoord = bcoord;
+      it.slot = slot;
+      it.median = median;
+      it.flags = flags;
+      it.D = D;
+      it.n = n;
+      it.i = i;
+      it.g = g;
+      it.cur = i;
+      it.epoch = X.epoch;
+      it.chunk = -1; /* every run is parked at its record and counted below */
+      it.local = 0;
+      it.count_chunks = false;
+      it.st = status;
+      it.have_first = true;
+      it.f_a = f_a;
+      it.f_b = f_b;
+      it.f_c = f_c;
+      it.f_bnum = f_bnum;
+      it.f_bcoord = f_bcoord;
+      it.head = i;
+      it.g_next = g_next;
+      if (COMMIT)
+        apply_commit_group(S, X, g, it, status, P);
+      else
+        apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status, nullptr, P);
     }
   }
   /* the runs parked at THIS chunk's records: by this workgroup's heads, or by a head of an earlier

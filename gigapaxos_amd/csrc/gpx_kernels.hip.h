@@ -1880,16 +1880,24 @@ __device__ __forceinline__ uint32_t small_batch_first_bad(int32_t n, const int32
   __shared__ uint32_t s_first_bad;
   if (threadIdx.x == 0) s_first_bad = 0xffffffffu;
   uint32_t mine = 0xffffffffu;
-  for (int32_t i0 = (int32_t)threadIdx.x * 4; i0 < n; i0 += (int32_t)blockDim.x * 4) {
-    int32_t g[5];
-    g[0] = i0 > 0 ? gidx[i0 - 1] : INT32_MIN;
+  /* sixteen entries and their predecessors in flight per lane and round, none of them behind a branch (an index
+   * behind the batch's end is clamped for the load): a column of 16,384 entries is one round trip for a workgroup of
+   * 1,024 lanes (round 4; before: four entries per lane and round, three rounds for 10,000 entries) */
+  const int32_t B = (int32_t)blockDim.x, t = (int32_t)threadIdx.x;
+  for (int32_t r0 = 0; r0 < n; r0 += 16 * B) {
+    int32_t gg[16], gp[16];
 #pragma unroll
-    for (int q = 0; q < 4; q++) g[q + 1] = i0 + q < n ? gidx[i0 + q] : INT32_MAX;
+    for (int k = 0; k < 16; k++) {
+      const int32_t ic = min(r0 + k * B + t, n - 1);
+      gg[k] = gidx[ic];
+      gp[k] = gidx[max(ic - 1, 0)];
+    }
 #pragma unroll
-    for (int q = 3; q >= 0; q--)
-      if (i0 + q < n && ((uint32_t)g[q + 1] >= (uint32_t)G ||
-                         (i0 + q > 0 && (STRICT ? g[q] >= g[q + 1] : g[q] > g[q + 1]))))
-        mine = min(mine, (uint32_t)(i0 + q));
+    for (int k = 15; k >= 0; k--) {
+      const int32_t i = r0 + k * B + t;
+      const bool viol = i < n && ((uint32_t)gg[k] >= (uint32_t)G || (i > 0 && (STRICT ? gp[k] >= gg[k] : gp[k] > gg[k])));
+      mine = viol ? min(mine, (uint32_t)i) : mine;
+    }
   }
   if (__syncthreads_or(mine != 0xffffffffu)) {
     if (mine != 0xffffffffu) atomicMin(&s_first_bad, mine);
@@ -1909,10 +1917,18 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_small(
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
     const int64_t* __restrict__ handle, int32_t refuse) {
   const int32_t i = blockIdx.x * GPX_BLOCK + threadIdx.x;
+  /* the record's group state is requested before the verdict is worked out, as in k_propose_one (a refused record
+   * has loaded in vain) */
+  const int32_t g = i < n ? gidx[i] : -1;
+  ProposePre<KMAX> P;
+  if ((uint32_t)g < (uint32_t)S.G) {
+    propose_preload<KMAX>(S, g, P);
+    propose_preload_ring<KMAX>(S, g, P);
+  }
   const uint32_t first_bad = small_batch_first_bad<true>(n, gidx, S.G);
   if (first_bad != 0xffffffffu && !refuse) { /* no promise: the partition path launched behind takes the whole batch */
     if (blockIdx.x == 0 && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
-    if (i < n) status[i] = (uint32_t)gidx[i] < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
+    if (i < n) status[i] = (uint32_t)g < (uint32_t)S.G ? GPX_S_OK : GPX_S_NOGROUP; /* what k_order_check leaves */
     return;
   }
   if (i >= n) return;
@@ -1925,10 +1941,6 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_small(
     return;
   }
   status[i] = GPX_S_OK;
-  const int32_t g = gidx[i];
-  ProposePre<KMAX> P;
-  propose_preload<KMAX>(S, g, P);
-  propose_preload_ring<KMAX>(S, g, P);
   OneRec it;
   it.idx = i;
   it.a = is_stop ? (int32_t)(is_stop[i] & 1) : 0;
