@@ -332,7 +332,7 @@ void end_call(gpx_engine* e, int) { e->call_seq++; }
 /* the verdict word of an ordered batch (gpx_one.hip.h) and a fresh, ascending epoch for it */
 OneCtl one_ctl(gpx_engine* e) {
   if (++e->one_epoch == 0) { /* 2^32 launches: start the epochs again from a cleared word */
-    HIPQ(hipMemsetAsync(e->one_words, 0, sizeof(unsigned long long), e->stream));
+    HIPQ(hipMemsetAsync(e->one_words, 0, sizeof(unsigned long long) * (GPX_ONE_TICKETS + GPX_ONE_XCHG_MAX_N / GPX_DBLOCK), e->stream));
     e->one_epoch = 1;
   }
   return OneCtl{e->one_words, e->one_epoch};
@@ -675,7 +675,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.o_rec, N, false);
   A(X.bucket_nout, nbk_alloc, true);
   A(e->rec_tag, N, true);
-  A(e->one_words, 16, true);
+  A(e->one_words, GPX_ONE_TICKETS + GPX_ONE_XCHG_MAX_N / GPX_DBLOCK, true); /* the verdict word, then k_ac_one<.., XCHG>'s tickets */
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
@@ -1120,10 +1120,18 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
   const bool promised = (e->ordered_mask & GPX_ORDERED_ACCEPT) != 0;
   e->last.kind = 0;
-  if (promised && !fused) {
+  if (promised && (!fused || lazy_outputs(e))) {
     /* the promise and more than 65,536 records: the verdict (k_one_check, which also writes the usual batch's
-     * count) and ONE work kernel (gpx_one.hip.h); the compaction pass follows unless the caller asked for lazy outputs */
-    {
+     * count) and ONE work kernel (gpx_one.hip.h); the compaction pass follows unless the caller asked for lazy outputs.
+     * At most 65,536 records with lazy outputs: the work kernel alone - its (at most 256, resident) workgroups
+     * exchange the verdict among themselves (k_ac_one<.., XCHG>); without lazy outputs k_ac_small's in-kernel run
+     * compaction is the one launch */
+    if (fused) {
+      const OneCtl C = one_ctl(e);
+      LaunchScope _ls(e, "k_ac_one_x");
+      hipLaunchKernelGGL((k_ac_one<false, true>), dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, C, n,
+                         gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, n_runs, 0);
+    } else {
       const OneCtl C = one_ctl(e);
       {
         LaunchScope _lc(e, "k_one_check");
@@ -1233,8 +1241,14 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N; /* one launch: k_ac_small */
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
   e->last.kind = 0;
-  if (promised && !fused) { /* check + one work kernel (gpx_one.hip.h), like the ACCEPT call */
-    {
+  if (promised && (!fused || lazy_outputs(e))) { /* check + one work kernel (gpx_one.hip.h), like the ACCEPT call */
+    if (fused) {
+      const OneCtl C = one_ctl(e);
+      LaunchScope _ls(e, "k_ac_one_x");
+      hipLaunchKernelGGL((k_ac_one<true, true>), dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, C, n,
+                         gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
+                         (uint8_t*)nullptr, status, D, n_runs, n);
+    } else {
       const OneCtl C = one_ctl(e);
       {
         LaunchScope _lc(e, "k_one_check");

@@ -87,31 +87,61 @@ __global__ __launch_bounds__(GPX_DBLOCK) void k_one_check(int32_t n, const int32
   }
 }
 
-template <bool COMMIT>
+/* XCHG (round 4, batches of at most 65,536 records = at most 256 workgroups, all resident): no k_one_check launch -
+ * every workgroup judges its OWN 256 records (it has loaded them and their predecessors anyway), publishes its first
+ * violation in an epoch-tagged ticket (C.verdict + GPX_ONE_TICKETS + blockIdx), and reads all tickets: one exchange
+ * between resident workgroups, with the group state already requested.  Workgroup 0 writes the regular count before
+ * its ticket, so a workgroup that overwrites it with -1 does so after it. */
+#define GPX_ONE_TICKETS 16
+#define GPX_ONE_XCHG_MAX_N 65536
+template <bool COMMIT, bool XCHG = false>
 __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
     DevState S, DevScratch X, OneCtl C, int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
     const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot, const int32_t* __restrict__ median,
     const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status, DirectStage D,
-    int32_t* __restrict__ n_runs) {
+    int32_t* __restrict__ n_runs, int32_t regular_count = 0) {
   const int32_t i = (int32_t)blockIdx.x * GPX_DBLOCK + (int32_t)threadIdx.x;
-  const uint32_t first_bad = one_first_bad(C);
+  uint32_t first_bad = XCHG ? ONE_NONE : one_first_bad(C);
   /* wave 1 of loads: the neighbours in gidx and this record's columns */
   int32_t g = 0, g_prev = 0, g_next = 0, f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
-  bool head = false, runstart = false;
+  bool head = false, runstart = false, oob = false;
   if (i < n) {
     g = gidx[i];
     g_prev = i > 0 ? gidx[i - 1] : ~g;
     g_next = i + 1 < n ? gidx[i + 1] : ~g;
     f_a = slot[i], f_b = median[i], f_c = flags ? (int32_t)flags[i] : 0;
     f_bnum = bnum[i], f_bcoord = bcoord[i];
-    const bool oob = (uint32_t)g >= (uint32_t)S.G;
+    oob = (uint32_t)g >= (uint32_t)S.G;
     runstart = g_prev != g; /* first record of a run of equal gidx: this lane answers for the whole run */
     head = runstart && !oob;
   }
   /* wave 2: the group's acceptor state and the ring entry of this record's slot */
   AccPre P = acc_nopre();
   if (head) acc_preload(S, g, f_a, P); /* (not made to wait for the verdict word: a refused head has loaded in vain) */
+  if (XCHG) {
+    __shared__ uint32_t s_mine, s_all;
+    if (threadIdx.x == 0) s_mine = 0, s_all = 0;
+    __syncthreads();
+    /* the verdict's encoding: ONE_NONE - index, 0 = none; the batch's first violation is the MAX over everybody */
+    if (i < n && (oob || (i > 0 && g_prev > g))) atomicMax(&s_mine, ONE_NONE - (uint32_t)i);
+    __syncthreads();
+    unsigned long long* const tick = C.verdict + GPX_ONE_TICKETS;
+    if (threadIdx.x == 0) {
+      if (blockIdx.x == 0 && n_runs) *n_runs = regular_count;
+      __hip_atomic_store(&tick[blockIdx.x], ((unsigned long long)C.epoch << 32) | s_mine, __ATOMIC_RELEASE,
+                         __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (threadIdx.x < gridDim.x) {
+      unsigned long long v;
+      do {
+        v = __hip_atomic_load(&tick[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+      } while ((uint32_t)(v >> 32) != C.epoch);
+      if ((uint32_t)v) atomicMax(&s_all, (uint32_t)v);
+    }
+    __syncthreads();
+    first_bad = ONE_NONE - s_all;
+  }
   bool irregular = false;
   if (runstart) {
     if ((uint32_t)i >= first_bad) {
