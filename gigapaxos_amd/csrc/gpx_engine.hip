@@ -1393,6 +1393,22 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
     HIPCHK(hipGetLastError());
     return GPX_OK;
   }
+  if (fused && promised) { /* the work kernel alone: its (at most 256, resident) workgroups exchange the verdict */
+    e->stream = e->sB;
+    const OneCtl C = one_ctl(e);
+    if (e->cfg.kmax <= 4)
+      LAUNCH(e, "k_propose_one_x", (k_propose_one<4, true>), grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord,
+             median_cp, status, handle);
+    else if (e->cfg.kmax <= 8)
+      LAUNCH(e, "k_propose_one_x", (k_propose_one<8, true>), grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord,
+             median_cp, status, handle);
+    else
+      LAUNCH(e, "k_propose_one_x", (k_propose_one<16, true>), grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord,
+             median_cp, status, handle);
+    end_call(e, fs);
+    HIPCHK(hipGetLastError());
+    return GPX_OK;
+  }
   if (fused) {
     e->stream = e->sB;
     if (e->cfg.kmax <= 4)

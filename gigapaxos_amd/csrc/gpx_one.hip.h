@@ -94,6 +94,33 @@ __global__ __launch_bounds__(GPX_DBLOCK) void k_one_check(int32_t n, const int32
  * its ticket, so a workgroup that overwrites it with -1 does so after it. */
 #define GPX_ONE_TICKETS 16
 #define GPX_ONE_XCHG_MAX_N 65536
+/* the exchange: this lane's record i violates the order (or not) -> the batch's first violation.  Every thread of every
+ * workgroup of the grid must call it (barriers; at most GPX_DBLOCK workgroups).  count_out / regular_count: workgroup 0
+ * writes the regular batch's count before its ticket goes out. */
+__device__ __forceinline__ uint32_t one_exchange(const OneCtl& C, bool viol, int32_t i, int32_t* __restrict__ count_out,
+                                                 int32_t regular_count) {
+  __shared__ uint32_t s_mine, s_all;
+  if (threadIdx.x == 0) s_mine = 0, s_all = 0;
+  __syncthreads();
+  /* the verdict's encoding: ONE_NONE - index, 0 = none; the batch's first violation is the MAX over everybody */
+  if (viol) atomicMax(&s_mine, ONE_NONE - (uint32_t)i);
+  __syncthreads();
+  unsigned long long* const tick = C.verdict + GPX_ONE_TICKETS;
+  if (threadIdx.x == 0) {
+    if (blockIdx.x == 0 && count_out) *count_out = regular_count;
+    __hip_atomic_store(&tick[blockIdx.x], ((unsigned long long)C.epoch << 32) | s_mine, __ATOMIC_RELEASE,
+                       __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (threadIdx.x < gridDim.x) {
+    unsigned long long v;
+    do {
+      v = __hip_atomic_load(&tick[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    } while ((uint32_t)(v >> 32) != C.epoch);
+    if ((uint32_t)v) atomicMax(&s_all, (uint32_t)v);
+  }
+  __syncthreads();
+  return ONE_NONE - s_all;
+}
 template <bool COMMIT, bool XCHG = false>
 __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
     DevState S, DevScratch X, OneCtl C, int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
@@ -119,29 +146,7 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
   /* wave 2: the group's acceptor state and the ring entry of this record's slot */
   AccPre P = acc_nopre();
   if (head) acc_preload(S, g, f_a, P); /* (not made to wait for the verdict word: a refused head has loaded in vain) */
-  if (XCHG) {
-    __shared__ uint32_t s_mine, s_all;
-    if (threadIdx.x == 0) s_mine = 0, s_all = 0;
-    __syncthreads();
-    /* the verdict's encoding: ONE_NONE - index, 0 = none; the batch's first violation is the MAX over everybody */
-    if (i < n && (oob || (i > 0 && g_prev > g))) atomicMax(&s_mine, ONE_NONE - (uint32_t)i);
-    __syncthreads();
-    unsigned long long* const tick = C.verdict + GPX_ONE_TICKETS;
-    if (threadIdx.x == 0) {
-      if (blockIdx.x == 0 && n_runs) *n_runs = regular_count;
-      __hip_atomic_store(&tick[blockIdx.x], ((unsigned long long)C.epoch << 32) | s_mine, __ATOMIC_RELEASE,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    }
-    if (threadIdx.x < gridDim.x) {
-      unsigned long long v;
-      do {
-        v = __hip_atomic_load(&tick[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-      } while ((uint32_t)(v >> 32) != C.epoch);
-      if ((uint32_t)v) atomicMax(&s_all, (uint32_t)v);
-    }
-    __syncthreads();
-    first_bad = ONE_NONE - s_all;
-  }
+  if (XCHG) first_bad = one_exchange(C, i < n && (oob || (i > 0 && g_prev > g)), i, n_runs, regular_count);
   bool irregular = false;
   if (runstart) {
     if ((uint32_t)i >= first_bad) {
@@ -211,20 +216,25 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_one_count(DevScratch X, int32_t 
 }
 
 /* PROPOSE: strictly ascending gidx (every group at most once), so every record is its group's only one */
-template <int KMAX>
+template <int KMAX, bool XCHG = false>
 __global__ __launch_bounds__(GPX_BLOCK) void k_propose_one(
     DevState S, DevScratch X, OneCtl C, int32_t n, const int32_t* __restrict__ gidx,
     const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
     const int64_t* __restrict__ handle) {
   const int32_t i = (int32_t)blockIdx.x * GPX_BLOCK + (int32_t)threadIdx.x;
-  if (i >= n) return;
-  const uint32_t first_bad = one_first_bad(C);
-  const int32_t g = gidx[i];
+  if (!XCHG && i >= n) return;
+  uint32_t first_bad = XCHG ? ONE_NONE : one_first_bad(C);
+  const int32_t g = i < n ? gidx[i] : -1;
+  const int32_t g_prev = (XCHG && i > 0 && i < n) ? gidx[i - 1] : INT32_MIN;
   ProposePre<KMAX> P;
-  if ((uint32_t)g < (uint32_t)S.G) { /* requested without waiting for the verdict word */
+  if ((uint32_t)g < (uint32_t)S.G) { /* requested without waiting for the verdict */
     propose_preload<KMAX>(S, g, P);
     propose_preload_ring<KMAX>(S, g, P);
+  }
+  if (XCHG) { /* at most 65,536 requests: no k_one_check launch (one_exchange); strictly ascending, in range */
+    first_bad = one_exchange(C, i < n && ((uint32_t)g >= (uint32_t)S.G || (i > 0 && g_prev >= g)), i, nullptr, 0);
+    if (i >= n) return;
   }
   if ((uint32_t)i >= first_bad) {
     o_slot[i] = 0;
