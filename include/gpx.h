@@ -34,7 +34,9 @@
  *     the sequential one, across groups the reference defines no order.)
  *   - one submitting thread per engine at a time (the ConsumerTask single-
  *     consumer discipline, ConsumerTask.java:163-174); different engines are
- *     fully concurrent.
+ *     fully concurrent - on ONE GPU up to four of them (the kernels of small
+ *     ordered batches exchange their verdict between workgroups that must all
+ *     be resident: DESIGN.md 3 ii-b; the deployment is one engine per GPU).
  *   - the plain entry points take HOST pointers (what a JNI direct ByteBuffer
  *     gives); the *_dev twins take DEVICE pointers, run asynchronously on the
  *     engine's stream (gpx_engine_set_stream) and leave counts in device memory
