@@ -16,6 +16,12 @@
 #   ktpy:SCRIPT[:ARGS[:LABEL]]  rocprofv3 --kernel-trace --stats of python scripts/SCRIPT ARGS -> per-kernel summary
 #   sh:SCRIPT[:ARGS]      bash scripts/SCRIPT ARGS
 #   reffix                scripts/make_ref_fixtures.sh when a JDK exists (row c of SURVEY 8)
+#   fast                  pytest -m gpu_fast (about a minute: after every kernel change)
+#   smoke                 __graft_entry__.smoke()
+# Round 4's visits were mostly of this shape (1-2 GPU-minutes each):
+#   bash scripts/gpu_visit.sh r04 testfile:tests/test_small_ar_gpu.py sh:ubench/sar_trace.sh:run \
+#        py:bench_batch_sweep.py:--min-log2+7+--max-log2+11 py:bench_full_round.py:--groups+10000+--rounds+101 fast
+# (GPX_SAR_MAX_N=0 in front of it for the partition pipeline's side of a comparison)
 TAG=${1:-visit}
 shift
 REPO=$(pwd)
@@ -44,6 +50,15 @@ for step in "$@"; do
   IFS=: read -r kind a b c <<<"$step"
   echo "=== $step"
   case $kind in
+  fast)
+    f=$(uniq_name pytest_fast log)
+    timeout 400 python -m pytest tests -m gpu_fast -q -x >"$f" 2>&1
+    echo "pytest exit $?" >>"$f"
+    tail -4 "$f" | cut -c1-240
+    ;;
+  smoke)
+    timeout 200 python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -2
+    ;;
   probe)
     (java -version; javac -version; ant -version) >"$OUT/jdk_probe.txt" 2>&1
     (nproc; free -g | head -2; rocm-smi --showmeminfo vram 2>/dev/null | grep -i total | head -2) >"$OUT/box.txt" 2>&1
