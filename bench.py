@@ -54,6 +54,63 @@ def alg_bytes_per_vote(k: int) -> float:
 
 STRONG_GROUPS, STRONG_K = 1_000_000, 5  # BASELINE config #4: the ONE group space the metric is quoted on
 
+# kernels of the accept-reply call (the unit's call): everything else a step launches belongs to the proposal call
+AR_KERNELS = ("k_hist", "k_scatter_ar16", "k_bucket_ar16", "k_emit_dec16", "k_runs_check", "k_ar_runs", "k_ar_runs_small",
+              "k_emit_dec_runs", "k_merge_runs", "k_runs_count", "k_ar_tiny")
+# the engine's profile labels name the launch (k_bucket_ar16), rocprofv3 the kernel (k_bucket16<0, 4>)
+PMC_ALIAS = {"k_bucket_ar16": "k_bucket16", "k_bucket_accept16": "k_bucket16", "k_bucket_commit16": "k_bucket16",
+             "k_ar_runs_small": "k_ar_runs"}
+
+
+def gen_round(args, streams, G, members, r, cfg_id, mix):
+    """Round r of the synthetic accept-reply stream in the shape the run asked for (every leg draws from here)."""
+    if args.runs:
+        return streams.vote_round_runs(G, members, r, 100, config_id=cfg_id, mix=mix)
+    return streams.vote_round(G, members, r, 100, config_id=cfg_id, shuffled=not args.sorted, mix=mix)
+
+
+def link_peaks(torch, dev, eng, mbytes=64, reps=6):
+    """What the host link of THIS box moves, measured in the same run as `end_to_end` (its denominator): plain
+    hipMemcpyAsync of `mbytes` MB, host -> device and device -> host, alone and both at once, from memory allocated
+    for DMA (hipHostMalloc: torch's pinned allocator, = gpx_host_alloc) and from ordinary pages pinned afterwards
+    (hipHostRegister through gpx_host_register: what registering a JVM direct buffer gives)."""
+    n = mbytes * (1 << 20) // 4
+    d_in = torch.empty(n, dtype=torch.int32, device=dev)
+    d_out = torch.ones(n, dtype=torch.int32, device=dev)
+    s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+
+    def timed(fn_a, fn_b=None):
+        best = 0.0
+        for _ in range(reps):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with torch.cuda.stream(s1):
+                fn_a()
+            if fn_b:
+                with torch.cuda.stream(s2):
+                    fn_b()
+            s1.synchronize()
+            s2.synchronize()
+            best = max(best, n * 4 / (time.perf_counter() - t0) / 1e9)
+        return round(best, 1)
+
+    out = {}
+    reg_a, reg_b = np.zeros(n, np.int32), np.zeros(n, np.int32)
+    eng.host_register(reg_a, reg_b)
+    kinds = {"hipHostMalloc": (torch.empty(n, dtype=torch.int32).pin_memory(), torch.empty(n, dtype=torch.int32).pin_memory()),
+             "hipHostRegister": (torch.from_numpy(reg_a), torch.from_numpy(reg_b))}
+    for name, (h_a, h_b) in kinds.items():
+        h_a.fill_(1)
+        pinned = bool(h_a.is_pinned())
+        h2d = lambda: d_in.copy_(h_a, non_blocking=True)  # noqa: E731
+        d2h = lambda: h_b.copy_(d_out, non_blocking=True)  # noqa: E731
+        out[name] = {"h2d_GBps": timed(h2d), "d2h_GBps": timed(d2h), "seen_as_pinned_by_the_runtime": pinned}
+        both = timed(h2d, d2h)  # n * 4 bytes each way in the measured time
+        out[name]["both_directions_each_GBps"] = both
+    eng.host_unregister(reg_a, reg_b)
+    out["bytes_per_copy"] = n * 4
+    return out
+
 
 def launch_ranks(n: int) -> int:
     """`python bench.py --gpus N` without a launcher around it: re-run this command line under
@@ -82,6 +139,9 @@ class CoordinatorLeg:
                  order=None):
         from gigapaxos_amd import Engine, hri_create, load_hip, streams, S_OK
         self.torch, self.dist, self.world, self.rank, self.dev = torch, dist, world, rank, dev
+        # collectives carry telemetry only: over RCCL on the ranks' GPUs, or - ranks sharing ONE device
+        # (--same-device) - over gloo on host tensors
+        self.cdev = torch.device("cpu") if args.same_device else dev
         mix = args.mix if mix is None else mix
         self.mix, self.K, self.rounds = mix, K, rounds
         G = G_global = groups
@@ -103,11 +163,11 @@ class CoordinatorLeg:
         torch.cuda.set_stream(tstream)
         assert tstream.cuda_stream != 0
         eng.set_stream(tstream.cuda_stream)
-        if not args.no_promise:
-            # the proposal batch is one request per group in gidx order (what RequestBatcher hands over):
-            # declared, verified on the device, so the partition path is not even launched for it
-            from gigapaxos_amd import ORDERED_PROPOSE, ORDERED_REPLY_RUNS
-            eng.set_ordered_batches(ORDERED_PROPOSE | (ORDERED_REPLY_RUNS if args.runs else 0))
+        # the proposal batch is one request per group in gidx order (what RequestBatcher hands over): declared,
+        # verified on the device, so the partition path is not even launched for it (--no-promise: mask 0).
+        # --runs: the votes are the acceptors' replies concatenated; a regular round's outputs are dense as parked, so
+        # the compaction launches are left to gpx_compact_last_dev (GPX_LAZY_OUTPUTS) - and never needed here
+        eng.set_ordered_batches(self.promise_mask(args))
         self.mem = mem = np.tile(np.array(members, np.int32), (G, 1))
         assert (eng.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
 
@@ -120,8 +180,7 @@ class CoordinatorLeg:
         pool_n = min(rounds, 8)
         pool = []
         for r in range(pool_n):
-            cols = (streams.vote_round_runs(G, members, r, 100, config_id=cfg_id, mix=mix) if args.runs else
-                    streams.vote_round(G, members, r, 100, config_id=cfg_id, shuffled=not args.sorted, mix=mix))
+            cols = gen_round(args, streams, G, members, r, cfg_id, mix)
             pool.append([torch.from_numpy(c).to(dev) for c in cols])
         self.nv = nv = int(pool[0][0].shape[0])
         vote_cols = []
@@ -140,17 +199,48 @@ class CoordinatorLeg:
         self.p_st, self.d_k, self.d_s = p_st, d_k, d_s
         P = lambda t: t.data_ptr()  # noqa: E731
 
-        def step(r):
+        def propose_call(r):
             eng.call_dev("propose_batch", G, P(g_all), 0, P(p_slot), P(p_bnum), P(p_bcoord), P(p_med), P(p_st))
+
+        def reply_call(r):
             c = vote_cols[r]
             eng.call_dev("accept_reply_batch", nv, P(c[0]), P(c[1]), P(c[2]), P(c[3]), P(c[4]), P(c[5]),
                          P(d_g), P(d_s), P(d_b), P(d_c), P(d_m), P(d_k), n_out[r:].data_ptr(), P(v_st))
-        self.step = step
+
+        def step(r):
+            propose_call(r)
+            reply_call(r)
+        self.step, self.propose_call, self.reply_call = step, propose_call, reply_call
         self._keep = (vote_cols, g_all, p_slot, p_bnum, p_bcoord, p_med, d_g, d_b, d_c, d_m, v_st)
+
+    @staticmethod
+    def promise_mask(args):
+        from gigapaxos_amd import ORDERED_PROPOSE, ORDERED_REPLY_RUNS, LAZY_OUTPUTS
+        if args.no_promise:
+            return 0
+        return ORDERED_PROPOSE | ((ORDERED_REPLY_RUNS | LAZY_OUTPUTS) if args.runs else 0)
 
     def barrier(self):
         if self.world > 1:
             self.dist.barrier()
+
+    def profile_calls(self, first_round, psteps):
+        """Per-kernel launch times (hipEvents on the launch stream, gpx_profile_enable) of `psteps` further steps, kept
+        apart per CALL: {"propose_batch": {kernel: (launches, ms)}, "accept_reply_batch": {...}}."""
+        eng, torch = self.eng, self.torch
+        per_call = {"propose_batch": {}, "accept_reply_batch": {}}
+        eng.sync()
+        for r in range(first_round, first_round + psteps):
+            for name, call in (("propose_batch", self.propose_call), ("accept_reply_batch", self.reply_call)):
+                eng.profile(2)
+                call(r)
+                torch.cuda.synchronize()
+                for k, (n, ms) in eng.profile_read().items():
+                    a = per_call[name].setdefault(k, [0, 0.0])
+                    a[0] += n
+                    a[1] += ms
+        eng.profile(0)
+        return per_call
 
     def run_timed(self, warmup, steps):
         torch, dist, eng, step, dev, world, G = self.torch, self.dist, self.eng, self.step, self.dev, self.world, self.G
@@ -173,7 +263,7 @@ class CoordinatorLeg:
         torch.cuda.synchronize()
         self.gpu_ms = ev0.elapsed_time(ev1)
         if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+            t = torch.tensor([elapsed], dtype=torch.float64, device=self.cdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
         self.elapsed = elapsed
@@ -187,15 +277,15 @@ class CoordinatorLeg:
         decisions_local = int(counts[warmup:].sum())
         self.shard_counters = None
         if world > 1:
-            t = torch.tensor([decisions_local], dtype=torch.int64, device=dev)
+            t = torch.tensor([decisions_local], dtype=torch.int64, device=self.cdev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             self.decisions_total = int(t.item())
             # optional telemetry exchange: shard load counters over RCCL (not on the decide path)
-            ctr = torch.tensor(eng.counters(), dtype=torch.int64, device=dev)
+            ctr = torch.tensor(eng.counters(), dtype=torch.int64, device=self.cdev)
             allc = [torch.zeros_like(ctr) for _ in range(world)]
             dist.all_gather(allc, ctr)
             self.shard_counters = [c.tolist() for c in allc]
-            t = torch.tensor([self.nv * steps], dtype=torch.int64, device=dev)
+            t = torch.tensor([self.nv * steps], dtype=torch.int64, device=self.cdev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             self.votes_total = int(t.item())
         else:
@@ -206,6 +296,132 @@ class CoordinatorLeg:
         self.eng.sync()
         self.eng.close()
         self._keep = None
+
+
+def end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, mem, cfg_id):
+    """The step through the HOST-pointer entry points, the rate a JNI caller gets: the plain (synchronous) calls, then
+    the asynchronous ones two steps deep, and - the denominator - what this box's link moves with plain copies."""
+    import ctypes as C
+    from gigapaxos_amd import Engine, hri_create, load_hip, streams, S_OK
+    from gigapaxos_amd._abi import _p
+
+    prev_affinity = pin_to_gpu_numa_node(local_rank)  # the batcher thread sits next to its GPU
+    hostmalloc = args.e2e_memory == "hostmalloc"
+    common = not args.mix  # clean stream: every vote carries the ballot (0, 100) - the common-ballot form, 16 B per vote
+
+    def fresh_engine():
+        e = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
+        assert (e.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
+        return e
+
+    def hbuf(e, n, dtype=np.int32):
+        """a host column for engine e: DMA memory from gpx_host_alloc, or numpy pages pinned with gpx_host_register"""
+        if hostmalloc:
+            return e.host_alloc(n, dtype)
+        a = np.zeros(max(n, 1), dtype)[:n]
+        e.host_register(a)
+        return a
+
+    def host_rounds(e, n_rounds):
+        out = []
+        for r in range(n_rounds):
+            cols = []
+            for c in gen_round(args, streams, G, members, r, cfg_id, args.mix):
+                b = hbuf(e, c.shape[0])
+                b[:] = c
+                cols.append(b)
+            out.append(cols)
+        return out
+
+    # -- the plain calls, one after the other
+    ee = fresh_engine()
+    link = link_peaks(torch, dev, ee)
+    e2e_rounds = 4
+    hcols = host_rounds(ee, e2e_rounds)
+    hg = hbuf(ee, G)
+    hg[:] = np.arange(G, dtype=np.int32)
+    ho = [hbuf(ee, G) for _ in range(4)] + [hbuf(ee, G, np.uint8)]
+    hd = [hbuf(ee, nv) for _ in range(5)] + [hbuf(ee, nv, np.uint8)]
+    hno, hst = hbuf(ee, 1), hbuf(ee, nv, np.uint8)
+    fn_p, fn_a = ee.lib.fn["propose_batch"], ee.lib.fn["accept_reply_batch"]
+
+    def host_step(r):
+        rc = fn_p(ee.h, G, _p(hg), None, _p(ho[0]), _p(ho[1]), _p(ho[2]), _p(ho[3]), _p(ho[4]))
+        c = hcols[r]
+        rc |= fn_a(ee.h, nv, _p(c[0]), _p(c[1]), _p(c[2]), _p(c[3]), _p(c[4]), _p(c[5]), _p(hd[0]), _p(hd[1]),
+                   _p(hd[2]), _p(hd[3]), _p(hd[4]), _p(hd[5]), _p(hno), _p(hst))
+        assert rc == 0
+    host_step(0)
+    te = time.perf_counter()
+    for r in range(1, e2e_rounds):
+        host_step(r)
+    te_sync = (time.perf_counter() - te) / (e2e_rounds - 1)
+    assert args.mix or int(hno[0]) == G
+    ee.close()  # (unpins / frees everything that was pinned or allocated through it)
+
+    # -- the asynchronous calls (gpx_*_batch_async + gpx_engine_wait), two steps in flight: the inputs of step r + 1
+    # travel to the device while the outputs of step r travel back - both directions of the link busy.
+    # slot / max_cp of a host round are only right once per engine: a fresh one, ten rounds
+    n_async = 10
+    ee = fresh_engine()
+    hcols = host_rounds(ee, n_async)
+    hg = hbuf(ee, G)
+    hg[:] = np.arange(G, dtype=np.int32)
+    fn_pa, fn_aa, fn_w = (ee.lib.fn[k] for k in ("propose_batch_async", "accept_reply_batch_async", "engine_wait"))
+    ring = []
+    for _ in range(2):
+        o = [hbuf(ee, G) for _ in range(4)] + [hbuf(ee, G, np.uint8)]
+        d = [hbuf(ee, nv) for _ in range(5)] + [hbuf(ee, nv, np.uint8)]
+        ring.append((o, d, hbuf(ee, 1), hbuf(ee, nv, np.uint8)))
+
+    def submit(r):
+        o, d, no, st = ring[r & 1]
+        c = hcols[r % n_async]
+        tp, ta = C.c_uint64(0), C.c_uint64(0)
+        rc = fn_pa(ee.h, G, _p(hg), None, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), C.byref(tp))
+        rc |= fn_aa(ee.h, nv, _p(c[0]), None if common else _p(c[1]), None if common else _p(c[2]), 0, 100, _p(c[3]),
+                    _p(c[4]), _p(c[5]), _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(d[4]), _p(d[5]), _p(no), _p(st),
+                    C.byref(ta))
+        assert rc == 0
+        return tp, ta
+
+    def wait(t):
+        assert fn_w(ee.h, t[0]) == 0 and fn_w(ee.h, t[1]) == 0
+    for t in [submit(0), submit(0)]:  # warm: all four sets of device columns allocated (the repeated
+        wait(t)                       # round only brings late votes; one more slot stays outstanding)
+    te = time.perf_counter()
+    prev = submit(1)
+    for r in range(2, n_async):
+        cur = submit(r)
+        wait(prev)
+        prev = cur
+    wait(prev)
+    te = (time.perf_counter() - te) / (n_async - 1)
+    n_dec = int(ring[(n_async - 1) & 1][2][0])
+    assert args.mix or n_dec == G
+    b_in = G * 4 + nv * (16 if common else 24)
+    b_out = G * 17 + nv + n_dec * 21 + 4
+    ee.close()
+    if prev_affinity is not None:
+        os.sched_setaffinity(0, prev_affinity)
+    kind = "hipHostMalloc" if hostmalloc else "hipHostRegister"
+    peak_in, peak_out = link[kind]["both_directions_each_GBps"], link[kind]["both_directions_each_GBps"]
+    # the step moves b_in in and b_out out concurrently: the bounding direction is the one closer to what the link
+    # gives each way when both are busy
+    in_frac, out_frac = (b_in / te / 1e9) / max(peak_in, 1e-9), (b_out / te / 1e9) / max(peak_out, 1e-9)
+    return {"ms_per_step": round(te * 1e3, 4), "decisions_per_sec": round(n_dec / te, 1),
+            "votes_per_sec": round(nv / te, 1), "bytes_over_pcie_per_step": int(b_in + b_out),
+            "pcie_in_GBps": round(b_in / te / 1e9, 1), "pcie_out_GBps": round(b_out / te / 1e9, 1),
+            "host_memory": kind + (" (gpx_host_alloc)" if hostmalloc else " (gpx_host_register on numpy pages)"),
+            "link": link,
+            "achieved_over_link_peak": {"in": round(in_frac, 3), "out": round(out_frac, 3),
+                                        "peak_used": "link.%s.both_directions_each_GBps (same run, same box)" % kind},
+            "common_ballot_form": bool(common),
+            "synchronous_calls_ms_per_step": round(te_sync * 1e3, 4),
+            "host_thread_pinned_to_gpu_numa_node": prev_affinity is not None,
+            "path": "gpx_propose_batch_async + gpx_accept_reply_batch_async + gpx_engine_wait with HOST "
+                    "pointers, two steps in flight: H2D of step r + 1 beside the kernels and the D2H of step r; "
+                    "synchronous_calls_ms_per_step = the plain calls, one after the other"}
 
 
 def main():
@@ -238,6 +454,13 @@ def main():
                     help="N > 1 only: skip the second timed leg on BASELINE config #4's fixed space (the `strong` object)")
     ap.add_argument("--no-promise", action="store_true",
                     help="do not declare the proposal batches ordered (gpx_engine_set_ordered_batches)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="N > 1 on a box with ONE GPU: every rank runs on device 0 and the ranks talk over gloo.  Runs "
+                         "the whole N > 1 code path (two timed legs, max-over-ranks, the counters' all_gather); the "
+                         "figures are N processes sharing one GPU - NOT a scaling measurement")
+    ap.add_argument("--e2e-memory", choices=("registered", "hostmalloc"), default="hostmalloc",
+                    help="host buffers of the end-to-end leg: numpy pages pinned with gpx_host_register, or memory "
+                         "from gpx_host_alloc (hipHostMalloc)")
     args = ap.parse_args()
 
     world_env = os.environ.get("WORLD_SIZE")
@@ -277,13 +500,21 @@ def main():
         return 0
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP engine has no CPU fallback)")
+    if args.same_device:
+        local_rank = 0
+        # the engines of the other ranks are invisible to this process: the exchange kernels' grids are sized for a
+        # device shared by `world` processes (include/gpx.h)
+        os.environ["GPX_DEVICE_SHARERS"] = str(world)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     torch.zeros(1, device=dev)  # wake the device before the HIP library's own runtime looks for it
     torch.cuda.synchronize()
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.same_device:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
     from gigapaxos_amd import Engine, hri_create, load_hip, streams, S_OK
 
@@ -296,42 +527,47 @@ def main():
     G, G_global, nv, nv_round, members, mem, cfg_id = leg.G, leg.G_global, leg.nv, leg.nv_round, leg.members, leg.mem, leg.cfg_id
     elapsed, gpu_ms, decisions_total, votes_total = leg.elapsed, leg.gpu_ms, leg.decisions_total, leg.votes_total
 
-    # ---- per-kernel timing with hipEvents on the launch stream (profile pass) ---------
+    # ---- per-kernel timing with hipEvents on the launch stream (profile pass), kept apart per call ---------
     roofline = None
-    kstats = {}
     if psteps > 0:
-        eng.sync()
-        eng.profile(2)
-        for r in range(warmup + steps, rounds):
-            step(r)
-        torch.cuda.synchronize()
-        kstats = eng.profile_read()
-        eng.profile(0)
-        ar_kernels = {k: v for k, v in kstats.items() if k not in ("k_apply_propose", "k_fill_pr")}
-        dom = max(kstats.items(), key=lambda kv: kv[1][1])
-        # launches of shared front-end kernels are split between propose and accept-reply:
-        # the dominant kernel is identified by total time; its avg duration = total / launches
-        dom_name, (dom_launches, dom_ms) = dom
+        per_call = leg.profile_calls(warmup + steps, psteps)
+        kstats = {}
+        for call in per_call.values():
+            for k, (nl, ms) in call.items():
+                a = kstats.setdefault(k, [0, 0.0])
+                a[0] += nl
+                a[1] += ms
+        ar = per_call["accept_reply_batch"]
+        # the dominant kernel of the unit's call (one accept-reply vote): by total time
+        dom_name, (dom_launches, dom_ms) = max(ar.items(), key=lambda kv: kv[1][1])
         avg_ms = dom_ms / max(dom_launches, 1)
-        units = nv if dom_name not in ("k_apply_propose", "k_fill_pr") else G
-        alg = alg_bytes_per_vote(K) * units
+        alg = alg_bytes_per_vote(K) * nv
         achieved = alg / (avg_ms * 1e-3) / 1e9
+        call_ms = sum(v[1] for v in ar.values()) / psteps
+        call_achieved = alg / (call_ms * 1e-3) / 1e9
         pipe_ms = sum(v[1] for v in kstats.values()) / psteps
-        pipe_achieved = alg_bytes_per_vote(K) * nv / (pipe_ms * 1e-3) / 1e9
-        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process;
-        # they come from separate `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this
-        # same command, summarised by scripts/rocprof_summary.py into profiles/pmc_traffic.json
-        # (2*FETCH_SIZE + WRITE_SIZE, the gfx950 correction of MI355X_MICROARCH.md §HBM).
-        traffic = traffic_raw = None
+        pipe_achieved = alg / (pipe_ms * 1e-3) / 1e9
+        # HBM traffic: PMC counters cannot be read from inside this process; they come from separate
+        # `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` passes of this same command, summarised by
+        # scripts/rocprof_summary.py into profiles/pmc_traffic.json (2*FETCH_SIZE + WRITE_SIZE, the gfx950
+        # correction of MI355X_MICROARCH.md section HBM).  Only the headline shape has such a file.
+        traffic = traffic_raw = traffic_call = None
+        traffic_call_kernels = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
-            # the engine's profile labels name the launch (k_bucket_ar16), rocprofv3 the kernel (k_bucket16<0, 4>)
-            alias = {"k_bucket_ar16": "k_bucket16", "k_bucket_accept16": "k_bucket16", "k_bucket_commit16": "k_bucket16"}
-            kname = alias.get(dom_name, dom_name)
-            cands = [(int(k.split("@")[1]), v) for k, v in pmc.items() if k.split("@")[0].split("<")[0] == kname]
-            if cands and G == 1_000_000 and K == 3 and not args.mix and not args.sorted:
-                _, v = max(cands, key=lambda kv: kv[0])
-                traffic, traffic_raw = int(v["hbm_bytes_corrected"]), int(v["hbm_bytes_raw"])
+
+            def pmc_of(name):
+                kname = PMC_ALIAS.get(name, name)
+                cands = [(int(k.split("@")[1]), v) for k, v in pmc.items() if k.split("@")[0].split("<")[0] == kname]
+                return max(cands, key=lambda kv: kv[0])[1] if cands else None
+            if G == 1_000_000 and K == 3 and not args.mix and not args.sorted and not args.no_promise:
+                v = pmc_of(dom_name)
+                if v:
+                    traffic, traffic_raw = int(v["hbm_bytes_corrected"]), int(v["hbm_bytes_raw"])
+                parts = {k: pmc_of(k) for k in ar}
+                if all(parts.values()):
+                    traffic_call_kernels = {k: int(v["hbm_bytes_corrected"]) for k, v in parts.items()}
+                    traffic_call = sum(traffic_call_kernels.values())
         except (OSError, ValueError, KeyError):
             pass
         roofline = {
@@ -342,6 +578,12 @@ def main():
             "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
             "(scripts/gpu_visit.sh TAG traffic), not counted in this run",
             "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg),
+            # `frac` is the prescribed per-kernel figure: the whole call's algorithmic bytes over ONE kernel's time.
+            # The unit - one accept-reply vote - is finished by all kernels of its call: `call_frac` divides the
+            # same bytes by their sum, `traffic_call` is what the counters saw them move together
+            "call_kernels": sorted(ar), "call_ms": round(call_ms, 4), "call_achieved": round(call_achieved, 1),
+            "call_frac": round(call_achieved / HBM_PEAK_GBS, 4), "traffic_call": traffic_call,
+            "traffic_call_kernels": traffic_call_kernels,
             "pipeline_ms_per_step": round(pipe_ms, 4),
             "pipeline_achieved": round(pipe_achieved, 1),
             "pipeline_frac": round(pipe_achieved / HBM_PEAK_GBS, 4),
@@ -368,104 +610,7 @@ def main():
     # gets): every input column crosses PCIe in, every output column comes back; never `value` -------
     end_to_end = None
     if rank == 0 and world == 1 and not args.no_end_to_end:
-        from gigapaxos_amd._abi import _p
-        prev_affinity = pin_to_gpu_numa_node(local_rank)  # the batcher thread sits next to its GPU
-        ee = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
-        assert (ee.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
-        e2e_rounds = 4
-        hcols = [[np.ascontiguousarray(c) for c in streams.vote_round(G, members, r, 100, config_id=cfg_id,
-                                                                        shuffled=not args.sorted, mix=args.mix)]
-                 for r in range(e2e_rounds)]
-        hg = np.arange(G, dtype=np.int32)
-        ho = [np.zeros(G, np.int32) for _ in range(4)] + [np.zeros(G, np.uint8)]
-        hd = [np.zeros(nv, np.int32) for _ in range(5)] + [np.zeros(nv, np.uint8)]
-        hno, hst = np.zeros(1, np.int32), np.zeros(nv, np.uint8)
-        pinned_rounds = hcols
-        pinned = [hg, hno, hst] + ho + hd + [c for cols in hcols for c in cols]
-        ee.host_register(*pinned)  # a JNI host registers its direct ByteBuffers once (gpx_host_register)
-        fn_p, fn_a = ee.lib.fn["propose_batch"], ee.lib.fn["accept_reply_batch"]
-
-        def host_step(r):
-            rc = fn_p(ee.h, G, _p(hg), None, _p(ho[0]), _p(ho[1]), _p(ho[2]), _p(ho[3]), _p(ho[4]))
-            c = hcols[r]
-            rc |= fn_a(ee.h, nv, _p(c[0]), _p(c[1]), _p(c[2]), _p(c[3]), _p(c[4]), _p(c[5]), _p(hd[0]), _p(hd[1]),
-                       _p(hd[2]), _p(hd[3]), _p(hd[4]), _p(hd[5]), _p(hno), _p(hst))
-            assert rc == 0
-        host_step(0)
-        te = time.perf_counter()
-        for r in range(1, e2e_rounds):
-            host_step(r)
-        te_sync = (time.perf_counter() - te) / (e2e_rounds - 1)
-        assert args.mix or int(hno[0]) == G
-        # the asynchronous calls (gpx_*_batch_async + gpx_engine_wait): two steps in flight, so the inputs of step
-        # r + 1 travel to the device while the outputs of step r travel back - both directions of the link busy;
-        # in the clean stream every vote carries the ballot (0, 100): the common-ballot form, 16 B per vote
-        import ctypes as C
-        fn_pa, fn_aa, fn_w = (ee.lib.fn[k] for k in ("propose_batch_async", "accept_reply_batch_async", "engine_wait"))
-        ring = []
-        for _ in range(2):
-            o = [np.zeros(G, np.int32) for _ in range(4)] + [np.zeros(G, np.uint8)]
-            d = [np.zeros(nv, np.int32) for _ in range(5)] + [np.zeros(nv, np.uint8)]
-            no, st = np.zeros(1, np.int32), np.zeros(nv, np.uint8)
-            ring.append((o, d, no, st))  # (pinned below, through the engine that uses them)
-        common = not args.mix
-
-        def submit(r):
-            o, d, no, st = ring[r & 1]
-            c = hcols[r % e2e_rounds]
-            tp, ta = C.c_uint64(0), C.c_uint64(0)
-            rc = fn_pa(ee.h, G, _p(hg), None, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), C.byref(tp))
-            rc |= fn_aa(ee.h, nv, _p(c[0]), None if common else _p(c[1]), None if common else _p(c[2]), 0, 100, _p(c[3]),
-                        _p(c[4]), _p(c[5]), _p(d[0]), _p(d[1]), _p(d[2]), _p(d[3]), _p(d[4]), _p(d[5]), _p(no), _p(st),
-                        C.byref(ta))
-            assert rc == 0
-            return tp, ta
-
-        def wait(t):
-            assert fn_w(ee.h, t[0]) == 0 and fn_w(ee.h, t[1]) == 0
-        n_async = 10
-        # slot / max_cp of the host rounds are only right for the first e2e_rounds rounds of an engine: a fresh one
-        ee.close()
-        ee = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
-        assert (ee.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
-        hcols = [[np.ascontiguousarray(c) for c in streams.vote_round(G, members, r, 100, config_id=cfg_id,
-                                                                        shuffled=not args.sorted, mix=args.mix)]
-                 for r in range(n_async)]
-        # (gpx_engine_destroy took away every pinning made through the first engine: round 4's unregister-on-destroy)
-        pinned_rounds = hcols
-        ee.host_register(hg, *[c for cols_ in hcols for c in cols_])
-        for o, d, no, st in ring:
-            ee.host_register(*(o + d + [no, st]))
-        e2e_rounds = n_async
-        for t in [submit(0), submit(0)]:  # warm: all four sets of device columns allocated (the repeated
-            wait(t)                       # round only brings late votes; one more slot stays outstanding)
-        te = time.perf_counter()
-        prev = submit(1)
-        for r in range(2, n_async):
-            cur = submit(r)
-            wait(prev)
-            prev = cur
-        wait(prev)
-        te = (time.perf_counter() - te) / (n_async - 1)
-        n_dec = int(ring[(n_async - 1) & 1][2][0])
-        assert args.mix or n_dec == G
-        b_in = G * 4 + nv * (16 if common else 24)
-        b_out = G * 17 + nv + n_dec * 21 + 4
-        end_to_end = {"ms_per_step": round(te * 1e3, 4), "decisions_per_sec": round(n_dec / te, 1),
-                      "votes_per_sec": round(nv / te, 1), "bytes_over_pcie_per_step": int(b_in + b_out),
-                      "pcie_in_GBps": round(b_in / te / 1e9, 1), "pcie_out_GBps": round(b_out / te / 1e9, 1),
-                      "common_ballot_form": bool(common),
-                      "synchronous_calls_ms_per_step": round(te_sync * 1e3, 4),
-                      "path": "gpx_propose_batch_async + gpx_accept_reply_batch_async + gpx_engine_wait with HOST "
-                              "pointers (registered memory), two steps in flight: H2D of step r + 1 beside the kernels "
-                              "and the D2H of step r; synchronous_calls_ms_per_step = the plain calls, one after the other"}
-        for o, d, no, st in ring:
-            ee.host_unregister(*(o + d + [no, st]))
-        ee.host_unregister(hg, *[c for cols_ in pinned_rounds for c in cols_])
-        ee.close()
-        end_to_end["host_thread_pinned_to_gpu_numa_node"] = prev_affinity is not None
-        if prev_affinity is not None:
-            os.sched_setaffinity(0, prev_affinity)
+        end_to_end = end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, mem, cfg_id)
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores ---
     cpu_baseline = None
@@ -476,39 +621,71 @@ def main():
         eo = Engine(load_oracle(), 100, G, kmax=K, window=8)
         assert (eo.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
         cpu_rounds = args.cpu_rounds
-        cols_cpu = [streams.vote_round(G, members, r, 100, config_id=cfg_id, shuffled=not args.sorted,
-                                       mix=args.mix) for r in range(cpu_rounds)]
+        cols_cpu = [gen_round(args, streams, G, members, r, cfg_id, args.mix) for r in range(cpu_rounds)]
         gnp = np.arange(G, dtype=np.int32)
+        from gigapaxos_amd import LAZY_OUTPUTS
+        mask = CoordinatorLeg.promise_mask(args)
+        eo.set_ordered_batches(mask & ~LAZY_OUTPUTS)  # the same promises (their refusals are part of the answer)
         tc = time.perf_counter()
         ndec = 0
-        oracle_dec = []
+        oracle_dec, oracle_prop = [], []
         for r in range(cpu_rounds):
-            eo.propose(gnp)
+            oracle_prop.append(eo.propose(gnp))
             d = eo.accept_reply(*cols_cpu[r])
             ndec += d.gidx.shape[0]
             oracle_dec.append(d)
         tcpu = time.perf_counter() - tc
         if not args.no_parity_check:
-            # what is timed is also what is checked: the same rounds through a fresh HIP engine
-            # (C-ABI, host pointers), decided stream / per-vote status / HotRestoreInfo rows against
-            # the oracle's (outside every timed region)
+            # what is timed is what is checked: the sample's rounds through a fresh HIP engine by the SAME entry points
+            # as the timed leg - gpx_propose_batch_dev / gpx_accept_reply_batch_dev on device columns, on a torch
+            # stream, under the same gpx_engine_set_ordered_batches mask - all five proposal columns, the decided
+            # stream, per-vote status, HotRestoreInfo rows and counters against the oracle's (outside every timed region)
             ep = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nv_round + 1024, device=local_rank)
             assert (ep.create_groups(gnp, mem, K, hri_create(G, K, 100)) == S_OK).all()
+            ep.set_stream(leg.tstream.cuda_stream)
+            ep.set_ordered_batches(mask)
+            P = lambda t: t.data_ptr()  # noqa: E731
+            i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
+            u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)  # noqa: E731
+            g_dev = torch.arange(G, dtype=torch.int32, device=dev)
             ok = True
+            kernels_seen = set()
             for r in range(cpu_rounds):
-                ep.propose(gnp)
-                d = ep.accept_reply(*cols_cpu[r])
-                ok = ok and d.as_tuple_array().shape == oracle_dec[r].as_tuple_array().shape \
-                    and bool((d.as_tuple_array() == oracle_dec[r].as_tuple_array()).all()) \
-                    and bool((d.status == oracle_dec[r].status).all())
+                vc = [torch.from_numpy(np.ascontiguousarray(c)).to(dev) for c in cols_cpu[r]]
+                n_r = int(vc[0].shape[0])
+                pr = [i32(G) for _ in range(4)] + [u8(G)]
+                dd = [i32(n_r) for _ in range(5)] + [u8(n_r)]
+                no, vst = torch.zeros(1, dtype=torch.int32, device=dev), u8(n_r)
+                torch.cuda.synchronize()
+                ep.profile(2)
+                ep.call_dev("propose_batch", G, P(g_dev), 0, *[P(t) for t in pr])
+                ep.call_dev("accept_reply_batch", n_r, *[P(t) for t in vc], *[P(t) for t in dd], P(no), P(vst))
+                ep.sync()
+                kernels_seen |= set(ep.profile_read())
+                ep.profile(0)
+                if int(no.item()) < 0:  # GPX_LAZY_OUTPUTS: an unusual batch's outputs are still parked
+                    ep.compact_last_dev()
+                    ep.sync()
+                m = int(no.item())
+                got = np.stack([t[:m].cpu().numpy().astype(np.int32) for t in dd], axis=1)
+                want = oracle_dec[r].as_tuple_array()
+                ok = ok and got.shape == want.shape and bool((got == want).all()) \
+                    and bool((vst.cpu().numpy() == oracle_dec[r].status).all()) \
+                    and all(bool((x.cpu().numpy() == y).all()) for x, y in zip(pr, oracle_prop[r]))
             ok = ok and ep.snapshot(gnp)[0].tobytes() == eo.snapshot(gnp)[0].tobytes()
             ok = ok and ep.counters() == eo.counters()
             ep.close()
+            timed_kernels = set(roofline["kernels_ms_per_step"]) if roofline else None
             parity_checked = {"rounds": cpu_rounds, "groups": G, "votes_per_round": int(cols_cpu[0][0].shape[0]),
-                              "compared": "decisions (gidx, slot, bnum, bcoord, median_cp, kind), per-vote status, "
-                                          "HotRestoreInfo rows of every group, counters", "ok": bool(ok)}
+                              "entry_points": "gpx_propose_batch_dev + gpx_accept_reply_batch_dev (device columns, the "
+                                              "timed leg's stream and gpx_engine_set_ordered_batches mask %d)" % mask,
+                              "kernels": sorted(kernels_seen),
+                              "same_kernels_as_timed_leg": None if timed_kernels is None else kernels_seen == timed_kernels,
+                              "compared": "proposals (slot, bnum, bcoord, median_cp, status), decisions (gidx, slot, bnum, "
+                                          "bcoord, median_cp, kind), per-vote status, HotRestoreInfo rows of every group, "
+                                          "counters", "ok": bool(ok)}
             assert ok, "HIP engine and oracle disagree on the bench workload"
-        del oracle_dec
+        del oracle_dec, oracle_prop
         single = {"decisions_per_sec": round(ndec / tcpu, 1),
                   "votes_per_sec": round(cols_cpu[0][0].shape[0] * cpu_rounds / tcpu, 1), "seconds": round(tcpu, 2)}
         # the same oracle on T host threads, thread t owning the groups with gidx % T == t (groups are
@@ -610,6 +787,7 @@ def main():
                 "groups_per_gpu": G, "groups_total": G_global if args.split_global else G * world,
                 "replicas": K, "votes_per_step_per_gpu": nv,
                 "ordered_proposals_promise": not args.no_promise,
+                "ordered_batches_mask": CoordinatorLeg.promise_mask(args),
                 "parallelism": "groups sharded across GPUs, no collective on the decide path",
             },
             "votes_per_sec": round(votes_total / elapsed, 1),
@@ -621,6 +799,11 @@ def main():
             "cpu_baseline": cpu_baseline,
             "parity_checked": parity_checked,
         }
+        if args.same_device:
+            out["same_device"] = {"ranks_on_device_0": world, "collectives": "gloo (host tensors)",
+                                  "note": "ONE GPU shared by %d processes: exercises the N > 1 code path (both timed legs, "
+                                          "max-over-ranks, the counters' all_gather); NOT a scaling figure" % world}
+            out["shard_counters"] = leg.shard_counters
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

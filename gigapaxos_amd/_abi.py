@@ -83,6 +83,8 @@ _SIGS = {
     "engine_set_ordered_batches": [C.c_int32],
     "host_register": [_VP, C.c_size_t],
     "host_unregister": [_VP],
+    "host_alloc": [C.c_size_t, C.POINTER(_VP)],
+    "host_free": [_VP],
     "group_create": [C.c_int32, _VP, _VP, _VP, _VP, _VP],
     "group_retire": [C.c_int32, _VP, C.c_int32, _VP, _VP],
     "group_snapshot": [C.c_int32, _VP, _VP, _VP],
@@ -368,6 +370,22 @@ class Engine:
     def host_unregister(self, *arrays):
         for a in arrays:
             self.lib.check(self.lib.fn["host_unregister"](self.h, _p(a)), "host_unregister")
+
+    def host_alloc(self, n: int, dtype=np.int32) -> np.ndarray:
+        """A numpy array of n elements over memory from gpx_host_alloc (hipHostMalloc): the DMA engines reach it
+        at the link's full rate.  Give it back with host_free(array) - or leave it to close()."""
+        dt = np.dtype(dtype)
+        nbytes = max(int(n), 1) * dt.itemsize
+        p = _VP()
+        self.lib.check(self.lib.fn["host_alloc"](self.h, nbytes, C.byref(p)), "host_alloc")
+        buf = (C.c_char * nbytes).from_address(p.value)
+        a = np.frombuffer(buf, dtype=dt, count=int(n))
+        a[...] = 0
+        return a
+
+    def host_free(self, *arrays):
+        for a in arrays:
+            self.lib.check(self.lib.fn["host_free"](self.h, _p(a)), "host_free")
 
     def sync(self):
         self.lib.check(self.lib.fn["engine_sync"](self.h), "engine_sync")

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 #include <algorithm>
@@ -57,6 +58,11 @@ struct PendingEvent {
   const char* name;
   hipEvent_t start, stop;
 };
+
+/* engines alive per device in this process: the exchange kernels (one_exchange, k_ar_runs<.., SMALL>) are only
+ * launched with grids that stay resident when EVERY live engine of the device launches one at the same moment */
+std::mutex g_live_mu;
+std::map<int, int> g_live_engines;
 
 }  // namespace
 
@@ -129,8 +135,17 @@ struct gpx_engine {
     int32_t *x_gidx = nullptr, *x_first = nullptr, *x_count = nullptr, *count = nullptr;
     RunsStage rs{};
     RunsInfo* info = nullptr;
+    uint64_t seq = 0; /* call_seq right after the call: gpx_compact_last_dev refuses once another batch call came in between */
   } last;
   int lazy_override = -1; /* 1: the host-pointer twins compact on demand themselves; 0: asynchronous calls need dense columns */
+  /* exchange kernels (workgroups that wait for each other's tickets): 256-thread workgroups of the greediest of them
+   * that the device holds at once (occupancy x CUs, measured at creation), the processes that share the device
+   * (GPX_DEVICE_SHARERS, default 1), and the host-mapped word a waiter that gave up writes (DevScratch.xabort) */
+  int xchg_slots = 0, sharers = 1;
+  bool registered_live = false;
+  uint32_t* h_abort = nullptr;
+  /* host blocks handed out by gpx_host_alloc (hipHostMalloc): freed by gpx_host_free or at destroy */
+  std::vector<void*> host_blocks;
   /* accept replies as a few sorted runs (gpx_runs.hip.h): allocated on first use */
   RunsInfo* runs_info = nullptr; /* [2], used alternately */
   uint64_t runs_seq = 0;
@@ -296,6 +311,7 @@ void apply_streams(gpx_engine* e) {
 
 /* Opens a batch call: the call's epoch (what *X.unsorted is compared with). */
 int begin_front(gpx_engine* e) {
+  e->last.kind = 0; /* whatever an earlier call left parked can no longer be compacted (gpx_compact_last_dev) */
   e->X.epoch = (uint32_t)(e->call_seq + 1);
   if (e->X.epoch == 0) { /* 2^32 calls: restart the epochs from cleared words */
     HIPQ(hipStreamSynchronize(e->stream));
@@ -406,7 +422,28 @@ void launch_scatter_ac(gpx_engine* e, int32_t n, const int32_t* gidx, const int3
 int check_batch(gpx_engine* h, int32_t n) {
   if (!h || n < 0) return GPX_EINVAL;
   if (n > h->cfg.max_batch) return GPX_ECAPACITY;
+  if (h->h_abort && *(volatile uint32_t*)h->h_abort) {
+    /* a workgroup of an exchange kernel waited two seconds for workgroups that never became resident (somebody this
+     * process cannot see holds the device's CUs): that call applied only part of its batch */
+    snprintf(g_err, sizeof(g_err), "an exchange kernel gave up waiting for its grid (call epoch %u): engine state is "
+             "incomplete; set GPX_DEVICE_SHARERS to the number of processes sharing the device", *(volatile uint32_t*)h->h_abort);
+    return GPX_EDEVICE;
+  }
   return GPX_OK;
+}
+
+/* May an exchange kernel (one_exchange, k_ar_runs<.., SMALL>: its workgroups wait for each other's tickets) be
+ * launched with `grid` workgroups of 256 threads?  Only if the grids of ALL live engines of this device (times the
+ * processes sharing it) fit the device at once - then a partly resident grid can never wait for workgroups that
+ * other waiters keep out.  Beyond the bound the caller takes the two-launch form of the same call. */
+bool xchg_ok(const gpx_engine* e, int64_t grid) {
+  int live = 1;
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    auto it = g_live_engines.find(e->device);
+    if (it != g_live_engines.end()) live = std::max(1, it->second);
+  }
+  return grid * live * e->sharers <= (int64_t)e->xchg_slots;
 }
 
 template <int KMAX>
@@ -602,6 +639,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
   if (const char* sv = getenv("GPX_SAR_MAX_N")) e->sar_max_n = std::max(0, std::min(GPX_SAR_MAX_N, atoi(sv)));
+  e->sar_max_n = std::min(e->sar_max_n, cfg->max_batch); /* its keys live in X.perm: [max_batch] entries */
   e->ordered_mask = e->env_mask;
   e->bucket_lds = GPX_BUCKET_LDS_BYTES(X.gb, X.lds_recs) + e->lds_pad;
   const size_t bucket_lds_hw = GPX_BUCKET_LDS_BYTES(X.gb, e->lds_recs_hw) + e->lds_pad;
@@ -643,7 +681,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     for (const void* f : fns)
       HIPCHK_CREATE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
   }
-  { /* the one-launch small accept-reply kernel stages 80 KiB (gpx_small.hip.h) */
+  { /* the one-launch small accept-reply kernel stages GPX_SAR_LDS_BYTES = 44 KiB (gpx_small.hip.h) */
     const void* fns[] = {(const void*)k_ar_tiny<4>, (const void*)k_ar_tiny<8>, (const void*)k_ar_tiny<16>};
     for (const void* f : fns)
       HIPCHK_CREATE(hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)GPX_SAR_LDS_BYTES));
@@ -681,8 +719,38 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
   A(e->st_count, 4, true);
 #undef A
+  { /* how many 256-thread workgroups of this engine's exchange kernels the device holds at once */
+    auto occ = [](const void* fn) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess) nb = 0;
+      (void)hipGetLastError();
+      return nb;
+    };
+    int nb = std::min(occ((const void*)k_ac_one<false, true>), occ((const void*)k_ac_one<true, true>));
+    if (cfg->kmax <= 4)
+      nb = std::min({nb, occ((const void*)k_propose_one<4, true>), occ((const void*)k_ar_runs<4, true>)});
+    else if (cfg->kmax <= 8)
+      nb = std::min({nb, occ((const void*)k_propose_one<8, true>), occ((const void*)k_ar_runs<8, true>)});
+    else
+      nb = std::min({nb, occ((const void*)k_propose_one<16, true>), occ((const void*)k_ar_runs<16, true>)});
+    int cus = 0;
+    HIPCHK_CREATE(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
+    e->xchg_slots = nb * cus;
+    if (const char* sv = getenv("GPX_XCHG_SLOTS")) e->xchg_slots = std::max(0, atoi(sv)); /* test switch: 0 = never exchange */
+    if (const char* sh = getenv("GPX_DEVICE_SHARERS")) e->sharers = std::max(1, atoi(sh));
+    HIPCHK_CREATE(hipHostMalloc((void**)&e->h_abort, 64, hipHostMallocMapped));
+    *e->h_abort = 0;
+    void* dptr = nullptr;
+    HIPCHK_CREATE(hipHostGetDevicePointer(&dptr, e->h_abort, 0));
+    X.xabort = (uint32_t*)dptr;
+  }
   HIPCHK_CREATE(hipDeviceSynchronize());
 #undef HIPCHK_CREATE
+  {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    g_live_engines[e->device]++;
+    e->registered_live = true;
+  }
   *out = e;
   return GPX_OK;
 }
@@ -702,8 +770,18 @@ int gpx_engine_destroy(gpx_engine* h) {
   /* first: nothing in flight - copies queued for a ticket nobody waited for read the AsyncSet columns and
    * write through the caller's registered mappings; only then may either go away */
   drain_all(h);
-  for (auto& r : h->registered) HIPQ(hipHostUnregister(r.first));
+  if (h->registered_live) {
+    std::lock_guard<std::mutex> lk(g_live_mu);
+    if (--g_live_engines[h->device] <= 0) g_live_engines.erase(h->device);
+    h->registered_live = false;
+  }
+  for (auto& r : h->registered)
+    if (std::find(h->host_blocks.begin(), h->host_blocks.end(), (void*)r.first) == h->host_blocks.end())
+      HIPQ(hipHostUnregister(r.first));
   h->registered.clear();
+  for (void* b : h->host_blocks) HIPQ(hipHostFree(b));
+  h->host_blocks.clear();
+  if (h->h_abort) HIPQ(hipHostFree(h->h_abort));
   for (auto& pe : h->pending) {
     HIPQ(hipEventDestroy(pe.start));
     HIPQ(hipEventDestroy(pe.stop));
@@ -765,6 +843,38 @@ int gpx_host_unregister(gpx_engine* h, void* ptr) {
   return GPX_OK;
 }
 
+/* Host memory the DMA engines reach at the link's full rate (hipHostMalloc): what a JNI host wraps in a direct
+ * ByteBuffer (NewDirectByteBuffer) for its batch columns instead of registering JVM memory afterwards.  Known to
+ * the asynchronous calls like a registered block (mapped_host). */
+int gpx_host_alloc(gpx_engine* h, size_t bytes, void** out) {
+  if (!h || !out || !bytes) return GPX_EINVAL;
+  void* p = nullptr;
+  if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) {
+    (void)hipGetLastError();
+    snprintf(g_err, sizeof(g_err), "hipHostMalloc(%zu) failed", bytes);
+    return GPX_ENOMEM;
+  }
+  h->host_blocks.push_back(p);
+  h->registered.emplace_back((char*)p, bytes);
+  *out = p;
+  return GPX_OK;
+}
+int gpx_host_free(gpx_engine* h, void* ptr) {
+  if (!h || !ptr) return GPX_EINVAL;
+  auto it = std::find(h->host_blocks.begin(), h->host_blocks.end(), ptr);
+  if (it == h->host_blocks.end()) return GPX_EINVAL;
+  drain_all(h); /* as gpx_host_unregister: nothing of the engine may still read or write the block */
+  HIPCHK(hipGetLastError());
+  h->host_blocks.erase(it);
+  for (size_t i = 0; i < h->registered.size(); i++)
+    if (h->registered[i].first == (char*)ptr) {
+      h->registered.erase(h->registered.begin() + (long)i);
+      break;
+    }
+  HIPCHK(hipHostFree(ptr));
+  return GPX_OK;
+}
+
 int gpx_engine_sync(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
   HIPCHK(hipStreamSynchronize(h->sF));
@@ -774,7 +884,7 @@ int gpx_engine_sync(gpx_engine* h) {
   if (h->s_in) HIPCHK(hipStreamSynchronize(h->s_in));
   for (auto& a : h->as)
     if (a.s_out) HIPCHK(hipStreamSynchronize(a.s_out));
-  return GPX_OK;
+  return check_batch(h, 0); /* (an exchange kernel that gave up: GPX_EDEVICE) */
 }
 
 int gpx_engine_counters(gpx_engine* h, uint64_t out[3]) {
@@ -1026,7 +1136,9 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
                                          GPX_SMALL_RUNS_TICKETS + GPX_SMALL_RUNS_MAX / GPX_RBLOCK),
                         true)) != GPX_OK)
       return rc;
-    const bool small = n <= GPX_SMALL_RUNS_MAX; /* one launch: every workgroup judges the (L2-resident) column itself */
+    /* one launch: every workgroup judges its own records and all of them exchange the verdict - if the grid is sure to
+     * be resident at once (xchg_ok); else the check kernel and the work kernel, as for larger batches */
+    const bool small = n <= GPX_SMALL_RUNS_MAX && xchg_ok(e, (n + GPX_RBLOCK - 1) / GPX_RBLOCK);
     if (!small)
       LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
                 gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
@@ -1065,6 +1177,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     if (runs_promised && lazy_outputs(e)) {
       gpx_engine::LastCall& L = e->last;
       L.kind = small ? 4 : 3, L.n = n, L.nchunks = nchunks, L.X = e->X, L.rs = st, L.info = info, L.count = n_out;
+      L.seq = e->call_seq + 1;
     } else {
       if (small) {
         LaunchScope _ls(e, "k_runs_count");
@@ -1126,7 +1239,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
      * At most 65,536 records with lazy outputs: the work kernel alone - its (at most 256, resident) workgroups
      * exchange the verdict among themselves (k_ac_one<.., XCHG>); without lazy outputs k_ac_small's in-kernel run
      * compaction is the one launch */
-    if (fused) {
+    if (fused && xchg_ok(e, (n + GPX_DBLOCK - 1) / GPX_DBLOCK)) {
       const OneCtl C = one_ctl(e);
       LaunchScope _ls(e, "k_ac_one_x");
       hipLaunchKernelGGL((k_ac_one<false, true>), dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, C, n,
@@ -1145,6 +1258,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     gpx_engine::LastCall& L = e->last;
     L.kind = 1, L.n = n, L.nchunks = nchunks, L.X = e->X, L.gidx = gidx, L.D = D;
     L.x_gidx = x_gidx, L.x_first = x_first, L.x_count = x_count, L.count = n_runs;
+    L.seq = e->call_seq + 1;
     if (!lazy_outputs(e)) {
       launch_one_compaction(e, L);
       L.kind = 0;
@@ -1242,7 +1356,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
   e->last.kind = 0;
   if (promised && (!fused || lazy_outputs(e))) { /* check + one work kernel (gpx_one.hip.h), like the ACCEPT call */
-    if (fused) {
+    if (fused && xchg_ok(e, (n + GPX_DBLOCK - 1) / GPX_DBLOCK)) {
       const OneCtl C = one_ctl(e);
       LaunchScope _ls(e, "k_ac_one_x");
       hipLaunchKernelGGL((k_ac_one<true, true>), dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, C, n,
@@ -1263,6 +1377,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     gpx_engine::LastCall& L = e->last;
     L.kind = 2, L.n = n, L.nchunks = nchunks, L.X = e->X, L.gidx = gidx, L.D = D;
     L.x_gidx = x_gidx, L.x_first = x_first, L.x_count = x_count, L.count = n_runs;
+    L.seq = e->call_seq + 1;
     if (!lazy_outputs(e)) {
       launch_one_compaction(e, L);
       L.kind = 0;
@@ -1337,6 +1452,11 @@ int gpx_compact_last_dev(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
   gpx_engine* e = h;
   gpx_engine::LastCall& L = e->last;
+  if (L.kind && L.seq != e->call_seq) { /* another batch call came in between: its scratch and columns are gone */
+    L.kind = 0;
+    snprintf(g_err, sizeof(g_err), "gpx_compact_last_dev: the call it belongs to is no longer the engine's most recent");
+    return GPX_EINVAL;
+  }
   if (L.kind == 1 || L.kind == 2) {
     launch_one_compaction(e, L);
   } else if (L.kind == 3 || L.kind == 4) {
@@ -1372,7 +1492,8 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   const int32_t refuse = promised ? 1 : 0;
   /* at most 65,536 requests on one stream: order check and direct application in one launch */
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
-  if (promised && !fused) { /* the verdict, then the application without a status prefill pass (gpx_one.hip.h) */
+  const bool xchg = fused && promised && xchg_ok(e, grid_for(n));
+  if (promised && !xchg) { /* the verdict, then the application without a status prefill pass (gpx_one.hip.h) */
     e->stream = e->sB;
     const OneCtl C = one_ctl(e);
     {
@@ -1393,7 +1514,7 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
     HIPCHK(hipGetLastError());
     return GPX_OK;
   }
-  if (fused && promised) { /* the work kernel alone: its (at most 256, resident) workgroups exchange the verdict */
+  if (xchg) { /* the work kernel alone: its (at most 256, resident) workgroups exchange the verdict */
     e->stream = e->sB;
     const OneCtl C = one_ctl(e);
     if (e->cfg.kmax <= 4)
@@ -1563,7 +1684,10 @@ int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
     int32_t* o_xc = st.out<int32_t>((size_t)n, &v_xc);
     int32_t* o_nr = st.out<int32_t>(4, &v_nr);
     if ((rc = st.upload()) != GPX_OK) return rc;
+    h->lazy_override = 0; /* one block comes back, whatever the batch: its columns must be dense (no GPX_LAZY_OUTPUTS here) */
     rc = gpx_accept_batch_dev(h, n, dg, db, dc, dsl, dm, df, o_rb, o_rc, o_rm, o_rf, o_st, o_xg, o_xf, o_xc, o_nr);
+    h->lazy_override = -1;
+    h->last.kind = 0;
     if (rc != GPX_OK) return rc;
     if ((rc = st.finish()) != GPX_OK) return rc;
     memcpy(r_bnum, v_rb, b4);
@@ -1646,7 +1770,10 @@ int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
     uint8_t* o_st = st.out<uint8_t>((size_t)n, &v_st);
     int32_t* o_no = st.out<int32_t>(4, &v_no);
     if ((rc = st.upload()) != GPX_OK) return rc;
+    h->lazy_override = 0; /* one block comes back, whatever the batch: its columns must be dense (no GPX_LAZY_OUTPUTS here) */
     rc = gpx_accept_reply_batch_dev(h, n, dg, db, dc, dsl, da, dm, o_g, o_s, o_b, o_c, o_m, o_k, o_no, o_st);
+    h->lazy_override = -1;
+    h->last.kind = 0;
     if (rc != GPX_OK) return rc;
     if ((rc = st.finish()) != GPX_OK) return rc;
     *n_out = v_no[0];
@@ -1723,7 +1850,10 @@ int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
     int32_t* o_xc = st.out<int32_t>((size_t)n, &v_xc);
     int32_t* o_nr = st.out<int32_t>(4, &v_nr);
     if ((rc = st.upload()) != GPX_OK) return rc;
+    h->lazy_override = 0; /* one block comes back, whatever the batch: its columns must be dense (no GPX_LAZY_OUTPUTS here) */
     rc = gpx_commit_batch_dev(h, n, dg, db, dc, dsl, dm, dk, o_st, o_xg, o_xf, o_xc, o_nr);
+    h->lazy_override = -1;
+    h->last.kind = 0;
     if (rc != GPX_OK) return rc;
     if ((rc = st.finish()) != GPX_OK) return rc;
     memcpy(status, v_st, (size_t)n);

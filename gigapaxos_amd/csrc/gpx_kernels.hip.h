@@ -167,7 +167,33 @@ struct DevScratch {
   uint32_t epoch;               /* call number, > 0 */
   int32_t gate;                 /* accept-reply partition kernels launched BEHIND the sorted-runs path
                                  * (gpx_runs.hip.h): they run only if k_runs_check raised *unsorted */
+  uint32_t* xabort;             /* [1] host-mapped word: a workgroup of an exchange kernel gave up waiting for the
+                                 * others' tickets (xchg_wait): the engine refuses every later call */
 };
+
+/* Workgroups that wait for each other (one_exchange, k_ar_runs<.., SMALL>) only make progress when the whole grid
+ * is resident.  The host sizes those grids from the occupancy of the kernel and the number of engines on the device
+ * (xchg_grid_limit in gpx_engine.hip) - this is the backstop for what the host cannot see (another process holding
+ * the CUs): a waiter gives up after about two seconds of the 100 MHz wall clock, leaves the call's epoch in the
+ * host-mapped word and the caller applies NOTHING of its records.  A hang becomes GPX_EDEVICE on the next call. */
+#define GPX_XCHG_TIMEOUT_TICKS 200000000ull
+struct XchgWait {
+  uint32_t spins = 0;
+  unsigned long long t0 = 0;
+  /* one more failed poll; true = give up */
+  __device__ __forceinline__ bool tired() {
+    if ((++spins & 1023u) != 0) return false;
+    const unsigned long long now = wall_clock64();
+    if (!t0) {
+      t0 = now;
+      return false;
+    }
+    return now - t0 > GPX_XCHG_TIMEOUT_TICKS;
+  }
+};
+__device__ __forceinline__ void xchg_abort(const DevScratch& X) {
+  if (X.xabort) __hip_atomic_store(X.xabort, X.epoch ? X.epoch : 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 /* Java int subtraction (wraps) */
 __device__ __forceinline__ int32_t jsub(int32_t a, int32_t b) {

@@ -97,10 +97,10 @@ __global__ __launch_bounds__(GPX_DBLOCK) void k_one_check(int32_t n, const int32
 /* the exchange: this lane's record i violates the order (or not) -> the batch's first violation.  Every thread of every
  * workgroup of the grid must call it (barriers; at most GPX_DBLOCK workgroups).  count_out / regular_count: workgroup 0
  * writes the regular batch's count before its ticket goes out. */
-__device__ __forceinline__ uint32_t one_exchange(const OneCtl& C, bool viol, int32_t i, int32_t* __restrict__ count_out,
-                                                 int32_t regular_count) {
-  __shared__ uint32_t s_mine, s_all;
-  if (threadIdx.x == 0) s_mine = 0, s_all = 0;
+__device__ __forceinline__ uint32_t one_exchange(const DevScratch& X, const OneCtl& C, bool viol, int32_t i,
+                                                 int32_t* __restrict__ count_out, int32_t regular_count) {
+  __shared__ uint32_t s_mine, s_all, s_gave_up;
+  if (threadIdx.x == 0) s_mine = 0, s_all = 0, s_gave_up = 0;
   __syncthreads();
   /* the verdict's encoding: ONE_NONE - index, 0 = none; the batch's first violation is the MAX over everybody */
   if (viol) atomicMax(&s_mine, ONE_NONE - (uint32_t)i);
@@ -113,12 +113,23 @@ __device__ __forceinline__ uint32_t one_exchange(const OneCtl& C, bool viol, int
   }
   if (threadIdx.x < gridDim.x) {
     unsigned long long v;
-    do {
+    XchgWait w;
+    for (;;) {
       v = __hip_atomic_load(&tick[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-    } while ((uint32_t)(v >> 32) != C.epoch);
+      if ((uint32_t)(v >> 32) == C.epoch) break;
+      if (w.tired()) { /* that workgroup never became resident (gpx_kernels.hip.h: XchgWait) */
+        s_gave_up = 1;
+        v = 0;
+        break;
+      }
+    }
     if ((uint32_t)v) atomicMax(&s_all, (uint32_t)v);
   }
   __syncthreads();
+  if (s_gave_up) { /* nothing of this workgroup's records is applied; the host refuses every later call */
+    if (threadIdx.x == 0) xchg_abort(X);
+    return 0u;
+  }
   return ONE_NONE - s_all;
 }
 template <bool COMMIT, bool XCHG = false>
@@ -146,7 +157,7 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
   /* wave 2: the group's acceptor state and the ring entry of this record's slot */
   AccPre P = acc_nopre();
   if (head) acc_preload(S, g, f_a, P); /* (not made to wait for the verdict word: a refused head has loaded in vain) */
-  if (XCHG) first_bad = one_exchange(C, i < n && (oob || (i > 0 && g_prev > g)), i, n_runs, regular_count);
+  if (XCHG) first_bad = one_exchange(X, C, i < n && (oob || (i > 0 && g_prev > g)), i, n_runs, regular_count);
   bool irregular = false;
   if (runstart) {
     if ((uint32_t)i >= first_bad) {
@@ -233,7 +244,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_one(
     propose_preload_ring<KMAX>(S, g, P);
   }
   if (XCHG) { /* at most 65,536 requests: no k_one_check launch (one_exchange); strictly ascending, in range */
-    first_bad = one_exchange(C, i < n && ((uint32_t)g >= (uint32_t)S.G || (i > 0 && g_prev >= g)), i, nullptr, 0);
+    first_bad = one_exchange(X, C, i < n && ((uint32_t)g >= (uint32_t)S.G || (i > 0 && g_prev >= g)), i, nullptr, 0);
     if (i >= n) return;
   }
   if ((uint32_t)i >= first_bad) {

@@ -371,9 +371,16 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
       /* (the barrier above orders this workgroup's run starts and its verdict before its ticket) */
       if (threadIdx.x == 0) __hip_atomic_store(&tick[blockIdx.x], X.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if (threadIdx.x < gridDim.x)
+      if (threadIdx.x < gridDim.x) {
+        XchgWait w;
         while (__hip_atomic_load(&tick[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != X.epoch) {
+          if (w.tired()) { /* that workgroup never became resident (gpx_kernels.hip.h: XchgWait): apply nothing */
+            xchg_abort(X);
+            atomicMax(X.unsorted, X.epoch);
+            break;
+          }
         }
+      }
       __syncthreads();
     }
     if (__hip_atomic_load(X.unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X.epoch) {

@@ -58,6 +58,19 @@ JFN(jint, hostRegister)(JNIEnv* env, jclass c, jlong h, jobject buf) {
   if (!p || cap <= 0) return GPX_EINVAL;
   return gpx_host_register(H(h), p, (size_t)cap);
 }
+/* a direct ByteBuffer over memory allocated for the DMA engines (gpx_host_alloc = hipHostMalloc): the batch columns of
+ * a host that wants the link's full rate without pinning JVM memory afterwards; hostFree(buffer) gives it back */
+JFN(jobject, hostAlloc)(JNIEnv* env, jclass c, jlong h, jlong bytes) {
+  (void)c;
+  void* p = NULL;
+  if (bytes <= 0 || gpx_host_alloc(H(h), (size_t)bytes, &p) != GPX_OK) return NULL;
+  return (*env)->NewDirectByteBuffer(env, p, bytes);
+}
+JFN(jint, hostFree)(JNIEnv* env, jclass c, jlong h, jobject buf) {
+  (void)c;
+  if (!buf) return GPX_EINVAL;
+  return gpx_host_free(H(h), (*env)->GetDirectBufferAddress(env, buf));
+}
 /* PaxosManager.createPaxosInstance(Map, ...) batch create (PaxosManager.java:664-691) */
 JFN(jint, groupCreate)(JNIEnv* env, jclass c, jlong h, jint n, jobject gidx, jobject members, jobject k,
                        jobject hriRows, jobject status) {

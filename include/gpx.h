@@ -34,9 +34,16 @@
  *     the sequential one, across groups the reference defines no order.)
  *   - one submitting thread per engine at a time (the ConsumerTask single-
  *     consumer discipline, ConsumerTask.java:163-174); different engines are
- *     fully concurrent - on ONE GPU up to four of them (the kernels of small
- *     ordered batches exchange their verdict between workgroups that must all
- *     be resident: DESIGN.md 3 ii-b; the deployment is one engine per GPU).
+ *     fully concurrent, any number of them per GPU.  (The one-launch kernels of
+ *     small ordered batches exchange their verdict between workgroups that must
+ *     all be resident.  The library enforces that itself: it counts the live
+ *     engines of a device and only launches such a kernel with a grid that fits
+ *     the device together with one of every other engine - occupancy x CUs /
+ *     engines; a larger batch takes the two-launch form with the same results.
+ *     Processes SHARING a device cannot see each other: tell each of them with
+ *     GPX_DEVICE_SHARERS=<processes>.  A waiter that still starves gives up
+ *     after two seconds and every later call returns GPX_EDEVICE - never a
+ *     hang.  DESIGN.md 3 ii-b.)
  *   - the plain entry points take HOST pointers (what a JNI direct ByteBuffer
  *     gives); the *_dev twins take DEVICE pointers, run asynchronously on the
  *     engine's stream (gpx_engine_set_stream) and leave counts in device memory
@@ -157,6 +164,14 @@ int gpx_host_register(gpx_engine* h, void* ptr, size_t bytes);
  * block's end is treated as unregistered memory (the copy path).
  */
 int gpx_host_unregister(gpx_engine* h, void* ptr);
+/*
+ * Host memory allocated FOR the DMA engines (hipHostMalloc) instead of pinned afterwards: what a JNI host wraps
+ * with NewDirectByteBuffer for its batch columns.  Treated like a registered block by every
+ * entry point; gpx_host_free (which waits like gpx_host_unregister) or gpx_engine_destroy gives it back.
+ * bench.py's end_to_end.link reports what either kind of memory reaches on the box.
+ */
+int gpx_host_alloc(gpx_engine* h, size_t bytes, void** out);
+int gpx_host_free(gpx_engine* h, void* ptr);
 /* block until everything submitted to the engine has finished: its stream and the asynchronous calls' copy streams */
 int gpx_engine_sync(gpx_engine* h);
 /*
@@ -172,10 +187,13 @@ int gpx_engine_sync(gpx_engine* h);
  * The promise is VERIFIED on the device, inside that kernel: the FIRST VIOLATION of a batch is the first index
  * that is out of range or whose gidx is lower than (PROPOSE: not higher than) its predecessor's.  The records
  * before it are applied as usual; the records from it on are refused - status GPX_S_UNORDERED, all their outputs
- * zero, no state change - exactly like a lost tail of the batch (the caller sends them again, in order).  A group's
- * records never lie on both sides (equal neighbours are no violation), so no group is applied in part.  (Until
- * round 4 such a batch was refused whole, which took a launch of its own for the verdict; applying the verified
- * prefix keeps the guarantee that matters - nothing is applied out of order, nothing silently - without it.)
+ * zero, no state change - exactly like a lost tail of the batch (the caller sends them again, in order).  The first
+ * violation is always the start of a run of equal gidx (equal neighbours are no violation), so no RUN is cut in two.
+ * A group that comes back behind a descent is a second run: in gidx = [1,1,3,2,1] the first violation is index 3,
+ * records 0-2 are applied (group 1's first run among them) and records 3-4 refused (group 1's second run among them) -
+ * to Paxos the refused records are a lost tail, per group as for the batch.  (Until round 4 such a batch was refused
+ * whole, which took a launch of its own for the verdict; applying the verified prefix keeps the guarantee that
+ * matters - nothing is applied out of order, nothing silently - without it.)
  * Results of a batch that keeps the promise are identical with and without it.
  */
 #define GPX_ORDERED_PROPOSE 1
@@ -190,7 +208,8 @@ int gpx_engine_sync(gpx_engine* h);
  * *n_runs / *n_out >= 0 - at 5-6 us per idle launch.  With GPX_LAZY_OUTPUTS it does not: *n_runs / *n_out < 0
  * then says "this batch's outputs are still parked" and the caller - who reads the count anyway - calls
  * gpx_compact_last_dev, which makes the columns of the engine's most recent call dense and rewrites the count
- * (>= 0).  No other batch call may come in between.  The host-pointer calls do this themselves.
+ * (>= 0).  No other batch call may come in between: gpx_compact_last_dev then returns GPX_EINVAL (the parked
+ * outputs of the earlier call are gone with its scratch).  The host-pointer calls never leave outputs parked.
  */
 #define GPX_LAZY_OUTPUTS 32
 /*

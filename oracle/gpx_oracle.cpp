@@ -39,6 +39,7 @@
  */
 #include <algorithm>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
 #include <deque>
 #include <initializer_list>
@@ -500,6 +501,17 @@ static bool batch_is_few_runs(const Engine* e, int32_t n, const int32_t* gidx) {
 }
 int orc_host_register(gpx_engine* h, void* p, size_t n) { return h && p && n ? GPX_OK : GPX_EINVAL; }
 int orc_host_unregister(gpx_engine* h, void* p) { return h && p ? GPX_OK : GPX_EINVAL; }
+/* (gpx_host_alloc / gpx_host_free: plain memory here - the oracle has no DMA engine to please) */
+int orc_host_alloc(gpx_engine* h, size_t n, void** out) {
+  if (!h || !n || !out) return GPX_EINVAL;
+  *out = malloc(n);
+  return *out ? GPX_OK : GPX_ENOMEM;
+}
+int orc_host_free(gpx_engine* h, void* p) {
+  if (!h || !p) return GPX_EINVAL;
+  free(p);
+  return GPX_OK;
+}
 int orc_engine_counters(gpx_engine* h, uint64_t out[3]) {
   if (!h) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);

@@ -24,7 +24,8 @@ GPU_FAST = [
     "test_runs_gpu.py::test_reply_runs_1m_groups_vs_oracle[3-8]",                          # sorted runs, promise
     "test_runs_gpu.py::test_reply_runs_fuzz[5-5000-42",                                    # ... hint, fuzz
     "test_one_gpu.py::test_lazy_outputs_on_the_device_path",                               # k_ac_one + lazy compaction
-    "test_one_gpu.py::test_lazy_reply_runs[3-150000]", "test_one_gpu.py::test_lazy_reply_runs[5-9000]",
+    "test_one_gpu.py::test_lazy_reply_runs[3-150000-True]", "test_one_gpu.py::test_lazy_reply_runs[5-9000-True]",
+    "test_one_gpu.py::test_lazy_reply_runs[3-20000-False]", "test_one_gpu.py::test_lazy_outputs_on_the_device_path[20000-False]",
     "test_runs_gpu.py::test_reply_runs_fuzz[3-700-41",
     "test_one_gpu.py::test_broken_promise_refuses_from_the_first_violation[descent]",
     "test_one_gpu.py::test_broken_promise_refuses_from_the_first_violation[repeated group]",

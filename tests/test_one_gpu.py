@@ -80,13 +80,17 @@ def _dev(torch, a):
     return torch.from_numpy(np.ascontiguousarray(a)).cuda()
 
 
-@pytest.mark.parametrize("G", [200_000, 20_000])
-def test_lazy_outputs_on_the_device_path(hip_lib, oracle_lib, G):
+@pytest.mark.parametrize("G,exchange", [(200_000, True), (20_000, True), (20_000, False)])
+def test_lazy_outputs_on_the_device_path(hip_lib, oracle_lib, monkeypatch, G, exchange):
     """GPX_LAZY_OUTPUTS through the *_dev calls: a usual batch comes back dense with its count and no compaction kernel
     runs (the engine's launch profile says so); an unusual one comes back with a negative count and
     gpx_compact_last_dev makes it the oracle's.  200,000 records: k_one_check + k_ac_one; 20,000: k_ac_one<.., XCHG>
-    alone (its workgroups exchange the verdict among themselves)."""
+    alone (its workgroups exchange the verdict among themselves) - or, when the engine may not count on that grid
+    being resident at once (here: GPX_XCHG_SLOTS=0; in production: many engines on the device), the two launches of
+    the large batches."""
     import torch
+    if not exchange:
+        monkeypatch.setenv("GPX_XCHG_SLOTS", "0")
     eh, eo = make_pair(hip_lib, oracle_lib, 100, G, 3, 8, max_batch=3 * G + 64)
     mem = np.tile(np.array(NODES, np.int32), (G, 1))
     for e in (eh, eo):
@@ -133,7 +137,7 @@ def test_lazy_outputs_on_the_device_path(hip_lib, oracle_lib, G):
     assert int(o[-1].item()) == G and (runs_of(o, 1) == runs2.as_tuple_array()).all() and (o[0].cpu().numpy() == st2).all()
     prof = eh.profile_read()
     assert "k_emit_runs_direct" not in prof and "k_copy_runs" not in prof and "k_order_check" not in prof, prof
-    assert ("k_ac_one" in prof and "k_one_check" in prof) if G > 65536 else (sorted(prof) == ["k_ac_one_x"]), prof
+    assert ("k_ac_one" in prof and "k_one_check" in prof) if (G > 65536 or not exchange) else (sorted(prof) == ["k_ac_one_x"]), prof
     # 3) unusual COMMIT batch: slot 3 before slot 2 for a third of the groups (executes nothing), slot 2 for the rest
     sl = np.where(g % 3 == 0, 3, 2).astype(np.int32)
     o = commit_dev(g, sl, z, kind)
@@ -173,12 +177,15 @@ def test_lazy_outputs_on_the_device_path(hip_lib, oracle_lib, G):
     eh.close(), eo.close()
 
 
-@pytest.mark.parametrize("K,G", [(3, 150_000), (5, 150_000), (3, 20_000), (5, 9_000)])
-def test_lazy_reply_runs(hip_lib, oracle_lib, K, G):
+@pytest.mark.parametrize("K,G,exchange", [(3, 150_000, True), (5, 150_000, True), (3, 20_000, True), (5, 9_000, True),
+                                          (3, 20_000, False)])
+def test_lazy_reply_runs(hip_lib, oracle_lib, monkeypatch, K, G, exchange):
     """Accept replies as K ascending runs under ORDERED_REPLY_RUNS | LAZY_OUTPUTS: the regular round's count is
     published without a compaction launch (by k_runs_check; calls of at most 65,536 votes: by the ONE kernel they
     take, k_ar_runs<.., SMALL>); a round with lost votes comes back negative and is compacted on demand."""
     import torch
+    if not exchange:   # the grid may not be resident at once: k_runs_check + k_ar_runs, as for larger calls
+        monkeypatch.setenv("GPX_XCHG_SLOTS", "0")
     members = list(range(100, 100 + K))
     eh, eo = make_pair(hip_lib, oracle_lib, 100, G, K, 8, max_batch=K * G + 64)
     mem = np.tile(np.array(members, np.int32), (G, 1))
@@ -205,7 +212,7 @@ def test_lazy_reply_runs(hip_lib, oracle_lib, K, G):
         torch.cuda.synchronize()
         prof = eh.profile_read()
         assert "k_emit_dec_runs" not in prof and "k_merge_runs" not in prof, prof
-        assert (list(prof) == ["k_ar_runs_small"]) == (n <= 65536), prof
+        assert (list(prof) == ["k_ar_runs_small"]) == (n <= 65536 and exchange), prof
         do = eo.accept_reply(*cols)
         if r % 2 == 0:
             assert int(no.item()) == G
@@ -220,3 +227,103 @@ def test_lazy_reply_runs(hip_lib, oracle_lib, K, G):
     assert_same_state(eh, eo, rng.integers(0, G, 300))
     assert eh.counters() == eo.counters()
     eh.close(), eo.close()
+
+
+# ---- round 5 -----------------------------------------------------------------------------------------------------------
+
+def test_host_pointer_calls_with_the_lazy_mask_small_irregular_batches(hip_lib, oracle_lib):
+    """GPX_LAZY_OUTPUTS set on the engine, HOST-pointer calls of at most 32,768 records (the staged
+    one-block path) whose batches are irregular - commits that execute nothing or two slots, ACCEPTs that release
+    placeholders, vote runs with lost replies, a broken promise.  gpx.h says the host-pointer calls never leave
+    outputs parked: the counts must come back >= 0 and everything must be the oracle's."""
+    G = 9000
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, 3, 8, max_batch=1 << 16)
+    mem = np.tile(np.array(NODES, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, 3, hri_create(G, 3, 100)) == S_OK).all()
+    mask = ORDERED_PROPOSE | ORDERED_ACCEPT | ORDERED_COMMIT | ORDERED_REPLY_RUNS
+    eh.set_ordered_batches(mask | LAZY_OUTPUTS)
+    eo.set_ordered_batches(mask)
+    g = np.arange(G, dtype=np.int32)
+    z, bc = np.zeros(G, np.int32), np.full(G, 100, np.int32)
+    kind = np.full(G, C_HASVALUE, np.uint8)
+    rng = np.random.default_rng(9)
+
+    def both(fn, *a):
+        ra, rb = getattr(eh, fn)(*a), getattr(eo, fn)(*a)
+        return ra, rb
+
+    def same_runs(ra, rb, what):
+        (sa, xa), (sb, xb) = ra, rb
+        if isinstance(sa, tuple):
+            for x, y in zip(sa, sb):
+                assert (x == y).all(), what
+        else:
+            assert (sa == sb).all(), what
+        assert xa.as_tuple_array().tolist() == xb.as_tuple_array().tolist(), what
+    # slot 3 before slot 2 for a third of the groups: an irregular commit batch (nothing executes there)
+    for x, y in zip(*both("propose", g)):
+        assert (x == y).all()
+    same_runs(*both("accept", g, z, bc, np.ones(G, np.int32), z), "accept slot 1")
+    same_runs(*both("commit", g, z, bc, np.ones(G, np.int32), z, kind), "commit slot 1")
+    sl = np.where(g % 3 == 0, 3, 2).astype(np.int32)
+    same_runs(*both("commit", g, z, bc, sl, z, kind), "commit 3 before 2")
+    gg = g[g % 3 == 0]
+    n3 = gg.shape[0]
+    same_runs(*both("commit", gg, z[:n3], bc[:n3], np.full(n3, 2, np.int32), z[:n3], kind[:n3]), "commit: two slots execute")
+    # placeholders (commits without a value), then the ACCEPTs that release them: an irregular ACCEPT batch
+    ph = np.zeros(G, np.uint8)
+    same_runs(*both("commit", g, z, bc, np.full(G, 4, np.int32), z, ph), "placeholders")
+    same_runs(*both("accept", g, z, bc, np.full(G, 4, np.int32), z), "accepts release placeholders")
+    # a broken promise in a small batch: applied up to the violation, refused from there on
+    gb = g.copy()
+    gb[5000] = gb[4999] - 7
+    ra, rb = both("accept", gb, z, bc, np.full(G, 5, np.int32), z)
+    same_runs(ra, rb, "broken promise")
+    assert (ra[0][4][5000:] == S_UNORDERED).all()
+    # votes as three runs with lost replies (under the runs promise): irregular, compacted inside the call
+    for r in range(2):
+        for x, y in zip(*both("propose", g)):
+            assert (x == y).all()
+        rows = eo.snapshot(g)[0]
+        cols = [c.copy() for c in streams.vote_round_runs(G, NODES, 0, 100, config_id=3)]
+        cols[3] = (rows["next_proposal_slot"][cols[0]] - 1).astype(np.int32)
+        cols[5] = cols[3] - 1
+        keep = rng.random(cols[0].shape[0]) > (0.25 if r == 0 else 0.0)
+        cols = [np.ascontiguousarray(c[keep]) for c in cols]
+        assert cols[0].shape[0] <= 32768
+        dh, do = both("accept_reply", *cols)
+        assert dh.as_tuple_array().tolist() == do.as_tuple_array().tolist() and (dh.status == do.status).all(), f"votes {r}"
+    assert_same_state(eh, eo, rng.integers(0, G, 300))
+    assert eh.counters() == eo.counters()
+    eh.close(), eo.close()
+
+
+def test_compact_last_dev_refuses_after_another_call(hip_lib):
+    """a stale pending compaction (another batch call came in between) is refused, not launched
+    with the earlier call's pointers."""
+    import torch
+    from gigapaxos_amd._abi import GpxError
+    G = 70_000
+    e = Engine(hip_lib, 100, G, kmax=3, window=8, max_batch=G + 64)
+    mem = np.tile(np.array(NODES, np.int32), (G, 1))
+    assert (e.create_groups(np.arange(G), mem, 3, hri_create(G, 3, 100)) == S_OK).all()
+    e.set_ordered_batches(ORDERED_PROPOSE | ORDERED_COMMIT | LAZY_OUTPUTS)
+    i32 = lambda n: torch.zeros(n, dtype=torch.int32, device="cuda")  # noqa: E731
+    u8 = lambda n: torch.zeros(n, dtype=torch.uint8, device="cuda")  # noqa: E731
+    P = lambda t: t.data_ptr()  # noqa: E731
+    g = torch.arange(G, dtype=torch.int32, device="cuda")
+    sl = torch.full((G,), 3, dtype=torch.int32, device="cuda")   # slot 3 first: executes nothing -> parked, count < 0
+    cols = [g, i32(G), torch.full((G,), 100, dtype=torch.int32, device="cuda"), sl, i32(G)]
+    kind = torch.full((G,), C_HASVALUE, dtype=torch.uint8, device="cuda")
+    o = [u8(G)] + [i32(G) for _ in range(3)] + [i32(1)]
+    e.call_dev("commit_batch", G, *[P(c) for c in cols], P(kind), *[P(t) for t in o])
+    e.sync()
+    assert int(o[-1].item()) < 0
+    p = [i32(G) for _ in range(4)] + [u8(G)]
+    e.call_dev("propose_batch", G, P(g), 0, *[P(t) for t in p])      # another batch call in between
+    with pytest.raises(GpxError):
+        e.compact_last_dev()
+    e.compact_last_dev()                                              # nothing pending any more: a no-op
+    e.sync()
+    e.close()
