@@ -136,6 +136,7 @@ struct gpx_engine {
     RunsStage rs{};
     RunsInfo* info = nullptr;
     uint64_t seq = 0; /* call_seq right after the call: gpx_compact_last_dev refuses once another batch call came in between */
+    bool stale = false; /* a pending compaction was overtaken by another batch call (begin_front) */
   } last;
   int lazy_override = -1; /* 1: the host-pointer twins compact on demand themselves; 0: asynchronous calls need dense columns */
   /* exchange kernels (workgroups that wait for each other's tickets): 256-thread workgroups of the greediest of them
@@ -311,7 +312,9 @@ void apply_streams(gpx_engine* e) {
 
 /* Opens a batch call: the call's epoch (what *X.unsorted is compared with). */
 int begin_front(gpx_engine* e) {
-  e->last.kind = 0; /* whatever an earlier call left parked can no longer be compacted (gpx_compact_last_dev) */
+  /* whatever an earlier call left parked can no longer be compacted: gpx_compact_last_dev says so once */
+  e->last.stale = e->last.kind != 0 || e->last.stale;
+  e->last.kind = 0;
   e->X.epoch = (uint32_t)(e->call_seq + 1);
   if (e->X.epoch == 0) { /* 2^32 calls: restart the epochs from cleared words */
     HIPQ(hipStreamSynchronize(e->stream));
@@ -1177,7 +1180,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     if (runs_promised && lazy_outputs(e)) {
       gpx_engine::LastCall& L = e->last;
       L.kind = small ? 4 : 3, L.n = n, L.nchunks = nchunks, L.X = e->X, L.rs = st, L.info = info, L.count = n_out;
-      L.seq = e->call_seq + 1;
+      L.seq = e->call_seq + 1, L.stale = false;
     } else {
       if (small) {
         LaunchScope _ls(e, "k_runs_count");
@@ -1258,7 +1261,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     gpx_engine::LastCall& L = e->last;
     L.kind = 1, L.n = n, L.nchunks = nchunks, L.X = e->X, L.gidx = gidx, L.D = D;
     L.x_gidx = x_gidx, L.x_first = x_first, L.x_count = x_count, L.count = n_runs;
-    L.seq = e->call_seq + 1;
+    L.seq = e->call_seq + 1, L.stale = false;
     if (!lazy_outputs(e)) {
       launch_one_compaction(e, L);
       L.kind = 0;
@@ -1377,7 +1380,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     gpx_engine::LastCall& L = e->last;
     L.kind = 2, L.n = n, L.nchunks = nchunks, L.X = e->X, L.gidx = gidx, L.D = D;
     L.x_gidx = x_gidx, L.x_first = x_first, L.x_count = x_count, L.count = n_runs;
-    L.seq = e->call_seq + 1;
+    L.seq = e->call_seq + 1, L.stale = false;
     if (!lazy_outputs(e)) {
       launch_one_compaction(e, L);
       L.kind = 0;
@@ -1452,8 +1455,9 @@ int gpx_compact_last_dev(gpx_engine* h) {
   if (!h) return GPX_EINVAL;
   gpx_engine* e = h;
   gpx_engine::LastCall& L = e->last;
-  if (L.kind && L.seq != e->call_seq) { /* another batch call came in between: its scratch and columns are gone */
+  if (L.stale || (L.kind && L.seq != e->call_seq)) { /* another batch call came in between: its scratch and columns are gone */
     L.kind = 0;
+    L.stale = false;
     snprintf(g_err, sizeof(g_err), "gpx_compact_last_dev: the call it belongs to is no longer the engine's most recent");
     return GPX_EINVAL;
   }
