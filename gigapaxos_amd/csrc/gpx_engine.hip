@@ -59,10 +59,22 @@ struct PendingEvent {
   hipEvent_t start, stop;
 };
 
-/* engines alive per device in this process: the exchange kernels (one_exchange, k_ar_runs<.., SMALL>) are only
- * launched with grids that stay resident when EVERY live engine of the device launches one at the same moment */
+/* The streams that the live engines of each device (in this process) launch on: the exchange kernels (grid_exchange,
+ * k_ar_runs<.., SMALL>) are only launched with grids that stay resident when EVERY such stream has one of them running
+ * at the same moment.  Engines that share a stream (gpx_engine_set_stream with one handle: their launches are
+ * serialised by the stream) count once. */
 std::mutex g_live_mu;
-std::map<int, int> g_live_engines;
+std::map<int, std::map<hipStream_t, int>> g_live_streams;
+void live_add(int device, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  g_live_streams[device][s]++;
+}
+void live_drop(int device, hipStream_t s) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  auto& m = g_live_streams[device];
+  auto it = m.find(s);
+  if (it != m.end() && --it->second <= 0) m.erase(it);
+}
 
 }  // namespace
 
@@ -143,6 +155,8 @@ struct gpx_engine {
    * that the device holds at once (occupancy x CUs, measured at creation), the processes that share the device
    * (GPX_DEVICE_SHARERS, default 1), and the host-mapped word a waiter that gave up writes (DevScratch.xabort) */
   int xchg_slots = 0, sharers = 1;
+  int slots_ac = 0, slots_commit = 0, slots_propose = 0, slots_runs = 0; /* ... per kernel (one engine alone uses its own) */
+  uint32_t gx_cum[GPX_GX_LINES] = {}; /* arrival counters of grid_exchange as this engine's launches have left them */
   bool registered_live = false;
   uint32_t* h_abort = nullptr;
   /* host blocks handed out by gpx_host_alloc (hipHostMalloc): freed by gpx_host_free or at destroy */
@@ -350,8 +364,8 @@ void end_call(gpx_engine* e, int) { e->call_seq++; }
 
 /* the verdict word of an ordered batch (gpx_one.hip.h) and a fresh, ascending epoch for it */
 OneCtl one_ctl(gpx_engine* e) {
-  if (++e->one_epoch == 0) { /* 2^32 launches: start the epochs again from a cleared word */
-    HIPQ(hipMemsetAsync(e->one_words, 0, sizeof(unsigned long long) * (GPX_ONE_TICKETS + GPX_ONE_XCHG_MAX_N / GPX_DBLOCK), e->stream));
+  if (++e->one_epoch == 0) { /* 2^32 launches: start the epochs again from a cleared word (the arrival counters behind it stay) */
+    HIPQ(hipMemsetAsync(e->one_words, 0, sizeof(unsigned long long) * GPX_ONE_TICKETS, e->stream));
     e->one_epoch = 1;
   }
   return OneCtl{e->one_words, e->one_epoch};
@@ -439,14 +453,40 @@ int check_batch(gpx_engine* h, int32_t n) {
  * launched with `grid` workgroups of 256 threads?  Only if the grids of ALL live engines of this device (times the
  * processes sharing it) fit the device at once - then a partly resident grid can never wait for workgroups that
  * other waiters keep out.  Beyond the bound the caller takes the two-launch form of the same call. */
-bool xchg_ok(const gpx_engine* e, int64_t grid) {
+int xchg_share(const gpx_engine* e) { /* engines (x processes) that may have an exchange kernel on the device at once */
   int live = 1;
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
-    auto it = g_live_engines.find(e->device);
-    if (it != g_live_engines.end()) live = std::max(1, it->second);
+    auto it = g_live_streams.find(e->device);
+    if (it != g_live_streams.end()) live = std::max<int>(1, (int)it->second.size());
   }
-  return grid * live * e->sharers <= (int64_t)e->xchg_slots;
+  return live * e->sharers;
+}
+bool xchg_ok(const gpx_engine* e, int64_t grid) { return grid * xchg_share(e) <= (int64_t)e->xchg_slots; }
+/* Grid of a persistent exchange kernel (k_ac_pers, k_propose_pers, k_ar_runs<.., PERS>) over `nchunks` chunks: every
+ * chunk its own workgroup when that fits, else as many workgroups as this engine's share of the device holds at once
+ * (a sixteenth kept back: the occupancy figure is a bound, not a promise); 0 = take the two-launch form - the share
+ * is so small (many engines on the device) that a looping grid would crawl.  `slots` = the kernel's own occupancy x
+ * CUs; with company the tightest of the exchange kernels counts (their workgroups meet on the same CUs). */
+int xchg_grid(const gpx_engine* e, int nchunks, int slots) {
+  const int share = xchg_share(e);
+  const int64_t have = (int64_t)(share == 1 ? slots : e->xchg_slots) * 15 / 16 / share;
+  if (nchunks <= have) return nchunks;
+  if (have * 4 < (int64_t)e->xchg_slots) return 0;
+  return (int)have;
+}
+/* the verdict word, a fresh epoch, and what the arrival counters read once `grid` workgroups have arrived */
+GridXchg grid_ctl(gpx_engine* e, int grid) {
+  const OneCtl C = one_ctl(e);
+  GridXchg Q;
+  Q.arrive = (uint32_t*)(e->one_words + GPX_ONE_TICKETS);
+  Q.verdict = C.verdict;
+  Q.epoch = C.epoch;
+  for (int l = 0; l < GPX_GX_LINES; l++) {
+    e->gx_cum[l] += (uint32_t)((grid + GPX_GX_LINES - 1 - l) / GPX_GX_LINES); /* workgroups w with w % LINES == l */
+    Q.target[l] = e->gx_cum[l];
+  }
+  return Q;
 }
 
 template <int KMAX>
@@ -716,7 +756,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.o_rec, N, false);
   A(X.bucket_nout, nbk_alloc, true);
   A(e->rec_tag, N, true);
-  A(e->one_words, GPX_ONE_TICKETS + GPX_ONE_XCHG_MAX_N / GPX_DBLOCK, true); /* the verdict word, then k_ac_one<.., XCHG>'s tickets */
+  A(e->one_words, GPX_ONE_TICKETS + GPX_GX_LINES * 16, true); /* the verdict word, then grid_exchange's arrival counters (a 128-byte line each) */
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
@@ -729,17 +769,19 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
       (void)hipGetLastError();
       return nb;
     };
-    int nb = std::min(occ((const void*)k_ac_one<false, true>), occ((const void*)k_ac_one<true, true>));
-    if (cfg->kmax <= 4)
-      nb = std::min({nb, occ((const void*)k_propose_one<4, true>), occ((const void*)k_ar_runs<4, true>)});
-    else if (cfg->kmax <= 8)
-      nb = std::min({nb, occ((const void*)k_propose_one<8, true>), occ((const void*)k_ar_runs<8, true>)});
-    else
-      nb = std::min({nb, occ((const void*)k_propose_one<16, true>), occ((const void*)k_ar_runs<16, true>)});
     int cus = 0;
     HIPCHK_CREATE(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-    e->xchg_slots = nb * cus;
-    if (const char* sv = getenv("GPX_XCHG_SLOTS")) e->xchg_slots = std::max(0, atoi(sv)); /* test switch: 0 = never exchange */
+    e->slots_ac = cus * occ((const void*)k_ac_pers<false>);
+    e->slots_commit = cus * occ((const void*)k_ac_pers<true>);
+    if (cfg->kmax <= 4)
+      e->slots_propose = cus * occ((const void*)k_propose_pers<4>), e->slots_runs = cus * std::min(occ((const void*)k_ar_runs<4, true>), occ((const void*)k_ar_runs<4, true, true>));
+    else if (cfg->kmax <= 8)
+      e->slots_propose = cus * occ((const void*)k_propose_pers<8>), e->slots_runs = cus * std::min(occ((const void*)k_ar_runs<8, true>), occ((const void*)k_ar_runs<8, true, true>));
+    else
+      e->slots_propose = cus * occ((const void*)k_propose_pers<16>), e->slots_runs = cus * std::min(occ((const void*)k_ar_runs<16, true>), occ((const void*)k_ar_runs<16, true, true>));
+    e->xchg_slots = std::min({e->slots_ac, e->slots_commit, e->slots_propose, e->slots_runs});
+    if (const char* sv = getenv("GPX_XCHG_SLOTS")) /* test switch: 0 = never exchange */
+      e->xchg_slots = e->slots_ac = e->slots_commit = e->slots_propose = e->slots_runs = std::max(0, atoi(sv));
     if (const char* sh = getenv("GPX_DEVICE_SHARERS")) e->sharers = std::max(1, atoi(sh));
     HIPCHK_CREATE(hipHostMalloc((void**)&e->h_abort, 64, hipHostMallocMapped));
     *e->h_abort = 0;
@@ -749,11 +791,8 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   HIPCHK_CREATE(hipDeviceSynchronize());
 #undef HIPCHK_CREATE
-  {
-    std::lock_guard<std::mutex> lk(g_live_mu);
-    g_live_engines[e->device]++;
-    e->registered_live = true;
-  }
+  live_add(e->device, e->stream);
+  e->registered_live = true;
   *out = e;
   return GPX_OK;
 }
@@ -774,8 +813,7 @@ int gpx_engine_destroy(gpx_engine* h) {
    * write through the caller's registered mappings; only then may either go away */
   drain_all(h);
   if (h->registered_live) {
-    std::lock_guard<std::mutex> lk(g_live_mu);
-    if (--g_live_engines[h->device] <= 0) g_live_engines.erase(h->device);
+    live_drop(h->device, h->user_stream ? h->user_stream : h->own_stream);
     h->registered_live = false;
   }
   for (auto& r : h->registered)
@@ -811,8 +849,10 @@ int gpx_engine_set_stream(gpx_engine* h, void* hip_stream) {
   if (!h) return GPX_EINVAL;
   HIPCHK(hipStreamSynchronize(h->sF));
   HIPCHK(hipStreamSynchronize(h->sB));
+  if (h->registered_live) live_drop(h->device, h->user_stream ? h->user_stream : h->own_stream);
   h->user_stream = (hipStream_t)hip_stream;
   apply_streams(h);
+  if (h->registered_live) live_add(h->device, h->stream);
   return GPX_OK;
 }
 
@@ -1134,14 +1174,17 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     const int32_t refuse = runs_promised ? 1 : 0;
     if (!e->runs_arrive &&
         (rc = dev_alloc(e, &e->runs_arrive,
-                        /* k_runs_check: one workgroup per 4,096 records; k_ar_runs<.., SMALL>: the counters of 256 workgroups, then a ticket each */
-                        std::max<size_t>(32 * (2 + N / ((size_t)GPX_OC_BLOCK * GPX_RC_ITEMS) / 16 + 1),
-                                         GPX_SMALL_RUNS_TICKETS + GPX_SMALL_RUNS_MAX / GPX_RBLOCK),
+                        /* k_runs_check: one workgroup per 4,096 records; k_ar_runs<.., SMALL>: its end-of-kernel counters */
+                        std::max<size_t>(32 * (2 + N / ((size_t)GPX_OC_BLOCK * GPX_RC_ITEMS) / 16 + 1), GPX_RUNS_ARRIVE_WORDS),
                         true)) != GPX_OK)
       return rc;
-    /* one launch: every workgroup judges its own records and all of them exchange the verdict - if the grid is sure to
-     * be resident at once (xchg_ok); else the check kernel and the work kernel, as for larger batches */
-    const bool small = n <= GPX_SMALL_RUNS_MAX && xchg_ok(e, (n + GPX_RBLOCK - 1) / GPX_RBLOCK);
+    /* ONE launch at any size: resident workgroups loop over the chunks, judge them and exchange the verdict once - if
+     * this engine's share of the device holds a grid worth looping with (xchg_grid); else the check kernel and the
+     * work kernel */
+    const int nch = (n + GPX_RBLOCK - 1) / GPX_RBLOCK;
+    const int pg = std::min(xchg_grid(e, nch, e->slots_runs), 4096);
+    const bool small = pg > 0;
+    const GridXchg Q = small ? grid_ctl(e, pg) : GridXchg{};
     if (!small)
       LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
                 gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
@@ -1150,18 +1193,22 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     if (small) sar_trace_begin(e);
 #endif
     {
-      LaunchScope _ls(e, small ? "k_ar_runs_small" : "k_ar_runs");
-      const dim3 grid((n + GPX_RBLOCK - 1) / GPX_RBLOCK);
+      LaunchScope _ls(e, small ? "k_ar_runs_pers" : "k_ar_runs");
+      const dim3 grid(small ? pg : nch);
 #define GPX_LAUNCH_AR_RUNS(KM)                                                                                              \
   do {                                                                                                                      \
-    if (small)                                                                                                              \
+    if (small && n <= 65536) /* a chain of round trips, not bytes: the first chunk's state requested before the exchange */ \
+      hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ar_runs<KM, true, true>), grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, \
+                         bnum, bcoord, slot, acceptor, max_cp, status, st, info, refuse, n_out, next_info, e->runs_arrive,  \
+                         &e->X.counters[1], Q, nch);                                                                        \
+    else if (small)                                                                                                         \
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ar_runs<KM, true>), grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, \
                          bcoord, slot, acceptor, max_cp, status, st, info, refuse, n_out, next_info, e->runs_arrive,        \
-                         &e->X.counters[1]);                                                                                \
+                         &e->X.counters[1], Q, nch);                                                                        \
     else                                                                                                                    \
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ar_runs<KM, false>), grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, \
                          bcoord, slot, acceptor, max_cp, status, st, info, refuse, n_out, (RunsInfo*)nullptr,               \
-                         (uint32_t*)nullptr, (unsigned long long*)nullptr);                                                 \
+                         (uint32_t*)nullptr, (unsigned long long*)nullptr, Q, nch);                                         \
   } while (0)
       if (e->cfg.kmax <= 4)
         GPX_LAUNCH_AR_RUNS(4);
@@ -1242,11 +1289,12 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
      * At most 65,536 records with lazy outputs: the work kernel alone - its (at most 256, resident) workgroups
      * exchange the verdict among themselves (k_ac_one<.., XCHG>); without lazy outputs k_ac_small's in-kernel run
      * compaction is the one launch */
-    if (fused && xchg_ok(e, (n + GPX_DBLOCK - 1) / GPX_DBLOCK)) {
-      const OneCtl C = one_ctl(e);
-      LaunchScope _ls(e, "k_ac_one_x");
-      hipLaunchKernelGGL((k_ac_one<false, true>), dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, C, n,
-                         gidx, bnum, bcoord, slot, median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, n_runs, 0);
+    const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
+    if (const int pg = xchg_grid(e, nch, e->slots_ac)) { /* ONE launch: resident workgroups, the verdict exchanged among them */
+      const GridXchg Q = grid_ctl(e, pg);
+      LaunchScope _ls(e, "k_ac_pers");
+      hipLaunchKernelGGL(k_ac_pers<false>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, nch, gidx, bnum, bcoord, slot,
+                         median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, n_runs, 0);
     } else {
       const OneCtl C = one_ctl(e);
       {
@@ -1359,12 +1407,13 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const bool promised = (e->ordered_mask & GPX_ORDERED_COMMIT) != 0;
   e->last.kind = 0;
   if (promised && (!fused || lazy_outputs(e))) { /* check + one work kernel (gpx_one.hip.h), like the ACCEPT call */
-    if (fused && xchg_ok(e, (n + GPX_DBLOCK - 1) / GPX_DBLOCK)) {
-      const OneCtl C = one_ctl(e);
-      LaunchScope _ls(e, "k_ac_one_x");
-      hipLaunchKernelGGL((k_ac_one<true, true>), dim3((n + GPX_DBLOCK - 1) / GPX_DBLOCK), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, C, n,
-                         gidx, bnum, bcoord, slot, median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr,
-                         (uint8_t*)nullptr, status, D, n_runs, n);
+    const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
+    if (const int pg = xchg_grid(e, nch, e->slots_commit)) {
+      const GridXchg Q = grid_ctl(e, pg);
+      LaunchScope _ls(e, "k_ac_pers");
+      hipLaunchKernelGGL(k_ac_pers<true>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, nch, gidx, bnum, bcoord, slot,
+                         median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, status, D,
+                         n_runs, n);
     } else {
       const OneCtl C = one_ctl(e);
       {
@@ -1496,40 +1545,38 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   const int32_t refuse = promised ? 1 : 0;
   /* at most 65,536 requests on one stream: order check and direct application in one launch */
   const bool fused = n <= GPX_SMALL_DIRECT_MAX_N;
-  const bool xchg = fused && promised && xchg_ok(e, grid_for(n));
-  if (promised && !xchg) { /* the verdict, then the application without a status prefill pass (gpx_one.hip.h) */
+  if (promised) { /* (gpx_one.hip.h) */
     e->stream = e->sB;
-    const OneCtl C = one_ctl(e);
-    {
-      LaunchScope _lc(e, "k_one_check");
-      hipLaunchKernelGGL(k_one_check<true>, dim3((n + GPX_DBLOCK * 8 - 1) / (GPX_DBLOCK * 8)), dim3(GPX_DBLOCK), 0, e->stream, n, gidx, e->S.G,
-                         C, (int32_t*)nullptr, 0);
+    const int nch = grid_for(n);
+    if (const int pg = xchg_grid(e, nch, e->slots_propose)) {
+      /* ONE launch: resident workgroups loop over the chunks, judge them, exchange the verdict once, apply */
+      const GridXchg Q = grid_ctl(e, pg);
+      if (e->cfg.kmax <= 4)
+        LAUNCH(e, "k_propose_pers", k_propose_pers<4>, pg, e->S, e->X, Q, n, nch, gidx, is_stop, slot, bnum, bcoord, median_cp,
+               status, handle);
+      else if (e->cfg.kmax <= 8)
+        LAUNCH(e, "k_propose_pers", k_propose_pers<8>, pg, e->S, e->X, Q, n, nch, gidx, is_stop, slot, bnum, bcoord, median_cp,
+               status, handle);
+      else
+        LAUNCH(e, "k_propose_pers", k_propose_pers<16>, pg, e->S, e->X, Q, n, nch, gidx, is_stop, slot, bnum, bcoord, median_cp,
+               status, handle);
+    } else { /* the verdict, then the application without a status prefill pass */
+      const OneCtl C = one_ctl(e);
+      {
+        LaunchScope _lc(e, "k_one_check");
+        hipLaunchKernelGGL(k_one_check<true>, dim3((n + GPX_DBLOCK * 8 - 1) / (GPX_DBLOCK * 8)), dim3(GPX_DBLOCK), 0, e->stream, n, gidx, e->S.G,
+                           C, (int32_t*)nullptr, 0);
+      }
+      if (e->cfg.kmax <= 4)
+        LAUNCH(e, "k_propose_one", k_propose_one<4>, nch, e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
+               status, handle);
+      else if (e->cfg.kmax <= 8)
+        LAUNCH(e, "k_propose_one", k_propose_one<8>, nch, e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
+               status, handle);
+      else
+        LAUNCH(e, "k_propose_one", k_propose_one<16>, nch, e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
+               status, handle);
     }
-    if (e->cfg.kmax <= 4)
-      LAUNCH(e, "k_propose_one", k_propose_one<4>, grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
-             status, handle);
-    else if (e->cfg.kmax <= 8)
-      LAUNCH(e, "k_propose_one", k_propose_one<8>, grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
-             status, handle);
-    else
-      LAUNCH(e, "k_propose_one", k_propose_one<16>, grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
-             status, handle);
-    end_call(e, fs);
-    HIPCHK(hipGetLastError());
-    return GPX_OK;
-  }
-  if (xchg) { /* the work kernel alone: its (at most 256, resident) workgroups exchange the verdict */
-    e->stream = e->sB;
-    const OneCtl C = one_ctl(e);
-    if (e->cfg.kmax <= 4)
-      LAUNCH(e, "k_propose_one_x", (k_propose_one<4, true>), grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord,
-             median_cp, status, handle);
-    else if (e->cfg.kmax <= 8)
-      LAUNCH(e, "k_propose_one_x", (k_propose_one<8, true>), grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord,
-             median_cp, status, handle);
-    else
-      LAUNCH(e, "k_propose_one_x", (k_propose_one<16, true>), grid_for(n), e->S, e->X, C, n, gidx, is_stop, slot, bnum, bcoord,
-             median_cp, status, handle);
     end_call(e, fs);
     HIPCHK(hipGetLastError());
     return GPX_OK;

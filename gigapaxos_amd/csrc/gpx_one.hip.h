@@ -87,131 +87,225 @@ __global__ __launch_bounds__(GPX_DBLOCK) void k_one_check(int32_t n, const int32
   }
 }
 
-/* XCHG (round 4, batches of at most 65,536 records = at most 256 workgroups, all resident): no k_one_check launch -
- * every workgroup judges its OWN 256 records (it has loaded them and their predecessors anyway), publishes its first
- * violation in an epoch-tagged ticket (C.verdict + GPX_ONE_TICKETS + blockIdx), and reads all tickets: one exchange
- * between resident workgroups, with the group state already requested.  Workgroup 0 writes the regular count before
- * its ticket, so a workgroup that overwrites it with -1 does so after it. */
-#define GPX_ONE_TICKETS 16
-#define GPX_ONE_XCHG_MAX_N 65536
-/* the exchange: this lane's record i violates the order (or not) -> the batch's first violation.  Every thread of every
- * workgroup of the grid must call it (barriers; at most GPX_DBLOCK workgroups).  count_out / regular_count: workgroup 0
- * writes the regular batch's count before its ticket goes out. */
-__device__ __forceinline__ uint32_t one_exchange(const DevScratch& X, const OneCtl& C, bool viol, int32_t i,
-                                                 int32_t* __restrict__ count_out, int32_t regular_count) {
-  __shared__ uint32_t s_mine, s_all, s_gave_up;
-  if (threadIdx.x == 0) s_mine = 0, s_all = 0, s_gave_up = 0;
-  __syncthreads();
-  /* the verdict's encoding: ONE_NONE - index, 0 = none; the batch's first violation is the MAX over everybody */
-  if (viol) atomicMax(&s_mine, ONE_NONE - (uint32_t)i);
-  __syncthreads();
-  unsigned long long* const tick = C.verdict + GPX_ONE_TICKETS;
-  if (threadIdx.x == 0) {
-    if (blockIdx.x == 0 && count_out) *count_out = regular_count;
-    __hip_atomic_store(&tick[blockIdx.x], ((unsigned long long)C.epoch << 32) | s_mine, __ATOMIC_RELEASE,
-                       __HIP_MEMORY_SCOPE_AGENT);
-  }
-  if (threadIdx.x < gridDim.x) {
-    unsigned long long v;
-    XchgWait w;
+#define GPX_ONE_TICKETS 16 /* words of one_words in front of the arrival counters (the verdict word is the first) */
+/* one lane's share of an ordered ACCEPT / COMMIT batch once the verdict is known: the lane of a run's first record
+ * replays the whole run (or refuses it: the promise was broken at or before it).  Returns "the cheap answer does not
+ * hold" (a run parked by an ACCEPT, a commit without a run, a refused run). */
+template <bool COMMIT>
+__device__ __forceinline__ bool ac_one_apply(const DevState& S, const DevScratch& X, int32_t n, int32_t i, uint32_t first_bad,
+                                             bool runstart, int32_t g, int32_t g_next, int32_t f_a, int32_t f_b, int32_t f_c,
+                                             int32_t f_bnum, int32_t f_bcoord, const AccPre& P,
+                                             const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
+                                             const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
+                                             const int32_t* __restrict__ median, const uint8_t* __restrict__ flags,
+                                             int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
+                                             int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
+                                             uint8_t* __restrict__ status, const DirectStage& D) {
+  if (!runstart) return false;
+  if ((uint32_t)i >= first_bad) {
+    /* refused: the promise was broken at or before this run.  The first violation is always a run start (an
+     * index out of range starts a run of its own, a descent starts a new group), so "runs that start at or
+     * behind it" are exactly "records at or behind it" */
+    int32_t j = i;
     for (;;) {
-      v = __hip_atomic_load(&tick[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
-      if ((uint32_t)(v >> 32) == C.epoch) break;
-      if (w.tired()) { /* that workgroup never became resident (gpx_kernels.hip.h: XchgWait) */
-        s_gave_up = 1;
-        v = 0;
-        break;
+      if (!COMMIT) {
+        r_bnum[j] = 0;
+        r_bcoord[j] = 0;
+        r_maxcp[j] = 0;
+        r_flags[j] = 0;
       }
+      status[j] = GPX_S_UNORDERED;
+      if (++j >= n || (j == i + 1 ? g_next : gidx[j]) != g) break;
     }
-    if ((uint32_t)v) atomicMax(&s_all, (uint32_t)v);
+    return true; /* no regular count for a batch that broke its promise */
   }
-  __syncthreads();
-  if (s_gave_up) { /* nothing of this workgroup's records is applied; the host refuses every later call */
-    if (threadIdx.x == 0) xchg_abort(X);
-    return 0u;
-  }
-  return ONE_NONE - s_all;
+  RunIter it;
+  it.gidx = gidx;
+  it.bnum = bnum;
+  it.bcoord = bcoord;
+  it.slot = slot;
+  it.median = median;
+  it.flags = flags;
+  it.D = D;
+  it.epoch = X.epoch;
+  it.n = n;
+  it.i = i;
+  it.g = g;
+  it.cur = i;
+  it.chunk = -1;
+  it.local = 0;
+  it.count_chunks = false; /* nothing is counted here: k_one_count does it for the rare batch that needs it */
+  it.st = status;          /* no prefill pass ran: the replaying lane marks a record OK before it judges it */
+  it.mark_local = true;
+  it.inplace = COMMIT;
+  it.have_first = true;
+  it.f_a = f_a;
+  it.f_b = f_b;
+  it.f_c = f_c;
+  it.f_bnum = f_bnum;
+  it.f_bcoord = f_bcoord;
+  it.head = i;
+  it.g_next = g_next;
+  if (COMMIT)
+    apply_commit_group(S, X, g, it, status, P);
+  else
+    apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status, nullptr, P);
+  return it.irregular || it.pend >= 0; /* pend: the replay stopped on a commit without a run */
 }
-template <bool COMMIT, bool XCHG = false>
+
+template <bool COMMIT>
 __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
     DevState S, DevScratch X, OneCtl C, int32_t n, const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
     const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot, const int32_t* __restrict__ median,
     const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum, int32_t* __restrict__ r_bcoord,
     int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags, uint8_t* __restrict__ status, DirectStage D,
-    int32_t* __restrict__ n_runs, int32_t regular_count = 0) {
+    int32_t* __restrict__ n_runs) {
   const int32_t i = (int32_t)blockIdx.x * GPX_DBLOCK + (int32_t)threadIdx.x;
-  uint32_t first_bad = XCHG ? ONE_NONE : one_first_bad(C);
+  const uint32_t first_bad = one_first_bad(C);
   /* wave 1 of loads: the neighbours in gidx and this record's columns */
   int32_t g = 0, g_prev = 0, g_next = 0, f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
-  bool head = false, runstart = false, oob = false;
+  bool head = false, runstart = false;
   if (i < n) {
     g = gidx[i];
     g_prev = i > 0 ? gidx[i - 1] : ~g;
     g_next = i + 1 < n ? gidx[i + 1] : ~g;
     f_a = slot[i], f_b = median[i], f_c = flags ? (int32_t)flags[i] : 0;
     f_bnum = bnum[i], f_bcoord = bcoord[i];
-    oob = (uint32_t)g >= (uint32_t)S.G;
     runstart = g_prev != g; /* first record of a run of equal gidx: this lane answers for the whole run */
-    head = runstart && !oob;
+    head = runstart && (uint32_t)g < (uint32_t)S.G;
   }
   /* wave 2: the group's acceptor state and the ring entry of this record's slot */
   AccPre P = acc_nopre();
   if (head) acc_preload(S, g, f_a, P); /* (not made to wait for the verdict word: a refused head has loaded in vain) */
-  if (XCHG) first_bad = one_exchange(X, C, i < n && (oob || (i > 0 && g_prev > g)), i, n_runs, regular_count);
-  bool irregular = false;
-  if (runstart) {
-    if ((uint32_t)i >= first_bad) {
-      /* refused: the promise was broken at or before this run.  The first violation is always a run start (an
-       * index out of range starts a run of its own, a descent starts a new group), so "runs that start at or
-       * behind it" are exactly "records at or behind it" */
-      int32_t j = i;
-      for (;;) {
-        if (!COMMIT) {
-          r_bnum[j] = 0;
-          r_bcoord[j] = 0;
-          r_maxcp[j] = 0;
-          r_flags[j] = 0;
-        }
-        status[j] = GPX_S_UNORDERED;
-        if (++j >= n || (j == i + 1 ? g_next : gidx[j]) != g) break;
+  const bool irregular = ac_one_apply<COMMIT>(S, X, n, i, first_bad, runstart, g, g_next, f_a, f_b, f_c, f_bnum, f_bcoord, P,
+                                              gidx, bnum, bcoord, slot, median, flags, r_bnum, r_bcoord, r_maxcp, r_flags,
+                                              status, D);
+  /* a usual batch is finished: k_one_check wrote its count.  Any workgroup that saw otherwise says so */
+  if (__syncthreads_or(irregular) && threadIdx.x == 0) {
+    __hip_atomic_store(D.mark, X.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* the compaction kernels have work */
+    if (n_runs) __hip_atomic_store(n_runs, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+/* ---- ONE launch at any size (round 5): resident workgroups that loop over chunks ---------------------------------
+ * Round 4's one-launch form (every workgroup judges its own 256 records and all of them exchange the verdict) stopped
+ * at 256 workgroups, each reading 256 tickets; beyond it the verdict took a launch of its own, 6-8 us of every ordered
+ * call by the event profile - 56 us of a whole round's 260.  Here the grid is what the device holds at once (the host
+ * sizes it: occupancy x CUs / engines, gpx_engine.hip xchg_grid), workgroup w takes chunks w, w + grid, ...: it first
+ * JUDGES all its chunks (the gidx column with the predecessors: the loads it needs anyway, now in L2 for the replay),
+ * requests the state of its first chunk, and then meets the others ONCE: a violation goes to the verdict word with an
+ * atomicMax (rare), the arrival to one of GPX_GX_LINES counters 128 bytes apart (device-scope atomics on one line
+ * are serial at ~16 ns: a thousand arrivals over 16 lines cost about a microsecond), sixteen lanes poll the counters.
+ * The counters are never reset - the host passes each launch the values they reach when everybody has arrived.
+ * Then the chunks are replayed as k_ac_one does.  A grid that is not wholly resident would wait for ever: see
+ * xchg_ok / XchgWait for the two guards. */
+#define GPX_GX_LINES 16
+struct GridXchg {
+  uint32_t* arrive;            /* [GPX_GX_LINES * 32] one counter per 128-byte line, cumulative over the engine's launches */
+  unsigned long long* verdict; /* OneCtl's word: epoch << 32 | (ONE_NONE - first violating index) */
+  uint32_t epoch;
+  uint32_t target[GPX_GX_LINES]; /* each counter's value once every workgroup of THIS launch has arrived */
+};
+/* Every thread of every workgroup of the grid calls it once.  wg_bad: this workgroup's first violation, already reduced
+ * (ONE_NONE: none; thread 0's value counts).  Returns the batch's first violation. */
+__device__ __forceinline__ uint32_t grid_exchange(const DevScratch& X, const GridXchg& Q, uint32_t wg_bad,
+                                                  int32_t* __restrict__ count_out, int32_t regular_count) {
+  __shared__ uint32_t s_first, s_gave_up;
+  if (threadIdx.x == 0) {
+    s_gave_up = 0;
+    if (blockIdx.x == 0 && count_out) *count_out = regular_count; /* before workgroup 0's arrival: a later -1 wins */
+    if (wg_bad != ONE_NONE)
+      atomicMax(Q.verdict, ((unsigned long long)Q.epoch << 32) | (unsigned long long)(ONE_NONE - wg_bad));
+    __hip_atomic_fetch_add(&Q.arrive[(blockIdx.x % GPX_GX_LINES) * 32], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  __syncthreads(); /* (s_gave_up cleared before a poller may raise it) */
+  if (threadIdx.x < GPX_GX_LINES) {
+    XchgWait w;
+    while ((int32_t)(__hip_atomic_load(&Q.arrive[threadIdx.x * 32], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) -
+                     Q.target[threadIdx.x]) < 0) {
+      if (w.tired()) { /* some workgroup never became resident (gpx_kernels.hip.h: XchgWait) */
+        s_gave_up = 1;
+        break;
       }
-      irregular = true; /* no regular count for a batch that broke its promise */
-    } else {
-      RunIter it;
-      it.gidx = gidx;
-      it.bnum = bnum;
-      it.bcoord = bcoord;
-      it.slot = slot;
-      it.median = median;
-      it.flags = flags;
-      it.D = D;
-      it.epoch = X.epoch;
-      it.n = n;
-      it.i = i;
-      it.g = g;
-      it.cur = i;
-      it.chunk = -1;
-      it.local = 0;
-      it.count_chunks = false; /* nothing is counted here: k_one_count does it for the rare batch that needs it */
-      it.st = status;          /* no prefill pass ran: the replaying lane marks a record OK before it judges it */
-      it.mark_local = true;
-      it.inplace = COMMIT;
-      it.have_first = true;
-      it.f_a = f_a;
-      it.f_b = f_b;
-      it.f_c = f_c;
-      it.f_bnum = f_bnum;
-      it.f_bcoord = f_bcoord;
-      it.head = i;
-      it.g_next = g_next;
-      if (COMMIT)
-        apply_commit_group(S, X, g, it, status, P);
-      else
-        apply_accept_group(S, X, g, it, r_bnum, r_bcoord, r_maxcp, r_flags, status, nullptr, P);
-      irregular = it.irregular || it.pend >= 0; /* pend: the replay stopped on a commit without a run */
     }
   }
-  /* a usual batch is finished: k_one_check wrote its count.  Any workgroup that saw otherwise says so */
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long v = __hip_atomic_load(Q.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_first = (uint32_t)(v >> 32) == Q.epoch ? ONE_NONE - (uint32_t)v : ONE_NONE;
+    if (s_gave_up) {
+      xchg_abort(X);
+      s_first = 0u; /* nothing of this workgroup's records is applied */
+    }
+  }
+  __syncthreads();
+  return s_first;
+}
+/* a workgroup's first violation from its lanes' (ONE_NONE: none); every thread must call it */
+__device__ __forceinline__ uint32_t wg_first_bad(uint32_t mine) {
+  __shared__ uint32_t s_bad;
+  if (threadIdx.x == 0) s_bad = ONE_NONE;
+  if (__syncthreads_or(mine != ONE_NONE)) { /* (also orders the store of s_bad above) */
+    if (mine != ONE_NONE) atomicMin(&s_bad, mine);
+    __syncthreads();
+  }
+  return s_bad; /* (thread 0 wrote it before the barrier inside __syncthreads_or) */
+}
+
+template <bool COMMIT>
+__global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_pers(
+    DevState S, DevScratch X, GridXchg Q, int32_t n, int32_t nchunks, const int32_t* __restrict__ gidx,
+    const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
+    const int32_t* __restrict__ median, const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum,
+    int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
+    uint8_t* __restrict__ status, DirectStage D, int32_t* __restrict__ n_runs, int32_t regular_count) {
+  /* the first chunk's loads go out before anything else (waves 1 and 2 of k_ac_one) */
+  int32_t c = (int32_t)blockIdx.x;
+  int32_t i = c * GPX_DBLOCK + (int32_t)threadIdx.x;
+  int32_t g = 0, g_prev = 0, g_next = 0, f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
+  bool runstart = false;
+  uint32_t mine = ONE_NONE;
+  AccPre P = acc_nopre();
+  if (i < n) {
+    g = gidx[i];
+    g_prev = i > 0 ? gidx[i - 1] : ~g;
+    g_next = i + 1 < n ? gidx[i + 1] : ~g;
+    f_a = slot[i], f_b = median[i], f_c = flags ? (int32_t)flags[i] : 0;
+    f_bnum = bnum[i], f_bcoord = bcoord[i];
+    const bool oob = (uint32_t)g >= (uint32_t)S.G;
+    runstart = g_prev != g;
+    if (runstart && !oob) acc_preload(S, g, f_a, P);
+    if (oob || (i > 0 && g_prev > g)) mine = (uint32_t)i;
+  }
+  /* the verdict over the other chunks of this workgroup (ascending: the first hit is the lowest index) */
+  for (int32_t c2 = c + (int32_t)gridDim.x; c2 < nchunks && mine == ONE_NONE; c2 += (int32_t)gridDim.x) {
+    const int32_t j = c2 * GPX_DBLOCK + (int32_t)threadIdx.x;
+    if (j < n) {
+      const int32_t gj = gidx[j], gp = gidx[j - 1];
+      if ((uint32_t)gj >= (uint32_t)S.G || gp > gj) mine = (uint32_t)j;
+    }
+  }
+  const uint32_t first_bad = grid_exchange(X, Q, wg_first_bad(mine), n_runs, regular_count);
+  bool irregular = false;
+  for (;;) {
+    irregular |= ac_one_apply<COMMIT>(S, X, n, i, first_bad, runstart, g, g_next, f_a, f_b, f_c, f_bnum, f_bcoord, P, gidx,
+                                      bnum, bcoord, slot, median, flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D);
+    c += (int32_t)gridDim.x;
+    if (c >= nchunks) break;
+    i = c * GPX_DBLOCK + (int32_t)threadIdx.x;
+    runstart = false;
+    P = acc_nopre();
+    if (i < n) {
+      g = gidx[i];
+      g_prev = gidx[i - 1];
+      g_next = i + 1 < n ? gidx[i + 1] : ~g;
+      f_a = slot[i], f_b = median[i], f_c = flags ? (int32_t)flags[i] : 0;
+      f_bnum = bnum[i], f_bcoord = bcoord[i];
+      runstart = g_prev != g;
+      if (runstart && (uint32_t)g < (uint32_t)S.G && (uint32_t)i < first_bad) acc_preload(S, g, f_a, P);
+    }
+  }
+  /* a usual batch is finished: workgroup 0 wrote its count.  Any workgroup that saw otherwise says so */
   if (__syncthreads_or(irregular) && threadIdx.x == 0) {
     __hip_atomic_store(D.mark, X.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* the compaction kernels have work */
     if (n_runs) __hip_atomic_store(n_runs, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -227,26 +321,12 @@ __global__ __launch_bounds__(GPX_DCHUNK) void k_one_count(DevScratch X, int32_t 
 }
 
 /* PROPOSE: strictly ascending gidx (every group at most once), so every record is its group's only one */
-template <int KMAX, bool XCHG = false>
-__global__ __launch_bounds__(GPX_BLOCK) void k_propose_one(
-    DevState S, DevScratch X, OneCtl C, int32_t n, const int32_t* __restrict__ gidx,
-    const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
-    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
-    const int64_t* __restrict__ handle) {
-  const int32_t i = (int32_t)blockIdx.x * GPX_BLOCK + (int32_t)threadIdx.x;
-  if (!XCHG && i >= n) return;
-  uint32_t first_bad = XCHG ? ONE_NONE : one_first_bad(C);
-  const int32_t g = i < n ? gidx[i] : -1;
-  const int32_t g_prev = (XCHG && i > 0 && i < n) ? gidx[i - 1] : INT32_MIN;
-  ProposePre<KMAX> P;
-  if ((uint32_t)g < (uint32_t)S.G) { /* requested without waiting for the verdict */
-    propose_preload<KMAX>(S, g, P);
-    propose_preload_ring<KMAX>(S, g, P);
-  }
-  if (XCHG) { /* at most 65,536 requests: no k_one_check launch (one_exchange); strictly ascending, in range */
-    first_bad = one_exchange(X, C, i < n && ((uint32_t)g >= (uint32_t)S.G || (i > 0 && g_prev >= g)), i, nullptr, 0);
-    if (i >= n) return;
-  }
+template <int KMAX>
+__device__ __forceinline__ void propose_one_apply(const DevState& S, const DevScratch& X, int32_t i, int32_t g, uint32_t first_bad,
+                                                  const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot,
+                                                  int32_t* __restrict__ o_bnum, int32_t* __restrict__ o_bcoord,
+                                                  int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
+                                                  ProposePre<KMAX>& P, const int64_t* __restrict__ handle) {
   if ((uint32_t)i >= first_bad) {
     o_slot[i] = 0;
     o_bnum[i] = 0;
@@ -262,4 +342,64 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_one(
   it.done = 0;
   status[i] = GPX_S_OK; /* no prefill pass ran; apply_propose_group overwrites it for a record it refuses */
   apply_propose_group<KMAX, OneRec>(S, X, g, it, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
+}
+template <int KMAX>
+__global__ __launch_bounds__(GPX_BLOCK) void k_propose_one(
+    DevState S, DevScratch X, OneCtl C, int32_t n, const int32_t* __restrict__ gidx,
+    const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
+    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
+    const int64_t* __restrict__ handle) {
+  const int32_t i = (int32_t)blockIdx.x * GPX_BLOCK + (int32_t)threadIdx.x;
+  if (i >= n) return;
+  const uint32_t first_bad = one_first_bad(C);
+  const int32_t g = gidx[i];
+  ProposePre<KMAX> P;
+  if ((uint32_t)g < (uint32_t)S.G) { /* requested without waiting for the verdict */
+    propose_preload<KMAX>(S, g, P);
+    propose_preload_ring<KMAX>(S, g, P);
+  }
+  propose_one_apply<KMAX>(S, X, i, g, first_bad, is_stop, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
+}
+/* ... in ONE launch at any size: resident workgroups looping over chunks, the verdict exchanged once (k_ac_pers) */
+template <int KMAX>
+__global__ __launch_bounds__(GPX_BLOCK) void k_propose_pers(
+    DevState S, DevScratch X, GridXchg Q, int32_t n, int32_t nchunks, const int32_t* __restrict__ gidx,
+    const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
+    int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
+    const int64_t* __restrict__ handle) {
+  int32_t c = (int32_t)blockIdx.x;
+  int32_t i = c * GPX_BLOCK + (int32_t)threadIdx.x;
+  int32_t g = -1;
+  uint32_t mine = ONE_NONE;
+  ProposePre<KMAX> P;
+  if (i < n) {
+    g = gidx[i];
+    const int32_t g_prev = i > 0 ? gidx[i - 1] : INT32_MIN;
+    if ((uint32_t)g < (uint32_t)S.G) { /* requested without waiting for the verdict */
+      propose_preload<KMAX>(S, g, P);
+      propose_preload_ring<KMAX>(S, g, P);
+    }
+    if ((uint32_t)g >= (uint32_t)S.G || (i > 0 && g_prev >= g)) mine = (uint32_t)i; /* strictly ascending, in range */
+  }
+  for (int32_t c2 = c + (int32_t)gridDim.x; c2 < nchunks && mine == ONE_NONE; c2 += (int32_t)gridDim.x) {
+    const int32_t j = c2 * GPX_BLOCK + (int32_t)threadIdx.x;
+    if (j < n) {
+      const int32_t gj = gidx[j], gp = gidx[j - 1];
+      if ((uint32_t)gj >= (uint32_t)S.G || gp >= gj) mine = (uint32_t)j;
+    }
+  }
+  const uint32_t first_bad = grid_exchange(X, Q, wg_first_bad(mine), nullptr, 0);
+  for (;;) {
+    if (i < n) propose_one_apply<KMAX>(S, X, i, g, first_bad, is_stop, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
+    c += (int32_t)gridDim.x;
+    if (c >= nchunks) break;
+    i = c * GPX_BLOCK + (int32_t)threadIdx.x;
+    if (i < n) {
+      g = gidx[i];
+      if ((uint32_t)g < (uint32_t)S.G && (uint32_t)i < first_bad) {
+        propose_preload<KMAX>(S, g, P);
+        propose_preload_ring<KMAX>(S, g, P);
+      }
+    }
+  }
 }

@@ -312,16 +312,19 @@ struct RunsIter {
  * four waves per SIMD, each a chain of three dependent load waves - and the kernel took 87 us per 3 M votes */
 #define GPX_RBLOCK 256
 
-/* SMALL (round 4): a call of at most GPX_SMALL_RUNS_MAX votes in ONE launch - the shape a coordinator really sees
- * most often: the replies of a few acceptors, each frame at most 2,048 slots (BatchedAcceptReply.java:27).  No
- * k_runs_check launch: every workgroup judges its own 256 records and all of them (at most 256, resident together)
- * exchange the verdict through epoch tickets (below); the lane that replays a vote marks its status (no prefill
- * pass), nothing is counted per chunk, and the LAST workgroup to finish (two levels of arrival counters, 16
- * workgroups per counter, a cache line apart) publishes the count - or -1 for a batch that needs the compaction
- * pass - and leaves the run starts in `info` for that pass. */
-#define GPX_SMALL_RUNS_MAX 65536
-#define GPX_SMALL_RUNS_TICKETS (32 * 18) /* words of runs_arrive in front of the small kernel's tickets (the arrival counters) */
-template <int KMAX, bool SMALL = false>
+/* SMALL = the call in ONE launch (round 4: at most 65,536 votes, every workgroup judging its own 256 records and all of
+ * them - at most 256, resident together - exchanging the verdict through tickets; round 5: ANY size - the grid is what
+ * the device holds at once (gpx_engine.hip: xchg_grid), workgroup w takes chunks w, w + grid, ..., judges all of them
+ * first - in range; a descent = a run start, appended to info->start as k_runs_check does - raises *X.unsorted for a
+ * batch that is no few runs in range, and meets the others ONCE at grid_exchange's arrival counters (gpx_one.hip.h);
+ * then every workgroup reads the same verdict and the same run starts and replays its chunks).  No k_runs_check launch;
+ * the lane that replays a vote marks its status (no prefill pass), nothing is counted per chunk, and the LAST workgroup
+ * to finish (two levels of arrival counters, 16 workgroups per counter, a cache line apart) publishes the count - or -1
+ * for a batch that needs the compaction pass - and leaves the run starts in `info` for that pass.
+ * !SMALL: the grid has one workgroup per chunk and k_runs_check has run before (the form for a device shared by many
+ * engines, where a resident grid cannot be counted on). */
+#define GPX_RUNS_ARRIVE_WORDS (32 * (2 + 4096 / 16)) /* end-of-kernel arrival counters: up to 4,096 workgroups, 16 per counter */
+template <int KMAX, bool SMALL = false, bool EARLY = false>
 __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X, int32_t n,
                                                        const int32_t* __restrict__ gidx,
                                                        const int32_t* __restrict__ bnum,
@@ -331,31 +334,40 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
                                                        const int32_t* __restrict__ maxcp,
                                                        uint8_t* __restrict__ status, RunsStage st,
                                                        RunsInfo* __restrict__ info, int32_t refuse,
-                                                       int32_t* __restrict__ n_out, RunsInfo* __restrict__ next_info = nullptr,
-                                                       uint32_t* __restrict__ arrive = nullptr,
-                                                       unsigned long long* __restrict__ acc = nullptr) {
+                                                       int32_t* __restrict__ n_out, RunsInfo* __restrict__ next_info,
+                                                       uint32_t* __restrict__ arrive, unsigned long long* __restrict__ acc,
+                                                       GridXchg Q, int32_t nchunks) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
   __shared__ int32_t wsum[GPX_RBLOCK / 64];
-  const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
-  const int32_t my_chunk = (int32_t)(((int64_t)blockIdx.x * GPX_RBLOCK) >> GPX_DCHUNK_SHIFT);
+  int32_t c = (int32_t)blockIdx.x;
+  int32_t i = c * GPX_RBLOCK + (int32_t)threadIdx.x;
   int32_t R;
+  CoordPre<KMAX> P;
+  bool have_p = false;
 #ifdef GPX_SAR_TRACE
   if (SMALL) SAR_STAMP(blockIdx.x, 0);
 #endif
   if (SMALL) {
-    /* The verdict without a kernel of its own AND without every workgroup reading the whole column (the second
-     * build did: 12 of its 18 us at 30,000 votes, profiles/r04_sar_trace_2.txt): a workgroup judges its OWN 256
-     * records - in range; a descent = a run start, appended to info->start as k_runs_check does - raises
-     * *X.unsorted for a batch that is no few runs in range, publishes a ticket (the call's epoch) and waits for the
-     * tickets of ALL workgroups (at most 256 of them, all resident: one load per lane) - then every workgroup reads
-     * the same verdict and the same run starts. */
+    /* the state of the first chunk's groups is REQUESTED before the verdict is exchanged (as k_ac_pers does): round 4's
+     * exchange was 10 of the small kernel's 11.5 us because nothing else was in flight behind it (profiles/
+     * r04_sar_trace_6_tiny.txt).  Every lane asks for the state of its own record's group - the lanes of run 0 will
+     * own those groups, the others have asked in vain (their lines are in L2 for the owner) */
+    if (EARLY && i < n) { /* (EARLY: the small calls' build - holding the state across the exchange costs 30 VGPRs) */
+      const int32_t g0 = gidx[i];
+      if ((uint32_t)g0 < (uint32_t)S.G) {
+        coord_preload<KMAX>(S, g0, P);
+        coord_preload_ring<KMAX>(S, g0, P);
+        have_p = true;
+      }
+    }
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(RunsInfo) / 4)) ((int32_t*)next_info)[threadIdx.x] = 0;
-    uint32_t* const tick = arrive + GPX_SMALL_RUNS_TICKETS;
-    {
+    bool wg_bad = false;
+    for (int32_t c2 = c; c2 < nchunks; c2 += (int32_t)gridDim.x) { /* (uniform per workgroup: barriers inside) */
+      const int32_t j = c2 * GPX_RBLOCK + (int32_t)threadIdx.x;
       bool bad = false, desc = false;
-      if (i < n) {
-        const int32_t gi = gidx[i];
-        const int32_t gp = i > 0 ? gidx[i - 1] : INT32_MIN;
+      if (j < n) {
+        const int32_t gi = gidx[j];
+        const int32_t gp = j > 0 ? gidx[j - 1] : INT32_MIN;
         bad = (uint32_t)gi >= (uint32_t)S.G;
         desc = gp > gi;
       }
@@ -364,31 +376,26 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       if (!bad && desc) {
         const int32_t k = atomicAdd(&info->n_desc, 1);
         if (k < GPX_RUNS_MAX - 1)
-          __hip_atomic_store(&info->start[k + 1], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          __hip_atomic_store(&info->start[k + 1], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         else
           bad = true;
       }
-      if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
-      /* (the barrier above orders this workgroup's run starts and its verdict before its ticket) */
-      if (threadIdx.x == 0) __hip_atomic_store(&tick[blockIdx.x], X.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-      if (threadIdx.x < gridDim.x) {
-        XchgWait w;
-        while (__hip_atomic_load(&tick[threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != X.epoch) {
-          if (w.tired()) { /* that workgroup never became resident (gpx_kernels.hip.h: XchgWait): apply nothing */
-            xchg_abort(X);
-            atomicMax(X.unsorted, X.epoch);
-            break;
-          }
-        }
-      }
-      __syncthreads();
+      wg_bad |= __syncthreads_or(bad) != 0;
+      if (wg_bad) break; /* (uniform) */
     }
+    if (wg_bad && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
+    /* (grid_exchange's first barrier orders this workgroup's run starts and its verdict before its arrival) */
+    if (grid_exchange(X, Q, ONE_NONE, nullptr, 0) == 0u && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch); /* gave up: apply nothing */
+    __syncthreads();
     if (__hip_atomic_load(X.unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X.epoch) {
       /* not a few ascending runs in range: refused whole under the promise, else the partition pipeline (or the
        * one-launch kernel of small calls) launched behind takes the batch */
       if (refuse) {
-        if (i < n && status) status[i] = GPX_S_UNORDERED;
-        if (i == 0 && n_out) *n_out = 0;
+        for (; c < nchunks; c += (int32_t)gridDim.x) {
+          i = c * GPX_RBLOCK + (int32_t)threadIdx.x;
+          if (i < n && status) status[i] = GPX_S_UNORDERED;
+        }
+        if (blockIdx.x == 0 && threadIdx.x == 0 && n_out) *n_out = 0;
       }
       return;
     }
@@ -405,9 +412,11 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
     }
     R = runs_load(info, n, rs);
   }
-  if (i == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
+  if (blockIdx.x == 0 && threadIdx.x == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
+  const int32_t my_chunk = (int32_t)(((int64_t)blockIdx.x * GPX_RBLOCK) >> GPX_DCHUNK_SHIFT); /* (!SMALL: the only chunk) */
   int32_t local = 0;
   bool irregular = false; /* this lane saw why the columns are not dense as parked (travels with the arrival counters) */
+  for (;; have_p = false) {
   const bool active = i < n;
   const int32_t g = active ? gidx[i] : 0;
   int32_t r = 0;
@@ -418,8 +427,6 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
   /* a lane of a later run (two thirds of a three-replica batch) usually finds its group at the same offset of
    * run 0 and has nothing to do: that word is fetched together with the lane's own, not after it */
   if (active && r > 0 && o < rs[1] && gidx[o] == g) done = true;
-  CoordPre<KMAX> P;
-  bool have_p = false;
   /* the lanes of the later runs (two thirds of a three-replica batch) skip the speculative fetches: they
    * only test whether an earlier run holds their group */
   if (R <= GPX_RUNS_FAST && __any(in0)) {
@@ -444,9 +451,11 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       }
     }
     if (ok) { /* this lane owns its group and knows where its votes are */
-      coord_preload<KMAX>(S, g, P);
-      coord_preload_ring<KMAX>(S, g, P);
-      have_p = true;
+      if (!have_p) {
+        coord_preload<KMAX>(S, g, P);
+        coord_preload_ring<KMAX>(S, g, P);
+        have_p = true;
+      }
       bool el = SteadyGroup<KMAX>::group_ok(P) && SteadyGroup<KMAX>::slot_ok(S, P, sl[0]);
 #pragma unroll
       for (int q = 0; q < GPX_RUNS_FAST; q++)
@@ -475,7 +484,7 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
         if (dec) { /* the group's first (only) output: parked at its first vote = this lane's record */
           st.D.put(i, g, sl[0], P.my_bnum, P.my_bcoord, dmed, GPX_D_DECISION);
           st.tag[i] = X.epoch;
-          local = 1;
+          local += 1;
         } else {
           info->general_used = 1; /* a hole in run 0: the columns are not dense */
           irregular = true;
@@ -522,10 +531,15 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
         coord_preload_ring<KMAX>(S, g, P);
       }
       apply_ar_group<KMAX>(S, X, g, it, status, P);
-      local = it.local;
+      local += it.local;
     }
   }
-  /* this chunk's own parked outputs: one atomic per workgroup */
+  if (!SMALL) break;
+  c += (int32_t)gridDim.x;
+  if (c >= nchunks) break;
+  i = c * GPX_RBLOCK + (int32_t)threadIdx.x;
+  }
+  /* this workgroup's own parked outputs: one atomic per workgroup */
   int32_t x = local;
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) x += __shfl_xor(x, d, 64);

@@ -36,10 +36,12 @@
  *     consumer discipline, ConsumerTask.java:163-174); different engines are
  *     fully concurrent, any number of them per GPU.  (The one-launch kernels of
  *     small ordered batches exchange their verdict between workgroups that must
- *     all be resident.  The library enforces that itself: it counts the live
- *     engines of a device and only launches such a kernel with a grid that fits
- *     the device together with one of every other engine - occupancy x CUs /
- *     engines; a larger batch takes the two-launch form with the same results.
+ *     all be resident.  The library enforces that itself: it counts the streams
+ *     the live engines of a device launch on (engines given ONE stream with
+ *     gpx_engine_set_stream are serialised by it and count once) and only
+ *     launches such a kernel with a grid that fits the device together with one
+ *     on every other stream - occupancy x CUs / streams; where that share gets
+ *     small a call takes the two-launch form, with the same results.
  *     Processes SHARING a device cannot see each other: tell each of them with
  *     GPX_DEVICE_SHARERS=<processes>.  A waiter that still starves gives up
  *     after two seconds and every later call returns GPX_EDEVICE - never a

@@ -1,6 +1,6 @@
 """Eight engines on ONE device, each driven from its own host thread through the device-pointer calls, every batch an
 ordered one of at most 65,536 records under the promises with GPX_LAZY_OUTPUTS - the shape that takes the one-launch
-exchange kernels (k_propose_one<.., XCHG>, k_ac_one<.., XCHG>, k_ar_runs<.., SMALL>), whose workgroups wait for each
+exchange kernels (k_propose_pers, k_ac_pers, k_ar_runs<.., SMALL>), whose workgroups wait for each
 other's tickets and therefore must all be resident.  VERDICT r4 weak #7 / ADVICE r4 medium: nothing used to bound how
 many such grids meet on a device.  Now the library counts the live engines of a device and sizes the grids it allows
 from the kernels' occupancy (gpx_engine.hip: xchg_ok); with eight engines alive a batch of about 40,000 records is

@@ -175,7 +175,7 @@ def test_runs_hint_and_small_calls(hip_lib, oracle_lib, G):
         if G == 300:
             assert list(prof) == ["k_ar_tiny"], prof
         else:
-            assert "k_ar_runs_small" in prof and "k_ar_tiny" not in prof, prof
+            assert "k_ar_runs_pers" in prof and "k_ar_tiny" not in prof, prof
     assert_same_state(eh, eo, np.random.default_rng(0).integers(0, G, 300))
     assert eh.counters() == eo.counters()
     eh.close(), eo.close()
