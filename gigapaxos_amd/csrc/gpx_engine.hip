@@ -151,12 +151,12 @@ struct gpx_engine {
     bool stale = false; /* a pending compaction was overtaken by another batch call (begin_front) */
   } last;
   int lazy_override = -1; /* 1: the host-pointer twins compact on demand themselves; 0: asynchronous calls need dense columns */
-  /* exchange kernels (workgroups that wait for each other's tickets): 256-thread workgroups of the greediest of them
-   * that the device holds at once (occupancy x CUs, measured at creation), the processes that share the device
-   * (GPX_DEVICE_SHARERS, default 1), and the host-mapped word a waiter that gave up writes (DevScratch.xabort) */
-  int xchg_slots = 0, sharers = 1;
-  int slots_ac = 0, slots_commit = 0, slots_propose = 0, slots_runs = 0; /* ... per kernel (one engine alone uses its own) */
-  uint32_t gx_cum[GPX_GX_LINES] = {}; /* arrival counters of grid_exchange as this engine's launches have left them */
+  /* one-launch calls (gpx_one.hip.h: judges that meet at arrival counters): the device's CUs and the processes sharing
+   * it (GPX_DEVICE_SHARERS, default 1) decide which grids need no tickets; the host-mapped word a waiter that gave up
+   * writes (DevScratch.xabort) */
+  int cus = 0, sharers = 1;
+  bool one_launch = true;            /* GPX_XCHG_SLOTS=0 (comparison builds, tests): the check kernel + the work kernel instead */
+  uint32_t gx_arrive = 0, gx_draw = 0; /* grid_exchange's arrival / ticket counters as this engine's launches have left them */
   bool registered_live = false;
   uint32_t* h_abort = nullptr;
   /* host blocks handed out by gpx_host_alloc (hipHostMalloc): freed by gpx_host_free or at destroy */
@@ -462,30 +462,25 @@ int xchg_share(const gpx_engine* e) { /* engines (x processes) that may have an 
   }
   return live * e->sharers;
 }
-bool xchg_ok(const gpx_engine* e, int64_t grid) { return grid * xchg_share(e) <= (int64_t)e->xchg_slots; }
-/* Grid of a persistent exchange kernel (k_ac_pers, k_propose_pers, k_ar_runs<.., PERS>) over `nchunks` chunks: every
- * chunk its own workgroup when that fits, else as many workgroups as this engine's share of the device holds at once
- * (a sixteenth kept back: the occupancy figure is a bound, not a promise); 0 = take the two-launch form - the share
- * is so small (many engines on the device) that a looping grid would crawl.  `slots` = the kernel's own occupancy x
- * CUs; with company the tightest of the exchange kernels counts (their workgroups meet on the same CUs). */
-int xchg_grid(const gpx_engine* e, int nchunks, int slots) {
-  const int share = xchg_share(e);
-  const int64_t have = (int64_t)(share == 1 ? slots : e->xchg_slots) * 15 / 16 / share;
-  if (nchunks <= have) return nchunks;
-  if (have * 4 < (int64_t)e->xchg_slots) return 0;
-  return (int)have;
-}
-/* the verdict word, a fresh epoch, and what the arrival counters read once `grid` workgroups have arrived */
-GridXchg grid_ctl(gpx_engine* e, int grid) {
+/* The control block of ONE-launch call over `nchunks` chunks (gpx_one.hip.h): the grid (a multiple of 16: every counter
+ * line gets the same number of tickets and arrivals), who judges, and what the cumulative counters read afterwards.
+ * A grid of at most 2 workgroups per CU and stream is resident whatever the kernel: no tickets, every workgroup judges
+ * its own chunk; anything larger draws tickets and its first GPX_GX_JUDGES workgroups to start judge the batch. */
+GridXchg xchg_ctl(gpx_engine* e, int nchunks, int* grid) {
   const OneCtl C = one_ctl(e);
   GridXchg Q;
+  const int g16 = (std::max(nchunks, 1) + GPX_GX_LINES - 1) / GPX_GX_LINES * GPX_GX_LINES;
+  *grid = g16;
   Q.arrive = (uint32_t*)(e->one_words + GPX_ONE_TICKETS);
+  Q.draw = Q.arrive + GPX_GX_LINES * 32;
   Q.verdict = C.verdict;
   Q.epoch = C.epoch;
-  for (int l = 0; l < GPX_GX_LINES; l++) {
-    e->gx_cum[l] += (uint32_t)((grid + GPX_GX_LINES - 1 - l) / GPX_GX_LINES); /* workgroups w with w % LINES == l */
-    Q.target[l] = e->gx_cum[l];
-  }
+  Q.tickets = (int64_t)g16 * xchg_share(e) <= (int64_t)2 * e->cus ? 0 : 1;
+  Q.judges = Q.tickets ? std::min(GPX_GX_JUDGES, g16) : g16;
+  Q.draw_base = e->gx_draw;
+  if (Q.tickets) e->gx_draw += (uint32_t)(g16 / GPX_GX_LINES);
+  e->gx_arrive += (uint32_t)(Q.judges / GPX_GX_LINES);
+  Q.arrive_target = e->gx_arrive;
   return Q;
 }
 
@@ -756,32 +751,15 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.o_rec, N, false);
   A(X.bucket_nout, nbk_alloc, true);
   A(e->rec_tag, N, true);
-  A(e->one_words, GPX_ONE_TICKETS + GPX_GX_LINES * 16, true); /* the verdict word, then grid_exchange's arrival counters (a 128-byte line each) */
+  A(e->one_words, GPX_ONE_TICKETS + 2 * GPX_GX_LINES * 16, true); /* the verdict word, then grid_exchange's arrival and ticket counters (a 128-byte line each) */
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
   A(e->st_count, 4, true);
 #undef A
-  { /* how many 256-thread workgroups of this engine's exchange kernels the device holds at once */
-    auto occ = [](const void* fn) {
-      int nb = 0;
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, fn, 256, 0) != hipSuccess) nb = 0;
-      (void)hipGetLastError();
-      return nb;
-    };
-    int cus = 0;
-    HIPCHK_CREATE(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, e->device));
-    e->slots_ac = cus * occ((const void*)k_ac_pers<false>);
-    e->slots_commit = cus * occ((const void*)k_ac_pers<true>);
-    if (cfg->kmax <= 4)
-      e->slots_propose = cus * occ((const void*)k_propose_pers<4>), e->slots_runs = cus * std::min(occ((const void*)k_ar_runs<4, true>), occ((const void*)k_ar_runs<4, true, true>));
-    else if (cfg->kmax <= 8)
-      e->slots_propose = cus * occ((const void*)k_propose_pers<8>), e->slots_runs = cus * std::min(occ((const void*)k_ar_runs<8, true>), occ((const void*)k_ar_runs<8, true, true>));
-    else
-      e->slots_propose = cus * occ((const void*)k_propose_pers<16>), e->slots_runs = cus * std::min(occ((const void*)k_ar_runs<16, true>), occ((const void*)k_ar_runs<16, true, true>));
-    e->xchg_slots = std::min({e->slots_ac, e->slots_commit, e->slots_propose, e->slots_runs});
-    if (const char* sv = getenv("GPX_XCHG_SLOTS")) /* test switch: 0 = never exchange */
-      e->xchg_slots = e->slots_ac = e->slots_commit = e->slots_propose = e->slots_runs = std::max(0, atoi(sv));
+  {
+    HIPCHK_CREATE(hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, e->device));
+    if (const char* sv = getenv("GPX_XCHG_SLOTS")) e->one_launch = atoi(sv) != 0; /* test switch: 0 = the two-launch forms */
     if (const char* sh = getenv("GPX_DEVICE_SHARERS")) e->sharers = std::max(1, atoi(sh));
     HIPCHK_CREATE(hipHostMalloc((void**)&e->h_abort, 64, hipHostMallocMapped));
     *e->h_abort = 0;
@@ -1175,16 +1153,15 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     if (!e->runs_arrive &&
         (rc = dev_alloc(e, &e->runs_arrive,
                         /* k_runs_check: one workgroup per 4,096 records; k_ar_runs<.., SMALL>: its end-of-kernel counters */
-                        std::max<size_t>(32 * (2 + N / ((size_t)GPX_OC_BLOCK * GPX_RC_ITEMS) / 16 + 1), GPX_RUNS_ARRIVE_WORDS),
+                        (size_t)32 * (3 + N / GPX_RBLOCK / 16 + 1),
                         true)) != GPX_OK)
       return rc;
-    /* ONE launch at any size: resident workgroups loop over the chunks, judge them and exchange the verdict once - if
-     * this engine's share of the device holds a grid worth looping with (xchg_grid); else the check kernel and the
-     * work kernel */
+    /* ONE launch at any size: the first workgroups to start judge the column among themselves and meet once
+     * (gpx_one.hip.h); GPX_XCHG_SLOTS=0: the check kernel and the work kernel */
     const int nch = (n + GPX_RBLOCK - 1) / GPX_RBLOCK;
-    const int pg = std::min(xchg_grid(e, nch, e->slots_runs), 4096);
-    const bool small = pg > 0;
-    const GridXchg Q = small ? grid_ctl(e, pg) : GridXchg{};
+    const bool small = e->one_launch;
+    int pg = nch;
+    const GridXchg Q = small ? xchg_ctl(e, nch, &pg) : GridXchg{};
     if (!small)
       LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
                 gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
@@ -1290,8 +1267,9 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
      * exchange the verdict among themselves (k_ac_one<.., XCHG>); without lazy outputs k_ac_small's in-kernel run
      * compaction is the one launch */
     const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
-    if (const int pg = xchg_grid(e, nch, e->slots_ac)) { /* ONE launch: resident workgroups, the verdict exchanged among them */
-      const GridXchg Q = grid_ctl(e, pg);
+    if (e->one_launch) { /* ONE launch: the first workgroups to start judge the batch among themselves (gpx_one.hip.h) */
+      int pg;
+      const GridXchg Q = xchg_ctl(e, nch, &pg);
       LaunchScope _ls(e, "k_ac_pers");
       hipLaunchKernelGGL(k_ac_pers<false>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, nch, gidx, bnum, bcoord, slot,
                          median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, n_runs, 0);
@@ -1408,8 +1386,9 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   e->last.kind = 0;
   if (promised && (!fused || lazy_outputs(e))) { /* check + one work kernel (gpx_one.hip.h), like the ACCEPT call */
     const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
-    if (const int pg = xchg_grid(e, nch, e->slots_commit)) {
-      const GridXchg Q = grid_ctl(e, pg);
+    if (e->one_launch) {
+      int pg;
+      const GridXchg Q = xchg_ctl(e, nch, &pg);
       LaunchScope _ls(e, "k_ac_pers");
       hipLaunchKernelGGL(k_ac_pers<true>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, nch, gidx, bnum, bcoord, slot,
                          median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, status, D,
@@ -1548,9 +1527,9 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   if (promised) { /* (gpx_one.hip.h) */
     e->stream = e->sB;
     const int nch = grid_for(n);
-    if (const int pg = xchg_grid(e, nch, e->slots_propose)) {
-      /* ONE launch: resident workgroups loop over the chunks, judge them, exchange the verdict once, apply */
-      const GridXchg Q = grid_ctl(e, pg);
+    if (e->one_launch) { /* ONE launch: the first workgroups to start judge the batch among themselves, everybody applies */
+      int pg;
+      const GridXchg Q = xchg_ctl(e, nch, &pg);
       if (e->cfg.kmax <= 4)
         LAUNCH(e, "k_propose_pers", k_propose_pers<4>, pg, e->S, e->X, Q, n, nch, gidx, is_stop, slot, bnum, bcoord, median_cp,
                status, handle);

@@ -171,11 +171,11 @@ struct DevScratch {
                                  * others' tickets (xchg_wait): the engine refuses every later call */
 };
 
-/* Workgroups that wait for each other (one_exchange, k_ar_runs<.., SMALL>) only make progress when the whole grid
- * is resident.  The host sizes those grids from the occupancy of the kernel and the number of engines on the device
- * (xchg_grid_limit in gpx_engine.hip) - this is the backstop for what the host cannot see (another process holding
- * the CUs): a waiter gives up after about two seconds of the 100 MHz wall clock, leaves the call's epoch in the
- * host-mapped word and the caller applies NOTHING of its records.  A hang becomes GPX_EDEVICE on the next call. */
+/* Workgroups that wait for each other (grid_exchange, gpx_one.hip.h) wait only for workgroups that have started (or,
+ * in a small grid, for a grid the host knows to be resident: xchg_ctl in gpx_engine.hip).  This is the backstop for
+ * what neither covers - a wedged device, another process holding every CU while a small grid starts: a waiter gives up
+ * after about two seconds of the 100 MHz wall clock, leaves the call's epoch in the host-mapped word and the caller
+ * applies NOTHING of its records.  A hang becomes GPX_EDEVICE on the next call. */
 #define GPX_XCHG_TIMEOUT_TICKS 200000000ull
 struct XchgWait {
   uint32_t spins = 0;

@@ -312,18 +312,16 @@ struct RunsIter {
  * four waves per SIMD, each a chain of three dependent load waves - and the kernel took 87 us per 3 M votes */
 #define GPX_RBLOCK 256
 
-/* SMALL = the call in ONE launch (round 4: at most 65,536 votes, every workgroup judging its own 256 records and all of
- * them - at most 256, resident together - exchanging the verdict through tickets; round 5: ANY size - the grid is what
- * the device holds at once (gpx_engine.hip: xchg_grid), workgroup w takes chunks w, w + grid, ..., judges all of them
- * first - in range; a descent = a run start, appended to info->start as k_runs_check does - raises *X.unsorted for a
- * batch that is no few runs in range, and meets the others ONCE at grid_exchange's arrival counters (gpx_one.hip.h);
- * then every workgroup reads the same verdict and the same run starts and replays its chunks).  No k_runs_check launch;
- * the lane that replays a vote marks its status (no prefill pass), nothing is counted per chunk, and the LAST workgroup
- * to finish (two levels of arrival counters, 16 workgroups per counter, a cache line apart) publishes the count - or -1
- * for a batch that needs the compaction pass - and leaves the run starts in `info` for that pass.
- * !SMALL: the grid has one workgroup per chunk and k_runs_check has run before (the form for a device shared by many
- * engines, where a resident grid cannot be counted on). */
-#define GPX_RUNS_ARRIVE_WORDS (32 * (2 + 4096 / 16)) /* end-of-kernel arrival counters: up to 4,096 workgroups, 16 per counter */
+/* SMALL = the call in ONE launch at any size (round 4: at most 65,536 votes, every workgroup judging its own 256
+ * records and all of them - at most 256, which had to be resident together - exchanging the verdict through tickets;
+ * round 5: the first workgroups to start judge the whole column among themselves and meet once at grid_exchange's
+ * arrival counters - gpx_one.hip.h: no assumption about residency): in range; a descent = a run start, appended to
+ * info->start as k_runs_check does; anything else raises *X.unsorted.  Then every workgroup reads the same verdict and
+ * the same run starts and replays its chunk.  No k_runs_check launch; the lane that replays a vote marks its status (no
+ * prefill pass), nothing is counted per chunk, and the LAST workgroup to finish (two levels of arrival counters, 16
+ * workgroups per counter, a cache line apart) publishes the count - or -1 for a batch that needs the compaction pass -
+ * and leaves the run starts in `info` for that pass.
+ * !SMALL: k_runs_check has run before (kept for comparison builds: GPX_XCHG_SLOTS=0). */
 template <int KMAX, bool SMALL = false, bool EARLY = false>
 __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X, int32_t n,
                                                        const int32_t* __restrict__ gidx,
@@ -339,8 +337,7 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
                                                        GridXchg Q, int32_t nchunks) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
   __shared__ int32_t wsum[GPX_RBLOCK / 64];
-  int32_t c = (int32_t)blockIdx.x;
-  int32_t i = c * GPX_RBLOCK + (int32_t)threadIdx.x;
+  const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
   int32_t R;
   CoordPre<KMAX> P;
   bool have_p = false;
@@ -348,11 +345,11 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
   if (SMALL) SAR_STAMP(blockIdx.x, 0);
 #endif
   if (SMALL) {
-    /* the state of the first chunk's groups is REQUESTED before the verdict is exchanged (as k_ac_pers does): round 4's
-     * exchange was 10 of the small kernel's 11.5 us because nothing else was in flight behind it (profiles/
-     * r04_sar_trace_6_tiny.txt).  Every lane asks for the state of its own record's group - the lanes of run 0 will
-     * own those groups, the others have asked in vain (their lines are in L2 for the owner) */
-    if (EARLY && i < n) { /* (EARLY: the small calls' build - holding the state across the exchange costs 30 VGPRs) */
+    /* EARLY (the small calls' build): the state of this chunk's groups is REQUESTED before the verdict is exchanged (as
+     * k_ac_pers does): round 4's exchange was 10 of the small kernel's 11.5 us because nothing else was in flight
+     * behind it (profiles/r04_sar_trace_6_tiny.txt).  Every lane asks for the state of its own record's group - the
+     * lanes of run 0 will own those groups, the others have asked in vain (their lines are in L2 for the owner) */
+    if (EARLY && i < n) {
       const int32_t g0 = gidx[i];
       if ((uint32_t)g0 < (uint32_t)S.G) {
         coord_preload<KMAX>(S, g0, P);
@@ -361,40 +358,39 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       }
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(RunsInfo) / 4)) ((int32_t*)next_info)[threadIdx.x] = 0;
-    bool wg_bad = false;
-    for (int32_t c2 = c; c2 < nchunks; c2 += (int32_t)gridDim.x) { /* (uniform per workgroup: barriers inside) */
-      const int32_t j = c2 * GPX_RBLOCK + (int32_t)threadIdx.x;
-      bool bad = false, desc = false;
-      if (j < n) {
-        const int32_t gi = gidx[j];
-        const int32_t gp = j > 0 ? gidx[j - 1] : INT32_MIN;
-        bad = (uint32_t)gi >= (uint32_t)S.G;
-        desc = gp > gi;
+    const int32_t role = grid_role(Q);
+    if (role >= 0) {
+      bool wg_bad = false;
+      for (int32_t c2 = role; c2 < nchunks && !wg_bad; c2 += Q.judges) { /* (uniform per workgroup: barriers inside) */
+        const int32_t j = c2 * GPX_RBLOCK + (int32_t)threadIdx.x;
+        bool bad = false, desc = false;
+        if (j < n) {
+          const int32_t gi = gidx[j];
+          const int32_t gp = j > 0 ? gidx[j - 1] : INT32_MIN;
+          bad = (uint32_t)gi >= (uint32_t)S.G;
+          desc = gp > gi;
+        }
+        const int32_t nd_wg = __syncthreads_count(desc);
+        bad = __syncthreads_or(bad) || nd_wg > GPX_RUNS_MAX - 1;
+        if (!bad && desc) {
+          const int32_t k = atomicAdd(&info->n_desc, 1);
+          if (k < GPX_RUNS_MAX - 1)
+            __hip_atomic_store(&info->start[k + 1], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          else
+            bad = true;
+        }
+        wg_bad = __syncthreads_or(bad) != 0;
       }
-      const int32_t nd_wg = __syncthreads_count(desc);
-      bad = __syncthreads_or(bad) || nd_wg > GPX_RUNS_MAX - 1;
-      if (!bad && desc) {
-        const int32_t k = atomicAdd(&info->n_desc, 1);
-        if (k < GPX_RUNS_MAX - 1)
-          __hip_atomic_store(&info->start[k + 1], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
-          bad = true;
-      }
-      wg_bad |= __syncthreads_or(bad) != 0;
-      if (wg_bad) break; /* (uniform) */
+      if (wg_bad && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
     }
-    if (wg_bad && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
-    /* (grid_exchange's first barrier orders this workgroup's run starts and its verdict before its arrival) */
-    if (grid_exchange(X, Q, ONE_NONE, nullptr, 0) == 0u && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch); /* gave up: apply nothing */
+    /* (grid_exchange's first barrier orders this judge's run starts and its verdict before its arrival) */
+    if (grid_exchange(X, Q, role, ONE_NONE, nullptr, 0) == 0u && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch); /* gave up: apply nothing */
     __syncthreads();
     if (__hip_atomic_load(X.unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X.epoch) {
       /* not a few ascending runs in range: refused whole under the promise, else the partition pipeline (or the
        * one-launch kernel of small calls) launched behind takes the batch */
       if (refuse) {
-        for (; c < nchunks; c += (int32_t)gridDim.x) {
-          i = c * GPX_RBLOCK + (int32_t)threadIdx.x;
-          if (i < n && status) status[i] = GPX_S_UNORDERED;
-        }
+        if (i < n && status) status[i] = GPX_S_UNORDERED;
         if (blockIdx.x == 0 && threadIdx.x == 0 && n_out) *n_out = 0;
       }
       return;
@@ -416,7 +412,6 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
   const int32_t my_chunk = (int32_t)(((int64_t)blockIdx.x * GPX_RBLOCK) >> GPX_DCHUNK_SHIFT); /* (!SMALL: the only chunk) */
   int32_t local = 0;
   bool irregular = false; /* this lane saw why the columns are not dense as parked (travels with the arrival counters) */
-  for (;; have_p = false) {
   const bool active = i < n;
   const int32_t g = active ? gidx[i] : 0;
   int32_t r = 0;
@@ -533,11 +528,6 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       apply_ar_group<KMAX>(S, X, g, it, status, P);
       local += it.local;
     }
-  }
-  if (!SMALL) break;
-  c += (int32_t)gridDim.x;
-  if (c >= nchunks) break;
-  i = c * GPX_RBLOCK + (int32_t)threadIdx.x;
   }
   /* this workgroup's own parked outputs: one atomic per workgroup */
   int32_t x = local;
