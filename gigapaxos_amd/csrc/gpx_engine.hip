@@ -156,7 +156,7 @@ struct gpx_engine {
    * writes (DevScratch.xabort) */
   int cus = 0, sharers = 1;
   bool one_launch = true;            /* GPX_XCHG_SLOTS=0 (comparison builds, tests): the check kernel + the work kernel instead */
-  uint32_t gx_arrive = 0, gx_draw = 0; /* grid_exchange's arrival / ticket counters as this engine's launches have left them */
+  uint32_t gx_arrive = 0; /* grid_exchange's arrival counters as this engine's launches have left them */
   bool registered_live = false;
   uint32_t* h_abort = nullptr;
   /* host blocks handed out by gpx_host_alloc (hipHostMalloc): freed by gpx_host_free or at destroy */
@@ -462,26 +462,21 @@ int xchg_share(const gpx_engine* e) { /* engines (x processes) that may have an 
   }
   return live * e->sharers;
 }
-/* The control block of ONE-launch call over `nchunks` chunks (gpx_one.hip.h): the grid (a multiple of 16: every counter
- * line gets the same number of tickets and arrivals), who judges, and what the cumulative counters read afterwards.
- * A grid of at most 2 workgroups per CU and stream is resident whatever the kernel: no tickets, every workgroup judges
- * its own chunk; anything larger draws tickets and its first GPX_GX_JUDGES workgroups to start judge the batch. */
-GridXchg xchg_ctl(gpx_engine* e, int nchunks, int* grid) {
-  const OneCtl C = one_ctl(e);
-  GridXchg Q;
+/* May a call over `nchunks` chunks of 256 records take the ONE-launch form (gpx_one.hip.h)?  Only with a grid that is
+ * resident whatever the kernel and whoever else is launching: at most 2 workgroups per CU, divided by the streams the
+ * device's engines launch on and the processes sharing it.  Then: the grid (a multiple of 16: every counter line gets
+ * the same number of arrivals) and what the cumulative arrival counters read afterwards. */
+bool xchg_ctl(gpx_engine* e, int nchunks, GridXchg* Q, int* grid) {
   const int g16 = (std::max(nchunks, 1) + GPX_GX_LINES - 1) / GPX_GX_LINES * GPX_GX_LINES;
+  if (!e->one_launch || (int64_t)g16 * xchg_share(e) > (int64_t)2 * e->cus) return false;
+  const OneCtl C = one_ctl(e);
   *grid = g16;
-  Q.arrive = (uint32_t*)(e->one_words + GPX_ONE_TICKETS);
-  Q.draw = Q.arrive + GPX_GX_LINES * 32;
-  Q.verdict = C.verdict;
-  Q.epoch = C.epoch;
-  Q.tickets = (int64_t)g16 * xchg_share(e) <= (int64_t)2 * e->cus ? 0 : 1;
-  Q.judges = Q.tickets ? std::min(GPX_GX_JUDGES, g16) : g16;
-  Q.draw_base = e->gx_draw;
-  if (Q.tickets) e->gx_draw += (uint32_t)(g16 / GPX_GX_LINES);
-  e->gx_arrive += (uint32_t)(Q.judges / GPX_GX_LINES);
-  Q.arrive_target = e->gx_arrive;
-  return Q;
+  Q->arrive = (uint32_t*)(e->one_words + GPX_ONE_TICKETS);
+  Q->verdict = C.verdict;
+  Q->epoch = C.epoch;
+  e->gx_arrive += (uint32_t)(g16 / GPX_GX_LINES);
+  Q->arrive_target = e->gx_arrive;
+  return true;
 }
 
 template <int KMAX>
@@ -751,7 +746,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   A(X.o_rec, N, false);
   A(X.bucket_nout, nbk_alloc, true);
   A(e->rec_tag, N, true);
-  A(e->one_words, GPX_ONE_TICKETS + 2 * GPX_GX_LINES * 16, true); /* the verdict word, then grid_exchange's arrival and ticket counters (a 128-byte line each) */
+  A(e->one_words, GPX_ONE_TICKETS + GPX_GX_LINES * 16, true); /* the verdict word, then grid_exchange's arrival counters (a 128-byte line each) */
   A(X.counters, 3, true);
   for (int i = 0; i < 12; i++) A(e->st_i32[i], N, false);
   for (int i = 0; i < 4; i++) A(e->st_u8[i], N, false);
@@ -1156,12 +1151,12 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
                         (size_t)32 * (3 + N / GPX_RBLOCK / 16 + 1),
                         true)) != GPX_OK)
       return rc;
-    /* ONE launch at any size: the first workgroups to start judge the column among themselves and meet once
-     * (gpx_one.hip.h); GPX_XCHG_SLOTS=0: the check kernel and the work kernel */
+    /* ONE launch where the grid is resident for sure (xchg_ctl): every workgroup judges its own records and all of them
+     * meet once (gpx_one.hip.h); else the check kernel and the work kernel */
     const int nch = (n + GPX_RBLOCK - 1) / GPX_RBLOCK;
-    const bool small = e->one_launch;
     int pg = nch;
-    const GridXchg Q = small ? xchg_ctl(e, nch, &pg) : GridXchg{};
+    GridXchg Q{};
+    const bool small = xchg_ctl(e, nch, &Q, &pg);
     if (!small)
       LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
                 gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
@@ -1177,15 +1172,15 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     if (small && n <= 65536) /* a chain of round trips, not bytes: the first chunk's state requested before the exchange */ \
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ar_runs<KM, true, true>), grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, \
                          bnum, bcoord, slot, acceptor, max_cp, status, st, info, refuse, n_out, next_info, e->runs_arrive,  \
-                         &e->X.counters[1], Q, nch);                                                                        \
+                         &e->X.counters[1], Q);                                                                             \
     else if (small)                                                                                                         \
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ar_runs<KM, true>), grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, \
                          bcoord, slot, acceptor, max_cp, status, st, info, refuse, n_out, next_info, e->runs_arrive,        \
-                         &e->X.counters[1], Q, nch);                                                                        \
+                         &e->X.counters[1], Q);                                                                             \
     else                                                                                                                    \
       hipLaunchKernelGGL(HIP_KERNEL_NAME(k_ar_runs<KM, false>), grid, dim3(GPX_RBLOCK), 0, e->stream, e->S, e->X, n, gidx, bnum, \
                          bcoord, slot, acceptor, max_cp, status, st, info, refuse, n_out, (RunsInfo*)nullptr,               \
-                         (uint32_t*)nullptr, (unsigned long long*)nullptr, Q, nch);                                         \
+                         (uint32_t*)nullptr, (unsigned long long*)nullptr, Q);                                              \
   } while (0)
       if (e->cfg.kmax <= 4)
         GPX_LAUNCH_AR_RUNS(4);
@@ -1267,11 +1262,11 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
      * exchange the verdict among themselves (k_ac_one<.., XCHG>); without lazy outputs k_ac_small's in-kernel run
      * compaction is the one launch */
     const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
-    if (e->one_launch) { /* ONE launch: the first workgroups to start judge the batch among themselves (gpx_one.hip.h) */
-      int pg;
-      const GridXchg Q = xchg_ctl(e, nch, &pg);
+    GridXchg Q;
+    int pg;
+    if (xchg_ctl(e, nch, &Q, &pg)) { /* ONE launch: a grid that is resident for sure, the verdict exchanged among its workgroups */
       LaunchScope _ls(e, "k_ac_pers");
-      hipLaunchKernelGGL(k_ac_pers<false>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, nch, gidx, bnum, bcoord, slot,
+      hipLaunchKernelGGL(k_ac_pers<false>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, gidx, bnum, bcoord, slot,
                          median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, n_runs, 0);
     } else {
       const OneCtl C = one_ctl(e);
@@ -1386,11 +1381,11 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   e->last.kind = 0;
   if (promised && (!fused || lazy_outputs(e))) { /* check + one work kernel (gpx_one.hip.h), like the ACCEPT call */
     const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
-    if (e->one_launch) {
-      int pg;
-      const GridXchg Q = xchg_ctl(e, nch, &pg);
+    GridXchg Q;
+    int pg;
+    if (xchg_ctl(e, nch, &Q, &pg)) {
       LaunchScope _ls(e, "k_ac_pers");
-      hipLaunchKernelGGL(k_ac_pers<true>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, nch, gidx, bnum, bcoord, slot,
+      hipLaunchKernelGGL(k_ac_pers<true>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, gidx, bnum, bcoord, slot,
                          median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, status, D,
                          n_runs, n);
     } else {
@@ -1527,17 +1522,17 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
   if (promised) { /* (gpx_one.hip.h) */
     e->stream = e->sB;
     const int nch = grid_for(n);
-    if (e->one_launch) { /* ONE launch: the first workgroups to start judge the batch among themselves, everybody applies */
-      int pg;
-      const GridXchg Q = xchg_ctl(e, nch, &pg);
+    GridXchg Q;
+    int pg;
+    if (xchg_ctl(e, nch, &Q, &pg)) { /* ONE launch: a grid that is resident for sure, the verdict exchanged among its workgroups */
       if (e->cfg.kmax <= 4)
-        LAUNCH(e, "k_propose_pers", k_propose_pers<4>, pg, e->S, e->X, Q, n, nch, gidx, is_stop, slot, bnum, bcoord, median_cp,
+        LAUNCH(e, "k_propose_pers", k_propose_pers<4>, pg, e->S, e->X, Q, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
                status, handle);
       else if (e->cfg.kmax <= 8)
-        LAUNCH(e, "k_propose_pers", k_propose_pers<8>, pg, e->S, e->X, Q, n, nch, gidx, is_stop, slot, bnum, bcoord, median_cp,
+        LAUNCH(e, "k_propose_pers", k_propose_pers<8>, pg, e->S, e->X, Q, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
                status, handle);
       else
-        LAUNCH(e, "k_propose_pers", k_propose_pers<16>, pg, e->S, e->X, Q, n, nch, gidx, is_stop, slot, bnum, bcoord, median_cp,
+        LAUNCH(e, "k_propose_pers", k_propose_pers<16>, pg, e->S, e->X, Q, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
                status, handle);
     } else { /* the verdict, then the application without a status prefill pass */
       const OneCtl C = one_ctl(e);

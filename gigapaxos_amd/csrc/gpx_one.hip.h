@@ -187,77 +187,57 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
   }
 }
 
-/* ---- ONE launch at any size (round 5) -----------------------------------------------------------------------------
- * Round 4's one-launch form (every workgroup judges its own 256 records and all of them exchange the verdict) stopped
- * at 256 workgroups and NEEDED them all resident; beyond it the verdict took a launch of its own, 6-8 us of every
- * ordered call by the event profile - 56 us of a whole round's 260.  Round 5's first form - a grid as large as the
- * device holds, workgroups looping over chunks - hung on the first full-size launch: hipOccupancyMaxActiveBlocks
- * PerMultiprocessor promises more workgroups than become resident (its give-up backstop turned that into an error
- * after two seconds, profiles/r05_pers_loop_gave_up.txt).  This form assumes NOTHING about residency:
- *   roles     the grid has one workgroup per chunk (hardware-scheduled, no loop in the work).  The first JUDGES
- *             workgroups TO START judge the order of the whole batch among themselves - judge j takes chunks j,
- *             j + JUDGES, ...: gidx with the predecessors - and meet ONCE: a violation goes to the verdict word with an
- *             atomicMax (rare), the arrival to one of GPX_GX_LINES counters 128 bytes apart (device-scope atomics on
- *             one line are serial at ~16 ns each).  "First to start" is a ticket drawn from one of sixteen counters
- *             (line = blockIdx % 16): a judge only ever waits for judges, which have all started - whatever the
- *             dispatch order, whatever else holds the CUs.  Every workgroup - judge or not - polls the sixteen arrival
- *             counters (sixteen lanes) before it applies anything; one that starts late finds them complete.
- *   own work  requested before any of that: the record's columns, the neighbours, the group's state (as k_ac_one).
- *   small     a grid of at most 2 x CUs / streams workgroups (gpx_engine.hip: xchg_ctl) is resident whatever the
- *             kernel: every workgroup judges its own chunk, no ticket (a returning atomic is a round trip a 10,000-
- *             record call would feel: BASELINE config #2).
- * The counters are never reset - every line gets the same number of tickets and arrivals per launch (the grid is
- * padded to a multiple of sixteen), so the host passes each launch two scalars. */
+/* ---- ONE launch up to 2 workgroups per CU (round 5) ---------------------------------------------------------------
+ * Round 4's one-launch form (every workgroup judges its own 256 records and all of them exchange the verdict through
+ * 256 tickets) NEEDED its workgroups resident together and nothing enforced it.  Now the host launches this form only
+ * with a grid that is resident whatever the kernel - at most 2 workgroups per CU, divided by the streams the device's
+ * engines launch on and the processes sharing it (gpx_engine.hip: xchg_ctl): 512 workgroups = 131,072 records for one
+ * engine on an MI355X - and the exchange is sixteen arrival counters 128 bytes apart instead of a ticket per
+ * workgroup (device-scope atomics on one line are serial at ~16 ns each: 32 arrivals per line), polled by sixteen
+ * lanes.  The counters are never reset: the grid is padded to a multiple of sixteen, every line gets the same number of
+ * arrivals per launch, the host passes the value they reach.  Everything that crosses workgroups here is a device-
+ * scope atomic (verdict word, arrivals, the count word); the arrival is ordered behind the verdict by a workgroup
+ * fence (a wait for the wave's outstanding memory operations - no L2 write-back), the polls are relaxed and ONE
+ * acquire fence follows the last of them (an acquire per iteration invalidates the caches every time round).
+ * Larger batches keep the check kernel + the work kernel.  Two one-launch forms for them were built this round and
+ * measured (DESIGN.md 3 ii-c): resident workgroups LOOPING over chunks - the grid hipOccupancyMaxActiveBlocksPer
+ * Multiprocessor promises does not all become resident: the waiters gave up after two seconds (profiles/
+ * r05_pers_loop_gave_up.txt); one workgroup per chunk with the first 512 TO START (a ticket each, sixteen counters) as
+ * judges and everybody polling the arrivals - correct at every size (all parity tests), no assumption about residency,
+ * and 5-7 x slower: 166 us against 7 + 16 for a 1 M-record proposal call, 138 against 6 + 28 for an ACCEPT call
+ * (profiles/r05_ticket_roles_one_launch.txt) - thousands of workgroups on sixteen lines. */
 #define GPX_GX_LINES 16
-#define GPX_GX_JUDGES 512 /* judges of a ticketed launch (a multiple of GPX_GX_LINES) */
 struct GridXchg {
   uint32_t* arrive;            /* [GPX_GX_LINES * 32] arrival counters, one per 128-byte line, cumulative */
-  uint32_t* draw;              /* [GPX_GX_LINES * 32] ticket counters, likewise */
   unsigned long long* verdict; /* OneCtl's word: epoch << 32 | (ONE_NONE - first violating index) */
   uint32_t epoch;
-  uint32_t arrive_target;      /* every arrival counter's value once all judges of THIS launch have arrived */
-  uint32_t draw_base;          /* every ticket counter's value before this launch */
-  int32_t judges;              /* a multiple of GPX_GX_LINES */
-  int32_t tickets;             /* 0: the whole grid is resident for sure - workgroup w is judge w (judges == the grid) */
+  uint32_t arrive_target;      /* every arrival counter's value once all workgroups of THIS launch have arrived */
 };
-/* this workgroup's judge index, -1: not a judge.  Every thread must call it (a barrier). */
-__device__ __forceinline__ int32_t grid_role(const GridXchg& Q) {
-  if (!Q.tickets) return (int32_t)blockIdx.x;
-  __shared__ int32_t s_role;
-  if (threadIdx.x == 0) {
-    const uint32_t line = blockIdx.x % GPX_GX_LINES;
-    const uint32_t t = __hip_atomic_fetch_add(&Q.draw[line * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - Q.draw_base;
-    const int64_t j = (int64_t)t * GPX_GX_LINES + line;
-    s_role = j < Q.judges ? (int32_t)j : -1;
-  }
-  __syncthreads();
-  return s_role;
-}
-/* Every thread of every workgroup of the grid calls it once.  role: grid_role's answer; wg_bad: a judge's first
- * violation over its chunks, already reduced (ONE_NONE: none; thread 0's value counts).  Returns the batch's first
- * violation once every judge has arrived. */
-__device__ __forceinline__ uint32_t grid_exchange(const DevScratch& X, const GridXchg& Q, int32_t role, uint32_t wg_bad,
+/* Every thread of every workgroup of the grid calls it once.  wg_bad: this workgroup's first violation, already reduced
+ * (ONE_NONE: none; thread 0's value counts).  Returns the batch's first violation once every workgroup has arrived. */
+__device__ __forceinline__ uint32_t grid_exchange(const DevScratch& X, const GridXchg& Q, uint32_t wg_bad,
                                                   int32_t* __restrict__ count_out, int32_t regular_count) {
   __shared__ uint32_t s_first, s_gave_up;
   if (threadIdx.x == 0) {
     s_gave_up = 0;
-    if (role == 0 && count_out) *count_out = regular_count; /* before judge 0's arrival: a later -1 wins */
-    if (role >= 0) {
-      if (wg_bad != ONE_NONE)
-        atomicMax(Q.verdict, ((unsigned long long)Q.epoch << 32) | (unsigned long long)(ONE_NONE - wg_bad));
-      __hip_atomic_fetch_add(&Q.arrive[((uint32_t)role % GPX_GX_LINES) * 32], 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (blockIdx.x == 0 && count_out) /* before workgroup 0's arrival: a later -1 wins */
+      __hip_atomic_store(count_out, regular_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (wg_bad != ONE_NONE)
+      atomicMax(Q.verdict, ((unsigned long long)Q.epoch << 32) | (unsigned long long)(ONE_NONE - wg_bad));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the atomics above have been performed */
+    __hip_atomic_fetch_add(&Q.arrive[(blockIdx.x % GPX_GX_LINES) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads(); /* (s_gave_up cleared before a poller may raise it) */
   if (threadIdx.x < GPX_GX_LINES) {
     XchgWait w;
-    while ((int32_t)(__hip_atomic_load(&Q.arrive[threadIdx.x * 32], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) -
+    while ((int32_t)(__hip_atomic_load(&Q.arrive[threadIdx.x * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
                      Q.arrive_target) < 0) {
-      if (w.tired()) { /* a judge died or the device is wedged (gpx_kernels.hip.h: XchgWait) */
+      if (w.tired()) { /* a workgroup of the grid never became resident (gpx_kernels.hip.h: XchgWait) */
         s_gave_up = 1;
         break;
       }
     }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent"); /* ONE cache invalidate per workgroup, after the last poll */
   }
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -281,30 +261,9 @@ __device__ __forceinline__ uint32_t wg_first_bad(uint32_t mine) {
   }
   return s_bad;
 }
-/* a judge's share of the verdict: the first index of chunks role, role + judges, ... (BLOCK records each) that is out of
- * range or lower (STRICT: not higher) than its predecessor; own_chunk's answer is known already (`mine`) */
-template <bool STRICT, int BLOCK>
-__device__ __forceinline__ uint32_t judge_chunks(const GridXchg& Q, int32_t role, int32_t nchunks, int32_t n, int32_t G,
-                                                 const int32_t* __restrict__ gidx, int32_t own_chunk, uint32_t mine) {
-  uint32_t bad = ONE_NONE;
-  if (role < 0) return bad;
-  for (int32_t c2 = role; c2 < nchunks; c2 += Q.judges) {
-    if (c2 == own_chunk) {
-      bad = min(bad, mine);
-      continue;
-    }
-    const int32_t j = c2 * BLOCK + (int32_t)threadIdx.x;
-    if (j < n) {
-      const int32_t gj = gidx[j], gp = j > 0 ? gidx[j - 1] : INT32_MIN;
-      if ((uint32_t)gj >= (uint32_t)G || (STRICT ? gp >= gj : gp > gj)) bad = min(bad, (uint32_t)j);
-    }
-  }
-  return bad;
-}
-
 template <bool COMMIT>
 __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_pers(
-    DevState S, DevScratch X, GridXchg Q, int32_t n, int32_t nchunks, const int32_t* __restrict__ gidx,
+    DevState S, DevScratch X, GridXchg Q, int32_t n, const int32_t* __restrict__ gidx,
     const int32_t* __restrict__ bnum, const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
     const int32_t* __restrict__ median, const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum,
     int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
@@ -326,13 +285,11 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_pers(
     if (runstart && !oob) acc_preload(S, g, f_a, P);
     if (oob || (i > 0 && g_prev > g)) mine = (uint32_t)i;
   }
-  const int32_t role = grid_role(Q);
-  const uint32_t judged = judge_chunks<false, GPX_DBLOCK>(Q, role, nchunks, n, S.G, gidx, (int32_t)blockIdx.x, mine);
-  const uint32_t first_bad = grid_exchange(X, Q, role, wg_first_bad(judged), n_runs, regular_count);
+  const uint32_t first_bad = grid_exchange(X, Q, wg_first_bad(mine), n_runs, regular_count);
   const bool irregular = ac_one_apply<COMMIT>(S, X, n, i, first_bad, runstart, g, g_next, f_a, f_b, f_c, f_bnum, f_bcoord, P,
                                               gidx, bnum, bcoord, slot, median, flags, r_bnum, r_bcoord, r_maxcp, r_flags,
                                               status, D);
-  /* a usual batch is finished: judge 0 wrote its count.  Any workgroup that saw otherwise says so */
+  /* a usual batch is finished: workgroup 0 wrote its count.  Any workgroup that saw otherwise says so */
   if (__syncthreads_or(irregular) && threadIdx.x == 0) {
     __hip_atomic_store(D.mark, X.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); /* the compaction kernels have work */
     if (n_runs) __hip_atomic_store(n_runs, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -387,10 +344,10 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_one(
   }
   propose_one_apply<KMAX>(S, X, i, g, first_bad, is_stop, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
 }
-/* ... in ONE launch at any size (roles, tickets and the exchange: see k_ac_pers) */
+/* ... in ONE launch: a grid that is resident for sure, the verdict exchanged at grid_exchange's counters (k_ac_pers) */
 template <int KMAX>
 __global__ __launch_bounds__(GPX_BLOCK) void k_propose_pers(
-    DevState S, DevScratch X, GridXchg Q, int32_t n, int32_t nchunks, const int32_t* __restrict__ gidx,
+    DevState S, DevScratch X, GridXchg Q, int32_t n, const int32_t* __restrict__ gidx,
     const uint8_t* __restrict__ is_stop, int32_t* __restrict__ o_slot, int32_t* __restrict__ o_bnum,
     int32_t* __restrict__ o_bcoord, int32_t* __restrict__ o_median, uint8_t* __restrict__ status,
     const int64_t* __restrict__ handle) {
@@ -407,8 +364,6 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_pers(
     }
     if ((uint32_t)g >= (uint32_t)S.G || (i > 0 && g_prev >= g)) mine = (uint32_t)i; /* strictly ascending, in range */
   }
-  const int32_t role = grid_role(Q);
-  const uint32_t judged = judge_chunks<true, GPX_BLOCK>(Q, role, nchunks, n, S.G, gidx, (int32_t)blockIdx.x, mine);
-  const uint32_t first_bad = grid_exchange(X, Q, role, wg_first_bad(judged), nullptr, 0);
+  const uint32_t first_bad = grid_exchange(X, Q, wg_first_bad(mine), nullptr, 0);
   if (i < n) propose_one_apply<KMAX>(S, X, i, g, first_bad, is_stop, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
 }

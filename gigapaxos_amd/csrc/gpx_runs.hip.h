@@ -312,16 +312,16 @@ struct RunsIter {
  * four waves per SIMD, each a chain of three dependent load waves - and the kernel took 87 us per 3 M votes */
 #define GPX_RBLOCK 256
 
-/* SMALL = the call in ONE launch at any size (round 4: at most 65,536 votes, every workgroup judging its own 256
- * records and all of them - at most 256, which had to be resident together - exchanging the verdict through tickets;
- * round 5: the first workgroups to start judge the whole column among themselves and meet once at grid_exchange's
- * arrival counters - gpx_one.hip.h: no assumption about residency): in range; a descent = a run start, appended to
- * info->start as k_runs_check does; anything else raises *X.unsorted.  Then every workgroup reads the same verdict and
- * the same run starts and replays its chunk.  No k_runs_check launch; the lane that replays a vote marks its status (no
- * prefill pass), nothing is counted per chunk, and the LAST workgroup to finish (two levels of arrival counters, 16
- * workgroups per counter, a cache line apart) publishes the count - or -1 for a batch that needs the compaction pass -
- * and leaves the run starts in `info` for that pass.
- * !SMALL: k_runs_check has run before (kept for comparison builds: GPX_XCHG_SLOTS=0). */
+/* SMALL = the call in ONE launch (round 4: at most 65,536 votes, the workgroups exchanging the verdict through a ticket
+ * each; round 5: any grid the host knows to be resident - xchg_ctl, 131,072 votes for one engine on an MI355X - and
+ * grid_exchange's sixteen arrival counters, gpx_one.hip.h): every workgroup judges its own 256 records - in range; a
+ * descent = a run start, appended to info->start as k_runs_check does - raises *X.unsorted for a batch that is no few
+ * runs in range, and meets the others once; then every workgroup reads the same verdict and the same run starts.  The
+ * lane that replays a vote marks its status (no prefill pass), nothing is counted per chunk, and the LAST workgroup to
+ * finish (two levels of arrival counters, 16 workgroups per counter, a cache line apart) publishes the count - or -1
+ * for a batch that needs the compaction pass - and leaves the run starts in `info` for that pass.
+ * EARLY (calls of at most 65,536 votes): the lane's group state is requested before the exchange.
+ * !SMALL: k_runs_check has run before - larger batches, or a device shared by many streams. */
 template <int KMAX, bool SMALL = false, bool EARLY = false>
 __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X, int32_t n,
                                                        const int32_t* __restrict__ gidx,
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
                                                        RunsInfo* __restrict__ info, int32_t refuse,
                                                        int32_t* __restrict__ n_out, RunsInfo* __restrict__ next_info,
                                                        uint32_t* __restrict__ arrive, unsigned long long* __restrict__ acc,
-                                                       GridXchg Q, int32_t nchunks) {
+                                                       GridXchg Q) {
   __shared__ int32_t rs[GPX_RUNS_MAX + 2];
   __shared__ int32_t wsum[GPX_RBLOCK / 64];
   const int32_t i = (int32_t)blockIdx.x * GPX_RBLOCK + (int32_t)threadIdx.x;
@@ -358,33 +358,27 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       }
     }
     if (blockIdx.x == 0 && threadIdx.x < (int)(sizeof(RunsInfo) / 4)) ((int32_t*)next_info)[threadIdx.x] = 0;
-    const int32_t role = grid_role(Q);
-    if (role >= 0) {
-      bool wg_bad = false;
-      for (int32_t c2 = role; c2 < nchunks && !wg_bad; c2 += Q.judges) { /* (uniform per workgroup: barriers inside) */
-        const int32_t j = c2 * GPX_RBLOCK + (int32_t)threadIdx.x;
-        bool bad = false, desc = false;
-        if (j < n) {
-          const int32_t gi = gidx[j];
-          const int32_t gp = j > 0 ? gidx[j - 1] : INT32_MIN;
-          bad = (uint32_t)gi >= (uint32_t)S.G;
-          desc = gp > gi;
-        }
-        const int32_t nd_wg = __syncthreads_count(desc);
-        bad = __syncthreads_or(bad) || nd_wg > GPX_RUNS_MAX - 1;
-        if (!bad && desc) {
-          const int32_t k = atomicAdd(&info->n_desc, 1);
-          if (k < GPX_RUNS_MAX - 1)
-            __hip_atomic_store(&info->start[k + 1], j, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          else
-            bad = true;
-        }
-        wg_bad = __syncthreads_or(bad) != 0;
+    {
+      bool bad = false, desc = false;
+      if (i < n) {
+        const int32_t gi = gidx[i];
+        const int32_t gp = i > 0 ? gidx[i - 1] : INT32_MIN;
+        bad = (uint32_t)gi >= (uint32_t)S.G;
+        desc = gp > gi;
       }
-      if (wg_bad && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
+      const int32_t nd_wg = __syncthreads_count(desc);
+      bad = __syncthreads_or(bad) || nd_wg > GPX_RUNS_MAX - 1;
+      if (!bad && desc) {
+        const int32_t k = atomicAdd(&info->n_desc, 1);
+        if (k < GPX_RUNS_MAX - 1)
+          __hip_atomic_store(&info->start[k + 1], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else
+          bad = true;
+      }
+      if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
     }
-    /* (grid_exchange's first barrier orders this judge's run starts and its verdict before its arrival) */
-    if (grid_exchange(X, Q, role, ONE_NONE, nullptr, 0) == 0u && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch); /* gave up: apply nothing */
+    /* (the barrier above and grid_exchange's fence order this workgroup's run starts and verdict before its arrival) */
+    if (grid_exchange(X, Q, ONE_NONE, nullptr, 0) == 0u && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch); /* gave up: apply nothing */
     __syncthreads();
     if (__hip_atomic_load(X.unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X.epoch) {
       /* not a few ascending runs in range: refused whole under the promise, else the partition pipeline (or the

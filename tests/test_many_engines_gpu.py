@@ -1,12 +1,12 @@
-"""Eight engines on ONE device, each driven from its own host thread through the device-pointer calls, every batch an
-ordered one of at most 65,536 records under the promises with GPX_LAZY_OUTPUTS - the shape that takes the one-launch
-exchange kernels (k_propose_pers, k_ac_pers, k_ar_runs<.., SMALL>), whose workgroups wait for each
-other's tickets and therefore must all be resident.  VERDICT r4 weak #7 / ADVICE r4 medium: nothing used to bound how
-many such grids meet on a device.  Now the library counts the live engines of a device and sizes the grids it allows
-from the kernels' occupancy (gpx_engine.hip: xchg_ok); with eight engines alive a batch of about 40,000 records is
-the largest that still takes one launch, larger ones take the two-launch form.  The test must FINISH (a partly
-resident grid waiting for workgroups that cannot start is a hang, not a slowdown) and every engine must give the
-oracle's answers."""
+"""Eight engines on ONE device, each driven from its own host thread through the device-pointer calls on its own stream,
+every batch an ordered one of at most 65,536 records under the promises with GPX_LAZY_OUTPUTS - the shape that takes the
+one-launch kernels (k_propose_pers, k_ac_pers, k_ar_runs<.., SMALL>), whose workgroups wait for each other at
+grid_exchange's counters and therefore must all be resident.  VERDICT r4 weak #7 / ADVICE r4 medium: nothing used to
+bound how many such grids meet on a device.  Now the library counts the streams the live engines of a device launch on
+and takes the one-launch form only with a grid of at most 2 workgroups per CU and stream (gpx_engine.hip: xchg_ctl):
+with sixteen streams alive here that is 32 workgroups = 8,192 records, larger batches take the check kernel + the work
+kernel.  The test must FINISH (a partly resident grid waiting for workgroups that cannot start would be a hang - or,
+with the kernels' own two-second backstop, GPX_EDEVICE) and every engine must give the oracle's answers."""
 import threading
 
 import numpy as np
@@ -107,7 +107,7 @@ def _drive(hip_lib, oracle_lib, G, rounds, seed, out, idx):
 
 
 def test_eight_engines_small_ordered_batches_from_their_own_threads(hip_lib, oracle_lib):
-    sizes = [13_000, 21_000, 40_000, 65_000, 9_000, 30_000, 50_000, 17_000]  # records per ordered batch (votes: three times)
+    sizes = [13_000, 2_500, 40_000, 65_000, 7_000, 30_000, 5_000, 17_000]  # records per ordered batch (votes: three times)
     out = [None] * len(sizes)
     # all eight engines exist before any of them works: the grids allowed are those of a device shared by eight
     start = threading.Barrier(len(sizes))
