@@ -196,9 +196,10 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
  * workgroup (device-scope atomics on one line are serial at ~16 ns each: 32 arrivals per line), polled by sixteen
  * lanes.  The counters are never reset: the grid is padded to a multiple of sixteen, every line gets the same number of
  * arrivals per launch, the host passes the value they reach.  Everything that crosses workgroups here is a device-
- * scope atomic (verdict word, arrivals, the count word); the arrival is ordered behind the verdict by a workgroup
- * fence (a wait for the wave's outstanding memory operations - no L2 write-back), the polls are relaxed and ONE
- * acquire fence follows the last of them (an acquire per iteration invalidates the caches every time round).
+ * scope atomic (verdict word, arrivals, the count word); what must be performed before the arrival is a RETURNING
+ * atomic whose result the arriving lane holds (no fence: a fence would also wait for the state preloads in flight),
+ * the polls are relaxed and ONE acquire fence follows the last of them (an acquire per iteration invalidates the
+ * caches every time round).
  * Larger batches keep the check kernel + the work kernel.  Two one-launch forms for them were built this round and
  * measured (DESIGN.md 3 ii-c): resident workgroups LOOPING over chunks - the grid hipOccupancyMaxActiveBlocksPer
  * Multiprocessor promises does not all become resident: the waiters gave up after two seconds (profiles/
@@ -213,18 +214,28 @@ struct GridXchg {
   uint32_t epoch;
   uint32_t arrive_target;      /* every arrival counter's value once all workgroups of THIS launch have arrived */
 };
-/* Every thread of every workgroup of the grid calls it once.  wg_bad: this workgroup's first violation, already reduced
- * (ONE_NONE: none; thread 0's value counts).  Returns the batch's first violation once every workgroup has arrived. */
-__device__ __forceinline__ uint32_t grid_exchange(const DevScratch& X, const GridXchg& Q, uint32_t wg_bad,
-                                                  int32_t* __restrict__ count_out, int32_t regular_count) {
+/* First thing in the kernel: workgroup 0 writes the REGULAR batch's count (a device-scope atomic store).  A workgroup
+ * that finds the batch irregular overwrites it with -1 AFTER the exchange, i.e. after it has seen workgroup 0's arrival,
+ * which leaves this wave microseconds behind this store, to the same address.  Nothing waits for the store: a fence
+ * (or a returning atomic whose result is held until the arrival - built, and the compiler turns that into vmcnt(0)
+ * too) would make this wave wait for its state preloads before it arrives, and everybody waits for the slowest
+ * arrival. */
+__device__ __forceinline__ void grid_begin(int32_t* __restrict__ count_out, int32_t regular_count) {
+  if (blockIdx.x == 0 && threadIdx.x == 0 && count_out)
+    __hip_atomic_store(count_out, regular_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+/* Every thread of every workgroup of the grid calls it once.  wg_bad: this workgroup's first violation,
+ * already reduced (ONE_NONE: none; thread 0's value counts).  Returns the batch's first violation once every workgroup
+ * has arrived. */
+__device__ __forceinline__ uint32_t grid_exchange(const DevScratch& X, const GridXchg& Q, uint32_t wg_bad) {
   __shared__ uint32_t s_first, s_gave_up;
   if (threadIdx.x == 0) {
     s_gave_up = 0;
-    if (blockIdx.x == 0 && count_out) /* before workgroup 0's arrival: a later -1 wins */
-      __hip_atomic_store(count_out, regular_count, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (wg_bad != ONE_NONE)
-      atomicMax(Q.verdict, ((unsigned long long)Q.epoch << 32) | (unsigned long long)(ONE_NONE - wg_bad));
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); /* the atomics above have been performed */
+    if (wg_bad != ONE_NONE) { /* rare: the verdict must have been performed before the arrival can be seen */
+      const unsigned long long old =
+          atomicMax(Q.verdict, ((unsigned long long)Q.epoch << 32) | (unsigned long long)(ONE_NONE - wg_bad));
+      asm volatile("" ::"v"((uint32_t)old));
+    }
     __hip_atomic_fetch_add(&Q.arrive[(blockIdx.x % GPX_GX_LINES) * 32], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   __syncthreads(); /* (s_gave_up cleared before a poller may raise it) */
@@ -268,6 +279,7 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_pers(
     const int32_t* __restrict__ median, const uint8_t* __restrict__ flags, int32_t* __restrict__ r_bnum,
     int32_t* __restrict__ r_bcoord, int32_t* __restrict__ r_maxcp, uint8_t* __restrict__ r_flags,
     uint8_t* __restrict__ status, DirectStage D, int32_t* __restrict__ n_runs, int32_t regular_count) {
+  grid_begin(n_runs, regular_count);
   /* this chunk's loads go out before anything else (waves 1 and 2 of k_ac_one) */
   const int32_t i = (int32_t)blockIdx.x * GPX_DBLOCK + (int32_t)threadIdx.x;
   int32_t g = 0, g_prev = 0, g_next = 0, f_a = 0, f_b = 0, f_c = 0, f_bnum = 0, f_bcoord = 0;
@@ -285,7 +297,7 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_pers(
     if (runstart && !oob) acc_preload(S, g, f_a, P);
     if (oob || (i > 0 && g_prev > g)) mine = (uint32_t)i;
   }
-  const uint32_t first_bad = grid_exchange(X, Q, wg_first_bad(mine), n_runs, regular_count);
+  const uint32_t first_bad = grid_exchange(X, Q, wg_first_bad(mine));
   const bool irregular = ac_one_apply<COMMIT>(S, X, n, i, first_bad, runstart, g, g_next, f_a, f_b, f_c, f_bnum, f_bcoord, P,
                                               gidx, bnum, bcoord, slot, median, flags, r_bnum, r_bcoord, r_maxcp, r_flags,
                                               status, D);
@@ -364,6 +376,6 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_propose_pers(
     }
     if ((uint32_t)g >= (uint32_t)S.G || (i > 0 && g_prev >= g)) mine = (uint32_t)i; /* strictly ascending, in range */
   }
-  const uint32_t first_bad = grid_exchange(X, Q, wg_first_bad(mine), nullptr, 0);
+  const uint32_t first_bad = grid_exchange(X, Q, wg_first_bad(mine));
   if (i < n) propose_one_apply<KMAX>(S, X, i, g, first_bad, is_stop, o_slot, o_bnum, o_bcoord, o_median, status, P, handle);
 }

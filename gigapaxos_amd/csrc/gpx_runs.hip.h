@@ -368,17 +368,22 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       }
       const int32_t nd_wg = __syncthreads_count(desc);
       bad = __syncthreads_or(bad) || nd_wg > GPX_RUNS_MAX - 1;
-      if (!bad && desc) {
+      if (!bad && desc) { /* (at most sixteen lanes of the whole batch) */
         const int32_t k = atomicAdd(&info->n_desc, 1);
-        if (k < GPX_RUNS_MAX - 1)
+        if (k < GPX_RUNS_MAX - 1) {
           __hip_atomic_store(&info->start[k + 1], i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        else
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); /* performed before this workgroup's arrival (behind the barrier) */
+        } else {
           bad = true;
+        }
       }
-      if (__syncthreads_or(bad) && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch);
+      if (__syncthreads_or(bad) && threadIdx.x == 0) { /* rare: performed before the arrival */
+        const uint32_t old = atomicMax(X.unsorted, X.epoch);
+        asm volatile("" ::"v"(old));
+      }
     }
     /* (the barrier above and grid_exchange's fence order this workgroup's run starts and verdict before its arrival) */
-    if (grid_exchange(X, Q, ONE_NONE, nullptr, 0) == 0u && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch); /* gave up: apply nothing */
+    if (grid_exchange(X, Q, ONE_NONE) == 0u && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch); /* gave up: apply nothing */
     __syncthreads();
     if (__hip_atomic_load(X.unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X.epoch) {
       /* not a few ascending runs in range: refused whole under the promise, else the partition pipeline (or the
