@@ -362,20 +362,24 @@ def end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, me
     # -- the asynchronous calls (gpx_*_batch_async + gpx_engine_wait), two steps in flight: the inputs of step r + 1
     # travel to the device while the outputs of step r travel back - both directions of the link busy.
     # slot / max_cp of a host round are only right once per engine: a fresh one, ten rounds
-    n_async = 10
+    n_async = 12
+    steps_in_flight = 3  # the copy-out (a kernel writing through the host mapping) is slower than the DMA copy-in: with two
+    # steps in flight the next submit waits for it; three keep the inbound link busy (six calls: GPX_ASYNC_DEPTH=6)
+    os.environ["GPX_ASYNC_DEPTH"] = str(2 * steps_in_flight)
     ee = fresh_engine()
+    del os.environ["GPX_ASYNC_DEPTH"]
     hcols = host_rounds(ee, n_async)
     hg = hbuf(ee, G)
     hg[:] = np.arange(G, dtype=np.int32)
     fn_pa, fn_aa, fn_w = (ee.lib.fn[k] for k in ("propose_batch_async", "accept_reply_batch_async", "engine_wait"))
     ring = []
-    for _ in range(2):
+    for _ in range(steps_in_flight):
         o = [hbuf(ee, G) for _ in range(4)] + [hbuf(ee, G, np.uint8)]
         d = [hbuf(ee, nv) for _ in range(5)] + [hbuf(ee, nv, np.uint8)]
         ring.append((o, d, hbuf(ee, 1), hbuf(ee, nv, np.uint8)))
 
     def submit(r):
-        o, d, no, st = ring[r & 1]
+        o, d, no, st = ring[r % steps_in_flight]
         c = hcols[r % n_async]
         tp, ta = C.c_uint64(0), C.c_uint64(0)
         rc = fn_pa(ee.h, G, _p(hg), None, _p(o[0]), _p(o[1]), _p(o[2]), _p(o[3]), _p(o[4]), C.byref(tp))
@@ -387,17 +391,19 @@ def end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, me
 
     def wait(t):
         assert fn_w(ee.h, t[0]) == 0 and fn_w(ee.h, t[1]) == 0
-    for t in [submit(0), submit(0)]:  # warm: all four sets of device columns allocated (the repeated
-        wait(t)                       # round only brings late votes; one more slot stays outstanding)
+    for t in [submit(0) for _ in range(steps_in_flight)]:  # warm: every set of device columns allocated (the repeated
+        wait(t)                                             # round only brings late votes; one more slot stays outstanding)
+    from collections import deque
     te = time.perf_counter()
-    prev = submit(1)
-    for r in range(2, n_async):
-        cur = submit(r)
-        wait(prev)
-        prev = cur
-    wait(prev)
+    flying = deque()
+    for r in range(1, n_async):
+        flying.append(submit(r))
+        if len(flying) == steps_in_flight:
+            wait(flying.popleft())
+    while flying:
+        wait(flying.popleft())
     te = (time.perf_counter() - te) / (n_async - 1)
-    n_dec = int(ring[(n_async - 1) & 1][2][0])
+    n_dec = int(ring[(n_async - 1) % steps_in_flight][2][0])
     assert args.mix or n_dec == G
     b_in = G * 4 + nv * (16 if common else 24)
     b_out = G * 17 + nv + n_dec * 21 + 4
@@ -419,8 +425,9 @@ def end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, me
             "common_ballot_form": bool(common),
             "synchronous_calls_ms_per_step": round(te_sync * 1e3, 4),
             "host_thread_pinned_to_gpu_numa_node": prev_affinity is not None,
+            "steps_in_flight": steps_in_flight,
             "path": "gpx_propose_batch_async + gpx_accept_reply_batch_async + gpx_engine_wait with HOST "
-                    "pointers, two steps in flight: H2D of step r + 1 beside the kernels and the D2H of step r; "
+                    "pointers, three steps in flight (GPX_ASYNC_DEPTH=6): H2D of the next steps beside the kernels and the D2H of step r; "
                     "synchronous_calls_ms_per_step = the plain calls, one after the other"}
 
 

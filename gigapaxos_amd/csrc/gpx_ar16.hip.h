@@ -26,6 +26,7 @@
  */
 #pragma once
 #include "gpx_kernels.hip.h"
+#include "gpx_slots.hip.h"
 
 struct __attribute__((aligned(16))) Vote16 {
   int32_t idx, slot, maxcp;
@@ -51,6 +52,7 @@ struct Stage16 { /* one block of six columns n apart (five of int32, one of byte
 /* the caller's vote columns the ESC path reads, and the batch's common ballot = ballot of vote 0 */
 struct VoteCols {
   const int32_t *bnum, *bcoord, *acceptor;
+  const int32_t *slot, *maxcp; /* the slotted front end's escape path (gpx_slots.hip.h) */
 };
 
 __device__ __forceinline__ void put_vote16(const DevScratch& X, int32_t* lds, int32_t G, int32_t mask,
@@ -353,9 +355,9 @@ struct AcceptOut {
 #define B16_AR 0     /* accept replies at the coordinator */
 #define B16_ACCEPT 1 /* ACCEPTs at an acceptor */
 #define B16_COMMIT 2 /* commits at every replica */
-template <int OP, int KMAX>
+template <int OP, int KMAX, bool SLOTS = false>
 __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratch& X, const Stage16& O, const VoteCols& in,
-                                              const AcceptOut& R, uint8_t* __restrict__ status) {
+                                              const AcceptOut& R, uint8_t* __restrict__ status, const SlotArea& A = SlotArea{}) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   constexpr bool AC = OP != B16_AR;
   /* ordered batch: k_ac_direct did it (a few sorted runs of votes: k_ar_runs); nothing was partitioned */
@@ -366,6 +368,12 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   if (threadIdx.x == 0) {
     X.bucket_tot[b] = 0; /* ready for the next batch's k_hist */
     if (nb == 0) X.bucket_nout[b] = 0;
+  }
+  int32_t novf = 0; /* SLOTS: this bucket's records on the overflow list, and the list's length */
+  int32_t novf_all = 0;
+  if (SLOTS) {
+    novf = A.ovf_cnt[b];
+    novf_all = novf ? A.ovf_n[1] : 0;
   }
   if (nb == 0) return;
   const int32_t gb = X.gb; /* == blockDim.x: one lane per group */
@@ -392,6 +400,39 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   Vote16* recG = (Vote16*)X.rec + boff;
   unsigned long long* keysG = X.perm + boff;
   lcnt[l] = 0;
+  /* SLOTS (gpx_slots.hip.h): the bucket's records are the used entries of its nwg slots - eight lanes per slot, a
+   * 64-byte line per step - and whatever of it is on the overflow list */
+  const int32_t slot0 = SLOTS ? in.slot[0] : 0;
+  auto each_slot_record = [&](auto f) {
+    const uint8_t* crow = A.cntm + (int64_t)b * A.nwg_pad;
+    for (int32_t w = l >> 3; w < A.nwg; w += gb >> 3) {
+      const int32_t cw = crow[w];
+      const Vote8* sl = A.slots + ((int64_t)b * A.nwg + w) * GPX_SL_SLOT;
+      for (int32_t j = l & 7; j < cw; j += 8) {
+        const I4 x = slot_expand(sl[j], w, A.tile, slot0, in.slot, in.maxcp);
+        Vote16 v;
+        v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
+        f(v);
+      }
+    }
+    if (novf)
+      for (int32_t e = l; e < novf_all; e += gb)
+        if (A.ovf_bkt[e] == b) {
+          const I4 x = A.ovf_rec[e];
+          Vote16 v;
+          v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
+          f(v);
+        }
+  };
+  if (SLOTS && !in_lds) {
+    /* too many records for the LDS staging (a skewed stream): copy them into this bucket's region of X.rec and go on as
+     * the partition path does (the count pass below also reads that region) */
+    __shared__ int32_t s_pos;
+    if (l == 0) s_pos = 0;
+    __syncthreads();
+    each_slot_record([&](const Vote16& v) { recG[atomicAdd(&s_pos, 1)] = v; });
+    __threadfence_block();
+  }
   __syncthreads();
   /* A: votes per group.  The first four votes of a lane stay in registers for the placement. */
   Vote16 r0, r1, r2, r3;
@@ -399,7 +440,9 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   r0.idx = r1.idx = r2.idx = r3.idx = 0;
   r0.slot = r1.slot = r2.slot = r3.slot = 0;
   r0.maxcp = r1.maxcp = r2.maxcp = r3.maxcp = 0;
-  {
+  if (SLOTS && in_lds) {
+    each_slot_record([&](const Vote16& v) { atomicAdd(&lcnt[v.meta & V16_LG_MASK], 1); });
+  } else {
     const int32_t j0 = l, j1 = gb + l, j2 = 2 * gb + l, j3 = 3 * gb + l;
     if (j0 < nb) r0 = recG[j0];
     if (j1 < nb) r1 = recG[j1];
@@ -428,11 +471,15 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
       cpA[p] = v.maxcp;
       metaA[p] = v.meta;
     };
-    if (l < nb) place(r0);
-    if (gb + l < nb) place(r1);
-    if (2 * gb + l < nb) place(r2);
-    if (3 * gb + l < nb) place(r3);
-    for (int32_t j = 4 * gb + l; j < nb; j += gb) place(recG[j]);
+    if (SLOTS) {
+      each_slot_record(place); /* the second reading of the slots: from L2 */
+    } else {
+      if (l < nb) place(r0);
+      if (gb + l < nb) place(r1);
+      if (2 * gb + l < nb) place(r2);
+      if (3 * gb + l < nb) place(r3);
+      for (int32_t j = 4 * gb + l; j < nb; j += gb) place(recG[j]);
+    }
   } else {
     for (int32_t j = l; j < nb; j += gb) {
       const Vote16 v = recG[j];
@@ -679,12 +726,22 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     }
     if (l == 0) X.bucket_nout[b] = tout;
   }
+  if (SLOTS && l == 0 && novf) A.ovf_cnt[b] = 0; /* ready for the next call's scatter (every lane has used its copy) */
 }
 
 template <int OP, int KMAX>
 __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, DevScratch X, Stage16 O, VoteCols in,
                                                    AcceptOut R, uint8_t* __restrict__ status) {
   bucket16_body<OP, KMAX>(S, X, O, in, R, status);
+}
+/* accept replies behind the slotted front end (gpx_slots.hip.h): K <= 4, and five replicas held to 6 waves like k_bucket_ar16_k5 */
+__global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16_slots(DevState S, DevScratch X, Stage16 O, VoteCols in,
+                                                                          uint8_t* __restrict__ status, SlotArea A) {
+  bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, A);
+}
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_k5_slots(
+    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, SlotArea A) {
+  bucket16_body<B16_AR, 5, true>(S, X, O, in, AcceptOut{}, status, A);
 }
 /* Five replicas (BASELINE config #4): the KMAX = 5 body needs 82 VGPRs left to itself - two over the step
  * to 5 waves per SIMD = two workgroups per CU instead of three; held to 6 waves it gives up two registers

@@ -171,6 +171,10 @@ struct gpx_engine {
   int32_t ar_passes = 1, shift16 = 0, nbk16 = 0;
   bool ac16 = false;          /* ACCEPT / COMMIT partition path on 16-byte records too (single pass only) */
   int32_t* ar_chain = nullptr; /* [2] running output count between passes */
+  /* the slotted front end of shuffled accept-reply calls (gpx_slots.hip.h; GPX_AR_SLOTS=1): allocated on first use */
+  bool ar_slots = false;
+  SlotArea slot_area{};
+  int32_t slot_tile = 0; /* votes per scatter workgroup: 16384 or 8192, by the number of buckets */
   I4* reply_rows = nullptr;    /* [max_batch] packed ACCEPT_REPLY rows of the partition path (first use) */
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
   /* asynchronous host-pointer calls (gpx_*_batch_async / gpx_engine_wait): GPX_ASYNC_DEPTH sets of device
@@ -192,7 +196,8 @@ struct gpx_engine {
     const uint8_t* dev_kind = nullptr;
     int32_t* host_count = nullptr; /* n_out / n_runs of the caller */
     int32_t n = 0;                 /* records of the call: the capacity of every output column (gpx.h) */
-  } as[GPX_ASYNC_DEPTH];
+  } as[GPX_ASYNC_DEPTH_MAX];
+  int async_depth = GPX_ASYNC_DEPTH; /* sets in use (GPX_ASYNC_DEPTH=n, up to GPX_ASYNC_DEPTH_MAX) */
   hipStream_t s_in = nullptr;
   uint64_t async_seq = 0;
   /* host blocks registered through gpx_host_register (base, bytes): the extent check of mapped_host, the
@@ -671,6 +676,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
+  if (const char* sl = getenv("GPX_AR_SLOTS")) e->ar_slots = atoi(sl) != 0;
   if (const char* sv = getenv("GPX_SAR_MAX_N")) e->sar_max_n = std::max(0, std::min(GPX_SAR_MAX_N, atoi(sv)));
   e->sar_max_n = std::min(e->sar_max_n, cfg->max_batch); /* its keys live in X.perm: [max_batch] entries */
   e->ordered_mask = e->env_mask;
@@ -756,6 +762,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
     HIPCHK_CREATE(hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, e->device));
     if (const char* sv = getenv("GPX_XCHG_SLOTS")) e->one_launch = atoi(sv) != 0; /* test switch: 0 = the two-launch forms */
     if (const char* sh = getenv("GPX_DEVICE_SHARERS")) e->sharers = std::max(1, atoi(sh));
+    if (const char* ad = getenv("GPX_ASYNC_DEPTH")) e->async_depth = std::max(1, std::min(GPX_ASYNC_DEPTH_MAX, atoi(ad)));
     HIPCHK_CREATE(hipHostMalloc((void**)&e->h_abort, 64, hipHostMallocMapped));
     *e->h_abort = 0;
     void* dptr = nullptr;
@@ -988,6 +995,80 @@ int gpx_route_batch_dev(gpx_engine* h, int32_t n, int32_t n_cols, const int32_t*
 
 /* ---- device-pointer data path ------------------------------------------------- */
 
+/* The slotted front end (gpx_slots.hip.h) for one pass over every bucket: k_scatter_slots, k_slot_offsets,
+ * k_bucket_ar16_slots, k_emit_dec16.  false: this call's shape is not one it takes (the caller goes on with k_hist +
+ * k_scatter_ar16). */
+static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const int32_t* bnum, const int32_t* bcoord,
+                          const int32_t* slot, const int32_t* acceptor, const int32_t* max_cp, int32_t* d_gidx,
+                          int32_t* d_slot, int32_t* d_bnum, int32_t* d_bcoord, int32_t* d_median_cp, uint8_t* d_kind,
+                          int32_t* n_out, uint8_t* status) {
+  const int32_t nbk = e->nbk16;
+  /* a slot holds what a workgroup's tile brings a bucket on average x 3: 8 votes per (bucket, workgroup) */
+  const int32_t T = nbk >= 1640 ? 16384 : nbk >= 820 ? 8192 : 0;
+  if (!T || nbk > GPX_MAX_BUCKETS || n < 8 * T || e->shift16 > 10) return false;
+  const size_t N = (size_t)e->cfg.max_batch;
+  SlotArea& A = e->slot_area;
+  if (!A.slots || e->slot_tile != T) {
+    if (A.slots) return false; /* (one tile size per engine: the bucket geometry does not change) */
+    const size_t nwg_max = (N + (size_t)T - 1) / (size_t)T;
+    const size_t pad = (nwg_max + 15) / 16 * 16;
+    if (dev_alloc(e, &A.slots, (size_t)nbk * nwg_max * GPX_SL_SLOT, false) != GPX_OK ||
+        dev_alloc(e, &A.cntm, (size_t)nbk * pad, true) != GPX_OK || dev_alloc(e, &A.ovf_rec, N, false) != GPX_OK ||
+        dev_alloc(e, &A.ovf_bkt, N, false) != GPX_OK || dev_alloc(e, &A.ovf_n, 2, true) != GPX_OK ||
+        dev_alloc(e, &A.ovf_cnt, (size_t)nbk, true) != GPX_OK) {
+      A.slots = nullptr;
+      e->ar_slots = false; /* no room: the partition front end from now on */
+      return false;
+    }
+    A.nwg_pad = (int32_t)pad;
+    e->slot_tile = T;
+    const size_t lds = (size_t)((nbk + 3) & ~3) * 4 + (size_t)T * sizeof(Vote8);
+    HIPQ(hipFuncSetAttribute((const void*)k_scatter_slots<16384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    HIPQ(hipFuncSetAttribute((const void*)k_scatter_slots<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    const size_t hw16 = GPX_BUCKET16_LDS_BYTES((size_t)1 << e->shift16, e->lds16_hw) + e->lds_pad;
+    HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_slots, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
+    HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_k5_slots, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
+  }
+  A.nwg = (n + T - 1) / T;
+  A.tile = T;
+  const DevScratch X0 = e->X;
+  const int threads0 = e->bucket_threads;
+  e->X.shift = e->shift16;
+  e->X.gb = 1 << e->shift16;
+  e->X.nbk = nbk;
+  e->bucket_threads = e->X.gb;
+  begin_back(e, 0, n, true);
+  const size_t lds = (size_t)((nbk + 3) & ~3) * 4 + (size_t)T * sizeof(Vote8);
+  {
+    LaunchScope _ls(e, "k_scatter_slots");
+    if (T == 16384)
+      hipLaunchKernelGGL(k_scatter_slots<16384>, dim3(tile_grid(A.nwg)), dim3(GPX_FBLOCK), lds, e->stream, n, e->S.G, e->X, A, gidx,
+                         bnum, bcoord, slot, acceptor, max_cp, status);
+    else
+      hipLaunchKernelGGL(k_scatter_slots<8192>, dim3(tile_grid(A.nwg)), dim3(GPX_FBLOCK), lds, e->stream, n, e->S.G, e->X, A, gidx,
+                         bnum, bcoord, slot, acceptor, max_cp, status);
+  }
+  {
+    LaunchScope _ls(e, "k_slot_offsets");
+    hipLaunchKernelGGL(k_slot_offsets, dim3(1), dim3(GPX_FBLOCK), 0, e->stream, e->X, A);
+  }
+  const Stage16 O{(int32_t*)e->X.o_rec, (int64_t)N};
+  const VoteCols in{bnum, bcoord, acceptor, slot, max_cp};
+  if (e->cfg.kmax <= 4)
+    LAUNCH_B(e, "k_bucket_ar16", k_bucket_ar16_slots, e->S, e->X, O, in, status, A);
+  else
+    LAUNCH_B(e, "k_bucket_ar16", k_bucket_ar16_k5_slots, e->S, e->X, O, in, status, A);
+  LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out,
+         &e->X.counters[1], (const int32_t*)nullptr, (int32_t*)nullptr);
+  const int32_t lds_recs = e->X.lds_recs;
+  const int32_t gate = e->X.gate;
+  e->X = X0;
+  e->X.lds_recs = lds_recs;
+  e->X.gate = gate;
+  e->bucket_threads = threads0;
+  return true;
+}
+
 /* the partition pipeline of an accept-reply batch: k_hist, k_scatter_ar16, k_bucket_ar16, k_emit_dec16, one
  * pass per range of groups; e->ar_chain holds the number of outputs written so far between the passes */
 static void ar_partition(gpx_engine* e, int32_t n, const int32_t* gidx, const int32_t* bnum, const int32_t* bcoord,
@@ -1014,6 +1095,9 @@ static void ar_partition(gpx_engine* e, int32_t n, const int32_t* gidx, const in
   }
   const int64_t bpp = (NB + want_passes - 1) / want_passes; /* buckets per pass, <= GPX_MAX_BUCKETS */
   const int32_t passes = (int32_t)((NB + bpp - 1) / bpp);
+  if (e->ar_slots && passes == 1 && vec && e->cfg.kmax <= 5 && ar_slots_call(e, n, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx,
+                                                                              d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, status))
+    return;
   const size_t N = (size_t)e->cfg.max_batch;
   int32_t* o32 = (int32_t*)e->X.o_rec; /* N x 32 bytes: five int columns + one byte column */
   const Stage16 O{o32, (int64_t)N};
@@ -2024,7 +2108,7 @@ int async_fail(gpx_engine* e, gpx_engine::AsyncSet& a, int rc) {
 int async_begin(gpx_engine* e, int32_t n, gpx_engine::AsyncSet** out) {
   int rc = check_batch(e, n);
   if (rc != GPX_OK) return rc;
-  gpx_engine::AsyncSet& a = e->as[e->async_seq % GPX_ASYNC_DEPTH];
+  gpx_engine::AsyncSet& a = e->as[e->async_seq % (uint64_t)e->async_depth];
   if (a.busy) return GPX_EBUSY;
   if (!e->s_in) {
     /* GPX_ASYNC_IN=engine (experiment): inputs on the engine's own stream instead of a copy stream */

@@ -1,0 +1,240 @@
+/*
+ * gpx_slots.hip.h — the SLOTTED front end of the shuffled accept-reply call (round 5).
+ *
+ * The partition front end (k_hist + k_scatter_ar16) writes every vote as ONE 16-byte record to an effectively random
+ * address: 3 M stores that each cost a 32-byte sector (95 MB of WRITE_SIZE for 48 MB of records) at the chip's
+ * random-access rate, ~50 us whatever is done around them, after a histogram pass whose 0.29 M returning atomics cost
+ * another ~16 us.  Round 4's micro-benchmark (scripts/ubench/ubench_front16.hip, variant D) showed the form whose
+ * writes reach HBM as whole 64-byte lines; this is that form inside the engine:
+ *
+ *   k_scatter_slots<T>   one workgroup SORTS T votes by bucket in LDS (counting sort on 8-byte records: offset in the
+ *                        tile | local group | escape, and slot / max_cp / acceptor as bytes relative to vote 0's) and
+ *                        writes the run of every bucket into a FIXED slot of GPX_SL_SLOT records that belongs to
+ *                        (bucket, workgroup): no histogram pass, no reservation, no atomics on shared words; eight
+ *                        lanes write a run, so it leaves as one to three full lines.  A count byte per (bucket,
+ *                        workgroup) says how many records the slot holds; a run longer than the slot puts its tail
+ *                        on an overflow list (a returning atomic per record: a skewed stream pays, a stream like
+ *                        BASELINE's has none - Poisson mean 8.4 against 24).  Also what k_hist did on the side:
+ *                        status prefill, the vote and dropped counters.
+ *   k_slot_offsets       one workgroup: row sums of the count matrix (+ overflow per bucket) -> X.bucket_off, so that
+ *                        everything behind - the per-bucket kernel's regions in X.rec / X.perm / the output staging,
+ *                        k_emit_dec16 - is what it was.
+ *   k_bucket16<.., SLOTS> (gpx_ar16.hip.h) reads its records from its nwg slots (eight lanes per slot) instead of one
+ *                        contiguous region: twice (count, then place - the second time from L2); a bucket too big for
+ *                        the LDS staging first copies them into its X.rec region and goes on as before.
+ *
+ * Taken by a call that is one partition pass over 820 ... 4096 buckets, 16-byte aligned columns, group sizes up to 5,
+ * and only when the engine was created with GPX_AR_SLOTS=1 - DESIGN.md 3 has what it measured.
+ */
+#pragma once
+#include "gpx_kernels.hip.h"
+
+#define GPX_SL_SLOT 24 /* records per (bucket, workgroup) slot: three 64-byte lines */
+struct __attribute__((aligned(8))) Vote8 {
+  uint32_t a; /* offset of the vote in its workgroup's tile (14 bits) | local group << 14 (10 bits) | ESC << 31 */
+  uint32_t b; /* slot - slot0 + 128 (8 bits) | (slot - 1 - max_cp + 128) << 8 (8 bits) | acceptor << 16 */
+};
+#define V8_ESC 0x80000000u
+struct SlotArea {
+  Vote8* slots;     /* [nbk][nwg][GPX_SL_SLOT] */
+  uint8_t* cntm;    /* [nbk][nwg_pad] records in each slot (at most GPX_SL_SLOT: the rest overflowed) */
+  I4* ovf_rec;      /* [max_batch] overflow records, as Vote16 */
+  int32_t* ovf_bkt; /* [max_batch] their buckets */
+  int32_t* ovf_n;   /* [2] overflow records of the call (k_scatter_slots adds; k_slot_offsets moves it to word 1 and clears) */
+  int32_t* ovf_cnt; /* [nbk] overflow records per bucket (cleared by the per-bucket kernel) */
+  int32_t nwg, nwg_pad, tile; /* scatter workgroups of this call, the count matrix's row stride, votes per workgroup */
+};
+
+/* the 16-byte record of a slot entry; w = the scatter workgroup that wrote it.  An escaped entry (another ballot than
+ * the batch's, an acceptor id beyond 16 bits, a slot or checkpoint that does not fit a byte next to vote 0's) fetches
+ * slot and max_cp from the caller's columns here and keeps ESC, so that the ballot and the acceptor are fetched where
+ * the 16-byte records' escape path fetches them */
+__device__ __forceinline__ I4 slot_expand(const Vote8 v, int32_t w, int32_t tile, int32_t slot0,
+                                          const int32_t* __restrict__ slot_col, const int32_t* __restrict__ maxcp_col) {
+  I4 r;
+  r.x = w * tile + (int32_t)(v.a & 0x3fffu);
+  const uint32_t lg = (v.a >> 14) & 0x3ffu;
+  if (v.a & V8_ESC) {
+    r.y = slot_col[r.x];
+    r.z = maxcp_col[r.x];
+    r.w = (int32_t)(lg | 0x4000u /* V16_ESC */);
+  } else {
+    r.y = slot0 + (int32_t)(v.b & 255u) - 128;
+    r.z = r.y - 1 - ((int32_t)((v.b >> 8) & 255u) - 128);
+    r.w = (int32_t)(lg | (v.b & 0xffff0000u));
+  }
+  return r;
+}
+
+template <int T>
+__global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_slots(int32_t n, int32_t G, DevScratch X, SlotArea A,
+                                                             const int32_t* __restrict__ gidx,
+                                                             const int32_t* __restrict__ bnum,
+                                                             const int32_t* __restrict__ bcoord,
+                                                             const int32_t* __restrict__ slot,
+                                                             const int32_t* __restrict__ acceptor,
+                                                             const int32_t* __restrict__ max_cp,
+                                                             uint8_t* __restrict__ status) {
+  extern __shared__ int32_t lds[];
+  constexpr int R4 = T / (GPX_FBLOCK * 4);
+  static_assert(T <= 16384 && T % (GPX_FBLOCK * 4) == 0, "14 bits of tile offset");
+  const int32_t nbk = X.nbk;
+  int32_t* cnt = lds; /* [nbk] count -> exclusive base */
+  Vote8* recs = (Vote8*)(lds + ((nbk + 3) & ~3));
+  const int32_t w = tile_of_block(A.nwg);
+  if (w >= A.nwg) return;
+  if (X.gate && *X.unsorted != X.epoch) return; /* a few sorted runs: k_ar_runs did it (gpx_runs.hip.h) */
+  const int32_t b0n = bnum[0], b0c = bcoord[0], slot0 = slot[0];
+  for (int32_t b = threadIdx.x; b < nbk; b += GPX_FBLOCK) cnt[b] = 0;
+  __syncthreads();
+  const int32_t shift = X.shift, mask = X.gb - 1;
+  int32_t rk[R4 * 4], bb[R4 * 4];
+  int32_t bad = 0;
+#pragma unroll
+  for (int k = 0; k < R4; k++) {
+    const int64_t i0 = (int64_t)w * T + (int64_t)(k * GPX_FBLOCK + threadIdx.x) * 4;
+    int32_t gg[4] = {-1, -1, -1, -1};
+    uint32_t stw = 0;
+    if (i0 + 3 < n) {
+      const I4 g = *(const I4*)(gidx + i0);
+      gg[0] = g.x, gg[1] = g.y, gg[2] = g.z, gg[3] = g.w;
+    } else {
+      for (int q = 0; q < 4; q++)
+        if (i0 + q < n) gg[q] = gidx[i0 + q];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      bb[k * 4 + q] = -1;
+      rk[k * 4 + q] = 0;
+      if (i0 + q < n) {
+        if ((uint32_t)gg[q] < (uint32_t)G) {
+          bb[k * 4 + q] = gg[q] >> shift;
+          rk[k * 4 + q] = atomicAdd(&cnt[bb[k * 4 + q]], 1);
+        } else {
+          bad++;
+          stw |= (uint32_t)GPX_S_NOGROUP << (8 * q); /* PaxosManager.java:1162-1194 */
+        }
+      }
+    }
+    if (status) { /* what k_hist does for the partition path (GPX_S_OK == 0) */
+      if (i0 + 3 < n && !((uintptr_t)status & 3)) {
+        *(uint32_t*)(status + i0) = stw;
+      } else {
+        for (int q = 0; q < 4; q++)
+          if (i0 + q < n) status[i0 + q] = (uint8_t)((stw >> (8 * q)) & 0xffu);
+      }
+    }
+  }
+  if (bad) atomicAdd(&X.counters[2], (unsigned long long)bad);
+  if (w == 0 && threadIdx.x == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
+  __syncthreads();
+  /* exclusive scan of the counts -> local bases; this workgroup's column of the count matrix */
+  const int32_t per = (nbk + GPX_FBLOCK - 1) / GPX_FBLOCK; /* <= 4: at most 4096 buckets */
+  const int32_t bq = (int32_t)threadIdx.x * per;
+  int32_t v[4], s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    v[q] = (q < per && bq + q < nbk) ? cnt[bq + q] : 0;
+    s += v[q];
+  }
+  int32_t tot;
+  int32_t ex = block_exscan_n<GPX_FBLOCK>(s, &tot);
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    if (q < per && bq + q < nbk) {
+      cnt[bq + q] = ex;
+      ex += v[q];
+      A.cntm[(int64_t)(bq + q) * A.nwg_pad + w] = (uint8_t)min(v[q], GPX_SL_SLOT);
+    }
+  __syncthreads();
+  /* the tile, sorted by bucket, as 8-byte records in LDS */
+#pragma unroll
+  for (int k = 0; k < R4; k++) {
+    const int64_t i0 = (int64_t)w * T + (int64_t)(k * GPX_FBLOCK + threadIdx.x) * 4;
+    int32_t gg[4], ss[4], aa[4], mm[4], nn[4], cc[4];
+    if (i0 + 3 < n) {
+      const I4 g = *(const I4*)(gidx + i0), s4 = *(const I4*)(slot + i0), a4 = *(const I4*)(acceptor + i0);
+      const I4 m4 = *(const I4*)(max_cp + i0), n4 = *(const I4*)(bnum + i0), c4 = *(const I4*)(bcoord + i0);
+      gg[0] = g.x, gg[1] = g.y, gg[2] = g.z, gg[3] = g.w;
+      ss[0] = s4.x, ss[1] = s4.y, ss[2] = s4.z, ss[3] = s4.w;
+      aa[0] = a4.x, aa[1] = a4.y, aa[2] = a4.z, aa[3] = a4.w;
+      mm[0] = m4.x, mm[1] = m4.y, mm[2] = m4.z, mm[3] = m4.w;
+      nn[0] = n4.x, nn[1] = n4.y, nn[2] = n4.z, nn[3] = n4.w;
+      cc[0] = c4.x, cc[1] = c4.y, cc[2] = c4.z, cc[3] = c4.w;
+    } else {
+      for (int q = 0; q < 4; q++) {
+        const int64_t i = i0 + q < n ? i0 + q : 0;
+        gg[q] = gidx[i], ss[q] = slot[i], aa[q] = acceptor[i], mm[q] = max_cp[i], nn[q] = bnum[i], cc[q] = bcoord[i];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int32_t b = bb[k * 4 + q];
+      if (b < 0) continue;
+      const uint32_t dslot = (uint32_t)(ss[q] - slot0 + 128), dcp = (uint32_t)(ss[q] - 1 - mm[q] + 128);
+      const bool esc = nn[q] != b0n || cc[q] != b0c || (uint32_t)aa[q] > 0xffffu || dslot > 255u || dcp > 255u;
+      Vote8 r;
+      r.a = (uint32_t)(i0 + q - (int64_t)w * T) | ((uint32_t)(gg[q] & mask) << 14) | (esc ? V8_ESC : 0u);
+      r.b = esc ? 0u : (dslot | (dcp << 8) | ((uint32_t)aa[q] << 16));
+      recs[cnt[b] + rk[k * 4 + q]] = r;
+    }
+  }
+  __syncthreads();
+  /* every bucket's run leaves in order: eight lanes per bucket, a 64-byte line per step */
+  for (int32_t b = (int32_t)threadIdx.x >> 3; b < nbk; b += GPX_FBLOCK >> 3) {
+    const int32_t base = cnt[b];
+    const int32_t c = (b + 1 < nbk ? cnt[b + 1] : tot) - base;
+    Vote8* sl = A.slots + ((int64_t)b * A.nwg + w) * GPX_SL_SLOT;
+    for (int32_t j = (int32_t)threadIdx.x & 7; j < c; j += 8) {
+      if (j < GPX_SL_SLOT) {
+        sl[j] = recs[base + j];
+      } else { /* the slot is full: the tail of the run goes to the overflow list (a skewed stream) */
+        const int32_t p = atomicAdd(A.ovf_n, 1);
+        A.ovf_rec[p] = slot_expand(recs[base + j], w, T, slot0, slot, max_cp);
+        A.ovf_bkt[p] = b;
+        atomicAdd(&A.ovf_cnt[b], 1);
+      }
+    }
+  }
+}
+
+/* row sums of the count matrix (+ the buckets' overflow) -> X.bucket_off: one workgroup */
+__global__ __launch_bounds__(GPX_FBLOCK) void k_slot_offsets(DevScratch X, SlotArea A) {
+  if (X.gate && *X.unsorted != X.epoch) return;
+  const int32_t nbk = X.nbk;
+  const int32_t per = (nbk + GPX_FBLOCK - 1) / GPX_FBLOCK; /* <= 4 */
+  const int32_t bq = (int32_t)threadIdx.x * per;
+  int32_t v[4], s = 0;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    v[q] = 0;
+    if (q < per && bq + q < nbk) {
+      const uint32_t* row = (const uint32_t*)(A.cntm + (int64_t)(bq + q) * A.nwg_pad);
+      uint32_t acc = 0; /* two 16-bit sums; a byte is at most GPX_SL_SLOT */
+      const int32_t full = A.nwg >> 2, rem = A.nwg & 3;
+      for (int32_t t = 0; t < full; t++) {
+        const uint32_t x = row[t];
+        acc += (x & 0x00ff00ffu) + ((x >> 8) & 0x00ff00ffu);
+      }
+      if (rem) { /* bytes at and beyond nwg may be an earlier, larger call's */
+        const uint32_t x = row[full] & ((1u << (8 * rem)) - 1u);
+        acc += (x & 0x00ff00ffu) + ((x >> 8) & 0x00ff00ffu);
+      }
+      v[q] = (int32_t)((acc & 0xffffu) + (acc >> 16)) + A.ovf_cnt[bq + q];
+      s += v[q];
+    }
+  }
+  int32_t tot;
+  int32_t ex = block_exscan_n<GPX_FBLOCK>(s, &tot);
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    if (q < per && bq + q < nbk) {
+      X.bucket_off[bq + q] = ex;
+      ex += v[q];
+    }
+  if (threadIdx.x == 0) {
+    X.bucket_off[nbk] = tot;
+    A.ovf_n[1] = A.ovf_n[0]; /* the list's length, for the per-bucket kernel */
+    A.ovf_n[0] = 0;          /* ... and the next call's scatter starts an empty one */
+  }
+}

@@ -371,8 +371,11 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
  * (PISM.handleBatchedAcceptReply unpacks one ballot per BatchedAcceptReply, PaxosInstanceStateMachine.java:
  * 1380-1387): 16 instead of 24 bytes per vote cross the link.
  */
-#define GPX_ASYNC_DEPTH 4
-#define GPX_EBUSY (-5) /* GPX_ASYNC_DEPTH calls in flight, or the ticket is unknown / already waited for */
+#define GPX_ASYNC_DEPTH 4     /* calls in flight an engine takes by default ... */
+#define GPX_ASYNC_DEPTH_MAX 8 /* ... and at most: environment GPX_ASYNC_DEPTH=n at engine creation (each call in flight holds
+                                 a set of device columns of max_batch entries; six = three steps of two calls: bench.py's
+                                 end-to-end leg, whose copy-out is slower than its copy-in) */
+#define GPX_EBUSY (-5) /* the engine's depth of calls is in flight, or the ticket is unknown / already waited for */
 typedef uint64_t gpx_ticket;
 int gpx_propose_batch_async(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop, int32_t* slot,
                             int32_t* bnum, int32_t* bcoord, int32_t* median_cp, uint8_t* status,

@@ -410,12 +410,15 @@ def run_long_random(lib, n, lengths=(8, 12), seed=77, orders=("interleaved", "gr
 
 
 def run_plan(lib, scale=1.0, orders=("interleaved", "grouped"), inits=("create", "initial"), from_disk=(True,),
-             promise=False, skip=(), both_inits_below=200_000):
+             promise=False, skip=(), both_inits_below=200_000, single_order_above=None):
     total = 0
-    for name, seqs in plan(scale):
+    for p, (name, seqs) in enumerate(plan(scale)):
         if name in skip:
             continue
-        for i, order in enumerate(orders):
+        plan_orders = orders
+        if single_order_above is not None and len(seqs) > single_order_above and len(orders) > 1:
+            plan_orders = (orders[p % len(orders)],)  # the exhaustive plans: one batch order each, alternating
+        for i, order in enumerate(plan_orders):
             # every batch order sees both initial rows on the short plans; the long ones alternate
             for init in (inits if len(seqs) < both_inits_below else (inits[i % len(inits)],)):
                 for fd in from_disk:

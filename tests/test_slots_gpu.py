@@ -1,0 +1,73 @@
+"""The slotted front end of the shuffled accept-reply call (gigapaxos_amd/csrc/gpx_slots.hip.h; engines created with
+GPX_AR_SLOTS=1; calls of one partition pass over at least 820 buckets, i.e. tables from about 420,000 groups) against the
+oracle: BASELINE's config #3 / #4 streams at 1 M groups, votes that do not fit the 8-byte slot entry (other ballots, node
+ids beyond 16 bits, slots and checkpoints far from vote 0's), and skewed streams - a bucket that gets more votes from one
+scatter workgroup than its slot holds (the overflow list) and more votes altogether than the LDS staging holds (copied
+into its X.rec region first)."""
+import numpy as np
+import pytest
+
+from gigapaxos_amd import hri_create, streams, S_OK
+from tests.parity_common import make_pair, assert_same_state
+from tests.test_fullsize_gpu import _same, _vote_stream_parity
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _slots(monkeypatch):
+    monkeypatch.setenv("GPX_AR_SLOTS", "1")
+
+
+def _took_slots(eh):
+    return "k_scatter_slots" in eh.profile_read()
+
+
+@pytest.mark.parametrize("k,mix", [(3, True), (5, True)])
+def test_config3_config4_streams_1m_groups_through_slots(hip_lib, oracle_lib, k, mix):
+    _vote_stream_parity(hip_lib, oracle_lib, 1_000_000, k, mix, R=3)
+
+
+def test_wide_node_ids_and_ballots_through_slots(hip_lib, oracle_lib):
+    """Entries that escape the 8-byte form re-read their fields from the caller's columns."""
+    _vote_stream_parity(hip_lib, oracle_lib, 600_000, 5, True, R=3, big_ids=True)
+
+
+@pytest.mark.parametrize("hot_votes", [3000, 400_000])
+def test_skewed_stream_overflow_and_big_bucket(hip_lib, oracle_lib, hot_votes):
+    """`hot_votes` extra votes aimed at the groups of ONE bucket (duplicates of their real votes, shuffled in): its slots
+    overflow - more than 24 votes from one 16,384-vote tile - and with 400,000 of them the bucket exceeds the LDS staging
+    as well.  Several slots outstanding per group, a slot far from vote 0's (an escaped entry).  The profile must show
+    that the slotted kernels ran."""
+    G, k, R = 1_000_000, 3, 3
+    members = [100, 101, 102]
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=3 * G + 3 * G // 50 + hot_votes + 4096)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 100)) == S_OK).all()
+    g = np.arange(G, dtype=np.int32)
+    rng = np.random.default_rng(hot_votes)
+    eh.profile(2)
+    for r in range(R):
+        for x, y in zip(eh.propose(g), eo.propose(g)):
+            assert (x == y).all()
+        cols = [c.copy() for c in streams.vote_round(G, members, r, 100, config_id=3, mix=(r == 1))]
+        n0 = cols[0].shape[0]
+        hot_groups = 512 * 777 + rng.integers(0, 512, hot_votes)          # one bucket of 512 groups
+        pick = rng.integers(0, n0, hot_votes)
+        extra = [c[pick].copy() for c in cols]
+        extra[0] = hot_groups.astype(np.int32)
+        extra[4] = rng.choice(members, hot_votes).astype(np.int32)
+        if r == 2:
+            extra[3][: hot_votes // 2] += 1000                              # slots a byte cannot reach from vote 0's
+        cols = [np.concatenate([c, x]) for c, x in zip(cols, extra)]
+        order = rng.permutation(cols[0].shape[0])
+        cols = [np.ascontiguousarray(c[order]) for c in cols]
+        dh, do = eh.accept_reply(*cols), eo.accept_reply(*cols)
+        _same(dh, do, f"round {r}")
+    assert _took_slots(eh)
+    assert eh.snapshot(g)[0].tobytes() == eo.snapshot(g)[0].tobytes()
+    assert_same_state(eh, eo, np.concatenate([rng.integers(0, G, 40), 512 * 777 + rng.integers(0, 512, 40)]))
+    assert eh.counters() == eo.counters()
+    eh.close()
+    eo.close()
