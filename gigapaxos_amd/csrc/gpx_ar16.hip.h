@@ -363,11 +363,20 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   /* ordered batch: k_ac_direct did it (a few sorted runs of votes: k_ar_runs); nothing was partitioned */
   if ((AC || X.gate) && *X.unsorted != X.epoch) return;
   const int32_t b = blockIdx.x;
-  const int32_t boff = X.bucket_off[b];
-  const int32_t nb = X.bucket_off[b + 1] - boff;
-  if (threadIdx.x == 0) {
-    X.bucket_tot[b] = 0; /* ready for the next batch's k_hist */
-    if (nb == 0) X.bucket_nout[b] = 0;
+  int32_t boff, nb;
+  if (SLOTS) { /* no k_hist, no scanned offsets: the records before this bucket are summed here (gpx_slots.hip.h) */
+    boff = slot_bucket_offset(X, b, &nb);
+    if (threadIdx.x == 0) {
+      X.bucket_off[b] = boff; /* where k_emit_dec16 finds this bucket's staged outputs */
+      if (nb == 0) X.bucket_nout[b] = 0;
+    }
+  } else {
+    boff = X.bucket_off[b];
+    nb = X.bucket_off[b + 1] - boff;
+    if (threadIdx.x == 0) {
+      X.bucket_tot[b] = 0; /* ready for the next batch's k_hist */
+      if (nb == 0) X.bucket_nout[b] = 0;
+    }
   }
   int32_t novf = 0; /* SLOTS: this bucket's records on the overflow list, and the list's length */
   int32_t novf_all = 0;
@@ -403,9 +412,43 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   /* SLOTS (gpx_slots.hip.h): the bucket's records are the used entries of its nwg slots - eight lanes per slot, a
    * 64-byte line per step - and whatever of it is on the overflow list */
   const int32_t slot0 = SLOTS ? in.slot[0] : 0;
+  /* The first GPX_SL_REG slots of a lane group (all of them up to 64 * GPX_SL_REG scatter workgroups: 3.1 M votes) are
+   * fetched ONCE, whole and unconditionally - count byte and the lane's three entries together, nothing waits for the
+   * count - and stay in registers for the count pass and the placement; entries beyond the count are garbage nobody
+   * looks at.  (Round 5's first form read count, then entries, twice: twelve dependent round trips, +17 us.) */
+  constexpr int GPX_SL_REG = 3;
+  int32_t rcw[GPX_SL_REG];
+  Vote8 rv[GPX_SL_REG][3];
+  if (SLOTS) {
+    const uint8_t* crow = A.cntm + (int64_t)b * A.nwg_pad;
+#pragma unroll
+    for (int t = 0; t < GPX_SL_REG; t++) {
+      const int32_t w = (l >> 3) + t * (gb >> 3);
+      rcw[t] = 0;
+      if (w < A.nwg) {
+        rcw[t] = crow[w];
+        const Vote8* sl = A.slots + ((int64_t)b * A.nwg + w) * GPX_SL_SLOT + (l & 7);
+        rv[t][0] = sl[0];
+        rv[t][1] = sl[8];
+        rv[t][2] = sl[16];
+      }
+    }
+  }
   auto each_slot_record = [&](auto f) {
     const uint8_t* crow = A.cntm + (int64_t)b * A.nwg_pad;
-    for (int32_t w = l >> 3; w < A.nwg; w += gb >> 3) {
+#pragma unroll
+    for (int t = 0; t < GPX_SL_REG; t++) {
+      const int32_t w = (l >> 3) + t * (gb >> 3);
+#pragma unroll
+      for (int q = 0; q < 3; q++)
+        if ((l & 7) + 8 * q < rcw[t]) {
+          const I4 x = slot_expand(rv[t][q], w, A.tile, slot0, in.slot, in.maxcp);
+          Vote16 v;
+          v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
+          f(v);
+        }
+    }
+    for (int32_t w = (l >> 3) + GPX_SL_REG * (gb >> 3); w < A.nwg; w += gb >> 3) {
       const int32_t cw = crow[w];
       const Vote8* sl = A.slots + ((int64_t)b * A.nwg + w) * GPX_SL_SLOT;
       for (int32_t j = l & 7; j < cw; j += 8) {
@@ -735,8 +778,8 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
   bucket16_body<OP, KMAX>(S, X, O, in, R, status);
 }
 /* accept replies behind the slotted front end (gpx_slots.hip.h): K <= 4, and five replicas held to 6 waves like k_bucket_ar16_k5 */
-__global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16_slots(DevState S, DevScratch X, Stage16 O, VoteCols in,
-                                                                          uint8_t* __restrict__ status, SlotArea A) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_slots(
+    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, SlotArea A) {
   bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, A);
 }
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_k5_slots(
@@ -775,6 +818,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec16(
   }
   const int32_t nd = X.bucket_nout[blockIdx.x];
   const int64_t src = X.bucket_off[blockIdx.x];
+  if (threadIdx.x == 0) X.bucket_tot[blockIdx.x] = 0; /* (the slotted front end leaves its totals there: ready for a k_hist) */
   for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {
     d_gidx[out0 + t] = O.gidx()[src + t];
     d_slot[out0 + t] = O.slot()[src + t];

@@ -995,7 +995,7 @@ int gpx_route_batch_dev(gpx_engine* h, int32_t n, int32_t n_cols, const int32_t*
 
 /* ---- device-pointer data path ------------------------------------------------- */
 
-/* The slotted front end (gpx_slots.hip.h) for one pass over every bucket: k_scatter_slots, k_slot_offsets,
+/* The slotted front end (gpx_slots.hip.h) for one pass over every bucket: k_scatter_slots, k_slot_totals,
  * k_bucket_ar16_slots, k_emit_dec16.  false: this call's shape is not one it takes (the caller goes on with k_hist +
  * k_scatter_ar16). */
 static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const int32_t* bnum, const int32_t* bcoord,
@@ -1049,8 +1049,8 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
                          bnum, bcoord, slot, acceptor, max_cp, status);
   }
   {
-    LaunchScope _ls(e, "k_slot_offsets");
-    hipLaunchKernelGGL(k_slot_offsets, dim3(1), dim3(GPX_FBLOCK), 0, e->stream, e->X, A);
+    LaunchScope _ls(e, "k_slot_totals");
+    hipLaunchKernelGGL(k_slot_totals, dim3((nbk + GPX_SL_ROWS - 1) / GPX_SL_ROWS), dim3(256), 0, e->stream, e->X, A);
   }
   const Stage16 O{(int32_t*)e->X.o_rec, (int64_t)N};
   const VoteCols in{bnum, bcoord, acceptor, slot, max_cp};
@@ -2028,7 +2028,25 @@ struct CopyOut {
 __global__ __launch_bounds__(256) void k_copy_out(const int32_t* __restrict__ count, CopyOut C) {
   const int32_t m = count ? *count : C.fixed_n;
   if (C.count_dst && blockIdx.x == 0 && threadIdx.x == 0) *C.count_dst = m;
-  for (int32_t i = blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
+  /* 16 bytes per lane and store where the columns allow it (round 5: the link takes a kernel's writes to host memory
+   * faster as 1 KB per wave and column than as 256 bytes; the tail and unaligned columns entry by entry) */
+  bool vec = true;
+#pragma unroll
+  for (int k = 0; k < 6; k++)
+    if (k < C.ncols) vec = vec && !(((uintptr_t)C.dst[k] | (uintptr_t)C.src[k]) & 15);
+#pragma unroll
+  for (int k = 0; k < 2; k++)
+    if (k < C.nb) vec = vec && !(((uintptr_t)C.bdst[k] | (uintptr_t)C.bsrc[k]) & 3);
+  const int32_t mv = vec ? (m & ~3) : 0;
+  for (int32_t i = (blockIdx.x * 256 + threadIdx.x) * 4; i < mv; i += gridDim.x * 256 * 4) {
+#pragma unroll
+    for (int k = 0; k < 6; k++)
+      if (k < C.ncols) *(I4*)(C.dst[k] + i) = *(const I4*)(C.src[k] + i);
+#pragma unroll
+    for (int k = 0; k < 2; k++)
+      if (k < C.nb) *(uint32_t*)(C.bdst[k] + i) = *(const uint32_t*)(C.bsrc[k] + i);
+  }
+  for (int32_t i = mv + blockIdx.x * 256 + threadIdx.x; i < m; i += gridDim.x * 256) {
 #pragma unroll
     for (int k = 0; k < 6; k++)
       if (k < C.ncols) C.dst[k][i] = C.src[k][i];

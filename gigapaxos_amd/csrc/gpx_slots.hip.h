@@ -16,9 +16,9 @@
  *                        on an overflow list (a returning atomic per record: a skewed stream pays, a stream like
  *                        BASELINE's has none - Poisson mean 8.4 against 24).  Also what k_hist did on the side:
  *                        status prefill, the vote and dropped counters.
- *   k_slot_offsets       one workgroup: row sums of the count matrix (+ overflow per bucket) -> X.bucket_off, so that
- *                        everything behind - the per-bucket kernel's regions in X.rec / X.perm / the output staging,
- *                        k_emit_dec16 - is what it was.
+ *   k_slot_totals        row sums of the count matrix (+ overflow per bucket) -> X.bucket_tot; the per-bucket kernel sums
+ *                        what lies before its bucket and from there on everything - its regions in X.rec / X.perm / the
+ *                        output staging, k_emit_dec16 - is what it was.
  *   k_bucket16<.., SLOTS> (gpx_ar16.hip.h) reads its records from its nwg slots (eight lanes per slot) instead of one
  *                        contiguous region: twice (count, then place - the second time from L2); a bucket too big for
  *                        the LDS staging first copies them into its X.rec region and goes on as before.
@@ -40,7 +40,7 @@ struct SlotArea {
   uint8_t* cntm;    /* [nbk][nwg_pad] records in each slot (at most GPX_SL_SLOT: the rest overflowed) */
   I4* ovf_rec;      /* [max_batch] overflow records, as Vote16 */
   int32_t* ovf_bkt; /* [max_batch] their buckets */
-  int32_t* ovf_n;   /* [2] overflow records of the call (k_scatter_slots adds; k_slot_offsets moves it to word 1 and clears) */
+  int32_t* ovf_n;   /* [2] overflow records of the call (k_scatter_slots adds; k_slot_totals moves it to word 1 and clears) */
   int32_t* ovf_cnt; /* [nbk] overflow records per bucket (cleared by the per-bucket kernel) */
   int32_t nwg, nwg_pad, tile; /* scatter workgroups of this call, the count matrix's row stride, votes per workgroup */
 };
@@ -198,43 +198,61 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_slots(int32_t n, int32_t
   }
 }
 
-/* row sums of the count matrix (+ the buckets' overflow) -> X.bucket_off: one workgroup */
-__global__ __launch_bounds__(GPX_FBLOCK) void k_slot_offsets(DevScratch X, SlotArea A) {
+/* row sums of the count matrix (+ the buckets' overflow) -> X.bucket_tot, and per GPX_SL_ROWS buckets -> X.tile_rel
+ * (free in this mode: no k_hist ran): the per-bucket kernel adds up what lies before its bucket itself.  Sixteen lanes
+ * per row, GPX_SL_ROWS rows per workgroup.  (Round 5's first form was ONE workgroup that also scanned the totals into
+ * X.bucket_off: 29 us for 360 KB - every thread walked two rows word by word.) */
+#define GPX_SL_ROWS 16
+__global__ __launch_bounds__(256) void k_slot_totals(DevScratch X, SlotArea A) {
   if (X.gate && *X.unsorted != X.epoch) return;
-  const int32_t nbk = X.nbk;
-  const int32_t per = (nbk + GPX_FBLOCK - 1) / GPX_FBLOCK; /* <= 4 */
-  const int32_t bq = (int32_t)threadIdx.x * per;
-  int32_t v[4], s = 0;
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    v[q] = 0;
-    if (q < per && bq + q < nbk) {
-      const uint32_t* row = (const uint32_t*)(A.cntm + (int64_t)(bq + q) * A.nwg_pad);
-      uint32_t acc = 0; /* two 16-bit sums; a byte is at most GPX_SL_SLOT */
-      const int32_t full = A.nwg >> 2, rem = A.nwg & 3;
-      for (int32_t t = 0; t < full; t++) {
-        const uint32_t x = row[t];
-        acc += (x & 0x00ff00ffu) + ((x >> 8) & 0x00ff00ffu);
-      }
-      if (rem) { /* bytes at and beyond nwg may be an earlier, larger call's */
-        const uint32_t x = row[full] & ((1u << (8 * rem)) - 1u);
-        acc += (x & 0x00ff00ffu) + ((x >> 8) & 0x00ff00ffu);
-      }
-      v[q] = (int32_t)((acc & 0xffffu) + (acc >> 16)) + A.ovf_cnt[bq + q];
-      s += v[q];
+  __shared__ int32_t s_row[GPX_SL_ROWS];
+  const int32_t b = (int32_t)blockIdx.x * GPX_SL_ROWS + ((int32_t)threadIdx.x >> 4);
+  const int32_t j = (int32_t)threadIdx.x & 15;
+  uint32_t acc = 0; /* two 16-bit sums; a byte is at most GPX_SL_SLOT */
+  if (b < X.nbk) {
+    const uint32_t* row = (const uint32_t*)(A.cntm + (int64_t)b * A.nwg_pad);
+    const int32_t full = A.nwg >> 2, rem = A.nwg & 3;
+    for (int32_t t = j; t < full; t += 16) {
+      const uint32_t x = row[t];
+      acc += (x & 0x00ff00ffu) + ((x >> 8) & 0x00ff00ffu);
+    }
+    if (rem && j == (full & 15)) { /* bytes at and beyond nwg may be an earlier, larger call's */
+      const uint32_t x = row[full] & ((1u << (8 * rem)) - 1u);
+      acc += (x & 0x00ff00ffu) + ((x >> 8) & 0x00ff00ffu);
     }
   }
-  int32_t tot;
-  int32_t ex = block_exscan_n<GPX_FBLOCK>(s, &tot);
+  int32_t v = (int32_t)((acc & 0xffffu) + (acc >> 16));
 #pragma unroll
-  for (int q = 0; q < 4; q++)
-    if (q < per && bq + q < nbk) {
-      X.bucket_off[bq + q] = ex;
-      ex += v[q];
+  for (int d = 8; d >= 1; d >>= 1) v += __shfl_xor(v, d, 16);
+  if (j == 0) {
+    if (b < X.nbk) {
+      v += A.ovf_cnt[b];
+      X.bucket_tot[b] = v;
+    } else {
+      v = 0;
     }
+    s_row[threadIdx.x >> 4] = v;
+  }
+  __syncthreads();
   if (threadIdx.x == 0) {
-    X.bucket_off[nbk] = tot;
-    A.ovf_n[1] = A.ovf_n[0]; /* the list's length, for the per-bucket kernel */
-    A.ovf_n[0] = 0;          /* ... and the next call's scatter starts an empty one */
+    int32_t t = 0;
+    for (int q = 0; q < GPX_SL_ROWS; q++) t += s_row[q];
+    X.tile_rel[blockIdx.x] = t;
+    if (blockIdx.x == 0) {
+      A.ovf_n[1] = A.ovf_n[0]; /* the list's length, for the per-bucket kernel */
+      A.ovf_n[0] = 0;          /* ... and the next call's scatter starts an empty one */
+    }
   }
+}
+/* records before bucket b and in it (every thread of the per-bucket workgroup calls it; gb threads) */
+__device__ __forceinline__ int32_t slot_bucket_offset(const DevScratch& X, int32_t b, int32_t* nb) {
+  int32_t s = 0;
+  const int32_t wfull = b / GPX_SL_ROWS;
+  for (int32_t t = (int32_t)threadIdx.x; t < wfull; t += (int32_t)blockDim.x) s += X.tile_rel[t];
+  const int32_t r = wfull * GPX_SL_ROWS + (int32_t)threadIdx.x;
+  if ((int32_t)threadIdx.x < GPX_SL_ROWS && r < b) s += X.bucket_tot[r];
+  int32_t tot;
+  block_exscan_rt(s, &tot);
+  *nb = X.bucket_tot[b];
+  return tot;
 }
