@@ -54,9 +54,6 @@ def alg_bytes_per_vote(k: int) -> float:
 
 STRONG_GROUPS, STRONG_K = 1_000_000, 5  # BASELINE config #4: the ONE group space the metric is quoted on
 
-# kernels of the accept-reply call (the unit's call): everything else a step launches belongs to the proposal call
-AR_KERNELS = ("k_hist", "k_scatter_ar16", "k_bucket_ar16", "k_emit_dec16", "k_runs_check", "k_ar_runs", "k_ar_runs_pers",
-              "k_emit_dec_runs", "k_merge_runs", "k_runs_count", "k_ar_tiny")
 # the engine's profile labels name the launch (k_bucket_ar16), rocprofv3 the kernel (k_bucket16<0, 4>)
 PMC_ALIAS = {"k_bucket_ar16": "k_bucket16", "k_bucket_accept16": "k_bucket16", "k_bucket_commit16": "k_bucket16",
              "k_ar_runs_pers": "k_ar_runs"}

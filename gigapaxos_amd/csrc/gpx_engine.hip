@@ -676,6 +676,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
+  e->ar_slots = true; /* GPX_AR_SLOTS=0: the partition front end for every shuffled call (comparison runs) */
   if (const char* sl = getenv("GPX_AR_SLOTS")) e->ar_slots = atoi(sl) != 0;
   if (const char* sv = getenv("GPX_SAR_MAX_N")) e->sar_max_n = std::max(0, std::min(GPX_SAR_MAX_N, atoi(sv)));
   e->sar_max_n = std::min(e->sar_max_n, cfg->max_batch); /* its keys live in X.perm: [max_batch] entries */
@@ -1005,7 +1006,10 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
   const int32_t nbk = e->nbk16;
   /* a slot holds what a workgroup's tile brings a bucket on average x 3: 8 votes per (bucket, workgroup) */
   const int32_t T = nbk >= 1640 ? 16384 : nbk >= 820 ? 8192 : 0;
-  if (!T || nbk > GPX_MAX_BUCKETS || n < 8 * T || e->shift16 > 10) return false;
+  /* ... and at most 192 scatter workgroups: the per-bucket kernel keeps the slots of three rounds of its lane groups in
+   * registers; beyond (five replicas at 1 M groups: 306) its second reading of the slots costs what the scatter saved
+   * (0.181 against 0.178 ms per step, profiles/r05_slots_front_end.txt) */
+  if (!T || nbk > GPX_MAX_BUCKETS || n < 8 * T || e->shift16 > 10 || (n + T - 1) / T > 192) return false;
   const size_t N = (size_t)e->cfg.max_batch;
   SlotArea& A = e->slot_area;
   if (!A.slots || e->slot_tile != T) {
@@ -1055,9 +1059,9 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
   const Stage16 O{(int32_t*)e->X.o_rec, (int64_t)N};
   const VoteCols in{bnum, bcoord, acceptor, slot, max_cp};
   if (e->cfg.kmax <= 4)
-    LAUNCH_B(e, "k_bucket_ar16", k_bucket_ar16_slots, e->S, e->X, O, in, status, A);
+    LAUNCH_B(e, "k_bucket_ar16_slots", k_bucket_ar16_slots, e->S, e->X, O, in, status, A);
   else
-    LAUNCH_B(e, "k_bucket_ar16", k_bucket_ar16_k5_slots, e->S, e->X, O, in, status, A);
+    LAUNCH_B(e, "k_bucket_ar16_slots", k_bucket_ar16_k5_slots, e->S, e->X, O, in, status, A);
   LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out,
          &e->X.counters[1], (const int32_t*)nullptr, (int32_t*)nullptr);
   const int32_t lds_recs = e->X.lds_recs;
@@ -2220,7 +2224,11 @@ int async_dense_out(gpx_engine* e, gpx_engine::AsyncSet& a, int32_t n, int ncols
     C.bdst[k] = (uint8_t*)mapped_host(e, hb[k], (size_t)n);
     ok = C.bdst[k] != nullptr;
   }
-  if (ok) {
+  /* a kernel writing through the host mapping saves the runtime's per-copy cost (a few microseconds each) but moves
+   * about 31 GB/s where the DMA engine moves 48 with the other direction busy (bench.py end_to_end, round 5): from
+   * 4 MB on, the columns go by DMA */
+  const bool big = (size_t)n * ((size_t)ncols * 4 + (size_t)nb) >= ((size_t)4 << 20);
+  if (ok && !big) {
     hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(256), 0, a.s_out, (const int32_t*)nullptr, C);
     return GPX_OK;
   }

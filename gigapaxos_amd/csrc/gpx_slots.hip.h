@@ -23,8 +23,10 @@
  *                        contiguous region: twice (count, then place - the second time from L2); a bucket too big for
  *                        the LDS staging first copies them into its X.rec region and goes on as before.
  *
- * Taken by a call that is one partition pass over 820 ... 4096 buckets, 16-byte aligned columns, group sizes up to 5,
- * and only when the engine was created with GPX_AR_SLOTS=1 - DESIGN.md 3 has what it measured.
+ * Taken by a call that is one partition pass over 820 ... 4096 buckets with at most 192 scatter workgroups (3.1 M
+ * votes over 1 M groups, 1.5 M over 500,000), 16-byte aligned columns, group sizes up to 5; GPX_AR_SLOTS=0 at engine
+ * creation keeps the partition front end for every call.  Measured (BASELINE config #3, bench.py): 0.103 against 0.128 ms
+ * per step - DESIGN.md 3.
  */
 #pragma once
 #include "gpx_kernels.hip.h"

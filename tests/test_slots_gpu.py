@@ -1,6 +1,6 @@
-"""The slotted front end of the shuffled accept-reply call (gigapaxos_amd/csrc/gpx_slots.hip.h; engines created with
-GPX_AR_SLOTS=1; calls of one partition pass over at least 820 buckets, i.e. tables from about 420,000 groups) against the
-oracle: BASELINE's config #3 / #4 streams at 1 M groups, votes that do not fit the 8-byte slot entry (other ballots, node
+"""The slotted front end of the shuffled accept-reply call (gigapaxos_amd/csrc/gpx_slots.hip.h: calls of one partition
+pass over at least 820 buckets - tables from about 420,000 groups - and at most 192 scatter workgroups, i.e. 3.1 M votes
+at 1 M groups) against the oracle: votes that do not fit the 8-byte slot entry (other ballots, node
 ids beyond 16 bits, slots and checkpoints far from vote 0's), and skewed streams - a bucket that gets more votes from one
 scatter workgroup than its slot holds (the overflow list) and more votes altogether than the LDS staging holds (copied
 into its X.rec region first)."""
@@ -23,20 +23,28 @@ def _took_slots(eh):
     return "k_scatter_slots" in eh.profile_read()
 
 
-@pytest.mark.parametrize("k,mix", [(3, True), (5, True)])
-def test_config3_config4_streams_1m_groups_through_slots(hip_lib, oracle_lib, k, mix):
-    _vote_stream_parity(hip_lib, oracle_lib, 1_000_000, k, mix, R=3)
+def test_partition_front_end_at_the_same_size(hip_lib, oracle_lib, monkeypatch):
+    """GPX_AR_SLOTS=0: k_hist + k_scatter_ar16 for the shape the slotted front end takes by default (tests/
+    test_fullsize_gpu.py's K = 3 cases at 1 M groups go through the slots now; K = 5 at 1 M groups, 4 M and 5 M
+    groups and every smaller table still take the partition front end)."""
+    monkeypatch.setenv("GPX_AR_SLOTS", "0")
+    _vote_stream_parity(hip_lib, oracle_lib, 1_000_000, 3, True, R=2)
+
+
+def test_config3_stream_500k_groups_through_slots(hip_lib, oracle_lib):
+    """977 buckets: tiles of 8,192 votes."""
+    _vote_stream_parity(hip_lib, oracle_lib, 500_000, 3, True, R=3)
 
 
 def test_wide_node_ids_and_ballots_through_slots(hip_lib, oracle_lib):
     """Entries that escape the 8-byte form re-read their fields from the caller's columns."""
-    _vote_stream_parity(hip_lib, oracle_lib, 600_000, 5, True, R=3, big_ids=True)
+    _vote_stream_parity(hip_lib, oracle_lib, 1_000_000, 3, True, R=3, big_ids=True)
 
 
-@pytest.mark.parametrize("hot_votes", [3000, 400_000])
+@pytest.mark.parametrize("hot_votes", [3000, 60_000])
 def test_skewed_stream_overflow_and_big_bucket(hip_lib, oracle_lib, hot_votes):
     """`hot_votes` extra votes aimed at the groups of ONE bucket (duplicates of their real votes, shuffled in): its slots
-    overflow - more than 24 votes from one 16,384-vote tile - and with 400,000 of them the bucket exceeds the LDS staging
+    overflow - more than 24 votes from one 16,384-vote tile - and with 60,000 of them the bucket exceeds the LDS staging
     as well.  Several slots outstanding per group, a slot far from vote 0's (an escaped entry).  The profile must show
     that the slotted kernels ran."""
     G, k, R = 1_000_000, 3, 3
