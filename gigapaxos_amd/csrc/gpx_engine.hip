@@ -2224,11 +2224,10 @@ int async_dense_out(gpx_engine* e, gpx_engine::AsyncSet& a, int32_t n, int ncols
     C.bdst[k] = (uint8_t*)mapped_host(e, hb[k], (size_t)n);
     ok = C.bdst[k] != nullptr;
   }
-  /* a kernel writing through the host mapping saves the runtime's per-copy cost (a few microseconds each) but moves
-   * about 31 GB/s where the DMA engine moves 48 with the other direction busy (bench.py end_to_end, round 5): from
-   * 4 MB on, the columns go by DMA */
-  const bool big = (size_t)n * ((size_t)ncols * 4 + (size_t)nb) >= ((size_t)4 << 20);
-  if (ok && !big) {
+  /* (a kernel writing through the host mapping moves about 31 GB/s where a lone DMA copy moves 48 with the other direction
+   * busy - but DMA copies for the big dense columns, tried in round 5, queue behind the copy-in stream's DMA: 2.35 ms per
+   * step against 1.33, profiles/r05_bench_e2e_dense_dma.json) */
+  if (ok) {
     hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(256), 0, a.s_out, (const int32_t*)nullptr, C);
     return GPX_OK;
   }
