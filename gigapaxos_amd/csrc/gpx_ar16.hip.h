@@ -26,7 +26,6 @@
  */
 #pragma once
 #include "gpx_kernels.hip.h"
-#include "gpx_lookback.hip.h"
 #include "gpx_slots.hip.h"
 
 struct __attribute__((aligned(16))) Vote16 {
@@ -50,40 +49,6 @@ struct Stage16 { /* one block of six columns n apart (five of int32, one of byte
   __host__ __device__ __forceinline__ int32_t* median() const { return base + 4 * n; }
   __host__ __device__ __forceinline__ uint8_t* kind() const { return (uint8_t*)(base + 5 * n); }
 };
-/* The slotted call's per-bucket kernel writes its decisions STRAIGHT into the caller's columns (round 5): where they go -
- * the outputs of the buckets before - comes from a decoupled look-back over one word per bucket (gpx_lookback.hip.h)
- * at the END of the workgroup's work, when the workgroups before it are done or nearly (they were dispatched first).
- * No staging block, no k_emit_dec16 launch: 10 us and 42 MB of the call.  look == null: staged, as the partition path. */
-struct EmitDirect {
-  int32_t *d_gidx, *d_slot, *d_bnum, *d_bcoord, *d_median;
-  uint8_t* d_kind;
-  int32_t* n_out;
-  unsigned long long* acc;  /* X.counters[1] */
-  unsigned long long* look; /* [nbk] epoch << 40 | state << 38 | outputs */
-  uint32_t epoch;           /* 24 bits, never 0 */
-};
-/* the outputs of the buckets before bucket b (every thread of the workgroup calls it; wave 0 walks) */
-__device__ __forceinline__ int32_t emit_direct_base(const EmitDirect& E, int32_t b, int32_t tout) {
-  __shared__ int32_t s_base;
-  if (threadIdx.x < 64) {
-    if (threadIdx.x == 0)
-      __hip_atomic_store(&E.look[b], wl_word(E.epoch, b == 0 ? WL_PRE : WL_AGG, (uint32_t)tout), __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-    const uint32_t excl = b == 0 ? 0u : wl_lookback(E.look, b, E.epoch);
-    if (threadIdx.x == 0) {
-      if (b != 0)
-        __hip_atomic_store(&E.look[b], wl_word(E.epoch, WL_PRE, excl + (uint32_t)tout), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      s_base = (int32_t)excl;
-      if (b == (int32_t)gridDim.x - 1) { /* the call's count */
-        *E.n_out = (int32_t)excl + tout;
-        if (E.acc) atomicAdd(E.acc, (unsigned long long)((int64_t)excl + tout));
-      }
-    }
-  }
-  __syncthreads();
-  return s_base;
-}
 /* the caller's vote columns the ESC path reads, and the batch's common ballot = ballot of vote 0 */
 struct VoteCols {
   const int32_t *bnum, *bcoord, *acceptor;
@@ -392,8 +357,7 @@ struct AcceptOut {
 #define B16_COMMIT 2 /* commits at every replica */
 template <int OP, int KMAX, bool SLOTS = false>
 __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratch& X, const Stage16& O, const VoteCols& in,
-                                              const AcceptOut& R, uint8_t* __restrict__ status, const SlotArea& A = SlotArea{},
-                                              const EmitDirect& E = EmitDirect{}) {
+                                              const AcceptOut& R, uint8_t* __restrict__ status, const SlotArea& A = SlotArea{}) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   constexpr bool AC = OP != B16_AR;
   /* ordered batch: k_ac_direct did it (a few sorted runs of votes: k_ar_runs); nothing was partitioned */
@@ -402,9 +366,9 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   int32_t boff, nb;
   if (SLOTS) { /* no k_hist, no scanned offsets: the records before this bucket are summed here (gpx_slots.hip.h) */
     boff = slot_bucket_offset(X, b, &nb);
-    if (nb == 0) { /* an empty bucket still has a place in the look-back chain (and may be the last one) */
-      emit_direct_base(E, b, 0);
-      return;
+    if (threadIdx.x == 0) {
+      X.bucket_off[b] = boff; /* where k_emit_dec16 finds this bucket's staged outputs */
+      if (nb == 0) X.bucket_nout[b] = 0;
     }
   } else {
     boff = X.bucket_off[b];
@@ -622,15 +586,6 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   /* a bucket's outputs, group-major, as columns: decisions (six columns) or execution runs (gidx,
    * first slot, count) */
   auto put = [&](int64_t o, int32_t a, int32_t z, int32_t kd) {
-    if (SLOTS) { /* straight into the caller's columns (o counts from the call's first output) */
-      E.d_gidx[o] = g;
-      E.d_slot[o] = a;
-      E.d_median[o] = z;
-      E.d_bnum[o] = P.my_bnum;
-      E.d_bcoord[o] = P.my_bcoord;
-      E.d_kind[o] = (uint8_t)kd;
-      return;
-    }
     O.gidx()[o] = g;
     O.slot()[o] = a;
     O.median()[o] = z;
@@ -778,13 +733,12 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     /* F: the bucket's outputs, group-major, as columns */
     int32_t tout;
     const int32_t ex = block_exscan_rt(nout, &tout);
-    const int64_t obase = SLOTS ? (int64_t)emit_direct_base(E, b, tout) : (int64_t)boff;
     for (int32_t q = 0; q < nout; q++) {
       int32_t sl, md, kd;
       it.output(q, &sl, &md, &kd, &omask);
-      put(obase + ex + q, sl, md, kd);
+      put((int64_t)boff + ex + q, sl, md, kd);
     }
-    if (!SLOTS && l == 0) X.bucket_nout[b] = tout;
+    if (l == 0) X.bucket_nout[b] = tout;
   } else {
     VoteIter<false, AC> it;
     it.idxA = idxA;
@@ -808,17 +762,14 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     nout = it.nout;
     int32_t tout;
     const int32_t ex = block_exscan_rt(nout, &tout);
-    const int64_t obase = SLOTS ? (int64_t)emit_direct_base(E, b, tout) : (int64_t)boff;
     for (int32_t q = 0; q < nout; q++) {
       int32_t sl, md, kd;
       it.output(q, &sl, &md, &kd, &omask);
-      put(obase + ex + q, sl, md, kd);
+      put((int64_t)boff + ex + q, sl, md, kd);
     }
-    if (!SLOTS && l == 0) X.bucket_nout[b] = tout;
+    if (l == 0) X.bucket_nout[b] = tout;
   }
   if (SLOTS && l == 0 && novf) A.ovf_cnt[b] = 0; /* ready for the next call's scatter (every lane has used its copy) */
-  /* (X.bucket_tot keeps this call's totals: workgroups behind still read them.  A later call through the partition
-   * front end finds them cleared by its host side - gpx_engine.hip: ar_partition) */
 }
 
 template <int OP, int KMAX>
@@ -828,12 +779,12 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
 }
 /* accept replies behind the slotted front end (gpx_slots.hip.h): K <= 4, and five replicas held to 6 waves like k_bucket_ar16_k5 */
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_slots(
-    DevState S, DevScratch X, VoteCols in, uint8_t* __restrict__ status, SlotArea A, EmitDirect E) {
-  bucket16_body<B16_AR, 4, true>(S, X, Stage16{}, in, AcceptOut{}, status, A, E);
+    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, SlotArea A) {
+  bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, A);
 }
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_k5_slots(
-    DevState S, DevScratch X, VoteCols in, uint8_t* __restrict__ status, SlotArea A, EmitDirect E) {
-  bucket16_body<B16_AR, 5, true>(S, X, Stage16{}, in, AcceptOut{}, status, A, E);
+    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, SlotArea A) {
+  bucket16_body<B16_AR, 5, true>(S, X, O, in, AcceptOut{}, status, A);
 }
 /* Five replicas (BASELINE config #4): the KMAX = 5 body needs 82 VGPRs left to itself - two over the step
  * to 5 waves per SIMD = two workgroups per CU instead of three; held to 6 waves it gives up two registers
@@ -867,6 +818,7 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec16(
   }
   const int32_t nd = X.bucket_nout[blockIdx.x];
   const int64_t src = X.bucket_off[blockIdx.x];
+  if (threadIdx.x == 0) X.bucket_tot[blockIdx.x] = 0; /* (the slotted front end leaves its totals there: ready for a k_hist) */
   for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {
     d_gidx[out0 + t] = O.gidx()[src + t];
     d_slot[out0 + t] = O.slot()[src + t];

@@ -175,9 +175,6 @@ struct gpx_engine {
   bool ar_slots = false;
   SlotArea slot_area{};
   int32_t slot_tile = 0; /* votes per scatter workgroup: 16384 or 8192, by the number of buckets */
-  unsigned long long* slot_look = nullptr; /* [nbk] look-back words of the per-bucket kernel's output placement */
-  uint32_t slot_epoch = 0;                 /* 24 bits, never 0 */
-  bool slots_dirty = false;                /* X.bucket_tot holds a slotted call's totals: cleared before the next k_hist */
   I4* reply_rows = nullptr;    /* [max_batch] packed ACCEPT_REPLY rows of the partition path (first use) */
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
   /* asynchronous host-pointer calls (gpx_*_batch_async / gpx_engine_wait): GPX_ASYNC_DEPTH sets of device
@@ -410,10 +407,6 @@ void launch_one_compaction(gpx_engine* e, const gpx_engine::LastCall& L) {
 /* bucket partition front end, part 1: per-bucket record counts of the batch */
 void front_hist(gpx_engine* e, int32_t n, const int32_t* gidx, uint8_t* status, int is_votes,
                 int check_order = 0) {
-  if (e->slots_dirty) { /* a slotted accept-reply call left its bucket totals there; k_hist adds to cleared words */
-    HIPQ(hipMemsetAsync(e->X.bucket_tot, 0, sizeof(int32_t) * (size_t)std::max(e->X.nbk, e->nbk16), e->stream));
-    e->slots_dirty = false;
-  }
   const int ntiles = ntiles_for(n);
   /* one histogram workgroup per `hsub` scatter tiles: about one workgroup per CU */
   /* (measured: 5 sub-tiles per histogram workgroup for 3 M votes - fewer returning atomics per bucket
@@ -1004,7 +997,7 @@ int gpx_route_batch_dev(gpx_engine* h, int32_t n, int32_t n_cols, const int32_t*
 /* ---- device-pointer data path ------------------------------------------------- */
 
 /* The slotted front end (gpx_slots.hip.h) for one pass over every bucket: k_scatter_slots, k_slot_totals,
- * k_bucket_ar16_slots (which places its outputs itself).  false: this call's shape is not one it takes (the caller goes on with k_hist +
+ * k_bucket_ar16_slots, k_emit_dec16.  false: this call's shape is not one it takes (the caller goes on with k_hist +
  * k_scatter_ar16). */
 static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const int32_t* bnum, const int32_t* bcoord,
                           const int32_t* slot, const int32_t* acceptor, const int32_t* max_cp, int32_t* d_gidx,
@@ -1026,7 +1019,7 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
     if (dev_alloc(e, &A.slots, (size_t)nbk * nwg_max * GPX_SL_SLOT, false) != GPX_OK ||
         dev_alloc(e, &A.cntm, (size_t)nbk * pad, true) != GPX_OK || dev_alloc(e, &A.ovf_rec, N, false) != GPX_OK ||
         dev_alloc(e, &A.ovf_bkt, N, false) != GPX_OK || dev_alloc(e, &A.ovf_n, 2, true) != GPX_OK ||
-        dev_alloc(e, &A.ovf_cnt, (size_t)nbk, true) != GPX_OK || dev_alloc(e, &e->slot_look, (size_t)nbk, true) != GPX_OK) {
+        dev_alloc(e, &A.ovf_cnt, (size_t)nbk, true) != GPX_OK) {
       A.slots = nullptr;
       e->ar_slots = false; /* no room: the partition front end from now on */
       return false;
@@ -1063,17 +1056,14 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
     LaunchScope _ls(e, "k_slot_totals");
     hipLaunchKernelGGL(k_slot_totals, dim3((nbk + GPX_SL_ROWS - 1) / GPX_SL_ROWS), dim3(256), 0, e->stream, e->X, A);
   }
-  if (++e->slot_epoch >= (1u << 24)) { /* 2^24 calls: start the look-back words' epochs again from cleared words */
-    HIPQ(hipMemsetAsync(e->slot_look, 0, sizeof(unsigned long long) * (size_t)nbk, e->stream));
-    e->slot_epoch = 1;
-  }
+  const Stage16 O{(int32_t*)e->X.o_rec, (int64_t)N};
   const VoteCols in{bnum, bcoord, acceptor, slot, max_cp};
-  const EmitDirect E{d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, &e->X.counters[1], e->slot_look, e->slot_epoch};
   if (e->cfg.kmax <= 4)
-    LAUNCH_B(e, "k_bucket_ar16_slots", k_bucket_ar16_slots, e->S, e->X, in, status, A, E);
+    LAUNCH_B(e, "k_bucket_ar16_slots", k_bucket_ar16_slots, e->S, e->X, O, in, status, A);
   else
-    LAUNCH_B(e, "k_bucket_ar16_slots", k_bucket_ar16_k5_slots, e->S, e->X, in, status, A, E);
-  e->slots_dirty = true;
+    LAUNCH_B(e, "k_bucket_ar16_slots", k_bucket_ar16_k5_slots, e->S, e->X, O, in, status, A);
+  LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out,
+         &e->X.counters[1], (const int32_t*)nullptr, (int32_t*)nullptr);
   const int32_t lds_recs = e->X.lds_recs;
   const int32_t gate = e->X.gate;
   e->X = X0;
