@@ -162,13 +162,13 @@ def _churn_across_ranges(hip_lib, oracle_lib, G_live, k, R, seed):
 def test_config5_churn_10m_live_groups_three_range_passes_vs_oracle(hip_lib, oracle_lib):
     """BASELINE config #5 at the size it states: 10,000,000 live groups (K = 3) on one engine, three
     group-range passes per accept-reply call, 0.1 % retire / create per round, two rounds."""
-    _churn_across_ranges(hip_lib, oracle_lib, 10_000_000, 3, R=2, seed=11)  # (the 5 M case keeps the third round: re-created rows vote again)
+    _churn_across_ranges(hip_lib, oracle_lib, 10_000_000, 3, R=2, seed=11)
 
 
 def test_config5_churn_5m_live_groups_k5_two_range_passes_vs_oracle(hip_lib, oracle_lib):
-    """The same with five replicas (config #4's group size): 4,300,000 live groups, two passes, three rounds (re-created
-    rows vote again)."""
-    _churn_across_ranges(hip_lib, oracle_lib, 4_300_000, 5, R=3, seed=12)
+    """The same with five replicas (config #4's group size): 4,300,000 live groups, two passes, two rounds (rows re-created
+    after a retirement vote again in tests/test_fullsize_gpu.py::test_config5_churn_1m_live_groups_vs_oracle, three rounds)."""
+    _churn_across_ranges(hip_lib, oracle_lib, 4_300_000, 5, R=2, seed=12)
 
 
 @pytest.mark.parametrize("order", ["grouped by group", "shuffled"])

@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 NODES = [100, 101, 102]
 
 
-@pytest.mark.parametrize("seed,G,batch,steps", [(41, 12_000, 100_000, 4), (42, 20_000, 150_000, 2)])
+@pytest.mark.parametrize("seed,G,batch,steps", [(41, 6_000, 100_000, 3), (42, 8_000, 150_000, 2)])
 def test_large_ordered_batches_under_the_promise(hip_lib, oracle_lib, seed, G, batch, steps):
     """parity_common.fuzz with grouped batches of up to `batch` records under PROPOSE | ACCEPT | COMMIT: k_propose_one /
     k_ac_one for the batches above 65,536 records, k_*_small below; one batch in eight carries an index out of range
