@@ -1344,10 +1344,10 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
   const bool promised = (e->ordered_mask & GPX_ORDERED_ACCEPT) != 0;
   e->last.kind = 0;
   if (promised && (!fused || lazy_outputs(e))) {
-    /* the promise and more than 65,536 records: the verdict (k_one_check, which also writes the usual batch's
-     * count) and ONE work kernel (gpx_one.hip.h); the compaction pass follows unless the caller asked for lazy outputs.
-     * At most 65,536 records with lazy outputs: the work kernel alone - its (at most 256, resident) workgroups
-     * exchange the verdict among themselves (k_ac_one<.., XCHG>); without lazy outputs k_ac_small's in-kernel run
+    /* the promise: the work kernel alone where its grid is resident for sure - its workgroups exchange the verdict among
+     * themselves (k_ac_pers, xchg_ctl: 131,072 records for one engine on an MI355X) - else the verdict (k_one_check,
+     * which also writes the usual batch's count) and ONE work kernel (gpx_one.hip.h); the compaction pass follows unless
+     * the caller asked for lazy outputs.  At most 65,536 records without lazy outputs: k_ac_small's in-kernel run
      * compaction is the one launch */
     const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
     GridXchg Q;
