@@ -31,6 +31,45 @@ def test_partition_front_end_at_the_same_size(hip_lib, oracle_lib, monkeypatch):
     _vote_stream_parity(hip_lib, oracle_lib, 1_000_000, 3, True, R=2)
 
 
+def test_shuffled_votes_under_the_runs_hint_through_slots(hip_lib, oracle_lib, monkeypatch):
+    """GPX_TRY_REPLY_RUNS on every call (the test switch GPX_TRY_RUNS=1): the runs check judges the shuffled batch first,
+    the slotted kernels are launched behind its gate word and take the batch."""
+    monkeypatch.setenv("GPX_TRY_RUNS", "1")
+    _vote_stream_parity(hip_lib, oracle_lib, 1_000_000, 3, True, R=2)
+
+
+def test_votes_without_a_status_column_through_slots(hip_lib, oracle_lib):
+    """`status` is nullable on the accept-reply call (include/gpx.h): the scatter's prefill and the replay's marks are
+    skipped, the decisions are the same."""
+    import torch
+    G, k = 1_000_000, 3
+    members = [100, 101, 102]
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=3 * G + 3 * G // 50 + 4096)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 100)) == S_OK).all()
+    g = np.arange(G, dtype=np.int32)
+    for x, y in zip(eh.propose(g), eo.propose(g)):
+        assert (x == y).all()
+    cols = streams.vote_round(G, members, 0, 100, config_id=3, mix=True)
+    n = cols[0].shape[0]
+    dc = [torch.from_numpy(c).cuda() for c in cols]
+    d = [torch.zeros(n, dtype=torch.int32, device="cuda") for _ in range(5)] + [torch.zeros(n, dtype=torch.uint8, device="cuda")]
+    no = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    eh.profile(2)
+    eh.call_dev("accept_reply_batch", n, *[t.data_ptr() for t in dc], *[t.data_ptr() for t in d], no.data_ptr(), 0)
+    eh.sync()
+    assert _took_slots(eh)
+    do = eo.accept_reply(*cols)
+    m = int(no.item())
+    got = np.stack([t[:m].cpu().numpy().astype(np.int32) for t in d], axis=1)
+    assert got.shape == do.as_tuple_array().shape and (got == do.as_tuple_array()).all()
+    assert eh.snapshot(g)[0].tobytes() == eo.snapshot(g)[0].tobytes()
+    eh.close()
+    eo.close()
+
+
 def test_config3_stream_500k_groups_through_slots(hip_lib, oracle_lib):
     """977 buckets: tiles of 8,192 votes."""
     _vote_stream_parity(hip_lib, oracle_lib, 500_000, 3, True, R=3)
