@@ -68,66 +68,70 @@ __device__ __forceinline__ I4 slot_expand(const Vote8 v, int32_t w, int32_t tile
   return r;
 }
 
-template <int T>
-__global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_slots(int32_t n, int32_t G, DevScratch X, SlotArea A,
-                                                             const int32_t* __restrict__ gidx,
-                                                             const int32_t* __restrict__ bnum,
-                                                             const int32_t* __restrict__ bcoord,
-                                                             const int32_t* __restrict__ slot,
-                                                             const int32_t* __restrict__ acceptor,
-                                                             const int32_t* __restrict__ max_cp,
-                                                             uint8_t* __restrict__ status) {
-  extern __shared__ int32_t lds[];
+/* four consecutive entries of a column; FULL: the whole vector is inside the batch (one 16-byte load) */
+template <bool FULL>
+__device__ __forceinline__ I4 slots_load4(const int32_t* __restrict__ col, int64_t i0, int32_t n, int32_t fill) {
+  if (FULL) return *(const I4*)(col + i0);
+  I4 r;
+  r.x = i0 + 0 < n ? col[i0 + 0] : fill;
+  r.y = i0 + 1 < n ? col[i0 + 1] : fill;
+  r.z = i0 + 2 < n ? col[i0 + 2] : fill;
+  r.w = i0 + 3 < n ? col[i0 + 3] : fill;
+  return r;
+}
+/* FULL: every vector of the tile lies inside the batch and the status column takes 4-byte stores - every workgroup but
+ * the last.  Then ALL of a phase's loads go out before the first is used (round 5, second form: the first had the
+ * compiler wait for each of the four gidx vectors, and each of the four sets of columns, in turn - eight round trips
+ * where two or three do - and read the gidx column twice). */
+template <int T, bool FULL>
+__device__ __forceinline__ void scatter_slots_tile(int32_t n, int32_t G, const DevScratch& X, const SlotArea& A, int32_t w,
+                                                   const int32_t* __restrict__ gidx, const int32_t* __restrict__ bnum,
+                                                   const int32_t* __restrict__ bcoord, const int32_t* __restrict__ slot,
+                                                   const int32_t* __restrict__ acceptor, const int32_t* __restrict__ max_cp,
+                                                   uint8_t* __restrict__ status, int32_t* cnt, Vote8* recs) {
   constexpr int R4 = T / (GPX_FBLOCK * 4);
-  static_assert(T <= 16384 && T % (GPX_FBLOCK * 4) == 0, "14 bits of tile offset");
   const int32_t nbk = X.nbk;
-  int32_t* cnt = lds; /* [nbk] count -> exclusive base */
-  Vote8* recs = (Vote8*)(lds + ((nbk + 3) & ~3));
-  const int32_t w = tile_of_block(A.nwg);
-  if (w >= A.nwg) return;
-  if (X.gate && *X.unsorted != X.epoch) return; /* a few sorted runs: k_ar_runs did it (gpx_runs.hip.h) */
   const int32_t b0n = bnum[0], b0c = bcoord[0], slot0 = slot[0];
-  for (int32_t b = threadIdx.x; b < nbk; b += GPX_FBLOCK) cnt[b] = 0;
-  __syncthreads();
   const int32_t shift = X.shift, mask = X.gb - 1;
-  int32_t rk[R4 * 4], bb[R4 * 4];
-  int32_t bad = 0;
+  const int64_t t0 = (int64_t)w * T + (int64_t)threadIdx.x * 4; /* this lane's first vector; the others GPX_FBLOCK * 4 apart */
+  /* phase 1: the group indices (kept for phase 2; an index outside the table becomes -1), ranks inside the buckets */
+  int32_t gg[R4 * 4], rk[R4 * 4];
+  {
+    I4 gq[R4];
 #pragma unroll
-  for (int k = 0; k < R4; k++) {
-    const int64_t i0 = (int64_t)w * T + (int64_t)(k * GPX_FBLOCK + threadIdx.x) * 4;
-    int32_t gg[4] = {-1, -1, -1, -1};
-    uint32_t stw = 0;
-    if (i0 + 3 < n) {
-      const I4 g = *(const I4*)(gidx + i0);
-      gg[0] = g.x, gg[1] = g.y, gg[2] = g.z, gg[3] = g.w;
-    } else {
-      for (int q = 0; q < 4; q++)
-        if (i0 + q < n) gg[q] = gidx[i0 + q];
-    }
+    for (int k = 0; k < R4; k++) gq[k] = slots_load4<FULL>(gidx, t0 + (int64_t)k * GPX_FBLOCK * 4, n, -1);
+    int32_t bad = 0;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      bb[k * 4 + q] = -1;
-      rk[k * 4 + q] = 0;
-      if (i0 + q < n) {
-        if ((uint32_t)gg[q] < (uint32_t)G) {
-          bb[k * 4 + q] = gg[q] >> shift;
-          rk[k * 4 + q] = atomicAdd(&cnt[bb[k * 4 + q]], 1);
+    for (int k = 0; k < R4; k++) {
+      const int64_t i0 = t0 + (int64_t)k * GPX_FBLOCK * 4;
+      gg[k * 4 + 0] = gq[k].x, gg[k * 4 + 1] = gq[k].y, gg[k * 4 + 2] = gq[k].z, gg[k * 4 + 3] = gq[k].w;
+      uint32_t stw = 0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        rk[k * 4 + q] = 0;
+        if (FULL || i0 + q < n) {
+          if ((uint32_t)gg[k * 4 + q] < (uint32_t)G) {
+            rk[k * 4 + q] = atomicAdd(&cnt[gg[k * 4 + q] >> shift], 1);
+          } else {
+            gg[k * 4 + q] = -1;
+            bad++;
+            stw |= (uint32_t)GPX_S_NOGROUP << (8 * q); /* PaxosManager.java:1162-1194 */
+          }
         } else {
-          bad++;
-          stw |= (uint32_t)GPX_S_NOGROUP << (8 * q); /* PaxosManager.java:1162-1194 */
+          gg[k * 4 + q] = -1;
+        }
+      }
+      if (status) { /* what k_hist does for the partition path (GPX_S_OK == 0) */
+        if (FULL) {
+          *(uint32_t*)(status + i0) = stw;
+        } else {
+          for (int q = 0; q < 4; q++)
+            if (i0 + q < n) status[i0 + q] = (uint8_t)((stw >> (8 * q)) & 0xffu);
         }
       }
     }
-    if (status) { /* what k_hist does for the partition path (GPX_S_OK == 0) */
-      if (i0 + 3 < n && !((uintptr_t)status & 3)) {
-        *(uint32_t*)(status + i0) = stw;
-      } else {
-        for (int q = 0; q < 4; q++)
-          if (i0 + q < n) status[i0 + q] = (uint8_t)((stw >> (8 * q)) & 0xffu);
-      }
-    }
+    if (bad) atomicAdd(&X.counters[2], (unsigned long long)bad);
   }
-  if (bad) atomicAdd(&X.counters[2], (unsigned long long)bad);
   if (w == 0 && threadIdx.x == 0) atomicAdd(&X.counters[0], (unsigned long long)n);
   __syncthreads();
   /* exclusive scan of the counts -> local bases; this workgroup's column of the count matrix */
@@ -149,36 +153,37 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_slots(int32_t n, int32_t
       A.cntm[(int64_t)(bq + q) * A.nwg_pad + w] = (uint8_t)min(v[q], GPX_SL_SLOT);
     }
   __syncthreads();
-  /* the tile, sorted by bucket, as 8-byte records in LDS */
+  /* phase 2: the tile, sorted by bucket, as 8-byte records in LDS; two vectors' worth of columns in flight at a time */
 #pragma unroll
-  for (int k = 0; k < R4; k++) {
-    const int64_t i0 = (int64_t)w * T + (int64_t)(k * GPX_FBLOCK + threadIdx.x) * 4;
-    int32_t gg[4], ss[4], aa[4], mm[4], nn[4], cc[4];
-    if (i0 + 3 < n) {
-      const I4 g = *(const I4*)(gidx + i0), s4 = *(const I4*)(slot + i0), a4 = *(const I4*)(acceptor + i0);
-      const I4 m4 = *(const I4*)(max_cp + i0), n4 = *(const I4*)(bnum + i0), c4 = *(const I4*)(bcoord + i0);
-      gg[0] = g.x, gg[1] = g.y, gg[2] = g.z, gg[3] = g.w;
-      ss[0] = s4.x, ss[1] = s4.y, ss[2] = s4.z, ss[3] = s4.w;
-      aa[0] = a4.x, aa[1] = a4.y, aa[2] = a4.z, aa[3] = a4.w;
-      mm[0] = m4.x, mm[1] = m4.y, mm[2] = m4.z, mm[3] = m4.w;
-      nn[0] = n4.x, nn[1] = n4.y, nn[2] = n4.z, nn[3] = n4.w;
-      cc[0] = c4.x, cc[1] = c4.y, cc[2] = c4.z, cc[3] = c4.w;
-    } else {
-      for (int q = 0; q < 4; q++) {
-        const int64_t i = i0 + q < n ? i0 + q : 0;
-        gg[q] = gidx[i], ss[q] = slot[i], aa[q] = acceptor[i], mm[q] = max_cp[i], nn[q] = bnum[i], cc[q] = bcoord[i];
-      }
+  for (int k0 = 0; k0 < R4; k0 += 2) {
+    I4 s4[2], a4[2], m4[2], n4[2], c4[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int64_t i0 = t0 + (int64_t)(k0 + u) * GPX_FBLOCK * 4;
+      s4[u] = slots_load4<FULL>(slot, i0, n, 0);
+      a4[u] = slots_load4<FULL>(acceptor, i0, n, 0);
+      m4[u] = slots_load4<FULL>(max_cp, i0, n, 0);
+      n4[u] = slots_load4<FULL>(bnum, i0, n, 0);
+      c4[u] = slots_load4<FULL>(bcoord, i0, n, 0);
     }
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int32_t b = bb[k * 4 + q];
-      if (b < 0) continue;
-      const uint32_t dslot = (uint32_t)(ss[q] - slot0 + 128), dcp = (uint32_t)(ss[q] - 1 - mm[q] + 128);
-      const bool esc = nn[q] != b0n || cc[q] != b0c || (uint32_t)aa[q] > 0xffffu || dslot > 255u || dcp > 255u;
-      Vote8 r;
-      r.a = (uint32_t)(i0 + q - (int64_t)w * T) | ((uint32_t)(gg[q] & mask) << 14) | (esc ? V8_ESC : 0u);
-      r.b = esc ? 0u : (dslot | (dcp << 8) | ((uint32_t)aa[q] << 16));
-      recs[cnt[b] + rk[k * 4 + q]] = r;
+    for (int u = 0; u < 2; u++) {
+      const int k = k0 + u;
+      const int64_t i0 = t0 + (int64_t)k * GPX_FBLOCK * 4;
+      const int32_t ss[4] = {s4[u].x, s4[u].y, s4[u].z, s4[u].w}, aa[4] = {a4[u].x, a4[u].y, a4[u].z, a4[u].w};
+      const int32_t mm[4] = {m4[u].x, m4[u].y, m4[u].z, m4[u].w}, nn[4] = {n4[u].x, n4[u].y, n4[u].z, n4[u].w};
+      const int32_t cc[4] = {c4[u].x, c4[u].y, c4[u].z, c4[u].w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int32_t g = gg[k * 4 + q];
+        if (g < 0) continue;
+        const uint32_t dslot = (uint32_t)(ss[q] - slot0 + 128), dcp = (uint32_t)(ss[q] - 1 - mm[q] + 128);
+        const bool esc = nn[q] != b0n || cc[q] != b0c || (uint32_t)aa[q] > 0xffffu || dslot > 255u || dcp > 255u;
+        Vote8 r;
+        r.a = (uint32_t)(i0 + q - (int64_t)w * T) | ((uint32_t)(g & mask) << 14) | (esc ? V8_ESC : 0u);
+        r.b = esc ? 0u : (dslot | (dcp << 8) | ((uint32_t)aa[q] << 16));
+        recs[cnt[g >> shift] + rk[k * 4 + q]] = r;
+      }
     }
   }
   __syncthreads();
@@ -198,6 +203,31 @@ __global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_slots(int32_t n, int32_t
       }
     }
   }
+}
+
+template <int T>
+__global__ __launch_bounds__(GPX_FBLOCK) void k_scatter_slots(int32_t n, int32_t G, DevScratch X, SlotArea A,
+                                                             const int32_t* __restrict__ gidx,
+                                                             const int32_t* __restrict__ bnum,
+                                                             const int32_t* __restrict__ bcoord,
+                                                             const int32_t* __restrict__ slot,
+                                                             const int32_t* __restrict__ acceptor,
+                                                             const int32_t* __restrict__ max_cp,
+                                                             uint8_t* __restrict__ status) {
+  extern __shared__ int32_t lds[];
+  static_assert(T <= 16384 && T % (GPX_FBLOCK * 8) == 0, "14 bits of tile offset; pairs of vectors per lane");
+  const int32_t nbk = X.nbk;
+  int32_t* cnt = lds; /* [nbk] count -> exclusive base */
+  Vote8* recs = (Vote8*)(lds + ((nbk + 3) & ~3));
+  const int32_t w = tile_of_block(A.nwg);
+  if (w >= A.nwg) return;
+  if (X.gate && *X.unsorted != X.epoch) return; /* a few sorted runs: k_ar_runs did it (gpx_runs.hip.h) */
+  for (int32_t b = threadIdx.x; b < nbk; b += GPX_FBLOCK) cnt[b] = 0;
+  __syncthreads();
+  if ((int64_t)(w + 1) * T <= n && !((uintptr_t)status & 3))
+    scatter_slots_tile<T, true>(n, G, X, A, w, gidx, bnum, bcoord, slot, acceptor, max_cp, status, cnt, recs);
+  else
+    scatter_slots_tile<T, false>(n, G, X, A, w, gidx, bnum, bcoord, slot, acceptor, max_cp, status, cnt, recs);
 }
 
 /* row sums of the count matrix (+ the buckets' overflow) -> X.bucket_tot, and per GPX_SL_ROWS buckets -> X.tile_rel
