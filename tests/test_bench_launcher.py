@@ -58,3 +58,11 @@ def test_world_and_flag_must_agree():
     env.update(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run-ranks"], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_same_device_flag_goes_through_the_launcher():
+    """`--gpus 2 --same-device` (round 5: N ranks on ONE GPU over gloo) is an ordinary launch as far as the launcher goes."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--same-device", "--dry-run-ranks"], capture_output=True, text=True,
+                       timeout=300, env=_env())
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert _line(r.stdout)["n_gpus"] == 2
