@@ -1014,11 +1014,13 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
   SlotArea& A = e->slot_area;
   if (!A.slots || e->slot_tile != T) {
     if (A.slots) return false; /* (one tile size per engine: the bucket geometry does not change) */
-    const size_t nwg_max = (N + (size_t)T - 1) / (size_t)T;
+    /* sized for the largest call this path takes (192 scatter workgroups), not for max_batch */
+    const size_t nwg_max = std::min<size_t>((N + (size_t)T - 1) / (size_t)T, 192);
     const size_t pad = (nwg_max + 15) / 16 * 16;
+    const size_t n_max = std::min<size_t>(N, nwg_max * (size_t)T); /* (every vote of a call can overflow: a skewed stream) */
     if (dev_alloc(e, &A.slots, (size_t)nbk * nwg_max * GPX_SL_SLOT, false) != GPX_OK ||
-        dev_alloc(e, &A.cntm, (size_t)nbk * pad, true) != GPX_OK || dev_alloc(e, &A.ovf_rec, N, false) != GPX_OK ||
-        dev_alloc(e, &A.ovf_bkt, N, false) != GPX_OK || dev_alloc(e, &A.ovf_n, 2, true) != GPX_OK ||
+        dev_alloc(e, &A.cntm, (size_t)nbk * pad, true) != GPX_OK || dev_alloc(e, &A.ovf_rec, n_max, false) != GPX_OK ||
+        dev_alloc(e, &A.ovf_bkt, n_max, false) != GPX_OK || dev_alloc(e, &A.ovf_n, 2, true) != GPX_OK ||
         dev_alloc(e, &A.ovf_cnt, (size_t)nbk, true) != GPX_OK) {
       A.slots = nullptr;
       e->ar_slots = false; /* no room: the partition front end from now on */
