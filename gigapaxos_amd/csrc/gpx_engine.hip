@@ -445,8 +445,8 @@ int check_batch(gpx_engine* h, int32_t n) {
   if (!h || n < 0) return GPX_EINVAL;
   if (n > h->cfg.max_batch) return GPX_ECAPACITY;
   if (h->h_abort && *(volatile uint32_t*)h->h_abort) {
-    /* a workgroup of an exchange kernel waited two seconds for workgroups that never became resident (somebody this
-     * process cannot see holds the device's CUs): that call applied only part of its batch */
+    /* a workgroup of a one-launch kernel waited two seconds at grid_exchange for workgroups that never became resident
+     * (somebody this process cannot see holds the device's CUs): that call applied only part of its batch */
     snprintf(g_err, sizeof(g_err), "an exchange kernel gave up waiting for its grid (call epoch %u): engine state is "
              "incomplete; set GPX_DEVICE_SHARERS to the number of processes sharing the device", *(volatile uint32_t*)h->h_abort);
     return GPX_EDEVICE;
@@ -454,11 +454,9 @@ int check_batch(gpx_engine* h, int32_t n) {
   return GPX_OK;
 }
 
-/* May an exchange kernel (one_exchange, k_ar_runs<.., SMALL>: its workgroups wait for each other's tickets) be
- * launched with `grid` workgroups of 256 threads?  Only if the grids of ALL live engines of this device (times the
- * processes sharing it) fit the device at once - then a partly resident grid can never wait for workgroups that
- * other waiters keep out.  Beyond the bound the caller takes the two-launch form of the same call. */
-int xchg_share(const gpx_engine* e) { /* engines (x processes) that may have an exchange kernel on the device at once */
+/* the streams (x processes) that may have a one-launch kernel - workgroups waiting for each other at grid_exchange -
+ * on this engine's device at the same moment */
+int xchg_share(const gpx_engine* e) {
   int live = 1;
   {
     std::lock_guard<std::mutex> lk(g_live_mu);
