@@ -63,7 +63,20 @@ def gen_round(args, streams, G, members, r, cfg_id, mix):
     """Round r of the synthetic accept-reply stream in the shape the run asked for (every leg draws from here)."""
     if args.runs:
         return streams.vote_round_runs(G, members, r, 100, config_id=cfg_id, mix=mix)
+    if stream_name(args, streams) == "survey-8d":
+        return streams.vote_round_survey(G, members, r, 100, config_id=cfg_id, shuffled=not args.sorted, mix=mix)
     return streams.vote_round(G, members, r, 100, config_id=cfg_id, shuffled=not args.sorted, mix=mix)
+
+
+def stream_name(args, streams):
+    """Which generator fills the rounds (reported as config.stream): SURVEY.md 8(d)'s own (xorshift64* + Fisher-Yates,
+    gigapaxos_amd/native/gpx_streams.c) unless --stream pcg64 asks for the numpy one the tests use or the small C
+    library was not built; the runs layout (--runs) has no shuffle to specify and stays with numpy."""
+    if args.runs:
+        return "pcg64-runs"
+    if args.stream == "survey" and streams.native_streams() is not None:
+        return "survey-8d"
+    return "pcg64"
 
 
 def link_peaks(torch, dev, eng, mbytes=64, reps=6):
@@ -441,6 +454,8 @@ def main():
                          "concatenated, what a coordinator really receives) under the GPX_ORDERED_REPLY_RUNS "
                          "promise - the sorted-runs path, no partition")
     ap.add_argument("--mix", action="store_true", help="adversarial mix (dups / stale / higher ballot)")
+    ap.add_argument("--stream", choices=("survey", "pcg64"), default="survey",
+                    help="survey: SURVEY.md 8(d)'s generator (xorshift64* + Fisher-Yates, in C); pcg64: the numpy one of the tests")
     ap.add_argument("--profile-steps", type=int, default=5)
     ap.add_argument("--cpu-rounds", type=int, default=8)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -790,6 +805,11 @@ def main():
                             % ("sorted" if args.sorted else "shuffled", " + adversarial mix" if args.mix else ""),
                 "groups_per_gpu": G, "groups_total": G_global if args.split_global else G * world,
                 "replicas": K, "votes_per_step_per_gpu": nv,
+                "stream": {"survey-8d": "SURVEY.md 8(d): xorshift64* seeded 0x9E3779B97F4A7C15 ^ (config << 32) ^ round, "
+                                        "Fisher-Yates per group and over the round (gigapaxos_amd/native/gpx_streams.c)",
+                           "pcg64": "numpy PCG64 with the same seed (gigapaxos_amd/streams.py vote_round)",
+                           "pcg64-runs": "numpy PCG64, K ascending runs (gigapaxos_amd/streams.py vote_round_runs)"
+                           }[stream_name(args, streams)],
                 "ordered_proposals_promise": not args.no_promise,
                 "ordered_batches_mask": CoordinatorLeg.promise_mask(args),
                 "parallelism": "groups sharded across GPUs, no collective on the decide path",
