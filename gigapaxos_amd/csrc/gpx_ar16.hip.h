@@ -384,6 +384,10 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     novf = A.ovf_cnt[b];
     novf_all = novf ? A.ovf_n[1] : 0;
   }
+  /* A short list (a shuffled stream leaves a record or two per call on it) is read whole by the few buckets that have
+   * anything there; a long one (a skewed or an unshuffled stream) through its segments.  The segments' directory alone
+   * costs such a bucket 192 LDS round trips per pass - 5 us on the kernel when ONE late workgroup pays them. */
+  const bool ovf_scan = novf_all <= GPX_SL_SCAN;
   if (nb == 0) return;
   const int32_t gb = X.gb; /* == blockDim.x: one lane per group */
   const int32_t l = (int32_t)threadIdx.x;
@@ -434,6 +438,27 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
       }
     }
   }
+  /* this bucket's part of every scatter workgroup's overflow segment: offset in the segment << 14 | records */
+  __shared__ uint32_t s_ovf[SLOTS ? GPX_SL_MAXWG : 1];
+  if (SLOTS && novf && !ovf_scan) { /* (the same for every lane: the count is cleared at the end of the kernel) */
+    for (int32_t w = l; w < A.nwg; w += gb) {
+      const int32_t len = A.ovf_seg[GPX_SL_MAXWG + w];
+      const int32_t* sb = A.ovf_bkt + A.ovf_seg[w];
+      int32_t lo = 0, hi = len;
+      while (lo < hi) {
+        const int32_t mid = (lo + hi) >> 1;
+        if (sb[mid] < b) lo = mid + 1; else hi = mid;
+      }
+      int32_t up = lo;
+      hi = len;
+      while (up < hi) {
+        const int32_t mid = (up + hi) >> 1;
+        if (sb[mid] <= b) up = mid + 1; else hi = mid;
+      }
+      s_ovf[w] = ((uint32_t)lo << 14) | (uint32_t)(up - lo);
+    }
+    __syncthreads();
+  }
   auto each_slot_record = [&](auto f) {
     const uint8_t* crow = A.cntm + (int64_t)b * A.nwg_pad;
 #pragma unroll
@@ -458,7 +483,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
         f(v);
       }
     }
-    if (novf)
+    if (novf && ovf_scan)
       for (int32_t e = l; e < novf_all; e += gb)
         if (A.ovf_bkt[e] == b) {
           const I4 x = A.ovf_rec[e];
@@ -466,6 +491,19 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
           v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
           f(v);
         }
+    if (novf && !ovf_scan)
+      for (int32_t w = 0; w < A.nwg; w++) {
+        const uint32_t sg = s_ovf[w];
+        const int32_t m = (int32_t)(sg & 0x3fffu);
+        if (!m) continue;
+        const I4* r = A.ovf_rec + A.ovf_seg[w] + (int32_t)(sg >> 14);
+        for (int32_t e = l; e < m; e += gb) {
+          const I4 x = r[e];
+          Vote16 v;
+          v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
+          f(v);
+        }
+      }
   };
   if (SLOTS && !in_lds) {
     /* too many records for the LDS staging (a skewed stream): copy them into this bucket's region of X.rec and go on as

@@ -1007,18 +1007,19 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
   /* ... and at most 192 scatter workgroups: the per-bucket kernel keeps the slots of three rounds of its lane groups in
    * registers; beyond (five replicas at 1 M groups: 306) its second reading of the slots costs what the scatter saved
    * (0.181 against 0.178 ms per step, profiles/r05_slots_front_end.txt) */
-  if (!T || nbk > GPX_MAX_BUCKETS || n < 8 * T || e->shift16 > 10 || (n + T - 1) / T > 192) return false;
+  if (!T || nbk > GPX_MAX_BUCKETS || n < 8 * T || e->shift16 > 10 || (n + T - 1) / T > GPX_SL_MAXWG) return false;
   const size_t N = (size_t)e->cfg.max_batch;
   SlotArea& A = e->slot_area;
   if (!A.slots || e->slot_tile != T) {
     if (A.slots) return false; /* (one tile size per engine: the bucket geometry does not change) */
     /* sized for the largest call this path takes (192 scatter workgroups), not for max_batch */
-    const size_t nwg_max = std::min<size_t>((N + (size_t)T - 1) / (size_t)T, 192);
+    const size_t nwg_max = std::min<size_t>((N + (size_t)T - 1) / (size_t)T, GPX_SL_MAXWG);
     const size_t pad = (nwg_max + 15) / 16 * 16;
     const size_t n_max = std::min<size_t>(N, nwg_max * (size_t)T); /* (every vote of a call can overflow: a skewed stream) */
     if (dev_alloc(e, &A.slots, (size_t)nbk * nwg_max * GPX_SL_SLOT, false) != GPX_OK ||
         dev_alloc(e, &A.cntm, (size_t)nbk * pad, true) != GPX_OK || dev_alloc(e, &A.ovf_rec, n_max, false) != GPX_OK ||
         dev_alloc(e, &A.ovf_bkt, n_max, false) != GPX_OK || dev_alloc(e, &A.ovf_n, 2, true) != GPX_OK ||
+        dev_alloc(e, &A.ovf_seg, 2 * GPX_SL_MAXWG, true) != GPX_OK ||
         dev_alloc(e, &A.ovf_cnt, (size_t)nbk, true) != GPX_OK) {
       A.slots = nullptr;
       e->ar_slots = false; /* no room: the partition front end from now on */
@@ -1029,7 +1030,10 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
     const size_t lds = (size_t)((nbk + 3) & ~3) * 4 + (size_t)T * sizeof(Vote8);
     HIPQ(hipFuncSetAttribute((const void*)k_scatter_slots<16384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     HIPQ(hipFuncSetAttribute((const void*)k_scatter_slots<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    const size_t hw16 = GPX_BUCKET16_LDS_BYTES((size_t)1 << e->shift16, e->lds16_hw) + e->lds_pad;
+    /* (these two keep 1.1 KB of static LDS - the overflow segments' directory -, and a call of this path stages
+     * 45 KB at most: 192 x 16,384 votes over 820 buckets) */
+    const size_t hw16 = std::min<size_t>(GPX_BUCKET16_LDS_BYTES((size_t)1 << e->shift16, e->lds16_hw) + e->lds_pad,
+                                         (size_t)158 * 1024);
     HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_slots, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
     HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_k5_slots, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
   }
@@ -1042,6 +1046,10 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
   e->X.nbk = nbk;
   e->bucket_threads = e->X.gb;
   begin_back(e, 0, n, true);
+  if (e->bucket_lds > (size_t)158 * 1024) { /* (not reachable inside this path's range; the static LDS must fit) */
+    e->X.lds_recs = (int32_t)(((size_t)158 * 1024 - e->lds_pad - (size_t)e->X.gb * 8) / 16);
+    e->bucket_lds = GPX_BUCKET16_LDS_BYTES(e->X.gb, e->X.lds_recs) + e->lds_pad;
+  }
   const size_t lds = (size_t)((nbk + 3) & ~3) * 4 + (size_t)T * sizeof(Vote8);
   {
     LaunchScope _ls(e, "k_scatter_slots");

@@ -32,6 +32,8 @@
 #include "gpx_kernels.hip.h"
 
 #define GPX_SL_SLOT 24 /* records per (bucket, workgroup) slot: three 64-byte lines */
+#define GPX_SL_MAXWG 192 /* scatter workgroups of a call at most (the engine routes larger calls elsewhere) */
+#define GPX_SL_SCAN 2048 /* an overflow list up to this long is read whole by the buckets that have records on it */
 struct __attribute__((aligned(8))) Vote8 {
   uint32_t a; /* offset of the vote in its workgroup's tile (14 bits) | local group << 14 (10 bits) | ESC << 31 */
   uint32_t b; /* slot - slot0 + 128 (8 bits) | (slot - 1 - max_cp + 128) << 8 (8 bits) | acceptor << 16 */
@@ -40,8 +42,14 @@ struct __attribute__((aligned(8))) Vote8 {
 struct SlotArea {
   Vote8* slots;     /* [nbk][nwg][GPX_SL_SLOT] */
   uint8_t* cntm;    /* [nbk][nwg_pad] records in each slot (at most GPX_SL_SLOT: the rest overflowed) */
+  /* The overflow list: ONE segment per scatter workgroup (reserved with one atomic, the records of a segment in bucket
+   * order: the tails of the tile's sorted runs), so that a bucket finds its records with a binary search per segment
+   * and a stream that is NOT shuffled - sorted by group, a few ascending runs: nearly every vote overflows - costs
+   * in proportion to its votes.  (The first form appended record by record and every bucket scanned the whole list:
+   * 10.5 ms per step on bench.py --sorted, the scatter 0.93 ms of it in the list's counter.) */
   I4* ovf_rec;      /* [max_batch] overflow records, as Vote16 */
-  int32_t* ovf_bkt; /* [max_batch] their buckets */
+  int32_t* ovf_bkt; /* [max_batch] their buckets (ascending inside a segment) */
+  int32_t* ovf_seg; /* [2][GPX_SL_MAXWG] where workgroup w's segment starts; its length */
   int32_t* ovf_n;   /* [2] overflow records of the call (k_scatter_slots adds; k_slot_totals moves it to word 1 and clears) */
   int32_t* ovf_cnt; /* [nbk] overflow records per bucket (cleared by the per-bucket kernel) */
   int32_t nwg, nwg_pad, tile; /* scatter workgroups of this call, the count matrix's row stride, votes per workgroup */
@@ -137,21 +145,31 @@ __device__ __forceinline__ void scatter_slots_tile(int32_t n, int32_t G, const D
   /* exclusive scan of the counts -> local bases; this workgroup's column of the count matrix */
   const int32_t per = (nbk + GPX_FBLOCK - 1) / GPX_FBLOCK; /* <= 4: at most 4096 buckets */
   const int32_t bq = (int32_t)threadIdx.x * per;
+  /* (two scans in one word: the records before a bucket in the low half, of those the ones beyond their slots - the
+   * bucket's place in this workgroup's overflow segment - in the high half; a tile has at most 16,384 of either) */
   int32_t v[4], s = 0;
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     v[q] = (q < per && bq + q < nbk) ? cnt[bq + q] : 0;
-    s += v[q];
+    s += v[q] + (max(v[q] - GPX_SL_SLOT, 0) << 16);
   }
-  int32_t tot;
-  int32_t ex = block_exscan_n<GPX_FBLOCK>(s, &tot);
+  int32_t tot2;
+  int32_t ex = block_exscan_n<GPX_FBLOCK>(s, &tot2);
 #pragma unroll
   for (int q = 0; q < 4; q++)
     if (q < per && bq + q < nbk) {
       cnt[bq + q] = ex;
-      ex += v[q];
+      ex += v[q] + (max(v[q] - GPX_SL_SLOT, 0) << 16);
       A.cntm[(int64_t)(bq + q) * A.nwg_pad + w] = (uint8_t)min(v[q], GPX_SL_SLOT);
     }
+  const int32_t tot = tot2 & 0xffff, wovf = tot2 >> 16;
+  __shared__ int32_t s_seg0;
+  if (threadIdx.x == 0) { /* this workgroup's segment of the overflow list (empty on a shuffled stream) */
+    const int32_t p0 = wovf ? atomicAdd(A.ovf_n, wovf) : 0;
+    A.ovf_seg[w] = p0;
+    A.ovf_seg[GPX_SL_MAXWG + w] = wovf;
+    s_seg0 = p0;
+  }
   __syncthreads();
   /* phase 2: the tile, sorted by bucket, as 8-byte records in LDS; two vectors' worth of columns in flight at a time */
 #pragma unroll
@@ -182,24 +200,25 @@ __device__ __forceinline__ void scatter_slots_tile(int32_t n, int32_t G, const D
         Vote8 r;
         r.a = (uint32_t)(i0 + q - (int64_t)w * T) | ((uint32_t)(g & mask) << 14) | (esc ? V8_ESC : 0u);
         r.b = esc ? 0u : (dslot | (dcp << 8) | ((uint32_t)aa[q] << 16));
-        recs[cnt[g >> shift] + rk[k * 4 + q]] = r;
+        recs[(cnt[g >> shift] & 0xffff) + rk[k * 4 + q]] = r;
       }
     }
   }
   __syncthreads();
   /* every bucket's run leaves in order: eight lanes per bucket, a 64-byte line per step */
+  const int32_t seg0 = s_seg0;
   for (int32_t b = (int32_t)threadIdx.x >> 3; b < nbk; b += GPX_FBLOCK >> 3) {
-    const int32_t base = cnt[b];
-    const int32_t c = (b + 1 < nbk ? cnt[b + 1] : tot) - base;
+    const int32_t base = cnt[b] & 0xffff;
+    const int32_t c = (b + 1 < nbk ? cnt[b + 1] & 0xffff : tot) - base;
     Vote8* sl = A.slots + ((int64_t)b * A.nwg + w) * GPX_SL_SLOT;
     for (int32_t j = (int32_t)threadIdx.x & 7; j < c; j += 8) {
       if (j < GPX_SL_SLOT) {
         sl[j] = recs[base + j];
-      } else { /* the slot is full: the tail of the run goes to the overflow list (a skewed stream) */
-        const int32_t p = atomicAdd(A.ovf_n, 1);
+      } else { /* the slot is full: the tail of the run goes to this workgroup's segment of the overflow list */
+        const int32_t p = seg0 + (cnt[b] >> 16) + j - GPX_SL_SLOT;
         A.ovf_rec[p] = slot_expand(recs[base + j], w, T, slot0, slot, max_cp);
         A.ovf_bkt[p] = b;
-        atomicAdd(&A.ovf_cnt[b], 1);
+        if (j == GPX_SL_SLOT) atomicAdd(&A.ovf_cnt[b], c - GPX_SL_SLOT);
       }
     }
   }
