@@ -13,9 +13,10 @@
  *                        (bucket, workgroup): no histogram pass, no reservation, no atomics on shared words; eight
  *                        lanes write a run, so it leaves as one to three full lines.  A count byte per (bucket,
  *                        workgroup) says how many records the slot holds; a run longer than the slot puts its tail
- *                        on an overflow list (a returning atomic per record: a skewed stream pays, a stream like
- *                        BASELINE's has none - Poisson mean 8.4 against 24).  Also what k_hist did on the side:
- *                        status prefill, the vote and dropped counters.
+ *                        on the overflow list, in the workgroup's own segment of it (a stream like BASELINE's has
+ *                        a record or two there per call - Poisson mean 8.4 against 24 -, a stream sorted by group
+ *                        nearly all its votes: see SlotArea).  Also what k_hist did on the side: status prefill, the
+ *                        vote and dropped counters.
  *   k_slot_totals        row sums of the count matrix (+ overflow per bucket) -> X.bucket_tot; the per-bucket kernel sums
  *                        what lies before its bucket and from there on everything - its regions in X.rec / X.perm / the
  *                        output staging, k_emit_dec16 - is what it was.
