@@ -118,3 +118,36 @@ def test_skewed_stream_overflow_and_big_bucket(hip_lib, oracle_lib, hot_votes):
     assert eh.counters() == eo.counters()
     eh.close()
     eo.close()
+
+
+def test_unshuffled_streams_through_the_overflow_segments(hip_lib, oracle_lib):
+    """Streams that are NOT shuffled, sent without a hint: votes sorted by group (a tile of 16,384 votes covers eleven
+    buckets, nearly every vote leaves its slot for the workgroup's overflow segment, every bucket finds its records
+    there by binary search), the three acceptors' ascending runs with the adversarial mix inside (a tile covers 32
+    buckets), and the sorted stream with the mix.  The slotted kernels must have taken them - not the runs kernel."""
+    G, k = 1_000_000, 3
+    members = [100, 101, 102]
+    eh, eo = make_pair(hip_lib, oracle_lib, 100, G, k, 8, max_batch=3 * G + 3 * G // 25 + 4096)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 100)) == S_OK).all()
+    g = np.arange(G, dtype=np.int32)
+    eh.profile(2)
+    rounds = [lambda r: streams.vote_round(G, members, r, 100, config_id=3, shuffled=False),
+              lambda r: streams.vote_round_runs(G, members, r, 100, config_id=3, mix=True),
+              lambda r: streams.vote_round(G, members, r, 100, config_id=3, shuffled=False, mix=True)]
+    for r, gen in enumerate(rounds):
+        for x, y in zip(eh.propose(g), eo.propose(g)):
+            assert (x == y).all()
+        cols = gen(r)
+        if r == 0:
+            assert (np.diff(cols[0]) >= 0).all()
+        dh, do = eh.accept_reply(*cols), eo.accept_reply(*cols)
+        _same(dh, do, f"round {r}")
+    prof = eh.profile_read()
+    assert "k_scatter_slots" in prof and not any(name.startswith("k_ar_runs") for name in prof), prof
+    assert eh.snapshot(g)[0].tobytes() == eo.snapshot(g)[0].tobytes()
+    assert_same_state(eh, eo, np.random.default_rng(5).integers(0, G, 64))
+    assert eh.counters() == eo.counters()
+    eh.close()
+    eo.close()
