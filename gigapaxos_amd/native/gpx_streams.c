@@ -28,7 +28,7 @@ static inline uint64_t xs_below(uint64_t* s, uint64_t m) { return (uint64_t)(((u
 /* columns of capacity gpx_stream_capacity(G, K, mix); returns the number of votes written */
 int64_t gpx_stream_capacity(int64_t G, int32_t K, int32_t mix) {
   const int64_t n = G * (int64_t)K;
-  if (!mix) return n;
+  if (!mix || n <= 0) return n > 0 ? n : 0;
   const int64_t nd = n / 100 > 0 ? n / 100 : 1, ns = n / 200 > 0 ? n / 200 : 1, nh = n / 1000 > 0 ? n / 1000 : 1;
   return n + nd + ns + nh;
 }

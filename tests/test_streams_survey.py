@@ -74,6 +74,12 @@ def test_mix_counts():
     assert int((cols[2] == 99).sum()) == n // 200 and int((cols[1] == 1).sum()) == n // 1000
 
 
+def test_empty_round():
+    for mix in (False, True):
+        cols = streams.vote_round_survey(0, [100, 101, 102], 0, 100, mix=mix)
+        assert all(c.shape == (0,) for c in cols)
+
+
 def test_churn_groups_column():
     """`groups`: the round covers these group indices instead of 0..G-1 (the churn configuration's live set)."""
     live = np.arange(5, 5000, 7, dtype=np.int32)
