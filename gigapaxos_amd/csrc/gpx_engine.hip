@@ -854,6 +854,8 @@ int gpx_host_register(gpx_engine* h, void* ptr, size_t bytes) {
  * engine has drained.  The tickets stay valid - gpx_engine_wait on them returns at once afterwards. */
 int gpx_host_unregister(gpx_engine* h, void* ptr) {
   if (!h || !ptr) return GPX_EINVAL;
+  if (std::find(h->host_blocks.begin(), h->host_blocks.end(), ptr) != h->host_blocks.end())
+    return GPX_EINVAL; /* a gpx_host_alloc block: gpx_host_free gives it back */
   drain_all(h);
   HIPCHK(hipGetLastError());
   HIPCHK(hipHostUnregister(ptr));

@@ -169,7 +169,8 @@ int gpx_host_unregister(gpx_engine* h, void* ptr);
 /*
  * Host memory allocated FOR the DMA engines (hipHostMalloc) instead of pinned afterwards: what a JNI host wraps
  * with NewDirectByteBuffer for its batch columns.  Treated like a registered block by every
- * entry point; gpx_host_free (which waits like gpx_host_unregister) or gpx_engine_destroy gives it back.
+ * entry point; gpx_host_free (which waits like gpx_host_unregister) or gpx_engine_destroy gives it back
+ * (gpx_host_unregister on such a block: GPX_EINVAL).
  * bench.py's end_to_end.link reports what either kind of memory reaches on the box.
  */
 int gpx_host_alloc(gpx_engine* h, size_t bytes, void** out);
