@@ -47,6 +47,19 @@ def pin_to_gpu_numa_node(device_index: int):
     return None
 
 
+def csrc_sha16() -> str:
+    """Fingerprint of the kernel sources (gigapaxos_amd/csrc/*.hip, *.h, *.inc): profiles/pmc_traffic.meta.json holds the
+    one the committed counter passes were taken on, so that a line can say whether its `traffic` is this library's."""
+    import hashlib
+    d = os.path.join(ROOT, "gigapaxos_amd", "csrc")
+    h = hashlib.sha256()
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".hip", ".h", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def alg_bytes_per_vote(k: int) -> float:
     """A(K) = 48 + 4K + 20/K bytes per accept-reply vote."""
     return 48.0 + 4.0 * k + 20.0 / k
@@ -477,10 +490,19 @@ def main():
                     help="N > 1 on a box with ONE GPU: every rank runs on device 0 and the ranks talk over gloo.  Runs "
                          "the whole N > 1 code path (two timed legs, max-over-ranks, the counters' all_gather); the "
                          "figures are N processes sharing one GPU - NOT a scaling measurement")
+    ap.add_argument("--stamp-traffic", action="store_true",
+                    help="write profiles/pmc_traffic.meta.json for the current kernel sources (after refreshing "
+                         "profiles/pmc_traffic.json from `scripts/gpu_visit.sh TAG traffic`) and exit")
     ap.add_argument("--e2e-memory", choices=("registered", "hostmalloc"), default="hostmalloc",
                     help="host buffers of the end-to-end leg: numpy pages pinned with gpx_host_register, or memory "
                          "from gpx_host_alloc (hipHostMalloc)")
     args = ap.parse_args()
+    if args.stamp_traffic:
+        meta = {"csrc_sha16": csrc_sha16(), "what": "fingerprint of gigapaxos_amd/csrc/*.hip, *.h, *.inc at the time "
+                "profiles/pmc_traffic.json's counter passes were taken (bench.py csrc_sha16)"}
+        json.dump(meta, open(os.path.join(ROOT, "profiles", "pmc_traffic.meta.json"), "w"), indent=1)
+        print(json.dumps(meta))
+        return 0
 
     world_env = os.environ.get("WORLD_SIZE")
     if world_env is None and args.gpus > 1:
@@ -572,8 +594,14 @@ def main():
         # correction of MI355X_MICROARCH.md section HBM).  Only the headline shape has such a file.
         traffic = traffic_raw = traffic_call = None
         traffic_call_kernels = None
+        traffic_same_source = None
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))
+            try:  # were the committed passes taken on THESE kernel sources?  (stamped by bench.py --stamp-traffic)
+                meta = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.meta.json")))
+                traffic_same_source = meta.get("csrc_sha16") == csrc_sha16()
+            except (OSError, ValueError):
+                pass
 
             def pmc_of(name):
                 kname = PMC_ALIAS.get(name, name)
@@ -596,6 +624,9 @@ def main():
             "traffic_source": None if traffic is None else
             "profiles/pmc_traffic.json: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command "
             "(scripts/gpu_visit.sh TAG traffic), not counted in this run",
+            # True: the passes were taken on the kernel sources this library was built from; False: a kernel source has
+            # changed since (re-run the passes); None: no stamp
+            "traffic_taken_on_these_kernel_sources": None if traffic is None else traffic_same_source,
             "avg_kernel_ms": round(avg_ms, 4), "alg_bytes_per_launch": int(alg),
             # `frac` is the prescribed per-kernel figure: the whole call's algorithmic bytes over ONE kernel's time.
             # The unit - one accept-reply vote - is finished by all kernels of its call: `call_frac` divides the

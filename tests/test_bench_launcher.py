@@ -66,3 +66,15 @@ def test_same_device_flag_goes_through_the_launcher():
                        timeout=300, env=_env())
     assert r.returncode == 0, r.stderr[-2000:]
     assert _line(r.stdout)["n_gpus"] == 2
+
+
+def test_traffic_stamp_is_a_source_fingerprint():
+    """profiles/pmc_traffic.meta.json (bench.py --stamp-traffic): the fingerprint of the kernel sources the committed
+    counter passes were taken on, in the form bench.py compares its own tree with."""
+    import json
+    import re
+    import bench
+    here = bench.csrc_sha16()
+    assert re.fullmatch(r"[0-9a-f]{16}", here)
+    meta = json.load(open(os.path.join(bench.ROOT, "profiles", "pmc_traffic.meta.json")))
+    assert re.fullmatch(r"[0-9a-f]{16}", meta["csrc_sha16"])
