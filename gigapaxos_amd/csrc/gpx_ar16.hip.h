@@ -26,7 +26,7 @@
  */
 #pragma once
 #include "gpx_kernels.hip.h"
-#include "gpx_slots.hip.h"
+#include "gpx_tiles.hip.h"
 
 struct __attribute__((aligned(16))) Vote16 {
   int32_t idx, slot, maxcp;
@@ -52,7 +52,7 @@ struct Stage16 { /* one block of six columns n apart (five of int32, one of byte
 /* the caller's vote columns the ESC path reads, and the batch's common ballot = ballot of vote 0 */
 struct VoteCols {
   const int32_t *bnum, *bcoord, *acceptor;
-  const int32_t *slot, *maxcp; /* the slotted front end's escape path (gpx_slots.hip.h) */
+  const int32_t *slot, *maxcp; /* the tiled front end's escape path (gpx_tiles.hip.h) */
 };
 
 __device__ __forceinline__ void put_vote16(const DevScratch& X, int32_t* lds, int32_t G, int32_t mask,
@@ -355,18 +355,59 @@ struct AcceptOut {
 #define B16_AR 0     /* accept replies at the coordinator */
 #define B16_ACCEPT 1 /* ACCEPTs at an acceptor */
 #define B16_COMMIT 2 /* commits at every replica */
-template <int OP, int KMAX, bool SLOTS = false>
+template <int OP, int KMAX, bool TILES = false>
 __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratch& X, const Stage16& O, const VoteCols& in,
-                                              const AcceptOut& R, uint8_t* __restrict__ status, const SlotArea& A = SlotArea{}) {
+                                              const AcceptOut& R, uint8_t* __restrict__ status, const TileArea& A = TileArea{}) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   constexpr bool AC = OP != B16_AR;
   /* ordered batch: k_ac_direct did it (a few sorted runs of votes: k_ar_runs); nothing was partitioned */
   if ((AC || X.gate) && *X.unsorted != X.epoch) return;
-  const int32_t b = blockIdx.x;
+  int32_t b = blockIdx.x;
+  if (TILES && A.xcd_rows) { /* consecutive buckets on one XCD (block i runs on XCD i % 8): they share lines of A.off / A.recs */
+    b = tile_of_block(X.nbk);
+    if (b >= X.nbk) return;
+  }
+  const int32_t gb = X.gb; /* == blockDim.x: one lane per group */
+  const int32_t l = (int32_t)threadIdx.x;
   int32_t boff, nb;
-  if (SLOTS) { /* no k_hist, no scanned offsets: the records before this bucket are summed here (gpx_slots.hip.h) */
-    boff = slot_bucket_offset(X, b, &nb);
-    if (threadIdx.x == 0) {
+  /* TILES (gpx_tiles.hip.h): the run of every tile in this bucket - where it starts in the tile (| TL_WIDE) and the
+   * exclusive prefix of the run lengths, what turns a record's index in the bucket into (tile, position) */
+  __shared__ int32_t s_pre[TILES ? GPX_TL_MAXWG + 1 : 1];
+  __shared__ uint16_t s_st[TILES ? GPX_TL_MAXWG : 1];
+  if (TILES) TL_STAMP(4096 + b, 0);
+  if (TILES) { /* no k_hist, no scanned offsets: rows b and b + 1 of A.off say everything */
+    /* A.off is [bucket / 4][tile][4]: this bucket's start and the next one's - the same 8-byte entry three times in four */
+    const unsigned long long* r0 = (const unsigned long long*)A.off + (uint32_t)(b >> 2) * (uint32_t)A.nwg_pad;
+    const unsigned long long* r1 = (const unsigned long long*)A.off + (uint32_t)((b + 1) >> 2) * (uint32_t)A.nwg_pad;
+    const int32_t per = (A.nwg + gb - 1) / gb; /* <= 4: at most 1024 tiles, at least 256 lanes */
+    int32_t cw[4], ssum = 0, csum = 0;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int32_t w = l * per + q;
+      cw[q] = 0;
+      if (q < per && w < A.nwg) {
+        const unsigned long long e0 = r0[w];
+        const unsigned long long e1 = ((b & 3) == 3) ? r1[w] : e0;
+        const uint16_t o0 = (uint16_t)(e0 >> (16 * (b & 3))), o1 = (uint16_t)(e1 >> (16 * ((b + 1) & 3)));
+        const int32_t st = (int32_t)(o0 & 0x7fffu);
+        cw[q] = (int32_t)(o1 & 0x7fffu) - st;
+        s_st[w] = o0;
+        ssum += st;
+        csum += cw[q];
+      }
+    }
+    /* (the starts add up to the records of the buckets before this one) */
+    int32_t ex = block_exscan_and_sum_rt(csum, ssum, &nb, &boff);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int32_t w = l * per + q;
+      if (q < per && w < A.nwg) {
+        s_pre[w] = ex;
+        ex += cw[q];
+      }
+    }
+    if (l == 0) {
+      s_pre[A.nwg] = nb;
       X.bucket_off[b] = boff; /* where k_emit_dec16 finds this bucket's staged outputs */
       if (nb == 0) X.bucket_nout[b] = 0;
     }
@@ -378,19 +419,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
       if (nb == 0) X.bucket_nout[b] = 0;
     }
   }
-  int32_t novf = 0; /* SLOTS: this bucket's records on the overflow list, and the list's length */
-  int32_t novf_all = 0;
-  if (SLOTS) {
-    novf = A.ovf_cnt[b];
-    novf_all = novf ? A.ovf_n[1] : 0;
-  }
-  /* A short list (a shuffled stream leaves a record or two per call on it) is read whole by the few buckets that have
-   * anything there; a long one (a skewed or an unshuffled stream) through its segments.  The segments' directory alone
-   * costs such a bucket 192 LDS round trips per pass - 5 us on the kernel when ONE late workgroup pays them. */
-  const bool ovf_scan = novf_all <= GPX_SL_SCAN;
   if (nb == 0) return;
-  const int32_t gb = X.gb; /* == blockDim.x: one lane per group */
-  const int32_t l = (int32_t)threadIdx.x;
   const int32_t g = X.g_base + (b << X.shift) + l;
   /* coordinator state of a dense batch: issued now, consumed after the regrouping */
 #ifdef GPX_B16_NOPRELOAD /* tuning build: state fetched after the regrouping (fewer live registers) */
@@ -413,105 +442,34 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   Vote16* recG = (Vote16*)X.rec + boff;
   unsigned long long* keysG = X.perm + boff;
   lcnt[l] = 0;
-  /* SLOTS (gpx_slots.hip.h): the bucket's records are the used entries of its nwg slots - eight lanes per slot, a
-   * 64-byte line per step - and whatever of it is on the overflow list */
-  const int32_t slot0 = SLOTS ? in.slot[0] : 0;
-  /* The first GPX_SL_REG slots of a lane group (all of them up to 64 * GPX_SL_REG scatter workgroups: 3.1 M votes) are
-   * fetched ONCE, whole and unconditionally - count byte and the lane's three entries together, nothing waits for the
-   * count - and stay in registers for the count pass and the placement; entries beyond the count are garbage nobody
-   * looks at.  (Round 5's first form read count, then entries, twice: twelve dependent round trips, +17 us.) */
-  constexpr int GPX_SL_REG = 3;
-  int32_t rcw[GPX_SL_REG];
-  Vote8 rv[GPX_SL_REG][3];
-  if (SLOTS) {
-    const uint8_t* crow = A.cntm + (int64_t)b * A.nwg_pad;
-#pragma unroll
-    for (int t = 0; t < GPX_SL_REG; t++) {
-      const int32_t w = (l >> 3) + t * (gb >> 3);
-      rcw[t] = 0;
-      if (w < A.nwg) {
-        rcw[t] = crow[w];
-        const Vote8* sl = A.slots + ((int64_t)b * A.nwg + w) * GPX_SL_SLOT + (l & 7);
-        rv[t][0] = sl[0];
-        rv[t][1] = sl[8];
-        rv[t][2] = sl[16];
-      }
+  /* the batch's reference vote (gpx_tiles.hip.h): ballot of the 8-byte records, base of their slot bytes */
+  const int32_t slot0 = TILES ? A.ref[0] : 0;
+  const int32_t ref_bn = TILES ? A.ref[1] : in.bnum[0], ref_bc = TILES ? A.ref[2] : in.bcoord[0];
+  int32_t srch = 0; /* steps of the search over s_pre */
+  if (TILES)
+    while ((1 << srch) < A.nwg) srch++;
+  /* record j of the bucket (TILES): the largest tile w with s_pre[w] <= j holds it at s_st[w] + j - s_pre[w] */
+  auto tile_rec = [&](int32_t j) -> Vote16 {
+    int32_t lo = 0, hi = A.nwg;
+    for (int32_t t = 0; t < srch; t++) { /* s_pre[lo] <= j < s_pre[hi]; neighbours: mid == lo, nothing moves */
+      const int32_t mid = (lo + hi) >> 1;
+      const bool up = s_pre[mid] <= j;
+      lo = up ? mid : lo;
+      hi = up ? hi : mid;
     }
-  }
-  /* this bucket's part of every scatter workgroup's overflow segment: offset in the segment << 14 | records */
-  __shared__ uint32_t s_ovf[SLOTS ? GPX_SL_MAXWG : 1];
-  if (SLOTS && novf && !ovf_scan) { /* (the same for every lane: the count is cleared at the end of the kernel) */
-    for (int32_t w = l; w < A.nwg; w += gb) {
-      const int32_t len = A.ovf_seg[GPX_SL_MAXWG + w];
-      const int32_t* sb = A.ovf_bkt + A.ovf_seg[w];
-      int32_t lo = 0, hi = len;
-      while (lo < hi) {
-        const int32_t mid = (lo + hi) >> 1;
-        if (sb[mid] < b) lo = mid + 1; else hi = mid;
-      }
-      int32_t up = lo;
-      hi = len;
-      while (up < hi) {
-        const int32_t mid = (up + hi) >> 1;
-        if (sb[mid] <= b) up = mid + 1; else hi = mid;
-      }
-      s_ovf[w] = ((uint32_t)lo << 14) | (uint32_t)(up - lo);
-    }
-    __syncthreads();
-  }
-  auto each_slot_record = [&](auto f) {
-    const uint8_t* crow = A.cntm + (int64_t)b * A.nwg_pad;
-#pragma unroll
-    for (int t = 0; t < GPX_SL_REG; t++) {
-      const int32_t w = (l >> 3) + t * (gb >> 3);
-#pragma unroll
-      for (int q = 0; q < 3; q++)
-        if ((l & 7) + 8 * q < rcw[t]) {
-          const I4 x = slot_expand(rv[t][q], w, A.tile, slot0, in.slot, in.maxcp);
-          Vote16 v;
-          v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
-          f(v);
-        }
-    }
-    for (int32_t w = (l >> 3) + GPX_SL_REG * (gb >> 3); w < A.nwg; w += gb >> 3) {
-      const int32_t cw = crow[w];
-      const Vote8* sl = A.slots + ((int64_t)b * A.nwg + w) * GPX_SL_SLOT;
-      for (int32_t j = l & 7; j < cw; j += 8) {
-        const I4 x = slot_expand(sl[j], w, A.tile, slot0, in.slot, in.maxcp);
-        Vote16 v;
-        v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
-        f(v);
-      }
-    }
-    if (novf && ovf_scan)
-      for (int32_t e = l; e < novf_all; e += gb)
-        if (A.ovf_bkt[e] == b) {
-          const I4 x = A.ovf_rec[e];
-          Vote16 v;
-          v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
-          f(v);
-        }
-    if (novf && !ovf_scan)
-      for (int32_t w = 0; w < A.nwg; w++) {
-        const uint32_t sg = s_ovf[w];
-        const int32_t m = (int32_t)(sg & 0x3fffu);
-        if (!m) continue;
-        const I4* r = A.ovf_rec + A.ovf_seg[w] + (int32_t)(sg >> 14);
-        for (int32_t e = l; e < m; e += gb) {
-          const I4 x = r[e];
-          Vote16 v;
-          v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
-          f(v);
-        }
-      }
+    const uint32_t st = s_st[lo];
+    const int64_t p = (int64_t)lo * A.tile + (int32_t)(st & 0x7fffu) + (j - s_pre[lo]);
+    const I4 x = tile_expand(A.recs[p], (st & TL_WIDE) ? A.ext + p : (const int2*)nullptr, lo, A.tile, slot0, in.slot, in.maxcp);
+    Vote16 v;
+    v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
+    return v;
   };
-  if (SLOTS && !in_lds) {
+  if (TILES) __syncthreads(); /* s_pre / s_st */
+  if (TILES) TL_STAMP(4096 + b, 1); /* rows of A.off read and scanned */
+  if (TILES && !in_lds) {
     /* too many records for the LDS staging (a skewed stream): copy them into this bucket's region of X.rec and go on as
-     * the partition path does (the count pass below also reads that region) */
-    __shared__ int32_t s_pos;
-    if (l == 0) s_pos = 0;
-    __syncthreads();
-    each_slot_record([&](const Vote16& v) { recG[atomicAdd(&s_pos, 1)] = v; });
+     * the partition path does (the count pass below reads that region) */
+    for (int32_t j = l; j < nb; j += gb) recG[j] = tile_rec(j);
     __threadfence_block();
   }
   __syncthreads();
@@ -521,21 +479,22 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   r0.idx = r1.idx = r2.idx = r3.idx = 0;
   r0.slot = r1.slot = r2.slot = r3.slot = 0;
   r0.maxcp = r1.maxcp = r2.maxcp = r3.maxcp = 0;
-  if (SLOTS && in_lds) {
-    each_slot_record([&](const Vote16& v) { atomicAdd(&lcnt[v.meta & V16_LG_MASK], 1); });
-  } else {
+  {
+    const bool from_tiles = TILES && in_lds; /* (beyond the LDS staging the records were just copied to recG) */
+    auto rec_at = [&](int32_t j) -> Vote16 { return from_tiles ? tile_rec(j) : recG[j]; };
     const int32_t j0 = l, j1 = gb + l, j2 = 2 * gb + l, j3 = 3 * gb + l;
-    if (j0 < nb) r0 = recG[j0];
-    if (j1 < nb) r1 = recG[j1];
-    if (j2 < nb) r2 = recG[j2];
-    if (j3 < nb) r3 = recG[j3];
+    if (j0 < nb) r0 = rec_at(j0);
+    if (j1 < nb) r1 = rec_at(j1);
+    if (j2 < nb) r2 = rec_at(j2);
+    if (j3 < nb) r3 = rec_at(j3);
     if (j0 < nb) atomicAdd(&lcnt[r0.meta & V16_LG_MASK], 1);
     if (j1 < nb) atomicAdd(&lcnt[r1.meta & V16_LG_MASK], 1);
     if (j2 < nb) atomicAdd(&lcnt[r2.meta & V16_LG_MASK], 1);
     if (j3 < nb) atomicAdd(&lcnt[r3.meta & V16_LG_MASK], 1);
-    for (int32_t j = 4 * gb + l; j < nb; j += gb) atomicAdd(&lcnt[recG[j].meta & V16_LG_MASK], 1);
+    for (int32_t j = 4 * gb + l; j < nb; j += gb) atomicAdd(&lcnt[rec_at(j).meta & V16_LG_MASK], 1);
   }
   __syncthreads();
+  if (TILES) TL_STAMP(4096 + b, 2); /* records fetched and counted */
   if (pre && g < X.g_end) coord_preload_ring<KMAX>(S, g, P);
   /* B: exclusive scan of the counts */
   const int32_t c = lcnt[l];
@@ -552,15 +511,12 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
       cpA[p] = v.maxcp;
       metaA[p] = v.meta;
     };
-    if (SLOTS) {
-      each_slot_record(place); /* the second reading of the slots: from L2 */
-    } else {
-      if (l < nb) place(r0);
-      if (gb + l < nb) place(r1);
-      if (2 * gb + l < nb) place(r2);
-      if (3 * gb + l < nb) place(r3);
-      for (int32_t j = 4 * gb + l; j < nb; j += gb) place(recG[j]);
-    }
+    if (l < nb) place(r0);
+    if (gb + l < nb) place(r1);
+    if (2 * gb + l < nb) place(r2);
+    if (3 * gb + l < nb) place(r3);
+    /* (a lane's records beyond its first four: read a second time, from L2) */
+    for (int32_t j = 4 * gb + l; j < nb; j += gb) place(TILES ? tile_rec(j) : recG[j]);
   } else {
     for (int32_t j = l; j < nb; j += gb) {
       const Vote16 v = recG[j];
@@ -569,6 +525,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     }
   }
   __syncthreads();
+  if (TILES) TL_STAMP(4096 + b, 3); /* placed group-major */
   /* D: segments that do not fit the nibble word (or a bucket in global mode): sorted keys in global
    * scratch.  A segment of up to V16_LANE_SORT votes staged in LDS is ordered by ITS OWN lane (rank by
    * counting over the arrival indices in LDS: a call that brings many rounds of votes at once has 17+
@@ -642,8 +599,8 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     it.recG = recG;
     it.keys = keysG + start;
     it.in = in;
-    it.b0n = in.bnum[0];
-    it.b0c = in.bcoord[0];
+    it.b0n = ref_bn;
+    it.b0c = ref_bc;
     it.start = start;
     it.c = c;
     it.done = 0;
@@ -768,6 +725,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     }
     nout = it.nout;
     omask = it.omask;
+    if (TILES) TL_STAMP(4096 + b, 4); /* thread 0 replayed */
     /* F: the bucket's outputs, group-major, as columns */
     int32_t tout;
     const int32_t ex = block_exscan_rt(nout, &tout);
@@ -777,6 +735,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
       put((int64_t)boff + ex + q, sl, md, kd);
     }
     if (l == 0) X.bucket_nout[b] = tout;
+    if (TILES) TL_STAMP(4096 + b, 5); /* outputs staged */
   } else {
     VoteIter<false, AC> it;
     it.idxA = idxA;
@@ -786,8 +745,8 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     it.recG = recG;
     it.keys = keysG + start;
     it.in = in;
-    it.b0n = in.bnum[0];
-    it.b0c = in.bcoord[0];
+    it.b0n = ref_bn;
+    it.b0c = ref_bc;
     it.start = start;
     it.c = c;
     it.done = 0;
@@ -807,7 +766,6 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     }
     if (l == 0) X.bucket_nout[b] = tout;
   }
-  if (SLOTS && l == 0 && novf) A.ovf_cnt[b] = 0; /* ready for the next call's scatter (every lane has used its copy) */
 }
 
 template <int OP, int KMAX>
@@ -815,13 +773,19 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
                                                    AcceptOut R, uint8_t* __restrict__ status) {
   bucket16_body<OP, KMAX>(S, X, O, in, R, status);
 }
-/* accept replies behind the slotted front end (gpx_slots.hip.h): K <= 4, and five replicas held to 6 waves like k_bucket_ar16_k5 */
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_slots(
-    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, SlotArea A) {
+/* accept replies behind the tiled front end (gpx_tiles.hip.h) */
+template <int KMAX>
+__global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16_tiles(DevState S, DevScratch X, Stage16 O, VoteCols in,
+                                                                         uint8_t* __restrict__ status, TileArea A) {
+  bucket16_body<B16_AR, KMAX, true>(S, X, O, in, AcceptOut{}, status, A);
+}
+/* K <= 4 and five replicas held to 6 waves like k_bucket_ar16_k5 */
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_tiles_k4(
+    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A) {
   bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, A);
 }
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_k5_slots(
-    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, SlotArea A) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_tiles_k5(
+    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A) {
   bucket16_body<B16_AR, 5, true>(S, X, O, in, AcceptOut{}, status, A);
 }
 /* Five replicas (BASELINE config #4): the KMAX = 5 body needs 82 VGPRs left to itself - two over the step

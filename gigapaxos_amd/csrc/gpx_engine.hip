@@ -155,6 +155,7 @@ struct gpx_engine {
    * it (GPX_DEVICE_SHARERS, default 1) decide which grids need no tickets; the host-mapped word a waiter that gave up
    * writes (DevScratch.xabort) */
   int cus = 0, sharers = 1;
+  uint32_t xchg_timeout_ms = GPX_XCHG_TIMEOUT_MS; /* GPX_XCHG_TIMEOUT_MS: how long an exchange kernel's pollers wait */
   bool one_launch = true;            /* GPX_XCHG_SLOTS=0 (comparison builds, tests): the check kernel + the work kernel instead */
   uint32_t gx_arrive = 0; /* grid_exchange's arrival counters as this engine's launches have left them */
   bool registered_live = false;
@@ -171,10 +172,12 @@ struct gpx_engine {
   int32_t ar_passes = 1, shift16 = 0, nbk16 = 0;
   bool ac16 = false;          /* ACCEPT / COMMIT partition path on 16-byte records too (single pass only) */
   int32_t* ar_chain = nullptr; /* [2] running output count between passes */
-  /* the slotted front end of shuffled accept-reply calls (gpx_slots.hip.h; GPX_AR_SLOTS=1): allocated on first use */
-  bool ar_slots = false;
-  SlotArea slot_area{};
-  int32_t slot_tile = 0; /* votes per scatter workgroup: 16384 or 8192, by the number of buckets */
+  /* the tiled front end of accept-reply calls (gpx_tiles.hip.h; GPX_AR_TILES=0 keeps the partition front end for every
+   * call): allocated on first use */
+  bool ar_tiles = false;
+  TileArea tile_area{};
+  int32_t tile_force = 0;   /* GPX_TILE_T (tuning): votes per scatter workgroup, 0 = chosen per call */
+  int32_t tile_threads = 0; /* GPX_TILE_NT (tuning): 512 or 1024 threads per scatter workgroup, 0 = chosen per call */
   I4* reply_rows = nullptr;    /* [max_batch] packed ACCEPT_REPLY rows of the partition path (first use) */
   size_t lds_pad = 0;         /* GPX_LDS_PAD (tuning): extra dynamic LDS per bucket workgroup */
   /* asynchronous host-pointer calls (gpx_*_batch_async / gpx_engine_wait): GPX_ASYNC_DEPTH sets of device
@@ -454,6 +457,15 @@ int check_batch(gpx_engine* h, int32_t n) {
   return GPX_OK;
 }
 
+/* A synchronous call's wait for its stream, and the question every such wait is followed by: did a workgroup of an
+ * exchange kernel give up during THIS call (check_batch reads the host-mapped word)?  Then the call's outputs are not a
+ * prefix of anything and the call itself - not the next one - says GPX_EDEVICE. */
+#define SYNC_CHECKED(h, stream_)                                \
+  do {                                                          \
+    HIPCHK(hipStreamSynchronize(stream_));                      \
+    if (int _rc_abort = check_batch((h), 0)) return _rc_abort;  \
+  } while (0)
+
 /* the streams (x processes) that may have a one-launch kernel - workgroups waiting for each other at grid_exchange -
  * on this engine's device at the same moment */
 int xchg_share(const gpx_engine* e) {
@@ -479,6 +491,7 @@ bool xchg_ctl(gpx_engine* e, int nchunks, GridXchg* Q, int* grid) {
   Q->epoch = C.epoch;
   e->gx_arrive += (uint32_t)(g16 / GPX_GX_LINES);
   Q->arrive_target = e->gx_arrive;
+  Q->timeout_ms = e->xchg_timeout_ms;
   return true;
 }
 
@@ -674,8 +687,15 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   }
   if (const char* lp = getenv("GPX_LDS_PAD")) e->lds_pad = (size_t)std::max(0, atoi(lp));
   if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
-  e->ar_slots = true; /* GPX_AR_SLOTS=0: the partition front end for every shuffled call (comparison runs) */
-  if (const char* sl = getenv("GPX_AR_SLOTS")) e->ar_slots = atoi(sl) != 0;
+  e->ar_tiles = true; /* GPX_AR_TILES=0: the partition front end for every shuffled call (comparison runs) */
+  if (const char* sl = getenv("GPX_AR_TILES")) e->ar_tiles = atoi(sl) != 0;
+  if (const char* tt = getenv("GPX_TILE_T")) e->tile_force = atoi(tt);
+  if (const char* tt = getenv("GPX_TILE_NT")) e->tile_threads = atoi(tt);
+  e->tile_area.xcd_rows = 1;
+  if (const char* xr = getenv("GPX_TILE_XCD_ROWS")) e->tile_area.xcd_rows = atoi(xr) != 0;
+#ifdef GPX_TL_TRACE
+  if (const char* ab = getenv("GPX_TL_ABLATE")) e->tile_area.xcd_rows |= atoi(ab) << 1; /* (wrong results: timing only) */
+#endif
   if (const char* sv = getenv("GPX_SAR_MAX_N")) e->sar_max_n = std::max(0, std::min(GPX_SAR_MAX_N, atoi(sv)));
   e->sar_max_n = std::min(e->sar_max_n, cfg->max_batch); /* its keys live in X.perm: [max_batch] entries */
   e->ordered_mask = e->env_mask;
@@ -996,50 +1016,94 @@ int gpx_route_batch_dev(gpx_engine* h, int32_t n, int32_t n_cols, const int32_t*
 
 /* ---- device-pointer data path ------------------------------------------------- */
 
-/* The slotted front end (gpx_slots.hip.h) for one pass over every bucket: k_scatter_slots, k_slot_totals,
- * k_bucket_ar16_slots, k_emit_dec16.  false: this call's shape is not one it takes (the caller goes on with k_hist +
- * k_scatter_ar16). */
-static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const int32_t* bnum, const int32_t* bcoord,
+/* The tiled front end (gpx_tiles.hip.h) for one pass over every bucket: k_scatter_tiles, k_bucket_ar16_tiles,
+ * k_emit_dec16.  false: this call's shape is not one it takes (the caller goes on with k_hist + k_scatter_ar16). */
+struct TileShape {
+  int32_t T, NT; /* votes and threads per scatter workgroup */
+};
+#ifdef GPX_TL_TRACE
+static unsigned long long* tl_trace_dev = nullptr;
+static void tl_trace_begin(gpx_engine* e) {
+  if (!tl_trace_dev) {
+    HIPQ(hipMalloc(&tl_trace_dev, TL_TRACE_ROWS * 8 * sizeof(unsigned long long)));
+    HIPQ(hipMemcpyToSymbol(HIP_SYMBOL(g_tl_trace), &tl_trace_dev, sizeof(tl_trace_dev)));
+  }
+  HIPQ(hipMemsetAsync(tl_trace_dev, 0, TL_TRACE_ROWS * 8 * sizeof(unsigned long long), e->stream));
+}
+static void tl_trace_end(gpx_engine* e) { /* every call: the last one wins */
+  const char* tf = getenv("GPX_TL_TRACE_FILE");
+  if (!tf) return;
+  HIPQ(hipStreamSynchronize(e->stream));
+  std::vector<unsigned long long> tr((size_t)TL_TRACE_ROWS * 8);
+  HIPQ(hipMemcpy(tr.data(), tl_trace_dev, tr.size() * 8, hipMemcpyDeviceToHost));
+  if (FILE* fp = fopen(tf, "wb")) {
+    fwrite(tr.data(), 8, tr.size(), fp);
+    fclose(fp);
+  }
+}
+#endif
+/* Votes per scatter workgroup.  A workgroup's LDS holds its whole tile (8 bytes per vote + the bucket counters), the
+ * kernel lasts as long as its busiest CU, and every tile costs the per-bucket kernel a run to look up: the largest tile
+ * that still spreads the call over the chip.  Measured (profiles/r06_tile_shapes.txt): 3 M votes - 12,288-vote tiles
+ * (245 workgroups) 28 us against 30-33 for 184 x 16,384, 367 x 8,192, 733 x 4,096; 5 M votes - 407 x 12,288. */
+static TileShape tile_shape(const gpx_engine* e, int32_t n, int32_t nbk) {
+  if (e->tile_force) return TileShape{e->tile_force, e->tile_threads ? e->tile_threads : (e->tile_force <= 8192 ? 512 : 1024)};
+  const int64_t cus = std::max(1, e->cus);
+  /* (16,384-vote tiles of 1024 threads spill registers - kept as a forced shape only) */
+  static const TileShape cand[] = {{12288, 1024}, {8192, 1024}, {4096, 512}};
+  TileShape best = cand[2];
+  int64_t best_cost = INT64_MAX;
+  for (const TileShape& c : cand) {
+    if (GPX_TL_LDS_BYTES(nbk, c.T, c.NT) > (size_t)158 * 1024) continue;
+    const int64_t nwg = ((int64_t)n + c.T - 1) / c.T;
+    if (nwg > GPX_TL_MAXWG) continue;
+    /* votes the busiest CU sorts (workgroups go round the CUs), and a charge per tile */
+    const int64_t cost = (nwg + cus - 1) / cus * c.T + nwg * 16;
+    if (cost < best_cost) best_cost = cost, best = c;
+  }
+  return best;
+}
+static bool ar_tiles_call(gpx_engine* e, int32_t n, const int32_t* gidx, const int32_t* bnum, const int32_t* bcoord,
                           const int32_t* slot, const int32_t* acceptor, const int32_t* max_cp, int32_t* d_gidx,
                           int32_t* d_slot, int32_t* d_bnum, int32_t* d_bcoord, int32_t* d_median_cp, uint8_t* d_kind,
                           int32_t* n_out, uint8_t* status) {
   const int32_t nbk = e->nbk16;
-  /* a slot holds what a workgroup's tile brings a bucket on average x 3: 8 votes per (bucket, workgroup) */
-  const int32_t T = nbk >= 1640 ? 16384 : nbk >= 820 ? 8192 : 0;
-  /* ... and at most 192 scatter workgroups: the per-bucket kernel keeps the slots of three rounds of its lane groups in
-   * registers; beyond (five replicas at 1 M groups: 306) its second reading of the slots costs what the scatter saved
-   * (0.181 against 0.178 ms per step, profiles/r05_slots_front_end.txt) */
-  if (!T || nbk > GPX_MAX_BUCKETS || n < 8 * T || e->shift16 > 10 || (n + T - 1) / T > GPX_SL_MAXWG) return false;
+  if (nbk > GPX_MAX_BUCKETS || e->shift16 > 10 || e->shift16 < 8) return false;
+  const TileShape ts = tile_shape(e, n, nbk);
+  const int32_t T = ts.T;
+  if ((T != 4096 && T != 8192 && T != 12288 && T != 16384) || (ts.NT != 512 && ts.NT != 1024) || T % (ts.NT * 4)) return false;
+  const int32_t nwg = (n + T - 1) / T;
+  if (nwg > GPX_TL_MAXWG) return false;
   const size_t N = (size_t)e->cfg.max_batch;
-  SlotArea& A = e->slot_area;
-  if (!A.slots || e->slot_tile != T) {
-    if (A.slots) return false; /* (one tile size per engine: the bucket geometry does not change) */
-    /* sized for the largest call this path takes (192 scatter workgroups), not for max_batch */
-    const size_t nwg_max = std::min<size_t>((N + (size_t)T - 1) / (size_t)T, GPX_SL_MAXWG);
-    const size_t pad = (nwg_max + 15) / 16 * 16;
-    const size_t n_max = std::min<size_t>(N, nwg_max * (size_t)T); /* (every vote of a call can overflow: a skewed stream) */
-    if (dev_alloc(e, &A.slots, (size_t)nbk * nwg_max * GPX_SL_SLOT, false) != GPX_OK ||
-        dev_alloc(e, &A.cntm, (size_t)nbk * pad, true) != GPX_OK || dev_alloc(e, &A.ovf_rec, n_max, false) != GPX_OK ||
-        dev_alloc(e, &A.ovf_bkt, n_max, false) != GPX_OK || dev_alloc(e, &A.ovf_n, 2, true) != GPX_OK ||
-        dev_alloc(e, &A.ovf_seg, 2 * GPX_SL_MAXWG, true) != GPX_OK ||
-        dev_alloc(e, &A.ovf_cnt, (size_t)nbk, true) != GPX_OK) {
-      A.slots = nullptr;
-      e->ar_slots = false; /* no room: the partition front end from now on */
+  TileArea& A = e->tile_area;
+  if (!A.recs) {
+    /* every tile of the largest call, whole: max_batch votes in the smallest tiles, rounded up to tiles */
+    const size_t cap = (N + 4095) / 4096 * 4096 + 16384;
+    const size_t nwg_max = std::min<size_t>((N + 4095) / 4096, GPX_TL_MAXWG);
+    const size_t pad = (nwg_max + 7) / 8 * 8; /* rows of A.off (8 bytes per tile) start on 64-byte lines */
+    if (dev_alloc(e, &A.recs, cap, false) != GPX_OK || dev_alloc(e, &A.ext, cap, false) != GPX_OK ||
+        dev_alloc(e, &A.off, ((size_t)nbk / 4 + 2) * pad * 4, true) != GPX_OK || dev_alloc(e, &A.ref, 4, true) != GPX_OK) {
+      A.recs = nullptr;
+      e->ar_tiles = false; /* no room: the partition front end from now on */
       return false;
     }
     A.nwg_pad = (int32_t)pad;
-    e->slot_tile = T;
-    const size_t lds = (size_t)((nbk + 3) & ~3) * 4 + (size_t)T * sizeof(Vote8);
-    HIPQ(hipFuncSetAttribute((const void*)k_scatter_slots<16384>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    HIPQ(hipFuncSetAttribute((const void*)k_scatter_slots<8192>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    /* (these two keep 1.1 KB of static LDS - the overflow segments' directory -, and a call of this path stages
-     * 45 KB at most: 192 x 16,384 votes over 820 buckets) */
+    const int maxlds = (int)std::min<size_t>(GPX_TL_LDS_BYTES(nbk, 16384, 1024), (size_t)158 * 1024);
+    HIPQ(hipFuncSetAttribute((const void*)k_scatter_tiles<1024, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    HIPQ(hipFuncSetAttribute((const void*)k_scatter_tiles<1024, 3>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    HIPQ(hipFuncSetAttribute((const void*)k_scatter_tiles<1024, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    HIPQ(hipFuncSetAttribute((const void*)k_scatter_tiles<1024, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    HIPQ(hipFuncSetAttribute((const void*)k_scatter_tiles<512, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    HIPQ(hipFuncSetAttribute((const void*)k_scatter_tiles<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
+    /* (the per-bucket kernels keep 6.2 KB of static LDS - the tiles' run starts and prefix) */
     const size_t hw16 = std::min<size_t>(GPX_BUCKET16_LDS_BYTES((size_t)1 << e->shift16, e->lds16_hw) + e->lds_pad,
-                                         (size_t)158 * 1024);
-    HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_slots, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
-    HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_k5_slots, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
+                                         (size_t)152 * 1024);
+    HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_tiles_k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
+    HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_tiles_k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
+    HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_tiles<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
+    HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_tiles<16>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
   }
-  A.nwg = (n + T - 1) / T;
+  A.nwg = nwg;
   A.tile = T;
   const DevScratch X0 = e->X;
   const int threads0 = e->bucket_threads;
@@ -1048,32 +1112,47 @@ static bool ar_slots_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
   e->X.nbk = nbk;
   e->bucket_threads = e->X.gb;
   begin_back(e, 0, n, true);
-  if (e->bucket_lds > (size_t)158 * 1024) { /* (not reachable inside this path's range; the static LDS must fit) */
-    e->X.lds_recs = (int32_t)(((size_t)158 * 1024 - e->lds_pad - (size_t)e->X.gb * 8) / 16);
+  if (e->bucket_lds > (size_t)152 * 1024) { /* the static LDS must fit beside the staging */
+    e->X.lds_recs = (int32_t)(((size_t)152 * 1024 - e->lds_pad - (size_t)e->X.gb * 8) / 16);
     e->bucket_lds = GPX_BUCKET16_LDS_BYTES(e->X.gb, e->X.lds_recs) + e->lds_pad;
   }
-  const size_t lds = (size_t)((nbk + 3) & ~3) * 4 + (size_t)T * sizeof(Vote8);
+  const size_t lds = GPX_TL_LDS_BYTES(nbk, T, ts.NT);
+#ifdef GPX_TL_TRACE
+  tl_trace_begin(e);
+#endif
   {
-    LaunchScope _ls(e, "k_scatter_slots");
-    if (T == 16384)
-      hipLaunchKernelGGL(k_scatter_slots<16384>, dim3(tile_grid(A.nwg)), dim3(GPX_FBLOCK), lds, e->stream, n, e->S.G, e->X, A, gidx,
-                         bnum, bcoord, slot, acceptor, max_cp, status);
-    else
-      hipLaunchKernelGGL(k_scatter_slots<8192>, dim3(tile_grid(A.nwg)), dim3(GPX_FBLOCK), lds, e->stream, n, e->S.G, e->X, A, gidx,
-                         bnum, bcoord, slot, acceptor, max_cp, status);
-  }
-  {
-    LaunchScope _ls(e, "k_slot_totals");
-    hipLaunchKernelGGL(k_slot_totals, dim3((nbk + GPX_SL_ROWS - 1) / GPX_SL_ROWS), dim3(256), 0, e->stream, e->X, A);
+    LaunchScope _ls(e, "k_scatter_tiles");
+#define GPX_LAUNCH_TILES(NT_, R4_)                                                                                       \
+  hipLaunchKernelGGL(HIP_KERNEL_NAME(k_scatter_tiles<NT_, R4_>), dim3(tile_grid(A.nwg)), dim3(NT_), lds, e->stream, n, e->S.G, \
+                     e->X, A, gidx, bnum, bcoord, slot, acceptor, max_cp, status)
+    const int r4 = T / (ts.NT * 4);
+    if (ts.NT == 1024 && r4 == 4) GPX_LAUNCH_TILES(1024, 4);
+    else if (ts.NT == 1024 && r4 == 3) GPX_LAUNCH_TILES(1024, 3);
+    else if (ts.NT == 1024 && r4 == 2) GPX_LAUNCH_TILES(1024, 2);
+    else if (ts.NT == 1024 && r4 == 1) GPX_LAUNCH_TILES(1024, 1);
+    else if (ts.NT == 512 && r4 == 4) GPX_LAUNCH_TILES(512, 4);
+    else GPX_LAUNCH_TILES(512, 2);
+#undef GPX_LAUNCH_TILES
   }
   const Stage16 O{(int32_t*)e->X.o_rec, (int64_t)N};
   const VoteCols in{bnum, bcoord, acceptor, slot, max_cp};
-  if (e->cfg.kmax <= 4)
-    LAUNCH_B(e, "k_bucket_ar16_slots", k_bucket_ar16_slots, e->S, e->X, O, in, status, A);
-  else
-    LAUNCH_B(e, "k_bucket_ar16_slots", k_bucket_ar16_k5_slots, e->S, e->X, O, in, status, A);
+  {
+    LaunchScope _ls(e, e->cfg.kmax <= 4 ? "k_bucket_ar16_tiles_k4" : e->cfg.kmax <= 5 ? "k_bucket_ar16_tiles_k5" : "k_bucket_ar16_tiles");
+    const dim3 grid(A.xcd_rows ? tile_grid(nbk) : nbk), block(e->bucket_threads);
+    if (e->cfg.kmax <= 4)
+      hipLaunchKernelGGL(k_bucket_ar16_tiles_k4, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A);
+    else if (e->cfg.kmax <= 5)
+      hipLaunchKernelGGL(k_bucket_ar16_tiles_k5, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A);
+    else if (e->cfg.kmax <= 8)
+      hipLaunchKernelGGL(k_bucket_ar16_tiles<8>, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A);
+    else
+      hipLaunchKernelGGL(k_bucket_ar16_tiles<16>, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A);
+  }
   LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out,
          &e->X.counters[1], (const int32_t*)nullptr, (int32_t*)nullptr);
+#ifdef GPX_TL_TRACE
+  tl_trace_end(e);
+#endif
   const int32_t lds_recs = e->X.lds_recs;
   const int32_t gate = e->X.gate;
   e->X = X0;
@@ -1109,8 +1188,8 @@ static void ar_partition(gpx_engine* e, int32_t n, const int32_t* gidx, const in
   }
   const int64_t bpp = (NB + want_passes - 1) / want_passes; /* buckets per pass, <= GPX_MAX_BUCKETS */
   const int32_t passes = (int32_t)((NB + bpp - 1) / bpp);
-  if (e->ar_slots && passes == 1 && vec && e->cfg.kmax <= 5 && ar_slots_call(e, n, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx,
-                                                                              d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out, status))
+  if (e->ar_tiles && passes == 1 && vec && ar_tiles_call(e, n, gidx, bnum, bcoord, slot, acceptor, max_cp, d_gidx, d_slot, d_bnum,
+                                                        d_bcoord, d_median_cp, d_kind, n_out, status))
     return;
   const size_t N = (size_t)e->cfg.max_batch;
   int32_t* o32 = (int32_t*)e->X.o_rec; /* N x 32 bytes: five int columns + one byte column */
@@ -1772,7 +1851,7 @@ int gpx_propose_batch_h(gpx_engine* h, int32_t n, const int32_t* gidx, const uin
   D2H(bcoord, h->st_i32[3], b4);
   D2H(median_cp, h->st_i32[4], b4);
   D2H(status, h->st_u8[1], (size_t)n);
-  HIPCHK(hipStreamSynchronize(h->sB));
+  SYNC_CHECKED(h, h->sB);
   return GPX_OK;
 }
 
@@ -1840,7 +1919,7 @@ int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   if (rc != GPX_OK) return rc;
   D2H(n_runs, h->st_count, 4);
   if (h->last.kind) {
-    HIPCHK(hipStreamSynchronize(h->sB));
+    SYNC_CHECKED(h, h->sB);
     if (*n_runs < 0) {
       if ((rc = gpx_compact_last_dev(h)) != GPX_OK) return rc;
       D2H(n_runs, h->st_count, 4);
@@ -1852,13 +1931,13 @@ int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   D2H(r_maxcp, h->st_i32[7], b4);
   D2H(r_flags, h->st_u8[1], (size_t)n);
   D2H(status, h->st_u8[2], (size_t)n);
-  HIPCHK(hipStreamSynchronize(h->sB));
+  SYNC_CHECKED(h, h->sB);
   const size_t m4 = (size_t)(*n_runs) * 4;
   if (m4) {
     D2H(x_gidx, h->st_i32[8], m4);
     D2H(x_first, h->st_i32[9], m4);
     D2H(x_count, h->st_i32[10], m4);
-    HIPCHK(hipStreamSynchronize(h->sB));
+    SYNC_CHECKED(h, h->sB);
   }
   return GPX_OK;
 }
@@ -1925,12 +2004,12 @@ int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
   if (rc != GPX_OK) return rc;
   D2H(n_out, h->st_count, 4);
   if (status) D2H(status, h->st_u8[1], (size_t)n);
-  HIPCHK(hipStreamSynchronize(h->sB));
+  SYNC_CHECKED(h, h->sB);
   if (h->last.kind) {
     if (*n_out < 0) {
       if ((rc = gpx_compact_last_dev(h)) != GPX_OK) return rc;
       D2H(n_out, h->st_count, 4);
-      HIPCHK(hipStreamSynchronize(h->sB));
+      SYNC_CHECKED(h, h->sB);
     }
     h->last.kind = 0;
   }
@@ -1942,7 +2021,7 @@ int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const 
     D2H(d_bcoord, h->st_i32[9], m * 4);
     D2H(d_median_cp, h->st_i32[10], m * 4);
     D2H(d_kind, h->st_u8[0], m);
-    HIPCHK(hipStreamSynchronize(h->sB));
+    SYNC_CHECKED(h, h->sB);
   }
   return GPX_OK;
 }
@@ -2001,7 +2080,7 @@ int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
   if (rc != GPX_OK) return rc;
   D2H(n_runs, h->st_count, 4);
   if (h->last.kind) {
-    HIPCHK(hipStreamSynchronize(h->sB));
+    SYNC_CHECKED(h, h->sB);
     if (*n_runs < 0) {
       if ((rc = gpx_compact_last_dev(h)) != GPX_OK) return rc;
       D2H(n_runs, h->st_count, 4);
@@ -2009,13 +2088,13 @@ int gpx_commit_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
     h->last.kind = 0;
   }
   D2H(status, h->st_u8[1], (size_t)n);
-  HIPCHK(hipStreamSynchronize(h->sB));
+  SYNC_CHECKED(h, h->sB);
   const size_t m4 = (size_t)(*n_runs) * 4;
   if (m4) {
     D2H(x_gidx, h->st_i32[5], m4);
     D2H(x_first, h->st_i32[6], m4);
     D2H(x_count, h->st_i32[7], m4);
-    HIPCHK(hipStreamSynchronize(h->sB));
+    SYNC_CHECKED(h, h->sB);
   }
   return GPX_OK;
 }
@@ -2460,13 +2539,17 @@ int gpx_engine_wait(gpx_engine* h, gpx_ticket ticket) {
   for (auto& a : h->as) {
     if (!a.busy || a.ticket != ticket) continue;
     HIPCHK(hipEventSynchronize(a.ev_cnt)); /* dense outputs and the count are on the host */
+    if (int rc_abort = check_batch(h, 0)) { /* an exchange kernel of this call (or one before it) gave up: nothing to hand over */
+      a.busy = false;
+      return rc_abort;
+    }
     if (a.host_count && !a.direct) {
       const int32_t m = a.ncols ? a.h_cnt[0] : 0;
       *a.host_count = m;
       if (m > 0) { /* exactly m compacted entries, not the capacity */
         for (int k = 0; k < a.ncols; k++) A_OUT(a.host_col[k], a.dev_col[k], (size_t)m * 4);
         if (a.host_kind) A_OUT(a.host_kind, a.dev_kind, (size_t)m);
-        HIPCHK(hipStreamSynchronize(a.s_out));
+        SYNC_CHECKED(h, a.s_out);
       }
     }
     a.busy = false;
@@ -2509,6 +2592,7 @@ int gpx_group_create(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
            (const int32_t*)d_m, (const uint8_t*)d_k, (const gpx_hri*)d_r, d_s, NameCopies{h->N.rows, (uint8_t*)h->N.tab});
     if (status) D2H(status + o, d_s, (size_t)c);
     HIPCHK(hipStreamSynchronize(h->sB));
+    rc = check_batch(h, 0); /* (an exchange kernel that gave up before this call: the table is not to be built on) */
   }
   (void)hipFree(d_g);
   (void)hipFree(d_m);
@@ -2531,7 +2615,8 @@ static int retire_impl(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mo
   HIPCHK(hipMalloc((void**)&d_g, (size_t)c0 * 4));
   HIPCHK(hipMalloc((void**)&d_s, (size_t)c0));
   HIPCHK(hipMalloc((void**)&d_r, (size_t)c0 * sizeof(gpx_hri)));
-  for (int32_t o = 0; o < n; o += chunk) {
+  int rc = GPX_OK;
+  for (int32_t o = 0; o < n && rc == GPX_OK; o += chunk) {
     const int32_t c = std::min(chunk, n - o);
     H2D_B(d_g, gidx + o, (size_t)c * 4);
     LAUNCH(h, "k_group_retire", k_group_retire, grid_for(c), h->S, c, (const int32_t*)d_g, mode, d_r,
@@ -2539,11 +2624,12 @@ static int retire_impl(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mo
     if (rows) D2H(rows + o, d_r, (size_t)c * sizeof(gpx_hri));
     if (status) D2H(status + o, d_s, (size_t)c);
     HIPCHK(hipStreamSynchronize(h->sB));
+    rc = check_batch(h, 0); /* a snapshot of a table an exchange kernel left half-written is not a snapshot */
   }
   (void)hipFree(d_g);
   (void)hipFree(d_s);
   (void)hipFree(d_r);
-  return GPX_OK;
+  return rc;
 }
 
 int gpx_group_retire(gpx_engine* h, int32_t n, const int32_t* gidx, int32_t mode, gpx_hri* rows,
@@ -2561,7 +2647,7 @@ int gpx_group_snapshot(gpx_engine* h, int32_t n, const int32_t* gidx, gpx_hri* r
 /* canonical dump (same word layout as the oracle's orc_group_dump) */
 int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
   if (!h || !buf) return GPX_EINVAL;
-  HIPCHK(hipStreamSynchronize(h->sB));
+  SYNC_CHECKED(h, h->sB);
   std::vector<int32_t> w;
   const DevState& S = h->S;
   auto rd32 = [&](const void* base, int64_t idx, int32_t* out) -> hipError_t {

@@ -45,6 +45,24 @@ __device__ unsigned long long* g_sar_trace = nullptr;
 #define SAR_STAMP(wg, k) do { } while (0)
 #endif
 
+/* ... and of the tiled accept-reply call's two kernels (-DGPX_TL_TRACE, scripts/ubench/tiles_trace.sh): row = scatter
+ * workgroup w, or 4096 + bucket; eight stamps a row */
+#ifdef GPX_TL_TRACE
+__device__ unsigned long long* g_tl_trace = nullptr;
+#define TL_TRACE_ROWS 8192
+#define TL_STAMP(row, k)                                                                             \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && g_tl_trace) g_tl_trace[(size_t)(row) * 8 + (k)] = wall_clock64();          \
+  } while (0)
+#define TL_CLOCK(row, k) /* the shader clock beside the 100 MHz wall clock: what the CUs really ran at */ \
+  do {                                                                                               \
+    if (threadIdx.x == 0 && g_tl_trace) g_tl_trace[(size_t)(row) * 8 + (k)] = clock64();               \
+  } while (0)
+#else
+#define TL_STAMP(row, k) do { } while (0)
+#define TL_CLOCK(row, k) do { } while (0)
+#endif
+
 /* Plain aggregates for packed records and ring entries (not HIP's int4: plain structs give the
  * same dwordx4 accesses and keep the code independent of the vector-type accessor proxies). */
 struct __attribute__((aligned(16))) I4 {
@@ -174,21 +192,24 @@ struct DevScratch {
 /* Workgroups that wait for each other (grid_exchange, gpx_one.hip.h) wait only for workgroups that have started (or,
  * in a small grid, for a grid the host knows to be resident: xchg_ctl in gpx_engine.hip).  This is the backstop for
  * what neither covers - a wedged device, another process holding every CU while a small grid starts: a waiter gives up
- * after about two seconds of the 100 MHz wall clock, leaves the call's epoch in the host-mapped word and the caller
- * applies NOTHING of its records.  A hang becomes GPX_EDEVICE on the next call. */
-#define GPX_XCHG_TIMEOUT_TICKS 200000000ull
+ * after ten seconds of the 100 MHz wall clock (GPX_XCHG_TIMEOUT_MS), leaves the call's epoch in the host-mapped word AND the
+ * verdict "first violation at record 0" in the exchange's verdict word, so that every workgroup that reads the verdict
+ * afterwards - the ones that were not resident and start once the quitters have left - applies NOTHING either.  (Not a
+ * transaction: a workgroup that saw every arrival an instant before another one's clock ran out has applied its records.
+ * The engine is unusable from then on, and the call during which it happened says so itself: GPX_EDEVICE.) */
+#define GPX_XCHG_TIMEOUT_MS 10000u /* default; GPX_XCHG_TIMEOUT_MS at engine creation (tests: a few ms) */
 struct XchgWait {
   uint32_t spins = 0;
   unsigned long long t0 = 0;
-  /* one more failed poll; true = give up */
-  __device__ __forceinline__ bool tired() {
+  /* one more failed poll; true = give up (limit_ms of the 100 MHz wall clock have passed since the first 1024 polls) */
+  __device__ __forceinline__ bool tired(uint32_t limit_ms) {
     if ((++spins & 1023u) != 0) return false;
     const unsigned long long now = wall_clock64();
     if (!t0) {
       t0 = now;
       return false;
     }
-    return now - t0 > GPX_XCHG_TIMEOUT_TICKS;
+    return now - t0 > (unsigned long long)limit_ms * 100000ull;
   }
 };
 __device__ __forceinline__ void xchg_abort(const DevScratch& X) {
@@ -623,6 +644,27 @@ __device__ __forceinline__ int32_t block_exscan_rt(int32_t v, int32_t* total) {
   const int32_t base = __shfl(ps, wid > 0 ? wid - 1 : 0, 64);
   __syncthreads();
   *total = tot;
+  return (wid > 0 ? base : 0) + x - v;
+}
+
+/* ... of v, and the block's sum of u, behind the same two barriers */
+__device__ __forceinline__ int32_t block_exscan_and_sum_rt(int32_t v, int32_t u, int32_t* vtotal, int32_t* utotal) {
+  __shared__ int32_t wsum2[32];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int nw = (int)(blockDim.x >> 6);
+  const int32_t x = wave_incscan(v), y = wave_incscan(u);
+  if (lane == 63) {
+    wsum2[wid] = x;
+    wsum2[16 + wid] = y;
+  }
+  __syncthreads();
+  const int32_t ps = wave_incscan(lane < nw ? wsum2[lane] : 0);
+  const int32_t pu = wave_incscan(lane < nw ? wsum2[16 + lane] : 0);
+  const int32_t tot = __shfl(ps, nw - 1, 64);
+  const int32_t base = __shfl(ps, wid > 0 ? wid - 1 : 0, 64);
+  *utotal = __shfl(pu, nw - 1, 64);
+  __syncthreads();
+  *vtotal = tot;
   return (wid > 0 ? base : 0) + x - v;
 }
 

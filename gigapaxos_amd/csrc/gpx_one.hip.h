@@ -213,6 +213,7 @@ struct GridXchg {
   unsigned long long* verdict; /* OneCtl's word: epoch << 32 | (ONE_NONE - first violating index) */
   uint32_t epoch;
   uint32_t arrive_target;      /* every arrival counter's value once all workgroups of THIS launch have arrived */
+  uint32_t timeout_ms;         /* a poller gives up after this long (XchgWait) */
 };
 /* First thing in the kernel: workgroup 0 writes the REGULAR batch's count (a device-scope atomic store).  A workgroup
  * that finds the batch irregular overwrites it with -1 AFTER the exchange, i.e. after it has seen workgroup 0's arrival,
@@ -243,7 +244,7 @@ __device__ __forceinline__ uint32_t grid_exchange(const DevScratch& X, const Gri
     XchgWait w;
     while ((int32_t)(__hip_atomic_load(&Q.arrive[threadIdx.x * 32], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) -
                      Q.arrive_target) < 0) {
-      if (w.tired()) { /* a workgroup of the grid never became resident (gpx_kernels.hip.h: XchgWait) */
+      if (w.tired(Q.timeout_ms)) { /* a workgroup of the grid never became resident (gpx_kernels.hip.h: XchgWait) */
         s_gave_up = 1;
         break;
       }
@@ -252,12 +253,16 @@ __device__ __forceinline__ uint32_t grid_exchange(const DevScratch& X, const Gri
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    if (s_gave_up) {
+      /* nobody who reads the verdict from now on applies anything: the workgroups that were not resident start when
+       * this one has left, find every arrival in and would otherwise go ahead with their part of the batch */
+      const unsigned long long old = atomicMax(Q.verdict, ((unsigned long long)Q.epoch << 32) | (unsigned long long)ONE_NONE);
+      asm volatile("" ::"v"((uint32_t)old));
+      xchg_abort(X);
+    }
     const unsigned long long v = __hip_atomic_load(Q.verdict, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_first = (uint32_t)(v >> 32) == Q.epoch ? ONE_NONE - (uint32_t)v : ONE_NONE;
-    if (s_gave_up) {
-      xchg_abort(X);
-      s_first = 0u; /* nothing of this workgroup's records is applied */
-    }
+    if (s_gave_up) s_first = 0u; /* nothing of this workgroup's records is applied */
   }
   __syncthreads();
   return s_first;

@@ -383,8 +383,13 @@ __global__ __launch_bounds__(GPX_RBLOCK) void k_ar_runs(DevState S, DevScratch X
       }
     }
     /* (the barrier above and grid_exchange's fence order this workgroup's run starts and verdict before its arrival) */
-    if (grid_exchange(X, Q, ONE_NONE) == 0u && threadIdx.x == 0) atomicMax(X.unsorted, X.epoch); /* gave up: apply nothing */
-    __syncthreads();
+    if (grid_exchange(X, Q, ONE_NONE) == 0u) {
+      /* somebody gave up waiting (nobody else writes a verdict here): apply nothing - and do NOT raise *X.unsorted: under
+       * the hint the partition pipeline launched behind would take the whole batch, on top of whatever the workgroups
+       * that got through have applied.  The call ends in GPX_EDEVICE. */
+      if (refuse && i < n && status) status[i] = GPX_S_UNORDERED;
+      return;
+    }
     if (__hip_atomic_load(X.unsorted, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == X.epoch) {
       /* not a few ascending runs in range: refused whole under the promise, else the partition pipeline (or the
        * one-launch kernel of small calls) launched behind takes the batch */
