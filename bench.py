@@ -162,6 +162,7 @@ class CoordinatorLeg:
                  order=None):
         from gigapaxos_amd import Engine, hri_create, load_hip, streams, S_OK
         self.torch, self.dist, self.world, self.rank, self.dev = torch, dist, world, rank, dev
+        self.coll = world > 1 or args.force_collectives  # (--force-collectives: the N > 1 branch with a world of one)
         # collectives carry telemetry only: over RCCL on the ranks' GPUs, or - ranks sharing ONE device
         # (--same-device) - over gloo on host tensors
         self.cdev = torch.device("cpu") if args.same_device else dev
@@ -200,11 +201,15 @@ class CoordinatorLeg:
         # A pool of independently shuffled rounds supplies (gidx, ballot, acceptor); the two columns that
         # depend on the round number - slot = r + 1 and max_cp = r for every vote of round r - are
         # filled on the device, so any --steps fits in memory and start-up time.
-        pool_n = min(rounds, 8)
-        pool = []
-        for r in range(pool_n):
-            cols = gen_round(args, streams, G, members, r, cfg_id, mix)
-            pool.append([torch.from_numpy(c).to(dev) for c in cols])
+        # (round 6: every round of the default run is its own seeded round, as SURVEY 8(d) says - the pool holds
+        # warmup + 3 x steps + profile rounds up to --pool; rounds 1-5 reused 8 shuffles modulo 8)
+        pool_n = min(rounds, max(1, args.pool))
+        self.pool_rounds = pool_n
+        from concurrent.futures import ThreadPoolExecutor
+        with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:  # (the C generator releases the GIL)
+            host_rounds_ = list(ex.map(lambda r: gen_round(args, streams, G, members, r, cfg_id, mix), range(pool_n)))
+        pool = [[torch.from_numpy(c).to(dev) for c in cols] for cols in host_rounds_]
+        del host_rounds_
         self.nv = nv = int(pool[0][0].shape[0])
         vote_cols = []
         for r in range(rounds):
@@ -244,7 +249,7 @@ class CoordinatorLeg:
         return ORDERED_PROPOSE | ((ORDERED_REPLY_RUNS | LAZY_OUTPUTS) if args.runs else 0)
 
     def barrier(self):
-        if self.world > 1:
+        if self.coll:
             self.dist.barrier()
 
     def profile_calls(self, first_round, psteps):
@@ -265,41 +270,51 @@ class CoordinatorLeg:
         eng.profile(0)
         return per_call
 
-    def run_timed(self, warmup, steps):
+    def run_timed(self, warmup, steps, reps=1):
+        """The driver's contract, `reps` times over: warm-up once, then per repetition barrier + synchronize, EXACTLY
+        `steps` steps, synchronize + barrier, MAX over ranks.  self.elapsed = the MEDIAN repetition (what `value` and
+        `ms_per_step` are computed from), self.elapsed_all = every repetition's."""
         torch, dist, eng, step, dev, world, G = self.torch, self.dist, self.eng, self.step, self.dev, self.world, self.G
         for r in range(warmup):
             step(r)
-        eng.sync()
-        torch.cuda.synchronize()
-        self.barrier()
-        torch.cuda.synchronize()
-        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        t0 = time.perf_counter()
-        ev0.record()
-        for r in range(warmup, warmup + steps):
-            step(r)
-        ev1.record()
-        eng.sync()
-        torch.cuda.synchronize()
-        elapsed = time.perf_counter() - t0  # this rank's K steps, all ranks started together; MAX below
-        self.barrier()
-        torch.cuda.synchronize()
-        self.gpu_ms = ev0.elapsed_time(ev1)
-        if world > 1:
-            t = torch.tensor([elapsed], dtype=torch.float64, device=self.cdev)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-        self.elapsed = elapsed
+        self.elapsed_all, self.gpu_ms_all = [], []
+        for rep in range(reps):
+            first = warmup + rep * steps
+            eng.sync()
+            torch.cuda.synchronize()
+            self.barrier()
+            torch.cuda.synchronize()
+            ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            ev0.record()
+            for r in range(first, first + steps):
+                step(r)
+            ev1.record()
+            eng.sync()
+            torch.cuda.synchronize()
+            elapsed = time.perf_counter() - t0  # this rank's K steps, all ranks started together; MAX below
+            self.barrier()
+            torch.cuda.synchronize()
+            self.gpu_ms_all.append(ev0.elapsed_time(ev1))
+            if self.coll:
+                t = torch.tensor([elapsed], dtype=torch.float64, device=self.cdev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                elapsed = float(t.item())
+            self.elapsed_all.append(elapsed)
+        mid = sorted(range(reps), key=lambda i: self.elapsed_all[i])[reps // 2]
+        self.elapsed, self.gpu_ms = self.elapsed_all[mid], self.gpu_ms_all[mid]
+        self.timed_rounds = (warmup + mid * steps, warmup + (mid + 1) * steps)  # the median repetition's rounds
+        steps_all = reps * steps
 
         # ---- checks outside the timed region ----------------------------------------------
-        counts = self.n_out[: warmup + steps].cpu().numpy()
+        counts = self.n_out[: warmup + steps_all].cpu().numpy()
         if not self.mix:
             assert (counts == G).all(), f"expected {G} decisions per round, got {counts[:8]}"
             assert bool((self.p_st == 0).all()) and bool((self.d_k[:G] == 1).all()) \
-                and bool((self.d_s[:G] == warmup + steps).all())
-        decisions_local = int(counts[warmup:].sum())
+                and bool((self.d_s[:G] == warmup + steps_all).all())
+        decisions_local = int(counts[self.timed_rounds[0]:self.timed_rounds[1]].sum())
         self.shard_counters = None
-        if world > 1:
+        if self.coll:
             t = torch.tensor([decisions_local], dtype=torch.int64, device=self.cdev)
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             self.decisions_total = int(t.item())
@@ -380,6 +395,7 @@ def end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, me
         host_step(r)
     te_sync = (time.perf_counter() - te) / (e2e_rounds - 1)
     assert args.mix or int(hno[0]) == G
+    del hcols, hg, ho, hd, hno, hst, host_step  # views of gpx_host_alloc memory: it goes away with the engine
     ee.close()  # (unpins / frees everything that was pinned or allocated through it)
 
     # -- the asynchronous calls (gpx_*_batch_async + gpx_engine_wait), two steps in flight: the inputs of step r + 1
@@ -430,6 +446,7 @@ def end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, me
     assert args.mix or n_dec == G
     b_in = G * 4 + nv * (16 if common else 24)
     b_out = G * 17 + nv + n_dec * 21 + 4
+    del hcols, hg, ring, submit, o, d  # views of gpx_host_alloc memory: it goes away with the engine
     ee.close()
     if prev_affinity is not None:
         os.sched_setaffinity(0, prev_affinity)
@@ -452,6 +469,119 @@ def end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, me
             "path": "gpx_propose_batch_async + gpx_accept_reply_batch_async + gpx_engine_wait with HOST "
                     "pointers, three steps in flight (GPX_ASYNC_DEPTH=6): H2D of the next steps beside the kernels and the D2H of step r; "
                     "synchronous_calls_ms_per_step = the plain calls, one after the other"}
+
+
+def wire_end_to_end_leg(args, torch, dev, local_rank, G, K, link, steps=6, in_flight=3):
+    """The same step as the NIO thread would hand it over: the remote acceptors' BATCHED_ACCEPT_REPLY
+    frames in host memory (BatchedAcceptReply.java:103-173: one frame per group and acceptor, one slot each) -> copy in
+    -> gpx_wire_decode_dev -> gpx_accept_reply_batch_dev -> gpx_wire_pack_commits_dev -> BATCHED_COMMIT frames
+    (BatchedCommit.java:184-215) copied back to host memory, `in_flight` steps deep on three streams (copy in / the
+    engine's / copy out).  The coordinator's own vote never was a frame: K - 1 frames per group come in.  Frames are
+    built beforehand (a messenger's work, not the engine's)."""
+    from gigapaxos_amd import Engine, hri_create, load_hip, S_OK
+    from gigapaxos_amd import wire as W
+    P = lambda t: t.data_ptr()  # noqa: E731
+    members = list(range(100, 100 + K))
+    nfr = (K - 1) * G
+    eng = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=nfr + 1024, device=local_rank)
+    we = W.WireEngine(eng)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    assert (eng.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
+    names = W.fixed_names(np.arange(G))
+    nb, noff = np.ascontiguousarray(names.reshape(-1)), (np.arange(G + 1, dtype=np.int32) * names.shape[1])
+    st, rows = np.zeros(G, np.uint8), np.arange(G, dtype=np.int32)
+    we.lib.check(we.lib.fn["names_bind"](eng.h, G, nb.ctypes.data, noff.ctypes.data, rows.ctypes.data, st.ctypes.data), "names_bind")
+    assert (st == S_OK).all()
+    s_k, s_in, s_out = (torch.cuda.Stream(device=dev) for _ in range(3))
+    eng.set_stream(s_k.cuda_stream)
+    rng = np.random.default_rng(6)
+    # host side: the frames of every step (pinned), the frames coming back
+    h_buf, h_off = [], []
+    for r in range(steps):
+        order = rng.permutation(nfr)
+        buf, off = W.bar_frames_single_slot(names[(order % G).astype(np.int64)], 0, np.asarray(members[1:], np.int32)[order // G], 0, 100, r, r + 1)
+        h_buf.append(torch.from_numpy(buf).pin_memory())
+        h_off.append(torch.from_numpy(off).pin_memory())
+    frame_bytes, off_bytes = int(h_buf[0].numel()), int(h_off[0].numel()) * 8
+    cap_bytes = 64 * G
+    i32 = lambda n: torch.empty(n, dtype=torch.int32, device=dev)  # noqa: E731
+    u8 = lambda n: torch.empty(n, dtype=torch.uint8, device=dev)  # noqa: E731
+    g_all = torch.arange(G, dtype=torch.int32, device=dev)
+    p_out = [i32(G) for _ in range(4)] + [u8(G)]
+    sets = []
+    for _ in range(in_flight):
+        sets.append(dict(
+            d_buf=torch.empty(frame_bytes, dtype=torch.uint8, device=dev), d_off=torch.empty(nfr + 1, dtype=torch.int64, device=dev),
+            fst=u8(nfr), fg=i32(nfr), ft=i32(nfr), vcols=[i32(nfr) for _ in range(7)],
+            counts=torch.zeros(8, dtype=torch.int32, device=dev), dcols=[i32(nfr) for _ in range(5)] + [u8(nfr)],
+            n_out=torch.zeros(1, dtype=torch.int32, device=dev), vst=u8(nfr), out=u8(cap_bytes),
+            foff=torch.empty(G, dtype=torch.int64, device=dev), flen=i32(G), fgi=i32(G),
+            nfo=torch.zeros(1, dtype=torch.int32, device=dev), nbo=torch.zeros(1, dtype=torch.int64, device=dev),
+            h_out=torch.empty(cap_bytes, dtype=torch.uint8).pin_memory(), h_nfo=torch.zeros(1, dtype=torch.int32).pin_memory(),
+            h_nbo=torch.zeros(1, dtype=torch.int64).pin_memory(),
+            ev_in=torch.cuda.Event(), ev_k=torch.cuda.Event(), ev_out=torch.cuda.Event(), used=False))
+    out_frame_bytes = [0]
+
+    def submit(r):
+        S = sets[r % in_flight]
+        with torch.cuda.stream(s_in):
+            if S["used"]:
+                s_in.wait_event(S["ev_k"])  # the kernels that read this set's frames are done
+            S["d_buf"].copy_(h_buf[r], non_blocking=True)
+            S["d_off"].copy_(h_off[r], non_blocking=True)
+            S["ev_in"].record(s_in)
+        with torch.cuda.stream(s_k):
+            s_k.wait_event(S["ev_in"])
+            if S["used"]:
+                s_k.wait_event(S["ev_out"])  # ... and its frames of the step before have left
+            eng.call_dev("propose_batch", G, P(g_all), 0, *[P(t) for t in p_out])
+            W.decode_dev(we, nfr, P(S["d_buf"]), P(S["d_off"]), P(S["fst"]), P(S["fg"]), P(S["ft"]),
+                         votes=(nfr, [P(c) for c in S["vcols"]]), counts_ptr=P(S["counts"]))
+            eng.call_dev("accept_reply_batch", nfr, *[P(S["vcols"][i]) for i in range(6)], *[P(c) for c in S["dcols"]],
+                         P(S["n_out"]), P(S["vst"]))
+            W.pack_commits_dev(we, nfr, P(S["n_out"]), [P(c) for c in S["dcols"]], P(S["out"]), cap_bytes, P(S["foff"]),
+                               P(S["flen"]), P(S["fgi"]), P(S["nfo"]), P(S["nbo"]))
+            S["ev_k"].record(s_k)
+        with torch.cuda.stream(s_out):
+            s_out.wait_event(S["ev_k"])
+            nbytes = out_frame_bytes[0] or cap_bytes  # (known after the first step: every round packs the same frames)
+            S["h_out"][:nbytes].copy_(S["out"][:nbytes], non_blocking=True)
+            S["h_nfo"].copy_(S["nfo"], non_blocking=True)
+            S["h_nbo"].copy_(S["nbo"], non_blocking=True)
+            S["ev_out"].record(s_out)
+        S["used"] = True
+        return S
+
+    def wait(S):
+        S["ev_out"].synchronize()
+        assert int(S["h_nfo"][0]) == G, (int(S["h_nfo"][0]), G)
+        return int(S["h_nbo"][0])
+    out_frame_bytes[0] = wait(submit(0))  # warm: every buffer touched, the outgoing size known
+    from collections import deque
+    t0 = time.perf_counter()
+    flying = deque()
+    for r in range(1, steps):
+        flying.append(submit(r))
+        if len(flying) == in_flight:
+            wait(flying.popleft())
+    while flying:
+        wait(flying.popleft())
+    te = (time.perf_counter() - t0) / (steps - 1)
+    torch.cuda.synchronize()
+    eng.close()
+    b_in, b_out = frame_bytes + off_bytes, out_frame_bytes[0] + 12
+    peak = link["hipHostMalloc"]["both_directions_each_GBps"]
+    return {"ms_per_step": round(te * 1e3, 4), "decisions_per_sec": round(G / te, 1), "votes_per_sec": round(nfr / te, 1),
+            "frames_in": nfr, "frame_bytes_in": frame_bytes, "frame_offsets_bytes_in": off_bytes,
+            "frames_out": G, "frame_bytes_out": out_frame_bytes[0],
+            "pcie_in_GBps": round(b_in / te / 1e9, 1), "pcie_out_GBps": round(b_out / te / 1e9, 1),
+            "achieved_over_link_peak": {"in": round(b_in / te / 1e9 / max(peak, 1e-9), 3), "out": round(b_out / te / 1e9 / max(peak, 1e-9), 3),
+                                        "peak_used": "link.hipHostMalloc.both_directions_each_GBps (same run, same box)"},
+            "steps_in_flight": in_flight,
+            "path": "pinned host frames -> hipMemcpyAsync -> gpx_wire_decode_dev -> gpx_accept_reply_batch_dev -> "
+                    "gpx_wire_pack_commits_dev -> hipMemcpyAsync -> pinned host frames; %d BATCHED_ACCEPT_REPLY frames of one slot "
+                    "(%d bytes each, + 8 bytes of offset) in, %d BATCHED_COMMIT frames out per step" %
+                    (nfr, frame_bytes // max(nfr, 1), G)}
 
 
 def main():
@@ -486,6 +616,17 @@ def main():
                     help="N > 1 only: skip the second timed leg on BASELINE config #4's fixed space (the `strong` object)")
     ap.add_argument("--no-promise", action="store_true",
                     help="do not declare the proposal batches ordered (gpx_engine_set_ordered_batches)")
+    ap.add_argument("--timed-regions", type=int, default=3,
+                    help="the timed region (exactly --steps steps between barrier + synchronize) is run this many times; "
+                         "ms_per_step / value are the median region's, ms_per_step_spread has them all")
+    ap.add_argument("--pool", type=int, default=96,
+                    help="independently seeded rounds kept in HBM (72 MB each at 1 M groups x 3): every step of the default "
+                         "run has its own; a longer run reuses them modulo this")
+    ap.add_argument("--force-collectives", action="store_true",
+                    help="take the N > 1 branch with a world of ONE rank: dist.init_process_group('nccl'), the barriers, the "
+                         "device-tensor all_reduce / all_gather and the strong-scaling leg really execute over RCCL on one "
+                         "GPU (tests/test_bench_collectives_gpu.py)")
+    ap.add_argument("--no-wire-leg", action="store_true", help="skip end_to_end.wire (frames in host memory -> frames back)")
     ap.add_argument("--same-device", action="store_true",
                     help="N > 1 on a box with ONE GPU: every rank runs on device 0 and the ranks talk over gloo.  Runs "
                          "the whole N > 1 code path (two timed legs, max-over-ranks, the counters' all_gather); the "
@@ -550,8 +691,9 @@ def main():
     dev = torch.device("cuda", local_rank)
     torch.zeros(1, device=dev)  # wake the device before the HIP library's own runtime looks for it
     torch.cuda.synchronize()
-    if world > 1:
+    if world > 1 or args.force_collectives:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         if args.same_device:
             dist.init_process_group("gloo", rank=rank, world_size=world)
         else:
@@ -561,17 +703,20 @@ def main():
 
     K = args.k
     steps, warmup, psteps = args.steps, args.warmup, args.profile_steps
+    REPS = max(1, args.timed_regions)
+    collectives = world > 1 or args.force_collectives
     leg = CoordinatorLeg(args, torch, dist, dev, local_rank, rank, world, args.groups, K, args.split_global,
-                         rounds=warmup + steps + psteps)
-    leg.run_timed(warmup, steps)
+                         rounds=warmup + REPS * steps + psteps)
+    leg.run_timed(warmup, steps, REPS)
     eng, step, rounds = leg.eng, leg.step, leg.rounds
+    leg_pool_rounds = leg.pool_rounds
     G, G_global, nv, nv_round, members, mem, cfg_id = leg.G, leg.G_global, leg.nv, leg.nv_round, leg.members, leg.mem, leg.cfg_id
     elapsed, gpu_ms, decisions_total, votes_total = leg.elapsed, leg.gpu_ms, leg.decisions_total, leg.votes_total
 
     # ---- per-kernel timing with hipEvents on the launch stream (profile pass), kept apart per call ---------
     roofline = None
     if psteps > 0:
-        per_call = leg.profile_calls(warmup + steps, psteps)
+        per_call = leg.profile_calls(warmup + REPS * steps, psteps)
         kstats = {}
         for call in per_call.values():
             for k, (nl, ms) in call.items():
@@ -643,7 +788,7 @@ def main():
     # ---- N > 1: the shape BASELINE's metric is quoted on - ONE space of 1 M groups, 5 replicas, hash-sharded over
     # the ranks (config #4): total work fixed, so this is the strong-scaling figure beside the weak `value` -------
     strong = None
-    if world > 1 and not args.split_global and not args.no_strong_leg:
+    if collectives and not args.split_global and not args.no_strong_leg:
         leg.close()
         sleg = CoordinatorLeg(args, torch, dist, dev, local_rank, rank, world, STRONG_GROUPS, STRONG_K, True,
                               rounds=warmup + steps, mix=False)
@@ -661,6 +806,8 @@ def main():
     end_to_end = None
     if rank == 0 and world == 1 and not args.no_end_to_end:
         end_to_end = end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, mem, cfg_id)
+        if not args.no_wire_leg and not args.mix and not args.runs and not args.sorted:
+            end_to_end["wire"] = wire_end_to_end_leg(args, torch, dev, local_rank, G, K, end_to_end["link"])
 
     # ---- CPU baseline: the oracle (port of the reference algorithm) on the host cores ---
     cpu_baseline = None
@@ -822,6 +969,11 @@ def main():
             "steps": steps,
             "warmup": warmup,
             "ms_per_step": round(elapsed * 1e3 / steps, 4),
+            # the timed region (barrier + synchronize, exactly `steps` steps, synchronize + barrier, MAX over ranks) run
+            # `timed_regions` times on consecutive rounds; `ms_per_step` and `value` are the MEDIAN region's
+            "ms_per_step_spread": {"timed_regions": REPS, "min": round(min(leg.elapsed_all) * 1e3 / steps, 4),
+                                   "median": round(elapsed * 1e3 / steps, 4), "max": round(max(leg.elapsed_all) * 1e3 / steps, 4),
+                                   "all": [round(x * 1e3 / steps, 4) for x in leg.elapsed_all]},
             "higher_is_better": True,
             "scaling": "strong" if args.split_global else "weak",
             "vs_baseline": None,
@@ -841,6 +993,7 @@ def main():
                            "pcg64": "numpy PCG64 with the same seed (gigapaxos_amd/streams.py vote_round)",
                            "pcg64-runs": "numpy PCG64, K ascending runs (gigapaxos_amd/streams.py vote_round_runs)"
                            }[stream_name(args, streams)],
+                "rounds_seeded_individually": leg_pool_rounds,
                 "ordered_proposals_promise": not args.no_promise,
                 "ordered_batches_mask": CoordinatorLeg.promise_mask(args),
                 "parallelism": "groups sharded across GPUs, no collective on the decide path",
@@ -854,13 +1007,18 @@ def main():
             "cpu_baseline": cpu_baseline,
             "parity_checked": parity_checked,
         }
+        if args.force_collectives:
+            out["collectives"] = {"backend": dist.get_backend(), "world": world, "forced": True,
+                                  "note": "the N > 1 branch executed with a world of one rank: init_process_group, barriers, "
+                                          "all_reduce(MAX / SUM) and all_gather on device tensors over RCCL, the strong leg",
+                                  "shard_counters": leg.shard_counters}
         if args.same_device:
             out["same_device"] = {"ranks_on_device_0": world, "collectives": "gloo (host tensors)",
                                   "note": "ONE GPU shared by %d processes: exercises the N > 1 code path (both timed legs, "
                                           "max-over-ranks, the counters' all_gather); NOT a scaling figure" % world}
             out["shard_counters"] = leg.shard_counters
         print(json.dumps(out))
-    if world > 1:
+    if world > 1 or args.force_collectives:
         dist.destroy_process_group()
 
 

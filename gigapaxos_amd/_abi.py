@@ -14,6 +14,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import weakref
 from dataclasses import dataclass
 
 import numpy as np
@@ -303,15 +304,24 @@ class Engine:
         self.h = h
         self.kmax = kmax
         self.my_id = my_id
+        self._host_views = {}  # address -> weakref of the numpy view handed out by host_alloc
 
-    def close(self):
+    def close(self, force: bool = False):
+        """gpx_engine_destroy.  Memory from host_alloc goes with it: while arrays over it are still referenced the call
+        raises (a later access would read freed pages) - drop them first, or force=True (the destructor's choice)."""
         if self.h:
+            views = getattr(self, "_host_views", None)
+            if views and not force:
+                live = [r() for r in views.values() if r() is not None]
+                if live:
+                    raise GpxError(f"{len(live)} host_alloc array(s) still referenced at close(): host_free them or drop "
+                                   "the references first (their memory is freed by gpx_engine_destroy)")
             self.lib.fn["engine_destroy"](self.h)
             self.h = None
 
     def __del__(self):
         try:
-            self.close()
+            self.close(force=True)
         except Exception:
             pass
 
@@ -373,7 +383,9 @@ class Engine:
 
     def host_alloc(self, n: int, dtype=np.int32) -> np.ndarray:
         """A numpy array of n elements over memory from gpx_host_alloc (hipHostMalloc): the DMA engines reach it
-        at the link's full rate.  Give it back with host_free(array) - or leave it to close()."""
+        at the link's full rate.  Give it back with host_free(array) - or leave it to close().  The array is a VIEW of
+        that block: it must not be touched after host_free / close() (numpy cannot be told; close() refuses to go on
+        while such arrays are still referenced elsewhere, unless force=True)."""
         dt = np.dtype(dtype)
         nbytes = max(int(n), 1) * dt.itemsize
         p = _VP()
@@ -381,11 +393,17 @@ class Engine:
         buf = (C.c_char * nbytes).from_address(p.value)
         a = np.frombuffer(buf, dtype=dt, count=int(n))
         a[...] = 0
+        self._host_views[p.value] = weakref.ref(a)
         return a
 
     def host_free(self, *arrays):
         for a in arrays:
+            self._host_views.pop(a.ctypes.data, None)
             self.lib.check(self.lib.fn["host_free"](self.h, _p(a)), "host_free")
+
+    def live_host_views(self):
+        """Arrays from host_alloc that somebody still holds (their memory goes away with close())."""
+        return [r() for r in self._host_views.values() if r() is not None]
 
     def sync(self):
         self.lib.check(self.lib.fn["engine_sync"](self.h), "engine_sync")

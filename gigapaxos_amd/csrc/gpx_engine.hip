@@ -7,6 +7,12 @@
  */
 #include <hip/hip_runtime.h>
 #include <unistd.h>
+#include <dirent.h>
+#include <signal.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <cerrno>
+#include <chrono>
 
 #include <cmath>
 #include <cstdio>
@@ -65,15 +71,93 @@ struct PendingEvent {
  * serialised by the stream) count once. */
 std::mutex g_live_mu;
 std::map<int, std::map<hipStream_t, int>> g_live_streams;
+/* ... and of the OTHER processes on the device (three processes that each believe they are alone size their
+ * grids at two workgroups per CU each, none is resident whole, all give up).  Every process keeps a file
+ * /dev/shm/gpx_engines/<PCI bus id>.<pid> holding the number of streams its engines launch on; the others' files are
+ * summed (files of dead pids are removed), at most every 50 ms.  Processes that do not share /dev/shm (separate
+ * containers) cannot see each other: GPX_DEVICE_SHARERS says it for them (include/gpx.h). */
+struct ProcRegistry {
+  std::string dir = "/dev/shm/gpx_engines", mine;
+  int foreign = 0;
+  std::chrono::steady_clock::time_point sampled{};
+  bool ok = false, tried = false;
+};
+std::map<int, ProcRegistry> g_proc_reg; /* by device; under g_live_mu */
+ProcRegistry& proc_registry(int device) {
+  ProcRegistry& R = g_proc_reg[device];
+  if (!R.tried) {
+    R.tried = true;
+    char bus[64] = {0};
+    if (hipDeviceGetPCIBusId(bus, (int)sizeof(bus) - 1, device) != hipSuccess) {
+      (void)hipGetLastError();
+      snprintf(bus, sizeof(bus), "dev%d", device);
+    }
+    if (const char* d = getenv("GPX_REGISTRY_DIR")) R.dir = d; /* tests */
+    if (mkdir(R.dir.c_str(), 0777) == 0 || errno == EEXIST) {
+      (void)chmod(R.dir.c_str(), 0777);
+      R.mine = R.dir + "/" + bus + "." + std::to_string((long)getpid());
+      R.ok = true;
+    }
+  }
+  return R;
+}
+void proc_registry_publish(int device, int nstreams) { /* g_live_mu held */
+  ProcRegistry& R = proc_registry(device);
+  if (!R.ok) return;
+  if (nstreams <= 0) {
+    (void)unlink(R.mine.c_str());
+    return;
+  }
+  if (FILE* fp = fopen((R.mine + ".tmp").c_str(), "w")) {
+    fprintf(fp, "%d\n", nstreams);
+    fclose(fp);
+    (void)rename((R.mine + ".tmp").c_str(), R.mine.c_str());
+  }
+}
+int proc_registry_foreign(int device) { /* g_live_mu held */
+  ProcRegistry& R = proc_registry(device);
+  if (!R.ok) return 0;
+  const auto now = std::chrono::steady_clock::now();
+  if (R.sampled.time_since_epoch().count() && now - R.sampled < std::chrono::milliseconds(50)) return R.foreign;
+  R.sampled = now;
+  int sum = 0;
+  const std::string base = R.mine.substr(R.dir.size() + 1);
+  const std::string prefix = base.substr(0, base.rfind('.') + 1);
+  if (DIR* d = opendir(R.dir.c_str())) {
+    while (struct dirent* de = readdir(d)) {
+      const std::string name = de->d_name;
+      if (name.compare(0, prefix.size(), prefix) != 0 || name == base || name.size() > 4 && name.substr(name.size() - 4) == ".tmp") continue;
+      const long pid = atol(name.c_str() + prefix.size());
+      const std::string path = R.dir + "/" + name;
+      if (pid <= 0 || (kill((pid_t)pid, 0) != 0 && errno == ESRCH)) { /* its process is gone (it did not get to unlink) */
+        (void)unlink(path.c_str());
+        continue;
+      }
+      int k = 0;
+      if (FILE* fp = fopen(path.c_str(), "r")) {
+        if (fscanf(fp, "%d", &k) != 1) k = 1;
+        fclose(fp);
+      }
+      sum += std::max(k, 1);
+    }
+    closedir(d);
+  }
+  R.foreign = sum;
+  return sum;
+}
+
 void live_add(int device, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_live_mu);
   g_live_streams[device][s]++;
+  proc_registry_publish(device, (int)g_live_streams[device].size());
 }
 void live_drop(int device, hipStream_t s) {
   std::lock_guard<std::mutex> lk(g_live_mu);
   auto& m = g_live_streams[device];
   auto it = m.find(s);
   if (it != m.end() && --it->second <= 0) m.erase(it);
+  proc_registry_publish(device, (int)m.size());
+  if (m.empty()) g_proc_reg.erase(device); /* (the next engine of this process looks the directory up afresh) */
 }
 
 }  // namespace
@@ -155,6 +239,9 @@ struct gpx_engine {
    * it (GPX_DEVICE_SHARERS, default 1) decide which grids need no tickets; the host-mapped word a waiter that gave up
    * writes (DevScratch.xabort) */
   int cus = 0, sharers = 1;
+  uint32_t xchg_test_skew = 0;          /* GPX_XCHG_TEST_SKEW (tests/test_many_engines_gpu.py): see xchg_ctl */
+  bool sharers_set = false;             /* GPX_DEVICE_SHARERS given: it replaces the registry of other processes */
+  std::map<const void*, int> occ;       /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the exchange kernels */
   uint32_t xchg_timeout_ms = GPX_XCHG_TIMEOUT_MS; /* GPX_XCHG_TIMEOUT_MS: how long an exchange kernel's pollers wait */
   bool one_launch = true;            /* GPX_XCHG_SLOTS=0 (comparison builds, tests): the check kernel + the work kernel instead */
   uint32_t gx_arrive = 0; /* grid_exchange's arrival counters as this engine's launches have left them */
@@ -466,31 +553,47 @@ int check_batch(gpx_engine* h, int32_t n) {
     if (int _rc_abort = check_batch((h), 0)) return _rc_abort;  \
   } while (0)
 
-/* the streams (x processes) that may have a one-launch kernel - workgroups waiting for each other at grid_exchange -
- * on this engine's device at the same moment */
+/* the streams that may have a one-launch kernel - workgroups waiting for each other at grid_exchange - on this engine's
+ * device at the same moment: those of this process's engines, plus either what GPX_DEVICE_SHARERS says about other
+ * processes (explicit: the count of processes, each taken to launch on as many streams as this one) or what their
+ * registry files say */
 int xchg_share(const gpx_engine* e) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
   int live = 1;
-  {
-    std::lock_guard<std::mutex> lk(g_live_mu);
-    auto it = g_live_streams.find(e->device);
-    if (it != g_live_streams.end()) live = std::max<int>(1, (int)it->second.size());
-  }
-  return live * e->sharers;
+  auto it = g_live_streams.find(e->device);
+  if (it != g_live_streams.end()) live = std::max<int>(1, (int)it->second.size());
+  if (e->sharers_set) return live * e->sharers;
+  return live + proc_registry_foreign(e->device);
 }
-/* May a call over `nchunks` chunks of 256 records take the ONE-launch form (gpx_one.hip.h)?  Only with a grid that is
- * resident whatever the kernel and whoever else is launching: at most 2 workgroups per CU, divided by the streams the
- * device's engines launch on and the processes sharing it.  Then: the grid (a multiple of 16: every counter line gets
+/* May a call over `nchunks` chunks take the ONE-launch form (gpx_one.hip.h) with this kernel?  Only with a grid that is
+ * resident whatever else is launching: per CU at most two workgroups AND at most one fewer than the occupancy query
+ * promises for THIS kernel (the hardware admits one fewer than the query says for some register counts:
+ * MI355X_MICROARCH.md, residency), divided by the sharers.  Then: the grid (a multiple of 16: every counter line gets
  * the same number of arrivals) and what the cumulative arrival counters read afterwards. */
-bool xchg_ctl(gpx_engine* e, int nchunks, GridXchg* Q, int* grid) {
+bool xchg_ctl(gpx_engine* e, int nchunks, GridXchg* Q, int* grid, const void* kernel, int block) {
   const int g16 = (std::max(nchunks, 1) + GPX_GX_LINES - 1) / GPX_GX_LINES * GPX_GX_LINES;
-  if (!e->one_launch || (int64_t)g16 * xchg_share(e) > (int64_t)2 * e->cus) return false;
+  if (!e->one_launch) return false;
+  int per_cu = 2;
+  {
+    auto it = e->occ.find(kernel);
+    if (it == e->occ.end()) {
+      int nb = 0;
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, kernel, block, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        nb = 0;
+      }
+      it = e->occ.emplace(kernel, nb).first;
+    }
+    per_cu = std::min(2, it->second - 1);
+  }
+  if (per_cu < 1 || (int64_t)g16 * xchg_share(e) > (int64_t)per_cu * e->cus) return false;
   const OneCtl C = one_ctl(e);
   *grid = g16;
   Q->arrive = (uint32_t*)(e->one_words + GPX_ONE_TICKETS);
   Q->verdict = C.verdict;
   Q->epoch = C.epoch;
   e->gx_arrive += (uint32_t)(g16 / GPX_GX_LINES);
-  Q->arrive_target = e->gx_arrive;
+  Q->arrive_target = e->gx_arrive + e->xchg_test_skew; /* (skew: test hook - a target no launch reaches: every poller gives up) */
   Q->timeout_ms = e->xchg_timeout_ms;
   return true;
 }
@@ -542,7 +645,7 @@ struct Stage {
   int finish() {
     HIPCHK(hipMemcpyAsync(e->hs_out, e->ds_out, out_off, hipMemcpyDeviceToHost, e->sB));
     HIPCHK(hipStreamSynchronize(e->sB));
-    return GPX_OK;
+    return check_batch(e, 0); /* (an exchange kernel of THIS call gave up: GPX_EDEVICE now, not on the next call) */
   }
 };
 
@@ -780,10 +883,12 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   {
     HIPCHK_CREATE(hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, e->device));
     if (const char* sv = getenv("GPX_XCHG_SLOTS")) e->one_launch = atoi(sv) != 0; /* test switch: 0 = the two-launch forms */
-    if (const char* sh = getenv("GPX_DEVICE_SHARERS")) e->sharers = std::max(1, atoi(sh));
+    if (const char* sh = getenv("GPX_DEVICE_SHARERS")) e->sharers = std::max(1, atoi(sh)), e->sharers_set = true;
+    if (const char* tm = getenv("GPX_XCHG_TIMEOUT_MS")) e->xchg_timeout_ms = (uint32_t)std::max(1, atoi(tm));
+    if (const char* sk = getenv("GPX_XCHG_TEST_SKEW")) e->xchg_test_skew = (uint32_t)std::max(0, atoi(sk));
     if (const char* ad = getenv("GPX_ASYNC_DEPTH")) e->async_depth = std::max(1, std::min(GPX_ASYNC_DEPTH_MAX, atoi(ad)));
     HIPCHK_CREATE(hipHostMalloc((void**)&e->h_abort, 64, hipHostMallocMapped));
-    *e->h_abort = 0;
+    memset(e->h_abort, 0, 64);
     void* dptr = nullptr;
     HIPCHK_CREATE(hipHostGetDevicePointer(&dptr, e->h_abort, 0));
     X.xabort = (uint32_t*)dptr;
@@ -1333,7 +1438,11 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
     const int nch = (n + GPX_RBLOCK - 1) / GPX_RBLOCK;
     int pg = nch;
     GridXchg Q{};
-    const bool small = xchg_ctl(e, nch, &Q, &pg);
+    const void* runs_kernel =
+        e->cfg.kmax <= 4 ? (n <= 65536 ? (const void*)k_ar_runs<4, true, true> : (const void*)k_ar_runs<4, true, false>)
+        : e->cfg.kmax <= 8 ? (n <= 65536 ? (const void*)k_ar_runs<8, true, true> : (const void*)k_ar_runs<8, true, false>)
+                           : (n <= 65536 ? (const void*)k_ar_runs<16, true, true> : (const void*)k_ar_runs<16, true, false>);
+    const bool small = xchg_ctl(e, nch, &Q, &pg, runs_kernel, GPX_RBLOCK);
     if (!small)
       LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
                 gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
@@ -1441,7 +1550,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
     GridXchg Q;
     int pg;
-    if (xchg_ctl(e, nch, &Q, &pg)) { /* ONE launch: a grid that is resident for sure, the verdict exchanged among its workgroups */
+    if (xchg_ctl(e, nch, &Q, &pg, (const void*)k_ac_pers<false>, GPX_DBLOCK)) { /* ONE launch: a grid that is resident for sure, the verdict exchanged among its workgroups */
       LaunchScope _ls(e, "k_ac_pers");
       hipLaunchKernelGGL(k_ac_pers<false>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, gidx, bnum, bcoord, slot,
                          median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, n_runs, 0);
@@ -1560,7 +1669,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
     GridXchg Q;
     int pg;
-    if (xchg_ctl(e, nch, &Q, &pg)) {
+    if (xchg_ctl(e, nch, &Q, &pg, (const void*)k_ac_pers<true>, GPX_DBLOCK)) {
       LaunchScope _ls(e, "k_ac_pers");
       hipLaunchKernelGGL(k_ac_pers<true>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, gidx, bnum, bcoord, slot,
                          median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, status, D,
@@ -1701,7 +1810,9 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
     const int nch = grid_for(n);
     GridXchg Q;
     int pg;
-    if (xchg_ctl(e, nch, &Q, &pg)) { /* ONE launch: a grid that is resident for sure, the verdict exchanged among its workgroups */
+    const void* pers_kernel = e->cfg.kmax <= 4 ? (const void*)k_propose_pers<4>
+                              : e->cfg.kmax <= 8 ? (const void*)k_propose_pers<8> : (const void*)k_propose_pers<16>;
+    if (xchg_ctl(e, nch, &Q, &pg, pers_kernel, GPX_BLOCK)) { /* ONE launch: a grid that is resident for sure, the verdict exchanged among its workgroups */
       if (e->cfg.kmax <= 4)
         LAUNCH(e, "k_propose_pers", k_propose_pers<4>, pg, e->S, e->X, Q, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
                status, handle);

@@ -64,7 +64,9 @@ JFN(jobject, hostAlloc)(JNIEnv* env, jclass c, jlong h, jlong bytes) {
   (void)c;
   void* p = NULL;
   if (bytes <= 0 || gpx_host_alloc(H(h), (size_t)bytes, &p) != GPX_OK) return NULL;
-  return (*env)->NewDirectByteBuffer(env, p, bytes);
+  jobject buf = (*env)->NewDirectByteBuffer(env, p, bytes);
+  if (!buf) (void)gpx_host_free(H(h), p); /* (no direct-buffer support, or out of memory: the block must not stay until destroy) */
+  return buf;
 }
 JFN(jint, hostFree)(JNIEnv* env, jclass c, jlong h, jobject buf) {
   (void)c;

@@ -40,12 +40,23 @@
  *     the live engines of a device launch on (engines given ONE stream with
  *     gpx_engine_set_stream are serialised by it and count once) and only
  *     launches such a kernel with a grid that fits the device together with one
- *     on every other stream - occupancy x CUs / streams; where that share gets
- *     small a call takes the two-launch form, with the same results.
- *     Processes SHARING a device cannot see each other: tell each of them with
- *     GPX_DEVICE_SHARERS=<processes>.  A waiter that still starves gives up
- *     after two seconds and every later call returns GPX_EDEVICE - never a
- *     hang.  DESIGN.md 3 ii-b.)
+ *     on every other stream - per CU at most two workgroups and at most one
+ *     fewer than hipOccupancyMaxActiveBlocksPerMultiprocessor promises for that
+ *     kernel, x CUs / streams; where that share gets small a call takes the
+ *     two-launch form, with the same results.  The streams of OTHER PROCESSES on
+ *     the device count too: every process keeps a file
+ *     /dev/shm/gpx_engines/<PCI bus id>.<pid> with its number of streams, read
+ *     by the others at most every 50 ms (files of dead processes are removed).
+ *     Processes that do not share /dev/shm - separate containers - cannot see
+ *     each other: tell each of them with GPX_DEVICE_SHARERS=<processes>, which
+ *     then replaces the files.  A waiter that still starves gives up after ten
+ *     seconds (GPX_XCHG_TIMEOUT_MS) and leaves a verdict that makes every
+ *     workgroup arriving later refuse its records; the call during which that
+ *     happens returns GPX_EDEVICE itself - from its own wait
+ *     (the host-pointer calls, gpx_engine_wait, gpx_engine_sync, and
+ *     gpx_group_create / retire / snapshot, which refuse to read or build on
+ *     such a table) - and so does every later call: never a hang, never
+ *     GPX_OK over partial outputs.  DESIGN.md 3.)
  *   - the plain entry points take HOST pointers (what a JNI direct ByteBuffer
  *     gives); the *_dev twins take DEVICE pointers, run asynchronously on the
  *     engine's stream (gpx_engine_set_stream) and leave counts in device memory

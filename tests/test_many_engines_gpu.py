@@ -126,3 +126,67 @@ def test_eight_engines_small_ordered_batches_from_their_own_threads(hip_lib, ora
     for h in holders:
         h.close()
     assert all(o and o[0] == "ok" for o in out), out
+
+
+def _one_small_propose(hip_lib, G=20_000):
+    """An ordered proposal batch of G records under the promise: the one-launch kernel (k_propose_pers) when the engine
+    may take it, k_one_check + k_propose_one otherwise.  Returns (rc of the call as an exception or None, kernels)."""
+    eh = Engine(hip_lib, 100, G, kmax=3, window=8, max_batch=G + 64)
+    mem = np.tile(np.array(MEMBERS, np.int32), (G, 1))
+    assert (eh.create_groups(np.arange(G, dtype=np.int32), mem, 3, hri_create(G, 3, 100)) == S_OK).all()
+    eh.set_ordered_batches(MASK)
+    eh.profile(2)
+    err = None
+    try:
+        out = eh.propose(np.arange(G, dtype=np.int32))
+        assert (out[4] == S_OK).all() and (out[0] == 1).all()
+    except Exception as ex:  # noqa: BLE001
+        err = ex
+    names = set() if err else set(eh.profile_read())
+    return eh, err, names
+
+
+def test_other_processes_on_the_device_are_counted(hip_lib, tmp_path, monkeypatch):
+    """the residency bound of the one-launch kernels covered one process.  Every process now keeps a file
+    <registry>/<PCI bus id>.<pid> with the number of streams its engines launch on (gpx_engine.hip: proc_registry);
+    three foreign processes with eight streams each leave this one 512 / 25 = 20 workgroups: a 20,000-record batch takes
+    the check kernel + the work kernel.  A file whose process is gone is removed and does not count."""
+    import os
+    monkeypatch.setenv("GPX_REGISTRY_DIR", str(tmp_path))
+    monkeypatch.delenv("GPX_DEVICE_SHARERS", raising=False)
+    eh, err, names = _one_small_propose(hip_lib)
+    assert err is None and "k_propose_pers" in names, names          # alone: one launch
+    mine = [f for f in os.listdir(tmp_path) if f.endswith("." + str(os.getpid()))]
+    assert len(mine) == 1, os.listdir(tmp_path)
+    bus = mine[0].rsplit(".", 1)[0]
+    eh.close()
+    # three live foreign processes (pids that exist: this one's parent, init, this one's session leader) ...
+    for pid in {os.getppid(), 1, os.getsid(0)} - {os.getpid()}:
+        (tmp_path / f"{bus}.{pid}").write_text("8\n")
+    # ... and a dead one
+    dead = tmp_path / f"{bus}.{2**22 - 7}"
+    dead.write_text("64\n")
+    eh, err, names = _one_small_propose(hip_lib)
+    assert err is None and "k_propose_one" in names and "k_propose_pers" not in names, names
+    assert not dead.exists()
+    eh.close()
+    assert not [f for f in os.listdir(tmp_path) if f.endswith("." + str(os.getpid()))]  # the last engine took its file along
+
+
+def test_a_give_up_is_reported_by_the_call_itself(hip_lib, monkeypatch):
+    """grid_exchange's give-up used to surface on the NEXT batch call only; the call during which it happened
+    returned GPX_OK with partial outputs, and gpx_group_snapshot never looked.  GPX_XCHG_TEST_SKEW makes the arrival
+    target unreachable, so every poller gives up after GPX_XCHG_TIMEOUT_MS: that very call must fail with GPX_EDEVICE,
+    so must the snapshot after it, and no record may have been applied (the quitters leave 'first violation at 0' in the
+    verdict word for whoever reads it later)."""
+    import time
+    monkeypatch.setenv("GPX_XCHG_TEST_SKEW", "1")
+    monkeypatch.setenv("GPX_XCHG_TIMEOUT_MS", "30")
+    monkeypatch.setenv("GPX_REGISTRY_DIR", "/tmp/gpx_registry_test_%d" % int(time.time()))
+    eh, err, _ = _one_small_propose(hip_lib)
+    assert err is not None and "rc=-3" in str(err) and "gave up" in str(err), err          # GPX_EDEVICE, with the reason
+    with pytest.raises(Exception):
+        eh.snapshot(np.arange(8, dtype=np.int32))
+    with pytest.raises(Exception):
+        eh.propose(np.arange(8, dtype=np.int32))
+    eh.close()
