@@ -35,6 +35,9 @@ struct __attribute__((aligned(16))) Vote16 {
 #define V16_LG_MASK 0x3fffu
 #define V16_ESC 0x4000u
 #define V16_MAX_SHIFT 10 /* one lane per group, at most 1024 lanes */
+/* dynamic LDS the tiled per-bucket kernels may take: the CU's 160 KB less their static block (run starts and prefix of
+ * up to 1024 tiles 6.1 KB, scan scratch) */
+#define GPX_TL_BUCKET_DYN_MAX (152 * 1024)
 
 /* staged outputs of the per-bucket kernel: six columns over the record index space (outputs of
  * bucket b at [bucket_off[b], bucket_off[b] + bucket_nout[b])) */
@@ -216,6 +219,8 @@ struct VoteIter {
   VoteCols in;
   int32_t b0n, b0c;
   int32_t start, c, done, nout;
+  int32_t stride; /* LDSM + nib: the group's vote of nibble t sits at start + t * stride (1: packed group-major; the
+                   * bucket's lane count: one row per vote rank, gpx_ar16.hip.h "slotted placement") */
   bool nib;
   unsigned long long order;
   uint32_t omask;
@@ -227,7 +232,7 @@ struct VoteIter {
     uint32_t meta;
     if (LDSM) {
       if (nib)
-        p = (uint32_t)start + (uint32_t)((order >> (4 * done)) & 15ull);
+        p = (uint32_t)start + (uint32_t)stride * (uint32_t)((order >> (4 * done)) & 15ull);
       else
         p = (uint32_t)keys[done];
       ix = idxA[p];
@@ -296,7 +301,7 @@ struct VoteIter {
     if (LDSM && nib) {
       const int d = __ffs((int)*om) - 1; /* arrival rank of the next vote with an output */
       *om &= *om - 1;
-      p = (uint32_t)start + (uint32_t)((order >> (4 * d)) & 15ull);
+      p = (uint32_t)start + (uint32_t)stride * (uint32_t)((order >> (4 * d)) & 15ull);
     } else {
       p = (uint32_t)keys[q];
     }
@@ -313,14 +318,14 @@ struct VoteIter {
 };
 
 /* arrival order of c <= 16 votes at idxA[start ..): nibble d = position of the vote with rank d */
-__device__ __forceinline__ unsigned long long arrival_order(const int32_t* idxA, int32_t start, int32_t c) {
+__device__ __forceinline__ unsigned long long arrival_order(const int32_t* idxA, int32_t start, int32_t c, int32_t stride = 1) {
   unsigned long long order = 0;
   if (c <= 4) {
     const uint32_t inf = 0xffffffffu;
     const uint32_t i0 = (uint32_t)idxA[start];
-    const uint32_t i1 = c > 1 ? (uint32_t)idxA[start + 1] : inf;
-    const uint32_t i2 = c > 2 ? (uint32_t)idxA[start + 2] : inf;
-    const uint32_t i3 = c > 3 ? (uint32_t)idxA[start + 3] : inf;
+    const uint32_t i1 = c > 1 ? (uint32_t)idxA[start + stride] : inf;
+    const uint32_t i2 = c > 2 ? (uint32_t)idxA[start + 2 * stride] : inf;
+    const uint32_t i3 = c > 3 ? (uint32_t)idxA[start + 3 * stride] : inf;
     /* arrival indices are distinct; absent entries (inf) rank last and are never read */
     const uint32_t r0 = (i1 < i0) + (i2 < i0) + (i3 < i0);
     const uint32_t r1 = (i0 < i1) + (i2 < i1) + (i3 < i1);
@@ -330,9 +335,9 @@ __device__ __forceinline__ unsigned long long arrival_order(const int32_t* idxA,
     order = o & 0xffffu;
   } else {
     for (int32_t t = 0; t < c; t++) {
-      const uint32_t it = (uint32_t)idxA[start + t];
+      const uint32_t it = (uint32_t)idxA[start + t * stride];
       int32_t r = 0;
-      for (int32_t u = 0; u < c; u++) r += (uint32_t)idxA[start + u] < it;
+      for (int32_t u = 0; u < c; u++) r += (uint32_t)idxA[start + u * stride] < it;
       order |= (unsigned long long)t << (4 * r);
     }
   }
@@ -421,7 +426,9 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   }
   if (nb == 0) return;
   const int32_t g = X.g_base + (b << X.shift) + l;
-  /* coordinator state of a dense batch: issued now, consumed after the regrouping */
+  /* coordinator state of a dense bucket: issued now, consumed after the regrouping.  (Requested one round trip earlier,
+   * beside the rows of A.off, when the host knows the call is dense: measured, no change - profiles/
+   * r06_bucket_kernel_attempts.txt.) */
 #ifdef GPX_B16_NOPRELOAD /* tuning build: state fetched after the regrouping (fewer live registers) */
   const bool pre = false;
 #else
@@ -473,35 +480,80 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     __threadfence_block();
   }
   __syncthreads();
-  /* A: votes per group.  The first four votes of a lane stay in registers for the placement. */
+  /* The first four votes of a lane stay in registers between its two passes (count, placement) - or its ONE pass: */
   Vote16 r0, r1, r2, r3;
   r0.meta = r1.meta = r2.meta = r3.meta = 0;
   r0.idx = r1.idx = r2.idx = r3.idx = 0;
   r0.slot = r1.slot = r2.slot = r3.slot = 0;
   r0.maxcp = r1.maxcp = r2.maxcp = r3.maxcp = 0;
+  const bool from_tiles = TILES && in_lds; /* (beyond the LDS staging the records were just copied to recG) */
+  auto rec_at = [&](int32_t j) -> Vote16 { return from_tiles ? tile_rec(j) : recG[j]; };
+  /* a lane's records: j = l + t * gb; the first four stay in registers, the fifth and later ones are fetched again by the
+   * placement.  (Looking the runs up by a max-scan over head flags instead of searching s_pre per record was built and
+   * measured: the same 40.5 us - profiles/r06_bucket_kernel_attempts.txt; the kernel waits for memory round trips.) */
+  const bool v0 = l < nb, v1 = gb + l < nb, v2 = 2 * gb + l < nb, v3 = 3 * gb + l < nb;
+  if (v0) r0 = rec_at(l);
+  if (v1) r1 = rec_at(gb + l);
+  if (v2) r2 = rec_at(2 * gb + l);
+  if (v3) r3 = rec_at(3 * gb + l);
+  const int32_t tail0 = 4 * gb + l; /* first record of the lane that is not in a register */
+  /* SLOTTED PLACEMENT (round 6; accept replies behind the tiled front end): a group's vote of rank t goes straight to
+   * row t of the staging arrays - [t * gb + group], KSLOT rows - at the rank its one LDS atomic returns: no count
+   * pass, no scan, no second atomic.  (The kernel is bound by the instructions it issues, 929 vector instructions
+   * per wave for 192 votes - profiles/r06_pmc_ar_loop.txt -, not by bytes.)  A group with more votes than rows - several
+   * rounds in one call, a hot group - sends the whole bucket through the two passes below instead. */
+  constexpr int KSLOT = KMAX <= 4 ? 4 : 8;
+  bool slotted = false;
+  if (TILES && !AC && in_lds && KSLOT * gb <= L) { /* (uniform over the workgroup) */
+    bool over = false;
+    auto put_row = [&](const Vote16& v) {
+      const int32_t lg = (int32_t)(v.meta & V16_LG_MASK);
+      const int32_t t = atomicAdd(&lcnt[lg], 1);
+      if (t < KSLOT) {
+        const int32_t p = t * gb + lg;
+        idxA[p] = v.idx;
+        slotA[p] = v.slot;
+        cpA[p] = v.maxcp;
+        metaA[p] = v.meta;
+      } else {
+        over = true;
+      }
+    };
+    if (v0) put_row(r0);
+    if (v1) put_row(r1);
+    if (v2) put_row(r2);
+    if (v3) put_row(r3);
+    for (int32_t j = tail0; j < nb; j += gb) put_row(rec_at(j));
+    slotted = !__syncthreads_or(over);
+    if (!slotted) { /* start over, the general way */
+      lcnt[l] = 0;
+      __syncthreads();
+    }
+  }
+  int32_t c, start, any_long = 0;
+  if (slotted) {
+    c = lcnt[l];
+    start = l;
+    if (TILES) TL_STAMP(4096 + b, 3);
+    if (pre && g < X.g_end) coord_preload_ring<KMAX>(S, g, P);
+  } else {
+  /* A: votes per group */
   {
-    const bool from_tiles = TILES && in_lds; /* (beyond the LDS staging the records were just copied to recG) */
-    auto rec_at = [&](int32_t j) -> Vote16 { return from_tiles ? tile_rec(j) : recG[j]; };
-    const int32_t j0 = l, j1 = gb + l, j2 = 2 * gb + l, j3 = 3 * gb + l;
-    if (j0 < nb) r0 = rec_at(j0);
-    if (j1 < nb) r1 = rec_at(j1);
-    if (j2 < nb) r2 = rec_at(j2);
-    if (j3 < nb) r3 = rec_at(j3);
-    if (j0 < nb) atomicAdd(&lcnt[r0.meta & V16_LG_MASK], 1);
-    if (j1 < nb) atomicAdd(&lcnt[r1.meta & V16_LG_MASK], 1);
-    if (j2 < nb) atomicAdd(&lcnt[r2.meta & V16_LG_MASK], 1);
-    if (j3 < nb) atomicAdd(&lcnt[r3.meta & V16_LG_MASK], 1);
-    for (int32_t j = 4 * gb + l; j < nb; j += gb) atomicAdd(&lcnt[rec_at(j).meta & V16_LG_MASK], 1);
+    if (v0) atomicAdd(&lcnt[r0.meta & V16_LG_MASK], 1);
+    if (v1) atomicAdd(&lcnt[r1.meta & V16_LG_MASK], 1);
+    if (v2) atomicAdd(&lcnt[r2.meta & V16_LG_MASK], 1);
+    if (v3) atomicAdd(&lcnt[r3.meta & V16_LG_MASK], 1);
+    for (int32_t j = tail0; j < nb; j += gb) atomicAdd(&lcnt[rec_at(j).meta & V16_LG_MASK], 1);
   }
   __syncthreads();
   if (TILES) TL_STAMP(4096 + b, 2); /* records fetched and counted */
   if (pre && g < X.g_end) coord_preload_ring<KMAX>(S, g, P);
   /* B: exclusive scan of the counts */
-  const int32_t c = lcnt[l];
+  c = lcnt[l];
   int32_t tot_;
-  const int32_t start = block_exscan_rt(c, &tot_);
+  start = block_exscan_rt(c, &tot_);
   lcur[l] = start;
-  const int32_t any_long = __syncthreads_or(c > V16_NIB_MAX || !in_lds);
+  any_long = __syncthreads_or(c > V16_NIB_MAX || !in_lds);
   /* C: placement.  LDS: the vote itself, group-major; global mode: a key per vote. */
   if (in_lds) {
     auto place = [&](const Vote16& v) {
@@ -511,12 +563,12 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
       cpA[p] = v.maxcp;
       metaA[p] = v.meta;
     };
-    if (l < nb) place(r0);
-    if (gb + l < nb) place(r1);
-    if (2 * gb + l < nb) place(r2);
-    if (3 * gb + l < nb) place(r3);
+    if (v0) place(r0);
+    if (v1) place(r1);
+    if (v2) place(r2);
+    if (v3) place(r3);
     /* (a lane's records beyond its first four: read a second time, from L2) */
-    for (int32_t j = 4 * gb + l; j < nb; j += gb) place(TILES ? tile_rec(j) : recG[j]);
+    for (int32_t j = tail0; j < nb; j += gb) place(TILES ? tile_rec(j) : recG[j]);
   } else {
     for (int32_t j = l; j < nb; j += gb) {
       const Vote16 v = recG[j];
@@ -526,6 +578,8 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   }
   __syncthreads();
   if (TILES) TL_STAMP(4096 + b, 3); /* placed group-major */
+  }
+  const int32_t pstride = slotted ? gb : 1; /* a group's vote of rank t: start + t * pstride */
   /* D: segments that do not fit the nibble word (or a bucket in global mode): sorted keys in global
    * scratch.  A segment of up to V16_LANE_SORT votes staged in LDS is ordered by ITS OWN lane (rank by
    * counting over the arrival indices in LDS: a call that brings many rounds of votes at once has 17+
@@ -602,6 +656,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     it.b0n = ref_bn;
     it.b0c = ref_bc;
     it.start = start;
+    it.stride = pstride;
     it.c = c;
     it.done = 0;
     it.nout = 0;
@@ -610,7 +665,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     it.omask = 0;
     it.cur = 0;
     if (live) {
-      if (it.nib) it.order = arrival_order(idxA, start, c);
+      if (it.nib) it.order = arrival_order(idxA, start, c, pstride);
       /* Steady state of a coordinator: every vote of the group answers ONE outstanding slot at the
        * group's current ballot (which is also the batch's common ballot).  When that holds for every
        * group of the wave, the replay is a straight line per vote - member bit, nodeSlotNumbers max,
@@ -636,7 +691,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
         } else if (el) {
           bool have = false;
           for (int32_t i = 0; i < c; i++) {
-            const uint32_t p = (uint32_t)start + (uint32_t)((it.order >> (4 * i)) & 15ull);
+            const uint32_t p = (uint32_t)start + (uint32_t)pstride * (uint32_t)((it.order >> (4 * i)) & 15ull);
             if (metaA[p] & V16_ESC) { /* another ballot than the batch's, or a node id beyond 16 bits */
               esc = true;
               const int32_t ix = idxA[p];
@@ -700,13 +755,13 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
           };
           if (!__any(esc)) { /* the wave holds no escaped vote at all: nothing to step over, acceptors in the records */
             for (int32_t i = 0; i < nvote; i++) {
-              const uint32_t p = (uint32_t)start + (uint32_t)((it.order >> (4 * i)) & 15ull);
+              const uint32_t p = (uint32_t)start + (uint32_t)pstride * (uint32_t)((it.order >> (4 * i)) & 15ull);
               vote(i, p, (int32_t)(metaA[p] >> 16), cpA[p]);
             }
           } else {
             for (int32_t i = 0; i < nvote; i++) {
               if ((skip >> i) & 1u) continue;
-              const uint32_t p = (uint32_t)start + (uint32_t)((it.order >> (4 * i)) & 15ull);
+              const uint32_t p = (uint32_t)start + (uint32_t)pstride * (uint32_t)((it.order >> (4 * i)) & 15ull);
               const uint32_t meta = metaA[p];
               vote(i, p, (meta & V16_ESC) ? in.acceptor[idxA[p]] : (int32_t)(meta >> 16), cpA[p]);
             }
@@ -748,6 +803,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     it.b0n = ref_bn;
     it.b0c = ref_bc;
     it.start = start;
+    it.stride = 1;
     it.c = c;
     it.done = 0;
     it.nout = 0;

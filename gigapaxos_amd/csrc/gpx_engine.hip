@@ -1202,7 +1202,7 @@ static bool ar_tiles_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
     HIPQ(hipFuncSetAttribute((const void*)k_scatter_tiles<512, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, maxlds));
     /* (the per-bucket kernels keep 6.2 KB of static LDS - the tiles' run starts and prefix) */
     const size_t hw16 = std::min<size_t>(GPX_BUCKET16_LDS_BYTES((size_t)1 << e->shift16, e->lds16_hw) + e->lds_pad,
-                                         (size_t)152 * 1024);
+                                         (size_t)GPX_TL_BUCKET_DYN_MAX);
     HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_tiles_k4, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
     HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_tiles_k5, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
     HIPQ(hipFuncSetAttribute((const void*)k_bucket_ar16_tiles<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)hw16));
@@ -1217,8 +1217,15 @@ static bool ar_tiles_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
   e->X.nbk = nbk;
   e->bucket_threads = e->X.gb;
   begin_back(e, 0, n, true);
-  if (e->bucket_lds > (size_t)152 * 1024) { /* the static LDS must fit beside the staging */
-    e->X.lds_recs = (int32_t)(((size_t)152 * 1024 - e->lds_pad - (size_t)e->X.gb * 8) / 16);
+  { /* room for the per-bucket kernel's slotted placement (gpx_ar16.hip.h): a row of the staging arrays per vote rank */
+    const int32_t kslot = e->cfg.kmax <= 4 ? 4 : 8;
+    if ((int64_t)n / nbk >= e->X.gb / 4 && e->X.lds_recs < kslot * e->X.gb) {
+      e->X.lds_recs = kslot * e->X.gb;
+      e->bucket_lds = GPX_BUCKET16_LDS_BYTES(e->X.gb, e->X.lds_recs) + e->lds_pad;
+    }
+  }
+  if (e->bucket_lds > (size_t)GPX_TL_BUCKET_DYN_MAX) { /* the static LDS must fit beside the staging */
+    e->X.lds_recs = (int32_t)(((size_t)GPX_TL_BUCKET_DYN_MAX - e->lds_pad - (size_t)e->X.gb * 8) / 16);
     e->bucket_lds = GPX_BUCKET16_LDS_BYTES(e->X.gb, e->X.lds_recs) + e->lds_pad;
   }
   const size_t lds = GPX_TL_LDS_BYTES(nbk, T, ts.NT);

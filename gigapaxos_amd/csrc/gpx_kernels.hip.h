@@ -252,6 +252,17 @@ __device__ __forceinline__ int32_t wave_incscan(int32_t v) {
   return x;
 #endif
 }
+/* the same with max over non-negative values (lanes without a source contribute 0) */
+__device__ __forceinline__ int32_t wave_incscan_max(int32_t v) {
+  int32_t x = v;
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x111, 0xf, 0xf, true));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x112, 0xf, 0xf, true));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x114, 0xf, 0xf, true));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x118, 0xf, 0xf, true));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x142, 0xa, 0xf, false));
+  x = max(x, __builtin_amdgcn_update_dpp(0, x, 0x143, 0xc, 0xf, false));
+  return x;
+}
 template <int NT>
 __device__ __forceinline__ int32_t block_exscan_n(int32_t v, int32_t* total) {
   __shared__ int32_t wsum[NT / 64];

@@ -29,10 +29,15 @@ def summary(title, tr, names):
     for k, nm in enumerate(names):
         col = tr[:, k]
         ok = col > 0
+        if not ok.any():
+            continue  # (a stamp this path does not pass)
         us = (col[ok] - t0) / 100.0  # wall_clock64: 100 MHz
         line = f"    {k} {nm:28s} at min {us.min():7.2f}  median {np.median(us):7.2f}  max {us.max():7.2f} us"
+        prev = k - 1
+        while prev > 0 and not (tr[:, prev] > 0).any():
+            prev -= 1
         if k:
-            d = (tr[ok, k] - tr[ok, k - 1]) / 100.0
+            d = (tr[ok, k] - tr[ok, prev]) / 100.0
             line += f"   phase: median {np.median(d):6.2f}  p90 {np.percentile(d, 90):6.2f}  max {d.max():6.2f}"
         print(line)
 
