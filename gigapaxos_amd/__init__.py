@@ -1,5 +1,5 @@
 """gigapaxos_amd — MI355X-native batched accept/decide engine for gigapaxos's
-PaxosInstanceStateMachine hot path.  The compute path is the
+PaxosInstanceStateMachine hot path (see docs/HISTORY.md).  The compute path is the
 hand-written HIP library gigapaxos_amd/csrc/libgpx_hip.so behind include/gpx.h."""
 from ._abi import (  # noqa: F401
     Engine, GpxLib, GpxError, load_hip, hri_create, hri_initial, make_hri, HRI_DTYPE,

@@ -345,7 +345,7 @@ __device__ __forceinline__ unsigned long long arrival_order(const int32_t* idxA,
 }
 
 /* (Forcing 8 or 7 waves per SIMD through amdgpu_waves_per_eu - 64 VGPRs and 60 bytes of spills - is slower:
- * 53.8 / 51.6 us against 47-49 us when it was measured; the kernel is issue-bound) */
+ * 53.8 / 51.6 us against 47-49 us when it was measured; the kernel is issue-bound, docs/HISTORY.md section 7.) */
 #ifdef GPX_AR16_WAVES
 #define GPX_AR16_ATTR __attribute__((amdgpu_waves_per_eu(GPX_AR16_WAVES, 8)))
 #else

@@ -2762,7 +2762,7 @@ int gpx_group_snapshot(gpx_engine* h, int32_t n, const int32_t* gidx, gpx_hri* r
   return retire_impl(h, n, gidx, 2, rows, status);
 }
 
-/* canonical dump (same word layout as the oracle's orc_group_dump) */
+/* canonical dump (same word layout as the oracle's orc_group_dump; docs/HISTORY.md §state-dump) */
 int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
   if (!h || !buf) return GPX_EINVAL;
   SYNC_CHECKED(h, h->sB);

@@ -3,7 +3,7 @@
  *
  * Integer / indexing work only: HBM-bound, no MFMA.  Wave = 64 lanes everywhere.
  *
- * Pipeline of every batch call.  Groups are binned into BUCKETS of GB = 2^shift
+ * Pipeline of every batch call (docs/HISTORY.md §3).  Groups are binned into BUCKETS of GB = 2^shift
  * consecutive group indices; a batch is partitioned by bucket in one pass, then ONE WORKGROUP PER
  * BUCKET regroups its records by group in LDS and ONE LANE PER GROUP replays them in arrival order:
  *

@@ -201,7 +201,7 @@ __global__ __launch_bounds__(GPX_DBLOCK) GPX_AC_ATTR void k_ac_one(
  * the polls are relaxed and ONE acquire fence follows the last of them (an acquire per iteration invalidates the
  * caches every time round).
  * Larger batches keep the check kernel + the work kernel.  Two one-launch forms for them were built this round and
- * measured (DESIGN.md 3 ii-c): resident workgroups LOOPING over chunks - the grid hipOccupancyMaxActiveBlocksPer
+ * measured (docs/HISTORY.md 3 ii-c): resident workgroups LOOPING over chunks - the grid hipOccupancyMaxActiveBlocksPer
  * Multiprocessor promises does not all become resident: the waiters gave up after two seconds (profiles/
  * r05_pers_loop_gave_up.txt); one workgroup per chunk with the first 512 TO START (a ticket each, sixteen counters) as
  * judges and everybody polling the arrivals - correct at every size (all parity tests), no assumption about residency,

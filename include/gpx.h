@@ -276,7 +276,7 @@ int gpx_group_snapshot(gpx_engine* h, int32_t n, const int32_t* gidx, gpx_hri* r
 
 /*
  * Canonical dump of ONE group's full protocol state for parity checks
- * (int32 words; layout in DESIGN.md §state-dump).  Returns the number of words
+ * (int32 words; layout in docs/HISTORY.md §state-dump).  Returns the number of words
  * written (<= cap) or a negative error.
  */
 int gpx_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap);

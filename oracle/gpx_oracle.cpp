@@ -21,13 +21,13 @@
  * PaxosAcceptor.testAcceptor's monotone-ballot property, HotRestoreInfoTest),
  * re-expressed in tests/test_oracle_kat.py against this file.  Beyond those: every row of
  * SURVEY.md 8 is read from the Java a second time, in Python and not from this file
- * (tests/acc_enum_common.py, pcs_enum_common.py, round_model.py, wire_model.py);
+ * (tests/acc_enum_common.py, pcs_enum_common.py, round_model.py, wire_model.py, docs/HISTORY.md 7b);
  * this file and the engine are both held to those readings, and scripts/oracle_mutants.py shows
  * that they notice a wrong oracle (66 single-fault copies of this file: 62 noticed, 4 equivalent).
  * Two readings of the same text can share a misreading: the status above stands until a JVM
  * produces reference outputs (scripts/make_ref_fixtures.sh).
  *
- * Modelling assumptions (same as the engine, stated in DESIGN.md):
+ * Modelling assumptions (same as the engine, stated in docs/HISTORY.md):
  *   - steady state: no wall-clock event fires (no checkRunForCoordinator election,
  *     no accept retransmit; PaxosInstanceStateMachine.java:480-492 preamble is a
  *     no-op), i.e. BOOTSTRAP_COORD_DETERMINISTIC-like behaviour;
@@ -603,7 +603,7 @@ int orc_group_snapshot(gpx_engine* h, int32_t n, const int32_t* gidx, gpx_hri* r
   return GPX_OK;
 }
 
-/* canonical state dump: see DESIGN.md §state-dump */
+/* canonical state dump: see docs/HISTORY.md §state-dump */
 int orc_group_dump(gpx_engine* h, int32_t gidx, int32_t* buf, int32_t cap) {
   if (!h || !buf) return GPX_EINVAL;
   Engine* e = reinterpret_cast<Engine*>(h);

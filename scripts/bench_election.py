@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Failover burst on one MI355X (not the judged bench line; numbers go to DESIGN.md 5).
+"""Failover burst on one MI355X (not the judged bench line; numbers go to docs/HISTORY.md 5).
 
 The node that coordinated every group dies.  One surviving node (one engine, G groups, 3 replicas):
   gpx_election_scan(all groups)            who must run

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Whole-protocol round on one MI355X (not the judged bench line; numbers go to DESIGN.md §5).
+"""Whole-protocol round on one MI355X (not the judged bench line; numbers go to docs/HISTORY.md §5).
 
 Three engines = the three replicas of every group (BASELINE config #2's shape at config #3's size),
 all on one GPU, columns resident in HBM.  One round =

@@ -1,5 +1,5 @@
 #!/bin/bash
-# bench.py at other sizes and streams (one JSON object per line); numbers go to DESIGN.md §5
+# bench.py at other sizes and streams (one JSON object per line); numbers go to docs/HISTORY.md §5
 #   gpurun --timeout 1200 -- 'bash scripts/bench_scale_sweep.sh > gpurun_out/scale_sweep.jsonl'
 run() { timeout 400 python bench.py "$@" --steps 10 --warmup 2 --no-cpu-baseline --no-end-to-end 2>/dev/null | python -c "
 import json,sys

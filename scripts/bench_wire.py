@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""Wire-path throughput on one MI355X (not the judged bench line; numbers go to DESIGN.md §wire).
+"""Wire-path throughput on one MI355X (not the judged bench line; numbers go to docs/HISTORY.md §wire).
 
 Coordinator side of one round at BASELINE config #3's size, frames resident in HBM:
   2 remote acceptors x G BATCHED_ACCEPT_REPLY frames (one slot each)  -> gpx_wire_decode_dev

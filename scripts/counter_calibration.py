@@ -14,7 +14,7 @@ def main():
     true = json.load(open(true_json))
     fetch = {n: v * 1024.0 for n, _, _, v, _ in counter_avgs(fetch_db, "FETCH_SIZE")}
     write = {n: v * 1024.0 for n, _, _, v, _ in counter_avgs(write_db, "WRITE_SIZE")}
-    avg_us = {n: avg / 1e3 for n, _, _, avg, _ in kernel_stats(kt_db)}
+    avg_us = {n: avg for n, _, _, avg, _ in kernel_stats(kt_db)}  # (top_kernels.average is in microseconds)
     lines = ["# counter calibration on this engine's access patterns (scripts/ubench/ubench_counters.hip), MI355X",
              "# FETCH_SIZE / WRITE_SIZE are rocprofv3's figures (KB x 1024), one counter per pass; true = bytes the kernel moves",
              "%-22s %14s %14s %8s %14s %14s %8s %9s %9s  %s" % ("kernel", "true_read", "FETCH_SIZE", "ratio", "true_write", "WRITE_SIZE", "ratio",

@@ -17,7 +17,7 @@ find "$REF/src/edu/umass/cs/gigapaxos" "$REF/src/edu/umass/cs/utils" "$REF/src/e
 javac -nowarn -d "$WORK/classes" -cp "$REF/lib/*" @"$WORK/sources.txt" "$HERE/scripts/ref_fixtures/RefFixtureDump.java"
 python "$HERE/scripts/ref_fixtures/make_stream.py" --outdir "$WORK"
 for f in "$WORK"/*.in; do
-  # assertions OFF: production behaviour, the engine's and the oracle's modelling assumption
+  # assertions OFF: production behaviour, the engine's and the oracle's modelling assumption (docs/HISTORY.md 1)
   java -da -Xms2g -cp "$WORK/classes:$REF/lib/*" edu.umass.cs.gigapaxos.RefFixtureDump "$f" "${f%.in}.out"
 done
 python "$HERE/scripts/ref_fixtures/make_stream.py" --outdir "$WORK" --collect

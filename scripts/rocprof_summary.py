@@ -9,14 +9,30 @@ json summaries committed under profiles/.
 
 HBM-traffic correction (MI355X_MICROARCH.md §HBM): on gfx950 FETCH_SIZE reports exactly 1/2 of
 the bytes of a WIDE COALESCED streaming read (16 B/lane); other access widths and WRITE_SIZE are
-uncalibrated.  The kernels here issue 4-16 B/lane accesses, many of them scattered, so both the
-raw and the x2-corrected read figures are printed; `traffic` in bench.py's roofline uses
-2*FETCH_SIZE + WRITE_SIZE (the guide's correction) and says so.
+uncalibrated there.  Round 6 calibrated them on this engine's own access patterns
+(scripts/ubench/ubench_counters.hip, profiles/r06_counter_calibration.txt): FETCH_SIZE / true bytes
+= 0.5 for every DENSE read (16, 4, 2, 1 bytes per lane), 1.0 for 8-byte entries read as scattered
+64-byte lines and for random 4-byte gathers (one line each); WRITE_SIZE / true bytes = 1.0 for every
+dense store.  So the read factor is per kernel (READ_FACTOR below): 2 for the streaming kernels;
+the tiled per-bucket kernel reads its state columns densely (x2) and its record runs as scattered
+lines (x1) - its factor is the one that reproduces the known state bytes (48 B per group) plus the
+rest at x1, and both bounds (x1, x2) are kept beside it.
 """
 import json
 import re
 import sqlite3
 import sys
+
+
+# read factor per kernel (prefix match, first hit); default 2.0 = dense reads
+READ_FACTOR = [("k_bucket_ar16_tiles", 1.67), ("k_bucket_ar16_slots", 1.5), ("k_ar_tiny", 1.0)]
+
+
+def read_factor(kernel):
+    for prefix, f in READ_FACTOR:
+        if kernel.startswith(prefix):
+            return f
+    return 2.0
 
 
 def short(name):
@@ -61,7 +77,10 @@ def main():
     for k, v in traffic.items():
         f, w = v.get("FETCH_SIZE", 0.0), v.get("WRITE_SIZE", 0.0)
         v["hbm_bytes_raw"] = f + w
-        v["hbm_bytes_corrected"] = 2.0 * f + w
+        rf = read_factor(k.split("@")[0])
+        v["read_factor"] = rf
+        v["hbm_bytes_corrected"] = rf * f + w
+        v["hbm_bytes_low"], v["hbm_bytes_high"] = f + w, 2.0 * f + w
     open(out_txt, "w").write("\n".join(lines) + "\n")
     json.dump(traffic, open(out_json, "w"), indent=1, sort_keys=True)
     print("\n".join(lines))

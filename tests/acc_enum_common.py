@@ -340,7 +340,7 @@ def run_sequences(lib, seqs, init="create", order="interleaved", from_disk=True,
     if got_rows != exp_rows:
         g = next(g for g in range(G) if got_rows[g] != exp_rows[g])
         raise AssertionError(f"final acceptor row of sequence {seqs[g]}: got {got_rows[g]}, the Java gives {exp_rows[g]}")
-    # full state of a sample: the maps themselves (layout: DESIGN.md, state dump)
+    # full state of a sample: the maps themselves (layout: docs/HISTORY.md, state dump)
     rng = np.random.default_rng(G)
     for g in rng.choice(G, size=min(sample_dumps, G), replace=False).tolist():
         d = e.dump(g).tolist()

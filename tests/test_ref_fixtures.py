@@ -1,6 +1,6 @@
 """Fixtures produced by the REFERENCE itself (scripts/make_ref_fixtures.sh: the Java classes of this path
 replaying recorded coordinator streams).  Present only once someone has run that script on a box with a
-JDK; without them the tests skip and DESIGN.md keeps saying "parity unpinned by reference fixtures"."""
+JDK; without them the tests skip and docs/HISTORY.md keeps saying "parity unpinned by reference fixtures"."""
 import glob
 import os
 
