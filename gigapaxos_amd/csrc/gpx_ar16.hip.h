@@ -360,15 +360,157 @@ struct AcceptOut {
 #define B16_AR 0     /* accept replies at the coordinator */
 #define B16_ACCEPT 1 /* ACCEPTs at an acceptor */
 #define B16_COMMIT 2 /* commits at every replica */
+/* The replay of ONE group whose votes are staged in LDS (the group's lane calls it): arrival order, then the straight
+ * line when the wave's groups all allow it, else apply_ar_group / apply_accept_group / apply_commit_group.  Shared by the
+ * per-bucket kernels (bucket16_body) and the pipelined one (k_bucket_ar16_tiles_pipe). */
+template <int OP, int KMAX, class IT>
+__device__ __forceinline__ void ar16_replay_group(const DevState& S, const DevScratch& X, int32_t g, IT& it, CoordPre<KMAX>& P,
+                                                  const VoteCols& in, const AcceptOut& R, uint8_t* __restrict__ status,
+                                                  const int32_t* idxA, int32_t* slotA, int32_t* cpA, uint32_t* metaA,
+                                                  int32_t start, int32_t pstride, int32_t c) {
+  auto replay = [&](auto& it_) {
+    if (OP == B16_AR)
+      apply_ar_group<KMAX>(S, X, g, it_, status, P);
+    else if (OP == B16_ACCEPT)
+      apply_accept_group(S, X, g, it_, R.r_bnum, R.r_bcoord, R.r_maxcp, R.r_flags, status, R.r_packed);
+    else
+      apply_commit_group(S, X, g, it_, status);
+  };
+  if (it.nib) it.order = arrival_order(idxA, start, c, pstride);
+  /* Steady state of a coordinator: every vote of the group answers ONE outstanding slot at the
+   * group's current ballot (which is also the batch's common ballot).  When that holds for every
+   * group of the wave, the replay is a straight line per vote - member bit, nodeSlotNumbers max,
+   * majority test - with exactly the effects of apply_ar_group's cmp == 0 branch
+   * (handleAcceptReplyMyBallot, PCS:597-640); votes of a lower ballot are stepped over, as the
+   * reference ignores them.  One group that needs anything else (a HIGHER ballot, a second slot, no
+   * coordinator, a view change in progress, more than eight votes) sends the whole wave down the
+   * general path. */
+  bool fast = false;
+  int32_t s0 = 0;
+  uint32_t skip = 0; /* votes of a LOWER ballot: ignored (PaxosCoordinator.java:241-247), whatever their slot */
+  int32_t nvote = c; /* votes the straight-line replay walks */
+  bool esc = false;  /* this group has an escaped vote */
+  if (OP == B16_AR) {
+    /* a group that coordinates nothing (preempted, or never the coordinator) ignores every vote
+     * (PaxosCoordinator.java:196-198: c == null) */
+    const bool idle = (P.gf & (GF_EXISTS | GF_STOPPED | GF_HASCOORD)) == GF_EXISTS;
+    bool el = c <= 8 && (P.gf & (GF_EXISTS | GF_STOPPED | GF_HASCOORD | GF_PREPARING)) == (GF_EXISTS | GF_HASCOORD) &&
+              it.b0n == P.my_bnum && it.b0c == P.my_bcoord;
+    if (idle) {
+      el = true;
+      nvote = 0;
+    } else if (el) {
+      bool have = false;
+      for (int32_t i = 0; i < c; i++) {
+        const uint32_t p = (uint32_t)start + (uint32_t)pstride * (uint32_t)((it.order >> (4 * i)) & 15ull);
+        if (metaA[p] & V16_ESC) { /* another ballot than the batch's, or a node id beyond 16 bits */
+          esc = true;
+          const int32_t ix = idxA[p];
+          const int32_t cmp = ballot_cmp(in.bnum[ix], in.bcoord[ix], P.my_bnum, P.my_bcoord);
+          if (cmp < 0) {
+            skip |= 1u << i;
+            continue;
+          }
+          el = el && cmp == 0; /* a higher ballot preempts: general path */
+        }
+        const int32_t sl = slotA[p];
+        if (!have) s0 = sl;
+        have = true;
+        el = el && sl == s0;
+      }
+      if (have) {
+        const int32_t d = jsub(P.next, s0);
+        el = el && d >= 1 && d <= S.W;
+      }
+    }
+    fast = __all(el);
+  }
+  if (fast) {
+    if (OP == B16_AR) {
+      const int32_t G = S.G, k = (int32_t)GF_K(P.gf);
+      int32_t mem[KMAX], ns[KMAX];
+#pragma unroll
+      for (int j = 0; j < KMAX; j++) {
+        mem[j] = (j < k) ? P.mem[j] : 0;
+        ns[j] = (j < k) ? P.ns[j] : 0;
+      }
+      const int64_t off = (int64_t)(s0 & (S.W - 1)) * G + g;
+      const uint32_t e0 = (P.have_pe && s0 == jsub(P.next, 1)) ? P.pe : S.p_ring[off];
+      uint32_t e = e0;
+      int32_t pcount = P.pcount;
+      bool ns_dirty = false;
+      auto vote = [&](int32_t i, uint32_t p, int32_t acc, int32_t maxcp) {
+        int32_t midx = -1;
+#pragma unroll
+        for (int q = 0; q < KMAX; q++) {
+          if (q < k && mem[q] == acc) {
+            midx = q; /* WaitforUtility.getIndex: last match */
+            if (ns[q] < maxcp) { /* recordSlotNumber :809-825 (plain <) */
+              ns[q] = maxcp;
+              ns_dirty = true;
+            }
+          }
+        }
+        if (e & PR_PRESENT) {
+          if (midx >= 0) e |= (1u << midx);       /* updateHeardFrom :51-62 */
+          if (__popc(e & 0xffffu) > k / 2) {     /* heardFromMajority :64-68 */
+            slotA[p] = s0;                       /* the decision, parked in the vote's own words */
+            cpA[p] = median_minus<KMAX>(ns, k);
+            metaA[p] = (uint32_t)GPX_D_DECISION;
+            it.omask |= 1u << i;
+            it.nout++;
+            e = 0;
+            pcount--;
+          }
+        }
+      };
+      if (!__any(esc)) { /* the wave holds no escaped vote at all: nothing to step over, acceptors in the records */
+        for (int32_t i = 0; i < nvote; i++) {
+          const uint32_t p = (uint32_t)start + (uint32_t)pstride * (uint32_t)((it.order >> (4 * i)) & 15ull);
+          vote(i, p, (int32_t)(metaA[p] >> 16), cpA[p]);
+        }
+      } else {
+        for (int32_t i = 0; i < nvote; i++) {
+          if ((skip >> i) & 1u) continue;
+          const uint32_t p = (uint32_t)start + (uint32_t)pstride * (uint32_t)((it.order >> (4 * i)) & 15ull);
+          const uint32_t meta = metaA[p];
+          vote(i, p, (meta & V16_ESC) ? in.acceptor[idxA[p]] : (int32_t)(meta >> 16), cpA[p]);
+        }
+      }
+      if (e != e0) S.p_ring[off] = e;
+      if (ns_dirty) {
+#pragma unroll
+        for (int q = 0; q < KMAX; q++)
+          if (q < k) S.node_slots[(int64_t)q * G + g] = ns[q];
+      }
+      if (pcount != P.pcount) S.c_pcount[g] = pcount;
+    }
+  } else {
+    replay(it);
+  }
+}
+
+/* the tiled kernels' LDS beside the staging: run starts (| TL_WIDE) and the exclusive prefix of the run lengths of the
+ * bucket in hand - declared by the KERNEL (the pipelined one shares them with the body it calls for unusual buckets) */
+struct TileLds {
+  int32_t* pre; /* [GPX_TL_MAXWG + 1] */
+  uint16_t* st; /* [GPX_TL_MAXWG] */
+};
+#define GPX_TILE_LDS_DECL(TILES_)                                   \
+  __shared__ int32_t s_pre_[(TILES_) ? GPX_TL_MAXWG + 1 : 1];       \
+  __shared__ uint16_t s_st_[(TILES_) ? GPX_TL_MAXWG : 1];           \
+  const TileLds TL{s_pre_, s_st_}
+/* b_in < 0: the workgroup's own bucket (blockIdx); else the bucket to do (k_bucket_ar16_tiles_pipe) */
 template <int OP, int KMAX, bool TILES = false>
 __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratch& X, const Stage16& O, const VoteCols& in,
-                                              const AcceptOut& R, uint8_t* __restrict__ status, const TileArea& A = TileArea{}) {
+                                              const AcceptOut& R, uint8_t* __restrict__ status, const TileLds& TL,
+                                              const TileArea& A = TileArea{}, int32_t b_in = -1) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   constexpr bool AC = OP != B16_AR;
   /* ordered batch: k_ac_direct did it (a few sorted runs of votes: k_ar_runs); nothing was partitioned */
   if ((AC || X.gate) && *X.unsorted != X.epoch) return;
-  int32_t b = blockIdx.x;
-  if (TILES && A.xcd_rows) { /* consecutive buckets on one XCD (block i runs on XCD i % 8): they share lines of A.off / A.recs */
+  int32_t b = b_in >= 0 ? b_in : (int32_t)blockIdx.x;
+  if (TILES && A.xcd_rows && b_in < 0) { /* consecutive buckets on one XCD (block i runs on XCD i % 8): they share lines of A.off / A.recs */
     b = tile_of_block(X.nbk);
     if (b >= X.nbk) return;
   }
@@ -377,8 +519,8 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   int32_t boff, nb;
   /* TILES (gpx_tiles.hip.h): the run of every tile in this bucket - where it starts in the tile (| TL_WIDE) and the
    * exclusive prefix of the run lengths, what turns a record's index in the bucket into (tile, position) */
-  __shared__ int32_t s_pre[TILES ? GPX_TL_MAXWG + 1 : 1];
-  __shared__ uint16_t s_st[TILES ? GPX_TL_MAXWG : 1];
+  int32_t* const s_pre = TL.pre;
+  uint16_t* const s_st = TL.st;
   if (TILES) TL_STAMP(4096 + b, 0);
   if (TILES) { /* no k_hist, no scanned offsets: rows b and b + 1 of A.off say everything */
     /* A.off is [bucket / 4][tile][4]: this bucket's start and the next one's - the same 8-byte entry three times in four */
@@ -664,120 +806,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     it.order = 0;
     it.omask = 0;
     it.cur = 0;
-    if (live) {
-      if (it.nib) it.order = arrival_order(idxA, start, c, pstride);
-      /* Steady state of a coordinator: every vote of the group answers ONE outstanding slot at the
-       * group's current ballot (which is also the batch's common ballot).  When that holds for every
-       * group of the wave, the replay is a straight line per vote - member bit, nodeSlotNumbers max,
-       * majority test - with exactly the effects of apply_ar_group's cmp == 0 branch
-       * (handleAcceptReplyMyBallot, PCS:597-640); votes of a lower ballot are stepped over, as the
-       * reference ignores them.  One group that needs anything else (a HIGHER ballot, a second slot, no
-       * coordinator, a view change in progress, more than eight votes) sends the whole wave down the
-       * general path. */
-      bool fast = false;
-      int32_t s0 = 0;
-      uint32_t skip = 0; /* votes of a LOWER ballot: ignored (PaxosCoordinator.java:241-247), whatever their slot */
-      int32_t nvote = c; /* votes the straight-line replay walks */
-      bool esc = false;  /* this group has an escaped vote */
-      if (OP == B16_AR) {
-        /* a group that coordinates nothing (preempted, or never the coordinator) ignores every vote
-         * (PaxosCoordinator.java:196-198: c == null) */
-        const bool idle = (P.gf & (GF_EXISTS | GF_STOPPED | GF_HASCOORD)) == GF_EXISTS;
-        bool el = c <= 8 && (P.gf & (GF_EXISTS | GF_STOPPED | GF_HASCOORD | GF_PREPARING)) == (GF_EXISTS | GF_HASCOORD) &&
-                  it.b0n == P.my_bnum && it.b0c == P.my_bcoord;
-        if (idle) {
-          el = true;
-          nvote = 0;
-        } else if (el) {
-          bool have = false;
-          for (int32_t i = 0; i < c; i++) {
-            const uint32_t p = (uint32_t)start + (uint32_t)pstride * (uint32_t)((it.order >> (4 * i)) & 15ull);
-            if (metaA[p] & V16_ESC) { /* another ballot than the batch's, or a node id beyond 16 bits */
-              esc = true;
-              const int32_t ix = idxA[p];
-              const int32_t cmp = ballot_cmp(in.bnum[ix], in.bcoord[ix], P.my_bnum, P.my_bcoord);
-              if (cmp < 0) {
-                skip |= 1u << i;
-                continue;
-              }
-              el = el && cmp == 0; /* a higher ballot preempts: general path */
-            }
-            const int32_t sl = slotA[p];
-            if (!have) s0 = sl;
-            have = true;
-            el = el && sl == s0;
-          }
-          if (have) {
-            const int32_t d = jsub(P.next, s0);
-            el = el && d >= 1 && d <= S.W;
-          }
-        }
-        fast = __all(el);
-      }
-      if (fast) {
-        if (OP == B16_AR) {
-          const int32_t G = S.G, k = (int32_t)GF_K(P.gf);
-          int32_t mem[KMAX], ns[KMAX];
-#pragma unroll
-          for (int j = 0; j < KMAX; j++) {
-            mem[j] = (j < k) ? P.mem[j] : 0;
-            ns[j] = (j < k) ? P.ns[j] : 0;
-          }
-          const int64_t off = (int64_t)(s0 & (S.W - 1)) * G + g;
-          const uint32_t e0 = (P.have_pe && s0 == jsub(P.next, 1)) ? P.pe : S.p_ring[off];
-          uint32_t e = e0;
-          int32_t pcount = P.pcount;
-          bool ns_dirty = false;
-          auto vote = [&](int32_t i, uint32_t p, int32_t acc, int32_t maxcp) {
-            int32_t midx = -1;
-#pragma unroll
-            for (int q = 0; q < KMAX; q++) {
-              if (q < k && mem[q] == acc) {
-                midx = q; /* WaitforUtility.getIndex: last match */
-                if (ns[q] < maxcp) { /* recordSlotNumber :809-825 (plain <) */
-                  ns[q] = maxcp;
-                  ns_dirty = true;
-                }
-              }
-            }
-            if (e & PR_PRESENT) {
-              if (midx >= 0) e |= (1u << midx);       /* updateHeardFrom :51-62 */
-              if (__popc(e & 0xffffu) > k / 2) {     /* heardFromMajority :64-68 */
-                slotA[p] = s0;                       /* the decision, parked in the vote's own words */
-                cpA[p] = median_minus<KMAX>(ns, k);
-                metaA[p] = (uint32_t)GPX_D_DECISION;
-                it.omask |= 1u << i;
-                it.nout++;
-                e = 0;
-                pcount--;
-              }
-            }
-          };
-          if (!__any(esc)) { /* the wave holds no escaped vote at all: nothing to step over, acceptors in the records */
-            for (int32_t i = 0; i < nvote; i++) {
-              const uint32_t p = (uint32_t)start + (uint32_t)pstride * (uint32_t)((it.order >> (4 * i)) & 15ull);
-              vote(i, p, (int32_t)(metaA[p] >> 16), cpA[p]);
-            }
-          } else {
-            for (int32_t i = 0; i < nvote; i++) {
-              if ((skip >> i) & 1u) continue;
-              const uint32_t p = (uint32_t)start + (uint32_t)pstride * (uint32_t)((it.order >> (4 * i)) & 15ull);
-              const uint32_t meta = metaA[p];
-              vote(i, p, (meta & V16_ESC) ? in.acceptor[idxA[p]] : (int32_t)(meta >> 16), cpA[p]);
-            }
-          }
-          if (e != e0) S.p_ring[off] = e;
-          if (ns_dirty) {
-#pragma unroll
-            for (int q = 0; q < KMAX; q++)
-              if (q < k) S.node_slots[(int64_t)q * G + g] = ns[q];
-          }
-          if (pcount != P.pcount) S.c_pcount[g] = pcount;
-        }
-      } else {
-        replay(it);
-      }
-    }
+    if (live) ar16_replay_group<OP, KMAX>(S, X, g, it, P, in, R, status, idxA, slotA, cpA, metaA, start, pstride, c);
     nout = it.nout;
     omask = it.omask;
     if (TILES) TL_STAMP(4096 + b, 4); /* thread 0 replayed */
@@ -827,29 +856,34 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
 template <int OP, int KMAX>
 __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, DevScratch X, Stage16 O, VoteCols in,
                                                    AcceptOut R, uint8_t* __restrict__ status) {
-  bucket16_body<OP, KMAX>(S, X, O, in, R, status);
+  GPX_TILE_LDS_DECL(false);
+  bucket16_body<OP, KMAX>(S, X, O, in, R, status, TL);
 }
 /* accept replies behind the tiled front end (gpx_tiles.hip.h) */
 template <int KMAX>
 __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16_tiles(DevState S, DevScratch X, Stage16 O, VoteCols in,
                                                                          uint8_t* __restrict__ status, TileArea A) {
-  bucket16_body<B16_AR, KMAX, true>(S, X, O, in, AcceptOut{}, status, A);
+  GPX_TILE_LDS_DECL(true);
+  bucket16_body<B16_AR, KMAX, true>(S, X, O, in, AcceptOut{}, status, TL, A);
 }
 /* K <= 4 and five replicas held to 6 waves like k_bucket_ar16_k5 */
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_tiles_k4(
     DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A) {
-  bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, A);
+  GPX_TILE_LDS_DECL(true);
+  bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, TL, A);
 }
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_tiles_k5(
     DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A) {
-  bucket16_body<B16_AR, 5, true>(S, X, O, in, AcceptOut{}, status, A);
+  GPX_TILE_LDS_DECL(true);
+  bucket16_body<B16_AR, 5, true>(S, X, O, in, AcceptOut{}, status, TL, A);
 }
 /* Five replicas (BASELINE config #4): the KMAX = 5 body needs 82 VGPRs left to itself - two over the step
  * to 5 waves per SIMD = two workgroups per CU instead of three; held to 6 waves it gives up two registers
  * to scratch instead. */
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_k5(
     DevState S, DevScratch X, Stage16 O, VoteCols in, AcceptOut R, uint8_t* __restrict__ status) {
-  bucket16_body<B16_AR, 5>(S, X, O, in, R, status);
+  GPX_TILE_LDS_DECL(false);
+  bucket16_body<B16_AR, 5>(S, X, O, in, R, status, TL);
 }
 
 /* staged columns -> the caller's columns, buckets in order */
