@@ -103,6 +103,21 @@ __device__ __forceinline__ void wave_majority2(int32_t x, int32_t y, int32_t m, 
   *ox = fx, *oy = fy;
 }
 
+/* A 16-byte store that is written THROUGH the XCD's L2 (sc1) instead of staying dirty in it: what a kernel leaves dirty
+ * is written back at its end, at ~6 TB/s, before the next kernel starts (MI355X_MICROARCH.md, price list: "boundary") -
+ * 24 MB of sorted records were 4 us of k_scatter_tiles behind its last workgroup's exit.  (Narrower sc1 stores cost a
+ * fabric write each: only for 16-byte streams.) */
+typedef int32_t gpx_i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_through(I4* dst, const I4 v) {
+#ifdef GPX_NO_SC1_STORES
+  *dst = v;
+#else
+  gpx_i32x4 x;
+  x.x = v.x, x.y = v.y, x.z = v.z, x.w = v.w;
+  asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst), "v"(x) : "memory");
+#endif
+}
+
 /* four consecutive entries of a column; FULL: the whole vector is inside the batch (one 16-byte load) */
 template <bool FULL>
 __device__ __forceinline__ I4 tiles_load4(const int32_t* __restrict__ col, int64_t i0, int32_t n, int32_t fill) {
@@ -303,10 +318,10 @@ __device__ __forceinline__ void scatter_tile(int32_t n, int32_t G, const DevScra
     int32_t i = (int32_t)threadIdx.x;
     for (; i + NT < nv; i += 2 * NT) { /* two LDS reads in flight */
       const I4 x = src[i], y = src[i + NT];
-      dst[i] = x;
-      dst[i + NT] = y;
+      store16_through(dst + i, x);
+      store16_through(dst + i + NT, y);
     }
-    if (i < nv) dst[i] = src[i];
+    if (i < nv) store16_through(dst + i, src[i]);
   }
   if (wide) {
     /* (rare) slot and max_cp of every vote take the same road behind the records: the two columns once more (from L2),
@@ -329,7 +344,7 @@ __device__ __forceinline__ void scatter_tile(int32_t n, int32_t G, const DevScra
     const I4* src = (const I4*)recs;
     I4* dst = (I4*)(A.ext + (int64_t)w * T);
     const int32_t nv = (tot + 1) >> 1;
-    for (int32_t i = (int32_t)threadIdx.x; i < nv; i += NT) dst[i] = src[i];
+    for (int32_t i = (int32_t)threadIdx.x; i < nv; i += NT) store16_through(dst + i, src[i]);
   }
   TL_STAMP(w, 4); /* stores issued */
   TL_CLOCK(w, 7);
