@@ -160,76 +160,6 @@ void live_drop(int device, hipStream_t s) {
   if (m.empty()) g_proc_reg.erase(device); /* (the next engine of this process looks the directory up afresh) */
 }
 
-/* Host pages pinned on behalf of gpx_host_register, process-wide.  hipHostRegister is only ever called on WHOLE pages
- * that no live registration of this process covers yet; a caller's block that shares a page with another registered
- * block - small heap arrays, a 4-byte count word - takes a reference on the segment that already pins that page
- * instead of pinning it a second time, and a segment is unpinned when its last reference goes.  (Round 6: the abort that
- * ended one GPU suite run in each of rounds 3, 5 and 6 is a GPU page fault - profiles/r06_abort_backtrace.txt - and the
- * runs it came in had registered and unregistered thousands of sub-page ranges; the runtime is not asked to pin a page
- * twice any more, nor to pin part of one.) */
-struct PinSeg {
-  uintptr_t end;
-  int refs;
-  bool owned; /* false: the pages were pinned by somebody else already (hipHostMalloc, the caller's own hipHostRegister) */
-};
-std::mutex g_pin_mu;
-std::map<uintptr_t, PinSeg> g_pin_segs; /* page-aligned, disjoint: base -> (end, references) */
-constexpr uintptr_t GPX_PAGE = 4096;
-/* pins [ptr, ptr + bytes): appends the bases of the segments the block now references to `segs` */
-hipError_t pin_block(void* ptr, size_t bytes, std::vector<uintptr_t>* segs) {
-  std::lock_guard<std::mutex> lk(g_pin_mu);
-  uintptr_t lo = (uintptr_t)ptr & ~(GPX_PAGE - 1), hi = ((uintptr_t)ptr + bytes + GPX_PAGE - 1) & ~(GPX_PAGE - 1);
-  std::vector<uintptr_t> took;
-  auto undo = [&](hipError_t err) {
-    for (uintptr_t b : took) {
-      auto it = g_pin_segs.find(b);
-      if (it != g_pin_segs.end() && --it->second.refs == 0) {
-        if (it->second.owned) (void)hipHostUnregister((void*)b);
-        g_pin_segs.erase(it);
-      }
-    }
-    return err;
-  };
-  uintptr_t at = lo;
-  while (at < hi) {
-    /* the segment that covers `at`, if any */
-    auto it = g_pin_segs.upper_bound(at);
-    if (it != g_pin_segs.begin()) {
-      auto pv = std::prev(it);
-      if (pv->second.end > at) {
-        pv->second.refs++;
-        took.push_back(pv->first);
-        at = pv->second.end;
-        continue;
-      }
-    }
-    const uintptr_t gap_end = (it != g_pin_segs.end() && it->first < hi) ? it->first : hi;
-    hipError_t err = hipHostRegister((void*)at, gap_end - at, hipHostRegisterDefault);
-    bool owned = true;
-    if (err == hipErrorHostMemoryAlreadyRegistered) { /* pinned memory the caller got elsewhere: known from now on, not ours to unpin */
-      (void)hipGetLastError();
-      err = hipSuccess;
-      owned = false;
-    }
-    if (err != hipSuccess) return undo(err);
-    g_pin_segs[at] = PinSeg{gap_end, 1, owned};
-    took.push_back(at);
-    at = gap_end;
-  }
-  segs->insert(segs->end(), took.begin(), took.end());
-  return hipSuccess;
-}
-void unpin_segments(const std::vector<uintptr_t>& segs) {
-  std::lock_guard<std::mutex> lk(g_pin_mu);
-  for (uintptr_t b : segs) {
-    auto it = g_pin_segs.find(b);
-    if (it != g_pin_segs.end() && --it->second.refs == 0) {
-      if (it->second.owned) (void)hipHostUnregister((void*)b);
-      g_pin_segs.erase(it);
-    }
-  }
-}
-
 }  // namespace
 
 struct gpx_engine {
@@ -363,7 +293,7 @@ struct gpx_engine {
   /* host blocks registered through gpx_host_register (base, bytes): the extent check of mapped_host, the
    * drain before gpx_host_unregister, and what gpx_engine_destroy still has to unregister */
   std::vector<std::pair<char*, size_t>> registered;
-  std::map<char*, std::vector<uintptr_t>> registered_segs; /* the pinned page segments each registered block references */
+  std::map<char*, bool> registered_own; /* block -> pinned by this engine (false: it was pinned already; not ours to unpin) */
   bool async_in_engine = false, async_fill_memset = false; /* experiments: GPX_ASYNC_IN, GPX_ASYNC_FILL */
   bool async_no_direct = false; /* GPX_ASYNC_DIRECT=0: compacted outputs fetched by gpx_engine_wait even from registered memory */
   bool async_kernel_in = false; /* GPX_ASYNC_COPYIN=kernel (experiment): inputs read by k_copy_in from registered memory */
@@ -991,9 +921,10 @@ int gpx_engine_destroy(gpx_engine* h) {
     live_drop(h->device, h->user_stream ? h->user_stream : h->own_stream);
     h->registered_live = false;
   }
-  if (!h->registered_segs.empty()) HIPQ(hipDeviceSynchronize());
-  for (auto& sg : h->registered_segs) unpin_segments(sg.second); /* (gpx_host_alloc blocks are in `registered` only) */
-  h->registered_segs.clear();
+  if (!h->registered_own.empty()) HIPQ(hipDeviceSynchronize());
+  for (auto& sg : h->registered_own) /* (gpx_host_alloc blocks are in `registered` only) */
+    if (sg.second) HIPQ(hipHostUnregister(sg.first));
+  h->registered_own.clear();
   h->registered.clear();
   for (void* b : h->host_blocks) HIPQ(hipHostFree(b));
   h->host_blocks.clear();
@@ -1041,12 +972,22 @@ int gpx_engine_set_ordered_batches(gpx_engine* h, int32_t mask) {
 
 int gpx_host_register(gpx_engine* h, void* ptr, size_t bytes) {
   if (!h || !ptr || !bytes) return GPX_EINVAL;
-  if (h->registered_segs.count((char*)ptr)) return GPX_EINVAL; /* already registered through this engine */
-  /* whatever the runtime itself still has pinned for earlier pageable copies of this range has been let go */
+  if (h->registered_own.count((char*)ptr)) return GPX_EINVAL; /* already registered through this engine */
+  /* nothing of the process is in flight while the pinning changes (the runtime pins pageable memory itself around
+   * large copies: whatever it still holds for earlier copies of this range has been let go) */
   HIPCHK(hipDeviceSynchronize());
-  std::vector<uintptr_t> segs;
-  HIPCHK(pin_block(ptr, bytes, &segs));
-  h->registered_segs[(char*)ptr] = std::move(segs);
+  /* The caller's exact range.  (Round 6 tried whole pages, each pinned once per process: the runtime then takes
+   * NEIGHBOURING heap memory on the rounded pages for registered memory and refuses copies that straddle the
+   * boundary - hipMemcpyAsync: invalid argument in five tests.  Not kept.) */
+  hipError_t err = hipHostRegister(ptr, bytes, hipHostRegisterDefault);
+  bool own = true;
+  if (err == hipErrorHostMemoryAlreadyRegistered) { /* pinned memory the caller got elsewhere: known from now on, not ours to unpin */
+    (void)hipGetLastError();
+    err = hipSuccess;
+    own = false;
+  }
+  HIPCHK(err);
+  h->registered_own[(char*)ptr] = own;
   h->registered.emplace_back((char*)ptr, bytes);
   return GPX_OK;
 }
@@ -1057,13 +998,13 @@ int gpx_host_unregister(gpx_engine* h, void* ptr) {
   if (!h || !ptr) return GPX_EINVAL;
   if (std::find(h->host_blocks.begin(), h->host_blocks.end(), ptr) != h->host_blocks.end())
     return GPX_EINVAL; /* a gpx_host_alloc block: gpx_host_free gives it back */
-  auto sg = h->registered_segs.find((char*)ptr);
-  if (sg == h->registered_segs.end()) return GPX_EINVAL; /* not a block gpx_host_register was given */
+  auto sg = h->registered_own.find((char*)ptr);
+  if (sg == h->registered_own.end()) return GPX_EINVAL; /* not a block gpx_host_register was given */
   drain_all(h);
   HIPCHK(hipGetLastError());
   HIPCHK(hipDeviceSynchronize()); /* (other streams of the process may hold DMA on these pages too: nothing may) */
-  unpin_segments(sg->second);
-  h->registered_segs.erase(sg);
+  if (sg->second) HIPCHK(hipHostUnregister(ptr));
+  h->registered_own.erase(sg);
   for (size_t i = 0; i < h->registered.size(); i++)
     if (h->registered[i].first == (char*)ptr) {
       h->registered.erase(h->registered.begin() + (long)i);

@@ -166,12 +166,11 @@ int gpx_engine_set_stream(gpx_engine* h, void* hip_stream);
  * their columns with asynchronous DMA from / to registered memory instead of the runtime's staged
  * copies of pageable memory.  A JNI host registers the memory of its direct ByteBuffers once, after
  * allocating them.  Purely an optimisation: unregistered pointers keep working.
- * Pages are pinned whole and once: blocks that share a 4 KB page (small heap arrays, a 4-byte count word) share its
- * pinning, released with the last of them.  Memory that is pinned already (hipHostMalloc, the caller's own
- * hipHostRegister) is accepted and noted; the engine never unpins it.  ONLY memory the engine was told about this way
- * (or got from gpx_host_alloc) is written through a device mapping by the asynchronous calls.  (Round 6: three
- * aborted test runs were GPU page faults in processes that had registered thousands of sub-page ranges; since then no
- * page is pinned twice or in part.  DESIGN.md 4.)
+ * Memory that is pinned already (hipHostMalloc, the caller's own hipHostRegister) is accepted and noted; the engine
+ * never unpins it.  ONLY memory the engine was told about this way (or got from gpx_host_alloc) is written through a
+ * device mapping by the asynchronous calls.  The device is synchronised before the pinning changes.  Prefer a few
+ * large, page-aligned blocks (or gpx_host_alloc) to many small ones: three aborted test runs of this repository were
+ * GPU page faults in processes that had registered and unregistered thousands of sub-page heap ranges.
  */
 int gpx_host_register(gpx_engine* h, void* ptr, size_t bytes);
 /*

@@ -147,7 +147,7 @@ for step in "$@"; do
     [ -n "$KT" ] && python scripts/rocprof_summary.py "$KT" "$KT" "$KT" "$OUT/kt_${L}_summary.txt" /dev/null | head -40
     ;;
   sh)
-    f=$(uniq_name "${a%.sh}" out)
+    f=$(uniq_name "$(basename "${a%.sh}")" out)
     timeout 1200 bash "scripts/$a" $(sp "$b") >"$f" 2>&1
     echo "$a exit $?"
     tail -25 "$f" | cut -c1-300
