@@ -101,6 +101,7 @@ _SIGS = {
     "poke_scan": [C.c_int32] + [_VP] * 9,
 }
 _DEV_SIGS = {
+    "engine_path_counters": [C.POINTER(C.c_uint64)],
     "engine_set_stream": [_VP],
     "propose_batch_dev": [C.c_int32] + [_VP] * 7,
     "accept_batch_dev": [C.c_int32] + [_VP] * 15,
@@ -371,6 +372,12 @@ class Engine:
         self.lib.check(self.lib.fn["engine_counters"](self.h, out), "engine_counters")
         return tuple(int(x) for x in out)
 
+    def path_counters(self):
+        """(accept-reply calls whose outputs were written in place, calls compacted from the staging) - gpx_engine_path_counters"""
+        out = (C.c_uint64 * 2)()
+        self.lib.check(self.lib.fn["engine_path_counters"](self.h, out), "engine_path_counters")
+        return int(out[0]), int(out[1])
+
     def host_register(self, *arrays):
         """Pins numpy arrays for DMA (gpx_host_register); returns them.  Unpin with host_unregister."""
         for a in arrays:
@@ -461,12 +468,24 @@ class Engine:
             self.eng.lib.check(self.eng.lib.fn["engine_wait"](self.eng.h, C.c_uint64(self.ticket)), "engine_wait")
             return self.finish()
 
+    @staticmethod
+    def page_array(n: int, dtype=np.int32) -> np.ndarray:
+        """A zeroed numpy array over its OWN anonymous pages (mmap: page-aligned, whole pages, nothing else of the heap
+        on them) - what gpx_host_register should be given (include/gpx.h: a few page-aligned blocks, never sub-page
+        ranges of the malloc heap).  Unmapped when the last reference goes."""
+        import mmap
+        dt = np.dtype(dtype)
+        nbytes = max(int(n), 1) * dt.itemsize
+        mm = mmap.mmap(-1, (nbytes + mmap.PAGESIZE - 1) // mmap.PAGESIZE * mmap.PAGESIZE)
+        return np.frombuffer(mm, dtype=dt, count=int(n))
+
     def propose_async(self, gidx, is_stop=None, pin_outputs=False):
         gidx = _i32(gidx)
         n = gidx.shape[0]
         is_stop = _u8(is_stop, n)
-        slot, bnum, bcoord, median = (np.zeros(n, np.int32) for _ in range(4))
-        status = np.zeros(n, np.uint8)
+        mk = Engine.page_array if pin_outputs else np.zeros   # registered outputs: whole pages of their own
+        slot, bnum, bcoord, median = (mk(n, np.int32) for _ in range(4))
+        status = mk(n, np.uint8)
         outs = (slot, bnum, bcoord, median, status)
         if pin_outputs:
             self.host_register(*outs)
@@ -490,10 +509,11 @@ class Engine:
             bnum, bcoord = _i32(bnum, n), _i32(bcoord, n)
         cb = common_ballot or (0, 0)
         cap = max(n, 1)
-        dg, ds, db, dc, dm = (np.zeros(cap, np.int32) for _ in range(5))
-        dk = np.zeros(cap, np.uint8)
-        status = np.zeros(n, np.uint8)
-        no = np.zeros(1, np.int32)
+        mk = Engine.page_array if pin_outputs else np.zeros   # registered outputs: whole pages of their own
+        dg, ds, db, dc, dm = (mk(cap, np.int32) for _ in range(5))
+        dk = mk(cap, np.uint8)
+        status = mk(n, np.uint8)
+        no = mk(1, np.int32)
         outs = (dg, ds, db, dc, dm, dk, no, status)
         if pin_outputs:
             self.host_register(*outs)

@@ -57,6 +57,23 @@ struct VoteCols {
   const int32_t *bnum, *bcoord, *acceptor;
   const int32_t *slot, *maxcp; /* the tiled front end's escape path (gpx_tiles.hip.h) */
 };
+/* The caller's output columns, for the per-bucket kernel of the tiled front end to write IN PLACE (round 6).  A bucket's
+ * place among the outputs is only known once every bucket before it has replayed - but in a coordinator's steady state
+ * every D votes make one output (D = the replicas that answer), so bucket b with `boff` records before it and `nb` of its
+ * own PREDICTS the span [boff / D, (boff + nb) / D) (the spans of all buckets telescope to a dense column).  A bucket whose
+ * output count IS its span writes there as well as to the staging; one whose count differs raises the call's epoch in
+ * `A.ref[3]`, and k_emit_dec16 then compacts the staging as before.  No bucket differing = the outputs are in place and
+ * k_emit_dec16 only publishes the total: the 63 MB staging round trip is a 21 MB second store.
+ * D is the engine's (a kernel argument, with its reciprocal): k_emit_dec16 leaves votes / outputs of a call that had to be
+ * compacted in a host-mapped word, the host reads that word - however stale: it is only a prediction - at its next call. */
+struct PlaceCols {
+  int32_t *gidx, *slot, *bnum, *bcoord, *median;
+  uint8_t* kind;
+  int32_t div;  /* D; 0: staging only (GPX_AR_INPLACE=0; the partition front end) */
+  uint32_t mul; /* floor(2^32 / D) + 1: x / D == umulhi(x, mul) for x < 2^26, D <= 64 (D == 1: x itself) */
+  __device__ __forceinline__ int32_t quot(int32_t x) const { return div == 1 ? x : (int32_t)__umulhi((uint32_t)x, mul); }
+};
+#define GPX_IP_LEARN_WORD 8 /* of the host-mapped block X.xabort points at */
 
 __device__ __forceinline__ void put_vote16(const DevScratch& X, int32_t* lds, int32_t G, int32_t mask,
                                            int32_t b0n, int32_t b0c, int64_t i, int32_t g, int32_t slot,
@@ -504,7 +521,8 @@ struct TileLds {
 template <int OP, int KMAX, bool TILES = false>
 __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratch& X, const Stage16& O, const VoteCols& in,
                                               const AcceptOut& R, uint8_t* __restrict__ status, const TileLds& TL,
-                                              const TileArea& A = TileArea{}, int32_t b_in = -1) {
+                                              const TileArea& A = TileArea{}, int32_t b_in = -1,
+                                              const PlaceCols& IP = PlaceCols{}) {
   extern __shared__ __attribute__((aligned(16))) int32_t lds[];
   constexpr bool AC = OP != B16_AR;
   /* ordered batch: k_ac_direct did it (a few sorted runs of votes: k_ar_runs); nothing was partitioned */
@@ -594,6 +612,13 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   /* the batch's reference vote (gpx_tiles.hip.h): ballot of the 8-byte records, base of their slot bytes */
   const int32_t slot0 = TILES ? A.ref[0] : 0;
   const int32_t ref_bn = TILES ? A.ref[1] : in.bnum[0], ref_bc = TILES ? A.ref[2] : in.bcoord[0];
+  /* in-place outputs (PlaceCols): this bucket's predicted span.  (The divisor as a kernel argument with its reciprocal:
+   * fetched from device memory and divided by at run time it cost the kernel 1.8 us - profiles/r06_in_place_outputs.txt.) */
+  int32_t ip_pb = 0, ip_span = -1;
+  if (TILES && !AC && IP.div) {
+    ip_pb = IP.quot(boff);
+    ip_span = IP.quot(boff + nb) - ip_pb;
+  }
   int32_t srch = 0; /* steps of the search over s_pre */
   if (TILES)
     while ((1 << srch) < A.nwg) srch++;
@@ -777,14 +802,45 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   /* a bucket's outputs, group-major, as columns: decisions (six columns) or execution runs (gidx,
    * first slot, count) */
   auto put = [&](int64_t o, int32_t a, int32_t z, int32_t kd) {
+#ifdef GPX_STAGE_NT /* tuning build: the staging is not read again when the outputs are in place */
+    if (TILES && !AC) {
+      __builtin_nontemporal_store(g, &O.gidx()[o]);
+      __builtin_nontemporal_store(a, &O.slot()[o]);
+      __builtin_nontemporal_store(z, &O.median()[o]);
+      __builtin_nontemporal_store(P.my_bnum, &O.bnum()[o]);
+      __builtin_nontemporal_store(P.my_bcoord, &O.bcoord()[o]);
+      __builtin_nontemporal_store((uint8_t)kd, &O.kind()[o]);
+      return;
+    }
+#endif
     O.gidx()[o] = g;
     O.slot()[o] = a;
     O.median()[o] = z;
     if (!AC) {
-      O.bnum()[o] = P.my_bnum;
-      O.bcoord()[o] = P.my_bcoord;
+      /* (in-place form: the ballot columns are not staged - a compacting k_emit_dec16 reads the group's own, which no
+       * accept-reply call changes) */
+      if (!(TILES && IP.div)) {
+        O.bnum()[o] = P.my_bnum;
+        O.bcoord()[o] = P.my_bcoord;
+      }
       O.kind()[o] = (uint8_t)kd;
     }
+  };
+  /* the tiled front end's in-place outputs (PlaceCols): this bucket's predicted first output, or -1 - its count is not
+   * the predicted one (the call's outputs get compacted from the staging: k_emit_dec16) or the form is off */
+  auto in_place = [&](int32_t tout) -> int32_t {
+    if (!TILES || AC || !IP.div) return -1;
+    if (tout == ip_span) return ip_pb;
+    if (l == 0) A.ref[3] = (int32_t)X.epoch;
+    return -1;
+  };
+  auto put_in_place = [&](int32_t o, int32_t a, int32_t z, int32_t kd) {
+    IP.gidx[o] = g;
+    IP.slot[o] = a;
+    IP.median[o] = z;
+    IP.bnum[o] = P.my_bnum;
+    IP.bcoord[o] = P.my_bcoord;
+    IP.kind[o] = (uint8_t)kd;
   };
   if (in_lds) {
     VoteIter<true, AC> it;
@@ -813,10 +869,12 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     /* F: the bucket's outputs, group-major, as columns */
     int32_t tout;
     const int32_t ex = block_exscan_rt(nout, &tout);
+    const int32_t pb = in_place(tout);
     for (int32_t q = 0; q < nout; q++) {
       int32_t sl, md, kd;
       it.output(q, &sl, &md, &kd, &omask);
       put((int64_t)boff + ex + q, sl, md, kd);
+      if (pb >= 0) put_in_place(pb + ex + q, sl, md, kd);
     }
     if (l == 0) X.bucket_nout[b] = tout;
     if (TILES) TL_STAMP(4096 + b, 5); /* outputs staged */
@@ -844,10 +902,12 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     nout = it.nout;
     int32_t tout;
     const int32_t ex = block_exscan_rt(nout, &tout);
+    const int32_t pb = in_place(tout);
     for (int32_t q = 0; q < nout; q++) {
       int32_t sl, md, kd;
       it.output(q, &sl, &md, &kd, &omask);
       put((int64_t)boff + ex + q, sl, md, kd);
+      if (pb >= 0) put_in_place(pb + ex + q, sl, md, kd);
     }
     if (l == 0) X.bucket_nout[b] = tout;
   }
@@ -862,20 +922,20 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
 /* accept replies behind the tiled front end (gpx_tiles.hip.h) */
 template <int KMAX>
 __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16_tiles(DevState S, DevScratch X, Stage16 O, VoteCols in,
-                                                                         uint8_t* __restrict__ status, TileArea A) {
+                                                                         uint8_t* __restrict__ status, TileArea A, PlaceCols IP) {
   GPX_TILE_LDS_DECL(true);
-  bucket16_body<B16_AR, KMAX, true>(S, X, O, in, AcceptOut{}, status, TL, A);
+  bucket16_body<B16_AR, KMAX, true>(S, X, O, in, AcceptOut{}, status, TL, A, -1, IP);
 }
 /* K <= 4 and five replicas held to 6 waves like k_bucket_ar16_k5 */
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_tiles_k4(
-    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A) {
+    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A, PlaceCols IP) {
   GPX_TILE_LDS_DECL(true);
-  bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, TL, A);
+  bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, TL, A, -1, IP);
 }
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_tiles_k5(
-    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A) {
+    DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A, PlaceCols IP) {
   GPX_TILE_LDS_DECL(true);
-  bucket16_body<B16_AR, 5, true>(S, X, O, in, AcceptOut{}, status, TL, A);
+  bucket16_body<B16_AR, 5, true>(S, X, O, in, AcceptOut{}, status, TL, A, -1, IP);
 }
 /* Five replicas (BASELINE config #4): the KMAX = 5 body needs 82 VGPRs left to itself - two over the step
  * to 5 waves per SIMD = two workgroups per CU instead of three; held to 6 waves it gives up two registers
@@ -891,10 +951,15 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec16(
     DevScratch X, Stage16 O, int32_t* __restrict__ d_gidx, int32_t* __restrict__ d_slot,
     int32_t* __restrict__ d_bnum, int32_t* __restrict__ d_bcoord, int32_t* __restrict__ d_median,
     uint8_t* __restrict__ d_kind, int32_t* total_out, unsigned long long* acc, const int32_t* base_in,
-    int32_t* chain_out) {
+    int32_t* chain_out, int32_t* in_place = nullptr, int32_t nvotes = 0, const int32_t* __restrict__ c_bnum = nullptr,
+    const int32_t* __restrict__ c_bcoord = nullptr) {
   /* base_in: outputs of the passes before this one (accept-reply calls over more than 4 M groups run
    * one pass per group range, ranges ascending: the concatenation is still grouped by gidx ascending) */
   if (X.gate && *X.unsorted != X.epoch) return; /* k_emit_dec_runs wrote the outputs (gpx_runs.hip.h) */
+  /* in_place = A.ref of the tiled front end whose per-bucket kernel wrote the caller's columns itself (PlaceCols): word 3
+   * holds the call's epoch iff some bucket's count was not the predicted one */
+  const bool placed = in_place && in_place[3] != (int32_t)X.epoch;
+  if (placed && blockIdx.x != gridDim.x - 1) return; /* (the last workgroup still publishes the total) */
   const int32_t base0 = base_in ? *base_in : 0;
   const int32_t b = blockIdx.x;
   int32_t before = 0;
@@ -907,15 +972,22 @@ __global__ __launch_bounds__(GPX_BLOCK) void k_emit_dec16(
     if (total_out) *total_out = base0 + tot;
     if (chain_out) *chain_out = base0 + tot; /* never the word base_in points at: later workgroups still read that */
     if (acc) atomicAdd(acc, (unsigned long long)tot);
+    /* a call that had to be compacted teaches the next one its votes per output */
+    if (in_place && !placed && tot > 0 && nvotes % tot == 0 && nvotes / tot <= 64 && X.xabort)
+      __hip_atomic_store(X.xabort + GPX_IP_LEARN_WORD, (uint32_t)(nvotes / tot), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (in_place) in_place[placed ? 5 : 6]++; /* gpx_engine_path_counters */
   }
+  if (placed) return;
   const int32_t nd = X.bucket_nout[blockIdx.x];
   const int64_t src = X.bucket_off[blockIdx.x];
   if (threadIdx.x == 0) X.bucket_tot[blockIdx.x] = 0; /* (the slotted front end leaves its totals there: ready for a k_hist) */
   for (int32_t t = threadIdx.x; t < nd; t += GPX_BLOCK) {
-    d_gidx[out0 + t] = O.gidx()[src + t];
+    const int32_t g = O.gidx()[src + t];
+    d_gidx[out0 + t] = g;
     d_slot[out0 + t] = O.slot()[src + t];
-    d_bnum[out0 + t] = O.bnum()[src + t];
-    d_bcoord[out0 + t] = O.bcoord()[src + t];
+    /* c_bnum: the in-place form staged no ballots - the coordinator's own (PlaceCols) */
+    d_bnum[out0 + t] = c_bnum ? c_bnum[g] : O.bnum()[src + t];
+    d_bcoord[out0 + t] = c_bnum ? c_bcoord[g] : O.bcoord()[src + t];
     d_median[out0 + t] = O.median()[src + t];
     d_kind[out0 + t] = O.kind()[src + t];
   }

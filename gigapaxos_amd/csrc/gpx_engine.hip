@@ -262,6 +262,7 @@ struct gpx_engine {
   /* the tiled front end of accept-reply calls (gpx_tiles.hip.h; GPX_AR_TILES=0 keeps the partition front end for every
    * call): allocated on first use */
   bool ar_tiles = false;
+  bool ar_in_place = true; /* GPX_AR_INPLACE=0: the per-bucket kernel stages only, k_emit_dec16 always compacts (PlaceCols, gpx_ar16.hip.h) */
   TileArea tile_area{};
   int32_t tile_force = 0;   /* GPX_TILE_T (tuning): votes per scatter workgroup, 0 = chosen per call */
   int32_t tile_threads = 0; /* GPX_TILE_NT (tuning): 512 or 1024 threads per scatter workgroup, 0 = chosen per call */
@@ -793,6 +794,7 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   if (const char* tr = getenv("GPX_TRY_RUNS")) e->env_mask = atoi(tr) ? GPX_TRY_REPLY_RUNS : 0;
   e->ar_tiles = true; /* GPX_AR_TILES=0: the partition front end for every shuffled call (comparison runs) */
   if (const char* sl = getenv("GPX_AR_TILES")) e->ar_tiles = atoi(sl) != 0;
+  if (const char* sl = getenv("GPX_AR_INPLACE")) e->ar_in_place = atoi(sl) != 0;
   if (const char* tt = getenv("GPX_TILE_T")) e->tile_force = atoi(tt);
   if (const char* tt = getenv("GPX_TILE_NT")) e->tile_threads = atoi(tt);
   e->tile_area.xcd_rows = 1;
@@ -1067,6 +1069,19 @@ int gpx_engine_counters(gpx_engine* h, uint64_t out[3]) {
   return GPX_OK;
 }
 
+int gpx_engine_path_counters(gpx_engine* h, uint64_t out[2]) {
+  if (!h || !out) return GPX_EINVAL;
+  out[0] = out[1] = 0;
+  if (!h->tile_area.ref) return GPX_OK; /* no call has gone through the tiled front end yet */
+  HIPCHK(hipStreamSynchronize(h->sF));
+  HIPCHK(hipStreamSynchronize(h->sB));
+  int32_t tmp[2];
+  HIPCHK(hipMemcpy(tmp, h->tile_area.ref + 5, sizeof(tmp), hipMemcpyDeviceToHost));
+  out[0] = (uint64_t)(uint32_t)tmp[0];
+  out[1] = (uint64_t)(uint32_t)tmp[1];
+  return GPX_OK;
+}
+
 int gpx_profile_enable(gpx_engine* h, int32_t enable) {
   if (!h) return GPX_EINVAL;
   int rc = flush_profile(h);
@@ -1208,7 +1223,7 @@ static bool ar_tiles_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
     const size_t nwg_max = std::min<size_t>((N + 4095) / 4096, GPX_TL_MAXWG);
     const size_t pad = (nwg_max + 7) / 8 * 8; /* rows of A.off (8 bytes per tile) start on 64-byte lines */
     if (dev_alloc(e, &A.recs, cap, false) != GPX_OK || dev_alloc(e, &A.ext, cap, false) != GPX_OK ||
-        dev_alloc(e, &A.off, ((size_t)nbk / 4 + 2) * pad * 4, true) != GPX_OK || dev_alloc(e, &A.ref, 4, true) != GPX_OK) {
+        dev_alloc(e, &A.off, ((size_t)nbk / 4 + 2) * pad * 4, true) != GPX_OK || dev_alloc(e, &A.ref, 8, true) != GPX_OK) {
       A.recs = nullptr;
       e->ar_tiles = false; /* no room: the partition front end from now on */
       return false;
@@ -1269,20 +1284,30 @@ static bool ar_tiles_call(gpx_engine* e, int32_t n, const int32_t* gidx, const i
   }
   const Stage16 O{(int32_t*)e->X.o_rec, (int64_t)N};
   const VoteCols in{bnum, bcoord, acceptor, slot, max_cp};
+  /* votes per output the per-bucket kernel predicts its place with: what the last compacted call left in the
+   * host-mapped word (read without waiting: stale is fine), the replica count until then - every replica answers */
+  int32_t ip_div = 0;
+  if (e->ar_in_place && n < (1 << 26)) {
+    const uint32_t learnt = e->h_abort ? ((volatile uint32_t*)e->h_abort)[GPX_IP_LEARN_WORD] : 0u;
+    ip_div = learnt >= 1 && learnt <= 64 ? (int32_t)learnt : std::max(1, e->cfg.kmax);
+  }
+  const PlaceCols IP{d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, ip_div,
+                     ip_div > 1 ? (uint32_t)((1ull << 32) / (uint64_t)ip_div) + 1u : 0u};
   {
     LaunchScope _ls(e, e->cfg.kmax <= 4 ? "k_bucket_ar16_tiles_k4" : e->cfg.kmax <= 5 ? "k_bucket_ar16_tiles_k5" : "k_bucket_ar16_tiles");
     const dim3 grid(A.xcd_rows ? tile_grid(nbk) : nbk), block(e->bucket_threads);
     if (e->cfg.kmax <= 4)
-      hipLaunchKernelGGL(k_bucket_ar16_tiles_k4, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A);
+      hipLaunchKernelGGL(k_bucket_ar16_tiles_k4, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A, IP);
     else if (e->cfg.kmax <= 5)
-      hipLaunchKernelGGL(k_bucket_ar16_tiles_k5, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A);
+      hipLaunchKernelGGL(k_bucket_ar16_tiles_k5, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A, IP);
     else if (e->cfg.kmax <= 8)
-      hipLaunchKernelGGL(k_bucket_ar16_tiles<8>, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A);
+      hipLaunchKernelGGL(k_bucket_ar16_tiles<8>, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A, IP);
     else
-      hipLaunchKernelGGL(k_bucket_ar16_tiles<16>, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A);
+      hipLaunchKernelGGL(k_bucket_ar16_tiles<16>, grid, block, e->bucket_lds, e->stream, e->S, e->X, O, in, status, A, IP);
   }
   LAUNCH(e, "k_emit_dec16", k_emit_dec16, e->X.nbk, e->X, O, d_gidx, d_slot, d_bnum, d_bcoord, d_median_cp, d_kind, n_out,
-         &e->X.counters[1], (const int32_t*)nullptr, (int32_t*)nullptr);
+         &e->X.counters[1], (const int32_t*)nullptr, (int32_t*)nullptr, ip_div ? A.ref : (int32_t*)nullptr, n,
+         ip_div ? (const int32_t*)e->S.c_bnum : (const int32_t*)nullptr, (const int32_t*)e->S.c_bcoord);
 #ifdef GPX_TL_TRACE
   tl_trace_end(e);
 #endif

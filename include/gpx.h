@@ -323,6 +323,9 @@ int gpx_accept_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_
  * One record = one vote (one slot of a BATCHED_ACCEPT_REPLY).  Compacted outputs: one
  * entry per DECISION / PREEMPTED, grouped by gidx (ORDER above); *n_out of them (<= n).
  * status (nullable): per-vote GPX_S_*.
+ * The output columns hold n entries each and overlap neither each other nor the inputs; entries at and beyond
+ * *n_out are unspecified after the call (the device path writes a steady-state batch's outputs in place while it is
+ * still reading votes, and may leave predicted entries behind when the batch turns out not to be one: DESIGN.md 3.2).
  */
 int gpx_accept_reply_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const int32_t* bnum,
                            const int32_t* bcoord, const int32_t* slot, const int32_t* acceptor,
@@ -653,6 +656,14 @@ int gpx_route_batch_dev(gpx_engine* h, int32_t n, int32_t n_cols, const int32_t*
 
 /* cumulative counters since engine creation: votes, decisions, dropped records */
 int gpx_engine_counters(gpx_engine* h, uint64_t out[3]);
+
+/*
+ * Which way the accept-reply calls of the tiled front end delivered their compacted outputs since engine creation
+ * (DESIGN.md 3.2): out[0] = calls whose per-bucket kernel wrote every output in its predicted place (a steady-state
+ * batch: k_emit_dec16 only published the count), out[1] = calls compacted from the staging.  Telemetry of the device
+ * path only - the results are the same either way; tests/test_inplace_gpu.py asserts which one a shape takes.
+ */
+int gpx_engine_path_counters(gpx_engine* h, uint64_t out[2]);
 
 /*
  * Per-kernel timing with hipEvents on the launch stream.  enable=1 brackets every

@@ -40,7 +40,7 @@ def test_hip_library_exports_every_declared_symbol():
 def test_oracle_exports_matching_symbols(oracle_lib):
     for name in _declared():
         if name.endswith(("_dev", "_async")) or name in ("gpx_engine_set_stream", "gpx_profile_enable", "gpx_profile_read",
-                                                          "gpx_engine_wait"):
+                                                          "gpx_engine_wait", "gpx_engine_path_counters"):
             continue
         assert hasattr(oracle_lib.lib, "orc_" + name[4:]), name
 
