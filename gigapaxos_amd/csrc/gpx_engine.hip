@@ -243,6 +243,10 @@ struct gpx_engine {
   bool sharers_set = false;             /* GPX_DEVICE_SHARERS given: it replaces the registry of other processes */
   std::map<const void*, int> occ;       /* hipOccupancyMaxActiveBlocksPerMultiprocessor of the exchange kernels */
   uint32_t xchg_timeout_ms = GPX_XCHG_TIMEOUT_MS; /* GPX_XCHG_TIMEOUT_MS: how long an exchange kernel's pollers wait */
+  /* largest batch, in workgroups of 256 records, that takes the one-launch form: PROPOSE, ACCEPT / COMMIT, reply runs
+   * (GPX_PERS_CHUNKS=a,b,c for tuning).  The exchange among the workgroups grows with their number, the check kernel of
+   * the two-launch form does not: profiles/r06_one_launch_propose_sizes.txt */
+  int pers_max_chunks[3] = {128, 192, 256};
   bool one_launch = true;            /* GPX_XCHG_SLOTS=0 (comparison builds, tests): the check kernel + the work kernel instead */
   uint32_t gx_arrive = 0; /* grid_exchange's arrival counters as this engine's launches have left them */
   bool registered_live = false;
@@ -886,6 +890,10 @@ int gpx_engine_create(const gpx_config* cfg, gpx_engine** out) {
   {
     HIPCHK_CREATE(hipDeviceGetAttribute(&e->cus, hipDeviceAttributeMultiprocessorCount, e->device));
     if (const char* sv = getenv("GPX_XCHG_SLOTS")) e->one_launch = atoi(sv) != 0; /* test switch: 0 = the two-launch forms */
+    if (const char* sv = getenv("GPX_PERS_CHUNKS")) {
+      int a = 0, b = 0, c = 0;
+      if (sscanf(sv, "%d,%d,%d", &a, &b, &c) == 3) e->pers_max_chunks[0] = a, e->pers_max_chunks[1] = b, e->pers_max_chunks[2] = c;
+    }
     if (const char* sh = getenv("GPX_DEVICE_SHARERS")) e->sharers = std::max(1, atoi(sh)), e->sharers_set = true;
     if (const char* tm = getenv("GPX_XCHG_TIMEOUT_MS")) e->xchg_timeout_ms = (uint32_t)std::max(1, atoi(tm));
     if (const char* sk = getenv("GPX_XCHG_TEST_SKEW")) e->xchg_test_skew = (uint32_t)std::max(0, atoi(sk));
@@ -1495,7 +1503,7 @@ int gpx_accept_reply_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx,
         e->cfg.kmax <= 4 ? (n <= 65536 ? (const void*)k_ar_runs<4, true, true> : (const void*)k_ar_runs<4, true, false>)
         : e->cfg.kmax <= 8 ? (n <= 65536 ? (const void*)k_ar_runs<8, true, true> : (const void*)k_ar_runs<8, true, false>)
                            : (n <= 65536 ? (const void*)k_ar_runs<16, true, true> : (const void*)k_ar_runs<16, true, false>);
-    const bool small = xchg_ctl(e, nch, &Q, &pg, runs_kernel, GPX_RBLOCK);
+    const bool small = nch <= e->pers_max_chunks[2] && xchg_ctl(e, nch, &Q, &pg, runs_kernel, GPX_RBLOCK);
     if (!small)
       LAUNCH_OC(e, "k_runs_check", k_runs_check, (n + GPX_OC_BLOCK * GPX_RC_ITEMS - 1) / (GPX_OC_BLOCK * GPX_RC_ITEMS), 0, n,
                 gidx, e->S.G, e->X, status, info, next_info, st.chunk_cnt, nchunks, e->runs_arrive, n_out, &e->X.counters[1],
@@ -1603,7 +1611,7 @@ int gpx_accept_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
     GridXchg Q;
     int pg;
-    if (xchg_ctl(e, nch, &Q, &pg, (const void*)k_ac_pers<false>, GPX_DBLOCK)) { /* ONE launch: a grid that is resident for sure, the verdict exchanged among its workgroups */
+    if (nch <= e->pers_max_chunks[1] && xchg_ctl(e, nch, &Q, &pg, (const void*)k_ac_pers<false>, GPX_DBLOCK)) { /* ONE launch: a grid that is resident for sure, the verdict exchanged among its workgroups */
       LaunchScope _ls(e, "k_ac_pers");
       hipLaunchKernelGGL(k_ac_pers<false>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, gidx, bnum, bcoord, slot,
                          median_cp, a_flags, r_bnum, r_bcoord, r_maxcp, r_flags, status, D, n_runs, 0);
@@ -1722,7 +1730,7 @@ int gpx_commit_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const in
     const int nch = (n + GPX_DBLOCK - 1) / GPX_DBLOCK;
     GridXchg Q;
     int pg;
-    if (xchg_ctl(e, nch, &Q, &pg, (const void*)k_ac_pers<true>, GPX_DBLOCK)) {
+    if (nch <= e->pers_max_chunks[1] && xchg_ctl(e, nch, &Q, &pg, (const void*)k_ac_pers<true>, GPX_DBLOCK)) {
       LaunchScope _ls(e, "k_ac_pers");
       hipLaunchKernelGGL(k_ac_pers<true>, dim3(pg), dim3(GPX_DBLOCK), 0, e->stream, e->S, e->X, Q, n, gidx, bnum, bcoord, slot,
                          median_cp, c_kind, (int32_t*)nullptr, (int32_t*)nullptr, (int32_t*)nullptr, (uint8_t*)nullptr, status, D,
@@ -1865,7 +1873,11 @@ static int propose_dev_impl(gpx_engine* h, int32_t n, const int32_t* gidx, const
     int pg;
     const void* pers_kernel = e->cfg.kmax <= 4 ? (const void*)k_propose_pers<4>
                               : e->cfg.kmax <= 8 ? (const void*)k_propose_pers<8> : (const void*)k_propose_pers<16>;
-    if (xchg_ctl(e, nch, &Q, &pg, pers_kernel, GPX_BLOCK)) { /* ONE launch: a grid that is resident for sure, the verdict exchanged among its workgroups */
+    /* ONE launch - a grid that is resident for sure, the verdict exchanged among its workgroups - up to 128 chunks
+     * (32,768 proposals): measured per step at 32,000 groups 0.0317 ms against 0.034 for check + work kernel, at 65,000
+     * 0.035 against 0.032, at 125,000 0.048 against 0.045 - the exchange grows with the arrivals
+     * (profiles/r06_one_launch_propose_sizes.txt) */
+    if (nch <= e->pers_max_chunks[0] && xchg_ctl(e, nch, &Q, &pg, pers_kernel, GPX_BLOCK)) {
       if (e->cfg.kmax <= 4)
         LAUNCH(e, "k_propose_pers", k_propose_pers<4>, pg, e->S, e->X, Q, n, gidx, is_stop, slot, bnum, bcoord, median_cp,
                status, handle);
