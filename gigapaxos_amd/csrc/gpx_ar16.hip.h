@@ -927,7 +927,10 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16_tiles(DevSta
   bucket16_body<B16_AR, KMAX, true>(S, X, O, in, AcceptOut{}, status, TL, A, -1, IP);
 }
 /* K <= 4 and five replicas held to 6 waves like k_bucket_ar16_k5 */
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_tiles_k4(
+#ifndef GPX_K4_WAVES
+#define GPX_K4_WAVES 6
+#endif
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(GPX_K4_WAVES, 8))) void k_bucket_ar16_tiles_k4(
     DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A, PlaceCols IP) {
   GPX_TILE_LDS_DECL(true);
   bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, TL, A, -1, IP);

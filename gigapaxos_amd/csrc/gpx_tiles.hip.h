@@ -41,7 +41,9 @@ __host__ __device__ __forceinline__ int32_t tl_cnt_words(int32_t nbk, int32_t nt
   const int32_t per = (nbk + 1 + nt - 1) / nt; /* (+ 1: the entry behind the last bucket holds the tile's total) */
   return nt * (per <= 4 ? 4 : 8);
 }
-#define GPX_TL_MAXWG 1024 /* tiles of a call at most: the per-bucket kernel keeps their run starts and prefix in LDS */
+#ifndef GPX_TL_MAXWG
+#define GPX_TL_MAXWG 1024
+#endif /* tiles of a call at most: the per-bucket kernel keeps their run starts and prefix in LDS */
 struct __attribute__((aligned(8))) Vote8 {
   uint32_t a; /* offset of the vote in its tile (14 bits) | local group << 14 (10 bits) | ESC_S << 30 | ESC_B << 31 */
   uint32_t b; /* slot - slot0 + 128 (8 bits) | (slot - 1 - max_cp + 128) << 8 (8 bits) | acceptor << 16 */

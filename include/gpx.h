@@ -244,7 +244,7 @@ int gpx_engine_sync(gpx_engine* h);
  *   GPX_TRY_REPLY_RUNS      hint, not a promise: the shape is checked on the device and any other batch
  *                           goes through the partition pipeline as before (a few idle launches dearer).
  * Results are identical on every path.  (A call of at most 1,024 votes that is not under the promise takes one launch
- * of one workgroup whatever its order - gigapaxos_amd/csrc/gpx_small.hip.h; a runs call of at most 131,072 votes one
+ * of one workgroup whatever its order - gigapaxos_amd/csrc/gpx_small.hip.h; a runs call of at most 65,536 votes one
  * launch too.  GPX_ORDERED_REPLY_RUNS keeps its refusal at every size.)
  */
 #define GPX_ORDERED_REPLY_RUNS 8
