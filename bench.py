@@ -303,6 +303,9 @@ class CoordinatorLeg:
             self.elapsed_all.append(elapsed)
         mid = sorted(range(reps), key=lambda i: self.elapsed_all[i])[reps // 2]
         self.elapsed, self.gpu_ms = self.elapsed_all[mid], self.gpu_ms_all[mid]
+        # which way the accept-reply calls delivered their outputs so far (warm-up + timed steps):
+        # (written in place by the per-bucket kernel, compacted from the staging by k_emit_dec16)
+        self.path_counters = eng.path_counters()
         self.timed_rounds = (warmup + mid * steps, warmup + (mid + 1) * steps)  # the median repetition's rounds
         steps_all = reps * steps
 
@@ -1001,6 +1004,9 @@ def main():
             "votes_per_sec": round(votes_total / elapsed, 1),
             "votes_per_sec_per_gpu": round(votes_total / elapsed / world, 1),
             "gpu_ms_per_step_rank0": round(gpu_ms / steps, 4),
+            # gpx_engine_path_counters after the warm-up and the timed regions (rank 0): accept-reply calls whose outputs
+            # the per-bucket kernel wrote in their final place / calls k_emit_dec16 compacted from the staging
+            "accept_reply_outputs": {"in_place_calls": leg.path_counters[0], "compacted_calls": leg.path_counters[1]},
             "roofline": roofline,
             "strong": strong,
             "end_to_end": end_to_end,

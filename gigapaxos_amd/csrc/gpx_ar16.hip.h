@@ -544,7 +544,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     /* A.off is [bucket / 4][tile][4]: this bucket's start and the next one's - the same 8-byte entry three times in four */
     const unsigned long long* r0 = (const unsigned long long*)A.off + (uint32_t)(b >> 2) * (uint32_t)A.nwg_pad;
     const unsigned long long* r1 = (const unsigned long long*)A.off + (uint32_t)((b + 1) >> 2) * (uint32_t)A.nwg_pad;
-    const int32_t per = (A.nwg + gb - 1) / gb; /* <= 4: at most 1024 tiles, at least 256 lanes */
+    const int32_t per = (A.nwg + gb - 1) >> X.shift; /* (gb == 1 << X.shift) <= 4: at most 1024 tiles, at least 256 lanes */
     int32_t cw[4], ssum = 0, csum = 0;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -623,7 +623,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   if (TILES)
     while ((1 << srch) < A.nwg) srch++;
   /* record j of the bucket (TILES): the largest tile w with s_pre[w] <= j holds it at s_st[w] + j - s_pre[w] */
-  auto tile_rec = [&](int32_t j) -> Vote16 {
+  auto tile_find = [&](int32_t j) -> int32_t {
     int32_t lo = 0, hi = A.nwg;
     for (int32_t t = 0; t < srch; t++) { /* s_pre[lo] <= j < s_pre[hi]; neighbours: mid == lo, nothing moves */
       const int32_t mid = (lo + hi) >> 1;
@@ -631,6 +631,14 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
       lo = up ? mid : lo;
       hi = up ? hi : mid;
     }
+    return lo;
+  };
+  /* the same from a tile that holds an EARLIER record (s_pre[nwg] = nb ends the walk; empty runs are stepped over) */
+  auto tile_adv = [&](int32_t j, int32_t lo) -> int32_t {
+    while (s_pre[lo + 1] <= j) lo++;
+    return lo;
+  };
+  auto tile_at = [&](int32_t j, int32_t lo) -> Vote16 {
     const uint32_t st = s_st[lo];
     const int64_t p = (int64_t)lo * A.tile + (int32_t)(st & 0x7fffu) + (j - s_pre[lo]);
     const I4 x = tile_expand(A.recs[p], (st & TL_WIDE) ? A.ext + p : (const int2*)nullptr, lo, A.tile, slot0, in.slot, in.maxcp);
@@ -638,8 +646,12 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
     return v;
   };
+  auto tile_rec = [&](int32_t j) -> Vote16 { return tile_at(j, tile_find(j)); };
   if (TILES) __syncthreads(); /* s_pre / s_st */
   if (TILES) TL_STAMP(4096 + b, 1); /* rows of A.off read and scanned */
+#ifdef GPX_ABL_STOP /* ablation builds (wrong results): the kernel up to one of its phases */
+  if (TILES && GPX_ABL_STOP == 1) return;
+#endif
   if (TILES && !in_lds) {
     /* too many records for the LDS staging (a skewed stream): copy them into this bucket's region of X.rec and go on as
      * the partition path does (the count pass below reads that region) */
@@ -654,16 +666,41 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   r0.slot = r1.slot = r2.slot = r3.slot = 0;
   r0.maxcp = r1.maxcp = r2.maxcp = r3.maxcp = 0;
   const bool from_tiles = TILES && in_lds; /* (beyond the LDS staging the records were just copied to recG) */
-  auto rec_at = [&](int32_t j) -> Vote16 { return from_tiles ? tile_rec(j) : recG[j]; };
-  /* a lane's records: j = l + t * gb; the first four stay in registers, the fifth and later ones are fetched again by the
-   * placement.  (Looking the runs up by a max-scan over head flags instead of searching s_pre per record was built and
-   * measured: the same 40.5 us - profiles/r06_bucket_kernel_attempts.txt; the kernel waits for memory round trips.) */
-  const bool v0 = l < nb, v1 = gb + l < nb, v2 = 2 * gb + l < nb, v3 = 3 * gb + l < nb;
-  if (v0) r0 = rec_at(l);
-  if (v1) r1 = rec_at(gb + l);
-  if (v2) r2 = rec_at(2 * gb + l);
-  if (v3) r3 = rec_at(3 * gb + l);
-  const int32_t tail0 = 4 * gb + l; /* first record of the lane that is not in a register */
+  /* A lane's records.  From the tiles: CONSECUTIVE ones, j = l * pl + t - they mostly sit in one run, so the run of the
+   * first is searched for and the others walk on from it (a search per record was 8 LDS round trips and ~60 instructions
+   * each, in a kernel bound by the instructions it issues: profiles/r06_bucket_kernel_attempts.txt).  From X.rec (the
+   * partition path; a bucket beyond the LDS staging): j = l + t * gb, coalesced 16-byte records.  The first four stay in
+   * registers, the fifth and later ones are fetched again by a second pass.  The order in which a workgroup takes its
+   * records is free: ranks come from LDS atomics, the replay orders a group's votes by arrival index. */
+  const int32_t pl = from_tiles ? (nb + gb - 1) >> X.shift : 0; /* records per lane */
+  const int32_t jb = from_tiles ? l * pl : l, jstep = from_tiles ? 1 : gb;
+  const int32_t jend = from_tiles ? min(jb + pl, nb) : nb;
+  const bool v0 = jb < jend, v1 = jb + jstep < jend, v2 = jb + 2 * jstep < jend, v3 = jb + 3 * jstep < jend;
+  int32_t lo3 = 0; /* tile of the lane's last record in a register */
+  if (from_tiles) {
+    if (v0) lo3 = tile_find(jb), r0 = tile_at(jb, lo3);
+    if (v1) lo3 = tile_adv(jb + 1, lo3), r1 = tile_at(jb + 1, lo3);
+    if (v2) lo3 = tile_adv(jb + 2, lo3), r2 = tile_at(jb + 2, lo3);
+    if (v3) lo3 = tile_adv(jb + 3, lo3), r3 = tile_at(jb + 3, lo3);
+  } else {
+    if (v0) r0 = recG[jb];
+    if (v1) r1 = recG[jb + jstep];
+    if (v2) r2 = recG[jb + 2 * jstep];
+    if (v3) r3 = recG[jb + 3 * jstep];
+  }
+  const int32_t tail0 = jb + 4 * jstep; /* first record of the lane that is not in a register */
+  /* calls f on the lane's records beyond the first four */
+  auto for_tail = [&](auto&& f) {
+    if (from_tiles) {
+      int32_t lo = lo3;
+      for (int32_t j = tail0; j < jend; j++) {
+        lo = tile_adv(j, lo);
+        f(tile_at(j, lo));
+      }
+    } else {
+      for (int32_t j = tail0; j < jend; j += jstep) f(recG[j]);
+    }
+  };
   /* SLOTTED PLACEMENT (round 6; accept replies behind the tiled front end): a group's vote of rank t goes straight to
    * row t of the staging arrays - [t * gb + group], KSLOT rows - at the rank its one LDS atomic returns: no count
    * pass, no scan, no second atomic.  (The kernel is bound by the instructions it issues, 929 vector instructions
@@ -690,7 +727,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     if (v1) put_row(r1);
     if (v2) put_row(r2);
     if (v3) put_row(r3);
-    for (int32_t j = tail0; j < nb; j += gb) put_row(rec_at(j));
+    for_tail([&](const Vote16& v) { put_row(v); });
     slotted = !__syncthreads_or(over);
     if (!slotted) { /* start over, the general way */
       lcnt[l] = 0;
@@ -702,6 +739,9 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     c = lcnt[l];
     start = l;
     if (TILES) TL_STAMP(4096 + b, 3);
+#ifdef GPX_ABL_STOP
+    if (TILES && GPX_ABL_STOP == 2) return;
+#endif
     if (pre && g < X.g_end) coord_preload_ring<KMAX>(S, g, P);
   } else {
   /* A: votes per group */
@@ -710,7 +750,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     if (v1) atomicAdd(&lcnt[r1.meta & V16_LG_MASK], 1);
     if (v2) atomicAdd(&lcnt[r2.meta & V16_LG_MASK], 1);
     if (v3) atomicAdd(&lcnt[r3.meta & V16_LG_MASK], 1);
-    for (int32_t j = tail0; j < nb; j += gb) atomicAdd(&lcnt[rec_at(j).meta & V16_LG_MASK], 1);
+    for_tail([&](const Vote16& v) { atomicAdd(&lcnt[v.meta & V16_LG_MASK], 1); });
   }
   __syncthreads();
   if (TILES) TL_STAMP(4096 + b, 2); /* records fetched and counted */
@@ -735,7 +775,7 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     if (v2) place(r2);
     if (v3) place(r3);
     /* (a lane's records beyond its first four: read a second time, from L2) */
-    for (int32_t j = tail0; j < nb; j += gb) place(TILES ? tile_rec(j) : recG[j]);
+    for_tail([&](const Vote16& v) { place(v); });
   } else {
     for (int32_t j = l; j < nb; j += gb) {
       const Vote16 v = recG[j];
@@ -866,6 +906,9 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     nout = it.nout;
     omask = it.omask;
     if (TILES) TL_STAMP(4096 + b, 4); /* thread 0 replayed */
+#ifdef GPX_ABL_STOP
+    if (TILES && GPX_ABL_STOP == 3) return;
+#endif
     /* F: the bucket's outputs, group-major, as columns */
     int32_t tout;
     const int32_t ex = block_exscan_rt(nout, &tout);

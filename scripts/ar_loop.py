@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=12)
     ap.add_argument("--mix", action="store_true")
     ap.add_argument("--sorted", action="store_true")
+    ap.add_argument("--profile", action="store_true", help="print the kernels' microseconds per launch (hipEvent brackets) of the last rounds")
     a = ap.parse_args()
     G, K = a.groups, a.k
     members = list(range(100, 100 + K))
@@ -43,11 +44,16 @@ def main():
     torch.cuda.synchronize()
     for r in range(a.rounds):
         c = rounds[r]
+        if a.profile and r == 4:
+            e.sync()
+            e.profile(2)
         e.call_dev("propose_batch", G, P(g), 0, *[P(t) for t in p])
         e.call_dev("accept_reply_batch", int(c[0].shape[0]), *[P(t) for t in c], *[P(t) for t in d], P(no), P(st))
     e.sync()
     torch.cuda.synchronize()
     print("decisions of the last round:", int(no))
+    if a.profile:
+        print({k: round(ms * 1e3 / max(nl, 1), 1) for k, (nl, ms) in sorted(e.profile_read().items())})
     e.close()
 
 

@@ -50,7 +50,7 @@ def round_cols(shape, r, rng, slot_g):
 
 
 def measure(name, shape, env, rounds=6, warm=2):
-    """-> ({kernel: us per launch} of the last accept-reply call, us per call: median of the timed calls)"""
+    """-> ({kernel: us per launch, median over the timed accept-reply calls}, us per call: median of the timed calls)"""
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update(env)
     try:
@@ -68,7 +68,7 @@ def measure(name, shape, env, rounds=6, warm=2):
         assert (e.create_groups(np.arange(G, dtype=np.int32), mem, K, rows) == S_OK).all()
         g = np.arange(G, dtype=np.int32)
         P = lambda t: t.data_ptr()  # noqa: E731
-        times, kernels = [], None
+        times, percall = [], []
         for r in range(rounds):
             slot_g = e.propose(g)[0]
             cols = round_cols(shape, r, rng, slot_g)
@@ -84,8 +84,11 @@ def measure(name, shape, env, rounds=6, warm=2):
             e.profile(0)
             if r >= warm:
                 times.append(sum(ms for _, ms in prof.values()) * 1e3)
-                kernels = {k: round(ms * 1e3 / max(nl, 1), 1) for k, (nl, ms) in prof.items()}  # us per launch, last call
+                percall.append({k: ms * 1e3 / max(nl, 1) for k, (nl, ms) in prof.items()})  # us per launch
         e.close()
+        # per kernel the MEDIAN over the timed calls (one call's bracket can be off by half its length on a small shape:
+        # the 125,000-group shard's scatter once read 20 us for 13 and "dominated" the call)
+        kernels = {k: round(float(np.median([c[k] for c in percall if k in c])), 1) for k in percall[-1]}
         return kernels, float(np.median(times))
     finally:
         for k, v in saved.items():
