@@ -1192,23 +1192,26 @@ static void tl_trace_end(gpx_engine* e) { /* every call: the last one wins */
 }
 #endif
 /* Votes per scatter workgroup.  A workgroup's LDS holds its whole tile (8 bytes per vote + the bucket counters), the
- * kernel lasts as long as its busiest CU, and every tile costs the per-bucket kernel a run to look up: the largest tile
- * that still spreads the call over the chip.  Measured (profiles/r06_tile_shapes.txt): 3 M votes - 12,288-vote tiles
- * (245 workgroups) 28 us against 30-33 for 184 x 16,384, 367 x 8,192, 733 x 4,096; 5 M votes - 407 x 12,288. */
+ * kernel lasts as long as its busiest CU - workgroups go round the CUs, and two of them on one CU take twice as long as
+ * one: they run in phase -, and every tile costs the per-bucket kernel a run to look up.  The model is the measured time
+ * of one round of tiles per shape (profiles/r06_tile_shapes.txt: 27.9 / 17.3 / 10.0 us for 12,288 / 8,192 / 4,096 votes)
+ * times the rounds, plus 5 ns per tile for the per-bucket kernel (733 tiles instead of 245: +2.3 us).  It picks what was
+ * measured best on every shape of that file: 3 M votes - 245 x 12,288 (scatter 27.9 us against 33.2 for 367 x 8,192: the
+ * second round), 5 M votes - 611 x 8,192 (51.8 against 55.9 for 407 x 12,288: three short rounds against two long ones),
+ * 1.5 M votes - 184 x 8,192, 625,000 votes - 153 x 4,096. */
 static TileShape tile_shape(const gpx_engine* e, int32_t n, int32_t nbk) {
   if (e->tile_force) return TileShape{e->tile_force, e->tile_threads ? e->tile_threads : (e->tile_force <= 8192 ? 512 : 1024)};
   const int64_t cus = std::max(1, e->cus);
   /* (16,384-vote tiles of 1024 threads spill registers - kept as a forced shape only) */
-  static const TileShape cand[] = {{12288, 1024}, {8192, 1024}, {4096, 512}};
-  TileShape best = cand[2];
+  static const struct { TileShape s; int64_t round_ns; } cand[] = {{{12288, 1024}, 27900}, {{8192, 1024}, 17300}, {{4096, 512}, 10000}};
+  TileShape best = cand[2].s;
   int64_t best_cost = INT64_MAX;
-  for (const TileShape& c : cand) {
-    if (GPX_TL_LDS_BYTES(nbk, c.T, c.NT) > (size_t)158 * 1024) continue;
-    const int64_t nwg = ((int64_t)n + c.T - 1) / c.T;
+  for (const auto& c : cand) {
+    if (GPX_TL_LDS_BYTES(nbk, c.s.T, c.s.NT) > (size_t)158 * 1024) continue;
+    const int64_t nwg = ((int64_t)n + c.s.T - 1) / c.s.T;
     if (nwg > GPX_TL_MAXWG) continue;
-    /* votes the busiest CU sorts (workgroups go round the CUs), and a charge per tile */
-    const int64_t cost = (nwg + cus - 1) / cus * c.T + nwg * 16;
-    if (cost < best_cost) best_cost = cost, best = c;
+    const int64_t cost = (nwg + cus - 1) / cus * c.round_ns + nwg * 5;
+    if (cost < best_cost) best_cost = cost, best = c.s;
   }
   return best;
 }
