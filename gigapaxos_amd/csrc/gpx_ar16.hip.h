@@ -638,13 +638,24 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
     while (s_pre[lo + 1] <= j) lo++;
     return lo;
   };
-  auto tile_at = [&](int32_t j, int32_t lo) -> Vote16 {
+  /* where record j sits in A.recs, given its tile (32-bit: the area holds max_batch votes + a tile; | TL_WIDE << 16 in
+   * *wide).  Split from the load and from the expansion so that a lane's loads go out TOGETHER: the expansion of one record
+   * waits for its data, and with the next record's address behind it the round trips came one after the other. */
+  auto tile_pos = [&](int32_t j, int32_t lo, uint32_t* wide) -> uint32_t {
     const uint32_t st = s_st[lo];
-    const int64_t p = (int64_t)lo * A.tile + (int32_t)(st & 0x7fffu) + (j - s_pre[lo]);
-    const I4 x = tile_expand(A.recs[p], (st & TL_WIDE) ? A.ext + p : (const int2*)nullptr, lo, A.tile, slot0, in.slot, in.maxcp);
+    *wide = st & TL_WIDE;
+    return __umul24((uint32_t)lo, (uint32_t)A.tile) + (st & 0x7fffu) + (uint32_t)(j - s_pre[lo]);
+  };
+  auto tile_exp = [&](const Vote8 raw, uint32_t p, uint32_t wide, int32_t lo) -> Vote16 {
+    const I4 x = tile_expand(raw, wide ? A.ext + p : (const int2*)nullptr, lo, A.tile, slot0, in.slot, in.maxcp);
     Vote16 v;
     v.idx = x.x, v.slot = x.y, v.maxcp = x.z, v.meta = (uint32_t)x.w;
     return v;
+  };
+  auto tile_at = [&](int32_t j, int32_t lo) -> Vote16 {
+    uint32_t wide;
+    const uint32_t p = tile_pos(j, lo, &wide);
+    return tile_exp(A.recs[p], p, wide, lo);
   };
   auto tile_rec = [&](int32_t j) -> Vote16 { return tile_at(j, tile_find(j)); };
   if (TILES) __syncthreads(); /* s_pre / s_st */
@@ -678,10 +689,19 @@ __device__ __forceinline__ void bucket16_body(const DevState& S, const DevScratc
   const bool v0 = jb < jend, v1 = jb + jstep < jend, v2 = jb + 2 * jstep < jend, v3 = jb + 3 * jstep < jend;
   int32_t lo3 = 0; /* tile of the lane's last record in a register */
   if (from_tiles) {
-    if (v0) lo3 = tile_find(jb), r0 = tile_at(jb, lo3);
-    if (v1) lo3 = tile_adv(jb + 1, lo3), r1 = tile_at(jb + 1, lo3);
-    if (v2) lo3 = tile_adv(jb + 2, lo3), r2 = tile_at(jb + 2, lo3);
-    if (v3) lo3 = tile_adv(jb + 3, lo3), r3 = tile_at(jb + 3, lo3);
+    int32_t l0 = 0, l1 = 0, l2 = 0;
+    uint32_t p0 = 0, p1 = 0, p2 = 0, p3 = 0, w0 = 0, w1 = 0, w2 = 0, w3 = 0;
+    Vote8 q0{}, q1{}, q2{}, q3{};
+    /* the four places, the four loads ... */
+    if (v0) lo3 = l0 = tile_find(jb), p0 = tile_pos(jb, l0, &w0), q0 = A.recs[p0];
+    if (v1) lo3 = l1 = tile_adv(jb + 1, l0), p1 = tile_pos(jb + 1, l1, &w1), q1 = A.recs[p1];
+    if (v2) lo3 = l2 = tile_adv(jb + 2, l1), p2 = tile_pos(jb + 2, l2, &w2), q2 = A.recs[p2];
+    if (v3) lo3 = tile_adv(jb + 3, l2), p3 = tile_pos(jb + 3, lo3, &w3), q3 = A.recs[p3];
+    /* ... then what they brought */
+    if (v0) r0 = tile_exp(q0, p0, w0, l0);
+    if (v1) r1 = tile_exp(q1, p1, w1, l1);
+    if (v2) r2 = tile_exp(q2, p2, w2, l2);
+    if (v3) r3 = tile_exp(q3, p3, w3, lo3);
   } else {
     if (v0) r0 = recG[jb];
     if (v1) r1 = recG[jb + jstep];
