@@ -982,12 +982,52 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket16(DevState S, Dev
   GPX_TILE_LDS_DECL(false);
   bucket16_body<OP, KMAX>(S, X, O, in, R, status, TL);
 }
-/* accept replies behind the tiled front end (gpx_tiles.hip.h) */
+/* accept replies behind the tiled front end (gpx_tiles.hip.h).
+ *
+ * The kernel's ~40 argument pointers do not fit the 102 SGPRs: taken by value, the compiler loads them all at entry and
+ * parks what does not fit in the lanes of a VGPR - 562 v_readlane + 122 v_writelane of the k4 kernel's 3,068 vector
+ * instructions (static; scripts/ubench/isa_mix.py), two v_readlane in front of every use of a parked pointer.  The blocks
+ * that are only needed here and there - the caller's vote columns (the escape path), the scratch descriptor, the in-place
+ * output columns (the last phase) - are therefore read from the kernarg segment WHERE THEY ARE USED (scalar loads from the
+ * constant cache; the by-value parameters stay in the signature for the launch and are otherwise dead): 76 v_readlane,
+ * 2,429 vector instructions, k4 40.9 -> 38.7 us, k5 76.5 -> 75.5 (profiles/r06_lazy_kernargs.txt).  The state block and the
+ * tile area taken the same way only add scalar loads (GPX_LAZY bits 16 / 32: measured, no gain). */
+struct TilesKernArgs { /* the argument block of the k_bucket_ar16_tiles kernels, as the kernarg segment lays it out */
+  DevState S;
+  DevScratch X;
+  Stage16 O;
+  VoteCols in;
+  uint8_t* status;
+  TileArea A;
+  PlaceCols IP;
+};
+/* every argument is 8-byte aligned and a multiple of 8 bytes long: the segment packs them exactly as this struct does
+ * (the mix stream's escapes and the in-place outputs of every parity test go through these offsets) */
+static_assert(alignof(DevState) == 8 && alignof(DevScratch) == 8 && alignof(Stage16) == 8 && alignof(VoteCols) == 8 &&
+                  alignof(TileArea) == 8 && alignof(PlaceCols) == 8,
+              "kernarg layout");
+static_assert(sizeof(DevState) % 8 == 0 && sizeof(DevScratch) % 8 == 0 && sizeof(Stage16) % 8 == 0 && sizeof(VoteCols) % 8 == 0 &&
+                  sizeof(TileArea) % 8 == 0 && sizeof(PlaceCols) % 8 == 0,
+              "kernarg layout");
+#ifndef GPX_LAZY
+#define GPX_LAZY 7 /* 1: the vote columns, 2: the scratch descriptor, 4: the in-place columns (8 status, 16 state, 32 tile area) */
+#endif
+template <bool LAZY, class T>
+__device__ __forceinline__ const T& lazy_pick(const T& from_kernarg, const T& by_value) {
+  if constexpr (LAZY) return from_kernarg;
+  else return by_value;
+}
+#define GPX_TILES_KERNEL_BODY(KM)                                                                                          \
+  GPX_TILE_LDS_DECL(true);                                                                                                 \
+  const TilesKernArgs* ka = (const TilesKernArgs*)__builtin_amdgcn_kernarg_segment_ptr();                                  \
+  bucket16_body<B16_AR, KM, true>(lazy_pick<(GPX_LAZY & 16) != 0>(ka->S, S), lazy_pick<(GPX_LAZY & 2) != 0>(ka->X, X), O,  \
+                                  lazy_pick<(GPX_LAZY & 1) != 0>(ka->in, in), AcceptOut{},                                 \
+                                  (GPX_LAZY & 8) ? ka->status : status, TL, lazy_pick<(GPX_LAZY & 32) != 0>(ka->A, A), -1, \
+                                  lazy_pick<(GPX_LAZY & 4) != 0>(ka->IP, IP))
 template <int KMAX>
 __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16_tiles(DevState S, DevScratch X, Stage16 O, VoteCols in,
                                                                          uint8_t* __restrict__ status, TileArea A, PlaceCols IP) {
-  GPX_TILE_LDS_DECL(true);
-  bucket16_body<B16_AR, KMAX, true>(S, X, O, in, AcceptOut{}, status, TL, A, -1, IP);
+  GPX_TILES_KERNEL_BODY(KMAX);
 }
 /* K <= 4 and five replicas held to 6 waves like k_bucket_ar16_k5 */
 #ifndef GPX_K4_WAVES
@@ -995,13 +1035,11 @@ __global__ __launch_bounds__(1024) GPX_AR16_ATTR void k_bucket_ar16_tiles(DevSta
 #endif
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(GPX_K4_WAVES, 8))) void k_bucket_ar16_tiles_k4(
     DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A, PlaceCols IP) {
-  GPX_TILE_LDS_DECL(true);
-  bucket16_body<B16_AR, 4, true>(S, X, O, in, AcceptOut{}, status, TL, A, -1, IP);
+  GPX_TILES_KERNEL_BODY(4);
 }
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(6, 8))) void k_bucket_ar16_tiles_k5(
     DevState S, DevScratch X, Stage16 O, VoteCols in, uint8_t* __restrict__ status, TileArea A, PlaceCols IP) {
-  GPX_TILE_LDS_DECL(true);
-  bucket16_body<B16_AR, 5, true>(S, X, O, in, AcceptOut{}, status, TL, A, -1, IP);
+  GPX_TILES_KERNEL_BODY(5);
 }
 /* Five replicas (BASELINE config #4): the KMAX = 5 body needs 82 VGPRs left to itself - two over the step
  * to 5 waves per SIMD = two workgroups per CU instead of three; held to 6 waves it gives up two registers

@@ -604,6 +604,34 @@ bool xchg_ctl(gpx_engine* e, int nchunks, GridXchg* Q, int* grid, const void* ke
   return true;
 }
 
+/* A copy between the device and HOST memory.  Memory the runtime knows as pinned (a block given to gpx_host_register, one
+ * from gpx_host_alloc, or pinned elsewhere) goes out as one DMA.  PAGEABLE memory goes out in pieces of 512 KB: above
+ * ~1 MB the HIP runtime would pin the caller's pages for the length of the copy instead of staging them through its own
+ * buffer (profiles/r06_copy_path_probe.txt), and every GPU page fault this code base has on file was raised while the main
+ * thread sat in exactly that transient pinning (profiles/r06_abort_backtrace.txt; once under gpx_group_create's 64 MB
+ * chunks).  A piece is staged; the engine never asks the runtime to pin memory it was not given.  Pageable calls pay for
+ * it in rate (about half of the pinned path's) - the fast host paths are the registered / gpx_host_alloc ones anyway. */
+constexpr size_t GPX_PAGEABLE_PIECE = (size_t)512 << 10;
+bool host_is_pinned(gpx_engine* e, const void* p) {
+  for (auto& r : e->registered)
+    if ((const char*)p >= r.first && (const char*)p < r.first + r.second) return true;
+  hipPointerAttribute_t at{};
+  if (hipPointerGetAttributes(&at, p) != hipSuccess) {
+    (void)hipGetLastError(); /* unknown to the runtime: plain pageable memory */
+    return false;
+  }
+  return at.type == hipMemoryTypeHost;
+}
+hipError_t xfer(gpx_engine* e, void* dst, const void* src, size_t bytes, hipMemcpyKind kind, hipStream_t st) {
+  if (bytes <= GPX_PAGEABLE_PIECE || host_is_pinned(e, kind == hipMemcpyHostToDevice ? src : (const void*)dst))
+    return hipMemcpyAsync(dst, src, bytes, kind, st);
+  for (size_t o = 0; o < bytes; o += GPX_PAGEABLE_PIECE) {
+    const hipError_t rc = hipMemcpyAsync((char*)dst + o, (const char*)src + o, std::min(GPX_PAGEABLE_PIECE, bytes - o), kind, st);
+    if (rc != hipSuccess) return rc;
+  }
+  return hipSuccess;
+}
+
 template <int KMAX>
 void launch_bucket_ar16(gpx_engine* e, const Stage16& O, const VoteCols& in, uint8_t* status) {
   LAUNCH_B(e, "k_bucket_ar16", (k_bucket16<B16_AR, KMAX>), e->S, e->X, O, in, AcceptOut{}, status);
@@ -1968,10 +1996,10 @@ int gpx_propose_batch_dev(gpx_engine* h, int32_t n, const int32_t* gidx, const u
 /* ---- host-pointer data path ---------------------------------------------------- */
 /* H2D into the engine's staging columns, the _dev twin, D2H of the results.        */
 
-#define H2D(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->sF))
+#define H2D(dst, src, bytes) HIPCHK(xfer(h, (dst), (src), (bytes), hipMemcpyHostToDevice, h->sF))
 /* lifecycle calls change group state: everything on the back-end stream, in call order */
-#define H2D_B(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyHostToDevice, h->sB))
-#define D2H(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, h->sB))
+#define H2D_B(dst, src, bytes) HIPCHK(xfer(h, (dst), (src), (bytes), hipMemcpyHostToDevice, h->sB))
+#define D2H(dst, src, bytes) HIPCHK(xfer(h, (dst), (src), (bytes), hipMemcpyDeviceToHost, h->sB))
 
 int gpx_propose_batch(gpx_engine* h, int32_t n, const int32_t* gidx, const uint8_t* is_stop,
                       int32_t* slot, int32_t* bnum, int32_t* bcoord, int32_t* median_cp,
@@ -2458,8 +2486,8 @@ int async_inputs(gpx_engine* e, int32_t n, int ncols, const int32_t* const* hsrc
     hipLaunchKernelGGL(k_copy_in, dim3(1024), dim3(256), 0, st, C);
     return GPX_OK;
   }
-  for (int k = 0; k < ncols; k++) HIPCHK(hipMemcpyAsync(ddst[k], hsrc[k], (size_t)n * 4, hipMemcpyHostToDevice, st));
-  if (hb) HIPCHK(hipMemcpyAsync(db, hb, (size_t)n, hipMemcpyHostToDevice, st));
+  for (int k = 0; k < ncols; k++) HIPCHK(xfer(e, ddst[k], hsrc[k], (size_t)n * 4, hipMemcpyHostToDevice, st));
+  if (hb) HIPCHK(xfer(e, db, hb, (size_t)n, hipMemcpyHostToDevice, st));
   return GPX_OK;
 }
 /* inputs are on their way: the kernels (engine stream) wait for them */
@@ -2500,8 +2528,8 @@ int async_dense_out(gpx_engine* e, gpx_engine::AsyncSet& a, int32_t n, int ncols
     hipLaunchKernelGGL(k_copy_out, dim3(512), dim3(256), 0, a.s_out, (const int32_t*)nullptr, C);
     return GPX_OK;
   }
-  for (int k = 0; k < ncols; k++) HIPCHK(hipMemcpyAsync(hdst[k], dsrc[k], (size_t)n * 4, hipMemcpyDeviceToHost, a.s_out));
-  for (int k = 0; k < nb; k++) HIPCHK(hipMemcpyAsync(hb[k], db[k], (size_t)n, hipMemcpyDeviceToHost, a.s_out));
+  for (int k = 0; k < ncols; k++) HIPCHK(xfer(e, hdst[k], dsrc[k], (size_t)n * 4, hipMemcpyDeviceToHost, a.s_out));
+  for (int k = 0; k < nb; k++) HIPCHK(xfer(e, hb[k], db[k], (size_t)n, hipMemcpyDeviceToHost, a.s_out));
   return GPX_OK;
 }
 
@@ -2536,7 +2564,7 @@ int async_submit(gpx_engine* e, gpx_engine::AsyncSet& a, bool with_count, gpx_ti
   *ticket = a.ticket;
   return GPX_OK;
 }
-#define A_OUT(dst, src, bytes) HIPCHK(hipMemcpyAsync((dst), (src), (bytes), hipMemcpyDeviceToHost, a.s_out))
+#define A_OUT(dst, src, bytes) HIPCHK(xfer(h, (dst), (src), (bytes), hipMemcpyDeviceToHost, a.s_out))
 
 }  // namespace
 

@@ -18,6 +18,7 @@
 #   reffix                scripts/make_ref_fixtures.sh when a JDK exists (row c of SURVEY 8)
 #   fast                  pytest -m gpu_fast (about a minute: after every kernel change)
 #   smoke                 __graft_entry__.smoke()
+#   dmesg[:N]             the kernel log's last N lines (is it readable on the box at all?)
 # Round 4's visits were mostly of this shape (1-2 GPU-minutes each):
 #   bash scripts/gpu_visit.sh r04 testfile:tests/test_small_ar_gpu.py sh:ubench/sar_trace.sh:run \
 #        py:bench_batch_sweep.py:--min-log2+7+--max-log2+11 py:bench_full_round.py:--groups+10000+--rounds+101 fast
@@ -71,8 +72,15 @@ for step in "$@"; do
     else
       timeout 1500 python -m pytest tests -m gpu -q --durations=8 >"$f" 2>&1
     fi
-    echo "pytest exit $?" >>"$f"
+    rc=$?
+    echo "pytest exit $rc" >>"$f"
+    # a GPU page fault kills the process (ROCr's VMFaultHandler aborts): the kernel log names the faulting client and address
+    [ $rc -ge 128 ] && (dmesg 2>&1 | tail -120 >"$OUT/dmesg_after_abort.txt"; grep -i -E "fault|amdgpu" "$OUT/dmesg_after_abort.txt" | tail -20)
     tail -14 "$f" | cut -c1-240
+    ;;
+  dmesg)
+    dmesg 2>&1 | tail -${a:-60} >"$OUT/dmesg.txt"
+    tail -12 "$OUT/dmesg.txt" | cut -c1-200
     ;;
   testfile)
     f=$(uniq_name pytest_file log)

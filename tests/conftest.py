@@ -2,6 +2,14 @@ import os
 import subprocess
 import sys
 
+# Pageable host <-> device copies of this process go through the runtime's own pinned staging buffer, never by pinning the
+# caller's pages for the length of the copy (the HIP runtime's choice above ~1 MB: scripts/probe_copy_path.py,
+# profiles/r06_copy_path_probe.txt).  Every GPU page fault that ever killed a run of this suite (one run in each of rounds
+# 3 and 5, two in round 6) found the main thread inside exactly that transient pinning
+# (hsaCopyStagedOrPinned -> addPinnedMem), three times under one of torch's copies and once under gpx_group_create's.  The
+# flag is read when the runtime initialises, so it is set before anything imports torch; the results of no test depend on it.
+os.environ.setdefault("GPU_PINNED_MIN_XFER_SIZE", "1048576")
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
