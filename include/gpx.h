@@ -169,8 +169,11 @@ int gpx_engine_set_stream(gpx_engine* h, void* hip_stream);
  * Memory that is pinned already (hipHostMalloc, the caller's own hipHostRegister) is accepted and noted; the engine
  * never unpins it.  ONLY memory the engine was told about this way (or got from gpx_host_alloc) is written through a
  * device mapping by the asynchronous calls.  The device is synchronised before the pinning changes.  Prefer a few
- * large, page-aligned blocks (or gpx_host_alloc) to many small ones: three aborted test runs of this repository were
- * GPU page faults in processes that had registered and unregistered thousands of sub-page heap ranges.
+ * large, page-aligned blocks (or gpx_host_alloc) to many small ones.
+ * Host memory that is NOT pinned is copied in 512 KB pieces: the HIP runtime stages such pieces through its own pinned
+ * buffer, where it would pin the caller's pages in place for the length of a larger copy - the path in which every GPU
+ * page fault this repository has on file was raised.  Pageable calls therefore run at about half the
+ * registered rate; nothing else changes for them.
  */
 int gpx_host_register(gpx_engine* h, void* ptr, size_t bytes);
 /*
