@@ -142,6 +142,15 @@ class GpxLib:
             )
         self.path = path
         self.prefix = prefix
+        if prefix == "gpx_":
+            # ONE HIP runtime per process, and it is torch's: torch ships its own libamdhip64.so.7 and the HIP library
+            # here needs the same soname.  Loaded after torch, the library binds to the copy torch already brought; loaded
+            # BEFORE torch it pulls /opt/rocm's copy first, and a process that then also uses torch ends with the engine
+            # reporting "no ROCm-capable device" (seen with build() and smoke() in one process, round 6).
+            try:
+                import torch  # noqa: F401
+            except ImportError:
+                pass
         self.lib = C.CDLL(path)
         self.fn = {}
         f = getattr(self.lib, prefix + "abi_version")
