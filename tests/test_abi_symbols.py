@@ -37,6 +37,21 @@ def test_hip_library_exports_every_declared_symbol():
     assert lib.gpx_abi_version() == 1
 
 
+def test_one_hip_runtime_per_process_whatever_the_import_order():
+    """build() (which loads the HIP library to check its symbols) followed by torch in the same process: the library must
+    have bound to torch's libamdhip64, not pulled /opt/rocm's copy first - two HIP runtimes in one process ended with the
+    engine reporting 'no ROCm-capable device' on the GPU box (round 6; gigapaxos_amd/_abi.py GpxLib)."""
+    import subprocess
+    import sys
+
+    code = ("import os, re, __graft_entry__ as g; g.build(); import torch; "
+            "m = open('/proc/self/maps').read(); "
+            "print(len({os.path.realpath(p) for p in re.findall(r'/\\S*libamdhip64\\S*', m)}))")
+    out = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert out.stdout.strip().splitlines()[-1] == "1", out.stdout
+
+
 def test_oracle_exports_matching_symbols(oracle_lib):
     for name in _declared():
         if name.endswith(("_dev", "_async")) or name in ("gpx_engine_set_stream", "gpx_profile_enable", "gpx_profile_read",
