@@ -83,6 +83,32 @@ def test_config4_shapes_through_tiles(hip_lib, oracle_lib, G, k):
     _vote_stream_parity(hip_lib, oracle_lib, G, k, True, R=2)
 
 
+@pytest.mark.parametrize("G,k", [(60_000, 7), (60_000, 8), (40_000, 12), (30_000, 16)])
+def test_larger_groups_through_tiles(hip_lib, oracle_lib, G, k):
+    """Groups of 6-8 and 9-16 replicas (PC.MAX_GROUP_SIZE = 16, PaxosConfig.java:532): the KMAX = 8 and KMAX = 16
+    instantiations of the per-bucket kernel - eight staging rows per group, so 12 and 16 votes per group send every bucket
+    through the general two-pass regrouping - with the adversarial mix (escapes, compacted outputs)."""
+    _vote_stream_parity(hip_lib, oracle_lib, G, k, True, R=2)
+    # ... and that such a call IS the tiled front end's (the helper above does not look at the kernels)
+    members = list(range(100, 100 + k))
+    eh, eo = make_pair(hip_lib, oracle_lib, 101, G, k, 8, max_batch=G * k + G * k // 50 + 4096)
+    mem = np.tile(np.array(members, np.int32), (G, 1))
+    for e in (eh, eo):
+        assert (e.create_groups(np.arange(G), mem, k, hri_create(G, k, 101)) == S_OK).all()
+    g = np.arange(G, dtype=np.int32)
+    for x, y in zip(eh.propose(g), eo.propose(g)):
+        assert (x == y).all()
+    cols = streams.vote_round(G, members, 0, 101, config_id=4, mix=True)
+    eh.profile(2)
+    dh, do = eh.accept_reply(*cols), eo.accept_reply(*cols)
+    ran = eh.profile_read()
+    eh.profile(0)
+    assert "k_scatter_tiles" in ran and "k_bucket_ar16_tiles" in ran, sorted(ran)
+    _same(dh, do, "profiled call")
+    eh.close()
+    eo.close()
+
+
 @pytest.mark.parametrize("T,NT", [(4096, 512), (8192, 512), (8192, 1024), (12288, 1024), (16384, 1024), (4096, 1024)])
 def test_every_tile_shape(hip_lib, oracle_lib, monkeypatch, T, NT):
     """The scatter kernel's instantiations (votes and threads per workgroup; chosen per call otherwise), each on a call
