@@ -244,6 +244,25 @@ class CoordinatorLeg:
             propose_call(r)
             reply_call(r)
         self.step, self.propose_call, self.reply_call = step, propose_call, reply_call
+
+        def prepared(r0, r1):
+            """The same two calls for the rounds [r0, r1) with their ctypes arguments built beforehand: (propose(r),
+            reply(r)).  The two-engine leg issues four calls per step - what Python spends per call on converting sixteen
+            arguments would otherwise bound it; a compiled host pays nothing of the kind."""
+            import ctypes as C
+            lib, VP = eng.lib, C.c_void_p
+            f_p, f_r = lib.fn["propose_batch_dev"], lib.fn["accept_reply_batch_dev"]
+            a_p = (eng.h, G, VP(P(g_all)), None, VP(P(p_slot)), VP(P(p_bnum)), VP(P(p_bcoord)), VP(P(p_med)), VP(P(p_st)))
+            a_r = {r: (eng.h, nv, *[VP(P(t)) for t in vote_cols[r]], VP(P(d_g)), VP(P(d_s)), VP(P(d_b)), VP(P(d_c)), VP(P(d_m)),
+                       VP(P(d_k)), VP(n_out[r:].data_ptr()), VP(P(v_st))) for r in range(r0, r1)}
+
+            def propose_prepared(r):
+                lib.check(f_p(*a_p), "propose_batch_dev")
+
+            def reply_prepared(r):
+                lib.check(f_r(*a_r[r]), "accept_reply_batch_dev")
+            return propose_prepared, reply_prepared
+        self.prepared = prepared
         self._keep = (vote_cols, g_all, p_slot, p_bnum, p_bcoord, p_med, d_g, d_b, d_c, d_m, v_st)
 
     @staticmethod
@@ -342,6 +361,60 @@ class CoordinatorLeg:
         self.eng.sync()
         self.eng.close()
         self._keep = None
+
+
+def two_engines_leg(args, torch, dist, dev, local_rank, G, K, warmup, steps, reps):
+    """Side figure, never `value`: the SAME table as two independent shards on this GPU - two engines of G / 2 groups, each on
+    its own stream with its own seeded shuffled stream, the step = both engines' propose_batch + accept_reply_batch (G
+    proposals, K * G votes, G decisions as in the headline step).  Inside one engine the kernels of a step are serial; a second
+    engine fills the phases in which the first leaves the memory system idle (profiles/
+    r06_two_engines_two_streams.txt).  Shards are independent (PaxosManager.java:3170-3171): no exchange between them."""
+    prev = torch.cuda.current_stream()
+    sizes = [G - G // 2, G // 2]
+    legs = [CoordinatorLeg(args, torch, dist, dev, local_rank, 40 + e, 1, sizes[e], K, False, rounds=warmup + reps * steps)
+            for e in range(2)]
+    try:
+        A, B = legs
+        for r in range(warmup):
+            for L in legs:
+                L.step(r)
+        (a_p, a_r), (b_p, b_r) = (L.prepared(warmup, warmup + reps * steps) for L in legs)
+        per = []
+        for rep in range(reps):
+            first = warmup + rep * steps
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            # B runs half a step behind A, so that one engine's proposals have the other's accept replies beside them
+            # (every call of the region is issued inside it: `steps` proposes and `steps` reply batches per engine)
+            b_p(first)
+            for r in range(first, first + steps):
+                a_p(r)
+                b_r(r)
+                a_r(r)
+                if r + 1 < first + steps:
+                    b_p(r + 1)
+            torch.cuda.synchronize()
+            per.append(time.perf_counter() - t0)
+        mid = sorted(range(reps), key=lambda i: per[i])[reps // 2]
+        lo, hi = warmup + mid * steps, warmup + (mid + 1) * steps
+        decisions = votes = 0
+        for L in legs:
+            counts = L.n_out[: warmup + reps * steps].cpu().numpy()
+            if not L.mix:
+                assert (counts == L.G).all(), f"expected {L.G} decisions per round and engine, got {counts[:8]}"
+            decisions += int(counts[lo:hi].sum())
+            votes += L.nv * steps
+        el = per[mid]
+        return {"engines": 2, "streams": 2, "groups_per_engine": sizes, "ms_per_step": round(el * 1e3 / steps, 4),
+                "ms_per_step_all": [round(x * 1e3 / steps, 4) for x in per],
+                "value": round(decisions / el, 1), "unit": "decisions/s", "votes_per_sec": round(votes / el, 1),
+                "workload": "the headline's table as two independent shards on ONE GPU: two engines, each on its own stream "
+                            "with its own seeded shuffled stream; step = both engines' propose_batch + accept_reply_batch "
+                            "(the headline step's proposals, votes and decisions); a side figure - `value` above is ONE engine"}
+    finally:
+        for L in legs:
+            L.close()
+        torch.cuda.set_stream(prev)
 
 
 def end_to_end_leg(args, torch, dev, local_rank, G, K, nv, nv_round, members, mem, cfg_id):
@@ -612,6 +685,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline leg (0 = every host core)")
     ap.add_argument("--no-end-to-end", action="store_true", help="skip the host-pointer (PCIe-inclusive) leg")
+    ap.add_argument("--two-engines", action="store_true",
+                    help="add the side leg `two_engines_per_gpu`: the table as two shards (two engines, two streams) on the "
+                         "GPU (off by default: the default command launches the headline's kernels at the headline's sizes "
+                         "only, so that a kernel trace of it averages what the line reports)")
     ap.add_argument("--no-parity-check", action="store_true", help="skip the engine-vs-oracle replay of the CPU sample")
     ap.add_argument("--cpu-mt-passes", type=int, default=16, help="passes over the sample in the multi-threaded leg")
     ap.add_argument("--split-global", action="store_true",
@@ -968,6 +1045,15 @@ def main():
         }
         eo.close()
 
+    # ---- side figure: the same table as two shards on this GPU, two engines on two streams (never `value`) -------------
+    two_engines = None
+    if rank == 0 and world == 1 and not collectives and not args.same_device and args.two_engines \
+            and not args.split_global and not args.runs and G >= 2048:
+        try:
+            two_engines = two_engines_leg(args, torch, dist, dev, local_rank, G, K, warmup, steps, REPS)
+        except Exception as ex:  # noqa: BLE001  (a side leg never takes the line with it)
+            two_engines = {"error": "%s: %s" % (type(ex).__name__, ex)}
+
     if rank == 0:
         out = {
             "metric": "decided_ops_per_sec",
@@ -1015,6 +1101,7 @@ def main():
             "roofline": roofline,
             "strong": strong,
             "end_to_end": end_to_end,
+            "two_engines_per_gpu": two_engines,
             "cpu_baseline": cpu_baseline,
             "parity_checked": parity_checked,
         }

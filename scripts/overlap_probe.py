@@ -32,12 +32,16 @@ def main():
     P = lambda t: t.data_ptr()  # noqa: E731
     mem = np.tile(np.array(members, np.int32), (G, 1))
     pool = 3 * (a.iters + 1) + 1  # every round of an engine's run is its own (slot numbers follow the proposals)
-    rounds = [[torch.from_numpy(c).to(dev) for c in streams.vote_round_survey(G, members, r, 100, config_id=3)] for r in range(pool)]
-    n = int(rounds[0][0].shape[0])
+    # every engine its OWN seeded rounds: two engines reading the same columns would find the second reading in the 256 MB
+    # memory-side cache (the first form of this probe did, and flattered the two-stream figure by 6-10 %)
+    rounds2 = [[[torch.from_numpy(c).to(dev) for c in streams.vote_round_survey(G, members, r, 100, config_id=3 + 16 * side)]
+                for r in range(pool)] for side in range(2)]
+    n = int(rounds2[0][0][0].shape[0])
     g = torch.arange(G, dtype=torch.int32, device=dev)
 
     class Side:
-        def __init__(self, stream):
+        def __init__(self, stream, side):
+            self.rounds = rounds2[side]
             self.e = Engine(load_hip(), 100, G, kmax=K, window=8, max_batch=G * K + 4096)
             assert (self.e.create_groups(np.arange(G, dtype=np.int32), mem, K, hri_create(G, K, 100)) == S_OK).all()
             self.e.set_ordered_batches(ORDERED_PROPOSE)
@@ -51,13 +55,13 @@ def main():
             self.e.call_dev("propose_batch", G, P(g), 0, *[P(t) for t in self.p])
 
         def reply(self):
-            c = rounds[self.r]
+            c = self.rounds[self.r]
             self.r += 1
             self.e.call_dev("accept_reply_batch", n, *[P(t) for t in c], *[P(t) for t in self.d], P(self.no), P(self.st))
 
     def timed(form):
         s1, s2 = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
-        A, B = Side(s1), Side(s1 if form == "serial" else s2)
+        A, B = Side(s1, 0), Side(s1 if form == "serial" else s2, 1)
         ev0, ev1, evb = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event()
         res = []
         for rep in range(3):
