@@ -25,6 +25,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--groups", type=int, default=1_000_000)
     ap.add_argument("--iters", type=int, default=16)
+    ap.add_argument("--engines", type=int, default=2, help="other than 2: E engines, every one a step per iteration (no stagger)")
     a = ap.parse_args()
     G, K = a.groups, 3
     members = [100, 101, 102]
@@ -87,6 +88,39 @@ def main():
         B.e.close()
         return res
 
+    def timed_many(E, form):
+        """E engines (every one on its own stream, or all on one): per iteration every engine one step, issued engine by engine
+        (no deliberate stagger: independent streams drift apart by themselves); ms per iteration = per E x G groups"""
+        ss = [torch.cuda.Stream(device=dev) for _ in range(E)]
+        sides = [Side(ss[0] if form == "serial" else ss[e], e % 2) for e in range(E)]
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        res = []
+        for rep in range(3):
+            torch.cuda.synchronize()
+            ev0.record(ss[0])
+            for _ in range(a.iters):
+                for sd in sides:
+                    sd.propose()
+                for sd in sides:
+                    sd.reply()
+            for e in range(1, E):
+                if form != "serial":
+                    evb = torch.cuda.Event()
+                    evb.record(ss[e])
+                    ss[0].wait_event(evb)
+            ev1.record(ss[0])
+            torch.cuda.synchronize()
+            assert all(int(sd.no) == G for sd in sides)
+            res.append(ev0.elapsed_time(ev1) / a.iters)
+        for sd in sides:
+            sd.e.close()
+        return res
+
+    if a.engines != 2:
+        for form in ("serial", "streams", "serial", "streams"):
+            r = timed_many(a.engines, form)
+            print(f"{a.engines} engines of {G} groups, {form:8s} ms per step of all engines: " + " ".join(f"{x:.4f}" for x in r), flush=True)
+        return
     for form in ("serial", "staggered", "serial", "staggered"):
         r = timed(form)
         print(f"{form:10s} ms per headline step: " + " ".join(f"{x:.4f}" for x in r), flush=True)
